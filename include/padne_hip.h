@@ -1,0 +1,168 @@
+/*
+ * padne_hip.h -- C ABI of libpadne_hip.so, the MI355X (gfx950) implementation of
+ * the padne solver hot path.
+ *
+ * The reference (atx/padne) has no FFI for this path: the seam is the Python
+ * module padne/solver.py.  Each entry point below names the reference code whose
+ * arithmetic it replaces (file:line in the reference tree); INTEGRATION.md shows
+ * the ctypes stub a padne maintainer would add to call them.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative PADNE_E_* code on failure;
+ *     padne_last_error() returns a thread-local human readable message.
+ *     Nothing throws across the boundary.
+ *   - "host" pointers are caller-owned host memory; "dev" pointers are raw device
+ *     addresses (hipMalloc / torch tensor.data_ptr()) valid on the context's GPU.
+ *   - all calls are blocking unless the name ends in _async.
+ *   - indices are int32 inside a matrix (nnz < 2^31), sizes are int64.
+ *   - all floating point data is IEEE binary64 (solver.py:21, DTYPE = float64).
+ */
+#ifndef PADNE_HIP_H
+#define PADNE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PADNE_ABI_VERSION 1
+
+#define PADNE_OK            0
+#define PADNE_E_INVALID    -1   /* bad argument (null pointer, negative size, index out of range) */
+#define PADNE_E_HIP        -2   /* a HIP runtime call failed */
+#define PADNE_E_NOMEM      -3
+#define PADNE_E_NONMANIFOLD -4  /* triangle soup is not an oriented manifold (mesh.py:342-343 ValueError) */
+#define PADNE_E_NOTCONVERGED -5 /* PCG hit max_iter (solution still returned) */
+#define PADNE_E_COMM       -6   /* RCCL not available / communicator failure */
+#define PADNE_E_BREAKDOWN  -7   /* PCG breakdown: matrix not SPD (p.Ap <= 0) or NaN */
+
+typedef struct padne_ctx padne_ctx;   /* device, stream, workspaces, optional RCCL communicator */
+typedef struct padne_csr padne_csr;   /* device-resident CSR matrix (f64 values, i32 indices)  */
+
+/* ---- library / context ------------------------------------------------------------------- */
+int         padne_abi_version(void);
+const char *padne_last_error(void);
+/* number of visible GPUs, or a negative error code */
+int         padne_device_count(void);
+/* create a context on `device` with its own non-blocking stream */
+int         padne_ctx_create(int device, padne_ctx **out);
+int         padne_ctx_destroy(padne_ctx *ctx);
+int         padne_ctx_synchronize(padne_ctx *ctx);
+/* raw hipStream_t of the context (for event timing by the caller) */
+void       *padne_ctx_stream(padne_ctx *ctx);
+
+/* ---- multi-GPU (RCCL over xGMI; one process per GPU) --------------------------------------
+ * No reference counterpart: the reference is single-process.
+ * padne_comm_unique_id fills 128 bytes on one rank; the caller broadcasts them
+ * (torch.distributed) and every rank calls padne_ctx_comm_init. */
+int padne_comm_unique_id(void *id128);
+int padne_ctx_comm_init(padne_ctx *ctx, const void *id128, int rank, int world_size);
+int padne_ctx_comm_rank(padne_ctx *ctx, int *rank, int *world_size);
+
+/* ---- device memory helpers (thin, so that callers need no HIP binding of their own) -------- */
+int padne_dev_alloc(padne_ctx *ctx, int64_t bytes, void **dev_out);
+int padne_dev_free(padne_ctx *ctx, void *dev);
+int padne_dev_upload(padne_ctx *ctx, void *dev_dst, const void *host_src, int64_t bytes);
+int padne_dev_download(padne_ctx *ctx, void *host_dst, const void *dev_src, int64_t bytes);
+int padne_dev_memset(padne_ctx *ctx, void *dev, int value, int64_t bytes);
+
+/* ---- matrices ------------------------------------------------------------------------------ */
+/* upload a host CSR (scipy layout: int32 indptr[n_rows+1], int32 indices[nnz], f64 data[nnz]).
+ * Replaces L.tocsc() as the hand-off of the assembled system, solver.py:772. */
+int padne_csr_from_host(padne_ctx *ctx, int64_t n_rows, int64_t n_cols,
+                        const int32_t *indptr, const int32_t *indices, const double *data,
+                        padne_csr **out);
+int padne_csr_destroy(padne_csr *m);
+int padne_csr_shape(const padne_csr *m, int64_t *n_rows, int64_t *n_cols, int64_t *nnz);
+/* copy back to caller-allocated host arrays (sizes from padne_csr_shape) */
+int padne_csr_to_host(padne_ctx *ctx, const padne_csr *m, int32_t *indptr, int32_t *indices, double *data);
+
+/* Assemble the global system matrix L in the reference layout and sign.
+ *   mesh part  : HalfEdge.cotan (mesh.py:124-139), laplace_operator (solver.py:171-213),
+ *                process_mesh_laplace_operators (solver.py:563-575)
+ *   lumped part: the COO stamps produced by stamp_network_into_system / setup_ground_node
+ *                (solver.py:469-560), already in global indices, in stamp order.
+ * xy[n_vert][2], tri[n_tri][3] hold mesh-LOCAL vertex ids; mesh m owns vertices
+ * [mesh_vertex_offset[m], mesh_vertex_offset[m+1]) (VertexIndexer, solver.py:221-229) and
+ * triangles [mesh_tri_offset[m], mesh_tri_offset[m+1]).  Duplicate (row, col) stamps are summed
+ * in stamp order after the mesh contribution; exact zeros are not stored (solver.py:187-190).
+ * Returns PADNE_E_NONMANIFOLD where Mesh.from_triangle_soup raises ValueError (mesh.py:342-343). */
+int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns,
+                          int64_t n_vert, const double *xy_host,
+                          int64_t n_tri, const int32_t *tri_host,
+                          int64_t n_mesh, const int64_t *mesh_vertex_offset,
+                          const int64_t *mesh_tri_offset, const double *conductance,
+                          int64_t n_coo, const int64_t *coo_row, const int64_t *coo_col,
+                          const double *coo_val,
+                          padne_csr **out);
+
+/* out = scale * P^T M P restricted to kept indices: entry (i,j,v) of M becomes
+ * (map[i], map[j], scale*v) if both maps are >= 0; duplicates are summed.  Used to turn the
+ * reference's indefinite KKT system into the SPD system A = -L_vv on the free potentials
+ * (ground eliminated, voltage-source-tied nodes merged; DESIGN.md "reduction"). */
+int padne_csr_reduce(padne_ctx *ctx, const padne_csr *m, const int32_t *map_host,
+                     int64_t n_out, double scale, padne_csr **out);
+
+/* ---- SpMV ---------------------------------------------------------------------------------- */
+/* y = M x, host vectors (the reference's residual product L_csc @ v, solver.py:775) */
+int padne_spmv(padne_ctx *ctx, const padne_csr *m, const double *x_host, double *y_host);
+/* y = M x on device vectors, enqueued `repeat` times on the context stream; blocking at the end */
+int padne_spmv_dev(padne_ctx *ctx, const padne_csr *m, const void *x_dev, void *y_dev, int repeat);
+/* residual: returns ||M x - b||_2 (device), host vectors in */
+int padne_residual_norm(padne_ctx *ctx, const padne_csr *m, const double *x_host,
+                        const double *b_host, double *norm_out);
+
+/* ---- solve --------------------------------------------------------------------------------- */
+typedef struct padne_solve_opts {
+    double  rtol;        /* stop when ||b - A x||_2 <= max(rtol*||b||_2, atol)            */
+    double  atol;
+    int32_t max_iter;
+    int32_t precond;     /* 0 = Jacobi                                                    */
+    int32_t check_every; /* iterations enqueued between host convergence polls (0 = auto) */
+    int32_t flags;       /* bit0: x holds an initial guess (otherwise x0 = 0)             */
+} padne_solve_opts;
+
+typedef struct padne_solve_info {
+    int32_t iterations;
+    int32_t restarts;        /* true-residual restarts taken                     */
+    double  rel_residual;    /* final TRUE ||b - A x|| / ||b||                    */
+    double  abs_residual;
+    double  solve_seconds;   /* device time of the iteration loop (HIP events)    */
+    double  spmv_seconds;    /* summed device time of the SpMV kernel, if timed   */
+    int32_t status;          /* PADNE_OK / PADNE_E_NOTCONVERGED / PADNE_E_BREAKDOWN */
+    int32_t n_rhs;
+} padne_solve_info;
+
+/* Preconditioned CG on an SPD CSR matrix: replaces scipy.sparse.linalg.spsolve in
+ * solve_system (solver.py:773) once the system is reduced.  b, x: host f64[n_rhs][n]
+ * (row-major, one right-hand side after another). */
+int padne_solve_spd(padne_ctx *ctx, const padne_csr *a, const double *b_host, double *x_host,
+                    int32_t n_rhs, const padne_solve_opts *opts, padne_solve_info *info);
+/* same with device-resident b and x */
+int padne_solve_spd_dev(padne_ctx *ctx, const padne_csr *a, const void *b_dev, void *x_dev,
+                        int32_t n_rhs, const padne_solve_opts *opts, padne_solve_info *info);
+
+/* ---- post-processing ----------------------------------------------------------------------- */
+/* per-face power density  p = sigma*|grad V|^2 with the reference's barycentric difference
+ * quotient (compute_triangle_gradient solver.py:689-725, compute_power_density :728-745).
+ * Also performs the scatter of produce_layer_solutions (solver.py:596-598): `potential` is the
+ * global solution vector, vertex v of mesh m reads potential[mesh_vertex_offset[m] + v]. */
+int padne_power_density(padne_ctx *ctx, int64_t n_vert, const double *xy_host,
+                        int64_t n_tri, const int32_t *tri_host,
+                        int64_t n_mesh, const int64_t *mesh_vertex_offset,
+                        const int64_t *mesh_tri_offset, const double *conductance,
+                        const double *potential_host, double *power_out_host);
+
+/* ---- introspection for benchmarks ---------------------------------------------------------- */
+/* algorithmic bytes of one CSR SpMV: 12*nnz + 20*n_rows + 4   */
+int64_t padne_spmv_algorithmic_bytes(const padne_csr *m);
+/* average device time (seconds) of `repeat` back-to-back SpMV launches measured with HIP
+ * events on the context stream, after `warmup` untimed launches */
+int padne_spmv_time(padne_ctx *ctx, const padne_csr *m, const void *x_dev, void *y_dev,
+                    int warmup, int repeat, double *seconds_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PADNE_HIP_H */

@@ -1,0 +1,420 @@
+"""ctypes binding of ``libpadne_hip.so`` (the C ABI declared in ``include/padne_hip.h``).
+
+The product path has NO CPU fallback: if the shared library is missing, or no
+GPU is visible, the first call raises ``HipUnavailableError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import sys
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpadne_hip.so")
+
+OK = 0
+E_INVALID, E_HIP, E_NOMEM, E_NONMANIFOLD, E_NOTCONVERGED, E_COMM, E_BREAKDOWN = -1, -2, -3, -4, -5, -6, -7
+
+
+class HipUnavailableError(RuntimeError):
+    """libpadne_hip.so cannot be loaded or no MI355X is visible."""
+
+
+class HipError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libpadne_hip error {code}: {message}")
+        self.code = code
+
+
+class NotConvergedError(HipError):
+    pass
+
+
+class SolveOpts(C.Structure):
+    _fields_ = [("rtol", C.c_double), ("atol", C.c_double), ("max_iter", C.c_int32),
+                ("precond", C.c_int32), ("check_every", C.c_int32), ("flags", C.c_int32)]
+
+
+class SolveInfo(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("restarts", C.c_int32), ("rel_residual", C.c_double),
+                ("abs_residual", C.c_double), ("solve_seconds", C.c_double), ("spmv_seconds", C.c_double),
+                ("status", C.c_int32), ("n_rhs", C.c_int32)]
+
+
+_P = C.c_void_p
+_I64 = C.c_int64
+_PI32 = C.POINTER(C.c_int32)
+_PI64 = C.POINTER(C.c_int64)
+_PF64 = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes): every symbol include/padne_hip.h declares
+SIGNATURES = {
+    "padne_abi_version": (C.c_int, []),
+    "padne_last_error": (C.c_char_p, []),
+    "padne_device_count": (C.c_int, []),
+    "padne_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "padne_ctx_destroy": (C.c_int, [_P]),
+    "padne_ctx_synchronize": (C.c_int, [_P]),
+    "padne_ctx_stream": (_P, [_P]),
+    "padne_comm_unique_id": (C.c_int, [_P]),
+    "padne_ctx_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "padne_ctx_comm_rank": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "padne_dev_alloc": (C.c_int, [_P, _I64, C.POINTER(_P)]),
+    "padne_dev_free": (C.c_int, [_P, _P]),
+    "padne_dev_upload": (C.c_int, [_P, _P, _P, _I64]),
+    "padne_dev_download": (C.c_int, [_P, _P, _P, _I64]),
+    "padne_dev_memset": (C.c_int, [_P, _P, C.c_int, _I64]),
+    "padne_csr_from_host": (C.c_int, [_P, _I64, _I64, _PI32, _PI32, _PF64, C.POINTER(_P)]),
+    "padne_csr_destroy": (C.c_int, [_P]),
+    "padne_csr_shape": (C.c_int, [_P, _PI64, _PI64, _PI64]),
+    "padne_csr_to_host": (C.c_int, [_P, _P, _PI32, _PI32, _PF64]),
+    "padne_assemble_system": (C.c_int, [_P, _I64, _I64, _PF64, _I64, _PI32, _I64, _PI64, _PI64, _PF64,
+                                        _I64, _PI64, _PI64, _PF64, C.POINTER(_P)]),
+    "padne_csr_reduce": (C.c_int, [_P, _P, _PI32, _I64, C.c_double, C.POINTER(_P)]),
+    "padne_spmv": (C.c_int, [_P, _P, _PF64, _PF64]),
+    "padne_spmv_dev": (C.c_int, [_P, _P, _P, _P, C.c_int]),
+    "padne_residual_norm": (C.c_int, [_P, _P, _PF64, _PF64, _PF64]),
+    "padne_solve_spd": (C.c_int, [_P, _P, _PF64, _PF64, C.c_int32, C.POINTER(SolveOpts), C.POINTER(SolveInfo)]),
+    "padne_solve_spd_dev": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(SolveOpts), C.POINTER(SolveInfo)]),
+    "padne_power_density": (C.c_int, [_P, _I64, _PF64, _I64, _PI32, _I64, _PI64, _PI64, _PF64, _PF64, _PF64]),
+    "padne_spmv_algorithmic_bytes": (_I64, [_P]),
+    "padne_spmv_time": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _PF64]),
+}
+
+_lib = None
+
+
+def load_library(path: str | None = None) -> C.CDLL:
+    """dlopen the in-tree library and attach prototypes.  Does not touch the GPU."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise HipUnavailableError(
+            f"{p} not found: build it with `python -m padne_amd.build` (hipcc --offload-arch=gfx950). "
+            "padne_amd has no CPU fallback.")
+    # When the process also uses torch (bench.py, torch.distributed ranks) let torch load its
+    # HIP runtime first so that both share one libamdhip64.so.7 / librccl.so.1.
+    if "torch" in sys.modules:
+        pass
+    try:
+        lib = C.CDLL(p, mode=C.RTLD_GLOBAL)
+    except OSError as exc:
+        raise HipUnavailableError(f"cannot load {p}: {exc}") from exc
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.padne_abi_version() != 1:
+        raise HipUnavailableError("libpadne_hip.so ABI version mismatch; rebuild it")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(rc: int) -> None:
+    if rc == OK:
+        return
+    msg = (load_library().padne_last_error() or b"").decode("utf-8", "replace")
+    if rc == E_NONMANIFOLD:
+        raise ValueError(msg or "Non-manifold mesh")   # mesh.py:342-343
+    if rc == E_INVALID:
+        raise ValueError(msg)
+    if rc == E_NOMEM:
+        raise MemoryError(msg)
+    if rc == E_NOTCONVERGED:
+        raise NotConvergedError(rc, msg)
+    raise HipError(rc, msg)
+
+
+def _f64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _i64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _ptr(a: np.ndarray, typ):
+    return a.ctypes.data_as(typ)
+
+
+def device_count() -> int:
+    n = load_library().padne_device_count()
+    return max(n, 0)
+
+
+class Context:
+    """Device context: GPU, stream, workspaces, optional RCCL communicator."""
+
+    def __init__(self, device: int = 0):
+        lib = load_library()
+        self._lib = lib
+        h = _P()
+        rc = lib.padne_ctx_create(int(device), C.byref(h))
+        if rc != OK:
+            msg = (lib.padne_last_error() or b"").decode()
+            raise HipUnavailableError(f"cannot create a context on GPU {device}: {msg}")
+        self._h = h
+        self.device = int(device)
+
+    # -- lifetime ------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.padne_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def synchronize(self):
+        _check(self._lib.padne_ctx_synchronize(self._h))
+
+    @property
+    def stream(self) -> int:
+        return int(self._lib.padne_ctx_stream(self._h) or 0)
+
+    # -- communicator ---------------------------------------------------------
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        _check(self._lib.padne_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world_size: int):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        _check(self._lib.padne_ctx_comm_init(self._h, buf, int(rank), int(world_size)))
+
+    # -- raw device memory ------------------------------------------------------
+    def alloc(self, nbytes: int) -> int:
+        p = _P()
+        _check(self._lib.padne_dev_alloc(self._h, int(nbytes), C.byref(p)))
+        return int(p.value)
+
+    def free(self, dev: int):
+        _check(self._lib.padne_dev_free(self._h, _P(dev)))
+
+    def upload(self, dev: int, host: np.ndarray):
+        host = np.ascontiguousarray(host)
+        _check(self._lib.padne_dev_upload(self._h, _P(dev), host.ctypes.data_as(_P), host.nbytes))
+
+    def download(self, dev: int, shape, dtype=np.float64) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        _check(self._lib.padne_dev_download(self._h, out.ctypes.data_as(_P), _P(dev), out.nbytes))
+        return out
+
+    def to_device(self, host: np.ndarray) -> "DeviceArray":
+        host = np.ascontiguousarray(host)
+        d = DeviceArray(self, host.shape, host.dtype)
+        self.upload(d.ptr, host)
+        return d
+
+    def empty(self, shape, dtype=np.float64) -> "DeviceArray":
+        return DeviceArray(self, shape, dtype)
+
+    # -- matrices -------------------------------------------------------------------
+    def csr_from_scipy(self, A) -> "CsrMatrix":
+        import scipy.sparse as sp
+        A = sp.csr_matrix(A)
+        A.sum_duplicates()
+        A.sort_indices()
+        if A.nnz >= 2**31 - 8192:
+            raise ValueError("matrix too large for int32 indices")
+        indptr, indices, data = _i32(A.indptr), _i32(A.indices), _f64(A.data)
+        h = _P()
+        _check(self._lib.padne_csr_from_host(self._h, A.shape[0], A.shape[1], _ptr(indptr, _PI32),
+                                             _ptr(indices, _PI32), _ptr(data, _PF64), C.byref(h)))
+        return CsrMatrix(self, h)
+
+    def assemble_system(self, n_unknowns, xy, tri, mesh_vertex_offset, mesh_tri_offset, conductance,
+                        coo_row, coo_col, coo_val) -> "CsrMatrix":
+        """L in the reference layout: cotangent Laplacians of all meshes + lumped stamps."""
+        xy = _f64(xy).reshape(-1, 2)
+        tri = _i32(tri).reshape(-1, 3)
+        mvo, mto, sig = _i64(mesh_vertex_offset), _i64(mesh_tri_offset), _f64(conductance)
+        cr, cc, cv = _i64(coo_row), _i64(coo_col), _f64(coo_val)
+        n_mesh = sig.shape[0]
+        if mvo.shape[0] != n_mesh + 1 or mto.shape[0] != n_mesh + 1:
+            raise ValueError("offset tables must have n_mesh+1 entries")
+        if not (cr.shape == cc.shape == cv.shape):
+            raise ValueError("coo arrays must have equal length")
+        h = _P()
+        _check(self._lib.padne_assemble_system(
+            self._h, int(n_unknowns), xy.shape[0], _ptr(xy, _PF64), tri.shape[0], _ptr(tri, _PI32), n_mesh,
+            _ptr(mvo, _PI64), _ptr(mto, _PI64), _ptr(sig, _PF64), cr.shape[0], _ptr(cr, _PI64),
+            _ptr(cc, _PI64), _ptr(cv, _PF64), C.byref(h)))
+        return CsrMatrix(self, h)
+
+    def power_density(self, xy, tri, mesh_vertex_offset, mesh_tri_offset, conductance, potential) -> np.ndarray:
+        xy = _f64(xy).reshape(-1, 2)
+        tri = _i32(tri).reshape(-1, 3)
+        mvo, mto, sig = _i64(mesh_vertex_offset), _i64(mesh_tri_offset), _f64(conductance)
+        pot = _f64(potential)
+        if pot.shape[0] < xy.shape[0]:
+            raise ValueError("potential vector shorter than the vertex count")
+        out = np.zeros(tri.shape[0], dtype=np.float64)
+        _check(self._lib.padne_power_density(self._h, xy.shape[0], _ptr(xy, _PF64), tri.shape[0],
+                                             _ptr(tri, _PI32), sig.shape[0], _ptr(mvo, _PI64), _ptr(mto, _PI64),
+                                             _ptr(sig, _PF64), _ptr(pot, _PF64), _ptr(out, _PF64)))
+        return out
+
+
+class DeviceArray:
+    """A flat device allocation with numpy-like shape/dtype metadata."""
+
+    def __init__(self, ctx: Context, shape, dtype=np.float64):
+        self.ctx = ctx
+        self.shape = tuple(np.atleast_1d(shape)) if not isinstance(shape, tuple) else shape
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self.ptr = ctx.alloc(max(self.nbytes, 8))
+
+    def numpy(self) -> np.ndarray:
+        return self.ctx.download(self.ptr, self.shape, self.dtype)
+
+    def set(self, host: np.ndarray):
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        if host.nbytes != self.nbytes:
+            raise ValueError("size mismatch")
+        self.ctx.upload(self.ptr, host)
+
+    def free(self):
+        if self.ptr:
+            self.ctx.free(self.ptr)
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            if self.ptr and self.ctx._h:
+                self.free()
+        except Exception:
+            pass
+
+
+@dataclass
+class SolveResult:
+    x: np.ndarray | None
+    iterations: int
+    restarts: int
+    rel_residual: float
+    abs_residual: float
+    seconds: float
+    status: int
+
+
+class CsrMatrix:
+    """Device-resident CSR matrix (opaque handle of the C ABI)."""
+
+    def __init__(self, ctx: Context, handle):
+        self.ctx = ctx
+        self._h = handle
+        nr, nc, nnz = C.c_int64(), C.c_int64(), C.c_int64()
+        _check(ctx._lib.padne_csr_shape(handle, C.byref(nr), C.byref(nc), C.byref(nnz)))
+        self.shape = (nr.value, nc.value)
+        self.nnz = nnz.value
+
+    def close(self):
+        if getattr(self, "_h", None) and self.ctx._h:
+            self.ctx._lib.padne_csr_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def spmv_bytes(self) -> int:
+        return int(self.ctx._lib.padne_spmv_algorithmic_bytes(self._h))
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        indptr = np.empty(self.shape[0] + 1, dtype=np.int32)
+        indices = np.empty(self.nnz, dtype=np.int32)
+        data = np.empty(self.nnz, dtype=np.float64)
+        _check(self.ctx._lib.padne_csr_to_host(self.ctx._h, self._h, _ptr(indptr, _PI32), _ptr(indices, _PI32),
+                                               _ptr(data, _PF64)))
+        return sp.csr_matrix((data, indices, indptr), shape=self.shape)
+
+    def reduce(self, index_map, n_out: int, scale: float = 1.0) -> "CsrMatrix":
+        m = _i32(index_map)
+        if m.shape[0] != self.shape[0]:
+            raise ValueError("index map length must equal the matrix dimension")
+        h = _P()
+        _check(self.ctx._lib.padne_csr_reduce(self.ctx._h, self._h, _ptr(m, _PI32), int(n_out), float(scale),
+                                              C.byref(h)))
+        return CsrMatrix(self.ctx, h)
+
+    def matvec(self, x) -> np.ndarray:
+        x = _f64(x)
+        if x.shape[0] != self.shape[1]:
+            raise ValueError("dimension mismatch")
+        y = np.empty(self.shape[0], dtype=np.float64)
+        _check(self.ctx._lib.padne_spmv(self.ctx._h, self._h, _ptr(x, _PF64), _ptr(y, _PF64)))
+        return y
+
+    def matvec_dev(self, x: DeviceArray, y: DeviceArray, repeat: int = 1):
+        _check(self.ctx._lib.padne_spmv_dev(self.ctx._h, self._h, _P(x.ptr), _P(y.ptr), int(repeat)))
+
+    def spmv_time(self, x: DeviceArray, y: DeviceArray, warmup: int = 5, repeat: int = 50) -> float:
+        t = C.c_double()
+        _check(self.ctx._lib.padne_spmv_time(self.ctx._h, self._h, _P(x.ptr), _P(y.ptr), warmup, repeat,
+                                             C.byref(t)))
+        return t.value
+
+    def residual_norm(self, x, b) -> float:
+        x, b = _f64(x), _f64(b)
+        out = C.c_double()
+        _check(self.ctx._lib.padne_residual_norm(self.ctx._h, self._h, _ptr(x, _PF64), _ptr(b, _PF64),
+                                                 C.byref(out)))
+        return out.value
+
+    @staticmethod
+    def _opts(rtol, atol, max_iter, check_every, guess) -> SolveOpts:
+        return SolveOpts(float(rtol), float(atol), int(max_iter), 0, int(check_every), 1 if guess else 0)
+
+    def solve_spd(self, b, *, rtol=1e-12, atol=0.0, max_iter=200000, check_every=0, x0=None,
+                  raise_on_fail=True) -> SolveResult:
+        """Jacobi-PCG on the device; b is host f64[n] or f64[k, n]."""
+        b = _f64(b)
+        n = self.shape[0]
+        k = 1 if b.ndim == 1 else b.shape[0]
+        if b.shape[-1] != n:
+            raise ValueError("right-hand side has the wrong length")
+        x = np.zeros_like(b) if x0 is None else _f64(x0).copy()
+        opts = self._opts(rtol, atol, max_iter, check_every, x0 is not None)
+        info = SolveInfo()
+        rc = self.ctx._lib.padne_solve_spd(self.ctx._h, self._h, _ptr(b, _PF64), _ptr(x, _PF64), k,
+                                           C.byref(opts), C.byref(info))
+        if rc != OK and (raise_on_fail or rc != E_NOTCONVERGED):
+            _check(rc)
+        return SolveResult(x, info.iterations, info.restarts, info.rel_residual, info.abs_residual,
+                           info.solve_seconds, info.status)
+
+    def solve_spd_dev(self, b: DeviceArray, x: DeviceArray, *, n_rhs=1, rtol=1e-12, atol=0.0, max_iter=200000,
+                      check_every=0, guess=False, raise_on_fail=True) -> SolveResult:
+        opts = self._opts(rtol, atol, max_iter, check_every, guess)
+        info = SolveInfo()
+        rc = self.ctx._lib.padne_solve_spd_dev(self.ctx._h, self._h, _P(b.ptr), _P(x.ptr), int(n_rhs),
+                                               C.byref(opts), C.byref(info))
+        if rc != OK and (raise_on_fail or rc != E_NOTCONVERGED):
+            _check(rc)
+        return SolveResult(None, info.iterations, info.restarts, info.rel_residual, info.abs_residual,
+                           info.solve_seconds, info.status)

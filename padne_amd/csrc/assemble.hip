@@ -1,0 +1,647 @@
+// System assembly on the device.
+//
+//   padne_assemble_system : triangle soup + lumped COO stamps  ->  CSR of L (reference layout/sign)
+//   padne_csr_reduce      : scale * P^T M P (index relabel + merge) -> CSR of the reduced SPD system
+//   padne_power_density   : per-face sigma*|grad V|^2 (+ the per-mesh scatter of the potentials)
+//
+// Reference arithmetic restated here: HalfEdge.cotan (mesh.py:124-139), laplace_operator
+// (solver.py:171-213), process_mesh_laplace_operators (solver.py:563-575), the += semantics of
+// stamp_network_into_system / setup_ground_node on a lil_matrix (solver.py:469-560),
+// compute_triangle_gradient / compute_power_density (solver.py:689-745).
+//
+// Pipeline (no global sort, no float atomics, bitwise reproducible):
+//   1 count   every triangle adds 2 slots to each of its 3 vertex rows, every stamp 1 slot
+//   2 scan    exclusive scan of the slot counts
+//   3 fill    every triangle computes its three |cot|/2 terms once and scatters the 6 directed
+//             entries into the row slots (an int atomic only hands out the slot number; the
+//             values are plain stores); stamps follow with their sequence number
+//   4 merge   one lane per row: sort the handful of slots by (column, sequence), add the (at
+//             most two) mesh terms of an edge, scale by the sheet conductance, add stamps in
+//             stamp order, form the diagonal -(w_1 + w_2 + ...) in ascending column order,
+//             drop exact zeros, compact in place
+//   5 scan    row lengths -> row pointers
+//   6 copy    compacted rows -> final CSR arrays
+// Because the sort key fixes the summation order, the values do not depend on the order in
+// which the atomics handed out slots.
+//
+// This file is compiled with -ffp-contract=off: the cotangent and gradient expressions must
+// round exactly like the reference's Python floats (no fused multiply-add).
+#include "common.hpp"
+
+#include <string.h>
+
+namespace padne {
+
+// ------------------------------------------------------------------------------------------
+// exclusive scan (int32 in, int32 out[n+1], total as int64)
+// ------------------------------------------------------------------------------------------
+constexpr int kScanItems = 16;
+constexpr int kScanChunk = 256 * kScanItems;
+
+__device__ __forceinline__ int block_exclusive_scan_256(int v, int *lds /*[5]*/, int *total) {
+    // inclusive scan inside the wave
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) lds[w] = inc;
+    __syncthreads();
+    int wave_off = 0;
+    for (int i = 0; i < w; ++i) wave_off += lds[i];
+    if (total) *total = lds[0] + lds[1] + lds[2] + lds[3];
+    __syncthreads();
+    return wave_off + inc - v;
+}
+
+__global__ __launch_bounds__(256) void scan_block_sums(const int *__restrict__ in, long long n,
+                                                       long long *__restrict__ block_sums) {
+    __shared__ int lds[5];
+    const long long base = (long long)blockIdx.x * kScanChunk + (long long)threadIdx.x * kScanItems;
+    int s = 0;
+    for (int j = 0; j < kScanItems; ++j)
+        if (base + j < n) s += in[base + j];
+    int total;
+    block_exclusive_scan_256(s, lds, &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ void scan_block_offsets(long long *block_sums, int nb, long long *total_out) {
+    // single thread: nb is at most a few thousand
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        long long run = 0;
+        for (int i = 0; i < nb; ++i) {
+            const long long v = block_sums[i];
+            block_sums[i] = run;
+            run += v;
+        }
+        *total_out = run;
+    }
+}
+
+__global__ __launch_bounds__(256) void scan_apply(const int *__restrict__ in, long long n,
+                                                  const long long *__restrict__ block_offs,
+                                                  const long long *__restrict__ total, int *__restrict__ out) {
+    __shared__ int lds[5];
+    const long long base = (long long)blockIdx.x * kScanChunk + (long long)threadIdx.x * kScanItems;
+    int v[kScanItems];
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) {
+        v[j] = (base + j < n) ? in[base + j] : 0;
+        s += v[j];
+    }
+    int run = block_exclusive_scan_256(s, lds, nullptr) + (int)block_offs[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) {
+        if (base + j < n) out[base + j] = run;
+        run += v[j];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = (int)(*total);
+}
+
+int exclusive_scan_i32(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t n, int64_t *total) {
+    const int nb = (int)((n + kScanChunk - 1) / kScanChunk);
+    long long *bs = nullptr;
+    PADNE_HIP_CHECK(hipMalloc((void **)&bs, sizeof(long long) * (size_t)(nb + 2)));
+    long long *tot = bs + nb;
+    if (nb > 0) hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(256), 0, ctx->stream, in, (long long)n, bs);
+    hipLaunchKernelGGL(scan_block_offsets, dim3(1), dim3(64), 0, ctx->stream, bs, nb, tot);
+    if (nb > 0)
+        hipLaunchKernelGGL(scan_apply, dim3(nb), dim3(256), 0, ctx->stream, in, (long long)n, bs, tot, out);
+    long long h = 0;
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, tot, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && nb == 0) e = hipMemsetAsync(out, 0, sizeof(int32_t), ctx->stream);
+    hipFree(bs);
+    if (e != hipSuccess) {
+        set_error("scan failed: %s", hipGetErrorString(e));
+        return PADNE_E_HIP;
+    }
+    if (h >= 2147483647LL) {
+        set_error("scan total %lld overflows int32 indices", h);
+        return PADNE_E_INVALID;
+    }
+    *total = h;
+    return PADNE_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// assembly kernels
+// ------------------------------------------------------------------------------------------
+enum { ERR_BAD_INDEX = 0, ERR_NONMANIFOLD = 1, ERR_WORDS = 4 };
+
+__device__ __forceinline__ int find_segment(const long long *__restrict__ offs, int n_seg, long long i) {
+    // largest m with offs[m] <= i   (offs has n_seg+1 entries, offs[0] = 0)
+    int lo = 0, hi = n_seg;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (offs[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void asm_count_tri(long long n_tri, const int *__restrict__ tri, int n_mesh,
+                              const long long *__restrict__ mesh_voff, const long long *__restrict__ mesh_toff,
+                              int *__restrict__ cnt, int *__restrict__ err) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tri) return;
+    const int m = find_segment(mesh_toff, n_mesh, t);
+    const long long v0 = mesh_voff[m];
+    const long long nv = mesh_voff[m + 1] - v0;
+    const int a = tri[3 * t], b = tri[3 * t + 1], c = tri[3 * t + 2];
+    if (a < 0 || b < 0 || c < 0 || a >= nv || b >= nv || c >= nv || a == b || b == c || a == c) {
+        atomicExch(&err[ERR_BAD_INDEX], 1);
+        return;
+    }
+    atomicAdd(&cnt[v0 + a], 2);
+    atomicAdd(&cnt[v0 + b], 2);
+    atomicAdd(&cnt[v0 + c], 2);
+}
+
+__global__ void asm_count_coo(long long n_coo, const int *__restrict__ row, int *__restrict__ cnt) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_coo) return;
+    atomicAdd(&cnt[row[k]], 1);
+}
+
+// |cot(theta_o)| / 2 for the edge (i,k) seen from the opposite corner o   -- mesh.py:136-138
+__device__ __forceinline__ double cot_half(double ix, double iy, double kx, double ky, double ox, double oy) {
+    const double vix = ix - ox, viy = iy - oy;
+    const double vkx = kx - ox, vky = ky - oy;
+    const double dot = vix * vkx + viy * vky;
+    const double cross = vix * vky - viy * vkx;
+    return fabs(dot / cross) / 2;
+}
+
+// slot key: column in the high word; low word orders duplicates: 0 = mesh term stored at the
+// origin of the directed triangle edge, 1 = mesh term stored at its target, 2 = the row's
+// diagonal placeholder, 3+k = stamp k
+__device__ __forceinline__ long long make_key(int col, int seq) { return ((long long)col << 32) | (unsigned)seq; }
+
+__global__ void asm_fill_tri(long long n_tri, const int *__restrict__ tri, const double *__restrict__ xy,
+                             int n_mesh, const long long *__restrict__ mesh_voff,
+                             const long long *__restrict__ mesh_toff, const int *__restrict__ slot_ptr,
+                             int *__restrict__ cursor, long long *__restrict__ key, double *__restrict__ val) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tri) return;
+    const int m = find_segment(mesh_toff, n_mesh, t);
+    const long long v0 = mesh_voff[m];
+    const int ga = (int)(v0 + tri[3 * t]), gb = (int)(v0 + tri[3 * t + 1]), gc = (int)(v0 + tri[3 * t + 2]);
+    const double ax = xy[2 * (long long)ga], ay = xy[2 * (long long)ga + 1];
+    const double bx = xy[2 * (long long)gb], by = xy[2 * (long long)gb + 1];
+    const double cx = xy[2 * (long long)gc], cy = xy[2 * (long long)gc + 1];
+    const double wab = cot_half(ax, ay, bx, by, cx, cy);   // edge a->b, opposite c
+    const double wbc = cot_half(bx, by, cx, cy, ax, ay);   // edge b->c, opposite a
+    const double wca = cot_half(cx, cy, ax, ay, bx, by);   // edge c->a, opposite b
+    // row a: (a,b) forward, (a,c) backward ; row b: (b,c) fwd, (b,a) bwd ; row c: (c,a) fwd, (c,b) bwd
+    int s;
+    s = slot_ptr[ga] + atomicAdd(&cursor[ga], 2);
+    key[s] = make_key(gb, 0); val[s] = wab;
+    key[s + 1] = make_key(gc, 1); val[s + 1] = wca;
+    s = slot_ptr[gb] + atomicAdd(&cursor[gb], 2);
+    key[s] = make_key(gc, 0); val[s] = wbc;
+    key[s + 1] = make_key(ga, 1); val[s + 1] = wab;
+    s = slot_ptr[gc] + atomicAdd(&cursor[gc], 2);
+    key[s] = make_key(ga, 0); val[s] = wca;
+    key[s + 1] = make_key(gb, 1); val[s + 1] = wbc;
+}
+
+__global__ void asm_fill_coo(long long n_coo, const int *__restrict__ row, const int *__restrict__ col,
+                             const double *__restrict__ v, const int *__restrict__ slot_ptr,
+                             int *__restrict__ cursor, long long *__restrict__ key, double *__restrict__ val) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_coo) return;
+    const int r = row[k];
+    const int s = slot_ptr[r] + atomicAdd(&cursor[r], 1);
+    key[s] = make_key(col[k], (int)(k + 3));
+    val[s] = v[k];
+}
+
+// in-place insertion sort of a row's slots by key
+__device__ __forceinline__ void sort_slots(long long *key, double *val, int n) {
+    for (int i = 1; i < n; ++i) {
+        const long long k = key[i];
+        const double v = val[i];
+        int j = i - 1;
+        while (j >= 0 && key[j] > k) {
+            key[j + 1] = key[j];
+            val[j + 1] = val[j];
+            --j;
+        }
+        key[j + 1] = k;
+        val[j + 1] = v;
+    }
+}
+
+// One lane per row.  MESH=true: slots with sequence 0/1 are raw cotangent terms of the row's
+// mesh, sequence 2 is the (zero valued) diagonal placeholder every row owns, 3+k is stamp k.
+// Every column group owns at least one slot and emits at most one entry, so the in-place
+// compaction (output cursor o <= input cursor i) never overtakes unread slots.
+template <bool MESH>
+__global__ void merge_rows(long long n_rows, long long n_vert, int n_mesh,
+                           const long long *__restrict__ mesh_voff, const double *__restrict__ sigma,
+                           const int *__restrict__ slot_ptr, long long *__restrict__ key,
+                           double *__restrict__ val, int *__restrict__ row_len, int *__restrict__ err) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const int s0 = slot_ptr[r];
+    const int n = slot_ptr[r + 1] - s0;
+    long long *K = key + s0;
+    double *V = val + s0;
+    sort_slots(K, V, n);
+    double sig = 0.0;
+    double dacc = 0.0;  // -(w_1 + w_2 + ...) in ascending column order   (diag[i] -= ratio, solver.py:203)
+    if (MESH && r < n_vert) {
+        sig = sigma[find_segment(mesh_voff, n_mesh, r)];
+        int fwd_only = 0, bwd_only = 0;
+        int i = 0;
+        while (i < n) {
+            const int col = (int)(K[i] >> 32);
+            int terms = 0, seq_sum = 0;
+            double wm = 0.0;
+            while (i < n && (int)(K[i] >> 32) == col && (unsigned)(K[i] & 0xffffffffLL) < 2u) {
+                wm = (terms == 0) ? V[i] : wm + V[i];          // 0. + c1 + c2   mesh.py:131-138
+                seq_sum += (int)(K[i] & 0xffffffffLL);
+                ++terms;
+                ++i;
+            }
+            while (i < n && (int)(K[i] >> 32) == col) ++i;      // stamps: second walk
+            // an interior edge has one forward and one backward term; anything else is the
+            // "Non-manifold mesh" of mesh.py:342-343 (or a doubly used directed edge)
+            if (terms > 2 || (terms == 2 && seq_sum != 1)) atomicExch(&err[ERR_NONMANIFOLD], 1);
+            if (terms == 1) { if (seq_sum == 0) ++fwd_only; else ++bwd_only; }
+            if (terms > 0 && wm != 0.0) dacc = dacc - wm;       // zero weights are skipped  solver.py:187-190
+        }
+        if (fwd_only > 1 || bwd_only > 1) atomicExch(&err[ERR_NONMANIFOLD], 1);
+    }
+    int o = 0;
+    int i = 0;
+    while (i < n) {
+        const int col = (int)(K[i] >> 32);
+        double v = 0.0;
+        if (MESH) {
+            if (col == (int)r) {
+                v = sig * dacc;                                   // conductance * (diagonal entry)
+            } else {
+                int terms = 0;
+                double wm = 0.0;
+                while (i < n && (int)(K[i] >> 32) == col && (unsigned)(K[i] & 0xffffffffLL) < 2u) {
+                    wm = (terms == 0) ? V[i] : wm + V[i];
+                    ++terms;
+                    ++i;
+                }
+                if (terms > 0) v = sig * wm;                      // conductance * laplace_operator(msh)
+            }
+        }
+        while (i < n && (int)(K[i] >> 32) == col) {               // L[i,j] += stamp, in stamp order
+            v = v + V[i];
+            ++i;
+        }
+        if (v != 0.0) {                                           // exact zeros are not stored
+            K[o] = (long long)col << 32;
+            V[o] = v;
+            ++o;
+        }
+    }
+    row_len[r] = o;
+}
+
+__global__ void compact_rows(long long n_rows, const int *__restrict__ slot_ptr, const int *__restrict__ rowptr,
+                             const long long *__restrict__ key, const double *__restrict__ val,
+                             int *__restrict__ cols, double *__restrict__ vals) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const int s = slot_ptr[r];
+    const int d0 = rowptr[r], d1 = rowptr[r + 1];
+    for (int j = 0; j < d1 - d0; ++j) {
+        cols[d0 + j] = (int)(key[s + j] >> 32);
+        vals[d0 + j] = val[s + j];
+    }
+}
+
+__global__ void fill_value_i32(int *p, long long n, int v) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+__global__ void asm_fill_diag_placeholder(long long n_rows, const int *__restrict__ slot_ptr,
+                                          long long *__restrict__ key, double *__restrict__ val) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const int s = slot_ptr[r];          // cursor starts at 1: slot 0 of every row is the placeholder
+    key[s] = make_key((int)r, 2);
+    val[s] = 0.0;
+}
+
+// ---- reduce:  out = scale * P^T M P ------------------------------------------------------------
+__global__ void reduce_count(long long n_rows, const int *__restrict__ rowptr, const int *__restrict__ cols,
+                             const int *__restrict__ map, int *__restrict__ cnt) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const int t = map[r];
+    if (t < 0) return;
+    int c = 0;
+    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) c += (map[cols[k]] >= 0) ? 1 : 0;
+    if (c) atomicAdd(&cnt[t], c);
+}
+
+__global__ void reduce_fill(long long n_rows, const int *__restrict__ rowptr, const int *__restrict__ cols,
+                            const double *__restrict__ vals, const int *__restrict__ map, double scale,
+                            const int *__restrict__ slot_ptr, int *__restrict__ cursor,
+                            long long *__restrict__ key, double *__restrict__ val) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const int t = map[r];
+    if (t < 0) return;
+    int c = 0;
+    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) c += (map[cols[k]] >= 0) ? 1 : 0;
+    if (!c) return;
+    int s = slot_ptr[t] + atomicAdd(&cursor[t], c);
+    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+        const int tc = map[cols[k]];
+        if (tc < 0) continue;
+        key[s] = make_key(tc, k);       // ties are broken by the position in the source matrix
+        val[s] = scale * vals[k];
+        ++s;
+    }
+}
+
+// ---- power density ---------------------------------------------------------------------------
+// compute_triangle_gradient (solver.py:689-725) with the face vertex order of the reference:
+// Face.edge is the last interior half-edge created (v3->v1, mesh.py:320-325) so face.vertices
+// yields (v3, v1, v2).
+__device__ __forceinline__ double interp(double x1, double y1, double x2, double y2, double x3, double y3,
+                                         double f1, double f2, double f3, double x, double y) {
+    const double D = (y2 - y3) * (x1 - x3) + (x3 - x2) * (y1 - y3);
+    const double l1 = ((y2 - y3) * (x - x3) + (x3 - x2) * (y - y3)) / D;
+    const double l2 = ((y3 - y1) * (x - x3) + (x1 - x3) * (y - y3)) / D;
+    const double l3 = 1 - l1 - l2;
+    return l1 * f1 + l2 * f2 + l3 * f3;
+}
+
+__global__ void power_density_kernel(long long n_tri, const int *__restrict__ tri, const double *__restrict__ xy,
+                                     int n_mesh, const long long *__restrict__ mesh_voff,
+                                     const long long *__restrict__ mesh_toff, const double *__restrict__ sigma,
+                                     const double *__restrict__ pot, double *__restrict__ out) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tri) return;
+    const int m = find_segment(mesh_toff, n_mesh, t);
+    const long long v0 = mesh_voff[m];
+    const long long g1 = v0 + tri[3 * t + 2], g2 = v0 + tri[3 * t], g3 = v0 + tri[3 * t + 1];
+    const double x1 = xy[2 * g1], y1 = xy[2 * g1 + 1];
+    const double x2 = xy[2 * g2], y2 = xy[2 * g2 + 1];
+    const double x3 = xy[2 * g3], y3 = xy[2 * g3 + 1];
+    const double f1 = pot[g1], f2 = pot[g2], f3 = pot[g3];
+    const double gx = interp(x1, y1, x2, y2, x3, y3, f1, f2, f3, x1 + 1, y1) - f1;
+    const double gy = interp(x1, y1, x2, y2, x3, y3, f1, f2, f3, x1, y1 + 1) - f1;
+    const double s = sigma[m];
+    const double jx = gx * s, jy = gy * s;      // J = E * conductivity
+    out[t] = jx * gx + jy * gy;                 // J.dot(E)
+}
+
+// ---- host orchestration ----------------------------------------------------------------------
+struct Scratch {   // frees everything on scope exit
+    std::vector<void *> ptrs;
+    ~Scratch() { for (void *p : ptrs) if (p) hipFree(p); }
+    template <typename T> int alloc(T **out, size_t count) {
+        void *p = nullptr;
+        if (hipMalloc(&p, sizeof(T) * (count ? count : 1)) != hipSuccess) {
+            set_error("hipMalloc of %zu bytes failed during assembly", sizeof(T) * count);
+            return PADNE_E_NOMEM;
+        }
+        ptrs.push_back(p);
+        *out = (T *)p;
+        return PADNE_OK;
+    }
+};
+
+static inline unsigned nblk(long long n, int bs = 256) { return (unsigned)((n + bs - 1) / bs > 0 ? (n + bs - 1) / bs : 1); }
+
+// shared tail: slots (key,val,slot_ptr) already filled -> merged CSR
+template <bool MESH>
+static int finish_rows(padne_ctx *ctx, Scratch &sc, long long n_rows, long long n_cols, long long n_vert, int n_mesh,
+                       const long long *d_voff, const double *d_sigma, const int *slot_ptr, long long *key,
+                       double *val, int *d_err, padne_csr **out) {
+    hipStream_t s = ctx->stream;
+    int *row_len = nullptr;
+    PADNE_TRY(sc.alloc(&row_len, (size_t)n_rows + 1));
+    hipLaunchKernelGGL(merge_rows<MESH>, dim3(nblk(n_rows, 128)), dim3(128), 0, s, n_rows, n_vert, n_mesh, d_voff,
+                       d_sigma, slot_ptr, key, val, row_len, d_err);
+    PADNE_HIP_CHECK(hipGetLastError());
+    int h_err[ERR_WORDS];
+    PADNE_HIP_CHECK(hipMemcpyAsync(h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
+    PADNE_HIP_CHECK(hipStreamSynchronize(s));
+    if (h_err[ERR_NONMANIFOLD]) {
+        set_error("Non-manifold mesh");
+        return PADNE_E_NONMANIFOLD;
+    }
+    int *rowptr_tmp = nullptr;
+    PADNE_TRY(sc.alloc(&rowptr_tmp, (size_t)n_rows + 1));
+    int64_t nnz = 0;
+    PADNE_TRY(exclusive_scan_i32(ctx, row_len, rowptr_tmp, n_rows, &nnz));
+    padne_csr *m = nullptr;
+    PADNE_TRY(csr_alloc(ctx, n_rows, n_cols, nnz, &m));
+    hipError_t e = hipMemcpyAsync(m->rowptr, rowptr_tmp, sizeof(int32_t) * (size_t)(n_rows + 1),
+                                  hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(compact_rows, dim3(nblk(n_rows)), dim3(256), 0, s, n_rows, slot_ptr, m->rowptr, key, val,
+                           m->cols, m->vals);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        set_error("row compaction failed: %s", hipGetErrorString(e));
+        padne_csr_destroy(m);
+        return PADNE_E_HIP;
+    }
+    *out = m;
+    return PADNE_OK;
+}
+
+}  // namespace padne
+
+using namespace padne;
+
+extern "C" int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns, int64_t n_vert, const double *xy_host,
+                                     int64_t n_tri, const int32_t *tri_host, int64_t n_mesh,
+                                     const int64_t *mesh_vertex_offset, const int64_t *mesh_tri_offset,
+                                     const double *conductance, int64_t n_coo, const int64_t *coo_row,
+                                     const int64_t *coo_col, const double *coo_val, padne_csr **out) {
+    PADNE_REQUIRE(ctx && out, "null argument");
+    PADNE_REQUIRE(n_unknowns >= 0 && n_vert >= 0 && n_tri >= 0 && n_mesh >= 0 && n_coo >= 0, "negative size");
+    PADNE_REQUIRE(n_vert <= n_unknowns, "more vertices than unknowns");
+    PADNE_REQUIRE(n_unknowns < 2147483647LL, "too many unknowns for int32 indices");
+    PADNE_REQUIRE(n_vert == 0 || xy_host, "xy");
+    PADNE_REQUIRE(n_tri == 0 || tri_host, "tri");
+    PADNE_REQUIRE(n_mesh == 0 || (mesh_vertex_offset && mesh_tri_offset && conductance), "mesh tables");
+    PADNE_REQUIRE(n_coo == 0 || (coo_row && coo_col && coo_val), "coo arrays");
+    PADNE_REQUIRE(n_mesh > 0 || (n_vert == 0 && n_tri == 0), "vertices without a mesh");
+    if (n_mesh > 0) {
+        PADNE_REQUIRE(mesh_vertex_offset[0] == 0 && mesh_tri_offset[0] == 0, "offset tables must start at 0");
+        PADNE_REQUIRE(mesh_vertex_offset[n_mesh] == n_vert && mesh_tri_offset[n_mesh] == n_tri,
+                      "offset tables must end at n_vert / n_tri");
+        for (int64_t m = 0; m < n_mesh; ++m)
+            PADNE_REQUIRE(mesh_vertex_offset[m] <= mesh_vertex_offset[m + 1] &&
+                              mesh_tri_offset[m] <= mesh_tri_offset[m + 1], "offset tables not monotone");
+    }
+    std::vector<int32_t> row32((size_t)n_coo), col32((size_t)n_coo);
+    for (int64_t k = 0; k < n_coo; ++k) {
+        PADNE_REQUIRE(coo_row[k] >= 0 && coo_row[k] < n_unknowns && coo_col[k] >= 0 && coo_col[k] < n_unknowns,
+                      "stamp index out of range");
+        row32[(size_t)k] = (int32_t)coo_row[k];
+        col32[(size_t)k] = (int32_t)coo_col[k];
+    }
+    PADNE_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    Scratch sc;
+    double *d_xy = nullptr, *d_sigma = nullptr, *d_cval = nullptr;
+    int *d_tri = nullptr, *d_crow = nullptr, *d_ccol = nullptr, *d_cnt = nullptr, *d_slot = nullptr, *d_err = nullptr;
+    long long *d_voff = nullptr, *d_toff = nullptr;
+    PADNE_TRY(sc.alloc(&d_xy, (size_t)n_vert * 2));
+    PADNE_TRY(sc.alloc(&d_tri, (size_t)n_tri * 3));
+    PADNE_TRY(sc.alloc(&d_sigma, (size_t)n_mesh));
+    PADNE_TRY(sc.alloc(&d_voff, (size_t)n_mesh + 1));
+    PADNE_TRY(sc.alloc(&d_toff, (size_t)n_mesh + 1));
+    PADNE_TRY(sc.alloc(&d_crow, (size_t)n_coo));
+    PADNE_TRY(sc.alloc(&d_ccol, (size_t)n_coo));
+    PADNE_TRY(sc.alloc(&d_cval, (size_t)n_coo));
+    PADNE_TRY(sc.alloc(&d_cnt, (size_t)n_unknowns + 1));
+    PADNE_TRY(sc.alloc(&d_slot, (size_t)n_unknowns + 1));
+    PADNE_TRY(sc.alloc(&d_err, (size_t)ERR_WORDS));
+    const long long zero_off[1] = {0};
+    PADNE_HIP_CHECK(hipMemcpyAsync(d_xy, xy_host, sizeof(double) * 2 * (size_t)n_vert, hipMemcpyHostToDevice, s));
+    PADNE_HIP_CHECK(hipMemcpyAsync(d_tri, tri_host, sizeof(int) * 3 * (size_t)n_tri, hipMemcpyHostToDevice, s));
+    if (n_mesh > 0) {
+        PADNE_HIP_CHECK(hipMemcpyAsync(d_sigma, conductance, sizeof(double) * (size_t)n_mesh, hipMemcpyHostToDevice, s));
+        PADNE_HIP_CHECK(hipMemcpyAsync(d_voff, mesh_vertex_offset, sizeof(long long) * (size_t)(n_mesh + 1), hipMemcpyHostToDevice, s));
+        PADNE_HIP_CHECK(hipMemcpyAsync(d_toff, mesh_tri_offset, sizeof(long long) * (size_t)(n_mesh + 1), hipMemcpyHostToDevice, s));
+    } else {
+        PADNE_HIP_CHECK(hipMemcpyAsync(d_voff, zero_off, sizeof(long long), hipMemcpyHostToDevice, s));
+        PADNE_HIP_CHECK(hipMemcpyAsync(d_toff, zero_off, sizeof(long long), hipMemcpyHostToDevice, s));
+    }
+    if (n_coo > 0) {
+        PADNE_HIP_CHECK(hipMemcpyAsync(d_crow, row32.data(), sizeof(int) * (size_t)n_coo, hipMemcpyHostToDevice, s));
+        PADNE_HIP_CHECK(hipMemcpyAsync(d_ccol, col32.data(), sizeof(int) * (size_t)n_coo, hipMemcpyHostToDevice, s));
+        PADNE_HIP_CHECK(hipMemcpyAsync(d_cval, coo_val, sizeof(double) * (size_t)n_coo, hipMemcpyHostToDevice, s));
+    }
+    PADNE_HIP_CHECK(hipMemsetAsync(d_err, 0, sizeof(int) * ERR_WORDS, s));
+    // 1 count (every row starts with its diagonal placeholder)
+    hipLaunchKernelGGL(fill_value_i32, dim3(nblk(n_unknowns + 1)), dim3(256), 0, s, d_cnt, (long long)n_unknowns + 1, 1);
+    if (n_tri > 0)
+        hipLaunchKernelGGL(asm_count_tri, dim3(nblk(n_tri)), dim3(256), 0, s, (long long)n_tri, d_tri, (int)n_mesh,
+                           d_voff, d_toff, d_cnt, d_err);
+    if (n_coo > 0)
+        hipLaunchKernelGGL(asm_count_coo, dim3(nblk(n_coo)), dim3(256), 0, s, (long long)n_coo, d_crow, d_cnt);
+    PADNE_HIP_CHECK(hipGetLastError());
+    int h_err[ERR_WORDS];
+    PADNE_HIP_CHECK(hipMemcpyAsync(h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
+    PADNE_HIP_CHECK(hipStreamSynchronize(s));
+    if (h_err[ERR_BAD_INDEX]) {
+        set_error("triangle refers to a vertex outside its mesh, or repeats a vertex");
+        return PADNE_E_INVALID;
+    }
+    // 2 scan
+    int64_t n_slots = 0;
+    PADNE_TRY(exclusive_scan_i32(ctx, d_cnt, d_slot, n_unknowns, &n_slots));
+    long long *d_key = nullptr;
+    double *d_val = nullptr;
+    PADNE_TRY(sc.alloc(&d_key, (size_t)n_slots));
+    PADNE_TRY(sc.alloc(&d_val, (size_t)n_slots));
+    // 3 fill (cursor = 1: slot 0 of each row is the diagonal placeholder)
+    hipLaunchKernelGGL(fill_value_i32, dim3(nblk(n_unknowns + 1)), dim3(256), 0, s, d_cnt, (long long)n_unknowns + 1, 1);
+    hipLaunchKernelGGL(asm_fill_diag_placeholder, dim3(nblk(n_unknowns)), dim3(256), 0, s, (long long)n_unknowns, d_slot,
+                       d_key, d_val);
+    if (n_tri > 0)
+        hipLaunchKernelGGL(asm_fill_tri, dim3(nblk(n_tri)), dim3(256), 0, s, (long long)n_tri, d_tri, d_xy, (int)n_mesh,
+                           d_voff, d_toff, d_slot, d_cnt, d_key, d_val);
+    if (n_coo > 0)
+        hipLaunchKernelGGL(asm_fill_coo, dim3(nblk(n_coo)), dim3(256), 0, s, (long long)n_coo, d_crow, d_ccol, d_cval,
+                           d_slot, d_cnt, d_key, d_val);
+    PADNE_HIP_CHECK(hipGetLastError());
+    // 4-6
+    return finish_rows<true>(ctx, sc, n_unknowns, n_unknowns, n_vert, (int)n_mesh, d_voff, d_sigma, d_slot, d_key,
+                             d_val, d_err, out);
+}
+
+extern "C" int padne_csr_reduce(padne_ctx *ctx, const padne_csr *m, const int32_t *map_host, int64_t n_out,
+                                double scale, padne_csr **out) {
+    PADNE_REQUIRE(ctx && m && map_host && out, "null argument");
+    PADNE_REQUIRE(m->n_rows == m->n_cols, "matrix must be square");
+    PADNE_REQUIRE(n_out >= 0 && n_out < 2147483647LL, "n_out");
+    for (int64_t i = 0; i < m->n_rows; ++i)
+        PADNE_REQUIRE(map_host[i] >= -1 && map_host[i] < n_out, "map entry out of range");
+    PADNE_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    Scratch sc;
+    int *d_map = nullptr, *d_cnt = nullptr, *d_slot = nullptr, *d_err = nullptr;
+    PADNE_TRY(sc.alloc(&d_map, (size_t)m->n_rows));
+    PADNE_TRY(sc.alloc(&d_cnt, (size_t)n_out + 1));
+    PADNE_TRY(sc.alloc(&d_slot, (size_t)n_out + 1));
+    PADNE_TRY(sc.alloc(&d_err, (size_t)ERR_WORDS));
+    PADNE_HIP_CHECK(hipMemcpyAsync(d_map, map_host, sizeof(int) * (size_t)m->n_rows, hipMemcpyHostToDevice, s));
+    PADNE_HIP_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(int) * (size_t)(n_out + 1), s));
+    PADNE_HIP_CHECK(hipMemsetAsync(d_err, 0, sizeof(int) * ERR_WORDS, s));
+    if (m->n_rows > 0)
+        hipLaunchKernelGGL(reduce_count, dim3(nblk(m->n_rows)), dim3(256), 0, s, (long long)m->n_rows, m->rowptr,
+                           m->cols, d_map, d_cnt);
+    PADNE_HIP_CHECK(hipGetLastError());
+    int64_t n_slots = 0;
+    PADNE_TRY(exclusive_scan_i32(ctx, d_cnt, d_slot, n_out, &n_slots));
+    long long *d_key = nullptr;
+    double *d_val = nullptr;
+    PADNE_TRY(sc.alloc(&d_key, (size_t)n_slots));
+    PADNE_TRY(sc.alloc(&d_val, (size_t)n_slots));
+    PADNE_HIP_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(int) * (size_t)(n_out + 1), s));
+    if (m->n_rows > 0)
+        hipLaunchKernelGGL(reduce_fill, dim3(nblk(m->n_rows)), dim3(256), 0, s, (long long)m->n_rows, m->rowptr, m->cols,
+                           m->vals, d_map, scale, d_slot, d_cnt, d_key, d_val);
+    PADNE_HIP_CHECK(hipGetLastError());
+    return finish_rows<false>(ctx, sc, n_out, n_out, 0, 0, nullptr, nullptr, d_slot, d_key, d_val, d_err, out);
+}
+
+extern "C" int padne_power_density(padne_ctx *ctx, int64_t n_vert, const double *xy_host, int64_t n_tri,
+                                   const int32_t *tri_host, int64_t n_mesh, const int64_t *mesh_vertex_offset,
+                                   const int64_t *mesh_tri_offset, const double *conductance,
+                                   const double *potential_host, double *power_out_host) {
+    PADNE_REQUIRE(ctx, "ctx");
+    PADNE_REQUIRE(n_vert >= 0 && n_tri >= 0 && n_mesh >= 0, "negative size");
+    if (n_tri == 0) return PADNE_OK;
+    PADNE_REQUIRE(xy_host && tri_host && mesh_vertex_offset && mesh_tri_offset && conductance && potential_host &&
+                      power_out_host && n_mesh > 0, "null argument");
+    PADNE_REQUIRE(mesh_vertex_offset[n_mesh] == n_vert && mesh_tri_offset[n_mesh] == n_tri, "offset tables");
+    for (int64_t m = 0; m < n_mesh; ++m) {
+        const int64_t nv = mesh_vertex_offset[m + 1] - mesh_vertex_offset[m];
+        for (int64_t t = mesh_tri_offset[m]; t < mesh_tri_offset[m + 1]; ++t)
+            for (int c = 0; c < 3; ++c)
+                PADNE_REQUIRE(tri_host[3 * t + c] >= 0 && tri_host[3 * t + c] < nv, "triangle index out of range");
+    }
+    PADNE_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    Scratch sc;
+    double *d_xy = nullptr, *d_sigma = nullptr, *d_pot = nullptr, *d_out = nullptr;
+    int *d_tri = nullptr;
+    long long *d_voff = nullptr, *d_toff = nullptr;
+    PADNE_TRY(sc.alloc(&d_xy, (size_t)n_vert * 2));
+    PADNE_TRY(sc.alloc(&d_tri, (size_t)n_tri * 3));
+    PADNE_TRY(sc.alloc(&d_sigma, (size_t)n_mesh));
+    PADNE_TRY(sc.alloc(&d_voff, (size_t)n_mesh + 1));
+    PADNE_TRY(sc.alloc(&d_toff, (size_t)n_mesh + 1));
+    PADNE_TRY(sc.alloc(&d_pot, (size_t)n_vert));
+    PADNE_TRY(sc.alloc(&d_out, (size_t)n_tri));
+    PADNE_HIP_CHECK(hipMemcpyAsync(d_xy, xy_host, sizeof(double) * 2 * (size_t)n_vert, hipMemcpyHostToDevice, s));
+    PADNE_HIP_CHECK(hipMemcpyAsync(d_tri, tri_host, sizeof(int) * 3 * (size_t)n_tri, hipMemcpyHostToDevice, s));
+    PADNE_HIP_CHECK(hipMemcpyAsync(d_sigma, conductance, sizeof(double) * (size_t)n_mesh, hipMemcpyHostToDevice, s));
+    PADNE_HIP_CHECK(hipMemcpyAsync(d_voff, mesh_vertex_offset, sizeof(long long) * (size_t)(n_mesh + 1), hipMemcpyHostToDevice, s));
+    PADNE_HIP_CHECK(hipMemcpyAsync(d_toff, mesh_tri_offset, sizeof(long long) * (size_t)(n_mesh + 1), hipMemcpyHostToDevice, s));
+    PADNE_HIP_CHECK(hipMemcpyAsync(d_pot, potential_host, sizeof(double) * (size_t)n_vert, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(power_density_kernel, dim3(nblk(n_tri)), dim3(256), 0, s, (long long)n_tri, d_tri, d_xy, (int)n_mesh,
+                       d_voff, d_toff, d_sigma, d_pot, d_out);
+    PADNE_HIP_CHECK(hipGetLastError());
+    PADNE_HIP_CHECK(hipMemcpyAsync(power_out_host, d_out, sizeof(double) * (size_t)n_tri, hipMemcpyDeviceToHost, s));
+    PADNE_HIP_CHECK(hipStreamSynchronize(s));
+    return PADNE_OK;
+}

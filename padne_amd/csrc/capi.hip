@@ -1,0 +1,332 @@
+// C ABI plumbing: contexts, device memory, CSR hand-off, SpMV entry points, timing.
+#include "common.hpp"
+
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+namespace padne {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int ensure_workspace(padne_ctx *ctx, size_t bytes) {
+    if (ctx->ws_bytes >= bytes) return PADNE_OK;
+    if (ctx->ws) {
+        PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        PADNE_HIP_CHECK(hipFree(ctx->ws));
+        ctx->ws = nullptr;
+        ctx->ws_bytes = 0;
+    }
+    if (hipMalloc(&ctx->ws, bytes) != hipSuccess) {
+        set_error("hipMalloc of %zu workspace bytes failed", bytes);
+        return PADNE_E_NOMEM;
+    }
+    ctx->ws_bytes = bytes;
+    return PADNE_OK;
+}
+
+int csr_alloc(padne_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, padne_csr **out) {
+    PADNE_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0, "negative size");
+    PADNE_REQUIRE(nnz < (int64_t)2147483647 - kPadNnz && n_rows < 2147483647 && n_cols < 2147483647,
+                  "matrix too large for int32 indices");
+    padne_csr *m = new padne_csr();
+    m->n_rows = n_rows;
+    m->n_cols = n_cols;
+    m->nnz = nnz;
+    m->device = ctx->device;
+    const size_t ne = (size_t)nnz + kPadNnz;
+    if (hipMalloc((void **)&m->rowptr, sizeof(int32_t) * (size_t)(n_rows + 1)) != hipSuccess ||
+        hipMalloc((void **)&m->cols, sizeof(int32_t) * ne) != hipSuccess ||
+        hipMalloc((void **)&m->vals, sizeof(double) * ne) != hipSuccess) {
+        padne_csr_destroy(m);
+        set_error("hipMalloc failed for a %lld x %lld matrix with %lld non-zeros", (long long)n_rows,
+                  (long long)n_cols, (long long)nnz);
+        return PADNE_E_NOMEM;
+    }
+    // zero the padding (column 0 / value 0.0) so the SpMV tile loads never need a bounds check
+    PADNE_HIP_CHECK(hipMemsetAsync(m->cols + nnz, 0, sizeof(int32_t) * kPadNnz, ctx->stream));
+    PADNE_HIP_CHECK(hipMemsetAsync(m->vals + nnz, 0, sizeof(double) * kPadNnz, ctx->stream));
+    *out = m;
+    return PADNE_OK;
+}
+
+__global__ void dot_partial_kernel(const long long n, const double *__restrict__ a, const double *__restrict__ b,
+                                   double *__restrict__ partials) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const double d = a[i] - b[i];
+        s += d * d;
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+}  // namespace padne
+
+using namespace padne;
+
+extern "C" {
+
+int padne_abi_version(void) { return PADNE_ABI_VERSION; }
+
+const char *padne_last_error(void) { return g_err; }
+
+int padne_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+        return PADNE_E_HIP;
+    }
+    return n;
+}
+
+int padne_ctx_create(int device, padne_ctx **out) {
+    PADNE_REQUIRE(out != nullptr, "out");
+    int n = 0;
+    PADNE_HIP_CHECK(hipGetDeviceCount(&n));
+    if (n <= 0) {
+        set_error("no HIP device visible: libpadne_hip has no CPU fallback");
+        return PADNE_E_HIP;
+    }
+    PADNE_REQUIRE(device >= 0 && device < n, "device index out of range");
+    PADNE_HIP_CHECK(hipSetDevice(device));
+    padne_ctx *ctx = new padne_ctx();
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void **)&ctx->partials, sizeof(double) * 8 * kMaxPartials) != hipSuccess ||
+        hipMalloc((void **)&ctx->scalars, sizeof(double) * 64) != hipSuccess ||
+        hipMalloc((void **)&ctx->status, 256) != hipSuccess ||
+        hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        set_error("context creation failed: %s", hipGetErrorString(hipGetLastError()));
+        padne_ctx_destroy(ctx);
+        return PADNE_E_HIP;
+    }
+    hipMemsetAsync(ctx->partials, 0, sizeof(double) * 8 * kMaxPartials, ctx->stream);
+    hipMemsetAsync(ctx->scalars, 0, sizeof(double) * 64, ctx->stream);
+    hipMemsetAsync(ctx->status, 0, 256, ctx->stream);
+    hipStreamSynchronize(ctx->stream);
+    *out = ctx;
+    return PADNE_OK;
+}
+
+int padne_ctx_destroy(padne_ctx *ctx) {
+    if (!ctx) return PADNE_OK;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    comm_destroy(ctx);
+    if (ctx->ws) hipFree(ctx->ws);
+    if (ctx->partials) hipFree(ctx->partials);
+    if (ctx->scalars) hipFree(ctx->scalars);
+    if (ctx->status) hipFree(ctx->status);
+    if (ctx->pinned) hipHostFree(ctx->pinned);
+    if (ctx->ev0) hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return PADNE_OK;
+}
+
+int padne_ctx_synchronize(padne_ctx *ctx) {
+    PADNE_REQUIRE(ctx, "ctx");
+    PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PADNE_OK;
+}
+
+void *padne_ctx_stream(padne_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int padne_dev_alloc(padne_ctx *ctx, int64_t bytes, void **dev_out) {
+    PADNE_REQUIRE(ctx && dev_out && bytes >= 0, "arguments");
+    PADNE_HIP_CHECK(hipSetDevice(ctx->device));
+    if (hipMalloc(dev_out, bytes > 0 ? (size_t)bytes : 8) != hipSuccess) {
+        set_error("hipMalloc(%lld) failed", (long long)bytes);
+        return PADNE_E_NOMEM;
+    }
+    return PADNE_OK;
+}
+
+int padne_dev_free(padne_ctx *ctx, void *dev) {
+    PADNE_REQUIRE(ctx, "ctx");
+    if (dev) {
+        PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        PADNE_HIP_CHECK(hipFree(dev));
+    }
+    return PADNE_OK;
+}
+
+int padne_dev_upload(padne_ctx *ctx, void *dev_dst, const void *host_src, int64_t bytes) {
+    PADNE_REQUIRE(ctx && bytes >= 0 && (bytes == 0 || (dev_dst && host_src)), "arguments");
+    if (bytes == 0) return PADNE_OK;
+    PADNE_HIP_CHECK(hipMemcpyAsync(dev_dst, host_src, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
+    PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PADNE_OK;
+}
+
+int padne_dev_download(padne_ctx *ctx, void *host_dst, const void *dev_src, int64_t bytes) {
+    PADNE_REQUIRE(ctx && bytes >= 0 && (bytes == 0 || (host_dst && dev_src)), "arguments");
+    if (bytes == 0) return PADNE_OK;
+    PADNE_HIP_CHECK(hipMemcpyAsync(host_dst, dev_src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PADNE_OK;
+}
+
+int padne_dev_memset(padne_ctx *ctx, void *dev, int value, int64_t bytes) {
+    PADNE_REQUIRE(ctx && bytes >= 0 && (bytes == 0 || dev), "arguments");
+    if (bytes == 0) return PADNE_OK;
+    PADNE_HIP_CHECK(hipMemsetAsync(dev, value, (size_t)bytes, ctx->stream));
+    PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PADNE_OK;
+}
+
+int padne_csr_from_host(padne_ctx *ctx, int64_t n_rows, int64_t n_cols, const int32_t *indptr,
+                        const int32_t *indices, const double *data, padne_csr **out) {
+    PADNE_REQUIRE(ctx && out && indptr, "null argument");
+    PADNE_REQUIRE(n_rows >= 0 && n_cols >= 0, "negative size");
+    const int64_t nnz = indptr[n_rows];
+    PADNE_REQUIRE(indptr[0] == 0 && nnz >= 0, "indptr must start at 0");
+    PADNE_REQUIRE(nnz == 0 || (indices && data), "null indices/data");
+    for (int64_t i = 0; i < n_rows; ++i) PADNE_REQUIRE(indptr[i] <= indptr[i + 1], "indptr not monotone");
+    for (int64_t k = 0; k < nnz; ++k)
+        PADNE_REQUIRE(indices[k] >= 0 && indices[k] < n_cols, "column index out of range");
+    PADNE_HIP_CHECK(hipSetDevice(ctx->device));
+    padne_csr *m = nullptr;
+    PADNE_TRY(csr_alloc(ctx, n_rows, n_cols, nnz, &m));
+    hipError_t e = hipMemcpyAsync(m->rowptr, indptr, sizeof(int32_t) * (size_t)(n_rows + 1),
+                                  hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && nnz > 0)
+        e = hipMemcpyAsync(m->cols, indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && nnz > 0)
+        e = hipMemcpyAsync(m->vals, data, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        set_error("matrix upload failed: %s", hipGetErrorString(e));
+        padne_csr_destroy(m);
+        return PADNE_E_HIP;
+    }
+    *out = m;
+    return PADNE_OK;
+}
+
+int padne_csr_destroy(padne_csr *m) {
+    if (!m) return PADNE_OK;
+    hipSetDevice(m->device);
+    hipDeviceSynchronize();
+    if (m->rowptr) hipFree(m->rowptr);
+    if (m->cols) hipFree(m->cols);
+    if (m->vals) hipFree(m->vals);
+    if (m->dinv) hipFree(m->dinv);
+    delete m;
+    return PADNE_OK;
+}
+
+int padne_csr_shape(const padne_csr *m, int64_t *n_rows, int64_t *n_cols, int64_t *nnz) {
+    PADNE_REQUIRE(m, "matrix");
+    if (n_rows) *n_rows = m->n_rows;
+    if (n_cols) *n_cols = m->n_cols;
+    if (nnz) *nnz = m->nnz;
+    return PADNE_OK;
+}
+
+int padne_csr_to_host(padne_ctx *ctx, const padne_csr *m, int32_t *indptr, int32_t *indices, double *data) {
+    PADNE_REQUIRE(ctx && m && indptr, "null argument");
+    PADNE_REQUIRE(m->nnz == 0 || (indices && data), "null indices/data");
+    PADNE_HIP_CHECK(hipMemcpyAsync(indptr, m->rowptr, sizeof(int32_t) * (size_t)(m->n_rows + 1),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    if (m->nnz > 0) {
+        PADNE_HIP_CHECK(hipMemcpyAsync(indices, m->cols, sizeof(int32_t) * (size_t)m->nnz,
+                                       hipMemcpyDeviceToHost, ctx->stream));
+        PADNE_HIP_CHECK(hipMemcpyAsync(data, m->vals, sizeof(double) * (size_t)m->nnz, hipMemcpyDeviceToHost,
+                                       ctx->stream));
+    }
+    PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PADNE_OK;
+}
+
+int padne_spmv_dev(padne_ctx *ctx, const padne_csr *m, const void *x_dev, void *y_dev, int repeat) {
+    PADNE_REQUIRE(ctx && m && x_dev && y_dev, "null argument");
+    PADNE_REQUIRE(repeat >= 1, "repeat");
+    PADNE_HIP_CHECK(hipSetDevice(ctx->device));
+    for (int i = 0; i < repeat; ++i)
+        PADNE_TRY(launch_spmv(ctx, m, (const double *)x_dev, (double *)y_dev, nullptr, nullptr, nullptr));
+    PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PADNE_OK;
+}
+
+int padne_spmv(padne_ctx *ctx, const padne_csr *m, const double *x_host, double *y_host) {
+    PADNE_REQUIRE(ctx && m && x_host && y_host, "null argument");
+    PADNE_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t xb = sizeof(double) * (size_t)m->n_cols, yb = sizeof(double) * (size_t)m->n_rows;
+    PADNE_TRY(ensure_workspace(ctx, xb + yb + 512));
+    double *x = (double *)ctx->ws;
+    double *y = (double *)((char *)ctx->ws + ((xb + 255) & ~(size_t)255));
+    PADNE_HIP_CHECK(hipMemcpyAsync(x, x_host, xb, hipMemcpyHostToDevice, ctx->stream));
+    PADNE_TRY(launch_spmv(ctx, m, x, y, nullptr, nullptr, nullptr));
+    PADNE_HIP_CHECK(hipMemcpyAsync(y_host, y, yb, hipMemcpyDeviceToHost, ctx->stream));
+    PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PADNE_OK;
+}
+
+int padne_residual_norm(padne_ctx *ctx, const padne_csr *m, const double *x_host, const double *b_host,
+                        double *norm_out) {
+    PADNE_REQUIRE(ctx && m && x_host && b_host && norm_out, "null argument");
+    PADNE_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t xb = ((sizeof(double) * (size_t)m->n_cols) + 255) & ~(size_t)255;
+    const size_t yb = ((sizeof(double) * (size_t)m->n_rows) + 255) & ~(size_t)255;
+    PADNE_TRY(ensure_workspace(ctx, xb + 2 * yb + 512));
+    double *x = (double *)ctx->ws;
+    double *y = (double *)((char *)ctx->ws + xb);
+    double *b = (double *)((char *)ctx->ws + xb + yb);
+    PADNE_HIP_CHECK(hipMemcpyAsync(x, x_host, sizeof(double) * (size_t)m->n_cols, hipMemcpyHostToDevice, ctx->stream));
+    PADNE_HIP_CHECK(hipMemcpyAsync(b, b_host, sizeof(double) * (size_t)m->n_rows, hipMemcpyHostToDevice, ctx->stream));
+    PADNE_TRY(launch_spmv(ctx, m, x, y, nullptr, nullptr, nullptr));
+    long long g = (m->n_rows + 255) / 256;
+    if (g > 1024) g = 1024;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(dot_partial_kernel, dim3((unsigned)g), dim3(256), 0, ctx->stream, (long long)m->n_rows, y, b,
+                       ctx->partials + 7 * kMaxPartials);
+    PADNE_HIP_CHECK(hipGetLastError());
+    std::vector<double> h((size_t)g);
+    PADNE_HIP_CHECK(hipMemcpyAsync(h.data(), ctx->partials + 7 * kMaxPartials, sizeof(double) * (size_t)g,
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    double s = 0.0;
+    for (double v : h) s += v;
+    *norm_out = sqrt(s);
+    return PADNE_OK;
+}
+
+int64_t padne_spmv_algorithmic_bytes(const padne_csr *m) {
+    if (!m) return 0;
+    return 12 * m->nnz + 20 * m->n_rows + 4;
+}
+
+int padne_spmv_time(padne_ctx *ctx, const padne_csr *m, const void *x_dev, void *y_dev, int warmup, int repeat,
+                    double *seconds_per_launch) {
+    PADNE_REQUIRE(ctx && m && x_dev && y_dev && seconds_per_launch, "null argument");
+    PADNE_REQUIRE(repeat >= 1 && warmup >= 0, "repeat/warmup");
+    PADNE_HIP_CHECK(hipSetDevice(ctx->device));
+    for (int i = 0; i < warmup; ++i)
+        PADNE_TRY(launch_spmv(ctx, m, (const double *)x_dev, (double *)y_dev, nullptr, nullptr, nullptr));
+    PADNE_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
+    for (int i = 0; i < repeat; ++i)
+        PADNE_TRY(launch_spmv(ctx, m, (const double *)x_dev, (double *)y_dev, nullptr, nullptr, nullptr));
+    PADNE_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
+    PADNE_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    PADNE_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *seconds_per_launch = (double)ms * 1e-3 / repeat;
+    return PADNE_OK;
+}
+
+}  // extern "C"

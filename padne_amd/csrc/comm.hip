@@ -1,0 +1,119 @@
+// RCCL (collectives over xGMI) bound at run time with dlopen, so that the library loads on a
+// single-GPU box without RCCL being touched and shares the RCCL copy torch already loaded when
+// the process is a torch.distributed rank.  No reference counterpart (the reference is
+// single-process).
+#include "common.hpp"
+
+#include <dlfcn.h>
+#include <string.h>
+
+namespace padne {
+
+// minimal mirror of the parts of rccl.h we use (ABI-stable since NCCL 2.x)
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef void *ncclComm_t;
+enum { ncclSuccess = 0 };
+enum { ncclFloat64 = 8 };   // ncclDataType_t: double
+enum { ncclSum = 0 };
+
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+
+static Rccl g_rccl;
+
+static int load_rccl() {
+    if (g_rccl.lib) return PADNE_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void *h = nullptr;
+    for (const char *n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);   // prefer the copy the process already has (torch's)
+        if (h) break;
+    }
+    if (!h)
+        for (const char *n : names) {
+            h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+    if (!h) {
+        set_error("RCCL not found: %s", dlerror());
+        return PADNE_E_COMM;
+    }
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
+    g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.AllGather) {
+        set_error("RCCL library lacks required symbols");
+        return PADNE_E_COMM;
+    }
+    g_rccl.lib = h;
+    return PADNE_OK;
+}
+
+static int check_nccl(int rc, const char *what) {
+    if (rc == ncclSuccess) return PADNE_OK;
+    set_error("%s failed: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "rccl error");
+    return PADNE_E_COMM;
+}
+
+int comm_allreduce_sum_f64(padne_ctx *ctx, double *dev_buf, int count) {
+    if (ctx->world <= 1) return PADNE_OK;
+    return check_nccl(g_rccl.AllReduce(dev_buf, dev_buf, (size_t)count, ncclFloat64, ncclSum, (ncclComm_t)ctx->comm,
+                                       ctx->stream), "ncclAllReduce");
+}
+
+int comm_allgather_f64(padne_ctx *ctx, const double *send, double *recv, int count_per_rank) {
+    if (ctx->world <= 1) return PADNE_OK;
+    return check_nccl(g_rccl.AllGather(send, recv, (size_t)count_per_rank, ncclFloat64, (ncclComm_t)ctx->comm,
+                                       ctx->stream), "ncclAllGather");
+}
+
+void comm_destroy(padne_ctx *ctx) {
+    if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)ctx->comm);
+    ctx->comm = nullptr;
+}
+
+}  // namespace padne
+
+using namespace padne;
+
+extern "C" int padne_comm_unique_id(void *id128) {
+    PADNE_REQUIRE(id128, "id128");
+    PADNE_TRY(load_rccl());
+    ncclUniqueId id;
+    PADNE_TRY(check_nccl(g_rccl.GetUniqueId(&id), "ncclGetUniqueId"));
+    memcpy(id128, &id, sizeof(id));
+    return PADNE_OK;
+}
+
+extern "C" int padne_ctx_comm_init(padne_ctx *ctx, const void *id128, int rank, int world_size) {
+    PADNE_REQUIRE(ctx && id128, "null argument");
+    PADNE_REQUIRE(world_size >= 1 && rank >= 0 && rank < world_size, "rank/world_size");
+    PADNE_REQUIRE(ctx->comm == nullptr, "communicator already initialised");
+    PADNE_TRY(load_rccl());
+    PADNE_HIP_CHECK(hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclComm_t comm = nullptr;
+    PADNE_TRY(check_nccl(g_rccl.CommInitRank(&comm, world_size, id, rank), "ncclCommInitRank"));
+    ctx->comm = comm;
+    ctx->rank = rank;
+    ctx->world = world_size;
+    return PADNE_OK;
+}
+
+extern "C" int padne_ctx_comm_rank(padne_ctx *ctx, int *rank, int *world_size) {
+    PADNE_REQUIRE(ctx, "ctx");
+    if (rank) *rank = ctx->rank;
+    if (world_size) *world_size = ctx->world;
+    return PADNE_OK;
+}

@@ -1,0 +1,106 @@
+// Shared declarations for libpadne_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/padne_hip.h"
+
+namespace padne {
+
+void set_error(const char *fmt, ...);
+
+#define PADNE_HIP_CHECK(expr)                                                              \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            ::padne::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),      \
+                               __FILE__, __LINE__);                                        \
+            return PADNE_E_HIP;                                                            \
+        }                                                                                  \
+    } while (0)
+
+#define PADNE_REQUIRE(cond, msg)                                                           \
+    do {                                                                                   \
+        if (!(cond)) {                                                                     \
+            ::padne::set_error("invalid argument: %s (%s)", msg, #cond);                   \
+            return PADNE_E_INVALID;                                                        \
+        }                                                                                  \
+    } while (0)
+
+#define PADNE_TRY(expr)                                                                    \
+    do {                                                                                   \
+        int _rc = (expr);                                                                  \
+        if (_rc != PADNE_OK) return _rc;                                                   \
+    } while (0)
+
+constexpr int kWave = 64;            // gfx950 wavefront
+constexpr int kNumXcd = 8;           // MI355X: 8 XCDs, each with a private L2
+constexpr int kNumCu = 256;
+
+// SpMV tile geometry (see spmv.hip)
+constexpr int kSpmvThreads = 256;
+constexpr int kSpmvRows = 256;       // rows per tile (one per thread in the reduce phase)
+constexpr int kSpmvTileNnz = 2048;   // non-zeros staged in LDS per pass (16 KiB of f64)
+constexpr int kPadNnz = 4096;        // cols/vals allocations are padded by this many zero entries
+
+// number of partial sums every reduction kernel emits (one per workgroup)
+constexpr int kMaxPartials = 2048;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace padne
+
+struct padne_csr {
+    int64_t n_rows = 0, n_cols = 0, nnz = 0;
+    int32_t *rowptr = nullptr;   // [n_rows + 1]
+    int32_t *cols = nullptr;     // [nnz + pad]   padding entries are column 0
+    double *vals = nullptr;      // [nnz + pad]   padding entries are 0.0
+    double *dinv = nullptr;      // [n_rows] 1/diag, built on first use (square matrices)
+    int device = 0;
+};
+
+struct padne_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // reduction scratch
+    double *partials = nullptr;      // [8][kMaxPartials]
+    double *scalars = nullptr;       // device scalars used by the PCG loop
+    int32_t *status = nullptr;       // device status words
+    void *pinned = nullptr;          // small pinned host buffer for polling
+    // grow-on-demand workspace for PCG vectors
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    // RCCL
+    void *comm = nullptr;
+    int rank = 0, world = 1;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace padne {
+
+int ensure_workspace(padne_ctx *ctx, size_t bytes);
+int csr_alloc(padne_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, padne_csr **out);
+int csr_build_dinv(padne_ctx *ctx, padne_csr *m);
+
+// kernels launched from several translation units
+int launch_spmv(padne_ctx *ctx, const padne_csr *m, const double *x, double *y,
+                const double *dot_with /* may be null */, double *partials /* may be null */,
+                const int32_t *done_flag /* may be null */);
+int spmv_grid(const padne_csr *m);
+
+// exclusive scan of int32 counts into int32 offsets (n+1 outputs); returns total via host
+int exclusive_scan_i32(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t n, int64_t *total);
+
+// comm.cpp
+int comm_allreduce_sum_f64(padne_ctx *ctx, double *dev_buf, int count);
+int comm_allgather_f64(padne_ctx *ctx, const double *send, double *recv, int count_per_rank);
+void comm_destroy(padne_ctx *ctx);
+
+}  // namespace padne

@@ -1,0 +1,361 @@
+// Jacobi-preconditioned conjugate gradients on the device, replacing the direct solve
+// scipy.sparse.linalg.spsolve of the reference (solver.py:773) on the reduced SPD system.
+//
+// One iteration = three kernels, all HBM-streaming, no host synchronisation:
+//   K1  q = A p            + partial sums of p.q                (spmv.hip, 104*N bytes)
+//   K2  alpha = rz/pq ; x += alpha p ; r -= alpha q             (56*N bytes)
+//       + partial sums of r.(D^-1 r) and r.r
+//   K3  beta = rz'/rz ; p = D^-1 r + beta p                      (32*N bytes)
+//       + workgroup 0 does the bookkeeping: iteration count, convergence / breakdown flags.
+// z = D^-1 r is never stored.  Scalars never visit the host: every workgroup of the consuming
+// kernel re-adds the producer's per-workgroup partials (<= 2048 doubles, L2 resident) in a
+// fixed order, so results are bitwise reproducible run to run (no float atomics).
+// In multi-GPU runs a one-workgroup kernel folds the partials into a scalar which is then
+// summed over ranks by RCCL on the same stream; consumers then read a single "partial".
+//
+// The host enqueues `check_every` iterations at a time and then polls one status word; kernels
+// launched after convergence return immediately on the `done` flag.
+#include "common.hpp"
+
+#include <chrono>
+#include <math.h>
+#include <string.h>
+
+namespace padne {
+
+__device__ __forceinline__ double wave_sum_v(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// every thread of a 256-thread workgroup gets the sum of partials[0..P) (fixed order)
+__device__ __forceinline__ double block_total(const double *__restrict__ partials, int P, double *red) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < P; i += 256) s += partials[i];
+    s = wave_sum_v(s);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) red[w] = s;
+    __syncthreads();
+    const double t = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return t;
+}
+
+__device__ __forceinline__ void block_store_partial(double v, double *red, double *out) {
+    v = wave_sum_v(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+}
+
+struct PcgStatus {       // lives in device memory, mirrored to pinned host memory when polled
+    int32_t done;        // 1 = stop iterating
+    int32_t code;        // PADNE_OK / PADNE_E_BREAKDOWN
+    int32_t iters;       // iterations completed
+    int32_t pad;
+    double rr;           // recurrence ||r||^2 after the last completed iteration
+    double tol2;         // stop when rr <= tol2
+    double bb;           // ||b||^2
+};
+
+// r = b - ax (ax may be null: x0 = 0) ; p = dinv*r ; partial sums rz, rr, bb
+__global__ __launch_bounds__(256) void pcg_init_kernel(
+    const long long n, const double *__restrict__ b, const double *__restrict__ ax,
+    const double *__restrict__ dinv, double *__restrict__ r, double *__restrict__ p,
+    double *__restrict__ part_rz, double *__restrict__ part_rr, double *__restrict__ part_bb) {
+    __shared__ double red[4];
+    double rz = 0.0, rr = 0.0, bb = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const double bi = b[i];
+        const double ri = ax ? bi - ax[i] : bi;
+        const double zi = dinv[i] * ri;
+        r[i] = ri;
+        p[i] = zi;
+        rz += ri * zi;
+        rr += ri * ri;
+        bb += bi * bi;
+    }
+    block_store_partial(rz, red, part_rz + blockIdx.x);
+    block_store_partial(rr, red, part_rr + blockIdx.x);
+    block_store_partial(bb, red, part_bb + blockIdx.x);
+}
+
+// folds partials into scalars (used once after init, and per reduction in multi-GPU mode)
+__global__ __launch_bounds__(256) void fold_partials_kernel(const double *__restrict__ partials, int P,
+                                                            int stride, int count, double *__restrict__ out) {
+    __shared__ double red[4];
+    for (int c = 0; c < count; ++c) {
+        const double t = block_total(partials + (size_t)c * stride, P, red);
+        if (threadIdx.x == 0) out[c] = t;
+    }
+}
+
+__global__ void pcg_set_tolerance_kernel(PcgStatus *st, const double *__restrict__ scal_rr_bb, double rtol,
+                                         double atol, int use_existing_bb) {
+    // scal_rr_bb[0] = rr, [1] = bb
+    const double bb = use_existing_bb ? st->bb : scal_rr_bb[1];
+    const double rr = scal_rr_bb[0];
+    double tol = rtol * sqrt(bb);
+    if (atol > tol) tol = atol;
+    st->bb = bb;
+    st->tol2 = tol * tol;
+    st->rr = rr;
+    st->code = PADNE_OK;
+    st->done = (rr <= tol * tol) ? 1 : 0;
+    if (!(rr == rr)) {  // NaN in the input
+        st->done = 1;
+        st->code = PADNE_E_BREAKDOWN;
+    }
+}
+
+// K2
+__global__ __launch_bounds__(256) void pcg_update_xr_kernel(
+    const long long n, const double *__restrict__ part_rz, const int P_rz,
+    const double *__restrict__ part_pq, const int P_pq, const double *__restrict__ p,
+    const double *__restrict__ q, const double *__restrict__ dinv, double *__restrict__ x,
+    double *__restrict__ r, double *__restrict__ part_rz_new, double *__restrict__ part_rr,
+    PcgStatus *__restrict__ st) {
+    __shared__ double red[4];
+    if (st->done) return;
+    const double rz = block_total(part_rz, P_rz, red);
+    const double pq = block_total(part_pq, P_pq, red);
+    const double alpha = rz / pq;
+    double s_rz = 0.0, s_rr = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const double pi = p[i];
+        const double ri = r[i] - alpha * q[i];
+        x[i] += alpha * pi;
+        r[i] = ri;
+        const double zi = dinv[i] * ri;
+        s_rz += ri * zi;
+        s_rr += ri * ri;
+    }
+    block_store_partial(s_rz, red, part_rz_new + blockIdx.x);
+    block_store_partial(s_rr, red, part_rr + blockIdx.x);
+}
+
+// K3
+__global__ __launch_bounds__(256) void pcg_update_p_kernel(
+    const long long n, const double *__restrict__ part_rz_new, const double *__restrict__ part_rz_old,
+    const int P_rz, const double *__restrict__ part_rr, const int P_rr,
+    const double *__restrict__ part_pq, const int P_pq, const double *__restrict__ r,
+    const double *__restrict__ dinv, double *__restrict__ p, PcgStatus *__restrict__ st,
+    const int max_iter) {
+    __shared__ double red[4];
+    if (st->done) return;
+    const double rz_new = block_total(part_rz_new, P_rz, red);
+    const double rz_old = block_total(part_rz_old, P_rz, red);
+    const double beta = rz_new / rz_old;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        p[i] = dinv[i] * r[i] + beta * p[i];
+    }
+    if (blockIdx.x == 0) {
+        const double rr = block_total(part_rr, P_rr, red);
+        const double pq = block_total(part_pq, P_pq, red);
+        // all other workgroups have already passed (or will pass) their own `done` read with the
+        // value 0 only if they were dispatched before this store lands; either way x and r are
+        // complete (K2), and p is dead once `done` is set.
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int it = st->iters + 1;
+            st->iters = it;
+            st->rr = rr;
+            if (!(pq > 0.0) || !(rr == rr)) {
+                st->code = PADNE_E_BREAKDOWN;
+                st->done = 1;
+            } else if (rr <= st->tol2 || it >= max_iter) {
+                st->done = 1;
+            }
+        }
+    }
+}
+
+// r = b - ax ; partial rr   (true-residual check)
+__global__ __launch_bounds__(256) void residual_kernel(const long long n, const double *__restrict__ b,
+                                                       const double *__restrict__ ax, double *__restrict__ r,
+                                                       double *__restrict__ part_rr) {
+    __shared__ double red[4];
+    double rr = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const double ri = ax[i] - b[i];
+        if (r) r[i] = -ri;
+        rr += ri * ri;
+    }
+    block_store_partial(rr, red, part_rr + blockIdx.x);
+}
+
+static int vec_grid(long long n) {
+    long long g = (n + 255) / 256;
+    if (g > 1024) g = 1024;  // 4 workgroups per CU, grid-stride the rest
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// partial slots inside ctx->partials
+enum { SLOT_PQ = 0, SLOT_RZ0 = 1, SLOT_RZ1 = 2, SLOT_RR = 3, SLOT_BB = 4, SLOT_TMP = 5 };
+static inline double *slot(padne_ctx *ctx, int s) { return ctx->partials + (size_t)s * kMaxPartials; }
+
+static int solve_one(padne_ctx *ctx, const padne_csr *a, const double *b, double *x,
+                     const padne_solve_opts *o, padne_solve_info *info, bool x_is_guess) {
+    const long long n = a->n_rows;
+    PADNE_TRY(ensure_workspace(ctx, sizeof(double) * (size_t)n * 3 + 4096));
+    double *r = (double *)ctx->ws;
+    double *p = r + n;
+    double *q = p + n;
+    PcgStatus *st = (PcgStatus *)ctx->status;
+    PcgStatus *hst = (PcgStatus *)ctx->pinned;
+    hipStream_t s = ctx->stream;
+    const int gv = vec_grid(n);
+    const int gs = spmv_grid(a);
+    const int max_iter = o->max_iter > 0 ? o->max_iter : 100000;
+    int check_every = o->check_every > 0 ? o->check_every : 50;
+    double *scal = ctx->scalars;  // [0]=rr [1]=bb scratch
+
+    PADNE_HIP_CHECK(hipMemsetAsync(st, 0, sizeof(PcgStatus), s));
+    PADNE_HIP_CHECK(hipEventRecord(ctx->ev0, s));
+
+    int restarts = 0;
+    int total_iters = 0;
+    double true_rr = 0.0, bb = 0.0, tol2 = 0.0;
+    bool have_ax = false;
+    if (x_is_guess) {
+        PADNE_TRY(launch_spmv(ctx, a, x, q, nullptr, nullptr, nullptr));
+        have_ax = true;
+    } else {
+        PADNE_HIP_CHECK(hipMemsetAsync(x, 0, sizeof(double) * (size_t)n, s));
+    }
+    int code = PADNE_OK;
+    for (;;) {
+        // (re)start: r = b - A x, p = D^-1 r
+        hipLaunchKernelGGL(pcg_init_kernel, dim3(gv), dim3(256), 0, s, n, b, have_ax ? q : nullptr, a->dinv, r,
+                           p, slot(ctx, SLOT_RZ0), slot(ctx, SLOT_RR), slot(ctx, SLOT_BB));
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(256), 0, s, slot(ctx, SLOT_RR), gv,
+                           kMaxPartials, 2, scal);  // SLOT_RR and SLOT_BB are adjacent
+        hipLaunchKernelGGL(pcg_set_tolerance_kernel, dim3(1), dim3(1), 0, s, st, scal, o->rtol, o->atol,
+                           restarts > 0 ? 1 : 0);
+        PADNE_HIP_CHECK(hipGetLastError());
+        int parity = 0;
+        int P_rz = gv;  // the init kernel wrote gv partials; K2 writes gv as well
+        bool done = false;
+        while (!done) {
+            for (int k = 0; k < check_every; ++k) {
+                double *rz_old = slot(ctx, parity ? SLOT_RZ1 : SLOT_RZ0);
+                double *rz_new = slot(ctx, parity ? SLOT_RZ0 : SLOT_RZ1);
+                PADNE_TRY(launch_spmv(ctx, a, p, q, p, slot(ctx, SLOT_PQ), &st->done));
+                hipLaunchKernelGGL(pcg_update_xr_kernel, dim3(gv), dim3(256), 0, s, n, rz_old, P_rz,
+                                   slot(ctx, SLOT_PQ), gs, p, q, a->dinv, x, r, rz_new, slot(ctx, SLOT_RR), st);
+                hipLaunchKernelGGL(pcg_update_p_kernel, dim3(gv), dim3(256), 0, s, n, rz_new, rz_old, P_rz,
+                                   slot(ctx, SLOT_RR), gv, slot(ctx, SLOT_PQ), gs, r, a->dinv, p, st,
+                                   max_iter - total_iters);
+                parity ^= 1;
+            }
+            PADNE_HIP_CHECK(hipGetLastError());
+            PADNE_HIP_CHECK(hipMemcpyAsync(hst, st, sizeof(PcgStatus), hipMemcpyDeviceToHost, s));
+            PADNE_HIP_CHECK(hipStreamSynchronize(s));
+            done = hst->done != 0;
+        }
+        total_iters += hst->iters;
+        code = hst->code;
+        bb = hst->bb;
+        tol2 = hst->tol2;
+        // true residual
+        PADNE_TRY(launch_spmv(ctx, a, x, q, nullptr, nullptr, nullptr));
+        hipLaunchKernelGGL(residual_kernel, dim3(gv), dim3(256), 0, s, n, b, q, (double *)nullptr,
+                           slot(ctx, SLOT_TMP));
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(256), 0, s, slot(ctx, SLOT_TMP), gv,
+                           kMaxPartials, 1, scal + 2);
+        PADNE_HIP_CHECK(hipGetLastError());
+        PADNE_HIP_CHECK(hipMemcpyAsync(&hst[1], scal + 2, sizeof(double), hipMemcpyDeviceToHost, s));
+        PADNE_HIP_CHECK(hipStreamSynchronize(s));
+        memcpy(&true_rr, &hst[1], sizeof(double));
+        if (code != PADNE_OK) break;
+        if (true_rr <= tol2 * 1.0000001 || total_iters >= max_iter || restarts >= 8) break;
+        // the recurrence residual drifted from the true one: restart from the true residual
+        ++restarts;
+        have_ax = true;  // q = A x is current
+        PADNE_HIP_CHECK(hipMemsetAsync(st, 0, 2 * sizeof(int32_t), s));   // done = code = 0
+        PADNE_HIP_CHECK(hipMemsetAsync(&st->iters, 0, sizeof(int32_t), s));
+    }
+    PADNE_HIP_CHECK(hipEventRecord(ctx->ev1, s));
+    PADNE_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    PADNE_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    if (info) {
+        info->iterations += total_iters;
+        info->restarts += restarts;
+        const double rel = bb > 0 ? sqrt(true_rr / bb) : sqrt(true_rr);
+        if (rel > info->rel_residual) info->rel_residual = rel;
+        if (sqrt(true_rr) > info->abs_residual) info->abs_residual = sqrt(true_rr);
+        info->solve_seconds += ms * 1e-3;
+        if (code != PADNE_OK) info->status = code;
+        else if (true_rr > tol2 * 1.0000001 && info->status == PADNE_OK) info->status = PADNE_E_NOTCONVERGED;
+    }
+    return PADNE_OK;
+}
+
+}  // namespace padne
+
+using namespace padne;
+
+extern "C" int padne_solve_spd_dev(padne_ctx *ctx, const padne_csr *a, const void *b_dev, void *x_dev,
+                                   int32_t n_rhs, const padne_solve_opts *opts, padne_solve_info *info) {
+    PADNE_REQUIRE(ctx && a && b_dev && x_dev && opts, "null argument");
+    PADNE_REQUIRE(a->n_rows == a->n_cols || ctx->world > 1, "matrix must be square");
+    PADNE_REQUIRE(n_rhs >= 1, "n_rhs");
+    PADNE_REQUIRE(opts->precond == 0, "only Jacobi (0) is implemented");
+    PADNE_HIP_CHECK(hipSetDevice(ctx->device));
+    PADNE_TRY(csr_build_dinv(ctx, const_cast<padne_csr *>(a)));
+    padne_solve_info local;
+    memset(&local, 0, sizeof(local));
+    local.n_rhs = n_rhs;
+    const long long n = a->n_rows;
+    for (int k = 0; k < n_rhs; ++k) {
+        PADNE_TRY(solve_one(ctx, a, (const double *)b_dev + (size_t)k * n, (double *)x_dev + (size_t)k * n, opts,
+                            &local, (opts->flags & 1) != 0));
+    }
+    if (info) *info = local;
+    if (local.status == PADNE_E_BREAKDOWN) {
+        set_error("PCG breakdown: matrix is not symmetric positive definite or contains NaN");
+        return PADNE_E_BREAKDOWN;
+    }
+    if (local.status == PADNE_E_NOTCONVERGED) {
+        set_error("PCG did not reach the tolerance in %d iterations (rel. residual %.3e)", local.iterations,
+                  local.rel_residual);
+        return PADNE_E_NOTCONVERGED;
+    }
+    return PADNE_OK;
+}
+
+extern "C" int padne_solve_spd(padne_ctx *ctx, const padne_csr *a, const double *b_host, double *x_host,
+                               int32_t n_rhs, const padne_solve_opts *opts, padne_solve_info *info) {
+    PADNE_REQUIRE(ctx && a && b_host && x_host && opts, "null argument");
+    PADNE_REQUIRE(n_rhs >= 1, "n_rhs");
+    PADNE_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t bytes = sizeof(double) * (size_t)a->n_rows * (size_t)n_rhs;
+    double *b = nullptr, *x = nullptr;
+    PADNE_HIP_CHECK(hipMalloc((void **)&b, bytes ? bytes : 8));
+    if (hipMalloc((void **)&x, bytes ? bytes : 8) != hipSuccess) {
+        hipFree(b);
+        set_error("hipMalloc failed");
+        return PADNE_E_NOMEM;
+    }
+    int rc = PADNE_OK;
+    if (hipMemcpyAsync(b, b_host, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = PADNE_E_HIP;
+    if (rc == PADNE_OK && (opts->flags & 1) &&
+        hipMemcpyAsync(x, x_host, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        rc = PADNE_E_HIP;
+    if (rc == PADNE_OK) rc = padne_solve_spd_dev(ctx, a, b, x, n_rhs, opts, info);
+    if (rc == PADNE_OK || rc == PADNE_E_NOTCONVERGED) {
+        if (hipMemcpyAsync(x_host, x, bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            set_error("copy-back of the solution failed");
+            rc = PADNE_E_HIP;
+        }
+    }
+    hipFree(b);
+    hipFree(x);
+    return rc;
+}
