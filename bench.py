@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Headline benchmark: CG solves/s (and SpMV GB/s vs the HBM roofline) on the synthetic layered
+Laplacian of BASELINE.json, MI355X.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A *step* is one complete solve of the reduced SPD system (the work of the reference's
+``solve_system``, solver.py:767-780): Jacobi-PCG from x0 = 0 to ||b - A x|| <= 1e-12 ||b||,
+including the final true-residual check, with the matrix and the right-hand side already resident
+in HBM.  Workload at every GPU count: config C4 of SURVEY.md section 8d -- 8 copper layers of
+1118 x 1118 vertices (N = 10M unknowns, ~70M non-zeros) stitched by via rings; with N GPUs the
+layers are dealt to the ranks (strong scaling: the problem is fixed, ``scaling: "strong"``).
+
+One JSON line is printed by rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md:36
+RTOL = 1e-12
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="C4", help="C2 | C3 | C4 (default, the headline config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-nx", type=int, default=177,
+                    help="grid edge of the bounded CPU-baseline sample (8 layers of nx*nx)")
+    return ap.parse_args()
+
+
+def stamps_of(sysm, N):
+    """Lumped COO stamps + rhs of a SyntheticSystem, in the reference's stamp order (solver.py:475-492, 558-560)."""
+    a, b, r = sysm.resistors
+    g = 1.0 / r
+    rows = np.stack([a, a, b, b], 1).reshape(-1)
+    cols = np.stack([a, b, b, a], 1).reshape(-1)
+    vals = np.stack([-g, g, -g, g], 1).reshape(-1)
+    gi = sysm.ground
+    rows = np.concatenate([rows, [N - 1, gi]])
+    cols = np.concatenate([cols, [gi, N - 1]])
+    vals = np.concatenate([vals, [1.0, 1.0]])
+    rhs = np.zeros(N)
+    f, t, i = sysm.current_sources
+    np.add.at(rhs, f, i)
+    np.add.at(rhs, t, -i)
+    return rows, cols, vals, rhs
+
+
+def flat(sysm):
+    xy = np.concatenate([m[0] for m in sysm.meshes])
+    tri = np.concatenate([m[1] for m in sysm.meshes])
+    mvo = sysm.mesh_offsets
+    mto = np.concatenate([[0], np.cumsum([m[1].shape[0] for m in sysm.meshes])]).astype(np.int64)
+    sig = np.array([m[2] for m in sysm.meshes])
+    return xy, tri, mvo, mto, sig
+
+
+def cpu_baseline(nx: int):
+    """The reference's solve step (tocsc + spsolve + residual, solver.py:772-775) on a bounded sample
+    of the same workload, timed on this host."""
+    from oracle import padne_oracle as O
+    from padne_amd import synthetic
+    lattice = max(2, int(round(32 * nx / 1118)))
+    sysm = synthetic.layered_system(8, nx, nx, via_lattice=lattice)
+    els = [("R", int(a), int(b), float(r)) for a, b, r in zip(*sysm.resistors)]
+    els += [("I", int(f), int(t), float(i)) for f, t, i in zip(*sysm.current_sources)]
+    L, r = O.assemble_system([(m[0], m[1], m[2]) for m in sysm.meshes], 0, els, sysm.ground)
+    t0 = time.perf_counter()
+    v, gc, res = O.solve_system(L, r)
+    dt = time.perf_counter() - t0
+    n = L.shape[0]
+    # scipy CSR SpMV on the same matrix
+    x = np.random.default_rng(1).uniform(-1, 1, n)
+    best = min(_time(lambda: L @ x) for _ in range(5))
+    spmv_gbs = (12 * L.nnz + 20 * n + 4) / best / 1e9
+    n_full = 8 * 1118 * 1118
+    return {
+        "value": 1.0 / dt, "unit": "solves/s", "cores": 1, "kind": "port",
+        "sample": f"8-layer {nx}x{nx} via-stitched Laplacian, N={n} (1/{n_full // n} of the workload): "
+                  f"oracle assembly, then the reference's tocsc+spsolve+residual (solver.py:772-775), "
+                  f"{dt:.2f} s, residual {res:.1e}; SuperLU is single-threaded ({os.cpu_count()} cores available)",
+        "seconds": dt, "n": n, "cpu_spmv_gbs": spmv_gbs,
+        "extrapolated_full_size_seconds": dt * (n_full / n) ** 1.4,
+    }
+
+
+def _time(fn):
+    t0 = time.perf_counter()
+    fn()
+    return time.perf_counter() - t0
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    import torch  # plumbing only: rendezvous, barrier, max-over-ranks
+    import torch.distributed as dist
+    from padne_amd import _hip, synthetic
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    ctx = _hip.Context(local_rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.synchronize()
+
+    # ---- build the workload (untimed) -----------------------------------------------------------
+    sysm = synthetic.config(args.workload)
+    nv = sysm.n_vertices
+    N = nv + 1
+    t_setup0 = time.perf_counter()
+    if world == 1:
+        xy, tri, mvo, mto, sig = flat(sysm)
+        rows, cols, vals, rhs = stamps_of(sysm, N)
+        t0 = time.perf_counter()
+        L = ctx.assemble_system(N, xy, tri, mvo, mto, sig, rows, cols, vals)
+        ctx.synchronize()
+        t_assemble = time.perf_counter() - t0
+        imap = np.arange(N, dtype=np.int32)
+        imap[sysm.ground] = -1
+        imap[imap > sysm.ground] -= 1
+        imap[N - 1] = -1
+        t0 = time.perf_counter()
+        A = L.reduce(imap, nv - 1, -1.0)
+        ctx.synchronize()
+        t_reduce = time.perf_counter() - t0
+        L.close()
+        keep = np.flatnonzero(imap[:nv] >= 0)
+        b = ctx.to_device(-rhs[keep])
+        x = ctx.empty(A.shape[0])
+        solver = lambda time_spmv=False: A.solve_spd_dev(b, x, rtol=RTOL, time_spmv=time_spmv)  # noqa: E731
+        n_local, nnz_local = A.shape[0], A.nnz
+        spmv_bytes = A.spmv_bytes
+    else:
+        from padne_amd import distributed
+        plan = distributed.build_layer_partition(sysm, rank, world)
+        dsolver = distributed.DistributedSolver(ctx, plan, dist)
+        t_assemble, t_reduce = dsolver.t_assemble, dsolver.t_reduce
+        solver = lambda time_spmv=False: dsolver.solve(rtol=RTOL, time_spmv=time_spmv)  # noqa: E731
+        n_local, nnz_local = dsolver.n_owned, dsolver.nnz
+        spmv_bytes = dsolver.spmv_bytes
+    t_setup = time.perf_counter() - t_setup0
+
+    # ---- warmup + timed steps ---------------------------------------------------------------------
+    for _ in range(args.warmup):
+        solver()
+    barrier()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = solver()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # one more (untimed) solve with HIP events around every 16th SpMV launch, on the kernels' stream
+    prof = solver(time_spmv=True)
+    barrier()
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        t_spmv = prof.spmv_seconds
+        achieved = spmv_bytes / t_spmv / 1e9 if t_spmv > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "spmv_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "CG solves/s",
+            "value": args.steps / elapsed,
+            "unit": "solves/s",
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{sysm.name}: {len(sysm.meshes)}-layer jittered triangular Laplacian, "
+                                   f"{nv} nodes, via-ring stitched, 1 A source/sink, Jacobi-PCG to rtol {RTOL:g}",
+                       "n_unknowns": int(nv - 1), "nnz_per_rank": int(nnz_local), "rows_per_rank": int(n_local),
+                       "parallelism": f"layer-partitioned x{args.gpus}"},
+            "iterations": int(last.iterations), "restarts": int(last.restarts),
+            "rel_residual": float(last.rel_residual),
+            "us_per_iteration": last.seconds / max(last.iterations, 1) * 1e6,
+            "pcg_textbook_gbs": 232.0 * n_local * last.iterations / last.seconds / 1e9 if last.seconds > 0 else 0.0,
+            "setup_seconds": {"total": t_setup, "assemble": t_assemble, "reduce": t_reduce},
+            "roofline": {"bound": "hbm", "kernel": "csr_spmv_kernel<true> (q = A p with p.q epilogue)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "bytes_per_launch": int(spmv_bytes), "seconds_per_launch": t_spmv},
+        }
+        if args.gpus == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.cpu_sample_nx)
+            except Exception as exc:  # the GPU numbers stand on their own
+                out["cpu_baseline"] = {"error": repr(exc)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -59,6 +59,16 @@ void       *padne_ctx_stream(padne_ctx *ctx);
 int padne_comm_unique_id(void *id128);
 int padne_ctx_comm_init(padne_ctx *ctx, const void *id128, int rank, int world_size);
 int padne_ctx_comm_rank(padne_ctx *ctx, int *rank, int *world_size);
+/* Halo plan of a row-partitioned matrix (layer partition).  Every vector the
+ * local matrix multiplies is laid out [n_owned owned entries | world_size * m exchanged entries];
+ * before each product the rank copies its `n_export` values export_idx[k] (local indices) into its
+ * own segment and one ncclAllGather (m doubles per rank) fills the rest, so a column that refers to
+ * unknown export_idx[k] of rank r is column n_owned + r*m + k.  The local matrix therefore has
+ * n_owned + world_size*m columns and its first n_owned rows are the owned equations (further rows
+ * must be empty).  With a communicator set, all PCG dot products are summed over the ranks by
+ * ncclAllReduce on the context stream.  n_owned < 0 clears the plan. */
+int padne_ctx_set_halo(padne_ctx *ctx, int64_t n_owned, int32_t m, int32_t n_export,
+                       const int32_t *export_idx_host);
 
 /* ---- device memory helpers (thin, so that callers need no HIP binding of their own) -------- */
 int padne_dev_alloc(padne_ctx *ctx, int64_t bytes, void **dev_out);
@@ -120,7 +130,8 @@ typedef struct padne_solve_opts {
     int32_t max_iter;
     int32_t precond;     /* 0 = Jacobi                                                    */
     int32_t check_every; /* iterations enqueued between host convergence polls (0 = auto) */
-    int32_t flags;       /* bit0: x holds an initial guess (otherwise x0 = 0)             */
+    int32_t flags;       /* bit0: x holds an initial guess (otherwise x0 = 0)
+                            bit1: time every 16th SpMV launch with HIP events -> info.spmv_seconds */
 } padne_solve_opts;
 
 typedef struct padne_solve_info {
@@ -129,7 +140,7 @@ typedef struct padne_solve_info {
     double  rel_residual;    /* final TRUE ||b - A x|| / ||b||                    */
     double  abs_residual;
     double  solve_seconds;   /* device time of the iteration loop (HIP events)    */
-    double  spmv_seconds;    /* summed device time of the SpMV kernel, if timed   */
+    double  spmv_seconds;    /* average device time of one SpMV launch (flags bit1) */
     int32_t status;          /* PADNE_OK / PADNE_E_NOTCONVERGED / PADNE_E_BREAKDOWN */
     int32_t n_rhs;
 } padne_solve_info;
@@ -153,6 +164,14 @@ int padne_power_density(padne_ctx *ctx, int64_t n_vert, const double *xy_host,
                         int64_t n_mesh, const int64_t *mesh_vertex_offset,
                         const int64_t *mesh_tri_offset, const double *conductance,
                         const double *potential_host, double *power_out_host);
+
+/* per-face gradient of the linear interpolant of `potential` (compute_triangle_gradient,
+ * solver.py:689-725), faces visited as (v3, v1, v2) like Face.vertices (mesh.py:320-325) */
+int padne_face_gradient(padne_ctx *ctx, int64_t n_vert, const double *xy_host,
+                        int64_t n_tri, const int32_t *tri_host,
+                        int64_t n_mesh, const int64_t *mesh_vertex_offset,
+                        const int64_t *mesh_tri_offset, const double *potential_host,
+                        double *gx_out_host, double *gy_out_host);
 
 /* ---- introspection for benchmarks ---------------------------------------------------------- */
 /* algorithmic bytes of one CSR SpMV: 12*nnz + 20*n_rows + 4   */

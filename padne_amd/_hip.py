@@ -62,6 +62,7 @@ SIGNATURES = {
     "padne_comm_unique_id": (C.c_int, [_P]),
     "padne_ctx_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "padne_ctx_comm_rank": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "padne_ctx_set_halo": (C.c_int, [_P, _I64, C.c_int32, C.c_int32, _PI32]),
     "padne_dev_alloc": (C.c_int, [_P, _I64, C.POINTER(_P)]),
     "padne_dev_free": (C.c_int, [_P, _P]),
     "padne_dev_upload": (C.c_int, [_P, _P, _P, _I64]),
@@ -80,6 +81,7 @@ SIGNATURES = {
     "padne_solve_spd": (C.c_int, [_P, _P, _PF64, _PF64, C.c_int32, C.POINTER(SolveOpts), C.POINTER(SolveInfo)]),
     "padne_solve_spd_dev": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(SolveOpts), C.POINTER(SolveInfo)]),
     "padne_power_density": (C.c_int, [_P, _I64, _PF64, _I64, _PI32, _I64, _PI64, _PI64, _PF64, _PF64, _PF64]),
+    "padne_face_gradient": (C.c_int, [_P, _I64, _PF64, _I64, _PI32, _I64, _PI64, _PI64, _PF64, _PF64, _PF64]),
     "padne_spmv_algorithmic_bytes": (_I64, [_P]),
     "padne_spmv_time": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _PF64]),
 }
@@ -201,6 +203,13 @@ class Context:
         buf = C.create_string_buffer(bytes(unique_id), 128)
         _check(self._lib.padne_ctx_comm_init(self._h, buf, int(rank), int(world_size)))
 
+    def set_halo(self, n_owned: int, m: int, export_idx) -> None:
+        e = _i32(export_idx)
+        _check(self._lib.padne_ctx_set_halo(self._h, int(n_owned), int(m), int(e.shape[0]), _ptr(e, _PI32)))
+
+    def clear_halo(self) -> None:
+        _check(self._lib.padne_ctx_set_halo(self._h, -1, 0, 0, None))
+
     # -- raw device memory ------------------------------------------------------
     def alloc(self, nbytes: int) -> int:
         p = _P()
@@ -275,6 +284,18 @@ class Context:
         return out
 
 
+    def face_gradient(self, xy, tri, mesh_vertex_offset, mesh_tri_offset, potential):
+        xy = _f64(xy).reshape(-1, 2)
+        tri = _i32(tri).reshape(-1, 3)
+        mvo, mto, pot = _i64(mesh_vertex_offset), _i64(mesh_tri_offset), _f64(potential)
+        gx = np.zeros(tri.shape[0], dtype=np.float64)
+        gy = np.zeros(tri.shape[0], dtype=np.float64)
+        _check(self._lib.padne_face_gradient(self._h, xy.shape[0], _ptr(xy, _PF64), tri.shape[0], _ptr(tri, _PI32),
+                                             mvo.shape[0] - 1, _ptr(mvo, _PI64), _ptr(mto, _PI64), _ptr(pot, _PF64),
+                                             _ptr(gx, _PF64), _ptr(gy, _PF64)))
+        return gx, gy
+
+
 class DeviceArray:
     """A flat device allocation with numpy-like shape/dtype metadata."""
 
@@ -316,6 +337,7 @@ class SolveResult:
     abs_residual: float
     seconds: float
     status: int
+    spmv_seconds: float = 0.0
 
 
 class CsrMatrix:
@@ -387,8 +409,9 @@ class CsrMatrix:
         return out.value
 
     @staticmethod
-    def _opts(rtol, atol, max_iter, check_every, guess) -> SolveOpts:
-        return SolveOpts(float(rtol), float(atol), int(max_iter), 0, int(check_every), 1 if guess else 0)
+    def _opts(rtol, atol, max_iter, check_every, guess, time_spmv=False) -> SolveOpts:
+        return SolveOpts(float(rtol), float(atol), int(max_iter), 0, int(check_every),
+                         (1 if guess else 0) | (2 if time_spmv else 0))
 
     def solve_spd(self, b, *, rtol=1e-12, atol=0.0, max_iter=200000, check_every=0, x0=None,
                   raise_on_fail=True) -> SolveResult:
@@ -409,12 +432,12 @@ class CsrMatrix:
                            info.solve_seconds, info.status)
 
     def solve_spd_dev(self, b: DeviceArray, x: DeviceArray, *, n_rhs=1, rtol=1e-12, atol=0.0, max_iter=200000,
-                      check_every=0, guess=False, raise_on_fail=True) -> SolveResult:
-        opts = self._opts(rtol, atol, max_iter, check_every, guess)
+                      check_every=0, guess=False, raise_on_fail=True, time_spmv=False) -> SolveResult:
+        opts = self._opts(rtol, atol, max_iter, check_every, guess, time_spmv)
         info = SolveInfo()
         rc = self.ctx._lib.padne_solve_spd_dev(self.ctx._h, self._h, _P(b.ptr), _P(x.ptr), int(n_rhs),
                                                C.byref(opts), C.byref(info))
         if rc != OK and (raise_on_fail or rc != E_NOTCONVERGED):
             _check(rc)
         return SolveResult(None, info.iterations, info.restarts, info.rel_residual, info.abs_residual,
-                           info.solve_seconds, info.status)
+                           info.solve_seconds, info.status, info.spmv_seconds)

@@ -13,7 +13,7 @@ SOURCES = ["capi.hip", "spmv.hip", "pcg.hip", "assemble.hip", "comm.hip"]
 HEADERS = ["common.hpp", os.path.join("..", "..", "include", "padne_hip.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off",
-         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+         "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 
 def hipcc() -> str:

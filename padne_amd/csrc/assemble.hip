@@ -386,7 +386,8 @@ __device__ __forceinline__ double interp(double x1, double y1, double x2, double
 __global__ void power_density_kernel(long long n_tri, const int *__restrict__ tri, const double *__restrict__ xy,
                                      int n_mesh, const long long *__restrict__ mesh_voff,
                                      const long long *__restrict__ mesh_toff, const double *__restrict__ sigma,
-                                     const double *__restrict__ pot, double *__restrict__ out) {
+                                     const double *__restrict__ pot, double *__restrict__ out,
+                                     double *__restrict__ gx_out, double *__restrict__ gy_out) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tri) return;
     const int m = find_segment(mesh_toff, n_mesh, t);
@@ -398,9 +399,15 @@ __global__ void power_density_kernel(long long n_tri, const int *__restrict__ tr
     const double f1 = pot[g1], f2 = pot[g2], f3 = pot[g3];
     const double gx = interp(x1, y1, x2, y2, x3, y3, f1, f2, f3, x1 + 1, y1) - f1;
     const double gy = interp(x1, y1, x2, y2, x3, y3, f1, f2, f3, x1, y1 + 1) - f1;
-    const double s = sigma[m];
-    const double jx = gx * s, jy = gy * s;      // J = E * conductivity
-    out[t] = jx * gx + jy * gy;                 // J.dot(E)
+    if (gx_out) {
+        gx_out[t] = gx;
+        gy_out[t] = gy;
+    }
+    if (out) {
+        const double s = sigma[m];
+        const double jx = gx * s, jy = gy * s;      // J = E * conductivity
+        out[t] = jx * gx + jy * gy;                 // J.dot(E)
+    }
 }
 
 // ---- host orchestration ----------------------------------------------------------------------
@@ -603,15 +610,16 @@ extern "C" int padne_csr_reduce(padne_ctx *ctx, const padne_csr *m, const int32_
     return finish_rows<false>(ctx, sc, n_out, n_out, 0, 0, nullptr, nullptr, d_slot, d_key, d_val, d_err, out);
 }
 
-extern "C" int padne_power_density(padne_ctx *ctx, int64_t n_vert, const double *xy_host, int64_t n_tri,
-                                   const int32_t *tri_host, int64_t n_mesh, const int64_t *mesh_vertex_offset,
-                                   const int64_t *mesh_tri_offset, const double *conductance,
-                                   const double *potential_host, double *power_out_host) {
+static int face_fields(padne_ctx *ctx, int64_t n_vert, const double *xy_host, int64_t n_tri,
+                       const int32_t *tri_host, int64_t n_mesh, const int64_t *mesh_vertex_offset,
+                       const int64_t *mesh_tri_offset, const double *conductance, const double *potential_host,
+                       double *power_out_host, double *gx_out_host, double *gy_out_host) {
     PADNE_REQUIRE(ctx, "ctx");
     PADNE_REQUIRE(n_vert >= 0 && n_tri >= 0 && n_mesh >= 0, "negative size");
     if (n_tri == 0) return PADNE_OK;
-    PADNE_REQUIRE(xy_host && tri_host && mesh_vertex_offset && mesh_tri_offset && conductance && potential_host &&
-                      power_out_host && n_mesh > 0, "null argument");
+    PADNE_REQUIRE(xy_host && tri_host && mesh_vertex_offset && mesh_tri_offset && potential_host && n_mesh > 0,
+                  "null argument");
+    PADNE_REQUIRE(power_out_host == nullptr || conductance != nullptr, "conductance");
     PADNE_REQUIRE(mesh_vertex_offset[n_mesh] == n_vert && mesh_tri_offset[n_mesh] == n_tri, "offset tables");
     for (int64_t m = 0; m < n_mesh; ++m) {
         const int64_t nv = mesh_vertex_offset[m + 1] - mesh_vertex_offset[m];
@@ -622,7 +630,7 @@ extern "C" int padne_power_density(padne_ctx *ctx, int64_t n_vert, const double 
     PADNE_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     Scratch sc;
-    double *d_xy = nullptr, *d_sigma = nullptr, *d_pot = nullptr, *d_out = nullptr;
+    double *d_xy = nullptr, *d_sigma = nullptr, *d_pot = nullptr, *d_out = nullptr, *d_gx = nullptr, *d_gy = nullptr;
     int *d_tri = nullptr;
     long long *d_voff = nullptr, *d_toff = nullptr;
     PADNE_TRY(sc.alloc(&d_xy, (size_t)n_vert * 2));
@@ -631,17 +639,45 @@ extern "C" int padne_power_density(padne_ctx *ctx, int64_t n_vert, const double 
     PADNE_TRY(sc.alloc(&d_voff, (size_t)n_mesh + 1));
     PADNE_TRY(sc.alloc(&d_toff, (size_t)n_mesh + 1));
     PADNE_TRY(sc.alloc(&d_pot, (size_t)n_vert));
-    PADNE_TRY(sc.alloc(&d_out, (size_t)n_tri));
+    if (power_out_host) PADNE_TRY(sc.alloc(&d_out, (size_t)n_tri));
+    if (gx_out_host) {
+        PADNE_TRY(sc.alloc(&d_gx, (size_t)n_tri));
+        PADNE_TRY(sc.alloc(&d_gy, (size_t)n_tri));
+    }
     PADNE_HIP_CHECK(hipMemcpyAsync(d_xy, xy_host, sizeof(double) * 2 * (size_t)n_vert, hipMemcpyHostToDevice, s));
     PADNE_HIP_CHECK(hipMemcpyAsync(d_tri, tri_host, sizeof(int) * 3 * (size_t)n_tri, hipMemcpyHostToDevice, s));
-    PADNE_HIP_CHECK(hipMemcpyAsync(d_sigma, conductance, sizeof(double) * (size_t)n_mesh, hipMemcpyHostToDevice, s));
+    if (conductance)
+        PADNE_HIP_CHECK(hipMemcpyAsync(d_sigma, conductance, sizeof(double) * (size_t)n_mesh, hipMemcpyHostToDevice, s));
     PADNE_HIP_CHECK(hipMemcpyAsync(d_voff, mesh_vertex_offset, sizeof(long long) * (size_t)(n_mesh + 1), hipMemcpyHostToDevice, s));
     PADNE_HIP_CHECK(hipMemcpyAsync(d_toff, mesh_tri_offset, sizeof(long long) * (size_t)(n_mesh + 1), hipMemcpyHostToDevice, s));
     PADNE_HIP_CHECK(hipMemcpyAsync(d_pot, potential_host, sizeof(double) * (size_t)n_vert, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(power_density_kernel, dim3(nblk(n_tri)), dim3(256), 0, s, (long long)n_tri, d_tri, d_xy, (int)n_mesh,
-                       d_voff, d_toff, d_sigma, d_pot, d_out);
+                       d_voff, d_toff, d_sigma, d_pot, d_out, d_gx, d_gy);
     PADNE_HIP_CHECK(hipGetLastError());
-    PADNE_HIP_CHECK(hipMemcpyAsync(power_out_host, d_out, sizeof(double) * (size_t)n_tri, hipMemcpyDeviceToHost, s));
+    if (power_out_host)
+        PADNE_HIP_CHECK(hipMemcpyAsync(power_out_host, d_out, sizeof(double) * (size_t)n_tri, hipMemcpyDeviceToHost, s));
+    if (gx_out_host) {
+        PADNE_HIP_CHECK(hipMemcpyAsync(gx_out_host, d_gx, sizeof(double) * (size_t)n_tri, hipMemcpyDeviceToHost, s));
+        PADNE_HIP_CHECK(hipMemcpyAsync(gy_out_host, d_gy, sizeof(double) * (size_t)n_tri, hipMemcpyDeviceToHost, s));
+    }
     PADNE_HIP_CHECK(hipStreamSynchronize(s));
     return PADNE_OK;
+}
+
+extern "C" int padne_power_density(padne_ctx *ctx, int64_t n_vert, const double *xy_host, int64_t n_tri,
+                                   const int32_t *tri_host, int64_t n_mesh, const int64_t *mesh_vertex_offset,
+                                   const int64_t *mesh_tri_offset, const double *conductance,
+                                   const double *potential_host, double *power_out_host) {
+    PADNE_REQUIRE(n_tri == 0 || (power_out_host && conductance), "null argument");
+    return face_fields(ctx, n_vert, xy_host, n_tri, tri_host, n_mesh, mesh_vertex_offset, mesh_tri_offset,
+                       conductance, potential_host, power_out_host, nullptr, nullptr);
+}
+
+extern "C" int padne_face_gradient(padne_ctx *ctx, int64_t n_vert, const double *xy_host, int64_t n_tri,
+                                   const int32_t *tri_host, int64_t n_mesh, const int64_t *mesh_vertex_offset,
+                                   const int64_t *mesh_tri_offset, const double *potential_host,
+                                   double *gx_out_host, double *gy_out_host) {
+    PADNE_REQUIRE(n_tri == 0 || (gx_out_host && gy_out_host), "null argument");
+    return face_fields(ctx, n_vert, xy_host, n_tri, tri_host, n_mesh, mesh_vertex_offset, mesh_tri_offset,
+                       nullptr, potential_host, nullptr, gx_out_host, gy_out_host);
 }

@@ -126,6 +126,7 @@ int padne_ctx_destroy(padne_ctx *ctx) {
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     comm_destroy(ctx);
+    if (ctx->halo_export) hipFree(ctx->halo_export);
     if (ctx->ws) hipFree(ctx->ws);
     if (ctx->partials) hipFree(ctx->partials);
     if (ctx->scalars) hipFree(ctx->scalars);

@@ -66,13 +66,13 @@ static int check_nccl(int rc, const char *what) {
 }
 
 int comm_allreduce_sum_f64(padne_ctx *ctx, double *dev_buf, int count) {
-    if (ctx->world <= 1) return PADNE_OK;
+    if (ctx->comm == nullptr) return PADNE_OK;
     return check_nccl(g_rccl.AllReduce(dev_buf, dev_buf, (size_t)count, ncclFloat64, ncclSum, (ncclComm_t)ctx->comm,
                                        ctx->stream), "ncclAllReduce");
 }
 
 int comm_allgather_f64(padne_ctx *ctx, const double *send, double *recv, int count_per_rank) {
-    if (ctx->world <= 1) return PADNE_OK;
+    if (ctx->comm == nullptr || count_per_rank == 0) return PADNE_OK;
     return check_nccl(g_rccl.AllGather(send, recv, (size_t)count_per_rank, ncclFloat64, (ncclComm_t)ctx->comm,
                                        ctx->stream), "ncclAllGather");
 }

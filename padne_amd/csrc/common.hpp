@@ -80,6 +80,11 @@ struct padne_ctx {
     // RCCL
     void *comm = nullptr;
     int rank = 0, world = 1;
+    // halo plan of a row-partitioned matrix: vectors are [owned | world * halo_m exchanged values]
+    bool halo_on = false;
+    long long halo_n_owned = 0;
+    int halo_m = 0, halo_n_export = 0;
+    int32_t *halo_export = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 

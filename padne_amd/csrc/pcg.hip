@@ -17,9 +17,10 @@
 // launched after convergence return immediately on the `done` flag.
 #include "common.hpp"
 
-#include <chrono>
+#include <algorithm>
 #include <math.h>
 #include <string.h>
+#include <vector>
 
 namespace padne {
 
@@ -198,13 +199,48 @@ static int vec_grid(long long n) {
 enum { SLOT_PQ = 0, SLOT_RZ0 = 1, SLOT_RZ1 = 2, SLOT_RR = 3, SLOT_BB = 4, SLOT_TMP = 5 };
 static inline double *slot(padne_ctx *ctx, int s) { return ctx->partials + (size_t)s * kMaxPartials; }
 
+// gathers the owned values other ranks need into this rank's segment of the exchange buffer that
+// sits behind the owned entries:  v[n_owned + rank*M + k] = v[export_idx[k]]
+__global__ void halo_pack_kernel(double *__restrict__ v, const int *__restrict__ export_idx, int n_export,
+                                 long long dst_offset, const int *__restrict__ done_flag) {
+    if (done_flag != nullptr && *done_flag != 0) return;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_export) v[dst_offset + k] = v[export_idx[k]];
+}
+
+// scalar slots inside ctx->scalars used when the reductions go through RCCL
+enum { S_RR = 0, S_BB = 1, S_TRUE = 2, S_PQ = 8, S_RZRR0 = 10, S_RZRR1 = 12 };
+
+static int halo_exchange(padne_ctx *ctx, double *v, const int32_t *done_flag) {
+    if (!ctx->halo_on) return PADNE_OK;
+    double *seg = v + ctx->halo_n_owned + (long long)ctx->rank * ctx->halo_m;
+    if (ctx->halo_n_export > 0) {
+        hipLaunchKernelGGL(halo_pack_kernel, dim3((ctx->halo_n_export + 255) / 256), dim3(256), 0, ctx->stream, v,
+                           ctx->halo_export, ctx->halo_n_export,
+                           (long long)ctx->halo_n_owned + (long long)ctx->rank * ctx->halo_m, done_flag);
+        PADNE_HIP_CHECK(hipGetLastError());
+    }
+    return comm_allgather_f64(ctx, seg, v + ctx->halo_n_owned, ctx->halo_m);
+}
+
 static int solve_one(padne_ctx *ctx, const padne_csr *a, const double *b, double *x,
                      const padne_solve_opts *o, padne_solve_info *info, bool x_is_guess) {
-    const long long n = a->n_rows;
-    PADNE_TRY(ensure_workspace(ctx, sizeof(double) * (size_t)n * 3 + 4096));
+    const bool dist = ctx->comm != nullptr;          // reductions via RCCL (also with a 1-rank communicator)
+    const bool halo = ctx->halo_on;
+    const long long nr = a->n_rows;                   // matrix rows (owned rows + empty exchange rows)
+    const long long n = halo ? ctx->halo_n_owned : nr;   // owned unknowns = length of b, x, r
+    const long long nc = a->n_cols;                   // length of any vector the matrix multiplies
+    if (halo) {
+        PADNE_REQUIRE(nc == ctx->halo_n_owned + (long long)ctx->world * ctx->halo_m && nr <= nc,
+                      "matrix shape does not match the halo plan");
+    } else {
+        PADNE_REQUIRE(nr == nc, "matrix must be square");
+    }
+    PADNE_TRY(ensure_workspace(ctx, sizeof(double) * (size_t)(n + 2 * nc + nr) + 4096));
     double *r = (double *)ctx->ws;
-    double *p = r + n;
-    double *q = p + n;
+    double *p = r + n;          // [nc]
+    double *q = p + nc;         // [nr]
+    double *xe = q + nr;        // [nc]  extended copy of x for products A x (halo runs only)
     PcgStatus *st = (PcgStatus *)ctx->status;
     PcgStatus *hst = (PcgStatus *)ctx->pinned;
     hipStream_t s = ctx->stream;
@@ -212,17 +248,37 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const double *b, double
     const int gs = spmv_grid(a);
     const int max_iter = o->max_iter > 0 ? o->max_iter : 100000;
     int check_every = o->check_every > 0 ? o->check_every : 50;
-    double *scal = ctx->scalars;  // [0]=rr [1]=bb scratch
+    double *scal = ctx->scalars;
 
     PADNE_HIP_CHECK(hipMemsetAsync(st, 0, sizeof(PcgStatus), s));
+    if (halo) PADNE_HIP_CHECK(hipMemsetAsync(p + n, 0, sizeof(double) * (size_t)(nc - n), s));
     PADNE_HIP_CHECK(hipEventRecord(ctx->ev0, s));
+
+    // y = A x for an owned-length x
+    auto product_Ax = [&](double *out) -> int {
+        if (!halo) return launch_spmv(ctx, a, x, out, nullptr, nullptr, nullptr);
+        PADNE_HIP_CHECK(hipMemcpyAsync(xe, x, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+        PADNE_HIP_CHECK(hipMemsetAsync(xe + n, 0, sizeof(double) * (size_t)(nc - n), s));
+        PADNE_TRY(halo_exchange(ctx, xe, nullptr));
+        return launch_spmv(ctx, a, xe, out, nullptr, nullptr, nullptr);
+    };
+    // fold per-workgroup partials into scalars and sum them over the ranks
+    auto fold_allreduce = [&](const double *first_slot, int P, long long stride, int count, double *out) -> int {
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(256), 0, s, first_slot, P, (int)stride, count, out);
+        PADNE_HIP_CHECK(hipGetLastError());
+        return dist ? comm_allreduce_sum_f64(ctx, out, count) : PADNE_OK;
+    };
 
     int restarts = 0;
     int total_iters = 0;
+    // optional in-situ timing of the SpMV kernel: every 16th launch is bracketed by an event pair
+    const bool sample_spmv = (o->flags & 2) != 0;
+    std::vector<hipEvent_t> ev_a, ev_b;
+    long long launched = 0;
     double true_rr = 0.0, bb = 0.0, tol2 = 0.0;
     bool have_ax = false;
     if (x_is_guess) {
-        PADNE_TRY(launch_spmv(ctx, a, x, q, nullptr, nullptr, nullptr));
+        PADNE_TRY(product_Ax(q));
         have_ax = true;
     } else {
         PADNE_HIP_CHECK(hipMemsetAsync(x, 0, sizeof(double) * (size_t)n, s));
@@ -232,24 +288,47 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const double *b, double
         // (re)start: r = b - A x, p = D^-1 r
         hipLaunchKernelGGL(pcg_init_kernel, dim3(gv), dim3(256), 0, s, n, b, have_ax ? q : nullptr, a->dinv, r,
                            p, slot(ctx, SLOT_RZ0), slot(ctx, SLOT_RR), slot(ctx, SLOT_BB));
-        hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(256), 0, s, slot(ctx, SLOT_RR), gv,
-                           kMaxPartials, 2, scal);  // SLOT_RR and SLOT_BB are adjacent
-        hipLaunchKernelGGL(pcg_set_tolerance_kernel, dim3(1), dim3(1), 0, s, st, scal, o->rtol, o->atol,
+        PADNE_TRY(fold_allreduce(slot(ctx, SLOT_RR), gv, kMaxPartials, 2, scal + S_RR));  // RR, BB adjacent
+        if (dist) PADNE_TRY(fold_allreduce(slot(ctx, SLOT_RZ0), gv, kMaxPartials, 1, scal + S_RZRR0));
+        hipLaunchKernelGGL(pcg_set_tolerance_kernel, dim3(1), dim3(1), 0, s, st, scal + S_RR, o->rtol, o->atol,
                            restarts > 0 ? 1 : 0);
         PADNE_HIP_CHECK(hipGetLastError());
         int parity = 0;
-        int P_rz = gv;  // the init kernel wrote gv partials; K2 writes gv as well
         bool done = false;
         while (!done) {
             for (int k = 0; k < check_every; ++k) {
-                double *rz_old = slot(ctx, parity ? SLOT_RZ1 : SLOT_RZ0);
-                double *rz_new = slot(ctx, parity ? SLOT_RZ0 : SLOT_RZ1);
+                const int rz_old_slot = parity ? SLOT_RZ1 : SLOT_RZ0;
+                const int rz_new_slot = parity ? SLOT_RZ0 : SLOT_RZ1;
+                double *rz_old = slot(ctx, rz_old_slot);
+                double *rz_new = slot(ctx, rz_new_slot);
+                double *s_old = scal + (parity ? S_RZRR1 : S_RZRR0);   // {rz, rr} of the previous iteration
+                double *s_new = scal + (parity ? S_RZRR0 : S_RZRR1);
+                PADNE_TRY(halo_exchange(ctx, p, &st->done));
+                const bool sampled = sample_spmv && (launched++ % 16) == 8 && ev_a.size() < 512;
+                if (sampled) {
+                    hipEvent_t e0, e1;
+                    PADNE_HIP_CHECK(hipEventCreate(&e0));
+                    PADNE_HIP_CHECK(hipEventCreate(&e1));
+                    ev_a.push_back(e0);
+                    ev_b.push_back(e1);
+                    PADNE_HIP_CHECK(hipEventRecord(e0, s));
+                }
                 PADNE_TRY(launch_spmv(ctx, a, p, q, p, slot(ctx, SLOT_PQ), &st->done));
-                hipLaunchKernelGGL(pcg_update_xr_kernel, dim3(gv), dim3(256), 0, s, n, rz_old, P_rz,
-                                   slot(ctx, SLOT_PQ), gs, p, q, a->dinv, x, r, rz_new, slot(ctx, SLOT_RR), st);
-                hipLaunchKernelGGL(pcg_update_p_kernel, dim3(gv), dim3(256), 0, s, n, rz_new, rz_old, P_rz,
-                                   slot(ctx, SLOT_RR), gv, slot(ctx, SLOT_PQ), gs, r, a->dinv, p, st,
-                                   max_iter - total_iters);
+                if (sampled) PADNE_HIP_CHECK(hipEventRecord(ev_b.back(), s));
+                if (dist) {
+                    PADNE_TRY(fold_allreduce(slot(ctx, SLOT_PQ), gs, kMaxPartials, 1, scal + S_PQ));
+                    hipLaunchKernelGGL(pcg_update_xr_kernel, dim3(gv), dim3(256), 0, s, n, s_old, 1, scal + S_PQ, 1,
+                                       p, q, a->dinv, x, r, rz_new, slot(ctx, SLOT_RR), st);
+                    PADNE_TRY(fold_allreduce(rz_new, gv, (long long)(SLOT_RR - rz_new_slot) * kMaxPartials, 2, s_new));
+                    hipLaunchKernelGGL(pcg_update_p_kernel, dim3(gv), dim3(256), 0, s, n, s_new, s_old, 1, s_new + 1, 1,
+                                       scal + S_PQ, 1, r, a->dinv, p, st, max_iter - total_iters);
+                } else {
+                    hipLaunchKernelGGL(pcg_update_xr_kernel, dim3(gv), dim3(256), 0, s, n, rz_old, gv,
+                                       slot(ctx, SLOT_PQ), gs, p, q, a->dinv, x, r, rz_new, slot(ctx, SLOT_RR), st);
+                    hipLaunchKernelGGL(pcg_update_p_kernel, dim3(gv), dim3(256), 0, s, n, rz_new, rz_old, gv,
+                                       slot(ctx, SLOT_RR), gv, slot(ctx, SLOT_PQ), gs, r, a->dinv, p, st,
+                                       max_iter - total_iters);
+                }
                 parity ^= 1;
             }
             PADNE_HIP_CHECK(hipGetLastError());
@@ -262,13 +341,11 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const double *b, double
         bb = hst->bb;
         tol2 = hst->tol2;
         // true residual
-        PADNE_TRY(launch_spmv(ctx, a, x, q, nullptr, nullptr, nullptr));
+        PADNE_TRY(product_Ax(q));
         hipLaunchKernelGGL(residual_kernel, dim3(gv), dim3(256), 0, s, n, b, q, (double *)nullptr,
                            slot(ctx, SLOT_TMP));
-        hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(256), 0, s, slot(ctx, SLOT_TMP), gv,
-                           kMaxPartials, 1, scal + 2);
-        PADNE_HIP_CHECK(hipGetLastError());
-        PADNE_HIP_CHECK(hipMemcpyAsync(&hst[1], scal + 2, sizeof(double), hipMemcpyDeviceToHost, s));
+        PADNE_TRY(fold_allreduce(slot(ctx, SLOT_TMP), gv, kMaxPartials, 1, scal + S_TRUE));
+        PADNE_HIP_CHECK(hipMemcpyAsync(&hst[1], scal + S_TRUE, sizeof(double), hipMemcpyDeviceToHost, s));
         PADNE_HIP_CHECK(hipStreamSynchronize(s));
         memcpy(&true_rr, &hst[1], sizeof(double));
         if (code != PADNE_OK) break;
@@ -283,6 +360,29 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const double *b, double
     PADNE_HIP_CHECK(hipEventSynchronize(ctx->ev1));
     float ms = 0.f;
     PADNE_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    if (!ev_a.empty()) {
+        // launches enqueued after convergence are no-ops: keep the samples within 2x of the median
+        std::vector<double> t_s;
+        for (size_t i = 0; i < ev_a.size(); ++i) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, ev_a[i], ev_b[i]) == hipSuccess) t_s.push_back(t * 1e-3);
+            hipEventDestroy(ev_a[i]);
+            hipEventDestroy(ev_b[i]);
+        }
+        if (info && !t_s.empty()) {
+            std::vector<double> sorted = t_s;
+            std::sort(sorted.begin(), sorted.end());
+            const double med = sorted[sorted.size() / 2];
+            double sum = 0.0;
+            int cnt = 0;
+            for (double t : t_s)
+                if (t >= 0.5 * med && t <= 2.0 * med) {
+                    sum += t;
+                    ++cnt;
+                }
+            if (cnt > 0) info->spmv_seconds = sum / cnt;
+        }
+    }
     if (info) {
         info->iterations += total_iters;
         info->restarts += restarts;
@@ -300,10 +400,35 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const double *b, double
 
 using namespace padne;
 
+extern "C" int padne_ctx_set_halo(padne_ctx *ctx, int64_t n_owned, int32_t m, int32_t n_export,
+                                  const int32_t *export_idx_host) {
+    PADNE_REQUIRE(ctx, "ctx");
+    PADNE_HIP_CHECK(hipSetDevice(ctx->device));
+    PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->halo_export) {
+        PADNE_HIP_CHECK(hipFree(ctx->halo_export));
+        ctx->halo_export = nullptr;
+    }
+    ctx->halo_on = false;
+    if (n_owned < 0) return PADNE_OK;                 // negative n_owned clears the plan
+    PADNE_REQUIRE(m >= 0 && n_export >= 0 && n_export <= m, "halo sizes");
+    PADNE_REQUIRE(n_export == 0 || export_idx_host, "export list");
+    for (int k = 0; k < n_export; ++k)
+        PADNE_REQUIRE(export_idx_host[k] >= 0 && export_idx_host[k] < n_owned, "export index out of range");
+    PADNE_HIP_CHECK(hipMalloc((void **)&ctx->halo_export, sizeof(int32_t) * (size_t)(n_export > 0 ? n_export : 1)));
+    if (n_export > 0)
+        PADNE_HIP_CHECK(hipMemcpy(ctx->halo_export, export_idx_host, sizeof(int32_t) * (size_t)n_export,
+                                  hipMemcpyHostToDevice));
+    ctx->halo_n_owned = n_owned;
+    ctx->halo_m = m;
+    ctx->halo_n_export = n_export;
+    ctx->halo_on = true;
+    return PADNE_OK;
+}
+
 extern "C" int padne_solve_spd_dev(padne_ctx *ctx, const padne_csr *a, const void *b_dev, void *x_dev,
                                    int32_t n_rhs, const padne_solve_opts *opts, padne_solve_info *info) {
     PADNE_REQUIRE(ctx && a && b_dev && x_dev && opts, "null argument");
-    PADNE_REQUIRE(a->n_rows == a->n_cols || ctx->world > 1, "matrix must be square");
     PADNE_REQUIRE(n_rhs >= 1, "n_rhs");
     PADNE_REQUIRE(opts->precond == 0, "only Jacobi (0) is implemented");
     PADNE_HIP_CHECK(hipSetDevice(ctx->device));
@@ -311,7 +436,7 @@ extern "C" int padne_solve_spd_dev(padne_ctx *ctx, const padne_csr *a, const voi
     padne_solve_info local;
     memset(&local, 0, sizeof(local));
     local.n_rhs = n_rhs;
-    const long long n = a->n_rows;
+    const long long n = ctx->halo_on ? ctx->halo_n_owned : a->n_rows;
     for (int k = 0; k < n_rhs; ++k) {
         PADNE_TRY(solve_one(ctx, a, (const double *)b_dev + (size_t)k * n, (double *)x_dev + (size_t)k * n, opts,
                             &local, (opts->flags & 1) != 0));
@@ -334,7 +459,7 @@ extern "C" int padne_solve_spd(padne_ctx *ctx, const padne_csr *a, const double 
     PADNE_REQUIRE(ctx && a && b_host && x_host && opts, "null argument");
     PADNE_REQUIRE(n_rhs >= 1, "n_rhs");
     PADNE_HIP_CHECK(hipSetDevice(ctx->device));
-    const size_t bytes = sizeof(double) * (size_t)a->n_rows * (size_t)n_rhs;
+    const size_t bytes = sizeof(double) * (size_t)(ctx->halo_on ? ctx->halo_n_owned : a->n_rows) * (size_t)n_rhs;
     double *b = nullptr, *x = nullptr;
     PADNE_HIP_CHECK(hipMalloc((void **)&b, bytes ? bytes : 8));
     if (hipMalloc((void **)&x, bytes ? bytes : 8) != hipSuccess) {

@@ -1,0 +1,346 @@
+"""Array-native triangle meshes and the 0-/2-form value containers.
+
+The reference keeps a half-edge object graph (``padne/mesh.py:72-378``) and
+walks it in Python to build the Laplacian.  On the device nothing but the flat
+``points[n,2]`` / ``triangles[t,3]`` arrays is needed, so this module stores
+exactly those and offers just enough of the reference's object views
+(``mesh.vertices``, ``mesh.faces``, ``vertex.p.x``, ``vertex.i``,
+``ZeroForm[vertex]``) for the solver seam and its tests.
+
+What is kept identical to the reference:
+
+* ``Mesh.from_triangle_soup(points, triangles)`` signature and its
+  ``ValueError("Non-manifold mesh")`` (``mesh.py:302-378``, ``:342-343``);
+* the order in which a face lists its vertices, (v3, v1, v2)
+  (``mesh.py:320-325``) -- it fixes the rounding of the triangle gradient;
+* ``ZeroForm.values`` / ``TwoForm.values``: float64 arrays indexed by
+  ``vertex.i`` / ``face.i`` (``mesh.py:381-397, 575-599``), ``KeyError`` for
+  foreign vertices/faces.
+
+The mesher (CGAL, ``mesh.py:662-795``) is out of scope; ``Mesher.Config``
+exists only so that callers can pass the same configuration object through.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Iterable, Iterator, Optional, Sequence
+
+import numpy as np
+
+index_type = np.uint64
+
+
+@dataclass(frozen=True)
+class Vector:
+    dx: float
+    dy: float
+
+    def dot(self, other: "Vector") -> float:
+        return self.dx * other.dx + self.dy * other.dy
+
+    def __xor__(self, other: "Vector") -> float:
+        return self.dx * other.dy - self.dy * other.dx
+
+    def __add__(self, other: "Vector") -> "Vector":
+        if not isinstance(other, Vector):
+            raise TypeError("Addition is only defined for Vectors")
+        return Vector(self.dx + other.dx, self.dy + other.dy)
+
+    def __mul__(self, scalar: float) -> "Vector":
+        return Vector(self.dx * scalar, self.dy * scalar)
+
+    __rmul__ = __mul__
+
+    def __neg__(self) -> "Vector":
+        return Vector(-self.dx, -self.dy)
+
+    def __abs__(self) -> float:
+        return float(np.hypot(self.dx, self.dy))
+
+
+@dataclass(frozen=True)
+class Point:
+    x: float
+    y: float
+
+    def __sub__(self, other: "Point") -> Vector:
+        if not isinstance(other, Point):
+            raise TypeError("Subtraction is only defined for Points")
+        return Vector(self.x - other.x, self.y - other.y)
+
+    def distance(self, other: "Point") -> float:
+        return float(np.hypot(self.x - other.x, self.y - other.y))
+
+
+class Vertex:
+    """View of one mesh vertex: ``.p`` (Point) and ``.i`` (index in the mesh)."""
+    __slots__ = ("p", "i", "_mesh")
+
+    def __init__(self, p: Point, i: int = 0, mesh: Optional["Mesh"] = None):
+        self.p = p
+        self.i = index_type(i)
+        self._mesh = mesh
+
+    def __repr__(self):
+        return f"Vertex({self.p.x}, {self.p.y}; i={int(self.i)})"
+
+
+class Face:
+    """View of one triangle: ``.i`` and ``.vertices`` in the reference's visiting order."""
+    __slots__ = ("i", "_mesh", "is_boundary")
+
+    def __init__(self, i: int, mesh: "Mesh"):
+        self.i = index_type(i)
+        self._mesh = mesh
+        self.is_boundary = False
+
+    @property
+    def vertices(self) -> Iterator[Vertex]:
+        a, b, c = self._mesh.triangles[int(self.i)]
+        for k in (c, a, b):                      # (v3, v1, v2): mesh.py:320-325
+            yield self._mesh.vertices[int(k)]
+
+    @property
+    def area(self) -> float:
+        a, b, c = self._mesh.points[self._mesh.triangles[int(self.i)]]
+        return 0.5 * abs((b[0] - a[0]) * (c[1] - a[1]) - (b[1] - a[1]) * (c[0] - a[0]))
+
+    @property
+    def centroid(self) -> Point:
+        p = self._mesh.points[self._mesh.triangles[int(self.i)]].mean(axis=0)
+        return Point(float(p[0]), float(p[1]))
+
+
+class _View(Sequence):
+    """Lazy, cached sequence of Vertex/Face views over the arrays."""
+
+    def __init__(self, mesh: "Mesh", n: int, make):
+        self._mesh, self._n, self._make = mesh, n, make
+        self._cache: dict = {}
+
+    def __len__(self) -> int:
+        return self._n
+
+    def __getitem__(self, i):
+        i = int(i)
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        obj = self._cache.get(i)
+        if obj is None:
+            obj = self._cache[i] = self._make(i)
+        return obj
+
+    def __iter__(self):
+        return (self[i] for i in range(self._n))
+
+    def __contains__(self, obj) -> bool:
+        return getattr(obj, "_mesh", None) is self._mesh and 0 <= int(obj.i) < self._n \
+            and self._cache.get(int(obj.i)) is obj
+
+    def to_index(self, obj):
+        return obj.i
+
+    def to_object(self, idx):
+        return self[int(idx)]
+
+
+def _as_xy(points) -> np.ndarray:
+    if isinstance(points, np.ndarray):
+        return np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 2)
+    pts = list(points)
+    out = np.empty((len(pts), 2), dtype=np.float64)
+    for k, p in enumerate(pts):
+        if hasattr(p, "x"):
+            out[k, 0], out[k, 1] = p.x, p.y
+        else:
+            out[k, 0], out[k, 1] = p[0], p[1]
+    return out
+
+
+def check_manifold(n_vert: int, tri: np.ndarray) -> None:
+    """Index-level restatement of the reference's manifold test (``mesh.py:335-345``).
+
+    Raises ``ValueError("Non-manifold mesh")`` if a directed edge is used by two
+    triangles or a vertex is the origin of more than one boundary half-edge.
+    (The device assembly performs the same test on the fly; this host check only
+    runs for meshes built through :meth:`Mesh.from_triangle_soup`.)
+    """
+    if tri.size == 0:
+        return
+    t = tri.astype(np.int64)
+    u = t.reshape(-1)
+    v = t[:, [1, 2, 0]].reshape(-1)
+    key = u * n_vert + v
+    srt = np.sort(key)
+    if np.any(srt[1:] == srt[:-1]):
+        raise ValueError("Non-manifold mesh")
+    twinless = ~np.isin(v * n_vert + u, key)
+    if twinless.any() and np.bincount(v[twinless]).max() > 1:
+        raise ValueError("Non-manifold mesh")
+
+
+class Mesh:
+    """A triangulated copper island as two flat arrays."""
+
+    def __init__(self, points=None, triangles=None):
+        self.points = _as_xy(points if points is not None else np.zeros((0, 2)))
+        self.triangles = np.ascontiguousarray(
+            triangles if triangles is not None else np.zeros((0, 3)), dtype=np.int32).reshape(-1, 3)
+        self._vertices = None
+        self._faces = None
+
+    # -- construction ----------------------------------------------------------
+    @classmethod
+    def from_triangle_soup(cls, points, triangles, validate: bool = True) -> "Mesh":
+        tri = np.asarray(list(triangles) if not isinstance(triangles, np.ndarray) else triangles)
+        if tri.size and tri.shape[-1] != 3:
+            raise AssertionError("triangles must have 3 vertices")
+        m = cls(points, tri.reshape(-1, 3) if tri.size else np.zeros((0, 3), np.int32))
+        if m.triangles.size and (m.triangles.min() < 0 or m.triangles.max() >= len(m.points)):
+            raise IndexError("triangle refers to a vertex that does not exist")
+        if validate:
+            check_manifold(len(m.points), m.triangles)
+        return m
+
+    @classmethod
+    def from_reference(cls, ref_mesh) -> "Mesh":
+        """Extract the arrays from a reference ``padne.mesh.Mesh`` (duck-typed half-edge mesh).
+
+        ``face.vertices`` yields (v3, v1, v2); rotate back to (v1, v2, v3).
+        """
+        pts = np.array([[v.p.x, v.p.y] for v in ref_mesh.vertices], dtype=np.float64).reshape(-1, 2)
+        tri = []
+        for f in ref_mesh.faces:
+            c, a, b = [int(v.i) for v in f.vertices]
+            tri.append((a, b, c))
+        return cls(pts, np.array(tri, dtype=np.int32).reshape(-1, 3))
+
+    # -- views -------------------------------------------------------------------
+    @property
+    def vertices(self) -> _View:
+        if self._vertices is None:
+            self._vertices = _View(self, len(self.points),
+                                   lambda i: Vertex(Point(float(self.points[i, 0]), float(self.points[i, 1])), i, self))
+        return self._vertices
+
+    @property
+    def faces(self) -> _View:
+        if self._faces is None:
+            self._faces = _View(self, len(self.triangles), lambda i: Face(i, self))
+        return self._faces
+
+    def __getstate__(self):
+        return {"points": self.points, "triangles": self.triangles}
+
+    def __setstate__(self, state):
+        self.points, self.triangles = state["points"], state["triangles"]
+        self._vertices = self._faces = None
+
+    # -- topology numbers (index arithmetic only) --------------------------------
+    def edge_count(self) -> int:
+        t = self.triangles.astype(np.int64)
+        u, v = t.reshape(-1), t[:, [1, 2, 0]].reshape(-1)
+        n = max(len(self.points), 1)
+        return int(np.unique(np.minimum(u, v) * n + np.maximum(u, v)).size)
+
+    def euler_characteristic(self) -> int:
+        return len(self.points) - self.edge_count() + len(self.triangles)
+
+
+def _index_of(obj, n: int, owner_view: _View) -> int:
+    if obj not in owner_view:
+        raise KeyError
+    return int(obj.i)
+
+
+@dataclass
+class ZeroForm:
+    """Values on vertices (node potentials)."""
+    mesh: Mesh
+    values: np.ndarray = field(init=False, repr=False)
+
+    def __post_init__(self):
+        self.values = np.zeros(len(self.mesh.vertices), dtype=np.float64)
+
+    def __getitem__(self, vertex) -> float:
+        if vertex not in self.mesh.vertices:
+            raise KeyError("Vertex not in mesh")
+        return float(self.values[int(vertex.i)])
+
+    def __setitem__(self, vertex, value: float) -> None:
+        if vertex not in self.mesh.vertices:
+            raise KeyError("Vertex not in mesh")
+        self.values[int(vertex.i)] = value
+
+
+@dataclass
+class TwoForm:
+    """Values on faces (power density)."""
+    mesh: Mesh
+    values: np.ndarray = field(init=False, repr=False)
+
+    def __post_init__(self):
+        self.values = np.zeros(len(self.mesh.faces), dtype=np.float64)
+
+    def __getitem__(self, face) -> float:
+        if face not in self.mesh.faces:
+            raise KeyError("Face not in mesh")
+        return float(self.values[int(face.i)])
+
+    def __setitem__(self, face, value: float) -> None:
+        if face not in self.mesh.faces:
+            raise KeyError("Face not in mesh.faces (boundary faces not supported)")
+        self.values[int(face.i)] = value
+
+
+class MeshingException(RuntimeError):
+    """Mesh generation failed (kept for API compatibility, ``mesh.py:646-659``)."""
+
+
+class Mesher:
+    """Placeholder for the reference's CGAL mesher (out of scope).
+
+    ``Config`` carries the same fields and validation (``mesh.py:668-705``) so a caller can pass
+    its configuration through ``solve(prob, mesher_config)`` unchanged; ``poly_to_mesh`` must be
+    supplied by the integrator (padne's own ``Mesher``) or by a structured generator such as
+    :class:`padne_amd.structured.StructuredMesher`.
+    """
+
+    @dataclass(frozen=True)
+    class Config:
+        minimum_angle: float = 20.0
+        maximum_size: float = 0.6
+        variable_density_min_distance: float = 0.5
+        variable_density_max_distance: float = 3.0
+        variable_size_maximum_factor: float = 3.0
+        distance_map_quantization: float = 1.0
+
+        @property
+        def is_variable_density(self) -> bool:
+            return self.variable_size_maximum_factor != 1.0
+
+        def __post_init__(self):
+            if not 0 <= self.minimum_angle <= 60:
+                raise ValueError(f"minimum_angle must be between 0 and 60 degrees, got {self.minimum_angle}")
+            if self.maximum_size < 0:
+                raise ValueError(f"maximum_size must be non-negative, got {self.maximum_size}")
+            if self.variable_density_min_distance < 0:
+                raise ValueError("variable_density_min_distance must be non-negative, "
+                                 f"got {self.variable_density_min_distance}")
+            if self.variable_density_max_distance <= self.variable_density_min_distance:
+                raise ValueError(f"variable_density_max_distance ({self.variable_density_max_distance}) must be "
+                                 f"greater than variable_density_min_distance ({self.variable_density_min_distance})")
+            if self.variable_size_maximum_factor < 1.0:
+                raise ValueError(f"variable_size_maximum_factor must be >= 1.0, got {self.variable_size_maximum_factor}")
+            if self.distance_map_quantization <= 0:
+                raise ValueError(f"distance_map_quantization must be positive, got {self.distance_map_quantization}")
+
+    def __init__(self, config: Optional["Mesher.Config"] = None):
+        self.config = config if config is not None else Mesher.Config()
+
+    def poly_to_mesh(self, poly, seed_points: Iterable = ()) -> Mesh:
+        raise MeshingException(
+            "mesh generation (CGAL) is outside the accelerated path: pass a mesher with poly_to_mesh() "
+            "to solve(), or call solve_meshed() with ready meshes")

@@ -1,0 +1,294 @@
+"""Host-side index logic that turns the reference's KKT system into an SPD one and back.
+
+The matrix assembled by the reference (``solver.py:783-812``) is indefinite: every
+``VoltageSource`` / ``VoltageRegulator`` and the ground add a multiplier row/column
+(``solver.py:493-538, 544-560``), and a regulator's gain column makes it non-symmetric.
+CG cannot run on that.  Algebraically equivalent rewriting, with *no arithmetic on matrix
+entries on the host* (the matrix work -- ``P^T L P``, products ``L c`` -- runs on the device):
+
+1. constraint rows say ``v_p - v_n = U`` (and ``v_g = 0``): union-find with potentials merges
+   the tied nodes into groups, ``v_x = y_G + c_x``; the ground group is known outright.
+2. adding the KCL rows of a group cancels the multiplier currents (``+i`` in row p, ``-i`` in
+   row n), leaving ``A y = b`` with ``A = -P^T L_vv P`` (SPD: negated Dirichlet Laplacian) and
+   ``b = -P^T (r - L c)``.
+3. after the solve the multipliers (source currents, ground current) follow from the KCL
+   residual of the merged rows, peeled leaf by leaf along each group's tree of sources.
+4. a gain column ``gamma_k`` (regulator mirror, ``solver.py:537-538``) makes the right-hand side
+   depend on the unknown current ``i_k``: ``y = y0 + sum_k i_k z_k`` with ``A z_k = P^T gamma_k``
+   (one extra solve per regulator), closed by a k*k linear system for ``i``.
+
+Everything here is O(#constraints) bookkeeping plus a few O(N) numpy gathers.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+
+class SingularSystemError(ValueError):
+    """The constraint rows are contradictory or redundant (the reference's LU would be singular)."""
+
+
+@dataclass
+class Constraint:
+    """One multiplier unknown ``index``: row says v[p] - v[n] = value (n = -1: v[p] = value).
+
+    ``gamma``: extra entries of the multiplier's *column* beyond the +1/-1 at p/n, as
+    ``{row: coefficient}`` (regulator gain stamps).
+    """
+    index: int
+    p: int
+    n: int
+    value: float
+    gamma: dict = field(default_factory=dict)
+
+
+@dataclass
+class KKTLayout:
+    size: int                       # N
+    n_potential: int                # vertices + internal nodes (indices [0, n_potential))
+    constraints: list               # list[Constraint], includes the ground row (n = -1)
+
+    @property
+    def ground_constraint(self) -> Constraint:
+        for c in self.constraints:
+            if c.n < 0:
+                return c
+        raise SingularSystemError("system has no ground row")
+
+
+def infer_layout(L_csr, r: np.ndarray) -> KKTLayout:
+    """Recover the KKT structure from a matrix in the reference's layout.
+
+    Used when ``solve_system(L, r)`` is handed a bare scipy matrix (e.g. one produced by the
+    reference's own ``assemble_system``).  A multiplier unknown is recognised by a zero diagonal
+    together with a row of one or two +-1 entries; the reference numbers them after all
+    potentials (``solver.py:441-460, 757-760``).
+    """
+    N = L_csr.shape[0]
+    indptr, indices, data = L_csr.indptr, L_csr.indices, L_csr.data
+    diag = L_csr.diagonal()
+    cand = np.flatnonzero(diag == 0)
+    row_len = np.diff(indptr)
+    mult = []
+    for k in cand:
+        n = row_len[k]
+        if n == 0 or n > 2:
+            continue
+        vals = data[indptr[k]:indptr[k + 1]]
+        if np.all(np.abs(vals) == 1.0):
+            mult.append(int(k))
+    mult_set = set(mult)
+    if not mult:
+        raise SingularSystemError("no ground / multiplier rows found: not a padne system matrix")
+    n_pot = min(mult)
+    if sorted(mult) != list(range(n_pot, N)):
+        # multipliers must form the tail block
+        raise SingularSystemError("multiplier unknowns are not a trailing block")
+    csc = L_csr.tocsc()
+    cons = []
+    for k in mult:
+        cols = indices[indptr[k]:indptr[k + 1]]
+        vals = data[indptr[k]:indptr[k + 1]]
+        if len(cols) == 1:
+            if vals[0] != 1.0:
+                raise SingularSystemError("unexpected single-entry multiplier row")
+            p, n = int(cols[0]), -1
+        else:
+            pos = cols[vals > 0]
+            neg = cols[vals < 0]
+            if len(pos) != 1 or len(neg) != 1:
+                raise SingularSystemError("multiplier row is not of the form v_p - v_n")
+            p, n = int(pos[0]), int(neg[0])
+        gamma = {}
+        rws = csc.indices[csc.indptr[k]:csc.indptr[k + 1]]
+        cv = csc.data[csc.indptr[k]:csc.indptr[k + 1]]
+        for rr, vv in zip(rws, cv):
+            rr = int(rr)
+            if rr in mult_set:
+                raise SingularSystemError("multiplier-multiplier coupling is not supported")
+            base = (1.0 if rr == p else 0.0) - (1.0 if rr == n else 0.0)
+            if vv - base != 0.0:
+                gamma[rr] = float(vv - base)
+        cons.append(Constraint(index=k, p=p, n=n, value=float(r[k]), gamma=gamma))
+    return KKTLayout(size=N, n_potential=n_pot, constraints=cons)
+
+
+class _UnionFind:
+    """Union-find with potentials: pot[x] = v[x] - v[find(x)]."""
+
+    def __init__(self):
+        self.parent: dict = {}
+        self.pot: dict = {}
+
+    def find(self, x):
+        if x not in self.parent:
+            self.parent[x] = x
+            self.pot[x] = 0.0
+            return x
+        path = []
+        while self.parent[x] != x:
+            path.append(x)
+            x = self.parent[x]
+        root = x
+        # path compression, accumulating potentials from the root outwards
+        for node in reversed(path):
+            par = self.parent[node]
+            self.pot[node] = self.pot[node] + (self.pot[par] if par != root else 0.0)
+            self.parent[node] = root
+        return root
+
+    def offset(self, x) -> float:
+        self.find(x)
+        return self.pot[x]
+
+    def union(self, a, b, d) -> bool:
+        """Impose v[a] - v[b] = d.  Returns False if a and b were already tied."""
+        ra, rb = self.find(a), self.find(b)
+        if ra == rb:
+            return False
+        # attach ra under rb:  v[ra] - v[rb] = d + pot[b] - pot[a]
+        self.parent[ra] = rb
+        self.pot[ra] = d + self.pot[b] - self.pot[a]
+        return True
+
+
+@dataclass
+class Reduction:
+    layout: KKTLayout
+    index_map: np.ndarray          # int32[N]: reduced unknown of each potential, -1 = eliminated
+    n_free: int
+    c: np.ndarray                  # f64[N]: known part of v (offsets / Dirichlet values), 0 on multipliers
+    groups: list                   # list of (members list[int], constraint list[Constraint], root or None)
+    regulators: list               # constraints with a non-empty gamma
+
+    def expand(self, y: np.ndarray) -> np.ndarray:
+        """v (multipliers still zero) from the reduced solution."""
+        v = self.c.copy()
+        free = self.index_map >= 0
+        v[free] += y[self.index_map[free]]
+        return v
+
+    def rhs(self, r: np.ndarray, Lc: np.ndarray | None) -> np.ndarray:
+        """b = -P^T (r - L c) on the free groups."""
+        resid = r if Lc is None else r - Lc
+        free = self.index_map >= 0
+        return -np.bincount(self.index_map[free], weights=resid[free], minlength=self.n_free)
+
+    def project(self, vec_rows: dict) -> np.ndarray:
+        """P^T applied to a sparse row-indexed vector {row: value}."""
+        out = np.zeros(self.n_free)
+        for row, val in vec_rows.items():
+            t = self.index_map[row]
+            if t >= 0:
+                out[t] += val
+        return out
+
+    def multipliers(self, kcl_residual: np.ndarray, known: dict | None = None) -> dict:
+        """Multiplier currents from rho = r - L v (v with zero multipliers).
+
+        Row x of the original system reads  L_x.v + sum_s sigma_xs i_s + sum_k gamma_k[x] i_k = r_x,
+        so rho_x = sum_s sigma_xs i_s + sum_k gamma_k[x] i_k.  ``known`` fixes the regulator currents
+        that enter through gamma.  Peels each group's tree of constraints leaf by leaf.
+        """
+        rho = {}
+        out = {}
+        gam = {}
+        if known:
+            for cst in self.regulators:
+                ik = known.get(cst.index, 0.0)
+                for row, g in cst.gamma.items():
+                    gam[row] = gam.get(row, 0.0) + g * ik
+        for members, cons, root in self.groups:
+            if not cons:
+                continue
+            for x in members:
+                rho[x] = float(kcl_residual[x]) - gam.get(x, 0.0)
+            # adjacency of the constraint tree
+            inc = {x: [] for x in members}
+            ground_c = None
+            for cst in cons:
+                if cst.n < 0:
+                    ground_c = cst
+                    continue
+                inc[cst.p].append(cst)
+                inc[cst.n].append(cst)
+            done = set()
+            leaves = [x for x in members if len(inc[x]) == 1 and x != root]
+            while leaves:
+                x = leaves.pop()
+                live = [cst for cst in inc[x] if cst.index not in done]
+                if len(live) != 1:
+                    continue
+                cst = live[0]
+                sign = 1.0 if cst.p == x else -1.0
+                i_s = rho[x] / sign
+                out[cst.index] = i_s
+                done.add(cst.index)
+                other = cst.n if cst.p == x else cst.p
+                rho[other] -= (-sign) * i_s
+                rho[x] = 0.0
+                rem = [q for q in inc[other] if q.index not in done]
+                if len(rem) == 1 and other != root:
+                    leaves.append(other)
+            if ground_c is not None:
+                out[ground_c.index] = rho[ground_c.p]       # L[g, -1] = 1  (solver.py:559)
+        return out
+
+
+def build_reduction(layout: KKTLayout) -> Reduction:
+    N, n_pot = layout.size, layout.n_potential
+    uf = _UnionFind()
+    ground = layout.ground_constraint
+    tied = {}
+    for cst in layout.constraints:
+        if cst.n < 0:
+            uf.find(cst.p)
+            continue
+        if cst.p == cst.n:
+            raise SingularSystemError("voltage source with both terminals on one node")
+        if not uf.union(cst.p, cst.n, cst.value):
+            raise SingularSystemError("loop of voltage sources: the constraint rows are linearly dependent")
+    # collect groups among the nodes touched by constraints
+    members: dict = {}
+    for x in list(uf.parent.keys()):
+        members.setdefault(uf.find(x), []).append(x)
+    gcons: dict = {root: [] for root in members}
+    for cst in layout.constraints:
+        gcons[uf.find(cst.p)].append(cst)
+    ground_root = uf.find(ground.p)
+    v_ground_root = ground.value - uf.offset(ground.p)      # v[root] of the ground group
+    index_map = np.full(N, -1, dtype=np.int32)
+    c = np.zeros(N, dtype=np.float64)
+    # representative of a free group = its smallest member, so singletons keep their place
+    rep_of = {}
+    eliminated = np.zeros(N, dtype=bool)
+    eliminated[n_pot:] = True
+    for root, mem in members.items():
+        if root == ground_root:
+            for x in mem:
+                eliminated[x] = True
+                c[x] = v_ground_root + uf.offset(x)
+        else:
+            rep = min(mem)
+            rep_of[root] = rep
+            for x in mem:
+                c[x] = uf.offset(x) - uf.offset(rep)
+                if x != rep:
+                    eliminated[x] = True          # numbered through its representative below
+    keep = ~eliminated
+    index_map[keep] = np.arange(int(keep.sum()), dtype=np.int32)
+    for root, mem in members.items():
+        if root == ground_root:
+            continue
+        rep = rep_of[root]
+        for x in mem:
+            index_map[x] = index_map[rep]
+    n_free = int(keep.sum())
+    groups = []
+    for root, mem in members.items():
+        r_node = ground.p if root == ground_root else rep_of[root]
+        groups.append((sorted(mem), gcons[root], r_node))
+    regs = [cst for cst in layout.constraints if cst.gamma]
+    return Reduction(layout=layout, index_map=index_map, n_free=n_free, c=c, groups=groups, regulators=regs)

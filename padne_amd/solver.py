@@ -1,0 +1,615 @@
+"""MI355X drop-in for the hot path of ``padne/solver.py``.
+
+Same public names, argument meaning and error behaviour as the reference
+(``solver.py:24-52, 171-229, 350-615, 671-902``); the arithmetic runs in
+``libpadne_hip.so``:
+
+=====================================  ====================================================
+reference (file:line)                  here
+=====================================  ====================================================
+HalfEdge.cotan  mesh.py:124-139        ``asm_fill_tri`` kernel (per triangle, once)
+laplace_operator  solver.py:171-213    ``padne_assemble_system`` (sigma = 1, no stamps)
+process_mesh_laplace_operators :563    ``padne_assemble_system`` (all meshes in one launch)
+stamp_network_into_system :469-541     host emits COO stamps in element order; the device
+setup_ground_node :544-560             merges them after the mesh terms, in stamp order
+solve_system :767-780 (SuperLU)        reduction to SPD (reduction.py) + Jacobi-PCG kernels,
+                                       multipliers recovered from device residual products
+produce_layer_solutions :578-615       numpy slice per mesh (contiguous blocks) + power kernel
+compute_power_density :728-745         ``power_density_kernel``
+=====================================  ====================================================
+
+There is no CPU fallback: every entry point that computes raises
+``_hip.HipUnavailableError`` when the library or the GPU is missing.
+"""
+from __future__ import annotations
+
+import logging
+import warnings
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.spatial
+
+from . import _hip, mesh, problem
+from .reduction import (Constraint, KKTLayout, Reduction, SingularSystemError, build_reduction,
+                        infer_layout)
+
+log = logging.getLogger(__name__)
+
+DTYPE = np.float64
+
+# tolerance of the iterative solve: ||b - A y|| <= RTOL * ||b||   
+RTOL = 1e-12
+MAX_ITER = 200000
+
+_default_ctx: Optional[_hip.Context] = None
+
+
+def get_context() -> _hip.Context:
+    """Process-wide device context (GPU 0 unless ``set_context`` was called)."""
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = _hip.Context(0)
+    return _default_ctx
+
+
+def set_context(ctx: Optional[_hip.Context]) -> None:
+    global _default_ctx
+    _default_ctx = ctx
+
+
+class SolverWarning(Warning):
+    """Non-fatal oddity of the problem (e.g. non-zero ground current), ``solver.py:24-30``."""
+
+
+@dataclass(frozen=True)
+class SolverInfo:
+    ground_node_current: float   # ~0 for a well-posed problem
+    residual_norm: float         # ||L v - r||_2 on the ORIGINAL (un-reduced) system
+    # extras (not in the reference; default so positional construction stays compatible)
+    iterations: int = 0
+    rel_residual: float = 0.0
+    solve_seconds: float = 0.0
+
+
+@dataclass
+class LayerSolution:
+    meshes: list
+    potentials: list
+    power_densities: list = field(default_factory=list)
+    disconnected_meshes: list = field(default_factory=list)
+
+
+@dataclass
+class Solution:
+    problem: problem.Problem
+    layer_solutions: list
+    solver_info: SolverInfo
+
+
+# --------------------------------------------------------------------------------------------
+# index bookkeeping (host): VertexIndexer, NodeIndexer
+# --------------------------------------------------------------------------------------------
+
+
+class VertexIndexer:
+    """Global numbering: one contiguous block per mesh, in mesh order (``solver.py:216-229``).
+
+    The reference materialises a list and a dict with one entry per vertex; here the numbering
+    is the offset table, and the two containers are built lazily for code that indexes them.
+    """
+
+    def __init__(self, sizes: Sequence[int] = ()):
+        self.offsets = np.concatenate([[0], np.cumsum(np.asarray(list(sizes), dtype=np.int64))]).astype(np.int64)
+        self._g2v = None
+        self._v2g = None
+
+    @classmethod
+    def create(cls, meshes) -> "VertexIndexer":
+        return cls([len(m.vertices) for m in meshes])
+
+    def __len__(self) -> int:
+        return int(self.offsets[-1])
+
+    def global_index(self, mesh_idx: int, vertex_idx: int) -> int:
+        return int(self.offsets[mesh_idx] + vertex_idx)
+
+    @property
+    def global_index_to_vertex_index(self) -> list:
+        if self._g2v is None:
+            self._g2v = [(m, v) for m in range(len(self.offsets) - 1)
+                         for v in range(int(self.offsets[m + 1] - self.offsets[m]))]
+        return self._g2v
+
+    @property
+    def mesh_vertex_index_to_global_index(self) -> dict:
+        if self._v2g is None:
+            self._v2g = {mv: g for g, mv in enumerate(self.global_index_to_vertex_index)}
+        return self._v2g
+
+
+@dataclass
+class NodeIndexer:
+    node_to_global_index: dict = field(default_factory=dict)
+    extra_source_to_global_index: dict = field(default_factory=dict)
+    internal_node_count: int = 0
+
+    @classmethod
+    def create(cls, prob, meshes, mesh_index_to_layer_index, vindex: VertexIndexer,
+               filtered_networks) -> "NodeIndexer":
+        """``solver.py:398-466``: snap connections to the nearest vertex of their layer, then number
+        internal nodes and one current unknown per voltage source / regulator."""
+        trees = {}
+        gidx = {}
+        for layer_i in range(len(prob.layers)):
+            blocks, ids = [], []
+            for mesh_i, msh in enumerate(meshes):
+                if mesh_index_to_layer_index[mesh_i] != layer_i or len(msh.vertices) == 0:
+                    continue
+                blocks.append(msh.points)
+                ids.append(np.arange(len(msh.points), dtype=np.int64) + vindex.offsets[mesh_i])
+            if not blocks:
+                continue
+            trees[layer_i] = scipy.spatial.KDTree(np.concatenate(blocks), leafsize=32)
+            gidx[layer_i] = np.concatenate(ids)
+        node_to_global = {}
+        for network in filtered_networks:
+            for conn in network.connections:
+                layer_i = prob.layers.index(conn.layer)
+                _, k = trees[layer_i].query((conn.point.x, conn.point.y), k=1)
+                g = int(gidx[layer_i][k])
+                node = conn.node_id
+                if node in node_to_global and node_to_global[node] != g:
+                    raise ValueError("Duplicate connection vertices found, this should not happen.")
+                node_to_global[node] = g
+        i_at = len(vindex)
+        internal = 0
+        for network in filtered_networks:
+            for node in network.nodes:
+                if node not in node_to_global:
+                    node_to_global[node] = i_at
+                    i_at += 1
+                    internal += 1
+        extra = {}
+        for network in filtered_networks:
+            for elem in network.elements:
+                if elem.extra_variable_count > 1:
+                    raise NotImplementedError("Extra variable count > 1 not supported yet")
+                for _ in range(elem.extra_variable_count):
+                    extra[elem] = i_at
+                    i_at += 1
+        return cls(node_to_global_index=node_to_global, extra_source_to_global_index=extra,
+                   internal_node_count=internal)
+
+
+# --------------------------------------------------------------------------------------------
+# stamps: the host only *lists* them; the device adds them up
+# --------------------------------------------------------------------------------------------
+
+
+class StampList:
+    """Write-only stand-in for the reference's ``lil_matrix`` during stamping.
+
+    ``L[i, j] += v`` style updates (``solver.py:475-538, 558-560``) are recorded as COO triples in
+    the order they were issued; the device merge adds duplicates in that order.
+    """
+
+    def __init__(self, n: int):
+        self.shape = (n, n)
+        self.rows: list = []
+        self.cols: list = []
+        self.vals: list = []
+        self.constraints: list = []          # filled by stamp_network_into_system / setup_ground_node
+
+    def add(self, i: int, j: int, v: float) -> None:
+        n = self.shape[0]
+        if i < 0:
+            i += n
+        if j < 0:
+            j += n
+        self.rows.append(int(i))
+        self.cols.append(int(j))
+        self.vals.append(float(v))
+
+    def arrays(self):
+        return (np.asarray(self.rows, dtype=np.int64), np.asarray(self.cols, dtype=np.int64),
+                np.asarray(self.vals, dtype=np.float64))
+
+
+def _stamp(L, i, j, v):
+    if isinstance(L, StampList):
+        L.add(i, j, v)
+    else:                       # any matrix with item assignment (e.g. a scipy lil_matrix)
+        L[i, j] = L[i, j] + v
+
+
+def stamp_network_into_system(network, node_indexer: NodeIndexer, L, r: np.ndarray) -> None:
+    """MNA stamps of one network, same entries in the same order as ``solver.py:469-541``."""
+    idx = node_indexer.node_to_global_index
+    for element in network.elements:
+        if isinstance(element, problem.Resistor):
+            a, b = idx[element.a], idx[element.b]
+            g = 1 / element.resistance
+            _stamp(L, a, a, -g)
+            _stamp(L, a, b, g)
+            _stamp(L, b, b, -g)
+            _stamp(L, b, a, g)
+        elif isinstance(element, problem.CurrentSource):
+            r[idx[element.f]] += element.current
+            r[idx[element.t]] += -element.current
+        elif isinstance(element, problem.VoltageSource):
+            p, n = idx[element.p], idx[element.n]
+            iv = node_indexer.extra_source_to_global_index[element]
+            _stamp(L, iv, p, 1.0)
+            _stamp(L, iv, n, -1.0)
+            r[iv] = element.voltage
+            _stamp(L, p, iv, 1.0)
+            _stamp(L, n, iv, -1.0)
+            if isinstance(L, StampList):
+                L.constraints.append(Constraint(index=iv, p=p, n=n, value=float(element.voltage)))
+        elif isinstance(element, problem.VoltageRegulator):
+            vp, vn = idx[element.v_p], idx[element.v_n]
+            sf, st = idx[element.s_f], idx[element.s_t]
+            iv = node_indexer.extra_source_to_global_index[element]
+            _stamp(L, iv, vp, 1.0)
+            _stamp(L, iv, vn, -1.0)
+            _stamp(L, vp, iv, 1.0)
+            _stamp(L, vn, iv, -1.0)
+            r[iv] += element.voltage
+            _stamp(L, sf, iv, element.gain)
+            _stamp(L, st, iv, -element.gain)
+            if isinstance(L, StampList):
+                gamma: dict = {}
+                gamma[sf] = gamma.get(sf, 0.0) + element.gain
+                gamma[st] = gamma.get(st, 0.0) - element.gain
+                L.constraints.append(Constraint(index=iv, p=vp, n=vn, value=float(element.voltage),
+                                                gamma={k: v for k, v in gamma.items() if v != 0.0}))
+        else:
+            raise NotImplementedError(f"Unsupported node type {element}")
+
+
+def setup_ground_node(i_gnd: int, L, r: np.ndarray) -> None:
+    """``solver.py:544-560``: last row/column = ground-current unknown."""
+    _stamp(L, -1, i_gnd, 1.0)
+    _stamp(L, i_gnd, -1, 1.0)
+    r[-1] = 0
+    if isinstance(L, StampList):
+        L.constraints.append(Constraint(index=L.shape[0] - 1, p=int(i_gnd), n=-1, value=0.0))
+
+
+def find_best_ground_node_index(prob, node_indexer: NodeIndexer) -> int:
+    """``solver.py:671-686``: the ``n`` terminal of the highest-voltage source, else unknown 0."""
+    best, ground = float("-inf"), 0
+    for network in prob.networks:
+        for element in network.elements:
+            if isinstance(element, problem.VoltageSource) and element.voltage > best:
+                best = element.voltage
+                ground = node_indexer.node_to_global_index[element.n]
+    return ground
+
+
+def allocate_system(vindex: VertexIndexer, node_indexer: NodeIndexer):
+    """``solver.py:748-764``: N = vertices + internal nodes + extra currents + 1 (ground)."""
+    N = len(vindex) + node_indexer.internal_node_count + len(node_indexer.extra_source_to_global_index) + 1
+    log.info(f"System matrix size: {N}x{N} variables")
+    return StampList(N), np.zeros(N, dtype=DTYPE)
+
+
+# --------------------------------------------------------------------------------------------
+# device-resident system matrix
+# --------------------------------------------------------------------------------------------
+
+
+class SystemMatrix:
+    """The assembled ``L`` (reference layout and sign), resident on the GPU.
+
+    Quacks enough like the ``lil_matrix`` the reference returns from ``assemble_system`` for the
+    callers on the seam: ``shape``, ``tocsr()/tocsc()/tolil()/toarray()/todense()``, ``L[i, j]``,
+    ``L @ v``.  Carries the KKT layout so that ``solve_system`` does not have to re-derive it.
+    """
+
+    def __init__(self, dev: _hip.CsrMatrix, layout: Optional[KKTLayout]):
+        self.dev = dev
+        self.layout = layout
+        self.shape = dev.shape
+        self._host = None
+
+    @property
+    def nnz(self) -> int:
+        return self.dev.nnz
+
+    def tocsr(self):
+        if self._host is None:
+            self._host = self.dev.to_scipy()
+        return self._host
+
+    def tocsc(self):
+        return self.tocsr().tocsc()
+
+    def tolil(self):
+        return self.tocsr().tolil()
+
+    def tocoo(self):
+        return self.tocsr().tocoo()
+
+    def toarray(self):
+        return self.tocsr().toarray()
+
+    def todense(self):
+        return self.tocsr().todense()
+
+    def __getitem__(self, key):
+        return self.tocsr()[key]
+
+    def __matmul__(self, v):
+        return self.dev.matvec(np.asarray(v, dtype=DTYPE))
+
+
+def _flatten_meshes(meshes, conductances):
+    xy = np.concatenate([m.points for m in meshes]) if meshes else np.zeros((0, 2))
+    tri = np.concatenate([m.triangles for m in meshes]) if meshes else np.zeros((0, 3), np.int32)
+    mvo = np.concatenate([[0], np.cumsum([len(m.points) for m in meshes])]).astype(np.int64)
+    mto = np.concatenate([[0], np.cumsum([len(m.triangles) for m in meshes])]).astype(np.int64)
+    return xy, tri, mvo, mto, np.asarray(conductances, dtype=np.float64)
+
+
+def laplace_operator(msh: mesh.Mesh) -> sp.coo_matrix:
+    """Mesh-local cotangent Laplacian (``solver.py:171-213``), computed on the device."""
+    ctx = get_context()
+    n = len(msh.vertices)
+    xy, tri, mvo, mto, sig = _flatten_meshes([msh], [1.0])
+    empty = np.zeros(0, dtype=np.int64)
+    dev = ctx.assemble_system(n, xy, tri, mvo, mto, sig, empty, empty, np.zeros(0))
+    out = dev.to_scipy().tocoo()
+    dev.close()
+    return out
+
+
+def process_mesh_laplace_operators(meshes, conductances, vindex: VertexIndexer, L) -> None:
+    """``solver.py:563-575``.  With a StampList the mesh terms are not listed at all: the device
+    assembles them straight from the triangles (see ``assemble_system``); this function exists for
+    callers that stamp into a host matrix."""
+    if isinstance(L, StampList):
+        L.meshes = (list(meshes), list(conductances))
+        return
+    for mesh_i, (msh, conductance) in enumerate(zip(meshes, conductances)):
+        L_msh = (conductance * laplace_operator(msh)).tocoo()
+        off = int(vindex.offsets[mesh_i])
+        for i, j, v in zip(L_msh.row, L_msh.col, L_msh.data):
+            L[off + i, off + j] += v
+
+
+def assemble_system(prob, meshes, mesh_index_to_layer_index, vindex: VertexIndexer, filtered_networks,
+                    node_indexer: NodeIndexer):
+    """``solver.py:783-812``: allocate, mesh Laplacians, network stamps, ground -> ``(L, r)``.
+
+    ``L`` is a :class:`SystemMatrix` on the device (convertible with ``.tocsr()`` / ``.tolil()``)."""
+    conductances = [prob.layers[mesh_index_to_layer_index[i]].conductance for i in range(len(meshes))]
+    stamps, r = allocate_system(vindex, node_indexer)
+    for network in filtered_networks:
+        stamp_network_into_system(network, node_indexer, stamps, r)
+    setup_ground_node(find_best_ground_node_index(prob, node_indexer), stamps, r)
+    L = assemble_from_arrays(meshes, conductances, stamps, n_potential=len(vindex) + node_indexer.internal_node_count)
+    return L, r
+
+
+def assemble_from_arrays(meshes, conductances, stamps: StampList, n_potential: int) -> SystemMatrix:
+    ctx = get_context()
+    xy, tri, mvo, mto, sig = _flatten_meshes(meshes, conductances)
+    rows, cols, vals = stamps.arrays()
+    dev = ctx.assemble_system(stamps.shape[0], xy, tri, mvo, mto, sig, rows, cols, vals)
+    layout = KKTLayout(size=stamps.shape[0], n_potential=n_potential, constraints=list(stamps.constraints))
+    return SystemMatrix(dev, layout)
+
+
+# --------------------------------------------------------------------------------------------
+# solve
+# --------------------------------------------------------------------------------------------
+
+
+def _solve_reduced(A: _hip.CsrMatrix, b: np.ndarray, rtol: float):
+    if A.shape[0] == 0:
+        return np.zeros(0), 0, 0.0, 0.0
+    if not np.any(b):
+        return np.zeros_like(b), 0, 0.0, 0.0
+    res = A.solve_spd(b, rtol=rtol, max_iter=MAX_ITER)
+    return res.x, res.iterations, res.rel_residual, res.seconds
+
+
+def solve_system(L, r: np.ndarray, *, rtol: float = RTOL):
+    """Solve ``L v = r`` and return ``(v, SolverInfo)`` like ``solver.py:767-780``.
+
+    ``L`` is a :class:`SystemMatrix` from :func:`assemble_system`, or any scipy sparse matrix in the
+    reference's layout (it is uploaded and its multiplier structure inferred).
+    """
+    ctx = get_context()
+    r = np.asarray(r, dtype=DTYPE)
+    if isinstance(L, SystemMatrix):
+        dev, layout = L.dev, L.layout
+        owned = False
+    else:
+        Lc = sp.csr_matrix(L)
+        Lc.sum_duplicates()
+        Lc.eliminate_zeros()
+        Lc.sort_indices()
+        dev, layout, owned = ctx.csr_from_scipy(Lc), None, True
+        layout = infer_layout(Lc, r)
+    if layout is None or not layout.constraints:
+        raise SingularSystemError("system has no ground constraint")
+    # multiplier rows take their right-hand side from r (solver.py:505, 530, 560)
+    for cst in layout.constraints:
+        cst.value = float(r[cst.index])
+    red: Reduction = build_reduction(layout)
+    N = layout.size
+    A = dev.reduce(red.index_map, red.n_free, -1.0)
+    try:
+        Lc_vec = dev.matvec(red.c) if np.any(red.c) else None
+        b0 = red.rhs(r, Lc_vec)
+        y0, iters, relres, secs = _solve_reduced(A, b0, rtol)
+        v = red.expand(y0)
+        mult_known = {}
+        if red.regulators:
+            # y = y0 + sum_k i_k z_k with A z_k = P^T gamma_k:  row x reads L_x.v + gamma_k[x] i_k = r_x, so
+            # summing a group's rows gives  -P^T L P y = -P^T (r - L c) + sum_k i_k P^T gamma_k
+            Z = []
+            for cst in red.regulators:
+                gk = red.project({row: val for row, val in cst.gamma.items()})
+                zk, it_k, rr_k, s_k = _solve_reduced(A, gk, rtol)
+                iters += it_k
+                secs += s_k
+                relres = max(relres, rr_k)
+                w = np.zeros(N)
+                free = red.index_map >= 0
+                w[free] = zk[red.index_map[free]]
+                Z.append(w)
+            K = len(red.regulators)
+            keys = [cst.index for cst in red.regulators]
+
+            def currents_for(i_vec):
+                vv = v + sum(i_vec[k] * Z[k] for k in range(K))
+                rho = r - dev.matvec(vv)
+                return red.multipliers(rho, dict(zip(keys, i_vec)))
+
+            base = currents_for(np.zeros(K))
+            F0 = np.array([base[k] for k in keys])
+            J = np.zeros((K, K))
+            for k in range(K):
+                e = np.zeros(K)
+                e[k] = 1.0
+                ck = currents_for(e)
+                J[:, k] = np.array([ck[q] for q in keys]) - F0
+            i_reg = np.linalg.solve(np.eye(K) - J, F0)
+            v = v + sum(i_reg[k] * Z[k] for k in range(K))
+            mult_known = dict(zip(keys, i_reg))
+        rho = r - dev.matvec(v)
+        for idx, val in red.multipliers(rho, mult_known).items():
+            v[idx] = val
+        residual_norm = dev.residual_norm(v, r)
+    finally:
+        A.close()
+        if owned:
+            dev.close()
+    info = SolverInfo(ground_node_current=float(v[-1]), residual_norm=float(residual_norm),
+                      iterations=int(iters), rel_residual=float(relres), solve_seconds=float(secs))
+    return v, info
+
+
+# --------------------------------------------------------------------------------------------
+# post-processing
+# --------------------------------------------------------------------------------------------
+
+
+def compute_triangle_gradient(vertices, values) -> mesh.Vector:
+    """Gradient of the linear interpolant on one triangle (``solver.py:689-725``), on the device."""
+    if len(vertices) != 3 or len(values) != 3:
+        raise ValueError("Vertices and values must be of length 3 for a triangle")
+    ctx = get_context()
+    # the kernel visits a face as (tri[2], tri[0], tri[1]); feed (v2, v3, v1) so it sees (v1, v2, v3)
+    v1, v2, v3 = vertices
+    xy = np.array([[v2.p.x, v2.p.y], [v3.p.x, v3.p.y], [v1.p.x, v1.p.y]], dtype=DTYPE)
+    pot = np.array([values[1], values[2], values[0]], dtype=DTYPE)
+    gx, gy = ctx_face_gradient(ctx, xy, np.array([[0, 1, 2]], np.int32), pot)
+    return mesh.Vector(float(gx[0]), float(gy[0]))
+
+
+def ctx_face_gradient(ctx, xy, tri, pot):
+    one = np.array([0, len(xy)], dtype=np.int64)
+    onet = np.array([0, len(tri)], dtype=np.int64)
+    return ctx.face_gradient(xy, tri, one, onet, pot)
+
+
+def compute_power_density(voltage: mesh.ZeroForm, conductivity: float) -> mesh.TwoForm:
+    """Per-face ``sigma |grad V|^2`` (``solver.py:728-745``)."""
+    ctx = get_context()
+    msh = voltage.mesh
+    out = mesh.TwoForm(msh)
+    if len(msh.triangles):
+        xy, tri, mvo, mto, sig = _flatten_meshes([msh], [conductivity])
+        out.values = ctx.power_density(xy, tri, mvo, mto, sig, voltage.values)
+    return out
+
+
+def produce_layer_solutions(layers, vindex: VertexIndexer, meshes, mesh_index_to_layer_index, v: np.ndarray,
+                            disconnected_meshes_by_layer) -> list:
+    """``solver.py:578-615``.  Each mesh's unknowns are one contiguous block of ``v``, so the scatter
+    is a slice; the power densities of all meshes come from one kernel launch."""
+    ctx = get_context()
+    sig = [layers[mesh_index_to_layer_index[i]].conductance for i in range(len(meshes))]
+    power_all = None
+    if meshes and sum(len(m.triangles) for m in meshes):
+        xy, tri, mvo, mto, sg = _flatten_meshes(meshes, sig)
+        power_all = ctx.power_density(xy, tri, mvo, mto, sg, v[:len(vindex)])
+    toff = np.concatenate([[0], np.cumsum([len(m.triangles) for m in meshes])]).astype(np.int64)
+    out = []
+    for layer_i, _layer in enumerate(layers):
+        sol = LayerSolution(meshes=[], potentials=[], power_densities=[],
+                            disconnected_meshes=disconnected_meshes_by_layer[layer_i])
+        for mesh_i, msh in enumerate(meshes):
+            if mesh_index_to_layer_index[mesh_i] != layer_i:
+                continue
+            zf = mesh.ZeroForm(msh)
+            zf.values = np.array(v[vindex.offsets[mesh_i]:vindex.offsets[mesh_i + 1]], dtype=DTYPE)
+            tf = mesh.TwoForm(msh)
+            if power_all is not None:
+                tf.values = np.array(power_all[toff[mesh_i]:toff[mesh_i + 1]], dtype=DTYPE)
+            sol.meshes.append(msh)
+            sol.potentials.append(zf)
+            sol.power_densities.append(tf)
+        out.append(sol)
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# orchestration
+# --------------------------------------------------------------------------------------------
+
+
+def solve_meshed(prob, meshes, mesh_index_to_layer_index, *, filtered_networks=None,
+                 disconnected_meshes_by_layer=None) -> Solution:
+    """Steps 4-11 of the reference's ``solve()`` (``solver.py:846-902``): everything after meshing."""
+    meshes = [m if isinstance(m, mesh.Mesh) else mesh.Mesh.from_reference(m) for m in meshes]
+    if filtered_networks is None:
+        filtered_networks = list(prob.networks)
+    if disconnected_meshes_by_layer is None:
+        disconnected_meshes_by_layer = [[] for _ in prob.layers]
+    log.info("Indexing vertices and connections")
+    vindex = VertexIndexer.create(meshes)
+    node_indexer = NodeIndexer.create(prob, meshes, mesh_index_to_layer_index, vindex, filtered_networks)
+    log.info("Assembling the global system")
+    L, r = assemble_system(prob, meshes, mesh_index_to_layer_index, vindex, filtered_networks, node_indexer)
+    log.info("Solving the system of equations")
+    v, solver_info = solve_system(L, r)
+    L.dev.close()
+    if not np.isclose(solver_info.ground_node_current, 0):
+        warnings.warn(
+            f"Ground node current is not zero ({solver_info.ground_node_current} A), this may indicate an issue "
+            "with the problem being solved. Check for unterminated current loops or floating connected "
+            "components. This may be harmless if the current is small, but it may indicate an "
+            "ill-conditioned system.", SolverWarning)
+    log.info("Producing the solution object")
+    layer_solutions = produce_layer_solutions(prob.layers, vindex, meshes, mesh_index_to_layer_index, v,
+                                              disconnected_meshes_by_layer)
+    return Solution(problem=prob, layer_solutions=layer_solutions, solver_info=solver_info)
+
+
+def solve(prob, mesher_config: Optional[mesh.Mesher.Config] = None, *, mesher=None) -> Solution:
+    """``padne.solver.solve`` (``solver.py:815-902``).
+
+    Meshing and the geometric connectivity pre-pass are out of scope (CGAL / shapely).  ``mesher``
+    must offer ``poly_to_mesh(polygon, seed_points) -> Mesh`` (padne's own ``mesh.Mesher`` does, and
+    so does :class:`padne_amd.structured.StructuredMesher` for rectangles and annuli); every
+    polygon of every layer is meshed and treated as connected.
+    """
+    if mesher is None:
+        mesher = mesh.Mesher(mesher_config)
+    meshes, mesh_index_to_layer_index = [], []
+    log.info("Meshing the connected components")
+    for layer_i, layer in enumerate(prob.layers):
+        seeds = [mesh.Point(c.point.x, c.point.y) for net in prob.networks for c in net.connections
+                 if c.layer is layer or c.layer == layer]
+        for geom in layer.geoms:
+            meshes.append(mesher.poly_to_mesh(geom, seeds))
+            mesh_index_to_layer_index.append(layer_i)
+    return solve_meshed(prob, meshes, mesh_index_to_layer_index)

@@ -1,0 +1,219 @@
+"""Generate the golden vectors under tests/golden/*.npz by running the REAL reference.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+For every case below the script builds the inputs as flat arrays, feeds them to the reference's
+own functions (loaded by oracle/ref_loader.py: Mesh.from_triangle_soup, laplace_operator,
+VertexIndexer, allocate_system, process_mesh_laplace_operators, stamp_network_into_system,
+setup_ground_node, solve_system, produce_layer_solutions / compute_power_density) and stores inputs
+and outputs side by side.  The fixtures are data only; no reference source travels.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_loader  # noqa: E402
+from padne_amd import synthetic  # noqa: E402  (pure index/geometry generators, no arithmetic of the path)
+
+KIND = {"R": 0, "I": 1, "V": 2, "REG": 3}
+
+
+# ---- case definitions (inputs only) -------------------------------------------------------------
+
+def case_unit_square():
+    pts = np.array([[0, 0], [1, 0], [1, 1], [0, 1], [0.5, 0.5]], float)          # test_solver.py:784-798
+    tri = np.array([[0, 1, 4], [1, 2, 4], [2, 3, 4], [3, 0, 4]], np.int32)
+    return dict(meshes=[(pts, tri, 1.0, 0)], n_internal=0,
+                elements=[("I", 0, 2, 1.0)], ground=4)
+
+
+def case_star():
+    pts = np.array([[-1, -1], [1, -1], [1, 1], [-1, 1], [-2, 0], [0, -2], [2, 0], [0, 2]], float)  # test_mesh.py:738-757
+    tri = np.array([[0, 1, 2], [0, 2, 3], [0, 3, 4], [1, 0, 5], [2, 1, 6], [3, 2, 7]], np.int32)
+    return dict(meshes=[(pts, tri, 2.5, 0)], n_internal=0,
+                elements=[("I", 4, 6, 0.5), ("R", 5, 7, 3.0)], ground=0)
+
+
+def case_square_with_hole():
+    pts = np.array([[0, 0], [4, 0], [4, 4], [0, 4], [1, 1], [3, 1], [3, 3], [1, 3]], float)       # test_mesh.py:774-800
+    tri = np.array([[0, 1, 4], [1, 5, 4], [1, 2, 5], [2, 6, 5], [2, 3, 6], [3, 7, 6], [3, 0, 7], [0, 4, 7]], np.int32)
+    return dict(meshes=[(pts, tri, 2082.5, 0)], n_internal=0,
+                elements=[("I", 0, 2, 1.0)], ground=1)
+
+
+def case_obtuse():
+    # obtuse corners: exercises the abs() in HalfEdge.cotan (mesh.py:138)
+    pts = np.array([[0, 0], [4, 0], [2, 0.4], [2, 3], [2, -2]], float)
+    tri = np.array([[0, 1, 2], [1, 3, 2], [3, 0, 2], [0, 4, 1]], np.int32)
+    return dict(meshes=[(pts, tri, 3.0, 0)], n_internal=0,
+                elements=[("I", 3, 4, 2.0)], ground=0)
+
+
+def case_strip20():
+    xy, tri = synthetic.jittered_grid(20, 20, 0.6, seed=7)
+    return dict(meshes=[(xy, tri, 2082.5, 0)], n_internal=0,
+                elements=[("I", 21, 378, 1.0)], ground=0)
+
+
+def case_two_layer_via():
+    xy0, tri0 = synthetic.jittered_grid(14, 9, 0.6, seed=1)
+    xy1, tri1 = synthetic.jittered_grid(14, 9, 0.6, seed=2)
+    n0 = len(xy0)
+    rv = synthetic.via_ring_resistance(0.5)
+    ring = [14 * 4 + 6, 14 * 4 + 7, 14 * 5 + 6, 14 * 5 + 7]
+    els = []
+    for k in range(16):                                     # 16 ring resistors snap onto 4 vertices
+        a = ring[k % 4]
+        els.append(("R", a, n0 + a, rv))
+    els.append(("I", 15, n0 + 14 * 7 + 12, 1.0))
+    return dict(meshes=[(xy0, tri0, 2082.5, 0), (xy1, tri1, 1041.25, 1)], n_internal=0, elements=els, ground=0)
+
+
+def case_voltage_source():
+    xy, tri = synthetic.jittered_grid(12, 5, 0.6, seed=3)
+    n = len(xy)
+    # 1 V source between the two ends (multiplier unknown n), a load resistor through an internal node
+    els = [("V", 12 * 2 + 11, 12 * 2 + 0, 1.0, n + 1), ("R", 12 * 2 + 5, n, 0.1), ("R", n, 12 * 2 + 0, 0.2)]
+    return dict(meshes=[(xy, tri, 2082.5, 0)], n_internal=1, elements=els, ground=12 * 2 + 0)
+
+
+def case_glue_sources():
+    # multi-pad source: the real source plus 0 V glue sources tying further pads (kicad.py:659-710)
+    xy, tri = synthetic.jittered_grid(10, 6, 0.6, seed=4)
+    n = len(xy)
+    els = [("V", 9, 0, 3.3, n), ("V", 19, 9, 0.0, n + 1), ("V", 10, 0, 0.0, n + 2), ("R", 35, 24, 5.0)]
+    return dict(meshes=[(xy, tri, 2082.5, 0)], n_internal=0, elements=els, ground=0)
+
+
+def case_regulator():
+    # two islands: output side (regulator voltage source + load), input side (mirrored current)
+    xy0, tri0 = synthetic.jittered_grid(8, 5, 0.6, seed=5)
+    xy1, tri1 = synthetic.jittered_grid(7, 6, 0.6, seed=6)
+    n0, n1 = len(xy0), len(xy1)
+    n = n0 + n1
+    els = [("R", 3, 36, 2.2),                              # load on the output island
+           ("REG", 39, 0, n0 + 5, n0 + 30, 3.3, 0.3, n + 0),
+           ("R", n0 + 4, n0 + 33, 1.4),
+           ("V", n0 + 41, n0 + 0, 5.0, n + 1),             # input supply
+           ("R", n0 + 0, 0, 1e5)]                          # couples the islands (test_solver.py:122-125)
+    return dict(meshes=[(xy0, tri0, 2082.5, 0), (xy1, tri1, 2082.5, 1)], n_internal=0, elements=els, ground=n0 + 0)
+
+
+def case_lumped_only():
+    # no mesh at all: the three network known-answer tests rolled into matrices (test_solver.py:65-147)
+    els = [("I", 0, 1, 1.1), ("R", 0, 1, 2.2)]
+    return dict(meshes=[], n_internal=2, elements=els, ground=0)
+
+
+CASES = {
+    "unit_square": case_unit_square, "star": case_star, "square_with_hole": case_square_with_hole,
+    "obtuse": case_obtuse, "strip20": case_strip20, "two_layer_via": case_two_layer_via,
+    "voltage_source": case_voltage_source, "glue_sources": case_glue_sources, "regulator": case_regulator,
+    "lumped_only": case_lumped_only,
+}
+
+
+# ---- run the reference ------------------------------------------------------------------------
+
+def run_reference(spec):
+    ref = ref_loader.load_reference()
+    P, M, S = ref.problem, ref.mesh, ref.solver
+    meshes = [M.Mesh.from_triangle_soup([M.Point(float(x), float(y)) for x, y in pts], [tuple(int(i) for i in t) for t in tri])
+              for pts, tri, _, _ in spec["meshes"]]
+    sig = [m[2] for m in spec["meshes"]]
+    n_layers = (max(m[3] for m in spec["meshes"]) + 1) if spec["meshes"] else 1
+    layer_sigma = [1.0] * n_layers
+    for m in spec["meshes"]:
+        layer_sigma[m[3]] = m[2]
+    layers = [P.Layer(shape=ref_loader.Geoms(1), name=f"L{i}", conductance=layer_sigma[i]) for i in range(n_layers)]
+    mesh_to_layer = [m[3] for m in spec["meshes"]]
+    vindex = S.VertexIndexer.create(meshes)
+    n_vert = len(vindex.global_index_to_vertex_index)
+    n_pot = n_vert + spec["n_internal"]
+    node_ids = [P.NodeID() for _ in range(n_pot)]
+    node_to_global = {nid: i for i, nid in enumerate(node_ids)}
+    extra = {}
+    elements = []
+    for e in spec["elements"]:
+        k = e[0]
+        if k == "R":
+            elements.append(P.Resistor(a=node_ids[e[1]], b=node_ids[e[2]], resistance=e[3]))
+        elif k == "I":
+            elements.append(P.CurrentSource(f=node_ids[e[1]], t=node_ids[e[2]], current=e[3]))
+        elif k == "V":
+            el = P.VoltageSource(p=node_ids[e[1]], n=node_ids[e[2]], voltage=e[3])
+            extra[el] = e[4]
+            elements.append(el)
+        elif k == "REG":
+            el = P.VoltageRegulator(v_p=node_ids[e[1]], v_n=node_ids[e[2]], s_f=node_ids[e[3]], s_t=node_ids[e[4]],
+                                    voltage=e[5], gain=e[6])
+            extra[el] = e[7]
+            elements.append(el)
+    network = P.Network(connections=[], elements=elements)
+    nix = S.NodeIndexer(node_to_global_index=node_to_global, extra_source_to_global_index=extra,
+                        internal_node_count=spec["n_internal"])
+    L, r = S.allocate_system(vindex, nix)
+    S.process_mesh_laplace_operators(meshes, sig, vindex, L)
+    S.stamp_network_into_system(network, nix, L, r)
+    S.setup_ground_node(spec["ground"], L, r)
+    v, info = S.solve_system(L, r)
+    Lc = L.tocsr()
+    Lc.sort_indices()
+    out = dict(L_indptr=Lc.indptr.astype(np.int64), L_indices=Lc.indices.astype(np.int64), L_data=Lc.data,
+               r=r, v=v, ground_node_current=np.float64(info.ground_node_current),
+               residual_norm=np.float64(info.residual_norm), N=np.int64(L.shape[0]))
+    # per-mesh laplace_operator COO, potentials and power densities
+    sols = S.produce_layer_solutions(layers, vindex, meshes, mesh_to_layer, v, [[] for _ in layers])
+    for mi, msh in enumerate(meshes):
+        coo = S.laplace_operator(msh)
+        c = coo.tocsr()
+        c.sort_indices()
+        out[f"lap{mi}_indptr"] = c.indptr.astype(np.int64)
+        out[f"lap{mi}_indices"] = c.indices.astype(np.int64)
+        out[f"lap{mi}_data"] = c.data
+    for li, ls in enumerate(sols):
+        for k, (zf, tf) in enumerate(zip(ls.potentials, ls.power_densities)):
+            mi = [i for i, l in enumerate(mesh_to_layer) if l == li][k]
+            out[f"pot{mi}"] = zf.values
+            out[f"pow{mi}"] = tf.values
+    return out
+
+
+def encode_inputs(spec):
+    d = dict(n_internal=np.int64(spec["n_internal"]), ground=np.int64(spec["ground"]),
+             n_mesh=np.int64(len(spec["meshes"])))
+    for mi, (pts, tri, sigma, layer) in enumerate(spec["meshes"]):
+        d[f"xy{mi}"] = np.asarray(pts, float)
+        d[f"tri{mi}"] = np.asarray(tri, np.int32)
+        d[f"sigma{mi}"] = np.float64(sigma)
+        d[f"layer{mi}"] = np.int64(layer)
+    el = np.zeros((len(spec["elements"]), 8))
+    for i, e in enumerate(spec["elements"]):
+        el[i, 0] = KIND[e[0]]
+        el[i, 1:len(e)] = e[1:]
+    d["elements"] = el
+    return d
+
+
+def main():
+    for name, fn in CASES.items():
+        spec = fn()
+        data = encode_inputs(spec)
+        data.update(run_reference(spec))
+        path = os.path.join(HERE, f"{name}.npz")
+        np.savez_compressed(path, **data)
+        print(f"{name}: N={int(data['N'])} nnz={len(data['L_data'])} |v|max={np.abs(data['v']).max():.4g} "
+              f"res={float(data['residual_norm']):.2e} -> {os.path.relpath(path, ROOT)}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,105 @@
+"""Shared helpers for the test-suite: golden fixtures <-> oracle / product inputs."""
+from __future__ import annotations
+
+import glob
+import os
+
+import numpy as np
+import scipy.sparse as sp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+KIND = {0: "R", 1: "I", 2: "V", 3: "REG"}
+NARGS = {"R": 3, "I": 3, "V": 4, "REG": 7}
+INT_ARGS = {"R": 2, "I": 2, "V": 2, "REG": 4}
+
+
+def golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, f"{name}.npz")))
+
+
+def elements_of(g):
+    out = []
+    for row in g["elements"]:
+        kind = KIND[int(row[0])]
+        args = list(row[1:1 + NARGS[kind]])
+        ni = INT_ARGS[kind]
+        vals = [int(a) for a in args[:ni]] + [float(a) for a in args[ni:]]
+        if kind in ("V", "REG"):
+            vals[-1] = int(vals[-1])
+        out.append((kind, *vals))
+    return out
+
+
+def meshes_of(g):
+    return [(g[f"xy{i}"], g[f"tri{i}"], float(g[f"sigma{i}"]), int(g[f"layer{i}"])) for i in range(int(g["n_mesh"]))]
+
+
+def golden_L(g):
+    N = int(g["N"])
+    return sp.csr_matrix((g["L_data"], g["L_indices"].astype(np.int32), g["L_indptr"].astype(np.int32)), shape=(N, N))
+
+
+def golden_lap(g, i):
+    n = len(g[f"xy{i}"])
+    return sp.csr_matrix((g[f"lap{i}_data"], g[f"lap{i}_indices"].astype(np.int32), g[f"lap{i}_indptr"].astype(np.int32)),
+                         shape=(n, n))
+
+
+def same_structure(A, B):
+    A = sp.csr_matrix(A)
+    B = sp.csr_matrix(B)
+    A.sort_indices()
+    B.sort_indices()
+    return A.shape == B.shape and np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices)
+
+
+def offdiag_and_diag(A):
+    A = sp.csr_matrix(A)
+    d = A.diagonal()
+    off = A - sp.diags(d)
+    off.eliminate_zeros()
+    return off.tocsr(), d
+
+
+# ---- product-side construction from a golden spec ------------------------------------------------
+
+def product_system(g):
+    """Build (meshes, conductances, StampList, r, n_potential) the way padne_amd.solver would."""
+    from padne_amd import mesh as pmesh, solver
+    ms = meshes_of(g)
+    meshes = [pmesh.Mesh(xy, tri) for xy, tri, _, _ in ms]
+    sig = [m[2] for m in ms]
+    n_vert = sum(len(m.points) for m in meshes)
+    n_pot = n_vert + int(g["n_internal"])
+    N = int(g["N"])
+    stamps = solver.StampList(N)
+    r = np.zeros(N)
+    from padne_amd.reduction import Constraint
+    for e in elements_of(g):
+        k = e[0]
+        if k == "R":
+            _, a, b, res = e
+            gg = 1 / res
+            stamps.add(a, a, -gg); stamps.add(a, b, gg); stamps.add(b, b, -gg); stamps.add(b, a, gg)
+        elif k == "I":
+            _, f, t, cur = e
+            r[f] += cur
+            r[t] += -cur
+        elif k == "V":
+            _, p, n, u, iv = e
+            stamps.add(iv, p, 1.0); stamps.add(iv, n, -1.0); r[iv] = u
+            stamps.add(p, iv, 1.0); stamps.add(n, iv, -1.0)
+            stamps.constraints.append(Constraint(index=iv, p=p, n=n, value=u))
+        elif k == "REG":
+            _, vp, vn, sf, st, u, gain, iv = e
+            stamps.add(iv, vp, 1.0); stamps.add(iv, vn, -1.0); stamps.add(vp, iv, 1.0); stamps.add(vn, iv, -1.0)
+            r[iv] += u
+            stamps.add(sf, iv, gain); stamps.add(st, iv, -gain)
+            stamps.constraints.append(Constraint(index=iv, p=vp, n=vn, value=u, gamma={sf: gain, st: -gain}))
+    solver.setup_ground_node(int(g["ground"]), stamps, r)
+    return meshes, sig, stamps, r, n_pot

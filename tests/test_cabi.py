@@ -1,0 +1,59 @@
+"""The C-ABI library builds, loads without a GPU and exports every symbol include/padne_hip.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from padne_amd import _hip, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "padne_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(padne_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_is_built_in_tree():
+    lib = build.build(verbose=False)
+    assert os.path.exists(lib) and lib.startswith(ROOT)
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    build.build(verbose=False)
+    lib = ctypes.CDLL(_hip.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 25
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in padne_hip.h but not exported"
+        assert name in _hip.SIGNATURES, f"{name} has no ctypes prototype in padne_amd/_hip.py"
+    for name in _hip.SIGNATURES:
+        assert name in names, f"{name} bound in _hip.py but not declared in the header"
+
+
+def test_abi_version_and_error_string():
+    lib = _hip.load_library()
+    assert lib.padne_abi_version() == 1
+    assert isinstance(lib.padne_last_error(), bytes)
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="only meaningful without a GPU")
+def test_product_path_fails_loudly_without_gpu():
+    with pytest.raises(_hip.HipUnavailableError):
+        _hip.Context(0)
+
+
+def test_missing_library_is_an_error(tmp_path):
+    with pytest.raises(_hip.HipUnavailableError):
+        _hip.load_library(str(tmp_path / "libpadne_hip.so"))
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "padne_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.lower() or f == "__never__", f"{f} mentions the oracle"

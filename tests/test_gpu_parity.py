@@ -1,0 +1,402 @@
+"""Parity of the HIP path against the oracle and the reference's golden vectors (needs an MI355X).
+
+Everything here goes through the C ABI (padne_amd._hip -> libpadne_hip.so).  Bars:
+  * assembled matrices: identical structure, bit-identical values vs the oracle (same operations in
+    the same order), and vs the reference goldens bit-identical except the Laplacian diagonal
+    (orbit-order vs column-order sum, rtol 1e-14);
+  * SpMV: bit-identical to a sequential CSR product (scipy);
+  * power density / gradients: bit-identical;
+  * potentials: <= 1e-8 relative to the reference's direct solve (north_star), in practice ~1e-12.
+"""
+import pickle
+import warnings
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import helpers as H
+from oracle import padne_oracle as O
+from padne_amd import _hip, mesh, problem, solver, structured, synthetic
+
+pytestmark = pytest.mark.gpu
+NAMES = H.golden_names()
+REL_TOL = 1e-8          # BASELINE.json north_star: potentials within 1e-8 relative
+
+
+def flat(meshes_spec):
+    xy = np.concatenate([m[0] for m in meshes_spec]) if meshes_spec else np.zeros((0, 2))
+    tri = np.concatenate([m[1] for m in meshes_spec]) if meshes_spec else np.zeros((0, 3), np.int32)
+    mvo = np.concatenate([[0], np.cumsum([len(m[0]) for m in meshes_spec])]).astype(np.int64)
+    mto = np.concatenate([[0], np.cumsum([len(m[1]) for m in meshes_spec])]).astype(np.int64)
+    sig = np.array([m[2] for m in meshes_spec], dtype=float)
+    return xy, tri, mvo, mto, sig
+
+
+# ---- assembly ---------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", NAMES)
+def test_laplace_operator_vs_golden_and_oracle(ctx, name):
+    g = H.load_golden(name)
+    for i, (xy, tri, _, _) in enumerate(H.meshes_of(g)):
+        got = solver.laplace_operator(mesh.Mesh(xy, tri)).tocsr()
+        orc = O.laplace_operator(xy, tri).tocsr()
+        assert H.same_structure(got, orc) and np.array_equal(got.data, orc.data), "bitwise vs oracle"
+        ref = H.golden_lap(g, i)
+        assert H.same_structure(got, ref)
+        ro, rd = H.offdiag_and_diag(ref)
+        go, gd = H.offdiag_and_diag(got)
+        assert np.array_equal(ro.data, go.data)
+        np.testing.assert_allclose(gd, rd, rtol=1e-14, atol=0)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_assemble_system_vs_golden_and_oracle(ctx, name):
+    g = H.load_golden(name)
+    meshes, sig, stamps, r, n_pot = H.product_system(g)
+    L = solver.assemble_from_arrays(meshes, sig, stamps, n_pot)
+    got = L.tocsr()
+    orc, r_o = O.assemble_system([(m[0], m[1], m[2]) for m in H.meshes_of(g)], int(g["n_internal"]),
+                                 H.elements_of(g), int(g["ground"]))
+    orc.sort_indices()
+    assert H.same_structure(got, orc) and np.array_equal(got.data, orc.data), "bitwise vs oracle"
+    assert np.array_equal(r, r_o) and np.array_equal(r, g["r"])
+    ref = H.golden_L(g)
+    assert H.same_structure(got, ref)
+    ro, rd = H.offdiag_and_diag(ref)
+    go, gd = H.offdiag_and_diag(got)
+    assert np.array_equal(ro.data, go.data)
+    np.testing.assert_allclose(gd, rd, rtol=1e-14, atol=0)
+    L.dev.close()
+
+
+def test_assembly_is_run_to_run_bitwise_reproducible(ctx):
+    sysm = synthetic.layered_system(3, 70, 50, via_lattice=5)
+    xy, tri, mvo, mto, sig = flat(sysm.meshes)
+    N = sysm.n_vertices + 1
+    a, b, rr = sysm.resistors
+    gg = 1 / rr
+    rows = np.stack([a, a, b, b], 1).reshape(-1)
+    cols = np.stack([a, b, b, a], 1).reshape(-1)
+    vals = np.stack([-gg, gg, -gg, gg], 1).reshape(-1)
+    first = ctx.assemble_system(N, xy, tri, mvo, mto, sig, rows, cols, vals).to_scipy()
+    for _ in range(3):
+        again = ctx.assemble_system(N, xy, tri, mvo, mto, sig, rows, cols, vals).to_scipy()
+        assert np.array_equal(first.indptr, again.indptr) and np.array_equal(first.indices, again.indices)
+        assert np.array_equal(first.data, again.data)
+
+
+def test_assembly_edge_cases(ctx):
+    e64 = np.zeros(0, np.int64)
+    # empty system
+    m = ctx.assemble_system(0, np.zeros((0, 2)), np.zeros((0, 3), np.int32), [0], [0], np.zeros(0), e64, e64, np.zeros(0))
+    assert m.shape == (0, 0) and m.nnz == 0
+    # stamps only, duplicates that cancel exactly are not stored
+    m = ctx.assemble_system(3, np.zeros((0, 2)), np.zeros((0, 3), np.int32), [0], [0], np.zeros(0),
+                            [0, 0, 1, 2], [1, 1, 1, 0], [2.0, -2.0, 3.0, 4.0]).to_scipy()
+    assert m.nnz == 2 and m[1, 1] == 3.0 and m[2, 0] == 4.0
+    # isolated vertex (no triangle): empty row, like lil += 0.0
+    xy = np.array([[0, 0], [1, 0], [0, 1], [5, 5]], float)
+    m = ctx.assemble_system(4, xy, np.array([[0, 1, 2]], np.int32), [0, 4], [0, 1], [1.0], e64, e64, np.zeros(0)).to_scipy()
+    assert m[3].nnz == 0
+    # non-manifold soup -> ValueError like Mesh.from_triangle_soup (tests/test_mesh.py:712-733)
+    xy = np.array([[0, 0], [1, 0], [0, 1], [0, -1]], float)
+    with pytest.raises(ValueError):
+        ctx.assemble_system(4, xy, np.array([[0, 1, 2], [0, 1, 3]], np.int32), [0, 4], [0, 2], [1.0], e64, e64, np.zeros(0))
+    # bow-tie vertex (two fans meeting in one vertex) is non-manifold too
+    xy = np.array([[0, 0], [1, 0], [1, 1], [-1, 0], [-1, -1]], float)
+    with pytest.raises(ValueError):
+        ctx.assemble_system(5, xy, np.array([[0, 1, 2], [0, 3, 4]], np.int32), [0, 5], [0, 2], [1.0], e64, e64, np.zeros(0))
+    # index out of range / repeated vertex
+    with pytest.raises(ValueError):
+        ctx.assemble_system(3, xy[:3], np.array([[0, 1, 3]], np.int32), [0, 3], [0, 1], [1.0], e64, e64, np.zeros(0))
+    with pytest.raises(ValueError):
+        ctx.assemble_system(3, xy[:3], np.array([[0, 1, 1]], np.int32), [0, 3], [0, 1], [1.0], e64, e64, np.zeros(0))
+    with pytest.raises(ValueError):
+        ctx.assemble_system(3, xy[:3], np.array([[0, 1, 2]], np.int32), [0, 3], [0, 1], [1.0], [7], [0], [1.0])
+
+
+def test_long_rows_and_ragged_meshes(ctx):
+    """A star node with hundreds of resistors (multi-pad terminal, kicad.py:535-556) and meshes of
+    very different size in one system."""
+    rng = np.random.default_rng(3)
+    parts = [synthetic.jittered_grid(40, 30, seed=1), synthetic.jittered_grid(3, 2, seed=2), synthetic.jittered_grid(17, 23, seed=3)]
+    ms = [(p[0], p[1], s) for p, s in zip(parts, (2082.5, 10.0, 500.0))]
+    nv = sum(len(m[0]) for m in ms)
+    hub = nv
+    pads = rng.choice(nv, size=700, replace=False)
+    els = [("R", int(p), hub, 1e-3) for p in pads] + [("I", 5, int(nv - 3), 1.0)]
+    Lo, ro = O.assemble_system(ms, 1, els, 0)
+    Lo.sort_indices()
+    xy, tri, mvo, mto, sig = flat(ms)
+    rows, cols, vals = [], [], []
+    for _, a, b, rr in els[:-1]:
+        g = 1 / rr
+        rows += [a, a, b, b]; cols += [a, b, b, a]; vals += [-g, g, -g, g]
+    N = nv + 2
+    rows += [N - 1, 0]; cols += [0, N - 1]; vals += [1.0, 1.0]
+    Ld = ctx.assemble_system(N, xy, tri, mvo, mto, sig, rows, cols, vals)
+    got = Ld.to_scipy()
+    assert H.same_structure(got, Lo) and np.array_equal(got.data, Lo.data)
+    x = rng.uniform(-1, 1, N)
+    assert np.array_equal(Ld.matvec(x), Lo @ x)          # the 701-entry hub row spans several LDS passes? no: one
+    # a row longer than one LDS pass (2048 non-zeros)
+    big = sp.random(50, 6000, density=0.9, random_state=5, format="csr")
+    B = ctx.csr_from_scipy(big)
+    xb = rng.uniform(-1, 1, 6000)
+    assert np.array_equal(B.matvec(xb), big @ xb)
+
+
+# ---- SpMV -------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("shape", [(1, 1), (255, 255), (256, 300), (257, 100), (5000, 5000), (100000, 100000)])
+def test_spmv_bitwise_vs_sequential_csr(ctx, shape):
+    rng = np.random.default_rng(shape[0])
+    A = sp.random(shape[0], shape[1], density=min(1.0, 7.0 / shape[1]), random_state=shape[0] + 1, format="csr")
+    A.data = rng.uniform(-1, 1, A.nnz)
+    d = ctx.csr_from_scipy(A)
+    x = rng.uniform(-1, 1, shape[1])
+    assert np.array_equal(d.matvec(x), A @ x)
+    assert d.spmv_bytes == 12 * A.nnz + 20 * shape[0] + 4
+
+
+def test_spmv_empty_rows_and_empty_matrix(ctx):
+    A = sp.csr_matrix((np.array([1.0, 2.0]), np.array([0, 3]), np.array([0, 0, 1, 1, 2, 2])), shape=(5, 4))
+    d = ctx.csr_from_scipy(A)
+    assert np.array_equal(d.matvec(np.arange(4.0)), A @ np.arange(4.0))
+    E = ctx.csr_from_scipy(sp.csr_matrix((0, 0)))
+    assert E.matvec(np.zeros(0)).shape == (0,)
+    with pytest.raises(ValueError):
+        d.matvec(np.zeros(3))
+
+
+def test_spmv_linearity_at_full_size(ctx):
+    """Size-independent property at BASELINE scale (N = 1M): A(ax + by) == a Ax + b Ay to rounding,
+    and rows of the reduced Laplacian sum to the Dirichlet coupling only."""
+    sysm = synthetic.config("C2")
+    xy, tri, mvo, mto, sig = flat(sysm.meshes)
+    e64 = np.zeros(0, np.int64)
+    L = ctx.assemble_system(sysm.n_vertices, xy, tri, mvo, mto, sig, e64, e64, np.zeros(0))
+    rng = np.random.default_rng(0)
+    x, y = rng.uniform(-1, 1, (2, sysm.n_vertices))
+    lhs = L.matvec(2.5 * x - 0.5 * y)
+    rhs = 2.5 * L.matvec(x) - 0.5 * L.matvec(y)
+    assert np.abs(lhs - rhs).max() <= 1e-9 * np.abs(rhs).max()
+    ones = L.matvec(np.ones(sysm.n_vertices))
+    assert np.abs(ones).max() <= 1e-8 * 2082.5          # constants are in the null space of the Laplacian
+
+
+# ---- solve ------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", NAMES)
+def test_solve_system_vs_reference_golden(ctx, name):
+    g = H.load_golden(name)
+    meshes, sig, stamps, r, n_pot = H.product_system(g)
+    L = solver.assemble_from_arrays(meshes, sig, stamps, n_pot)
+    v, info = solver.solve_system(L, r)
+    scale_pot = np.abs(g["v"][:n_pot]).max()
+    tol = 1e-6 if name == "regulator" else REL_TOL       # regulator fixture: condition ~1e9, see test_oracle_golden
+    assert np.abs(v[:n_pot] - g["v"][:n_pot]).max() <= tol * scale_pot
+    scale_cur = max(np.abs(g["v"][n_pot:]).max(), 1e-30)
+    assert np.abs(v[n_pot:] - g["v"][n_pot:]).max() <= max(tol * scale_cur, 1e-9)
+    assert abs(info.ground_node_current - float(g["ground_node_current"])) <= max(tol * scale_cur, 1e-9)
+    assert info.residual_norm < 1e-9 * max(1.0, scale_cur)   # tests/test_solver.py:2083-2089 (amps-scaled)
+    L.dev.close()
+
+
+@pytest.mark.parametrize("name", ["voltage_source", "regulator", "two_layer_via"])
+def test_solve_system_accepts_a_bare_scipy_matrix(ctx, name):
+    """Drop-in seam: solve_system(L, r) with the lil_matrix the reference's own assemble_system builds."""
+    g = H.load_golden(name)
+    v, info = solver.solve_system(H.golden_L(g).tolil(), g["r"])
+    n_pot = int(g["N"]) - 1 - sum(1 for e in H.elements_of(g) if e[0] in ("V", "REG"))
+    tol = 1e-6 if name == "regulator" else REL_TOL
+    assert np.abs(v[:n_pot] - g["v"][:n_pot]).max() <= tol * np.abs(g["v"][:n_pot]).max()
+
+
+def test_pcg_vs_direct_solve_on_layered_system(ctx):
+    sysm = synthetic.layered_system(4, 150, 150, via_lattice=8)
+    els = [("R", int(a), int(b), float(r)) for a, b, r in zip(*sysm.resistors)]
+    els += [("I", int(f), int(t), float(i)) for f, t, i in zip(*sysm.current_sources)]
+    Lo, ro = O.assemble_system([(m[0], m[1], m[2]) for m in sysm.meshes], 0, els, 0)
+    v_ref, gc, _ = O.solve_system(Lo, ro)
+    v, info = solver.solve_system(Lo, ro)
+    n = sysm.n_vertices
+    assert np.abs(v[:n] - v_ref[:n]).max() <= REL_TOL * np.abs(v_ref[:n]).max()
+    assert info.residual_norm < 1e-9 and abs(info.ground_node_current) < 1e-9
+    assert info.iterations > 100 and info.rel_residual <= 1.1e-12
+
+
+def test_pcg_multiple_rhs_and_initial_guess(ctx):
+    xy, tri = synthetic.jittered_grid(60, 60, seed=9)
+    Lo = O.laplace_operator(xy, tri).tocsr()
+    A = (-2082.5 * Lo[1:, 1:]).tocsr()
+    d = ctx.csr_from_scipy(A)
+    rng = np.random.default_rng(2)
+    B = rng.uniform(-1, 1, (3, A.shape[0]))
+    res = d.solve_spd(B, rtol=1e-12)
+    for k in range(3):
+        assert np.linalg.norm(B[k] - A @ res.x[k]) <= 2e-12 * np.linalg.norm(B[k])
+    warm = d.solve_spd(B[0], rtol=1e-12, x0=res.x[0])
+    assert warm.iterations <= 2
+    zero = d.solve_spd(np.zeros(A.shape[0]))
+    assert zero.iterations == 0 and not zero.x.any()
+
+
+def test_pcg_reports_breakdown_and_non_convergence(ctx):
+    A = sp.csr_matrix(np.array([[1.0, 2.0], [2.0, 1.0]]))           # indefinite
+    with pytest.raises(_hip.HipError):
+        ctx.csr_from_scipy(A).solve_spd(np.array([1.0, -1.0]))
+    xy, tri = synthetic.jittered_grid(40, 40, seed=1)
+    A = (-O.laplace_operator(xy, tri).tocsr()[1:, 1:]).tocsr()
+    with pytest.raises(_hip.NotConvergedError):
+        ctx.csr_from_scipy(A).solve_spd(np.ones(A.shape[0]), max_iter=5)
+
+
+def test_solves_are_bitwise_reproducible(ctx):
+    xy, tri = synthetic.jittered_grid(120, 90, seed=4)
+    A = (-O.laplace_operator(xy, tri).tocsr()[1:, 1:]).tocsr()
+    d = ctx.csr_from_scipy(A)
+    b = np.random.default_rng(0).uniform(-1, 1, A.shape[0])
+    x1 = d.solve_spd(b).x
+    x2 = d.solve_spd(b).x
+    assert np.array_equal(x1, x2)
+
+
+# ---- post-processing ----------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", NAMES)
+def test_power_density_vs_golden(ctx, name):
+    g = H.load_golden(name)
+    ms = H.meshes_of(g)
+    if not ms:
+        return
+    xy, tri, mvo, mto, sig = flat(ms)
+    got = ctx.power_density(xy, tri, mvo, mto, sig, g["v"])
+    want = np.concatenate([g[f"pow{i}"] for i in range(len(ms))])
+    assert np.array_equal(got, want)
+    for i, (pxy, ptri, s, _) in enumerate(ms):                        # and through the ZeroForm seam
+        z = mesh.ZeroForm(mesh.Mesh(pxy, ptri))
+        z.values = g[f"pot{i}"].copy()
+        assert np.array_equal(solver.compute_power_density(z, s).values, g[f"pow{i}"])
+
+
+@pytest.mark.parametrize("values,expected", [((5.0, 5.0, 5.0), (0.0, 0.0)), ((0.0, 1.0, 0.0), (1.0, 0.0)),
+                                             ((0.0, 0.0, 1.0), (0.0, 1.0)), ((0.0, 1.0, 1.0), (1.0, 1.0))])
+def test_triangle_gradient_known_answers(ctx, values, expected):
+    vs = [mesh.Vertex(mesh.Point(0.0, 0.0)), mesh.Vertex(mesh.Point(1.0, 0.0)), mesh.Vertex(mesh.Point(0.0, 1.0))]
+    g = solver.compute_triangle_gradient(vs, list(values))           # tests/test_solver.py:1042-1112
+    assert g.dx == pytest.approx(expected[0], abs=1e-10) and g.dy == pytest.approx(expected[1], abs=1e-10)
+    gx, gy = O.triangle_gradient(np.array([0.0, 0.0]), np.array([1.0, 0.0]), np.array([0.0, 1.0]), *values)
+    assert g.dx == gx and g.dy == gy
+    with pytest.raises(ValueError):
+        solver.compute_triangle_gradient(vs[:2], [0.0, 1.0])
+
+
+# ---- Problem-level drop-in (the reference's synthetic end-to-end tests) --------------------------
+
+def strip_problem(n_src=5):
+    layer = problem.Layer(shape=structured.Shapes.of(structured.Rect(0, 0, 10, 1)), name="F.Cu", conductance=1.0)
+    nets = []
+    ys = np.linspace(0.1, 0.9, n_src)
+    lefts = [problem.Connection(layer=layer, point=mesh.Point(0.0, float(y))) for y in ys]
+    rights = [problem.Connection(layer=layer, point=mesh.Point(10.0, float(y))) for y in ys]
+    for cl, cr in zip(lefts, rights):
+        nets.append(problem.Network(connections=[cl, cr],
+                                    elements=[problem.VoltageSource(p=cr.node_id, n=cl.node_id, voltage=1.0)]))
+    for a, b in zip(lefts[1:], lefts[:-1]):                           # tie the pads of each side (0 V glue)
+        ca = problem.Connection(layer=layer, point=a.point)
+        cb = problem.Connection(layer=layer, point=b.point)
+        nets.append(problem.Network(connections=[ca, cb],
+                                    elements=[problem.VoltageSource(p=ca.node_id, n=cb.node_id, voltage=0.0)]))
+    return problem.Problem(layers=[layer], networks=nets)
+
+
+def test_linear_rectangle_end_to_end(ctx):
+    """tests/test_solver.py:461-595: 10x1 strip, 1 V end to end -> V linear in x within 0.05."""
+    prob = strip_problem()
+    mesher = structured.StructuredMesher(mesh.Mesher.Config(maximum_size=0.2), jitter=0.15, seed=3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", solver.SolverWarning)
+        sol = solver.solve(prob, mesher=mesher)
+    ls = sol.layer_solutions[0]
+    msh, pot, pw = ls.meshes[0], ls.potentials[0], ls.power_densities[0]
+    assert np.all(np.isfinite(pot.values))
+    assert np.abs(pot.values - msh.points[:, 0] / 10.0).max() < 0.05
+    # uniform power density sigma*|E|^2 = 1 * 0.1^2 (tests/test_solver.py:1249-1321 analogue)
+    area = np.array([f.area for f in msh.faces])
+    assert abs((pw.values * area).sum() / area.sum() - 0.01) < 1e-3 * 0.01 * 50
+    assert sol.solver_info.residual_norm < 1e-9
+    assert abs(sol.solver_info.ground_node_current) < 1e-9
+    blob = pickle.dumps(sol)                                          # cli.py:223-224: Solution must pickle
+    assert np.array_equal(pickle.loads(blob).layer_solutions[0].potentials[0].values, pot.values)
+
+
+def test_coaxial_structure_end_to_end(ctx):
+    """tests/test_solver.py:597-751: V(r) = ln(9/r)/ln 9 within 0.03, rings equipotential to 1e-3."""
+    layer = problem.Layer(shape=structured.Shapes.of(structured.Annulus(0, 0, 1.0, 9.0)), name="F.Cu", conductance=1.0)
+    n_t = 96
+    ang = np.arange(n_t) * 2 * np.pi / n_t
+    inner = [problem.Connection(layer=layer, point=mesh.Point(float(np.cos(a)), float(np.sin(a)))) for a in ang]
+    outer = [problem.Connection(layer=layer, point=mesh.Point(float(9 * np.cos(a)), float(9 * np.sin(a)))) for a in ang]
+    nets = [problem.Network(connections=[inner[0], outer[0]],
+                            elements=[problem.VoltageSource(p=inner[0].node_id, n=outer[0].node_id, voltage=1.0)])]
+    for ring in (inner, outer):
+        for a, b in zip(ring[1:], ring[:-1]):
+            ca = problem.Connection(layer=layer, point=a.point)
+            cb = problem.Connection(layer=layer, point=b.point)
+            nets.append(problem.Network(connections=[ca, cb],
+                                        elements=[problem.VoltageSource(p=ca.node_id, n=cb.node_id, voltage=0.0)]))
+    prob = problem.Problem(layers=[layer], networks=nets)
+
+    class M(structured.StructuredMesher):
+        def poly_to_mesh(self, poly, seed_points=()):
+            xy, tri = synthetic.annulus_mesh(1.0, 9.0, 33, n_t)
+            return mesh.Mesh(xy, tri)
+    sol = solver.solve(prob, mesher=M())
+    msh, pot = sol.layer_solutions[0].meshes[0], sol.layer_solutions[0].potentials[0]
+    rad = np.hypot(msh.points[:, 0], msh.points[:, 1])
+    assert np.abs(pot.values - np.log(9 / rad) / np.log(9)).max() < 0.03
+    ring = pot.values[n_t * 10:n_t * 11]
+    assert ring.max() - ring.min() < 1e-3
+
+
+
+
+# ---- multi-GPU code path on one GPU ---------------------------------------------------------------
+
+def test_halo_and_rccl_path_with_one_rank_communicator():
+    """Exercises pack -> ncclAllGather -> SpMV on exchange columns -> fold -> ncclAllReduce with a
+    1-rank RCCL communicator: off-diagonal couplings to a subset of unknowns are re-routed through
+    the exchange area, which must not change the solution."""
+    xy, tri = synthetic.jittered_grid(70, 50, seed=6)
+    A = (-2082.5 * O.laplace_operator(xy, tri).tocsr()[1:, 1:]).tocsr()
+    n = A.shape[0]
+    b = np.random.default_rng(1).uniform(-1, 1, n)
+    x_ref = O.solve_system(sp.bmat([[A, None], [None, sp.identity(1)]]).tocsr(), np.concatenate([b, [0.0]]))[0][:n]
+    export = np.arange(3, n, 7, dtype=np.int32)
+    m = len(export) + 5                                        # padded segment, like max over ranks
+    pos = -np.ones(n, dtype=np.int64)
+    pos[export] = np.arange(len(export))
+    C = A.tocoo()
+    cols = C.col.astype(np.int64).copy()
+    move = (pos[cols] >= 0) & (C.row != C.col)
+    cols[move] = n + pos[cols[move]]
+    A_ext = sp.coo_matrix((C.data, (C.row, cols)), shape=(n + m, n + m)).tocsr()
+    ctx2 = _hip.Context(0)
+    try:
+        ctx2.comm_init(ctx2.comm_unique_id(), 0, 1)
+        ctx2.set_halo(n, m, export)
+        d = ctx2.csr_from_scipy(A_ext)
+        res = d.solve_spd(b, rtol=1e-12)
+        assert res.x.shape == (n,)
+        assert np.abs(res.x - x_ref).max() <= REL_TOL * np.abs(x_ref).max()
+        plain = ctx2.csr_from_scipy(A)
+        ctx2.clear_halo()
+        res2 = plain.solve_spd(b, rtol=1e-12)                  # reductions still via RCCL (communicator set)
+        assert np.abs(res2.x - x_ref).max() <= REL_TOL * np.abs(x_ref).max()
+        assert abs(res2.iterations - res.iterations) <= 3
+        d.close()
+        plain.close()
+    finally:
+        ctx2.close()
