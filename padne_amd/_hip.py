@@ -167,6 +167,7 @@ class Context:
             raise HipUnavailableError(f"cannot create a context on GPU {device}: {msg}")
         self._h = h
         self.device = int(device)
+        self.halo_n_owned = None      # length of b / x when a halo plan is active
 
     # -- lifetime ------------------------------------------------------------
     def close(self):
@@ -206,9 +207,11 @@ class Context:
     def set_halo(self, n_owned: int, m: int, export_idx) -> None:
         e = _i32(export_idx)
         _check(self._lib.padne_ctx_set_halo(self._h, int(n_owned), int(m), int(e.shape[0]), _ptr(e, _PI32)))
+        self.halo_n_owned = int(n_owned)
 
     def clear_halo(self) -> None:
         _check(self._lib.padne_ctx_set_halo(self._h, -1, 0, 0, None))
+        self.halo_n_owned = None
 
     # -- raw device memory ------------------------------------------------------
     def alloc(self, nbytes: int) -> int:
@@ -417,7 +420,7 @@ class CsrMatrix:
                   raise_on_fail=True) -> SolveResult:
         """Jacobi-PCG on the device; b is host f64[n] or f64[k, n]."""
         b = _f64(b)
-        n = self.shape[0]
+        n = self.shape[0] if self.ctx.halo_n_owned is None else self.ctx.halo_n_owned
         k = 1 if b.ndim == 1 else b.shape[0]
         if b.shape[-1] != n:
             raise ValueError("right-hand side has the wrong length")

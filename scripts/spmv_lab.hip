@@ -1,0 +1,287 @@
+// SpMV kernel laboratory (not part of the product): times design variants of the CSR SpMV on a
+// synthetic 7-point triangular-grid matrix of the C4 shape (8 layers of 1118x1118).
+//   hipcc -O3 --offload-arch=gfx950 -o spmv_lab scripts/spmv_lab.hip && ./spmv_lab
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+constexpr int NXCD = 8;
+
+__device__ __forceinline__ int vblock(int G) {
+    const int per = G / NXCD;
+    if (per > 0 && G % NXCD == 0) return (blockIdx.x % NXCD) * per + blockIdx.x / NXCD;
+    return blockIdx.x;
+}
+
+// ---- V0/V1: LDS-staged, TILE nnz per pass, ROWS rows per tile, optional non-temporal streams ----
+template <int TILE, int ROWS, bool NT>
+__global__ __launch_bounds__(256) void spmv_lds(int n_rows, int n_tiles, const int *__restrict__ rowptr,
+                                                const int *__restrict__ cols, const double *__restrict__ vals,
+                                                const double *__restrict__ x, double *__restrict__ y) {
+    __shared__ __attribute__((aligned(16))) double prod[TILE];
+    const int tid = threadIdx.x;
+    const int G = gridDim.x;
+    const int vb = vblock(G);
+    const long long t0 = (long long)vb * n_tiles / G, t1 = (long long)(vb + 1) * n_tiles / G;
+    for (int tile = (int)t0; tile < (int)t1; ++tile) {
+        const int row0 = tile * ROWS;
+        const int row1 = min(row0 + ROWS, n_rows);
+        const int k0 = rowptr[row0], k1 = rowptr[row1];
+        int rs[ROWS / 256], re[ROWS / 256];
+#pragma unroll
+        for (int q = 0; q < ROWS / 256; ++q) {
+            const int r = row0 + tid + 256 * q;
+            rs[q] = re[q] = 0;
+            if (r < row1) { rs[q] = rowptr[r]; re[q] = rowptr[r + 1]; }
+        }
+        double acc[ROWS / 256];
+#pragma unroll
+        for (int q = 0; q < ROWS / 256; ++q) acc[q] = 0.0;
+        for (int base = k0 & ~3; base < k1; base += TILE) {
+#pragma unroll
+            for (int j = 0; j < TILE / 1024; ++j) {
+                const int l = 4 * (tid + 256 * j);
+                const int e = base + l;
+                int4 c; double2 v01, v23;
+                if (NT) {
+                    c.x = __builtin_nontemporal_load(cols + e); c.y = __builtin_nontemporal_load(cols + e + 1);
+                    c.z = __builtin_nontemporal_load(cols + e + 2); c.w = __builtin_nontemporal_load(cols + e + 3);
+                    v01.x = __builtin_nontemporal_load(vals + e); v01.y = __builtin_nontemporal_load(vals + e + 1);
+                    v23.x = __builtin_nontemporal_load(vals + e + 2); v23.y = __builtin_nontemporal_load(vals + e + 3);
+                } else {
+                    c = *reinterpret_cast<const int4 *>(cols + e);
+                    v01 = *reinterpret_cast<const double2 *>(vals + e);
+                    v23 = *reinterpret_cast<const double2 *>(vals + e + 2);
+                }
+                double2 p01, p23;
+                p01.x = v01.x * x[c.x]; p01.y = v01.y * x[c.y];
+                p23.x = v23.x * x[c.z]; p23.y = v23.y * x[c.w];
+                *reinterpret_cast<double2 *>(prod + l) = p01;
+                *reinterpret_cast<double2 *>(prod + l + 2) = p23;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < ROWS / 256; ++q) {
+                const int lo = max(rs[q], base), hi = min(re[q], base + TILE);
+                for (int k = lo; k < hi; ++k) acc[q] += prod[k - base];
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int q = 0; q < ROWS / 256; ++q) {
+            const int r = row0 + tid + 256 * q;
+            if (r < row1) y[r] = acc[q];
+        }
+    }
+}
+
+// ---- V2: as V0 (TILE 2048, ROWS 256) with the next tile's stream loads issued before the reduce phase
+__global__ __launch_bounds__(256) void spmv_pipe(int n_rows, int n_tiles, const int *__restrict__ rowptr,
+                                                 const int *__restrict__ cols, const double *__restrict__ vals,
+                                                 const double *__restrict__ x, double *__restrict__ y) {
+    constexpr int TILE = 2048, ROWS = 256;
+    __shared__ __attribute__((aligned(16))) double prod[TILE];
+    const int tid = threadIdx.x;
+    const int G = gridDim.x;
+    const int vb = vblock(G);
+    const int t0 = (int)((long long)vb * n_tiles / G), t1 = (int)((long long)(vb + 1) * n_tiles / G);
+    if (t0 >= t1) return;
+    int4 c[2]; double2 v[4];
+    int k0 = rowptr[t0 * ROWS];
+    {
+        const int base = k0 & ~3;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int e = base + 4 * (tid + 256 * j);
+            c[j] = *reinterpret_cast<const int4 *>(cols + e);
+            v[2 * j] = *reinterpret_cast<const double2 *>(vals + e);
+            v[2 * j + 1] = *reinterpret_cast<const double2 *>(vals + e + 2);
+        }
+    }
+    for (int tile = t0; tile < t1; ++tile) {
+        const int row0 = tile * ROWS;
+        const int row1 = min(row0 + ROWS, n_rows);
+        const int k1 = rowptr[row1];
+        const int r = row0 + tid;
+        int rs = 0, re = 0;
+        if (r < row1) { rs = rowptr[r]; re = rowptr[r + 1]; }
+        double acc = 0.0;
+        int base = k0 & ~3;
+        // first pass: registers were loaded one tile ahead
+        {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int l = 4 * (tid + 256 * j);
+                double2 p01, p23;
+                p01.x = v[2 * j].x * x[c[j].x]; p01.y = v[2 * j].y * x[c[j].y];
+                p23.x = v[2 * j + 1].x * x[c[j].z]; p23.y = v[2 * j + 1].y * x[c[j].w];
+                *reinterpret_cast<double2 *>(prod + l) = p01;
+                *reinterpret_cast<double2 *>(prod + l + 2) = p23;
+            }
+            // prefetch the first pass of the next tile (its range starts at k1)
+            if (tile + 1 < t1) {
+                const int nb = k1 & ~3;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int e = nb + 4 * (tid + 256 * j);
+                    c[j] = *reinterpret_cast<const int4 *>(cols + e);
+                    v[2 * j] = *reinterpret_cast<const double2 *>(vals + e);
+                    v[2 * j + 1] = *reinterpret_cast<const double2 *>(vals + e + 2);
+                }
+            }
+            __syncthreads();
+            const int lo = max(rs, base), hi = min(re, base + TILE);
+            for (int k = lo; k < hi; ++k) acc += prod[k - base];
+            __syncthreads();
+        }
+        for (base += TILE; base < k1; base += TILE) {   // rare: tile longer than one pass
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int l = 4 * (tid + 256 * j);
+                const int e = base + l;
+                const int4 cc = *reinterpret_cast<const int4 *>(cols + e);
+                const double2 a = *reinterpret_cast<const double2 *>(vals + e);
+                const double2 b = *reinterpret_cast<const double2 *>(vals + e + 2);
+                double2 p01, p23;
+                p01.x = a.x * x[cc.x]; p01.y = a.y * x[cc.y];
+                p23.x = b.x * x[cc.z]; p23.y = b.y * x[cc.w];
+                *reinterpret_cast<double2 *>(prod + l) = p01;
+                *reinterpret_cast<double2 *>(prod + l + 2) = p23;
+            }
+            __syncthreads();
+            const int lo = max(rs, base), hi = min(re, base + TILE);
+            for (int k = lo; k < hi; ++k) acc += prod[k - base];
+            __syncthreads();
+        }
+        if (r < row1) y[r] = acc;
+        k0 = k1;
+    }
+}
+
+// ---- V3: no LDS, LPR lanes cooperate on a row, shuffle reduce (CSR-vector with sub-waves) ----
+template <int LPR>
+__global__ __launch_bounds__(256) void spmv_subwave(int n_rows, const int *__restrict__ rowptr,
+                                                    const int *__restrict__ cols, const double *__restrict__ vals,
+                                                    const double *__restrict__ x, double *__restrict__ y) {
+    const long long gt = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int sub = threadIdx.x & (LPR - 1);
+    const long long nsub = (long long)gridDim.x * 256 / LPR;
+    for (long long r = gt / LPR; r < n_rows; r += nsub) {
+        const int rs = rowptr[r], re = rowptr[r + 1];
+        double acc = 0.0;
+        for (int k = rs + sub; k < re; k += LPR) acc += vals[k] * x[cols[k]];
+#pragma unroll
+        for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off, LPR);
+        if (sub == 0) y[r] = acc;
+    }
+}
+
+// ---- V5: plain streaming read of the same bytes (upper bound for this access mix) ----
+__global__ __launch_bounds__(256) void stream_ref(long long nnz4, const int4 *__restrict__ cols, const double2 *__restrict__ vals,
+                                                  double *__restrict__ y) {
+    double s = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nnz4; i += (long long)gridDim.x * 256) {
+        const int4 c = cols[i];
+        const double2 a = vals[2 * i], b = vals[2 * i + 1];
+        s += a.x + a.y + b.x + b.y + (double)(c.x ^ c.y ^ c.z ^ c.w);
+    }
+    if (s == 12345.678) y[0] = s;
+}
+
+struct Mat { int n; long long nnz; int *rowptr, *cols; double *vals; };
+
+static Mat build(int layers, int nx, int ny) {
+    const long long n = (long long)layers * nx * ny;
+    std::vector<int> rp(n + 1); std::vector<int> cl; std::vector<double> vl;
+    cl.reserve(n * 7); vl.reserve(n * 7);
+    unsigned s = 12345;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (double)(s >> 8) / (1 << 24); };
+    for (int l = 0; l < layers; ++l)
+        for (int iy = 0; iy < ny; ++iy)
+            for (int ix = 0; ix < nx; ++ix) {
+                const long long i = ((long long)l * ny + iy) * nx + ix;
+                rp[i] = (int)cl.size();
+                const int dx[7] = {-1, 0, -1, 0, 1, 0, 1}, dy[7] = {-1, -1, 0, 0, 0, 1, 1};
+                for (int k = 0; k < 7; ++k) {
+                    const int jx = ix + dx[k], jy = iy + dy[k];
+                    if (jx < 0 || jy < 0 || jx >= nx || jy >= ny) continue;
+                    cl.push_back((int)(((long long)l * ny + jy) * nx + jx));
+                    vl.push_back(k == 3 ? 6.0 + rnd() : -rnd());
+                }
+            }
+    rp[n] = (int)cl.size();
+    Mat m; m.n = (int)n; m.nnz = (long long)cl.size();
+    const size_t pad = 8192;
+    CK(hipMalloc(&m.rowptr, sizeof(int) * (n + 1)));
+    CK(hipMalloc(&m.cols, sizeof(int) * (cl.size() + pad)));
+    CK(hipMalloc(&m.vals, sizeof(double) * (cl.size() + pad)));
+    CK(hipMemset(m.cols, 0, sizeof(int) * (cl.size() + pad)));
+    CK(hipMemset(m.vals, 0, sizeof(double) * (cl.size() + pad)));
+    CK(hipMemcpy(m.rowptr, rp.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice));
+    CK(hipMemcpy(m.cols, cl.data(), sizeof(int) * cl.size(), hipMemcpyHostToDevice));
+    CK(hipMemcpy(m.vals, vl.data(), sizeof(double) * vl.size(), hipMemcpyHostToDevice));
+    return m;
+}
+
+template <typename F> static double timeit(F launch, int reps = 30) {
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 5; ++i) launch();
+    CK(hipEventRecord(a));
+    for (int i = 0; i < reps; ++i) launch();
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    CK(hipGetLastError());
+    return ms * 1e-3 / reps;
+}
+
+int main(int argc, char **argv) {
+    const int layers = argc > 1 ? atoi(argv[1]) : 8, nx = argc > 2 ? atoi(argv[2]) : 1118;
+    Mat m = build(layers, nx, nx);
+    double *x, *y, *yref;
+    CK(hipMalloc(&x, sizeof(double) * m.n)); CK(hipMalloc(&y, sizeof(double) * m.n)); CK(hipMalloc(&yref, sizeof(double) * m.n));
+    std::vector<double> hx(m.n);
+    for (int i = 0; i < m.n; ++i) hx[i] = sin(0.001 * i) + 0.5;
+    CK(hipMemcpy(x, hx.data(), sizeof(double) * m.n, hipMemcpyHostToDevice));
+    const double bytes = 12.0 * m.nnz + 20.0 * m.n + 4;
+    printf("n=%d nnz=%lld bytes=%.0f\n", m.n, m.nnz, bytes);
+    auto report = [&](const char *name, double t, bool check) {
+        double err = -1;
+        if (check) {
+            std::vector<double> a(m.n), b(m.n);
+            CK(hipMemcpy(a.data(), y, sizeof(double) * m.n, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(b.data(), yref, sizeof(double) * m.n, hipMemcpyDeviceToHost));
+            err = 0;
+            for (int i = 0; i < m.n; ++i) err = fmax(err, fabs(a[i] - b[i]));
+        }
+        printf("%-34s %8.1f us  %7.1f GB/s  %5.1f%%  maxdiff=%g\n", name, t * 1e6, bytes / t / 1e9, bytes / t / 8e10, err);
+        fflush(stdout);
+    };
+    const int nt256 = (m.n + 255) / 256, nt512 = (m.n + 511) / 512;
+    auto G = [](int nt, int cap) { int g = nt < cap ? nt : cap; if (g >= 8) g -= g % 8; return g < 1 ? 1 : g; };
+    // reference result
+    spmv_lds<2048, 256, false><<<G(nt256, 2048), 256>>>(m.n, nt256, m.rowptr, m.cols, m.vals, x, yref);
+    CK(hipDeviceSynchronize());
+    for (int cap : {1024, 2048, 4096, 8192}) {
+        char nm[64];
+        snprintf(nm, 64, "lds 2048/256 grid<=%d", cap);
+        report(nm, timeit([&] { spmv_lds<2048, 256, false><<<G(nt256, cap), 256>>>(m.n, nt256, m.rowptr, m.cols, m.vals, x, y); }), true);
+    }
+    report("lds 2048/256 nontemporal", timeit([&] { spmv_lds<2048, 256, true><<<G(nt256, 2048), 256>>>(m.n, nt256, m.rowptr, m.cols, m.vals, x, y); }), true);
+    report("lds 4096/512", timeit([&] { spmv_lds<4096, 512, false><<<G(nt512, 2048), 256>>>(m.n, nt512, m.rowptr, m.cols, m.vals, x, y); }), true);
+    report("lds 4096/512 grid 1024", timeit([&] { spmv_lds<4096, 512, false><<<G(nt512, 1024), 256>>>(m.n, nt512, m.rowptr, m.cols, m.vals, x, y); }), true);
+    for (int cap : {1024, 2048, 4096})  {
+        char nm[64];
+        snprintf(nm, 64, "pipelined 2048/256 grid<=%d", cap);
+        report(nm, timeit([&] { spmv_pipe<<<G(nt256, cap), 256>>>(m.n, nt256, m.rowptr, m.cols, m.vals, x, y); }), true);
+    }
+    report("subwave 8 lanes/row", timeit([&] { spmv_subwave<8><<<8192, 256>>>(m.n, m.rowptr, m.cols, m.vals, x, y); }), true);
+    report("subwave 4 lanes/row", timeit([&] { spmv_subwave<4><<<8192, 256>>>(m.n, m.rowptr, m.cols, m.vals, x, y); }), true);
+    report("subwave 2 lanes/row", timeit([&] { spmv_subwave<2><<<8192, 256>>>(m.n, m.rowptr, m.cols, m.vals, x, y); }), true);
+    report("subwave 1 lane/row", timeit([&] { spmv_subwave<1><<<8192, 256>>>(m.n, m.rowptr, m.cols, m.vals, x, y); }), true);
+    report("stream cols+vals only (bound)", timeit([&] { stream_ref<<<2048, 256>>>(m.nnz / 4, (const int4 *)m.cols, (const double2 *)m.vals, y); }), false);
+    return 0;
+}

@@ -103,3 +103,17 @@ def product_system(g):
             stamps.constraints.append(Constraint(index=iv, p=vp, n=vn, value=u, gamma={sf: gain, st: -gain}))
     solver.setup_ground_node(int(g["ground"]), stamps, r)
     return meshes, sig, stamps, r, n_pot
+
+
+def random_csr(n_rows, n_cols, per_row, seed):
+    """Random CSR with ~per_row sorted, unique column indices per row (cheap for any shape)."""
+    rng = np.random.default_rng(seed)
+    k = min(per_row, n_cols)
+    lens = rng.integers(0, 2 * k + 1, size=n_rows).clip(0, n_cols)
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    cols = rng.integers(0, n_cols, size=int(indptr[-1]))
+    rows = np.repeat(np.arange(n_rows), lens)
+    key = np.unique(rows.astype(np.int64) * n_cols + cols)
+    rows, cols = key // n_cols, key % n_cols
+    data = rng.uniform(-1, 1, size=len(key))
+    return sp.csr_matrix((data, (rows, cols)), shape=(n_rows, n_cols))
