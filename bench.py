@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="C4", help="C2 | C3 | C4 (default, the headline config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-nx", type=int, default=500,
+    ap.add_argument("--cpu-sample-nx", type=int, default=400,
                     help="grid edge of the bounded CPU-baseline sample (8 layers of nx*nx)")
     return ap.parse_args()
 

@@ -1,24 +1,27 @@
 // CSR SpMV for gfx950 (MI355X): y = A x, f64 values, i32 indices.
 //
-// Bandwidth-bound (0.135 flop/B), so no MFMA: the whole design is about moving
-// 12 B per non-zero + 20 B per row exactly once at full HBM rate.
+// Bandwidth-bound (0.135 flop/B), so no MFMA: the design is about moving 12 B per non-zero +
+// 20 B per row exactly once, at the rate the HBM delivers (measured with rocprofv3 FETCH_SIZE, see
+// DESIGN.md "SpMV"):
 //
-//  * a workgroup (4 waves of 64) owns a contiguous run of 256-row tiles; tiles
-//    are dealt to workgroups so that the workgroups of one XCD (blockIdx % 8)
-//    cover one contiguous slab of the matrix: the x entries a tile gathers are
-//    shared with the neighbouring tiles, and each XCD has a private L2.
-//  * the non-zeros of a tile are one contiguous range of `cols`/`vals`; the
-//    workgroup streams that range with 16-byte-per-lane loads (int4 columns,
-//    2 x double2 values per 4 non-zeros), fully coalesced and independent of
-//    the row structure.  Arrays are padded so no bounds checks are needed.
-//  * each lane gathers x[col] (L1/L2 hits: mesh neighbours are close in
-//    index), multiplies, and parks the products in LDS (16 KiB per pass).
-//  * one lane per row then adds its row segment out of LDS in CSR order, so
-//    the result is bit-identical to a sequential CSR product (scipy's
-//    csr_matvec); rows longer than a pass simply span several passes.
-//  * optional epilogue: partial sums of dot_with[row]*y[row], reduced over the
-//    wave with DPP shuffles and over the workgroup through LDS, one partial
-//    per workgroup (deterministic, no atomics).
+//  * wave-private tiles: a wavefront (64 lanes) owns 64 consecutive rows.  Their non-zeros are one
+//    contiguous range of `cols`/`vals`, which the wave streams lane-consecutively (lane l takes
+//    elements l, l+64, ...: every load instruction covers 256/512 contiguous bytes) and predicated
+//    on the end of the range, so no byte of the matrix is fetched twice.
+//  * each lane gathers x[col] (adjacent lanes hold adjacent non-zeros, whose columns are mostly
+//    adjacent mesh neighbours: L1 hits), multiplies, and parks the product in the wave's private
+//    4 KiB slice of LDS.
+//  * one lane per row then adds its row segment out of LDS in CSR order, so the result is
+//    bit-identical to a sequential CSR product (scipy's csr_matvec).  LDS operations of one wave
+//    execute in order: no workgroup barrier anywhere, waves never wait for each other.  Rows longer
+//    than the slice simply span several passes.
+//  * XCD-aware sweep: workgroups b, b+8, b+16, ... share an XCD and its private 4 MiB L2.  Each XCD
+//    gets one contiguous slab of the matrix and ALL its waves sweep that slab together, one 64-row
+//    tile per wave per turn.  The rows in flight on an XCD are therefore neighbours, and the x
+//    entries gathered for mesh row i (columns i-nx-1 .. i+nx+1) are still in L2 when rows i+-nx use
+//    them: FETCH_SIZE drops from 1.31x to 1.05x of the algorithmic bytes.
+//  * optional epilogue: dot_with[row]*y[row] summed over the wave with shuffles, over the workgroup
+//    through LDS, one partial per workgroup (deterministic, no float atomics).
 #include "common.hpp"
 
 namespace padne {
@@ -41,63 +44,72 @@ __device__ __forceinline__ double block_sum_256(double v, double *red) {
     return s;
 }
 
+constexpr int kEpl = 8;                 // elements per lane per pass
+constexpr int kWaveChunk = 64 * kEpl;   // non-zeros parked in LDS per wave per pass (4 KiB)
+
 template <bool WITH_DOT>
 __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
-    const int n_rows, const int n_tiles, const int *__restrict__ rowptr,
+    const int n_rows, const int n_wtiles, const int *__restrict__ rowptr,
     const int *__restrict__ cols, const double *__restrict__ vals,
     const double *__restrict__ x, double *__restrict__ y,
     const double *__restrict__ dot_with, double *__restrict__ partials,
     const int *__restrict__ done_flag) {
-    __shared__ __attribute__((aligned(16))) double prod[kSpmvTileNnz];
+    __shared__ double prod_all[4 * kWaveChunk];
     __shared__ double red[4];
 
     if (done_flag != nullptr && *done_flag != 0) return;
 
-    const int tid = threadIdx.x;
-    // XCD-aware tile assignment: workgroups b, b+8, b+16, ... share an XCD (and its L2);
-    // give them consecutive slabs of tiles.
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double *prod = prod_all + w * kWaveChunk;
     const int G = gridDim.x;
-    const int per_xcd = G / kNumXcd;                     // G is a multiple of 8 (or < 8)
-    int vb = blockIdx.x;
-    if (per_xcd > 0 && G % kNumXcd == 0) vb = (blockIdx.x % kNumXcd) * per_xcd + blockIdx.x / kNumXcd;
-    const long long t0 = (long long)vb * n_tiles / G;
-    const long long t1 = (long long)(vb + 1) * n_tiles / G;
+    // slabs: one per XCD when the grid is a multiple of 8, otherwise a single slab
+    const int nslab = (G % kNumXcd == 0) ? kNumXcd : 1;
+    const int slab = blockIdx.x % nslab;
+    const int wx = (blockIdx.x / nslab) * 4 + w;       // wave index inside the slab
+    const int wps = (G / nslab) * 4;                   // waves per slab
+    const int s0 = (int)((long long)slab * n_wtiles / nslab);
+    const int s1 = (int)((long long)(slab + 1) * n_wtiles / nslab);
 
     double dot_acc = 0.0;
-
-    for (int tile = (int)t0; tile < (int)t1; ++tile) {
-        const int row0 = tile * kSpmvRows;
-        const int row1 = min(row0 + kSpmvRows, n_rows);
-        const int k0 = rowptr[row0];
-        const int k1 = rowptr[row1];
-        const int r = row0 + tid;
+    for (int wt = s0 + wx; wt < s1; wt += wps) {
+        const int row0 = wt * 64;
+        const int row1 = min(row0 + 64, n_rows);
+        const int r = row0 + lane;
         int rs = 0, re = 0;
         if (r < row1) {
             rs = rowptr[r];
             re = rowptr[r + 1];
         }
+        const int k0 = __shfl(rs, 0, 64);
+        const int k1 = __shfl(re, row1 - row0 - 1, 64);
         double acc = 0.0;
-        for (int base = k0 & ~3; base < k1; base += kSpmvTileNnz) {
+        for (int base = k0; base < k1; base += kWaveChunk) {
+            int c[kEpl];
+            double v[kEpl];
 #pragma unroll
-            for (int j = 0; j < kSpmvTileNnz / (4 * kSpmvThreads); ++j) {
-                const int l = 4 * (tid + kSpmvThreads * j);
-                const int e = base + l;
-                const int4 c = *reinterpret_cast<const int4 *>(cols + e);
-                const double2 v01 = *reinterpret_cast<const double2 *>(vals + e);
-                const double2 v23 = *reinterpret_cast<const double2 *>(vals + e + 2);
-                const double x0 = x[c.x], x1 = x[c.y], x2 = x[c.z], x3 = x[c.w];
-                double2 p01, p23;
-                p01.x = v01.x * x0;
-                p01.y = v01.y * x1;
-                p23.x = v23.x * x2;
-                p23.y = v23.y * x3;
-                *reinterpret_cast<double2 *>(prod + l) = p01;
-                *reinterpret_cast<double2 *>(prod + l + 2) = p23;
+            for (int j = 0; j < kEpl; ++j) {
+                const int e = base + lane + 64 * j;
+                c[j] = 0;
+                v[j] = 0.0;
+                if (e < k1) {
+                    c[j] = cols[e];
+                    v[j] = vals[e];
+                }
             }
-            __syncthreads();
-            const int lo = max(rs, base), hi = min(re, base + kSpmvTileNnz);
+#pragma unroll
+            for (int j = 0; j < kEpl; ++j) {
+                const int e = base + lane + 64 * j;
+                double xv = 0.0;
+                if (e < k1) xv = x[c[j]];
+                prod[lane + 64 * j] = v[j] * xv;
+            }
+            // same-wave LDS traffic is processed in issue order; keep the compiler from reordering
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const int lo = max(rs, base), hi = min(re, base + kWaveChunk);
             for (int k = lo; k < hi; ++k) acc += prod[k - base];
-            __syncthreads();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
         }
         if (r < row1) {
             y[r] = acc;
@@ -106,12 +118,12 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
     }
     if (WITH_DOT) {
         const double s = block_sum_256(dot_acc, red);
-        if (tid == 0) partials[blockIdx.x] = s;
+        if (threadIdx.x == 0) partials[blockIdx.x] = s;
     }
 }
 
 int spmv_grid(const padne_csr *m) {
-    const long long n_tiles = (m->n_rows + kSpmvRows - 1) / kSpmvRows;
+    const long long n_tiles = (m->n_rows + kSpmvRows - 1) / kSpmvRows;   // 4 wave-tiles per workgroup-turn
     long long g = n_tiles < kMaxPartials ? n_tiles : kMaxPartials;
     if (g >= kNumXcd) g -= g % kNumXcd;
     if (g < 1) g = 1;
@@ -121,7 +133,7 @@ int spmv_grid(const padne_csr *m) {
 int launch_spmv(padne_ctx *ctx, const padne_csr *m, const double *x, double *y,
                 const double *dot_with, double *partials, const int32_t *done_flag) {
     if (m->n_rows == 0) return PADNE_OK;
-    const int n_tiles = (int)((m->n_rows + kSpmvRows - 1) / kSpmvRows);
+    const int n_tiles = (int)((m->n_rows + 63) / 64);   // wave-tiles of 64 rows
     const int g = spmv_grid(m);
     if (dot_with != nullptr) {
         hipLaunchKernelGGL(csr_spmv_kernel<true>, dim3(g), dim3(kSpmvThreads), 0, ctx->stream,

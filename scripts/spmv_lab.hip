@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
@@ -18,7 +19,7 @@ __device__ __forceinline__ int vblock(int G) {
 }
 
 // ---- V0/V1: LDS-staged, TILE nnz per pass, ROWS rows per tile, optional non-temporal streams ----
-template <int TILE, int ROWS, bool NT>
+template <int TILE, int ROWS, bool NT, bool PRED = false>
 __global__ __launch_bounds__(256) void spmv_lds(int n_rows, int n_tiles, const int *__restrict__ rowptr,
                                                 const int *__restrict__ cols, const double *__restrict__ vals,
                                                 const double *__restrict__ x, double *__restrict__ y) {
@@ -46,8 +47,10 @@ __global__ __launch_bounds__(256) void spmv_lds(int n_rows, int n_tiles, const i
             for (int j = 0; j < TILE / 1024; ++j) {
                 const int l = 4 * (tid + 256 * j);
                 const int e = base + l;
-                int4 c; double2 v01, v23;
-                if (NT) {
+                int4 c = make_int4(0, 0, 0, 0); double2 v01 = make_double2(0, 0), v23 = make_double2(0, 0);
+                if (PRED && e >= k1) {
+                    // nothing to fetch: this quad belongs to the next tile
+                } else if (NT) {
                     c.x = __builtin_nontemporal_load(cols + e); c.y = __builtin_nontemporal_load(cols + e + 1);
                     c.z = __builtin_nontemporal_load(cols + e + 2); c.w = __builtin_nontemporal_load(cols + e + 3);
                     v01.x = __builtin_nontemporal_load(vals + e); v01.y = __builtin_nontemporal_load(vals + e + 1);
@@ -75,6 +78,165 @@ __global__ __launch_bounds__(256) void spmv_lds(int n_rows, int n_tiles, const i
         for (int q = 0; q < ROWS / 256; ++q) {
             const int r = row0 + tid + 256 * q;
             if (r < row1) y[r] = acc[q];
+        }
+    }
+}
+
+
+// ---- V6: LDS-staged, lane-consecutive element mapping (element = base + tid + 256*j): adjacent lanes
+// gather adjacent non-zeros, whose columns are mostly adjacent in x -> far fewer L1 tag lookups ----
+template <int TILE, int ROWS, int UNROLL>
+__global__ __launch_bounds__(256) void spmv_lds_lc(int n_rows, int n_tiles, const int *__restrict__ rowptr,
+                                                   const int *__restrict__ cols, const double *__restrict__ vals,
+                                                   const double *__restrict__ x, double *__restrict__ y) {
+    __shared__ double prod[TILE];
+    const int tid = threadIdx.x;
+    const int G = gridDim.x;
+    const int vb = vblock(G);
+    const long long t0 = (long long)vb * n_tiles / G, t1 = (long long)(vb + 1) * n_tiles / G;
+    for (int tile = (int)t0; tile < (int)t1; ++tile) {
+        const int row0 = tile * ROWS;
+        const int row1 = min(row0 + ROWS, n_rows);
+        const int k0 = rowptr[row0], k1 = rowptr[row1];
+        int rs[ROWS / 256], re[ROWS / 256];
+#pragma unroll
+        for (int q = 0; q < ROWS / 256; ++q) {
+            const int r = row0 + tid + 256 * q;
+            rs[q] = re[q] = 0;
+            if (r < row1) { rs[q] = rowptr[r]; re[q] = rowptr[r + 1]; }
+        }
+        double acc[ROWS / 256];
+#pragma unroll
+        for (int q = 0; q < ROWS / 256; ++q) acc[q] = 0.0;
+        for (int base = k0; base < k1; base += TILE) {
+            int c[TILE / 256];
+            double v[TILE / 256];
+#pragma unroll
+            for (int j = 0; j < TILE / 256; ++j) {
+                c[j] = cols[base + tid + 256 * j];
+                v[j] = vals[base + tid + 256 * j];
+            }
+#pragma unroll
+            for (int j = 0; j < TILE / 256; ++j) prod[tid + 256 * j] = v[j] * x[c[j]];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < ROWS / 256; ++q) {
+                const int lo = max(rs[q], base), hi = min(re[q], base + TILE);
+                for (int k = lo; k < hi; ++k) acc[q] += prod[k - base];
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int q = 0; q < ROWS / 256; ++q) {
+            const int r = row0 + tid + 256 * q;
+            if (r < row1) y[r] = acc[q];
+        }
+    }
+}
+
+
+// ---- V8: wave-private tiles (64 rows per wave), no workgroup barrier: each wave streams its own
+// non-zero range (lane-consecutive, predicated), parks products in its private 4 KiB LDS slice and
+// reduces its 64 rows.  LDS operations of one wave execute in order, so write->read needs no barrier.
+template <int EPL>
+__global__ __launch_bounds__(256) void spmv_wave(int n_rows, int n_wtiles, const int *__restrict__ rowptr,
+                                                 const int *__restrict__ cols, const double *__restrict__ vals,
+                                                 const double *__restrict__ x, double *__restrict__ y) {
+    constexpr int CH = 64 * EPL;
+    __shared__ double prod_all[4 * CH];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double *prod = prod_all + w * CH;
+    const int G = gridDim.x;
+    const int vb = vblock(G);
+    const long long W = (long long)G * 4, gw = (long long)vb * 4 + w;
+    const int t0 = (int)(gw * n_wtiles / W), t1 = (int)((gw + 1) * n_wtiles / W);
+    for (int wt = t0; wt < t1; ++wt) {
+        const int row0 = wt * 64;
+        const int row1 = min(row0 + 64, n_rows);
+        const int r = row0 + lane;
+        int rs = 0, re = 0;
+        if (r < row1) { rs = rowptr[r]; re = rowptr[r + 1]; }
+        const int k0 = __shfl(rs, 0, 64);
+        const int k1 = __shfl(re, row1 - row0 - 1, 64);
+        double acc = 0.0;
+        for (int base = k0; base < k1; base += CH) {
+            int c[EPL];
+            double v[EPL];
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const int e = base + lane + 64 * j;
+                c[j] = 0; v[j] = 0.0;
+                if (e < k1) { c[j] = cols[e]; v[j] = vals[e]; }
+            }
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const int e = base + lane + 64 * j;
+                double xv = 0.0;
+                if (e < k1) xv = x[c[j]];
+                prod[lane + 64 * j] = v[j] * xv;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const int lo = max(rs, base), hi = min(re, base + CH);
+            for (int k = lo; k < hi; ++k) acc += prod[k - base];
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (r < row1) y[r] = acc;
+    }
+}
+
+
+// ---- V9: V8 with interleaved assignment: the waves of one XCD sweep that XCD's slab of wave-tiles
+// together, CHUNK wave-tiles per wave per turn, so co-resident waves work on neighbouring rows ----
+template <int EPL, int CHUNK>
+__global__ __launch_bounds__(256) void spmv_wave_rr(int n_rows, int n_wtiles, const int *__restrict__ rowptr,
+                                                    const int *__restrict__ cols, const double *__restrict__ vals,
+                                                    const double *__restrict__ x, double *__restrict__ y) {
+    constexpr int CH = 64 * EPL;
+    __shared__ double prod_all[4 * CH];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double *prod = prod_all + w * CH;
+    const int G = gridDim.x;                       // multiple of 8
+    const int xcd = blockIdx.x % NXCD;
+    const int wx = (blockIdx.x / NXCD) * 4 + w;    // wave index inside the XCD
+    const int wpx = (G / NXCD) * 4;                // waves per XCD
+    const int s0 = (int)((long long)xcd * n_wtiles / NXCD), s1 = (int)((long long)(xcd + 1) * n_wtiles / NXCD);
+    for (int first = s0 + wx * CHUNK; first < s1; first += wpx * CHUNK) {
+        const int last = min(first + CHUNK, s1);
+        for (int wt = first; wt < last; ++wt) {
+            const int row0 = wt * 64;
+            const int row1 = min(row0 + 64, n_rows);
+            const int r = row0 + lane;
+            int rs = 0, re = 0;
+            if (r < row1) { rs = rowptr[r]; re = rowptr[r + 1]; }
+            const int k0 = __shfl(rs, 0, 64);
+            const int k1 = __shfl(re, row1 - row0 - 1, 64);
+            double acc = 0.0;
+            for (int base = k0; base < k1; base += CH) {
+                int c[EPL];
+                double v[EPL];
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) {
+                    const int e = base + lane + 64 * j;
+                    c[j] = 0; v[j] = 0.0;
+                    if (e < k1) { c[j] = cols[e]; v[j] = vals[e]; }
+                }
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) {
+                    const int e = base + lane + 64 * j;
+                    double xv = 0.0;
+                    if (e < k1) xv = x[c[j]];
+                    prod[lane + 64 * j] = v[j] * xv;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                const int lo = max(rs, base), hi = min(re, base + CH);
+                for (int k = lo; k < hi; ++k) acc += prod[k - base];
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (r < row1) y[r] = acc;
         }
     }
 }
@@ -227,7 +389,11 @@ static Mat build(int layers, int nx, int ny) {
     return m;
 }
 
+static const char *g_only = nullptr;
+static const char *g_name = nullptr;
 template <typename F> static double timeit(F launch, int reps = 30) {
+    if (g_only && !strstr(g_name, g_only)) return -1.0;
+    if (g_only) reps = 3;
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     for (int i = 0; i < 5; ++i) launch();
     CK(hipEventRecord(a));
@@ -240,6 +406,7 @@ template <typename F> static double timeit(F launch, int reps = 30) {
 
 int main(int argc, char **argv) {
     const int layers = argc > 1 ? atoi(argv[1]) : 8, nx = argc > 2 ? atoi(argv[2]) : 1118;
+    const char *only = argc > 3 ? argv[3] : nullptr;
     Mat m = build(layers, nx, nx);
     double *x, *y, *yref;
     CK(hipMalloc(&x, sizeof(double) * m.n)); CK(hipMalloc(&y, sizeof(double) * m.n)); CK(hipMalloc(&yref, sizeof(double) * m.n));
@@ -249,6 +416,7 @@ int main(int argc, char **argv) {
     const double bytes = 12.0 * m.nnz + 20.0 * m.n + 4;
     printf("n=%d nnz=%lld bytes=%.0f\n", m.n, m.nnz, bytes);
     auto report = [&](const char *name, double t, bool check) {
+        if (t < 0) return;
         double err = -1;
         if (check) {
             std::vector<double> a(m.n), b(m.n);
@@ -260,6 +428,8 @@ int main(int argc, char **argv) {
         printf("%-34s %8.1f us  %7.1f GB/s  %5.1f%%  maxdiff=%g\n", name, t * 1e6, bytes / t / 1e9, bytes / t / 8e10, err);
         fflush(stdout);
     };
+    g_only = only;
+#define RUN(NAME, ...) do { g_name = NAME; report(NAME, timeit(__VA_ARGS__), true); } while (0)
     const int nt256 = (m.n + 255) / 256, nt512 = (m.n + 511) / 512;
     auto G = [](int nt, int cap) { int g = nt < cap ? nt : cap; if (g >= 8) g -= g % 8; return g < 1 ? 1 : g; };
     // reference result
@@ -268,20 +438,37 @@ int main(int argc, char **argv) {
     for (int cap : {1024, 2048, 4096, 8192}) {
         char nm[64];
         snprintf(nm, 64, "lds 2048/256 grid<=%d", cap);
-        report(nm, timeit([&] { spmv_lds<2048, 256, false><<<G(nt256, cap), 256>>>(m.n, nt256, m.rowptr, m.cols, m.vals, x, y); }), true);
+        RUN(nm, [&] { spmv_lds<2048, 256, false><<<G(nt256, cap), 256>>>(m.n, nt256, m.rowptr, m.cols, m.vals, x, y); });
     }
-    report("lds 2048/256 nontemporal", timeit([&] { spmv_lds<2048, 256, true><<<G(nt256, 2048), 256>>>(m.n, nt256, m.rowptr, m.cols, m.vals, x, y); }), true);
-    report("lds 4096/512", timeit([&] { spmv_lds<4096, 512, false><<<G(nt512, 2048), 256>>>(m.n, nt512, m.rowptr, m.cols, m.vals, x, y); }), true);
-    report("lds 4096/512 grid 1024", timeit([&] { spmv_lds<4096, 512, false><<<G(nt512, 1024), 256>>>(m.n, nt512, m.rowptr, m.cols, m.vals, x, y); }), true);
+    RUN("lanecons 2048/256", [&] { spmv_lds_lc<2048, 256, 0><<<G(nt256, 2048), 256>>>(m.n, nt256, m.rowptr, m.cols, m.vals, x, y); });
+    RUN("lanecons 2048/256 grid 8192", [&] { spmv_lds_lc<2048, 256, 0><<<G(nt256, 8192), 256>>>(m.n, nt256, m.rowptr, m.cols, m.vals, x, y); });
+    RUN("lanecons 4096/512", [&] { spmv_lds_lc<4096, 512, 0><<<G(nt512, 2048), 256>>>(m.n, nt512, m.rowptr, m.cols, m.vals, x, y); });
+    RUN("lanecons 4096/512 grid 8192", [&] { spmv_lds_lc<4096, 512, 0><<<G(nt512, 8192), 256>>>(m.n, nt512, m.rowptr, m.cols, m.vals, x, y); });
+    RUN("lds 2048/256 predicated", [&] { spmv_lds<2048, 256, false, true><<<G(nt256, 2048), 256>>>(m.n, nt256, m.rowptr, m.cols, m.vals, x, y); });
+    RUN("lds 2048/256 predicated grid 8192", [&] { spmv_lds<2048, 256, false, true><<<G(nt256, 8192), 256>>>(m.n, nt256, m.rowptr, m.cols, m.vals, x, y); });
+    { const int nwt = (m.n + 63) / 64;
+      RUN("wave-private epl8 grid 2048", [&] { spmv_wave<8><<<2048, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); });
+      RUN("wave-private epl8 grid 8192", [&] { spmv_wave<8><<<8192, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); });
+      RUN("wave-private epl8 grid 16384", [&] { spmv_wave<8><<<16384, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); }); }
+    { const int nwt = (m.n + 63) / 64;
+      RUN("wave-rr chunk1 grid 2048", [&] { spmv_wave_rr<8, 1><<<2048, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); });
+      RUN("wave-rr chunk2 grid 2048", [&] { spmv_wave_rr<8, 2><<<2048, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); });
+      RUN("wave-rr chunk4 grid 2048", [&] { spmv_wave_rr<8, 4><<<2048, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); });
+      RUN("wave-rr chunk8 grid 2048", [&] { spmv_wave_rr<8, 8><<<2048, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); });
+      RUN("wave-rr chunk4 grid 1024", [&] { spmv_wave_rr<8, 4><<<1024, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); });
+      RUN("wave-rr chunk4 grid 1536", [&] { spmv_wave_rr<8, 4><<<1536, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); }); }
+    RUN("lds 2048/256 nontemporal", [&] { spmv_lds<2048, 256, true><<<G(nt256, 2048), 256>>>(m.n, nt256, m.rowptr, m.cols, m.vals, x, y); });
+    RUN("lds 4096/512", [&] { spmv_lds<4096, 512, false><<<G(nt512, 2048), 256>>>(m.n, nt512, m.rowptr, m.cols, m.vals, x, y); });
+    RUN("lds 4096/512 grid 1024", [&] { spmv_lds<4096, 512, false><<<G(nt512, 1024), 256>>>(m.n, nt512, m.rowptr, m.cols, m.vals, x, y); });
     for (int cap : {1024, 2048, 4096})  {
         char nm[64];
         snprintf(nm, 64, "pipelined 2048/256 grid<=%d", cap);
-        report(nm, timeit([&] { spmv_pipe<<<G(nt256, cap), 256>>>(m.n, nt256, m.rowptr, m.cols, m.vals, x, y); }), true);
+        RUN(nm, [&] { spmv_pipe<<<G(nt256, cap), 256>>>(m.n, nt256, m.rowptr, m.cols, m.vals, x, y); });
     }
-    report("subwave 8 lanes/row", timeit([&] { spmv_subwave<8><<<8192, 256>>>(m.n, m.rowptr, m.cols, m.vals, x, y); }), true);
-    report("subwave 4 lanes/row", timeit([&] { spmv_subwave<4><<<8192, 256>>>(m.n, m.rowptr, m.cols, m.vals, x, y); }), true);
-    report("subwave 2 lanes/row", timeit([&] { spmv_subwave<2><<<8192, 256>>>(m.n, m.rowptr, m.cols, m.vals, x, y); }), true);
-    report("subwave 1 lane/row", timeit([&] { spmv_subwave<1><<<8192, 256>>>(m.n, m.rowptr, m.cols, m.vals, x, y); }), true);
-    report("stream cols+vals only (bound)", timeit([&] { stream_ref<<<2048, 256>>>(m.nnz / 4, (const int4 *)m.cols, (const double2 *)m.vals, y); }), false);
+    RUN("subwave 8 lanes/row", [&] { spmv_subwave<8><<<8192, 256>>>(m.n, m.rowptr, m.cols, m.vals, x, y); });
+    RUN("subwave 4 lanes/row", [&] { spmv_subwave<4><<<8192, 256>>>(m.n, m.rowptr, m.cols, m.vals, x, y); });
+    RUN("subwave 2 lanes/row", [&] { spmv_subwave<2><<<8192, 256>>>(m.n, m.rowptr, m.cols, m.vals, x, y); });
+    RUN("subwave 1 lane/row", [&] { spmv_subwave<1><<<8192, 256>>>(m.n, m.rowptr, m.cols, m.vals, x, y); });
+    g_name = "stream"; report("stream cols+vals only (bound)", timeit([&] { stream_ref<<<2048, 256>>>(m.nnz / 4, (const int4 *)m.cols, (const double2 *)m.vals, y); }), false);
     return 0;
 }
