@@ -128,10 +128,12 @@ typedef struct padne_solve_opts {
     double  rtol;        /* stop when ||b - A x||_2 <= max(rtol*||b||_2, atol)            */
     double  atol;
     int32_t max_iter;
-    int32_t precond;     /* 0 = Jacobi                                                    */
+    int32_t precond;     /* 0 = Jacobi, 1 = smoothed-aggregation multigrid V-cycle (single GPU;
+                            the hierarchy is built on first use and cached on the matrix)  */
     int32_t check_every; /* iterations enqueued between host convergence polls (0 = auto) */
     int32_t flags;       /* bit0: x holds an initial guess (otherwise x0 = 0)
-                            bit1: time every 16th SpMV launch with HIP events -> info.spmv_seconds */
+                            bit1: time sampled SpMV launches with HIP events -> info.spmv_seconds
+                            bit2: rebuild the multigrid hierarchy even if one is cached          */
 } padne_solve_opts;
 
 typedef struct padne_solve_info {
@@ -143,6 +145,10 @@ typedef struct padne_solve_info {
     double  spmv_seconds;    /* average device time of one SpMV launch (flags bit1) */
     int32_t status;          /* PADNE_OK / PADNE_E_NOTCONVERGED / PADNE_E_BREAKDOWN */
     int32_t n_rhs;
+    double  precond_setup_seconds; /* device time of the multigrid setup done inside this call (0 if cached) */
+    double  operator_complexity;   /* sum of nnz over the levels / nnz of the fine matrix                    */
+    int32_t levels;                /* multigrid levels (0 with Jacobi)                                       */
+    int32_t reserved;
 } padne_solve_info;
 
 /* Preconditioned CG on an SPD CSR matrix: replaces scipy.sparse.linalg.spsolve in
@@ -153,6 +159,14 @@ int padne_solve_spd(padne_ctx *ctx, const padne_csr *a, const double *b_host, do
 /* same with device-resident b and x */
 int padne_solve_spd_dev(padne_ctx *ctx, const padne_csr *a, const void *b_dev, void *x_dev,
                         int32_t n_rhs, const padne_solve_opts *opts, padne_solve_info *info);
+
+/* z = M^-1 r: one V-cycle of the multigrid preconditioner (built on first use and cached on `a`);
+ * host vectors.  Exposed for tests: M must be symmetric positive definite for PCG to apply. */
+int padne_amg_apply(padne_ctx *ctx, padne_csr *a, const double *r_host, double *z_host);
+
+/* introspection: borrowed handle of a hierarchy operator (which: 0 = A_l, 1 = P_l, 2 = R_l = P_l^T);
+ * it stays valid as long as `a` does and must NOT be destroyed */
+int padne_amg_level(padne_ctx *ctx, padne_csr *a, int level, int which, const padne_csr **out);
 
 /* ---- post-processing ----------------------------------------------------------------------- */
 /* per-face power density  p = sigma*|grad V|^2 with the reference's barycentric difference

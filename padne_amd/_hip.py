@@ -41,7 +41,8 @@ class SolveOpts(C.Structure):
 class SolveInfo(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("restarts", C.c_int32), ("rel_residual", C.c_double),
                 ("abs_residual", C.c_double), ("solve_seconds", C.c_double), ("spmv_seconds", C.c_double),
-                ("status", C.c_int32), ("n_rhs", C.c_int32)]
+                ("status", C.c_int32), ("n_rhs", C.c_int32), ("precond_setup_seconds", C.c_double),
+                ("operator_complexity", C.c_double), ("levels", C.c_int32), ("reserved", C.c_int32)]
 
 
 _P = C.c_void_p
@@ -80,6 +81,8 @@ SIGNATURES = {
     "padne_residual_norm": (C.c_int, [_P, _P, _PF64, _PF64, _PF64]),
     "padne_solve_spd": (C.c_int, [_P, _P, _PF64, _PF64, C.c_int32, C.POINTER(SolveOpts), C.POINTER(SolveInfo)]),
     "padne_solve_spd_dev": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(SolveOpts), C.POINTER(SolveInfo)]),
+    "padne_amg_apply": (C.c_int, [_P, _P, _PF64, _PF64]),
+    "padne_amg_level": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
     "padne_power_density": (C.c_int, [_P, _I64, _PF64, _I64, _PI32, _I64, _PI64, _PI64, _PF64, _PF64, _PF64]),
     "padne_face_gradient": (C.c_int, [_P, _I64, _PF64, _I64, _PI32, _I64, _PI64, _PI64, _PF64, _PF64, _PF64]),
     "padne_spmv_algorithmic_bytes": (_I64, [_P]),
@@ -341,6 +344,9 @@ class SolveResult:
     seconds: float
     status: int
     spmv_seconds: float = 0.0
+    setup_seconds: float = 0.0
+    operator_complexity: float = 0.0
+    levels: int = 0
 
 
 class CsrMatrix:
@@ -411,13 +417,36 @@ class CsrMatrix:
                                                  C.byref(out)))
         return out.value
 
+    def amg_level(self, level: int, which: str = "A"):
+        """scipy copy of a hierarchy operator: which in 'A', 'P', 'R'."""
+        import scipy.sparse as sp
+        h = _P()
+        _check(self.ctx._lib.padne_amg_level(self.ctx._h, self._h, int(level), {"A": 0, "P": 1, "R": 2}[which], C.byref(h)))
+        nr, nc, nnz = C.c_int64(), C.c_int64(), C.c_int64()
+        _check(self.ctx._lib.padne_csr_shape(h, C.byref(nr), C.byref(nc), C.byref(nnz)))
+        indptr = np.empty(nr.value + 1, dtype=np.int32)
+        indices = np.empty(nnz.value, dtype=np.int32)
+        data = np.empty(nnz.value, dtype=np.float64)
+        _check(self.ctx._lib.padne_csr_to_host(self.ctx._h, h, _ptr(indptr, _PI32), _ptr(indices, _PI32), _ptr(data, _PF64)))
+        return sp.csr_matrix((data, indices, indptr), shape=(nr.value, nc.value))
+
+    def amg_apply(self, r) -> np.ndarray:
+        """z = M^-1 r: one multigrid V-cycle (the preconditioner of solve_spd)."""
+        r = _f64(r)
+        if r.shape[0] != self.shape[0]:
+            raise ValueError("dimension mismatch")
+        z = np.empty_like(r)
+        _check(self.ctx._lib.padne_amg_apply(self.ctx._h, self._h, _ptr(r, _PF64), _ptr(z, _PF64)))
+        return z
+
     @staticmethod
-    def _opts(rtol, atol, max_iter, check_every, guess, time_spmv=False) -> SolveOpts:
-        return SolveOpts(float(rtol), float(atol), int(max_iter), 0, int(check_every),
-                         (1 if guess else 0) | (2 if time_spmv else 0))
+    def _opts(rtol, atol, max_iter, check_every, guess, time_spmv=False, precond="jacobi", rebuild=False) -> SolveOpts:
+        pc = {"jacobi": 0, "amg": 1, 0: 0, 1: 1}[precond]
+        return SolveOpts(float(rtol), float(atol), int(max_iter), pc, int(check_every),
+                         (1 if guess else 0) | (2 if time_spmv else 0) | (4 if rebuild else 0))
 
     def solve_spd(self, b, *, rtol=1e-12, atol=0.0, max_iter=200000, check_every=0, x0=None,
-                  raise_on_fail=True) -> SolveResult:
+                  raise_on_fail=True, precond="amg", rebuild=False) -> SolveResult:
         """Jacobi-PCG on the device; b is host f64[n] or f64[k, n]."""
         b = _f64(b)
         n = self.shape[0] if self.ctx.halo_n_owned is None else self.ctx.halo_n_owned
@@ -425,22 +454,25 @@ class CsrMatrix:
         if b.shape[-1] != n:
             raise ValueError("right-hand side has the wrong length")
         x = np.zeros_like(b) if x0 is None else _f64(x0).copy()
-        opts = self._opts(rtol, atol, max_iter, check_every, x0 is not None)
+        opts = self._opts(rtol, atol, max_iter, check_every, x0 is not None, precond=precond, rebuild=rebuild)
         info = SolveInfo()
         rc = self.ctx._lib.padne_solve_spd(self.ctx._h, self._h, _ptr(b, _PF64), _ptr(x, _PF64), k,
                                            C.byref(opts), C.byref(info))
         if rc != OK and (raise_on_fail or rc != E_NOTCONVERGED):
             _check(rc)
         return SolveResult(x, info.iterations, info.restarts, info.rel_residual, info.abs_residual,
-                           info.solve_seconds, info.status)
+                           info.solve_seconds, info.status, info.spmv_seconds, info.precond_setup_seconds,
+                           info.operator_complexity, info.levels)
 
     def solve_spd_dev(self, b: DeviceArray, x: DeviceArray, *, n_rhs=1, rtol=1e-12, atol=0.0, max_iter=200000,
-                      check_every=0, guess=False, raise_on_fail=True, time_spmv=False) -> SolveResult:
-        opts = self._opts(rtol, atol, max_iter, check_every, guess, time_spmv)
+                      check_every=0, guess=False, raise_on_fail=True, time_spmv=False, precond="amg",
+                      rebuild=False) -> SolveResult:
+        opts = self._opts(rtol, atol, max_iter, check_every, guess, time_spmv, precond, rebuild)
         info = SolveInfo()
         rc = self.ctx._lib.padne_solve_spd_dev(self.ctx._h, self._h, _P(b.ptr), _P(x.ptr), int(n_rhs),
                                                C.byref(opts), C.byref(info))
         if rc != OK and (raise_on_fail or rc != E_NOTCONVERGED):
             _check(rc)
         return SolveResult(None, info.iterations, info.restarts, info.rel_residual, info.abs_residual,
-                           info.solve_seconds, info.status, info.spmv_seconds)
+                           info.solve_seconds, info.status, info.spmv_seconds, info.precond_setup_seconds,
+                           info.operator_complexity, info.levels)

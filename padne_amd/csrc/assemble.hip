@@ -102,8 +102,40 @@ __global__ __launch_bounds__(256) void scan_apply(const int *__restrict__ in, lo
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = (int)(*total);
 }
 
+__global__ void sum_i32_as_i64(const int *__restrict__ in, long long n, unsigned long long *__restrict__ out,
+                               int *__restrict__ negative) {
+    long long s = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int v = in[i];
+        if (v < 0) atomicExch(negative, 1);
+        s += v;
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0 && s != 0) atomicAdd(out, (unsigned long long)s);
+}
+
 int exclusive_scan_i32(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t n, int64_t *total) {
     const int nb = (int)((n + kScanChunk - 1) / kScanChunk);
+    {   // exact 64-bit total first: the 32-bit scan below must not overflow silently
+        unsigned long long *d_tot = nullptr;
+        PADNE_HIP_CHECK(hipMalloc((void **)&d_tot, 16));
+        PADNE_HIP_CHECK(hipMemsetAsync(d_tot, 0, 16, ctx->stream));
+        if (n > 0)
+            hipLaunchKernelGGL(sum_i32_as_i64, dim3((unsigned)(nb < 1024 ? (nb > 0 ? nb : 1) : 1024)), dim3(256), 0,
+                               ctx->stream, in, (long long)n, d_tot, (int *)(d_tot + 1));
+        unsigned long long h2[2] = {0, 0};
+        hipError_t e2 = hipMemcpyAsync(h2, d_tot, 16, hipMemcpyDeviceToHost, ctx->stream);
+        if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d_tot);
+        if (e2 != hipSuccess) {
+            set_error("scan failed: %s", hipGetErrorString(e2));
+            return PADNE_E_HIP;
+        }
+        if (h2[0] >= 2147483647ULL || (h2[1] & 0xffffffffULL) != 0) {
+            set_error("scan total %llu overflows int32 indices", h2[0]);
+            return PADNE_E_INVALID;
+        }
+    }
     long long *bs = nullptr;
     PADNE_HIP_CHECK(hipMalloc((void **)&bs, sizeof(long long) * (size_t)(nb + 2)));
     long long *tot = bs + nb;
@@ -411,23 +443,6 @@ __global__ void power_density_kernel(long long n_tri, const int *__restrict__ tr
 }
 
 // ---- host orchestration ----------------------------------------------------------------------
-struct Scratch {   // frees everything on scope exit
-    std::vector<void *> ptrs;
-    ~Scratch() { for (void *p : ptrs) if (p) hipFree(p); }
-    template <typename T> int alloc(T **out, size_t count) {
-        void *p = nullptr;
-        if (hipMalloc(&p, sizeof(T) * (count ? count : 1)) != hipSuccess) {
-            set_error("hipMalloc of %zu bytes failed during assembly", sizeof(T) * count);
-            return PADNE_E_NOMEM;
-        }
-        ptrs.push_back(p);
-        *out = (T *)p;
-        return PADNE_OK;
-    }
-};
-
-static inline unsigned nblk(long long n, int bs = 256) { return (unsigned)((n + bs - 1) / bs > 0 ? (n + bs - 1) / bs : 1); }
-
 // shared tail: slots (key,val,slot_ptr) already filled -> merged CSR
 template <bool MESH>
 static int finish_rows(padne_ctx *ctx, Scratch &sc, long long n_rows, long long n_cols, long long n_vert, int n_mesh,
@@ -455,6 +470,44 @@ static int finish_rows(padne_ctx *ctx, Scratch &sc, long long n_rows, long long 
     hipError_t e = hipMemcpyAsync(m->rowptr, rowptr_tmp, sizeof(int32_t) * (size_t)(n_rows + 1),
                                   hipMemcpyDeviceToDevice, s);
     if (e == hipSuccess) {
+        hipLaunchKernelGGL(compact_rows, dim3(nblk(n_rows)), dim3(256), 0, s, n_rows, slot_ptr, m->rowptr, key, val,
+                           m->cols, m->vals);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        set_error("row compaction failed: %s", hipGetErrorString(e));
+        padne_csr_destroy(m);
+        return PADNE_E_HIP;
+    }
+    *out = m;
+    return PADNE_OK;
+}
+
+
+// exported to amg.hip --------------------------------------------------------------------------
+int merge_slots_generic(padne_ctx *ctx, long long n_rows, const int *slot_ptr, long long *key, double *val,
+                        int *row_len) {
+    hipLaunchKernelGGL(merge_rows<false>, dim3(nblk(n_rows, 128)), dim3(128), 0, ctx->stream, n_rows, 0LL, 0,
+                       (const long long *)nullptr, (const double *)nullptr, slot_ptr, key, val, row_len,
+                       (int *)nullptr);
+    PADNE_HIP_CHECK(hipGetLastError());
+    return PADNE_OK;
+}
+
+int csr_from_slots(padne_ctx *ctx, long long n_rows, long long n_cols, const int *slot_ptr, const long long *key,
+                   const double *val, const int *row_len, padne_csr **out) {
+    hipStream_t s = ctx->stream;
+    Scratch sc;
+    int *rowptr_tmp = nullptr;
+    PADNE_TRY(sc.alloc(&rowptr_tmp, (size_t)n_rows + 1));
+    int64_t nnz = 0;
+    PADNE_TRY(exclusive_scan_i32(ctx, row_len, rowptr_tmp, n_rows, &nnz));
+    padne_csr *m = nullptr;
+    PADNE_TRY(csr_alloc(ctx, n_rows, n_cols, nnz, &m));
+    hipError_t e = hipMemcpyAsync(m->rowptr, rowptr_tmp, sizeof(int32_t) * (size_t)(n_rows + 1),
+                                  hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess && n_rows > 0) {
         hipLaunchKernelGGL(compact_rows, dim3(nblk(n_rows)), dim3(256), 0, s, n_rows, slot_ptr, m->rowptr, key, val,
                            m->cols, m->vals);
         e = hipGetLastError();

@@ -227,6 +227,7 @@ int padne_csr_destroy(padne_csr *m) {
     if (m->cols) hipFree(m->cols);
     if (m->vals) hipFree(m->vals);
     if (m->dinv) hipFree(m->dinv);
+    if (m->amg) amg_destroy(m->amg);
     delete m;
     return PADNE_OK;
 }

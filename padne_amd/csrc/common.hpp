@@ -64,6 +64,7 @@ struct padne_csr {
     double *vals = nullptr;      // [nnz + pad]   padding entries are 0.0
     double *dinv = nullptr;      // [n_rows] 1/diag, built on first use (square matrices)
     int device = 0;
+    void *amg = nullptr;         // cached multigrid hierarchy (padne::Amg*), owned
 };
 
 struct padne_ctx {
@@ -99,6 +100,10 @@ int launch_spmv(padne_ctx *ctx, const padne_csr *m, const double *x, double *y,
                 const double *dot_with /* may be null */, double *partials /* may be null */,
                 const int32_t *done_flag /* may be null */);
 int spmv_grid(const padne_csr *m);
+enum { SPMV_PLAIN = 0, SPMV_DOT = 1, SPMV_RESID = 2, SPMV_ADD = 3, SPMV_JACOBI = 4 };
+int launch_spmv_mode(padne_ctx *ctx, const padne_csr *m, int mode, const double *x, double *y,
+                     const double *dot_with, double *partials, const int32_t *done_flag, const double *aux1,
+                     const double *aux2, double scale);
 
 // exclusive scan of int32 counts into int32 offsets (n+1 outputs); returns total via host
 int exclusive_scan_i32(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t n, int64_t *total);
@@ -107,5 +112,36 @@ int exclusive_scan_i32(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t 
 int comm_allreduce_sum_f64(padne_ctx *ctx, double *dev_buf, int count);
 int comm_allgather_f64(padne_ctx *ctx, const double *send, double *recv, int count_per_rank);
 void comm_destroy(padne_ctx *ctx);
+
+// amg.hip
+void amg_destroy(void *amg);
+// pcg.hip: largest eigenvalue of D^-1 A from `steps` Lanczos (Jacobi-PCG) steps
+int estimate_lambda_max(padne_ctx *ctx, const padne_csr *a, int steps, double *lambda);
+
+// assemble.hip helpers shared with amg.hip
+struct Scratch {   // device allocations freed on scope exit
+    std::vector<void *> ptrs;
+    ~Scratch() { for (void *p : ptrs) if (p) (void)hipFree(p); }
+    template <typename T> int alloc(T **out, size_t count) {
+        void *p = nullptr;
+        if (hipMalloc(&p, sizeof(T) * (count ? count : 1)) != hipSuccess) {
+            set_error("hipMalloc of %zu bytes failed", sizeof(T) * count);
+            return PADNE_E_NOMEM;
+        }
+        ptrs.push_back(p);
+        *out = (T *)p;
+        return PADNE_OK;
+    }
+};
+static inline unsigned nblk(long long n, int bs = 256) {
+    const long long b = (n + bs - 1) / bs;
+    return (unsigned)(b > 0 ? b : 1);
+}
+// sort each row's slots by key = (col << 32 | seq), add duplicates in key order, compact in place
+int merge_slots_generic(padne_ctx *ctx, long long n_rows, const int *slot_ptr, long long *key, double *val,
+                        int *row_len);
+// rows already compacted at their slot offsets (key >> 32 = column) -> new CSR matrix
+int csr_from_slots(padne_ctx *ctx, long long n_rows, long long n_cols, const int *slot_ptr, const long long *key,
+                   const double *val, const int *row_len, padne_csr **out);
 
 }  // namespace padne

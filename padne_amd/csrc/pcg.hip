@@ -188,6 +188,76 @@ __global__ __launch_bounds__(256) void residual_kernel(const long long n, const 
     block_store_partial(rr, red, part_rr + blockIdx.x);
 }
 
+// ---- kernels of the multigrid-preconditioned loop (z comes from amg_apply) --------------------------
+// alpha = rz/pq ; x += alpha p ; r -= alpha q ; partial r.r
+__global__ __launch_bounds__(256) void pcg_update_xr_plain_kernel(
+    const long long n, const double *__restrict__ part_rz, const int P_rz, const double *__restrict__ part_pq,
+    const int P_pq, const double *__restrict__ p, const double *__restrict__ q, double *__restrict__ x,
+    double *__restrict__ r, double *__restrict__ part_rr, PcgStatus *__restrict__ st) {
+    __shared__ double red[4];
+    if (st->done) return;
+    const double rz = block_total(part_rz, P_rz, red);
+    const double pq = block_total(part_pq, P_pq, red);
+    const double alpha = rz / pq;
+    double s_rr = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const double ri = r[i] - alpha * q[i];
+        x[i] += alpha * p[i];
+        r[i] = ri;
+        s_rr += ri * ri;
+    }
+    block_store_partial(s_rr, red, part_rr + blockIdx.x);
+}
+
+// beta = rz'/rz ; p = z + beta p ; bookkeeping
+__global__ __launch_bounds__(256) void pcg_update_p_z_kernel(
+    const long long n, const double *__restrict__ part_rz_new, const double *__restrict__ part_rz_old,
+    const int P_rz, const double *__restrict__ part_rr, const int P_rr, const double *__restrict__ part_pq,
+    const int P_pq, const double *__restrict__ z, double *__restrict__ p, PcgStatus *__restrict__ st,
+    const int max_iter) {
+    __shared__ double red[4];
+    if (st->done) return;
+    const double rz_new = block_total(part_rz_new, P_rz, red);
+    const double rz_old = block_total(part_rz_old, P_rz, red);
+    const double beta = rz_new / rz_old;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        p[i] = z[i] + beta * p[i];
+    if (blockIdx.x == 0) {
+        const double rr = block_total(part_rr, P_rr, red);
+        const double pq = block_total(part_pq, P_pq, red);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int it = st->iters + 1;
+            st->iters = it;
+            st->rr = rr;
+            if (!(pq > 0.0) || !(rr == rr) || !(rz_new > 0.0)) {
+                st->code = PADNE_E_BREAKDOWN;
+                st->done = 1;
+            } else if (rr <= st->tol2 || it >= max_iter) {
+                st->done = 1;
+            }
+        }
+    }
+}
+
+// r = b - ax (ax may be null) ; partial rr, bb
+__global__ __launch_bounds__(256) void pcg_init_plain_kernel(const long long n, const double *__restrict__ b,
+                                                             const double *__restrict__ ax, double *__restrict__ r,
+                                                             double *__restrict__ part_rr,
+                                                             double *__restrict__ part_bb) {
+    __shared__ double red[4];
+    double rr = 0.0, bb = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const double bi = b[i];
+        const double ri = ax ? bi - ax[i] : bi;
+        r[i] = ri;
+        rr += ri * ri;
+        bb += bi * bi;
+    }
+    block_store_partial(rr, red, part_rr + blockIdx.x);
+    block_store_partial(bb, red, part_bb + blockIdx.x);
+}
+
 static int vec_grid(long long n) {
     long long g = (n + 255) / 256;
     if (g > 1024) g = 1024;  // 4 workgroups per CU, grid-stride the rest
@@ -396,9 +466,275 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const double *b, double
     return PADNE_OK;
 }
 
+
+// ---- largest eigenvalue of D^-1 A from the Lanczos coefficients of a few Jacobi-PCG steps ------------
+__global__ void fill_pseudo_random(long long n, double *__restrict__ v) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        unsigned int h = (unsigned int)i * 2654435761u + 0x9e3779b9u;
+        h ^= h >> 16;
+        h *= 2246822519u;
+        h ^= h >> 13;
+        h *= 3266489917u;
+        h ^= h >> 16;
+        v[i] = (double)h * (2.0 / 4294967296.0) - 1.0;
+    }
+}
+
+static double tridiag_max_eig(const std::vector<double> &d, const std::vector<double> &e) {
+    // bisection on the Sturm count; e[k] couples d[k] and d[k+1]
+    const int m = (int)d.size();
+    double lo = d[0], hi = d[0];
+    for (int k = 0; k < m; ++k) {
+        const double r = (k > 0 ? fabs(e[k - 1]) : 0.0) + (k + 1 < m ? fabs(e[k]) : 0.0);
+        lo = std::min(lo, d[k] - r);
+        hi = std::max(hi, d[k] + r);
+    }
+    auto count_below = [&](double x) {   // number of eigenvalues < x
+        int c = 0;
+        double q = d[0] - x;
+        if (q < 0) ++c;
+        for (int k = 1; k < m; ++k) {
+            const double den = (fabs(q) < 1e-300) ? 1e-300 : q;
+            q = d[k] - x - e[k - 1] * e[k - 1] / den;
+            if (q < 0) ++c;
+        }
+        return c;
+    };
+    for (int it = 0; it < 100; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        if (count_below(mid) >= m) hi = mid; else lo = mid;
+    }
+    return 0.5 * (lo + hi);
+}
+
+int estimate_lambda_max(padne_ctx *ctx, const padne_csr *a, int steps, double *lambda) {
+    const long long n = a->n_rows;
+    PADNE_TRY(csr_build_dinv(ctx, const_cast<padne_csr *>(a)));
+    PADNE_TRY(ensure_workspace(ctx, sizeof(double) * (size_t)n * 5 + 4096));
+    double *r = (double *)ctx->ws, *p = r + n, *q = p + n, *x = q + n, *b = x + n;
+    PcgStatus *st = (PcgStatus *)ctx->status;
+    hipStream_t s = ctx->stream;
+    const int gv = vec_grid(n), gs = spmv_grid(a);
+    double *scal = ctx->scalars + 32;
+    double *h = (double *)ctx->pinned + 64;
+    PADNE_HIP_CHECK(hipMemsetAsync(st, 0, sizeof(PcgStatus), s));
+    PADNE_HIP_CHECK(hipMemsetAsync(x, 0, sizeof(double) * (size_t)n, s));
+    hipLaunchKernelGGL(fill_pseudo_random, dim3(gv), dim3(256), 0, s, n, b);
+    hipLaunchKernelGGL(pcg_init_kernel, dim3(gv), dim3(256), 0, s, n, b, (const double *)nullptr, a->dinv, r, p,
+                       slot(ctx, SLOT_RZ0), slot(ctx, SLOT_RR), slot(ctx, SLOT_BB));
+    PADNE_HIP_CHECK(hipGetLastError());
+    std::vector<double> alpha, beta;
+    int parity = 0;
+    for (int k = 0; k < steps; ++k) {
+        double *rz_old = slot(ctx, parity ? SLOT_RZ1 : SLOT_RZ0);
+        double *rz_new = slot(ctx, parity ? SLOT_RZ0 : SLOT_RZ1);
+        PADNE_TRY(launch_spmv(ctx, a, p, q, p, slot(ctx, SLOT_PQ), nullptr));
+        hipLaunchKernelGGL(pcg_update_xr_kernel, dim3(gv), dim3(256), 0, s, n, rz_old, gv, slot(ctx, SLOT_PQ), gs, p, q,
+                           a->dinv, x, r, rz_new, slot(ctx, SLOT_RR), st);
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(256), 0, s, slot(ctx, SLOT_PQ), gs, kMaxPartials, 1, scal);
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(256), 0, s, rz_old, gv, kMaxPartials, 1, scal + 1);
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(256), 0, s, rz_new, gv, kMaxPartials, 1, scal + 2);
+        hipLaunchKernelGGL(pcg_update_p_kernel, dim3(gv), dim3(256), 0, s, n, rz_new, rz_old, gv, slot(ctx, SLOT_RR), gv,
+                           slot(ctx, SLOT_PQ), gs, r, a->dinv, p, st, 1 << 30);
+        PADNE_HIP_CHECK(hipGetLastError());
+        PADNE_HIP_CHECK(hipMemcpyAsync(h, scal, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+        PADNE_HIP_CHECK(hipStreamSynchronize(s));
+        const double pq = h[0], rzo = h[1], rzn = h[2];
+        if (!(pq > 0.0) || !(rzo > 0.0)) break;
+        alpha.push_back(rzo / pq);
+        beta.push_back(rzn / rzo);
+        if (!(rzn > 0.0) || rzn < 1e-30 * rzo) break;
+        parity ^= 1;
+    }
+    const int m = (int)alpha.size();
+    if (m == 0) {
+        *lambda = 2.0;
+        return PADNE_OK;
+    }
+    std::vector<double> d((size_t)m), e((size_t)(m > 1 ? m - 1 : 0));
+    for (int k = 0; k < m; ++k) {
+        d[(size_t)k] = 1.0 / alpha[(size_t)k] + (k > 0 ? beta[(size_t)k - 1] / alpha[(size_t)k - 1] : 0.0);
+        if (k + 1 < m) e[(size_t)k] = sqrt(beta[(size_t)k]) / alpha[(size_t)k];
+    }
+    *lambda = tridiag_max_eig(d, e);
+    return PADNE_OK;
+}
+
+int amg_setup(padne_ctx *ctx, padne_csr *A0);
+int amg_apply(padne_ctx *ctx, const padne_csr *A0, const double *r, double *z, double *partials_rz,
+              const int32_t *done_flag);
+void amg_info(const padne_csr *A0, int *levels, double *complexity, double *setup_seconds, long long *coarse_n);
+const padne_csr *amg_level_matrix(const padne_csr *A0, int level, int which);
+
+// CG preconditioned by one multigrid V-cycle per iteration (single GPU)
+static int solve_one_amg(padne_ctx *ctx, const padne_csr *a, const double *b, double *x, const padne_solve_opts *o,
+                         padne_solve_info *info, bool x_is_guess) {
+    const long long n = a->n_rows;
+    PADNE_TRY(ensure_workspace(ctx, sizeof(double) * (size_t)n * 4 + 4096));
+    double *r = (double *)ctx->ws;
+    double *p = r + n;
+    double *q = p + n;
+    double *z = q + n;
+    PcgStatus *st = (PcgStatus *)ctx->status;
+    PcgStatus *hst = (PcgStatus *)ctx->pinned;
+    hipStream_t s = ctx->stream;
+    const int gv = vec_grid(n);
+    const int gs = spmv_grid(a);
+    const int max_iter = o->max_iter > 0 ? o->max_iter : 100000;
+    const int check_every = o->check_every > 0 ? o->check_every : 4;
+    double *scal = ctx->scalars;
+    PADNE_HIP_CHECK(hipMemsetAsync(st, 0, sizeof(PcgStatus), s));
+    PADNE_HIP_CHECK(hipEventRecord(ctx->ev0, s));
+    int restarts = 0, total_iters = 0, code = PADNE_OK;
+    double true_rr = 0.0, bb = 0.0, tol2 = 0.0;
+    bool have_ax = false;
+    if (x_is_guess) {
+        PADNE_TRY(launch_spmv(ctx, a, x, q, nullptr, nullptr, nullptr));
+        have_ax = true;
+    } else {
+        PADNE_HIP_CHECK(hipMemsetAsync(x, 0, sizeof(double) * (size_t)n, s));
+    }
+    const bool sample_spmv = (o->flags & 2) != 0;
+    std::vector<hipEvent_t> ev_a, ev_b;
+    long long launched = 0;
+    for (;;) {
+        hipLaunchKernelGGL(pcg_init_plain_kernel, dim3(gv), dim3(256), 0, s, n, b, have_ax ? q : nullptr, r,
+                           slot(ctx, SLOT_RR), slot(ctx, SLOT_BB));
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(256), 0, s, slot(ctx, SLOT_RR), gv, kMaxPartials, 2,
+                           scal + S_RR);
+        hipLaunchKernelGGL(pcg_set_tolerance_kernel, dim3(1), dim3(1), 0, s, st, scal + S_RR, o->rtol, o->atol,
+                           restarts > 0 ? 1 : 0);
+        PADNE_HIP_CHECK(hipGetLastError());
+        PADNE_TRY(amg_apply(ctx, a, r, z, slot(ctx, SLOT_RZ0), nullptr));
+        PADNE_HIP_CHECK(hipMemcpyAsync(p, z, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+        int parity = 0;
+        bool done = false;
+        while (!done) {
+            for (int k = 0; k < check_every; ++k) {
+                double *rz_old = slot(ctx, parity ? SLOT_RZ1 : SLOT_RZ0);
+                double *rz_new = slot(ctx, parity ? SLOT_RZ0 : SLOT_RZ1);
+                const bool sampled = sample_spmv && (launched++ % 4) == 1 && ev_a.size() < 256;
+                if (sampled) {
+                    hipEvent_t e0, e1;
+                    PADNE_HIP_CHECK(hipEventCreate(&e0));
+                    PADNE_HIP_CHECK(hipEventCreate(&e1));
+                    ev_a.push_back(e0);
+                    ev_b.push_back(e1);
+                    PADNE_HIP_CHECK(hipEventRecord(e0, s));
+                }
+                PADNE_TRY(launch_spmv(ctx, a, p, q, p, slot(ctx, SLOT_PQ), &st->done));
+                if (sampled) PADNE_HIP_CHECK(hipEventRecord(ev_b.back(), s));
+                hipLaunchKernelGGL(pcg_update_xr_plain_kernel, dim3(gv), dim3(256), 0, s, n, rz_old, gs,
+                                   slot(ctx, SLOT_PQ), gs, p, q, x, r, slot(ctx, SLOT_RR), st);
+                PADNE_TRY(amg_apply(ctx, a, r, z, rz_new, &st->done));
+                hipLaunchKernelGGL(pcg_update_p_z_kernel, dim3(gv), dim3(256), 0, s, n, rz_new, rz_old, gs,
+                                   slot(ctx, SLOT_RR), gv, slot(ctx, SLOT_PQ), gs, z, p, st, max_iter - total_iters);
+                parity ^= 1;
+            }
+            PADNE_HIP_CHECK(hipGetLastError());
+            PADNE_HIP_CHECK(hipMemcpyAsync(hst, st, sizeof(PcgStatus), hipMemcpyDeviceToHost, s));
+            PADNE_HIP_CHECK(hipStreamSynchronize(s));
+            done = hst->done != 0;
+        }
+        total_iters += hst->iters;
+        code = hst->code;
+        bb = hst->bb;
+        tol2 = hst->tol2;
+        PADNE_TRY(launch_spmv(ctx, a, x, q, nullptr, nullptr, nullptr));
+        hipLaunchKernelGGL(residual_kernel, dim3(gv), dim3(256), 0, s, n, b, q, (double *)nullptr, slot(ctx, SLOT_TMP));
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(256), 0, s, slot(ctx, SLOT_TMP), gv, kMaxPartials, 1,
+                           scal + S_TRUE);
+        PADNE_HIP_CHECK(hipGetLastError());
+        PADNE_HIP_CHECK(hipMemcpyAsync(&hst[1], scal + S_TRUE, sizeof(double), hipMemcpyDeviceToHost, s));
+        PADNE_HIP_CHECK(hipStreamSynchronize(s));
+        memcpy(&true_rr, &hst[1], sizeof(double));
+        if (code != PADNE_OK) break;
+        if (true_rr <= tol2 * 1.0000001 || total_iters >= max_iter || restarts >= 8) break;
+        ++restarts;
+        have_ax = true;
+        PADNE_HIP_CHECK(hipMemsetAsync(st, 0, 2 * sizeof(int32_t), s));
+        PADNE_HIP_CHECK(hipMemsetAsync(&st->iters, 0, sizeof(int32_t), s));
+    }
+    PADNE_HIP_CHECK(hipEventRecord(ctx->ev1, s));
+    PADNE_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    PADNE_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    if (!ev_a.empty()) {
+        std::vector<double> t_s;
+        for (size_t i = 0; i < ev_a.size(); ++i) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, ev_a[i], ev_b[i]) == hipSuccess) t_s.push_back(t * 1e-3);
+            hipEventDestroy(ev_a[i]);
+            hipEventDestroy(ev_b[i]);
+        }
+        if (info && !t_s.empty()) {
+            std::vector<double> sorted = t_s;
+            std::sort(sorted.begin(), sorted.end());
+            const double med = sorted[sorted.size() / 2];
+            double sum = 0.0;
+            int cnt = 0;
+            for (double t : t_s)
+                if (t >= 0.5 * med && t <= 2.0 * med) {
+                    sum += t;
+                    ++cnt;
+                }
+            if (cnt > 0) info->spmv_seconds = sum / cnt;
+        }
+    }
+    if (info) {
+        info->iterations += total_iters;
+        info->restarts += restarts;
+        const double rel = bb > 0 ? sqrt(true_rr / bb) : sqrt(true_rr);
+        if (rel > info->rel_residual) info->rel_residual = rel;
+        if (sqrt(true_rr) > info->abs_residual) info->abs_residual = sqrt(true_rr);
+        info->solve_seconds += ms * 1e-3;
+        if (code != PADNE_OK) info->status = code;
+        else if (true_rr > tol2 * 1.0000001 && info->status == PADNE_OK) info->status = PADNE_E_NOTCONVERGED;
+    }
+    return PADNE_OK;
+}
+
 }  // namespace padne
 
 using namespace padne;
+
+// z = M^-1 r with the multigrid V-cycle (builds the hierarchy if needed); host vectors
+extern "C" int padne_amg_apply(padne_ctx *ctx, padne_csr *a, const double *r_host, double *z_host) {
+    PADNE_REQUIRE(ctx && a && r_host && z_host, "null argument");
+    PADNE_REQUIRE(a->n_rows == a->n_cols && a->n_rows > 1024, "multigrid needs a square matrix with more than 1024 rows");
+    PADNE_HIP_CHECK(hipSetDevice(ctx->device));
+    PADNE_TRY(amg_setup(ctx, a));
+    const size_t bytes = sizeof(double) * (size_t)a->n_rows;
+    double *r = nullptr, *z = nullptr;
+    PADNE_HIP_CHECK(hipMalloc((void **)&r, bytes));
+    if (hipMalloc((void **)&z, bytes) != hipSuccess) {
+        (void)hipFree(r);
+        set_error("hipMalloc failed");
+        return PADNE_E_NOMEM;
+    }
+    int rc = PADNE_OK;
+    if (hipMemcpyAsync(r, r_host, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = PADNE_E_HIP;
+    if (rc == PADNE_OK) rc = amg_apply(ctx, a, r, z, slot(ctx, SLOT_TMP), nullptr);
+    if (rc == PADNE_OK && (hipMemcpyAsync(z_host, z, bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                           hipStreamSynchronize(ctx->stream) != hipSuccess))
+        rc = PADNE_E_HIP;
+    (void)hipFree(r);
+    (void)hipFree(z);
+    if (rc == PADNE_E_HIP) set_error("multigrid apply failed: %s", hipGetErrorString(hipGetLastError()));
+    return rc;
+}
+
+// borrowed handle of a hierarchy matrix (which: 0 = A_l, 1 = P_l, 2 = R_l); valid while `a` lives
+extern "C" int padne_amg_level(padne_ctx *ctx, padne_csr *a, int level, int which, const padne_csr **out) {
+    PADNE_REQUIRE(ctx && a && out, "null argument");
+    PADNE_TRY(amg_setup(ctx, a));
+    *out = amg_level_matrix(a, level, which);
+    if (*out == nullptr) {
+        set_error("no such multigrid level / operator");
+        return PADNE_E_INVALID;
+    }
+    return PADNE_OK;
+}
 
 extern "C" int padne_ctx_set_halo(padne_ctx *ctx, int64_t n_owned, int32_t m, int32_t n_export,
                                   const int32_t *export_idx_host) {
@@ -430,16 +766,33 @@ extern "C" int padne_solve_spd_dev(padne_ctx *ctx, const padne_csr *a, const voi
                                    int32_t n_rhs, const padne_solve_opts *opts, padne_solve_info *info) {
     PADNE_REQUIRE(ctx && a && b_dev && x_dev && opts, "null argument");
     PADNE_REQUIRE(n_rhs >= 1, "n_rhs");
-    PADNE_REQUIRE(opts->precond == 0, "only Jacobi (0) is implemented");
+    PADNE_REQUIRE(opts->precond == 0 || opts->precond == 1, "precond must be 0 (Jacobi) or 1 (multigrid)");
     PADNE_HIP_CHECK(hipSetDevice(ctx->device));
     PADNE_TRY(csr_build_dinv(ctx, const_cast<padne_csr *>(a)));
     padne_solve_info local;
     memset(&local, 0, sizeof(local));
     local.n_rhs = n_rhs;
+    // multigrid: single GPU, and only where there is something to coarsen
+    bool use_amg = opts->precond == 1 && !ctx->halo_on && ctx->comm == nullptr && a->n_rows > 1024;
+    if (use_amg) {
+        const bool fresh = a->amg == nullptr || (opts->flags & 4) != 0;
+        if (fresh && a->amg) {
+            amg_destroy(a->amg);
+            const_cast<padne_csr *>(a)->amg = nullptr;
+        }
+        PADNE_TRY(amg_setup(ctx, const_cast<padne_csr *>(a)));
+        double setup_s = 0.0;
+        amg_info(a, &local.levels, &local.operator_complexity, &setup_s, nullptr);
+        if (fresh) local.precond_setup_seconds = setup_s;
+    }
     const long long n = ctx->halo_on ? ctx->halo_n_owned : a->n_rows;
     for (int k = 0; k < n_rhs; ++k) {
-        PADNE_TRY(solve_one(ctx, a, (const double *)b_dev + (size_t)k * n, (double *)x_dev + (size_t)k * n, opts,
-                            &local, (opts->flags & 1) != 0));
+        if (use_amg)
+            PADNE_TRY(solve_one_amg(ctx, a, (const double *)b_dev + (size_t)k * n, (double *)x_dev + (size_t)k * n,
+                                    opts, &local, (opts->flags & 1) != 0));
+        else
+            PADNE_TRY(solve_one(ctx, a, (const double *)b_dev + (size_t)k * n, (double *)x_dev + (size_t)k * n, opts,
+                                &local, (opts->flags & 1) != 0));
     }
     if (info) *info = local;
     if (local.status == PADNE_E_BREAKDOWN) {

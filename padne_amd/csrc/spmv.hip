@@ -47,13 +47,22 @@ __device__ __forceinline__ double block_sum_256(double v, double *red) {
 constexpr int kEpl = 8;                 // elements per lane per pass
 constexpr int kWaveChunk = 64 * kEpl;   // non-zeros parked in LDS per wave per pass (4 KiB)
 
-template <bool WITH_DOT>
+// Epilogues (acc = (A x)[row]):
+//   SPMV_PLAIN   y = acc
+//   SPMV_DOT     y = acc ; partial sums of dot_with[row] * acc
+//   SPMV_RESID   y = aux1[row] - acc                                   (residual b - A x)
+//   SPMV_ADD     y += acc                                              (prolongation: x += P xc)
+//   SPMV_JACOBI  y = x[row] + scale * aux2[row] * (aux1[row] - acc)    (damped-Jacobi sweep, aux2 = 1/diag)
+//                optional partial sums of aux1[row] * y[row]           (r.z of the preconditioned CG)
+template <int MODE>
 __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
     const int n_rows, const int n_wtiles, const int *__restrict__ rowptr,
     const int *__restrict__ cols, const double *__restrict__ vals,
     const double *__restrict__ x, double *__restrict__ y,
     const double *__restrict__ dot_with, double *__restrict__ partials,
-    const int *__restrict__ done_flag) {
+    const int *__restrict__ done_flag, const double *__restrict__ aux1,
+    const double *__restrict__ aux2, const double scale) {
+    constexpr bool WITH_DOT = (MODE == SPMV_DOT) || (MODE == SPMV_JACOBI);
     __shared__ double prod_all[4 * kWaveChunk];
     __shared__ double red[4];
 
@@ -112,11 +121,24 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
             __builtin_amdgcn_wave_barrier();
         }
         if (r < row1) {
-            y[r] = acc;
-            if (WITH_DOT) dot_acc += dot_with[r] * acc;
+            if (MODE == SPMV_PLAIN) {
+                y[r] = acc;
+            } else if (MODE == SPMV_DOT) {
+                y[r] = acc;
+                dot_acc += dot_with[r] * acc;
+            } else if (MODE == SPMV_RESID) {
+                y[r] = aux1[r] - acc;
+            } else if (MODE == SPMV_ADD) {
+                y[r] += acc;
+            } else {
+                const double b = aux1[r];
+                const double out = x[r] + scale * aux2[r] * (b - acc);
+                y[r] = out;
+                dot_acc += b * out;
+            }
         }
     }
-    if (WITH_DOT) {
+    if (WITH_DOT && partials != nullptr) {
         const double s = block_sum_256(dot_acc, red);
         if (threadIdx.x == 0) partials[blockIdx.x] = s;
     }
@@ -130,22 +152,33 @@ int spmv_grid(const padne_csr *m) {
     return (int)g;
 }
 
-int launch_spmv(padne_ctx *ctx, const padne_csr *m, const double *x, double *y,
-                const double *dot_with, double *partials, const int32_t *done_flag) {
+int launch_spmv_mode(padne_ctx *ctx, const padne_csr *m, int mode, const double *x, double *y,
+                     const double *dot_with, double *partials, const int32_t *done_flag, const double *aux1,
+                     const double *aux2, double scale) {
     if (m->n_rows == 0) return PADNE_OK;
     const int n_tiles = (int)((m->n_rows + 63) / 64);   // wave-tiles of 64 rows
     const int g = spmv_grid(m);
-    if (dot_with != nullptr) {
-        hipLaunchKernelGGL(csr_spmv_kernel<true>, dim3(g), dim3(kSpmvThreads), 0, ctx->stream,
-                           (int)m->n_rows, n_tiles, m->rowptr, m->cols, m->vals, x, y, dot_with,
-                           partials, done_flag);
-    } else {
-        hipLaunchKernelGGL(csr_spmv_kernel<false>, dim3(g), dim3(kSpmvThreads), 0, ctx->stream,
-                           (int)m->n_rows, n_tiles, m->rowptr, m->cols, m->vals, x, y, nullptr,
-                           nullptr, done_flag);
+#define PADNE_SPMV_LAUNCH(M)                                                                           \
+    hipLaunchKernelGGL(csr_spmv_kernel<M>, dim3(g), dim3(kSpmvThreads), 0, ctx->stream, (int)m->n_rows, \
+                       n_tiles, m->rowptr, m->cols, m->vals, x, y, dot_with, partials, done_flag, aux1,  \
+                       aux2, scale)
+    switch (mode) {
+        case SPMV_PLAIN: PADNE_SPMV_LAUNCH(SPMV_PLAIN); break;
+        case SPMV_DOT: PADNE_SPMV_LAUNCH(SPMV_DOT); break;
+        case SPMV_RESID: PADNE_SPMV_LAUNCH(SPMV_RESID); break;
+        case SPMV_ADD: PADNE_SPMV_LAUNCH(SPMV_ADD); break;
+        case SPMV_JACOBI: PADNE_SPMV_LAUNCH(SPMV_JACOBI); break;
+        default: set_error("bad SpMV mode %d", mode); return PADNE_E_INVALID;
     }
+#undef PADNE_SPMV_LAUNCH
     PADNE_HIP_CHECK(hipGetLastError());
     return PADNE_OK;
+}
+
+int launch_spmv(padne_ctx *ctx, const padne_csr *m, const double *x, double *y,
+                const double *dot_with, double *partials, const int32_t *done_flag) {
+    return launch_spmv_mode(ctx, m, dot_with != nullptr ? SPMV_DOT : SPMV_PLAIN, x, y, dot_with, partials,
+                            done_flag, nullptr, nullptr, 0.0);
 }
 
 // ---- 1/diag ---------------------------------------------------------------------------------

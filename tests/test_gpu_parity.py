@@ -223,22 +223,23 @@ def test_pcg_vs_direct_solve_on_layered_system(ctx):
     n = sysm.n_vertices
     assert np.abs(v[:n] - v_ref[:n]).max() <= REL_TOL * np.abs(v_ref[:n]).max()
     assert info.residual_norm < 1e-9 and abs(info.ground_node_current) < 1e-9
-    assert info.iterations > 100 and info.rel_residual <= 1.1e-12
+    assert 5 < info.iterations < 100 and info.rel_residual <= 1.1e-12        # multigrid-preconditioned
 
 
-def test_pcg_multiple_rhs_and_initial_guess(ctx):
+@pytest.mark.parametrize("precond", ["jacobi", "amg"])
+def test_pcg_multiple_rhs_and_initial_guess(ctx, precond):
     xy, tri = synthetic.jittered_grid(60, 60, seed=9)
     Lo = O.laplace_operator(xy, tri).tocsr()
     A = (-2082.5 * Lo[1:, 1:]).tocsr()
     d = ctx.csr_from_scipy(A)
     rng = np.random.default_rng(2)
     B = rng.uniform(-1, 1, (3, A.shape[0]))
-    res = d.solve_spd(B, rtol=1e-12)
+    res = d.solve_spd(B, rtol=1e-12, precond=precond)
     for k in range(3):
         assert np.linalg.norm(B[k] - A @ res.x[k]) <= 2e-12 * np.linalg.norm(B[k])
-    warm = d.solve_spd(B[0], rtol=1e-12, x0=res.x[0])
+    warm = d.solve_spd(B[0], rtol=1e-12, x0=res.x[0], precond=precond)
     assert warm.iterations <= 2
-    zero = d.solve_spd(np.zeros(A.shape[0]))
+    zero = d.solve_spd(np.zeros(A.shape[0]), precond=precond)
     assert zero.iterations == 0 and not zero.x.any()
 
 
@@ -248,18 +249,77 @@ def test_pcg_reports_breakdown_and_non_convergence(ctx):
         ctx.csr_from_scipy(A).solve_spd(np.array([1.0, -1.0]))
     xy, tri = synthetic.jittered_grid(40, 40, seed=1)
     A = (-O.laplace_operator(xy, tri).tocsr()[1:, 1:]).tocsr()
-    with pytest.raises(_hip.NotConvergedError):
-        ctx.csr_from_scipy(A).solve_spd(np.ones(A.shape[0]), max_iter=5)
+    for precond, cap in (("jacobi", 5), ("amg", 2)):
+        with pytest.raises(_hip.NotConvergedError):
+            ctx.csr_from_scipy(A).solve_spd(np.ones(A.shape[0]), max_iter=cap, precond=precond)
 
 
-def test_solves_are_bitwise_reproducible(ctx):
+@pytest.mark.parametrize("precond", ["jacobi", "amg"])
+def test_solves_are_bitwise_reproducible(ctx, precond):
     xy, tri = synthetic.jittered_grid(120, 90, seed=4)
     A = (-O.laplace_operator(xy, tri).tocsr()[1:, 1:]).tocsr()
-    d = ctx.csr_from_scipy(A)
     b = np.random.default_rng(0).uniform(-1, 1, A.shape[0])
-    x1 = d.solve_spd(b).x
-    x2 = d.solve_spd(b).x
+    x1 = ctx.csr_from_scipy(A).solve_spd(b, precond=precond).x       # two independently built hierarchies
+    x2 = ctx.csr_from_scipy(A).solve_spd(b, precond=precond).x
     assert np.array_equal(x1, x2)
+
+
+# ---- multigrid preconditioner ----------------------------------------------------------------------
+
+def layered_spd(nl=3, nx=90, ny=70, lattice=5):
+    sysm = synthetic.layered_system(nl, nx, ny, via_lattice=lattice)
+    els = [("R", int(a), int(b), float(r)) for a, b, r in zip(*sysm.resistors)]
+    els += [("I", int(f), int(t), float(i)) for f, t, i in zip(*sysm.current_sources)]
+    Lo, ro = O.assemble_system([(m[0], m[1], m[2]) for m in sysm.meshes], 0, els, 0)
+    n = sysm.n_vertices
+    A = (-Lo[1:n, 1:n]).tocsr()
+    A.sort_indices()
+    return A, -ro[1:n], Lo, ro, n
+
+
+def test_multigrid_hierarchy_is_galerkin_and_partition_of_unity(ctx):
+    A, b, _, _, _ = layered_spd()
+    d = ctx.csr_from_scipy(A)
+    res = d.solve_spd(b, precond="amg")
+    assert res.levels >= 3 and 1.0 < res.operator_complexity < 2.0
+    for lvl in range(res.levels - 1):
+        Al, P, R = d.amg_level(lvl, "A"), d.amg_level(lvl, "P"), d.amg_level(lvl, "R")
+        Ac = d.amg_level(lvl + 1, "A")
+        assert abs(R - P.T).max() == 0.0                               # R is exactly P^T
+        ref = (P.T @ Al @ P).tocsr()
+        assert abs(Ac - ref).max() <= 1e-12 * abs(ref).max()           # Galerkin product
+        assert abs(Ac - Ac.T).max() <= 1e-12 * abs(Ac).max()
+        # rows whose equation sums to zero are interpolated with unit row sum (constants are reproduced)
+        interior = np.abs(np.asarray(Al.sum(axis=1)).ravel()) <= 1e-9 * Al.diagonal()
+        assert np.abs(np.asarray(P.sum(axis=1)).ravel()[interior] - 1.0).max() < 1e-12
+        assert P.shape[1] < 0.5 * P.shape[0]
+
+
+def test_multigrid_preconditioner_is_symmetric_positive_definite(ctx):
+    A, b, _, _, _ = layered_spd(2, 70, 60, 4)
+    d = ctx.csr_from_scipy(A)
+    rng = np.random.default_rng(5)
+    r1, r2 = rng.uniform(-1, 1, (2, A.shape[0]))
+    z1, z2 = d.amg_apply(r1), d.amg_apply(r2)
+    assert abs(r2 @ z1 - r1 @ z2) <= 1e-10 * (np.linalg.norm(r1) * np.linalg.norm(z2))
+    assert r1 @ z1 > 0 and r2 @ z2 > 0
+    # linear: M(a r1 + b r2) = a M r1 + b M r2
+    z12 = d.amg_apply(2.0 * r1 - 3.0 * r2)
+    assert np.abs(z12 - (2.0 * z1 - 3.0 * z2)).max() <= 1e-10 * np.abs(z12).max()
+    assert np.array_equal(d.amg_apply(r1), z1)                          # deterministic
+
+
+def test_multigrid_and_jacobi_agree_with_the_direct_solve(ctx):
+    A, b, Lo, ro, n = layered_spd(4, 120, 100, 6)
+    v_ref = O.solve_system(Lo, ro)[0]
+    d = ctx.csr_from_scipy(A)
+    xa = d.solve_spd(b, precond="amg")
+    xj = d.solve_spd(b, precond="jacobi")
+    scale = np.abs(v_ref[:n]).max()
+    assert np.abs(xa.x - v_ref[1:n]).max() <= REL_TOL * scale
+    assert np.abs(xj.x - v_ref[1:n]).max() <= REL_TOL * scale
+    assert xa.iterations * 10 < xj.iterations
+    assert xa.rel_residual <= 1.1e-12 and xj.rel_residual <= 1.1e-12
 
 
 # ---- post-processing ----------------------------------------------------------------------------
