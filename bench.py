@@ -7,9 +7,10 @@ Laplacian of BASELINE.json, MI355X.
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A *step* is one complete solve of the reduced SPD system (the work of the reference's
-``solve_system``, solver.py:767-780): Jacobi-PCG from x0 = 0 to ||b - A x|| <= 1e-12 ||b||,
-including the final true-residual check, with the matrix and the right-hand side already resident
-in HBM.  Workload at every GPU count: config C4 of SURVEY.md section 8d -- 8 copper layers of
+``solve_system``, solver.py:767-780, which factorises and solves): build the multigrid hierarchy
+(the counterpart of the factorisation; it is rebuilt inside EVERY timed step), then preconditioned CG
+from x0 = 0 to ||b - A x|| <= 1e-12 ||b||, including the final true-residual check, with the matrix
+and the right-hand side already resident in HBM.  Workload at every GPU count: config C4 of SURVEY.md section 8d -- 8 copper layers of
 1118 x 1118 vertices (N = 10M unknowns, ~70M non-zeros) stitched by via rings; with N GPUs the
 layers are dealt to the ranks (strong scaling: the problem is fixed, ``scaling: "strong"``).
 
@@ -38,6 +39,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="C4", help="C2 | C3 | C4 (default, the headline config)")
+    ap.add_argument("--precond", default="amg", choices=["amg", "jacobi"],
+                    help="amg: smoothed-aggregation multigrid V-cycle (rebuilt inside every step); jacobi: diagonal")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-nx", type=int, default=400,
                     help="grid edge of the bounded CPU-baseline sample (8 layers of nx*nx)")
@@ -153,7 +156,8 @@ def main():
         keep = np.flatnonzero(imap[:nv] >= 0)
         b = ctx.to_device(-rhs[keep])
         x = ctx.empty(A.shape[0])
-        solver = lambda time_spmv=False: A.solve_spd_dev(b, x, rtol=RTOL, time_spmv=time_spmv)  # noqa: E731
+        solver = lambda time_spmv=False: A.solve_spd_dev(b, x, rtol=RTOL, time_spmv=time_spmv, precond=args.precond,  # noqa: E731
+                                                         rebuild=True)
         n_local, nnz_local = A.shape[0], A.nnz
         spmv_bytes = A.spmv_bytes
     else:
@@ -161,7 +165,8 @@ def main():
         plan = distributed.build_layer_partition(sysm, rank, world)
         dsolver = distributed.DistributedSolver(ctx, plan, dist)
         t_assemble, t_reduce = dsolver.t_assemble, dsolver.t_reduce
-        solver = lambda time_spmv=False: dsolver.solve(rtol=RTOL, time_spmv=time_spmv)  # noqa: E731
+        solver = lambda time_spmv=False: dsolver.solve(rtol=RTOL, time_spmv=time_spmv, precond=args.precond,  # noqa: E731
+                                                       rebuild=True)
         n_local, nnz_local = dsolver.n_owned, dsolver.nnz
         spmv_bytes = dsolver.spmv_bytes
     t_setup = time.perf_counter() - t_setup0
@@ -207,15 +212,20 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{sysm.name}: {len(sysm.meshes)}-layer jittered triangular Laplacian, "
-                                   f"{nv} nodes, via-ring stitched, 1 A source/sink, Jacobi-PCG to rtol {RTOL:g}",
+                                   f"{nv} nodes, via-ring stitched, 1 A source/sink, {args.precond}-PCG to rtol {RTOL:g}",
                        "n_unknowns": int(nv - 1), "nnz_per_rank": int(nnz_local), "rows_per_rank": int(n_local),
                        "parallelism": f"layer-partitioned x{args.gpus}"},
+            "preconditioner": {"kind": args.precond, "levels": int(last.levels),
+                               "operator_complexity": float(last.operator_complexity),
+                               "setup_ms_per_step": float(last.setup_seconds) * 1e3,
+                               "solve_ms_per_step": float(last.seconds) * 1e3},
             "iterations": int(last.iterations), "restarts": int(last.restarts),
             "rel_residual": float(last.rel_residual),
             "us_per_iteration": last.seconds / max(last.iterations, 1) * 1e6,
-            "pcg_textbook_gbs": 232.0 * n_local * last.iterations / last.seconds / 1e9 if last.seconds > 0 else 0.0,
+            "pcg_textbook_gbs": (232.0 * n_local * last.iterations / last.seconds / 1e9
+                                 if last.seconds > 0 and args.precond == "jacobi" else None),
             "setup_seconds": {"total": t_setup, "assemble": t_assemble, "reduce": t_reduce},
-            "roofline": {"bound": "hbm", "kernel": "csr_spmv_kernel<true> (q = A p with p.q epilogue)",
+            "roofline": {"bound": "hbm", "kernel": "csr_spmv_kernel<SPMV_DOT> (q = A p with p.q epilogue)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_launch": int(spmv_bytes), "seconds_per_launch": t_spmv},

@@ -160,6 +160,11 @@ int padne_solve_spd(padne_ctx *ctx, const padne_csr *a, const double *b_host, do
 int padne_solve_spd_dev(padne_ctx *ctx, const padne_csr *a, const void *b_dev, void *x_dev,
                         int32_t n_rhs, const padne_solve_opts *opts, padne_solve_info *info);
 
+/* Row-partitioned runs: attach the rank's owned x owned diagonal block; with precond = 1 the multigrid
+ * hierarchy is built on that block (block-Jacobi with multigrid blocks, no communication inside the
+ * cycle).  Borrowed handle; null detaches. */
+int padne_csr_set_preconditioner_block(padne_csr *a, padne_csr *block);
+
 /* z = M^-1 r: one V-cycle of the multigrid preconditioner (built on first use and cached on `a`);
  * host vectors.  Exposed for tests: M must be symmetric positive definite for PCG to apply. */
 int padne_amg_apply(padne_ctx *ctx, padne_csr *a, const double *r_host, double *z_host);

@@ -82,6 +82,7 @@ SIGNATURES = {
     "padne_solve_spd": (C.c_int, [_P, _P, _PF64, _PF64, C.c_int32, C.POINTER(SolveOpts), C.POINTER(SolveInfo)]),
     "padne_solve_spd_dev": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(SolveOpts), C.POINTER(SolveInfo)]),
     "padne_amg_apply": (C.c_int, [_P, _P, _PF64, _PF64]),
+    "padne_csr_set_preconditioner_block": (C.c_int, [_P, _P]),
     "padne_amg_level": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
     "padne_power_density": (C.c_int, [_P, _I64, _PF64, _I64, _PI32, _I64, _PI64, _PI64, _PF64, _PF64, _PF64]),
     "padne_face_gradient": (C.c_int, [_P, _I64, _PF64, _I64, _PI32, _I64, _PI64, _PI64, _PF64, _PF64, _PF64]),
@@ -416,6 +417,11 @@ class CsrMatrix:
         _check(self.ctx._lib.padne_residual_norm(self.ctx._h, self._h, _ptr(x, _PF64), _ptr(b, _PF64),
                                                  C.byref(out)))
         return out.value
+
+    def set_preconditioner_block(self, block: "CsrMatrix | None") -> None:
+        """Row-partitioned runs: multigrid is built on this owned x owned diagonal block."""
+        _check(self.ctx._lib.padne_csr_set_preconditioner_block(self._h, block._h if block is not None else None))
+        self._prec_block = block        # keep it alive
 
     def amg_level(self, level: int, which: str = "A"):
         """scipy copy of a hierarchy operator: which in 'A', 'P', 'R'."""

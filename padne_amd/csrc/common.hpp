@@ -65,6 +65,7 @@ struct padne_csr {
     double *dinv = nullptr;      // [n_rows] 1/diag, built on first use (square matrices)
     int device = 0;
     void *amg = nullptr;         // cached multigrid hierarchy (padne::Amg*), owned
+    padne_csr *prec_block = nullptr;   // borrowed: owned x owned diagonal block for the preconditioner
 };
 
 struct padne_ctx {

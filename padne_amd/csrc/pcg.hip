@@ -293,22 +293,36 @@ static int halo_exchange(padne_ctx *ctx, double *v, const int32_t *done_flag) {
     return comm_allgather_f64(ctx, seg, v + ctx->halo_n_owned, ctx->halo_m);
 }
 
-static int solve_one(padne_ctx *ctx, const padne_csr *a, const double *b, double *x,
+int amg_setup(padne_ctx *ctx, padne_csr *A0);
+int amg_apply(padne_ctx *ctx, const padne_csr *A0, const double *r, double *z, double *partials_rz,
+              const int32_t *done_flag);
+void amg_info(const padne_csr *A0, int *levels, double *complexity, double *setup_seconds, long long *coarse_n);
+const padne_csr *amg_level_matrix(const padne_csr *A0, int level, int which);
+
+// One preconditioned CG solve.  Preconditioner: Jacobi (prec == nullptr) or one multigrid V-cycle of the
+// hierarchy cached on `prec` (the matrix itself on one GPU; the rank's own diagonal block in a
+// row-partitioned run, i.e. block-Jacobi with multigrid blocks: no communication inside the cycle).
+// Reductions go through RCCL when the context has a communicator; the halo plan (if any) is applied
+// before every product.
+static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, const double *b, double *x,
                      const padne_solve_opts *o, padne_solve_info *info, bool x_is_guess) {
-    const bool dist = ctx->comm != nullptr;          // reductions via RCCL (also with a 1-rank communicator)
+    const bool dist = ctx->comm != nullptr;
     const bool halo = ctx->halo_on;
-    const long long nr = a->n_rows;                   // matrix rows (owned rows + empty exchange rows)
-    const long long n = halo ? ctx->halo_n_owned : nr;   // owned unknowns = length of b, x, r
-    const long long nc = a->n_cols;                   // length of any vector the matrix multiplies
+    const bool amg = prec != nullptr;
+    const long long nr = a->n_rows;                       // matrix rows (owned rows + empty exchange rows)
+    const long long n = halo ? ctx->halo_n_owned : nr;    // owned unknowns = length of b, x, r, z
+    const long long nc = a->n_cols;                       // length of any vector the matrix multiplies
     if (halo) {
         PADNE_REQUIRE(nc == ctx->halo_n_owned + (long long)ctx->world * ctx->halo_m && nr <= nc,
                       "matrix shape does not match the halo plan");
     } else {
         PADNE_REQUIRE(nr == nc, "matrix must be square");
     }
-    PADNE_TRY(ensure_workspace(ctx, sizeof(double) * (size_t)(n + 2 * nc + nr) + 4096));
+    if (amg) PADNE_REQUIRE(prec->n_rows == n && prec->n_cols == n, "preconditioner block must be owned x owned");
+    PADNE_TRY(ensure_workspace(ctx, sizeof(double) * (size_t)(2 * n + 2 * nc + nr) + 4096));
     double *r = (double *)ctx->ws;
-    double *p = r + n;          // [nc]
+    double *z = r + n;          // [n]   multigrid output
+    double *p = z + n;          // [nc]
     double *q = p + nc;         // [nr]
     double *xe = q + nr;        // [nc]  extended copy of x for products A x (halo runs only)
     PcgStatus *st = (PcgStatus *)ctx->status;
@@ -316,32 +330,31 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const double *b, double
     hipStream_t s = ctx->stream;
     const int gv = vec_grid(n);
     const int gs = spmv_grid(a);
+    const int P_rz = amg ? spmv_grid(prec) : gv;          // workgroups that emit r.z partials
     const int max_iter = o->max_iter > 0 ? o->max_iter : 100000;
-    int check_every = o->check_every > 0 ? o->check_every : 50;
+    const int check_every = o->check_every > 0 ? o->check_every : (amg ? 4 : 50);
+    const int sample_stride = amg ? 4 : 16;
     double *scal = ctx->scalars;
 
     PADNE_HIP_CHECK(hipMemsetAsync(st, 0, sizeof(PcgStatus), s));
     if (halo) PADNE_HIP_CHECK(hipMemsetAsync(p + n, 0, sizeof(double) * (size_t)(nc - n), s));
     PADNE_HIP_CHECK(hipEventRecord(ctx->ev0, s));
 
-    // y = A x for an owned-length x
-    auto product_Ax = [&](double *out) -> int {
+    auto product_Ax = [&](double *out) -> int {            // out = A x for the owned-length x
         if (!halo) return launch_spmv(ctx, a, x, out, nullptr, nullptr, nullptr);
         PADNE_HIP_CHECK(hipMemcpyAsync(xe, x, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
         PADNE_HIP_CHECK(hipMemsetAsync(xe + n, 0, sizeof(double) * (size_t)(nc - n), s));
         PADNE_TRY(halo_exchange(ctx, xe, nullptr));
         return launch_spmv(ctx, a, xe, out, nullptr, nullptr, nullptr);
     };
-    // fold per-workgroup partials into scalars and sum them over the ranks
-    auto fold_allreduce = [&](const double *first_slot, int P, long long stride, int count, double *out) -> int {
+    auto fold = [&](const double *first_slot, int P, long long stride, int count, double *out) -> int {
         hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(256), 0, s, first_slot, P, (int)stride, count, out);
         PADNE_HIP_CHECK(hipGetLastError());
-        return dist ? comm_allreduce_sum_f64(ctx, out, count) : PADNE_OK;
+        return PADNE_OK;
     };
+    auto allreduce = [&](double *buf, int count) -> int { return dist ? comm_allreduce_sum_f64(ctx, buf, count) : PADNE_OK; };
 
-    int restarts = 0;
-    int total_iters = 0;
-    // optional in-situ timing of the SpMV kernel: every 16th launch is bracketed by an event pair
+    int restarts = 0, total_iters = 0, code = PADNE_OK;
     const bool sample_spmv = (o->flags & 2) != 0;
     std::vector<hipEvent_t> ev_a, ev_b;
     long long launched = 0;
@@ -353,13 +366,25 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const double *b, double
     } else {
         PADNE_HIP_CHECK(hipMemsetAsync(x, 0, sizeof(double) * (size_t)n, s));
     }
-    int code = PADNE_OK;
     for (;;) {
-        // (re)start: r = b - A x, p = D^-1 r
-        hipLaunchKernelGGL(pcg_init_kernel, dim3(gv), dim3(256), 0, s, n, b, have_ax ? q : nullptr, a->dinv, r,
-                           p, slot(ctx, SLOT_RZ0), slot(ctx, SLOT_RR), slot(ctx, SLOT_BB));
-        PADNE_TRY(fold_allreduce(slot(ctx, SLOT_RR), gv, kMaxPartials, 2, scal + S_RR));  // RR, BB adjacent
-        if (dist) PADNE_TRY(fold_allreduce(slot(ctx, SLOT_RZ0), gv, kMaxPartials, 1, scal + S_RZRR0));
+        // ---- (re)start: r = b - A x ; z = M^-1 r ; p = z ------------------------------------------------
+        if (amg) {
+            hipLaunchKernelGGL(pcg_init_plain_kernel, dim3(gv), dim3(256), 0, s, n, b, have_ax ? q : nullptr, r,
+                               slot(ctx, SLOT_RR), slot(ctx, SLOT_BB));
+            PADNE_HIP_CHECK(hipGetLastError());
+            PADNE_TRY(amg_apply(ctx, prec, r, z, slot(ctx, SLOT_RZ0), nullptr));
+            PADNE_HIP_CHECK(hipMemcpyAsync(p, z, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+        } else {
+            hipLaunchKernelGGL(pcg_init_kernel, dim3(gv), dim3(256), 0, s, n, b, have_ax ? q : nullptr, a->dinv, r, p,
+                               slot(ctx, SLOT_RZ0), slot(ctx, SLOT_RR), slot(ctx, SLOT_BB));
+            PADNE_HIP_CHECK(hipGetLastError());
+        }
+        PADNE_TRY(fold(slot(ctx, SLOT_RR), gv, kMaxPartials, 2, scal + S_RR));   // RR, BB adjacent
+        PADNE_TRY(allreduce(scal + S_RR, 2));
+        if (dist) {
+            PADNE_TRY(fold(slot(ctx, SLOT_RZ0), P_rz, kMaxPartials, 1, scal + S_RZRR0));
+            PADNE_TRY(allreduce(scal + S_RZRR0, 1));
+        }
         hipLaunchKernelGGL(pcg_set_tolerance_kernel, dim3(1), dim3(1), 0, s, st, scal + S_RR, o->rtol, o->atol,
                            restarts > 0 ? 1 : 0);
         PADNE_HIP_CHECK(hipGetLastError());
@@ -369,12 +394,17 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const double *b, double
             for (int k = 0; k < check_every; ++k) {
                 const int rz_old_slot = parity ? SLOT_RZ1 : SLOT_RZ0;
                 const int rz_new_slot = parity ? SLOT_RZ0 : SLOT_RZ1;
-                double *rz_old = slot(ctx, rz_old_slot);
-                double *rz_new = slot(ctx, rz_new_slot);
-                double *s_old = scal + (parity ? S_RZRR1 : S_RZRR0);   // {rz, rr} of the previous iteration
+                double *s_old = scal + (parity ? S_RZRR1 : S_RZRR0);   // {rz, rr} reduced over ranks
                 double *s_new = scal + (parity ? S_RZRR0 : S_RZRR1);
+                // how the consumers read their scalars: per-workgroup partials, or one reduced value
+                const double *rz_old = dist ? s_old : slot(ctx, rz_old_slot);
+                const double *rz_new = dist ? s_new : slot(ctx, rz_new_slot);
+                const double *pq = dist ? scal + S_PQ : slot(ctx, SLOT_PQ);
+                const double *rr = dist ? s_new + 1 : slot(ctx, SLOT_RR);
+                const int Pz = dist ? 1 : P_rz, Pq = dist ? 1 : gs, Pr = dist ? 1 : gv;
+
                 PADNE_TRY(halo_exchange(ctx, p, &st->done));
-                const bool sampled = sample_spmv && (launched++ % 16) == 8 && ev_a.size() < 512;
+                const bool sampled = sample_spmv && (launched++ % sample_stride) == 1 && ev_a.size() < 512;
                 if (sampled) {
                     hipEvent_t e0, e1;
                     PADNE_HIP_CHECK(hipEventCreate(&e0));
@@ -386,18 +416,31 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const double *b, double
                 PADNE_TRY(launch_spmv(ctx, a, p, q, p, slot(ctx, SLOT_PQ), &st->done));
                 if (sampled) PADNE_HIP_CHECK(hipEventRecord(ev_b.back(), s));
                 if (dist) {
-                    PADNE_TRY(fold_allreduce(slot(ctx, SLOT_PQ), gs, kMaxPartials, 1, scal + S_PQ));
-                    hipLaunchKernelGGL(pcg_update_xr_kernel, dim3(gv), dim3(256), 0, s, n, s_old, 1, scal + S_PQ, 1,
-                                       p, q, a->dinv, x, r, rz_new, slot(ctx, SLOT_RR), st);
-                    PADNE_TRY(fold_allreduce(rz_new, gv, (long long)(SLOT_RR - rz_new_slot) * kMaxPartials, 2, s_new));
-                    hipLaunchKernelGGL(pcg_update_p_kernel, dim3(gv), dim3(256), 0, s, n, s_new, s_old, 1, s_new + 1, 1,
-                                       scal + S_PQ, 1, r, a->dinv, p, st, max_iter - total_iters);
+                    PADNE_TRY(fold(slot(ctx, SLOT_PQ), gs, kMaxPartials, 1, scal + S_PQ));
+                    PADNE_TRY(allreduce(scal + S_PQ, 1));
+                }
+                if (amg) {
+                    hipLaunchKernelGGL(pcg_update_xr_plain_kernel, dim3(gv), dim3(256), 0, s, n, rz_old, Pz, pq, Pq, p, q,
+                                       x, r, slot(ctx, SLOT_RR), st);
+                    PADNE_HIP_CHECK(hipGetLastError());
+                    PADNE_TRY(amg_apply(ctx, prec, r, z, slot(ctx, rz_new_slot), &st->done));
+                    if (dist) {
+                        PADNE_TRY(fold(slot(ctx, rz_new_slot), P_rz, kMaxPartials, 1, s_new));
+                        PADNE_TRY(fold(slot(ctx, SLOT_RR), gv, kMaxPartials, 1, s_new + 1));
+                        PADNE_TRY(allreduce(s_new, 2));
+                    }
+                    hipLaunchKernelGGL(pcg_update_p_z_kernel, dim3(gv), dim3(256), 0, s, n, rz_new, rz_old, Pz, rr, Pr,
+                                       pq, Pq, z, p, st, max_iter - total_iters);
                 } else {
-                    hipLaunchKernelGGL(pcg_update_xr_kernel, dim3(gv), dim3(256), 0, s, n, rz_old, gv,
-                                       slot(ctx, SLOT_PQ), gs, p, q, a->dinv, x, r, rz_new, slot(ctx, SLOT_RR), st);
-                    hipLaunchKernelGGL(pcg_update_p_kernel, dim3(gv), dim3(256), 0, s, n, rz_new, rz_old, gv,
-                                       slot(ctx, SLOT_RR), gv, slot(ctx, SLOT_PQ), gs, r, a->dinv, p, st,
-                                       max_iter - total_iters);
+                    hipLaunchKernelGGL(pcg_update_xr_kernel, dim3(gv), dim3(256), 0, s, n, rz_old, Pz, pq, Pq, p, q,
+                                       a->dinv, x, r, slot(ctx, rz_new_slot), slot(ctx, SLOT_RR), st);
+                    if (dist) {
+                        PADNE_TRY(fold(slot(ctx, rz_new_slot), gv, (long long)(SLOT_RR - rz_new_slot) * kMaxPartials, 2,
+                                       s_new));
+                        PADNE_TRY(allreduce(s_new, 2));
+                    }
+                    hipLaunchKernelGGL(pcg_update_p_kernel, dim3(gv), dim3(256), 0, s, n, rz_new, rz_old, Pz, rr, Pr, pq,
+                                       Pq, r, a->dinv, p, st, max_iter - total_iters);
                 }
                 parity ^= 1;
             }
@@ -410,11 +453,11 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const double *b, double
         code = hst->code;
         bb = hst->bb;
         tol2 = hst->tol2;
-        // true residual
+        // ---- true residual ---------------------------------------------------------------------------
         PADNE_TRY(product_Ax(q));
-        hipLaunchKernelGGL(residual_kernel, dim3(gv), dim3(256), 0, s, n, b, q, (double *)nullptr,
-                           slot(ctx, SLOT_TMP));
-        PADNE_TRY(fold_allreduce(slot(ctx, SLOT_TMP), gv, kMaxPartials, 1, scal + S_TRUE));
+        hipLaunchKernelGGL(residual_kernel, dim3(gv), dim3(256), 0, s, n, b, q, (double *)nullptr, slot(ctx, SLOT_TMP));
+        PADNE_TRY(fold(slot(ctx, SLOT_TMP), gv, kMaxPartials, 1, scal + S_TRUE));
+        PADNE_TRY(allreduce(scal + S_TRUE, 1));
         PADNE_HIP_CHECK(hipMemcpyAsync(&hst[1], scal + S_TRUE, sizeof(double), hipMemcpyDeviceToHost, s));
         PADNE_HIP_CHECK(hipStreamSynchronize(s));
         memcpy(&true_rr, &hst[1], sizeof(double));
@@ -465,7 +508,6 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const double *b, double
     }
     return PADNE_OK;
 }
-
 
 // ---- largest eigenvalue of D^-1 A from the Lanczos coefficients of a few Jacobi-PCG steps ------------
 __global__ void fill_pseudo_random(long long n, double *__restrict__ v) {
@@ -560,140 +602,6 @@ int estimate_lambda_max(padne_ctx *ctx, const padne_csr *a, int steps, double *l
     return PADNE_OK;
 }
 
-int amg_setup(padne_ctx *ctx, padne_csr *A0);
-int amg_apply(padne_ctx *ctx, const padne_csr *A0, const double *r, double *z, double *partials_rz,
-              const int32_t *done_flag);
-void amg_info(const padne_csr *A0, int *levels, double *complexity, double *setup_seconds, long long *coarse_n);
-const padne_csr *amg_level_matrix(const padne_csr *A0, int level, int which);
-
-// CG preconditioned by one multigrid V-cycle per iteration (single GPU)
-static int solve_one_amg(padne_ctx *ctx, const padne_csr *a, const double *b, double *x, const padne_solve_opts *o,
-                         padne_solve_info *info, bool x_is_guess) {
-    const long long n = a->n_rows;
-    PADNE_TRY(ensure_workspace(ctx, sizeof(double) * (size_t)n * 4 + 4096));
-    double *r = (double *)ctx->ws;
-    double *p = r + n;
-    double *q = p + n;
-    double *z = q + n;
-    PcgStatus *st = (PcgStatus *)ctx->status;
-    PcgStatus *hst = (PcgStatus *)ctx->pinned;
-    hipStream_t s = ctx->stream;
-    const int gv = vec_grid(n);
-    const int gs = spmv_grid(a);
-    const int max_iter = o->max_iter > 0 ? o->max_iter : 100000;
-    const int check_every = o->check_every > 0 ? o->check_every : 4;
-    double *scal = ctx->scalars;
-    PADNE_HIP_CHECK(hipMemsetAsync(st, 0, sizeof(PcgStatus), s));
-    PADNE_HIP_CHECK(hipEventRecord(ctx->ev0, s));
-    int restarts = 0, total_iters = 0, code = PADNE_OK;
-    double true_rr = 0.0, bb = 0.0, tol2 = 0.0;
-    bool have_ax = false;
-    if (x_is_guess) {
-        PADNE_TRY(launch_spmv(ctx, a, x, q, nullptr, nullptr, nullptr));
-        have_ax = true;
-    } else {
-        PADNE_HIP_CHECK(hipMemsetAsync(x, 0, sizeof(double) * (size_t)n, s));
-    }
-    const bool sample_spmv = (o->flags & 2) != 0;
-    std::vector<hipEvent_t> ev_a, ev_b;
-    long long launched = 0;
-    for (;;) {
-        hipLaunchKernelGGL(pcg_init_plain_kernel, dim3(gv), dim3(256), 0, s, n, b, have_ax ? q : nullptr, r,
-                           slot(ctx, SLOT_RR), slot(ctx, SLOT_BB));
-        hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(256), 0, s, slot(ctx, SLOT_RR), gv, kMaxPartials, 2,
-                           scal + S_RR);
-        hipLaunchKernelGGL(pcg_set_tolerance_kernel, dim3(1), dim3(1), 0, s, st, scal + S_RR, o->rtol, o->atol,
-                           restarts > 0 ? 1 : 0);
-        PADNE_HIP_CHECK(hipGetLastError());
-        PADNE_TRY(amg_apply(ctx, a, r, z, slot(ctx, SLOT_RZ0), nullptr));
-        PADNE_HIP_CHECK(hipMemcpyAsync(p, z, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
-        int parity = 0;
-        bool done = false;
-        while (!done) {
-            for (int k = 0; k < check_every; ++k) {
-                double *rz_old = slot(ctx, parity ? SLOT_RZ1 : SLOT_RZ0);
-                double *rz_new = slot(ctx, parity ? SLOT_RZ0 : SLOT_RZ1);
-                const bool sampled = sample_spmv && (launched++ % 4) == 1 && ev_a.size() < 256;
-                if (sampled) {
-                    hipEvent_t e0, e1;
-                    PADNE_HIP_CHECK(hipEventCreate(&e0));
-                    PADNE_HIP_CHECK(hipEventCreate(&e1));
-                    ev_a.push_back(e0);
-                    ev_b.push_back(e1);
-                    PADNE_HIP_CHECK(hipEventRecord(e0, s));
-                }
-                PADNE_TRY(launch_spmv(ctx, a, p, q, p, slot(ctx, SLOT_PQ), &st->done));
-                if (sampled) PADNE_HIP_CHECK(hipEventRecord(ev_b.back(), s));
-                hipLaunchKernelGGL(pcg_update_xr_plain_kernel, dim3(gv), dim3(256), 0, s, n, rz_old, gs,
-                                   slot(ctx, SLOT_PQ), gs, p, q, x, r, slot(ctx, SLOT_RR), st);
-                PADNE_TRY(amg_apply(ctx, a, r, z, rz_new, &st->done));
-                hipLaunchKernelGGL(pcg_update_p_z_kernel, dim3(gv), dim3(256), 0, s, n, rz_new, rz_old, gs,
-                                   slot(ctx, SLOT_RR), gv, slot(ctx, SLOT_PQ), gs, z, p, st, max_iter - total_iters);
-                parity ^= 1;
-            }
-            PADNE_HIP_CHECK(hipGetLastError());
-            PADNE_HIP_CHECK(hipMemcpyAsync(hst, st, sizeof(PcgStatus), hipMemcpyDeviceToHost, s));
-            PADNE_HIP_CHECK(hipStreamSynchronize(s));
-            done = hst->done != 0;
-        }
-        total_iters += hst->iters;
-        code = hst->code;
-        bb = hst->bb;
-        tol2 = hst->tol2;
-        PADNE_TRY(launch_spmv(ctx, a, x, q, nullptr, nullptr, nullptr));
-        hipLaunchKernelGGL(residual_kernel, dim3(gv), dim3(256), 0, s, n, b, q, (double *)nullptr, slot(ctx, SLOT_TMP));
-        hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(256), 0, s, slot(ctx, SLOT_TMP), gv, kMaxPartials, 1,
-                           scal + S_TRUE);
-        PADNE_HIP_CHECK(hipGetLastError());
-        PADNE_HIP_CHECK(hipMemcpyAsync(&hst[1], scal + S_TRUE, sizeof(double), hipMemcpyDeviceToHost, s));
-        PADNE_HIP_CHECK(hipStreamSynchronize(s));
-        memcpy(&true_rr, &hst[1], sizeof(double));
-        if (code != PADNE_OK) break;
-        if (true_rr <= tol2 * 1.0000001 || total_iters >= max_iter || restarts >= 8) break;
-        ++restarts;
-        have_ax = true;
-        PADNE_HIP_CHECK(hipMemsetAsync(st, 0, 2 * sizeof(int32_t), s));
-        PADNE_HIP_CHECK(hipMemsetAsync(&st->iters, 0, sizeof(int32_t), s));
-    }
-    PADNE_HIP_CHECK(hipEventRecord(ctx->ev1, s));
-    PADNE_HIP_CHECK(hipEventSynchronize(ctx->ev1));
-    float ms = 0.f;
-    PADNE_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-    if (!ev_a.empty()) {
-        std::vector<double> t_s;
-        for (size_t i = 0; i < ev_a.size(); ++i) {
-            float t = 0.f;
-            if (hipEventElapsedTime(&t, ev_a[i], ev_b[i]) == hipSuccess) t_s.push_back(t * 1e-3);
-            hipEventDestroy(ev_a[i]);
-            hipEventDestroy(ev_b[i]);
-        }
-        if (info && !t_s.empty()) {
-            std::vector<double> sorted = t_s;
-            std::sort(sorted.begin(), sorted.end());
-            const double med = sorted[sorted.size() / 2];
-            double sum = 0.0;
-            int cnt = 0;
-            for (double t : t_s)
-                if (t >= 0.5 * med && t <= 2.0 * med) {
-                    sum += t;
-                    ++cnt;
-                }
-            if (cnt > 0) info->spmv_seconds = sum / cnt;
-        }
-    }
-    if (info) {
-        info->iterations += total_iters;
-        info->restarts += restarts;
-        const double rel = bb > 0 ? sqrt(true_rr / bb) : sqrt(true_rr);
-        if (rel > info->rel_residual) info->rel_residual = rel;
-        if (sqrt(true_rr) > info->abs_residual) info->abs_residual = sqrt(true_rr);
-        info->solve_seconds += ms * 1e-3;
-        if (code != PADNE_OK) info->status = code;
-        else if (true_rr > tol2 * 1.0000001 && info->status == PADNE_OK) info->status = PADNE_E_NOTCONVERGED;
-    }
-    return PADNE_OK;
-}
-
 }  // namespace padne
 
 using namespace padne;
@@ -736,6 +644,15 @@ extern "C" int padne_amg_level(padne_ctx *ctx, padne_csr *a, int level, int whic
     return PADNE_OK;
 }
 
+// attach the owned x owned diagonal block used to build the multigrid preconditioner of a row-partitioned
+// matrix (borrowed: the caller keeps both handles alive; pass null to detach)
+extern "C" int padne_csr_set_preconditioner_block(padne_csr *a, padne_csr *block) {
+    PADNE_REQUIRE(a != nullptr, "matrix");
+    PADNE_REQUIRE(block == nullptr || block->n_rows == block->n_cols, "block must be square");
+    a->prec_block = block;
+    return PADNE_OK;
+}
+
 extern "C" int padne_ctx_set_halo(padne_ctx *ctx, int64_t n_owned, int32_t m, int32_t n_export,
                                   const int32_t *export_idx_host) {
     PADNE_REQUIRE(ctx, "ctx");
@@ -773,26 +690,29 @@ extern "C" int padne_solve_spd_dev(padne_ctx *ctx, const padne_csr *a, const voi
     memset(&local, 0, sizeof(local));
     local.n_rhs = n_rhs;
     // multigrid: single GPU, and only where there is something to coarsen
-    bool use_amg = opts->precond == 1 && !ctx->halo_on && ctx->comm == nullptr && a->n_rows > 1024;
+    // multigrid: on the matrix itself, or on the rank's diagonal block attached with
+    // padne_csr_set_preconditioner_block (row-partitioned runs); small systems stay with Jacobi
+    padne_csr *pm = a->prec_block ? a->prec_block : const_cast<padne_csr *>(a);
+    const long long n_owned = ctx->halo_on ? ctx->halo_n_owned : a->n_rows;
+    PADNE_REQUIRE(!(opts->precond == 1 && ctx->halo_on && a->prec_block == nullptr),
+                  "multigrid on a row-partitioned matrix needs padne_csr_set_preconditioner_block");
+    bool use_amg = opts->precond == 1 && n_owned > 1024;
     if (use_amg) {
-        const bool fresh = a->amg == nullptr || (opts->flags & 4) != 0;
-        if (fresh && a->amg) {
-            amg_destroy(a->amg);
-            const_cast<padne_csr *>(a)->amg = nullptr;
+        PADNE_REQUIRE(pm->n_rows == n_owned && pm->n_cols == n_owned, "preconditioner block must be owned x owned");
+        const bool fresh = pm->amg == nullptr || (opts->flags & 4) != 0;
+        if (fresh && pm->amg) {
+            amg_destroy(pm->amg);
+            pm->amg = nullptr;
         }
-        PADNE_TRY(amg_setup(ctx, const_cast<padne_csr *>(a)));
+        PADNE_TRY(amg_setup(ctx, pm));
         double setup_s = 0.0;
-        amg_info(a, &local.levels, &local.operator_complexity, &setup_s, nullptr);
+        amg_info(pm, &local.levels, &local.operator_complexity, &setup_s, nullptr);
         if (fresh) local.precond_setup_seconds = setup_s;
     }
     const long long n = ctx->halo_on ? ctx->halo_n_owned : a->n_rows;
     for (int k = 0; k < n_rhs; ++k) {
-        if (use_amg)
-            PADNE_TRY(solve_one_amg(ctx, a, (const double *)b_dev + (size_t)k * n, (double *)x_dev + (size_t)k * n,
-                                    opts, &local, (opts->flags & 1) != 0));
-        else
-            PADNE_TRY(solve_one(ctx, a, (const double *)b_dev + (size_t)k * n, (double *)x_dev + (size_t)k * n, opts,
-                                &local, (opts->flags & 1) != 0));
+        PADNE_TRY(solve_one(ctx, a, use_amg ? pm : nullptr, (const double *)b_dev + (size_t)k * n,
+                            (double *)x_dev + (size_t)k * n, opts, &local, (opts->flags & 1) != 0));
     }
     if (info) *info = local;
     if (local.status == PADNE_E_BREAKDOWN) {

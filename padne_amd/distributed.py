@@ -163,6 +163,12 @@ class DistributedSolver:
         imap, n_owned, export_red = reduced_local_map(plan)
         t0 = time.perf_counter()
         self.A = L.reduce(imap, n_owned + plan.world * plan.m, -1.0)
+        # owned x owned diagonal block (couplings to other ranks dropped): the multigrid preconditioner is
+        # built on it, i.e. block-Jacobi across ranks with one V-cycle per block and no communication inside
+        bmap = imap.copy()
+        bmap[plan.n_owned_vertices:] = -1
+        self.A_block = L.reduce(bmap, n_owned, -1.0)
+        self.A.set_preconditioner_block(self.A_block)
         ctx.synchronize()
         self.t_reduce = time.perf_counter() - t0
         L.close()
@@ -174,8 +180,8 @@ class DistributedSolver:
         self.nnz = self.A.nnz
         self.spmv_bytes = 12 * self.A.nnz + 20 * n_owned + 4
 
-    def solve(self, rtol=1e-12, time_spmv=False):
-        return self.A.solve_spd_dev(self.b, self.x, rtol=rtol, time_spmv=time_spmv)
+    def solve(self, rtol=1e-12, time_spmv=False, precond="amg", rebuild=False):
+        return self.A.solve_spd_dev(self.b, self.x, rtol=rtol, time_spmv=time_spmv, precond=precond, rebuild=rebuild)
 
     def solution(self) -> np.ndarray:
         return self.x.numpy()

@@ -447,15 +447,27 @@ def test_halo_and_rccl_path_with_one_rank_communicator():
         ctx2.comm_init(ctx2.comm_unique_id(), 0, 1)
         ctx2.set_halo(n, m, export)
         d = ctx2.csr_from_scipy(A_ext)
-        res = d.solve_spd(b, rtol=1e-12)
+        res = d.solve_spd(b, rtol=1e-12, precond="jacobi")
         assert res.x.shape == (n,)
         assert np.abs(res.x - x_ref).max() <= REL_TOL * np.abs(x_ref).max()
+        # multigrid on the attached owned x owned block (what a rank of a layer-partitioned run does)
+        block = ctx2.csr_from_scipy(A)
+        d.set_preconditioner_block(block)
+        res_amg = d.solve_spd(b, rtol=1e-12, precond="amg")
+        assert res_amg.levels >= 2 and res_amg.iterations * 10 < res.iterations
+        assert np.abs(res_amg.x - x_ref).max() <= REL_TOL * np.abs(x_ref).max()
+        d.set_preconditioner_block(None)
+        with pytest.raises(ValueError):                        # without a block a halo matrix cannot be coarsened
+            d.solve_spd(b, precond="amg")
         plain = ctx2.csr_from_scipy(A)
         ctx2.clear_halo()
-        res2 = plain.solve_spd(b, rtol=1e-12)                  # reductions still via RCCL (communicator set)
+        res2 = plain.solve_spd(b, rtol=1e-12, precond="jacobi")  # reductions still via RCCL (communicator set)
         assert np.abs(res2.x - x_ref).max() <= REL_TOL * np.abs(x_ref).max()
         assert abs(res2.iterations - res.iterations) <= 3
+        res3 = plain.solve_spd(b, rtol=1e-12, precond="amg")
+        assert np.abs(res3.x - x_ref).max() <= REL_TOL * np.abs(x_ref).max()
         d.close()
         plain.close()
+        block.close()
     finally:
         ctx2.close()
