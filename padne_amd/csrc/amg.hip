@@ -41,6 +41,7 @@ struct AmgLevel {
 };
 
 struct Amg {
+    padne_ctx *ctx = nullptr;
     std::vector<AmgLevel> levels;
     double *coarse_inv = nullptr;   // dense n_c x n_c
     int n_coarse = 0;
@@ -76,21 +77,80 @@ __global__ void mis_prep(int n, const signed char *__restrict__ state, unsigned 
     else out[i] = state[i] == 1 ? 1ull : 0ull;                   // roots radiate coverage
 }
 
-__global__ void nbr_max(int n, const int *__restrict__ rowptr, const int *__restrict__ cols,
-                        const double *__restrict__ vals, const double *__restrict__ dinv, double theta2,
-                        const unsigned long long *__restrict__ in, unsigned long long *__restrict__ out) {
+// strength graph S: for every row the strong off-diagonal neighbours (columns sorted) and |a_ij|
+__global__ void strength_count(int n, const int *__restrict__ rowptr, const int *__restrict__ cols,
+                               const double *__restrict__ vals, const double *__restrict__ dinv, double theta2,
+                               int *__restrict__ cnt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    unsigned long long m = in[i];
     const double di = dinv[i];
+    int c = 0;
     for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
         const int j = cols[k];
-        if (j != i && j < n && strong(vals[k], di, dinv[j], theta2)) {
-            const unsigned long long v = in[j];
-            m = v > m ? v : m;
+        c += (j != i && strong(vals[k], di, dinv[j], theta2)) ? 1 : 0;
+    }
+    cnt[i] = c;
+}
+
+__global__ void strength_fill(int n, const int *__restrict__ rowptr, const int *__restrict__ cols,
+                              const double *__restrict__ vals, const double *__restrict__ dinv, double theta2,
+                              const int *__restrict__ srow, int *__restrict__ scol, double *__restrict__ sval) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double di = dinv[i];
+    int o = srow[i];
+    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+        const int j = cols[k];
+        if (j != i && strong(vals[k], di, dinv[j], theta2)) {
+            scol[o] = j;
+            sval[o] = fabs(vals[k]);
+            ++o;
         }
     }
-    out[i] = m;
+}
+
+// out[i] = max(in[i], max over the strong neighbours j of in[j]).  Same wave-private, lane-consecutive
+// streaming as the SpMV kernel (spmv.hip): 64 rows per wave, neighbour values parked in LDS, one lane per row.
+__global__ __launch_bounds__(256) void nbr_max(int n, int n_wtiles, const int *__restrict__ srow,
+                                               const int *__restrict__ scol,
+                                               const unsigned long long *__restrict__ in,
+                                               unsigned long long *__restrict__ out) {
+    constexpr int CH = 512;
+    __shared__ unsigned long long park_all[4 * CH];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned long long *park = park_all + w * CH;
+    const long long W = (long long)gridDim.x * 4, gw = (long long)blockIdx.x * 4 + w;
+    for (long long wt = gw; wt < n_wtiles; wt += W) {
+        const int row0 = (int)wt * 64;
+        const int row1 = min(row0 + 64, n);
+        const int r = row0 + lane;
+        int rs = 0, re = 0;
+        unsigned long long m = 0ull;
+        if (r < row1) {
+            rs = srow[r];
+            re = srow[r + 1];
+            m = in[r];
+        }
+        const int k0 = __shfl(rs, 0, 64);
+        const int k1 = __shfl(re, row1 - row0 - 1, 64);
+        for (int base = k0; base < k1; base += CH) {
+#pragma unroll
+            for (int j = 0; j < CH / 64; ++j) {
+                const int e = base + lane + 64 * j;
+                park[lane + 64 * j] = (e < k1) ? in[scol[e]] : 0ull;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const int lo = max(rs, base), hi = min(re, base + CH);
+            for (int k = lo; k < hi; ++k) {
+                const unsigned long long v = park[k - base];
+                m = v > m ? v : m;
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (r < row1) out[r] = m;
+    }
 }
 
 __global__ void mis_mark_roots(int n, signed char *__restrict__ state, const unsigned long long *__restrict__ m2) {
@@ -102,11 +162,12 @@ __global__ void mis_mark_roots(int n, signed char *__restrict__ state, const uns
 __global__ void mis_cover(int n, signed char *__restrict__ state, const unsigned long long *__restrict__ c2,
                           int *__restrict__ undecided) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (state[i] == 0) {
+    bool open = false;
+    if (i < n && state[i] == 0) {
         if (c2[i] > 0) state[i] = 2;
-        else atomicAdd(undecided, 1);
+        else open = true;
     }
+    if (__ballot(open) != 0ull && (threadIdx.x & 63) == 0) atomicAdd(undecided, 1);   // only "any left?" matters
 }
 
 __global__ void flag_state(int n, const signed char *__restrict__ state, int *__restrict__ flag, int which) {
@@ -120,23 +181,17 @@ __global__ void agg_from_roots(int n, const signed char *__restrict__ state, con
     if (i < n) agg[i] = state[i] == 1 ? scan[i] : -1;
 }
 
-__global__ void agg_join(int n, const int *__restrict__ rowptr, const int *__restrict__ cols,
-                         const double *__restrict__ vals, const double *__restrict__ dinv, double theta2,
-                         const int *__restrict__ agg_in, int *__restrict__ agg_out) {
+__global__ void agg_join(int n, const int *__restrict__ srow, const int *__restrict__ scol,
+                         const double *__restrict__ sval, const int *__restrict__ agg_in, int *__restrict__ agg_out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int a = agg_in[i];
     if (a < 0) {
         double best = -1.0;
-        const double di = dinv[i];
-        for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
-            const int j = cols[k];
-            if (j == i || j >= n) continue;
-            const double v = vals[k];
-            if (!strong(v, di, dinv[j], theta2)) continue;
-            const int aj = agg_in[j];
+        for (int k = srow[i]; k < srow[i + 1]; ++k) {
+            const int aj = agg_in[scol[k]];
             if (aj < 0) continue;
-            const double w = fabs(v);
+            const double w = sval[k];
             if (w > best) {   // ties: columns are sorted, the smaller index wins
                 best = w;
                 a = aj;
@@ -221,6 +276,11 @@ __global__ void prolong_fill(int n, const int *__restrict__ rowptr, const int *_
             val[s] = 0.0;                         // lumped: contributes nothing to P, dropped by the merge
         }
     }
+}
+
+__global__ void prolong_slot_ptr(int n, const int *__restrict__ rowptr, int *__restrict__ slot_ptr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n) slot_ptr[i] = rowptr[i] + i;
 }
 
 // Gershgorin bound of D_F^-1 A_F (filtered matrix)
@@ -565,14 +625,29 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
     PADNE_TRY(sc.alloc(&counter, 1));
     PADNE_HIP_CHECK(hipMemsetAsync(state, 0, (size_t)n, s));
     const dim3 g(nblk(n)), b(256);
+    // strength graph, built once per level
+    int *scnt = nullptr, *srow = nullptr, *scol = nullptr;
+    double *sval = nullptr;
+    PADNE_TRY(sc.alloc(&scnt, (size_t)n + 1));
+    PADNE_TRY(sc.alloc(&srow, (size_t)n + 1));
+    hipLaunchKernelGGL(strength_count, g, b, 0, s, n, A->rowptr, A->cols, A->vals, A->dinv, theta2, scnt);
+    PADNE_HIP_CHECK(hipGetLastError());
+    int64_t s_nnz = 0;
+    PADNE_TRY(exclusive_scan_i32(ctx, scnt, srow, n, &s_nnz));
+    PADNE_TRY(sc.alloc(&scol, (size_t)s_nnz));
+    PADNE_TRY(sc.alloc(&sval, (size_t)s_nnz));
+    hipLaunchKernelGGL(strength_fill, g, b, 0, s, n, A->rowptr, A->cols, A->vals, A->dinv, theta2, srow, scol, sval);
+    PADNE_HIP_CHECK(hipGetLastError());
+    const int n_wt = (n + 63) / 64;
+    const dim3 gm((unsigned)std::min(2048, (n_wt + 3) / 4 > 0 ? (n_wt + 3) / 4 : 1));
     for (int round = 0; round < 64; ++round) {
         hipLaunchKernelGGL(mis_prep, g, b, 0, s, n, state, u0, 0);
-        hipLaunchKernelGGL(nbr_max, g, b, 0, s, n, A->rowptr, A->cols, A->vals, A->dinv, theta2, u0, u1);
-        hipLaunchKernelGGL(nbr_max, g, b, 0, s, n, A->rowptr, A->cols, A->vals, A->dinv, theta2, u1, u2);
+        hipLaunchKernelGGL(nbr_max, gm, b, 0, s, n, n_wt, srow, scol, u0, u1);
+        hipLaunchKernelGGL(nbr_max, gm, b, 0, s, n, n_wt, srow, scol, u1, u2);
         hipLaunchKernelGGL(mis_mark_roots, g, b, 0, s, n, state, u2);
         hipLaunchKernelGGL(mis_prep, g, b, 0, s, n, state, u0, 1);
-        hipLaunchKernelGGL(nbr_max, g, b, 0, s, n, A->rowptr, A->cols, A->vals, A->dinv, theta2, u0, u1);
-        hipLaunchKernelGGL(nbr_max, g, b, 0, s, n, A->rowptr, A->cols, A->vals, A->dinv, theta2, u1, u2);
+        hipLaunchKernelGGL(nbr_max, gm, b, 0, s, n, n_wt, srow, scol, u0, u1);
+        hipLaunchKernelGGL(nbr_max, gm, b, 0, s, n, n_wt, srow, scol, u1, u2);
         PADNE_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(int), s));
         hipLaunchKernelGGL(mis_cover, g, b, 0, s, n, state, u2, counter);
         PADNE_HIP_CHECK(hipGetLastError());
@@ -586,8 +661,8 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
     int64_t n_roots = 0;
     PADNE_TRY(exclusive_scan_i32(ctx, flag, scan, n, &n_roots));
     hipLaunchKernelGGL(agg_from_roots, g, b, 0, s, n, state, scan, agg0);
-    hipLaunchKernelGGL(agg_join, g, b, 0, s, n, A->rowptr, A->cols, A->vals, A->dinv, theta2, agg0, agg1);
-    hipLaunchKernelGGL(agg_join, g, b, 0, s, n, A->rowptr, A->cols, A->vals, A->dinv, theta2, agg1, agg0);
+    hipLaunchKernelGGL(agg_join, g, b, 0, s, n, srow, scol, sval, agg0, agg1);
+    hipLaunchKernelGGL(agg_join, g, b, 0, s, n, srow, scol, sval, agg1, agg0);
     hipLaunchKernelGGL(flag_unaggregated, g, b, 0, s, n, agg0, flag);
     PADNE_HIP_CHECK(hipGetLastError());
     int64_t n_single = 0;
@@ -599,29 +674,114 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
     return PADNE_OK;
 }
 
+// LDS variant of the prolongator rows: sorted (aggregate, value) lists per lane, products added in the
+// order prolong_fill + merge would add them.  Rows with more than CAP aggregates return -1 and take the
+// slot path below.
+template <int CAP>
+__global__ __launch_bounds__(128) void prolong_rows_lds(int n, const int *__restrict__ rowptr, const int *__restrict__ cols,
+                                                        const double *__restrict__ vals, const double *__restrict__ dinv,
+                                                        double theta2, double omega, const int *__restrict__ agg,
+                                                        const int *__restrict__ slot_ptr, long long *__restrict__ key,
+                                                        double *__restrict__ val, int *__restrict__ row_len) {
+    __shared__ int Kc[CAP][128];
+    __shared__ double Vc[CAP][128];
+    const int t = threadIdx.x;
+    const int i = blockIdx.x * 128 + t;
+    if (i >= n) return;
+    const double di = dinv[i];
+    double dF = 1.0 / di;
+    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+        const int j = cols[k];
+        if (j != i && !strong(vals[k], di, dinv[j], theta2)) dF += vals[k];
+    }
+    const bool keep_all = !(dF * di > 0.05);
+    if (keep_all) dF = 1.0 / di;
+    const double w = -omega / dF;
+    const int ai = agg[i];
+    int m = 1;
+    Kc[0][t] = ai;
+    Vc[0][t] = 1.0;
+    bool overflow = false;
+    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+        const int j = cols[k];
+        int c;
+        double v;
+        if (j == i) { c = ai; v = -omega; }
+        else if (keep_all || strong(vals[k], di, dinv[j], theta2)) { c = agg[j]; v = w * vals[k]; }
+        else continue;
+        int lo = 0;
+        while (lo < m && Kc[lo][t] < c) ++lo;
+        if (lo < m && Kc[lo][t] == c) {
+            Vc[lo][t] = Vc[lo][t] + v;
+        } else {
+            if (m == CAP) { overflow = true; break; }
+            for (int u = m; u > lo; --u) {
+                Kc[u][t] = Kc[u - 1][t];
+                Vc[u][t] = Vc[u - 1][t];
+            }
+            Kc[lo][t] = c;
+            Vc[lo][t] = v;
+            ++m;
+        }
+    }
+    if (overflow) {
+        row_len[i] = -1;
+        return;
+    }
+    long long *K = key + slot_ptr[i];
+    double *V = val + slot_ptr[i];
+    int o = 0;
+    for (int u = 0; u < m; ++u)
+        if (Vc[u][t] != 0.0) {
+            K[o] = (long long)Kc[u][t] << 32;
+            V[o] = Vc[u][t];
+            ++o;
+        }
+    row_len[i] = o;
+}
+
+// fix-up of rows the LDS kernel gave up on: merge their slots (filled by prolong_fill) the slow way
+__global__ void prolong_redo_flag(int n, const int *__restrict__ row_len, int *__restrict__ any) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && row_len[i] < 0) atomicExch(any, 1);
+}
+
 static int build_prolongator(padne_ctx *ctx, const padne_csr *A, const int *agg, int n_agg, double omega,
                              padne_csr **P) {
     hipStream_t s = ctx->stream;
     const int n = (int)A->n_rows;
-    Scratch sc;
+    Scratch sc(ctx);
     const size_t n_slots = (size_t)A->nnz + (size_t)n;
-    int *slot_ptr = nullptr, *row_len = nullptr;
+    int *slot_ptr = nullptr, *row_len = nullptr, *any = nullptr;
     long long *key = nullptr;
     double *val = nullptr;
     PADNE_TRY(sc.alloc(&slot_ptr, (size_t)n + 1));
     PADNE_TRY(sc.alloc(&row_len, (size_t)n + 1));
+    PADNE_TRY(sc.alloc(&any, 1));
     PADNE_TRY(sc.alloc(&key, n_slots));
     PADNE_TRY(sc.alloc(&val, n_slots));
-    hipLaunchKernelGGL(prolong_fill, dim3(nblk((long long)n + 1)), dim3(256), 0, s, n, A->rowptr, A->cols, A->vals,
-                       A->dinv, kTheta * kTheta, omega, agg, slot_ptr, key, val);
+    PADNE_HIP_CHECK(hipMemsetAsync(any, 0, sizeof(int), s));
+    hipLaunchKernelGGL(prolong_slot_ptr, dim3(nblk((long long)n + 1)), dim3(256), 0, s, n, A->rowptr, slot_ptr);
+    hipLaunchKernelGGL(prolong_rows_lds<24>, dim3(nblk(n, 128)), dim3(128), 0, s, n, A->rowptr, A->cols, A->vals, A->dinv,
+                       kTheta * kTheta, omega, agg, slot_ptr, key, val, row_len);
+    hipLaunchKernelGGL(prolong_redo_flag, dim3(nblk(n)), dim3(256), 0, s, n, row_len, any);
     PADNE_HIP_CHECK(hipGetLastError());
-    PADNE_TRY(merge_slots_generic(ctx, n, slot_ptr, key, val, row_len));
+    int h_any = 0;
+    PADNE_HIP_CHECK(hipMemcpyAsync(&h_any, any, sizeof(int), hipMemcpyDeviceToHost, s));
+    PADNE_HIP_CHECK(hipStreamSynchronize(s));
+    if (h_any) {
+        // rare (rows touching more than 24 aggregates): redo everything through the slot + merge path
+        hipLaunchKernelGGL(prolong_fill, dim3(nblk((long long)n + 1)), dim3(256), 0, s, n, A->rowptr, A->cols, A->vals,
+                           A->dinv, kTheta * kTheta, omega, agg, slot_ptr, key, val);
+        PADNE_HIP_CHECK(hipGetLastError());
+        PADNE_TRY(merge_slots_generic(ctx, n, slot_ptr, key, val, row_len));
+    }
     return csr_from_slots(ctx, n, n_agg, slot_ptr, key, val, row_len, P);
 }
 
 static int transpose(padne_ctx *ctx, const padne_csr *M, padne_csr **T) {
     hipStream_t s = ctx->stream;
-    Scratch sc;
+    Scratch sc(ctx);
     const long long nc = M->n_cols;
     int *cnt = nullptr, *slot_ptr = nullptr, *row_len = nullptr;
     long long *key = nullptr;
@@ -647,7 +807,7 @@ static int transpose(padne_ctx *ctx, const padne_csr *M, padne_csr **T) {
 
 static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_csr **C) {
     hipStream_t s = ctx->stream;
-    Scratch sc;
+    Scratch sc(ctx);
     const int n = (int)X->n_rows;
     int *cnt = nullptr, *slot_ptr = nullptr, *row_len = nullptr;
     PADNE_TRY(sc.alloc(&cnt, (size_t)n + 1));
@@ -672,7 +832,7 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
                                       (int)dense_lds);
             hipLaunchKernelGGL(spgemm_rows_dense, dim3(n), dim3(256), dense_lds, s, (int)Y->n_cols, X->rowptr, X->cols,
                                X->vals, Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len);
-        } else if (avg <= 64.0) {
+        } else if (avg <= 160.0) {
             // short rows: sorted lists in LDS, the few overflowing rows are redone in global memory
             hipLaunchKernelGGL(spgemm_rows_lds<24>, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
                                Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len);
@@ -690,15 +850,13 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
 static int dense_inverse(padne_ctx *ctx, const padne_csr *A, double **inv_out) {
     hipStream_t s = ctx->stream;
     const int n = (int)A->n_rows;
-    Scratch sc;
+    Scratch sc(ctx);
     double *W = nullptr, *frow = nullptr, *fcol = nullptr, *inv = nullptr;
     PADNE_TRY(sc.alloc(&W, (size_t)n * 2 * n));
     PADNE_TRY(sc.alloc(&frow, (size_t)2 * n));
     PADNE_TRY(sc.alloc(&fcol, (size_t)n));
-    if (hipMalloc((void **)&inv, sizeof(double) * (size_t)(n > 0 ? n : 1) * (size_t)(n > 0 ? n : 1)) != hipSuccess) {
-        set_error("hipMalloc failed for the coarse inverse");
-        return PADNE_E_NOMEM;
-    }
+    inv = (double *)pool_alloc(ctx, sizeof(double) * (size_t)(n > 0 ? n : 1) * (size_t)(n > 0 ? n : 1));
+    if (inv == nullptr) return PADNE_E_NOMEM;
     if (n > 0) {
         hipLaunchKernelGGL(dense_from_csr, dim3(n), dim3(256), 0, s, n, A->rowptr, A->cols, A->vals, W);
         const dim3 ge(nblk(2 * n), n);
@@ -711,7 +869,7 @@ static int dense_inverse(padne_ctx *ctx, const padne_csr *A, double **inv_out) {
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) {
-        (void)hipFree(inv);
+        pool_free(ctx, inv);
         set_error("coarse inverse failed: %s", hipGetErrorString(e));
         return PADNE_E_HIP;
     }
@@ -723,26 +881,22 @@ void amg_destroy(void *p) {
     Amg *amg = (Amg *)p;
     if (!amg) return;
     (void)hipSetDevice(amg->device);
-    (void)hipDeviceSynchronize();
     for (AmgLevel &L : amg->levels) {
         if (L.A_owned) padne_csr_destroy(L.A_owned);
         if (L.P) padne_csr_destroy(L.P);
         if (L.R) padne_csr_destroy(L.R);
-        if (L.b) (void)hipFree(L.b);
-        if (L.xa) (void)hipFree(L.xa);
-        if (L.xb) (void)hipFree(L.xb);
-        if (L.tmp) (void)hipFree(L.tmp);
+        pool_free(amg->ctx, L.b);
+        pool_free(amg->ctx, L.xa);
+        pool_free(amg->ctx, L.xb);
+        pool_free(amg->ctx, L.tmp);
     }
-    if (amg->coarse_inv) (void)hipFree(amg->coarse_inv);
+    pool_free(amg->ctx, amg->coarse_inv);
     delete amg;
 }
 
-static int alloc_vec(double **p, long long n) {
-    if (hipMalloc((void **)p, sizeof(double) * (size_t)(n > 0 ? n : 1)) != hipSuccess) {
-        set_error("hipMalloc failed for a multigrid work vector");
-        return PADNE_E_NOMEM;
-    }
-    return PADNE_OK;
+static int alloc_vec(padne_ctx *ctx, double **p, long long n) {
+    *p = (double *)pool_alloc(ctx, sizeof(double) * (size_t)(n > 0 ? n : 1));
+    return *p != nullptr ? PADNE_OK : PADNE_E_NOMEM;
 }
 
 struct PhaseTimer {   // wall-clock phase timing, only when PADNE_AMG_VERBOSE is set
@@ -774,6 +928,7 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
     PADNE_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
     Amg *amg = new Amg();
     amg->device = ctx->device;
+    amg->ctx = ctx;
     int rc = PADNE_OK;
     const padne_csr *A = A0;
     double nnz_total = 0.0;
@@ -796,13 +951,13 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         }
         L.jac = 1.0 / (0.5 * (L.lambda + L.lambda / kChebRatio));
         const bool coarsest = A->n_rows <= kCoarseN || lvl == kMaxLevels - 1;
-        if ((rc = alloc_vec(&L.xa, L.n)) != PADNE_OK || (rc = alloc_vec(&L.tmp, L.n)) != PADNE_OK) { amg->levels.push_back(L); break; }
-        if (lvl > 0 && ((rc = alloc_vec(&L.b, L.n)) != PADNE_OK || (rc = alloc_vec(&L.xb, L.n)) != PADNE_OK)) { amg->levels.push_back(L); break; }
+        if ((rc = alloc_vec(ctx, &L.xa, L.n)) != PADNE_OK || (rc = alloc_vec(ctx, &L.tmp, L.n)) != PADNE_OK) { amg->levels.push_back(L); break; }
+        if (lvl > 0 && ((rc = alloc_vec(ctx, &L.b, L.n)) != PADNE_OK || (rc = alloc_vec(ctx, &L.xb, L.n)) != PADNE_OK)) { amg->levels.push_back(L); break; }
         if (coarsest) {
             amg->levels.push_back(L);
             break;
         }
-        Scratch sc;
+        Scratch sc(ctx);
         int *agg = nullptr, n_agg = 0;
         PhaseTimer pt(ctx, amg_verbose());
         if ((rc = aggregate(ctx, sc, A, &agg, &n_agg)) != PADNE_OK) { amg->levels.push_back(L); break; }
@@ -839,6 +994,9 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         amg->levels.push_back(L);
         if (rc != PADNE_OK) break;
         if ((rc = csr_build_dinv(ctx, Ac)) != PADNE_OK) { padne_csr_destroy(Ac); break; }
+        Ac->hierarchy_operator = true;
+        amg->levels.back().P->hierarchy_operator = true;
+        amg->levels.back().R->hierarchy_operator = true;
         A = Ac;
     }
     if (rc == PADNE_OK) {

@@ -117,8 +117,8 @@ __global__ void sum_i32_as_i64(const int *__restrict__ in, long long n, unsigned
 int exclusive_scan_i32(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t n, int64_t *total) {
     const int nb = (int)((n + kScanChunk - 1) / kScanChunk);
     {   // exact 64-bit total first: the 32-bit scan below must not overflow silently
-        unsigned long long *d_tot = nullptr;
-        PADNE_HIP_CHECK(hipMalloc((void **)&d_tot, 16));
+        unsigned long long *d_tot = (unsigned long long *)pool_alloc(ctx, 16);
+        if (d_tot == nullptr) return PADNE_E_NOMEM;
         PADNE_HIP_CHECK(hipMemsetAsync(d_tot, 0, 16, ctx->stream));
         if (n > 0)
             hipLaunchKernelGGL(sum_i32_as_i64, dim3((unsigned)(nb < 1024 ? (nb > 0 ? nb : 1) : 1024)), dim3(256), 0,
@@ -126,7 +126,7 @@ int exclusive_scan_i32(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t 
         unsigned long long h2[2] = {0, 0};
         hipError_t e2 = hipMemcpyAsync(h2, d_tot, 16, hipMemcpyDeviceToHost, ctx->stream);
         if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
-        (void)hipFree(d_tot);
+        pool_free(ctx, d_tot);
         if (e2 != hipSuccess) {
             set_error("scan failed: %s", hipGetErrorString(e2));
             return PADNE_E_HIP;
@@ -136,8 +136,8 @@ int exclusive_scan_i32(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t 
             return PADNE_E_INVALID;
         }
     }
-    long long *bs = nullptr;
-    PADNE_HIP_CHECK(hipMalloc((void **)&bs, sizeof(long long) * (size_t)(nb + 2)));
+    long long *bs = (long long *)pool_alloc(ctx, sizeof(long long) * (size_t)(nb + 2));
+    if (bs == nullptr) return PADNE_E_NOMEM;
     long long *tot = bs + nb;
     if (nb > 0) hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(256), 0, ctx->stream, in, (long long)n, bs);
     hipLaunchKernelGGL(scan_block_offsets, dim3(1), dim3(64), 0, ctx->stream, bs, nb, tot);
@@ -148,7 +148,7 @@ int exclusive_scan_i32(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t 
     if (e == hipSuccess) e = hipMemcpyAsync(&h, tot, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess && nb == 0) e = hipMemsetAsync(out, 0, sizeof(int32_t), ctx->stream);
-    hipFree(bs);
+    pool_free(ctx, bs);
     if (e != hipSuccess) {
         set_error("scan failed: %s", hipGetErrorString(e));
         return PADNE_E_HIP;
@@ -277,11 +277,13 @@ template <bool MESH>
 __global__ void merge_rows(long long n_rows, long long n_vert, int n_mesh,
                            const long long *__restrict__ mesh_voff, const double *__restrict__ sigma,
                            const int *__restrict__ slot_ptr, long long *__restrict__ key,
-                           double *__restrict__ val, int *__restrict__ row_len, int *__restrict__ err) {
+                           double *__restrict__ val, int *__restrict__ row_len, int *__restrict__ err,
+                           const int min_len) {
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
     const int s0 = slot_ptr[r];
     const int n = slot_ptr[r + 1] - s0;
+    if (n < min_len) return;                       // short rows were merged by merge_rows_lds
     long long *K = key + s0;
     double *V = val + s0;
     sort_slots(K, V, n);
@@ -336,6 +338,49 @@ __global__ void merge_rows(long long n_rows, long long n_vert, int n_mesh,
         if (v != 0.0) {                                           // exact zeros are not stored
             K[o] = (long long)col << 32;
             V[o] = v;
+            ++o;
+        }
+    }
+    row_len[r] = o;
+}
+
+// Short rows of the generic merge: sort and add duplicates inside LDS ([slot][thread] layout), one lane per row.
+// Same order of additions as merge_rows<false> (key = column, then sequence), hence the same bits.
+template <int CAP>
+__global__ __launch_bounds__(128) void merge_rows_lds(long long n_rows, const int *__restrict__ slot_ptr,
+                                                      long long *__restrict__ key, double *__restrict__ val,
+                                                      int *__restrict__ row_len) {
+    __shared__ long long Kc[CAP][128];
+    __shared__ double Vc[CAP][128];
+    const int t = threadIdx.x;
+    const long long r = (long long)blockIdx.x * 128 + t;
+    if (r >= n_rows) return;
+    const int s0 = slot_ptr[r];
+    const int n = slot_ptr[r + 1] - s0;
+    if (n > CAP) return;                           // left to merge_rows<false>
+    for (int i = 0; i < n; ++i) {                  // insertion sort while loading
+        const long long k = key[s0 + i];
+        const double v = val[s0 + i];
+        int j = i - 1;
+        while (j >= 0 && Kc[j][t] > k) {
+            Kc[j + 1][t] = Kc[j][t];
+            Vc[j + 1][t] = Vc[j][t];
+            --j;
+        }
+        Kc[j + 1][t] = k;
+        Vc[j + 1][t] = v;
+    }
+    int o = 0, i = 0;
+    while (i < n) {
+        const int col = (int)(Kc[i][t] >> 32);
+        double v = 0.0;
+        while (i < n && (int)(Kc[i][t] >> 32) == col) {
+            v = v + Vc[i][t];
+            ++i;
+        }
+        if (v != 0.0) {
+            key[s0 + o] = (long long)col << 32;
+            val[s0 + o] = v;
             ++o;
         }
     }
@@ -451,9 +496,13 @@ static int finish_rows(padne_ctx *ctx, Scratch &sc, long long n_rows, long long 
     hipStream_t s = ctx->stream;
     int *row_len = nullptr;
     PADNE_TRY(sc.alloc(&row_len, (size_t)n_rows + 1));
-    hipLaunchKernelGGL(merge_rows<MESH>, dim3(nblk(n_rows, 128)), dim3(128), 0, s, n_rows, n_vert, n_mesh, d_voff,
-                       d_sigma, slot_ptr, key, val, row_len, d_err);
-    PADNE_HIP_CHECK(hipGetLastError());
+    if (MESH) {
+        hipLaunchKernelGGL(merge_rows<MESH>, dim3(nblk(n_rows, 128)), dim3(128), 0, s, n_rows, n_vert, n_mesh, d_voff,
+                           d_sigma, slot_ptr, key, val, row_len, d_err, 0);
+        PADNE_HIP_CHECK(hipGetLastError());
+    } else {
+        PADNE_TRY(merge_slots_generic(ctx, n_rows, slot_ptr, key, val, row_len));
+    }
     int h_err[ERR_WORDS];
     PADNE_HIP_CHECK(hipMemcpyAsync(h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
     PADNE_HIP_CHECK(hipStreamSynchronize(s));
@@ -488,9 +537,12 @@ static int finish_rows(padne_ctx *ctx, Scratch &sc, long long n_rows, long long 
 // exported to amg.hip --------------------------------------------------------------------------
 int merge_slots_generic(padne_ctx *ctx, long long n_rows, const int *slot_ptr, long long *key, double *val,
                         int *row_len) {
+    constexpr int kLdsCap = 32;
+    hipLaunchKernelGGL(merge_rows_lds<kLdsCap>, dim3(nblk(n_rows, 128)), dim3(128), 0, ctx->stream, n_rows, slot_ptr, key,
+                       val, row_len);
     hipLaunchKernelGGL(merge_rows<false>, dim3(nblk(n_rows, 128)), dim3(128), 0, ctx->stream, n_rows, 0LL, 0,
                        (const long long *)nullptr, (const double *)nullptr, slot_ptr, key, val, row_len,
-                       (int *)nullptr);
+                       (int *)nullptr, kLdsCap + 1);
     PADNE_HIP_CHECK(hipGetLastError());
     return PADNE_OK;
 }
@@ -498,7 +550,7 @@ int merge_slots_generic(padne_ctx *ctx, long long n_rows, const int *slot_ptr, l
 int csr_from_slots(padne_ctx *ctx, long long n_rows, long long n_cols, const int *slot_ptr, const long long *key,
                    const double *val, const int *row_len, padne_csr **out) {
     hipStream_t s = ctx->stream;
-    Scratch sc;
+    Scratch sc(ctx);
     int *rowptr_tmp = nullptr;
     PADNE_TRY(sc.alloc(&rowptr_tmp, (size_t)n_rows + 1));
     int64_t nnz = 0;
@@ -557,7 +609,7 @@ extern "C" int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns, int64_t
     }
     PADNE_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    Scratch sc;
+    Scratch sc(ctx);
     double *d_xy = nullptr, *d_sigma = nullptr, *d_cval = nullptr;
     int *d_tri = nullptr, *d_crow = nullptr, *d_ccol = nullptr, *d_cnt = nullptr, *d_slot = nullptr, *d_err = nullptr;
     long long *d_voff = nullptr, *d_toff = nullptr;
@@ -636,7 +688,7 @@ extern "C" int padne_csr_reduce(padne_ctx *ctx, const padne_csr *m, const int32_
         PADNE_REQUIRE(map_host[i] >= -1 && map_host[i] < n_out, "map entry out of range");
     PADNE_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    Scratch sc;
+    Scratch sc(ctx);
     int *d_map = nullptr, *d_cnt = nullptr, *d_slot = nullptr, *d_err = nullptr;
     PADNE_TRY(sc.alloc(&d_map, (size_t)m->n_rows));
     PADNE_TRY(sc.alloc(&d_cnt, (size_t)n_out + 1));
@@ -682,7 +734,7 @@ static int face_fields(padne_ctx *ctx, int64_t n_vert, const double *xy_host, in
     }
     PADNE_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    Scratch sc;
+    Scratch sc(ctx);
     double *d_xy = nullptr, *d_sigma = nullptr, *d_pot = nullptr, *d_out = nullptr, *d_gx = nullptr, *d_gy = nullptr;
     int *d_tri = nullptr;
     long long *d_voff = nullptr, *d_toff = nullptr;

@@ -32,6 +32,68 @@ int ensure_workspace(padne_ctx *ctx, size_t bytes) {
     return PADNE_OK;
 }
 
+constexpr size_t kPoolCacheLimit = (size_t)96 << 30;   // bytes kept for reuse (the card has 288 GB)
+
+static size_t pool_round(size_t bytes) {
+    if (bytes < 256) bytes = 256;
+    if (bytes >= ((size_t)1 << 20)) return (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);   // MiB granules
+    size_t p = 256;
+    while (p < bytes) p <<= 1;
+    return p;
+}
+
+void *pool_alloc(padne_ctx *ctx, size_t bytes) {
+    const size_t want = pool_round(bytes);
+    auto it = ctx->pool_free_blocks.lower_bound(want);
+    if (it != ctx->pool_free_blocks.end() && it->first <= want + want / 2 + ((size_t)1 << 20)) {
+        void *p = it->second;
+        ctx->pool_cached_bytes -= it->first;
+        ctx->pool_free_blocks.erase(it);
+        return p;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {   // give cached blocks back to the driver and retry once
+        (void)hipGetLastError();
+        pool_release_all(ctx);
+        e = hipMalloc(&p, want);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("hipMalloc of %zu bytes failed: %s", want, hipGetErrorString(e));
+        return nullptr;
+    }
+    ctx->pool_sizes[p] = want;
+    return p;
+}
+
+void pool_free(padne_ctx *ctx, void *p) {
+    if (p == nullptr) return;
+    auto it = ctx->pool_sizes.find(p);
+    if (it == ctx->pool_sizes.end()) {   // not ours: plain free
+        (void)hipFree(p);
+        return;
+    }
+    if (ctx->pool_cached_bytes + it->second > kPoolCacheLimit) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(p);
+        ctx->pool_sizes.erase(it);
+        return;
+    }
+    ctx->pool_free_blocks.emplace(it->second, p);
+    ctx->pool_cached_bytes += it->second;
+}
+
+void pool_release_all(padne_ctx *ctx) {
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->pool_free_blocks) {
+        (void)hipFree(kv.second);
+        ctx->pool_sizes.erase(kv.second);
+    }
+    ctx->pool_free_blocks.clear();
+    ctx->pool_cached_bytes = 0;
+}
+
 int csr_alloc(padne_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, padne_csr **out) {
     PADNE_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0, "negative size");
     PADNE_REQUIRE(nnz < (int64_t)2147483647 - kPadNnz && n_rows < 2147483647 && n_cols < 2147483647,
@@ -41,13 +103,13 @@ int csr_alloc(padne_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, padne
     m->n_cols = n_cols;
     m->nnz = nnz;
     m->device = ctx->device;
+    m->owner = ctx;
     const size_t ne = (size_t)nnz + kPadNnz;
-    if (hipMalloc((void **)&m->rowptr, sizeof(int32_t) * (size_t)(n_rows + 1)) != hipSuccess ||
-        hipMalloc((void **)&m->cols, sizeof(int32_t) * ne) != hipSuccess ||
-        hipMalloc((void **)&m->vals, sizeof(double) * ne) != hipSuccess) {
+    m->rowptr = (int32_t *)pool_alloc(ctx, sizeof(int32_t) * (size_t)(n_rows + 1));
+    m->cols = (int32_t *)pool_alloc(ctx, sizeof(int32_t) * ne);
+    m->vals = (double *)pool_alloc(ctx, sizeof(double) * ne);
+    if (!m->rowptr || !m->cols || !m->vals) {
         padne_csr_destroy(m);
-        set_error("hipMalloc failed for a %lld x %lld matrix with %lld non-zeros", (long long)n_rows,
-                  (long long)n_cols, (long long)nnz);
         return PADNE_E_NOMEM;
     }
     // zero the padding (column 0 / value 0.0) so the SpMV tile loads never need a bounds check
@@ -126,6 +188,9 @@ int padne_ctx_destroy(padne_ctx *ctx) {
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     comm_destroy(ctx);
+    pool_release_all(ctx);
+    for (auto &kv : ctx->pool_sizes) (void)hipFree(kv.first);   // blocks still held by live matrices
+    ctx->pool_sizes.clear();
     if (ctx->halo_export) hipFree(ctx->halo_export);
     if (ctx->ws) hipFree(ctx->ws);
     if (ctx->partials) hipFree(ctx->partials);
@@ -222,12 +287,14 @@ int padne_csr_from_host(padne_ctx *ctx, int64_t n_rows, int64_t n_cols, const in
 int padne_csr_destroy(padne_csr *m) {
     if (!m) return PADNE_OK;
     hipSetDevice(m->device);
-    hipDeviceSynchronize();
-    if (m->rowptr) hipFree(m->rowptr);
-    if (m->cols) hipFree(m->cols);
-    if (m->vals) hipFree(m->vals);
-    if (m->dinv) hipFree(m->dinv);
     if (m->amg) amg_destroy(m->amg);
+    // the arrays go back to the owner's pool: later work on the same stream may reuse them at once
+    if (m->owner) {
+        pool_free(m->owner, m->rowptr);
+        pool_free(m->owner, m->cols);
+        pool_free(m->owner, m->vals);
+        pool_free(m->owner, m->dinv);
+    }
     delete m;
     return PADNE_OK;
 }

@@ -4,7 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <map>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/padne_hip.h"
@@ -64,7 +66,9 @@ struct padne_csr {
     double *vals = nullptr;      // [nnz + pad]   padding entries are 0.0
     double *dinv = nullptr;      // [n_rows] 1/diag, built on first use (square matrices)
     int device = 0;
+    padne_ctx *owner = nullptr;  // context whose pool the arrays came from (must outlive the matrix)
     void *amg = nullptr;         // cached multigrid hierarchy (padne::Amg*), owned
+    bool hierarchy_operator = false;   // multigrid-internal operator: may use the wave-per-row SpMV
     padne_csr *prec_block = nullptr;   // borrowed: owned x owned diagonal block for the preconditioner
 };
 
@@ -88,6 +92,11 @@ struct padne_ctx {
     int halo_m = 0, halo_n_export = 0;
     int32_t *halo_export = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // caching device allocator (see pool_alloc): hipMalloc/hipFree of GB-sized blocks cost up to hundreds of
+    // milliseconds, which would dominate the multigrid setup that runs inside every solve
+    std::multimap<size_t, void *> pool_free_blocks;
+    std::unordered_map<void *, size_t> pool_sizes;
+    size_t pool_cached_bytes = 0;
 };
 
 namespace padne {
@@ -119,16 +128,22 @@ void amg_destroy(void *amg);
 // pcg.hip: largest eigenvalue of D^-1 A from `steps` Lanczos (Jacobi-PCG) steps
 int estimate_lambda_max(padne_ctx *ctx, const padne_csr *a, int steps, double *lambda);
 
+// Per-context caching allocator.  All work of a context is ordered on its one stream, so a block handed back
+// may be reused by later launches without synchronisation.  Blocks are kept (up to kPoolCacheLimit) until the
+// context is destroyed.
+void *pool_alloc(padne_ctx *ctx, size_t bytes);     // nullptr on failure (error message set)
+void pool_free(padne_ctx *ctx, void *p);
+void pool_release_all(padne_ctx *ctx);
+
 // assemble.hip helpers shared with amg.hip
-struct Scratch {   // device allocations freed on scope exit
+struct Scratch {   // device allocations returned to the pool on scope exit
+    padne_ctx *ctx;
     std::vector<void *> ptrs;
-    ~Scratch() { for (void *p : ptrs) if (p) (void)hipFree(p); }
+    explicit Scratch(padne_ctx *c) : ctx(c) {}
+    ~Scratch() { for (void *p : ptrs) if (p) pool_free(ctx, p); }
     template <typename T> int alloc(T **out, size_t count) {
-        void *p = nullptr;
-        if (hipMalloc(&p, sizeof(T) * (count ? count : 1)) != hipSuccess) {
-            set_error("hipMalloc of %zu bytes failed", sizeof(T) * count);
-            return PADNE_E_NOMEM;
-        }
+        void *p = pool_alloc(ctx, sizeof(T) * (count ? count : 1));
+        if (p == nullptr) return PADNE_E_NOMEM;
         ptrs.push_back(p);
         *out = (T *)p;
         return PADNE_OK;

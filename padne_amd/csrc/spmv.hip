@@ -144,7 +144,60 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
     }
 }
 
+// Wave-per-row variant for the small, dense operators at the bottom of the multigrid hierarchy (tens to
+// hundreds of non-zeros per row, a few thousand rows): there the tile kernel above is latency-bound on a
+// handful of waves.  The lanes of a wave stride over one row and the partial sums are combined with a
+// fixed shuffle tree, so results are reproducible (but not in CSR order: never used for the fine matrix).
+template <int MODE>
+__global__ __launch_bounds__(kSpmvThreads) void csr_spmv_wpr_kernel(
+    const int n_rows, const int *__restrict__ rowptr, const int *__restrict__ cols, const double *__restrict__ vals,
+    const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ dot_with,
+    double *__restrict__ partials, const int *__restrict__ done_flag, const double *__restrict__ aux1,
+    const double *__restrict__ aux2, const double scale) {
+    constexpr bool WITH_DOT = (MODE == SPMV_DOT) || (MODE == SPMV_JACOBI);
+    __shared__ double red[4];
+    if (done_flag != nullptr && *done_flag != 0) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int W = gridDim.x * 4;
+    double dot_acc = 0.0;
+    for (int r = blockIdx.x * 4 + w; r < n_rows; r += W) {
+        const int rs = rowptr[r], re = rowptr[r + 1];
+        double acc = 0.0;
+        for (int k = rs + lane; k < re; k += 64) acc += vals[k] * x[cols[k]];
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            if (MODE == SPMV_PLAIN) {
+                y[r] = acc;
+            } else if (MODE == SPMV_DOT) {
+                y[r] = acc;
+                dot_acc += dot_with[r] * acc;
+            } else if (MODE == SPMV_RESID) {
+                y[r] = aux1[r] - acc;
+            } else if (MODE == SPMV_ADD) {
+                y[r] += acc;
+            } else {
+                const double b = aux1[r];
+                const double out = x[r] + scale * aux2[r] * (b - acc);
+                y[r] = out;
+                dot_acc += b * out;
+            }
+        }
+    }
+    if (WITH_DOT && partials != nullptr) {
+        const double s = block_sum_256(dot_acc, red);
+        if (threadIdx.x == 0) partials[blockIdx.x] = s;
+    }
+}
+
+static inline bool use_wave_per_row(const padne_csr *m) {
+    return m->hierarchy_operator && m->n_rows > 0 && m->n_rows <= 65536 && m->nnz >= 24 * m->n_rows;
+}
+
 int spmv_grid(const padne_csr *m) {
+    if (use_wave_per_row(m)) {
+        long long g = (m->n_rows + 3) / 4;
+        return (int)(g < kMaxPartials ? g : kMaxPartials);
+    }
     const long long n_tiles = (m->n_rows + kSpmvRows - 1) / kSpmvRows;   // 4 wave-tiles per workgroup-turn
     long long g = n_tiles < kMaxPartials ? n_tiles : kMaxPartials;
     if (g >= kNumXcd) g -= g % kNumXcd;
@@ -158,6 +211,22 @@ int launch_spmv_mode(padne_ctx *ctx, const padne_csr *m, int mode, const double 
     if (m->n_rows == 0) return PADNE_OK;
     const int n_tiles = (int)((m->n_rows + 63) / 64);   // wave-tiles of 64 rows
     const int g = spmv_grid(m);
+    if (use_wave_per_row(m)) {
+#define PADNE_SPMV_WPR(M)                                                                                  \
+    hipLaunchKernelGGL(csr_spmv_wpr_kernel<M>, dim3(g), dim3(kSpmvThreads), 0, ctx->stream, (int)m->n_rows, \
+                       m->rowptr, m->cols, m->vals, x, y, dot_with, partials, done_flag, aux1, aux2, scale)
+        switch (mode) {
+            case SPMV_PLAIN: PADNE_SPMV_WPR(SPMV_PLAIN); break;
+            case SPMV_DOT: PADNE_SPMV_WPR(SPMV_DOT); break;
+            case SPMV_RESID: PADNE_SPMV_WPR(SPMV_RESID); break;
+            case SPMV_ADD: PADNE_SPMV_WPR(SPMV_ADD); break;
+            case SPMV_JACOBI: PADNE_SPMV_WPR(SPMV_JACOBI); break;
+            default: set_error("bad SpMV mode %d", mode); return PADNE_E_INVALID;
+        }
+#undef PADNE_SPMV_WPR
+        PADNE_HIP_CHECK(hipGetLastError());
+        return PADNE_OK;
+    }
 #define PADNE_SPMV_LAUNCH(M)                                                                           \
     hipLaunchKernelGGL(csr_spmv_kernel<M>, dim3(g), dim3(kSpmvThreads), 0, ctx->stream, (int)m->n_rows, \
                        n_tiles, m->rowptr, m->cols, m->vals, x, y, dot_with, partials, done_flag, aux1,  \
@@ -196,7 +265,8 @@ __global__ void csr_dinv_kernel(int n_rows, const int *__restrict__ rowptr,
 int csr_build_dinv(padne_ctx *ctx, padne_csr *m) {
     if (m->dinv != nullptr) return PADNE_OK;
     PADNE_REQUIRE(m->n_rows <= m->n_cols, "Jacobi needs a diagonal");
-    PADNE_HIP_CHECK(hipMalloc((void **)&m->dinv, sizeof(double) * (size_t)(m->n_rows > 0 ? m->n_rows : 1)));
+    m->dinv = (double *)pool_alloc(m->owner ? m->owner : ctx, sizeof(double) * (size_t)(m->n_rows > 0 ? m->n_rows : 1));
+    if (m->dinv == nullptr) return PADNE_E_NOMEM;
     if (m->n_rows > 0) {
         const int bs = 256;
         hipLaunchKernelGGL(csr_dinv_kernel, dim3((unsigned)((m->n_rows + bs - 1) / bs)), dim3(bs), 0,
