@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--precond", default="amg", choices=["amg", "jacobi"],
                     help="amg: smoothed-aggregation multigrid V-cycle (rebuilt inside every step); jacobi: diagonal")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-distributed", action="store_true",
+                    help="run the row-partitioned code path (RCCL communicator, halo plan, block multigrid) even on 1 GPU")
     ap.add_argument("--cpu-sample-nx", type=int, default=400,
                     help="grid edge of the bounded CPU-baseline sample (8 layers of nx*nx)")
     return ap.parse_args()
@@ -120,14 +122,16 @@ def main():
     import torch.distributed as dist
     from padne_amd import _hip, synthetic
 
-    if world > 1:
+    distributed_path = world > 1 or args.force_distributed
+    if distributed_path:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     ctx = _hip.Context(local_rank)
 
     def barrier():
-        if world > 1:
+        if distributed_path:
             dist.barrier()
         torch.cuda.synchronize()
         ctx.synchronize()
@@ -137,7 +141,7 @@ def main():
     nv = sysm.n_vertices
     N = nv + 1
     t_setup0 = time.perf_counter()
-    if world == 1:
+    if not distributed_path:
         xy, tri, mvo, mto, sig = flat(sysm)
         rows, cols, vals, rhs = stamps_of(sysm, N)
         t0 = time.perf_counter()
@@ -181,7 +185,7 @@ def main():
         last = solver()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if distributed_path:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -236,7 +240,7 @@ def main():
             except Exception as exc:  # the GPU numbers stand on their own
                 out["cpu_baseline"] = {"error": repr(exc)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if distributed_path:
         dist.barrier()
         dist.destroy_process_group()
 
