@@ -51,7 +51,17 @@ struct Amg {
 };
 
 constexpr double kTheta = 0.1;
-constexpr int kCoarseN = 1024;
+static int coarse_n_limit() {   // coarsest-level size below which the dense inverse takes over
+    static int v = 0;
+    if (v == 0) {
+        const char *e = getenv("PADNE_AMG_COARSE_N");
+        v = e ? atoi(e) : 1024;
+        if (v < 16) v = 16;
+        if (v > 4096) v = 4096;
+    }
+    return v;
+}
+#define kCoarseN coarse_n_limit()
 constexpr int kMaxLevels = 16;
 constexpr double kChebRatio = 10.0;
 
@@ -167,7 +177,7 @@ __global__ void mis_cover(int n, signed char *__restrict__ state, const unsigned
         if (c2[i] > 0) state[i] = 2;
         else open = true;
     }
-    if (__ballot(open) != 0ull && (threadIdx.x & 63) == 0) atomicAdd(undecided, 1);   // only "any left?" matters
+    if (__ballot(open) != 0ull && (threadIdx.x & 63) == 0) *undecided = 1;   // only "any left?" matters (benign race)
 }
 
 __global__ void flag_state(int n, const signed char *__restrict__ state, int *__restrict__ flag, int which) {
@@ -834,7 +844,7 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
                                X->vals, Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len);
         } else if (avg <= 160.0) {
             // short rows: sorted lists in LDS, the few overflowing rows are redone in global memory
-            hipLaunchKernelGGL(spgemm_rows_lds<24>, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
+            hipLaunchKernelGGL(spgemm_rows_lds<32>, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
                                Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len);
             hipLaunchKernelGGL(spgemm_rows_redo, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
                                Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len);

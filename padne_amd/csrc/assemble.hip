@@ -387,16 +387,39 @@ __global__ __launch_bounds__(128) void merge_rows_lds(long long n_rows, const in
     row_len[r] = o;
 }
 
-__global__ void compact_rows(long long n_rows, const int *__restrict__ slot_ptr, const int *__restrict__ rowptr,
-                             const long long *__restrict__ key, const double *__restrict__ val,
-                             int *__restrict__ cols, double *__restrict__ vals) {
-    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rows) return;
-    const int s = slot_ptr[r];
-    const int d0 = rowptr[r], d1 = rowptr[r + 1];
-    for (int j = 0; j < d1 - d0; ++j) {
-        cols[d0 + j] = (int)(key[s + j] >> 32);
-        vals[d0 + j] = val[s + j];
+// Rows already compacted at their slot offsets -> final CSR arrays.  A wave moves 64 consecutive rows: both the
+// source span [slot_ptr[r0], slot_ptr[r0+64]) and the destination span [rowptr[r0], rowptr[r0+64]) are
+// contiguous, lanes walk the destination (coalesced stores) and find their row by bisection in LDS.
+__global__ __launch_bounds__(256) void compact_rows(long long n_rows, const int *__restrict__ slot_ptr,
+                                                    const int *__restrict__ rowptr, const long long *__restrict__ key,
+                                                    const double *__restrict__ val, int *__restrict__ cols,
+                                                    double *__restrict__ vals) {
+    __shared__ int rp_all[4][65];
+    __shared__ int sp_all[4][65];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int *rp = rp_all[w], *sp = sp_all[w];
+    const long long n_wt = (n_rows + 63) / 64;
+    for (long long wt = (long long)blockIdx.x * 4 + w; wt < n_wt; wt += (long long)gridDim.x * 4) {
+        const long long r0 = wt * 64;
+        const int nr = (int)((n_rows - r0) < 64 ? (n_rows - r0) : 64);
+        if (lane <= nr) rp[lane] = rowptr[r0 + lane];
+        if (lane < nr) sp[lane] = slot_ptr[r0 + lane];
+        if (lane == 0 && nr == 64) rp[64] = rowptr[r0 + 64];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const int d0 = rp[0], d1 = rp[nr];
+        for (int k = d0 + lane; k < d1; k += 64) {
+            int lo = 0, hi = nr;                     // largest row with rp[row] <= k
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (rp[mid] <= k) lo = mid; else hi = mid;
+            }
+            const int src = sp[lo] + (k - rp[lo]);
+            cols[k] = (int)(key[src] >> 32);
+            vals[k] = val[src];
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -519,7 +542,7 @@ static int finish_rows(padne_ctx *ctx, Scratch &sc, long long n_rows, long long 
     hipError_t e = hipMemcpyAsync(m->rowptr, rowptr_tmp, sizeof(int32_t) * (size_t)(n_rows + 1),
                                   hipMemcpyDeviceToDevice, s);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(compact_rows, dim3(nblk(n_rows)), dim3(256), 0, s, n_rows, slot_ptr, m->rowptr, key, val,
+        hipLaunchKernelGGL(compact_rows, dim3(nblk((n_rows + 63) / 64, 4)), dim3(256), 0, s, n_rows, slot_ptr, m->rowptr, key, val,
                            m->cols, m->vals);
         e = hipGetLastError();
     }
@@ -560,7 +583,7 @@ int csr_from_slots(padne_ctx *ctx, long long n_rows, long long n_cols, const int
     hipError_t e = hipMemcpyAsync(m->rowptr, rowptr_tmp, sizeof(int32_t) * (size_t)(n_rows + 1),
                                   hipMemcpyDeviceToDevice, s);
     if (e == hipSuccess && n_rows > 0) {
-        hipLaunchKernelGGL(compact_rows, dim3(nblk(n_rows)), dim3(256), 0, s, n_rows, slot_ptr, m->rowptr, key, val,
+        hipLaunchKernelGGL(compact_rows, dim3(nblk((n_rows + 63) / 64, 4)), dim3(256), 0, s, n_rows, slot_ptr, m->rowptr, key, val,
                            m->cols, m->vals);
         e = hipGetLastError();
     }

@@ -471,3 +471,57 @@ def test_halo_and_rccl_path_with_one_rank_communicator():
         block.close()
     finally:
         ctx2.close()
+
+
+# ---- unstructured meshes (what CGAL produces: arbitrary vertex order, variable valence) ---------------
+
+def delaunay_mesh(n_points, seed, hole=True):
+    import scipy.spatial
+    rng = np.random.default_rng(seed)
+    pts = rng.uniform(0, 40, (n_points, 2))
+    if hole:
+        pts = pts[np.hypot(pts[:, 0] - 20, pts[:, 1] - 20) > 6.0]
+    d = scipy.spatial.Delaunay(pts)
+    tri = d.simplices.astype(np.int32)
+    if hole:
+        c = pts[tri].mean(axis=1)
+        tri = tri[np.hypot(c[:, 0] - 20, c[:, 1] - 20) > 6.5]
+    a, b, c = pts[tri[:, 0]], pts[tri[:, 1]], pts[tri[:, 2]]
+    cross = (b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (b[:, 1] - a[:, 1]) * (c[:, 0] - a[:, 0])
+    tri[cross < 0] = tri[cross < 0][:, [0, 2, 1]]              # counter-clockwise like CGAL
+    used = np.unique(tri)
+    remap = -np.ones(len(pts), dtype=np.int64)
+    remap[used] = np.arange(len(used))
+    return pts[used], remap[tri].astype(np.int32)
+
+
+def test_unstructured_delaunay_mesh_assembly_and_solve(ctx):
+    xy, tri = delaunay_mesh(30000, seed=11)
+    n = len(xy)
+    O.check_manifold(n, tri)                                           # sanity of the generator
+    sigma = 2082.5
+    far = int(np.argmax(xy[:, 0] + xy[:, 1]))
+    near = int(np.argmin(xy[:, 0] + xy[:, 1]))
+    els = [("I", near, far, 1.0), ("R", near, far, 0.05)]
+    Lo, ro = O.assemble_system([(xy, tri, sigma)], 0, els, 7)
+    Lo.sort_indices()
+    stamps = solver.StampList(n + 1)
+    g = 1 / 0.05
+    for (i, j, v) in ((near, near, -g), (near, far, g), (far, far, -g), (far, near, g)):
+        stamps.add(i, j, v)
+    r = np.zeros(n + 1)
+    r[near] += 1.0
+    r[far] -= 1.0
+    solver.setup_ground_node(7, stamps, r)
+    L = solver.assemble_from_arrays([mesh.Mesh(xy, tri)], [sigma], stamps, n)
+    got = L.tocsr()
+    assert H.same_structure(got, Lo) and np.array_equal(got.data, Lo.data)
+    assert np.array_equal(r, ro)
+    v_ref, gc, res = O.solve_system(Lo, ro)
+    v, info = solver.solve_system(L, r)
+    assert np.abs(v[:n] - v_ref[:n]).max() <= REL_TOL * np.abs(v_ref[:n]).max()
+    assert info.residual_norm < 1e-9 and abs(info.ground_node_current) < 1e-9
+    assert info.iterations < 80                                          # multigrid copes with the irregular mesh
+    pd = ctx.power_density(xy, tri, [0, n], [0, len(tri)], [sigma], v_ref[:n])
+    assert np.array_equal(pd, O.power_density(xy, tri, v_ref[:n], sigma))
+    L.dev.close()
