@@ -525,3 +525,83 @@ def test_unstructured_delaunay_mesh_assembly_and_solve(ctx):
     pd = ctx.power_density(xy, tri, [0, n], [0, len(tri)], [sigma], v_ref[:n])
     assert np.array_equal(pd, O.power_density(xy, tri, v_ref[:n], sigma))
     L.dev.close()
+
+
+# ---- more Problem-level behaviour of the reference's solve() ---------------------------------------------
+
+def two_island_problem():
+    """Two copper islands on one layer and a second layer; a star of 1 mOhm resistors to an internal node
+    (multi-pad terminal, kicad.py:535-556), a regulator between the islands, a load resistor."""
+    top = problem.Layer(shape=structured.Shapes.of(structured.Rect(0, 0, 6, 3), structured.Rect(8, 0, 14, 3)),
+                        name="F.Cu", conductance=2082.5)
+    bot = problem.Layer(shape=structured.Shapes.of(structured.Rect(0, 0, 14, 3)), name="B.Cu", conductance=1041.25)
+    P = mesh.Point
+    # supply: 5 V source on the left island, its return on the bottom layer
+    c_in_p = problem.Connection(layer=top, point=P(0.6, 1.5))
+    c_in_n = problem.Connection(layer=bot, point=P(0.6, 1.5))
+    supply = problem.Network(connections=[c_in_p, c_in_n],
+                             elements=[problem.VoltageSource(p=c_in_p.node_id, n=c_in_n.node_id, voltage=5.0)])
+    # regulator: senses the left island (s_f -> s_t draws gain * output current), drives the right island at 3.3 V
+    c_sf = problem.Connection(layer=top, point=P(5.4, 1.5))
+    c_st = problem.Connection(layer=bot, point=P(5.4, 1.5))
+    c_vp = problem.Connection(layer=top, point=P(8.6, 1.5))
+    c_vn = problem.Connection(layer=bot, point=P(8.6, 1.5))
+    reg = problem.Network(connections=[c_sf, c_st, c_vp, c_vn],
+                          elements=[problem.VoltageRegulator(v_p=c_vp.node_id, v_n=c_vn.node_id, s_f=c_sf.node_id,
+                                                             s_t=c_st.node_id, voltage=3.3, gain=1.0)])
+    # load: three pads on the right island tied to an internal node by 1 mOhm, then 2.2 Ohm to the bottom layer
+    pads = [problem.Connection(layer=top, point=P(13.2, y)) for y in (0.6, 1.5, 2.4)]
+    c_ret = problem.Connection(layer=bot, point=P(13.2, 1.5))
+    hub = problem.NodeID()
+    load = problem.Network(connections=pads + [c_ret],
+                           elements=[problem.Resistor(a=c.node_id, b=hub, resistance=1e-3) for c in pads] +
+                                    [problem.Resistor(a=hub, b=c_ret.node_id, resistance=2.2)])
+    return problem.Problem(layers=[top, bot], networks=[supply, reg, load]), (c_vp, c_vn, c_sf, c_st, hub, c_ret, pads)
+
+
+def test_regulator_star_and_multi_island_problem_end_to_end(ctx):
+    prob, (c_vp, c_vn, c_sf, c_st, hub, c_ret, pads) = two_island_problem()
+    mesher = structured.StructuredMesher(mesh.Mesher.Config(maximum_size=0.3), jitter=0.1, seed=1)
+    sol = solver.solve(prob, mesher=mesher)
+    assert len(sol.layer_solutions) == 2
+    assert len(sol.layer_solutions[0].meshes) == 2 and len(sol.layer_solutions[1].meshes) == 1
+    # 5 V forced across a 2 kS sheet drives kilo-amps: scale the reference's absolute 1e-9 A bar accordingly
+    amps = 5.0 * 2082.5
+    assert sol.solver_info.residual_norm < 1e-9 * amps and abs(sol.solver_info.ground_node_current) < 1e-9 * amps
+    # rebuild the same system through the reference-shaped seams and check against the oracle's direct solve
+    meshes = [m for ls in sol.layer_solutions for m in ls.meshes]
+    m2l = [0, 0, 1]
+    vi = solver.VertexIndexer.create(meshes)
+    ni = solver.NodeIndexer.create(prob, meshes, m2l, vi, prob.networks)
+    L, r = solver.assemble_system(prob, meshes, m2l, vi, prob.networks, ni)
+    els = []
+    for net in prob.networks:
+        for e in net.elements:
+            ix = ni.node_to_global_index
+            if isinstance(e, problem.Resistor):
+                els.append(("R", ix[e.a], ix[e.b], e.resistance))
+            elif isinstance(e, problem.VoltageSource):
+                els.append(("V", ix[e.p], ix[e.n], e.voltage, ni.extra_source_to_global_index[e]))
+            elif isinstance(e, problem.VoltageRegulator):
+                els.append(("REG", ix[e.v_p], ix[e.v_n], ix[e.s_f], ix[e.s_t], e.voltage, e.gain,
+                            ni.extra_source_to_global_index[e]))
+    sig = [prob.layers[l].conductance for l in m2l]
+    Lo, ro = O.assemble_system([(m.points, m.triangles, s) for m, s in zip(meshes, sig)], ni.internal_node_count, els,
+                               solver.find_best_ground_node_index(prob, ni))
+    Lo.sort_indices()
+    got = L.tocsr()
+    assert H.same_structure(got, Lo) and np.array_equal(got.data, Lo.data) and np.array_equal(r, ro)
+    v_ref, gc_ref, _ = O.solve_system(Lo, ro)
+    v, info = solver.solve_system(L, r)
+    n_pot = len(vi) + ni.internal_node_count
+    assert np.abs(v[:n_pot] - v_ref[:n_pot]).max() <= REL_TOL * np.abs(v_ref[:n_pot]).max()
+    assert np.abs(v[n_pot:] - v_ref[n_pot:]).max() <= 1e-7 * np.abs(v_ref[n_pot:]).max()
+    ix = ni.node_to_global_index
+    # physics: the regulator holds 3.3 V across its output pins, the load draws ~1.5 A, the input mirrors it
+    assert abs((v[ix[c_vp.node_id]] - v[ix[c_vn.node_id]]) - 3.3) < 1e-9
+    i_out = v[ni.extra_source_to_global_index[prob.networks[1].elements[0]]]
+    assert abs(i_out - 3.3 / 2.2) < 0.01 * 3.3 / 2.2
+    i_in = v[ni.extra_source_to_global_index[prob.networks[0].elements[0]]]
+    assert abs(abs(i_in) - i_out) < 0.01 * i_out         # gain 1.0: the supply delivers the mirrored current
+    assert i_in < 0 < i_out                               # MNA sign: a delivering source has a negative branch current
+    L.dev.close()
