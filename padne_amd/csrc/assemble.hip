@@ -344,6 +344,90 @@ __global__ void merge_rows(long long n_rows, long long n_vert, int n_mesh,
     row_len[r] = o;
 }
 
+// LDS variant of merge_rows<true> for the (overwhelmingly common) mesh rows with at most CAP slots: the row's
+// slots are insertion-sorted while being loaded into LDS ([slot][thread] layout) and then walked exactly like
+// merge_rows<true> does -- same operations in the same order, hence bit-identical matrices.  Rows with more
+// slots (hubs of lumped elements) are left to merge_rows<true> (min_len = CAP + 1).
+template <int CAP>
+__global__ __launch_bounds__(128) void merge_rows_mesh_lds(long long n_rows, long long n_vert, int n_mesh,
+                                                           const long long *__restrict__ mesh_voff,
+                                                           const double *__restrict__ sigma,
+                                                           const int *__restrict__ slot_ptr, long long *__restrict__ key,
+                                                           double *__restrict__ val, int *__restrict__ row_len,
+                                                           int *__restrict__ err) {
+    __shared__ long long Kc[CAP][128];
+    __shared__ double Vc[CAP][128];
+    const int t = threadIdx.x;
+    const long long r = (long long)blockIdx.x * 128 + t;
+    if (r >= n_rows) return;
+    const int s0 = slot_ptr[r];
+    const int n = slot_ptr[r + 1] - s0;
+    if (n > CAP) return;
+    for (int i = 0; i < n; ++i) {
+        const long long k = key[s0 + i];
+        const double v = val[s0 + i];
+        int j = i - 1;
+        while (j >= 0 && Kc[j][t] > k) {
+            Kc[j + 1][t] = Kc[j][t];
+            Vc[j + 1][t] = Vc[j][t];
+            --j;
+        }
+        Kc[j + 1][t] = k;
+        Vc[j + 1][t] = v;
+    }
+    double sig = 0.0;
+    double dacc = 0.0;
+    if (r < n_vert) {
+        sig = sigma[find_segment(mesh_voff, n_mesh, r)];
+        int fwd_only = 0, bwd_only = 0;
+        int i = 0;
+        while (i < n) {
+            const int col = (int)(Kc[i][t] >> 32);
+            int terms = 0, seq_sum = 0;
+            double wm = 0.0;
+            while (i < n && (int)(Kc[i][t] >> 32) == col && (unsigned)(Kc[i][t] & 0xffffffffLL) < 2u) {
+                wm = (terms == 0) ? Vc[i][t] : wm + Vc[i][t];
+                seq_sum += (int)(Kc[i][t] & 0xffffffffLL);
+                ++terms;
+                ++i;
+            }
+            while (i < n && (int)(Kc[i][t] >> 32) == col) ++i;
+            if (terms > 2 || (terms == 2 && seq_sum != 1)) atomicExch(&err[ERR_NONMANIFOLD], 1);
+            if (terms == 1) { if (seq_sum == 0) ++fwd_only; else ++bwd_only; }
+            if (terms > 0 && wm != 0.0) dacc = dacc - wm;
+        }
+        if (fwd_only > 1 || bwd_only > 1) atomicExch(&err[ERR_NONMANIFOLD], 1);
+    }
+    int o = 0;
+    int i = 0;
+    while (i < n) {
+        const int col = (int)(Kc[i][t] >> 32);
+        double v = 0.0;
+        if (col == (int)r) {
+            v = sig * dacc;
+        } else {
+            int terms = 0;
+            double wm = 0.0;
+            while (i < n && (int)(Kc[i][t] >> 32) == col && (unsigned)(Kc[i][t] & 0xffffffffLL) < 2u) {
+                wm = (terms == 0) ? Vc[i][t] : wm + Vc[i][t];
+                ++terms;
+                ++i;
+            }
+            if (terms > 0) v = sig * wm;
+        }
+        while (i < n && (int)(Kc[i][t] >> 32) == col) {
+            v = v + Vc[i][t];
+            ++i;
+        }
+        if (v != 0.0) {
+            key[s0 + o] = (long long)col << 32;
+            val[s0 + o] = v;
+            ++o;
+        }
+    }
+    row_len[r] = o;
+}
+
 // Short rows of the generic merge: sort and add duplicates inside LDS ([slot][thread] layout), one lane per row.
 // Same order of additions as merge_rows<false> (key = column, then sequence), hence the same bits.
 template <int CAP>
@@ -520,8 +604,11 @@ static int finish_rows(padne_ctx *ctx, Scratch &sc, long long n_rows, long long 
     int *row_len = nullptr;
     PADNE_TRY(sc.alloc(&row_len, (size_t)n_rows + 1));
     if (MESH) {
+        constexpr int kCap = 32;
+        hipLaunchKernelGGL(merge_rows_mesh_lds<kCap>, dim3(nblk(n_rows, 128)), dim3(128), 0, s, n_rows, n_vert, n_mesh,
+                           d_voff, d_sigma, slot_ptr, key, val, row_len, d_err);
         hipLaunchKernelGGL(merge_rows<MESH>, dim3(nblk(n_rows, 128)), dim3(128), 0, s, n_rows, n_vert, n_mesh, d_voff,
-                           d_sigma, slot_ptr, key, val, row_len, d_err, 0);
+                           d_sigma, slot_ptr, key, val, row_len, d_err, kCap + 1);
         PADNE_HIP_CHECK(hipGetLastError());
     } else {
         PADNE_TRY(merge_slots_generic(ctx, n_rows, slot_ptr, key, val, row_len));

@@ -241,6 +241,166 @@ __global__ __launch_bounds__(256) void spmv_wave_rr(int n_rows, int n_wtiles, co
     }
 }
 
+
+// ---- V10: V9 with 16-bit column offsets relative to the first row of the 64-row wave tile ----
+template <int EPL>
+__global__ __launch_bounds__(256) void spmv_wave_rr16(int n_rows, int n_wtiles, const int *__restrict__ rowptr,
+                                                      const short *__restrict__ cols16, const double *__restrict__ vals,
+                                                      const double *__restrict__ x, double *__restrict__ y) {
+    constexpr int CH = 64 * EPL;
+    __shared__ double prod_all[4 * CH];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double *prod = prod_all + w * CH;
+    const int G = gridDim.x;
+    const int xcd = blockIdx.x % NXCD;
+    const int wx = (blockIdx.x / NXCD) * 4 + w;
+    const int wpx = (G / NXCD) * 4;
+    const int s0 = (int)((long long)xcd * n_wtiles / NXCD), s1 = (int)((long long)(xcd + 1) * n_wtiles / NXCD);
+    for (int wt = s0 + wx; wt < s1; wt += wpx) {
+        const int row0 = wt * 64;
+        const int row1 = min(row0 + 64, n_rows);
+        const int r = row0 + lane;
+        int rs = 0, re = 0;
+        if (r < row1) { rs = rowptr[r]; re = rowptr[r + 1]; }
+        const int k0 = __shfl(rs, 0, 64);
+        const int k1 = __shfl(re, row1 - row0 - 1, 64);
+        double acc = 0.0;
+        for (int base = k0; base < k1; base += CH) {
+            short c[EPL];
+            double v[EPL];
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const int e = base + lane + 64 * j;
+                c[j] = 0; v[j] = 0.0;
+                if (e < k1) { c[j] = cols16[e]; v[j] = vals[e]; }
+            }
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const int e = base + lane + 64 * j;
+                double xv = 0.0;
+                if (e < k1) xv = x[row0 + (int)c[j]];
+                prod[lane + 64 * j] = v[j] * xv;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const int lo = max(rs, base), hi = min(re, base + CH);
+            for (int k = lo; k < hi; ++k) acc += prod[k - base];
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (r < row1) y[r] = acc;
+    }
+}
+
+
+// ---- V11: V9 software-pipelined per wave: while tile t is gathered/reduced, the stream loads of tile t+1 and
+// the row pointers of tile t+2 are already in flight (issued AFTER the gathers of t so that vmcnt ordering lets
+// the gathers complete first) ----
+template <int EPL>
+__global__ __launch_bounds__(256) void spmv_wave_pipe(int n_rows, int n_wtiles, const int *__restrict__ rowptr,
+                                                      const int *__restrict__ cols, const double *__restrict__ vals,
+                                                      const double *__restrict__ x, double *__restrict__ y) {
+    constexpr int CH = 64 * EPL;
+    __shared__ double prod_all[4 * CH];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double *prod = prod_all + w * CH;
+    const int G = gridDim.x;
+    const int xcd = blockIdx.x % NXCD;
+    const int wx = (blockIdx.x / NXCD) * 4 + w;
+    const int wpx = (G / NXCD) * 4;
+    const int s0 = (int)((long long)xcd * n_wtiles / NXCD), s1 = (int)((long long)(xcd + 1) * n_wtiles / NXCD);
+    int wt = s0 + wx;
+    if (wt >= s1) return;
+    // ---- prologue: row pointers of tile 0 and 1, stream loads of tile 0
+    int rs, re, rsn = 0, ren = 0;
+    {
+        const int r = wt * 64 + lane;
+        rs = re = 0;
+        if (r < n_rows) { rs = rowptr[r]; re = rowptr[min(r + 1, n_rows)]; }
+    }
+    int c[EPL]; double v[EPL];
+    int k0 = __shfl(rs, 0, 64);
+    int k1 = __shfl(re, min(wt * 64 + 64, n_rows) - wt * 64 - 1, 64);
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+        const int e = k0 + lane + 64 * j;
+        c[j] = 0; v[j] = 0.0;
+        if (e < k1) { c[j] = cols[e]; v[j] = vals[e]; }
+    }
+    {
+        const int wn = wt + wpx;
+        const int r = wn * 64 + lane;
+        if (wn < s1 && r < n_rows) { rsn = rowptr[r]; ren = rowptr[min(r + 1, n_rows)]; }
+    }
+    for (; wt < s1; wt += wpx) {
+        const int row0 = wt * 64;
+        const int row1 = min(row0 + 64, n_rows);
+        const int r = row0 + lane;
+        // 1. gathers of the current tile (first pass)
+        double xv[EPL];
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            const int e = k0 + lane + 64 * j;
+            xv[j] = 0.0;
+            if (e < k1) xv[j] = x[c[j]];
+        }
+        double p[EPL];
+        // 2. prefetch: stream loads of the next tile, row pointers of the one after
+        const int wn = wt + wpx;
+        int k0n = 0, k1n = 0;
+        int cn[EPL]; double vn[EPL];
+        if (wn < s1) {
+            k0n = __shfl(rsn, 0, 64);
+            k1n = __shfl(ren, min(wn * 64 + 64, n_rows) - wn * 64 - 1, 64);
+        }
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            const int e = k0n + lane + 64 * j;
+            cn[j] = 0; vn[j] = 0.0;
+            if (e < k1n) { cn[j] = cols[e]; vn[j] = vals[e]; }
+        }
+        int rsnn = 0, renn = 0;
+        {
+            const int wnn = wn + wpx;
+            const int rr = wnn * 64 + lane;
+            if (wnn < s1 && rr < n_rows) { rsnn = rowptr[rr]; renn = rowptr[min(rr + 1, n_rows)]; }
+        }
+        // 3. products of the current tile -> LDS, reduce
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) { p[j] = v[j] * xv[j]; prod[lane + 64 * j] = p[j]; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        double acc = 0.0;
+        {
+            const int lo = max(rs, k0), hi = min(re, k0 + CH);
+            for (int k = lo; k < hi; ++k) acc += prod[k - k0];
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        for (int base = k0 + CH; base < k1; base += CH) {       // rare: more than CH non-zeros in the tile
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const int e = base + lane + 64 * j;
+                double t = 0.0;
+                if (e < k1) t = vals[e] * x[cols[e]];
+                prod[lane + 64 * j] = t;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const int lo = max(rs, base), hi = min(re, base + CH);
+            for (int k = lo; k < hi; ++k) acc += prod[k - base];
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (r < row1) y[r] = acc;
+        // 4. rotate
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) { c[j] = cn[j]; v[j] = vn[j]; }
+        rs = rsn; re = ren; rsn = rsnn; ren = renn;
+        k0 = k0n; k1 = k1n;
+    }
+}
+
 // ---- V2: as V0 (TILE 2048, ROWS 256) with the next tile's stream loads issued before the reduce phase
 __global__ __launch_bounds__(256) void spmv_pipe(int n_rows, int n_tiles, const int *__restrict__ rowptr,
                                                  const int *__restrict__ cols, const double *__restrict__ vals,
@@ -354,7 +514,7 @@ __global__ __launch_bounds__(256) void stream_ref(long long nnz4, const int4 *__
     if (s == 12345.678) y[0] = s;
 }
 
-struct Mat { int n; long long nnz; int *rowptr, *cols; double *vals; };
+struct Mat { int n; long long nnz; int *rowptr, *cols; double *vals; short *cols16; };
 
 static Mat build(int layers, int nx, int ny) {
     const long long n = (long long)layers * nx * ny;
@@ -386,6 +546,11 @@ static Mat build(int layers, int nx, int ny) {
     CK(hipMemcpy(m.rowptr, rp.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice));
     CK(hipMemcpy(m.cols, cl.data(), sizeof(int) * cl.size(), hipMemcpyHostToDevice));
     CK(hipMemcpy(m.vals, vl.data(), sizeof(double) * vl.size(), hipMemcpyHostToDevice));
+    std::vector<short> c16(cl.size() + pad, 0);
+    for (long long i = 0; i < n; ++i)
+        for (int k = rp[i]; k < rp[i + 1]; ++k) c16[k] = (short)(cl[k] - (int)((i / 64) * 64));
+    CK(hipMalloc(&m.cols16, sizeof(short) * c16.size()));
+    CK(hipMemcpy(m.cols16, c16.data(), sizeof(short) * c16.size(), hipMemcpyHostToDevice));
     return m;
 }
 
@@ -457,6 +622,14 @@ int main(int argc, char **argv) {
       RUN("wave-rr chunk8 grid 2048", [&] { spmv_wave_rr<8, 8><<<2048, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); });
       RUN("wave-rr chunk4 grid 1024", [&] { spmv_wave_rr<8, 4><<<1024, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); });
       RUN("wave-rr chunk4 grid 1536", [&] { spmv_wave_rr<8, 4><<<1536, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); }); }
+    { const int nwt = (m.n + 63) / 64;
+      RUN("wave-rr16 chunk1 grid 2048", [&] { spmv_wave_rr16<8><<<2048, 256>>>(m.n, nwt, m.rowptr, m.cols16, m.vals, x, y); });
+      RUN("wave-rr16 chunk1 grid 1536", [&] { spmv_wave_rr16<8><<<1536, 256>>>(m.n, nwt, m.rowptr, m.cols16, m.vals, x, y); });
+      RUN("wave-rr16 chunk1 grid 4096", [&] { spmv_wave_rr16<8><<<4096, 256>>>(m.n, nwt, m.rowptr, m.cols16, m.vals, x, y); }); }
+    { const int nwt = (m.n + 63) / 64;
+      RUN("wave-pipe epl8 grid 2048", [&] { spmv_wave_pipe<8><<<2048, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); });
+      RUN("wave-pipe epl8 grid 1536", [&] { spmv_wave_pipe<8><<<1536, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); });
+      RUN("wave-pipe epl8 grid 1024", [&] { spmv_wave_pipe<8><<<1024, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); }); }
     RUN("lds 2048/256 nontemporal", [&] { spmv_lds<2048, 256, true><<<G(nt256, 2048), 256>>>(m.n, nt256, m.rowptr, m.cols, m.vals, x, y); });
     RUN("lds 4096/512", [&] { spmv_lds<4096, 512, false><<<G(nt512, 2048), 256>>>(m.n, nt512, m.rowptr, m.cols, m.vals, x, y); });
     RUN("lds 4096/512 grid 1024", [&] { spmv_lds<4096, 512, false><<<G(nt512, 1024), 256>>>(m.n, nt512, m.rowptr, m.cols, m.vals, x, y); });
