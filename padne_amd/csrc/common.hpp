@@ -39,23 +39,15 @@ void set_error(const char *fmt, ...);
         if (_rc != PADNE_OK) return _rc;                                                   \
     } while (0)
 
-constexpr int kWave = 64;            // gfx950 wavefront
 constexpr int kNumXcd = 8;           // MI355X: 8 XCDs, each with a private L2
-constexpr int kNumCu = 256;
 
 // SpMV tile geometry (see spmv.hip)
 constexpr int kSpmvThreads = 256;
-constexpr int kSpmvRows = 256;       // rows per tile (one per thread in the reduce phase)
-constexpr int kSpmvTileNnz = 2048;   // non-zeros staged in LDS per pass (16 KiB of f64)
+constexpr int kSpmvRows = 256;       // rows per workgroup turn: four wave-private tiles of 64 rows
 constexpr int kPadNnz = 4096;        // cols/vals allocations are padded by this many zero entries
 
 // number of partial sums every reduction kernel emits (one per workgroup)
 constexpr int kMaxPartials = 2048;
-
-struct DevBuf {
-    void *p = nullptr;
-    size_t bytes = 0;
-};
 
 }  // namespace padne
 
