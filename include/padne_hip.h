@@ -125,7 +125,10 @@ int padne_residual_norm(padne_ctx *ctx, const padne_csr *m, const double *x_host
 
 /* ---- solve --------------------------------------------------------------------------------- */
 typedef struct padne_solve_opts {
-    double  rtol;        /* stop when ||b - A x||_2 <= max(rtol*||b||_2, atol)            */
+    double  rtol;        /* stop when ||b - A x||_2 <= max(rtol*||b||_2, atol); if the TRUE residual
+                            stagnates above that (binary64 evaluation floor of b - A x, ~1e-12 at
+                            N = 5 M) the solve ends successfully within 10x of the request and
+                            reports what it reached in padne_solve_info.rel_residual           */
     double  atol;
     int32_t max_iter;
     int32_t precond;     /* 0 = Jacobi, 1 = smoothed-aggregation multigrid V-cycle (single GPU;

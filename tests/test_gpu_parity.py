@@ -605,3 +605,78 @@ def test_regulator_star_and_multi_island_problem_end_to_end(ctx):
     assert abs(abs(i_in) - i_out) < 0.01 * i_out         # gain 1.0: the supply delivers the mirrored current
     assert i_in < 0 < i_out                               # MNA sign: a delivering source has a negative branch current
     L.dev.close()
+
+
+# ---- size-independent properties at BASELINE scale (direct solve unaffordable there) --------------------
+
+@pytest.fixture(scope="module")
+def c3_system(ctx):
+    """Config C3 of BASELINE.json: 4 layers of 1118x1118, N = 5 M, via rings, assembled on the device."""
+    sysm = synthetic.config("C3")
+    nv = sysm.n_vertices
+    N = nv + 1
+    xy, tri, mvo, mto, sig = flat(sysm.meshes)
+    a, b, rr = sysm.resistors
+    gg = 1 / rr
+    rows = np.concatenate([np.stack([a, a, b, b], 1).reshape(-1), [N - 1, sysm.ground]])
+    cols = np.concatenate([np.stack([a, b, b, a], 1).reshape(-1), [sysm.ground, N - 1]])
+    vals = np.concatenate([np.stack([-gg, gg, -gg, gg], 1).reshape(-1), [1.0, 1.0]])
+    Ld = ctx.assemble_system(N, xy, tri, mvo, mto, sig, rows, cols, vals)
+    from padne_amd.reduction import Constraint, KKTLayout
+    L = solver.SystemMatrix(Ld, KKTLayout(size=N, n_potential=nv,
+                                          constraints=[Constraint(index=N - 1, p=sysm.ground, n=-1, value=0.0)]))
+    yield sysm, L
+    Ld.close()
+
+
+def _rhs(sysm, pairs):
+    r = np.zeros(sysm.n_vertices + 1)
+    for f, t, i in pairs:
+        r[f] += i
+        r[t] -= i
+    return r
+
+
+def test_full_size_residual_ground_current_and_symmetry(ctx, c3_system):
+    sysm, L = c3_system
+    nv = sysm.n_vertices
+    f, t, i = int(sysm.current_sources[0][0]), int(sysm.current_sources[1][0]), 1.0
+    r = _rhs(sysm, [(f, t, i)])
+    v, info = solver.solve_system(L, r)
+    assert np.all(np.isfinite(v))
+    assert info.residual_norm < 1e-9                                   # tests/test_solver.py:2083-2089
+    assert abs(info.ground_node_current) < 1e-9                        # solver.py:880-888 (no SolverWarning)
+    assert 5 < info.iterations < 100
+    # current conservation through every layer pair: the via rings carry exactly the injected 1 A
+    a, b, rr = sysm.resistors
+    n_per = nv // len(sysm.meshes)
+    for l in range(len(sysm.meshes) - 1):
+        sel = (a // n_per == l) & (b // n_per == l + 1)
+        # CurrentSource(f, t, I) raises V_t above V_f (tests/test_solver.py:82-83): the amp flows from t's layer to f's
+        assert abs(np.sum((v[b[sel]] - v[a[sel]]) / rr[sel]) - 1.0) < 1e-7
+    # the potential extremes sit at the source and the sink (discrete maximum principle of an M-matrix)
+    assert int(np.argmax(v[:nv])) == t and int(np.argmin(v[:nv])) == f
+    # matrix symmetry on random probes: x.(L y) == y.(L x) on the potential block
+    rng = np.random.default_rng(0)
+    x, y = rng.uniform(-1, 1, (2, nv + 1))
+    x[-1] = y[-1] = 0.0
+    assert abs(x @ (L @ y) - y @ (L @ x)) <= 1e-9 * abs(x @ (L @ y))
+
+
+def test_full_size_superposition_and_reciprocity(ctx, c3_system):
+    """tests/test_solver.py:1449-1564 (superposition) on the 5 M-node system, plus reciprocity of the
+    transfer resistance, both without a direct solve."""
+    sysm, L = c3_system
+    nv = sysm.n_vertices
+    n_per = nv // len(sysm.meshes)
+    p1 = (3 * 1118 + 7, 2 * n_per + 500 * 1118 + 40)
+    p2 = (n_per + 900 * 1118 + 900, 3 * n_per + 100 * 1118 + 1000)
+    v1, _ = solver.solve_system(L, _rhs(sysm, [(p1[0], p1[1], 1.0)]))
+    v2, _ = solver.solve_system(L, _rhs(sysm, [(p2[0], p2[1], 2.5)]))
+    v12, _ = solver.solve_system(L, _rhs(sysm, [(p1[0], p1[1], 1.0), (p2[0], p2[1], 2.5)]))
+    scale = np.abs(v12[:nv]).max()
+    assert np.abs(v12[:nv] - (v1[:nv] + v2[:nv])).max() <= 1e-9 * scale
+    # reciprocity: voltage across pair 2 per amp into pair 1 == voltage across pair 1 per amp into pair 2
+    z21 = (v1[p2[0]] - v1[p2[1]]) / 1.0
+    z12 = (v2[p1[0]] - v2[p1[1]]) / 2.5
+    assert abs(z21 - z12) <= 1e-9 * max(abs(z21), abs(v1[:nv]).max())
