@@ -551,20 +551,16 @@ __global__ void dense_from_csr(int n, const int *__restrict__ rowptr, const int 
     for (int k = rowptr[i] + threadIdx.x; k < rowptr[i + 1]; k += blockDim.x) W[(size_t)i * 2 * n + cols[k]] = vals[k];
 }
 
-__global__ void gj_pivot(int n, int k, const double *__restrict__ W, double *__restrict__ frow, double *__restrict__ fcol) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const double piv = W[(size_t)k * 2 * n + k];
-    if (t < 2 * n) frow[t] = W[(size_t)k * 2 * n + t] / piv;
-    if (t < n) fcol[t] = W[(size_t)t * 2 * n + k];
-}
-
-__global__ void gj_eliminate(int n, int k, double *__restrict__ W, const double *__restrict__ frow,
-                             const double *__restrict__ fcol) {
+// One Gauss-Jordan step, ping-pong between two copies of [A | I] so that one launch per pivot suffices: every
+// entry reads the OLD pivot row / column from `in` and writes the new value to `out`.
+__global__ __launch_bounds__(256) void gj_step(int n, int k, const double *__restrict__ in, double *__restrict__ out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const int r = blockIdx.y;
     if (c >= 2 * n) return;
-    const size_t idx = (size_t)r * 2 * n + c;
-    W[idx] = (r == k) ? frow[c] : W[idx] - fcol[r] * frow[c];
+    const size_t w = (size_t)2 * n;
+    const double piv = in[(size_t)k * w + k];
+    const double prow = in[(size_t)k * w + c] / piv;
+    out[(size_t)r * w + c] = (r == k) ? prow : in[(size_t)r * w + c] - in[(size_t)r * w + k] * prow;
 }
 
 __global__ void dense_extract_inverse(int n, const double *__restrict__ W, double *__restrict__ inv) {
@@ -844,8 +840,12 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
                                X->vals, Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len);
         } else if (avg <= 160.0) {
             // short rows: sorted lists in LDS, the few overflowing rows are redone in global memory
-            hipLaunchKernelGGL(spgemm_rows_lds<32>, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
-                               Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len);
+            if (avg <= 24.0)   // A*P on the fine levels: a dozen distinct columns at most -> small lists, more waves per CU
+                hipLaunchKernelGGL(spgemm_rows_lds<16>, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
+                                   Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len);
+            else
+                hipLaunchKernelGGL(spgemm_rows_lds<32>, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
+                                   Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len);
             hipLaunchKernelGGL(spgemm_rows_redo, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
                                Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len);
         } else {
@@ -861,20 +861,20 @@ static int dense_inverse(padne_ctx *ctx, const padne_csr *A, double **inv_out) {
     hipStream_t s = ctx->stream;
     const int n = (int)A->n_rows;
     Scratch sc(ctx);
-    double *W = nullptr, *frow = nullptr, *fcol = nullptr, *inv = nullptr;
+    double *W = nullptr, *W2 = nullptr, *inv = nullptr;
     PADNE_TRY(sc.alloc(&W, (size_t)n * 2 * n));
-    PADNE_TRY(sc.alloc(&frow, (size_t)2 * n));
-    PADNE_TRY(sc.alloc(&fcol, (size_t)n));
+    PADNE_TRY(sc.alloc(&W2, (size_t)n * 2 * n));
     inv = (double *)pool_alloc(ctx, sizeof(double) * (size_t)(n > 0 ? n : 1) * (size_t)(n > 0 ? n : 1));
     if (inv == nullptr) return PADNE_E_NOMEM;
     if (n > 0) {
         hipLaunchKernelGGL(dense_from_csr, dim3(n), dim3(256), 0, s, n, A->rowptr, A->cols, A->vals, W);
         const dim3 ge(nblk(2 * n), n);
+        double *src = W, *dst = W2;
         for (int k = 0; k < n; ++k) {
-            hipLaunchKernelGGL(gj_pivot, dim3(nblk(2 * n)), dim3(256), 0, s, n, k, W, frow, fcol);
-            hipLaunchKernelGGL(gj_eliminate, ge, dim3(256), 0, s, n, k, W, frow, fcol);
+            hipLaunchKernelGGL(gj_step, ge, dim3(256), 0, s, n, k, src, dst);
+            std::swap(src, dst);
         }
-        hipLaunchKernelGGL(dense_extract_inverse, dim3(nblk(n), n), dim3(256), 0, s, n, W, inv);
+        hipLaunchKernelGGL(dense_extract_inverse, dim3(nblk(n), n), dim3(256), 0, s, n, src, inv);
     }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(s);
