@@ -292,3 +292,57 @@ def build_reduction(layout: KKTLayout) -> Reduction:
         groups.append((sorted(mem), gcons[root], r_node))
     regs = [cst for cst in layout.constraints if cst.gamma]
     return Reduction(layout=layout, index_map=index_map, n_free=n_free, c=c, groups=groups, regulators=regs)
+
+
+# ---- locality ordering ------------------------------------------------------------------------------------
+
+def _spread_bits(v: np.ndarray) -> np.ndarray:
+    v = v.astype(np.uint64)
+    v = (v | (v << np.uint64(16))) & np.uint64(0x0000FFFF0000FFFF)
+    v = (v | (v << np.uint64(8))) & np.uint64(0x00FF00FF00FF00FF)
+    v = (v | (v << np.uint64(4))) & np.uint64(0x0F0F0F0F0F0F0F0F)
+    v = (v | (v << np.uint64(2))) & np.uint64(0x3333333333333333)
+    v = (v | (v << np.uint64(1))) & np.uint64(0x5555555555555555)
+    return v
+
+
+def morton_keys(xy: np.ndarray, bits: int = 16) -> np.ndarray:
+    """Z-order key of every point (quantised to `bits` per axis inside the bounding box)."""
+    lo = xy.min(axis=0)
+    span = np.maximum(xy.max(axis=0) - lo, 1e-300)
+    q = np.minimum(((xy - lo) / span * (2 ** bits - 1)).astype(np.uint64), np.uint64(2 ** bits - 1))
+    return _spread_bits(q[:, 0]) | (_spread_bits(q[:, 1]) << np.uint64(1))
+
+
+def ordering_is_scattered(tri: np.ndarray, n_vert: int) -> bool:
+    """True if mesh neighbours are far apart in the numbering (CGAL insertion order, random order):
+    mean index distance along triangle edges well beyond the O(sqrt(n)) of a scan-line numbering."""
+    if len(tri) == 0 or n_vert < 4096:
+        return False
+    step = max(1, len(tri) // 200000)
+    t = tri[::step].astype(np.int64)
+    mean_dist = float(np.mean(np.abs(t[:, 0] - t[:, 1]) + np.abs(t[:, 1] - t[:, 2])) / 2)
+    return mean_dist > 8.0 * np.sqrt(n_vert)
+
+
+def apply_locality_ordering(red: "Reduction", xy: np.ndarray, mesh_offsets: np.ndarray) -> None:
+    """Relabel the reduced unknowns so that vertices close in space are close in index (Z-order inside each
+    mesh; mesh blocks stay contiguous and in order; non-mesh unknowns keep their place behind them).
+    Purely internal: ``index_map`` is the only thing that changes, ``expand``/``rhs``/``project`` follow it."""
+    n_vert = int(mesh_offsets[-1])
+    imap = red.index_map
+    owner = np.full(red.n_free, -1, dtype=np.int64)           # representative vertex of every reduced unknown
+    vert = np.flatnonzero(imap[:n_vert] >= 0)
+    # the first vertex that maps to a group represents it (groups are numbered by their smallest member)
+    first = np.unique(imap[vert], return_index=True)
+    owner[first[0]] = vert[first[1]]
+    mesh_id = np.searchsorted(mesh_offsets, np.maximum(owner, 0), side="right") - 1
+    key = np.full(red.n_free, np.uint64(2 ** 63), dtype=np.uint64)        # non-mesh unknowns sort last, stably
+    has = owner >= 0
+    mk = morton_keys(xy[owner[has]])
+    key[has] = (mesh_id[has].astype(np.uint64) << np.uint64(40)) | mk
+    order = np.argsort(key, kind="stable")                                # new position -> old reduced index
+    new_of_old = np.empty(red.n_free, dtype=np.int32)
+    new_of_old[order] = np.arange(red.n_free, dtype=np.int32)
+    free = imap >= 0
+    imap[free] = new_of_old[imap[free]]

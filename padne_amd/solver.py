@@ -310,11 +310,13 @@ class SystemMatrix:
     ``L @ v``.  Carries the KKT layout so that ``solve_system`` does not have to re-derive it.
     """
 
-    def __init__(self, dev: _hip.CsrMatrix, layout: Optional[KKTLayout]):
+    def __init__(self, dev: _hip.CsrMatrix, layout: Optional[KKTLayout], xy=None, tri=None, mesh_offsets=None):
         self.dev = dev
         self.layout = layout
         self.shape = dev.shape
         self._host = None
+        # geometry of the mesh unknowns (optional): lets solve_system pick a cache-friendly internal ordering
+        self.xy, self.tri, self.mesh_offsets = xy, tri, mesh_offsets
 
     @property
     def nnz(self) -> int:
@@ -401,7 +403,7 @@ def assemble_from_arrays(meshes, conductances, stamps: StampList, n_potential: i
     rows, cols, vals = stamps.arrays()
     dev = ctx.assemble_system(stamps.shape[0], xy, tri, mvo, mto, sig, rows, cols, vals)
     layout = KKTLayout(size=stamps.shape[0], n_potential=n_potential, constraints=list(stamps.constraints))
-    return SystemMatrix(dev, layout)
+    return SystemMatrix(dev, layout, xy=xy, tri=tri, mesh_offsets=mvo)
 
 
 # --------------------------------------------------------------------------------------------
@@ -418,11 +420,12 @@ def _solve_reduced(A: _hip.CsrMatrix, b: np.ndarray, rtol: float):
     return res.x, res.iterations, res.rel_residual, res.seconds
 
 
-def solve_system(L, r: np.ndarray, *, rtol: float = RTOL):
+def solve_system(L, r: np.ndarray, *, rtol: float = RTOL, reorder=None):
     """Solve ``L v = r`` and return ``(v, SolverInfo)`` like ``solver.py:767-780``.
 
     ``L`` is a :class:`SystemMatrix` from :func:`assemble_system`, or any scipy sparse matrix in the
-    reference's layout (it is uploaded and its multiplier structure inferred).
+    reference's layout (it is uploaded and its multiplier structure inferred).  ``reorder``: None = solve in
+    Z-order when the mesh numbering is scattered (decided from the triangles), True / False = force.
     """
     ctx = get_context()
     r = np.asarray(r, dtype=DTYPE)
@@ -442,6 +445,12 @@ def solve_system(L, r: np.ndarray, *, rtol: float = RTOL):
     for cst in layout.constraints:
         cst.value = float(r[cst.index])
     red: Reduction = build_reduction(layout)
+    if isinstance(L, SystemMatrix) and L.xy is not None and reorder is not False:
+        # CGAL numbers vertices in insertion order; when neighbours are far apart in the numbering the SpMV
+        # gathers miss the caches, so the reduced system is solved in Z-order (internal: v comes back unpermuted)
+        from .reduction import apply_locality_ordering, ordering_is_scattered
+        if reorder is True or ordering_is_scattered(L.tri, len(L.xy)):
+            apply_locality_ordering(red, L.xy, L.mesh_offsets)
     N = layout.size
     A = dev.reduce(red.index_map, red.n_free, -1.0)
     try:

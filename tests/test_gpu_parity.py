@@ -680,3 +680,25 @@ def test_full_size_superposition_and_reciprocity(ctx, c3_system):
     z21 = (v1[p2[0]] - v1[p2[1]]) / 1.0
     z12 = (v2[p1[0]] - v2[p1[1]]) / 2.5
     assert abs(z21 - z12) <= 1e-9 * max(abs(z21), abs(v1[:nv]).max())
+
+
+def test_locality_reordering_is_transparent(ctx):
+    """A scattered vertex numbering is solved in Z-order internally; v comes back in the caller's numbering."""
+    xy, tri = delaunay_mesh(20000, seed=3, hole=False)
+    n = len(xy)
+    from padne_amd import reduction as red
+    assert red.ordering_is_scattered(tri, n)
+    stamps = solver.StampList(n + 1)
+    r = np.zeros(n + 1)
+    r[5] += 1.0
+    r[n - 9] -= 1.0
+    solver.setup_ground_node(11, stamps, r)
+    L = solver.assemble_from_arrays([mesh.Mesh(xy, tri)], [2082.5], stamps, n)
+    v_plain, i_plain = solver.solve_system(L, r, reorder=False)
+    v_auto, i_auto = solver.solve_system(L, r)                      # picks the Z-order by itself
+    v_forced, _ = solver.solve_system(L, r, reorder=True)
+    scale = np.abs(v_plain[:n]).max()
+    assert np.abs(v_auto[:n] - v_plain[:n]).max() <= 1e-9 * scale
+    assert np.array_equal(v_auto, v_forced)
+    assert i_auto.residual_norm < 1e-9 and i_plain.residual_norm < 1e-9
+    L.dev.close()

@@ -252,3 +252,32 @@ def test_synthetic_generators_are_deterministic():
     assert np.array_equal(a.meshes[1][0], b.meshes[1][0]) and np.array_equal(a.resistors[0], b.resistors[0])
     assert a.n_vertices == 240 and a.meshes[0][1].shape == (2 * 11 * 9, 3)
     assert synthetic.via_ring_resistance(0.5) == pytest.approx(16 * 0.5 / (5.95e4 * np.pi * (0.185**2 - 0.15**2)))
+
+
+def test_locality_ordering_is_a_permutation_that_keeps_mesh_blocks():
+    g = H.load_golden("two_layer_via")
+    layout = reduction.infer_layout(H.golden_L(g), g["r"])
+    red = reduction.build_reduction(layout)
+    before = red.index_map.copy()
+    xy = np.concatenate([g["xy0"], g["xy1"]])
+    offs = np.array([0, len(g["xy0"]), len(xy)])
+    reduction.apply_locality_ordering(red, xy, offs)
+    free = before >= 0
+    assert np.array_equal(red.index_map >= 0, free)
+    assert sorted(red.index_map[free]) == sorted(before[free])               # a permutation of the same labels
+    n0 = len(g["xy0"])
+    first_block = red.index_map[:n0][red.index_map[:n0] >= 0]
+    second_block = red.index_map[n0:len(xy)][red.index_map[n0:len(xy)] >= 0]
+    assert first_block.max() < second_block.min()                              # mesh blocks stay in order
+    # neighbours in space get closer in index on a shuffled mesh
+    rng = np.random.default_rng(0)
+    pxy, ptri = synthetic.jittered_grid(80, 80)
+    perm = rng.permutation(len(pxy))
+    inv = np.empty_like(perm); inv[perm] = np.arange(len(perm))
+    sxy, stri = pxy[perm], inv[ptri]
+    assert reduction.ordering_is_scattered(stri, len(sxy)) and not reduction.ordering_is_scattered(ptri, len(pxy))
+    keys = reduction.morton_keys(sxy)
+    rank = np.empty(len(sxy), dtype=np.int64); rank[np.argsort(keys, kind="stable")] = np.arange(len(sxy))
+    d_before = np.abs(stri[:, 0].astype(np.int64) - stri[:, 1]).mean()
+    d_after = np.abs(rank[stri[:, 0]] - rank[stri[:, 1]]).mean()
+    assert d_after * 10 < d_before
