@@ -151,7 +151,7 @@ typedef struct padne_solve_info {
     double  precond_setup_seconds; /* device time of the multigrid setup done inside this call (0 if cached) */
     double  operator_complexity;   /* sum of nnz over the levels / nnz of the fine matrix                    */
     int32_t levels;                /* multigrid levels (0 with Jacobi)                                       */
-    int32_t reserved;
+    int32_t precond_fallbacks;     /* right-hand sides redone with Jacobi after a multigrid breakdown/stall  */
 } padne_solve_info;
 
 /* Preconditioned CG on an SPD CSR matrix: replaces scipy.sparse.linalg.spsolve in

@@ -42,7 +42,7 @@ class SolveInfo(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("restarts", C.c_int32), ("rel_residual", C.c_double),
                 ("abs_residual", C.c_double), ("solve_seconds", C.c_double), ("spmv_seconds", C.c_double),
                 ("status", C.c_int32), ("n_rhs", C.c_int32), ("precond_setup_seconds", C.c_double),
-                ("operator_complexity", C.c_double), ("levels", C.c_int32), ("reserved", C.c_int32)]
+                ("operator_complexity", C.c_double), ("levels", C.c_int32), ("precond_fallbacks", C.c_int32)]
 
 
 _P = C.c_void_p

@@ -715,15 +715,35 @@ extern "C" int padne_solve_spd_dev(padne_ctx *ctx, const padne_csr *a, const voi
             amg_destroy(pm->amg);
             pm->amg = nullptr;
         }
-        PADNE_TRY(amg_setup(ctx, pm));
-        double setup_s = 0.0;
-        amg_info(pm, &local.levels, &local.operator_complexity, &setup_s, nullptr);
-        if (fresh) local.precond_setup_seconds = setup_s;
+        const int rc_setup = amg_setup(ctx, pm);
+        if (rc_setup == PADNE_E_INVALID) {
+            // coarsening stalled on this matrix: the solve proceeds with the diagonal preconditioner (levels = 0)
+            use_amg = false;
+        } else if (rc_setup != PADNE_OK) {
+            return rc_setup;
+        } else {
+            double setup_s = 0.0;
+            amg_info(pm, &local.levels, &local.operator_complexity, &setup_s, nullptr);
+            if (fresh) local.precond_setup_seconds = setup_s;
+        }
     }
     const long long n = ctx->halo_on ? ctx->halo_n_owned : a->n_rows;
     for (int k = 0; k < n_rhs; ++k) {
+        const int status_before = local.status;
         PADNE_TRY(solve_one(ctx, a, use_amg ? pm : nullptr, (const double *)b_dev + (size_t)k * n,
                             (double *)x_dev + (size_t)k * n, opts, &local, (opts->flags & 1) != 0));
+        if (use_amg && local.status != PADNE_OK && status_before == PADNE_OK) {
+            // the V-cycle lost positive definiteness or stalled far from the tolerance on this system:
+            // redo this right-hand side from scratch with the diagonal preconditioner
+            padne_solve_opts retry = *opts;
+            retry.flags &= ~1;
+            local.status = PADNE_OK;
+            local.rel_residual = 0.0;
+            local.abs_residual = 0.0;
+            local.precond_fallbacks += 1;
+            PADNE_TRY(solve_one(ctx, a, nullptr, (const double *)b_dev + (size_t)k * n,
+                                (double *)x_dev + (size_t)k * n, &retry, &local, false));
+        }
     }
     if (info) *info = local;
     if (local.status == PADNE_E_BREAKDOWN) {

@@ -702,3 +702,27 @@ def test_locality_reordering_is_transparent(ctx):
     assert np.array_equal(v_auto, v_forced)
     assert i_auto.residual_norm < 1e-9 and i_plain.residual_norm < 1e-9
     L.dev.close()
+
+
+def test_multigrid_with_hubs_and_strong_lumped_couplings(ctx):
+    """Star hubs (hundreds of 1 mOhm resistors into one internal node, kicad.py:535-556) and very stiff
+    layer-to-layer links next to the sheet Laplacian: rows of very different length and weight."""
+    rng = np.random.default_rng(8)
+    parts = [synthetic.jittered_grid(90, 70, seed=1), synthetic.jittered_grid(60, 50, seed=2)]
+    ms = [(parts[0][0], parts[0][1], 2082.5), (parts[1][0], parts[1][1], 300.0)]
+    n0, n1 = len(parts[0][0]), len(parts[1][0])
+    nv = n0 + n1
+    hub_a, hub_b = nv, nv + 1
+    els = [("R", int(p), hub_a, 1e-3) for p in rng.choice(n0, 400, replace=False)]
+    els += [("R", int(n0 + p), hub_b, 1e-3) for p in rng.choice(n1, 250, replace=False)]
+    els += [("R", hub_a, hub_b, 0.5), ("R", 17, n0 + 23, 1e-6), ("I", 5, n0 + n1 - 3, 2.0)]
+    Lo, ro = O.assemble_system(ms, 2, els, 0)
+    v_ref, _, _ = O.solve_system(Lo, ro)
+    v, info = solver.solve_system(Lo, ro)
+    n_pot = nv + 2
+    assert np.abs(v[:n_pot] - v_ref[:n_pot]).max() <= REL_TOL * np.abs(v_ref[:n_pot]).max()
+    assert info.residual_norm < 1e-9
+    A = (-Lo[1:n_pot, 1:n_pot]).tocsr()
+    d = ctx.csr_from_scipy(A)
+    res = d.solve_spd(-ro[1:n_pot], precond="amg")
+    assert res.levels >= 2 and res.iterations < 200
