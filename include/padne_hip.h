@@ -59,6 +59,14 @@ void       *padne_ctx_stream(padne_ctx *ctx);
 int padne_comm_unique_id(void *id128);
 int padne_ctx_comm_init(padne_ctx *ctx, const void *id128, int rank, int world_size);
 int padne_ctx_comm_rank(padne_ctx *ctx, int *rank, int *world_size);
+/* In-process team: several contexts of ONE process on ONE GPU act as ranks (one host thread per context drives
+ * its solve); all-reduce / all-gather go through host barriers and peer copies instead of RCCL, which refuses two
+ * ranks on one device.  For rehearsing the row-partitioned solver on a single-GPU box (tests); sums are formed in
+ * rank order, so every rank sees the same bits, like with RCCL. */
+int padne_team_create(int world_size, void **team_out);
+int padne_team_destroy(void *team);
+int padne_ctx_join_team(padne_ctx *ctx, void *team, int rank);
+
 /* Halo plan of a row-partitioned matrix (layer partition).  Every vector the
  * local matrix multiplies is laid out [n_owned owned entries | world_size * m exchanged entries];
  * before each product the rank copies its `n_export` values export_idx[k] (local indices) into its

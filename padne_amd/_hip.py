@@ -63,6 +63,9 @@ SIGNATURES = {
     "padne_comm_unique_id": (C.c_int, [_P]),
     "padne_ctx_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "padne_ctx_comm_rank": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "padne_team_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "padne_team_destroy": (C.c_int, [_P]),
+    "padne_ctx_join_team": (C.c_int, [_P, _P, C.c_int]),
     "padne_ctx_set_halo": (C.c_int, [_P, _I64, C.c_int32, C.c_int32, _PI32]),
     "padne_dev_alloc": (C.c_int, [_P, _I64, C.POINTER(_P)]),
     "padne_dev_free": (C.c_int, [_P, _P]),
@@ -301,6 +304,27 @@ class Context:
                                              mvo.shape[0] - 1, _ptr(mvo, _PI64), _ptr(mto, _PI64), _ptr(pot, _PF64),
                                              _ptr(gx, _PF64), _ptr(gy, _PF64)))
         return gx, gy
+
+
+class LocalTeam:
+    """In-process team of contexts acting as ranks on one GPU (rehearsal of the multi-rank path)."""
+
+    def __init__(self, world_size: int):
+        lib = load_library()
+        self._lib = lib
+        h = _P()
+        _check(lib.padne_team_create(int(world_size), C.byref(h)))
+        self._h = h
+        self.world = int(world_size)
+
+    def join(self, ctx: "Context", rank: int) -> None:
+        _check(self._lib.padne_ctx_join_team(ctx._h, self._h, int(rank)))
+        ctx._team = self       # keep the team alive as long as its members
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.padne_team_destroy(self._h)
+            self._h = None
 
 
 class DeviceArray:

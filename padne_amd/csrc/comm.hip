@@ -4,7 +4,9 @@
 // single-process).
 #include "common.hpp"
 
+#include <condition_variable>
 #include <dlfcn.h>
+#include <mutex>
 #include <string.h>
 
 namespace padne {
@@ -65,14 +67,86 @@ static int check_nccl(int rc, const char *what) {
     return PADNE_E_COMM;
 }
 
+// ---- in-process team: several contexts ("ranks") of ONE process on ONE device, one host thread per rank -----
+// RCCL refuses two ranks on the same GPU, so the row-partitioned solver cannot be exercised with world > 1 on a
+// single-GPU box through RCCL.  A team offers the same two collectives between the contexts of one process
+// (host barrier + peer reads on the shared device) so that the multi-rank control flow, halo plan and block
+// preconditioner run for real in the test-suite.  Results are summed in rank order: identical on every rank.
+struct Team {
+    int world = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    long long generation = 0;
+    std::vector<const double *> ptrs;
+    std::vector<double> stage;      // host staging for the reduced values
+    bool failed = false;
+};
+
+static void team_barrier(Team *t) {
+    std::unique_lock<std::mutex> lk(t->mu);
+    const long long gen = t->generation;
+    if (++t->arrived == t->world) {
+        t->arrived = 0;
+        ++t->generation;
+        t->cv.notify_all();
+    } else {
+        t->cv.wait(lk, [&] { return t->generation != gen; });
+    }
+}
+
+static int team_allreduce(padne_ctx *ctx, double *dev_buf, int count) {
+    Team *t = (Team *)ctx->team;
+    PADNE_REQUIRE(count <= 16, "team all-reduce is for a handful of scalars");
+    double mine[16];
+    PADNE_HIP_CHECK(hipMemcpyAsync(mine, dev_buf, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
+    PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    {
+        std::lock_guard<std::mutex> lk(t->mu);
+        for (int c = 0; c < count; ++c) t->stage[(size_t)ctx->rank * 16 + c] = mine[c];
+    }
+    team_barrier(t);
+    double sum[16];
+    for (int c = 0; c < count; ++c) {
+        double s = 0.0;
+        for (int r = 0; r < t->world; ++r) s += t->stage[(size_t)r * 16 + c];   // rank order: same bits everywhere
+        sum[c] = s;
+    }
+    team_barrier(t);                 // everybody has read the stage before anyone overwrites it
+    PADNE_HIP_CHECK(hipMemcpyAsync(dev_buf, sum, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
+    PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PADNE_OK;
+}
+
+static int team_allgather(padne_ctx *ctx, const double *send, double *recv, int count_per_rank) {
+    Team *t = (Team *)ctx->team;
+    PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));          // my segment is complete
+    {
+        std::lock_guard<std::mutex> lk(t->mu);
+        t->ptrs[(size_t)ctx->rank] = send;
+    }
+    team_barrier(t);
+    for (int r = 0; r < t->world; ++r) {
+        if (r == ctx->rank && send == recv + (size_t)r * count_per_rank) continue;   // in place
+        PADNE_HIP_CHECK(hipMemcpyAsync(recv + (size_t)r * count_per_rank, t->ptrs[(size_t)r],
+                                       sizeof(double) * (size_t)count_per_rank, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    team_barrier(t);                 // peers may now overwrite their segments
+    return PADNE_OK;
+}
+
 int comm_allreduce_sum_f64(padne_ctx *ctx, double *dev_buf, int count) {
+    if (ctx->team != nullptr) return team_allreduce(ctx, dev_buf, count);
     if (ctx->comm == nullptr) return PADNE_OK;
     return check_nccl(g_rccl.AllReduce(dev_buf, dev_buf, (size_t)count, ncclFloat64, ncclSum, (ncclComm_t)ctx->comm,
                                        ctx->stream), "ncclAllReduce");
 }
 
 int comm_allgather_f64(padne_ctx *ctx, const double *send, double *recv, int count_per_rank) {
-    if (ctx->comm == nullptr || count_per_rank == 0) return PADNE_OK;
+    if (count_per_rank == 0) return PADNE_OK;
+    if (ctx->team != nullptr) return team_allgather(ctx, send, recv, count_per_rank);
+    if (ctx->comm == nullptr) return PADNE_OK;
     return check_nccl(g_rccl.AllGather(send, recv, (size_t)count_per_rank, ncclFloat64, (ncclComm_t)ctx->comm,
                                        ctx->stream), "ncclAllGather");
 }
@@ -80,6 +154,7 @@ int comm_allgather_f64(padne_ctx *ctx, const double *send, double *recv, int cou
 void comm_destroy(padne_ctx *ctx) {
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)ctx->comm);
     ctx->comm = nullptr;
+    ctx->team = nullptr;
 }
 
 }  // namespace padne
@@ -115,5 +190,32 @@ extern "C" int padne_ctx_comm_rank(padne_ctx *ctx, int *rank, int *world_size) {
     PADNE_REQUIRE(ctx, "ctx");
     if (rank) *rank = ctx->rank;
     if (world_size) *world_size = ctx->world;
+    return PADNE_OK;
+}
+
+// ---- in-process team (tests / single-GPU rehearsal of the multi-rank path) --------------------------------------
+extern "C" int padne_team_create(int world_size, void **team_out) {
+    PADNE_REQUIRE(team_out && world_size >= 1 && world_size <= 64, "team size");
+    Team *t = new Team();
+    t->world = world_size;
+    t->ptrs.assign((size_t)world_size, nullptr);
+    t->stage.assign((size_t)world_size * 16, 0.0);
+    *team_out = t;
+    return PADNE_OK;
+}
+
+extern "C" int padne_team_destroy(void *team) {
+    delete (Team *)team;
+    return PADNE_OK;
+}
+
+extern "C" int padne_ctx_join_team(padne_ctx *ctx, void *team, int rank) {
+    PADNE_REQUIRE(ctx && team, "null argument");
+    Team *t = (Team *)team;
+    PADNE_REQUIRE(rank >= 0 && rank < t->world, "rank");
+    PADNE_REQUIRE(ctx->comm == nullptr && ctx->team == nullptr, "context already has a communicator");
+    ctx->team = t;
+    ctx->rank = rank;
+    ctx->world = t->world;
     return PADNE_OK;
 }

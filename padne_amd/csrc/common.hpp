@@ -77,6 +77,7 @@ struct padne_ctx {
     size_t ws_bytes = 0;
     // RCCL
     void *comm = nullptr;
+    void *team = nullptr;            // in-process team of contexts (single-GPU rehearsal of the multi-rank path)
     int rank = 0, world = 1;
     // halo plan of a row-partitioned matrix: vectors are [owned | world * halo_m exchanged values]
     bool halo_on = false;

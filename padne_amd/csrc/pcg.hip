@@ -306,7 +306,7 @@ const padne_csr *amg_level_matrix(const padne_csr *A0, int level, int which);
 // before every product.
 static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, const double *b, double *x,
                      const padne_solve_opts *o, padne_solve_info *info, bool x_is_guess) {
-    const bool dist = ctx->comm != nullptr;
+    const bool dist = ctx->comm != nullptr || ctx->team != nullptr;
     const bool halo = ctx->halo_on;
     const bool amg = prec != nullptr;
     const long long nr = a->n_rows;                       // matrix rows (owned rows + empty exchange rows)

@@ -138,17 +138,22 @@ def reduced_local_map(plan: RankPlan):
 class DistributedSolver:
     """Per-rank driver: local assembly, reduction, halo plan, RCCL communicator, solve."""
 
-    def __init__(self, ctx, plan: RankPlan, dist):
+    def __init__(self, ctx, plan: RankPlan, dist=None, team=None):
+        """``dist``: an initialised ``torch.distributed`` module (one process per GPU, RCCL), or ``team``: a
+        ``_hip.LocalTeam`` whose members are contexts of this process (single-GPU rehearsal, one thread per rank)."""
         self.ctx, self.plan = ctx, plan
-        # RCCL communicator: rank 0 creates the id, torch.distributed broadcasts the 128 bytes
-        import torch
-        if plan.rank == 0:
-            uid = np.frombuffer(ctx.comm_unique_id(), dtype=np.uint8).copy()
+        if team is not None:
+            team.join(ctx, plan.rank)
         else:
-            uid = np.zeros(128, dtype=np.uint8)
-        t = torch.from_numpy(uid).cuda()
-        dist.broadcast(t, src=0)
-        ctx.comm_init(bytes(t.cpu().numpy().tobytes()), plan.rank, plan.world)
+            # RCCL communicator: rank 0 creates the id, torch.distributed broadcasts the 128 bytes
+            import torch
+            if plan.rank == 0:
+                uid = np.frombuffer(ctx.comm_unique_id(), dtype=np.uint8).copy()
+            else:
+                uid = np.zeros(128, dtype=np.uint8)
+            t = torch.from_numpy(uid).cuda()
+            dist.broadcast(t, src=0)
+            ctx.comm_init(bytes(t.cpu().numpy().tobytes()), plan.rank, plan.world)
         # local assembly on this GPU
         xy = np.concatenate([mm[0] for mm in plan.meshes])
         tri = np.concatenate([mm[1] for mm in plan.meshes])

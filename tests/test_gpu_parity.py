@@ -726,3 +726,55 @@ def test_multigrid_with_hubs_and_strong_lumped_couplings(ctx):
     d = ctx.csr_from_scipy(A)
     res = d.solve_spd(-ro[1:n_pot], precond="amg")
     assert res.levels >= 2 and res.iterations < 200
+
+
+# ---- the multi-rank solver with world > 1 on one GPU (in-process team instead of RCCL) ----------------------
+
+def run_team(sysm, world, precond):
+    """One thread per rank, each with its own context on GPU 0; returns (global potentials, iterations)."""
+    import threading
+    from padne_amd import distributed
+    team = _hip.LocalTeam(world)
+    out = [None] * world
+    errors = []
+
+    def rank_main(rank):
+        try:
+            c = _hip.Context(0)
+            plan = distributed.build_layer_partition(sysm, rank, world)
+            ds = distributed.DistributedSolver(c, plan, team=team)
+            res = ds.solve(rtol=1e-12, precond=precond)
+            out[rank] = (plan, ds.solution(), res)
+        except Exception as exc:                                  # surface failures instead of dead-locking peers
+            errors.append((rank, exc))
+            raise
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert all(o is not None for o in out), "a rank did not finish"
+    v = np.zeros(sysm.n_vertices)
+    for plan, xs, _ in out:
+        idx = np.arange(plan.g0, plan.g1)
+        if plan.ground_local >= 0:
+            idx = np.delete(idx, plan.ground_local)
+        v[idx] = xs
+    its = {o[2].iterations for o in out}
+    assert len(its) == 1, f"ranks disagree on the iteration count: {its}"
+    return v, its.pop(), out[0][2]
+
+
+@pytest.mark.parametrize("world,precond", [(2, "jacobi"), (2, "amg"), (4, "amg"), (8, "amg")])
+def test_layer_partitioned_solver_with_several_ranks_on_one_gpu(world, precond):
+    sysm = synthetic.layered_system(8, 90, 70, via_lattice=5)
+    els = [("R", int(a), int(b), float(r)) for a, b, r in zip(*sysm.resistors)]
+    els += [("I", int(f), int(t), float(i)) for f, t, i in zip(*sysm.current_sources)]
+    Lo, ro = O.assemble_system([(m[0], m[1], m[2]) for m in sysm.meshes], 0, els, sysm.ground)
+    v_ref = O.solve_system(Lo, ro)[0][:sysm.n_vertices]
+    v, iters, res = run_team(sysm, world, precond)
+    assert np.abs(v - v_ref).max() <= REL_TOL * np.abs(v_ref).max()
+    assert res.rel_residual <= 1.1e-12
+    if precond == "amg":
+        assert res.levels >= 2 and iters < 400
