@@ -121,6 +121,14 @@ int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns,
  * (ground eliminated, voltage-source-tied nodes merged; DESIGN.md "reduction"). */
 int padne_csr_reduce(padne_ctx *ctx, const padne_csr *m, const int32_t *map_host,
                      int64_t n_out, double scale, padne_csr **out);
+/* Rectangular form of the same operation with separate row and column maps (row_map has m.n_rows entries,
+ * col_map m.n_cols): out (n_rows_out x n_cols_out) = scale * R^T M C.  The row-partitioned solve uses it
+ * to keep exactly the owned rows of a rank while the columns keep the exchange slots (DESIGN.md
+ * "multi-GPU"). */
+int padne_csr_relabel(padne_ctx *ctx, const padne_csr *m, const int32_t *row_map_host, int64_t n_rows_out,
+                      const int32_t *col_map_host, int64_t n_cols_out, double scale, padne_csr **out);
+/* rows of `top` followed by the rows of `bottom` (equal column counts) */
+int padne_csr_vstack(padne_ctx *ctx, const padne_csr *top, const padne_csr *bottom, padne_csr **out);
 
 /* ---- SpMV ---------------------------------------------------------------------------------- */
 /* y = M x, host vectors (the reference's residual product L_csc @ v, solver.py:775) */

@@ -79,6 +79,8 @@ SIGNATURES = {
     "padne_assemble_system": (C.c_int, [_P, _I64, _I64, _PF64, _I64, _PI32, _I64, _PI64, _PI64, _PF64,
                                         _I64, _PI64, _PI64, _PF64, C.POINTER(_P)]),
     "padne_csr_reduce": (C.c_int, [_P, _P, _PI32, _I64, C.c_double, C.POINTER(_P)]),
+    "padne_csr_relabel": (C.c_int, [_P, _P, _PI32, _I64, _PI32, _I64, C.c_double, C.POINTER(_P)]),
+    "padne_csr_vstack": (C.c_int, [_P, _P, _P, C.POINTER(_P)]),
     "padne_spmv": (C.c_int, [_P, _P, _PF64, _PF64]),
     "padne_spmv_dev": (C.c_int, [_P, _P, _P, _P, C.c_int]),
     "padne_residual_norm": (C.c_int, [_P, _P, _PF64, _PF64, _PF64]),
@@ -416,6 +418,23 @@ class CsrMatrix:
         h = _P()
         _check(self.ctx._lib.padne_csr_reduce(self.ctx._h, self._h, _ptr(m, _PI32), int(n_out), float(scale),
                                               C.byref(h)))
+        return CsrMatrix(self.ctx, h)
+
+    def relabel(self, row_map: np.ndarray, n_rows_out: int, col_map: np.ndarray, n_cols_out: int,
+                scale: float = 1.0) -> "CsrMatrix":
+        """``scale * R^T M C`` with separate row / column index maps (-1 drops the row / column)."""
+        rm = np.ascontiguousarray(row_map, dtype=np.int32)
+        cm = np.ascontiguousarray(col_map, dtype=np.int32)
+        if rm.shape[0] != self.shape[0] or cm.shape[0] != self.shape[1]:
+            raise ValueError("index map lengths must equal the matrix dimensions")
+        h = _P()
+        _check(self.ctx._lib.padne_csr_relabel(self.ctx._h, self._h, _ptr(rm, _PI32), int(n_rows_out), _ptr(cm, _PI32),
+                                               int(n_cols_out), float(scale), C.byref(h)))
+        return CsrMatrix(self.ctx, h)
+
+    def vstack(self, bottom: "CsrMatrix") -> "CsrMatrix":
+        h = _P()
+        _check(self.ctx._lib.padne_csr_vstack(self.ctx._h, self._h, bottom._h, C.byref(h)))
         return CsrMatrix(self.ctx, h)
 
     def matvec(self, x) -> np.ndarray:

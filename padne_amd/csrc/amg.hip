@@ -38,6 +38,10 @@ struct AmgLevel {
     double jac = 0.0;               // Jacobi damping 1/theta_c
     long long n = 0;
     double *b = nullptr, *xa = nullptr, *xb = nullptr, *tmp = nullptr;   // work vectors (levels >= 1: all; level 0: xa, tmp)
+    // row-partitioned hierarchy: A is this rank's rows, columns [owned | world * halo.m exchange slots]
+    HaloPlan halo;
+    int32_t *export_owned = nullptr;   // device copy of the export list (levels >= 1; level 0 borrows the context's)
+    std::vector<int> export_host;
 };
 
 struct Amg {
@@ -45,6 +49,15 @@ struct Amg {
     std::vector<AmgLevel> levels;
     double *coarse_inv = nullptr;   // dense n_c x n_c
     int n_coarse = 0;
+    // row-partitioned hierarchy: below the gather level every rank holds the whole operator (`tail`, with its
+    // own single-GPU hierarchy) and runs the rest of the cycle redundantly
+    bool dist = false;
+    padne_csr *tail = nullptr;
+    int n_pad = 0;                     // longest per-rank piece of the gather level
+    long long tail_n = 0, tail_off = 0;   // gathered size, first row of this rank's piece
+    int *seg_off = nullptr;            // device [world + 1]: first gathered row of every rank
+    double *coarse_gather = nullptr;   // [world * n_pad] padded pieces as exchanged
+    double *tail_r = nullptr, *tail_z = nullptr;   // [tail_n]
     double setup_seconds = 0.0;
     double operator_complexity = 0.0;
     int device = 0;
@@ -570,11 +583,11 @@ __global__ void dense_extract_inverse(int n, const double *__restrict__ W, doubl
 }
 
 // y = Inv * b : one wave per row
-__global__ __launch_bounds__(256) void dense_gemv(int n, const double *__restrict__ inv, const double *__restrict__ b,
-                                                  double *__restrict__ y) {
+__global__ __launch_bounds__(256) void dense_gemv(int n_rows, int n, const double *__restrict__ inv,
+                                                  const double *__restrict__ b, double *__restrict__ y) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (row >= n) return;
+    if (row >= n_rows) return;
     double s = 0.0;
     for (int c = lane; c < n; c += 64) s += inv[(size_t)row * n + c] * b[c];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
@@ -899,8 +912,14 @@ void amg_destroy(void *p) {
         pool_free(amg->ctx, L.xa);
         pool_free(amg->ctx, L.xb);
         pool_free(amg->ctx, L.tmp);
+        pool_free(amg->ctx, L.export_owned);
     }
     pool_free(amg->ctx, amg->coarse_inv);
+    pool_free(amg->ctx, amg->coarse_gather);
+    pool_free(amg->ctx, amg->seg_off);
+    pool_free(amg->ctx, amg->tail_r);
+    pool_free(amg->ctx, amg->tail_z);
+    if (amg->tail) padne_csr_destroy(amg->tail);
     delete amg;
 }
 
@@ -931,8 +950,11 @@ static bool amg_verbose() {
     return v == 1;
 }
 
+static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0);
+
 int amg_setup(padne_ctx *ctx, padne_csr *A0) {
     if (A0->amg) return PADNE_OK;
+    if (ctx->halo_on && A0->n_cols != A0->n_rows) return amg_setup_dist(ctx, A0);
     PADNE_REQUIRE(A0->n_rows == A0->n_cols, "multigrid needs a square matrix");
     PADNE_TRY(csr_build_dinv(ctx, A0));
     PADNE_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
@@ -1038,6 +1060,467 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
     return PADNE_OK;
 }
 
+// ---- row-partitioned hierarchy ---------------------------------------------------------------------
+// One global hierarchy over all ranks whose aggregates never cross a rank boundary: the prolongator is block
+// diagonal (built from the rank's own block of A_l), so restriction and prolongation stay local and the
+// Galerkin product needs the remote rows of P only for the exchanged vertices.  Every level is again a
+// row-partitioned operator [owned | world * m_l exchange slots] with its own exchange plan; the V-cycle
+// exchanges the smoothed iterate twice per level.  The coarsest operator is gathered to every rank and
+// inverted densely.
+
+// cnt[i] = entries of row i in the owned columns
+__global__ void block_count(int n, const int *__restrict__ rowptr, const int *__restrict__ cols, int n_own,
+                            int *__restrict__ cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int c = 0;
+    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) c += cols[k] < n_own ? 1 : 0;
+    cnt[i] = c;
+}
+
+// owned x owned block of the rank's rows.  The dropped couplings are lumped onto the diagonal (row sums of
+// the block equal those of the full operator, so the smoothed prolongator keeps its unit row sums at the
+// exchanged vertices) unless that would eat more than 70 % of the diagonal.
+__global__ void block_fill(int n, const int *__restrict__ rowptr, const int *__restrict__ cols,
+                           const double *__restrict__ vals, int n_own, const int *__restrict__ optr,
+                           int *__restrict__ ocols, double *__restrict__ ovals) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int o = optr[i], dpos = -1;
+    double dropped = 0.0;
+    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+        const int c = cols[k];
+        if (c < n_own) {
+            ocols[o] = c;
+            ovals[o] = vals[k];
+            if (c == i) dpos = o;
+            ++o;
+        } else {
+            dropped += vals[k];
+        }
+    }
+    if (dpos >= 0 && dropped != 0.0) {
+        const double d = ovals[dpos];
+        if (d + dropped > 0.3 * d) ovals[dpos] = d + dropped;
+    }
+}
+
+// rows idx[0..ne) of a CSR matrix into fixed-width records of K entries
+__global__ void extract_rows(int ne, const int *__restrict__ idx, const int *__restrict__ rowptr,
+                             const int *__restrict__ cols, const double *__restrict__ vals, int K,
+                             int *__restrict__ len, int *__restrict__ oc, double *__restrict__ ov) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ne) return;
+    const int i = idx[e];
+    const int L = rowptr[i + 1] - rowptr[i];
+    len[e] = L;
+    for (int k = 0; k < L && k < K; ++k) {
+        oc[(size_t)e * K + k] = cols[rowptr[i] + k];
+        ov[(size_t)e * K + k] = vals[rowptr[i] + k];
+    }
+}
+
+// all-gather of equally sized host records through the context's communicator
+static int host_allgather(padne_ctx *ctx, const std::vector<double> &mine, std::vector<double> &all) {
+    const size_t cnt = mine.size();
+    const int W = ctx->world;
+    all.assign(cnt * (size_t)W, 0.0);
+    if (cnt == 0) return PADNE_OK;
+    PADNE_REQUIRE(cnt < (1u << 30), "exchange record too large");
+    Scratch sc(ctx);
+    double *d = nullptr;
+    PADNE_TRY(sc.alloc(&d, cnt * (size_t)W));
+    PADNE_HIP_CHECK(hipMemcpyAsync(d + cnt * (size_t)ctx->rank, mine.data(), sizeof(double) * cnt, hipMemcpyHostToDevice,
+                                   ctx->stream));
+    if (W > 1) PADNE_TRY(comm_allgather_f64(ctx, d + cnt * (size_t)ctx->rank, d, (int)cnt));
+    PADNE_HIP_CHECK(hipMemcpyAsync(all.data(), d, sizeof(double) * cnt * (size_t)W, hipMemcpyDeviceToHost, ctx->stream));
+    PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PADNE_OK;
+}
+
+static int upload_csr(padne_ctx *ctx, long long n_rows, long long n_cols, const std::vector<int> &rowptr,
+                      const std::vector<int> &cols, const std::vector<double> &vals, padne_csr **out) {
+    padne_csr *m = nullptr;
+    PADNE_TRY(csr_alloc(ctx, n_rows, n_cols, (long long)cols.size(), &m));
+    hipError_t e = hipMemcpyAsync(m->rowptr, rowptr.data(), sizeof(int) * (size_t)(n_rows + 1), hipMemcpyHostToDevice,
+                                  ctx->stream);
+    if (e == hipSuccess && !cols.empty()) {
+        e = hipMemcpyAsync(m->cols, cols.data(), sizeof(int) * cols.size(), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(m->vals, vals.data(), sizeof(double) * vals.size(), hipMemcpyHostToDevice, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        set_error("matrix upload failed: %s", hipGetErrorString(e));
+        padne_csr_destroy(m);
+        return PADNE_E_HIP;
+    }
+    *out = m;
+    return PADNE_OK;
+}
+
+static int owned_block(padne_ctx *ctx, const padne_csr *A, long long n_own, padne_csr **blk) {
+    hipStream_t s = ctx->stream;
+    const int n = (int)n_own;
+    Scratch sc(ctx);
+    int *cnt = nullptr, *optr = nullptr;
+    PADNE_TRY(sc.alloc(&cnt, (size_t)n + 1));
+    PADNE_TRY(sc.alloc(&optr, (size_t)n + 1));
+    PADNE_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)(n + 1), s));
+    hipLaunchKernelGGL(block_count, dim3(nblk(n)), dim3(256), 0, s, n, A->rowptr, A->cols, n, cnt);
+    PADNE_HIP_CHECK(hipGetLastError());
+    int64_t nnz = 0;
+    PADNE_TRY(exclusive_scan_i32(ctx, cnt, optr, n, &nnz));
+    padne_csr *m = nullptr;
+    PADNE_TRY(csr_alloc(ctx, n, n, nnz, &m));
+    hipError_t e = hipMemcpyAsync(m->rowptr, optr, sizeof(int) * (size_t)(n + 1), hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(block_fill, dim3(nblk(n)), dim3(256), 0, s, n, A->rowptr, A->cols, A->vals, n, m->rowptr,
+                           m->cols, m->vals);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) {
+        set_error("owned block extraction failed: %s", hipGetErrorString(e));
+        padne_csr_destroy(m);
+        return PADNE_E_HIP;
+    }
+    *blk = m;
+    return PADNE_OK;
+}
+
+// The rows of P that belong to exchanged vertices, as every other rank needs them: rows of the exchange
+// slots [world * m] over the coarse columns [n_agg | world * m_c].  Also returns this rank's coarse export
+// list (the aggregates its exported rows touch) and the common coarse segment length m_c.
+static int exchange_prolongator_rows(padne_ctx *ctx, const AmgLevel &L, const padne_csr *P, int n_agg,
+                                     std::vector<int> &export_c, int *m_c_out, padne_csr **P_halo) {
+    const int W = ctx->world, rank = ctx->rank, m = L.halo.m, ne = L.halo.n_export;
+    hipStream_t s = ctx->stream;
+    int K = 16, kmax = 0;
+    std::vector<int> len((size_t)ne), pc;
+    std::vector<double> pv;
+    if (ne > 0) {
+        for (int pass = 0; pass < 2; ++pass) {
+            Scratch sc(ctx);
+            int *d_len = nullptr, *d_pc = nullptr;
+            double *d_pv = nullptr;
+            PADNE_TRY(sc.alloc(&d_len, (size_t)ne));
+            PADNE_TRY(sc.alloc(&d_pc, (size_t)ne * K));
+            PADNE_TRY(sc.alloc(&d_pv, (size_t)ne * K));
+            hipLaunchKernelGGL(extract_rows, dim3(nblk(ne)), dim3(256), 0, s, ne, L.halo.export_idx, P->rowptr, P->cols,
+                               P->vals, K, d_len, d_pc, d_pv);
+            PADNE_HIP_CHECK(hipGetLastError());
+            pc.resize((size_t)ne * K);
+            pv.resize((size_t)ne * K);
+            PADNE_HIP_CHECK(hipMemcpyAsync(len.data(), d_len, sizeof(int) * (size_t)ne, hipMemcpyDeviceToHost, s));
+            PADNE_HIP_CHECK(hipMemcpyAsync(pc.data(), d_pc, sizeof(int) * pc.size(), hipMemcpyDeviceToHost, s));
+            PADNE_HIP_CHECK(hipMemcpyAsync(pv.data(), d_pv, sizeof(double) * pv.size(), hipMemcpyDeviceToHost, s));
+            PADNE_HIP_CHECK(hipStreamSynchronize(s));
+            kmax = 0;
+            for (int e = 0; e < ne; ++e) kmax = std::max(kmax, len[(size_t)e]);
+            if (kmax <= K) break;
+            K = kmax;
+        }
+    }
+    export_c.clear();
+    for (int e = 0; e < ne; ++e)
+        for (int k = 0; k < len[(size_t)e]; ++k) export_c.push_back(pc[(size_t)e * K + k]);
+    std::sort(export_c.begin(), export_c.end());
+    export_c.erase(std::unique(export_c.begin(), export_c.end()), export_c.end());
+    std::vector<double> head = {(double)ne, (double)export_c.size(), (double)kmax}, heads;
+    PADNE_TRY(host_allgather(ctx, head, heads));
+    int m_c = 0, Kg = 1;
+    for (int q = 0; q < W; ++q) {
+        PADNE_REQUIRE((int)heads[(size_t)q * 3] <= m, "export list longer than the exchange segment");
+        m_c = std::max(m_c, (int)heads[(size_t)q * 3 + 1]);
+        Kg = std::max(Kg, (int)heads[(size_t)q * 3 + 2]);
+    }
+    // fixed-width records (position in my coarse export list, value); position -1 = unused
+    std::vector<double> rec((size_t)m * Kg * 2, -1.0), recs;
+    for (int e = 0; e < ne; ++e)
+        for (int k = 0; k < len[(size_t)e]; ++k) {
+            const int c = pc[(size_t)e * K + k];
+            const int pos = (int)(std::lower_bound(export_c.begin(), export_c.end(), c) - export_c.begin());
+            rec[((size_t)e * Kg + k) * 2] = (double)pos;
+            rec[((size_t)e * Kg + k) * 2 + 1] = pv[(size_t)e * K + k];
+        }
+    PADNE_TRY(host_allgather(ctx, rec, recs));
+    std::vector<int> rowptr((size_t)W * m + 1, 0), cols;
+    std::vector<double> vals;
+    for (int q = 0; q < W; ++q)
+        for (int e = 0; e < m; ++e) {
+            if (q != rank) {
+                const double *r = recs.data() + ((size_t)q * m + e) * Kg * 2;
+                for (int k = 0; k < Kg; ++k)
+                    if (r[2 * k] >= 0.0) {
+                        cols.push_back(n_agg + q * m_c + (int)r[2 * k]);
+                        vals.push_back(r[2 * k + 1]);
+                    }
+            }
+            rowptr[(size_t)q * m + e + 1] = (int)cols.size();
+        }
+    *m_c_out = m_c;
+    return upload_csr(ctx, (long long)W * m, (long long)n_agg + (long long)W * m_c, rowptr, cols, vals, P_halo);
+}
+
+// padded per-rank pieces [world][n_pad] -> the gathered vector [sum n_q]
+__global__ void compact_pieces(int world, int n_pad, const int *__restrict__ seg_off, const double *__restrict__ src,
+                               double *__restrict__ dst, const int *__restrict__ done_flag) {
+    if (done_flag != nullptr && *done_flag != 0) return;
+    const int q = blockIdx.y;
+    const int nq = seg_off[q + 1] - seg_off[q];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += gridDim.x * blockDim.x)
+        dst[seg_off[q] + i] = src[(size_t)q * n_pad + i];
+}
+
+// Gather the last row-partitioned level to every rank (rows in rank order) and build an ordinary hierarchy
+// on it: the small levels are cheaper to run redundantly than to exchange, and their aggregates may then
+// cross rank boundaries, which matters once the couplings between ranks dominate a coarse operator.
+static int gather_tail(padne_ctx *ctx, Amg *amg) {
+    AmgLevel &L = amg->levels.back();
+    const int W = ctx->world, m = L.halo.m, n = (int)L.n;
+    hipStream_t s = ctx->stream;
+    const padne_csr *A = L.A;
+    std::vector<int> rp((size_t)n + 1), cl((size_t)A->nnz);
+    std::vector<double> vl((size_t)A->nnz);
+    PADNE_HIP_CHECK(hipMemcpyAsync(rp.data(), A->rowptr, sizeof(int) * rp.size(), hipMemcpyDeviceToHost, s));
+    if (A->nnz > 0) {
+        PADNE_HIP_CHECK(hipMemcpyAsync(cl.data(), A->cols, sizeof(int) * cl.size(), hipMemcpyDeviceToHost, s));
+        PADNE_HIP_CHECK(hipMemcpyAsync(vl.data(), A->vals, sizeof(double) * vl.size(), hipMemcpyDeviceToHost, s));
+    }
+    PADNE_HIP_CHECK(hipStreamSynchronize(s));
+    std::vector<double> head = {(double)n, (double)A->nnz, (double)L.halo.n_export}, heads;
+    PADNE_TRY(host_allgather(ctx, head, heads));
+    int n_pad = 1;
+    long long nnz_max = 0, nnz_sum = 0;
+    std::vector<int> off((size_t)W + 1, 0);
+    for (int q = 0; q < W; ++q) {
+        n_pad = std::max(n_pad, (int)heads[(size_t)q * 3]);
+        nnz_max = std::max(nnz_max, (long long)heads[(size_t)q * 3 + 1]);
+        nnz_sum += (long long)heads[(size_t)q * 3 + 1];
+        off[(size_t)q + 1] = off[(size_t)q] + (int)heads[(size_t)q * 3];
+    }
+    const long long N = off[(size_t)W];
+    PADNE_REQUIRE(nnz_sum < 2147483647LL, "gathered operator too large");
+    // record: rowptr[n_pad + 1] | cols[nnz_max] | vals[nnz_max] | export[m]
+    const size_t o_cols = (size_t)n_pad + 1, o_vals = o_cols + (size_t)nnz_max, o_exp = o_vals + (size_t)nnz_max;
+    std::vector<double> rec(o_exp + (size_t)m, 0.0), recs;
+    for (int i = 0; i <= n; ++i) rec[(size_t)i] = (double)rp[(size_t)i];
+    for (long long k = 0; k < A->nnz; ++k) {
+        rec[o_cols + (size_t)k] = (double)cl[(size_t)k];
+        rec[o_vals + (size_t)k] = vl[(size_t)k];
+    }
+    for (int e = 0; e < L.halo.n_export; ++e) rec[o_exp + (size_t)e] = (double)L.export_host[(size_t)e];
+    PADNE_TRY(host_allgather(ctx, rec, recs));
+    std::vector<int> grp((size_t)N + 1, 0), gcl;
+    std::vector<double> gvl;
+    gcl.reserve((size_t)nnz_sum);
+    gvl.reserve((size_t)nnz_sum);
+    std::vector<std::pair<int, double>> row;
+    for (int q = 0; q < W; ++q) {
+        const double *r = recs.data() + (size_t)q * rec.size();
+        const int nq = (int)heads[(size_t)q * 3];
+        for (int i = 0; i < nq; ++i) {
+            row.clear();
+            for (int k = (int)r[i]; k < (int)r[i + 1]; ++k) {
+                const int j = (int)r[o_cols + (size_t)k];
+                int col;
+                if (j < nq) {
+                    col = off[(size_t)q] + j;
+                } else {
+                    const int slot = j - nq, p = slot / m, e = slot % m;
+                    col = off[(size_t)p] + (int)recs[(size_t)p * rec.size() + o_exp + (size_t)e];
+                }
+                row.emplace_back(col, r[o_vals + (size_t)k]);
+            }
+            std::sort(row.begin(), row.end(), [](const std::pair<int, double> &x, const std::pair<int, double> &y) {
+                return x.first < y.first;
+            });
+            for (const auto &cv : row) {
+                gcl.push_back(cv.first);
+                gvl.push_back(cv.second);
+            }
+            grp[(size_t)off[(size_t)q] + i + 1] = (int)gcl.size();
+        }
+    }
+    PADNE_TRY(upload_csr(ctx, N, N, grp, gcl, gvl, &amg->tail));
+    amg->tail->hierarchy_operator = true;
+    PADNE_TRY(amg_setup(ctx, amg->tail));
+    amg->n_pad = n_pad;
+    amg->tail_n = N;
+    amg->tail_off = off[(size_t)ctx->rank];
+    amg->seg_off = (int *)pool_alloc(ctx, sizeof(int) * ((size_t)W + 1));
+    amg->coarse_gather = (double *)pool_alloc(ctx, sizeof(double) * (size_t)W * n_pad);
+    amg->tail_r = (double *)pool_alloc(ctx, sizeof(double) * (size_t)(N > 0 ? N : 1));
+    amg->tail_z = (double *)pool_alloc(ctx, sizeof(double) * (size_t)(N > 0 ? N : 1));
+    if (!amg->seg_off || !amg->coarse_gather || !amg->tail_r || !amg->tail_z) return PADNE_E_NOMEM;
+    PADNE_HIP_CHECK(hipMemcpyAsync(amg->seg_off, off.data(), sizeof(int) * ((size_t)W + 1), hipMemcpyHostToDevice, s));
+    PADNE_HIP_CHECK(hipMemsetAsync(amg->coarse_gather, 0, sizeof(double) * (size_t)W * n_pad, s));
+    PADNE_HIP_CHECK(hipStreamSynchronize(s));
+    return PADNE_OK;
+}
+
+static int gather_n_limit() {   // global size at which the row-partitioned levels hand over to the gathered tail
+    const char *e = getenv("PADNE_AMG_GATHER_N");
+    int v = e ? atoi(e) : 262144;
+    if (v < 64) v = 64;
+    return v;
+}
+
+static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0) {
+    const int W = ctx->world;
+    PADNE_REQUIRE(A0->n_rows == ctx->halo_n_owned && A0->n_cols == ctx->halo_n_owned + (long long)W * ctx->halo_m,
+                  "row-partitioned multigrid: the matrix must be owned rows x [owned | world * m] columns");
+    PADNE_TRY(csr_build_dinv(ctx, A0));
+    hipStream_t s = ctx->stream;
+    PADNE_HIP_CHECK(hipStreamSynchronize(s));
+    const auto t_begin = std::chrono::steady_clock::now();
+    const long long gather_n = gather_n_limit();
+    Amg *amg = new Amg();
+    amg->device = ctx->device;
+    amg->ctx = ctx;
+    amg->dist = true;
+    int rc = PADNE_OK;
+    const padne_csr *A = A0;
+    HaloPlan plan;
+    plan.n_owned = ctx->halo_n_owned;
+    plan.m = ctx->halo_m;
+    plan.n_export = ctx->halo_n_export;
+    plan.export_idx = ctx->halo_export;
+    std::vector<int> export_host((size_t)plan.n_export);
+    int32_t *export_owned = nullptr;       // device list owned by the level being built (levels >= 1)
+    if (plan.n_export > 0) {
+        hipError_t e = hipMemcpyAsync(export_host.data(), plan.export_idx, sizeof(int) * export_host.size(),
+                                      hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) rc = PADNE_E_HIP;
+    }
+    double nnz_total = 0.0;
+    bool stalled = false;
+    for (int lvl = 0; lvl < kMaxLevels && rc == PADNE_OK; ++lvl) {
+        AmgLevel L;
+        L.A = A;
+        L.A_owned = (lvl == 0) ? nullptr : const_cast<padne_csr *>(A);
+        L.n = plan.n_owned;
+        L.halo = plan;
+        L.export_owned = export_owned;
+        L.export_host = export_host;
+        export_owned = nullptr;
+        nnz_total += (double)A->nnz;
+        amg->levels.push_back(L);
+        AmgLevel &Lr = amg->levels.back();
+        double lam = 2.0;
+        if ((rc = gershgorin(ctx, A, &lam)) != PADNE_OK) break;
+        std::vector<double> st = {(double)Lr.n, lam}, sts;
+        if ((rc = host_allgather(ctx, st, sts)) != PADNE_OK) break;
+        long long n_glob = 0, n_max = 0;
+        for (int q = 0; q < W; ++q) {
+            n_glob += (long long)sts[(size_t)q * 2];
+            n_max = std::max(n_max, (long long)sts[(size_t)q * 2]);
+            lam = std::max(lam, sts[(size_t)q * 2 + 1]);
+        }
+        Lr.lambda = lam;
+        // level 0 always stays row-partitioned (the CG vectors are); below it the levels are gathered as soon
+        // as they are small enough to run redundantly
+        const bool coarsest = lvl > 0 && (n_glob <= gather_n || lvl == kMaxLevels - 1);
+        if (lvl > 0 && !coarsest && getenv("PADNE_AMG_NO_LANCZOS") == nullptr) {
+            double ritz = 0.0;
+            if ((rc = estimate_lambda_max(ctx, A, 12, &ritz, &plan)) != PADNE_OK) break;
+            const double est = 1.08 * ritz;
+            if (est > 0.0 && est < Lr.lambda) Lr.lambda = est;
+        }
+        Lr.jac = 1.0 / (0.5 * (Lr.lambda + Lr.lambda / kChebRatio));
+        if ((rc = alloc_vec(ctx, &Lr.xa, Lr.n + (long long)W * plan.m)) != PADNE_OK) break;
+        if ((rc = alloc_vec(ctx, &Lr.tmp, A->n_rows)) != PADNE_OK) break;
+        if (lvl > 0 && ((rc = alloc_vec(ctx, &Lr.b, Lr.n)) != PADNE_OK || (rc = alloc_vec(ctx, &Lr.xb, Lr.n)) != PADNE_OK)) break;
+        if ((rc = hipMemsetAsync(Lr.xa, 0, sizeof(double) * (size_t)(Lr.n + (long long)W * plan.m), s) == hipSuccess
+                      ? PADNE_OK : PADNE_E_HIP) != PADNE_OK) break;
+        if (coarsest) break;
+        // aggregates and prolongator from the rank's own block
+        padne_csr *blk = nullptr;
+        if ((rc = owned_block(ctx, A, Lr.n, &blk)) != PADNE_OK) break;
+        Scratch sc(ctx);
+        int *agg = nullptr, n_agg = 0;
+        double lambda_f = 2.0, lambda_g = 2.0;
+        if ((rc = csr_build_dinv(ctx, blk)) == PADNE_OK && (rc = aggregate(ctx, sc, blk, &agg, &n_agg)) == PADNE_OK &&
+            (rc = gershgorin(ctx, blk, &lambda_f, true)) == PADNE_OK)
+            rc = gershgorin(ctx, blk, &lambda_g, false);
+        if (rc != PADNE_OK) { padne_csr_destroy(blk); break; }
+        std::vector<double> ag = {(double)n_agg}, ags;
+        if ((rc = host_allgather(ctx, ag, ags)) != PADNE_OK) { padne_csr_destroy(blk); break; }
+        long long agg_glob = 0;
+        for (int q = 0; q < W; ++q) agg_glob += (long long)ags[(size_t)q];
+        if (amg_verbose() && ctx->rank == 0)
+            fprintf(stderr, "[amg] level %d: global n=%lld (this rank %lld, nnz %lld, m=%d) lambda=%.3f -> %lld aggregates\n",
+                    lvl, n_glob, Lr.n, (long long)A->nnz, plan.m, Lr.lambda, agg_glob);
+        if (agg_glob == 0 || (double)agg_glob > 0.8 * (double)n_glob) {
+            // coarsening inside the ranks stalled: gather this level (level 0 cannot be: diagonal preconditioner,
+            // the same decision on every rank)
+            padne_csr_destroy(blk);
+            stalled = true;
+            if (lvl == 0) {
+                rc = PADNE_E_INVALID;
+                set_error("row-partitioned multigrid: no coarsening on the finest level");
+            }
+            break;
+        }
+        if (lambda_g < lambda_f) lambda_f = lambda_g;
+        rc = build_prolongator(ctx, blk, agg, n_agg, 4.0 / (3.0 * lambda_f), &Lr.P);
+        padne_csr_destroy(blk);
+        if (rc != PADNE_OK) break;
+        if ((rc = transpose(ctx, Lr.P, &Lr.R)) != PADNE_OK) break;
+        padne_csr *P_halo = nullptr, *P_ext = nullptr, *AP = nullptr, *Ac = nullptr;
+        std::vector<int> export_c;
+        int m_c = 0;
+        if ((rc = exchange_prolongator_rows(ctx, Lr, Lr.P, n_agg, export_c, &m_c, &P_halo)) != PADNE_OK) break;
+        rc = csr_vstack(ctx, Lr.P, P_halo, (long long)n_agg + (long long)W * m_c, &P_ext);
+        padne_csr_destroy(P_halo);
+        if (rc != PADNE_OK) break;
+        rc = spgemm(ctx, A, P_ext, &AP);
+        padne_csr_destroy(P_ext);
+        if (rc != PADNE_OK) break;
+        rc = spgemm(ctx, Lr.R, AP, &Ac);
+        padne_csr_destroy(AP);
+        if (rc != PADNE_OK) break;
+        if ((rc = csr_build_dinv(ctx, Ac)) != PADNE_OK) { padne_csr_destroy(Ac); break; }
+        Ac->hierarchy_operator = true;
+        Lr.P->hierarchy_operator = true;
+        Lr.R->hierarchy_operator = true;
+        // exchange plan of the coarse level
+        export_owned = (int32_t *)pool_alloc(ctx, sizeof(int32_t) * (export_c.empty() ? 1 : export_c.size()));
+        if (export_owned == nullptr) { padne_csr_destroy(Ac); rc = PADNE_E_NOMEM; break; }
+        if (!export_c.empty()) {
+            hipError_t e = hipMemcpyAsync(export_owned, export_c.data(), sizeof(int) * export_c.size(),
+                                          hipMemcpyHostToDevice, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) { padne_csr_destroy(Ac); pool_free(ctx, export_owned); export_owned = nullptr; rc = PADNE_E_HIP; break; }
+        }
+        plan.n_owned = n_agg;
+        plan.m = m_c;
+        plan.n_export = (int)export_c.size();
+        plan.export_idx = export_owned;
+        export_host = export_c;
+        A = Ac;
+    }
+    if (export_owned != nullptr) pool_free(ctx, export_owned);
+    if (rc == PADNE_OK) {
+        if (amg->levels.back().P != nullptr && !stalled) {
+            rc = PADNE_E_INVALID;
+            set_error("multigrid setup did not reach a coarsest level");
+        } else {
+            rc = gather_tail(ctx, amg);
+        }
+    }
+    if (rc != PADNE_OK) {
+        amg_destroy(amg);
+        return rc;
+    }
+    amg->operator_complexity = nnz_total / (double)(A0->nnz > 0 ? A0->nnz : 1);
+    PADNE_HIP_CHECK(hipStreamSynchronize(s));
+    amg->setup_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    A0->amg = amg;
+    return PADNE_OK;
+}
+
 // z = M^-1 r on level 0 ; optional partial sums of r.z (written by the last kernel of the cycle)
 int amg_apply(padne_ctx *ctx, const padne_csr *A0, const double *r, double *z, double *partials_rz,
               const int32_t *done_flag) {
@@ -1050,9 +1533,20 @@ int amg_apply(padne_ctx *ctx, const padne_csr *A0, const double *r, double *z, d
         const double *b = (l == 0) ? r : L.b;
         if (l == nl - 1) {
             double *out = (l == 0) ? z : L.xb;
-            if (amg->n_coarse > 0)
+            if (amg->dist) {
+                // gather the restricted residual and run the rest of the cycle redundantly on every rank
+                double *seg = amg->coarse_gather + (size_t)ctx->rank * amg->n_pad;
+                PADNE_HIP_CHECK(hipMemcpyAsync(seg, b, sizeof(double) * (size_t)L.n, hipMemcpyDeviceToDevice, s));
+                PADNE_TRY(comm_allgather_f64(ctx, seg, amg->coarse_gather, amg->n_pad));
+                hipLaunchKernelGGL(compact_pieces, dim3(nblk(amg->n_pad), ctx->world), dim3(256), 0, s, ctx->world,
+                                   amg->n_pad, amg->seg_off, amg->coarse_gather, amg->tail_r, done_flag);
+                PADNE_HIP_CHECK(hipGetLastError());
+                PADNE_TRY(amg_apply(ctx, amg->tail, amg->tail_r, amg->tail_z, nullptr, done_flag));
+                PADNE_HIP_CHECK(hipMemcpyAsync(out, amg->tail_z + amg->tail_off, sizeof(double) * (size_t)L.n,
+                                               hipMemcpyDeviceToDevice, s));
+            } else if (amg->n_coarse > 0)
                 hipLaunchKernelGGL(dense_gemv, dim3((amg->n_coarse + 3) / 4), dim3(256), 0, s, amg->n_coarse,
-                                   amg->coarse_inv, b, out);
+                                   amg->n_coarse, amg->coarse_inv, b, out);
             PADNE_HIP_CHECK(hipGetLastError());
             break;
         }
@@ -1060,6 +1554,7 @@ int amg_apply(padne_ctx *ctx, const padne_csr *A0, const double *r, double *z, d
         hipLaunchKernelGGL(scale_dinv_kernel, dim3(gv > 0 ? gv : 1), dim3(256), 0, s, L.n, L.jac, L.A->dinv, b, L.xa,
                            done_flag);
         PADNE_HIP_CHECK(hipGetLastError());
+        if (amg->dist) PADNE_TRY(halo_exchange_plan(ctx, L.halo, L.xa, done_flag));
         PADNE_TRY(launch_spmv_mode(ctx, L.A, SPMV_RESID, L.xa, L.tmp, nullptr, nullptr, done_flag, b, nullptr, 0.0));
         PADNE_TRY(launch_spmv_mode(ctx, L.R, SPMV_PLAIN, L.tmp, amg->levels[l + 1].b, nullptr, nullptr, done_flag,
                                    nullptr, nullptr, 0.0));
@@ -1071,6 +1566,7 @@ int amg_apply(padne_ctx *ctx, const padne_csr *A0, const double *r, double *z, d
         const double *xc = amg->levels[l + 1].xb;
         double *out = (l == 0) ? z : L.xb;
         PADNE_TRY(launch_spmv_mode(ctx, L.P, SPMV_ADD, xc, L.xa, nullptr, nullptr, done_flag, nullptr, nullptr, 0.0));
+        if (amg->dist) PADNE_TRY(halo_exchange_plan(ctx, L.halo, L.xa, done_flag));
         PADNE_TRY(launch_spmv_mode(ctx, L.A, SPMV_JACOBI, L.xa, out, nullptr, (l == 0) ? partials_rz : nullptr,
                                    done_flag, b, L.A->dinv, L.jac));
     }
@@ -1088,10 +1584,16 @@ const padne_csr *amg_level_matrix(const padne_csr *A0, int level, int which) {
     return which == 0 ? L.A : (which == 1 ? L.P : L.R);
 }
 
+int csr_matmul(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_csr **C) { return spgemm(ctx, X, Y, C); }
+int csr_transpose(padne_ctx *ctx, const padne_csr *M, padne_csr **T) { return transpose(ctx, M, T); }
+
 void amg_info(const padne_csr *A0, int *levels, double *complexity, double *setup_seconds, long long *coarse_n) {
     const Amg *amg = (const Amg *)A0->amg;
     if (!amg) return;
-    if (levels) *levels = (int)amg->levels.size();
+    if (levels) {
+        *levels = (int)amg->levels.size();
+        if (amg->tail && amg->tail->amg) *levels += (int)((const Amg *)amg->tail->amg)->levels.size() - 1;
+    }
     if (complexity) *complexity = amg->operator_complexity;
     if (setup_seconds) *setup_seconds = amg->setup_seconds;
     if (coarse_n) *coarse_n = amg->n_coarse;

@@ -523,18 +523,19 @@ __global__ void asm_fill_diag_placeholder(long long n_rows, const int *__restric
 
 // ---- reduce:  out = scale * P^T M P ------------------------------------------------------------
 __global__ void reduce_count(long long n_rows, const int *__restrict__ rowptr, const int *__restrict__ cols,
-                             const int *__restrict__ map, int *__restrict__ cnt) {
+                             const int *__restrict__ map, const int *__restrict__ cmap, int *__restrict__ cnt) {
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
     const int t = map[r];
     if (t < 0) return;
     int c = 0;
-    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) c += (map[cols[k]] >= 0) ? 1 : 0;
+    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) c += (cmap[cols[k]] >= 0) ? 1 : 0;
     if (c) atomicAdd(&cnt[t], c);
 }
 
 __global__ void reduce_fill(long long n_rows, const int *__restrict__ rowptr, const int *__restrict__ cols,
-                            const double *__restrict__ vals, const int *__restrict__ map, double scale,
+                            const double *__restrict__ vals, const int *__restrict__ map,
+                            const int *__restrict__ cmap, double scale,
                             const int *__restrict__ slot_ptr, int *__restrict__ cursor,
                             long long *__restrict__ key, double *__restrict__ val) {
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -542,11 +543,11 @@ __global__ void reduce_fill(long long n_rows, const int *__restrict__ rowptr, co
     const int t = map[r];
     if (t < 0) return;
     int c = 0;
-    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) c += (map[cols[k]] >= 0) ? 1 : 0;
+    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) c += (cmap[cols[k]] >= 0) ? 1 : 0;
     if (!c) return;
     int s = slot_ptr[t] + atomicAdd(&cursor[t], c);
     for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
-        const int tc = map[cols[k]];
+        const int tc = cmap[cols[k]];
         if (tc < 0) continue;
         key[s] = make_key(tc, k);       // ties are broken by the position in the source matrix
         val[s] = scale * vals[k];
@@ -789,40 +790,108 @@ extern "C" int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns, int64_t
                              d_val, d_err, out);
 }
 
-extern "C" int padne_csr_reduce(padne_ctx *ctx, const padne_csr *m, const int32_t *map_host, int64_t n_out,
-                                double scale, padne_csr **out) {
-    PADNE_REQUIRE(ctx && m && map_host && out, "null argument");
-    PADNE_REQUIRE(m->n_rows == m->n_cols, "matrix must be square");
-    PADNE_REQUIRE(n_out >= 0 && n_out < 2147483647LL, "n_out");
+// out = scale * R^T M C: entry (i, j, v) becomes (row_map[i], col_map[j], scale*v) when both maps are >= 0,
+// duplicates are added in the order of their position in M.
+static int csr_relabel(padne_ctx *ctx, const padne_csr *m, const int32_t *row_map_host, int64_t n_rows_out,
+                       const int32_t *col_map_host, int64_t n_cols_out, double scale, padne_csr **out) {
+    PADNE_REQUIRE(n_rows_out >= 0 && n_rows_out < 2147483647LL && n_cols_out >= 0 && n_cols_out < 2147483647LL,
+                  "output shape");
     for (int64_t i = 0; i < m->n_rows; ++i)
-        PADNE_REQUIRE(map_host[i] >= -1 && map_host[i] < n_out, "map entry out of range");
+        PADNE_REQUIRE(row_map_host[i] >= -1 && row_map_host[i] < n_rows_out, "row map entry out of range");
+    for (int64_t j = 0; j < m->n_cols; ++j)
+        PADNE_REQUIRE(col_map_host[j] >= -1 && col_map_host[j] < n_cols_out, "column map entry out of range");
     PADNE_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     Scratch sc(ctx);
-    int *d_map = nullptr, *d_cnt = nullptr, *d_slot = nullptr, *d_err = nullptr;
+    int *d_map = nullptr, *d_cmap = nullptr, *d_cnt = nullptr, *d_slot = nullptr, *d_err = nullptr;
     PADNE_TRY(sc.alloc(&d_map, (size_t)m->n_rows));
-    PADNE_TRY(sc.alloc(&d_cnt, (size_t)n_out + 1));
-    PADNE_TRY(sc.alloc(&d_slot, (size_t)n_out + 1));
+    PADNE_TRY(sc.alloc(&d_cnt, (size_t)n_rows_out + 1));
+    PADNE_TRY(sc.alloc(&d_slot, (size_t)n_rows_out + 1));
     PADNE_TRY(sc.alloc(&d_err, (size_t)ERR_WORDS));
-    PADNE_HIP_CHECK(hipMemcpyAsync(d_map, map_host, sizeof(int) * (size_t)m->n_rows, hipMemcpyHostToDevice, s));
-    PADNE_HIP_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(int) * (size_t)(n_out + 1), s));
+    PADNE_HIP_CHECK(hipMemcpyAsync(d_map, row_map_host, sizeof(int) * (size_t)m->n_rows, hipMemcpyHostToDevice, s));
+    if (col_map_host == row_map_host) {
+        d_cmap = d_map;
+    } else {
+        PADNE_TRY(sc.alloc(&d_cmap, (size_t)m->n_cols));
+        PADNE_HIP_CHECK(hipMemcpyAsync(d_cmap, col_map_host, sizeof(int) * (size_t)m->n_cols, hipMemcpyHostToDevice, s));
+    }
+    PADNE_HIP_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(int) * (size_t)(n_rows_out + 1), s));
     PADNE_HIP_CHECK(hipMemsetAsync(d_err, 0, sizeof(int) * ERR_WORDS, s));
     if (m->n_rows > 0)
         hipLaunchKernelGGL(reduce_count, dim3(nblk(m->n_rows)), dim3(256), 0, s, (long long)m->n_rows, m->rowptr,
-                           m->cols, d_map, d_cnt);
+                           m->cols, d_map, d_cmap, d_cnt);
     PADNE_HIP_CHECK(hipGetLastError());
     int64_t n_slots = 0;
-    PADNE_TRY(exclusive_scan_i32(ctx, d_cnt, d_slot, n_out, &n_slots));
+    PADNE_TRY(exclusive_scan_i32(ctx, d_cnt, d_slot, n_rows_out, &n_slots));
     long long *d_key = nullptr;
     double *d_val = nullptr;
     PADNE_TRY(sc.alloc(&d_key, (size_t)n_slots));
     PADNE_TRY(sc.alloc(&d_val, (size_t)n_slots));
-    PADNE_HIP_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(int) * (size_t)(n_out + 1), s));
+    PADNE_HIP_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(int) * (size_t)(n_rows_out + 1), s));
     if (m->n_rows > 0)
         hipLaunchKernelGGL(reduce_fill, dim3(nblk(m->n_rows)), dim3(256), 0, s, (long long)m->n_rows, m->rowptr, m->cols,
-                           m->vals, d_map, scale, d_slot, d_cnt, d_key, d_val);
+                           m->vals, d_map, d_cmap, scale, d_slot, d_cnt, d_key, d_val);
     PADNE_HIP_CHECK(hipGetLastError());
-    return finish_rows<false>(ctx, sc, n_out, n_out, 0, 0, nullptr, nullptr, d_slot, d_key, d_val, d_err, out);
+    return finish_rows<false>(ctx, sc, n_rows_out, n_cols_out, 0, 0, nullptr, nullptr, d_slot, d_key, d_val, d_err, out);
+}
+
+extern "C" int padne_csr_relabel(padne_ctx *ctx, const padne_csr *m, const int32_t *row_map_host, int64_t n_rows_out,
+                                 const int32_t *col_map_host, int64_t n_cols_out, double scale, padne_csr **out) {
+    PADNE_REQUIRE(ctx && m && row_map_host && col_map_host && out, "null argument");
+    return csr_relabel(ctx, m, row_map_host, n_rows_out, col_map_host, n_cols_out, scale, out);
+}
+
+// rows of `top` followed by the rows of `bottom` (same number of columns)
+__global__ void vstack_shift(int n, const int *__restrict__ src, int shift, int *__restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i] + shift;
+}
+
+namespace padne {
+int csr_vstack(padne_ctx *ctx, const padne_csr *top, const padne_csr *bottom, int64_t n_cols, padne_csr **out) {
+    PADNE_REQUIRE(top->n_cols <= n_cols && bottom->n_cols <= n_cols, "column count");
+    PADNE_REQUIRE(top->nnz + bottom->nnz < 2147483647LL, "too many entries");
+    hipStream_t s = ctx->stream;
+    padne_csr *m = nullptr;
+    PADNE_TRY(csr_alloc(ctx, top->n_rows + bottom->n_rows, n_cols, top->nnz + bottom->nnz, &m));
+    hipError_t e = hipMemcpyAsync(m->rowptr, top->rowptr, sizeof(int) * (size_t)(top->n_rows + 1), hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(vstack_shift, dim3(nblk(bottom->n_rows + 1)), dim3(256), 0, s, (int)bottom->n_rows + 1,
+                           bottom->rowptr, (int)top->nnz, m->rowptr + top->n_rows);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && top->nnz > 0) {
+        e = hipMemcpyAsync(m->cols, top->cols, sizeof(int) * (size_t)top->nnz, hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(m->vals, top->vals, sizeof(double) * (size_t)top->nnz, hipMemcpyDeviceToDevice, s);
+    }
+    if (e == hipSuccess && bottom->nnz > 0) {
+        e = hipMemcpyAsync(m->cols + top->nnz, bottom->cols, sizeof(int) * (size_t)bottom->nnz, hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(m->vals + top->nnz, bottom->vals, sizeof(double) * (size_t)bottom->nnz, hipMemcpyDeviceToDevice, s);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        set_error("vstack failed: %s", hipGetErrorString(e));
+        padne_csr_destroy(m);
+        return PADNE_E_HIP;
+    }
+    *out = m;
+    return PADNE_OK;
+}
+}  // namespace padne
+
+extern "C" int padne_csr_vstack(padne_ctx *ctx, const padne_csr *top, const padne_csr *bottom, padne_csr **out) {
+    PADNE_REQUIRE(ctx && top && bottom && out, "null argument");
+    PADNE_REQUIRE(top->n_cols == bottom->n_cols, "column counts differ");
+    PADNE_HIP_CHECK(hipSetDevice(ctx->device));
+    return csr_vstack(ctx, top, bottom, top->n_cols, out);
+}
+
+extern "C" int padne_csr_reduce(padne_ctx *ctx, const padne_csr *m, const int32_t *map_host, int64_t n_out,
+                                double scale, padne_csr **out) {
+    PADNE_REQUIRE(ctx && m && map_host && out, "null argument");
+    PADNE_REQUIRE(m->n_rows == m->n_cols, "matrix must be square");
+    return csr_relabel(ctx, m, map_host, n_out, map_host, n_out, scale, out);
 }
 
 static int face_fields(padne_ctx *ctx, int64_t n_vert, const double *xy_host, int64_t n_tri,

@@ -116,10 +116,22 @@ int comm_allreduce_sum_f64(padne_ctx *ctx, double *dev_buf, int count);
 int comm_allgather_f64(padne_ctx *ctx, const double *send, double *recv, int count_per_rank);
 void comm_destroy(padne_ctx *ctx);
 
+// exchange plan of a row-partitioned operator: vectors are [n_owned | world * m exchanged values]; every
+// rank packs its n_export (<= m) exported owned entries into its segment and one all-gather fills the rest
+struct HaloPlan {
+    long long n_owned = 0;
+    int m = 0, n_export = 0;
+    const int32_t *export_idx = nullptr;   // device
+};
+int halo_exchange_plan(padne_ctx *ctx, const HaloPlan &plan, double *v, const int32_t *done_flag);
+
 // amg.hip
 void amg_destroy(void *amg);
-// pcg.hip: largest eigenvalue of D^-1 A from `steps` Lanczos (Jacobi-PCG) steps
-int estimate_lambda_max(padne_ctx *ctx, const padne_csr *a, int steps, double *lambda);
+// pcg.hip: largest eigenvalue of D^-1 A from `steps` Lanczos (Jacobi-PCG) steps; with a plan the matrix is
+// this rank's rows of a row-partitioned operator and the estimate (identical on all ranks) is the global one
+int estimate_lambda_max(padne_ctx *ctx, const padne_csr *a, int steps, double *lambda, const HaloPlan *plan = nullptr);
+// assemble.hip: rows of `top` followed by the rows of `bottom`, n_cols columns
+int csr_vstack(padne_ctx *ctx, const padne_csr *top, const padne_csr *bottom, int64_t n_cols, padne_csr **out);
 
 // Per-context caching allocator.  All work of a context is ordered on its one stream, so a block handed back
 // may be reused by later launches without synchronisation.  Blocks are kept (up to kPoolCacheLimit) until the

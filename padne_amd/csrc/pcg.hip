@@ -281,16 +281,25 @@ __global__ void halo_pack_kernel(double *__restrict__ v, const int *__restrict__
 // scalar slots inside ctx->scalars used when the reductions go through RCCL
 enum { S_RR = 0, S_BB = 1, S_TRUE = 2, S_PQ = 8, S_RZRR0 = 10, S_RZRR1 = 12 };
 
-static int halo_exchange(padne_ctx *ctx, double *v, const int32_t *done_flag) {
-    if (!ctx->halo_on) return PADNE_OK;
-    double *seg = v + ctx->halo_n_owned + (long long)ctx->rank * ctx->halo_m;
-    if (ctx->halo_n_export > 0) {
-        hipLaunchKernelGGL(halo_pack_kernel, dim3((ctx->halo_n_export + 255) / 256), dim3(256), 0, ctx->stream, v,
-                           ctx->halo_export, ctx->halo_n_export,
-                           (long long)ctx->halo_n_owned + (long long)ctx->rank * ctx->halo_m, done_flag);
+int halo_exchange_plan(padne_ctx *ctx, const HaloPlan &plan, double *v, const int32_t *done_flag) {
+    if (plan.m <= 0) return PADNE_OK;
+    const long long seg_off = plan.n_owned + (long long)ctx->rank * plan.m;
+    if (plan.n_export > 0) {
+        hipLaunchKernelGGL(halo_pack_kernel, dim3((plan.n_export + 255) / 256), dim3(256), 0, ctx->stream, v,
+                           plan.export_idx, plan.n_export, seg_off, done_flag);
         PADNE_HIP_CHECK(hipGetLastError());
     }
-    return comm_allgather_f64(ctx, seg, v + ctx->halo_n_owned, ctx->halo_m);
+    return comm_allgather_f64(ctx, v + seg_off, v + plan.n_owned, plan.m);
+}
+
+static int halo_exchange(padne_ctx *ctx, double *v, const int32_t *done_flag) {
+    if (!ctx->halo_on) return PADNE_OK;
+    HaloPlan plan;
+    plan.n_owned = ctx->halo_n_owned;
+    plan.m = ctx->halo_m;
+    plan.n_export = ctx->halo_n_export;
+    plan.export_idx = ctx->halo_export;
+    return halo_exchange_plan(ctx, plan, v, done_flag);
 }
 
 int amg_setup(padne_ctx *ctx, padne_csr *A0);
@@ -318,7 +327,9 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
     } else {
         PADNE_REQUIRE(nr == nc, "matrix must be square");
     }
-    if (amg) PADNE_REQUIRE(prec->n_rows == n && prec->n_cols == n, "preconditioner block must be owned x owned");
+    if (amg)
+        PADNE_REQUIRE(prec->n_rows == n && (prec->n_cols == n || prec == a),
+                      "preconditioner must be the matrix itself or its owned x owned block");
     PADNE_TRY(ensure_workspace(ctx, sizeof(double) * (size_t)(2 * n + 2 * nc + nr) + 4096));
     double *r = (double *)ctx->ws;
     double *z = r + n;          // [n]   multigrid output
@@ -560,41 +571,62 @@ static double tridiag_max_eig(const std::vector<double> &d, const std::vector<do
     return 0.5 * (lo + hi);
 }
 
-int estimate_lambda_max(padne_ctx *ctx, const padne_csr *a, int steps, double *lambda) {
-    const long long n = a->n_rows;
+int estimate_lambda_max(padne_ctx *ctx, const padne_csr *a, int steps, double *lambda, const HaloPlan *plan) {
+    const bool dist = plan != nullptr;
+    const long long n = dist ? plan->n_owned : a->n_rows;   // owned unknowns
+    const long long nc = dist ? a->n_cols : n;              // length of the vector the matrix multiplies
+    const long long nr = a->n_rows;
+    PADNE_REQUIRE(nr >= n && nc >= n, "operator shape");
     PADNE_TRY(csr_build_dinv(ctx, const_cast<padne_csr *>(a)));
-    PADNE_TRY(ensure_workspace(ctx, sizeof(double) * (size_t)n * 5 + 4096));
-    double *r = (double *)ctx->ws, *p = r + n, *q = p + n, *x = q + n, *b = x + n;
+    PADNE_TRY(ensure_workspace(ctx, sizeof(double) * (size_t)(3 * n + nc + nr) + 4096));
+    double *r = (double *)ctx->ws, *x = r + n, *b = x + n, *p = b + n, *q = p + nc;
     PcgStatus *st = (PcgStatus *)ctx->status;
     hipStream_t s = ctx->stream;
     const int gv = vec_grid(n), gs = spmv_grid(a);
-    double *scal = ctx->scalars + 32;
+    double *scal = ctx->scalars + 32;     // [0] pq  [2..3] {rz, rr} even  [4..5] {rz, rr} odd
     double *h = (double *)ctx->pinned + 64;
     PADNE_HIP_CHECK(hipMemsetAsync(st, 0, sizeof(PcgStatus), s));
     PADNE_HIP_CHECK(hipMemsetAsync(x, 0, sizeof(double) * (size_t)n, s));
+    if (nc > n) PADNE_HIP_CHECK(hipMemsetAsync(p + n, 0, sizeof(double) * (size_t)(nc - n), s));
     hipLaunchKernelGGL(fill_pseudo_random, dim3(gv), dim3(256), 0, s, n, b);
     hipLaunchKernelGGL(pcg_init_kernel, dim3(gv), dim3(256), 0, s, n, b, (const double *)nullptr, a->dinv, r, p,
                        slot(ctx, SLOT_RZ0), slot(ctx, SLOT_RR), slot(ctx, SLOT_BB));
     PADNE_HIP_CHECK(hipGetLastError());
+    auto fold = [&](const double *first_slot, int P, double *out) -> int {
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(256), 0, s, first_slot, P, kMaxPartials, 1, out);
+        PADNE_HIP_CHECK(hipGetLastError());
+        return PADNE_OK;
+    };
+    PADNE_TRY(fold(slot(ctx, SLOT_RZ0), gv, scal + 2));
+    if (dist) PADNE_TRY(comm_allreduce_sum_f64(ctx, scal + 2, 1));
     std::vector<double> alpha, beta;
     int parity = 0;
     for (int k = 0; k < steps; ++k) {
-        double *rz_old = slot(ctx, parity ? SLOT_RZ1 : SLOT_RZ0);
-        double *rz_new = slot(ctx, parity ? SLOT_RZ0 : SLOT_RZ1);
+        double *rz_old_part = slot(ctx, parity ? SLOT_RZ1 : SLOT_RZ0);
+        double *rz_new_part = slot(ctx, parity ? SLOT_RZ0 : SLOT_RZ1);
+        double *s_old = scal + (parity ? 4 : 2), *s_new = scal + (parity ? 2 : 4);
+        if (dist) PADNE_TRY(halo_exchange_plan(ctx, *plan, p, nullptr));
         PADNE_TRY(launch_spmv(ctx, a, p, q, p, slot(ctx, SLOT_PQ), nullptr));
-        hipLaunchKernelGGL(pcg_update_xr_kernel, dim3(gv), dim3(256), 0, s, n, rz_old, gv, slot(ctx, SLOT_PQ), gs, p, q,
-                           a->dinv, x, r, rz_new, slot(ctx, SLOT_RR), st);
-        hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(256), 0, s, slot(ctx, SLOT_PQ), gs, kMaxPartials, 1, scal);
-        hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(256), 0, s, rz_old, gv, kMaxPartials, 1, scal + 1);
-        hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(256), 0, s, rz_new, gv, kMaxPartials, 1, scal + 2);
-        hipLaunchKernelGGL(pcg_update_p_kernel, dim3(gv), dim3(256), 0, s, n, rz_new, rz_old, gv, slot(ctx, SLOT_RR), gv,
-                           slot(ctx, SLOT_PQ), gs, r, a->dinv, p, st, 1 << 30);
+        PADNE_TRY(fold(slot(ctx, SLOT_PQ), gs, scal));
+        if (dist) PADNE_TRY(comm_allreduce_sum_f64(ctx, scal, 1));
+        // consumers read per-workgroup partials on one GPU and the reduced scalars across ranks
+        const double *rz_old = dist ? s_old : rz_old_part, *pq = dist ? scal : slot(ctx, SLOT_PQ);
+        const int Pz = dist ? 1 : gv, Pq = dist ? 1 : gs;
+        hipLaunchKernelGGL(pcg_update_xr_kernel, dim3(gv), dim3(256), 0, s, n, rz_old, Pz, pq, Pq, p, q, a->dinv, x, r,
+                           rz_new_part, slot(ctx, SLOT_RR), st);
         PADNE_HIP_CHECK(hipGetLastError());
-        PADNE_HIP_CHECK(hipMemcpyAsync(h, scal, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+        PADNE_TRY(fold(rz_new_part, gv, s_new));
+        PADNE_TRY(fold(slot(ctx, SLOT_RR), gv, s_new + 1));
+        if (dist) PADNE_TRY(comm_allreduce_sum_f64(ctx, s_new, 2));
+        const double *rz_new = dist ? s_new : rz_new_part, *rr = dist ? s_new + 1 : slot(ctx, SLOT_RR);
+        hipLaunchKernelGGL(pcg_update_p_kernel, dim3(gv), dim3(256), 0, s, n, rz_new, rz_old, Pz, rr, Pz, pq, Pq, r,
+                           a->dinv, p, st, 1 << 30);
+        PADNE_HIP_CHECK(hipGetLastError());
+        PADNE_HIP_CHECK(hipMemcpyAsync(h, scal, 6 * sizeof(double), hipMemcpyDeviceToHost, s));
         PADNE_HIP_CHECK(hipStreamSynchronize(s));
-        const double pq = h[0], rzo = h[1], rzn = h[2];
-        if (!(pq > 0.0) || !(rzo > 0.0)) break;
-        alpha.push_back(rzo / pq);
+        const double pqv = h[0], rzo = h[parity ? 4 : 2], rzn = h[parity ? 2 : 4];
+        if (!(pqv > 0.0) || !(rzo > 0.0)) break;
+        alpha.push_back(rzo / pqv);
         beta.push_back(rzn / rzo);
         if (!(rzn > 0.0) || rzn < 1e-30 * rzo) break;
         parity ^= 1;
@@ -700,16 +732,18 @@ extern "C" int padne_solve_spd_dev(padne_ctx *ctx, const padne_csr *a, const voi
     padne_solve_info local;
     memset(&local, 0, sizeof(local));
     local.n_rhs = n_rhs;
-    // multigrid: single GPU, and only where there is something to coarsen
-    // multigrid: on the matrix itself, or on the rank's diagonal block attached with
-    // padne_csr_set_preconditioner_block (row-partitioned runs); small systems stay with Jacobi
+    // multigrid: on the matrix itself (one GPU: square; row-partitioned: this rank's rows of one global
+    // hierarchy, see amg.hip), or block-Jacobi on the rank's diagonal block when one is attached with
+    // padne_csr_set_preconditioner_block; small single-GPU systems stay with Jacobi
     padne_csr *pm = a->prec_block ? a->prec_block : const_cast<padne_csr *>(a);
     const long long n_owned = ctx->halo_on ? ctx->halo_n_owned : a->n_rows;
-    PADNE_REQUIRE(!(opts->precond == 1 && ctx->halo_on && a->prec_block == nullptr),
-                  "multigrid on a row-partitioned matrix needs padne_csr_set_preconditioner_block");
-    bool use_amg = opts->precond == 1 && n_owned > 1024;
+    const bool global_hierarchy = ctx->halo_on && a->prec_block == nullptr;
+    PADNE_REQUIRE(!(opts->precond == 1 && global_hierarchy && a->n_rows != n_owned),
+                  "row-partitioned multigrid needs a matrix with exactly the owned rows");
+    bool use_amg = opts->precond == 1 && (global_hierarchy || n_owned > 1024);
     if (use_amg) {
-        PADNE_REQUIRE(pm->n_rows == n_owned && pm->n_cols == n_owned, "preconditioner block must be owned x owned");
+        PADNE_REQUIRE(pm->n_rows == n_owned && (global_hierarchy || pm->n_cols == n_owned),
+                      "preconditioner block must be owned x owned");
         const bool fresh = pm->amg == nullptr || (opts->flags & 4) != 0;
         if (fresh && pm->amg) {
             amg_destroy(pm->amg);

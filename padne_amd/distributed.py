@@ -138,9 +138,13 @@ def reduced_local_map(plan: RankPlan):
 class DistributedSolver:
     """Per-rank driver: local assembly, reduction, halo plan, RCCL communicator, solve."""
 
-    def __init__(self, ctx, plan: RankPlan, dist=None, team=None):
+    def __init__(self, ctx, plan: RankPlan, dist=None, team=None, block_preconditioner: bool = False):
         """``dist``: an initialised ``torch.distributed`` module (one process per GPU, RCCL), or ``team``: a
-        ``_hip.LocalTeam`` whose members are contexts of this process (single-GPU rehearsal, one thread per rank)."""
+        ``_hip.LocalTeam`` whose members are contexts of this process (single-GPU rehearsal, one thread per rank).
+
+        The multigrid preconditioner is one hierarchy over all ranks (aggregates stay inside a rank; every level
+        has its own exchange plan).  ``block_preconditioner=True`` selects block-Jacobi instead: one V-cycle of
+        each rank's own diagonal block with no communication inside the cycle (3-6x more CG iterations)."""
         self.ctx, self.plan = ctx, plan
         if team is not None:
             team.join(ctx, plan.rank)
@@ -167,13 +171,15 @@ class DistributedSolver:
         self.t_assemble = time.perf_counter() - t0
         imap, n_owned, export_red = reduced_local_map(plan)
         t0 = time.perf_counter()
-        self.A = L.reduce(imap, n_owned + plan.world * plan.m, -1.0)
-        # owned x owned diagonal block (couplings to other ranks dropped): the multigrid preconditioner is
-        # built on it, i.e. block-Jacobi across ranks with one V-cycle per block and no communication inside
-        bmap = imap.copy()
-        bmap[plan.n_owned_vertices:] = -1
-        self.A_block = L.reduce(bmap, n_owned, -1.0)
-        self.A.set_preconditioner_block(self.A_block)
+        # this rank's rows of A = -L_vv: owned rows x [owned | world * m exchange slots]
+        rmap = imap.copy()
+        rmap[plan.n_owned_vertices:] = -1
+        self.A = L.relabel(rmap, n_owned, imap, n_owned + plan.world * plan.m, -1.0)
+        self.A_block = None
+        if block_preconditioner:
+            # owned x owned diagonal block (couplings to other ranks dropped)
+            self.A_block = L.reduce(rmap, n_owned, -1.0)
+            self.A.set_preconditioner_block(self.A_block)
         ctx.synchronize()
         self.t_reduce = time.perf_counter() - t0
         L.close()

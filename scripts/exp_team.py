@@ -1,0 +1,24 @@
+"""Iteration counts of the layer-partitioned solver at world = 1..8 on ONE GPU (in-process team)."""
+import os, sys, threading, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from padne_amd import _hip, distributed, synthetic
+
+block = "--block" in sys.argv
+sys.argv = [a for a in sys.argv if a != "--block"]
+name = sys.argv[1] if len(sys.argv) > 1 else "C4"
+sysm = synthetic.config(name)
+for world in [int(w) for w in (sys.argv[2:] or ["2", "4", "8"])]:
+    team = _hip.LocalTeam(world)
+    out = [None] * world
+    def rank_main(rank):
+        c = _hip.Context(0)
+        plan = distributed.build_layer_partition(sysm, rank, world)
+        ds = distributed.DistributedSolver(c, plan, team=team, block_preconditioner=block)
+        t = time.perf_counter(); res = ds.solve(rtol=1e-12, precond="amg"); w = time.perf_counter() - t
+        out[rank] = (res, w, plan.m)
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    [t.start() for t in th]; [t.join() for t in th]
+    res, w, m = out[0]
+    print(f"[{name}] world={world}: {'block' if block else 'global'}-AMG iterations={res.iterations} levels={res.levels} relres={res.rel_residual:.2e} "
+          f"halo m={m} (shared-GPU wall {w*1e3:.0f} ms, not a timing)", flush=True)
