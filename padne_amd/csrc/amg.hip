@@ -1272,6 +1272,37 @@ __global__ void compact_pieces(int world, int n_pad, const int *__restrict__ seg
         dst[seg_off[q] + i] = src[(size_t)q * n_pad + i];
 }
 
+// this rank's piece of the gather level as one record of doubles: rowptr[n_pad + 1] | cols[nnz_max] (already in
+// gathered numbering) | vals[nnz_max]
+__global__ void tail_pack(int n, int nnz, const int *__restrict__ rowptr, const int *__restrict__ cols,
+                          const double *__restrict__ vals, int my_off, const int *__restrict__ slot_to_global,
+                          long long o_cols, long long o_vals, double *__restrict__ rec) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t <= n) rec[t] = (double)rowptr[t];
+    if (t < nnz) {
+        const int j = cols[t];
+        rec[o_cols + t] = (double)(j < n ? my_off + j : slot_to_global[j - n]);
+        rec[o_vals + t] = vals[t];
+    }
+}
+
+// records of all ranks -> one CSR matrix, rows in rank order
+__global__ void tail_unpack(const double *__restrict__ recs, long long rec_len, long long o_cols, long long o_vals,
+                            const int *__restrict__ seg_off, const int *__restrict__ nnz_off, int *__restrict__ rowptr,
+                            int *__restrict__ cols, double *__restrict__ vals) {
+    const int q = blockIdx.y;
+    const double *rec = recs + (size_t)q * rec_len;
+    const int nq = seg_off[q + 1] - seg_off[q], zq = nnz_off[q + 1] - nnz_off[q];
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nq || t < zq; t += gridDim.x * blockDim.x) {
+        if (t < nq) rowptr[seg_off[q] + t] = nnz_off[q] + (int)rec[t];
+        if (t < zq) {
+            cols[nnz_off[q] + t] = (int)rec[o_cols + t];
+            vals[nnz_off[q] + t] = rec[o_vals + t];
+        }
+    }
+    if (q == gridDim.y - 1 && blockIdx.x == 0 && threadIdx.x == 0) rowptr[seg_off[q + 1]] = nnz_off[q + 1];
+}
+
 // Gather the last row-partitioned level to every rank (rows in rank order) and build an ordinary hierarchy
 // on it: the small levels are cheaper to run redundantly than to exchange, and their aggregates may then
 // cross rank boundaries, which matters once the couplings between ranks dominate a coarse operator.
@@ -1280,69 +1311,54 @@ static int gather_tail(padne_ctx *ctx, Amg *amg) {
     const int W = ctx->world, m = L.halo.m, n = (int)L.n;
     hipStream_t s = ctx->stream;
     const padne_csr *A = L.A;
-    std::vector<int> rp((size_t)n + 1), cl((size_t)A->nnz);
-    std::vector<double> vl((size_t)A->nnz);
-    PADNE_HIP_CHECK(hipMemcpyAsync(rp.data(), A->rowptr, sizeof(int) * rp.size(), hipMemcpyDeviceToHost, s));
-    if (A->nnz > 0) {
-        PADNE_HIP_CHECK(hipMemcpyAsync(cl.data(), A->cols, sizeof(int) * cl.size(), hipMemcpyDeviceToHost, s));
-        PADNE_HIP_CHECK(hipMemcpyAsync(vl.data(), A->vals, sizeof(double) * vl.size(), hipMemcpyDeviceToHost, s));
-    }
-    PADNE_HIP_CHECK(hipStreamSynchronize(s));
     std::vector<double> head = {(double)n, (double)A->nnz, (double)L.halo.n_export}, heads;
     PADNE_TRY(host_allgather(ctx, head, heads));
     int n_pad = 1;
-    long long nnz_max = 0, nnz_sum = 0;
-    std::vector<int> off((size_t)W + 1, 0);
+    long long nnz_max = 1;
+    std::vector<int> off((size_t)W + 1, 0), zoff((size_t)W + 1, 0);
     for (int q = 0; q < W; ++q) {
         n_pad = std::max(n_pad, (int)heads[(size_t)q * 3]);
         nnz_max = std::max(nnz_max, (long long)heads[(size_t)q * 3 + 1]);
-        nnz_sum += (long long)heads[(size_t)q * 3 + 1];
         off[(size_t)q + 1] = off[(size_t)q] + (int)heads[(size_t)q * 3];
+        PADNE_REQUIRE((long long)zoff[(size_t)q] + (long long)heads[(size_t)q * 3 + 1] < 2147483647LL,
+                      "gathered operator too large");
+        zoff[(size_t)q + 1] = zoff[(size_t)q] + (int)heads[(size_t)q * 3 + 1];
     }
-    const long long N = off[(size_t)W];
-    PADNE_REQUIRE(nnz_sum < 2147483647LL, "gathered operator too large");
-    // record: rowptr[n_pad + 1] | cols[nnz_max] | vals[nnz_max] | export[m]
-    const size_t o_cols = (size_t)n_pad + 1, o_vals = o_cols + (size_t)nnz_max, o_exp = o_vals + (size_t)nnz_max;
-    std::vector<double> rec(o_exp + (size_t)m, 0.0), recs;
-    for (int i = 0; i <= n; ++i) rec[(size_t)i] = (double)rp[(size_t)i];
-    for (long long k = 0; k < A->nnz; ++k) {
-        rec[o_cols + (size_t)k] = (double)cl[(size_t)k];
-        rec[o_vals + (size_t)k] = vl[(size_t)k];
+    const long long N = off[(size_t)W], nnz_sum = zoff[(size_t)W];
+    // where every exchange slot lives in the gathered numbering
+    std::vector<double> ex((size_t)m, 0.0), exs;
+    for (int e = 0; e < L.halo.n_export; ++e) ex[(size_t)e] = (double)L.export_host[(size_t)e];
+    PADNE_TRY(host_allgather(ctx, ex, exs));
+    std::vector<int> slot_to_global((size_t)W * m + 1, 0);
+    for (int p = 0; p < W; ++p)
+        for (int e = 0; e < m; ++e) slot_to_global[(size_t)p * m + e] = off[(size_t)p] + (int)exs[(size_t)p * m + e];
+    const long long o_cols = (long long)n_pad + 1, o_vals = o_cols + nnz_max, rec_len = o_vals + nnz_max;
+    PADNE_REQUIRE(rec_len < (1LL << 30), "gather record too large");
+    {
+        Scratch sc(ctx);
+        int *d_s2g = nullptr, *d_off = nullptr, *d_zoff = nullptr;
+        double *recs = nullptr;
+        PADNE_TRY(sc.alloc(&d_s2g, slot_to_global.size()));
+        PADNE_TRY(sc.alloc(&d_off, (size_t)W + 1));
+        PADNE_TRY(sc.alloc(&d_zoff, (size_t)W + 1));
+        PADNE_TRY(sc.alloc(&recs, (size_t)rec_len * W));
+        PADNE_HIP_CHECK(hipMemcpyAsync(d_s2g, slot_to_global.data(), sizeof(int) * slot_to_global.size(),
+                                       hipMemcpyHostToDevice, s));
+        PADNE_HIP_CHECK(hipMemcpyAsync(d_off, off.data(), sizeof(int) * ((size_t)W + 1), hipMemcpyHostToDevice, s));
+        PADNE_HIP_CHECK(hipMemcpyAsync(d_zoff, zoff.data(), sizeof(int) * ((size_t)W + 1), hipMemcpyHostToDevice, s));
+        double *mine = recs + (size_t)ctx->rank * rec_len;
+        const long long work = std::max<long long>((long long)n + 1, A->nnz);
+        hipLaunchKernelGGL(tail_pack, dim3(nblk(work)), dim3(256), 0, s, n, (int)A->nnz, A->rowptr, A->cols, A->vals,
+                           off[(size_t)ctx->rank], d_s2g, o_cols, o_vals, mine);
+        PADNE_HIP_CHECK(hipGetLastError());
+        if (W > 1) PADNE_TRY(comm_allgather_f64(ctx, mine, recs, (int)rec_len));
+        PADNE_TRY(csr_alloc(ctx, N, N, nnz_sum, &amg->tail));
+        const long long per_rank = std::max<long long>(n_pad, nnz_max);
+        hipLaunchKernelGGL(tail_unpack, dim3((unsigned)std::min<long long>(nblk(per_rank), 4096), W), dim3(256), 0, s, recs,
+                           rec_len, o_cols, o_vals, d_off, d_zoff, amg->tail->rowptr, amg->tail->cols, amg->tail->vals);
+        PADNE_HIP_CHECK(hipGetLastError());
+        PADNE_HIP_CHECK(hipStreamSynchronize(s));   // the staging arrays go back to the pool
     }
-    for (int e = 0; e < L.halo.n_export; ++e) rec[o_exp + (size_t)e] = (double)L.export_host[(size_t)e];
-    PADNE_TRY(host_allgather(ctx, rec, recs));
-    std::vector<int> grp((size_t)N + 1, 0), gcl;
-    std::vector<double> gvl;
-    gcl.reserve((size_t)nnz_sum);
-    gvl.reserve((size_t)nnz_sum);
-    std::vector<std::pair<int, double>> row;
-    for (int q = 0; q < W; ++q) {
-        const double *r = recs.data() + (size_t)q * rec.size();
-        const int nq = (int)heads[(size_t)q * 3];
-        for (int i = 0; i < nq; ++i) {
-            row.clear();
-            for (int k = (int)r[i]; k < (int)r[i + 1]; ++k) {
-                const int j = (int)r[o_cols + (size_t)k];
-                int col;
-                if (j < nq) {
-                    col = off[(size_t)q] + j;
-                } else {
-                    const int slot = j - nq, p = slot / m, e = slot % m;
-                    col = off[(size_t)p] + (int)recs[(size_t)p * rec.size() + o_exp + (size_t)e];
-                }
-                row.emplace_back(col, r[o_vals + (size_t)k]);
-            }
-            std::sort(row.begin(), row.end(), [](const std::pair<int, double> &x, const std::pair<int, double> &y) {
-                return x.first < y.first;
-            });
-            for (const auto &cv : row) {
-                gcl.push_back(cv.first);
-                gvl.push_back(cv.second);
-            }
-            grp[(size_t)off[(size_t)q] + i + 1] = (int)gcl.size();
-        }
-    }
-    PADNE_TRY(upload_csr(ctx, N, N, grp, gcl, gvl, &amg->tail));
     amg->tail->hierarchy_operator = true;
     PADNE_TRY(amg_setup(ctx, amg->tail));
     amg->n_pad = n_pad;
@@ -1436,6 +1452,7 @@ static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0) {
                       ? PADNE_OK : PADNE_E_HIP) != PADNE_OK) break;
         if (coarsest) break;
         // aggregates and prolongator from the rank's own block
+        PhaseTimer pt(ctx, amg_verbose() && ctx->rank == 0);
         padne_csr *blk = nullptr;
         if ((rc = owned_block(ctx, A, Lr.n, &blk)) != PADNE_OK) break;
         Scratch sc(ctx);
@@ -1464,10 +1481,12 @@ static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0) {
             break;
         }
         if (lambda_g < lambda_f) lambda_f = lambda_g;
+        pt.lap("block+aggregate");
         rc = build_prolongator(ctx, blk, agg, n_agg, 4.0 / (3.0 * lambda_f), &Lr.P);
         padne_csr_destroy(blk);
         if (rc != PADNE_OK) break;
         if ((rc = transpose(ctx, Lr.P, &Lr.R)) != PADNE_OK) break;
+        pt.lap("prolongator+transpose");
         padne_csr *P_halo = nullptr, *P_ext = nullptr, *AP = nullptr, *Ac = nullptr;
         std::vector<int> export_c;
         int m_c = 0;
@@ -1475,6 +1494,7 @@ static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0) {
         rc = csr_vstack(ctx, Lr.P, P_halo, (long long)n_agg + (long long)W * m_c, &P_ext);
         padne_csr_destroy(P_halo);
         if (rc != PADNE_OK) break;
+        pt.lap("exchange P rows");
         rc = spgemm(ctx, A, P_ext, &AP);
         padne_csr_destroy(P_ext);
         if (rc != PADNE_OK) break;
@@ -1482,6 +1502,7 @@ static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0) {
         padne_csr_destroy(AP);
         if (rc != PADNE_OK) break;
         if ((rc = csr_build_dinv(ctx, Ac)) != PADNE_OK) { padne_csr_destroy(Ac); break; }
+        pt.lap("galerkin");
         Ac->hierarchy_operator = true;
         Lr.P->hierarchy_operator = true;
         Lr.R->hierarchy_operator = true;
@@ -1507,7 +1528,9 @@ static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0) {
             rc = PADNE_E_INVALID;
             set_error("multigrid setup did not reach a coarsest level");
         } else {
+            PhaseTimer pg(ctx, amg_verbose() && ctx->rank == 0);
             rc = gather_tail(ctx, amg);
+            pg.lap("gather + tail hierarchy");
         }
     }
     if (rc != PADNE_OK) {

@@ -21,4 +21,4 @@ for world in [int(w) for w in (sys.argv[2:] or ["2", "4", "8"])]:
     [t.start() for t in th]; [t.join() for t in th]
     res, w, m = out[0]
     print(f"[{name}] world={world}: {'block' if block else 'global'}-AMG iterations={res.iterations} levels={res.levels} relres={res.rel_residual:.2e} "
-          f"halo m={m} (shared-GPU wall {w*1e3:.0f} ms, not a timing)", flush=True)
+          f"halo m={m} setup {res.setup_seconds*1e3:.0f} ms solve {res.seconds*1e3:.0f} ms (shared-GPU wall {w*1e3:.0f} ms, not a timing)", flush=True)

@@ -514,6 +514,62 @@ __global__ __launch_bounds__(256) void stream_ref(long long nnz4, const int4 *__
     if (s == 12345.678) y[0] = s;
 }
 
+// ---- V12: wave-private tiles, cols/vals parked in LDS, then ONE LANE PER ROW gathers x: adjacent lanes hold
+// adjacent rows, whose k-th neighbours are adjacent entries of x, so a gather instruction touches a few
+// contiguous runs instead of 64 scattered addresses ----
+template <int EPL, int U>
+__global__ __launch_bounds__(256) void spmv_wave_rg(int n_rows, int n_wtiles, const int *__restrict__ rowptr,
+                                                    const int *__restrict__ cols, const double *__restrict__ vals,
+                                                    const double *__restrict__ x, double *__restrict__ y) {
+    constexpr int CH = 64 * EPL;
+    __shared__ double vs_all[4 * CH];
+    __shared__ int cs_all[4 * CH];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double *vs = vs_all + w * CH;
+    int *cs = cs_all + w * CH;
+    const int G = gridDim.x;
+    const int xcd = blockIdx.x % NXCD;
+    const int wx = (blockIdx.x / NXCD) * 4 + w;
+    const int wpx = (G / NXCD) * 4;
+    const int s0 = (int)((long long)xcd * n_wtiles / NXCD), s1 = (int)((long long)(xcd + 1) * n_wtiles / NXCD);
+    for (int wt = s0 + wx; wt < s1; wt += wpx) {
+        const int row0 = wt * 64;
+        const int row1 = min(row0 + 64, n_rows);
+        const int r = row0 + lane;
+        int rs = 0, re = 0;
+        if (r < row1) { rs = rowptr[r]; re = rowptr[r + 1]; }
+        const int k0 = __shfl(rs, 0, 64);
+        const int k1 = __shfl(re, row1 - row0 - 1, 64);
+        double acc = 0.0;
+        for (int base = k0; base < k1; base += CH) {
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const int e = base + lane + 64 * j;
+                if (e < k1) { cs[lane + 64 * j] = cols[e]; vs[lane + 64 * j] = vals[e]; }
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const int lo = max(rs, base), hi = min(re, base + CH);
+            for (int k = lo; k < hi; k += U) {
+                int c[U];
+                double v[U], xv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    c[u] = 0; v[u] = 0.0;
+                    if (k + u < hi) { c[u] = cs[k + u - base]; v[u] = vs[k + u - base]; }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) { xv[u] = 0.0; if (k + u < hi) xv[u] = x[c[u]]; }
+#pragma unroll
+                for (int u = 0; u < U; ++u) if (k + u < hi) acc += v[u] * xv[u];
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (r < row1) y[r] = acc;
+    }
+}
+
 struct Mat { int n; long long nnz; int *rowptr, *cols; double *vals; short *cols16; };
 
 static Mat build(int layers, int nx, int ny) {
@@ -622,6 +678,12 @@ int main(int argc, char **argv) {
       RUN("wave-rr chunk8 grid 2048", [&] { spmv_wave_rr<8, 8><<<2048, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); });
       RUN("wave-rr chunk4 grid 1024", [&] { spmv_wave_rr<8, 4><<<1024, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); });
       RUN("wave-rr chunk4 grid 1536", [&] { spmv_wave_rr<8, 4><<<1536, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); }); }
+    { const int nwt = (m.n + 63) / 64;
+      RUN("rowgather epl8 u8 grid 2048", [&] { spmv_wave_rg<8, 8><<<2048, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); });
+      RUN("rowgather epl8 u4 grid 2048", [&] { spmv_wave_rg<8, 4><<<2048, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); });
+      RUN("rowgather epl8 u8 grid 1536", [&] { spmv_wave_rg<8, 8><<<1536, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); });
+      RUN("rowgather epl8 u8 grid 4096", [&] { spmv_wave_rg<8, 8><<<4096, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); });
+      RUN("rowgather epl16 u8 grid 2048", [&] { spmv_wave_rg<16, 8><<<2048, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); }); }
     { const int nwt = (m.n + 63) / 64;
       RUN("wave-rr16 chunk1 grid 2048", [&] { spmv_wave_rr16<8><<<2048, 256>>>(m.n, nwt, m.rowptr, m.cols16, m.vals, x, y); });
       RUN("wave-rr16 chunk1 grid 1536", [&] { spmv_wave_rr16<8><<<1536, 256>>>(m.n, nwt, m.rowptr, m.cols16, m.vals, x, y); });
