@@ -374,6 +374,7 @@ class SolveResult:
     setup_seconds: float = 0.0
     operator_complexity: float = 0.0
     levels: int = 0
+    precond_fallbacks: int = 0      # right-hand sides redone with the Jacobi preconditioner after a multigrid failure
 
 
 class CsrMatrix:
@@ -511,7 +512,7 @@ class CsrMatrix:
             _check(rc)
         return SolveResult(x, info.iterations, info.restarts, info.rel_residual, info.abs_residual,
                            info.solve_seconds, info.status, info.spmv_seconds, info.precond_setup_seconds,
-                           info.operator_complexity, info.levels)
+                           info.operator_complexity, info.levels, info.precond_fallbacks)
 
     def solve_spd_dev(self, b: DeviceArray, x: DeviceArray, *, n_rhs=1, rtol=1e-12, atol=0.0, max_iter=200000,
                       check_every=0, guess=False, raise_on_fail=True, time_spmv=False, precond="amg",
@@ -524,4 +525,4 @@ class CsrMatrix:
             _check(rc)
         return SolveResult(None, info.iterations, info.restarts, info.rel_residual, info.abs_residual,
                            info.solve_seconds, info.status, info.spmv_seconds, info.precond_setup_seconds,
-                           info.operator_complexity, info.levels)
+                           info.operator_complexity, info.levels, info.precond_fallbacks)

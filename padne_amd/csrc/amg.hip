@@ -49,6 +49,9 @@ struct Amg {
     std::vector<AmgLevel> levels;
     double *coarse_inv = nullptr;   // dense n_c x n_c
     int n_coarse = 0;
+    // single-precision cycle: the operators of every level have float copies and all cycle vectors are float
+    bool f32 = false;
+    float *coarse_inv32 = nullptr;
     // row-partitioned hierarchy: below the gather level every rank holds the whole operator (`tail`, with its
     // own single-GPU hierarchy) and runs the rest of the cycle redundantly
     bool dist = false;
@@ -583,22 +586,75 @@ __global__ void dense_extract_inverse(int n, const double *__restrict__ W, doubl
 }
 
 // y = Inv * b : one wave per row
-__global__ __launch_bounds__(256) void dense_gemv(int n_rows, int n, const double *__restrict__ inv,
-                                                  const double *__restrict__ b, double *__restrict__ y) {
+template <typename T>
+__global__ __launch_bounds__(256) void dense_gemv(int n_rows, int n, const T *__restrict__ inv,
+                                                  const T *__restrict__ b, T *__restrict__ y) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= n_rows) return;
-    double s = 0.0;
+    T s = 0;
     for (int c = lane; c < n; c += 64) s += inv[(size_t)row * n + c] * b[c];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if (lane == 0) y[row] = s;
 }
 
-__global__ void scale_dinv_kernel(long long n, double c, const double *__restrict__ dinv, const double *__restrict__ b,
-                                  double *__restrict__ x, const int *__restrict__ done_flag) {
+template <typename T>
+__global__ void scale_dinv_kernel(long long n, T c, const T *__restrict__ dinv, const T *__restrict__ b,
+                                  T *__restrict__ x, const int *__restrict__ done_flag) {
     if (done_flag != nullptr && *done_flag != 0) return;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         x[i] = c * dinv[i] * b[i];
+}
+
+// entry of the single-precision cycle: b = r / ||b_rhs|| in float (the cycle is linear, the last stage multiplies
+// the norm back in; keeps every intermediate far from the float range limits whatever the units of the system),
+// and the first Jacobi sweep from a zero guess
+__global__ void amg_entry_f32_kernel(long long n, const double *__restrict__ r, const double *__restrict__ bb2, float c,
+                                     const float *__restrict__ dinv, float *__restrict__ b, float *__restrict__ x,
+                                     const int *__restrict__ done_flag) {
+    if (done_flag != nullptr && *done_flag != 0) return;
+    double s_inv = 1.0;
+    if (bb2 != nullptr) {
+        const double s2 = *bb2;
+        if (s2 > 0.0) s_inv = 1.0 / sqrt(s2);
+    }
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = (float)(r[i] * s_inv);
+        b[i] = v;
+        x[i] = c * dinv[i] * v;
+    }
+}
+
+__global__ void f32_copy_amg(long long n, const double *__restrict__ src, float *__restrict__ dst) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (float)src[i];
+}
+
+// per-workgroup min / max of |v| (range check before switching a hierarchy to single precision)
+__global__ __launch_bounds__(256) void abs_range_kernel(long long n, const double *__restrict__ v, double *__restrict__ mins,
+                                                        double *__restrict__ maxs) {
+    __shared__ double lo[256], hi[256];
+    double a = 1e300, b = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const double t = fabs(v[i]);
+        a = t < a ? t : a;
+        b = (t > b || !(t == t)) ? t : b;
+    }
+    lo[threadIdx.x] = a;
+    hi[threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            lo[threadIdx.x] = fmin(lo[threadIdx.x], lo[threadIdx.x + o]);
+            const double h2 = hi[threadIdx.x + o];
+            if (h2 > hi[threadIdx.x] || !(h2 == h2)) hi[threadIdx.x] = h2;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        mins[blockIdx.x] = lo[0];
+        maxs[blockIdx.x] = hi[0];
+    }
 }
 
 // ---- host side ----------------------------------------------------------------------------------
@@ -915,6 +971,7 @@ void amg_destroy(void *p) {
         pool_free(amg->ctx, L.export_owned);
     }
     pool_free(amg->ctx, amg->coarse_inv);
+    pool_free(amg->ctx, amg->coarse_inv32);
     pool_free(amg->ctx, amg->coarse_gather);
     pool_free(amg->ctx, amg->seg_off);
     pool_free(amg->ctx, amg->tail_r);
@@ -951,6 +1008,46 @@ static bool amg_verbose() {
 }
 
 static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0);
+
+// Single-precision cycle (default; PADNE_AMG_F64=1 keeps double): float copies of every level operator.  Skipped
+// when 1/diag of the fine matrix leaves [1e-15, 1e15] (the cycle input is normalised, the operator is not).
+static int enable_f32(padne_ctx *ctx, Amg *amg) {
+    if (getenv("PADNE_AMG_F64") != nullptr || amg->dist || amg->levels.size() < 2) return PADNE_OK;
+    if (amg->levels[0].A->hierarchy_operator) return PADNE_OK;   // the gathered tail of a row-partitioned hierarchy
+    hipStream_t s = ctx->stream;
+    const padne_csr *A0 = amg->levels[0].A;
+    const int g = (int)std::min<long long>((A0->n_rows + 255) / 256, 1024);
+    double *mins = ctx->partials + 6 * kMaxPartials, *maxs = ctx->partials + 7 * kMaxPartials;
+    hipLaunchKernelGGL(abs_range_kernel, dim3(g), dim3(256), 0, s, (long long)A0->n_rows, (const double *)A0->dinv, mins,
+                       maxs);
+    PADNE_HIP_CHECK(hipGetLastError());
+    std::vector<double> h((size_t)2 * g);
+    PADNE_HIP_CHECK(hipMemcpyAsync(h.data(), mins, sizeof(double) * (size_t)g, hipMemcpyDeviceToHost, s));
+    PADNE_HIP_CHECK(hipMemcpyAsync(h.data() + g, maxs, sizeof(double) * (size_t)g, hipMemcpyDeviceToHost, s));
+    PADNE_HIP_CHECK(hipStreamSynchronize(s));
+    double lo = 1e300, hi = 0.0;
+    for (int i = 0; i < g; ++i) {
+        lo = std::min(lo, h[(size_t)i]);
+        if (h[(size_t)g + i] > hi || !(h[(size_t)g + i] == h[(size_t)g + i])) hi = h[(size_t)g + i];
+    }
+    if (!(lo >= 1e-15) || !(hi <= 1e15)) return PADNE_OK;
+    for (AmgLevel &L : amg->levels) {
+        PADNE_TRY(csr_build_f32(ctx, const_cast<padne_csr *>(L.A)));
+        if (L.P) PADNE_TRY(csr_build_f32(ctx, L.P));
+        if (L.R) PADNE_TRY(csr_build_f32(ctx, L.R));
+    }
+    if (amg->levels[0].b == nullptr) PADNE_TRY(alloc_vec(ctx, &amg->levels[0].b, amg->levels[0].n));
+    if (amg->n_coarse > 0) {
+        const size_t cnt = (size_t)amg->n_coarse * (size_t)amg->n_coarse;
+        amg->coarse_inv32 = (float *)pool_alloc(ctx, sizeof(float) * cnt);
+        if (amg->coarse_inv32 == nullptr) return PADNE_E_NOMEM;
+        hipLaunchKernelGGL(f32_copy_amg, dim3(nblk((long long)cnt)), dim3(256), 0, s, (long long)cnt, amg->coarse_inv,
+                           amg->coarse_inv32);
+        PADNE_HIP_CHECK(hipGetLastError());
+    }
+    amg->f32 = true;
+    return PADNE_OK;
+}
 
 int amg_setup(padne_ctx *ctx, padne_csr *A0) {
     if (A0->amg) return PADNE_OK;
@@ -1051,6 +1148,10 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         return rc;
     }
     amg->operator_complexity = nnz_total / (double)(A0->nnz > 0 ? A0->nnz : 1);
+    if ((rc = enable_f32(ctx, amg)) != PADNE_OK) {
+        amg_destroy(amg);
+        return rc;
+    }
     PADNE_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
     PADNE_HIP_CHECK(hipEventSynchronize(ctx->ev1));
     float ms = 0.f;
@@ -1545,9 +1646,54 @@ static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0) {
 }
 
 // z = M^-1 r on level 0 ; optional partial sums of r.z (written by the last kernel of the cycle)
+// the same cycle on the single-precision copies; r comes in and z goes out in double
+static int amg_apply_f32(padne_ctx *ctx, Amg *amg, const double *r, double *z, double *partials_rz,
+                         const int32_t *done_flag, const double *bb2) {
+    hipStream_t s = ctx->stream;
+    const int nl = (int)amg->levels.size();
+    if (partials_rz == nullptr) {
+        set_error("the single-precision cycle is only used as the CG preconditioner");
+        return PADNE_E_INVALID;
+    }
+    for (int l = 0; l < nl; ++l) {
+        AmgLevel &L = amg->levels[l];
+        float *b = (float *)L.b, *xa = (float *)L.xa, *tmp = (float *)L.tmp;
+        if (l == nl - 1) {
+            hipLaunchKernelGGL(dense_gemv<float>, dim3((amg->n_coarse + 3) / 4), dim3(256), 0, s, amg->n_coarse,
+                               amg->n_coarse, (const float *)amg->coarse_inv32, (const float *)b, (float *)L.xb);
+            PADNE_HIP_CHECK(hipGetLastError());
+            break;
+        }
+        const int gv = (int)std::min<long long>((L.n + 255) / 256, 1024);
+        if (l == 0)
+            hipLaunchKernelGGL(amg_entry_f32_kernel, dim3(gv > 0 ? gv : 1), dim3(256), 0, s, L.n, r, bb2, (float)L.jac,
+                               (const float *)L.A->dinv32, b, xa, done_flag);
+        else
+            hipLaunchKernelGGL(scale_dinv_kernel<float>, dim3(gv > 0 ? gv : 1), dim3(256), 0, s, L.n, (float)L.jac,
+                               (const float *)L.A->dinv32, (const float *)b, xa, done_flag);
+        PADNE_HIP_CHECK(hipGetLastError());
+        PADNE_TRY(launch_spmv_f32(ctx, L.A, SPMV_RESID, xa, tmp, nullptr, done_flag, b, nullptr, 0.f));
+        PADNE_TRY(launch_spmv_f32(ctx, L.R, SPMV_PLAIN, tmp, (float *)amg->levels[l + 1].b, nullptr, done_flag, nullptr,
+                                  nullptr, 0.f));
+    }
+    for (int l = nl - 2; l >= 0; --l) {
+        AmgLevel &L = amg->levels[l];
+        float *b = (float *)L.b, *xa = (float *)L.xa;
+        PADNE_TRY(launch_spmv_f32(ctx, L.P, SPMV_ADD, (const float *)amg->levels[l + 1].xb, xa, nullptr, done_flag,
+                                  nullptr, nullptr, 0.f));
+        if (l > 0)
+            PADNE_TRY(launch_spmv_f32(ctx, L.A, SPMV_JACOBI, xa, (float *)L.xb, nullptr, done_flag, b, L.A->dinv32,
+                                      (float)L.jac));
+        else
+            PADNE_TRY(launch_spmv_f32_exit(ctx, L.A, xa, z, r, partials_rz, done_flag, b, L.A->dinv32, (float)L.jac, bb2));
+    }
+    return PADNE_OK;
+}
+
 int amg_apply(padne_ctx *ctx, const padne_csr *A0, const double *r, double *z, double *partials_rz,
-              const int32_t *done_flag) {
+              const int32_t *done_flag, const double *bb2) {
     Amg *amg = (Amg *)A0->amg;
+    if (amg->f32) return amg_apply_f32(ctx, amg, r, z, partials_rz, done_flag, bb2);
     hipStream_t s = ctx->stream;
     const int nl = (int)amg->levels.size();
     // downward sweep
@@ -1564,18 +1710,18 @@ int amg_apply(padne_ctx *ctx, const padne_csr *A0, const double *r, double *z, d
                 hipLaunchKernelGGL(compact_pieces, dim3(nblk(amg->n_pad), ctx->world), dim3(256), 0, s, ctx->world,
                                    amg->n_pad, amg->seg_off, amg->coarse_gather, amg->tail_r, done_flag);
                 PADNE_HIP_CHECK(hipGetLastError());
-                PADNE_TRY(amg_apply(ctx, amg->tail, amg->tail_r, amg->tail_z, nullptr, done_flag));
+                PADNE_TRY(amg_apply(ctx, amg->tail, amg->tail_r, amg->tail_z, nullptr, done_flag, nullptr));
                 PADNE_HIP_CHECK(hipMemcpyAsync(out, amg->tail_z + amg->tail_off, sizeof(double) * (size_t)L.n,
                                                hipMemcpyDeviceToDevice, s));
             } else if (amg->n_coarse > 0)
-                hipLaunchKernelGGL(dense_gemv, dim3((amg->n_coarse + 3) / 4), dim3(256), 0, s, amg->n_coarse,
-                                   amg->n_coarse, amg->coarse_inv, b, out);
+                hipLaunchKernelGGL(dense_gemv<double>, dim3((amg->n_coarse + 3) / 4), dim3(256), 0, s, amg->n_coarse,
+                                   amg->n_coarse, (const double *)amg->coarse_inv, b, out);
             PADNE_HIP_CHECK(hipGetLastError());
             break;
         }
         const int gv = (int)std::min<long long>((L.n + 255) / 256, 1024);
-        hipLaunchKernelGGL(scale_dinv_kernel, dim3(gv > 0 ? gv : 1), dim3(256), 0, s, L.n, L.jac, L.A->dinv, b, L.xa,
-                           done_flag);
+        hipLaunchKernelGGL(scale_dinv_kernel<double>, dim3(gv > 0 ? gv : 1), dim3(256), 0, s, L.n, L.jac,
+                           (const double *)L.A->dinv, b, L.xa, done_flag);
         PADNE_HIP_CHECK(hipGetLastError());
         if (amg->dist) PADNE_TRY(halo_exchange_plan(ctx, L.halo, L.xa, done_flag));
         PADNE_TRY(launch_spmv_mode(ctx, L.A, SPMV_RESID, L.xa, L.tmp, nullptr, nullptr, done_flag, b, nullptr, 0.0));

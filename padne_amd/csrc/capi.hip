@@ -294,6 +294,8 @@ int padne_csr_destroy(padne_csr *m) {
         pool_free(m->owner, m->cols);
         pool_free(m->owner, m->vals);
         pool_free(m->owner, m->dinv);
+        pool_free(m->owner, m->vals32);
+        pool_free(m->owner, m->dinv32);
     }
     delete m;
     return PADNE_OK;

@@ -60,6 +60,7 @@ struct padne_csr {
     int device = 0;
     padne_ctx *owner = nullptr;  // context whose pool the arrays came from (must outlive the matrix)
     void *amg = nullptr;         // cached multigrid hierarchy (padne::Amg*), owned
+    float *vals32 = nullptr, *dinv32 = nullptr;   // single-precision copies for the multigrid cycle (csr_build_f32)
     bool hierarchy_operator = false;   // multigrid-internal operator: may use the wave-per-row SpMV
     padne_csr *prec_block = nullptr;   // borrowed: owned x owned diagonal block for the preconditioner
 };
@@ -107,6 +108,13 @@ enum { SPMV_PLAIN = 0, SPMV_DOT = 1, SPMV_RESID = 2, SPMV_ADD = 3, SPMV_JACOBI =
 int launch_spmv_mode(padne_ctx *ctx, const padne_csr *m, int mode, const double *x, double *y,
                      const double *dot_with, double *partials, const int32_t *done_flag, const double *aux1,
                      const double *aux2, double scale);
+
+int launch_spmv_f32(padne_ctx *ctx, const padne_csr *m, int mode, const float *x, float *y, double *partials,
+                    const int32_t *done_flag, const float *aux1, const float *aux2, float scale);
+int launch_spmv_f32_exit(padne_ctx *ctx, const padne_csr *m, const float *x, double *y, const double *dot_with,
+                         double *partials, const int32_t *done_flag, const float *aux1, const float *aux2, float scale,
+                         const double *out_scale2);
+int csr_build_f32(padne_ctx *ctx, padne_csr *m);
 
 // exclusive scan of int32 counts into int32 offsets (n+1 outputs); returns total via host
 int exclusive_scan_i32(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t n, int64_t *total);

@@ -304,7 +304,7 @@ static int halo_exchange(padne_ctx *ctx, double *v, const int32_t *done_flag) {
 
 int amg_setup(padne_ctx *ctx, padne_csr *A0);
 int amg_apply(padne_ctx *ctx, const padne_csr *A0, const double *r, double *z, double *partials_rz,
-              const int32_t *done_flag);
+              const int32_t *done_flag, const double *bb2 = nullptr);
 void amg_info(const padne_csr *A0, int *levels, double *complexity, double *setup_seconds, long long *coarse_n);
 const padne_csr *amg_level_matrix(const padne_csr *A0, int level, int which);
 
@@ -346,6 +346,7 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
     const int check_every = o->check_every > 0 ? o->check_every : (amg ? 4 : 50);
     const int sample_stride = amg ? 4 : 16;
     double *scal = ctx->scalars;
+    const double *bb_scalar = scal + S_BB;
 
     PADNE_HIP_CHECK(hipMemsetAsync(st, 0, sizeof(PcgStatus), s));
     if (halo) PADNE_HIP_CHECK(hipMemsetAsync(p + n, 0, sizeof(double) * (size_t)(nc - n), s));
@@ -383,15 +384,18 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
             hipLaunchKernelGGL(pcg_init_plain_kernel, dim3(gv), dim3(256), 0, s, n, b, have_ax ? q : nullptr, r,
                                slot(ctx, SLOT_RR), slot(ctx, SLOT_BB));
             PADNE_HIP_CHECK(hipGetLastError());
-            PADNE_TRY(amg_apply(ctx, prec, r, z, slot(ctx, SLOT_RZ0), nullptr));
+            // ||b||^2 first: the single-precision cycle normalises its input with it
+            PADNE_TRY(fold(slot(ctx, SLOT_RR), gv, kMaxPartials, 2, scal + S_RR));   // RR, BB adjacent
+            PADNE_TRY(allreduce(scal + S_RR, 2));
+            PADNE_TRY(amg_apply(ctx, prec, r, z, slot(ctx, SLOT_RZ0), nullptr, bb_scalar));
             PADNE_HIP_CHECK(hipMemcpyAsync(p, z, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
         } else {
             hipLaunchKernelGGL(pcg_init_kernel, dim3(gv), dim3(256), 0, s, n, b, have_ax ? q : nullptr, a->dinv, r, p,
                                slot(ctx, SLOT_RZ0), slot(ctx, SLOT_RR), slot(ctx, SLOT_BB));
             PADNE_HIP_CHECK(hipGetLastError());
+            PADNE_TRY(fold(slot(ctx, SLOT_RR), gv, kMaxPartials, 2, scal + S_RR));   // RR, BB adjacent
+            PADNE_TRY(allreduce(scal + S_RR, 2));
         }
-        PADNE_TRY(fold(slot(ctx, SLOT_RR), gv, kMaxPartials, 2, scal + S_RR));   // RR, BB adjacent
-        PADNE_TRY(allreduce(scal + S_RR, 2));
         if (dist) {
             PADNE_TRY(fold(slot(ctx, SLOT_RZ0), P_rz, kMaxPartials, 1, scal + S_RZRR0));
             PADNE_TRY(allreduce(scal + S_RZRR0, 1));
@@ -434,7 +438,7 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
                     hipLaunchKernelGGL(pcg_update_xr_plain_kernel, dim3(gv), dim3(256), 0, s, n, rz_old, Pz, pq, Pq, p, q,
                                        x, r, slot(ctx, SLOT_RR), st);
                     PADNE_HIP_CHECK(hipGetLastError());
-                    PADNE_TRY(amg_apply(ctx, prec, r, z, slot(ctx, rz_new_slot), &st->done));
+                    PADNE_TRY(amg_apply(ctx, prec, r, z, slot(ctx, rz_new_slot), &st->done, bb_scalar));
                     if (dist) {
                         PADNE_TRY(fold(slot(ctx, rz_new_slot), P_rz, kMaxPartials, 1, s_new));
                         PADNE_TRY(fold(slot(ctx, SLOT_RR), gv, kMaxPartials, 1, s_new + 1));

@@ -24,9 +24,16 @@
 //    through LDS, one partial per workgroup (deterministic, no float atomics).
 #include "common.hpp"
 
+#include <algorithm>
+
 namespace padne {
 
 __device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+template <typename T> __device__ __forceinline__ T wave_sum_t(T v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
@@ -54,22 +61,33 @@ constexpr int kWaveChunk = 64 * kEpl;   // non-zeros parked in LDS per wave per 
 //   SPMV_ADD     y += acc                                              (prolongation: x += P xc)
 //   SPMV_JACOBI  y = x[row] + scale * aux2[row] * (aux1[row] - acc)    (damped-Jacobi sweep, aux2 = 1/diag)
 //                optional partial sums of aux1[row] * y[row]           (r.z of the preconditioned CG)
-template <int MODE>
+//
+// Scalar types: VT matrix values, XT the vectors x / aux1 / aux2 and the arithmetic, YT the output.  The solver's
+// own products are <double, double, double>; the multigrid cycle runs <float, float, float> (single-precision
+// copies of its operators: 8 instead of 12 bytes per non-zero, half the vector traffic), and its last stage
+// <float, float, double> hands z back to CG in double, multiplied by sqrt(*out_scale2) (the cycle works on
+// r / ||b||, see amg.hip) and with the r.z partials taken against the double residual `dot_with`.
+template <int MODE, typename VT, typename XT, typename YT>
 __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
     const int n_rows, const int n_wtiles, const int *__restrict__ rowptr,
-    const int *__restrict__ cols, const double *__restrict__ vals,
-    const double *__restrict__ x, double *__restrict__ y,
+    const int *__restrict__ cols, const VT *__restrict__ vals,
+    const XT *__restrict__ x, YT *__restrict__ y,
     const double *__restrict__ dot_with, double *__restrict__ partials,
-    const int *__restrict__ done_flag, const double *__restrict__ aux1,
-    const double *__restrict__ aux2, const double scale) {
+    const int *__restrict__ done_flag, const XT *__restrict__ aux1,
+    const XT *__restrict__ aux2, const XT scale, const double *__restrict__ out_scale2) {
     constexpr bool WITH_DOT = (MODE == SPMV_DOT) || (MODE == SPMV_JACOBI);
-    __shared__ double prod_all[4 * kWaveChunk];
+    __shared__ XT prod_all[4 * kWaveChunk];
     __shared__ double red[4];
 
     if (done_flag != nullptr && *done_flag != 0) return;
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    double *prod = prod_all + w * kWaveChunk;
+    XT *prod = prod_all + w * kWaveChunk;
+    double out_mul = 1.0;
+    if (out_scale2 != nullptr) {
+        const double s2 = *out_scale2;
+        out_mul = s2 > 0.0 ? sqrt(s2) : 1.0;
+    }
     const int G = gridDim.x;
     // slabs: one per XCD when the grid is a multiple of 8, otherwise a single slab
     const int nslab = (G % kNumXcd == 0) ? kNumXcd : 1;
@@ -91,15 +109,15 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
         }
         const int k0 = __shfl(rs, 0, 64);
         const int k1 = __shfl(re, row1 - row0 - 1, 64);
-        double acc = 0.0;
+        XT acc = 0;
         for (int base = k0; base < k1; base += kWaveChunk) {
             int c[kEpl];
-            double v[kEpl];
+            VT v[kEpl];
 #pragma unroll
             for (int j = 0; j < kEpl; ++j) {
                 const int e = base + lane + 64 * j;
                 c[j] = 0;
-                v[j] = 0.0;
+                v[j] = 0;
                 if (e < k1) {
                     c[j] = cols[e];
                     v[j] = vals[e];
@@ -108,9 +126,9 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
 #pragma unroll
             for (int j = 0; j < kEpl; ++j) {
                 const int e = base + lane + 64 * j;
-                double xv = 0.0;
+                XT xv = 0;
                 if (e < k1) xv = x[c[j]];
-                prod[lane + 64 * j] = v[j] * xv;
+                prod[lane + 64 * j] = (XT)v[j] * xv;
             }
             // same-wave LDS traffic is processed in issue order; keep the compiler from reordering
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -122,19 +140,25 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
         }
         if (r < row1) {
             if (MODE == SPMV_PLAIN) {
-                y[r] = acc;
+                y[r] = (YT)acc;
             } else if (MODE == SPMV_DOT) {
-                y[r] = acc;
-                dot_acc += dot_with[r] * acc;
+                y[r] = (YT)acc;
+                dot_acc += dot_with[r] * (double)acc;
             } else if (MODE == SPMV_RESID) {
-                y[r] = aux1[r] - acc;
+                y[r] = (YT)(aux1[r] - acc);
             } else if (MODE == SPMV_ADD) {
-                y[r] += acc;
+                y[r] += (YT)acc;
             } else {
-                const double b = aux1[r];
-                const double out = x[r] + scale * aux2[r] * (b - acc);
-                y[r] = out;
-                dot_acc += b * out;
+                const XT b = aux1[r];
+                const XT out = x[r] + scale * aux2[r] * (b - acc);
+                if (dot_with != nullptr) {
+                    const double outd = (double)out * out_mul;
+                    y[r] = (YT)outd;
+                    dot_acc += dot_with[r] * outd;
+                } else {
+                    y[r] = (YT)out;
+                    dot_acc += (double)(b * out);
+                }
             }
         }
     }
@@ -148,38 +172,49 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
 // hundreds of non-zeros per row, a few thousand rows): there the tile kernel above is latency-bound on a
 // handful of waves.  The lanes of a wave stride over one row and the partial sums are combined with a
 // fixed shuffle tree, so results are reproducible (but not in CSR order: never used for the fine matrix).
-template <int MODE>
+template <int MODE, typename VT, typename XT, typename YT>
 __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_wpr_kernel(
-    const int n_rows, const int *__restrict__ rowptr, const int *__restrict__ cols, const double *__restrict__ vals,
-    const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ dot_with,
-    double *__restrict__ partials, const int *__restrict__ done_flag, const double *__restrict__ aux1,
-    const double *__restrict__ aux2, const double scale) {
+    const int n_rows, const int *__restrict__ rowptr, const int *__restrict__ cols, const VT *__restrict__ vals,
+    const XT *__restrict__ x, YT *__restrict__ y, const double *__restrict__ dot_with,
+    double *__restrict__ partials, const int *__restrict__ done_flag, const XT *__restrict__ aux1,
+    const XT *__restrict__ aux2, const XT scale, const double *__restrict__ out_scale2) {
     constexpr bool WITH_DOT = (MODE == SPMV_DOT) || (MODE == SPMV_JACOBI);
     __shared__ double red[4];
     if (done_flag != nullptr && *done_flag != 0) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int W = gridDim.x * 4;
+    double out_mul = 1.0;
+    if (out_scale2 != nullptr) {
+        const double s2 = *out_scale2;
+        out_mul = s2 > 0.0 ? sqrt(s2) : 1.0;
+    }
     double dot_acc = 0.0;
     for (int r = blockIdx.x * 4 + w; r < n_rows; r += W) {
         const int rs = rowptr[r], re = rowptr[r + 1];
-        double acc = 0.0;
-        for (int k = rs + lane; k < re; k += 64) acc += vals[k] * x[cols[k]];
-        acc = wave_sum(acc);
+        XT acc = 0;
+        for (int k = rs + lane; k < re; k += 64) acc += (XT)vals[k] * x[cols[k]];
+        acc = wave_sum_t(acc);
         if (lane == 0) {
             if (MODE == SPMV_PLAIN) {
-                y[r] = acc;
+                y[r] = (YT)acc;
             } else if (MODE == SPMV_DOT) {
-                y[r] = acc;
-                dot_acc += dot_with[r] * acc;
+                y[r] = (YT)acc;
+                dot_acc += dot_with[r] * (double)acc;
             } else if (MODE == SPMV_RESID) {
-                y[r] = aux1[r] - acc;
+                y[r] = (YT)(aux1[r] - acc);
             } else if (MODE == SPMV_ADD) {
-                y[r] += acc;
+                y[r] += (YT)acc;
             } else {
-                const double b = aux1[r];
-                const double out = x[r] + scale * aux2[r] * (b - acc);
-                y[r] = out;
-                dot_acc += b * out;
+                const XT b = aux1[r];
+                const XT out = x[r] + scale * aux2[r] * (b - acc);
+                if (dot_with != nullptr) {
+                    const double outd = (double)out * out_mul;
+                    y[r] = (YT)outd;
+                    dot_acc += dot_with[r] * outd;
+                } else {
+                    y[r] = (YT)out;
+                    dot_acc += (double)(b * out);
+                }
             }
         }
     }
@@ -205,16 +240,18 @@ int spmv_grid(const padne_csr *m) {
     return (int)g;
 }
 
-int launch_spmv_mode(padne_ctx *ctx, const padne_csr *m, int mode, const double *x, double *y,
-                     const double *dot_with, double *partials, const int32_t *done_flag, const double *aux1,
-                     const double *aux2, double scale) {
+template <typename VT, typename XT, typename YT>
+static int launch_spmv_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals, int mode, const XT *x, YT *y,
+                             const double *dot_with, double *partials, const int32_t *done_flag, const XT *aux1,
+                             const XT *aux2, XT scale, const double *out_scale2) {
     if (m->n_rows == 0) return PADNE_OK;
     const int n_tiles = (int)((m->n_rows + 63) / 64);   // wave-tiles of 64 rows
     const int g = spmv_grid(m);
     if (use_wave_per_row(m)) {
-#define PADNE_SPMV_WPR(M)                                                                                  \
-    hipLaunchKernelGGL(csr_spmv_wpr_kernel<M>, dim3(g), dim3(kSpmvThreads), 0, ctx->stream, (int)m->n_rows, \
-                       m->rowptr, m->cols, m->vals, x, y, dot_with, partials, done_flag, aux1, aux2, scale)
+#define PADNE_SPMV_WPR(M)                                                                                           \
+    hipLaunchKernelGGL((csr_spmv_wpr_kernel<M, VT, XT, YT>), dim3(g), dim3(kSpmvThreads), 0, ctx->stream,            \
+                       (int)m->n_rows, m->rowptr, m->cols, vals, x, y, dot_with, partials, done_flag, aux1, aux2,    \
+                       scale, out_scale2)
         switch (mode) {
             case SPMV_PLAIN: PADNE_SPMV_WPR(SPMV_PLAIN); break;
             case SPMV_DOT: PADNE_SPMV_WPR(SPMV_DOT); break;
@@ -227,10 +264,10 @@ int launch_spmv_mode(padne_ctx *ctx, const padne_csr *m, int mode, const double 
         PADNE_HIP_CHECK(hipGetLastError());
         return PADNE_OK;
     }
-#define PADNE_SPMV_LAUNCH(M)                                                                           \
-    hipLaunchKernelGGL(csr_spmv_kernel<M>, dim3(g), dim3(kSpmvThreads), 0, ctx->stream, (int)m->n_rows, \
-                       n_tiles, m->rowptr, m->cols, m->vals, x, y, dot_with, partials, done_flag, aux1,  \
-                       aux2, scale)
+#define PADNE_SPMV_LAUNCH(M)                                                                                     \
+    hipLaunchKernelGGL((csr_spmv_kernel<M, VT, XT, YT>), dim3(g), dim3(kSpmvThreads), 0, ctx->stream,             \
+                       (int)m->n_rows, n_tiles, m->rowptr, m->cols, vals, x, y, dot_with, partials, done_flag,    \
+                       aux1, aux2, scale, out_scale2)
     switch (mode) {
         case SPMV_PLAIN: PADNE_SPMV_LAUNCH(SPMV_PLAIN); break;
         case SPMV_DOT: PADNE_SPMV_LAUNCH(SPMV_DOT); break;
@@ -240,6 +277,56 @@ int launch_spmv_mode(padne_ctx *ctx, const padne_csr *m, int mode, const double 
         default: set_error("bad SpMV mode %d", mode); return PADNE_E_INVALID;
     }
 #undef PADNE_SPMV_LAUNCH
+    PADNE_HIP_CHECK(hipGetLastError());
+    return PADNE_OK;
+}
+
+int launch_spmv_mode(padne_ctx *ctx, const padne_csr *m, int mode, const double *x, double *y,
+                     const double *dot_with, double *partials, const int32_t *done_flag, const double *aux1,
+                     const double *aux2, double scale) {
+    return launch_spmv_typed<double, double, double>(ctx, m, m->vals, mode, x, y, dot_with, partials, done_flag, aux1,
+                                                     aux2, scale, nullptr);
+}
+
+// single-precision operator copy (csr_build_f32) on single-precision vectors
+int launch_spmv_f32(padne_ctx *ctx, const padne_csr *m, int mode, const float *x, float *y, double *partials,
+                    const int32_t *done_flag, const float *aux1, const float *aux2, float scale) {
+    PADNE_REQUIRE(m->vals32 != nullptr, "single-precision copy missing");
+    return launch_spmv_typed<float, float, float>(ctx, m, m->vals32, mode, x, y, nullptr, partials, done_flag, aux1,
+                                                  aux2, scale, nullptr);
+}
+
+// last stage of the single-precision cycle: damped-Jacobi sweep whose result goes out in double, multiplied by
+// sqrt(*out_scale2), with partial sums of dot_with . y
+int launch_spmv_f32_exit(padne_ctx *ctx, const padne_csr *m, const float *x, double *y, const double *dot_with,
+                         double *partials, const int32_t *done_flag, const float *aux1, const float *aux2, float scale,
+                         const double *out_scale2) {
+    PADNE_REQUIRE(m->vals32 != nullptr && dot_with != nullptr, "single-precision exit stage");
+    return launch_spmv_typed<float, float, double>(ctx, m, m->vals32, SPMV_JACOBI, x, y, dot_with, partials, done_flag,
+                                                   aux1, aux2, scale, out_scale2);
+}
+
+__global__ void f32_copy_kernel(long long n, const double *__restrict__ src, float *__restrict__ dst) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = (float)src[i];
+}
+
+// single-precision copies of the values and of 1/diag (kept with the matrix, freed with it)
+int csr_build_f32(padne_ctx *ctx, padne_csr *m) {
+    if (m->vals32 != nullptr) return PADNE_OK;
+    padne_ctx *owner = m->owner ? m->owner : ctx;
+    m->vals32 = (float *)pool_alloc(owner, sizeof(float) * (size_t)(m->nnz > 0 ? m->nnz : 1));
+    if (m->vals32 == nullptr) return PADNE_E_NOMEM;
+    if (m->nnz > 0)
+        hipLaunchKernelGGL(f32_copy_kernel, dim3((unsigned)std::min<long long>((m->nnz + 255) / 256, 8192)), dim3(256), 0,
+                           ctx->stream, (long long)m->nnz, m->vals, m->vals32);
+    if (m->dinv != nullptr && m->dinv32 == nullptr) {
+        m->dinv32 = (float *)pool_alloc(owner, sizeof(float) * (size_t)(m->n_rows > 0 ? m->n_rows : 1));
+        if (m->dinv32 == nullptr) return PADNE_E_NOMEM;
+        if (m->n_rows > 0)
+            hipLaunchKernelGGL(f32_copy_kernel, dim3((unsigned)std::min<long long>((m->n_rows + 255) / 256, 8192)),
+                               dim3(256), 0, ctx->stream, (long long)m->n_rows, m->dinv, m->dinv32);
+    }
     PADNE_HIP_CHECK(hipGetLastError());
     return PADNE_OK;
 }

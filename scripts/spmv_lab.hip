@@ -570,7 +570,345 @@ __global__ __launch_bounds__(256) void spmv_wave_rg(int n_rows, int n_wtiles, co
     }
 }
 
-struct Mat { int n; long long nnz; int *rowptr, *cols; double *vals; short *cols16; };
+// ---- V13: x windows staged in LDS.  Per 64-row tile a descriptor lists up to 3 contiguous runs of x that cover
+// every column of the tile; the runs are loaded with wide coalesced loads into the wave's LDS slice and the
+// per-non-zero column becomes a 16-bit index into that slice (2 B instead of 4 B per non-zero, and no scattered
+// global gathers at all) ----
+constexpr int XW = 72;   // entries reserved per run
+template <int EPL, int PHASE = 0>
+__global__ __launch_bounds__(256) void spmv_wave_xw(int n_rows, int n_wtiles, const int *__restrict__ rowptr,
+                                                    const unsigned short *__restrict__ lidx, const double *__restrict__ vals,
+                                                    const int4 *__restrict__ desc, const double *__restrict__ x,
+                                                    double *__restrict__ y) {
+    constexpr int CH = 64 * EPL;
+    __shared__ double prod_all[4 * CH];
+    __shared__ double xs_all[4 * 3 * XW];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double *prod = prod_all + w * CH;
+    double *xs = xs_all + w * 3 * XW;
+    const int G = gridDim.x;
+    const int xcd = blockIdx.x % NXCD;
+    const int wx = (blockIdx.x / NXCD) * 4 + w;
+    const int wpx = (G / NXCD) * 4;
+    const int s0 = (int)((long long)xcd * n_wtiles / NXCD), s1 = (int)((long long)(xcd + 1) * n_wtiles / NXCD);
+    for (int wt = s0 + wx; wt < s1; wt += wpx) {
+        const int row0 = wt * 64;
+        const int row1 = min(row0 + 64, n_rows);
+        const int r = row0 + lane;
+        int rs = 0, re = 0;
+        if (r < row1) { rs = rowptr[r]; re = rowptr[r + 1]; }
+        const int4 d = desc[wt];                   // three run starts (clipped to [0, n_rows)), .w unused
+        const int k0 = __shfl(rs, 0, 64);
+        const int k1 = __shfl(re, row1 - row0 - 1, 64);
+        // stage the runs: 72 entries each, two loads per run (64 + 8)
+        if (PHASE != 2) {
+            const int st[3] = {d.x, d.y, d.z};
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int a = st[q] + lane;
+                xs[q * XW + lane] = (a < n_rows) ? x[a] : 0.0;
+                if (lane < XW - 64) {
+                    const int b = st[q] + 64 + lane;
+                    xs[q * XW + 64 + lane] = (b < n_rows) ? x[b] : 0.0;
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        double acc = 0.0;
+        for (int base = k0; base < k1; base += CH) {
+            int c[EPL];
+            double v[EPL];
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const int e = base + lane + 64 * j;
+                c[j] = 0; v[j] = 0.0;
+                if (e < k1) { c[j] = lidx[e]; v[j] = vals[e]; }
+            }
+            if (PHASE == 1 || PHASE == 3) {
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) acc += v[j] * (PHASE == 3 ? (double)c[j] : xs[c[j]]);
+                continue;
+            }
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) prod[lane + 64 * j] = v[j] * xs[c[j]];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const int lo = max(rs, base), hi = min(re, base + CH);
+            for (int k = lo; k < hi; ++k) acc += prod[k - base];
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (r < row1) y[r] = acc;
+    }
+}
+
+// ---- V14: V13 with all global loads of a tile issued back to back (matrix stream first, then the x runs) ----
+template <int EPL>
+__global__ __launch_bounds__(256) void spmv_wave_xw2(int n_rows, int n_wtiles, const int *__restrict__ rowptr,
+                                                     const unsigned short *__restrict__ lidx, const double *__restrict__ vals,
+                                                     const int4 *__restrict__ desc, const double *__restrict__ x,
+                                                     double *__restrict__ y) {
+    constexpr int CH = 64 * EPL;
+    __shared__ double prod_all[4 * CH];
+    __shared__ double xs_all[4 * 3 * XW];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double *prod = prod_all + w * CH;
+    double *xs = xs_all + w * 3 * XW;
+    const int G = gridDim.x;
+    const int xcd = blockIdx.x % NXCD;
+    const int wx = (blockIdx.x / NXCD) * 4 + w;
+    const int wpx = (G / NXCD) * 4;
+    const int s0 = (int)((long long)xcd * n_wtiles / NXCD), s1 = (int)((long long)(xcd + 1) * n_wtiles / NXCD);
+    for (int wt = s0 + wx; wt < s1; wt += wpx) {
+        const int row0 = wt * 64;
+        const int row1 = min(row0 + 64, n_rows);
+        const int r = row0 + lane;
+        int rs = 0, re = 0;
+        if (r < row1) { rs = rowptr[r]; re = rowptr[r + 1]; }
+        const int4 d = desc[wt];
+        const int k0 = __shfl(rs, 0, 64);
+        const int k1 = __shfl(re, row1 - row0 - 1, 64);
+        int c[EPL];
+        double v[EPL];
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            const int e = k0 + lane + 64 * j;
+            c[j] = 0; v[j] = 0.0;
+            if (e < k1) { c[j] = lidx[e]; v[j] = vals[e]; }
+        }
+        {
+            const int st[3] = {d.x, d.y, d.z};
+            double xa[3], xb[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int a = st[q] + lane, b = st[q] + 64 + lane;
+                xa[q] = (a < n_rows) ? x[a] : 0.0;
+                xb[q] = (lane < XW - 64 && b < n_rows) ? x[b] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                xs[q * XW + lane] = xa[q];
+                if (lane < XW - 64) xs[q * XW + 64 + lane] = xb[q];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        double acc = 0.0;
+        for (int base = k0; base < k1; base += CH) {
+            if (base != k0) {
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) {
+                    const int e = base + lane + 64 * j;
+                    c[j] = 0; v[j] = 0.0;
+                    if (e < k1) { c[j] = lidx[e]; v[j] = vals[e]; }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) prod[lane + 64 * j] = v[j] * xs[c[j]];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const int lo = max(rs, base), hi = min(re, base + CH);
+            for (int k = lo; k < hi; ++k) acc += prod[k - base];
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (r < row1) y[r] = acc;
+    }
+}
+
+// ---- V15: V9 with 16-byte loads of the matrix stream: a lane takes PAIRS of consecutive non-zeros ----
+template <int EPL>   // EPL pairs per lane per pass
+__global__ __launch_bounds__(256) void spmv_wave_rr_v2(int n_rows, int n_wtiles, const int *__restrict__ rowptr,
+                                                       const int *__restrict__ cols, const double *__restrict__ vals,
+                                                       const double *__restrict__ x, double *__restrict__ y) {
+    constexpr int CH = 128 * EPL;
+    __shared__ double prod_all[4 * CH];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double *prod = prod_all + w * CH;
+    const int G = gridDim.x;
+    const int xcd = blockIdx.x % NXCD;
+    const int wx = (blockIdx.x / NXCD) * 4 + w;
+    const int wpx = (G / NXCD) * 4;
+    const int s0 = (int)((long long)xcd * n_wtiles / NXCD), s1 = (int)((long long)(xcd + 1) * n_wtiles / NXCD);
+    for (int wt = s0 + wx; wt < s1; wt += wpx) {
+        const int row0 = wt * 64;
+        const int row1 = min(row0 + 64, n_rows);
+        const int r = row0 + lane;
+        int rs = 0, re = 0;
+        if (r < row1) { rs = rowptr[r]; re = rowptr[r + 1]; }
+        const int k0 = __shfl(rs, 0, 64);
+        const int k1 = __shfl(re, row1 - row0 - 1, 64);
+        double acc = 0.0;
+        for (int base = k0 & ~1; base < k1; base += CH) {
+            int2 c[EPL];
+            double2 v[EPL];
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const int e = base + 2 * lane + 128 * j;
+                c[j] = make_int2(0, 0); v[j] = make_double2(0.0, 0.0);
+                if (e < k1) {   // the arrays are padded: reading one element past k1 is safe
+                    c[j] = *reinterpret_cast<const int2 *>(cols + e);
+                    v[j] = *reinterpret_cast<const double2 *>(vals + e);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const int e = base + 2 * lane + 128 * j;
+                double x0 = 0.0, x1 = 0.0;
+                if (e < k1 && e >= k0) x0 = x[c[j].x];
+                if (e + 1 < k1) x1 = x[c[j].y];
+                *reinterpret_cast<double2 *>(prod + 2 * lane + 128 * j) = make_double2(v[j].x * x0, v[j].y * x1);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const int lo = max(rs, base), hi = min(re, base + CH);
+            for (int k = lo; k < hi; ++k) acc += prod[k - base];
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (r < row1) y[r] = acc;
+    }
+}
+
+// ---- V16: V14 software-pipelined: the matrix stream and the x runs of the NEXT tile are in flight while the
+// current tile goes through LDS ----
+template <int EPL>
+__global__ __launch_bounds__(256) void spmv_wave_xw3(int n_rows, int n_wtiles, const int *__restrict__ rowptr,
+                                                     const unsigned short *__restrict__ lidx, const double *__restrict__ vals,
+                                                     const int4 *__restrict__ desc, const double *__restrict__ x,
+                                                     double *__restrict__ y) {
+    constexpr int CH = 64 * EPL;
+    __shared__ double prod_all[4 * CH];
+    __shared__ double xs_all[4 * 3 * XW];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double *prod = prod_all + w * CH;
+    double *xs = xs_all + w * 3 * XW;
+    const int G = gridDim.x;
+    const int xcd = blockIdx.x % NXCD;
+    const int wx = (blockIdx.x / NXCD) * 4 + w;
+    const int wpx = (G / NXCD) * 4;
+    const int s0 = (int)((long long)xcd * n_wtiles / NXCD), s1 = (int)((long long)(xcd + 1) * n_wtiles / NXCD);
+    int wt = s0 + wx;
+    if (wt >= s1) return;
+    // state of the tile whose loads are in flight
+    int rs, re, k0, k1, row1;
+    int c[EPL];
+    double v[EPL], xa[3], xb[3];
+    auto issue = [&](int t) {
+        const int row0 = t * 64;
+        row1 = min(row0 + 64, n_rows);
+        const int r = row0 + lane;
+        rs = 0; re = 0;
+        if (r < row1) { rs = rowptr[r]; re = rowptr[r + 1]; }
+        const int4 d = desc[t];
+        k0 = __shfl(rs, 0, 64);
+        k1 = __shfl(re, row1 - row0 - 1, 64);
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            const int e = k0 + lane + 64 * j;
+            c[j] = 0; v[j] = 0.0;
+            if (e < k1) { c[j] = lidx[e]; v[j] = vals[e]; }
+        }
+        const int st[3] = {d.x, d.y, d.z};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int a = st[q] + lane, b = st[q] + 64 + lane;
+            xa[q] = (a < n_rows) ? x[a] : 0.0;
+            xb[q] = (lane < XW - 64 && b < n_rows) ? x[b] : 0.0;
+        }
+    };
+    issue(wt);
+    while (wt < s1) {
+        // take over the in-flight tile
+        const int crs = rs, cre = re, ck0 = k0, ck1 = k1, crow1 = row1, cwt = wt;
+        int cc[EPL];
+        double cv[EPL], cxa[3], cxb[3];
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) { cc[j] = c[j]; cv[j] = v[j]; }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { cxa[q] = xa[q]; cxb[q] = xb[q]; }
+        wt += wpx;
+        if (wt < s1) issue(wt);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            xs[q * XW + lane] = cxa[q];
+            if (lane < XW - 64) xs[q * XW + 64 + lane] = cxb[q];
+        }
+        __builtin_amdgcn_wave_barrier();
+        double acc = 0.0;
+        for (int base = ck0; base < ck1; base += CH) {
+            if (base != ck0) {
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) {
+                    const int e = base + lane + 64 * j;
+                    cc[j] = 0; cv[j] = 0.0;
+                    if (e < ck1) { cc[j] = lidx[e]; cv[j] = vals[e]; }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) prod[lane + 64 * j] = cv[j] * xs[cc[j]];
+            __builtin_amdgcn_wave_barrier();
+            const int lo = max(crs, base), hi = min(cre, base + CH);
+            for (int k = lo; k < hi; ++k) acc += prod[k - base];
+            __builtin_amdgcn_wave_barrier();
+        }
+        const int r = cwt * 64 + lane;
+        if (r < crow1) y[r] = acc;
+    }
+}
+
+// ---- V17: V9 in single precision (values, x, y, products): what a mixed-precision V-cycle would run ----
+template <int EPL, typename VT, typename XT>
+__global__ __launch_bounds__(256) void spmv_wave_rr_mp(int n_rows, int n_wtiles, const int *__restrict__ rowptr,
+                                                       const int *__restrict__ cols, const VT *__restrict__ vals,
+                                                       const XT *__restrict__ x, XT *__restrict__ y) {
+    constexpr int CH = 64 * EPL;
+    __shared__ XT prod_all[4 * CH];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    XT *prod = prod_all + w * CH;
+    const int G = gridDim.x;
+    const int xcd = blockIdx.x % NXCD;
+    const int wx = (blockIdx.x / NXCD) * 4 + w;
+    const int wpx = (G / NXCD) * 4;
+    const int s0 = (int)((long long)xcd * n_wtiles / NXCD), s1 = (int)((long long)(xcd + 1) * n_wtiles / NXCD);
+    for (int wt = s0 + wx; wt < s1; wt += wpx) {
+        const int row0 = wt * 64;
+        const int row1 = min(row0 + 64, n_rows);
+        const int r = row0 + lane;
+        int rs = 0, re = 0;
+        if (r < row1) { rs = rowptr[r]; re = rowptr[r + 1]; }
+        const int k0 = __shfl(rs, 0, 64);
+        const int k1 = __shfl(re, row1 - row0 - 1, 64);
+        XT acc = 0;
+        for (int base = k0; base < k1; base += CH) {
+            int c[EPL];
+            VT v[EPL];
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const int e = base + lane + 64 * j;
+                c[j] = 0; v[j] = 0;
+                if (e < k1) { c[j] = cols[e]; v[j] = vals[e]; }
+            }
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const int e = base + lane + 64 * j;
+                XT xv = 0;
+                if (e < k1) xv = x[c[j]];
+                prod[lane + 64 * j] = (XT)v[j] * xv;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const int lo = max(rs, base), hi = min(re, base + CH);
+            for (int k = lo; k < hi; ++k) acc += prod[k - base];
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (r < row1) y[r] = acc;
+    }
+}
+
+struct Mat { int n; long long nnz; int *rowptr, *cols; double *vals; short *cols16; unsigned short *lidx; int4 *desc; };
 
 static Mat build(int layers, int nx, int ny) {
     const long long n = (long long)layers * nx * ny;
@@ -607,6 +945,30 @@ static Mat build(int layers, int nx, int ny) {
         for (int k = rp[i]; k < rp[i + 1]; ++k) c16[k] = (short)(cl[k] - (int)((i / 64) * 64));
     CK(hipMalloc(&m.cols16, sizeof(short) * c16.size()));
     CK(hipMemcpy(m.cols16, c16.data(), sizeof(short) * c16.size(), hipMemcpyHostToDevice));
+    // x-window descriptors: runs start at row0 - nx - 1, row0 - 1, row0 + nx - 1 (72 entries each)
+    const long long nt = (n + 63) / 64;
+    std::vector<int4> ds(nt);
+    std::vector<unsigned short> li(cl.size() + pad, 0);
+    long long bad = 0;
+    for (long long t = 0; t < nt; ++t) {
+        const long long row0 = t * 64;
+        long long st[3] = {row0 - nx - 1, row0 - 1, row0 + nx - 1};
+        for (int q = 0; q < 3; ++q) st[q] = st[q] < 0 ? 0 : st[q];
+        ds[t] = make_int4((int)st[0], (int)st[1], (int)st[2], 0);
+        for (long long i = row0; i < row0 + 64 && i < n; ++i)
+            for (int k = rp[i]; k < rp[i + 1]; ++k) {
+                int found = -1;
+                for (int q = 0; q < 3; ++q)
+                    if (cl[k] >= st[q] && cl[k] < st[q] + 72) { found = q * 72 + (int)(cl[k] - st[q]); break; }
+                if (found < 0) { ++bad; found = 0; }
+                li[k] = (unsigned short)found;
+            }
+    }
+    if (bad) printf("WARNING: %lld columns outside the staged windows\n", bad);
+    CK(hipMalloc(&m.lidx, sizeof(unsigned short) * li.size()));
+    CK(hipMemcpy(m.lidx, li.data(), sizeof(unsigned short) * li.size(), hipMemcpyHostToDevice));
+    CK(hipMalloc(&m.desc, sizeof(int4) * nt));
+    CK(hipMemcpy(m.desc, ds.data(), sizeof(int4) * nt, hipMemcpyHostToDevice));
     return m;
 }
 
@@ -614,7 +976,7 @@ static const char *g_only = nullptr;
 static const char *g_name = nullptr;
 template <typename F> static double timeit(F launch, int reps = 30) {
     if (g_only && !strstr(g_name, g_only)) return -1.0;
-    if (g_only) reps = 3;
+    if (g_only) reps = 20;
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     for (int i = 0; i < 5; ++i) launch();
     CK(hipEventRecord(a));
@@ -678,6 +1040,35 @@ int main(int argc, char **argv) {
       RUN("wave-rr chunk8 grid 2048", [&] { spmv_wave_rr<8, 8><<<2048, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); });
       RUN("wave-rr chunk4 grid 1024", [&] { spmv_wave_rr<8, 4><<<1024, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); });
       RUN("wave-rr chunk4 grid 1536", [&] { spmv_wave_rr<8, 4><<<1536, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); }); }
+    { const int nwt = (m.n + 63) / 64;
+      // single-precision copies (contents irrelevant for the timing: reinterpret the double arrays)
+      const float *vf = (const float *)m.vals; const float *xf = (const float *)x; float *yf = (float *)y;
+      g_name = "mixed f32 vals+x grid 2048"; report(g_name, timeit([&] { spmv_wave_rr_mp<8, float, float><<<2048, 256>>>(m.n, nwt, m.rowptr, m.cols, vf, xf, yf); }), false);
+      g_name = "mixed f32 vals+x grid 4096"; report(g_name, timeit([&] { spmv_wave_rr_mp<8, float, float><<<4096, 256>>>(m.n, nwt, m.rowptr, m.cols, vf, xf, yf); }), false);
+      g_name = "mixed f32 vals, f64 x grid 2048"; report(g_name, timeit([&] { spmv_wave_rr_mp<8, float, double><<<2048, 256>>>(m.n, nwt, m.rowptr, m.cols, vf, x, y); }), false);
+      g_name = "mixed f64 vals, f64 x (check) grid 2048"; report(g_name, timeit([&] { spmv_wave_rr_mp<8, double, double><<<2048, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); }), true); }
+    { const int nwt = (m.n + 63) / 64;
+      RUN("pairs epl4 grid 2048", [&] { spmv_wave_rr_v2<4><<<2048, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); });
+      RUN("pairs epl4 grid 1536", [&] { spmv_wave_rr_v2<4><<<1536, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); });
+      RUN("pairs epl2 grid 2048", [&] { spmv_wave_rr_v2<2><<<2048, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); });
+      RUN("pairs epl2 grid 4096", [&] { spmv_wave_rr_v2<2><<<4096, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); }); }
+    { const int nwt = (m.n + 63) / 64;
+      RUN("xwindow epl8 grid 2048", [&] { spmv_wave_xw<8><<<2048, 256>>>(m.n, nwt, m.rowptr, m.lidx, m.vals, m.desc, x, y); });
+      RUN("xwindow epl8 grid 1536", [&] { spmv_wave_xw<8><<<1536, 256>>>(m.n, nwt, m.rowptr, m.lidx, m.vals, m.desc, x, y); });
+      RUN("xwindow epl8 grid 4096", [&] { spmv_wave_xw<8><<<4096, 256>>>(m.n, nwt, m.rowptr, m.lidx, m.vals, m.desc, x, y); });
+      RUN("xwindow epl4 grid 2048", [&] { spmv_wave_xw<4><<<2048, 256>>>(m.n, nwt, m.rowptr, m.lidx, m.vals, m.desc, x, y); });
+      RUN("xwindow3 epl8 grid 1024", [&] { spmv_wave_xw3<8><<<1024, 256>>>(m.n, nwt, m.rowptr, m.lidx, m.vals, m.desc, x, y); });
+      RUN("xwindow3 epl8 grid 1536", [&] { spmv_wave_xw3<8><<<1536, 256>>>(m.n, nwt, m.rowptr, m.lidx, m.vals, m.desc, x, y); });
+      RUN("xwindow3 epl8 grid 2048", [&] { spmv_wave_xw3<8><<<2048, 256>>>(m.n, nwt, m.rowptr, m.lidx, m.vals, m.desc, x, y); });
+      RUN("xwindow2 epl8 grid 1536", [&] { spmv_wave_xw2<8><<<1536, 256>>>(m.n, nwt, m.rowptr, m.lidx, m.vals, m.desc, x, y); });
+      RUN("xwindow2 epl8 grid 2048", [&] { spmv_wave_xw2<8><<<2048, 256>>>(m.n, nwt, m.rowptr, m.lidx, m.vals, m.desc, x, y); });
+      RUN("xwindow2 epl4 grid 2048", [&] { spmv_wave_xw2<4><<<2048, 256>>>(m.n, nwt, m.rowptr, m.lidx, m.vals, m.desc, x, y); });
+      RUN("xwindow2 epl4 grid 4096", [&] { spmv_wave_xw2<4><<<4096, 256>>>(m.n, nwt, m.rowptr, m.lidx, m.vals, m.desc, x, y); });
+      RUN("xwindow-norowsum epl4 grid 2048", [&] { spmv_wave_xw<4, 1><<<2048, 256>>>(m.n, nwt, m.rowptr, m.lidx, m.vals, m.desc, x, y); });
+      RUN("xwindow-nostage epl4 grid 2048", [&] { spmv_wave_xw<4, 2><<<2048, 256>>>(m.n, nwt, m.rowptr, m.lidx, m.vals, m.desc, x, y); });
+      RUN("xwindow-streamonly epl4 grid 2048", [&] { spmv_wave_xw<4, 3><<<2048, 256>>>(m.n, nwt, m.rowptr, m.lidx, m.vals, m.desc, x, y); });
+      RUN("xwindow-streamonly epl8 grid 2048", [&] { spmv_wave_xw<8, 3><<<2048, 256>>>(m.n, nwt, m.rowptr, m.lidx, m.vals, m.desc, x, y); });
+      RUN("xwindow epl4 grid 4096", [&] { spmv_wave_xw<4><<<4096, 256>>>(m.n, nwt, m.rowptr, m.lidx, m.vals, m.desc, x, y); }); }
     { const int nwt = (m.n + 63) / 64;
       RUN("rowgather epl8 u8 grid 2048", [&] { spmv_wave_rg<8, 8><<<2048, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); });
       RUN("rowgather epl8 u4 grid 2048", [&] { spmv_wave_rg<8, 4><<<2048, 256>>>(m.n, nwt, m.rowptr, m.cols, m.vals, x, y); });

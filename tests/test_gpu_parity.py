@@ -295,18 +295,40 @@ def test_multigrid_hierarchy_is_galerkin_and_partition_of_unity(ctx):
         assert P.shape[1] < 0.5 * P.shape[0]
 
 
-def test_multigrid_preconditioner_is_symmetric_positive_definite(ctx):
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_multigrid_preconditioner_is_symmetric_positive_definite(ctx, monkeypatch, precision):
+    """The cycle runs on single-precision copies of its operators by default (PADNE_AMG_F64=1: double): a fixed
+    linear SPD operator up to the rounding of the working precision."""
+    if precision == "f64":
+        monkeypatch.setenv("PADNE_AMG_F64", "1")
+    tol = 1e-10 if precision == "f64" else 2e-5
     A, b, _, _, _ = layered_spd(2, 70, 60, 4)
     d = ctx.csr_from_scipy(A)
     rng = np.random.default_rng(5)
     r1, r2 = rng.uniform(-1, 1, (2, A.shape[0]))
     z1, z2 = d.amg_apply(r1), d.amg_apply(r2)
-    assert abs(r2 @ z1 - r1 @ z2) <= 1e-10 * (np.linalg.norm(r1) * np.linalg.norm(z2))
+    assert abs(r2 @ z1 - r1 @ z2) <= tol * (np.linalg.norm(r1) * np.linalg.norm(z2))
     assert r1 @ z1 > 0 and r2 @ z2 > 0
     # linear: M(a r1 + b r2) = a M r1 + b M r2
     z12 = d.amg_apply(2.0 * r1 - 3.0 * r2)
-    assert np.abs(z12 - (2.0 * z1 - 3.0 * z2)).max() <= 1e-10 * np.abs(z12).max()
+    assert np.abs(z12 - (2.0 * z1 - 3.0 * z2)).max() <= tol * np.abs(z12).max()
     assert np.array_equal(d.amg_apply(r1), z1)                          # deterministic
+    # both precisions precondition the same operator: M32 r = M64 r to single-precision rounding
+    if precision == "f32":
+        monkeypatch.setenv("PADNE_AMG_F64", "1")
+        d64 = ctx.csr_from_scipy(A)
+        assert np.abs(d64.amg_apply(r1) - z1).max() <= 2e-5 * np.abs(z1).max()
+
+
+def test_single_precision_cycle_is_independent_of_the_units_of_the_system(ctx):
+    """The cycle input is normalised by ||b||, so right-hand sides of 1e-30 A or 1e+30 A converge like 1 A ones."""
+    A, b, _, _, _ = layered_spd(2, 70, 60, 4)
+    d = ctx.csr_from_scipy(A)
+    base = d.solve_spd(b, precond="amg")
+    for scale in (1e-30, 1e30):
+        res = d.solve_spd(b * scale, precond="amg")
+        assert res.precond_fallbacks == 0 and abs(res.iterations - base.iterations) <= 1
+        assert np.abs(res.x / scale - base.x).max() <= 1e-9 * np.abs(base.x).max()
 
 
 def test_multigrid_and_jacobi_agree_with_the_direct_solve(ctx):
