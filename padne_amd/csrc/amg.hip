@@ -1008,11 +1008,12 @@ static bool amg_verbose() {
 }
 
 static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0);
+static int host_allgather(padne_ctx *ctx, const std::vector<double> &mine, std::vector<double> &all);
 
 // Single-precision cycle (default; PADNE_AMG_F64=1 keeps double): float copies of every level operator.  Skipped
 // when 1/diag of the fine matrix leaves [1e-15, 1e15] (the cycle input is normalised, the operator is not).
 static int enable_f32(padne_ctx *ctx, Amg *amg) {
-    if (getenv("PADNE_AMG_F64") != nullptr || amg->dist || amg->levels.size() < 2) return PADNE_OK;
+    if (getenv("PADNE_AMG_F64") != nullptr || amg->levels.size() < 2) return PADNE_OK;
     if (amg->levels[0].A->hierarchy_operator) return PADNE_OK;   // the gathered tail of a row-partitioned hierarchy
     hipStream_t s = ctx->stream;
     const padne_csr *A0 = amg->levels[0].A;
@@ -1030,6 +1031,15 @@ static int enable_f32(padne_ctx *ctx, Amg *amg) {
         lo = std::min(lo, h[(size_t)i]);
         if (h[(size_t)g + i] > hi || !(h[(size_t)g + i] == h[(size_t)g + i])) hi = h[(size_t)g + i];
     }
+    if (amg->dist) {
+        // the same decision on every rank
+        std::vector<double> mine = {lo, hi}, all;
+        PADNE_TRY(host_allgather(ctx, mine, all));
+        for (int q = 0; q < ctx->world; ++q) {
+            lo = std::min(lo, all[(size_t)q * 2]);
+            if (all[(size_t)q * 2 + 1] > hi || !(all[(size_t)q * 2 + 1] == all[(size_t)q * 2 + 1])) hi = all[(size_t)q * 2 + 1];
+        }
+    }
     if (!(lo >= 1e-15) || !(hi <= 1e15)) return PADNE_OK;
     for (AmgLevel &L : amg->levels) {
         PADNE_TRY(csr_build_f32(ctx, const_cast<padne_csr *>(L.A)));
@@ -1037,7 +1047,7 @@ static int enable_f32(padne_ctx *ctx, Amg *amg) {
         if (L.R) PADNE_TRY(csr_build_f32(ctx, L.R));
     }
     if (amg->levels[0].b == nullptr) PADNE_TRY(alloc_vec(ctx, &amg->levels[0].b, amg->levels[0].n));
-    if (amg->n_coarse > 0) {
+    if (!amg->dist && amg->n_coarse > 0) {
         const size_t cnt = (size_t)amg->n_coarse * (size_t)amg->n_coarse;
         amg->coarse_inv32 = (float *)pool_alloc(ctx, sizeof(float) * cnt);
         if (amg->coarse_inv32 == nullptr) return PADNE_E_NOMEM;
@@ -1364,13 +1374,21 @@ static int exchange_prolongator_rows(padne_ctx *ctx, const AmgLevel &L, const pa
 }
 
 // padded per-rank pieces [world][n_pad] -> the gathered vector [sum n_q]
-__global__ void compact_pieces(int world, int n_pad, const int *__restrict__ seg_off, const double *__restrict__ src,
+template <typename T>
+__global__ void compact_pieces(int world, int n_pad, const int *__restrict__ seg_off, const T *__restrict__ src,
                                double *__restrict__ dst, const int *__restrict__ done_flag) {
     if (done_flag != nullptr && *done_flag != 0) return;
     const int q = blockIdx.y;
     const int nq = seg_off[q + 1] - seg_off[q];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += gridDim.x * blockDim.x)
-        dst[seg_off[q] + i] = src[(size_t)q * n_pad + i];
+        dst[seg_off[q] + i] = (double)src[(size_t)q * n_pad + i];
+}
+
+__global__ void f32_from_f64_kernel(long long n, const double *__restrict__ src, float *__restrict__ dst,
+                                    const int *__restrict__ done_flag) {
+    if (done_flag != nullptr && *done_flag != 0) return;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (float)src[i];
 }
 
 // this rank's piece of the gather level as one record of doubles: rowptr[n_pad + 1] | cols[nnz_max] (already in
@@ -1639,6 +1657,10 @@ static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0) {
         return rc;
     }
     amg->operator_complexity = nnz_total / (double)(A0->nnz > 0 ? A0->nnz : 1);
+    if ((rc = enable_f32(ctx, amg)) != PADNE_OK) {
+        amg_destroy(amg);
+        return rc;
+    }
     PADNE_HIP_CHECK(hipStreamSynchronize(s));
     amg->setup_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     A0->amg = amg;
@@ -1646,6 +1668,9 @@ static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0) {
 }
 
 // z = M^-1 r on level 0 ; optional partial sums of r.z (written by the last kernel of the cycle)
+int amg_apply(padne_ctx *ctx, const padne_csr *A0, const double *r, double *z, double *partials_rz,
+              const int32_t *done_flag, const double *bb2);
+
 // the same cycle on the single-precision copies; r comes in and z goes out in double
 static int amg_apply_f32(padne_ctx *ctx, Amg *amg, const double *r, double *z, double *partials_rz,
                          const int32_t *done_flag, const double *bb2) {
@@ -1659,6 +1684,21 @@ static int amg_apply_f32(padne_ctx *ctx, Amg *amg, const double *r, double *z, d
         AmgLevel &L = amg->levels[l];
         float *b = (float *)L.b, *xa = (float *)L.xa, *tmp = (float *)L.tmp;
         if (l == nl - 1) {
+            if (amg->dist) {
+                // gather level: float pieces travel, the redundant tail cycle runs in double (launch-bound anyway)
+                float *cg = (float *)amg->coarse_gather;
+                float *seg = cg + (size_t)ctx->rank * amg->n_pad;
+                PADNE_HIP_CHECK(hipMemcpyAsync(seg, b, sizeof(float) * (size_t)L.n, hipMemcpyDeviceToDevice, s));
+                PADNE_TRY(comm_allgather_f32(ctx, seg, cg, amg->n_pad));
+                hipLaunchKernelGGL(compact_pieces<float>, dim3(nblk(amg->n_pad), ctx->world), dim3(256), 0, s, ctx->world,
+                                   amg->n_pad, amg->seg_off, (const float *)cg, amg->tail_r, done_flag);
+                PADNE_HIP_CHECK(hipGetLastError());
+                PADNE_TRY(amg_apply(ctx, amg->tail, amg->tail_r, amg->tail_z, nullptr, done_flag, nullptr));
+                hipLaunchKernelGGL(f32_from_f64_kernel, dim3(nblk(L.n)), dim3(256), 0, s, L.n,
+                                   (const double *)(amg->tail_z + amg->tail_off), (float *)L.xb, done_flag);
+                PADNE_HIP_CHECK(hipGetLastError());
+                break;
+            }
             hipLaunchKernelGGL(dense_gemv<float>, dim3((amg->n_coarse + 3) / 4), dim3(256), 0, s, amg->n_coarse,
                                amg->n_coarse, (const float *)amg->coarse_inv32, (const float *)b, (float *)L.xb);
             PADNE_HIP_CHECK(hipGetLastError());
@@ -1672,6 +1712,7 @@ static int amg_apply_f32(padne_ctx *ctx, Amg *amg, const double *r, double *z, d
             hipLaunchKernelGGL(scale_dinv_kernel<float>, dim3(gv > 0 ? gv : 1), dim3(256), 0, s, L.n, (float)L.jac,
                                (const float *)L.A->dinv32, (const float *)b, xa, done_flag);
         PADNE_HIP_CHECK(hipGetLastError());
+        if (amg->dist) PADNE_TRY(halo_exchange_plan_f32(ctx, L.halo, xa, done_flag));
         PADNE_TRY(launch_spmv_f32(ctx, L.A, SPMV_RESID, xa, tmp, nullptr, done_flag, b, nullptr, 0.f));
         PADNE_TRY(launch_spmv_f32(ctx, L.R, SPMV_PLAIN, tmp, (float *)amg->levels[l + 1].b, nullptr, done_flag, nullptr,
                                   nullptr, 0.f));
@@ -1681,6 +1722,7 @@ static int amg_apply_f32(padne_ctx *ctx, Amg *amg, const double *r, double *z, d
         float *b = (float *)L.b, *xa = (float *)L.xa;
         PADNE_TRY(launch_spmv_f32(ctx, L.P, SPMV_ADD, (const float *)amg->levels[l + 1].xb, xa, nullptr, done_flag,
                                   nullptr, nullptr, 0.f));
+        if (amg->dist) PADNE_TRY(halo_exchange_plan_f32(ctx, L.halo, xa, done_flag));
         if (l > 0)
             PADNE_TRY(launch_spmv_f32(ctx, L.A, SPMV_JACOBI, xa, (float *)L.xb, nullptr, done_flag, b, L.A->dinv32,
                                       (float)L.jac));
@@ -1707,8 +1749,8 @@ int amg_apply(padne_ctx *ctx, const padne_csr *A0, const double *r, double *z, d
                 double *seg = amg->coarse_gather + (size_t)ctx->rank * amg->n_pad;
                 PADNE_HIP_CHECK(hipMemcpyAsync(seg, b, sizeof(double) * (size_t)L.n, hipMemcpyDeviceToDevice, s));
                 PADNE_TRY(comm_allgather_f64(ctx, seg, amg->coarse_gather, amg->n_pad));
-                hipLaunchKernelGGL(compact_pieces, dim3(nblk(amg->n_pad), ctx->world), dim3(256), 0, s, ctx->world,
-                                   amg->n_pad, amg->seg_off, amg->coarse_gather, amg->tail_r, done_flag);
+                hipLaunchKernelGGL(compact_pieces<double>, dim3(nblk(amg->n_pad), ctx->world), dim3(256), 0, s, ctx->world,
+                                   amg->n_pad, amg->seg_off, (const double *)amg->coarse_gather, amg->tail_r, done_flag);
                 PADNE_HIP_CHECK(hipGetLastError());
                 PADNE_TRY(amg_apply(ctx, amg->tail, amg->tail_r, amg->tail_z, nullptr, done_flag, nullptr));
                 PADNE_HIP_CHECK(hipMemcpyAsync(out, amg->tail_z + amg->tail_off, sizeof(double) * (size_t)L.n,

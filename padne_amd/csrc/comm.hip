@@ -15,7 +15,7 @@ namespace padne {
 typedef struct { char internal[128]; } ncclUniqueId;
 typedef void *ncclComm_t;
 enum { ncclSuccess = 0 };
-enum { ncclFloat64 = 8 };   // ncclDataType_t: double
+enum { ncclFloat32 = 7, ncclFloat64 = 8 };   // ncclDataType_t: float, double
 enum { ncclSum = 0 };
 
 struct Rccl {
@@ -118,18 +118,20 @@ static int team_allreduce(padne_ctx *ctx, double *dev_buf, int count) {
     return PADNE_OK;
 }
 
-static int team_allgather(padne_ctx *ctx, const double *send, double *recv, int count_per_rank) {
+static int team_allgather(padne_ctx *ctx, const void *send_v, void *recv_v, size_t bytes_per_rank) {
+    const char *send = (const char *)send_v;
+    char *recv = (char *)recv_v;
     Team *t = (Team *)ctx->team;
     PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));          // my segment is complete
     {
         std::lock_guard<std::mutex> lk(t->mu);
-        t->ptrs[(size_t)ctx->rank] = send;
+        t->ptrs[(size_t)ctx->rank] = (const double *)send_v;
     }
     team_barrier(t);
     for (int r = 0; r < t->world; ++r) {
-        if (r == ctx->rank && send == recv + (size_t)r * count_per_rank) continue;   // in place
-        PADNE_HIP_CHECK(hipMemcpyAsync(recv + (size_t)r * count_per_rank, t->ptrs[(size_t)r],
-                                       sizeof(double) * (size_t)count_per_rank, hipMemcpyDeviceToDevice, ctx->stream));
+        if (r == ctx->rank && send == recv + (size_t)r * bytes_per_rank) continue;   // in place
+        PADNE_HIP_CHECK(hipMemcpyAsync(recv + (size_t)r * bytes_per_rank, t->ptrs[(size_t)r], bytes_per_rank,
+                                       hipMemcpyDeviceToDevice, ctx->stream));
     }
     PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     team_barrier(t);                 // peers may now overwrite their segments
@@ -145,9 +147,17 @@ int comm_allreduce_sum_f64(padne_ctx *ctx, double *dev_buf, int count) {
 
 int comm_allgather_f64(padne_ctx *ctx, const double *send, double *recv, int count_per_rank) {
     if (count_per_rank == 0) return PADNE_OK;
-    if (ctx->team != nullptr) return team_allgather(ctx, send, recv, count_per_rank);
+    if (ctx->team != nullptr) return team_allgather(ctx, send, recv, sizeof(double) * (size_t)count_per_rank);
     if (ctx->comm == nullptr) return PADNE_OK;
     return check_nccl(g_rccl.AllGather(send, recv, (size_t)count_per_rank, ncclFloat64, (ncclComm_t)ctx->comm,
+                                       ctx->stream), "ncclAllGather");
+}
+
+int comm_allgather_f32(padne_ctx *ctx, const float *send, float *recv, int count_per_rank) {
+    if (count_per_rank == 0) return PADNE_OK;
+    if (ctx->team != nullptr) return team_allgather(ctx, send, recv, sizeof(float) * (size_t)count_per_rank);
+    if (ctx->comm == nullptr) return PADNE_OK;
+    return check_nccl(g_rccl.AllGather(send, recv, (size_t)count_per_rank, ncclFloat32, (ncclComm_t)ctx->comm,
                                        ctx->stream), "ncclAllGather");
 }
 

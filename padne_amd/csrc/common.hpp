@@ -122,6 +122,7 @@ int exclusive_scan_i32(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t 
 // comm.cpp
 int comm_allreduce_sum_f64(padne_ctx *ctx, double *dev_buf, int count);
 int comm_allgather_f64(padne_ctx *ctx, const double *send, double *recv, int count_per_rank);
+int comm_allgather_f32(padne_ctx *ctx, const float *send, float *recv, int count_per_rank);
 void comm_destroy(padne_ctx *ctx);
 
 // exchange plan of a row-partitioned operator: vectors are [n_owned | world * m exchanged values]; every
@@ -132,6 +133,7 @@ struct HaloPlan {
     const int32_t *export_idx = nullptr;   // device
 };
 int halo_exchange_plan(padne_ctx *ctx, const HaloPlan &plan, double *v, const int32_t *done_flag);
+int halo_exchange_plan_f32(padne_ctx *ctx, const HaloPlan &plan, float *v, const int32_t *done_flag);
 
 // amg.hip
 void amg_destroy(void *amg);

@@ -271,7 +271,8 @@ static inline double *slot(padne_ctx *ctx, int s) { return ctx->partials + (size
 
 // gathers the owned values other ranks need into this rank's segment of the exchange buffer that
 // sits behind the owned entries:  v[n_owned + rank*M + k] = v[export_idx[k]]
-__global__ void halo_pack_kernel(double *__restrict__ v, const int *__restrict__ export_idx, int n_export,
+template <typename T>
+__global__ void halo_pack_kernel(T *__restrict__ v, const int *__restrict__ export_idx, int n_export,
                                  long long dst_offset, const int *__restrict__ done_flag) {
     if (done_flag != nullptr && *done_flag != 0) return;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -285,11 +286,22 @@ int halo_exchange_plan(padne_ctx *ctx, const HaloPlan &plan, double *v, const in
     if (plan.m <= 0) return PADNE_OK;
     const long long seg_off = plan.n_owned + (long long)ctx->rank * plan.m;
     if (plan.n_export > 0) {
-        hipLaunchKernelGGL(halo_pack_kernel, dim3((plan.n_export + 255) / 256), dim3(256), 0, ctx->stream, v,
+        hipLaunchKernelGGL(halo_pack_kernel<double>, dim3((plan.n_export + 255) / 256), dim3(256), 0, ctx->stream, v,
                            plan.export_idx, plan.n_export, seg_off, done_flag);
         PADNE_HIP_CHECK(hipGetLastError());
     }
     return comm_allgather_f64(ctx, v + seg_off, v + plan.n_owned, plan.m);
+}
+
+int halo_exchange_plan_f32(padne_ctx *ctx, const HaloPlan &plan, float *v, const int32_t *done_flag) {
+    if (plan.m <= 0) return PADNE_OK;
+    const long long seg_off = plan.n_owned + (long long)ctx->rank * plan.m;
+    if (plan.n_export > 0) {
+        hipLaunchKernelGGL(halo_pack_kernel<float>, dim3((plan.n_export + 255) / 256), dim3(256), 0, ctx->stream, v,
+                           plan.export_idx, plan.n_export, seg_off, done_flag);
+        PADNE_HIP_CHECK(hipGetLastError());
+    }
+    return comm_allgather_f32(ctx, v + seg_off, v + plan.n_owned, plan.m);
 }
 
 static int halo_exchange(padne_ctx *ctx, double *v, const int32_t *done_flag) {
