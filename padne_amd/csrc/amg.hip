@@ -467,6 +467,140 @@ __global__ __launch_bounds__(128) void spgemm_rows_lds(int n_rows, const int *__
     row_len[i] = m;
 }
 
+// Wave-per-row variant for rows with tens to hundreds of products (R * (A P) on every level, A * P below the
+// finest): the thread-per-row list kernels above serialise ~100 sorted insertions per thread, this one spreads a
+// row over the 64 lanes of a wave.
+//   1. lanes = entries of the X row: lengths of the Y rows they select, wave prefix sum -> product offsets;
+//   2. the products (column, x*y) are written to LDS in generation order (k, q), lane-strided;
+//   3. distinct columns: open-addressing hash set in LDS (integer CAS only), compacted and rank-sorted;
+//   4. lane j owns the j-th distinct column and adds ITS products in generation order while all lanes walk the
+//      product list together (broadcast LDS reads) -> bit-identical to spgemm_rows, no float atomics.
+// Rows that do not fit (X row > 64 entries, > CAPP products, > HT/2 distinct columns) are flagged for spgemm_rows_redo.
+template <int CAPP, int HT>
+__global__ __launch_bounds__(256) void spgemm_rows_wave(int n_rows, const int *__restrict__ xr, const int *__restrict__ xc,
+                                                        const double *__restrict__ xv, const int *__restrict__ yr,
+                                                        const int *__restrict__ yc, const double *__restrict__ yv,
+                                                        const int *__restrict__ slot_ptr, long long *__restrict__ key,
+                                                        double *__restrict__ val, int *__restrict__ row_len) {
+    __shared__ int s_pc[4][CAPP];
+    __shared__ double s_pv[4][CAPP];
+    __shared__ int s_ht[4][HT];
+    __shared__ int s_dk[4][HT / 2];
+    __shared__ int s_sk[4][HT / 2];
+    __shared__ int s_off[4][65];
+    __shared__ int s_ys[4][64];
+    __shared__ double s_xv[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int *pc = s_pc[w], *ht = s_ht[w], *dk = s_dk[w], *sk = s_sk[w], *off = s_off[w], *ys = s_ys[w];
+    double *pv = s_pv[w], *xs = s_xv[w];
+    constexpr int EMPTY = -1;
+    for (int i = blockIdx.x * 4 + w; i < n_rows; i += gridDim.x * 4) {
+        const int x0 = xr[i], nx = xr[i + 1] - x0;
+        if (nx > 64) {
+            if (lane == 0) row_len[i] = -1;
+            continue;
+        }
+        // 1. product offsets
+        int len = 0, ystart = 0;
+        double a = 0.0;
+        if (lane < nx) {
+            const int mid = xc[x0 + lane];
+            a = xv[x0 + lane];
+            ystart = yr[mid];
+            len = yr[mid + 1] - ystart;
+        }
+        int incl = len;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        const int np = __shfl(incl, 63, 64);
+        if (np > CAPP) {
+            if (lane == 0) row_len[i] = -1;
+            continue;
+        }
+        off[lane] = incl - len;
+        if (lane == 63) off[64] = np;
+        ys[lane] = ystart;
+        xs[lane] = a;
+        for (int h = lane; h < HT; h += 64) ht[h] = EMPTY;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // 2. products in generation order, 3a. hash-set insertion of their columns
+        bool overflow = false;
+        for (int p = lane; p < np; p += 64) {
+            int lo = 0, hi = nx;                       // largest k with off[k] <= p
+            while (hi - lo > 1) {
+                const int m = (lo + hi) >> 1;
+                if (off[m] <= p) lo = m; else hi = m;
+            }
+            const int q = ys[lo] + (p - off[lo]);
+            const int c = yc[q];
+            pc[p] = c;
+            pv[p] = xs[lo] * yv[q];
+            unsigned h = ((unsigned)c * 2654435761u) >> 7;
+            int probes = 0;
+            for (;;) {
+                h &= (HT - 1);
+                const int old = atomicCAS(&ht[h], EMPTY, c);
+                if (old == EMPTY || old == c) break;
+                ++h;
+                if (++probes >= HT) { overflow = true; break; }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // 3b. compact the table into dk[0..nd)
+        int nd = 0;
+        for (int h0 = 0; h0 < HT; h0 += 64) {
+            const int kv = ht[h0 + lane];
+            const unsigned long long mask = __ballot(kv != EMPTY);
+            const int pos = nd + __popcll(mask & ((1ull << lane) - 1ull));
+            if (kv != EMPTY && pos < HT / 2) dk[pos] = kv;
+            nd += __popcll(mask);
+        }
+        if (__any(overflow) || nd > HT / 2) {
+            if (lane == 0) row_len[i] = -1;
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // 3c. rank sort (keys are distinct)
+        for (int q = lane; q < nd; q += 64) {
+            const int kq = dk[q];
+            int rank = 0;
+            for (int t = 0; t < nd; ++t) rank += dk[t] < kq ? 1 : 0;
+            sk[rank] = kq;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // 4. every lane sums the products of its column(s) in generation order
+        long long *K = key + slot_ptr[i];
+        double *V = val + slot_ptr[i];
+        for (int q0 = 0; q0 < nd; q0 += 64) {
+            const int q = q0 + lane;
+            const int col = q < nd ? sk[q] : EMPTY;
+            double acc = 0.0;
+            bool first = true;
+            for (int p = 0; p < np; ++p) {
+                if (pc[p] == col) {
+                    const double v = pv[p];
+                    acc = first ? v : acc + v;
+                    first = false;
+                }
+            }
+            if (q < nd) {
+                K[q] = (long long)col << 32;
+                V[q] = acc;
+            }
+        }
+        if (lane == 0) row_len[i] = nd;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // One workgroup per row with a dense accumulator in LDS (coarse levels: few thousand columns, long rows).
 // The X entries of the row are processed one after another and the lanes spread over the Y row, whose
 // columns are distinct, so every accumulator cell sees its products in the same order as spgemm_rows.
@@ -567,16 +701,70 @@ __global__ void dense_from_csr(int n, const int *__restrict__ rowptr, const int 
     for (int k = rowptr[i] + threadIdx.x; k < rowptr[i + 1]; k += blockDim.x) W[(size_t)i * 2 * n + cols[k]] = vals[k];
 }
 
-// One Gauss-Jordan step, ping-pong between two copies of [A | I] so that one launch per pivot suffices: every
-// entry reads the OLD pivot row / column from `in` and writes the new value to `out`.
-__global__ __launch_bounds__(256) void gj_step(int n, int k, const double *__restrict__ in, double *__restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = blockIdx.y;
-    if (c >= 2 * n) return;
+// Blocked Gauss-Jordan, ping-pong between two copies of [A | I]: one launch eliminates kGjBlock pivots at once
+// (814 launches of a 5 us kernel were 10 % of the multigrid setup).  With D the kGjBlock x kGjBlock pivot block,
+// the pivot rows become D^-1 W[K, :] and every other row i loses W[i, K] times that; each thread owns one column
+// of a strip of rows, forms its column of D^-1 W[K, :] once and applies it down the strip.  No pivoting (the
+// coarse operators are symmetric positive definite); every entry reads the OLD matrix and writes the new one.
+constexpr int kGjBlock = 8;
+constexpr int kGjStrip = 32;
+__global__ __launch_bounds__(256) void gj_block_step(int n, int k0, const double *__restrict__ in, double *__restrict__ out) {
+    __shared__ double Dinv[kGjBlock][kGjBlock];
+    __shared__ double Lcol[kGjStrip][kGjBlock];      // W[i, K] of the strip's rows
     const size_t w = (size_t)2 * n;
-    const double piv = in[(size_t)k * w + k];
-    const double prow = in[(size_t)k * w + c] / piv;
-    out[(size_t)r * w + c] = (r == k) ? prow : in[(size_t)r * w + c] - in[(size_t)r * w + k] * prow;
+    const int bs = min(kGjBlock, n - k0);
+    const int r0 = blockIdx.y * kGjStrip;
+    // pivot block inverse: Gauss-Jordan on [D | I] in LDS, one thread per entry, and the strip's multipliers
+    __shared__ double Daug[kGjBlock][2 * kGjBlock];
+    const int ea = threadIdx.x / (2 * kGjBlock), eb = threadIdx.x % (2 * kGjBlock);
+    const bool entry = threadIdx.x < kGjBlock * 2 * kGjBlock;
+    if (entry) {
+        double v;
+        if (eb < kGjBlock) v = (ea < bs && eb < bs) ? in[(size_t)(k0 + ea) * w + k0 + eb] : (ea == eb ? 1.0 : 0.0);
+        else v = (eb - kGjBlock == ea) ? 1.0 : 0.0;
+        Daug[ea][eb] = v;
+    }
+    __syncthreads();
+    for (int p = 0; p < kGjBlock; ++p) {
+        double v = 0.0;
+        if (entry) {
+            const double prow = Daug[p][eb] / Daug[p][p];
+            v = (ea == p) ? prow : Daug[ea][eb] - Daug[ea][p] * prow;
+        }
+        __syncthreads();
+        if (entry) Daug[ea][eb] = v;
+        __syncthreads();
+    }
+    if (entry && eb >= kGjBlock) Dinv[ea][eb - kGjBlock] = Daug[ea][eb];
+    for (int t = threadIdx.x; t < kGjStrip * kGjBlock; t += blockDim.x) {
+        const int i = r0 + t / kGjBlock, b = t % kGjBlock;
+        Lcol[t / kGjBlock][b] = (i < n && b < bs) ? in[(size_t)i * w + k0 + b] : 0.0;
+    }
+    __syncthreads();
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= 2 * n) return;
+    double P[kGjBlock], R[kGjBlock];
+#pragma unroll
+    for (int b = 0; b < kGjBlock; ++b) P[b] = b < bs ? in[(size_t)(k0 + b) * w + c] : 0.0;
+#pragma unroll
+    for (int a = 0; a < kGjBlock; ++a) {
+        double sum = 0.0;
+#pragma unroll
+        for (int b = 0; b < kGjBlock; ++b) sum += Dinv[a][b] * P[b];
+        R[a] = sum;
+    }
+    const int r1 = min(r0 + kGjStrip, n);
+    for (int i = r0; i < r1; ++i) {
+        double v;
+        if (i >= k0 && i < k0 + bs) {
+            v = R[i - k0];
+        } else {
+            v = in[(size_t)i * w + c];
+#pragma unroll
+            for (int b = 0; b < kGjBlock; ++b) v -= Lcol[i - r0][b] * R[b];
+        }
+        out[(size_t)i * w + c] = v;
+    }
 }
 
 __global__ void dense_extract_inverse(int n, const double *__restrict__ W, double *__restrict__ inv) {
@@ -907,13 +1095,20 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
                                       (int)dense_lds);
             hipLaunchKernelGGL(spgemm_rows_dense, dim3(n), dim3(256), dense_lds, s, (int)Y->n_cols, X->rowptr, X->cols,
                                X->vals, Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len);
-        } else if (avg <= 160.0) {
-            // short rows: sorted lists in LDS, the few overflowing rows are redone in global memory
-            if (avg <= 24.0)   // A*P on the fine levels: a dozen distinct columns at most -> small lists, more waves per CU
-                hipLaunchKernelGGL(spgemm_rows_lds<16>, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
+        } else if (avg <= 24.0 && getenv("PADNE_SPGEMM_WAVE_ALL") == nullptr) {
+            // A*P on the fine levels: a dozen products per row -> one thread per row with small sorted lists in LDS
+            hipLaunchKernelGGL(spgemm_rows_lds<16>, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
+                               Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len);
+            hipLaunchKernelGGL(spgemm_rows_redo, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
+                               Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len);
+        } else if (avg <= 256.0) {
+            // tens to hundreds of products per row: one wave per row, the rows that do not fit are redone in global memory
+            const unsigned gw = (unsigned)std::min<long long>(((long long)n + 3) / 4, 16384);
+            if (avg <= 110.0)   // short rows: small LDS footprint, twice the waves per CU to hide the dependent gathers
+                hipLaunchKernelGGL((spgemm_rows_wave<256, 128>), dim3(gw), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
                                    Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len);
             else
-                hipLaunchKernelGGL(spgemm_rows_lds<32>, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
+                hipLaunchKernelGGL((spgemm_rows_wave<512, 256>), dim3(gw), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
                                    Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len);
             hipLaunchKernelGGL(spgemm_rows_redo, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
                                Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len);
@@ -937,10 +1132,10 @@ static int dense_inverse(padne_ctx *ctx, const padne_csr *A, double **inv_out) {
     if (inv == nullptr) return PADNE_E_NOMEM;
     if (n > 0) {
         hipLaunchKernelGGL(dense_from_csr, dim3(n), dim3(256), 0, s, n, A->rowptr, A->cols, A->vals, W);
-        const dim3 ge(nblk(2 * n), n);
+        const dim3 ge(nblk(2 * n), (unsigned)((n + kGjStrip - 1) / kGjStrip));
         double *src = W, *dst = W2;
-        for (int k = 0; k < n; ++k) {
-            hipLaunchKernelGGL(gj_step, ge, dim3(256), 0, s, n, k, src, dst);
+        for (int k = 0; k < n; k += kGjBlock) {
+            hipLaunchKernelGGL(gj_block_step, ge, dim3(256), 0, s, n, k, src, dst);
             std::swap(src, dst);
         }
         hipLaunchKernelGGL(dense_extract_inverse, dim3(nblk(n), n), dim3(256), 0, s, n, src, inv);
