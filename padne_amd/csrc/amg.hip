@@ -91,6 +91,20 @@ __device__ __forceinline__ unsigned long long prio_of(int i) {
     return ((unsigned long long)h << 32) | (unsigned int)(i + 1);
 }
 
+// 32-bit competition word of the MIS rounds: 0 = decided (covered), kMisRoot = root, otherwise a priority that
+// is unique per vertex (bijective 31-bit mix of the index, + 1)
+constexpr unsigned int kMisRoot = 0xffffffffu;
+__device__ __forceinline__ unsigned int prio32_of(int i) {
+    unsigned int h = (unsigned int)i & 0x7fffffffu;
+    h = (h * 0x5bd1e995u) & 0x7fffffffu;      // odd multiplier: a bijection modulo 2^31
+    h ^= h >> 15;
+    h = (h * 0x2c1b3c6du) & 0x7fffffffu;
+    h ^= h >> 13;
+    h = (h * 0x297a2d39u) & 0x7fffffffu;
+    h ^= h >> 16;
+    return h + 1u;
+}
+
 __device__ __forceinline__ bool strong(double a, double di, double dj, double theta2) {
     return a * a * di * dj >= theta2;   // a_ij^2 >= theta^2 a_ii a_jj with d = 1/a_ii
 }
@@ -137,21 +151,21 @@ __global__ void strength_fill(int n, const int *__restrict__ rowptr, const int *
 
 // out[i] = max(in[i], max over the strong neighbours j of in[j]).  Same wave-private, lane-consecutive
 // streaming as the SpMV kernel (spmv.hip): 64 rows per wave, neighbour values parked in LDS, one lane per row.
+template <typename T>
 __global__ __launch_bounds__(256) void nbr_max(int n, int n_wtiles, const int *__restrict__ srow,
-                                               const int *__restrict__ scol,
-                                               const unsigned long long *__restrict__ in,
-                                               unsigned long long *__restrict__ out) {
+                                               const int *__restrict__ scol, const T *__restrict__ in,
+                                               T *__restrict__ out) {
     constexpr int CH = 512;
-    __shared__ unsigned long long park_all[4 * CH];
+    __shared__ T park_all[4 * CH];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    unsigned long long *park = park_all + w * CH;
+    T *park = park_all + w * CH;
     const long long W = (long long)gridDim.x * 4, gw = (long long)blockIdx.x * 4 + w;
     for (long long wt = gw; wt < n_wtiles; wt += W) {
         const int row0 = (int)wt * 64;
         const int row1 = min(row0 + 64, n);
         const int r = row0 + lane;
         int rs = 0, re = 0;
-        unsigned long long m = 0ull;
+        T m = 0;
         if (r < row1) {
             rs = srow[r];
             re = srow[r + 1];
@@ -163,13 +177,13 @@ __global__ __launch_bounds__(256) void nbr_max(int n, int n_wtiles, const int *_
 #pragma unroll
             for (int j = 0; j < CH / 64; ++j) {
                 const int e = base + lane + 64 * j;
-                park[lane + 64 * j] = (e < k1) ? in[scol[e]] : 0ull;
+                park[lane + 64 * j] = (e < k1) ? in[scol[e]] : (T)0;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
             const int lo = max(rs, base), hi = min(re, base + CH);
             for (int k = lo; k < hi; ++k) {
-                const unsigned long long v = park[k - base];
+                const T v = park[k - base];
                 m = v > m ? v : m;
             }
             asm volatile("" ::: "memory");
@@ -177,6 +191,34 @@ __global__ __launch_bounds__(256) void nbr_max(int n, int n_wtiles, const int *_
         }
         if (r < row1) out[r] = m;
     }
+}
+
+// One round of the distance-2 independent set on the competition words (Bell, Dalton, Olson: MIS-k).  m2 is the
+// maximum of the words within two strong hops.  An undecided vertex that sees a root is covered; one that sees
+// nothing above its own priority becomes a root (the vertices around it are covered in the next round).
+__global__ void mis_init_words(int n, unsigned int *__restrict__ word) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) word[i] = prio32_of(i);
+}
+
+__global__ void mis_decide(int n, unsigned int *__restrict__ word, const unsigned int *__restrict__ m2,
+                           signed char *__restrict__ state, int *__restrict__ undecided) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool open = false;
+    if (i < n && state[i] == 0) {
+        const unsigned int mine = word[i], top = m2[i];
+        if (top == kMisRoot) {
+            state[i] = 2;
+            word[i] = 0u;
+        } else if (top == mine) {
+            state[i] = 1;
+            word[i] = kMisRoot;
+            open = true;          // its neighbourhood is still to be covered
+        } else {
+            open = true;
+        }
+    }
+    if (__ballot(open) != 0ull && (threadIdx.x & 63) == 0) *undecided = 1;   // only "any left?" matters (benign race)
 }
 
 __global__ void mis_mark_roots(int n, signed char *__restrict__ state, const unsigned long long *__restrict__ m2) {
@@ -903,16 +945,13 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
     PADNE_HIP_CHECK(hipGetLastError());
     const int n_wt = (n + 63) / 64;
     const dim3 gm((unsigned)std::min(2048, (n_wt + 3) / 4 > 0 ? (n_wt + 3) / 4 : 1));
-    for (int round = 0; round < 64; ++round) {
-        hipLaunchKernelGGL(mis_prep, g, b, 0, s, n, state, u0, 0);
-        hipLaunchKernelGGL(nbr_max, gm, b, 0, s, n, n_wt, srow, scol, u0, u1);
-        hipLaunchKernelGGL(nbr_max, gm, b, 0, s, n, n_wt, srow, scol, u1, u2);
-        hipLaunchKernelGGL(mis_mark_roots, g, b, 0, s, n, state, u2);
-        hipLaunchKernelGGL(mis_prep, g, b, 0, s, n, state, u0, 1);
-        hipLaunchKernelGGL(nbr_max, gm, b, 0, s, n, n_wt, srow, scol, u0, u1);
-        hipLaunchKernelGGL(nbr_max, gm, b, 0, s, n, n_wt, srow, scol, u1, u2);
+    unsigned int *w0 = (unsigned int *)u0, *w1 = (unsigned int *)u1, *w2 = (unsigned int *)u2;
+    hipLaunchKernelGGL(mis_init_words, g, b, 0, s, n, w0);
+    for (int round = 0; round < 128; ++round) {
+        hipLaunchKernelGGL(nbr_max<unsigned int>, gm, b, 0, s, n, n_wt, srow, scol, w0, w1);
+        hipLaunchKernelGGL(nbr_max<unsigned int>, gm, b, 0, s, n, n_wt, srow, scol, w1, w2);
         PADNE_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(int), s));
-        hipLaunchKernelGGL(mis_cover, g, b, 0, s, n, state, u2, counter);
+        hipLaunchKernelGGL(mis_decide, g, b, 0, s, n, w0, w2, state, counter);
         PADNE_HIP_CHECK(hipGetLastError());
         int h = 0;
         PADNE_HIP_CHECK(hipMemcpyAsync(&h, counter, sizeof(int), hipMemcpyDeviceToHost, s));

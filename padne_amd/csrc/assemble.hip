@@ -56,28 +56,50 @@ __device__ __forceinline__ int block_exclusive_scan_256(int v, int *lds /*[5]*/,
     return wave_off + inc - v;
 }
 
+// per-chunk sums in 64 bits (the counts may be saturated upper bounds) + a flag for negative inputs
 __global__ __launch_bounds__(256) void scan_block_sums(const int *__restrict__ in, long long n,
-                                                       long long *__restrict__ block_sums) {
-    __shared__ int lds[5];
+                                                       long long *__restrict__ block_sums, long long *__restrict__ flags) {
+    __shared__ long long red[4];
     const long long base = (long long)blockIdx.x * kScanChunk + (long long)threadIdx.x * kScanItems;
-    int s = 0;
+    long long s = 0;
+    bool neg = false;
     for (int j = 0; j < kScanItems; ++j)
-        if (base + j < n) s += in[base + j];
-    int total;
-    block_exclusive_scan_256(s, lds, &total);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+        if (base + j < n) {
+            const int v = in[base + j];
+            neg |= v < 0;
+            s += v;
+        }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    if (neg) atomicExch((unsigned long long *)flags, 1ull);
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ void scan_block_offsets(long long *block_sums, int nb, long long *total_out) {
-    // single thread: nb is at most a few thousand
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
+// exclusive scan of the chunk sums by one workgroup: every thread takes a contiguous piece
+__global__ __launch_bounds__(256) void scan_block_offsets(long long *block_sums, int nb, long long *total_out) {
+    __shared__ long long piece[256];
+    const int per = (nb + 255) / 256;
+    const int b0 = threadIdx.x * per, b1 = min(b0 + per, nb);
+    long long s = 0;
+    for (int i = b0; i < b1; ++i) s += block_sums[i];
+    piece[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
         long long run = 0;
-        for (int i = 0; i < nb; ++i) {
-            const long long v = block_sums[i];
-            block_sums[i] = run;
+        for (int t = 0; t < 256; ++t) {
+            const long long v = piece[t];
+            piece[t] = run;
             run += v;
         }
         *total_out = run;
+    }
+    __syncthreads();
+    long long run = piece[threadIdx.x];
+    for (int i = b0; i < b1; ++i) {
+        const long long v = block_sums[i];
+        block_sums[i] = run;
+        run += v;
     }
 }
 
@@ -102,50 +124,21 @@ __global__ __launch_bounds__(256) void scan_apply(const int *__restrict__ in, lo
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = (int)(*total);
 }
 
-__global__ void sum_i32_as_i64(const int *__restrict__ in, long long n, unsigned long long *__restrict__ out,
-                               int *__restrict__ negative) {
-    long long s = 0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int v = in[i];
-        if (v < 0) atomicExch(negative, 1);
-        s += v;
-    }
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if ((threadIdx.x & 63) == 0 && s != 0) atomicAdd(out, (unsigned long long)s);
-}
-
 int exclusive_scan_i32(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t n, int64_t *total) {
     const int nb = (int)((n + kScanChunk - 1) / kScanChunk);
-    {   // exact 64-bit total first: the 32-bit scan below must not overflow silently
-        unsigned long long *d_tot = (unsigned long long *)pool_alloc(ctx, 16);
-        if (d_tot == nullptr) return PADNE_E_NOMEM;
-        PADNE_HIP_CHECK(hipMemsetAsync(d_tot, 0, 16, ctx->stream));
-        if (n > 0)
-            hipLaunchKernelGGL(sum_i32_as_i64, dim3((unsigned)(nb < 1024 ? (nb > 0 ? nb : 1) : 1024)), dim3(256), 0,
-                               ctx->stream, in, (long long)n, d_tot, (int *)(d_tot + 1));
-        unsigned long long h2[2] = {0, 0};
-        hipError_t e2 = hipMemcpyAsync(h2, d_tot, 16, hipMemcpyDeviceToHost, ctx->stream);
-        if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
-        pool_free(ctx, d_tot);
-        if (e2 != hipSuccess) {
-            set_error("scan failed: %s", hipGetErrorString(e2));
-            return PADNE_E_HIP;
-        }
-        if (h2[0] >= 2147483647ULL || (h2[1] & 0xffffffffULL) != 0) {
-            set_error("scan total %llu overflows int32 indices", h2[0]);
-            return PADNE_E_INVALID;
-        }
-    }
     long long *bs = (long long *)pool_alloc(ctx, sizeof(long long) * (size_t)(nb + 2));
     if (bs == nullptr) return PADNE_E_NOMEM;
-    long long *tot = bs + nb;
-    if (nb > 0) hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(256), 0, ctx->stream, in, (long long)n, bs);
-    hipLaunchKernelGGL(scan_block_offsets, dim3(1), dim3(64), 0, ctx->stream, bs, nb, tot);
-    if (nb > 0)
+    long long *tot = bs + nb;          // [0] exact 64-bit total, [1] negative-input flag
+    hipError_t e = hipMemsetAsync(tot, 0, 2 * sizeof(long long), ctx->stream);
+    if (e == hipSuccess && nb > 0) {
+        hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(256), 0, ctx->stream, in, (long long)n, bs, tot + 1);
+        hipLaunchKernelGGL(scan_block_offsets, dim3(1), dim3(256), 0, ctx->stream, bs, nb, tot);
+        // a total beyond int32 makes the 32-bit offsets below meaningless: it is detected from the 64-bit total
         hipLaunchKernelGGL(scan_apply, dim3(nb), dim3(256), 0, ctx->stream, in, (long long)n, bs, tot, out);
-    long long h = 0;
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(&h, tot, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream);
+        e = hipGetLastError();
+    }
+    long long h[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(h, tot, 2 * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess && nb == 0) e = hipMemsetAsync(out, 0, sizeof(int32_t), ctx->stream);
     pool_free(ctx, bs);
@@ -153,11 +146,11 @@ int exclusive_scan_i32(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t 
         set_error("scan failed: %s", hipGetErrorString(e));
         return PADNE_E_HIP;
     }
-    if (h >= 2147483647LL) {
-        set_error("scan total %lld overflows int32 indices", h);
+    if (h[0] >= 2147483647LL || h[0] < 0 || h[1] != 0) {
+        set_error("scan total %lld overflows int32 indices", h[0]);
         return PADNE_E_INVALID;
     }
-    *total = h;
+    *total = h[0];
     return PADNE_OK;
 }
 
