@@ -536,21 +536,34 @@ __global__ __launch_bounds__(256) void spgemm_rows_wave(int n_rows, const int *_
     int *pc = s_pc[w], *ht = s_ht[w], *dk = s_dk[w], *sk = s_sk[w], *off = s_off[w], *ys = s_ys[w];
     double *pv = s_pv[w], *xs = s_xv[w];
     constexpr int EMPTY = -1;
-    for (int i = blockIdx.x * 4 + w; i < n_rows; i += gridDim.x * 4) {
-        const int x0 = xr[i], nx = xr[i + 1] - x0;
+    // The loads that lead to a row's products form a chain of four dependent global accesses (xr -> xc/xv -> yr ->
+    // yc/yv); the first three are issued one row ahead so that only the last one is exposed.
+    const int stride = gridDim.x * 4;
+    int nx_n = 0, len_n = 0, ystart_n = 0;
+    double a_n = 0.0;
+    auto prefetch = [&](int row) {
+        nx_n = 0; len_n = 0; ystart_n = 0; a_n = 0.0;
+        if (row < n_rows) {
+            const int x0 = xr[row];
+            nx_n = xr[row + 1] - x0;
+            if (nx_n <= 64 && lane < nx_n) {
+                const int mid = xc[x0 + lane];
+                a_n = xv[x0 + lane];
+                ystart_n = yr[mid];
+                len_n = yr[mid + 1] - ystart_n;
+            }
+        }
+    };
+    prefetch(blockIdx.x * 4 + w);
+    for (int i = blockIdx.x * 4 + w; i < n_rows; i += stride) {
+        const int nx = nx_n, len = len_n, ystart = ystart_n;
+        const double a = a_n;
+        prefetch(i + stride);
         if (nx > 64) {
             if (lane == 0) row_len[i] = -1;
             continue;
         }
         // 1. product offsets
-        int len = 0, ystart = 0;
-        double a = 0.0;
-        if (lane < nx) {
-            const int mid = xc[x0 + lane];
-            a = xv[x0 + lane];
-            ystart = yr[mid];
-            len = yr[mid + 1] - ystart;
-        }
         int incl = len;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
