@@ -135,6 +135,10 @@ int padne_csr_vstack(padne_ctx *ctx, const padne_csr *top, const padne_csr *bott
 int padne_spmv(padne_ctx *ctx, const padne_csr *m, const double *x_host, double *y_host);
 /* y = M x on device vectors, enqueued `repeat` times on the context stream; blocking at the end */
 int padne_spmv_dev(padne_ctx *ctx, const padne_csr *m, const void *x_dev, void *y_dev, int repeat);
+/* Y = M X for 8 right-hand sides at once, device arrays interleaved as X[i*8 + j] = entry i of vector j
+ * (X: n_cols x 8, Y: n_rows x 8); every column of Y is bit-identical to padne_spmv_dev on that vector.
+ * The batched solve (padne_solve_spd with n_rhs a multiple of 8) is built on it. */
+int padne_spmm8_dev(padne_ctx *ctx, const padne_csr *m, const void *x_dev, void *y_dev, int repeat);
 /* residual: returns ||M x - b||_2 (device), host vectors in */
 int padne_residual_norm(padne_ctx *ctx, const padne_csr *m, const double *x_host,
                         const double *b_host, double *norm_out);
@@ -218,6 +222,11 @@ int64_t padne_spmv_algorithmic_bytes(const padne_csr *m);
  * events on the context stream, after `warmup` untimed launches */
 int padne_spmv_time(padne_ctx *ctx, const padne_csr *m, const void *x_dev, void *y_dev,
                     int warmup, int repeat, double *seconds_per_launch);
+
+/* the same two for the 8-vector product: 12*nnz + 4*n_rows + 16*n_rows*8 + 4 bytes */
+int64_t padne_spmm8_algorithmic_bytes(const padne_csr *m);
+int padne_spmm8_time(padne_ctx *ctx, const padne_csr *m, const void *x_dev, void *y_dev,
+                     int warmup, int repeat, double *seconds_per_launch);
 
 #ifdef __cplusplus
 }

@@ -83,6 +83,9 @@ SIGNATURES = {
     "padne_csr_vstack": (C.c_int, [_P, _P, _P, C.POINTER(_P)]),
     "padne_spmv": (C.c_int, [_P, _P, _PF64, _PF64]),
     "padne_spmv_dev": (C.c_int, [_P, _P, _P, _P, C.c_int]),
+    "padne_spmm8_dev": (C.c_int, [_P, _P, _P, _P, C.c_int]),
+    "padne_spmm8_algorithmic_bytes": (_I64, [_P]),
+    "padne_spmm8_time": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _PF64]),
     "padne_residual_norm": (C.c_int, [_P, _P, _PF64, _PF64, _PF64]),
     "padne_solve_spd": (C.c_int, [_P, _P, _PF64, _PF64, C.c_int32, C.POINTER(SolveOpts), C.POINTER(SolveInfo)]),
     "padne_solve_spd_dev": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(SolveOpts), C.POINTER(SolveInfo)]),
@@ -454,6 +457,32 @@ class CsrMatrix:
         _check(self.ctx._lib.padne_spmv_time(self.ctx._h, self._h, _P(x.ptr), _P(y.ptr), warmup, repeat,
                                              C.byref(t)))
         return t.value
+
+    def matmat8_dev(self, x: DeviceArray, y: DeviceArray, repeat: int = 1):
+        """Y = M X for 8 interleaved vectors: x holds shape[1]*8 doubles laid out [i][j], y shape[0]*8."""
+        if x.nbytes != self.shape[1] * 64 or y.nbytes != self.shape[0] * 64:
+            raise ValueError("dimension mismatch")
+        _check(self.ctx._lib.padne_spmm8_dev(self.ctx._h, self._h, _P(x.ptr), _P(y.ptr), int(repeat)))
+
+    def matmat8(self, X) -> np.ndarray:
+        """Host convenience: X (n_cols, 8) -> M @ X (n_rows, 8)."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        if X.shape != (self.shape[1], 8):
+            raise ValueError("X must have shape (n_cols, 8)")
+        xd = self.ctx.to_device(X.reshape(-1))
+        yd = self.ctx.empty(self.shape[0] * 8)
+        self.matmat8_dev(xd, yd)
+        return yd.numpy().reshape(self.shape[0], 8)
+
+    def spmm8_time(self, x: DeviceArray, y: DeviceArray, warmup: int = 5, repeat: int = 50) -> float:
+        t = C.c_double()
+        _check(self.ctx._lib.padne_spmm8_time(self.ctx._h, self._h, _P(x.ptr), _P(y.ptr), warmup, repeat,
+                                              C.byref(t)))
+        return t.value
+
+    @property
+    def spmm8_bytes(self) -> int:
+        return int(self.ctx._lib.padne_spmm8_algorithmic_bytes(self._h))
 
     def residual_norm(self, x, b) -> float:
         x, b = _f64(x), _f64(b)

@@ -49,6 +49,8 @@ constexpr int kPadNnz = 4096;        // cols/vals allocations are padded by this
 // number of partial sums every reduction kernel emits (one per workgroup)
 constexpr int kMaxPartials = 2048;
 
+constexpr int kSpmmK = 8;            // right-hand sides of the batched path (spmm.hip), interleaved [n][8]
+
 }  // namespace padne
 
 struct padne_csr {
@@ -115,6 +117,18 @@ int launch_spmv_f32_exit(padne_ctx *ctx, const padne_csr *m, const float *x, dou
                          double *partials, const int32_t *done_flag, const float *aux1, const float *aux2, float scale,
                          const double *out_scale2);
 int csr_build_f32(padne_ctx *ctx, padne_csr *m);
+
+// spmm.hip: the same products for 8 interleaved right-hand sides (vectors [n][8]; aux2 = 1/diag stays [n]);
+// dot partials are [8][kMaxPartials]
+int spmm8_grid(const padne_csr *m);
+int launch_spmm8_mode(padne_ctx *ctx, const padne_csr *m, int mode, const double *x, double *y, const double *dot_with,
+                      double *partials, const int32_t *done_flag, const double *aux1, const double *aux2, double scale);
+int launch_spmm8_f32(padne_ctx *ctx, const padne_csr *m, int mode, const float *x, float *y, double *partials,
+                     const int32_t *done_flag, const float *aux1, const float *aux2, float scale);
+int launch_spmm8_f32_exit(padne_ctx *ctx, const padne_csr *m, const float *x, double *y, const double *dot_with,
+                          double *partials, const int32_t *done_flag, const float *aux1, const float *aux2,
+                          float scale, const double *out_scale2);
+int interleave8(padne_ctx *ctx, long long n, const double *src, double *dst, bool to_interleaved);
 
 // exclusive scan of int32 counts into int32 offsets (n+1 outputs); returns total via host
 int exclusive_scan_i32(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t n, int64_t *total);

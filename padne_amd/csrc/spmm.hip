@@ -1,0 +1,295 @@
+// CSR SpMM for gfx950: Y = A X for kSpmmK = 8 right-hand sides at once (config C5: the same matrix, 8 current
+// source configurations; SURVEY.md section 8d: 12*nnz + 4*N + 16*N*k algorithmic bytes instead of k SpMVs).
+//
+// Layout: the k vectors are interleaved, X[i*8 + j] is entry i of right-hand side j, so the gather for one
+// non-zero is ONE contiguous 64-byte line instead of eight scattered doubles.
+//
+// Kernel: the SpMV skeleton (spmv.hip) with the roles in the second half swapped.
+//   * a wave owns 64 consecutive rows and streams their cols/vals lane-consecutively into its LDS slice
+//     (coalesced, predicated, every byte of the matrix fetched once);
+//   * then lane = (row-in-group r, pair of right-hand sides jp), 16 x 4: the four lanes of a row read the same
+//     (col, val) from LDS (broadcast) and gather the 64-byte line X[col*8 .. col*8+7] with one 16-byte load each;
+//     a wave works through its 64 rows in 4 groups of 16.  Every (row, j) sum runs in CSR order in one lane, so
+//     each column of Y is bit-identical to the single-vector product.
+//   * epilogues as in spmv.hip; the dot partials are per right-hand side.
+#include "common.hpp"
+
+#include <algorithm>
+
+namespace padne {
+
+constexpr int kSpmmChunk = 512;      // non-zeros staged per wave per pass (6 KiB: 4 B col + 8 B val)
+
+template <int MODE, typename VT, typename XT, typename YT>
+__global__ __launch_bounds__(kSpmvThreads) void csr_spmm8_kernel(
+    const int n_rows, const int n_wtiles, const int *__restrict__ rowptr, const int *__restrict__ cols,
+    const VT *__restrict__ vals, const XT *__restrict__ x, YT *__restrict__ y, const double *__restrict__ dot_with,
+    double *__restrict__ partials /* [8][kMaxPartials] */, const int *__restrict__ done_flag,
+    const XT *__restrict__ aux1, const XT *__restrict__ aux2, const XT scale,
+    const double *__restrict__ out_scale2 /* [8] or null */) {
+    constexpr int K = kSpmmK;
+    constexpr bool WITH_DOT = (MODE == SPMV_DOT) || (MODE == SPMV_JACOBI);
+    __shared__ int cs_all[4 * kSpmmChunk];
+    __shared__ VT vs_all[4 * kSpmmChunk];
+    __shared__ double red[4][K];
+
+    if (done_flag != nullptr && *done_flag != 0) return;
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int rsub = lane >> 2, j = (lane & 3) * 2;        // this lane's columns: j, j + 1
+    int *cs = cs_all + w * kSpmmChunk;
+    VT *vs = vs_all + w * kSpmmChunk;
+    double out_mul0 = 1.0, out_mul1 = 1.0;
+    if (out_scale2 != nullptr) {
+        const double a0 = out_scale2[j], a1 = out_scale2[j + 1];
+        out_mul0 = a0 > 0.0 ? sqrt(a0) : 1.0;
+        out_mul1 = a1 > 0.0 ? sqrt(a1) : 1.0;
+    }
+    const int G = gridDim.x;
+    const int nslab = (G % kNumXcd == 0) ? kNumXcd : 1;
+    const int slab = blockIdx.x % nslab;
+    const int wx = (blockIdx.x / nslab) * 4 + w;
+    const int wps = (G / nslab) * 4;
+    const int s0 = (int)((long long)slab * n_wtiles / nslab);
+    const int s1 = (int)((long long)(slab + 1) * n_wtiles / nslab);
+    struct alignas(2 * sizeof(XT)) X2 { XT a, b; };
+    struct alignas(2 * sizeof(YT)) Y2 { YT a, b; };
+
+    double dot0 = 0.0, dot1 = 0.0;
+    for (int wt = s0 + wx; wt < s1; wt += wps) {
+        const int row0 = wt * 64;
+        const int row1 = min(row0 + 64, n_rows);
+        int rs = 0, re = 0;
+        if (row0 + lane < row1) {
+            rs = rowptr[row0 + lane];
+            re = rowptr[row0 + lane + 1];
+        }
+        const int k0 = __shfl(rs, 0, 64);
+        const int k1 = __shfl(re, row1 - row0 - 1, 64);
+        XT acc0[4], acc1[4];
+        int grs[4], gre[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            acc0[g] = 0;
+            acc1[g] = 0;
+            grs[g] = __shfl(rs, g * 16 + rsub, 64);
+            gre[g] = __shfl(re, g * 16 + rsub, 64);
+        }
+        for (int base = k0; base < k1; base += kSpmmChunk) {
+#pragma unroll
+            for (int q = 0; q < kSpmmChunk / 64; ++q) {
+                const int e = base + lane + 64 * q;
+                if (e < k1) {
+                    cs[lane + 64 * q] = cols[e];
+                    vs[lane + 64 * q] = vals[e];
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int lo = max(grs[g], base), hi = min(gre[g], base + kSpmmChunk);
+                XT a0 = acc0[g], a1 = acc1[g];
+                for (int k = lo; k < hi; k += 8) {             // up to eight 16-byte gathers in flight per lane
+                    X2 xv[8];
+                    XT vv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        xv[u].a = 0;
+                        xv[u].b = 0;
+                        vv[u] = 0;
+                        if (k + u < hi) {
+                            xv[u] = *reinterpret_cast<const X2 *>(x + (size_t)cs[k + u - base] * K + j);
+                            vv[u] = (XT)vs[k + u - base];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (k + u < hi) {
+                            a0 += vv[u] * xv[u].a;
+                            a1 += vv[u] * xv[u].b;
+                        }
+                }
+                acc0[g] = a0;
+                acc1[g] = a1;
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int r = row0 + g * 16 + rsub;
+            if (r >= row1) continue;
+            const size_t o = (size_t)r * K + j;
+            const XT a0 = acc0[g], a1 = acc1[g];
+            Y2 out2;
+            if (MODE == SPMV_PLAIN) {
+                out2.a = (YT)a0;
+                out2.b = (YT)a1;
+            } else if (MODE == SPMV_DOT) {
+                out2.a = (YT)a0;
+                out2.b = (YT)a1;
+                dot0 += dot_with[o] * (double)a0;
+                dot1 += dot_with[o + 1] * (double)a1;
+            } else if (MODE == SPMV_RESID) {
+                const X2 b = *reinterpret_cast<const X2 *>(aux1 + o);
+                out2.a = (YT)(b.a - a0);
+                out2.b = (YT)(b.b - a1);
+            } else if (MODE == SPMV_ADD) {
+                const Y2 old = *reinterpret_cast<const Y2 *>(y + o);
+                out2.a = old.a + (YT)a0;
+                out2.b = old.b + (YT)a1;
+            } else {
+                const X2 b = *reinterpret_cast<const X2 *>(aux1 + o);
+                const X2 xo = *reinterpret_cast<const X2 *>(x + o);
+                const XT d = scale * aux2[r];
+                const XT o0 = xo.a + d * (b.a - a0), o1 = xo.b + d * (b.b - a1);
+                if (dot_with != nullptr) {
+                    const double d0 = (double)o0 * out_mul0, d1 = (double)o1 * out_mul1;
+                    out2.a = (YT)d0;
+                    out2.b = (YT)d1;
+                    dot0 += dot_with[o] * d0;
+                    dot1 += dot_with[o + 1] * d1;
+                } else {
+                    out2.a = (YT)o0;
+                    out2.b = (YT)o1;
+                    dot0 += (double)(b.a * o0);
+                    dot1 += (double)(b.b * o1);
+                }
+            }
+            *reinterpret_cast<Y2 *>(y + o) = out2;
+        }
+    }
+    if (WITH_DOT && partials != nullptr) {
+        // lanes with the same column pair: 4, 8, 16, 32 apart
+#pragma unroll
+        for (int d = 4; d < 64; d <<= 1) {
+            dot0 += __shfl_xor(dot0, d, 64);
+            dot1 += __shfl_xor(dot1, d, 64);
+        }
+        if (lane < 4) {
+            red[w][lane * 2] = dot0;
+            red[w][lane * 2 + 1] = dot1;
+        }
+        __syncthreads();
+        if (threadIdx.x < K)
+            partials[(size_t)threadIdx.x * kMaxPartials + blockIdx.x] =
+                (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    }
+}
+
+template <typename VT, typename XT, typename YT>
+static int launch_spmm8_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals, int mode, const XT *x, YT *y,
+                              const double *dot_with, double *partials, const int32_t *done_flag, const XT *aux1,
+                              const XT *aux2, XT scale, const double *out_scale2) {
+    if (m->n_rows == 0) return PADNE_OK;
+    const int n_tiles = (int)((m->n_rows + 63) / 64);
+    long long g = (m->n_rows + kSpmvRows - 1) / kSpmvRows;
+    if (g > kMaxPartials) g = kMaxPartials;
+    if (g >= kNumXcd) g -= g % kNumXcd;
+    if (g < 1) g = 1;
+#define PADNE_SPMM_LAUNCH(M)                                                                                      \
+    hipLaunchKernelGGL((csr_spmm8_kernel<M, VT, XT, YT>), dim3((unsigned)g), dim3(kSpmvThreads), 0, ctx->stream,   \
+                       (int)m->n_rows, n_tiles, m->rowptr, m->cols, vals, x, y, dot_with, partials, done_flag,     \
+                       aux1, aux2, scale, out_scale2)
+    switch (mode) {
+        case SPMV_PLAIN: PADNE_SPMM_LAUNCH(SPMV_PLAIN); break;
+        case SPMV_DOT: PADNE_SPMM_LAUNCH(SPMV_DOT); break;
+        case SPMV_RESID: PADNE_SPMM_LAUNCH(SPMV_RESID); break;
+        case SPMV_ADD: PADNE_SPMM_LAUNCH(SPMV_ADD); break;
+        case SPMV_JACOBI: PADNE_SPMM_LAUNCH(SPMV_JACOBI); break;
+        default: set_error("bad SpMM mode %d", mode); return PADNE_E_INVALID;
+    }
+#undef PADNE_SPMM_LAUNCH
+    PADNE_HIP_CHECK(hipGetLastError());
+    return PADNE_OK;
+}
+
+int spmm8_grid(const padne_csr *m) {
+    long long g = (m->n_rows + kSpmvRows - 1) / kSpmvRows;
+    if (g > kMaxPartials) g = kMaxPartials;
+    if (g >= kNumXcd) g -= g % kNumXcd;
+    return (int)(g < 1 ? 1 : g);
+}
+
+int launch_spmm8_mode(padne_ctx *ctx, const padne_csr *m, int mode, const double *x, double *y, const double *dot_with,
+                      double *partials, const int32_t *done_flag, const double *aux1, const double *aux2,
+                      double scale) {
+    return launch_spmm8_typed<double, double, double>(ctx, m, m->vals, mode, x, y, dot_with, partials, done_flag, aux1,
+                                                      aux2, scale, nullptr);
+}
+
+int launch_spmm8_f32(padne_ctx *ctx, const padne_csr *m, int mode, const float *x, float *y, double *partials,
+                     const int32_t *done_flag, const float *aux1, const float *aux2, float scale) {
+    PADNE_REQUIRE(m->vals32 != nullptr, "single-precision copy missing");
+    return launch_spmm8_typed<float, float, float>(ctx, m, m->vals32, mode, x, y, nullptr, partials, done_flag, aux1,
+                                                   aux2, scale, nullptr);
+}
+
+int launch_spmm8_f32_exit(padne_ctx *ctx, const padne_csr *m, const float *x, double *y, const double *dot_with,
+                          double *partials, const int32_t *done_flag, const float *aux1, const float *aux2,
+                          float scale, const double *out_scale2) {
+    PADNE_REQUIRE(m->vals32 != nullptr && dot_with != nullptr, "single-precision exit stage");
+    return launch_spmm8_typed<float, float, double>(ctx, m, m->vals32, SPMV_JACOBI, x, y, dot_with, partials, done_flag,
+                                                    aux1, aux2, scale, out_scale2);
+}
+
+// [k][n] (one vector after the other) <-> [n][k] (interleaved)
+__global__ void interleave8_kernel(long long n, const double *__restrict__ src, double *__restrict__ dst, int to_interleaved) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * kSpmmK) return;
+    const long long i = t / kSpmmK;
+    const int j = (int)(t % kSpmmK);
+    if (to_interleaved) dst[t] = src[(size_t)j * n + i];
+    else dst[(size_t)j * n + i] = src[t];
+}
+
+int interleave8(padne_ctx *ctx, long long n, const double *src, double *dst, bool to_interleaved) {
+    if (n <= 0) return PADNE_OK;
+    hipLaunchKernelGGL(interleave8_kernel, dim3((unsigned)((n * kSpmmK + 255) / 256)), dim3(256), 0, ctx->stream, n, src,
+                       dst, to_interleaved ? 1 : 0);
+    PADNE_HIP_CHECK(hipGetLastError());
+    return PADNE_OK;
+}
+
+}  // namespace padne
+
+using namespace padne;
+
+// Y = M X for 8 interleaved vectors on the device (X: n_cols x 8, Y: n_rows x 8, row-major), `repeat` launches
+extern "C" int padne_spmm8_dev(padne_ctx *ctx, const padne_csr *m, const void *x_dev, void *y_dev, int repeat) {
+    PADNE_REQUIRE(ctx && m && x_dev && y_dev, "null argument");
+    PADNE_REQUIRE(repeat >= 1, "repeat");
+    PADNE_HIP_CHECK(hipSetDevice(ctx->device));
+    for (int i = 0; i < repeat; ++i)
+        PADNE_TRY(launch_spmm8_mode(ctx, m, SPMV_PLAIN, (const double *)x_dev, (double *)y_dev, nullptr, nullptr, nullptr,
+                                    nullptr, nullptr, 0.0));
+    PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PADNE_OK;
+}
+
+extern "C" int padne_spmm8_time(padne_ctx *ctx, const padne_csr *m, const void *x_dev, void *y_dev, int warmup,
+                                int repeat, double *seconds_per_launch) {
+    PADNE_REQUIRE(ctx && m && x_dev && y_dev && seconds_per_launch, "null argument");
+    PADNE_REQUIRE(repeat >= 1 && warmup >= 0, "repeat / warmup");
+    PADNE_HIP_CHECK(hipSetDevice(ctx->device));
+    for (int i = 0; i < warmup; ++i)
+        PADNE_TRY(launch_spmm8_mode(ctx, m, SPMV_PLAIN, (const double *)x_dev, (double *)y_dev, nullptr, nullptr, nullptr,
+                                    nullptr, nullptr, 0.0));
+    PADNE_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
+    for (int i = 0; i < repeat; ++i)
+        PADNE_TRY(launch_spmm8_mode(ctx, m, SPMV_PLAIN, (const double *)x_dev, (double *)y_dev, nullptr, nullptr, nullptr,
+                                    nullptr, nullptr, 0.0));
+    PADNE_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
+    PADNE_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    PADNE_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *seconds_per_launch = ms * 1e-3 / repeat;
+    return PADNE_OK;
+}
+
+// algorithmic bytes of one 8-vector product: 12*nnz + 4*n_rows + 16*n_rows*8 + 4  
+extern "C" int64_t padne_spmm8_algorithmic_bytes(const padne_csr *m) {
+    if (!m) return 0;
+    return 12 * m->nnz + 4 * m->n_rows + 16 * m->n_rows * kSpmmK + 4;
+}

@@ -820,6 +820,19 @@ def test_row_partitioned_hierarchy_with_several_exchanged_levels(monkeypatch):
         assert res.levels >= 4 and iters < 60
 
 
+def test_spmm8_columns_are_bitwise_the_single_vector_products(ctx):
+    """8 interleaved right-hand sides through one pass over the matrix; ragged rows, empty rows, long rows."""
+    rng = np.random.default_rng(3)
+    for M in (H.random_csr(5000, 5000, 7, 21), H.random_csr(777, 900, 40, 22), H.random_csr(130, 64, 300, 23)):
+        d = ctx.csr_from_scipy(M)
+        X = rng.uniform(-1, 1, (M.shape[1], 8))
+        Y = d.matmat8(X)
+        for j in range(8):
+            yj = d.matvec(np.ascontiguousarray(X[:, j]))
+            assert np.array_equal(Y[:, j], yj)
+            assert np.array_equal(yj, M @ X[:, j])            # and both equal scipy's CSR product bit for bit
+
+
 def test_relabel_and_vstack_against_scipy(ctx):
     rng = np.random.default_rng(12)
     M = H.random_csr(300, 420, 9, 12)
