@@ -38,6 +38,7 @@ struct AmgLevel {
     double jac = 0.0;               // Jacobi damping 1/theta_c
     long long n = 0;
     double *b = nullptr, *xa = nullptr, *xb = nullptr, *tmp = nullptr;   // work vectors (levels >= 1: all; level 0: xa, tmp)
+    float *b8 = nullptr, *xa8 = nullptr, *xb8 = nullptr, *tmp8 = nullptr;   // [n][8] vectors of the batched cycle
     // row-partitioned hierarchy: A is this rank's rows, columns [owned | world * halo.m exchange slots]
     HaloPlan halo;
     int32_t *export_owned = nullptr;   // device copy of the export list (levels >= 1; level 0 borrows the context's)
@@ -1215,6 +1216,10 @@ void amg_destroy(void *p) {
         pool_free(amg->ctx, L.xa);
         pool_free(amg->ctx, L.xb);
         pool_free(amg->ctx, L.tmp);
+        pool_free(amg->ctx, L.b8);
+        pool_free(amg->ctx, L.xa8);
+        pool_free(amg->ctx, L.xb8);
+        pool_free(amg->ctx, L.tmp8);
         pool_free(amg->ctx, L.export_owned);
     }
     pool_free(amg->ctx, amg->coarse_inv);
@@ -1977,6 +1982,102 @@ static int amg_apply_f32(padne_ctx *ctx, Amg *amg, const double *r, double *z, d
             PADNE_TRY(launch_spmv_f32_exit(ctx, L.A, xa, z, r, partials_rz, done_flag, b, L.A->dinv32, (float)L.jac, bb2));
     }
     return PADNE_OK;
+}
+
+// ---- the single-precision cycle on 8 interleaved right-hand sides ([n][8] vectors, spmm.hip) ---------------
+__global__ void amg_entry_f32x8_kernel(long long n, const double *__restrict__ r, const double *__restrict__ bb2, float c,
+                                       const float *__restrict__ dinv, float *__restrict__ b, float *__restrict__ x,
+                                       const int *__restrict__ done_flag) {
+    if (done_flag != nullptr && *done_flag != 0) return;
+    const int j = threadIdx.x & 7;
+    double s_inv = 1.0;
+    if (bb2 != nullptr) {
+        const double s2 = bb2[j];
+        if (s2 > 0.0) s_inv = 1.0 / sqrt(s2);
+    }
+    // blockDim.x is a multiple of 8 and so is every stride: a thread keeps its right-hand side j
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n * 8; t += (long long)gridDim.x * blockDim.x) {
+        const float v = (float)(r[t] * s_inv);
+        b[t] = v;
+        x[t] = c * dinv[t >> 3] * v;
+    }
+}
+
+__global__ void scale_dinv_x8_kernel(long long n, float c, const float *__restrict__ dinv, const float *__restrict__ b,
+                                     float *__restrict__ x, const int *__restrict__ done_flag) {
+    if (done_flag != nullptr && *done_flag != 0) return;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n * 8; t += (long long)gridDim.x * blockDim.x)
+        x[t] = c * dinv[t >> 3] * b[t];
+}
+
+// Y[row][j] = sum_c Inv[row][c] B[c][j] : one wave per row, lane = (c mod 8, j)
+__global__ __launch_bounds__(256) void dense_gemm_x8(int n, const float *__restrict__ inv, const float *__restrict__ b,
+                                                     float *__restrict__ y) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const int cs = lane >> 3, j = lane & 7;
+    float s = 0.f;
+    for (int c = cs; c < n; c += 8) s += inv[(size_t)row * n + c] * b[(size_t)c * 8 + j];
+    s += __shfl_xor(s, 8, 64);
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (lane < 8) y[(size_t)row * 8 + j] = s;
+}
+
+// z8 = M^-1 r8 for 8 interleaved right-hand sides; partials_rz [8][kMaxPartials]; bb2 [8]
+int amg_apply_batch8(padne_ctx *ctx, const padne_csr *A0, const double *r8, double *z8, double *partials_rz,
+                     const int32_t *done_flag, const double *bb2) {
+    Amg *amg = (Amg *)A0->amg;
+    PADNE_REQUIRE(amg != nullptr && amg->f32 && !amg->dist, "the batched cycle needs the single-GPU single-precision hierarchy");
+    hipStream_t s = ctx->stream;
+    const int nl = (int)amg->levels.size();
+    for (AmgLevel &L : amg->levels) {
+        if (L.b8 != nullptr) continue;
+        const size_t bytes = sizeof(float) * 8 * (size_t)(L.n > 0 ? L.n : 1);
+        L.b8 = (float *)pool_alloc(ctx, bytes);
+        L.xa8 = (float *)pool_alloc(ctx, bytes);
+        L.xb8 = (float *)pool_alloc(ctx, bytes);
+        L.tmp8 = (float *)pool_alloc(ctx, bytes);
+        if (!L.b8 || !L.xa8 || !L.xb8 || !L.tmp8) return PADNE_E_NOMEM;
+    }
+    for (int l = 0; l < nl; ++l) {
+        AmgLevel &L = amg->levels[l];
+        if (l == nl - 1) {
+            hipLaunchKernelGGL(dense_gemm_x8, dim3((amg->n_coarse + 3) / 4), dim3(256), 0, s, amg->n_coarse,
+                               (const float *)amg->coarse_inv32, (const float *)L.b8, L.xb8);
+            PADNE_HIP_CHECK(hipGetLastError());
+            break;
+        }
+        const int gv = (int)std::min<long long>((L.n * 8 + 255) / 256, 2048);
+        if (l == 0)
+            hipLaunchKernelGGL(amg_entry_f32x8_kernel, dim3(gv > 0 ? gv : 1), dim3(256), 0, s, L.n, r8, bb2, (float)L.jac,
+                               (const float *)L.A->dinv32, L.b8, L.xa8, done_flag);
+        else
+            hipLaunchKernelGGL(scale_dinv_x8_kernel, dim3(gv > 0 ? gv : 1), dim3(256), 0, s, L.n, (float)L.jac,
+                               (const float *)L.A->dinv32, (const float *)L.b8, L.xa8, done_flag);
+        PADNE_HIP_CHECK(hipGetLastError());
+        PADNE_TRY(launch_spmm8_f32(ctx, L.A, SPMV_RESID, L.xa8, L.tmp8, nullptr, done_flag, L.b8, nullptr, 0.f));
+        PADNE_TRY(launch_spmm8_f32(ctx, L.R, SPMV_PLAIN, L.tmp8, amg->levels[l + 1].b8, nullptr, done_flag, nullptr,
+                                   nullptr, 0.f));
+    }
+    for (int l = nl - 2; l >= 0; --l) {
+        AmgLevel &L = amg->levels[l];
+        PADNE_TRY(launch_spmm8_f32(ctx, L.P, SPMV_ADD, amg->levels[l + 1].xb8, L.xa8, nullptr, done_flag, nullptr, nullptr,
+                                   0.f));
+        if (l > 0)
+            PADNE_TRY(launch_spmm8_f32(ctx, L.A, SPMV_JACOBI, L.xa8, L.xb8, nullptr, done_flag, L.b8, L.A->dinv32,
+                                       (float)L.jac));
+        else
+            PADNE_TRY(launch_spmm8_f32_exit(ctx, L.A, L.xa8, z8, r8, partials_rz, done_flag, L.b8, L.A->dinv32,
+                                            (float)L.jac, bb2));
+    }
+    return PADNE_OK;
+}
+
+bool amg_supports_batch8(const padne_csr *A0) {
+    const Amg *amg = (const Amg *)A0->amg;
+    return amg != nullptr && amg->f32 && !amg->dist && amg->levels.size() >= 2 && amg->coarse_inv32 != nullptr;
 }
 
 int amg_apply(padne_ctx *ctx, const padne_csr *A0, const double *r, double *z, double *partials_rz,

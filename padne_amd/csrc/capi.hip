@@ -168,7 +168,7 @@ int padne_ctx_create(int device, padne_ctx **out) {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void **)&ctx->partials, sizeof(double) * 8 * kMaxPartials) != hipSuccess ||
         hipMalloc((void **)&ctx->scalars, sizeof(double) * 64) != hipSuccess ||
-        hipMalloc((void **)&ctx->status, 256) != hipSuccess ||
+        hipMalloc((void **)&ctx->status, 1024) != hipSuccess ||
         hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
         set_error("context creation failed: %s", hipGetErrorString(hipGetLastError()));
@@ -177,7 +177,7 @@ int padne_ctx_create(int device, padne_ctx **out) {
     }
     hipMemsetAsync(ctx->partials, 0, sizeof(double) * 8 * kMaxPartials, ctx->stream);
     hipMemsetAsync(ctx->scalars, 0, sizeof(double) * 64, ctx->stream);
-    hipMemsetAsync(ctx->status, 0, 256, ctx->stream);
+    hipMemsetAsync(ctx->status, 0, 1024, ctx->stream);
     hipStreamSynchronize(ctx->stream);
     *out = ctx;
     return PADNE_OK;

@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -547,6 +548,279 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
     return PADNE_OK;
 }
 
+// ---- 8 right-hand sides in lockstep (config C5) ----------------------------------------------------------
+// The same preconditioned CG recurrences, one per right-hand side, advanced together so that the matrix and the
+// multigrid operators are streamed once per iteration for all of them (spmm.hip; vectors interleaved [n][8]).
+// Every column keeps its own alpha / beta / stopping test; a column that has converged is frozen (alpha = 0)
+// while the others go on.  Reductions: per-workgroup partials [8][kMaxPartials] folded by an 8-workgroup kernel
+// into 8 device scalars that the consumers read.
+int amg_apply_batch8(padne_ctx *ctx, const padne_csr *A0, const double *r8, double *z8, double *partials_rz,
+                     const int32_t *done_flag, const double *bb2);
+bool amg_supports_batch8(const padne_csr *A0);
+
+struct Pcg8Status {
+    int32_t done, code, iters, pad;
+    int32_t col_done[8];
+    int32_t col_iters[8];
+    double rr[8], tol2[8], bb[8];
+};
+
+// sums over this thread's strided share of an interleaved vector end up per column j = threadIdx.x & 7;
+// combine the 32 threads of a workgroup that share j and store one partial per column
+__device__ __forceinline__ void block_store_partial8(double v, double (*red)[8], double *part /* [8][kMaxPartials] */) {
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane < 8) red[w][lane] = v;
+    __syncthreads();
+    if (threadIdx.x < 8)
+        part[(size_t)threadIdx.x * kMaxPartials + blockIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void fold8_kernel(const double *__restrict__ partials, int P, double *__restrict__ out) {
+    __shared__ double red[4];
+    const double t = block_total(partials + (size_t)blockIdx.x * kMaxPartials, P, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void pcg8_init_kernel(const long long n, const double *__restrict__ b,
+                                                        const double *__restrict__ ax, double *__restrict__ r,
+                                                        double *__restrict__ part_rr, double *__restrict__ part_bb) {
+    __shared__ double red[4][8];
+    double rr = 0.0, bb = 0.0;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n * 8; t += (long long)gridDim.x * 256) {
+        const double bi = b[t];
+        const double ri = ax ? bi - ax[t] : bi;
+        r[t] = ri;
+        rr += ri * ri;
+        bb += bi * bi;
+    }
+    block_store_partial8(rr, red, part_rr);
+    block_store_partial8(bb, red, part_bb);
+}
+
+__global__ void pcg8_set_tolerance_kernel(Pcg8Status *st, const double *__restrict__ rr, const double *__restrict__ bbv,
+                                          double rtol, double atol, int use_existing_bb) {
+    const int j = threadIdx.x;
+    if (j < 8) {
+        const double bb = use_existing_bb ? st->bb[j] : bbv[j];
+        double tol = rtol * sqrt(bb);
+        if (atol > tol) tol = atol;
+        st->bb[j] = bb;
+        st->tol2[j] = tol * tol;
+        st->rr[j] = rr[j];
+        st->col_done[j] = (rr[j] <= tol * tol) ? 1 : 0;
+        if (!(rr[j] == rr[j])) st->code = PADNE_E_BREAKDOWN;
+    }
+    __syncthreads();
+    if (j == 0) {
+        int all = 1;
+        for (int c = 0; c < 8; ++c) all &= st->col_done[c];
+        st->done = (all || st->code != PADNE_OK) ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void pcg8_update_xr_kernel(const long long n, const double *__restrict__ rz,
+                                                             const double *__restrict__ pq, const double *__restrict__ p,
+                                                             const double *__restrict__ q, double *__restrict__ x,
+                                                             double *__restrict__ r, double *__restrict__ part_rr,
+                                                             const Pcg8Status *__restrict__ st) {
+    __shared__ double red[4][8];
+    if (st->done) return;
+    const int j = threadIdx.x & 7;
+    const double alpha = st->col_done[j] ? 0.0 : rz[j] / pq[j];
+    double s_rr = 0.0;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n * 8; t += (long long)gridDim.x * 256) {
+        const double ri = r[t] - alpha * q[t];
+        x[t] += alpha * p[t];
+        r[t] = ri;
+        s_rr += ri * ri;
+    }
+    block_store_partial8(s_rr, red, part_rr);
+}
+
+__global__ __launch_bounds__(256) void pcg8_update_p_kernel(const long long n, const double *__restrict__ rz_new,
+                                                            const double *__restrict__ rz_old, const double *__restrict__ rr,
+                                                            const double *__restrict__ pq, const double *__restrict__ z,
+                                                            double *__restrict__ p, Pcg8Status *__restrict__ st,
+                                                            const int max_iter) {
+    if (st->done) return;
+    const int j = threadIdx.x & 7;
+    const double beta = st->col_done[j] ? 0.0 : rz_new[j] / rz_old[j];
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n * 8; t += (long long)gridDim.x * 256)
+        p[t] = z[t] + beta * p[t];
+    if (blockIdx.x == 0) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int it = st->iters + 1;
+            st->iters = it;
+            int all = 1;
+            for (int c = 0; c < 8; ++c) {
+                if (st->col_done[c]) continue;
+                st->col_iters[c] += 1;
+                st->rr[c] = rr[c];
+                if (!(pq[c] > 0.0) || !(rr[c] == rr[c]) || !(rz_new[c] > 0.0)) {
+                    st->code = PADNE_E_BREAKDOWN;
+                } else if (rr[c] <= st->tol2[c]) {
+                    st->col_done[c] = 1;
+                    continue;
+                }
+                all = 0;
+            }
+            if (all || st->code != PADNE_OK || it >= max_iter) st->done = 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void residual8_kernel(const long long n, const double *__restrict__ b,
+                                                        const double *__restrict__ ax, double *__restrict__ part_rr) {
+    __shared__ double red[4][8];
+    double rr = 0.0;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n * 8; t += (long long)gridDim.x * 256) {
+        const double ri = ax[t] - b[t];
+        rr += ri * ri;
+    }
+    block_store_partial8(rr, red, part_rr);
+}
+
+// b_cols / x_cols: 8 vectors of n doubles one after the other (the C ABI layout)
+static int solve_batch8(padne_ctx *ctx, const padne_csr *a, const double *b_cols, double *x_cols,
+                        const padne_solve_opts *o, padne_solve_info *info, bool x_is_guess) {
+    const long long n = a->n_rows;
+    PADNE_REQUIRE(a->n_rows == a->n_cols && !ctx->halo_on, "the batched solve is single-GPU");
+    hipStream_t s = ctx->stream;
+    Scratch sc(ctx);
+    double *b8 = nullptr, *x8 = nullptr, *r8 = nullptr, *z8 = nullptr, *p8 = nullptr, *q8 = nullptr, *part = nullptr,
+           *scal = nullptr;
+    const size_t nv = (size_t)n * 8;
+    PADNE_TRY(sc.alloc(&b8, nv));
+    PADNE_TRY(sc.alloc(&x8, nv));
+    PADNE_TRY(sc.alloc(&r8, nv));
+    PADNE_TRY(sc.alloc(&z8, nv));
+    PADNE_TRY(sc.alloc(&p8, nv));
+    PADNE_TRY(sc.alloc(&q8, nv));
+    PADNE_TRY(sc.alloc(&part, (size_t)6 * 8 * kMaxPartials));
+    PADNE_TRY(sc.alloc(&scal, 64));
+    enum { P_PQ = 0, P_RZ0 = 1, P_RZ1 = 2, P_RR = 3, P_BB = 4, P_TMP = 5 };
+    auto pslot = [&](int k) { return part + (size_t)k * 8 * kMaxPartials; };
+    enum { C_PQ = 0, C_RZ0 = 8, C_RZ1 = 16, C_RR = 24, C_BB = 32, C_TRUE = 40 };
+    Pcg8Status *st = (Pcg8Status *)ctx->status;
+    Pcg8Status *hst = (Pcg8Status *)ctx->pinned;
+    const int gv = vec_grid(n * 8);
+    const int gs = spmm8_grid(a);
+    const int max_iter = o->max_iter > 0 ? o->max_iter : 100000;
+    const int check_every = o->check_every > 0 ? o->check_every : 4;
+    auto fold = [&](const double *partials, int P, double *out) -> int {
+        hipLaunchKernelGGL(fold8_kernel, dim3(8), dim3(256), 0, s, partials, P, out);
+        PADNE_HIP_CHECK(hipGetLastError());
+        return PADNE_OK;
+    };
+    PADNE_HIP_CHECK(hipMemsetAsync(st, 0, sizeof(Pcg8Status), s));
+    PADNE_TRY(interleave8(ctx, n, b_cols, b8, true));
+    PADNE_HIP_CHECK(hipEventRecord(ctx->ev0, s));
+    bool have_ax = false;
+    if (x_is_guess) {
+        PADNE_TRY(interleave8(ctx, n, x_cols, x8, true));
+        PADNE_TRY(launch_spmm8_mode(ctx, a, SPMV_PLAIN, x8, q8, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0));
+        have_ax = true;
+    } else {
+        PADNE_HIP_CHECK(hipMemsetAsync(x8, 0, sizeof(double) * nv, s));
+    }
+    int restarts = 0, total_iters = 0, code = PADNE_OK;
+    double true_rr[8] = {0}, prev_true_rr[8] = {0}, bb[8] = {0}, tol2[8] = {0};
+    int col_iters[8] = {0};
+    bool stagnated[8] = {false};
+    for (;;) {
+        hipLaunchKernelGGL(pcg8_init_kernel, dim3(gv), dim3(256), 0, s, n, b8, have_ax ? q8 : nullptr, r8, pslot(P_RR),
+                           pslot(P_BB));
+        PADNE_HIP_CHECK(hipGetLastError());
+        PADNE_TRY(fold(pslot(P_RR), gv, scal + C_RR));
+        PADNE_TRY(fold(pslot(P_BB), gv, scal + C_BB));
+        PADNE_TRY(amg_apply_batch8(ctx, a, r8, z8, pslot(P_RZ0), nullptr, scal + C_BB));
+        PADNE_TRY(fold(pslot(P_RZ0), gs, scal + C_RZ0));
+        PADNE_HIP_CHECK(hipMemcpyAsync(p8, z8, sizeof(double) * nv, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(pcg8_set_tolerance_kernel, dim3(1), dim3(64), 0, s, st, scal + C_RR, scal + C_BB, o->rtol,
+                           o->atol, restarts > 0 ? 1 : 0);
+        PADNE_HIP_CHECK(hipGetLastError());
+        int parity = 0;
+        bool done = false;
+        while (!done) {
+            for (int k = 0; k < check_every; ++k) {
+                double *rz_old = scal + (parity ? C_RZ1 : C_RZ0), *rz_new = scal + (parity ? C_RZ0 : C_RZ1);
+                const int rz_new_slot = parity ? P_RZ0 : P_RZ1;
+                PADNE_TRY(launch_spmm8_mode(ctx, a, SPMV_DOT, p8, q8, p8, pslot(P_PQ), &st->done, nullptr, nullptr, 0.0));
+                PADNE_TRY(fold(pslot(P_PQ), gs, scal + C_PQ));
+                hipLaunchKernelGGL(pcg8_update_xr_kernel, dim3(gv), dim3(256), 0, s, n, rz_old, scal + C_PQ, p8, q8, x8, r8,
+                                   pslot(P_RR), st);
+                PADNE_HIP_CHECK(hipGetLastError());
+                PADNE_TRY(amg_apply_batch8(ctx, a, r8, z8, pslot(rz_new_slot), &st->done, scal + C_BB));
+                PADNE_TRY(fold(pslot(rz_new_slot), gs, rz_new));
+                PADNE_TRY(fold(pslot(P_RR), gv, scal + C_RR));
+                hipLaunchKernelGGL(pcg8_update_p_kernel, dim3(gv), dim3(256), 0, s, n, rz_new, rz_old, scal + C_RR,
+                                   scal + C_PQ, z8, p8, st, max_iter - total_iters);
+                PADNE_HIP_CHECK(hipGetLastError());
+                parity ^= 1;
+            }
+            PADNE_HIP_CHECK(hipMemcpyAsync(hst, st, sizeof(Pcg8Status), hipMemcpyDeviceToHost, s));
+            PADNE_HIP_CHECK(hipStreamSynchronize(s));
+            done = hst->done != 0;
+        }
+        total_iters += hst->iters;
+        code = hst->code;
+        for (int c = 0; c < 8; ++c) {
+            bb[c] = hst->bb[c];
+            tol2[c] = hst->tol2[c];
+            col_iters[c] += hst->col_iters[c];
+        }
+        // true residuals
+        PADNE_TRY(launch_spmm8_mode(ctx, a, SPMV_PLAIN, x8, q8, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0));
+        hipLaunchKernelGGL(residual8_kernel, dim3(gv), dim3(256), 0, s, n, b8, q8, pslot(P_TMP));
+        PADNE_HIP_CHECK(hipGetLastError());
+        PADNE_TRY(fold(pslot(P_TMP), gv, scal + C_TRUE));
+        double *hd = (double *)((char *)ctx->pinned + 1024);
+        PADNE_HIP_CHECK(hipMemcpyAsync(hd, scal + C_TRUE, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
+        PADNE_HIP_CHECK(hipStreamSynchronize(s));
+        bool all_final = true;
+        for (int c = 0; c < 8; ++c) {
+            true_rr[c] = hd[c];
+            if (true_rr[c] <= tol2[c] * 1.0000001) continue;
+            if (restarts > 0 && true_rr[c] >= 0.25 * prev_true_rr[c]) {
+                stagnated[c] = true;      // the evaluation floor of b - A x in binary64 (see solve_one)
+                continue;
+            }
+            all_final = false;
+        }
+        if (code != PADNE_OK || all_final || total_iters >= max_iter || restarts >= 8) break;
+        for (int c = 0; c < 8; ++c) prev_true_rr[c] = true_rr[c];
+        ++restarts;
+        have_ax = true;
+        PADNE_HIP_CHECK(hipMemsetAsync(st, 0, 4 * sizeof(int32_t) + 16 * sizeof(int32_t), s));   // flags and counters
+    }
+    PADNE_TRY(interleave8(ctx, n, x8, x_cols, false));
+    PADNE_HIP_CHECK(hipEventRecord(ctx->ev1, s));
+    PADNE_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    PADNE_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    if (info) {
+        for (int c = 0; c < 8; ++c) {
+            info->iterations += col_iters[c];
+            const double rel = bb[c] > 0 ? sqrt(true_rr[c] / bb[c]) : sqrt(true_rr[c]);
+            if (rel > info->rel_residual) info->rel_residual = rel;
+            if (sqrt(true_rr[c]) > info->abs_residual) info->abs_residual = sqrt(true_rr[c]);
+            if (code == PADNE_OK && true_rr[c] > tol2[c] * 1.0000001 && info->status == PADNE_OK &&
+                !(stagnated[c] && true_rr[c] <= 100.0 * tol2[c]))
+                info->status = PADNE_E_NOTCONVERGED;
+        }
+        info->restarts += restarts;
+        info->solve_seconds += ms * 1e-3;
+        if (code != PADNE_OK) info->status = code;
+    }
+    return PADNE_OK;
+}
+
 // ---- largest eigenvalue of D^-1 A from the Lanczos coefficients of a few Jacobi-PCG steps ------------
 __global__ void fill_pseudo_random(long long n, double *__restrict__ v) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -778,7 +1052,23 @@ extern "C" int padne_solve_spd_dev(padne_ctx *ctx, const padne_csr *a, const voi
         }
     }
     const long long n = ctx->halo_on ? ctx->halo_n_owned : a->n_rows;
-    for (int k = 0; k < n_rhs; ++k) {
+    int k_first = 0;
+    if (use_amg && !ctx->halo_on && ctx->comm == nullptr && ctx->team == nullptr && pm == a && amg_supports_batch8(a) &&
+        getenv("PADNE_NO_BATCH") == nullptr) {
+        // groups of 8 right-hand sides advance in lockstep (one pass over the operators per iteration for all of
+        // them); a group whose cycle breaks down falls through to the one-at-a-time path below
+        for (; k_first + 8 <= n_rhs; k_first += 8) {
+            padne_solve_info grp = local;
+            grp.status = PADNE_OK;
+            PADNE_TRY(solve_batch8(ctx, a, (const double *)b_dev + (size_t)k_first * n, (double *)x_dev + (size_t)k_first * n,
+                                   opts, &grp, (opts->flags & 1) != 0));
+            if (grp.status != PADNE_OK) break;
+            const int keep = local.status;
+            local = grp;
+            local.status = keep;
+        }
+    }
+    for (int k = k_first; k < n_rhs; ++k) {
         const int status_before = local.status;
         PADNE_TRY(solve_one(ctx, a, use_amg ? pm : nullptr, (const double *)b_dev + (size_t)k * n,
                             (double *)x_dev + (size_t)k * n, opts, &local, (opts->flags & 1) != 0));

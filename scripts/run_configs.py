@@ -26,9 +26,21 @@ for name in ["C2", "C3", "C4", "C5"]:
             full = np.zeros(nv); full[f[k]] += 1.0; full[tt[k]] -= 1.0
             B[k] = full[keep]
         b = ctx.to_device(B); x = ctx.empty((8, nv - 1))
+        A.solve_spd_dev(b, x, n_rhs=8, precond="amg", rebuild=True)        # warm the allocator
         t = time.perf_counter(); r = A.solve_spd_dev(b, x, n_rhs=8, precond="amg", rebuild=True); w = time.perf_counter() - t
+        xb = x.numpy()
         rec.update({"n_rhs": 8, "iterations_total": r.iterations, "setup_ms": r.setup_seconds * 1e3, "solve_ms_all_rhs": r.seconds * 1e3,
-                    "wall_ms": w * 1e3, "rel_residual_max": r.rel_residual, "note": "right-hand sides solved one after another on one cached hierarchy"})
+                    "wall_ms": w * 1e3, "rel_residual_max": r.rel_residual,
+                    "note": "8 right-hand sides advanced in lockstep (SpMM, one pass over the operators per iteration)"})
+        xs8 = ctx.to_device(np.random.default_rng(2).uniform(-1, 1, A.shape[1] * 8)); ys8 = ctx.empty(A.shape[0] * 8)
+        t8 = min(A.spmm8_time(xs8, ys8, 5, 30) for _ in range(3))
+        rec.update({"spmm8_us": t8 * 1e6, "spmm8_gbs_algorithmic": A.spmm8_bytes / t8 / 1e9, "spmm8_vs_8_spmv": 8 * t_spmv / t8})
+        os.environ["PADNE_NO_BATCH"] = "1"
+        t = time.perf_counter(); r1 = A.solve_spd_dev(b, x, n_rhs=8, precond="amg", rebuild=True); w1 = time.perf_counter() - t
+        del os.environ["PADNE_NO_BATCH"]
+        rec.update({"one_at_a_time": {"iterations_total": r1.iterations, "solve_ms_all_rhs": r1.seconds * 1e3, "wall_ms": w1 * 1e3},
+                    "batched_vs_one_at_a_time_max_rel_diff": float(np.abs(xb - x.numpy()).max() / np.abs(xb).max())})
+        del xs8, ys8
     else:
         b = ctx.to_device(-rhs[keep]); x = ctx.empty(nv - 1)
         best = None

@@ -820,6 +820,36 @@ def test_row_partitioned_hierarchy_with_several_exchanged_levels(monkeypatch):
         assert res.levels >= 4 and iters < 60
 
 
+def test_batched_right_hand_sides_in_lockstep(ctx, monkeypatch):
+    """Config C5 at test size: 11 current-source configurations = one lockstep group of 8 + 3 solved one at a time;
+    every column must match the direct solve and the one-at-a-time path."""
+    A, b, Lo, ro, n = layered_spd(4, 120, 100, 6)
+    rng = np.random.default_rng(9)
+    k = 11
+    B = np.zeros((k, A.shape[0]))
+    for c in range(k):
+        f, t = rng.choice(A.shape[0], 2, replace=False)
+        B[c, f] += 1.0 + c
+        B[c, t] -= 1.0 + c
+    B[3] *= 1e-20                                  # wildly different scales in one group
+    B[5] = 0.0                                     # and a zero right-hand side (converged at once)
+    d = ctx.csr_from_scipy(A)
+    res = d.solve_spd(B, precond="amg")
+    assert res.rel_residual <= 1.1e-12 and res.precond_fallbacks == 0
+    monkeypatch.setenv("PADNE_NO_BATCH", "1")
+    seq = d.solve_spd(B, precond="amg")
+    import scipy.sparse.linalg as spla
+    lu = spla.splu(A.tocsc())
+    for c in range(k):
+        ref = lu.solve(B[c])
+        scale = max(np.abs(ref).max(), 1e-300)
+        assert np.abs(res.x[c] - ref).max() <= REL_TOL * scale
+        assert np.abs(res.x[c] - seq.x[c]).max() <= REL_TOL * scale
+    assert np.all(res.x[5] == 0.0)
+    # the lockstep group does not cost more iterations per column than the one-at-a-time path
+    assert res.iterations <= seq.iterations + 8
+
+
 def test_spmm8_columns_are_bitwise_the_single_vector_products(ctx):
     """8 interleaved right-hand sides through one pass over the matrix; ragged rows, empty rows, long rows."""
     rng = np.random.default_rng(3)
