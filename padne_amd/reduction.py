@@ -163,18 +163,56 @@ class Reduction:
     groups: list                   # list of (members list[int], constraint list[Constraint], root or None)
     regulators: list               # constraints with a non-empty gamma
 
+    def _plan(self):
+        """Split the index map into long contiguous runs (index_map[i0:i1] == arange(t0, t0 + i1 - i0)), which are
+        copied with slices, and the few remaining entries (ground, source-tied groups, run borders).  A reduced
+        system is almost the identity with a handful of holes, so at N = 10 M this replaces two boolean-mask
+        gathers of 80 MB (45 ms each) by slice copies."""
+        plan = getattr(self, "_run_plan", None)
+        if plan is not None and plan[0] is self.index_map:
+            return plan
+        imap = self.index_map
+        n = imap.shape[0]
+        brk = np.flatnonzero((imap[1:] != imap[:-1] + 1) | (imap[1:] < 0) | (imap[:-1] < 0)) + 1
+        starts = np.concatenate([[0], brk])
+        ends = np.concatenate([brk, [n]])
+        runs, rest = [], []
+        if len(starts) <= 4096:
+            for i0, i1 in zip(starts.tolist(), ends.tolist()):
+                if imap[i0] >= 0 and i1 - i0 >= 256:
+                    runs.append((i0, i1, int(imap[i0])))
+                elif imap[i0] >= 0 or i1 - i0 > 1:
+                    rest.append(np.arange(i0, i1))
+            rest = np.concatenate(rest) if rest else np.zeros(0, dtype=np.int64)
+            rest = rest[imap[rest] >= 0]
+        else:                                   # scattered map (e.g. after the locality reordering): generic path
+            runs, rest = [], np.flatnonzero(imap >= 0)
+        plan = (imap, runs, rest, imap[rest].astype(np.int64))
+        self._run_plan = plan
+        return plan
+
     def expand(self, y: np.ndarray) -> np.ndarray:
         """v (multipliers still zero) from the reduced solution."""
+        _, runs, rest, rest_t = self._plan()
         v = self.c.copy()
-        free = self.index_map >= 0
-        v[free] += y[self.index_map[free]]
+        for i0, i1, t0 in runs:
+            v[i0:i1] += y[t0:t0 + (i1 - i0)]
+        if len(rest):
+            v[rest] += y[rest_t]
         return v
 
     def rhs(self, r: np.ndarray, Lc: np.ndarray | None) -> np.ndarray:
         """b = -P^T (r - L c) on the free groups."""
         resid = r if Lc is None else r - Lc
-        free = self.index_map >= 0
-        return -np.bincount(self.index_map[free], weights=resid[free], minlength=self.n_free)
+        _, runs, rest, rest_t = self._plan()
+        b = np.zeros(self.n_free)
+        if len(rest) * 8 > self.n_free:
+            b -= np.bincount(rest_t, weights=resid[rest], minlength=self.n_free)
+        elif len(rest):
+            np.subtract.at(b, rest_t, resid[rest])
+        for i0, i1, t0 in runs:
+            b[t0:t0 + (i1 - i0)] -= resid[i0:i1]
+        return b
 
     def project(self, vec_rows: dict) -> np.ndarray:
         """P^T applied to a sparse row-indexed vector {row: value}."""

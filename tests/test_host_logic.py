@@ -281,3 +281,37 @@ def test_locality_ordering_is_a_permutation_that_keeps_mesh_blocks():
     d_before = np.abs(stri[:, 0].astype(np.int64) - stri[:, 1]).mean()
     d_after = np.abs(rank[stri[:, 0]] - rank[stri[:, 1]]).mean()
     assert d_after * 10 < d_before
+
+
+def test_reduction_run_plan_matches_the_plain_formulas():
+    """expand / rhs use slice copies over the contiguous runs of the index map; same result as the masks."""
+    from padne_amd.reduction import Reduction
+    rng = np.random.default_rng(4)
+    n = 20000
+    imap = np.full(n + 3, -1, dtype=np.int32)
+    elim = np.zeros(n, dtype=bool)
+    elim[rng.choice(n, 40, replace=False)] = True          # ground-like holes
+    keep = ~elim
+    imap[:n][keep] = np.arange(keep.sum(), dtype=np.int32)
+    merged = np.flatnonzero(elim)[:15]                      # tied nodes numbered through another node
+    imap[merged] = imap[:n][keep][rng.integers(0, keep.sum(), 15)]
+    n_free = int(keep.sum())
+    c = np.zeros(n + 3)
+    c[merged] = rng.uniform(-1, 1, 15)
+    red = Reduction(layout=None, index_map=imap, n_free=n_free, c=c, groups=[], regulators=[])
+    y = rng.uniform(-1, 1, n_free)
+    r = rng.uniform(-1, 1, n + 3)
+    free = imap >= 0
+    v_ref = c.copy()
+    v_ref[free] += y[imap[free]]
+    b_ref = -np.bincount(imap[free], weights=r[free], minlength=n_free)
+    assert len(red._plan()[1]) > 5                          # the long runs are really used
+    assert np.array_equal(red.expand(y), v_ref)
+    assert np.allclose(red.rhs(r, None), b_ref, rtol=0, atol=1e-15)
+    # a scattered map (after the locality reordering) takes the generic path
+    perm = rng.permutation(n_free).astype(np.int32)
+    red2 = Reduction(layout=None, index_map=np.where(imap >= 0, perm[np.maximum(imap, 0)], -1).astype(np.int32),
+                     n_free=n_free, c=c, groups=[], regulators=[])
+    v2 = c.copy()
+    v2[free] += y[red2.index_map[free]]
+    assert np.array_equal(red2.expand(y), v2)
