@@ -5,20 +5,26 @@
 //
 // Setup per level (all deterministic -- priorities are hashes of the index, sums have a fixed order):
 //   strength   j is a strong neighbour of i  <=>  a_ij^2 >= theta^2 a_ii a_jj          (theta = 0.1)
-//   aggregate  distance-2 maximal independent set of the strength graph by Luby rounds on
-//              (hash(i), i) priorities -> roots; every other vertex joins the aggregate of its
-//              strongest aggregated neighbour (two passes); vertices without strong neighbours
-//              become singletons
-//   prolong    P = (I - omega D^-1 A) T,  T = piecewise constant,  omega = 4 / (3 lambda),
-//              lambda = max_i sum_j |a_ij| / a_ii  >=  lambda_max(D^-1 A)   (Gershgorin)
+//   aggregate  distance-2 maximal independent set of the strength graph (MIS-k rounds on unique 32-bit
+//              priority words, two neighbour-max passes per round) -> roots; every other vertex joins the
+//              aggregate of its strongest aggregated neighbour (two passes); vertices without strong
+//              neighbours become singletons
+//   prolong    P = (I - omega D_F^-1 A_F) T,  T = piecewise constant, A_F = A with the weak entries lumped into
+//              the diagonal,  omega = 4 / (3 lambda),  lambda = Gershgorin bound of D_F^-1 A_F
 //   restrict   R = P^T stored explicitly (CSR) so that restriction is the same SpMV kernel
-//   coarse     A_c = R (A P) by two row-wise sparse products (sorted-insert accumulation)
-// until n <= 512, where the dense inverse is formed by Gauss-Jordan (SPD: no pivoting).
+//   coarse     A_c = R (A P) by two row-wise sparse products: one thread per row with sorted lists in LDS for
+//              short rows, one wave per row (hash set + per-lane ordered sums) for medium rows, a dense LDS
+//              accumulator for the long rows of the coarse levels; products are always added in generation order
+// until n <= 1024, where the dense inverse is formed by a blocked Gauss-Jordan (SPD: no pivoting).
 //
 // Apply: V(1,1) cycle with damped Jacobi (first-degree Chebyshev on [lambda/10, lambda]); every
 // stage is the SpMV kernel of spmv.hip with a different epilogue (residual, prolong-add,
 // Jacobi sweep), so the fine level costs three matrix passes per CG iteration.  The cycle is a
-// fixed symmetric positive definite linear operator, hence plain PCG applies.
+// fixed symmetric positive definite linear operator, hence plain PCG applies.  By default it runs in
+// single precision on float copies of its operators (amg_apply_f32), also for 8 interleaved right-hand
+// sides at once (amg_apply_batch8).
+//
+// Row-partitioned runs (one rank per GPU): one hierarchy over all ranks, see amg_setup_dist below.
 #include "common.hpp"
 
 #include <algorithm>
@@ -84,13 +90,6 @@ constexpr double kChebRatio = 10.0;
 
 // ---- small kernels -----------------------------------------------------------------------------
 
-__device__ __forceinline__ unsigned long long prio_of(int i) {
-    unsigned int h = (unsigned int)i * 2654435761u;
-    h ^= h >> 15;
-    h *= 2246822519u;
-    h ^= h >> 13;
-    return ((unsigned long long)h << 32) | (unsigned int)(i + 1);
-}
 
 // 32-bit competition word of the MIS rounds: 0 = decided (covered), kMisRoot = root, otherwise a priority that
 // is unique per vertex (bijective 31-bit mix of the index, + 1)
@@ -108,14 +107,6 @@ __device__ __forceinline__ unsigned int prio32_of(int i) {
 
 __device__ __forceinline__ bool strong(double a, double di, double dj, double theta2) {
     return a * a * di * dj >= theta2;   // a_ij^2 >= theta^2 a_ii a_jj with d = 1/a_ii
-}
-
-__global__ void mis_prep(int n, const signed char *__restrict__ state, unsigned long long *__restrict__ out,
-                         int what) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (what == 0) out[i] = state[i] == 0 ? prio_of(i) : 0ull;   // undecided vertices compete
-    else out[i] = state[i] == 1 ? 1ull : 0ull;                   // roots radiate coverage
 }
 
 // strength graph S: for every row the strong off-diagonal neighbours (columns sorted) and |a_ij|
@@ -218,23 +209,6 @@ __global__ void mis_decide(int n, unsigned int *__restrict__ word, const unsigne
         } else {
             open = true;
         }
-    }
-    if (__ballot(open) != 0ull && (threadIdx.x & 63) == 0) *undecided = 1;   // only "any left?" matters (benign race)
-}
-
-__global__ void mis_mark_roots(int n, signed char *__restrict__ state, const unsigned long long *__restrict__ m2) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (state[i] == 0 && m2[i] == prio_of(i)) state[i] = 1;
-}
-
-__global__ void mis_cover(int n, signed char *__restrict__ state, const unsigned long long *__restrict__ c2,
-                          int *__restrict__ undecided) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool open = false;
-    if (i < n && state[i] == 0) {
-        if (c2[i] > 0) state[i] = 2;
-        else open = true;
     }
     if (__ballot(open) != 0ull && (threadIdx.x & 63) == 0) *undecided = 1;   // only "any left?" matters (benign race)
 }
@@ -931,12 +905,12 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
     const int n = (int)A->n_rows;
     const double theta2 = kTheta * kTheta;
     signed char *state = nullptr;
-    unsigned long long *u0 = nullptr, *u1 = nullptr, *u2 = nullptr;
+    unsigned int *w0 = nullptr, *w1 = nullptr, *w2 = nullptr;
     int *flag = nullptr, *scan = nullptr, *agg0 = nullptr, *agg1 = nullptr, *counter = nullptr;
     PADNE_TRY(sc.alloc(&state, (size_t)n));
-    PADNE_TRY(sc.alloc(&u0, (size_t)n));
-    PADNE_TRY(sc.alloc(&u1, (size_t)n));
-    PADNE_TRY(sc.alloc(&u2, (size_t)n));
+    PADNE_TRY(sc.alloc(&w0, (size_t)n));
+    PADNE_TRY(sc.alloc(&w1, (size_t)n));
+    PADNE_TRY(sc.alloc(&w2, (size_t)n));
     PADNE_TRY(sc.alloc(&flag, (size_t)n + 1));
     PADNE_TRY(sc.alloc(&scan, (size_t)n + 1));
     PADNE_TRY(sc.alloc(&agg0, (size_t)n));
@@ -959,7 +933,6 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
     PADNE_HIP_CHECK(hipGetLastError());
     const int n_wt = (n + 63) / 64;
     const dim3 gm((unsigned)std::min(2048, (n_wt + 3) / 4 > 0 ? (n_wt + 3) / 4 : 1));
-    unsigned int *w0 = (unsigned int *)u0, *w1 = (unsigned int *)u1, *w2 = (unsigned int *)u2;
     hipLaunchKernelGGL(mis_init_words, g, b, 0, s, n, w0);
     for (int round = 0; round < 128; ++round) {
         hipLaunchKernelGGL(nbr_max<unsigned int>, gm, b, 0, s, n, n_wt, srow, scol, w0, w1);
