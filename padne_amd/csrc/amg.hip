@@ -109,34 +109,51 @@ __device__ __forceinline__ bool strong(double a, double di, double dj, double th
     return a * a * di * dj >= theta2;   // a_ij^2 >= theta^2 a_ii a_jj with d = 1/a_ii
 }
 
-// strength graph S: for every row the strong off-diagonal neighbours (columns sorted) and |a_ij|
-__global__ void strength_count(int n, const int *__restrict__ rowptr, const int *__restrict__ cols,
-                               const double *__restrict__ vals, const double *__restrict__ dinv, double theta2,
-                               int *__restrict__ cnt) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double di = dinv[i];
-    int c = 0;
-    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
-        const int j = cols[k];
-        c += (j != i && strong(vals[k], di, dinv[j], theta2)) ? 1 : 0;
-    }
-    cnt[i] = c;
-}
-
-__global__ void strength_fill(int n, const int *__restrict__ rowptr, const int *__restrict__ cols,
-                              const double *__restrict__ vals, const double *__restrict__ dinv, double theta2,
-                              const int *__restrict__ srow, int *__restrict__ scol, double *__restrict__ sval) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double di = dinv[i];
-    int o = srow[i];
-    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
-        const int j = cols[k];
-        if (j != i && strong(vals[k], di, dinv[j], theta2)) {
-            scol[o] = j;
-            sval[o] = fabs(vals[k]);
-            ++o;
+// Strength graph S on the pattern of A: scol[k] = column of entry k if it is a strong off-diagonal coupling,
+// otherwise the row itself (a self loop is neutral for the neighbour maxima and is skipped by the joins).  No
+// compaction, no second array of weights (the joins read |a_ij| from A): one coalesced pass over the matrix.
+// Wave-private tiles of 64 rows as in the SpMV kernel; the row of every staged element comes from LDS.
+__global__ __launch_bounds__(256) void strength_mark(int n, int n_wtiles, const int *__restrict__ rowptr,
+                                                     const int *__restrict__ cols, const double *__restrict__ vals,
+                                                     const double *__restrict__ dinv, double theta2,
+                                                     int *__restrict__ scol) {
+    constexpr int CH = 512;
+    __shared__ unsigned char rid_all[4 * CH];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned char *rid = rid_all + w * CH;
+    const long long W = (long long)gridDim.x * 4, gw = (long long)blockIdx.x * 4 + w;
+    for (long long wt = gw; wt < n_wtiles; wt += W) {
+        const int row0 = (int)wt * 64;
+        const int row1 = min(row0 + 64, n);
+        const int r = row0 + lane;
+        int rs = 0, re = 0;
+        double di = 0.0;
+        if (r < row1) {
+            rs = rowptr[r];
+            re = rowptr[r + 1];
+            di = dinv[r];
+        }
+        const int k0 = __shfl(rs, 0, 64);
+        const int k1 = __shfl(re, row1 - row0 - 1, 64);
+        for (int base = k0; base < k1; base += CH) {
+            const int lo = max(rs, base), hi = min(re, base + CH);
+            for (int k = lo; k < hi; ++k) rid[k - base] = (unsigned char)lane;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < CH / 64; ++q) {
+                const int e = base + lane + 64 * q;
+                const int rl = e < k1 ? rid[e - base] : 0;
+                const double dr = __shfl(di, rl, 64);          // all lanes take part: the source lane may be past k1
+                if (e < k1) {
+                    const int i = row0 + rl;
+                    const int c = cols[e];
+                    const bool st = c != i && strong(vals[e], dr, dinv[c], theta2);
+                    scol[e] = st ? c : i;
+                }
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -193,24 +210,112 @@ __global__ void mis_init_words(int n, unsigned int *__restrict__ word) {
     if (i < n) word[i] = prio32_of(i);
 }
 
-__global__ void mis_decide(int n, unsigned int *__restrict__ word, const unsigned int *__restrict__ m2,
-                           signed char *__restrict__ state, int *__restrict__ undecided) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool open = false;
-    if (i < n && state[i] == 0) {
-        const unsigned int mine = word[i], top = m2[i];
-        if (top == kMisRoot) {
-            state[i] = 2;
-            word[i] = 0u;
-        } else if (top == mine) {
-            state[i] = 1;
-            word[i] = kMisRoot;
-            open = true;          // its neighbourhood is still to be covered
-        } else {
-            open = true;
+__device__ __forceinline__ bool mis_decide_one(int i, unsigned int top, unsigned int *__restrict__ word,
+                                               signed char *__restrict__ state) {
+    // returns true if vertex i is still undecided after this round
+    const unsigned int mine = word[i];
+    if (top == kMisRoot) {
+        state[i] = 2;
+        word[i] = 0u;
+        return false;
+    }
+    if (top == mine) {
+        state[i] = 1;
+        word[i] = kMisRoot;
+        return false;
+    }
+    return true;
+}
+
+// full round: every vertex looks at its two-hop maximum m2; *undecided = number of vertices still open
+// (grid-stride, one atomic per workgroup: a per-wave atomic on one address costs 1.7 ms at N = 10 M)
+__global__ __launch_bounds__(256) void mis_decide(int n, unsigned int *__restrict__ word, const unsigned int *__restrict__ m2,
+                                                  signed char *__restrict__ state, int *__restrict__ undecided) {
+    __shared__ int red[4];
+    int open = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+        if (state[i] == 0 && mis_decide_one(i, m2[i], word, state)) ++open;
+    for (int off = 32; off > 0; off >>= 1) open += __shfl_down(open, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = open;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = red[0] + red[1] + red[2] + red[3];
+        if (t) atomicAdd(undecided, t);
+    }
+}
+
+// Late rounds touch only the vertices that are still open (a few per cent after three or four rounds, while a
+// full neighbour-max pass streams the whole strength graph): compact list + direct two-hop maximum per vertex.
+// Same words, same decisions as the full rounds, so the aggregates do not depend on where the switch happens.
+// Every workgroup compacts one contiguous slice: count, one atomic for the base, then write.
+__global__ __launch_bounds__(256) void mis_collect_open(int n, const signed char *__restrict__ state, int *__restrict__ list,
+                                                        int *__restrict__ count) {
+    __shared__ int red[4];
+    __shared__ int base_s;
+    const int per = (n + gridDim.x - 1) / gridDim.x;
+    const int i0 = blockIdx.x * per, i1 = min(i0 + per, n);
+    int mine = 0;
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) mine += state[i] == 0 ? 1 : 0;
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = red[0] + red[1] + red[2] + red[3];
+        base_s = t ? atomicAdd(count, t) : 0;
+    }
+    __syncthreads();
+    int base = base_s;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int c0 = i0; c0 < i1; c0 += 256) {
+        const int i = c0 + threadIdx.x;
+        const bool open = i < i1 && state[i] == 0;
+        const unsigned long long mask = __ballot(open);
+        __syncthreads();
+        if (lane == 0) red[w] = __popcll(mask);
+        __syncthreads();
+        int before = 0;
+        for (int q = 0; q < w; ++q) before += red[q];
+        if (open) list[base + before + __popcll(mask & ((1ull << lane) - 1ull))] = i;
+        base += red[0] + red[1] + red[2] + red[3];
+    }
+}
+
+__global__ void mis_two_hop_max(int cnt, const int *__restrict__ list, const int *__restrict__ srow,
+                                const int *__restrict__ scol, const unsigned int *__restrict__ word,
+                                unsigned int *__restrict__ m2) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= cnt) return;
+    const int i = list[t];
+    unsigned int m = word[i];
+    for (int a = srow[i]; a < srow[i + 1]; ++a) {
+        const int j = scol[a];
+        if (j == i) continue;
+        const unsigned int wj = word[j];
+        m = wj > m ? wj : m;
+        for (int b = srow[j]; b < srow[j + 1]; ++b) {
+            const unsigned int wk = word[scol[b]];
+            m = wk > m ? wk : m;
         }
     }
-    if (__ballot(open) != 0ull && (threadIdx.x & 63) == 0) *undecided = 1;   // only "any left?" matters (benign race)
+    m2[t] = m;
+}
+
+__global__ void mis_decide_list(int cnt, const int *__restrict__ list, const unsigned int *__restrict__ m2,
+                                unsigned int *__restrict__ word, signed char *__restrict__ state,
+                                int *__restrict__ list_next, int *__restrict__ count_next) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    bool open = false;
+    int i = 0;
+    if (t < cnt) {
+        i = list[t];
+        open = mis_decide_one(i, m2[t], word, state);
+    }
+    const unsigned long long mask = __ballot(open);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0 && mask != 0ull) base = atomicAdd(count_next, __popcll(mask));
+    base = __shfl(base, 0, 64);
+    if (open) list_next[base + __popcll(mask & ((1ull << lane) - 1ull))] = i;
 }
 
 __global__ void flag_state(int n, const signed char *__restrict__ state, int *__restrict__ flag, int which) {
@@ -225,16 +330,18 @@ __global__ void agg_from_roots(int n, const signed char *__restrict__ state, con
 }
 
 __global__ void agg_join(int n, const int *__restrict__ srow, const int *__restrict__ scol,
-                         const double *__restrict__ sval, const int *__restrict__ agg_in, int *__restrict__ agg_out) {
+                         const double *__restrict__ vals, const int *__restrict__ agg_in, int *__restrict__ agg_out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int a = agg_in[i];
     if (a < 0) {
         double best = -1.0;
         for (int k = srow[i]; k < srow[i + 1]; ++k) {
-            const int aj = agg_in[scol[k]];
+            const int j = scol[k];
+            if (j == i) continue;                 // weak or diagonal entry
+            const int aj = agg_in[j];
             if (aj < 0) continue;
-            const double w = sval[k];
+            const double w = fabs(vals[k]);
             if (w > best) {   // ties: columns are sorted, the smaller index wins
                 best = w;
                 a = aj;
@@ -918,40 +1025,60 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
     PADNE_TRY(sc.alloc(&counter, 1));
     PADNE_HIP_CHECK(hipMemsetAsync(state, 0, (size_t)n, s));
     const dim3 g(nblk(n)), b(256);
-    // strength graph, built once per level
-    int *scnt = nullptr, *srow = nullptr, *scol = nullptr;
-    double *sval = nullptr;
-    PADNE_TRY(sc.alloc(&scnt, (size_t)n + 1));
-    PADNE_TRY(sc.alloc(&srow, (size_t)n + 1));
-    hipLaunchKernelGGL(strength_count, g, b, 0, s, n, A->rowptr, A->cols, A->vals, A->dinv, theta2, scnt);
-    PADNE_HIP_CHECK(hipGetLastError());
-    int64_t s_nnz = 0;
-    PADNE_TRY(exclusive_scan_i32(ctx, scnt, srow, n, &s_nnz));
-    PADNE_TRY(sc.alloc(&scol, (size_t)s_nnz));
-    PADNE_TRY(sc.alloc(&sval, (size_t)s_nnz));
-    hipLaunchKernelGGL(strength_fill, g, b, 0, s, n, A->rowptr, A->cols, A->vals, A->dinv, theta2, srow, scol, sval);
-    PADNE_HIP_CHECK(hipGetLastError());
+    // strength graph on the pattern of A, built once per level
+    const int *srow = A->rowptr;
+    int *scol = nullptr;
+    PADNE_TRY(sc.alloc(&scol, (size_t)(A->nnz > 0 ? A->nnz : 1)));
     const int n_wt = (n + 63) / 64;
     const dim3 gm((unsigned)std::min(2048, (n_wt + 3) / 4 > 0 ? (n_wt + 3) / 4 : 1));
+    hipLaunchKernelGGL(strength_mark, gm, b, 0, s, n, n_wt, A->rowptr, A->cols, A->vals, A->dinv, theta2, scol);
+    PADNE_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(mis_init_words, g, b, 0, s, n, w0);
-    for (int round = 0; round < 128; ++round) {
+    int open_count = n;
+    int round = 0;
+    // the compact rounds pay off on sparse rows only: a direct two-hop maximum visits (nnz/row)^2 words per vertex
+    const bool compact_ok = A->nnz <= 16LL * n;
+    for (; round < 256 && open_count > 0 && (!compact_ok || round < 2 || open_count > n / 8); ++round) {
         hipLaunchKernelGGL(nbr_max<unsigned int>, gm, b, 0, s, n, n_wt, srow, scol, w0, w1);
         hipLaunchKernelGGL(nbr_max<unsigned int>, gm, b, 0, s, n, n_wt, srow, scol, w1, w2);
         PADNE_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(int), s));
-        hipLaunchKernelGGL(mis_decide, g, b, 0, s, n, w0, w2, state, counter);
+        hipLaunchKernelGGL(mis_decide, dim3(std::min<unsigned>(g.x, 1024u)), b, 0, s, n, w0, w2, state, counter);
         PADNE_HIP_CHECK(hipGetLastError());
-        int h = 0;
-        PADNE_HIP_CHECK(hipMemcpyAsync(&h, counter, sizeof(int), hipMemcpyDeviceToHost, s));
+        PADNE_HIP_CHECK(hipMemcpyAsync(&open_count, counter, sizeof(int), hipMemcpyDeviceToHost, s));
         PADNE_HIP_CHECK(hipStreamSynchronize(s));
-        if (h == 0) break;
     }
+    if (open_count > 0) {
+        // compact rounds; the word buffers of the full passes are free now and serve as the two lists (w1, w2 hold
+        // n entries each, the open vertices are fewer)
+        int *list_a = (int *)w1, *list_b = (int *)w2;
+        unsigned int *m2 = nullptr;
+        int *counters = nullptr;
+        PADNE_TRY(sc.alloc(&m2, (size_t)open_count));
+        PADNE_TRY(sc.alloc(&counters, 2));
+        PADNE_HIP_CHECK(hipMemsetAsync(counters, 0, 2 * sizeof(int), s));
+        hipLaunchKernelGGL(mis_collect_open, dim3(std::min<unsigned>(g.x, 1024u)), b, 0, s, n, state, list_a, counters);
+        PADNE_HIP_CHECK(hipGetLastError());
+        int cnt = open_count;
+        for (; round < 256 && cnt > 0; ++round) {
+            const dim3 gl(nblk(cnt));
+            hipLaunchKernelGGL(mis_two_hop_max, gl, b, 0, s, cnt, list_a, srow, scol, w0, m2);
+            PADNE_HIP_CHECK(hipMemsetAsync(counters + 1, 0, sizeof(int), s));
+            hipLaunchKernelGGL(mis_decide_list, gl, b, 0, s, cnt, list_a, m2, w0, state, list_b, counters + 1);
+            PADNE_HIP_CHECK(hipGetLastError());
+            PADNE_HIP_CHECK(hipMemcpyAsync(&cnt, counters + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+            PADNE_HIP_CHECK(hipStreamSynchronize(s));
+            std::swap(list_a, list_b);
+        }
+        open_count = cnt;
+    }
+    PADNE_REQUIRE(open_count == 0, "independent-set rounds did not terminate");
     // number the roots
     hipLaunchKernelGGL(flag_state, g, b, 0, s, n, state, flag, 1);
     int64_t n_roots = 0;
     PADNE_TRY(exclusive_scan_i32(ctx, flag, scan, n, &n_roots));
     hipLaunchKernelGGL(agg_from_roots, g, b, 0, s, n, state, scan, agg0);
-    hipLaunchKernelGGL(agg_join, g, b, 0, s, n, srow, scol, sval, agg0, agg1);
-    hipLaunchKernelGGL(agg_join, g, b, 0, s, n, srow, scol, sval, agg1, agg0);
+    hipLaunchKernelGGL(agg_join, g, b, 0, s, n, srow, scol, A->vals, agg0, agg1);
+    hipLaunchKernelGGL(agg_join, g, b, 0, s, n, srow, scol, A->vals, agg1, agg0);
     hipLaunchKernelGGL(flag_unaggregated, g, b, 0, s, n, agg0, flag);
     PADNE_HIP_CHECK(hipGetLastError());
     int64_t n_single = 0;
