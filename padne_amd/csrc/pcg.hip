@@ -873,8 +873,14 @@ int estimate_lambda_max(padne_ctx *ctx, const padne_csr *a, int steps, double *l
     PcgStatus *st = (PcgStatus *)ctx->status;
     hipStream_t s = ctx->stream;
     const int gv = vec_grid(n), gs = spmv_grid(a);
-    double *scal = ctx->scalars + 32;     // [0] pq  [2..3] {rz, rr} even  [4..5] {rz, rr} odd
-    double *h = (double *)ctx->pinned + 64;
+    // every step's scalars stay on the device (kernels consume them there); the host reads the whole history
+    // once at the end instead of synchronising 12 times per level
+    PADNE_REQUIRE(steps >= 1 && steps <= 60, "Lanczos steps");
+    Scratch sc(ctx);
+    double *hist = nullptr;                 // rz[0..steps] | pq[0..steps) | rr (scratch)
+    PADNE_TRY(sc.alloc(&hist, (size_t)2 * steps + 4));
+    double *H_rz = hist, *H_pq = hist + steps + 1, *s_rr = hist + 2 * steps + 2;
+    PADNE_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(double) * ((size_t)2 * steps + 4), s));
     PADNE_HIP_CHECK(hipMemsetAsync(st, 0, sizeof(PcgStatus), s));
     PADNE_HIP_CHECK(hipMemsetAsync(x, 0, sizeof(double) * (size_t)n, s));
     if (nc > n) PADNE_HIP_CHECK(hipMemsetAsync(p + n, 0, sizeof(double) * (size_t)(nc - n), s));
@@ -887,39 +893,44 @@ int estimate_lambda_max(padne_ctx *ctx, const padne_csr *a, int steps, double *l
         PADNE_HIP_CHECK(hipGetLastError());
         return PADNE_OK;
     };
-    PADNE_TRY(fold(slot(ctx, SLOT_RZ0), gv, scal + 2));
-    if (dist) PADNE_TRY(comm_allreduce_sum_f64(ctx, scal + 2, 1));
-    std::vector<double> alpha, beta;
+    PADNE_TRY(fold(slot(ctx, SLOT_RZ0), gv, H_rz));
+    if (dist) PADNE_TRY(comm_allreduce_sum_f64(ctx, H_rz, 1));
     int parity = 0;
     for (int k = 0; k < steps; ++k) {
         double *rz_old_part = slot(ctx, parity ? SLOT_RZ1 : SLOT_RZ0);
         double *rz_new_part = slot(ctx, parity ? SLOT_RZ0 : SLOT_RZ1);
-        double *s_old = scal + (parity ? 4 : 2), *s_new = scal + (parity ? 2 : 4);
         if (dist) PADNE_TRY(halo_exchange_plan(ctx, *plan, p, nullptr));
         PADNE_TRY(launch_spmv(ctx, a, p, q, p, slot(ctx, SLOT_PQ), nullptr));
-        PADNE_TRY(fold(slot(ctx, SLOT_PQ), gs, scal));
-        if (dist) PADNE_TRY(comm_allreduce_sum_f64(ctx, scal, 1));
+        PADNE_TRY(fold(slot(ctx, SLOT_PQ), gs, H_pq + k));
+        if (dist) PADNE_TRY(comm_allreduce_sum_f64(ctx, H_pq + k, 1));
         // consumers read per-workgroup partials on one GPU and the reduced scalars across ranks
-        const double *rz_old = dist ? s_old : rz_old_part, *pq = dist ? scal : slot(ctx, SLOT_PQ);
+        const double *rz_old = dist ? H_rz + k : rz_old_part, *pq = dist ? H_pq + k : slot(ctx, SLOT_PQ);
         const int Pz = dist ? 1 : gv, Pq = dist ? 1 : gs;
         hipLaunchKernelGGL(pcg_update_xr_kernel, dim3(gv), dim3(256), 0, s, n, rz_old, Pz, pq, Pq, p, q, a->dinv, x, r,
                            rz_new_part, slot(ctx, SLOT_RR), st);
         PADNE_HIP_CHECK(hipGetLastError());
-        PADNE_TRY(fold(rz_new_part, gv, s_new));
-        PADNE_TRY(fold(slot(ctx, SLOT_RR), gv, s_new + 1));
-        if (dist) PADNE_TRY(comm_allreduce_sum_f64(ctx, s_new, 2));
-        const double *rz_new = dist ? s_new : rz_new_part, *rr = dist ? s_new + 1 : slot(ctx, SLOT_RR);
+        PADNE_TRY(fold(rz_new_part, gv, H_rz + k + 1));
+        if (dist) {
+            PADNE_TRY(fold(slot(ctx, SLOT_RR), gv, s_rr));
+            PADNE_TRY(comm_allreduce_sum_f64(ctx, H_rz + k + 1, 1));
+            PADNE_TRY(comm_allreduce_sum_f64(ctx, s_rr, 1));
+        }
+        const double *rz_new = dist ? H_rz + k + 1 : rz_new_part, *rr = dist ? s_rr : slot(ctx, SLOT_RR);
         hipLaunchKernelGGL(pcg_update_p_kernel, dim3(gv), dim3(256), 0, s, n, rz_new, rz_old, Pz, rr, Pz, pq, Pq, r,
                            a->dinv, p, st, 1 << 30);
         PADNE_HIP_CHECK(hipGetLastError());
-        PADNE_HIP_CHECK(hipMemcpyAsync(h, scal, 6 * sizeof(double), hipMemcpyDeviceToHost, s));
-        PADNE_HIP_CHECK(hipStreamSynchronize(s));
-        const double pqv = h[0], rzo = h[parity ? 4 : 2], rzn = h[parity ? 2 : 4];
-        if (!(pqv > 0.0) || !(rzo > 0.0)) break;
+        parity ^= 1;
+    }
+    std::vector<double> hh((size_t)2 * steps + 4);
+    PADNE_HIP_CHECK(hipMemcpyAsync(hh.data(), hist, sizeof(double) * hh.size(), hipMemcpyDeviceToHost, s));
+    PADNE_HIP_CHECK(hipStreamSynchronize(s));
+    std::vector<double> alpha, beta;
+    for (int k = 0; k < steps; ++k) {
+        const double pqv = hh[(size_t)steps + 1 + k], rzo = hh[(size_t)k], rzn = hh[(size_t)k + 1];
+        if (!(pqv > 0.0) || !(rzo > 0.0)) break;      // also stops at the first NaN after a breakdown
         alpha.push_back(rzo / pqv);
         beta.push_back(rzn / rzo);
         if (!(rzn > 0.0) || rzn < 1e-30 * rzo) break;
-        parity ^= 1;
     }
     const int m = (int)alpha.size();
     if (m == 0) {
