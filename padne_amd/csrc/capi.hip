@@ -296,6 +296,8 @@ int padne_csr_destroy(padne_csr *m) {
         pool_free(m->owner, m->dinv);
         pool_free(m->owner, m->vals32);
         pool_free(m->owner, m->dinv32);
+        pool_free(m->owner, m->xw_desc);
+        pool_free(m->owner, m->xw_lidx);
     }
     delete m;
     return PADNE_OK;
@@ -328,6 +330,7 @@ int padne_spmv_dev(padne_ctx *ctx, const padne_csr *m, const void *x_dev, void *
     PADNE_REQUIRE(ctx && m && x_dev && y_dev, "null argument");
     PADNE_REQUIRE(repeat >= 1, "repeat");
     PADNE_HIP_CHECK(hipSetDevice(ctx->device));
+    PADNE_TRY(csr_build_xw_plan(ctx, const_cast<padne_csr *>(m)));
     for (int i = 0; i < repeat; ++i)
         PADNE_TRY(launch_spmv(ctx, m, (const double *)x_dev, (double *)y_dev, nullptr, nullptr, nullptr));
     PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -339,6 +342,7 @@ int padne_spmv(padne_ctx *ctx, const padne_csr *m, const double *x_host, double 
     PADNE_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t xb = sizeof(double) * (size_t)m->n_cols, yb = sizeof(double) * (size_t)m->n_rows;
     PADNE_TRY(ensure_workspace(ctx, xb + yb + 512));
+    PADNE_TRY(csr_build_xw_plan(ctx, const_cast<padne_csr *>(m)));
     double *x = (double *)ctx->ws;
     double *y = (double *)((char *)ctx->ws + ((xb + 255) & ~(size_t)255));
     PADNE_HIP_CHECK(hipMemcpyAsync(x, x_host, xb, hipMemcpyHostToDevice, ctx->stream));
@@ -387,6 +391,7 @@ int padne_spmv_time(padne_ctx *ctx, const padne_csr *m, const void *x_dev, void 
     PADNE_REQUIRE(ctx && m && x_dev && y_dev && seconds_per_launch, "null argument");
     PADNE_REQUIRE(repeat >= 1 && warmup >= 0, "repeat/warmup");
     PADNE_HIP_CHECK(hipSetDevice(ctx->device));
+    PADNE_TRY(csr_build_xw_plan(ctx, const_cast<padne_csr *>(m)));
     for (int i = 0; i < warmup; ++i)
         PADNE_TRY(launch_spmv(ctx, m, (const double *)x_dev, (double *)y_dev, nullptr, nullptr, nullptr));
     PADNE_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));

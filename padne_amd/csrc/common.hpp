@@ -63,6 +63,10 @@ struct padne_csr {
     padne_ctx *owner = nullptr;  // context whose pool the arrays came from (must outlive the matrix)
     void *amg = nullptr;         // cached multigrid hierarchy (padne::Amg*), owned
     float *vals32 = nullptr, *dinv32 = nullptr;   // single-precision copies for the multigrid cycle (csr_build_f32)
+    // x-window plan of the SpMV (csr_build_xw_plan): per 64-row tile up to three runs of x that cover all its columns
+    int4 *xw_desc = nullptr;             // [n_tiles] run starts in .x .y .z, .w = 1 if the tile qualifies
+    unsigned short *xw_lidx = nullptr;   // [nnz + pad] position of every column inside its tile's staged runs
+    int xw_state = 0;                    // 0 = not examined, 1 = in use, -1 = examined and not worth it
     bool hierarchy_operator = false;   // multigrid-internal operator: may use the wave-per-row SpMV
     padne_csr *prec_block = nullptr;   // borrowed: owned x owned diagonal block for the preconditioner
 };
@@ -117,6 +121,7 @@ int launch_spmv_f32_exit(padne_ctx *ctx, const padne_csr *m, const float *x, dou
                          double *partials, const int32_t *done_flag, const float *aux1, const float *aux2, float scale,
                          const double *out_scale2);
 int csr_build_f32(padne_ctx *ctx, padne_csr *m);
+int csr_build_xw_plan(padne_ctx *ctx, padne_csr *m);
 
 // spmm.hip: the same products for 8 interleaved right-hand sides (vectors [n][8]; aux2 = 1/diag stays [n]);
 // dot partials are [8][kMaxPartials]

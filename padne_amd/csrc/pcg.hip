@@ -1030,6 +1030,7 @@ extern "C" int padne_solve_spd_dev(padne_ctx *ctx, const padne_csr *a, const voi
     PADNE_REQUIRE(opts->precond == 0 || opts->precond == 1, "precond must be 0 (Jacobi) or 1 (multigrid)");
     PADNE_HIP_CHECK(hipSetDevice(ctx->device));
     PADNE_TRY(csr_build_dinv(ctx, const_cast<padne_csr *>(a)));
+    PADNE_TRY(csr_build_xw_plan(ctx, const_cast<padne_csr *>(a)));
     padne_solve_info local;
     memset(&local, 0, sizeof(local));
     local.n_rhs = n_rhs;

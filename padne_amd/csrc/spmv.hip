@@ -22,9 +22,17 @@
 //    them: FETCH_SIZE drops from 1.31x to 1.05x of the algorithmic bytes.
 //  * optional epilogue: dot_with[row]*y[row] summed over the wave with shuffles, over the workgroup
 //    through LDS, one partial per workgroup (deterministic, no float atomics).
+//  * x windows (csr_build_xw_plan): what bounds the kernel after all that is the gather path (the L1/TA unit
+//    spends about two accesses per gathered double while the matrix stream alone runs at 6 TB/s).  A tile whose
+//    columns are covered by at most three runs of kXwRun consecutive x entries -- every tile of a band matrix
+//    such as a scan-line numbered mesh -- stages those runs into LDS with wide coalesced loads and addresses them
+//    through a 16-bit index per non-zero (2 instead of 4 bytes of index traffic, no scattered global loads at
+//    all); other tiles (rows with lumped couplings to far-away unknowns, unstructured numberings) take the
+//    gather path, tile by tile, inside the same launch.  Products and their summation order are unchanged.
 #include "common.hpp"
 
 #include <algorithm>
+#include <stdlib.h>
 
 namespace padne {
 
@@ -51,6 +59,8 @@ __device__ __forceinline__ double block_sum_256(double v, double *red) {
     return s;
 }
 
+constexpr int kXwRun = 72;              // x entries per staged run (64 rows + the mesh neighbours on both sides)
+constexpr int kXwRuns = 3;
 constexpr int kEpl = 8;                 // elements per lane per pass
 constexpr int kWaveChunk = 64 * kEpl;   // non-zeros parked in LDS per wave per pass (4 KiB)
 
@@ -69,20 +79,24 @@ constexpr int kWaveChunk = 64 * kEpl;   // non-zeros parked in LDS per wave per 
 // r / ||b||, see amg.hip) and with the r.z partials taken against the double residual `dot_with`.
 template <int MODE, typename VT, typename XT, typename YT>
 __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
-    const int n_rows, const int n_wtiles, const int *__restrict__ rowptr,
+    const int n_rows, const int n_cols, const int n_wtiles, const int *__restrict__ rowptr,
     const int *__restrict__ cols, const VT *__restrict__ vals,
     const XT *__restrict__ x, YT *__restrict__ y,
     const double *__restrict__ dot_with, double *__restrict__ partials,
     const int *__restrict__ done_flag, const XT *__restrict__ aux1,
-    const XT *__restrict__ aux2, const XT scale, const double *__restrict__ out_scale2) {
+    const XT *__restrict__ aux2, const XT scale, const double *__restrict__ out_scale2,
+    const int4 *__restrict__ xw_desc, const unsigned short *__restrict__ xw_lidx) {
     constexpr bool WITH_DOT = (MODE == SPMV_DOT) || (MODE == SPMV_JACOBI);
     __shared__ XT prod_all[4 * kWaveChunk];
+    extern __shared__ unsigned char xs_dyn[];      // 4 * kXwRuns * kXwRun entries of XT when the plan is in use
+    XT *xs_all = reinterpret_cast<XT *>(xs_dyn);
     __shared__ double red[4];
 
     if (done_flag != nullptr && *done_flag != 0) return;
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     XT *prod = prod_all + w * kWaveChunk;
+    XT *xs = xs_all + w * kXwRuns * kXwRun;
     double out_mul = 1.0;
     if (out_scale2 != nullptr) {
         const double s2 = *out_scale2;
@@ -110,25 +124,63 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
         const int k0 = __shfl(rs, 0, 64);
         const int k1 = __shfl(re, row1 - row0 - 1, 64);
         XT acc = 0;
+        bool windowed = false;                       // wave-uniform
+        if (xw_desc != nullptr) {
+            const int4 d = xw_desc[wt];
+            windowed = d.w != 0;
+            if (windowed) {
+                // stage the tile's runs of x: two loads per run (64 + 8 entries), all issued before the wait
+                const int st[kXwRuns] = {d.x, d.y, d.z};
+                XT xa[kXwRuns], xb[kXwRuns];
+#pragma unroll
+                for (int q = 0; q < kXwRuns; ++q) {
+                    const int a = st[q] + lane, b = st[q] + 64 + lane;
+                    xa[q] = (a < n_cols) ? x[a] : (XT)0;
+                    xb[q] = (lane < kXwRun - 64 && b < n_cols) ? x[b] : (XT)0;
+                }
+#pragma unroll
+                for (int q = 0; q < kXwRuns; ++q) {
+                    xs[q * kXwRun + lane] = xa[q];
+                    if (lane < kXwRun - 64) xs[q * kXwRun + 64 + lane] = xb[q];
+                }
+            }
+        }
         for (int base = k0; base < k1; base += kWaveChunk) {
             int c[kEpl];
             VT v[kEpl];
+            if (windowed) {
 #pragma unroll
-            for (int j = 0; j < kEpl; ++j) {
-                const int e = base + lane + 64 * j;
-                c[j] = 0;
-                v[j] = 0;
-                if (e < k1) {
-                    c[j] = cols[e];
-                    v[j] = vals[e];
+                for (int j = 0; j < kEpl; ++j) {
+                    const int e = base + lane + 64 * j;
+                    c[j] = 0;
+                    v[j] = 0;
+                    if (e < k1) {
+                        c[j] = xw_lidx[e];
+                        v[j] = vals[e];
+                    }
                 }
-            }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the staged runs are in LDS
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int j = 0; j < kEpl; ++j) {
-                const int e = base + lane + 64 * j;
-                XT xv = 0;
-                if (e < k1) xv = x[c[j]];
-                prod[lane + 64 * j] = (XT)v[j] * xv;
+                for (int j = 0; j < kEpl; ++j) prod[lane + 64 * j] = (XT)v[j] * xs[c[j]];
+            } else {
+#pragma unroll
+                for (int j = 0; j < kEpl; ++j) {
+                    const int e = base + lane + 64 * j;
+                    c[j] = 0;
+                    v[j] = 0;
+                    if (e < k1) {
+                        c[j] = cols[e];
+                        v[j] = vals[e];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < kEpl; ++j) {
+                    const int e = base + lane + 64 * j;
+                    XT xv = 0;
+                    if (e < k1) xv = x[c[j]];
+                    prod[lane + 64 * j] = (XT)v[j] * xv;
+                }
             }
             // same-wave LDS traffic is processed in issue order; keep the compiler from reordering
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -235,6 +287,9 @@ int spmv_grid(const padne_csr *m) {
     }
     const long long n_tiles = (m->n_rows + kSpmvRows - 1) / kSpmvRows;   // 4 wave-tiles per workgroup-turn
     long long g = n_tiles < kMaxPartials ? n_tiles : kMaxPartials;
+    // with the x windows a double-precision workgroup holds 23 KiB of LDS: six fit on a CU, so the persistent
+    // sweep uses 6 x 256 workgroups (a seventh and eighth would run as a second wave of work)
+    if (m->xw_state == 1 && g > 1536) g = 1536;
     if (g >= kNumXcd) g -= g % kNumXcd;
     if (g < 1) g = 1;
     return (int)g;
@@ -264,10 +319,13 @@ static int launch_spmv_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals,
         PADNE_HIP_CHECK(hipGetLastError());
         return PADNE_OK;
     }
+    const size_t xs_bytes = m->xw_state == 1 ? sizeof(XT) * 4 * kXwRuns * kXwRun : 0;
+    const int4 *xw_desc = m->xw_state == 1 ? m->xw_desc : nullptr;
+    const unsigned short *xw_lidx = m->xw_state == 1 ? m->xw_lidx : nullptr;
 #define PADNE_SPMV_LAUNCH(M)                                                                                     \
-    hipLaunchKernelGGL((csr_spmv_kernel<M, VT, XT, YT>), dim3(g), dim3(kSpmvThreads), 0, ctx->stream,             \
-                       (int)m->n_rows, n_tiles, m->rowptr, m->cols, vals, x, y, dot_with, partials, done_flag,    \
-                       aux1, aux2, scale, out_scale2)
+    hipLaunchKernelGGL((csr_spmv_kernel<M, VT, XT, YT>), dim3(g), dim3(kSpmvThreads), xs_bytes, ctx->stream,      \
+                       (int)m->n_rows, (int)m->n_cols, n_tiles, m->rowptr, m->cols, vals, x, y, dot_with,         \
+                       partials, done_flag, aux1, aux2, scale, out_scale2, xw_desc, xw_lidx)
     switch (mode) {
         case SPMV_PLAIN: PADNE_SPMV_LAUNCH(SPMV_PLAIN); break;
         case SPMV_DOT: PADNE_SPMV_LAUNCH(SPMV_DOT); break;
@@ -304,6 +362,98 @@ int launch_spmv_f32_exit(padne_ctx *ctx, const padne_csr *m, const float *x, dou
     PADNE_REQUIRE(m->vals32 != nullptr && dot_with != nullptr, "single-precision exit stage");
     return launch_spmv_typed<float, float, double>(ctx, m, m->vals32, SPMV_JACOBI, x, y, dot_with, partials, done_flag,
                                                    aux1, aux2, scale, out_scale2);
+}
+
+// ---- x-window plan -------------------------------------------------------------------------------------
+// One wave per 64-row tile: greedy cover of the tile's columns by runs of kXwRun entries starting at the smallest
+// uncovered column; at most kXwRuns runs or the tile keeps the gather path.  A qualifying tile gets, for every
+// non-zero, the 16-bit position of its column inside the staged runs.
+__global__ __launch_bounds__(256) void xw_plan_kernel(int n_rows, int n_wtiles, const int *__restrict__ rowptr,
+                                                      const int *__restrict__ cols, int4 *__restrict__ desc,
+                                                      unsigned short *__restrict__ lidx, int *__restrict__ n_ok) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long W = (long long)gridDim.x * 4, gw = (long long)blockIdx.x * 4 + w;
+    int ok_count = 0;
+    for (long long wt = gw; wt < n_wtiles; wt += W) {
+        const int row0 = (int)wt * 64;
+        const int row1 = min(row0 + 64, n_rows);
+        const int k0 = rowptr[row0], k1 = rowptr[row1];
+        int start[kXwRuns];
+        int bound = -1;                      // columns <= bound are covered
+        bool fits = true;
+#pragma unroll
+        for (int q = 0; q <= kXwRuns; ++q) {
+            int mn = 0x7fffffff;
+            for (int e = k0 + lane; e < k1; e += 64) {
+                const int c = cols[e];
+                if (c > bound && c < mn) mn = c;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mn = min(mn, __shfl_xor(mn, off, 64));
+            if (q == kXwRuns) {
+                fits = mn == 0x7fffffff;     // nothing left beyond the last run
+            } else {
+                start[q] = mn == 0x7fffffff ? (q > 0 ? start[q - 1] : 0) : mn;
+                if (mn != 0x7fffffff) bound = mn + kXwRun - 1;
+            }
+        }
+        if (fits) {
+            for (int e = k0 + lane; e < k1; e += 64) {
+                const int c = cols[e];
+                int pos = 0;
+#pragma unroll
+                for (int q = kXwRuns - 1; q >= 0; --q)
+                    if (c >= start[q] && c < start[q] + kXwRun) pos = q * kXwRun + (c - start[q]);
+                lidx[e] = (unsigned short)pos;
+            }
+            ++ok_count;
+        }
+        if (lane == 0) desc[wt] = make_int4(start[0], start[1], start[2], fits ? 1 : 0);
+    }
+    if (lane == 0 && ok_count) atomicAdd(n_ok, ok_count);
+}
+
+int csr_build_xw_plan(padne_ctx *ctx, padne_csr *m) {
+    if (m->xw_state != 0) return PADNE_OK;
+    m->xw_state = -1;
+    // worth examining only for the big streaming operators; hierarchy operators are not band matrices
+    if (m->n_rows < 65536 || m->hierarchy_operator || m->nnz > 64LL * m->n_rows || getenv("PADNE_NO_XWINDOW") != nullptr)
+        return PADNE_OK;
+    padne_ctx *owner = m->owner ? m->owner : ctx;
+    const int n_tiles = (int)((m->n_rows + 63) / 64);
+    int4 *desc = (int4 *)pool_alloc(owner, sizeof(int4) * (size_t)n_tiles);
+    unsigned short *lidx = (unsigned short *)pool_alloc(owner, sizeof(unsigned short) * ((size_t)m->nnz + kPadNnz));
+    int *d_ok = (int *)pool_alloc(ctx, sizeof(int));
+    if (!desc || !lidx || !d_ok) {
+        pool_free(owner, desc);
+        pool_free(owner, lidx);
+        pool_free(ctx, d_ok);
+        return PADNE_E_NOMEM;
+    }
+    int h_ok = 0;
+    hipError_t e = hipMemsetAsync(d_ok, 0, sizeof(int), ctx->stream);
+    if (e == hipSuccess) {
+        const unsigned g = (unsigned)std::min<long long>(((long long)n_tiles + 3) / 4, 8192);
+        hipLaunchKernelGGL(xw_plan_kernel, dim3(g), dim3(256), 0, ctx->stream, (int)m->n_rows, n_tiles, m->rowptr, m->cols,
+                           desc, lidx, d_ok);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_ok, d_ok, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    pool_free(ctx, d_ok);
+    if (e != hipSuccess || 2LL * h_ok < n_tiles) {     // fewer than half of the tiles qualify: not worth the extra array
+        pool_free(owner, desc);
+        pool_free(owner, lidx);
+        if (e != hipSuccess) {
+            set_error("x-window plan failed: %s", hipGetErrorString(e));
+            return PADNE_E_HIP;
+        }
+        return PADNE_OK;
+    }
+    m->xw_desc = desc;
+    m->xw_lidx = lidx;
+    m->xw_state = 1;
+    return PADNE_OK;
 }
 
 __global__ void f32_copy_kernel(long long n, const double *__restrict__ src, float *__restrict__ dst) {

@@ -908,6 +908,91 @@ __global__ __launch_bounds__(256) void spmv_wave_rr_mp(int n_rows, int n_wtiles,
     }
 }
 
+// ---- V18: x windows + 16-byte matrix loads: a lane takes PAIRS of consecutive non-zeros (double2 values, two
+// 16-bit window indices in one 4-byte load) ----
+template <int EPL>   // pairs per lane per pass
+__global__ __launch_bounds__(256) void spmv_wave_xw_pairs(int n_rows, int n_wtiles, const int *__restrict__ rowptr,
+                                                          const unsigned short *__restrict__ lidx, const double *__restrict__ vals,
+                                                          const int4 *__restrict__ desc, const double *__restrict__ x,
+                                                          double *__restrict__ y) {
+    constexpr int CH = 128 * EPL;
+    __shared__ double prod_all[4 * CH];
+    __shared__ double xs_all[4 * 3 * XW];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double *prod = prod_all + w * CH;
+    double *xs = xs_all + w * 3 * XW;
+    const int G = gridDim.x;
+    const int xcd = blockIdx.x % NXCD;
+    const int wx = (blockIdx.x / NXCD) * 4 + w;
+    const int wpx = (G / NXCD) * 4;
+    const int s0 = (int)((long long)xcd * n_wtiles / NXCD), s1 = (int)((long long)(xcd + 1) * n_wtiles / NXCD);
+    for (int wt = s0 + wx; wt < s1; wt += wpx) {
+        const int row0 = wt * 64;
+        const int row1 = min(row0 + 64, n_rows);
+        const int r = row0 + lane;
+        int rs = 0, re = 0;
+        if (r < row1) { rs = rowptr[r]; re = rowptr[r + 1]; }
+        const int4 d = desc[wt];
+        const int k0 = __shfl(rs, 0, 64);
+        const int k1 = __shfl(re, row1 - row0 - 1, 64);
+        const int base0 = k0 & ~1;
+        unsigned int c[EPL];
+        double2 v[EPL];
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            const int e = base0 + 2 * lane + 128 * j;
+            c[j] = 0u; v[j] = make_double2(0.0, 0.0);
+            if (e < k1) {
+                c[j] = *reinterpret_cast<const unsigned int *>(lidx + e);
+                v[j] = *reinterpret_cast<const double2 *>(vals + e);
+            }
+        }
+        {
+            const int st[3] = {d.x, d.y, d.z};
+            double xa[3], xb[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int a = st[q] + lane, b = st[q] + 64 + lane;
+                xa[q] = (a < n_rows) ? x[a] : 0.0;
+                xb[q] = (lane < XW - 64 && b < n_rows) ? x[b] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                xs[q * XW + lane] = xa[q];
+                if (lane < XW - 64) xs[q * XW + 64 + lane] = xb[q];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        double acc = 0.0;
+        for (int base = base0; base < k1; base += CH) {
+            if (base != base0) {
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) {
+                    const int e = base + 2 * lane + 128 * j;
+                    c[j] = 0u; v[j] = make_double2(0.0, 0.0);
+                    if (e < k1) {
+                        c[j] = *reinterpret_cast<const unsigned int *>(lidx + e);
+                        v[j] = *reinterpret_cast<const double2 *>(vals + e);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const double p0 = v[j].x * xs[c[j] & 0xffffu], p1 = v[j].y * xs[c[j] >> 16];
+                *reinterpret_cast<double2 *>(prod + 2 * lane + 128 * j) = make_double2(p0, p1);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const int lo = max(rs, base), hi = min(re, base + CH);
+            for (int k = lo; k < hi; ++k) acc += prod[k - base];
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (r < row1) y[r] = acc;
+    }
+}
+
 struct Mat { int n; long long nnz; int *rowptr, *cols; double *vals; short *cols16; unsigned short *lidx; int4 *desc; };
 
 static Mat build(int layers, int nx, int ny) {
@@ -1057,6 +1142,10 @@ int main(int argc, char **argv) {
       RUN("xwindow epl8 grid 1536", [&] { spmv_wave_xw<8><<<1536, 256>>>(m.n, nwt, m.rowptr, m.lidx, m.vals, m.desc, x, y); });
       RUN("xwindow epl8 grid 4096", [&] { spmv_wave_xw<8><<<4096, 256>>>(m.n, nwt, m.rowptr, m.lidx, m.vals, m.desc, x, y); });
       RUN("xwindow epl4 grid 2048", [&] { spmv_wave_xw<4><<<2048, 256>>>(m.n, nwt, m.rowptr, m.lidx, m.vals, m.desc, x, y); });
+      RUN("xwpairs epl4 grid 1536", [&] { spmv_wave_xw_pairs<4><<<1536, 256>>>(m.n, nwt, m.rowptr, m.lidx, m.vals, m.desc, x, y); });
+      RUN("xwpairs epl4 grid 2048", [&] { spmv_wave_xw_pairs<4><<<2048, 256>>>(m.n, nwt, m.rowptr, m.lidx, m.vals, m.desc, x, y); });
+      RUN("xwpairs epl2 grid 2048", [&] { spmv_wave_xw_pairs<2><<<2048, 256>>>(m.n, nwt, m.rowptr, m.lidx, m.vals, m.desc, x, y); });
+      RUN("xwpairs epl2 grid 4096", [&] { spmv_wave_xw_pairs<2><<<4096, 256>>>(m.n, nwt, m.rowptr, m.lidx, m.vals, m.desc, x, y); });
       RUN("xwindow3 epl8 grid 1024", [&] { spmv_wave_xw3<8><<<1024, 256>>>(m.n, nwt, m.rowptr, m.lidx, m.vals, m.desc, x, y); });
       RUN("xwindow3 epl8 grid 1536", [&] { spmv_wave_xw3<8><<<1536, 256>>>(m.n, nwt, m.rowptr, m.lidx, m.vals, m.desc, x, y); });
       RUN("xwindow3 epl8 grid 2048", [&] { spmv_wave_xw3<8><<<2048, 256>>>(m.n, nwt, m.rowptr, m.lidx, m.vals, m.desc, x, y); });

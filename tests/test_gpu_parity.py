@@ -850,6 +850,25 @@ def test_batched_right_hand_sides_in_lockstep(ctx, monkeypatch):
     assert res.iterations <= seq.iterations + 8
 
 
+def test_x_window_tiles_and_gather_tiles_in_one_product(ctx, monkeypatch):
+    """A scan-line mesh matrix large enough for the x-window plan, with lumped couplings to far-away unknowns in some
+    rows (those tiles keep the gather path): the product is bit-identical to scipy's and to the plan-free kernel."""
+    sysm = synthetic.layered_system(2, 260, 260, via_lattice=6)
+    els = [("R", int(a), int(b), float(r)) for a, b, r in zip(*sysm.resistors)]
+    els += [("I", int(f), int(t), float(i)) for f, t, i in zip(*sysm.current_sources)]
+    Lo, _ = O.assemble_system([(m[0], m[1], m[2]) for m in sysm.meshes], 0, els, 0)
+    n = sysm.n_vertices
+    A = (-Lo[1:n, 1:n]).tocsr()
+    A.sort_indices()
+    assert A.shape[0] > 65536
+    x = np.random.default_rng(0).uniform(-1, 1, A.shape[0])
+    y_plan = ctx.csr_from_scipy(A).matvec(x)
+    monkeypatch.setenv("PADNE_NO_XWINDOW", "1")
+    y_gather = ctx.csr_from_scipy(A).matvec(x)
+    assert np.array_equal(y_plan, A @ x)
+    assert np.array_equal(y_plan, y_gather)
+
+
 def test_spmm8_columns_are_bitwise_the_single_vector_products(ctx):
     """8 interleaved right-hand sides through one pass over the matrix; ragged rows, empty rows, long rows."""
     rng = np.random.default_rng(3)
