@@ -67,6 +67,7 @@ struct padne_csr {
     int4 *xw_desc = nullptr;             // [n_tiles] run starts in .x .y .z, .w = 1 if the tile qualifies
     unsigned short *xw_lidx = nullptr;   // [nnz + pad] position of every column inside its tile's staged runs
     int xw_state = 0;                    // 0 = not examined, 1 = in use, -1 = examined and not worth it
+    int xw_run = 0;                      // entries per staged run (72 for scan-line meshes, 128 for strip-ordered ones)
     bool hierarchy_operator = false;   // multigrid-internal operator: may use the wave-per-row SpMV
     padne_csr *prec_block = nullptr;   // borrowed: owned x owned diagonal block for the preconditioner
 };

@@ -24,8 +24,8 @@
 //    through LDS, one partial per workgroup (deterministic, no float atomics).
 //  * x windows (csr_build_xw_plan): what bounds the kernel after all that is the gather path (the L1/TA unit
 //    spends about two accesses per gathered double while the matrix stream alone runs at 6 TB/s).  A tile whose
-//    columns are covered by at most three runs of kXwRun consecutive x entries -- every tile of a band matrix
-//    such as a scan-line numbered mesh -- stages those runs into LDS with wide coalesced loads and addresses them
+//    columns are covered by at most three runs of 72 (or 128) consecutive x entries -- every tile of a band matrix
+//    such as a scan-line numbered mesh, most tiles of a strip-ordered unstructured mesh -- stages those runs into LDS with wide coalesced loads and addresses them
 //    through a 16-bit index per non-zero (2 instead of 4 bytes of index traffic, no scattered global loads at
 //    all); other tiles (rows with lumped couplings to far-away unknowns, unstructured numberings) take the
 //    gather path, tile by tile, inside the same launch.  Products and their summation order are unchanged.
@@ -59,8 +59,9 @@ __device__ __forceinline__ double block_sum_256(double v, double *red) {
     return s;
 }
 
-constexpr int kXwRun = 72;              // x entries per staged run (64 rows + the mesh neighbours on both sides)
-constexpr int kXwRuns = 3;
+constexpr int kXwRuns = 3;              // staged runs of x per tile
+constexpr int kXwRunShort = 72;         // entries per run: 64 rows + the mesh neighbours on both sides (scan-line grids),
+constexpr int kXwRunLong = 128;         // or twice the tile for strip-ordered unstructured meshes
 constexpr int kEpl = 8;                 // elements per lane per pass
 constexpr int kWaveChunk = 64 * kEpl;   // non-zeros parked in LDS per wave per pass (4 KiB)
 
@@ -85,10 +86,10 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
     const double *__restrict__ dot_with, double *__restrict__ partials,
     const int *__restrict__ done_flag, const XT *__restrict__ aux1,
     const XT *__restrict__ aux2, const XT scale, const double *__restrict__ out_scale2,
-    const int4 *__restrict__ xw_desc, const unsigned short *__restrict__ xw_lidx) {
+    const int4 *__restrict__ xw_desc, const unsigned short *__restrict__ xw_lidx, const int xw_run) {
     constexpr bool WITH_DOT = (MODE == SPMV_DOT) || (MODE == SPMV_JACOBI);
     __shared__ XT prod_all[4 * kWaveChunk];
-    extern __shared__ unsigned char xs_dyn[];      // 4 * kXwRuns * kXwRun entries of XT when the plan is in use
+    extern __shared__ unsigned char xs_dyn[];      // 4 * kXwRuns * xw_run entries of XT when the plan is in use
     XT *xs_all = reinterpret_cast<XT *>(xs_dyn);
     __shared__ double red[4];
 
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     XT *prod = prod_all + w * kWaveChunk;
-    XT *xs = xs_all + w * kXwRuns * kXwRun;
+    XT *xs = xs_all + w * kXwRuns * xw_run;
     double out_mul = 1.0;
     if (out_scale2 != nullptr) {
         const double s2 = *out_scale2;
@@ -129,19 +130,19 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
             const int4 d = xw_desc[wt];
             windowed = d.w != 0;
             if (windowed) {
-                // stage the tile's runs of x: two loads per run (64 + 8 entries), all issued before the wait
+                // stage the tile's runs of x: two loads per run (64 + the rest), all issued before the wait
                 const int st[kXwRuns] = {d.x, d.y, d.z};
                 XT xa[kXwRuns], xb[kXwRuns];
 #pragma unroll
                 for (int q = 0; q < kXwRuns; ++q) {
                     const int a = st[q] + lane, b = st[q] + 64 + lane;
                     xa[q] = (a < n_cols) ? x[a] : (XT)0;
-                    xb[q] = (lane < kXwRun - 64 && b < n_cols) ? x[b] : (XT)0;
+                    xb[q] = (lane < xw_run - 64 && b < n_cols) ? x[b] : (XT)0;
                 }
 #pragma unroll
                 for (int q = 0; q < kXwRuns; ++q) {
-                    xs[q * kXwRun + lane] = xa[q];
-                    if (lane < kXwRun - 64) xs[q * kXwRun + 64 + lane] = xb[q];
+                    xs[q * xw_run + lane] = xa[q];
+                    if (lane < xw_run - 64) xs[q * xw_run + 64 + lane] = xb[q];
                 }
             }
         }
@@ -289,7 +290,7 @@ int spmv_grid(const padne_csr *m) {
     long long g = n_tiles < kMaxPartials ? n_tiles : kMaxPartials;
     // with the x windows a double-precision workgroup holds 23 KiB of LDS: six fit on a CU, so the persistent
     // sweep uses 6 x 256 workgroups (a seventh and eighth would run as a second wave of work)
-    if (m->xw_state == 1 && g > 1536) g = 1536;
+    if (m->xw_state == 1 && g > (m->xw_run > kXwRunShort ? 1280 : 1536)) g = m->xw_run > kXwRunShort ? 1280 : 1536;
     if (g >= kNumXcd) g -= g % kNumXcd;
     if (g < 1) g = 1;
     return (int)g;
@@ -319,13 +320,13 @@ static int launch_spmv_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals,
         PADNE_HIP_CHECK(hipGetLastError());
         return PADNE_OK;
     }
-    const size_t xs_bytes = m->xw_state == 1 ? sizeof(XT) * 4 * kXwRuns * kXwRun : 0;
+    const size_t xs_bytes = m->xw_state == 1 ? sizeof(XT) * 4 * kXwRuns * (size_t)m->xw_run : 0;
     const int4 *xw_desc = m->xw_state == 1 ? m->xw_desc : nullptr;
     const unsigned short *xw_lidx = m->xw_state == 1 ? m->xw_lidx : nullptr;
 #define PADNE_SPMV_LAUNCH(M)                                                                                     \
     hipLaunchKernelGGL((csr_spmv_kernel<M, VT, XT, YT>), dim3(g), dim3(kSpmvThreads), xs_bytes, ctx->stream,      \
                        (int)m->n_rows, (int)m->n_cols, n_tiles, m->rowptr, m->cols, vals, x, y, dot_with,         \
-                       partials, done_flag, aux1, aux2, scale, out_scale2, xw_desc, xw_lidx)
+                       partials, done_flag, aux1, aux2, scale, out_scale2, xw_desc, xw_lidx, m->xw_run)
     switch (mode) {
         case SPMV_PLAIN: PADNE_SPMV_LAUNCH(SPMV_PLAIN); break;
         case SPMV_DOT: PADNE_SPMV_LAUNCH(SPMV_DOT); break;
@@ -368,7 +369,7 @@ int launch_spmv_f32_exit(padne_ctx *ctx, const padne_csr *m, const float *x, dou
 // One wave per 64-row tile: greedy cover of the tile's columns by runs of kXwRun entries starting at the smallest
 // uncovered column; at most kXwRuns runs or the tile keeps the gather path.  A qualifying tile gets, for every
 // non-zero, the 16-bit position of its column inside the staged runs.
-__global__ __launch_bounds__(256) void xw_plan_kernel(int n_rows, int n_wtiles, const int *__restrict__ rowptr,
+__global__ __launch_bounds__(256) void xw_plan_kernel(int n_rows, int n_wtiles, int run, const int *__restrict__ rowptr,
                                                       const int *__restrict__ cols, int4 *__restrict__ desc,
                                                       unsigned short *__restrict__ lidx, int *__restrict__ n_ok) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(256) void xw_plan_kernel(int n_rows, int n_wtiles, 
                 fits = mn == 0x7fffffff;     // nothing left beyond the last run
             } else {
                 start[q] = mn == 0x7fffffff ? (q > 0 ? start[q - 1] : 0) : mn;
-                if (mn != 0x7fffffff) bound = mn + kXwRun - 1;
+                if (mn != 0x7fffffff) bound = mn + run - 1;
             }
         }
         if (fits) {
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(256) void xw_plan_kernel(int n_rows, int n_wtiles, 
                 int pos = 0;
 #pragma unroll
                 for (int q = kXwRuns - 1; q >= 0; --q)
-                    if (c >= start[q] && c < start[q] + kXwRun) pos = q * kXwRun + (c - start[q]);
+                    if (c >= start[q] && c < start[q] + run) pos = q * run + (c - start[q]);
                 lidx[e] = (unsigned short)pos;
             }
             ++ok_count;
@@ -430,17 +431,22 @@ int csr_build_xw_plan(padne_ctx *ctx, padne_csr *m) {
         pool_free(ctx, d_ok);
         return PADNE_E_NOMEM;
     }
-    int h_ok = 0;
-    hipError_t e = hipMemsetAsync(d_ok, 0, sizeof(int), ctx->stream);
-    if (e == hipSuccess) {
-        const unsigned g = (unsigned)std::min<long long>(((long long)n_tiles + 3) / 4, 8192);
-        hipLaunchKernelGGL(xw_plan_kernel, dim3(g), dim3(256), 0, ctx->stream, (int)m->n_rows, n_tiles, m->rowptr, m->cols,
-                           desc, lidx, d_ok);
+    int h_ok = 0, run = 0;
+    hipError_t e = hipSuccess;
+    const unsigned g = (unsigned)std::min<long long>(((long long)n_tiles + 3) / 4, 8192);
+    for (int attempt = 0; attempt < 2 && e == hipSuccess && 2LL * h_ok < n_tiles; ++attempt) {
+        run = attempt == 0 ? kXwRunShort : kXwRunLong;
+        e = hipMemsetAsync(d_ok, 0, sizeof(int), ctx->stream);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(xw_plan_kernel, dim3(g), dim3(256), 0, ctx->stream, (int)m->n_rows, n_tiles, run, m->rowptr,
+                           m->cols, desc, lidx, d_ok);
         e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(&h_ok, d_ok, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(&h_ok, d_ok, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     pool_free(ctx, d_ok);
+    if (getenv("PADNE_XW_VERBOSE") != nullptr)
+        fprintf(stderr, "[spmv] x-window plan: %d of %d tiles qualify with runs of %d\n", h_ok, n_tiles, run);
     if (e != hipSuccess || 2LL * h_ok < n_tiles) {     // fewer than half of the tiles qualify: not worth the extra array
         pool_free(owner, desc);
         pool_free(owner, lidx);
@@ -450,6 +456,7 @@ int csr_build_xw_plan(padne_ctx *ctx, padne_csr *m) {
         }
         return PADNE_OK;
     }
+    m->xw_run = run;
     m->xw_desc = desc;
     m->xw_lidx = lidx;
     m->xw_state = 1;

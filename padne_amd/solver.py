@@ -447,7 +447,8 @@ def solve_system(L, r: np.ndarray, *, rtol: float = RTOL, reorder=None):
     red: Reduction = build_reduction(layout)
     if isinstance(L, SystemMatrix) and L.xy is not None and reorder is not False:
         # CGAL numbers vertices in insertion order; when neighbours are far apart in the numbering the SpMV
-        # gathers miss the caches, so the reduced system is solved in Z-order (internal: v comes back unpermuted)
+        # gathers miss the caches, so the reduced system is solved in a band numbering by horizontal strips
+        # (internal: v comes back unpermuted)
         from .reduction import apply_locality_ordering, ordering_is_scattered
         if reorder is True or ordering_is_scattered(L.tri, len(L.xy)):
             apply_locality_ordering(red, L.xy, L.mesh_offsets)

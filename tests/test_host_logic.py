@@ -281,6 +281,23 @@ def test_locality_ordering_is_a_permutation_that_keeps_mesh_blocks():
     d_before = np.abs(stri[:, 0].astype(np.int64) - stri[:, 1]).mean()
     d_after = np.abs(rank[stri[:, 0]] - rank[stri[:, 1]]).mean()
     assert d_after * 10 < d_before
+    # the strip numbering is a band numbering: almost every 64-row tile touches at most 3 runs of 128 indices
+    strip = reduction.strip_index(sxy, np.zeros(len(sxy), dtype=np.int64))
+    order = np.lexsort((sxy[:, 0], strip))
+    srank = np.empty(len(sxy), dtype=np.int64); srank[order] = np.arange(len(sxy))
+    e = np.concatenate([stri[:, [0, 1]], stri[:, [1, 2]], stri[:, [2, 0]]])
+    rows = np.concatenate([srank[e[:, 0]], srank[e[:, 1]], np.arange(len(sxy))])
+    cols = np.concatenate([srank[e[:, 1]], srank[e[:, 0]], np.arange(len(sxy))])
+    ok = 0
+    n_tiles = (len(sxy) + 63) // 64
+    for t in range(n_tiles):
+        c = np.unique(cols[(rows >= 64 * t) & (rows < 64 * t + 64)])
+        runs, i = 0, 0
+        while i < len(c):
+            runs += 1
+            i = np.searchsorted(c, c[i] + 127, side="right")
+        ok += runs <= 3
+    assert ok >= 0.9 * n_tiles
 
 
 def test_reduction_run_plan_matches_the_plain_formulas():
