@@ -549,6 +549,83 @@ def test_unstructured_delaunay_mesh_assembly_and_solve(ctx):
     L.dev.close()
 
 
+def _graded_two_layer_system(needles: bool):
+    import scipy.spatial
+    rng = np.random.default_rng(21)
+    u = rng.uniform(0, 1, (60000, 2))
+    if needles:     # different grading in x and y: needle triangles, cotangent weights spanning 11 decades
+        pts = np.column_stack([30.0 * u[:, 0] ** 3, 30.0 * u[:, 1] ** 2.5])
+    else:           # isotropic grading towards the origin (what a sizing field produces): spacing 1 : 300
+        rad = 30.0 * u[:, 0] ** 2.5
+        pts = np.column_stack([rad * np.cos(2 * np.pi * u[:, 1]), rad * np.sin(2 * np.pi * u[:, 1])])
+    pts = np.unique(np.round(pts, 9), axis=0)
+    tri = scipy.spatial.Delaunay(pts).simplices.astype(np.int32)
+    a, b, c = pts[tri[:, 0]], pts[tri[:, 1]], pts[tri[:, 2]]
+    cross = (b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (b[:, 1] - a[:, 1]) * (c[:, 0] - a[:, 0])
+    tri = tri[np.abs(cross) > 1e-12]                                        # drop degenerate slivers of the hull
+    cross = cross[np.abs(cross) > 1e-12]
+    tri[cross < 0] = tri[cross < 0][:, [0, 2, 1]]
+    used = np.unique(tri)
+    remap = -np.ones(len(pts), dtype=np.int64)
+    remap[used] = np.arange(len(used))
+    xy, tri = pts[used], remap[tri].astype(np.int32)
+    n1 = len(xy)
+    ms = [(xy, tri, 2082.5), (xy.copy(), tri.copy(), 52.0)]                 # 40x conductivity jump between the layers
+    n = 2 * n1
+    ties = np.random.default_rng(5).choice(n1, 25, replace=False)
+    els = [("R", int(t), int(n1 + t), 2e-3) for t in ties]
+    src, snk = int(np.argmin(xy.sum(axis=1))), int(n1 + np.argmax(xy.sum(axis=1)))
+    els += [("I", src, snk, 3.0)]
+    Lo, ro = O.assemble_system(ms, 0, els, 11)
+    stamps = solver.StampList(n + 1)
+    for t in ties:
+        g = 1 / 2e-3
+        for (i, j, v) in ((t, t, -g), (t, n1 + t, g), (n1 + t, n1 + t, -g), (n1 + t, t, g)):
+            stamps.add(int(i), int(j), v)
+    r = np.zeros(n + 1)
+    r[src] += 3.0
+    r[snk] -= 3.0
+    solver.setup_ground_node(11, stamps, r)
+    L = solver.assemble_from_arrays([mesh.Mesh(xy, tri), mesh.Mesh(xy.copy(), tri.copy())], [2082.5, 52.0], stamps, n)
+    assert np.array_equal(r, ro)
+    return xy, tri, n, Lo, ro, L, r
+
+
+def test_strongly_graded_mesh_with_conductivity_jump(ctx):
+    """CGAL sizing fields give meshes whose element size varies by orders of magnitude, and stacked layers differ in
+    conductance: vertex spacing graded 1 : 300 towards a point, two layers with a 40x conductivity jump stitched by
+    a few resistors.  Strip reordering, multigrid and the x-window plan must all cope."""
+    xy, tri, n, Lo, ro, L, r = _graded_two_layer_system(needles=False)
+    edge = np.linalg.norm(xy[tri[:, 0]] - xy[tri[:, 1]], axis=1)
+    assert np.percentile(edge, 99) > 100 * np.percentile(edge, 1)           # really graded
+    v_ref = O.solve_system(Lo, ro)[0]
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", solver.SolverWarning)
+        v, info = solver.solve_system(L, r)
+        v2, info2 = solver.solve_system(L, r, reorder=True)
+    scale = np.abs(v_ref[:n]).max()
+    assert np.abs(v[:n] - v_ref[:n]).max() <= REL_TOL * scale
+    assert np.abs(v2[:n] - v_ref[:n]).max() <= REL_TOL * scale
+    assert info.residual_norm < 1e-8 and info.iterations < 80 and info2.iterations < 80
+    L.dev.close()
+
+
+def test_needle_triangles_stall_gracefully(ctx):
+    """Needle triangles put cotangent weights of 1e13 next to weights of 1e2 (entry ratio 1e11): b - A x cannot be evaluated below
+    ~1e-6 ||b|| in binary64, so no iteration can certify rtol = 1e-12.  Like the reference (which always returns the
+    LU answer and reports its residual), solve_system returns its best iterate, reports the residual it reached and
+    warns -- it does not raise."""
+    xy, tri, n, Lo, ro, L, r = _graded_two_layer_system(needles=True)
+    assert abs(Lo).max() > 1e10 * np.percentile(abs(Lo.data), 50)
+    v_ref = O.solve_system(Lo, ro)[0]
+    with pytest.warns(solver.SolverWarning, match="relative residual"):
+        v, info = solver.solve_system(L, r)
+    assert np.all(np.isfinite(v))
+    assert info.residual_norm < 1e-4                                       # reported honestly, far above 1e-12
+    assert np.abs(v[:n] - v_ref[:n]).max() <= 1e-3 * np.abs(v_ref[:n]).max()
+    L.dev.close()
+
+
 # ---- more Problem-level behaviour of the reference's solve() ---------------------------------------------
 
 def two_island_problem():
