@@ -146,24 +146,36 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
                 }
             }
         }
-        for (int base = k0; base < k1; base += kWaveChunk) {
+        // windowed tiles read PAIRS of consecutive non-zeros per lane (one 16-byte load of two values, one 4-byte
+        // load of two 16-bit indices): the chunk then starts on an even element, the stray element in front of k0
+        // or behind k1 is multiplied like the others but never summed
+        for (int base = windowed ? (k0 & ~1) : k0; base < k1; base += kWaveChunk) {
             int c[kEpl];
             VT v[kEpl];
             if (windowed) {
+                struct alignas(2 * sizeof(VT)) V2 { VT a, b; };
+                const int top = kXwRuns * xw_run - 1;
+                unsigned int c2[kEpl / 2];
+                V2 v2[kEpl / 2];
 #pragma unroll
-                for (int j = 0; j < kEpl; ++j) {
-                    const int e = base + lane + 64 * j;
-                    c[j] = 0;
-                    v[j] = 0;
-                    if (e < k1) {
-                        c[j] = xw_lidx[e];
-                        v[j] = vals[e];
+                for (int j = 0; j < kEpl / 2; ++j) {
+                    const int e = base + 2 * lane + 128 * j;
+                    c2[j] = 0u;
+                    v2[j].a = 0;
+                    v2[j].b = 0;
+                    if (e < k1) {                       // both arrays are padded: e + 1 == k1 is a legal address
+                        c2[j] = *reinterpret_cast<const unsigned int *>(xw_lidx + e);
+                        v2[j] = *reinterpret_cast<const V2 *>(vals + e);
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the staged runs are in LDS
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int j = 0; j < kEpl; ++j) prod[lane + 64 * j] = (XT)v[j] * xs[c[j]];
+                for (int j = 0; j < kEpl / 2; ++j) {
+                    const int i0 = min((int)(c2[j] & 0xffffu), top), i1 = min((int)(c2[j] >> 16), top);
+                    prod[2 * lane + 128 * j] = (XT)v2[j].a * xs[i0];
+                    prod[2 * lane + 128 * j + 1] = (XT)v2[j].b * xs[i1];
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < kEpl; ++j) {
@@ -472,7 +484,7 @@ __global__ void f32_copy_kernel(long long n, const double *__restrict__ src, flo
 int csr_build_f32(padne_ctx *ctx, padne_csr *m) {
     if (m->vals32 != nullptr) return PADNE_OK;
     padne_ctx *owner = m->owner ? m->owner : ctx;
-    m->vals32 = (float *)pool_alloc(owner, sizeof(float) * (size_t)(m->nnz > 0 ? m->nnz : 1));
+    m->vals32 = (float *)pool_alloc(owner, sizeof(float) * ((size_t)m->nnz + kPadNnz));   // padded like vals
     if (m->vals32 == nullptr) return PADNE_E_NOMEM;
     if (m->nnz > 0)
         hipLaunchKernelGGL(f32_copy_kernel, dim3((unsigned)std::min<long long>((m->nnz + 255) / 256, 8192)), dim3(256), 0,
