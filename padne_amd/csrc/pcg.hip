@@ -1029,6 +1029,22 @@ extern "C" int padne_solve_spd_dev(padne_ctx *ctx, const padne_csr *a, const voi
     PADNE_REQUIRE(n_rhs >= 1, "n_rhs");
     PADNE_REQUIRE(opts->precond == 0 || opts->precond == 1, "precond must be 0 (Jacobi) or 1 (multigrid)");
     PADNE_HIP_CHECK(hipSetDevice(ctx->device));
+    if ((opts->flags & 4) != 0) {
+        // "rebuild": everything derived from the matrix is recomputed inside this call, as for a matrix seen for the
+        // first time -- the hierarchy (below), and also the single-precision copy and the x-window plan cached on it
+        padne_csr *m = const_cast<padne_csr *>(a);
+        padne_ctx *owner = m->owner ? m->owner : ctx;
+        PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        pool_free(owner, m->vals32);
+        pool_free(owner, m->dinv32);
+        pool_free(owner, m->xw_desc);
+        pool_free(owner, m->xw_lidx);
+        m->vals32 = nullptr;
+        m->dinv32 = nullptr;
+        m->xw_desc = nullptr;
+        m->xw_lidx = nullptr;
+        m->xw_state = 0;
+    }
     PADNE_TRY(csr_build_dinv(ctx, const_cast<padne_csr *>(a)));
     PADNE_TRY(csr_build_xw_plan(ctx, const_cast<padne_csr *>(a)));
     padne_solve_info local;
