@@ -1846,9 +1846,12 @@ static int gather_tail(padne_ctx *ctx, Amg *amg) {
     return PADNE_OK;
 }
 
-static int gather_n_limit() {   // global size at which the row-partitioned levels hand over to the gathered tail
+// global size at which the row-partitioned levels hand over to the gathered tail: the tail is replicated work (a
+// fixed cost per rank), a partitioned level costs two exchanges per cycle -- with 4+ ranks the 100 k-unknown level
+// is still cheaper partitioned
+static int gather_n_limit(int world) {
     const char *e = getenv("PADNE_AMG_GATHER_N");
-    int v = e ? atoi(e) : 262144;
+    int v = e ? atoi(e) : (world >= 4 ? 65536 : 262144);
     if (v < 64) v = 64;
     return v;
 }
@@ -1861,7 +1864,7 @@ static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0) {
     hipStream_t s = ctx->stream;
     PADNE_HIP_CHECK(hipStreamSynchronize(s));
     const auto t_begin = std::chrono::steady_clock::now();
-    const long long gather_n = gather_n_limit();
+    const long long gather_n = gather_n_limit(W);
     Amg *amg = new Amg();
     amg->device = ctx->device;
     amg->ctx = ctx;
