@@ -1218,7 +1218,9 @@ static int transpose(padne_ctx *ctx, const padne_csr *M, padne_csr **T) {
                            M->vals, slot_ptr, cnt, key, val);
     PADNE_HIP_CHECK(hipGetLastError());
     PADNE_TRY(merge_slots_generic(ctx, nc, slot_ptr, key, val, row_len));
-    return csr_from_slots(ctx, nc, M->n_rows, slot_ptr, key, val, row_len, T);
+    // a transpose has no duplicates: the counted slots are exact and, once sorted, already the CSR rows
+    // (the scratch arrays go back to the pool without a synchronisation: reuse is ordered on the context's stream)
+    return csr_from_exact_slots(ctx, nc, M->n_rows, tot, slot_ptr, key, val, T);
 }
 
 static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_csr **C) {
@@ -1430,6 +1432,7 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         L.n = A->n_rows;
         nnz_total += (double)A->nnz;
         if ((rc = gershgorin(ctx, A, &L.lambda)) != PADNE_OK) break;
+        const double lambda_gershgorin = L.lambda;       // kept for the prolongator damping below
         if (lvl > 0 && A->n_rows > kCoarseN && getenv("PADNE_AMG_NO_LANCZOS") == nullptr) {
             // the Gershgorin bound is loose on the coarse operators (2.8 against ~1.7): tighten it with the
             // largest Ritz value of 12 Lanczos steps (converges from below; 8 % margin keeps the sweep stable)
@@ -1461,8 +1464,7 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         if ((rc = gershgorin(ctx, A, &lambda_f, true)) != PADNE_OK) { amg->levels.push_back(L); break; }
         // omega uses Gershgorin bounds (filtered operator, capped by the unfiltered one): the sharper Lanczos
         // estimate of lambda(D^-1 A) over-relaxes the prolongator (44 instead of 34 CG iterations at N = 0.5 M)
-        double lambda_g = 2.0;
-        if ((rc = gershgorin(ctx, A, &lambda_g, false)) != PADNE_OK) { amg->levels.push_back(L); break; }
+        const double lambda_g = lambda_gershgorin;
         if (lambda_g < lambda_f) lambda_f = lambda_g;
         const double omega = 4.0 / (3.0 * lambda_f);
         if (amg_verbose())

@@ -28,6 +28,8 @@
 // round exactly like the reference's Python floats (no fused multiply-add).
 #include "common.hpp"
 
+#include <algorithm>
+
 #include <string.h>
 
 namespace padne {
@@ -671,6 +673,36 @@ int csr_from_slots(padne_ctx *ctx, long long n_rows, long long n_cols, const int
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) {
         set_error("row compaction failed: %s", hipGetErrorString(e));
+        padne_csr_destroy(m);
+        return PADNE_E_HIP;
+    }
+    *out = m;
+    return PADNE_OK;
+}
+
+// slots that are already exact (row i occupies [slot_ptr[i], slot_ptr[i+1]) completely, e.g. a transpose whose
+// counts are exact and whose rows have been sorted): no scan, no per-row compaction, one streaming pass
+__global__ void unpack_slots_kernel(long long nnz, const long long *__restrict__ key, const double *__restrict__ val,
+                                    int *__restrict__ cols, double *__restrict__ vals) {
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (long long)gridDim.x * blockDim.x) {
+        cols[k] = (int)(key[k] >> 32);
+        vals[k] = val[k];
+    }
+}
+
+int csr_from_exact_slots(padne_ctx *ctx, long long n_rows, long long n_cols, long long nnz, const int *slot_ptr,
+                         const long long *key, const double *val, padne_csr **out) {
+    hipStream_t s = ctx->stream;
+    padne_csr *m = nullptr;
+    PADNE_TRY(csr_alloc(ctx, n_rows, n_cols, nnz, &m));
+    hipError_t e = hipMemcpyAsync(m->rowptr, slot_ptr, sizeof(int32_t) * (size_t)(n_rows + 1), hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess && nnz > 0) {
+        hipLaunchKernelGGL(unpack_slots_kernel, dim3((unsigned)std::min<long long>((nnz + 255) / 256, 8192)), dim3(256), 0, s,
+                           nnz, key, val, m->cols, m->vals);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) {
+        set_error("slot unpacking failed: %s", hipGetErrorString(e));
         padne_csr_destroy(m);
         return PADNE_E_HIP;
     }
