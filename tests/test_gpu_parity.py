@@ -898,8 +898,8 @@ def test_row_partitioned_hierarchy_with_several_exchanged_levels(monkeypatch):
 
 
 def test_batched_right_hand_sides_in_lockstep(ctx, monkeypatch):
-    """Config C5 at test size: 11 current-source configurations = one lockstep group of 8 + 3 solved one at a time;
-    every column must match the direct solve and the one-at-a-time path."""
+    """Config C5 at test size: 11 current-source configurations = one lockstep group of 8 + 3 solved one at a time
+    (and 14 = 8 + a padded group of 6); every column must match the direct solve and the one-at-a-time path."""
     A, b, Lo, ro, n = layered_spd(4, 120, 100, 6)
     rng = np.random.default_rng(9)
     k = 11
@@ -925,6 +925,13 @@ def test_batched_right_hand_sides_in_lockstep(ctx, monkeypatch):
     assert np.all(res.x[5] == 0.0)
     # the lockstep group does not cost more iterations per column than the one-at-a-time path
     assert res.iterations <= seq.iterations + 8
+    monkeypatch.delenv("PADNE_NO_BATCH")
+    B14 = np.vstack([B, B[:3] * 0.5])
+    res14 = d.solve_spd(B14, precond="amg")
+    assert res14.rel_residual <= 1.1e-12
+    for c in range(14):
+        ref = lu.solve(B14[c])
+        assert np.abs(res14.x[c] - ref).max() <= REL_TOL * max(np.abs(ref).max(), 1e-300)
 
 
 def test_x_window_tiles_and_gather_tiles_in_one_product(ctx, monkeypatch):
