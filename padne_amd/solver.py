@@ -427,6 +427,24 @@ def _solve_reduced(A: _hip.CsrMatrix, b: np.ndarray, rtol: float):
     return res.x, res.iterations, res.rel_residual, res.seconds
 
 
+def _solve_reduced_many(A: _hip.CsrMatrix, bs: list, rtol: float):
+    """Solve A y_k = b_k for every right-hand side of the list (zero right-hand sides cost nothing)."""
+    if len(bs) == 1:
+        y, it, rr, sec = _solve_reduced(A, bs[0], rtol)
+        return [y], it, rr, sec
+    live = [k for k, b in enumerate(bs) if A.shape[0] > 0 and np.any(b)]
+    sols = [np.zeros_like(b) for b in bs]
+    if not live:
+        return sols, 0, 0.0, 0.0
+    res = A.solve_spd(np.stack([bs[k] for k in live]), rtol=rtol, max_iter=MAX_ITER, raise_on_fail=False)
+    if res.status != _hip.OK:
+        warnings.warn(f"iterative solve stopped at a relative residual of {res.rel_residual:.2e} "
+                      f"(requested {rtol:.1e}) after {res.iterations} iterations", SolverWarning)
+    for row, k in enumerate(live):
+        sols[k] = res.x[row]
+    return sols, res.iterations, res.rel_residual, res.seconds
+
+
 def solve_system(L, r: np.ndarray, *, rtol: float = RTOL, reorder=None):
     """Solve ``L v = r`` and return ``(v, SolverInfo)`` like ``solver.py:767-780``.
 
@@ -464,19 +482,17 @@ def solve_system(L, r: np.ndarray, *, rtol: float = RTOL, reorder=None):
     try:
         Lc_vec = dev.matvec(red.c) if np.any(red.c) else None
         b0 = red.rhs(r, Lc_vec)
-        y0, iters, relres, secs = _solve_reduced(A, b0, rtol)
+        # all right-hand sides of this system in one call: the library advances groups of 5-8 of them in lockstep
+        gks = [red.project({row: val for row, val in cst.gamma.items()}) for cst in red.regulators]
+        sols, iters, relres, secs = _solve_reduced_many(A, [b0] + gks, rtol)
+        y0 = sols[0]
         v = red.expand(y0)
         mult_known = {}
         if red.regulators:
             # y = y0 + sum_k i_k z_k with A z_k = P^T gamma_k:  row x reads L_x.v + gamma_k[x] i_k = r_x, so
             # summing a group's rows gives  -P^T L P y = -P^T (r - L c) + sum_k i_k P^T gamma_k
             Z = []
-            for cst in red.regulators:
-                gk = red.project({row: val for row, val in cst.gamma.items()})
-                zk, it_k, rr_k, s_k = _solve_reduced(A, gk, rtol)
-                iters += it_k
-                secs += s_k
-                relres = max(relres, rr_k)
+            for zk in sols[1:]:
                 w = np.zeros(N)
                 free = red.index_map >= 0
                 w[free] = zk[red.index_map[free]]
