@@ -1,20 +1,24 @@
-// Jacobi-preconditioned conjugate gradients on the device, replacing the direct solve
+// Preconditioned conjugate gradients on the device, replacing the direct solve
 // scipy.sparse.linalg.spsolve of the reference (solver.py:773) on the reduced SPD system.
+// Preconditioners: Jacobi (below) or one smoothed-aggregation multigrid V-cycle (amg.hip; the default).
 //
-// One iteration = three kernels, all HBM-streaming, no host synchronisation:
+// One Jacobi-PCG iteration = three kernels, all HBM-streaming, no host synchronisation:
 //   K1  q = A p            + partial sums of p.q                (spmv.hip, 104*N bytes)
 //   K2  alpha = rz/pq ; x += alpha p ; r -= alpha q             (56*N bytes)
 //       + partial sums of r.(D^-1 r) and r.r
 //   K3  beta = rz'/rz ; p = D^-1 r + beta p                      (32*N bytes)
 //       + workgroup 0 does the bookkeeping: iteration count, convergence / breakdown flags.
-// z = D^-1 r is never stored.  Scalars never visit the host: every workgroup of the consuming
+// z = D^-1 r is never stored.  With multigrid K2 stops at r.r, the cycle produces z and the r.z partials
+// (its last stage), and K3 reads z.  Scalars never visit the host: every workgroup of the consuming
 // kernel re-adds the producer's per-workgroup partials (<= 2048 doubles, L2 resident) in a
 // fixed order, so results are bitwise reproducible run to run (no float atomics).
 // In multi-GPU runs a one-workgroup kernel folds the partials into a scalar which is then
 // summed over ranks by RCCL on the same stream; consumers then read a single "partial".
 //
 // The host enqueues `check_every` iterations at a time and then polls one status word; kernels
-// launched after convergence return immediately on the `done` flag.
+// launched after convergence return immediately on the `done` flag.  After convergence the true
+// residual is re-evaluated and the iteration restarted from it if the recurrence drifted.
+// solve_batch8 runs the same recurrences for 8 right-hand sides in lockstep (spmm.hip).
 #include "common.hpp"
 
 #include <algorithm>

@@ -1,4 +1,4 @@
-// CSR SpMV for gfx950 (MI355X): y = A x, f64 values, i32 indices.
+// CSR SpMV for gfx950 (MI355X): y = A x, i32 indices; f64 for the solver's products, f32 copies for the multigrid cycle.
 //
 // Bandwidth-bound (0.135 flop/B), so no MFMA: the design is about moving 12 B per non-zero +
 // 20 B per row exactly once, at the rate the HBM delivers (measured with rocprofv3 FETCH_SIZE, see
@@ -25,8 +25,8 @@
 //  * x windows (csr_build_xw_plan): what bounds the kernel after all that is the gather path (the L1/TA unit
 //    spends about two accesses per gathered double while the matrix stream alone runs at 6 TB/s).  A tile whose
 //    columns are covered by at most three runs of 72 (or 128) consecutive x entries -- every tile of a band matrix
-//    such as a scan-line numbered mesh, most tiles of a strip-ordered unstructured mesh -- stages those runs into LDS with wide coalesced loads and addresses them
-//    through a 16-bit index per non-zero (2 instead of 4 bytes of index traffic, no scattered global loads at
+//    such as a scan-line numbered mesh, most tiles of a strip-ordered unstructured mesh -- stages those runs
+//    into LDS with wide coalesced loads and addresses them through a 16-bit index per non-zero (2 instead of 4 bytes of index traffic, no scattered global loads at
 //    all); other tiles (rows with lumped couplings to far-away unknowns, unstructured numberings) take the
 //    gather path, tile by tile, inside the same launch.  Products and their summation order are unchanged.
 #include "common.hpp"
