@@ -151,12 +151,16 @@ typedef struct padne_solve_opts {
                             reports what it reached in padne_solve_info.rel_residual           */
     double  atol;
     int32_t max_iter;
-    int32_t precond;     /* 0 = Jacobi, 1 = smoothed-aggregation multigrid V-cycle (single GPU;
-                            the hierarchy is built on first use and cached on the matrix)  */
+    int32_t precond;     /* 0 = Jacobi, 1 = smoothed-aggregation multigrid V-cycle (the hierarchy is built on
+                            first use and cached on the matrix; the cycle runs in single precision inside
+                            the double-precision CG unless PADNE_AMG_F64 is set; on a row-partitioned
+                            matrix it is one hierarchy over all ranks, or block-Jacobi with
+                            padne_csr_set_preconditioner_block)                                    */
     int32_t check_every; /* iterations enqueued between host convergence polls (0 = auto) */
     int32_t flags;       /* bit0: x holds an initial guess (otherwise x0 = 0)
                             bit1: time sampled SpMV launches with HIP events -> info.spmv_seconds
-                            bit2: rebuild the multigrid hierarchy even if one is cached          */
+                            bit2: rebuild everything derived from the matrix inside this call (multigrid
+                                  hierarchy, single-precision copies, x-window plan of the SpMV)   */
 } padne_solve_opts;
 
 typedef struct padne_solve_info {
@@ -176,16 +180,20 @@ typedef struct padne_solve_info {
 
 /* Preconditioned CG on an SPD CSR matrix: replaces scipy.sparse.linalg.spsolve in
  * solve_system (solver.py:773) once the system is reduced.  b, x: host f64[n_rhs][n]
- * (row-major, one right-hand side after another). */
+ * (row-major, one right-hand side after another).  With the multigrid preconditioner on one GPU, groups of
+ * 8 right-hand sides (and remainders of 5-7, zero-padded) advance in lockstep: one pass over the matrix
+ * and the hierarchy per iteration for the whole group; results do not depend on the grouping beyond the
+ * tolerance.  PADNE_E_NOTCONVERGED still returns the best iterate in x and the residual reached in info. */
 int padne_solve_spd(padne_ctx *ctx, const padne_csr *a, const double *b_host, double *x_host,
                     int32_t n_rhs, const padne_solve_opts *opts, padne_solve_info *info);
 /* same with device-resident b and x */
 int padne_solve_spd_dev(padne_ctx *ctx, const padne_csr *a, const void *b_dev, void *x_dev,
                         int32_t n_rhs, const padne_solve_opts *opts, padne_solve_info *info);
 
-/* Row-partitioned runs: attach the rank's owned x owned diagonal block; with precond = 1 the multigrid
- * hierarchy is built on that block (block-Jacobi with multigrid blocks, no communication inside the
- * cycle).  Borrowed handle; null detaches. */
+/* Row-partitioned runs, optional: attach the rank's owned x owned diagonal block; with precond = 1 the
+ * multigrid hierarchy is then built on that block only (block-Jacobi with multigrid blocks, no
+ * communication inside the cycle, 3-6x more CG iterations than the default hierarchy over all ranks).
+ * Borrowed handle; null detaches. */
 int padne_csr_set_preconditioner_block(padne_csr *a, padne_csr *block);
 
 /* z = M^-1 r: one V-cycle of the multigrid preconditioner (built on first use and cached on `a`);
