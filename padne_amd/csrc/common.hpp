@@ -111,7 +111,8 @@ int launch_spmv(padne_ctx *ctx, const padne_csr *m, const double *x, double *y,
                 const double *dot_with /* may be null */, double *partials /* may be null */,
                 const int32_t *done_flag /* may be null */);
 int spmv_grid(const padne_csr *m);
-enum { SPMV_PLAIN = 0, SPMV_DOT = 1, SPMV_RESID = 2, SPMV_ADD = 3, SPMV_JACOBI = 4 };
+enum { SPMV_PLAIN = 0, SPMV_DOT = 1, SPMV_RESID = 2, SPMV_ADD = 3, SPMV_JACOBI = 4,
+       SPMV_DOT_AUX = 5 };   // same as SPMV_DOT; used outside the CG loop (Lanczos estimates) so that kernel profiles keep the two apart
 int launch_spmv_mode(padne_ctx *ctx, const padne_csr *m, int mode, const double *x, double *y,
                      const double *dot_with, double *partials, const int32_t *done_flag, const double *aux1,
                      const double *aux2, double scale);

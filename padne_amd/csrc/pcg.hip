@@ -904,7 +904,7 @@ int estimate_lambda_max(padne_ctx *ctx, const padne_csr *a, int steps, double *l
         double *rz_old_part = slot(ctx, parity ? SLOT_RZ1 : SLOT_RZ0);
         double *rz_new_part = slot(ctx, parity ? SLOT_RZ0 : SLOT_RZ1);
         if (dist) PADNE_TRY(halo_exchange_plan(ctx, *plan, p, nullptr));
-        PADNE_TRY(launch_spmv(ctx, a, p, q, p, slot(ctx, SLOT_PQ), nullptr));
+        PADNE_TRY(launch_spmv_mode(ctx, a, SPMV_DOT_AUX, p, q, p, slot(ctx, SLOT_PQ), nullptr, nullptr, nullptr, 0.0));
         PADNE_TRY(fold(slot(ctx, SLOT_PQ), gs, H_pq + k));
         if (dist) PADNE_TRY(comm_allreduce_sum_f64(ctx, H_pq + k, 1));
         // consumers read per-workgroup partials on one GPU and the reduced scalars across ranks

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
     const int *__restrict__ done_flag, const XT *__restrict__ aux1,
     const XT *__restrict__ aux2, const XT scale, const double *__restrict__ out_scale2,
     const int4 *__restrict__ xw_desc, const unsigned short *__restrict__ xw_lidx, const int xw_run) {
-    constexpr bool WITH_DOT = (MODE == SPMV_DOT) || (MODE == SPMV_JACOBI);
+    constexpr bool WITH_DOT = (MODE == SPMV_DOT) || (MODE == SPMV_DOT_AUX) || (MODE == SPMV_JACOBI);
     __shared__ XT prod_all[4 * kWaveChunk];
     extern __shared__ unsigned char xs_dyn[];      // 4 * kXwRuns * xw_run entries of XT when the plan is in use
     XT *xs_all = reinterpret_cast<XT *>(xs_dyn);
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
         if (r < row1) {
             if (MODE == SPMV_PLAIN) {
                 y[r] = (YT)acc;
-            } else if (MODE == SPMV_DOT) {
+            } else if (MODE == SPMV_DOT || MODE == SPMV_DOT_AUX) {
                 y[r] = (YT)acc;
                 dot_acc += dot_with[r] * (double)acc;
             } else if (MODE == SPMV_RESID) {
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_wpr_kernel(
     const XT *__restrict__ x, YT *__restrict__ y, const double *__restrict__ dot_with,
     double *__restrict__ partials, const int *__restrict__ done_flag, const XT *__restrict__ aux1,
     const XT *__restrict__ aux2, const XT scale, const double *__restrict__ out_scale2) {
-    constexpr bool WITH_DOT = (MODE == SPMV_DOT) || (MODE == SPMV_JACOBI);
+    constexpr bool WITH_DOT = (MODE == SPMV_DOT) || (MODE == SPMV_DOT_AUX) || (MODE == SPMV_JACOBI);
     __shared__ double red[4];
     if (done_flag != nullptr && *done_flag != 0) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_wpr_kernel(
         if (lane == 0) {
             if (MODE == SPMV_PLAIN) {
                 y[r] = (YT)acc;
-            } else if (MODE == SPMV_DOT) {
+            } else if (MODE == SPMV_DOT || MODE == SPMV_DOT_AUX) {
                 y[r] = (YT)acc;
                 dot_acc += dot_with[r] * (double)acc;
             } else if (MODE == SPMV_RESID) {
@@ -323,6 +323,7 @@ static int launch_spmv_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals,
         switch (mode) {
             case SPMV_PLAIN: PADNE_SPMV_WPR(SPMV_PLAIN); break;
             case SPMV_DOT: PADNE_SPMV_WPR(SPMV_DOT); break;
+            case SPMV_DOT_AUX: PADNE_SPMV_WPR(SPMV_DOT_AUX); break;
             case SPMV_RESID: PADNE_SPMV_WPR(SPMV_RESID); break;
             case SPMV_ADD: PADNE_SPMV_WPR(SPMV_ADD); break;
             case SPMV_JACOBI: PADNE_SPMV_WPR(SPMV_JACOBI); break;
@@ -342,6 +343,7 @@ static int launch_spmv_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals,
     switch (mode) {
         case SPMV_PLAIN: PADNE_SPMV_LAUNCH(SPMV_PLAIN); break;
         case SPMV_DOT: PADNE_SPMV_LAUNCH(SPMV_DOT); break;
+        case SPMV_DOT_AUX: PADNE_SPMV_LAUNCH(SPMV_DOT_AUX); break;
         case SPMV_RESID: PADNE_SPMV_LAUNCH(SPMV_RESID); break;
         case SPMV_ADD: PADNE_SPMV_LAUNCH(SPMV_ADD); break;
         case SPMV_JACOBI: PADNE_SPMV_LAUNCH(SPMV_JACOBI); break;
