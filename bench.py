@@ -202,7 +202,7 @@ def main():
         achieved = spmv_bytes / t_spmv / 1e9 if t_spmv > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "spmv_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and not distributed_path:      # measured on the 1-GPU launch; a rank's launch is smaller
             try:
                 traffic = json.load(open(tpath)).get("bytes_per_launch")
             except Exception:
@@ -232,7 +232,7 @@ def main():
             "pcg_textbook_gbs": (232.0 * n_local * last.iterations / last.seconds / 1e9
                                  if last.seconds > 0 and args.precond == "jacobi" else None),
             "setup_seconds": {"total": t_setup, "assemble": t_assemble, "reduce": t_reduce},
-            "roofline": {"bound": "hbm", "kernel": "csr_spmv_kernel<SPMV_DOT> (q = A p with p.q epilogue)",
+            "roofline": {"bound": "hbm", "kernel": "csr_spmv_kernel<SPMV_DOT, double, double, double> (q = A p with p.q epilogue)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_launch": int(spmv_bytes), "seconds_per_launch": t_spmv,
