@@ -43,7 +43,7 @@ def parse():
                     help="amg: smoothed-aggregation multigrid V-cycle (rebuilt inside every step); jacobi: diagonal")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-distributed", action="store_true",
-                    help="run the row-partitioned code path (RCCL communicator, halo plan, block multigrid) even on 1 GPU")
+                    help="run the row-partitioned code path (RCCL communicator, halo plan) even on 1 GPU")
     ap.add_argument("--cpu-sample-nx", type=int, default=400,
                     help="grid edge of the bounded CPU-baseline sample (8 layers of nx*nx)")
     return ap.parse_args()
@@ -116,8 +116,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 as `python -m torch.distributed.run "
+                         f"--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`")
     import torch  # plumbing only: rendezvous, barrier, max-over-ranks
     import torch.distributed as dist
     from padne_amd import _hip, synthetic
