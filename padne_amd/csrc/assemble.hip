@@ -159,7 +159,7 @@ int exclusive_scan_i32(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t 
 // ------------------------------------------------------------------------------------------
 // assembly kernels
 // ------------------------------------------------------------------------------------------
-enum { ERR_BAD_INDEX = 0, ERR_NONMANIFOLD = 1, ERR_WORDS = 4 };
+enum { ERR_BAD_INDEX = 0, ERR_NONMANIFOLD = 1, ERR_LONG_ROWS = 2, ERR_WORDS = 4 };
 
 __device__ __forceinline__ int find_segment(const long long *__restrict__ offs, int n_seg, long long i) {
     // largest m with offs[m] <= i   (offs has n_seg+1 entries, offs[0] = 0)
@@ -281,6 +281,10 @@ __global__ void merge_rows(long long n_rows, long long n_vert, int n_mesh,
     if (n < min_len) return;                       // short rows were merged by merge_rows_lds
     long long *K = key + s0;
     double *V = val + s0;
+    if (MESH) {                                    // the diagonal placeholder of the assembled system (see above)
+        K[0] = make_key((int)r, 2);
+        V[0] = 0.0;
+    }
     sort_slots(K, V, n);
     double sig = 0.0;
     double dacc = 0.0;  // -(w_1 + w_2 + ...) in ascending column order   (diag[i] -= ratio, solver.py:203)
@@ -357,10 +361,15 @@ __global__ __launch_bounds__(128) void merge_rows_mesh_lds(long long n_rows, lon
     if (r >= n_rows) return;
     const int s0 = slot_ptr[r];
     const int n = slot_ptr[r + 1] - s0;
-    if (n > CAP) return;
+    if (n > CAP) {
+        atomicExch(&err[ERR_LONG_ROWS], 1);        // the host then launches merge_rows<true> for these rows
+        return;
+    }
     for (int i = 0; i < n; ++i) {
-        const long long k = key[s0 + i];
-        const double v = val[s0 + i];
+        // slot 0 is the row's diagonal placeholder (sequence 2, value 0): it is never written to global memory,
+        // every merge kernel supplies it itself
+        const long long k = i == 0 ? make_key((int)r, 2) : key[s0 + i];
+        const double v = i == 0 ? 0.0 : val[s0 + i];
         int j = i - 1;
         while (j >= 0 && Kc[j][t] > k) {
             Kc[j + 1][t] = Kc[j][t];
@@ -507,15 +516,6 @@ __global__ void fill_value_i32(int *p, long long n, int v) {
     if (i < n) p[i] = v;
 }
 
-__global__ void asm_fill_diag_placeholder(long long n_rows, const int *__restrict__ slot_ptr,
-                                          long long *__restrict__ key, double *__restrict__ val) {
-    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rows) return;
-    const int s = slot_ptr[r];          // cursor starts at 1: slot 0 of every row is the placeholder
-    key[s] = make_key((int)r, 2);
-    val[s] = 0.0;
-}
-
 // ---- reduce:  out = scale * P^T M P ------------------------------------------------------------
 __global__ void reduce_count(long long n_rows, const int *__restrict__ rowptr, const int *__restrict__ cols,
                              const int *__restrict__ map, const int *__restrict__ cmap, int *__restrict__ cnt) {
@@ -603,9 +603,15 @@ static int finish_rows(padne_ctx *ctx, Scratch &sc, long long n_rows, long long 
         constexpr int kCap = 32;
         hipLaunchKernelGGL(merge_rows_mesh_lds<kCap>, dim3(nblk(n_rows, 128)), dim3(128), 0, s, n_rows, n_vert, n_mesh,
                            d_voff, d_sigma, slot_ptr, key, val, row_len, d_err);
-        hipLaunchKernelGGL(merge_rows<MESH>, dim3(nblk(n_rows, 128)), dim3(128), 0, s, n_rows, n_vert, n_mesh, d_voff,
-                           d_sigma, slot_ptr, key, val, row_len, d_err, kCap + 1);
         PADNE_HIP_CHECK(hipGetLastError());
+        int h_long[ERR_WORDS];
+        PADNE_HIP_CHECK(hipMemcpyAsync(h_long, d_err, sizeof(h_long), hipMemcpyDeviceToHost, s));
+        PADNE_HIP_CHECK(hipStreamSynchronize(s));
+        if (h_long[ERR_LONG_ROWS]) {               // rows with more than kCap slots (hubs): global-memory merge
+            hipLaunchKernelGGL(merge_rows<MESH>, dim3(nblk(n_rows, 128)), dim3(128), 0, s, n_rows, n_vert, n_mesh, d_voff,
+                               d_sigma, slot_ptr, key, val, row_len, d_err, kCap + 1);
+            PADNE_HIP_CHECK(hipGetLastError());
+        }
     } else {
         PADNE_TRY(merge_slots_generic(ctx, n_rows, slot_ptr, key, val, row_len));
     }
@@ -801,8 +807,6 @@ extern "C" int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns, int64_t
     PADNE_TRY(sc.alloc(&d_val, (size_t)n_slots));
     // 3 fill (cursor = 1: slot 0 of each row is the diagonal placeholder)
     hipLaunchKernelGGL(fill_value_i32, dim3(nblk(n_unknowns + 1)), dim3(256), 0, s, d_cnt, (long long)n_unknowns + 1, 1);
-    hipLaunchKernelGGL(asm_fill_diag_placeholder, dim3(nblk(n_unknowns)), dim3(256), 0, s, (long long)n_unknowns, d_slot,
-                       d_key, d_val);
     if (n_tri > 0)
         hipLaunchKernelGGL(asm_fill_tri, dim3(nblk(n_tri)), dim3(256), 0, s, (long long)n_tri, d_tri, d_xy, (int)n_mesh,
                            d_voff, d_toff, d_slot, d_cnt, d_key, d_val);
