@@ -204,6 +204,14 @@ int padne_amg_apply(padne_ctx *ctx, padne_csr *a, const double *r_host, double *
  * it stays valid as long as `a` does and must NOT be destroyed */
 int padne_amg_level(padne_ctx *ctx, padne_csr *a, int level, int which, const padne_csr **out);
 
+/* ---- connection snapping ------------------------------------------------------------------- */
+/* index of the nearest point of xy[n_points][2] for every query point (squared Euclidean distance in binary64,
+ * ties to the smallest index): what NodeIndexer.create asks of its per-layer KD-trees
+ * (_construct_kdtrees solver.py:356-396, query solver.py:425).  Brute force on the device: at a million vertices
+ * the KD-tree build is two thirds of the host time of solve(). */
+int padne_nearest_vertex(padne_ctx *ctx, int64_t n_points, const double *xy_host, int64_t n_query,
+                         const double *query_host, int64_t *index_out_host);
+
 /* ---- post-processing ----------------------------------------------------------------------- */
 /* per-face power density  p = sigma*|grad V|^2 with the reference's barycentric difference
  * quotient (compute_triangle_gradient solver.py:689-725, compute_power_density :728-745).

@@ -92,6 +92,7 @@ SIGNATURES = {
     "padne_amg_apply": (C.c_int, [_P, _P, _PF64, _PF64]),
     "padne_csr_set_preconditioner_block": (C.c_int, [_P, _P]),
     "padne_amg_level": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
+    "padne_nearest_vertex": (C.c_int, [_P, _I64, _PF64, _I64, _PF64, _PI64]),
     "padne_power_density": (C.c_int, [_P, _I64, _PF64, _I64, _PI32, _I64, _PI64, _PI64, _PF64, _PF64, _PF64]),
     "padne_face_gradient": (C.c_int, [_P, _I64, _PF64, _I64, _PI32, _I64, _PI64, _PI64, _PF64, _PF64, _PF64]),
     "padne_spmv_algorithmic_bytes": (_I64, [_P]),
@@ -284,6 +285,16 @@ class Context:
             _ptr(mvo, _PI64), _ptr(mto, _PI64), _ptr(sig, _PF64), cr.shape[0], _ptr(cr, _PI64),
             _ptr(cc, _PI64), _ptr(cv, _PF64), C.byref(h)))
         return CsrMatrix(self, h)
+
+    def nearest_vertex(self, points: np.ndarray, queries: np.ndarray) -> np.ndarray:
+        """Index of the nearest of ``points`` (n, 2) for every row of ``queries`` (m, 2); ties to the smallest index."""
+        pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 2)
+        q = np.ascontiguousarray(queries, dtype=np.float64).reshape(-1, 2)
+        out = np.empty(len(q), dtype=np.int64)
+        if len(q):
+            _check(self._lib.padne_nearest_vertex(self._h, len(pts), _ptr(pts, _PF64), len(q), _ptr(q, _PF64),
+                                                  _ptr(out, _PI64)))
+        return out
 
     def power_density(self, xy, tri, mesh_vertex_offset, mesh_tri_offset, conductance, potential) -> np.ndarray:
         xy = _f64(xy).reshape(-1, 2)

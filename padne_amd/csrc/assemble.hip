@@ -994,3 +994,110 @@ extern "C" int padne_face_gradient(padne_ctx *ctx, int64_t n_vert, const double 
     return face_fields(ctx, n_vert, xy_host, n_tri, tri_host, n_mesh, mesh_vertex_offset, mesh_tri_offset,
                        nullptr, potential_host, nullptr, gx_out_host, gy_out_host);
 }
+
+// ---- connection snapping: nearest mesh vertex of every query point ------------------------------------------
+// The reference builds a KD-tree per layer (solver.py:356-396) and queries it once per connection
+// (solver.py:425); with a million vertices and a few hundred connections the tree build is two thirds of the host
+// time of solve().  Brute force on the device instead: every workgroup takes a chunk of kNnChunk vertices and,
+// for every query, the closest vertex of its chunk; a second kernel takes the minimum over the chunks.  Ties go to
+// the smallest vertex index (a KD-tree leaves them to its traversal order).
+constexpr int kNnChunk = 4096;
+
+__global__ __launch_bounds__(256) void nn_chunk_kernel(long long n, const double *__restrict__ xy, int nq,
+                                                       const double *__restrict__ q, double *__restrict__ part_d,
+                                                       long long *__restrict__ part_i) {
+    __shared__ double sd[4];
+    __shared__ long long si[4];
+    const long long base = (long long)blockIdx.x * kNnChunk;
+    double px[kNnChunk / 256], py[kNnChunk / 256];
+#pragma unroll
+    for (int k = 0; k < kNnChunk / 256; ++k) {
+        const long long i = base + threadIdx.x + 256LL * k;
+        px[k] = i < n ? xy[2 * i] : 0.0;
+        py[k] = i < n ? xy[2 * i + 1] : 0.0;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int j = 0; j < nq; ++j) {
+        const double qx = q[2 * j], qy = q[2 * j + 1];
+        double best = 1e300;
+        long long bi = 0x7fffffffffffffffLL;
+#pragma unroll
+        for (int k = 0; k < kNnChunk / 256; ++k) {
+            const long long i = base + threadIdx.x + 256LL * k;
+            const double dx = px[k] - qx, dy = py[k] - qy;
+            const double d = dx * dx + dy * dy;
+            if (i < n && (d < best || (d == best && i < bi))) {
+                best = d;
+                bi = i;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const double od = __shfl_down(best, off, 64);
+            const long long oi = __shfl_down(bi, off, 64);
+            if (od < best || (od == best && oi < bi)) {
+                best = od;
+                bi = oi;
+            }
+        }
+        if (lane == 0) {
+            sd[w] = best;
+            si[w] = bi;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int t = 1; t < 4; ++t)
+                if (sd[t] < best || (sd[t] == best && si[t] < bi)) {
+                    best = sd[t];
+                    bi = si[t];
+                }
+            part_d[(size_t)blockIdx.x * nq + j] = best;
+            part_i[(size_t)blockIdx.x * nq + j] = bi;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void nn_reduce_kernel(int n_chunks, int nq, const double *__restrict__ part_d,
+                                 const long long *__restrict__ part_i, long long *__restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nq) return;
+    double best = 1e300;
+    long long bi = 0x7fffffffffffffffLL;
+    for (int c = 0; c < n_chunks; ++c) {
+        const double d = part_d[(size_t)c * nq + j];
+        const long long i = part_i[(size_t)c * nq + j];
+        if (d < best || (d == best && i < bi)) {
+            best = d;
+            bi = i;
+        }
+    }
+    out[j] = bi;
+}
+
+extern "C" int padne_nearest_vertex(padne_ctx *ctx, int64_t n_points, const double *xy_host, int64_t n_query,
+                                    const double *query_host, int64_t *index_out_host) {
+    PADNE_REQUIRE(ctx && (n_query == 0 || (query_host && index_out_host)), "null argument");
+    PADNE_REQUIRE(n_points >= 1 && xy_host, "at least one point is needed");
+    PADNE_REQUIRE(n_query >= 0 && n_query < (1 << 24), "number of queries");
+    if (n_query == 0) return PADNE_OK;
+    PADNE_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    Scratch sc(ctx);
+    const int n_chunks = (int)((n_points + kNnChunk - 1) / kNnChunk);
+    double *d_xy = nullptr, *d_q = nullptr, *d_pd = nullptr;
+    long long *d_pi = nullptr, *d_out = nullptr;
+    PADNE_TRY(sc.alloc(&d_xy, (size_t)2 * n_points));
+    PADNE_TRY(sc.alloc(&d_q, (size_t)2 * n_query));
+    PADNE_TRY(sc.alloc(&d_pd, (size_t)n_chunks * n_query));
+    PADNE_TRY(sc.alloc(&d_pi, (size_t)n_chunks * n_query));
+    PADNE_TRY(sc.alloc(&d_out, (size_t)n_query));
+    PADNE_HIP_CHECK(hipMemcpyAsync(d_xy, xy_host, sizeof(double) * 2 * (size_t)n_points, hipMemcpyHostToDevice, s));
+    PADNE_HIP_CHECK(hipMemcpyAsync(d_q, query_host, sizeof(double) * 2 * (size_t)n_query, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(nn_chunk_kernel, dim3(n_chunks), dim3(256), 0, s, (long long)n_points, d_xy, (int)n_query, d_q, d_pd,
+                       d_pi);
+    hipLaunchKernelGGL(nn_reduce_kernel, dim3(nblk(n_query)), dim3(256), 0, s, n_chunks, (int)n_query, d_pd, d_pi, d_out);
+    PADNE_HIP_CHECK(hipGetLastError());
+    PADNE_HIP_CHECK(hipMemcpyAsync(index_out_host, d_out, sizeof(long long) * (size_t)n_query, hipMemcpyDeviceToHost, s));
+    PADNE_HIP_CHECK(hipStreamSynchronize(s));
+    return PADNE_OK;
+}

@@ -60,6 +60,9 @@ def set_context(ctx: Optional[_hip.Context]) -> None:
     _default_ctx = ctx
 
 
+NEAREST_ON_DEVICE_FROM = 50000     # vertices of a layer from which connections are snapped on the device
+
+
 class SolverWarning(Warning):
     """Non-fatal oddity of the problem (e.g. non-zero ground current), ``solver.py:24-30``."""
 
@@ -141,7 +144,7 @@ class NodeIndexer:
                filtered_networks) -> "NodeIndexer":
         """``solver.py:398-466``: snap connections to the nearest vertex of their layer, then number
         internal nodes and one current unknown per voltage source / regulator."""
-        trees = {}
+        points = {}
         gidx = {}
         for layer_i in range(len(prob.layers)):
             blocks, ids = [], []
@@ -152,13 +155,28 @@ class NodeIndexer:
                 ids.append(np.arange(len(msh.points), dtype=np.int64) + vindex.offsets[mesh_i])
             if not blocks:
                 continue
-            trees[layer_i] = scipy.spatial.KDTree(np.concatenate(blocks), leafsize=32)
+            points[layer_i] = np.concatenate(blocks)
             gidx[layer_i] = np.concatenate(ids)
+        # all connections of a layer are snapped together: small layers through a KD-tree exactly like the
+        # reference (solver.py:356-396, leafsize=32, k=1); from NEAREST_ON_DEVICE_FROM vertices on, by brute force
+        # on the device, where the tree build alone would cost more than the whole linear solve
+        wanted = {}
+        for network in filtered_networks:
+            for conn in network.connections:
+                wanted.setdefault(prob.layers.index(conn.layer), []).append((conn.point.x, conn.point.y))
+        snapped = {}
+        for layer_i, pts in wanted.items():
+            q = np.asarray(pts, dtype=np.float64).reshape(-1, 2)
+            if len(points[layer_i]) >= NEAREST_ON_DEVICE_FROM:
+                k = get_context().nearest_vertex(points[layer_i], q)
+            else:
+                _, k = scipy.spatial.KDTree(points[layer_i], leafsize=32).query(q, k=1)
+            snapped[layer_i] = iter(np.asarray(k, dtype=np.int64))
         node_to_global = {}
         for network in filtered_networks:
             for conn in network.connections:
                 layer_i = prob.layers.index(conn.layer)
-                _, k = trees[layer_i].query((conn.point.x, conn.point.y), k=1)
+                k = next(snapped[layer_i])
                 g = int(gidx[layer_i][k])
                 node = conn.node_id
                 if node in node_to_global and node_to_global[node] != g:

@@ -953,6 +953,21 @@ def test_x_window_tiles_and_gather_tiles_in_one_product(ctx, monkeypatch):
     assert np.array_equal(y_plan, y_gather)
 
 
+def test_nearest_vertex_matches_the_kd_tree(ctx):
+    """Connection snapping (solver.py:425): the device brute force returns what the reference's KD-tree returns."""
+    import scipy.spatial
+    rng = np.random.default_rng(17)
+    for n in (1, 5, 4096, 4097, 300001):
+        pts = rng.uniform(-50, 50, (n, 2))
+        q = np.vstack([rng.uniform(-60, 60, (257, 2)), pts[rng.integers(0, n, 7)]])        # some exactly on a vertex
+        got = ctx.nearest_vertex(pts, q)
+        _, ref = scipy.spatial.KDTree(pts, leafsize=32).query(q, k=1)
+        assert np.array_equal(got, ref)
+    # ties: the smallest index wins
+    pts = np.array([[0.0, 0.0], [2.0, 0.0], [0.0, 0.0]])
+    assert list(ctx.nearest_vertex(pts, np.array([[1.0, 0.0], [0.0, 0.0]]))) == [0, 0]
+
+
 def test_spmm8_columns_are_bitwise_the_single_vector_products(ctx):
     """8 interleaved right-hand sides through one pass over the matrix; ragged rows, empty rows, long rows."""
     rng = np.random.default_rng(3)
