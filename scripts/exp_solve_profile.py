@@ -29,5 +29,7 @@ mesher = structured.StructuredMesher(mesh.Mesher.Config(maximum_size=size), jitt
 t0 = time.perf_counter(); sol = solver.solve(prob, mesher=mesher); t1 = time.perf_counter()
 nv = sum(len(ls.meshes[0].vertices) if hasattr(ls.meshes[0], "vertices") else 0 for ls in sol.layer_solutions)
 print(f"first solve() {t1 - t0:.3f} s", flush=True)
+for _ in range(2):
+    t0 = time.perf_counter(); sol = solver.solve(prob, mesher=mesher); print(f"solve() again {time.perf_counter() - t0:.3f} s", flush=True)
 pr = cProfile.Profile(); pr.enable(); sol = solver.solve(prob, mesher=mesher); pr.disable()
 st = pstats.Stats(pr); st.sort_stats("cumulative").print_stats(28)
