@@ -951,6 +951,27 @@ def test_x_window_tiles_and_gather_tiles_in_one_product(ctx, monkeypatch):
     y_gather = ctx.csr_from_scipy(A).matvec(x)
     assert np.array_equal(y_plan, A @ x)
     assert np.array_equal(y_plan, y_gather)
+    # random band matrices: three bands of varying width (some tiles fit runs of 72, some need 128, some none),
+    # ragged rows, empty rows, 1 % of the rows with far-away columns, a rectangular shape
+    monkeypatch.delenv("PADNE_NO_XWINDOW")
+    rng = np.random.default_rng(33)
+    for n, ncols, half in ((70001, 70001, 20), (90000, 90500, 45), (66000, 66000, 70)):
+        rows, cols = [], []
+        for off in (-311, 0, 297):
+            for d in range(-half, half + 1):
+                keep = rng.random(n) < 0.12
+                r = np.flatnonzero(keep)
+                c = r + off + d
+                ok = (c >= 0) & (c < ncols)
+                rows.append(r[ok]); cols.append(c[ok])
+        far = rng.choice(n, n // 100, replace=False)
+        rows.append(far); cols.append(rng.integers(0, ncols, len(far)))
+        rows, cols = np.concatenate(rows), np.concatenate(cols)
+        rows, cols = rows[rows % 997 != 0], cols[rows % 997 != 0]                # some empty rows
+        M = sp.csr_matrix((rng.uniform(-1, 1, len(rows)), (rows, cols)), shape=(n, ncols))
+        M.sum_duplicates(); M.sort_indices()
+        xv = rng.uniform(-1, 1, ncols)
+        assert np.array_equal(ctx.csr_from_scipy(M).matvec(xv), M @ xv)
 
 
 def test_nearest_vertex_matches_the_kd_tree(ctx):
