@@ -73,7 +73,7 @@ struct Amg {
     int device = 0;
 };
 
-constexpr double kTheta = 0.1;
+#define kTheta theta_val()
 static int coarse_n_limit() {   // coarsest-level size below which the dense inverse takes over
     static int v = 0;
     if (v == 0) {
@@ -86,7 +86,10 @@ static int coarse_n_limit() {   // coarsest-level size below which the dense inv
 }
 #define kCoarseN coarse_n_limit()
 constexpr int kMaxLevels = 16;
-constexpr double kChebRatio = 10.0;
+static double cheb_ratio() { const char *e = getenv("PADNE_AMG_CHEB_RATIO"); return e ? atof(e) : 10.0; }
+#define kChebRatio cheb_ratio()
+static double omega_num() { const char *e = getenv("PADNE_AMG_OMEGA"); return e ? atof(e) : 1.5; }
+static double theta_val() { const char *e = getenv("PADNE_AMG_THETA"); return e ? atof(e) : 0.08; }
 
 // ---- small kernels -----------------------------------------------------------------------------
 
@@ -1466,7 +1469,7 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         // estimate of lambda(D^-1 A) over-relaxes the prolongator (44 instead of 34 CG iterations at N = 0.5 M)
         const double lambda_g = lambda_gershgorin;
         if (lambda_g < lambda_f) lambda_f = lambda_g;
-        const double omega = 4.0 / (3.0 * lambda_f);
+        const double omega = omega_num() / lambda_f;
         if (amg_verbose())
             fprintf(stderr, "[amg] level %d: n=%lld nnz=%lld lambda=%.3f (P: %.3f) -> %d aggregates\n", lvl,
                     (long long)A->n_rows, (long long)A->nnz, L.lambda, lambda_f, n_agg);
@@ -1958,7 +1961,7 @@ static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0) {
         }
         if (lambda_g < lambda_f) lambda_f = lambda_g;
         pt.lap("block+aggregate");
-        rc = build_prolongator(ctx, blk, agg, n_agg, 4.0 / (3.0 * lambda_f), &Lr.P);
+        rc = build_prolongator(ctx, blk, agg, n_agg, omega_num() / lambda_f, &Lr.P);
         padne_csr_destroy(blk);
         if (rc != PADNE_OK) break;
         if ((rc = transpose(ctx, Lr.P, &Lr.R)) != PADNE_OK) break;

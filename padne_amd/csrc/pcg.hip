@@ -330,8 +330,11 @@ const padne_csr *amg_level_matrix(const padne_csr *A0, int level, int which);
 // row-partitioned run, i.e. block-Jacobi with multigrid blocks: no communication inside the cycle).
 // Reductions go through RCCL when the context has a communicator; the halo plan (if any) is applied
 // before every product.
+static thread_local bool t_last_solve_stagnated = false;   // the last solve_one ended at the evaluation floor of b - A x
+
 static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, const double *b, double *x,
                      const padne_solve_opts *o, padne_solve_info *info, bool x_is_guess) {
+    t_last_solve_stagnated = false;
     const bool dist = ctx->comm != nullptr || ctx->team != nullptr;
     const bool halo = ctx->halo_on;
     const bool amg = prec != nullptr;
@@ -499,6 +502,7 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
         // evaluate (about eps |A||x| per row, ~1e-12 ||b|| at N = 5 M): stop instead of spinning
         if (restarts > 0 && true_rr >= 0.25 * prev_true_rr) {
             stagnated = true;
+            t_last_solve_stagnated = true;
             break;
         }
         prev_true_rr = true_rr;
@@ -1129,7 +1133,9 @@ extern "C" int padne_solve_spd_dev(padne_ctx *ctx, const padne_csr *a, const voi
         const int status_before = local.status;
         PADNE_TRY(solve_one(ctx, a, use_amg ? pm : nullptr, (const double *)b_dev + (size_t)k * n,
                             (double *)x_dev + (size_t)k * n, opts, &local, (opts->flags & 1) != 0));
-        if (use_amg && local.status != PADNE_OK && status_before == PADNE_OK) {
+        // (a solve that stalled at the binary64 floor of b - A x is not redone: no preconditioner gets below it)
+        if (use_amg && local.status != PADNE_OK && status_before == PADNE_OK &&
+            !(local.status == PADNE_E_NOTCONVERGED && t_last_solve_stagnated)) {
             // the V-cycle lost positive definiteness or stalled far from the tolerance on this system:
             // redo this right-hand side from scratch with the diagonal preconditioner
             padne_solve_opts retry = *opts;
