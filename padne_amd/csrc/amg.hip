@@ -15,7 +15,7 @@
 //   coarse     A_c = R (A P) by two row-wise sparse products: one thread per row with sorted lists in LDS for
 //              short rows, one wave per row (hash set + per-lane ordered sums) for medium rows, a dense LDS
 //              accumulator for the long rows of the coarse levels; products are always added in generation order
-// until n <= 1024, where the dense inverse is formed by a blocked Gauss-Jordan (SPD: no pivoting).
+// until n <= 2048, where the dense inverse is formed by a blocked Gauss-Jordan (SPD: no pivoting).
 //
 // Apply: V(1,1) cycle with damped Jacobi (first-degree Chebyshev on [lambda/10, lambda]); every
 // stage is the SpMV kernel of spmv.hip with a different epilogue (residual, prolong-add,
@@ -75,10 +75,11 @@ struct Amg {
 
 #define kTheta theta_val()
 static int coarse_n_limit() {   // coarsest-level size below which the dense inverse takes over
+    if (const char *dyn = getenv("PADNE_AMG_COARSE_N_DYN")) { const int d = atoi(dyn); return d < 16 ? 16 : (d > 4096 ? 4096 : d); }
     static int v = 0;
     if (v == 0) {
         const char *e = getenv("PADNE_AMG_COARSE_N");
-        v = e ? atoi(e) : 1024;
+        v = e ? atoi(e) : 2048;
         if (v < 16) v = 16;
         if (v > 4096) v = 4096;
     }
@@ -89,7 +90,14 @@ constexpr int kMaxLevels = 16;
 static double cheb_ratio() { const char *e = getenv("PADNE_AMG_CHEB_RATIO"); return e ? atof(e) : 10.0; }
 #define kChebRatio cheb_ratio()
 static double omega_num() { const char *e = getenv("PADNE_AMG_OMEGA"); return e ? atof(e) : 1.5; }
-static double theta_val() { const char *e = getenv("PADNE_AMG_THETA"); return e ? atof(e) : 0.08; }
+static thread_local int t_setup_level = 0;     // level whose operators are being built (strength threshold decays with it)
+static double theta_val() {
+    const char *e = getenv("PADNE_AMG_THETA"), *d = getenv("PADNE_AMG_THETA_DECAY");
+    double th = e ? atof(e) : 0.08;
+    const double decay = d ? atof(d) : 1.0;
+    for (int l = 0; l < t_setup_level; ++l) th *= decay;
+    return th;
+}
 
 // ---- small kernels -----------------------------------------------------------------------------
 
@@ -1429,6 +1437,7 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
     const padne_csr *A = A0;
     double nnz_total = 0.0;
     for (int lvl = 0; lvl < kMaxLevels; ++lvl) {
+        t_setup_level = lvl;
         AmgLevel L;
         L.A = A;
         L.A_owned = (lvl == 0) ? nullptr : const_cast<padne_csr *>(A);
@@ -1892,6 +1901,7 @@ static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0) {
     double nnz_total = 0.0;
     bool stalled = false;
     for (int lvl = 0; lvl < kMaxLevels && rc == PADNE_OK; ++lvl) {
+        t_setup_level = lvl;
         AmgLevel L;
         L.A = A;
         L.A_owned = (lvl == 0) ? nullptr : const_cast<padne_csr *>(A);

@@ -961,7 +961,7 @@ using namespace padne;
 // z = M^-1 r with the multigrid V-cycle (builds the hierarchy if needed); host vectors
 extern "C" int padne_amg_apply(padne_ctx *ctx, padne_csr *a, const double *r_host, double *z_host) {
     PADNE_REQUIRE(ctx && a && r_host && z_host, "null argument");
-    PADNE_REQUIRE(a->n_rows == a->n_cols && a->n_rows > 1024, "multigrid needs a square matrix with more than 1024 rows");
+    PADNE_REQUIRE(a->n_rows == a->n_cols && a->n_rows > 2048, "multigrid needs a square matrix with more than 2048 rows");
     PADNE_HIP_CHECK(hipSetDevice(ctx->device));
     PADNE_TRY(amg_setup(ctx, a));
     const size_t bytes = sizeof(double) * (size_t)a->n_rows;
@@ -1085,6 +1085,11 @@ extern "C" int padne_solve_spd_dev(padne_ctx *ctx, const padne_csr *a, const voi
             double setup_s = 0.0;
             amg_info(pm, &local.levels, &local.operator_complexity, &setup_s, nullptr);
             if (fresh) local.precond_setup_seconds = setup_s;
+            if (local.levels < 2) {      // the whole matrix fits the dense coarse solve: nothing to cycle over, use Jacobi
+                use_amg = false;
+                local.levels = 0;
+                local.operator_complexity = 0.0;
+            }
         }
     }
     const long long n = ctx->halo_on ? ctx->halo_n_owned : a->n_rows;
