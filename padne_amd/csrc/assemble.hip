@@ -676,7 +676,7 @@ int csr_from_slots(padne_ctx *ctx, long long n_rows, long long n_cols, const int
                            m->cols, m->vals);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    // no synchronisation: the caller's scratch goes back to the pool, whose reuse is ordered on the same stream
     if (e != hipSuccess) {
         set_error("row compaction failed: %s", hipGetErrorString(e));
         padne_csr_destroy(m);
