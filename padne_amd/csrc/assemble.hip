@@ -353,7 +353,7 @@ __global__ __launch_bounds__(128) void merge_rows_mesh_lds(long long n_rows, lon
                                                            const double *__restrict__ sigma,
                                                            const int *__restrict__ slot_ptr, long long *__restrict__ key,
                                                            double *__restrict__ val, int *__restrict__ row_len,
-                                                           int *__restrict__ err) {
+                                                           int *__restrict__ err, const int skip_upto) {
     __shared__ long long Kc[CAP][128];
     __shared__ double Vc[CAP][128];
     const int t = threadIdx.x;
@@ -361,8 +361,9 @@ __global__ __launch_bounds__(128) void merge_rows_mesh_lds(long long n_rows, lon
     if (r >= n_rows) return;
     const int s0 = slot_ptr[r];
     const int n = slot_ptr[r + 1] - s0;
+    if (n <= skip_upto) return;                    // merged by the previous, smaller pass
     if (n > CAP) {
-        atomicExch(&err[ERR_LONG_ROWS], 1);        // the host then launches merge_rows<true> for these rows
+        atomicExch(&err[ERR_LONG_ROWS], 1);        // the host then launches the next larger pass for these rows
         return;
     }
     for (int i = 0; i < n; ++i) {
@@ -600,13 +601,23 @@ static int finish_rows(padne_ctx *ctx, Scratch &sc, long long n_rows, long long 
     int *row_len = nullptr;
     PADNE_TRY(sc.alloc(&row_len, (size_t)n_rows + 1));
     if (MESH) {
-        constexpr int kCap = 32;
-        hipLaunchKernelGGL(merge_rows_mesh_lds<kCap>, dim3(nblk(n_rows, 128)), dim3(128), 0, s, n_rows, n_vert, n_mesh,
-                           d_voff, d_sigma, slot_ptr, key, val, row_len, d_err);
+        // rows of up to 20 slots (vertices of degree <= 9) first: 40 KiB of LDS per 128 rows, twice the waves per CU of the
+        // 32-slot pass, which only runs for meshes that have longer rows; beyond that (hubs) the global-memory merge
+        constexpr int kCapSmall = 20, kCap = 32;
+        hipLaunchKernelGGL(merge_rows_mesh_lds<kCapSmall>, dim3(nblk(n_rows, 128)), dim3(128), 0, s, n_rows, n_vert, n_mesh,
+                           d_voff, d_sigma, slot_ptr, key, val, row_len, d_err, 0);
         PADNE_HIP_CHECK(hipGetLastError());
         int h_long[ERR_WORDS];
         PADNE_HIP_CHECK(hipMemcpyAsync(h_long, d_err, sizeof(h_long), hipMemcpyDeviceToHost, s));
         PADNE_HIP_CHECK(hipStreamSynchronize(s));
+        if (h_long[ERR_LONG_ROWS]) {
+            PADNE_HIP_CHECK(hipMemsetAsync(d_err + ERR_LONG_ROWS, 0, sizeof(int), s));
+            hipLaunchKernelGGL(merge_rows_mesh_lds<kCap>, dim3(nblk(n_rows, 128)), dim3(128), 0, s, n_rows, n_vert, n_mesh,
+                               d_voff, d_sigma, slot_ptr, key, val, row_len, d_err, kCapSmall);
+            PADNE_HIP_CHECK(hipGetLastError());
+            PADNE_HIP_CHECK(hipMemcpyAsync(h_long, d_err, sizeof(h_long), hipMemcpyDeviceToHost, s));
+            PADNE_HIP_CHECK(hipStreamSynchronize(s));
+        }
         if (h_long[ERR_LONG_ROWS]) {               // rows with more than kCap slots (hubs): global-memory merge
             hipLaunchKernelGGL(merge_rows<MESH>, dim3(nblk(n_rows, 128)), dim3(128), 0, s, n_rows, n_vert, n_mesh, d_voff,
                                d_sigma, slot_ptr, key, val, row_len, d_err, kCap + 1);
