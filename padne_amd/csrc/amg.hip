@@ -1445,7 +1445,7 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         nnz_total += (double)A->nnz;
         if ((rc = gershgorin(ctx, A, &L.lambda)) != PADNE_OK) break;
         const double lambda_gershgorin = L.lambda;       // kept for the prolongator damping below
-        if (lvl > 0 && A->n_rows > kCoarseN && getenv("PADNE_AMG_NO_LANCZOS") == nullptr) {
+        if (lvl > 0 && A->n_rows > kCoarseN && getenv("PADNE_AMG_NO_LANCZOS") == nullptr) {   // level 0: the bound is tight (1.99 by Lanczos)
             // the Gershgorin bound is loose on the coarse operators (2.8 against ~1.7): tighten it with the
             // largest Ritz value of 12 Lanczos steps (converges from below; 8 % margin keeps the sweep stable)
             double ritz = 0.0;
