@@ -75,14 +75,10 @@ struct Amg {
 
 #define kTheta theta_val()
 static int coarse_n_limit() {   // coarsest-level size below which the dense inverse takes over
-    if (const char *dyn = getenv("PADNE_AMG_COARSE_N_DYN")) { const int d = atoi(dyn); return d < 16 ? 16 : (d > 4096 ? 4096 : d); }
-    static int v = 0;
-    if (v == 0) {
-        const char *e = getenv("PADNE_AMG_COARSE_N");
-        v = e ? atoi(e) : 2048;
-        if (v < 16) v = 16;
-        if (v > 4096) v = 4096;
-    }
+    const char *e = getenv("PADNE_AMG_COARSE_N");
+    int v = e ? atoi(e) : 2048;
+    if (v < 16) v = 16;
+    if (v > 4096) v = 4096;
     return v;
 }
 #define kCoarseN coarse_n_limit()

@@ -45,7 +45,7 @@ else:
     keep = np.flatnonzero(imap[:nv] >= 0)
     b = ctx.to_device(-rhs[keep]); x = ctx.empty(nv - 1)
 def run(env):
-    for k in ("PADNE_AMG_CHEB_RATIO", "PADNE_AMG_OMEGA", "PADNE_AMG_THETA", "PADNE_AMG_F64", "PADNE_AMG_THETA_DECAY", "PADNE_AMG_COARSE_N_DYN"): os.environ.pop(k, None)
+    for k in ("PADNE_AMG_CHEB_RATIO", "PADNE_AMG_OMEGA", "PADNE_AMG_THETA", "PADNE_AMG_F64", "PADNE_AMG_THETA_DECAY", "PADNE_AMG_COARSE_N"): os.environ.pop(k, None)
     os.environ.update(env)
     A.solve_spd_dev(b, x, precond="amg", rebuild=True, raise_on_fail=False)
     t = time.perf_counter(); r = A.solve_spd_dev(b, x, precond="amg", rebuild=True, raise_on_fail=False); w = time.perf_counter() - t
@@ -60,8 +60,8 @@ if len(sys.argv) > 2:
 for dec in ("0.7", "0.5", "0.35"):
     run({"PADNE_AMG_THETA_DECAY": dec})
 for cn in ("512", "2048", "3000"):
-    os.environ["PADNE_AMG_COARSE_N_DYN"] = cn
-    run({"PADNE_AMG_COARSE_N_DYN": cn})
-os.environ.pop("PADNE_AMG_COARSE_N_DYN", None)
+    os.environ["PADNE_AMG_COARSE_N"] = cn
+    run({"PADNE_AMG_COARSE_N": cn})
+os.environ.pop("PADNE_AMG_COARSE_N", None)
 for th, om in itertools.product(("0.07", "0.09"), ("1.4", "1.5", "1.6")):
     run({"PADNE_AMG_THETA": th, "PADNE_AMG_OMEGA": om})
