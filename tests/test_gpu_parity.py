@@ -413,6 +413,71 @@ def test_linear_rectangle_end_to_end(ctx):
     assert np.array_equal(pickle.loads(blob).layer_solutions[0].potentials[0].values, pot.values)
 
 
+def test_long_thin_trace_resistance_and_power_density(ctx):
+    """tests/test_solver.py:1214-1321: a 100 mm x 0.2 mm trace of 35 um copper carries 1 A -> 0.24 V end to end,
+    power density I^2 R / (L w) everywhere (5 % per face away from the pads, 0.1 % area-weighted)."""
+    sigma = 2082.5                                                    # 5.95e4 S/mm * 0.035 mm
+    layer = problem.Layer(shape=structured.Shapes.of(structured.Rect(0, 0, 100, 0.2)), name="F.Cu", conductance=sigma)
+    P = mesh.Point
+    ys = (0.0, 0.1, 0.2)                                              # the whole width of each end is a pad
+    left = [problem.Connection(layer=layer, point=P(0.0, y)) for y in ys]
+    right = [problem.Connection(layer=layer, point=P(100.0, y)) for y in ys]
+    nets = [problem.Network(connections=[left[1], right[1]],
+                            elements=[problem.CurrentSource(f=left[1].node_id, t=right[1].node_id, current=1.0)])]
+    for side in (left, right):                                        # 0 V glue across the pad
+        for a, b in ((side[0], side[1]), (side[2], side[1])):
+            ca, cb = problem.Connection(layer=layer, point=a.point), problem.Connection(layer=layer, point=b.point)
+            nets.append(problem.Network(connections=[ca, cb],
+                                        elements=[problem.VoltageSource(p=ca.node_id, n=cb.node_id, voltage=0.0)]))
+    prob = problem.Problem(layers=[layer], networks=nets)
+    # a regular grid: every angle <= 90 degrees, so the reference's |cot| equals cot and the uniform field is reproduced
+    # exactly (a jittered grid has obtuse corners whose flipped cotangents cost ~5 %, the tolerance of the reference's
+    # own strip test)
+    mesher = structured.StructuredMesher(mesh.Mesher.Config(maximum_size=0.1), jitter=0.0)
+    sol = solver.solve(prob, mesher=mesher)
+    ls = sol.layer_solutions[0]
+    msh, pot, pw = ls.meshes[0], ls.potentials[0], ls.power_densities[0]
+    x = msh.points[:, 0]
+    v_left, v_right = pot.values[x == 0.0].mean(), pot.values[x == 100.0].mean()
+    r_expected = 100.0 / (sigma * 0.2)                                # 0.2401 ohm
+    assert abs(abs(v_right - v_left) - r_expected) < 0.01 * r_expected
+    area = np.array([f.area for f in msh.faces])
+    p_expected = 1.0 ** 2 * r_expected / (100.0 * 0.2)
+    cxa = msh.points[msh.triangles].mean(axis=1)[:, 0]
+    inner = (cxa > 1.0) & (cxa < 99.0)
+    assert np.abs(pw.values[inner] - p_expected).max() < 0.05 * p_expected
+    assert abs((pw.values * area).sum() / area.sum() - p_expected) < 2e-3 * p_expected
+    assert sol.solver_info.residual_norm < 1e-9
+
+
+def test_floating_plane_stays_equipotential(ctx):
+    """tests/test_solver.py:1664-1758: a plane that touches the circuit in a single node carries no current, so all
+    its vertices sit at that node's potential (to 1e-10), whatever happens on the driven layer."""
+    top = problem.Layer(shape=structured.Shapes.of(structured.Rect(0, 0, 20, 10)), name="F.Cu", conductance=2082.5)
+    bot = problem.Layer(shape=structured.Shapes.of(structured.Rect(0, 0, 20, 10)), name="B.Cu", conductance=1041.25)
+    P = mesh.Point
+    a, b = problem.Connection(layer=top, point=P(1, 5)), problem.Connection(layer=top, point=P(19, 5))
+    nets = [problem.Network(connections=[a, b], elements=[problem.VoltageSource(p=b.node_id, n=a.node_id, voltage=2.0)])]
+    load_a, load_b = problem.Connection(layer=top, point=P(3, 2)), problem.Connection(layer=top, point=P(17, 8))
+    nets.append(problem.Network(connections=[load_a, load_b],
+                                elements=[problem.Resistor(a=load_a.node_id, b=load_b.node_id, resistance=1.0)]))
+    via_t, via_b = problem.Connection(layer=top, point=P(10, 5)), problem.Connection(layer=bot, point=P(10, 5))
+    nets.append(problem.Network(connections=[via_t, via_b],
+                                elements=[problem.Resistor(a=via_t.node_id, b=via_b.node_id, resistance=1e-3)]))
+    prob = problem.Problem(layers=[top, bot], networks=nets)
+    mesher = structured.StructuredMesher(mesh.Mesher.Config(maximum_size=0.25), jitter=0.2, seed=4)
+    sol = solver.solve(prob, mesher=mesher)
+    top_s, bot_s = sol.layer_solutions
+    vb = bot_s.potentials[0].values
+    vt, mt = top_s.potentials[0].values, top_s.meshes[0]
+    k = int(np.argmin(np.hypot(mt.points[:, 0] - 10.0, mt.points[:, 1] - 5.0)))
+    assert np.ptp(vt) > 1.9                                            # the driven layer really carries the 2 V
+    assert np.abs(vb - vt[k]).max() <= 1e-10 * max(1.0, abs(vt[k]))
+    assert np.abs(bot_s.power_densities[0].values).max() <= 1e-12
+    # the 2 V source enters the reduced right-hand side as L c (norm ~1e4 here): rtol 1e-12 of that
+    assert sol.solver_info.rel_residual <= 1e-12 and sol.solver_info.residual_norm < 1e-8
+
+
 def test_coaxial_structure_end_to_end(ctx):
     """tests/test_solver.py:597-751: V(r) = ln(9/r)/ln 9 within 0.03, rings equipotential to 1e-3."""
     layer = problem.Layer(shape=structured.Shapes.of(structured.Annulus(0, 0, 1.0, 9.0)), name="F.Cu", conductance=1.0)
