@@ -991,6 +991,12 @@ def test_batched_right_hand_sides_in_lockstep(ctx, monkeypatch):
     # the lockstep group does not cost more iterations per column than the one-at-a-time path
     assert res.iterations <= seq.iterations + 8
     monkeypatch.delenv("PADNE_NO_BATCH")
+    # a lockstep group started from a good guess stops at once; from a perturbed guess it still converges
+    warm = d.solve_spd(B[:8], precond="amg", x0=res.x[:8])
+    assert warm.iterations <= 8 and warm.rel_residual <= 1.1e-12
+    rough = d.solve_spd(B[:8], precond="amg", x0=res.x[:8] * (1.0 + 1e-3))
+    assert rough.rel_residual <= 1.1e-12 and rough.iterations < res.iterations
+    assert np.abs(rough.x - res.x[:8]).max() <= REL_TOL * np.abs(res.x[:8]).max()
     B14 = np.vstack([B, B[:3] * 0.5])
     res14 = d.solve_spd(B14, precond="amg")
     assert res14.rel_residual <= 1.1e-12
