@@ -2035,11 +2035,11 @@ static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0) {
 
 // z = M^-1 r on level 0 ; optional partial sums of r.z (written by the last kernel of the cycle)
 int amg_apply(padne_ctx *ctx, const padne_csr *A0, const double *r, double *z, double *partials_rz,
-              const int32_t *done_flag, const double *bb2);
+              const int32_t *done_flag, const double *bb2, bool entry_done);
 
 // the same cycle on the single-precision copies; r comes in and z goes out in double
 static int amg_apply_f32(padne_ctx *ctx, Amg *amg, const double *r, double *z, double *partials_rz,
-                         const int32_t *done_flag, const double *bb2) {
+                         const int32_t *done_flag, const double *bb2, bool entry_done) {
     hipStream_t s = ctx->stream;
     const int nl = (int)amg->levels.size();
     if (partials_rz == nullptr) {
@@ -2059,7 +2059,7 @@ static int amg_apply_f32(padne_ctx *ctx, Amg *amg, const double *r, double *z, d
                 hipLaunchKernelGGL(compact_pieces<float>, dim3(nblk(amg->n_pad), ctx->world), dim3(256), 0, s, ctx->world,
                                    amg->n_pad, amg->seg_off, (const float *)cg, amg->tail_r, done_flag);
                 PADNE_HIP_CHECK(hipGetLastError());
-                PADNE_TRY(amg_apply(ctx, amg->tail, amg->tail_r, amg->tail_z, nullptr, done_flag, nullptr));
+                PADNE_TRY(amg_apply(ctx, amg->tail, amg->tail_r, amg->tail_z, nullptr, done_flag, nullptr, false));
                 hipLaunchKernelGGL(f32_from_f64_kernel, dim3(nblk(L.n)), dim3(256), 0, s, L.n,
                                    (const double *)(amg->tail_z + amg->tail_off), (float *)L.xb, done_flag);
                 PADNE_HIP_CHECK(hipGetLastError());
@@ -2071,7 +2071,9 @@ static int amg_apply_f32(padne_ctx *ctx, Amg *amg, const double *r, double *z, d
             break;
         }
         const int gv = (int)std::min<long long>((L.n + 255) / 256, 1024);
-        if (l == 0)
+        if (l == 0 && entry_done) {
+            // the caller's x / r update already wrote b = r / ||b|| and the first sweep (pcg_update_xr_entry_kernel)
+        } else if (l == 0)
             hipLaunchKernelGGL(amg_entry_f32_kernel, dim3(gv > 0 ? gv : 1), dim3(256), 0, s, L.n, r, bb2, (float)L.jac,
                                (const float *)L.A->dinv32, b, xa, done_flag);
         else
@@ -2194,10 +2196,22 @@ bool amg_supports_batch8(const padne_csr *A0) {
     return amg != nullptr && amg->f32 && !amg->dist && amg->levels.size() >= 2 && amg->coarse_inv32 != nullptr;
 }
 
+// buffers of the single-precision entry stage, for callers that fuse it into their own kernel (false: double cycle)
+bool amg_f32_entry_args(const padne_csr *A0, float *jac, const float **dinv32, float **b32, float **xa32) {
+    const Amg *amg = (const Amg *)A0->amg;
+    if (amg == nullptr || !amg->f32 || amg->levels.size() < 2) return false;
+    const AmgLevel &L = amg->levels[0];
+    *jac = (float)L.jac;
+    *dinv32 = L.A->dinv32;
+    *b32 = (float *)L.b;
+    *xa32 = (float *)L.xa;
+    return true;
+}
+
 int amg_apply(padne_ctx *ctx, const padne_csr *A0, const double *r, double *z, double *partials_rz,
-              const int32_t *done_flag, const double *bb2) {
+              const int32_t *done_flag, const double *bb2, bool entry_done) {
     Amg *amg = (Amg *)A0->amg;
-    if (amg->f32) return amg_apply_f32(ctx, amg, r, z, partials_rz, done_flag, bb2);
+    if (amg->f32) return amg_apply_f32(ctx, amg, r, z, partials_rz, done_flag, bb2, entry_done);
     hipStream_t s = ctx->stream;
     const int nl = (int)amg->levels.size();
     // downward sweep
@@ -2214,7 +2228,7 @@ int amg_apply(padne_ctx *ctx, const padne_csr *A0, const double *r, double *z, d
                 hipLaunchKernelGGL(compact_pieces<double>, dim3(nblk(amg->n_pad), ctx->world), dim3(256), 0, s, ctx->world,
                                    amg->n_pad, amg->seg_off, (const double *)amg->coarse_gather, amg->tail_r, done_flag);
                 PADNE_HIP_CHECK(hipGetLastError());
-                PADNE_TRY(amg_apply(ctx, amg->tail, amg->tail_r, amg->tail_z, nullptr, done_flag, nullptr));
+                PADNE_TRY(amg_apply(ctx, amg->tail, amg->tail_r, amg->tail_z, nullptr, done_flag, nullptr, false));
                 PADNE_HIP_CHECK(hipMemcpyAsync(out, amg->tail_z + amg->tail_off, sizeof(double) * (size_t)L.n,
                                                hipMemcpyDeviceToDevice, s));
             } else if (amg->n_coarse > 0)

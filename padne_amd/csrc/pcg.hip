@@ -214,6 +214,33 @@ __global__ __launch_bounds__(256) void pcg_update_xr_plain_kernel(
     block_store_partial(s_rr, red, part_rr + blockIdx.x);
 }
 
+// the same update with the entry stage of the single-precision multigrid cycle fused in: while r is in registers,
+// b32 = r / ||b|| and the first damped-Jacobi sweep xa32 = c * dinv * b32 are written as well (amg.hip, amg_entry_f32)
+__global__ __launch_bounds__(256) void pcg_update_xr_entry_kernel(
+    const long long n, const double *__restrict__ part_rz, const int P_rz, const double *__restrict__ part_pq,
+    const int P_pq, const double *__restrict__ p, const double *__restrict__ q, double *__restrict__ x,
+    double *__restrict__ r, double *__restrict__ part_rr, PcgStatus *__restrict__ st, const double *__restrict__ bb2,
+    const float c, const float *__restrict__ dinv32, float *__restrict__ b32, float *__restrict__ xa32) {
+    __shared__ double red[4];
+    if (st->done) return;
+    const double rz = block_total(part_rz, P_rz, red);
+    const double pq = block_total(part_pq, P_pq, red);
+    const double alpha = rz / pq;
+    const double s2 = *bb2;
+    const double s_inv = s2 > 0.0 ? 1.0 / sqrt(s2) : 1.0;
+    double s_rr = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const double ri = r[i] - alpha * q[i];
+        x[i] += alpha * p[i];
+        r[i] = ri;
+        s_rr += ri * ri;
+        const float v = (float)(ri * s_inv);
+        b32[i] = v;
+        xa32[i] = c * dinv32[i] * v;
+    }
+    block_store_partial(s_rr, red, part_rr + blockIdx.x);
+}
+
 // beta = rz'/rz ; p = z + beta p ; bookkeeping
 __global__ __launch_bounds__(256) void pcg_update_p_z_kernel(
     const long long n, const double *__restrict__ part_rz_new, const double *__restrict__ part_rz_old,
@@ -321,7 +348,8 @@ static int halo_exchange(padne_ctx *ctx, double *v, const int32_t *done_flag) {
 
 int amg_setup(padne_ctx *ctx, padne_csr *A0);
 int amg_apply(padne_ctx *ctx, const padne_csr *A0, const double *r, double *z, double *partials_rz,
-              const int32_t *done_flag, const double *bb2 = nullptr);
+              const int32_t *done_flag, const double *bb2 = nullptr, bool entry_done = false);
+bool amg_f32_entry_args(const padne_csr *A0, float *jac, const float **dinv32, float **b32, float **xa32);
 void amg_info(const padne_csr *A0, int *levels, double *complexity, double *setup_seconds, long long *coarse_n);
 const padne_csr *amg_level_matrix(const padne_csr *A0, int level, int which);
 
@@ -367,6 +395,10 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
     const int sample_stride = amg ? 4 : 16;
     double *scal = ctx->scalars;
     const double *bb_scalar = scal + S_BB;
+    float e_jac = 0.f;
+    const float *e_dinv32 = nullptr;
+    float *e_b32 = nullptr, *e_xa32 = nullptr;
+    const bool fuse_entry = amg && amg_f32_entry_args(prec, &e_jac, &e_dinv32, &e_b32, &e_xa32);
 
     PADNE_HIP_CHECK(hipMemsetAsync(st, 0, sizeof(PcgStatus), s));
     if (halo) PADNE_HIP_CHECK(hipMemsetAsync(p + n, 0, sizeof(double) * (size_t)(nc - n), s));
@@ -455,10 +487,14 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
                     PADNE_TRY(allreduce(scal + S_PQ, 1));
                 }
                 if (amg) {
-                    hipLaunchKernelGGL(pcg_update_xr_plain_kernel, dim3(gv), dim3(256), 0, s, n, rz_old, Pz, pq, Pq, p, q,
-                                       x, r, slot(ctx, SLOT_RR), st);
+                    if (fuse_entry)
+                        hipLaunchKernelGGL(pcg_update_xr_entry_kernel, dim3(gv), dim3(256), 0, s, n, rz_old, Pz, pq, Pq, p, q,
+                                           x, r, slot(ctx, SLOT_RR), st, bb_scalar, e_jac, e_dinv32, e_b32, e_xa32);
+                    else
+                        hipLaunchKernelGGL(pcg_update_xr_plain_kernel, dim3(gv), dim3(256), 0, s, n, rz_old, Pz, pq, Pq, p, q,
+                                           x, r, slot(ctx, SLOT_RR), st);
                     PADNE_HIP_CHECK(hipGetLastError());
-                    PADNE_TRY(amg_apply(ctx, prec, r, z, slot(ctx, rz_new_slot), &st->done, bb_scalar));
+                    PADNE_TRY(amg_apply(ctx, prec, r, z, slot(ctx, rz_new_slot), &st->done, bb_scalar, fuse_entry));
                     if (dist) {
                         PADNE_TRY(fold(slot(ctx, rz_new_slot), P_rz, kMaxPartials, 1, s_new));
                         PADNE_TRY(fold(slot(ctx, SLOT_RR), gv, kMaxPartials, 1, s_new + 1));
