@@ -22,7 +22,7 @@ def big(name, C):      # mean over the launches on the finest level (the largest
     return sum(v) / len(v) if v else float("nan"), len(v)
 names = [k for k in acc["FETCH_SIZE"] if "csr_spmv_kernel<1, double, double, double>" in k]
 dot = names[0]
-cal = [k for k in acc["FETCH_SIZE"] if "pcg_update_xr_plain_kernel" in k][0]
+cal = [k for k in acc["FETCH_SIZE"] if "pcg_update_p_z_kernel" in k][0]     # p = z + beta p: reads z, p; writes p
 f_dot, n_dot = big(dot, "FETCH_SIZE"); w_dot, _ = big(dot, "WRITE_SIZE")
 f_cal, n_cal = big(cal, "FETCH_SIZE"); w_cal, _ = big(cal, "WRITE_SIZE")
 rec = {"kernel": dot, "workload": "C4 (N=10M, nnz=70M)", "round": 1, "launches_averaged": n_dot,
@@ -30,8 +30,8 @@ rec = {"kernel": dot, "workload": "C4 (N=10M, nnz=70M)", "round": 1, "launches_a
        "bytes_per_launch": 2 * f_dot * 1024 + w_dot * 1024,
        "algorithmic_bytes_per_launch": 1039450524,
        "calibration": {"kernel": cal, "launches_averaged": n_cal, "FETCH_SIZE_KB": f_cal, "WRITE_SIZE_KB": w_cal,
-                       "expected_read_bytes": 4 * 8 * 9999391, "expected_write_bytes": 2 * 8 * 9999391,
-                       "read_ratio_with_x2": 2 * f_cal * 1024 / (4 * 8 * 9999391), "write_ratio": w_cal * 1024 / (2 * 8 * 9999391)},
+                       "expected_read_bytes": 2 * 8 * 9999391, "expected_write_bytes": 8 * 9999391,
+                       "read_ratio_with_x2": 2 * f_cal * 1024 / (2 * 8 * 9999391), "write_ratio": w_cal * 1024 / (8 * 9999391)},
        "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B (MI355X_MICROARCH.md, HBM section) -> x2, checked on the "
                      "calibration kernel of the same run whose traffic is known exactly; WRITE_SIZE exact"}
 json.dump(rec, open(out + "/spmv_traffic.json", "w"), indent=1)
