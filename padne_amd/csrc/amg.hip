@@ -612,7 +612,8 @@ __global__ __launch_bounds__(256) void spgemm_rows_wave(int n_rows, const int *_
                                                         const double *__restrict__ xv, const int *__restrict__ yr,
                                                         const int *__restrict__ yc, const double *__restrict__ yv,
                                                         const int *__restrict__ slot_ptr, long long *__restrict__ key,
-                                                        double *__restrict__ val, int *__restrict__ row_len) {
+                                                        double *__restrict__ val, int *__restrict__ row_len,
+                                                        const int only_flagged) {
     __shared__ int s_pc[4][CAPP];
     __shared__ double s_pv[4][CAPP];
     __shared__ int s_ht[4][HT];
@@ -632,7 +633,7 @@ __global__ __launch_bounds__(256) void spgemm_rows_wave(int n_rows, const int *_
     double a_n = 0.0;
     auto prefetch = [&](int row) {
         nx_n = 0; len_n = 0; ystart_n = 0; a_n = 0.0;
-        if (row < n_rows) {
+        if (row < n_rows && !(only_flagged && row_len[row] >= 0)) {
             const int x0 = xr[row];
             nx_n = xr[row + 1] - x0;
             if (nx_n <= 64 && lane < nx_n) {
@@ -647,7 +648,9 @@ __global__ __launch_bounds__(256) void spgemm_rows_wave(int n_rows, const int *_
     for (int i = blockIdx.x * 4 + w; i < n_rows; i += stride) {
         const int nx = nx_n, len = len_n, ystart = ystart_n;
         const double a = a_n;
+        const bool skip = only_flagged && row_len[i] >= 0;      // finished by the sub-wave pass
         prefetch(i + stride);
+        if (skip) continue;
         if (nx > 64) {
             if (lane == 0) row_len[i] = -1;
             continue;
@@ -741,6 +744,144 @@ __global__ __launch_bounds__(256) void spgemm_rows_wave(int n_rows, const int *_
             }
         }
         if (lane == 0) row_len[i] = nd;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// The same algorithm with LANES (32) lanes per row, i.e. two rows per wave and half the LDS per row: the wave
+// kernel above is bound by the latency of its dependent phases, not by issue slots (~750 wave instructions per row
+// against 7 us per row at full occupancy), so what counts is the number of rows in flight per CU.  Rows that do not
+// fit the smaller limits are flagged and finished by the wave kernel (only_flagged) and, beyond that, spgemm_rows_redo.
+template <int CAPP, int HT, int LANES>
+__global__ __launch_bounds__(256) void spgemm_rows_sub(int n_rows, const int *__restrict__ xr, const int *__restrict__ xc,
+                                                       const double *__restrict__ xv, const int *__restrict__ yr,
+                                                       const int *__restrict__ yc, const double *__restrict__ yv,
+                                                       const int *__restrict__ slot_ptr, long long *__restrict__ key,
+                                                       double *__restrict__ val, int *__restrict__ row_len) {
+    constexpr int G = 256 / LANES;                    // rows (lane groups) per workgroup
+    __shared__ int s_pc[G][CAPP];
+    __shared__ double s_pv[G][CAPP];
+    __shared__ int s_ht[G][HT];
+    __shared__ int s_dk[G][HT / 2];
+    __shared__ int s_sk[G][HT / 2];
+    __shared__ int s_off[G][LANES + 1];
+    __shared__ int s_ys[G][LANES];
+    __shared__ double s_xv[G][LANES];
+    const int lane = threadIdx.x & 63;
+    const int sl = lane % LANES, sub = lane / LANES, g = threadIdx.x / LANES;
+    const unsigned long long sub_mask = (LANES == 64 ? ~0ull : ((1ull << LANES) - 1ull));
+    int *pc = s_pc[g], *ht = s_ht[g], *dk = s_dk[g], *sk = s_sk[g], *off = s_off[g], *ys = s_ys[g];
+    double *pv = s_pv[g], *xs = s_xv[g];
+    constexpr int EMPTY = -1;
+    const int stride = gridDim.x * G;
+    int nx_n = 0, len_n = 0, ystart_n = 0;
+    double a_n = 0.0;
+    auto prefetch = [&](int row) {
+        nx_n = 0; len_n = 0; ystart_n = 0; a_n = 0.0;
+        if (row < n_rows) {
+            const int x0 = xr[row];
+            nx_n = xr[row + 1] - x0;
+            if (nx_n <= LANES && sl < nx_n) {
+                const int mid = xc[x0 + sl];
+                a_n = xv[x0 + sl];
+                ystart_n = yr[mid];
+                len_n = yr[mid + 1] - ystart_n;
+            }
+        }
+    };
+    prefetch(blockIdx.x * G + g);
+    for (int i = blockIdx.x * G + g; i < n_rows; i += stride) {
+        const int nx = nx_n, len = len_n, ystart = ystart_n;
+        const double a = a_n;
+        prefetch(i + stride);
+        if (nx > LANES) {
+            if (sl == 0) row_len[i] = -1;
+            continue;
+        }
+        int incl = len;
+#pragma unroll
+        for (int d = 1; d < LANES; d <<= 1) {
+            const int t = __shfl_up(incl, d, LANES);
+            if (sl >= d) incl += t;
+        }
+        const int np = __shfl(incl, LANES - 1, LANES);
+        if (np > CAPP) {
+            if (sl == 0) row_len[i] = -1;
+            continue;
+        }
+        off[sl] = incl - len;
+        if (sl == LANES - 1) off[LANES] = np;
+        ys[sl] = ystart;
+        xs[sl] = a;
+        for (int h = sl; h < HT; h += LANES) ht[h] = EMPTY;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        bool overflow = false;
+        for (int p = sl; p < np; p += LANES) {
+            int lo = 0, hi = nx;
+            while (hi - lo > 1) {
+                const int m = (lo + hi) >> 1;
+                if (off[m] <= p) lo = m; else hi = m;
+            }
+            const int q = ys[lo] + (p - off[lo]);
+            const int c = yc[q];
+            pc[p] = c;
+            pv[p] = xs[lo] * yv[q];
+            unsigned h = ((unsigned)c * 2654435761u) >> 7;
+            int probes = 0;
+            for (;;) {
+                h &= (HT - 1);
+                const int old = atomicCAS(&ht[h], EMPTY, c);
+                if (old == EMPTY || old == c) break;
+                ++h;
+                if (++probes >= HT) { overflow = true; break; }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        int nd = 0;
+        for (int h0 = 0; h0 < HT; h0 += LANES) {
+            const int kv = ht[h0 + sl];
+            const unsigned long long mask = (__ballot(kv != EMPTY) >> (sub * LANES)) & sub_mask;
+            const int pos = nd + __popcll(mask & ((1ull << sl) - 1ull));
+            if (kv != EMPTY && pos < HT / 2) dk[pos] = kv;
+            nd += __popcll(mask);
+        }
+        const bool any_overflow = ((__ballot(overflow) >> (sub * LANES)) & sub_mask) != 0ull;
+        if (any_overflow || nd > HT / 2) {
+            if (sl == 0) row_len[i] = -1;
+            continue;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        for (int q = sl; q < nd; q += LANES) {
+            const int kq = dk[q];
+            int rank = 0;
+            for (int t = 0; t < nd; ++t) rank += dk[t] < kq ? 1 : 0;
+            sk[rank] = kq;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        long long *K = key + slot_ptr[i];
+        double *V = val + slot_ptr[i];
+        for (int q0 = 0; q0 < nd; q0 += LANES) {
+            const int q = q0 + sl;
+            const int col = q < nd ? sk[q] : EMPTY;
+            double acc = 0.0;
+            bool first = true;
+            for (int p = 0; p < np; ++p) {
+                if (pc[p] == col) {
+                    const double v = pv[p];
+                    acc = first ? v : acc + v;
+                    first = false;
+                }
+            }
+            if (q < nd) {
+                K[q] = (long long)col << 32;
+                V[q] = acc;
+            }
+        }
+        if (sl == 0) row_len[i] = nd;
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -1266,12 +1407,18 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
         } else if (avg <= 256.0) {
             // tens to hundreds of products per row: one wave per row, the rows that do not fit are redone in global memory
             const unsigned gw = (unsigned)std::min<long long>(((long long)n + 3) / 4, 16384);
-            if (avg <= 110.0)   // short rows: small LDS footprint, twice the waves per CU to hide the dependent gathers
+            if (avg <= 110.0) {
+                // short rows: two rows per wave with small limits first (2.5 KiB of LDS per row: 56 rows in flight per
+                // CU), then one row per wave for the rows that did not fit
+                const unsigned gs = (unsigned)std::min<long long>(((long long)n + 7) / 8, 16384);
+                hipLaunchKernelGGL((spgemm_rows_sub<128, 64, 32>), dim3(gs), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
+                                   Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len);
                 hipLaunchKernelGGL((spgemm_rows_wave<256, 128>), dim3(gw), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
-                                   Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len);
-            else
+                                   Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len, 1);
+            } else {
                 hipLaunchKernelGGL((spgemm_rows_wave<512, 256>), dim3(gw), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
-                                   Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len);
+                                   Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len, 0);
+            }
             hipLaunchKernelGGL(spgemm_rows_redo, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
                                Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len);
         } else {
