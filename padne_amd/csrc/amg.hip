@@ -1415,9 +1415,16 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
                                    Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len);
                 hipLaunchKernelGGL((spgemm_rows_wave<256, 128>), dim3(gw), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
                                    Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len, 1);
+                if (n <= 500000)   // coarse levels: the few long rows stay away from the serial fallback
+                    hipLaunchKernelGGL((spgemm_rows_wave<1024, 512>), dim3(gw), dim3(256), 0, s, n, X->rowptr, X->cols,
+                                       X->vals, Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len, 1);
             } else {
+                // coarse levels: rows of a few hundred products, some of a thousand -- a second wave pass with doubled
+                // limits keeps those away from the serial fallback (0.5 ms for a handful of rows)
                 hipLaunchKernelGGL((spgemm_rows_wave<512, 256>), dim3(gw), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
                                    Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len, 0);
+                hipLaunchKernelGGL((spgemm_rows_wave<1024, 512>), dim3(gw), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
+                                   Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len, 1);
             }
             hipLaunchKernelGGL(spgemm_rows_redo, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
                                Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len);
