@@ -363,7 +363,10 @@ __global__ __launch_bounds__(128) void merge_rows_mesh_lds(long long n_rows, lon
     const int n = slot_ptr[r + 1] - s0;
     if (n <= skip_upto) return;                    // merged by the previous, smaller pass
     if (n > CAP) {
-        atomicExch(&err[ERR_LONG_ROWS], 1);        // the host then launches the next larger pass for these rows
+        // the host then launches the next larger pass for these rows.  A plain store of the same value by one lane per
+        // wave: on an unstructured mesh a few per cent of the rows land here, and as many atomics on one address serialise
+        const unsigned long long m = __ballot(true);
+        if ((threadIdx.x & 63) == __ffsll((long long)m) - 1) *(volatile int *)&err[ERR_LONG_ROWS] = 1;
         return;
     }
     for (int i = 0; i < n; ++i) {
