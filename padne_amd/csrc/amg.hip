@@ -979,83 +979,109 @@ __global__ void spgemm_rows_redo(int n_rows, const int *__restrict__ xr, const i
 // dense coarse matrix and its inverse
 __global__ void dense_from_csr(int n, const int *__restrict__ rowptr, const int *__restrict__ cols,
                                const double *__restrict__ vals, double *__restrict__ W) {
-    // W = [A | I], n x 2n row-major
+    // W = A, n x n row-major
     const int i = blockIdx.x;
-    for (int c = threadIdx.x; c < 2 * n; c += blockDim.x) W[(size_t)i * 2 * n + c] = (c == n + i) ? 1.0 : 0.0;
+    for (int c = threadIdx.x; c < n; c += blockDim.x) W[(size_t)i * n + c] = 0.0;
     __syncthreads();
-    for (int k = rowptr[i] + threadIdx.x; k < rowptr[i + 1]; k += blockDim.x) W[(size_t)i * 2 * n + cols[k]] = vals[k];
+    for (int k = rowptr[i] + threadIdx.x; k < rowptr[i + 1]; k += blockDim.x) W[(size_t)i * n + cols[k]] = vals[k];
 }
 
-// Blocked Gauss-Jordan, ping-pong between two copies of [A | I]: one launch eliminates kGjBlock pivots at once
-// (814 launches of a 5 us kernel were 10 % of the multigrid setup).  With D the kGjBlock x kGjBlock pivot block,
-// the pivot rows become D^-1 W[K, :] and every other row i loses W[i, K] times that; each thread owns one column
-// of a strip of rows, forms its column of D^-1 W[K, :] once and applies it down the strip.  No pivoting (the
-// coarse operators are symmetric positive definite); every entry reads the OLD matrix and writes the new one.
-constexpr int kGjBlock = 8;
+// Blocked in-place Gauss-Jordan inversion, ping-pong between two n x n copies: one launch eliminates kGjBlock pivots
+// (the first version, one pivot per launch on [A | I], was 10 % of the multigrid setup; eight pivots per launch on
+// [A | I] still moved 17 GB for n = 1600).  With K the pivot indices and D = W[K, K]:
+//     W[K, K] <- D^-1            W[K, j] <- D^-1 W[K, j]
+//     W[i, K] <- -W[i, K] D^-1   W[i, j] <- W[i, j] - W[i, K] D^-1 W[K, j]          (i, j outside K)
+// Each thread owns one column of a strip of rows, forms its column R of the new pivot rows once (for a pivot
+// column that is the column of D^-1 itself, and the old entry counts as zero) and applies it down the strip.  No
+// pivoting (the coarse operators are symmetric positive definite); every entry reads the OLD matrix and writes the new.
+constexpr int kGjBlock = 16;
 constexpr int kGjStrip = 32;
-__global__ __launch_bounds__(256) void gj_block_step(int n, int k0, const double *__restrict__ in, double *__restrict__ out) {
-    __shared__ double Dinv[kGjBlock][kGjBlock];
-    __shared__ double Lcol[kGjStrip][kGjBlock];      // W[i, K] of the strip's rows
-    const size_t w = (size_t)2 * n;
-    const int bs = min(kGjBlock, n - k0);
-    const int r0 = blockIdx.y * kGjStrip;
-    // pivot block inverse: Gauss-Jordan on [D | I] in LDS, one thread per entry, and the strip's multipliers
-    __shared__ double Daug[kGjBlock][2 * kGjBlock];
-    const int ea = threadIdx.x / (2 * kGjBlock), eb = threadIdx.x % (2 * kGjBlock);
-    const bool entry = threadIdx.x < kGjBlock * 2 * kGjBlock;
-    if (entry) {
-        double v;
-        if (eb < kGjBlock) v = (ea < bs && eb < bs) ? in[(size_t)(k0 + ea) * w + k0 + eb] : (ea == eb ? 1.0 : 0.0);
-        else v = (eb - kGjBlock == ea) ? 1.0 : 0.0;
-        Daug[ea][eb] = v;
-    }
-    __syncthreads();
-    for (int p = 0; p < kGjBlock; ++p) {
-        double v = 0.0;
-        if (entry) {
-            const double prow = Daug[p][eb] / Daug[p][p];
-            v = (ea == p) ? prow : Daug[ea][eb] - Daug[ea][p] * prow;
-        }
-        __syncthreads();
-        if (entry) Daug[ea][eb] = v;
-        __syncthreads();
-    }
-    if (entry && eb >= kGjBlock) Dinv[ea][eb - kGjBlock] = Daug[ea][eb];
-    for (int t = threadIdx.x; t < kGjStrip * kGjBlock; t += blockDim.x) {
-        const int i = r0 + t / kGjBlock, b = t % kGjBlock;
-        Lcol[t / kGjBlock][b] = (i < n && b < bs) ? in[(size_t)i * w + k0 + b] : 0.0;
-    }
-    __syncthreads();
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= 2 * n) return;
-    double P[kGjBlock], R[kGjBlock];
+__device__ __forceinline__ double Rsel(const double (&R)[kGjBlock], int a) {
+    double v = 0.0;
 #pragma unroll
-    for (int b = 0; b < kGjBlock; ++b) P[b] = b < bs ? in[(size_t)(k0 + b) * w + c] : 0.0;
-#pragma unroll
-    for (int a = 0; a < kGjBlock; ++a) {
-        double sum = 0.0;
-#pragma unroll
-        for (int b = 0; b < kGjBlock; ++b) sum += Dinv[a][b] * P[b];
-        R[a] = sum;
-    }
-    const int r1 = min(r0 + kGjStrip, n);
-    for (int i = r0; i < r1; ++i) {
-        double v;
-        if (i >= k0 && i < k0 + bs) {
-            v = R[i - k0];
-        } else {
-            v = in[(size_t)i * w + c];
-#pragma unroll
-            for (int b = 0; b < kGjBlock; ++b) v -= Lcol[i - r0][b] * R[b];
-        }
-        out[(size_t)i * w + c] = v;
-    }
+    for (int b = 0; b < kGjBlock; ++b) v = (a == b) ? R[b] : v;
+    return v;
 }
-
-__global__ void dense_extract_inverse(int n, const double *__restrict__ W, double *__restrict__ inv) {
+template <bool kFull>      // kFull: all 16 pivots exist (every launch but possibly the last)
+__global__ __launch_bounds__(256) void gj_block_step(int n, int k0, const double *__restrict__ in, double *__restrict__ out) {
+    static_assert(kGjBlock == 16, "the pivot block inversion below maps a 16 x 16 block onto one wave");
+    __shared__ double Dsh[kGjBlock][kGjBlock + 1];
+    __shared__ __attribute__((aligned(16))) double Dinv[kGjBlock][kGjBlock];      // read as broadcasts: no padding, 16-byte reads
+    __shared__ __attribute__((aligned(16))) double Lcol[kGjStrip][kGjBlock];     // W[i, K] of the strip's rows
+    const int bs = kFull ? kGjBlock : min(kGjBlock, n - k0);
+    const int r0 = blockIdx.y * kGjStrip;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = blockIdx.y;
-    if (c < n) inv[(size_t)r * n + c] = W[(size_t)r * 2 * n + n + c];
+    const bool live = c < n;
+    const bool pivot_col = c >= k0 && c < k0 + bs;
+    // everything this thread needs from the old matrix is requested before the pivot block is inverted, so the
+    // inversion (a serial chain of 16 steps) runs under the memory latency: its column of the pivot rows, the
+    // strip's old entries, the strip's multipliers
+    double P[kGjBlock], V[kGjStrip];
+#pragma unroll
+    for (int b = 0; b < kGjBlock; ++b) P[b] = (live && !pivot_col && b < bs) ? in[(size_t)(k0 + b) * n + c] : 0.0;
+#pragma unroll
+    for (int q = 0; q < kGjStrip; ++q) {
+        const int i = r0 + q;
+        V[q] = (live && i < n && !pivot_col) ? in[(size_t)i * n + c] : 0.0;
+    }
+    for (int t = threadIdx.x; t < kGjStrip * kGjBlock; t += 256) {
+        const int i = r0 + t / kGjBlock, b = t % kGjBlock;
+        Lcol[t / kGjBlock][b] = (i < n && (kFull || b < bs)) ? in[(size_t)i * n + k0 + b] : 0.0;
+    }
+    if (threadIdx.x < 64) {
+        // in-place Gauss-Jordan of the pivot block D by ONE wave, entries in registers (lane: column lane % 16, rows
+        // lane / 16 + 4 q), exchanged through LDS whose operations a wave sees in order: no workgroup barrier in the
+        // chain.  Padded with the identity when fewer than 16 pivots are left.
+        const int lane = threadIdx.x, eb = lane & 15, ea0 = lane >> 4;
+        double dd[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ea = ea0 + 4 * q;
+            dd[q] = (ea < bs && eb < bs) ? in[(size_t)(k0 + ea) * n + k0 + eb] : (ea == eb ? 1.0 : 0.0);
+        }
+        for (int p = 0; p < kGjBlock; ++p) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Dsh[ea0 + 4 * q][eb] = dd[q];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const double inv = 1.0 / Dsh[p][p];
+            const double rp = Dsh[p][eb] * inv;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ea = ea0 + 4 * q;
+                const double cp = Dsh[ea][p];
+                dd[q] = (ea == p) ? (eb == p ? inv : rp) : (eb == p ? -cp * inv : dd[q] - cp * rp);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Dinv[ea0 + 4 * q][eb] = dd[q];
+    }
+    __syncthreads();
+    if (!live) return;
+    double R[kGjBlock];
+    if (pivot_col) {
+#pragma unroll
+        for (int a = 0; a < kGjBlock; ++a) R[a] = Dinv[a][c - k0];
+    } else {
+#pragma unroll
+        for (int a = 0; a < kGjBlock; ++a) {
+            double sum = 0.0;
+#pragma unroll
+            for (int b = 0; b < kGjBlock; ++b) sum = fma(Dinv[a][b], P[b], sum);
+            R[a] = sum;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < kGjStrip; ++q) {
+        const int i = r0 + q;
+        double v = V[q];
+#pragma unroll
+        for (int b = 0; b < kGjBlock; ++b) v = fma(-Lcol[q][b], R[b], v);
+        if (i >= k0 && i < k0 + bs) v = Rsel(R, i - k0);
+        if (i < n) out[(size_t)i * n + c] = v;
+    }
 }
 
 // y = Inv * b : one wave per row
@@ -1442,19 +1468,22 @@ static int dense_inverse(padne_ctx *ctx, const padne_csr *A, double **inv_out) {
     const int n = (int)A->n_rows;
     Scratch sc(ctx);
     double *W = nullptr, *W2 = nullptr, *inv = nullptr;
-    PADNE_TRY(sc.alloc(&W, (size_t)n * 2 * n));
-    PADNE_TRY(sc.alloc(&W2, (size_t)n * 2 * n));
+    PADNE_TRY(sc.alloc(&W, (size_t)n * n));
+    PADNE_TRY(sc.alloc(&W2, (size_t)n * n));
     inv = (double *)pool_alloc(ctx, sizeof(double) * (size_t)(n > 0 ? n : 1) * (size_t)(n > 0 ? n : 1));
     if (inv == nullptr) return PADNE_E_NOMEM;
     if (n > 0) {
         hipLaunchKernelGGL(dense_from_csr, dim3(n), dim3(256), 0, s, n, A->rowptr, A->cols, A->vals, W);
-        const dim3 ge(nblk(2 * n), (unsigned)((n + kGjStrip - 1) / kGjStrip));
+        const dim3 ge(nblk(n), (unsigned)((n + kGjStrip - 1) / kGjStrip));
         double *src = W, *dst = W2;
         for (int k = 0; k < n; k += kGjBlock) {
-            hipLaunchKernelGGL(gj_block_step, ge, dim3(256), 0, s, n, k, src, dst);
+            // the last step writes the finished inverse where it stays
+            if (k + kGjBlock <= n)
+                hipLaunchKernelGGL(gj_block_step<true>, ge, dim3(256), 0, s, n, k, src, k + kGjBlock >= n ? inv : dst);
+            else
+                hipLaunchKernelGGL(gj_block_step<false>, ge, dim3(256), 0, s, n, k, src, inv);
             std::swap(src, dst);
         }
-        hipLaunchKernelGGL(dense_extract_inverse, dim3(nblk(n), n), dim3(256), 0, s, n, src, inv);
     }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(s);

@@ -113,61 +113,61 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
     const int s1 = (int)((long long)(slab + 1) * n_wtiles / nslab);
 
     double dot_acc = 0.0;
+    int rs = 0, re = 0;
+    int4 d = make_int4(0, 0, 0, 0);
     for (int wt = s0 + wx; wt < s1; wt += wps) {
         const int row0 = wt * 64;
         const int row1 = min(row0 + 64, n_rows);
         const int r = row0 + lane;
-        int rs = 0, re = 0;
-        if (r < row1) {
+        rs = 0;
+        re = 0;
+        if (r < n_rows) {
             rs = rowptr[r];
             re = rowptr[r + 1];
         }
+        if (xw_desc != nullptr) d = xw_desc[wt];
         const int k0 = __shfl(rs, 0, 64);
         const int k1 = __shfl(re, row1 - row0 - 1, 64);
         XT acc = 0;
-        bool windowed = false;                       // wave-uniform
-        if (xw_desc != nullptr) {
-            const int4 d = xw_desc[wt];
-            windowed = d.w != 0;
-            if (windowed) {
-                // stage the tile's runs of x: two loads per run (64 + the rest), all issued before the wait
-                const int st[kXwRuns] = {d.x, d.y, d.z};
-                XT xa[kXwRuns], xb[kXwRuns];
+        const bool windowed = xw_desc != nullptr && d.w != 0;      // wave-uniform
+        if (windowed) {
+            // the tile's runs of x: two loads per run (64 + the rest)
+            const int st[kXwRuns] = {d.x, d.y, d.z};
+            XT xa[kXwRuns], xb[kXwRuns];
 #pragma unroll
-                for (int q = 0; q < kXwRuns; ++q) {
-                    const int a = st[q] + lane, b = st[q] + 64 + lane;
-                    xa[q] = (a < n_cols) ? x[a] : (XT)0;
-                    xb[q] = (lane < xw_run - 64 && b < n_cols) ? x[b] : (XT)0;
-                }
-#pragma unroll
-                for (int q = 0; q < kXwRuns; ++q) {
-                    xs[q * xw_run + lane] = xa[q];
-                    if (lane < xw_run - 64) xs[q * xw_run + 64 + lane] = xb[q];
-                }
+            for (int q = 0; q < kXwRuns; ++q) {
+                const int a = st[q] + lane, b = st[q] + 64 + lane;
+                xa[q] = (a < n_cols) ? x[a] : (XT)0;
+                xb[q] = (lane < xw_run - 64 && b < n_cols) ? x[b] : (XT)0;
             }
-        }
-        // windowed tiles read PAIRS of consecutive non-zeros per lane (one 16-byte load of two values, one 4-byte
-        // load of two 16-bit indices): the chunk then starts on an even element, the stray element in front of k0
-        // or behind k1 is multiplied like the others but never summed
-        for (int base = windowed ? (k0 & ~1) : k0; base < k1; base += kWaveChunk) {
-            int c[kEpl];
-            VT v[kEpl];
-            if (windowed) {
-                struct alignas(2 * sizeof(VT)) V2 { VT a, b; };
-                const int top = kXwRuns * xw_run - 1;
-                unsigned int c2[kEpl / 2];
-                V2 v2[kEpl / 2];
+            // PAIRS of consecutive non-zeros per lane (one 16-byte load of two values, one 4-byte load of two 16-bit
+            // indices): the pass then starts on an even element, the stray element in front of k0 or behind k1 is
+            // multiplied like the others but never summed
+            struct alignas(2 * sizeof(VT)) V2 { VT a, b; };
+            const int top = kXwRuns * xw_run - 1;
+            unsigned int c2[kEpl / 2];
+            V2 v2[kEpl / 2];
+#define PADNE_LOAD_PAIRS(BASE)                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < kEpl / 2; ++j) {                                                         \
+        const int e = (BASE) + 2 * lane + 128 * j;                                                                 \
+        c2[j] = 0u;                                                                                                \
+        v2[j].a = 0;                                                                                               \
+        v2[j].b = 0;                                                                                               \
+        if (e < k1) { /* both arrays are padded: e + 1 == k1 is a legal address */                                 \
+            c2[j] = *reinterpret_cast<const unsigned int *>(xw_lidx + e);                                          \
+            v2[j] = *reinterpret_cast<const V2 *>(vals + e);                                                       \
+        }                                                                                                          \
+    }
+            // (issuing the first pass of non-zeros ahead of these LDS stores, or fetching the next tile's header one
+            // tile early, gains nothing: the kernel is not bound by the dependent latencies of one tile)
+            int base = k0 & ~1;
 #pragma unroll
-                for (int j = 0; j < kEpl / 2; ++j) {
-                    const int e = base + 2 * lane + 128 * j;
-                    c2[j] = 0u;
-                    v2[j].a = 0;
-                    v2[j].b = 0;
-                    if (e < k1) {                       // both arrays are padded: e + 1 == k1 is a legal address
-                        c2[j] = *reinterpret_cast<const unsigned int *>(xw_lidx + e);
-                        v2[j] = *reinterpret_cast<const V2 *>(vals + e);
-                    }
-                }
+            for (int q = 0; q < kXwRuns; ++q) {
+                xs[q * xw_run + lane] = xa[q];
+                if (lane < xw_run - 64) xs[q * xw_run + 64 + lane] = xb[q];
+            }
+            PADNE_LOAD_PAIRS(base)
+            for (;;) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the staged runs are in LDS
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -176,7 +176,22 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
                     prod[2 * lane + 128 * j] = (XT)v2[j].a * xs[i0];
                     prod[2 * lane + 128 * j + 1] = (XT)v2[j].b * xs[i1];
                 }
-            } else {
+                // same-wave LDS traffic is processed in issue order; keep the compiler from reordering
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                const int lo = max(rs, base), hi = min(re, base + kWaveChunk);
+                for (int k = lo; k < hi; ++k) acc += prod[k - base];
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                base += kWaveChunk;
+                if (base >= k1) break;
+                PADNE_LOAD_PAIRS(base)
+            }
+#undef PADNE_LOAD_PAIRS
+        } else {
+            for (int base = k0; base < k1; base += kWaveChunk) {
+                int c[kEpl];
+                VT v[kEpl];
 #pragma unroll
                 for (int j = 0; j < kEpl; ++j) {
                     const int e = base + lane + 64 * j;
@@ -194,14 +209,13 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
                     if (e < k1) xv = x[c[j]];
                     prod[lane + 64 * j] = (XT)v[j] * xv;
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                const int lo = max(rs, base), hi = min(re, base + kWaveChunk);
+                for (int k = lo; k < hi; ++k) acc += prod[k - base];
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
             }
-            // same-wave LDS traffic is processed in issue order; keep the compiler from reordering
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            const int lo = max(rs, base), hi = min(re, base + kWaveChunk);
-            for (int k = lo; k < hi; ++k) acc += prod[k - base];
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
         }
         if (r < row1) {
             if (MODE == SPMV_PLAIN) {

@@ -1,0 +1,9 @@
+#!/bin/bash
+# default bench under several environment variants (no profiler)
+cd $GRAFT_REPO_ROOT
+i=0
+for v in "$@"; do
+  i=$((i+1))
+  ( export $v; timeout -k 10 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bv_$i.log 2>&1 ) || exit 1
+  echo "variant $i: $v"; grep '^{' gpurun_out/bv_$i.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], {k:v for k,v in d['config'].items() if k in ('iterations','levels','setup_ms_per_step','solve_ms_per_step','operator_complexity')})"
+done
