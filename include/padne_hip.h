@@ -59,6 +59,10 @@ void       *padne_ctx_stream(padne_ctx *ctx);
 int padne_comm_unique_id(void *id128);
 int padne_ctx_comm_init(padne_ctx *ctx, const void *id128, int rank, int world_size);
 int padne_ctx_comm_rank(padne_ctx *ctx, int *rank, int *world_size);
+/* collectives this process has issued since the library was loaded: calls[0..2] / bytes[0..2] = all-reduce (f64
+ * scalars), all-gather of f64 values, all-gather of f32 values; bytes are this rank's contributions.  Bookkeeping for
+ * DESIGN.md section 6 (how many launches a multi-GPU solve costs), also counted for the in-process team. */
+int padne_comm_call_counts(long long calls[3], long long bytes[3]);
 /* In-process team: several contexts of ONE process on ONE GPU act as ranks (one host thread per context drives
  * its solve); all-reduce / all-gather go through host barriers and peer copies instead of RCCL, which refuses two
  * ranks on one device.  For rehearsing the row-partitioned solver on a single-GPU box (tests); sums are formed in

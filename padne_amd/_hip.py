@@ -63,6 +63,7 @@ SIGNATURES = {
     "padne_comm_unique_id": (C.c_int, [_P]),
     "padne_ctx_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "padne_ctx_comm_rank": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "padne_comm_call_counts": (C.c_int, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "padne_team_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
     "padne_team_destroy": (C.c_int, [_P]),
     "padne_ctx_join_team": (C.c_int, [_P, _P, C.c_int]),
@@ -216,6 +217,13 @@ class Context:
     def comm_init(self, unique_id: bytes, rank: int, world_size: int):
         buf = C.create_string_buffer(bytes(unique_id), 128)
         _check(self._lib.padne_ctx_comm_init(self._h, buf, int(rank), int(world_size)))
+
+    def comm_call_counts(self):
+        """(calls, bytes) of the collectives issued so far: all-reduce, all-gather f64, all-gather f32."""
+        calls = (C.c_longlong * 3)()
+        nbytes = (C.c_longlong * 3)()
+        _check(self._lib.padne_comm_call_counts(calls, nbytes))
+        return list(calls), list(nbytes)
 
     def set_halo(self, n_owned: int, m: int, export_idx) -> None:
         e = _i32(export_idx)

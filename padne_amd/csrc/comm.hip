@@ -4,6 +4,7 @@
 // single-process).
 #include "common.hpp"
 
+#include <atomic>
 #include <condition_variable>
 #include <dlfcn.h>
 #include <mutex>
@@ -29,6 +30,10 @@ struct Rccl {
 };
 
 static Rccl g_rccl;
+
+// collectives issued by this process since load (all-reduce, all-gather f64, all-gather f32) and the bytes this rank
+// contributed: what a multi-GPU solve costs in launches is counted, not estimated (padne_comm_call_counts)
+static std::atomic<long long> g_calls[3], g_bytes[3];
 
 static int load_rccl() {
     if (g_rccl.lib) return PADNE_OK;
@@ -139,6 +144,10 @@ static int team_allgather(padne_ctx *ctx, const void *send_v, void *recv_v, size
 }
 
 int comm_allreduce_sum_f64(padne_ctx *ctx, double *dev_buf, int count) {
+    if (ctx->team != nullptr || ctx->comm != nullptr) {
+        ++g_calls[0];
+        g_bytes[0] += 8LL * count;
+    }
     if (ctx->team != nullptr) return team_allreduce(ctx, dev_buf, count);
     if (ctx->comm == nullptr) return PADNE_OK;
     return check_nccl(g_rccl.AllReduce(dev_buf, dev_buf, (size_t)count, ncclFloat64, ncclSum, (ncclComm_t)ctx->comm,
@@ -147,6 +156,10 @@ int comm_allreduce_sum_f64(padne_ctx *ctx, double *dev_buf, int count) {
 
 int comm_allgather_f64(padne_ctx *ctx, const double *send, double *recv, int count_per_rank) {
     if (count_per_rank == 0) return PADNE_OK;
+    if (ctx->team != nullptr || ctx->comm != nullptr) {
+        ++g_calls[1];
+        g_bytes[1] += 8LL * count_per_rank;
+    }
     if (ctx->team != nullptr) return team_allgather(ctx, send, recv, sizeof(double) * (size_t)count_per_rank);
     if (ctx->comm == nullptr) return PADNE_OK;
     return check_nccl(g_rccl.AllGather(send, recv, (size_t)count_per_rank, ncclFloat64, (ncclComm_t)ctx->comm,
@@ -155,6 +168,10 @@ int comm_allgather_f64(padne_ctx *ctx, const double *send, double *recv, int cou
 
 int comm_allgather_f32(padne_ctx *ctx, const float *send, float *recv, int count_per_rank) {
     if (count_per_rank == 0) return PADNE_OK;
+    if (ctx->team != nullptr || ctx->comm != nullptr) {
+        ++g_calls[2];
+        g_bytes[2] += 4LL * count_per_rank;
+    }
     if (ctx->team != nullptr) return team_allgather(ctx, send, recv, sizeof(float) * (size_t)count_per_rank);
     if (ctx->comm == nullptr) return PADNE_OK;
     return check_nccl(g_rccl.AllGather(send, recv, (size_t)count_per_rank, ncclFloat32, (ncclComm_t)ctx->comm,
@@ -193,6 +210,15 @@ extern "C" int padne_ctx_comm_init(padne_ctx *ctx, const void *id128, int rank, 
     ctx->comm = comm;
     ctx->rank = rank;
     ctx->world = world_size;
+    return PADNE_OK;
+}
+
+extern "C" int padne_comm_call_counts(long long calls[3], long long bytes[3]) {
+    PADNE_REQUIRE(calls && bytes, "null argument");
+    for (int k = 0; k < 3; ++k) {
+        calls[k] = g_calls[k].load();
+        bytes[k] = g_bytes[k].load();
+    }
     return PADNE_OK;
 }
 

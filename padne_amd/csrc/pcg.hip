@@ -921,10 +921,10 @@ int estimate_lambda_max(padne_ctx *ctx, const padne_csr *a, int steps, double *l
     // once at the end instead of synchronising 12 times per level
     PADNE_REQUIRE(steps >= 1 && steps <= 60, "Lanczos steps");
     Scratch sc(ctx);
-    double *hist = nullptr;                 // rz[0..steps] | pq[0..steps) | rr (scratch)
-    PADNE_TRY(sc.alloc(&hist, (size_t)2 * steps + 4));
-    double *H_rz = hist, *H_pq = hist + steps + 1, *s_rr = hist + 2 * steps + 2;
-    PADNE_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(double) * ((size_t)2 * steps + 4), s));
+    double *hist = nullptr;                 // (rz, rr)[0..steps] interleaved | pq[0..steps)
+    PADNE_TRY(sc.alloc(&hist, (size_t)3 * steps + 4));
+    double *H_rz = hist, *H_pq = hist + 2 * steps + 2;      // rz of step k at H_rz[2 k], its r.r right behind it
+    PADNE_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(double) * ((size_t)3 * steps + 4), s));
     PADNE_HIP_CHECK(hipMemsetAsync(st, 0, sizeof(PcgStatus), s));
     PADNE_HIP_CHECK(hipMemsetAsync(x, 0, sizeof(double) * (size_t)n, s));
     if (nc > n) PADNE_HIP_CHECK(hipMemsetAsync(p + n, 0, sizeof(double) * (size_t)(nc - n), s));
@@ -948,29 +948,29 @@ int estimate_lambda_max(padne_ctx *ctx, const padne_csr *a, int steps, double *l
         PADNE_TRY(fold(slot(ctx, SLOT_PQ), gs, H_pq + k));
         if (dist) PADNE_TRY(comm_allreduce_sum_f64(ctx, H_pq + k, 1));
         // consumers read per-workgroup partials on one GPU and the reduced scalars across ranks
-        const double *rz_old = dist ? H_rz + k : rz_old_part, *pq = dist ? H_pq + k : slot(ctx, SLOT_PQ);
+        const double *rz_old = dist ? H_rz + 2 * k : rz_old_part, *pq = dist ? H_pq + k : slot(ctx, SLOT_PQ);
         const int Pz = dist ? 1 : gv, Pq = dist ? 1 : gs;
         hipLaunchKernelGGL(pcg_update_xr_kernel, dim3(gv), dim3(256), 0, s, n, rz_old, Pz, pq, Pq, p, q, a->dinv, x, r,
                            rz_new_part, slot(ctx, SLOT_RR), st);
         PADNE_HIP_CHECK(hipGetLastError());
-        PADNE_TRY(fold(rz_new_part, gv, H_rz + k + 1));
+        PADNE_TRY(fold(rz_new_part, gv, H_rz + 2 * (k + 1)));
         if (dist) {
-            PADNE_TRY(fold(slot(ctx, SLOT_RR), gv, s_rr));
-            PADNE_TRY(comm_allreduce_sum_f64(ctx, H_rz + k + 1, 1));
-            PADNE_TRY(comm_allreduce_sum_f64(ctx, s_rr, 1));
+            // r.z and r.r of the step travel in ONE all-reduce (two per Lanczos step in all, three before)
+            PADNE_TRY(fold(slot(ctx, SLOT_RR), gv, H_rz + 2 * (k + 1) + 1));
+            PADNE_TRY(comm_allreduce_sum_f64(ctx, H_rz + 2 * (k + 1), 2));
         }
-        const double *rz_new = dist ? H_rz + k + 1 : rz_new_part, *rr = dist ? s_rr : slot(ctx, SLOT_RR);
+        const double *rz_new = dist ? H_rz + 2 * (k + 1) : rz_new_part, *rr = dist ? H_rz + 2 * (k + 1) + 1 : slot(ctx, SLOT_RR);
         hipLaunchKernelGGL(pcg_update_p_kernel, dim3(gv), dim3(256), 0, s, n, rz_new, rz_old, Pz, rr, Pz, pq, Pq, r,
                            a->dinv, p, st, 1 << 30);
         PADNE_HIP_CHECK(hipGetLastError());
         parity ^= 1;
     }
-    std::vector<double> hh((size_t)2 * steps + 4);
+    std::vector<double> hh((size_t)3 * steps + 4);
     PADNE_HIP_CHECK(hipMemcpyAsync(hh.data(), hist, sizeof(double) * hh.size(), hipMemcpyDeviceToHost, s));
     PADNE_HIP_CHECK(hipStreamSynchronize(s));
     std::vector<double> alpha, beta;
     for (int k = 0; k < steps; ++k) {
-        const double pqv = hh[(size_t)steps + 1 + k], rzo = hh[(size_t)k], rzn = hh[(size_t)k + 1];
+        const double pqv = hh[(size_t)2 * steps + 2 + k], rzo = hh[(size_t)2 * k], rzn = hh[(size_t)2 * k + 2];
         if (!(pqv > 0.0) || !(rzo > 0.0)) break;      // also stops at the first NaN after a breakdown
         alpha.push_back(rzo / pqv);
         beta.push_back(rzn / rzo);
