@@ -65,7 +65,7 @@ struct padne_csr {
     float *vals32 = nullptr, *dinv32 = nullptr;   // single-precision copies for the multigrid cycle (csr_build_f32)
     // x-window plan of the SpMV (csr_build_xw_plan): per 64-row tile up to three runs of x that cover all its columns
     int4 *xw_desc = nullptr;             // [n_tiles] run starts in .x .y .z, .w = 1 if the tile qualifies
-    unsigned short *xw_lidx = nullptr;   // [nnz + pad] position of every column inside its tile's staged runs
+    unsigned short *xw_lidx = nullptr;   // [nnz + pad] position of every column inside its tile's staged runs (bytes when xw_run == 72)
     int xw_state = 0;                    // 0 = not examined, 1 = in use, -1 = examined and not worth it
     int xw_run = 0;                      // entries per staged run (72 for scan-line meshes, 128 for strip-ordered ones)
     bool hierarchy_operator = false;   // multigrid-internal operator: may use the wave-per-row SpMV

@@ -65,6 +65,55 @@ constexpr int kXwRunLong = 128;         // or twice the tile for strip-ordered u
 constexpr int kEpl = 8;                 // elements per lane per pass
 constexpr int kWaveChunk = 64 * kEpl;   // non-zeros parked in LDS per wave per pass (4 KiB)
 
+// The streaming part of a windowed tile: G consecutive non-zeros per lane and load (one 4-byte word of G positions --
+// 16-bit ones in pairs, 8-bit ones in fours -- and one or two 16-byte loads of G values), products parked in the
+// wave's LDS slice, one lane per row summing its segment in CSR order.  A pass starts on a multiple of G; the stray
+// elements in front of k0 or behind k1 are multiplied like the others but never summed (both arrays are padded).
+template <int G, typename IT, typename VT, typename XT>
+__device__ __forceinline__ XT xw_stream_tile(const VT *__restrict__ vals, const IT *__restrict__ lidx, const XT *xs, XT *prod,
+                                             const int k0, const int k1, const int rs, const int re, const int lane,
+                                             const int top) {
+    static_assert(G * sizeof(IT) == 4, "one index word per lane and load");
+    constexpr int NJ = kEpl / G;
+    struct alignas(G * sizeof(VT) < 16 ? G * sizeof(VT) : 16) VG { VT v[G]; };
+    unsigned int cw[NJ];
+    VG vg[NJ];
+    XT acc = 0;
+    for (int base = k0 & ~(G - 1);;) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int e = base + G * lane + 64 * G * j;
+            cw[j] = 0u;
+#pragma unroll
+            for (int t = 0; t < G; ++t) vg[j].v[t] = 0;
+            if (e < k1) {
+                cw[j] = *reinterpret_cast<const unsigned int *>(lidx + e);
+                vg[j] = *reinterpret_cast<const VG *>(vals + e);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the staged runs are in LDS
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+            for (int t = 0; t < G; ++t) {
+                const int pos = min((int)((cw[j] >> (8 * sizeof(IT) * t)) & ((1u << (8 * sizeof(IT))) - 1u)), top);
+                prod[G * lane + 64 * G * j + t] = (XT)vg[j].v[t] * xs[pos];
+            }
+        }
+        // same-wave LDS traffic is processed in issue order; keep the compiler from reordering
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const int lo = max(rs, base), hi = min(re, base + kWaveChunk);
+        for (int k = lo; k < hi; ++k) acc += prod[k - base];
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        base += kWaveChunk;
+        if (base >= k1) break;
+    }
+    return acc;
+}
+
 // Epilogues (acc = (A x)[row]):
 //   SPMV_PLAIN   y = acc
 //   SPMV_DOT     y = acc ; partial sums of dot_with[row] * acc
@@ -86,7 +135,7 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
     const double *__restrict__ dot_with, double *__restrict__ partials,
     const int *__restrict__ done_flag, const XT *__restrict__ aux1,
     const XT *__restrict__ aux2, const XT scale, const double *__restrict__ out_scale2,
-    const int4 *__restrict__ xw_desc, const unsigned short *__restrict__ xw_lidx, const int xw_run) {
+    const int4 *__restrict__ xw_desc, const void *__restrict__ xw_lidx, const int xw_run) {
     constexpr bool WITH_DOT = (MODE == SPMV_DOT) || (MODE == SPMV_DOT_AUX) || (MODE == SPMV_JACOBI);
     __shared__ XT prod_all[4 * kWaveChunk];
     extern __shared__ unsigned char xs_dyn[];      // 4 * kXwRuns * xw_run entries of XT when the plan is in use
@@ -140,54 +189,19 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
                 xa[q] = (a < n_cols) ? x[a] : (XT)0;
                 xb[q] = (lane < xw_run - 64 && b < n_cols) ? x[b] : (XT)0;
             }
-            // PAIRS of consecutive non-zeros per lane (one 16-byte load of two values, one 4-byte load of two 16-bit
-            // indices): the pass then starts on an even element, the stray element in front of k0 or behind k1 is
-            // multiplied like the others but never summed
-            struct alignas(2 * sizeof(VT)) V2 { VT a, b; };
-            const int top = kXwRuns * xw_run - 1;
-            unsigned int c2[kEpl / 2];
-            V2 v2[kEpl / 2];
-#define PADNE_LOAD_PAIRS(BASE)                                                                                      \
-    _Pragma("unroll") for (int j = 0; j < kEpl / 2; ++j) {                                                         \
-        const int e = (BASE) + 2 * lane + 128 * j;                                                                 \
-        c2[j] = 0u;                                                                                                \
-        v2[j].a = 0;                                                                                               \
-        v2[j].b = 0;                                                                                               \
-        if (e < k1) { /* both arrays are padded: e + 1 == k1 is a legal address */                                 \
-            c2[j] = *reinterpret_cast<const unsigned int *>(xw_lidx + e);                                          \
-            v2[j] = *reinterpret_cast<const V2 *>(vals + e);                                                       \
-        }                                                                                                          \
-    }
             // (issuing the first pass of non-zeros ahead of these LDS stores, or fetching the next tile's header one
             // tile early, gains nothing: the kernel is not bound by the dependent latencies of one tile)
-            int base = k0 & ~1;
 #pragma unroll
             for (int q = 0; q < kXwRuns; ++q) {
                 xs[q * xw_run + lane] = xa[q];
                 if (lane < xw_run - 64) xs[q * xw_run + 64 + lane] = xb[q];
             }
-            PADNE_LOAD_PAIRS(base)
-            for (;;) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the staged runs are in LDS
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int j = 0; j < kEpl / 2; ++j) {
-                    const int i0 = min((int)(c2[j] & 0xffffu), top), i1 = min((int)(c2[j] >> 16), top);
-                    prod[2 * lane + 128 * j] = (XT)v2[j].a * xs[i0];
-                    prod[2 * lane + 128 * j + 1] = (XT)v2[j].b * xs[i1];
-                }
-                // same-wave LDS traffic is processed in issue order; keep the compiler from reordering
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                const int lo = max(rs, base), hi = min(re, base + kWaveChunk);
-                for (int k = lo; k < hi; ++k) acc += prod[k - base];
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                base += kWaveChunk;
-                if (base >= k1) break;
-                PADNE_LOAD_PAIRS(base)
-            }
-#undef PADNE_LOAD_PAIRS
+            const int top = kXwRuns * xw_run - 1;
+            // three runs of 72 are 216 positions: one byte each, four non-zeros per lane and load; runs of 128 need 16 bits
+            if (xw_run <= kXwRunShort)
+                acc = xw_stream_tile<4, unsigned char, VT, XT>(vals, (const unsigned char *)xw_lidx, xs, prod, k0, k1, rs, re, lane, top);
+            else
+                acc = xw_stream_tile<2, unsigned short, VT, XT>(vals, (const unsigned short *)xw_lidx, xs, prod, k0, k1, rs, re, lane, top);
         } else {
             for (int base = k0; base < k1; base += kWaveChunk) {
                 int c[kEpl];
@@ -349,7 +363,7 @@ static int launch_spmv_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals,
     }
     const size_t xs_bytes = m->xw_state == 1 ? sizeof(XT) * 4 * kXwRuns * (size_t)m->xw_run : 0;
     const int4 *xw_desc = m->xw_state == 1 ? m->xw_desc : nullptr;
-    const unsigned short *xw_lidx = m->xw_state == 1 ? m->xw_lidx : nullptr;
+    const void *xw_lidx = m->xw_state == 1 ? (const void *)m->xw_lidx : nullptr;
 #define PADNE_SPMV_LAUNCH(M)                                                                                     \
     hipLaunchKernelGGL((csr_spmv_kernel<M, VT, XT, YT>), dim3(g), dim3(kSpmvThreads), xs_bytes, ctx->stream,      \
                        (int)m->n_rows, (int)m->n_cols, n_tiles, m->rowptr, m->cols, vals, x, y, dot_with,         \
@@ -397,9 +411,10 @@ int launch_spmv_f32_exit(padne_ctx *ctx, const padne_csr *m, const float *x, dou
 // One wave per 64-row tile: greedy cover of the tile's columns by runs of kXwRun entries starting at the smallest
 // uncovered column; at most kXwRuns runs or the tile keeps the gather path.  A qualifying tile gets, for every
 // non-zero, the 16-bit position of its column inside the staged runs.
+template <typename IT>      // unsigned char for runs of 72 (216 positions), unsigned short for runs of 128
 __global__ __launch_bounds__(256) void xw_plan_kernel(int n_rows, int n_wtiles, int run, const int *__restrict__ rowptr,
                                                       const int *__restrict__ cols, int4 *__restrict__ desc,
-                                                      unsigned short *__restrict__ lidx, int *__restrict__ n_ok) {
+                                                      IT *__restrict__ lidx, int *__restrict__ n_ok) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long long W = (long long)gridDim.x * 4, gw = (long long)blockIdx.x * 4 + w;
     int ok_count = 0;
@@ -433,7 +448,7 @@ __global__ __launch_bounds__(256) void xw_plan_kernel(int n_rows, int n_wtiles, 
 #pragma unroll
                 for (int q = kXwRuns - 1; q >= 0; --q)
                     if (c >= start[q] && c < start[q] + run) pos = q * run + (c - start[q]);
-                lidx[e] = (unsigned short)pos;
+                lidx[e] = (IT)pos;
             }
             ++ok_count;
         }
@@ -466,8 +481,13 @@ int csr_build_xw_plan(padne_ctx *ctx, padne_csr *m) {
         run = attempt == 0 ? kXwRunShort : kXwRunLong;
         e = hipMemsetAsync(d_ok, 0, sizeof(int), ctx->stream);
         if (e != hipSuccess) break;
-        hipLaunchKernelGGL(xw_plan_kernel, dim3(g), dim3(256), 0, ctx->stream, (int)m->n_rows, n_tiles, run, m->rowptr,
-                           m->cols, desc, lidx, d_ok);
+        static_assert(kXwRuns * kXwRunShort <= 256, "8-bit positions");
+        if (run == kXwRunShort)
+            hipLaunchKernelGGL(xw_plan_kernel<unsigned char>, dim3(g), dim3(256), 0, ctx->stream, (int)m->n_rows, n_tiles, run,
+                               m->rowptr, m->cols, desc, (unsigned char *)lidx, d_ok);
+        else
+            hipLaunchKernelGGL(xw_plan_kernel<unsigned short>, dim3(g), dim3(256), 0, ctx->stream, (int)m->n_rows, n_tiles, run,
+                               m->rowptr, m->cols, desc, lidx, d_ok);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(&h_ok, d_ok, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
