@@ -1,0 +1,13 @@
+#!/bin/bash
+# The round's measurement suite on one MI355X; everything lands in gpurun_out/final/ (copy what is judged into profiles/)
+O=gpurun_out/final; mkdir -p $O; cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+timeout -k 10 600 python bench.py > $O/bench_default.log 2>&1 || exit 1
+grep '^{' $O/bench_default.log > $O/bench_c4_1gpu_amg.json; echo bench done
+( cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats -o run -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/stats.log 2>&1 ) || exit 2
+echo stats done
+timeout -k 10 600 bash scripts/pmc_bench.sh $O/pmc > $O/pmc.log 2>&1 || exit 3
+echo pmc done
+timeout -k 10 600 python scripts/run_configs.py > $O/configs.log 2>&1 || exit 4
+cp gpurun_out/r01_configs.json $O/ ; echo configs done
+timeout -k 10 300 python bench.py --precond jacobi --steps 1 --warmup 0 --no-cpu-baseline > $O/bench_jacobi.log 2>&1 || exit 5
+grep '^{' $O/bench_jacobi.log > $O/bench_c4_1gpu_jacobi.json; echo jacobi done
