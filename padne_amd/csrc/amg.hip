@@ -85,6 +85,7 @@ static int coarse_n_limit() {   // coarsest-level size below which the dense inv
 constexpr int kMaxLevels = 16;
 static double cheb_ratio() { const char *e = getenv("PADNE_AMG_CHEB_RATIO"); return e ? atof(e) : 10.0; }
 #define kChebRatio cheb_ratio()
+static int lanczos_steps() { const char *e = getenv("PADNE_AMG_LANCZOS_STEPS"); const int v = e ? atoi(e) : 12; return v < 2 ? 2 : (v > 60 ? 60 : v); }
 static double omega_num() { const char *e = getenv("PADNE_AMG_OMEGA"); return e ? atof(e) : 1.5; }
 static thread_local int t_setup_level = 0;     // level whose operators are being built (strength threshold decays with it)
 static double theta_val() {
@@ -287,11 +288,13 @@ __global__ __launch_bounds__(256) void mis_collect_open(int n, const signed char
     }
 }
 
-__global__ void mis_two_hop_max(int cnt, const int *__restrict__ list, const int *__restrict__ srow,
+// (the list length is read on the device: several rounds are enqueued per host synchronisation, on a grid sized by the
+// last length the host has seen; lists only shrink)
+__global__ void mis_two_hop_max(const int *__restrict__ cnt_ptr, const int *__restrict__ list, const int *__restrict__ srow,
                                 const int *__restrict__ scol, const unsigned int *__restrict__ word,
                                 unsigned int *__restrict__ m2) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= cnt) return;
+    if (t >= *cnt_ptr) return;
     const int i = list[t];
     unsigned int m = word[i];
     for (int a = srow[i]; a < srow[i + 1]; ++a) {
@@ -307,13 +310,13 @@ __global__ void mis_two_hop_max(int cnt, const int *__restrict__ list, const int
     m2[t] = m;
 }
 
-__global__ void mis_decide_list(int cnt, const int *__restrict__ list, const unsigned int *__restrict__ m2,
+__global__ void mis_decide_list(const int *__restrict__ cnt_ptr, const int *__restrict__ list, const unsigned int *__restrict__ m2,
                                 unsigned int *__restrict__ word, signed char *__restrict__ state,
                                 int *__restrict__ list_next, int *__restrict__ count_next) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     bool open = false;
     int i = 0;
-    if (t < cnt) {
+    if (t < *cnt_ptr) {
         i = list[t];
         open = mis_decide_one(i, m2[t], word, state);
     }
@@ -1212,11 +1215,17 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
     int round = 0;
     // the compact rounds pay off on sparse rows only: a direct two-hop maximum visits (nnz/row)^2 words per vertex
     const bool compact_ok = A->nnz <= 16LL * n;
-    for (; round < 256 && open_count > 0 && (!compact_ok || round < 2 || open_count > n / 8); ++round) {
-        hipLaunchKernelGGL(nbr_max<unsigned int>, gm, b, 0, s, n, n_wt, srow, scol, w0, w1);
-        hipLaunchKernelGGL(nbr_max<unsigned int>, gm, b, 0, s, n, n_wt, srow, scol, w1, w2);
-        PADNE_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(int), s));
-        hipLaunchKernelGGL(mis_decide, dim3(std::min<unsigned>(g.x, 1024u)), b, 0, s, n, w0, w2, state, counter);
+    // Rounds are enqueued in batches between two reads of the open count (a host synchronisation costs ~30 us, as
+    // much as a round on a small level): one round per batch while a pass over the level is expensive, four on the
+    // small levels, where a superfluous round after the last vertex was decided is cheaper than the wait.
+    const int full_batch = n > 200000 ? 1 : 4;
+    while (round < 256 && open_count > 0 && (!compact_ok || round < 2 || open_count > n / 8)) {
+        for (int rep = 0; rep < full_batch; ++rep, ++round) {
+            hipLaunchKernelGGL(nbr_max<unsigned int>, gm, b, 0, s, n, n_wt, srow, scol, w0, w1);
+            hipLaunchKernelGGL(nbr_max<unsigned int>, gm, b, 0, s, n, n_wt, srow, scol, w1, w2);
+            PADNE_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(int), s));
+            hipLaunchKernelGGL(mis_decide, dim3(std::min<unsigned>(g.x, 1024u)), b, 0, s, n, w0, w2, state, counter);
+        }
         PADNE_HIP_CHECK(hipGetLastError());
         PADNE_HIP_CHECK(hipMemcpyAsync(&open_count, counter, sizeof(int), hipMemcpyDeviceToHost, s));
         PADNE_HIP_CHECK(hipStreamSynchronize(s));
@@ -1232,16 +1241,20 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
         PADNE_HIP_CHECK(hipMemsetAsync(counters, 0, 2 * sizeof(int), s));
         hipLaunchKernelGGL(mis_collect_open, dim3(std::min<unsigned>(g.x, 1024u)), b, 0, s, n, state, list_a, counters);
         PADNE_HIP_CHECK(hipGetLastError());
-        int cnt = open_count;
-        for (; round < 256 && cnt > 0; ++round) {
+        int cnt = open_count, cur = 0;       // counters[cur]: length of list_a, on the device
+        while (round < 256 && cnt > 0) {
             const dim3 gl(nblk(cnt));
-            hipLaunchKernelGGL(mis_two_hop_max, gl, b, 0, s, cnt, list_a, srow, scol, w0, m2);
-            PADNE_HIP_CHECK(hipMemsetAsync(counters + 1, 0, sizeof(int), s));
-            hipLaunchKernelGGL(mis_decide_list, gl, b, 0, s, cnt, list_a, m2, w0, state, list_b, counters + 1);
+            const int batch = cnt > 200000 ? 1 : 3;
+            for (int rep = 0; rep < batch; ++rep, ++round) {
+                hipLaunchKernelGGL(mis_two_hop_max, gl, b, 0, s, counters + cur, list_a, srow, scol, w0, m2);
+                PADNE_HIP_CHECK(hipMemsetAsync(counters + (cur ^ 1), 0, sizeof(int), s));
+                hipLaunchKernelGGL(mis_decide_list, gl, b, 0, s, counters + cur, list_a, m2, w0, state, list_b, counters + (cur ^ 1));
+                std::swap(list_a, list_b);
+                cur ^= 1;
+            }
             PADNE_HIP_CHECK(hipGetLastError());
-            PADNE_HIP_CHECK(hipMemcpyAsync(&cnt, counters + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+            PADNE_HIP_CHECK(hipMemcpyAsync(&cnt, counters + cur, sizeof(int), hipMemcpyDeviceToHost, s));
             PADNE_HIP_CHECK(hipStreamSynchronize(s));
-            std::swap(list_a, list_b);
         }
         open_count = cnt;
     }
@@ -1629,7 +1642,7 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
             // largest Ritz value of 12 Lanczos steps (converges from below; 8 % margin keeps the sweep stable)
             double ritz = 0.0;
             PhaseTimer pl(ctx, amg_verbose());
-            if ((rc = estimate_lambda_max(ctx, A, 12, &ritz)) != PADNE_OK) break;
+            if ((rc = estimate_lambda_max(ctx, A, lanczos_steps(), &ritz)) != PADNE_OK) break;
             pl.lap("lanczos");
             const double est = 1.08 * ritz;
             if (est > 0.0 && est < L.lambda) L.lambda = est;
@@ -2108,7 +2121,7 @@ static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0) {
         const bool coarsest = lvl > 0 && (n_glob <= gather_n || lvl == kMaxLevels - 1);
         if (lvl > 0 && !coarsest && getenv("PADNE_AMG_NO_LANCZOS") == nullptr) {
             double ritz = 0.0;
-            if ((rc = estimate_lambda_max(ctx, A, 12, &ritz, &plan)) != PADNE_OK) break;
+            if ((rc = estimate_lambda_max(ctx, A, lanczos_steps(), &ritz, &plan)) != PADNE_OK) break;
             const double est = 1.08 * ritz;
             if (est > 0.0 && est < Lr.lambda) Lr.lambda = est;
         }
