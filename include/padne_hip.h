@@ -36,6 +36,7 @@ extern "C" {
 #define PADNE_E_NOTCONVERGED -5 /* PCG hit max_iter (solution still returned) */
 #define PADNE_E_COMM       -6   /* RCCL not available / communicator failure */
 #define PADNE_E_BREAKDOWN  -7   /* PCG breakdown: matrix not SPD (p.Ap <= 0) or NaN */
+#define PADNE_E_TOOLARGE   -8   /* a count exceeds the 32-bit index space of the CSR structures (nnz, slot offsets) */
 
 typedef struct padne_ctx padne_ctx;   /* device, stream, workspaces, optional RCCL communicator */
 typedef struct padne_csr padne_csr;   /* device-resident CSR matrix (f64 values, i32 indices)  */

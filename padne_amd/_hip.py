@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpadne_hip.so")
 
 OK = 0
-E_INVALID, E_HIP, E_NOMEM, E_NONMANIFOLD, E_NOTCONVERGED, E_COMM, E_BREAKDOWN = -1, -2, -3, -4, -5, -6, -7
+E_INVALID, E_HIP, E_NOMEM, E_NONMANIFOLD, E_NOTCONVERGED, E_COMM, E_BREAKDOWN, E_TOOLARGE = -1, -2, -3, -4, -5, -6, -7, -8
 
 
 class HipUnavailableError(RuntimeError):
@@ -142,6 +142,8 @@ def _check(rc: int) -> None:
         raise ValueError(msg)
     if rc == E_NOMEM:
         raise MemoryError(msg)
+    if rc == E_TOOLARGE:
+        raise OverflowError(msg)
     if rc == E_NOTCONVERGED:
         raise NotConvergedError(rc, msg)
     raise HipError(rc, msg)

@@ -1422,7 +1422,32 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
     if (n > 0) hipLaunchKernelGGL(spgemm_count, dim3(nblk(n)), dim3(256), 0, s, n, X->rowptr, X->cols, Y->rowptr, cnt);
     PADNE_HIP_CHECK(hipGetLastError());
     int64_t n_slots = 0;
-    PADNE_TRY(exclusive_scan_i32(ctx, cnt, slot_ptr, n, &n_slots));
+    const int rc_scan = exclusive_scan_i32(ctx, cnt, slot_ptr, n, &n_slots);
+    // (PADNE_SPGEMM_SPLIT_SLOTS lowers the limit so that tests reach the split path on small systems)
+    const char *split_env = getenv("PADNE_SPGEMM_SPLIT_SLOTS");
+    const long long split_limit = split_env ? atoll(split_env) : 0;
+    if ((rc_scan == PADNE_E_TOOLARGE || (rc_scan == PADNE_OK && split_limit > 0 && n_slots > split_limit)) && n >= 2) {
+        // more product slots than 32-bit offsets address (A*P of a 130 M-row mesh Laplacian: 17 per row) although the
+        // product itself fits: multiply the two halves of the rows separately and stack the results.  A half is a
+        // view of X -- row pointers are absolute positions in cols / vals.
+        sc.release();
+        const int h = n / 2;
+        padne_csr top = *X, bottom = *X;
+        top.n_rows = h;
+        bottom.n_rows = n - h;
+        bottom.rowptr = X->rowptr + h;
+        top.nnz = bottom.nnz = 0;      // not used by the product kernels
+        top.amg = bottom.amg = nullptr;
+        if (amg_verbose()) fprintf(stderr, "[amg]   spgemm %lld rows: %lld product slots, split in two\n", (long long)n, (long long)n_slots);
+        padne_csr *Ct = nullptr, *Cb = nullptr;
+        int rc = spgemm(ctx, &top, Y, &Ct);
+        if (rc == PADNE_OK) rc = spgemm(ctx, &bottom, Y, &Cb);
+        if (rc == PADNE_OK) rc = csr_vstack(ctx, Ct, Cb, Y->n_cols, C);
+        if (Ct) padne_csr_destroy(Ct);
+        if (Cb) padne_csr_destroy(Cb);
+        return rc;
+    }
+    PADNE_TRY(rc_scan);
     if (amg_verbose()) fprintf(stderr, "[amg]   spgemm %lld rows, %lld product slots\n", (long long)n, (long long)n_slots);
     long long *key = nullptr;
     double *val = nullptr;

@@ -148,9 +148,15 @@ int exclusive_scan_i32(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t 
         set_error("scan failed: %s", hipGetErrorString(e));
         return PADNE_E_HIP;
     }
-    if (h[0] >= 2147483647LL || h[0] < 0 || h[1] != 0) {
-        set_error("scan total %lld overflows int32 indices", h[0]);
+    if (h[0] < 0 || h[1] != 0) {
+        set_error("scan of negative counts");
         return PADNE_E_INVALID;
+    }
+    if (h[0] >= 2147483647LL) {
+        // callers that can split their work (the sparse products of the multigrid setup) look at *total and do so
+        *total = h[0];
+        set_error("%lld entries exceed the 32-bit index space", h[0]);
+        return PADNE_E_TOOLARGE;
     }
     *total = h[0];
     return PADNE_OK;

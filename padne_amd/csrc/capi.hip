@@ -32,7 +32,7 @@ int ensure_workspace(padne_ctx *ctx, size_t bytes) {
     return PADNE_OK;
 }
 
-constexpr size_t kPoolCacheLimit = (size_t)96 << 30;   // bytes kept for reuse (the card has 288 GB)
+constexpr size_t kPoolCacheLimit = (size_t)240 << 30;  // bytes kept for reuse (the card has 288 GB; a failed hipMalloc releases them and retries)
 
 static size_t pool_round(size_t bytes) {
     if (bytes < 256) bytes = 256;

@@ -176,7 +176,11 @@ struct Scratch {   // device allocations returned to the pool on scope exit
     padne_ctx *ctx;
     std::vector<void *> ptrs;
     explicit Scratch(padne_ctx *c) : ctx(c) {}
-    ~Scratch() { for (void *p : ptrs) if (p) pool_free(ctx, p); }
+    ~Scratch() { release(); }
+    void release() {
+        for (void *p : ptrs) if (p) pool_free(ctx, p);
+        ptrs.clear();
+    }
     template <typename T> int alloc(T **out, size_t count) {
         void *p = pool_alloc(ctx, sizeof(T) * (count ? count : 1));
         if (p == nullptr) return PADNE_E_NOMEM;

@@ -331,6 +331,21 @@ def test_single_precision_cycle_is_independent_of_the_units_of_the_system(ctx):
         assert np.abs(res.x / scale - base.x).max() <= 1e-9 * np.abs(base.x).max()
 
 
+def test_sparse_products_of_the_setup_split_their_rows_when_the_slots_exceed_the_index_space(ctx, monkeypatch):
+    """A*P of a 130 M-row Laplacian has more product slots than 32-bit offsets address: the product is then formed in
+    row halves and stacked.  PADNE_SPGEMM_SPLIT_SLOTS lowers the limit so that a small system takes that path (several
+    levels of recursion); hierarchy and solution must not change."""
+    A, b, _, _, _ = layered_spd(2, 90, 80, 4)
+    base = ctx.csr_from_scipy(A).solve_spd(b, precond="amg")
+    monkeypatch.setenv("PADNE_SPGEMM_SPLIT_SLOTS", "30000")
+    d = ctx.csr_from_scipy(A)
+    res = d.solve_spd(b, precond="amg")
+    assert res.levels == base.levels and res.levels >= 2 and res.precond_fallbacks == 0
+    assert abs(res.operator_complexity - base.operator_complexity) <= 1e-12
+    assert abs(res.iterations - base.iterations) <= 1
+    assert np.abs(res.x - base.x).max() <= 1e-9 * np.abs(base.x).max()
+
+
 def test_multigrid_and_jacobi_agree_with_the_direct_solve(ctx):
     A, b, Lo, ro, n = layered_spd(4, 120, 100, 6)
     v_ref = O.solve_system(Lo, ro)[0]
