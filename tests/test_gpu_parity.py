@@ -861,6 +861,60 @@ def test_full_size_superposition_and_reciprocity(ctx, c3_system):
     assert abs(z21 - z12) <= 1e-9 * max(abs(z21), abs(v1[:nv]).max())
 
 
+def test_headline_config_at_full_size(ctx, monkeypatch):
+    """Config C4 of BASELINE.json itself (8 layers of 1118x1118, N = 10 M, the bench workload), through the
+    properties that need no direct solve: the windowed and the gather path of the product agree bit for bit, the
+    mesh rows annihilate constants, the solve reaches the requested residual, conserves the current through
+    every layer pair, puts the potential extremes at source and sink, and is linear in the right-hand side."""
+    sysm = synthetic.config("C4")
+    nv = sysm.n_vertices
+    N = nv + 1
+    xy, tri, mvo, mto, sig = flat(sysm.meshes)
+    a, b, rr = sysm.resistors
+    gg = 1 / rr
+    rows = np.stack([a, a, b, b], 1).reshape(-1)
+    cols = np.stack([a, b, b, a], 1).reshape(-1)
+    vals = np.stack([-gg, gg, -gg, gg], 1).reshape(-1)
+    Ld = ctx.assemble_system(N, xy, tri, mvo, mto, sig, rows, cols, vals)
+    del xy, tri
+    imap = np.arange(N, dtype=np.int32)
+    imap[sysm.ground] = -1
+    imap[imap > sysm.ground] -= 1
+    imap[N - 1] = -1
+    A = Ld.reduce(imap, nv - 1, -1.0)
+    n = A.shape[0]
+    rng = np.random.default_rng(11)
+    x = rng.uniform(-1, 1, n)
+    y_win = A.matvec(x)
+    # constants: every row of the Laplacian part sums to zero; with the ground column removed A 1 is the ground
+    # vertex's couplings, i.e. non-zero only in its handful of neighbours
+    ones = A.matvec(np.ones(n))
+    assert np.count_nonzero(np.abs(ones) > 1e-9 * np.abs(y_win).max()) <= 16
+    monkeypatch.setenv("PADNE_NO_XWINDOW", "1")
+    A_gather = Ld.reduce(imap, nv - 1, -1.0)
+    assert np.array_equal(A_gather.matvec(x), y_win)
+    A_gather.close()
+    monkeypatch.delenv("PADNE_NO_XWINDOW")
+    Ld.close()
+    keep = np.flatnonzero(imap[:nv] >= 0)
+    f, t = int(sysm.current_sources[0][0]), int(sysm.current_sources[1][0])
+    full = np.zeros(nv)
+    full[f] += 1.0
+    full[t] -= 1.0
+    res = A.solve_spd(-full[keep], rtol=1e-12, precond="amg")
+    assert res.status == _hip.OK and res.levels >= 4 and 10 < res.iterations < 60 and res.rel_residual <= 1.1e-12
+    v = np.zeros(nv)
+    v[keep] = res.x
+    n_per = nv // len(sysm.meshes)
+    for l in range(len(sysm.meshes) - 1):                    # the via rings carry exactly the injected 1 A
+        sel = (a // n_per == l) & (b // n_per == l + 1)
+        assert abs(np.sum((v[b[sel]] - v[a[sel]]) / rr[sel]) - 1.0) < 1e-7
+    assert int(np.argmax(v)) == t and int(np.argmin(v)) == f
+    res2 = A.solve_spd(-2.5 * full[keep], rtol=1e-12, precond="amg")
+    assert np.abs(res2.x - 2.5 * res.x).max() <= 1e-9 * np.abs(res2.x).max()
+    A.close()
+
+
 def test_locality_reordering_is_transparent(ctx):
     """A scattered vertex numbering is solved in Z-order internally; v comes back in the caller's numbering."""
     xy, tri = delaunay_mesh(20000, seed=3, hole=False)
