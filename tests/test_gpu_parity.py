@@ -915,6 +915,20 @@ def test_headline_config_at_full_size(ctx, monkeypatch):
     A.close()
 
 
+def test_randomised_systems_against_the_direct_solve(ctx):
+    """scripts/fuzz_parity.py: random multi-layer systems with vias, internal nodes, current sources, forests of
+    voltage sources and regulators, in the reference's KKT layout; the product path against the reference's direct
+    solve on the same matrix.  (The script runs hundreds of cases; a fixed dozen here.)"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_parity.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    worst_v, worst_i = fuzz.run(12, seed0=3, verbose=False)
+    assert worst_v <= REL_TOL and worst_i <= 1e-7
+
+
 def test_locality_reordering_is_transparent(ctx):
     """A scattered vertex numbering is solved in Z-order internally; v comes back in the caller's numbering."""
     xy, tri = delaunay_mesh(20000, seed=3, hole=False)
