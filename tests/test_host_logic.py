@@ -332,3 +332,32 @@ def test_reduction_run_plan_matches_the_plain_formulas():
     v2 = c.copy()
     v2[free] += y[red2.index_map[free]]
     assert np.array_equal(red2.expand(y), v2)
+
+
+def test_strip_order_equals_the_three_key_sort_it_replaces():
+    """_strip_order sorts one 64-bit key [mesh | strip | x] and repairs ties by index: the result is the permutation
+    of lexsort((x, strip, mesh)) with non-mesh unknowns behind the meshes in their old order -- also with equal x
+    coordinates, interleaved mesh ids and the fall-back branch for key fields that do not fit."""
+    rng = np.random.default_rng(4)
+    n = 20000
+    xy = rng.uniform(0, 50, (n, 2))
+    xy[500:1000, 0] = xy[1000:1500, 0]                       # equal x inside strips
+    xy[3000:3400] = xy[3400:3800]                            # coincident points
+    owner = np.concatenate([rng.permutation(n), -np.ones(7, dtype=np.int64)]).astype(np.int64)
+    has = owner >= 0
+    mesh_id = np.where(has, (owner >= n // 3).astype(np.int64) + (owner >= 2 * n // 3), 0)     # three meshes, interleaved
+    order = reduction._strip_order(n + 7, has, mesh_id, xy, owner)
+    strip = np.zeros(n + 7, dtype=np.int64)
+    strip[has] = reduction.strip_index(xy[owner[has]], mesh_id[has])
+    k_x = np.arange(n + 7, dtype=np.float64)
+    k_x[has] = xy[owner[has], 0]
+    want = np.lexsort((k_x, strip, np.where(has, mesh_id, 2 ** 40)))
+    same_key = (np.where(has, mesh_id, 2 ** 40)[order] == np.where(has, mesh_id, 2 ** 40)[want]).all() and \
+        (strip[order] == strip[want]).all()
+    assert same_key and np.array_equal(np.sort(order), np.arange(n + 7))
+    assert np.array_equal(order[-7:], np.arange(n, n + 7))                       # non-mesh unknowns: last, old order
+    # x is quantised to 32 bits inside each mesh: the order may differ from the exact sort only between points
+    # closer than that resolution, and never between equal keys (those are in index order)
+    assert np.abs(k_x[order][:-7] - k_x[want][:-7]).max() <= 50 / 2.0 ** 31
+    eq = (k_x[order][1:] == k_x[order][:-1]) & (strip[order][1:] == strip[order][:-1]) & (mesh_id[order][1:] == mesh_id[order][:-1])
+    assert (order[1:][eq] > order[:-1][eq]).all()
