@@ -177,9 +177,13 @@ __device__ __forceinline__ int find_segment(const long long *__restrict__ offs, 
     return lo;
 }
 
+// Vertex -> incident triangles, counted and listed in ONE pass: every vertex owns kIncCap list entries (a structured
+// grid has 6 triangles around a vertex, Delaunay meshes rarely more than 10); the counter keeps counting beyond that,
+// such a vertex takes the slot path.  The order inside a list is left to the atomics: nothing below depends on it.
+constexpr int kIncCap = 12;
 __global__ void asm_count_tri(long long n_tri, const int *__restrict__ tri, int n_mesh,
                               const long long *__restrict__ mesh_voff, const long long *__restrict__ mesh_toff,
-                              int *__restrict__ cnt, int *__restrict__ err) {
+                              int *__restrict__ cnt, int *__restrict__ inc, int *__restrict__ err) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tri) return;
     const int m = find_segment(mesh_toff, n_mesh, t);
@@ -190,9 +194,19 @@ __global__ void asm_count_tri(long long n_tri, const int *__restrict__ tri, int 
         atomicExch(&err[ERR_BAD_INDEX], 1);
         return;
     }
-    atomicAdd(&cnt[v0 + a], 2);
-    atomicAdd(&cnt[v0 + b], 2);
-    atomicAdd(&cnt[v0 + c], 2);
+    const long long g[3] = {v0 + a, v0 + b, v0 + c};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int pos = atomicAdd(&cnt[g[q]], 1);      // incident triangles per vertex; a row owns two slots per incidence
+        if (pos < kIncCap) inc[g[q] * kIncCap + pos] = (int)t;
+    }
+}
+
+// slots of a row: its diagonal placeholder, two per incident triangle, one per stamp
+__global__ void asm_slot_counts(long long n, const int *__restrict__ n_inc, const int *__restrict__ n_coo,
+                                int *__restrict__ cnt) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) cnt[r] = 1 + 2 * n_inc[r] + n_coo[r];
 }
 
 __global__ void asm_count_coo(long long n_coo, const int *__restrict__ row, int *__restrict__ cnt) {
@@ -218,12 +232,18 @@ __device__ __forceinline__ long long make_key(int col, int seq) { return ((long 
 __global__ void asm_fill_tri(long long n_tri, const int *__restrict__ tri, const double *__restrict__ xy,
                              int n_mesh, const long long *__restrict__ mesh_voff,
                              const long long *__restrict__ mesh_toff, const int *__restrict__ slot_ptr,
-                             int *__restrict__ cursor, long long *__restrict__ key, double *__restrict__ val) {
+                             int *__restrict__ cursor, long long *__restrict__ key, double *__restrict__ val,
+                             const int *__restrict__ only_flagged) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tri) return;
     const int m = find_segment(mesh_toff, n_mesh, t);
     const long long v0 = mesh_voff[m];
     const int ga = (int)(v0 + tri[3 * t]), gb = (int)(v0 + tri[3 * t + 1]), gc = (int)(v0 + tri[3 * t + 2]);
+    // only_flagged: rows already finished by asm_rows_from_incidence (row_len >= 0) take no slots
+    const bool fa = only_flagged == nullptr || only_flagged[ga] == -1;
+    const bool fb = only_flagged == nullptr || only_flagged[gb] == -1;
+    const bool fc = only_flagged == nullptr || only_flagged[gc] == -1;
+    if (!(fa || fb || fc)) return;
     const double ax = xy[2 * (long long)ga], ay = xy[2 * (long long)ga + 1];
     const double bx = xy[2 * (long long)gb], by = xy[2 * (long long)gb + 1];
     const double cx = xy[2 * (long long)gc], cy = xy[2 * (long long)gc + 1];
@@ -232,15 +252,157 @@ __global__ void asm_fill_tri(long long n_tri, const int *__restrict__ tri, const
     const double wca = cot_half(cx, cy, ax, ay, bx, by);   // edge c->a, opposite b
     // row a: (a,b) forward, (a,c) backward ; row b: (b,c) fwd, (b,a) bwd ; row c: (c,a) fwd, (c,b) bwd
     int s;
-    s = slot_ptr[ga] + atomicAdd(&cursor[ga], 2);
-    key[s] = make_key(gb, 0); val[s] = wab;
-    key[s + 1] = make_key(gc, 1); val[s + 1] = wca;
-    s = slot_ptr[gb] + atomicAdd(&cursor[gb], 2);
-    key[s] = make_key(gc, 0); val[s] = wbc;
-    key[s + 1] = make_key(ga, 1); val[s + 1] = wab;
-    s = slot_ptr[gc] + atomicAdd(&cursor[gc], 2);
-    key[s] = make_key(ga, 0); val[s] = wca;
-    key[s + 1] = make_key(gb, 1); val[s + 1] = wbc;
+    if (fa) {
+        s = slot_ptr[ga] + atomicAdd(&cursor[ga], 2);
+        key[s] = make_key(gb, 0); val[s] = wab;
+        key[s + 1] = make_key(gc, 1); val[s + 1] = wca;
+    }
+    if (fb) {
+        s = slot_ptr[gb] + atomicAdd(&cursor[gb], 2);
+        key[s] = make_key(gc, 0); val[s] = wbc;
+        key[s + 1] = make_key(ga, 1); val[s + 1] = wab;
+    }
+    if (fc) {
+        s = slot_ptr[gc] + atomicAdd(&cursor[gc], 2);
+        key[s] = make_key(ga, 0); val[s] = wca;
+        key[s + 1] = make_key(gb, 1); val[s + 1] = wbc;
+    }
+}
+
+// Rows of mesh vertices without stamps, straight from the incidence lists: the lane of vertex r walks its triangles,
+// computes the two cotangent terms that land in row r (the same cot_half calls with the same arguments as
+// asm_fill_tri), keeps one entry per neighbour in LDS, sorts the few entries by column and writes the finished row at
+// its slot offset -- no slot traffic, no float atomics.  Bit-identical to the slot path: an entry is the sum of at
+// most one forward and one backward term (a + b == b + a), the diagonal is -(w_1 + w_2 + ...) in ascending column
+// order.  Rows it does not take (stamps, more than CAP triangles, neighbour list overflow of a non-manifold fan) are
+// marked row_len = -1, listed in slow_list, and go through the slots (asm_fill_tri with only_flagged, the merge
+// kernels over the list).
+template <int CAP>
+__global__ __launch_bounds__(128) void asm_rows_from_incidence(
+    long long n_vert, int n_mesh, const long long *__restrict__ mesh_voff, const double *__restrict__ sigma,
+    const int *__restrict__ tri, const double *__restrict__ xy, const int *__restrict__ n_inc,
+    const int *__restrict__ inc, const int *__restrict__ n_coo, const int *__restrict__ slot_ptr,
+    long long *__restrict__ key, double *__restrict__ val, int *__restrict__ row_len, int *__restrict__ err,
+    int *__restrict__ slow_list, int *__restrict__ n_slow) {
+    static_assert(CAP == kIncCap, "the incidence lists have kIncCap entries per vertex");
+    __shared__ int Cc[CAP + 1][128];
+    __shared__ double Wc[CAP + 1][128];
+    __shared__ int Fc[CAP + 1][128];      // bit 0: forward term seen, bit 1: backward term seen
+    const int t = threadIdx.x;
+    const long long r = (long long)blockIdx.x * 128 + t;
+    if (r >= n_vert) return;
+    const long long i0 = r * CAP;
+    const int T = n_inc[r];
+    bool slow = n_coo[r] != 0 || T > CAP;
+    int nn = 0;
+    bool bad = false;
+    if (!slow) {
+        const int m = find_segment(mesh_voff, n_mesh, r);
+        const long long v0 = mesh_voff[m];
+        const double vx = xy[2 * r], vy = xy[2 * r + 1];
+        for (int q = 0; q < T && !slow; ++q) {
+            const long long tt = inc[i0 + q];
+            const int a = (int)(v0 + tri[3 * tt]), b = (int)(v0 + tri[3 * tt + 1]), c = (int)(v0 + tri[3 * tt + 2]);
+            int j, k;                       // r -> j is the edge leaving r in this triangle, k -> r the one arriving
+            if (a == (int)r) { j = b; k = c; } else if (b == (int)r) { j = c; k = a; } else { j = a; k = b; }
+            const double jx = xy[2 * (long long)j], jy = xy[2 * (long long)j + 1];
+            const double kx = xy[2 * (long long)k], ky = xy[2 * (long long)k + 1];
+            const double wf = cot_half(vx, vy, jx, jy, kx, ky);      // edge r -> j, opposite k
+            const double wb = cot_half(kx, ky, vx, vy, jx, jy);      // edge k -> r, opposite j
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                const int col = side == 0 ? j : k;
+                const double w = side == 0 ? wf : wb;
+                const int bit = 1 << side;
+                int u = 0;
+                while (u < nn && Cc[u][t] != col) ++u;
+                if (u < nn) {
+                    if (Fc[u][t] & bit) bad = true;                  // two triangles on the same side of an edge
+                    Wc[u][t] = (Fc[u][t] == 1) ? Wc[u][t] + w : w + Wc[u][t];      // forward + backward, as the merge adds them
+                    Fc[u][t] |= bit;
+                } else if (nn <= CAP) {
+                    Cc[nn][t] = col;
+                    Wc[nn][t] = w;
+                    Fc[nn][t] = bit;
+                    ++nn;
+                } else {
+                    slow = true;                                     // more neighbours than a manifold fan has
+                    break;
+                }
+            }
+        }
+    }
+    {
+        // rows for the slot path are listed (one atomic per wave), the merge kernels then run over the list only
+        const unsigned long long mk = __ballot(slow);
+        if (mk != 0ull) {
+            const int lane = threadIdx.x & 63;
+            int base = 0;
+            if (lane == __ffsll((long long)mk) - 1) base = atomicAdd(n_slow, __popcll(mk));
+            base = __shfl(base, __ffsll((long long)mk) - 1, 64);
+            if (slow) {
+                slow_list[base + __popcll(mk & ((1ull << lane) - 1ull))] = (int)r;
+                row_len[r] = -1;
+            }
+        }
+    }
+    if (slow) return;
+    // sort the neighbours by column (insertion sort, a handful of entries)
+    for (int i = 1; i < nn; ++i) {
+        const int c = Cc[i][t], f = Fc[i][t];
+        const double w = Wc[i][t];
+        int u = i - 1;
+        while (u >= 0 && Cc[u][t] > c) {
+            Cc[u + 1][t] = Cc[u][t];
+            Wc[u + 1][t] = Wc[u][t];
+            Fc[u + 1][t] = Fc[u][t];
+            --u;
+        }
+        Cc[u + 1][t] = c;
+        Wc[u + 1][t] = w;
+        Fc[u + 1][t] = f;
+    }
+    const double sig = sigma[find_segment(mesh_voff, n_mesh, r)];
+    int fwd_only = 0, bwd_only = 0;
+    double dacc = 0.0;
+    for (int i = 0; i < nn; ++i) {
+        if (Fc[i][t] == 1) ++fwd_only;
+        if (Fc[i][t] == 2) ++bwd_only;
+        const double wm = Wc[i][t];
+        if (wm != 0.0) dacc = dacc - wm;
+    }
+    if (bad || fwd_only > 1 || bwd_only > 1) atomicExch(&err[ERR_NONMANIFOLD], 1);
+    const int s0 = slot_ptr[r];
+    int o = 0;
+    bool diag_done = false;
+    for (int i = 0; i <= nn; ++i) {
+        if (!diag_done && (i == nn || Cc[i][t] > (int)r)) {
+            const double v = sig * dacc;
+            if (v != 0.0) {
+                key[s0 + o] = (long long)r << 32;
+                val[s0 + o] = v;
+                ++o;
+            }
+            diag_done = true;
+        }
+        if (i < nn) {
+            const double v = sig * Wc[i][t];
+            if (v != 0.0) {                                          // exact zeros are not stored
+                key[s0 + o] = (long long)Cc[i][t] << 32;
+                val[s0 + o] = v;
+                ++o;
+            }
+        }
+    }
+    row_len[r] = o;
+}
+
+__global__ void asm_list_tail_rows(int n_vert, int n_unknowns, int *__restrict__ row_len, int *__restrict__ slow_list,
+                                   int *__restrict__ n_slow) {
+    const int r = n_vert + blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_unknowns) return;
+    row_len[r] = -1;
+    slow_list[atomicAdd(n_slow, 1)] = r;
 }
 
 __global__ void asm_fill_coo(long long n_coo, const int *__restrict__ row, const int *__restrict__ col,
@@ -270,6 +432,44 @@ __device__ __forceinline__ void sort_slots(long long *key, double *val, int n) {
     }
 }
 
+// Long rows of the slot path (a vertex that a via ring's resistors all snapped to, a hub of lumped elements): the
+// one-lane insertion sort of merge_rows costs O(n^2) dependent global accesses (0.9 ms for the few hundred 70-slot rows
+// of config C4).  One wave per such row sorts its slots first: keys and values into LDS, every lane ranks its elements
+// by counting smaller keys (ties by position: keys are unique for a manifold mesh, repeated ones must keep their
+// order), sorted slots back in place.  merge_rows then finds the row sorted -- its insertion sort degenerates to one
+// pass -- and walks it as before: same operations in the same order.
+constexpr int kWaveSortCap = 1024;
+__global__ __launch_bounds__(256) void sort_long_rows_wave(long long n_list, const int *__restrict__ row_list,
+                                                           const int *__restrict__ slot_ptr, long long *__restrict__ key,
+                                                           double *__restrict__ val, const int min_len, const int mesh) {
+    __shared__ long long Ks[4][kWaveSortCap];
+    __shared__ double Vs[4][kWaveSortCap];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long idx = (long long)blockIdx.x * 4 + w;
+    if (idx >= n_list) return;
+    const long long r = row_list != nullptr ? row_list[idx] : idx;
+    const int s0 = slot_ptr[r];
+    const int n = slot_ptr[r + 1] - s0;
+    if (n < min_len || n > kWaveSortCap) return;
+    for (int e = lane; e < n; e += 64) {
+        // slot 0 is the row's diagonal placeholder, which nobody wrote (see merge_rows)
+        Ks[w][e] = (mesh && e == 0) ? make_key((int)r, 2) : key[s0 + e];
+        Vs[w][e] = (mesh && e == 0) ? 0.0 : val[s0 + e];
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < n; e += 64) {
+        const long long k = Ks[w][e];
+        int rank = 0;
+        for (int f = 0; f < n; ++f) {
+            const long long kf = Ks[w][f];
+            rank += (kf < k || (kf == k && f < e)) ? 1 : 0;
+        }
+        key[s0 + rank] = k;
+        val[s0 + rank] = Vs[w][e];
+    }
+}
+
 // One lane per row.  MESH=true: slots with sequence 0/1 are raw cotangent terms of the row's
 // mesh, sequence 2 is the (zero valued) diagonal placeholder every row owns, 3+k is stamp k.
 // Every column group owns at least one slot and emits at most one entry, so the in-place
@@ -279,19 +479,24 @@ __global__ void merge_rows(long long n_rows, long long n_vert, int n_mesh,
                            const long long *__restrict__ mesh_voff, const double *__restrict__ sigma,
                            const int *__restrict__ slot_ptr, long long *__restrict__ key,
                            double *__restrict__ val, int *__restrict__ row_len, int *__restrict__ err,
-                           const int min_len) {
-    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rows) return;
+                           const int min_len, const int *__restrict__ row_list = nullptr, const int presorted_upto = 0) {
+    // row_list: the kernel runs over these n_rows rows only (the assembly's slot rows), otherwise over rows 0..n_rows-1;
+    // presorted_upto: rows of up to that many slots were sorted by sort_long_rows_wave (placeholder included)
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_rows) return;
+    const long long r = row_list != nullptr ? row_list[idx] : idx;
     const int s0 = slot_ptr[r];
     const int n = slot_ptr[r + 1] - s0;
     if (n < min_len) return;                       // short rows were merged by merge_rows_lds
     long long *K = key + s0;
     double *V = val + s0;
-    if (MESH) {                                    // the diagonal placeholder of the assembled system (see above)
-        K[0] = make_key((int)r, 2);
-        V[0] = 0.0;
+    if (n > presorted_upto) {
+        if (MESH) {                                // the diagonal placeholder of the assembled system (see above)
+            K[0] = make_key((int)r, 2);
+            V[0] = 0.0;
+        }
+        sort_slots(K, V, n);
     }
-    sort_slots(K, V, n);
     double sig = 0.0;
     double dacc = 0.0;  // -(w_1 + w_2 + ...) in ascending column order   (diag[i] -= ratio, solver.py:203)
     if (MESH && r < n_vert) {
@@ -359,12 +564,14 @@ __global__ __launch_bounds__(128) void merge_rows_mesh_lds(long long n_rows, lon
                                                            const double *__restrict__ sigma,
                                                            const int *__restrict__ slot_ptr, long long *__restrict__ key,
                                                            double *__restrict__ val, int *__restrict__ row_len,
-                                                           int *__restrict__ err, const int skip_upto) {
+                                                           int *__restrict__ err, const int skip_upto,
+                                                           const int *__restrict__ row_list) {
     __shared__ long long Kc[CAP][128];
     __shared__ double Vc[CAP][128];
     const int t = threadIdx.x;
-    const long long r = (long long)blockIdx.x * 128 + t;
-    if (r >= n_rows) return;
+    const long long idx = (long long)blockIdx.x * 128 + t;
+    if (idx >= n_rows) return;
+    const long long r = row_list != nullptr ? row_list[idx] : idx;
     const int s0 = slot_ptr[r];
     const int n = slot_ptr[r + 1] - s0;
     if (n <= skip_upto) return;                    // merged by the previous, smaller pass
@@ -605,34 +812,40 @@ __global__ void power_density_kernel(long long n_tri, const int *__restrict__ tr
 template <bool MESH>
 static int finish_rows(padne_ctx *ctx, Scratch &sc, long long n_rows, long long n_cols, long long n_vert, int n_mesh,
                        const long long *d_voff, const double *d_sigma, const int *slot_ptr, long long *key,
-                       double *val, int *d_err, padne_csr **out) {
+                       double *val, int *d_err, padne_csr **out, int *row_len_in = nullptr,
+                       const int *row_list = nullptr, long long n_list = 0) {
+    // row_len_in + row_list: rows with row_len >= 0 are already merged at their slot offsets
+    // (asm_rows_from_incidence); the merge kernels run over the n_list rows of row_list only
     hipStream_t s = ctx->stream;
-    int *row_len = nullptr;
-    PADNE_TRY(sc.alloc(&row_len, (size_t)n_rows + 1));
-    if (MESH) {
+    int *row_len = row_len_in;
+    if (row_len == nullptr) PADNE_TRY(sc.alloc(&row_len, (size_t)n_rows + 1));
+    const long long n_merge = row_len_in != nullptr ? n_list : n_rows;
+    if (MESH && n_merge > 0) {
         // rows of up to 20 slots (vertices of degree <= 9) first: 40 KiB of LDS per 128 rows, twice the waves per CU of the
         // 32-slot pass, which only runs for meshes that have longer rows; beyond that (hubs) the global-memory merge
         constexpr int kCapSmall = 20, kCap = 32;
-        hipLaunchKernelGGL(merge_rows_mesh_lds<kCapSmall>, dim3(nblk(n_rows, 128)), dim3(128), 0, s, n_rows, n_vert, n_mesh,
-                           d_voff, d_sigma, slot_ptr, key, val, row_len, d_err, 0);
+        hipLaunchKernelGGL(merge_rows_mesh_lds<kCapSmall>, dim3(nblk(n_merge, 128)), dim3(128), 0, s, n_merge, n_vert, n_mesh,
+                           d_voff, d_sigma, slot_ptr, key, val, row_len, d_err, 0, row_list);
         PADNE_HIP_CHECK(hipGetLastError());
         int h_long[ERR_WORDS];
         PADNE_HIP_CHECK(hipMemcpyAsync(h_long, d_err, sizeof(h_long), hipMemcpyDeviceToHost, s));
         PADNE_HIP_CHECK(hipStreamSynchronize(s));
         if (h_long[ERR_LONG_ROWS]) {
             PADNE_HIP_CHECK(hipMemsetAsync(d_err + ERR_LONG_ROWS, 0, sizeof(int), s));
-            hipLaunchKernelGGL(merge_rows_mesh_lds<kCap>, dim3(nblk(n_rows, 128)), dim3(128), 0, s, n_rows, n_vert, n_mesh,
-                               d_voff, d_sigma, slot_ptr, key, val, row_len, d_err, kCapSmall);
+            hipLaunchKernelGGL(merge_rows_mesh_lds<kCap>, dim3(nblk(n_merge, 128)), dim3(128), 0, s, n_merge, n_vert, n_mesh,
+                               d_voff, d_sigma, slot_ptr, key, val, row_len, d_err, kCapSmall, row_list);
             PADNE_HIP_CHECK(hipGetLastError());
             PADNE_HIP_CHECK(hipMemcpyAsync(h_long, d_err, sizeof(h_long), hipMemcpyDeviceToHost, s));
             PADNE_HIP_CHECK(hipStreamSynchronize(s));
         }
-        if (h_long[ERR_LONG_ROWS]) {               // rows with more than kCap slots (hubs): global-memory merge
-            hipLaunchKernelGGL(merge_rows<MESH>, dim3(nblk(n_rows, 128)), dim3(128), 0, s, n_rows, n_vert, n_mesh, d_voff,
-                               d_sigma, slot_ptr, key, val, row_len, d_err, kCap + 1);
+        if (h_long[ERR_LONG_ROWS]) {               // rows with more than kCap slots (hubs): wave sort, then the global-memory merge
+            hipLaunchKernelGGL(sort_long_rows_wave, dim3(nblk(n_merge, 4)), dim3(256), 0, s, n_merge, row_list, slot_ptr, key, val,
+                               kCap + 1, 1);
+            hipLaunchKernelGGL(merge_rows<MESH>, dim3(nblk(n_merge, 128)), dim3(128), 0, s, n_merge, n_vert, n_mesh, d_voff,
+                               d_sigma, slot_ptr, key, val, row_len, d_err, kCap + 1, row_list, kWaveSortCap);
             PADNE_HIP_CHECK(hipGetLastError());
         }
-    } else {
+    } else if (!MESH) {
         PADNE_TRY(merge_slots_generic(ctx, n_rows, slot_ptr, key, val, row_len));
     }
     int h_err[ERR_WORDS];
@@ -803,13 +1016,24 @@ extern "C" int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns, int64_t
         PADNE_HIP_CHECK(hipMemcpyAsync(d_cval, coo_val, sizeof(double) * (size_t)n_coo, hipMemcpyHostToDevice, s));
     }
     PADNE_HIP_CHECK(hipMemsetAsync(d_err, 0, sizeof(int) * ERR_WORDS, s));
-    // 1 count (every row starts with its diagonal placeholder)
-    hipLaunchKernelGGL(fill_value_i32, dim3(nblk(n_unknowns + 1)), dim3(256), 0, s, d_cnt, (long long)n_unknowns + 1, 1);
+    // 1 one pass over the triangles: validation, incident triangles per vertex and their lists; stamps per row
+    int *d_ninc = nullptr, *d_ncoo = nullptr, *d_inc = nullptr, *d_rowlen = nullptr, *d_list = nullptr, *d_nslow = nullptr;
+    PADNE_TRY(sc.alloc(&d_ninc, (size_t)n_unknowns + 1));
+    PADNE_TRY(sc.alloc(&d_ncoo, (size_t)n_unknowns + 1));
+    PADNE_TRY(sc.alloc(&d_inc, (size_t)n_vert * kIncCap));
+    PADNE_TRY(sc.alloc(&d_rowlen, (size_t)n_unknowns + 1));
+    PADNE_TRY(sc.alloc(&d_list, (size_t)n_unknowns + 1));
+    PADNE_TRY(sc.alloc(&d_nslow, 1));
+    PADNE_HIP_CHECK(hipMemsetAsync(d_ninc, 0, sizeof(int) * (size_t)(n_unknowns + 1), s));
+    PADNE_HIP_CHECK(hipMemsetAsync(d_ncoo, 0, sizeof(int) * (size_t)(n_unknowns + 1), s));
+    PADNE_HIP_CHECK(hipMemsetAsync(d_nslow, 0, sizeof(int), s));
     if (n_tri > 0)
         hipLaunchKernelGGL(asm_count_tri, dim3(nblk(n_tri)), dim3(256), 0, s, (long long)n_tri, d_tri, (int)n_mesh,
-                           d_voff, d_toff, d_cnt, d_err);
+                           d_voff, d_toff, d_ninc, d_inc, d_err);
     if (n_coo > 0)
-        hipLaunchKernelGGL(asm_count_coo, dim3(nblk(n_coo)), dim3(256), 0, s, (long long)n_coo, d_crow, d_cnt);
+        hipLaunchKernelGGL(asm_count_coo, dim3(nblk(n_coo)), dim3(256), 0, s, (long long)n_coo, d_crow, d_ncoo);
+    hipLaunchKernelGGL(asm_slot_counts, dim3(nblk(n_unknowns + 1)), dim3(256), 0, s, (long long)n_unknowns + 1, d_ninc, d_ncoo,
+                       d_cnt);
     PADNE_HIP_CHECK(hipGetLastError());
     int h_err[ERR_WORDS];
     PADNE_HIP_CHECK(hipMemcpyAsync(h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
@@ -818,25 +1042,39 @@ extern "C" int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns, int64_t
         set_error("triangle refers to a vertex outside its mesh, or repeats a vertex");
         return PADNE_E_INVALID;
     }
-    // 2 scan
+    // 2 scan: slot offsets of the rows (a finished row is written at its slot offset, whichever path produces it)
     int64_t n_slots = 0;
     PADNE_TRY(exclusive_scan_i32(ctx, d_cnt, d_slot, n_unknowns, &n_slots));
     long long *d_key = nullptr;
     double *d_val = nullptr;
     PADNE_TRY(sc.alloc(&d_key, (size_t)n_slots));
     PADNE_TRY(sc.alloc(&d_val, (size_t)n_slots));
-    // 3 fill (cursor = 1: slot 0 of each row is the diagonal placeholder)
-    hipLaunchKernelGGL(fill_value_i32, dim3(nblk(n_unknowns + 1)), dim3(256), 0, s, d_cnt, (long long)n_unknowns + 1, 1);
-    if (n_tri > 0)
-        hipLaunchKernelGGL(asm_fill_tri, dim3(nblk(n_tri)), dim3(256), 0, s, (long long)n_tri, d_tri, d_xy, (int)n_mesh,
-                           d_voff, d_toff, d_slot, d_cnt, d_key, d_val);
-    if (n_coo > 0)
-        hipLaunchKernelGGL(asm_fill_coo, dim3(nblk(n_coo)), dim3(256), 0, s, (long long)n_coo, d_crow, d_ccol, d_cval,
-                           d_slot, d_cnt, d_key, d_val);
+    // 3 mesh rows without stamps straight from the incidence lists; the others are listed for the slot path
+    if (n_vert > 0)
+        hipLaunchKernelGGL(asm_rows_from_incidence<kIncCap>, dim3(nblk(n_vert, 128)), dim3(128), 0, s, (long long)n_vert,
+                           (int)n_mesh, d_voff, d_sigma, d_tri, d_xy, d_ninc, d_inc, d_ncoo, d_slot, d_key, d_val, d_rowlen,
+                           d_err, d_list, d_nslow);
+    if (n_unknowns > n_vert)       // rows of internal nodes and extra unknowns: stamps only
+        hipLaunchKernelGGL(asm_list_tail_rows, dim3(nblk(n_unknowns - n_vert)), dim3(256), 0, s, (int)n_vert, (int)n_unknowns,
+                           d_rowlen, d_list, d_nslow);
     PADNE_HIP_CHECK(hipGetLastError());
-    // 4-6
+    int h_slow = 0;
+    PADNE_HIP_CHECK(hipMemcpyAsync(&h_slow, d_nslow, sizeof(int), hipMemcpyDeviceToHost, s));
+    PADNE_HIP_CHECK(hipStreamSynchronize(s));
+    // 4 the listed rows through the slots (cursor = 1: slot 0 of each row is the diagonal placeholder)
+    if (h_slow > 0) {
+        hipLaunchKernelGGL(fill_value_i32, dim3(nblk(n_unknowns + 1)), dim3(256), 0, s, d_cnt, (long long)n_unknowns + 1, 1);
+        if (n_tri > 0)
+            hipLaunchKernelGGL(asm_fill_tri, dim3(nblk(n_tri)), dim3(256), 0, s, (long long)n_tri, d_tri, d_xy, (int)n_mesh,
+                               d_voff, d_toff, d_slot, d_cnt, d_key, d_val, (const int *)d_rowlen);
+        if (n_coo > 0)
+            hipLaunchKernelGGL(asm_fill_coo, dim3(nblk(n_coo)), dim3(256), 0, s, (long long)n_coo, d_crow, d_ccol, d_cval,
+                               d_slot, d_cnt, d_key, d_val);
+        PADNE_HIP_CHECK(hipGetLastError());
+    }
+    // 5-7 merge of the slot rows, scan, compaction
     return finish_rows<true>(ctx, sc, n_unknowns, n_unknowns, n_vert, (int)n_mesh, d_voff, d_sigma, d_slot, d_key,
-                             d_val, d_err, out);
+                             d_val, d_err, out, d_rowlen, d_list, (long long)h_slow);
 }
 
 // out = scale * R^T M C: entry (i, j, v) becomes (row_map[i], col_map[j], scale*v) when both maps are >= 0,
