@@ -767,6 +767,95 @@ __global__ void reduce_fill(long long n_rows, const int *__restrict__ rowptr, co
     }
 }
 
+
+// ---- relabel with injective maps: every output row is ONE relabelled source row -------------------------------------
+// (ground elimination, locality permutations, the row / column split of the row-partitioned solver; only tied groups
+// of unknowns -- voltage sources -- merge rows.)  No slots, no merge, no compaction: count, scan, write.
+__global__ void map_is_injective(long long n, const int *__restrict__ map, int *__restrict__ hist, int *__restrict__ flag) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int t = map[i];
+    if (t >= 0 && atomicAdd(&hist[t], 1) > 0) *(volatile int *)flag = 1;
+}
+
+// (the count does not look at the values: a kept entry whose scaled value is exactly zero -- an explicit zero in a
+// matrix handed in by the caller; the assembly stores none -- is noticed by the fill kernel, and the whole relabel is
+// then redone through the slots, which drop such entries)
+__global__ void relabel_count_direct(long long n_rows, const int *__restrict__ rowptr, const int *__restrict__ cols,
+                                     const int *__restrict__ map, const int *__restrict__ cmap, int *__restrict__ cnt) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const int t = map[r];
+    if (t < 0) return;
+    int c = 0;
+    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) c += (cmap[cols[k]] >= 0) ? 1 : 0;
+    cnt[t] = c;
+}
+
+template <int CAP>
+__global__ __launch_bounds__(128) void relabel_fill_direct(long long n_rows, const int *__restrict__ rowptr,
+                                                           const int *__restrict__ cols, const double *__restrict__ vals,
+                                                           const int *__restrict__ map, const int *__restrict__ cmap,
+                                                           double scale, const int *__restrict__ out_rowptr,
+                                                           int *__restrict__ out_cols, double *__restrict__ out_vals,
+                                                           int *__restrict__ zero_seen) {
+    __shared__ int Cc[CAP][128];
+    __shared__ double Vc[CAP][128];
+    const int th = threadIdx.x;
+    const long long r = (long long)blockIdx.x * 128 + th;
+    if (r >= n_rows) return;
+    const int t = map[r];
+    if (t < 0) return;
+    const int o0 = out_rowptr[t], n_out = out_rowptr[t + 1] - o0;
+    if (n_out <= CAP) {
+        // the usual case: the row's entries sorted by their new column while being collected in LDS
+        int m = 0;
+        for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+            const int tc = cmap[cols[k]];
+            const double v = scale * vals[k];
+            if (tc < 0) continue;
+            if (v == 0.0) *(volatile int *)zero_seen = 1;
+            int u = m - 1;
+            while (u >= 0 && Cc[u][th] > tc) {
+                Cc[u + 1][th] = Cc[u][th];
+                Vc[u + 1][th] = Vc[u][th];
+                --u;
+            }
+            Cc[u + 1][th] = tc;
+            Vc[u + 1][th] = v;
+            ++m;
+        }
+        for (int u = 0; u < m; ++u) {
+            out_cols[o0 + u] = Cc[u][th];
+            out_vals[o0 + u] = Vc[u][th];
+        }
+    } else {
+        // long rows (hubs): written in source order, then sorted in place
+        int m = 0;
+        for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+            const int tc = cmap[cols[k]];
+            const double v = scale * vals[k];
+            if (tc < 0) continue;
+            if (v == 0.0) *(volatile int *)zero_seen = 1;
+            out_cols[o0 + m] = tc;
+            out_vals[o0 + m] = v;
+            ++m;
+        }
+        for (int i = 1; i < m; ++i) {
+            const int c = out_cols[o0 + i];
+            const double v = out_vals[o0 + i];
+            int u = i - 1;
+            while (u >= 0 && out_cols[o0 + u] > c) {
+                out_cols[o0 + u + 1] = out_cols[o0 + u];
+                out_vals[o0 + u + 1] = out_vals[o0 + u];
+                --u;
+            }
+            out_cols[o0 + u + 1] = c;
+            out_vals[o0 + u + 1] = v;
+        }
+    }
+}
+
 // ---- power density ---------------------------------------------------------------------------
 // compute_triangle_gradient (solver.py:689-725) with the face vertex order of the reference:
 // Face.edge is the last interior half-edge created (v3->v1, mesh.py:320-325) so face.vertices
@@ -1104,6 +1193,57 @@ static int csr_relabel(padne_ctx *ctx, const padne_csr *m, const int32_t *row_ma
     }
     PADNE_HIP_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(int) * (size_t)(n_rows_out + 1), s));
     PADNE_HIP_CHECK(hipMemsetAsync(d_err, 0, sizeof(int) * ERR_WORDS, s));
+    {
+        // injective row and column maps (everything but tied groups of unknowns): direct relabel, no slots
+        int *d_hist = nullptr;
+        const long long n_hist = std::max<long long>(n_rows_out, n_cols_out) + 1;
+        PADNE_TRY(sc.alloc(&d_hist, (size_t)n_hist));
+        PADNE_HIP_CHECK(hipMemsetAsync(d_hist, 0, sizeof(int) * (size_t)n_hist, s));
+        if (m->n_rows > 0)
+            hipLaunchKernelGGL(map_is_injective, dim3(nblk(m->n_rows)), dim3(256), 0, s, (long long)m->n_rows, d_map, d_hist,
+                               d_err + ERR_LONG_ROWS);
+        if (d_cmap != d_map && m->n_cols > 0) {
+            PADNE_HIP_CHECK(hipMemsetAsync(d_hist, 0, sizeof(int) * (size_t)n_hist, s));
+            hipLaunchKernelGGL(map_is_injective, dim3(nblk(m->n_cols)), dim3(256), 0, s, (long long)m->n_cols, d_cmap, d_hist,
+                               d_err + ERR_LONG_ROWS);
+        }
+        PADNE_HIP_CHECK(hipGetLastError());
+        int h_dup = 0;
+        PADNE_HIP_CHECK(hipMemcpyAsync(&h_dup, d_err + ERR_LONG_ROWS, sizeof(int), hipMemcpyDeviceToHost, s));
+        PADNE_HIP_CHECK(hipStreamSynchronize(s));
+        if (h_dup == 0 && getenv("PADNE_RELABEL_SLOTS") == nullptr) {
+            if (m->n_rows > 0)
+                hipLaunchKernelGGL(relabel_count_direct, dim3(nblk(m->n_rows)), dim3(256), 0, s, (long long)m->n_rows, m->rowptr,
+                                   m->cols, d_map, d_cmap, d_cnt);
+            PADNE_HIP_CHECK(hipGetLastError());
+            int64_t nnz = 0;
+            PADNE_TRY(exclusive_scan_i32(ctx, d_cnt, d_slot, n_rows_out, &nnz));
+            padne_csr *res = nullptr;
+            PADNE_TRY(csr_alloc(ctx, n_rows_out, n_cols_out, nnz, &res));
+            hipError_t e = hipMemcpyAsync(res->rowptr, d_slot, sizeof(int32_t) * (size_t)(n_rows_out + 1), hipMemcpyDeviceToDevice, s);
+            if (e == hipSuccess && m->n_rows > 0) {
+                hipLaunchKernelGGL(relabel_fill_direct<16>, dim3(nblk(m->n_rows, 128)), dim3(128), 0, s, (long long)m->n_rows,
+                                   m->rowptr, m->cols, m->vals, d_map, d_cmap, scale, res->rowptr, res->cols, res->vals,
+                                   d_err + ERR_LONG_ROWS);
+                e = hipGetLastError();
+            }
+            int h_zero = 0;
+            if (e == hipSuccess) e = hipMemcpyAsync(&h_zero, d_err + ERR_LONG_ROWS, sizeof(int), hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) {
+                set_error("relabel failed: %s", hipGetErrorString(e));
+                padne_csr_destroy(res);
+                return PADNE_E_HIP;
+            }
+            if (h_zero == 0) {
+                *out = res;
+                return PADNE_OK;
+            }
+            padne_csr_destroy(res);           // explicit zeros in the source: the slot path drops them
+            PADNE_HIP_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(int) * (size_t)(n_rows_out + 1), s));
+        }
+        PADNE_HIP_CHECK(hipMemsetAsync(d_err, 0, sizeof(int) * ERR_WORDS, s));
+    }
     if (m->n_rows > 0)
         hipLaunchKernelGGL(reduce_count, dim3(nblk(m->n_rows)), dim3(256), 0, s, (long long)m->n_rows, m->rowptr,
                            m->cols, d_map, d_cmap, d_cnt);

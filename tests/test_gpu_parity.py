@@ -1156,6 +1156,40 @@ def test_spmm8_columns_are_bitwise_the_single_vector_products(ctx):
             assert np.array_equal(yj, M @ X[:, j])            # and both equal scipy's CSR product bit for bit
 
 
+def test_relabel_with_injective_maps_is_the_slot_path_bit_for_bit(ctx, monkeypatch):
+    """Eliminations and permutations (injective row and column maps) are relabelled directly -- count, scan, write,
+    rows re-sorted by their new columns -- instead of through slots and a merge: same matrix, bit for bit, including
+    rows longer than the in-LDS sort, dropped rows / columns and exact zeros."""
+    rng = np.random.default_rng(21)
+    M = H.random_csr(5000, 5000, 9, 3).tolil()
+    M[17, :40] = rng.uniform(-1, 1, 40)                      # a long row
+    M[:60, 23] = rng.uniform(-1, 1, (60, 1))                 # a long column
+    M = M.tocsr()
+    perm = rng.permutation(5000).astype(np.int32)
+    drop = rng.choice(5000, 300, replace=False)
+    rmap = perm.copy()
+    rmap[drop] = -1
+    rmap[rmap >= 0] = np.argsort(np.argsort(rmap[rmap >= 0])).astype(np.int32)      # compress to 0..n-1, order scrambled
+    n_out = int((rmap >= 0).sum())
+    cmap = np.arange(5000, dtype=np.int32)
+    cmap[drop[:100]] = -1
+    cmap[cmap >= 0] = np.arange((cmap >= 0).sum(), dtype=np.int32)                 # monotone column map
+    cases = [("reduce", lambda m: m.reduce(rmap, n_out, -1.0)),
+             ("relabel", lambda m: m.relabel(rmap, n_out, cmap, int((cmap >= 0).sum()), 2.5))]
+    Mz = M.copy()
+    Mz.data[::37] = 0.0               # explicit zeros: no path stores them (the direct one notices and hands over to the slots)
+    for src in (M, Mz):
+        d = ctx.csr_from_scipy(src)
+        for name, fn in cases:
+            direct = fn(d).to_scipy()
+            monkeypatch.setenv("PADNE_RELABEL_SLOTS", "1")
+            slots = fn(d).to_scipy()
+            monkeypatch.delenv("PADNE_RELABEL_SLOTS")
+            assert direct.shape == slots.shape and np.array_equal(direct.indptr, slots.indptr), name
+            assert np.array_equal(direct.indices, slots.indices) and np.array_equal(direct.data, slots.data), name
+            assert direct.has_sorted_indices and direct.nnz > 0 and np.all(direct.data != 0.0)
+
+
 def test_relabel_and_vstack_against_scipy(ctx):
     rng = np.random.default_rng(12)
     M = H.random_csr(300, 420, 9, 12)
