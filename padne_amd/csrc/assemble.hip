@@ -771,10 +771,17 @@ __global__ void reduce_fill(long long n_rows, const int *__restrict__ rowptr, co
 // ---- relabel with injective maps: every output row is ONE relabelled source row -------------------------------------
 // (ground elimination, locality permutations, the row / column split of the row-partitioned solver; only tied groups
 // of unknowns -- voltage sources -- merge rows.)  No slots, no merge, no compaction: count, scan, write.
-__global__ void map_is_injective(long long n, const int *__restrict__ map, int *__restrict__ hist, int *__restrict__ flag) {
+// flag[0] = 1: two indices share a target (not injective); flag[1] = 1: an entry outside [-1, n_out) (checked here, on
+// the device copy of the map, instead of in a host loop over 10 M entries)
+__global__ void map_is_injective(long long n, const int *__restrict__ map, int n_out, int *__restrict__ hist,
+                                 int *__restrict__ flag) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int t = map[i];
+    if (t < -1 || t >= n_out) {
+        *(volatile int *)(flag + 1) = 1;
+        return;
+    }
     if (t >= 0 && atomicAdd(&hist[t], 1) > 0) *(volatile int *)flag = 1;
 }
 
@@ -1172,10 +1179,6 @@ static int csr_relabel(padne_ctx *ctx, const padne_csr *m, const int32_t *row_ma
                        const int32_t *col_map_host, int64_t n_cols_out, double scale, padne_csr **out) {
     PADNE_REQUIRE(n_rows_out >= 0 && n_rows_out < 2147483647LL && n_cols_out >= 0 && n_cols_out < 2147483647LL,
                   "output shape");
-    for (int64_t i = 0; i < m->n_rows; ++i)
-        PADNE_REQUIRE(row_map_host[i] >= -1 && row_map_host[i] < n_rows_out, "row map entry out of range");
-    for (int64_t j = 0; j < m->n_cols; ++j)
-        PADNE_REQUIRE(col_map_host[j] >= -1 && col_map_host[j] < n_cols_out, "column map entry out of range");
     PADNE_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     Scratch sc(ctx);
@@ -1200,17 +1203,25 @@ static int csr_relabel(padne_ctx *ctx, const padne_csr *m, const int32_t *row_ma
         PADNE_TRY(sc.alloc(&d_hist, (size_t)n_hist));
         PADNE_HIP_CHECK(hipMemsetAsync(d_hist, 0, sizeof(int) * (size_t)n_hist, s));
         if (m->n_rows > 0)
-            hipLaunchKernelGGL(map_is_injective, dim3(nblk(m->n_rows)), dim3(256), 0, s, (long long)m->n_rows, d_map, d_hist,
-                               d_err + ERR_LONG_ROWS);
+            hipLaunchKernelGGL(map_is_injective, dim3(nblk(m->n_rows)), dim3(256), 0, s, (long long)m->n_rows, d_map,
+                               (int)n_rows_out, d_hist, d_err + ERR_LONG_ROWS);
         if (d_cmap != d_map && m->n_cols > 0) {
             PADNE_HIP_CHECK(hipMemsetAsync(d_hist, 0, sizeof(int) * (size_t)n_hist, s));
-            hipLaunchKernelGGL(map_is_injective, dim3(nblk(m->n_cols)), dim3(256), 0, s, (long long)m->n_cols, d_cmap, d_hist,
-                               d_err + ERR_LONG_ROWS);
+            hipLaunchKernelGGL(map_is_injective, dim3(nblk(m->n_cols)), dim3(256), 0, s, (long long)m->n_cols, d_cmap,
+                               (int)n_cols_out, d_hist, d_err + ERR_LONG_ROWS);
+        } else if (d_cmap == d_map) {
+            PADNE_REQUIRE(n_rows_out <= n_cols_out, "shared index map needs n_rows_out <= n_cols_out");
         }
         PADNE_HIP_CHECK(hipGetLastError());
-        int h_dup = 0;
-        PADNE_HIP_CHECK(hipMemcpyAsync(&h_dup, d_err + ERR_LONG_ROWS, sizeof(int), hipMemcpyDeviceToHost, s));
+        int h_flags[2] = {0, 0};
+        static_assert(ERR_LONG_ROWS + 1 < ERR_WORDS, "two flag words");
+        PADNE_HIP_CHECK(hipMemcpyAsync(h_flags, d_err + ERR_LONG_ROWS, sizeof(h_flags), hipMemcpyDeviceToHost, s));
         PADNE_HIP_CHECK(hipStreamSynchronize(s));
+        if (h_flags[1]) {
+            set_error("invalid argument: index map entry out of range");
+            return PADNE_E_INVALID;
+        }
+        const int h_dup = h_flags[0];
         if (h_dup == 0 && getenv("PADNE_RELABEL_SLOTS") == nullptr) {
             if (m->n_rows > 0)
                 hipLaunchKernelGGL(relabel_count_direct, dim3(nblk(m->n_rows)), dim3(256), 0, s, (long long)m->n_rows, m->rowptr,

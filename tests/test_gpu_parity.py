@@ -1176,6 +1176,10 @@ def test_relabel_with_injective_maps_is_the_slot_path_bit_for_bit(ctx, monkeypat
     cmap[cmap >= 0] = np.arange((cmap >= 0).sum(), dtype=np.int32)                 # monotone column map
     cases = [("reduce", lambda m: m.reduce(rmap, n_out, -1.0)),
              ("relabel", lambda m: m.relabel(rmap, n_out, cmap, int((cmap >= 0).sum()), 2.5))]
+    bad = rmap.copy()
+    bad[7] = n_out                    # out of range: rejected (checked on the device copy of the map)
+    with pytest.raises(ValueError):
+        ctx.csr_from_scipy(M).reduce(bad, n_out, 1.0)
     Mz = M.copy()
     Mz.data[::37] = 0.0               # explicit zeros: no path stores them (the direct one notices and hands over to the slots)
     for src in (M, Mz):
