@@ -445,28 +445,43 @@ __global__ __launch_bounds__(256) void sort_long_rows_wave(long long n_list, con
     __shared__ long long Ks[4][kWaveSortCap];
     __shared__ double Vs[4][kWaveSortCap];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const long long idx = (long long)blockIdx.x * 4 + w;
-    if (idx >= n_list) return;
-    const long long r = row_list != nullptr ? row_list[idx] : idx;
-    const int s0 = slot_ptr[r];
-    const int n = slot_ptr[r + 1] - s0;
-    if (n < min_len || n > kWaveSortCap) return;
-    for (int e = lane; e < n; e += 64) {
-        // slot 0 is the row's diagonal placeholder, which nobody wrote (see merge_rows)
-        Ks[w][e] = (mesh && e == 0) ? make_key((int)r, 2) : key[s0 + e];
-        Vs[w][e] = (mesh && e == 0) ? 0.0 : val[s0 + e];
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    for (int e = lane; e < n; e += 64) {
-        const long long k = Ks[w][e];
-        int rank = 0;
-        for (int f = 0; f < n; ++f) {
-            const long long kf = Ks[w][f];
-            rank += (kf < k || (kf == k && f < e)) ? 1 : 0;
+    const long long n_waves = (long long)gridDim.x * 4;
+    // a wave looks at 64 rows at a time (one lane each, coalesced reads of the offsets) and sorts the long ones it finds
+    for (long long c0 = ((long long)blockIdx.x * 4 + w) * 64; c0 < n_list; c0 += n_waves * 64) {
+        const long long idx = c0 + lane;
+        long long r_l = 0;
+        int s0_l = 0, n_l = 0;
+        if (idx < n_list) {
+            r_l = row_list != nullptr ? row_list[idx] : idx;
+            s0_l = slot_ptr[r_l];
+            n_l = slot_ptr[r_l + 1] - s0_l;
         }
-        key[s0 + rank] = k;
-        val[s0 + rank] = Vs[w][e];
+        unsigned long long todo = __ballot(n_l >= min_len && n_l <= kWaveSortCap);
+        while (todo != 0ull) {
+            const int b = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            const long long r = __shfl(r_l, b, 64);
+            const int s0 = __shfl(s0_l, b, 64), n = __shfl(n_l, b, 64);
+            for (int e = lane; e < n; e += 64) {
+                // slot 0 of an assembly row is its diagonal placeholder, which nobody wrote (see merge_rows)
+                Ks[w][e] = (mesh && e == 0) ? make_key((int)r, 2) : key[s0 + e];
+                Vs[w][e] = (mesh && e == 0) ? 0.0 : val[s0 + e];
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            for (int e = lane; e < n; e += 64) {
+                const long long k = Ks[w][e];
+                int rank = 0;
+                for (int f = 0; f < n; ++f) {
+                    const long long kf = Ks[w][f];
+                    rank += (kf < k || (kf == k && f < e)) ? 1 : 0;
+                }
+                key[s0 + rank] = k;
+                val[s0 + rank] = Vs[w][e];
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // LDS is reused by the next row
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 }
 
@@ -935,8 +950,8 @@ static int finish_rows(padne_ctx *ctx, Scratch &sc, long long n_rows, long long 
             PADNE_HIP_CHECK(hipStreamSynchronize(s));
         }
         if (h_long[ERR_LONG_ROWS]) {               // rows with more than kCap slots (hubs): wave sort, then the global-memory merge
-            hipLaunchKernelGGL(sort_long_rows_wave, dim3(nblk(n_merge, 4)), dim3(256), 0, s, n_merge, row_list, slot_ptr, key, val,
-                               kCap + 1, 1);
+            hipLaunchKernelGGL(sort_long_rows_wave, dim3(std::min(nblk(n_merge, 256), 2048u)), dim3(256), 0, s, n_merge, row_list,
+                               slot_ptr, key, val, kCap + 1, 1);
             hipLaunchKernelGGL(merge_rows<MESH>, dim3(nblk(n_merge, 128)), dim3(128), 0, s, n_merge, n_vert, n_mesh, d_voff,
                                d_sigma, slot_ptr, key, val, row_len, d_err, kCap + 1, row_list, kWaveSortCap);
             PADNE_HIP_CHECK(hipGetLastError());
@@ -981,9 +996,13 @@ int merge_slots_generic(padne_ctx *ctx, long long n_rows, const int *slot_ptr, l
     constexpr int kLdsCap = 32;
     hipLaunchKernelGGL(merge_rows_lds<kLdsCap>, dim3(nblk(n_rows, 128)), dim3(128), 0, ctx->stream, n_rows, slot_ptr, key,
                        val, row_len);
+    // rows beyond the LDS pass (transposed prolongators and products of the coarse levels: hundreds of entries): one
+    // wave sorts each, the one-lane merge then walks a sorted row
+    hipLaunchKernelGGL(sort_long_rows_wave, dim3(std::min(nblk(n_rows, 256), 2048u)), dim3(256), 0, ctx->stream, n_rows,
+                       (const int *)nullptr, slot_ptr, key, val, kLdsCap + 1, 0);
     hipLaunchKernelGGL(merge_rows<false>, dim3(nblk(n_rows, 128)), dim3(128), 0, ctx->stream, n_rows, 0LL, 0,
                        (const long long *)nullptr, (const double *)nullptr, slot_ptr, key, val, row_len,
-                       (int *)nullptr, kLdsCap + 1);
+                       (int *)nullptr, kLdsCap + 1, (const int *)nullptr, kWaveSortCap);
     PADNE_HIP_CHECK(hipGetLastError());
     return PADNE_OK;
 }
