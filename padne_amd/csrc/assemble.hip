@@ -202,11 +202,16 @@ __global__ void asm_count_tri(long long n_tri, const int *__restrict__ tri, int 
     }
 }
 
-// slots of a row: its diagonal placeholder, two per incident triangle, one per stamp
-__global__ void asm_slot_counts(long long n, const int *__restrict__ n_inc, const int *__restrict__ n_coo,
+// slots of a row.  A mesh vertex without stamps and with at most kIncCap triangles is finished by
+// asm_rows_from_incidence, which writes at most one entry per neighbour plus the diagonal: a manifold fan of T triangles
+// has at most T + 1 neighbours.  Every other row goes through the slots: its diagonal placeholder, two per incident
+// triangle, one per stamp.  (Half the slot memory, and the 32-bit offsets last for 1.5 times as many vertices.)
+__global__ void asm_slot_counts(long long n, long long n_vert, const int *__restrict__ n_inc, const int *__restrict__ n_coo,
                                 int *__restrict__ cnt) {
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < n) cnt[r] = 1 + 2 * n_inc[r] + n_coo[r];
+    if (r >= n) return;
+    const bool direct = r < n_vert && n_coo[r] == 0 && n_inc[r] <= kIncCap;
+    cnt[r] = direct ? n_inc[r] + 2 : 1 + 2 * n_inc[r] + n_coo[r];
 }
 
 __global__ void asm_count_coo(long long n_coo, const int *__restrict__ row, int *__restrict__ cnt) {
@@ -274,7 +279,7 @@ __global__ void asm_fill_tri(long long n_tri, const int *__restrict__ tri, const
 // asm_fill_tri), keeps one entry per neighbour in LDS, sorts the few entries by column and writes the finished row at
 // its slot offset -- no slot traffic, no float atomics.  Bit-identical to the slot path: an entry is the sum of at
 // most one forward and one backward term (a + b == b + a), the diagonal is -(w_1 + w_2 + ...) in ascending column
-// order.  Rows it does not take (stamps, more than CAP triangles, neighbour list overflow of a non-manifold fan) are
+// order.  Rows it does not take (stamps, more than CAP triangles) are
 // marked row_len = -1, listed in slow_list, and go through the slots (asm_fill_tri with only_flagged, the merge
 // kernels over the list).
 template <int CAP>
@@ -293,14 +298,14 @@ __global__ __launch_bounds__(128) void asm_rows_from_incidence(
     if (r >= n_vert) return;
     const long long i0 = r * CAP;
     const int T = n_inc[r];
-    bool slow = n_coo[r] != 0 || T > CAP;
+    const bool slow = n_coo[r] != 0 || T > CAP;
     int nn = 0;
     bool bad = false;
     if (!slow) {
         const int m = find_segment(mesh_voff, n_mesh, r);
         const long long v0 = mesh_voff[m];
         const double vx = xy[2 * r], vy = xy[2 * r + 1];
-        for (int q = 0; q < T && !slow; ++q) {
+        for (int q = 0; q < T; ++q) {
             const long long tt = inc[i0 + q];
             const int a = (int)(v0 + tri[3 * tt]), b = (int)(v0 + tri[3 * tt + 1]), c = (int)(v0 + tri[3 * tt + 2]);
             int j, k;                       // r -> j is the edge leaving r in this triangle, k -> r the one arriving
@@ -320,13 +325,15 @@ __global__ __launch_bounds__(128) void asm_rows_from_incidence(
                     if (Fc[u][t] & bit) bad = true;                  // two triangles on the same side of an edge
                     Wc[u][t] = (Fc[u][t] == 1) ? Wc[u][t] + w : w + Wc[u][t];      // forward + backward, as the merge adds them
                     Fc[u][t] |= bit;
-                } else if (nn <= CAP) {
+                } else if (nn <= T) {                                // a manifold fan of T triangles has at most T + 1 neighbours: the row owns T + 2 slots
                     Cc[nn][t] = col;
                     Wc[nn][t] = w;
                     Fc[nn][t] = bit;
                     ++nn;
                 } else {
-                    slow = true;                                     // more neighbours than a manifold fan has
+                    bad = true;                                      // more neighbours than a manifold fan has
+                    nn = 0;
+                    q = T;
                     break;
                 }
             }
@@ -1147,8 +1154,8 @@ extern "C" int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns, int64_t
                            d_voff, d_toff, d_ninc, d_inc, d_err);
     if (n_coo > 0)
         hipLaunchKernelGGL(asm_count_coo, dim3(nblk(n_coo)), dim3(256), 0, s, (long long)n_coo, d_crow, d_ncoo);
-    hipLaunchKernelGGL(asm_slot_counts, dim3(nblk(n_unknowns + 1)), dim3(256), 0, s, (long long)n_unknowns + 1, d_ninc, d_ncoo,
-                       d_cnt);
+    hipLaunchKernelGGL(asm_slot_counts, dim3(nblk(n_unknowns + 1)), dim3(256), 0, s, (long long)n_unknowns + 1, (long long)n_vert,
+                       d_ninc, d_ncoo, d_cnt);
     PADNE_HIP_CHECK(hipGetLastError());
     int h_err[ERR_WORDS];
     PADNE_HIP_CHECK(hipMemcpyAsync(h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
