@@ -228,6 +228,11 @@ int padne_power_density(padne_ctx *ctx, int64_t n_vert, const double *xy_host,
                         const int64_t *mesh_tri_offset, const double *conductance,
                         const double *potential_host, double *power_out_host);
 
+/* The same power densities for the mesh an assembled system was built from: padne_assemble_system leaves the mesh
+ * on the device with the matrix, so only the potentials travel (n_vert doubles up, n_tri doubles down).
+ * potential_host: the first n_vert entries of the solution in the global vertex numbering. */
+int padne_csr_power_density(padne_ctx *ctx, const padne_csr *m, const double *potential_host, double *power_out_host);
+
 /* per-face gradient of the linear interpolant of `potential` (compute_triangle_gradient,
  * solver.py:689-725), faces visited as (v3, v1, v2) like Face.vertices (mesh.py:320-325) */
 int padne_face_gradient(padne_ctx *ctx, int64_t n_vert, const double *xy_host,

@@ -95,6 +95,7 @@ SIGNATURES = {
     "padne_amg_level": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
     "padne_nearest_vertex": (C.c_int, [_P, _I64, _PF64, _I64, _PF64, _PI64]),
     "padne_power_density": (C.c_int, [_P, _I64, _PF64, _I64, _PI32, _I64, _PI64, _PI64, _PF64, _PF64, _PF64]),
+    "padne_csr_power_density": (C.c_int, [_P, _P, _PF64, _PF64]),
     "padne_face_gradient": (C.c_int, [_P, _I64, _PF64, _I64, _PI32, _I64, _PI64, _PI64, _PF64, _PF64, _PF64]),
     "padne_spmv_algorithmic_bytes": (_I64, [_P]),
     "padne_spmv_time": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _PF64]),
@@ -456,6 +457,13 @@ class CsrMatrix:
         _check(self.ctx._lib.padne_csr_relabel(self.ctx._h, self._h, _ptr(rm, _PI32), int(n_rows_out), _ptr(cm, _PI32),
                                                int(n_cols_out), float(scale), C.byref(h)))
         return CsrMatrix(self.ctx, h)
+
+    def power_density(self, potential: np.ndarray, n_tri: int) -> np.ndarray:
+        """Per-triangle power density on the mesh this system was assembled from (kept on the device with it)."""
+        pot = _f64(potential)
+        out = np.empty(int(n_tri), dtype=np.float64)
+        _check(self.ctx._lib.padne_csr_power_density(self.ctx._h, self._h, _ptr(pot, _PF64), _ptr(out, _PF64)))
+        return out
 
     def vstack(self, bottom: "CsrMatrix") -> "CsrMatrix":
         h = _P()

@@ -902,12 +902,18 @@ __global__ void power_density_kernel(long long n_tri, const int *__restrict__ tr
                                      int n_mesh, const long long *__restrict__ mesh_voff,
                                      const long long *__restrict__ mesh_toff, const double *__restrict__ sigma,
                                      const double *__restrict__ pot, double *__restrict__ out,
-                                     double *__restrict__ gx_out, double *__restrict__ gy_out) {
+                                     double *__restrict__ gx_out, double *__restrict__ gy_out, int *__restrict__ err) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tri) return;
     const int m = find_segment(mesh_toff, n_mesh, t);
     const long long v0 = mesh_voff[m];
-    const long long g1 = v0 + tri[3 * t + 2], g2 = v0 + tri[3 * t], g3 = v0 + tri[3 * t + 1];
+    const long long nv = mesh_voff[m + 1] - v0;
+    const int l1 = tri[3 * t + 2], l2 = tri[3 * t], l3 = tri[3 * t + 1];
+    if (l1 < 0 || l2 < 0 || l3 < 0 || l1 >= nv || l2 >= nv || l3 >= nv) {      // checked here instead of in a host loop over all triangles
+        *(volatile int *)err = 1;
+        return;
+    }
+    const long long g1 = v0 + l1, g2 = v0 + l2, g3 = v0 + l3;
     const double x1 = xy[2 * g1], y1 = xy[2 * g1 + 1];
     const double x2 = xy[2 * g2], y2 = xy[2 * g2 + 1];
     const double x3 = xy[2 * g3], y3 = xy[2 * g3 + 1];
@@ -1110,11 +1116,19 @@ extern "C" int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns, int64_t
     double *d_xy = nullptr, *d_sigma = nullptr, *d_cval = nullptr;
     int *d_tri = nullptr, *d_crow = nullptr, *d_ccol = nullptr, *d_cnt = nullptr, *d_slot = nullptr, *d_err = nullptr;
     long long *d_voff = nullptr, *d_toff = nullptr;
-    PADNE_TRY(sc.alloc(&d_xy, (size_t)n_vert * 2));
-    PADNE_TRY(sc.alloc(&d_tri, (size_t)n_tri * 3));
-    PADNE_TRY(sc.alloc(&d_sigma, (size_t)n_mesh));
-    PADNE_TRY(sc.alloc(&d_voff, (size_t)n_mesh + 1));
-    PADNE_TRY(sc.alloc(&d_toff, (size_t)n_mesh + 1));
+    // the mesh arrays outlive this call: they are handed to the matrix at the end (MeshKeep frees them on any error path)
+    struct MeshKeep {
+        padne_ctx *ctx;
+        void *p[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        bool released = false;
+        ~MeshKeep() { if (!released) for (void *q : p) pool_free(ctx, q); }
+    } keep{ctx};
+    keep.p[0] = d_xy = (double *)pool_alloc(ctx, sizeof(double) * ((size_t)n_vert * 2 + 1));
+    keep.p[1] = d_tri = (int *)pool_alloc(ctx, sizeof(int) * ((size_t)n_tri * 3 + 1));
+    keep.p[2] = d_sigma = (double *)pool_alloc(ctx, sizeof(double) * ((size_t)n_mesh + 1));
+    keep.p[3] = d_voff = (long long *)pool_alloc(ctx, sizeof(long long) * ((size_t)n_mesh + 1));
+    keep.p[4] = d_toff = (long long *)pool_alloc(ctx, sizeof(long long) * ((size_t)n_mesh + 1));
+    if (!d_xy || !d_tri || !d_sigma || !d_voff || !d_toff) return PADNE_E_NOMEM;
     PADNE_TRY(sc.alloc(&d_crow, (size_t)n_coo));
     PADNE_TRY(sc.alloc(&d_ccol, (size_t)n_coo));
     PADNE_TRY(sc.alloc(&d_cval, (size_t)n_coo));
@@ -1195,8 +1209,46 @@ extern "C" int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns, int64_t
         PADNE_HIP_CHECK(hipGetLastError());
     }
     // 5-7 merge of the slot rows, scan, compaction
-    return finish_rows<true>(ctx, sc, n_unknowns, n_unknowns, n_vert, (int)n_mesh, d_voff, d_sigma, d_slot, d_key,
-                             d_val, d_err, out, d_rowlen, d_list, (long long)h_slow);
+    PADNE_TRY(finish_rows<true>(ctx, sc, n_unknowns, n_unknowns, n_vert, (int)n_mesh, d_voff, d_sigma, d_slot, d_key,
+                                d_val, d_err, out, d_rowlen, d_list, (long long)h_slow));
+    padne_csr *res = *out;
+    res->mesh_xy = d_xy;
+    res->mesh_tri = d_tri;
+    res->mesh_sigma = d_sigma;
+    res->mesh_voff = d_voff;
+    res->mesh_toff = d_toff;
+    res->mesh_n_vert = n_vert;
+    res->mesh_n_tri = n_tri;
+    res->mesh_n_mesh = n_mesh;
+    keep.released = true;
+    return PADNE_OK;
+}
+
+// Power density of a solution on the mesh the matrix was assembled from (kept on the device): uploads the potentials,
+// downloads one value per triangle.  compute_power_density, solver.py:728-745, for all meshes in one launch.
+extern "C" int padne_csr_power_density(padne_ctx *ctx, const padne_csr *m, const double *potential_host,
+                                       double *power_out_host) {
+    PADNE_REQUIRE(ctx && m, "null argument");
+    PADNE_REQUIRE(m->mesh_n_mesh > 0 || m->mesh_n_tri == 0, "the matrix does not carry a mesh (only padne_assemble_system keeps it)");
+    if (m->mesh_n_tri == 0) return PADNE_OK;
+    PADNE_REQUIRE(potential_host && power_out_host, "null argument");
+    PADNE_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    Scratch sc(ctx);
+    double *d_pot = nullptr, *d_out = nullptr;
+    int *d_bad = nullptr;
+    PADNE_TRY(sc.alloc(&d_pot, (size_t)m->mesh_n_vert));
+    PADNE_TRY(sc.alloc(&d_out, (size_t)m->mesh_n_tri));
+    PADNE_TRY(sc.alloc(&d_bad, 1));
+    PADNE_HIP_CHECK(hipMemsetAsync(d_bad, 0, sizeof(int), s));
+    PADNE_HIP_CHECK(hipMemcpyAsync(d_pot, potential_host, sizeof(double) * (size_t)m->mesh_n_vert, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(power_density_kernel, dim3(nblk(m->mesh_n_tri)), dim3(256), 0, s, (long long)m->mesh_n_tri, m->mesh_tri,
+                       m->mesh_xy, (int)m->mesh_n_mesh, m->mesh_voff, m->mesh_toff, m->mesh_sigma, d_pot, d_out,
+                       (double *)nullptr, (double *)nullptr, d_bad);
+    PADNE_HIP_CHECK(hipGetLastError());
+    PADNE_HIP_CHECK(hipMemcpyAsync(power_out_host, d_out, sizeof(double) * (size_t)m->mesh_n_tri, hipMemcpyDeviceToHost, s));
+    PADNE_HIP_CHECK(hipStreamSynchronize(s));
+    return PADNE_OK;
 }
 
 // out = scale * R^T M C: entry (i, j, v) becomes (row_map[i], col_map[j], scale*v) when both maps are >= 0,
@@ -1369,18 +1421,18 @@ static int face_fields(padne_ctx *ctx, int64_t n_vert, const double *xy_host, in
                   "null argument");
     PADNE_REQUIRE(power_out_host == nullptr || conductance != nullptr, "conductance");
     PADNE_REQUIRE(mesh_vertex_offset[n_mesh] == n_vert && mesh_tri_offset[n_mesh] == n_tri, "offset tables");
-    for (int64_t m = 0; m < n_mesh; ++m) {
-        const int64_t nv = mesh_vertex_offset[m + 1] - mesh_vertex_offset[m];
-        for (int64_t t = mesh_tri_offset[m]; t < mesh_tri_offset[m + 1]; ++t)
-            for (int c = 0; c < 3; ++c)
-                PADNE_REQUIRE(tri_host[3 * t + c] >= 0 && tri_host[3 * t + c] < nv, "triangle index out of range");
-    }
+    PADNE_REQUIRE(mesh_vertex_offset[0] == 0 && mesh_tri_offset[0] == 0, "offset tables must start at 0");
+    for (int64_t m = 0; m < n_mesh; ++m)
+        PADNE_REQUIRE(mesh_vertex_offset[m] <= mesh_vertex_offset[m + 1] && mesh_tri_offset[m] <= mesh_tri_offset[m + 1],
+                      "offset tables not monotone");
     PADNE_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     Scratch sc(ctx);
     double *d_xy = nullptr, *d_sigma = nullptr, *d_pot = nullptr, *d_out = nullptr, *d_gx = nullptr, *d_gy = nullptr;
-    int *d_tri = nullptr;
+    int *d_tri = nullptr, *d_bad = nullptr;
     long long *d_voff = nullptr, *d_toff = nullptr;
+    PADNE_TRY(sc.alloc(&d_bad, 1));
+    PADNE_HIP_CHECK(hipMemsetAsync(d_bad, 0, sizeof(int), s));
     PADNE_TRY(sc.alloc(&d_xy, (size_t)n_vert * 2));
     PADNE_TRY(sc.alloc(&d_tri, (size_t)n_tri * 3));
     PADNE_TRY(sc.alloc(&d_sigma, (size_t)n_mesh));
@@ -1400,8 +1452,10 @@ static int face_fields(padne_ctx *ctx, int64_t n_vert, const double *xy_host, in
     PADNE_HIP_CHECK(hipMemcpyAsync(d_toff, mesh_tri_offset, sizeof(long long) * (size_t)(n_mesh + 1), hipMemcpyHostToDevice, s));
     PADNE_HIP_CHECK(hipMemcpyAsync(d_pot, potential_host, sizeof(double) * (size_t)n_vert, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(power_density_kernel, dim3(nblk(n_tri)), dim3(256), 0, s, (long long)n_tri, d_tri, d_xy, (int)n_mesh,
-                       d_voff, d_toff, d_sigma, d_pot, d_out, d_gx, d_gy);
+                       d_voff, d_toff, d_sigma, d_pot, d_out, d_gx, d_gy, d_bad);
     PADNE_HIP_CHECK(hipGetLastError());
+    int h_bad = 0;
+    PADNE_HIP_CHECK(hipMemcpyAsync(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, s));
     if (power_out_host)
         PADNE_HIP_CHECK(hipMemcpyAsync(power_out_host, d_out, sizeof(double) * (size_t)n_tri, hipMemcpyDeviceToHost, s));
     if (gx_out_host) {
@@ -1409,6 +1463,10 @@ static int face_fields(padne_ctx *ctx, int64_t n_vert, const double *xy_host, in
         PADNE_HIP_CHECK(hipMemcpyAsync(gy_out_host, d_gy, sizeof(double) * (size_t)n_tri, hipMemcpyDeviceToHost, s));
     }
     PADNE_HIP_CHECK(hipStreamSynchronize(s));
+    if (h_bad) {
+        set_error("invalid argument: triangle index out of range");
+        return PADNE_E_INVALID;
+    }
     return PADNE_OK;
 }
 

@@ -297,6 +297,11 @@ int padne_csr_destroy(padne_csr *m) {
         pool_free(m->owner, m->vals32);
         pool_free(m->owner, m->dinv32);
         pool_free(m->owner, m->xw_desc);
+        pool_free(m->owner, m->mesh_xy);
+        pool_free(m->owner, m->mesh_sigma);
+        pool_free(m->owner, m->mesh_tri);
+        pool_free(m->owner, m->mesh_voff);
+        pool_free(m->owner, m->mesh_toff);
         pool_free(m->owner, m->xw_lidx);
     }
     delete m;

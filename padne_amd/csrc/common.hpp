@@ -70,6 +70,12 @@ struct padne_csr {
     int xw_run = 0;                      // entries per staged run (72 for scan-line meshes, 128 for strip-ordered ones)
     bool hierarchy_operator = false;   // multigrid-internal operator: may use the wave-per-row SpMV
     padne_csr *prec_block = nullptr;   // borrowed: owned x owned diagonal block for the preconditioner
+    // the mesh the system was assembled from stays on the device with it (padne_assemble_system), so that the
+    // post-processing of the solution (padne_csr_power_density) does not upload 40 bytes per vertex again
+    double *mesh_xy = nullptr, *mesh_sigma = nullptr;
+    int32_t *mesh_tri = nullptr;
+    long long *mesh_voff = nullptr, *mesh_toff = nullptr;
+    int64_t mesh_n_vert = 0, mesh_n_tri = 0, mesh_n_mesh = 0;
 };
 
 struct padne_ctx {

@@ -583,15 +583,20 @@ def compute_power_density(voltage: mesh.ZeroForm, conductivity: float) -> mesh.T
 
 
 def produce_layer_solutions(layers, vindex: VertexIndexer, meshes, mesh_index_to_layer_index, v: np.ndarray,
-                            disconnected_meshes_by_layer) -> list:
+                            disconnected_meshes_by_layer, system: Optional["SystemMatrix"] = None) -> list:
     """``solver.py:578-615``.  Each mesh's unknowns are one contiguous block of ``v``, so the scatter
     is a slice; the power densities of all meshes come from one kernel launch."""
     ctx = get_context()
     sig = [layers[mesh_index_to_layer_index[i]].conductance for i in range(len(meshes))]
     power_all = None
-    if meshes and sum(len(m.triangles) for m in meshes):
-        xy, tri, mvo, mto, sg = _flatten_meshes(meshes, sig)
-        power_all = ctx.power_density(xy, tri, mvo, mto, sg, v[:len(vindex)])
+    n_tri = sum(len(m.triangles) for m in meshes)
+    if meshes and n_tri:
+        if system is not None and system.tri is not None and len(system.tri) == n_tri:
+            # the system was assembled from these meshes: they are still on the device, only the potentials travel
+            power_all = system.dev.power_density(v[:len(vindex)], n_tri)
+        else:
+            xy, tri, mvo, mto, sg = _flatten_meshes(meshes, sig)
+            power_all = ctx.power_density(xy, tri, mvo, mto, sg, v[:len(vindex)])
     toff = np.concatenate([[0], np.cumsum([len(m.triangles) for m in meshes])]).astype(np.int64)
     out = []
     for layer_i, _layer in enumerate(layers):
@@ -631,8 +636,11 @@ def solve_meshed(prob, meshes, mesh_index_to_layer_index, *, filtered_networks=N
     log.info("Assembling the global system")
     L, r = assemble_system(prob, meshes, mesh_index_to_layer_index, vindex, filtered_networks, node_indexer)
     log.info("Solving the system of equations")
-    v, solver_info = solve_system(L, r)
-    L.dev.close()
+    try:
+        v, solver_info = solve_system(L, r)
+    except BaseException:
+        L.dev.close()
+        raise
     if not np.isclose(solver_info.ground_node_current, 0):
         warnings.warn(
             f"Ground node current is not zero ({solver_info.ground_node_current} A), this may indicate an issue "
@@ -640,8 +648,12 @@ def solve_meshed(prob, meshes, mesh_index_to_layer_index, *, filtered_networks=N
             "components. This may be harmless if the current is small, but it may indicate an "
             "ill-conditioned system.", SolverWarning)
     log.info("Producing the solution object")
-    layer_solutions = produce_layer_solutions(prob.layers, vindex, meshes, mesh_index_to_layer_index, v,
-                                              disconnected_meshes_by_layer)
+    try:
+        # the mesh is still on the device with the assembled system: the power densities need only the potentials
+        layer_solutions = produce_layer_solutions(prob.layers, vindex, meshes, mesh_index_to_layer_index, v,
+                                                  disconnected_meshes_by_layer, system=L)
+    finally:
+        L.dev.close()
     return Solution(problem=prob, layer_solutions=layer_solutions, solver_info=solver_info)
 
 

@@ -23,8 +23,7 @@ for rep in range(3):
     ctx.synchronize(); t2 = time.perf_counter()
     v, info = solver.solve_system(L, r)
     t3 = time.perf_counter()
-    xy, tri, mvo, mto, sg = solver._flatten_meshes(meshes, sig)
-    pd = ctx.power_density(xy, tri, mvo, mto, sg, v[:nv])
+    pd = L.dev.power_density(v[:nv], len(L.tri))          # the mesh stayed on the device with the assembled system
     t4 = time.perf_counter()
     L.dev.close()
     print(f"[{name}] stamps(list) {t1-t0:.3f} s | assemble (H2D 0.4 GB + kernels) {t2-t1:.3f} s | solve_system (host reduction + device) {t3-t2:.3f} s "

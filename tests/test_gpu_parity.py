@@ -369,6 +369,12 @@ def test_power_density_vs_golden(ctx, name):
         return
     xy, tri, mvo, mto, sig = flat(ms)
     got = ctx.power_density(xy, tri, mvo, mto, sig, g["v"])
+    # the same through the mesh an assembled system keeps on the device
+    empty = np.zeros(0, dtype=np.int64)
+    n_vert = len(xy)
+    Ld = ctx.assemble_system(n_vert, xy, tri, mvo, mto, sig, empty, empty, np.zeros(0))
+    assert np.array_equal(Ld.power_density(g["v"][:n_vert], len(tri)), got)
+    Ld.close()
     want = np.concatenate([g[f"pow{i}"] for i in range(len(ms))])
     assert np.array_equal(got, want)
     for i, (pxy, ptri, s, _) in enumerate(ms):                        # and through the ZeroForm seam
