@@ -1404,7 +1404,7 @@ static int transpose(padne_ctx *ctx, const padne_csr *M, padne_csr **T) {
         hipLaunchKernelGGL(transpose_fill, dim3(nblk(M->n_rows)), dim3(256), 0, s, (int)M->n_rows, M->rowptr, M->cols,
                            M->vals, slot_ptr, cnt, key, val);
     PADNE_HIP_CHECK(hipGetLastError());
-    PADNE_TRY(merge_slots_generic(ctx, nc, slot_ptr, key, val, row_len));
+    PADNE_TRY(sort_slots_exact(ctx, nc, slot_ptr, key, val, row_len));
     // a transpose has no duplicates: the counted slots are exact and, once sorted, already the CSR rows
     // (the scratch arrays go back to the pool without a synchronisation: reuse is ordered on the context's stream)
     return csr_from_exact_slots(ctx, nc, M->n_rows, tot, slot_ptr, key, val, T);

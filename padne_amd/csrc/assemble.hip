@@ -446,24 +446,26 @@ __device__ __forceinline__ void sort_slots(long long *key, double *val, int n) {
 // order), sorted slots back in place.  merge_rows then finds the row sorted -- its insertion sort degenerates to one
 // pass -- and walks it as before: same operations in the same order.
 constexpr int kWaveSortCap = 1024;
+template <int CAPW, int CHUNK = 64>      // slots per wave in LDS (1024 for the long rows, 64 when every row of a transpose is sorted
+                                          // this way); rows a wave examines per turn (few when most of them qualify)
 __global__ __launch_bounds__(256) void sort_long_rows_wave(long long n_list, const int *__restrict__ row_list,
                                                            const int *__restrict__ slot_ptr, long long *__restrict__ key,
                                                            double *__restrict__ val, const int min_len, const int mesh) {
-    __shared__ long long Ks[4][kWaveSortCap];
-    __shared__ double Vs[4][kWaveSortCap];
+    __shared__ long long Ks[4][CAPW];
+    __shared__ double Vs[4][CAPW];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long long n_waves = (long long)gridDim.x * 4;
     // a wave looks at 64 rows at a time (one lane each, coalesced reads of the offsets) and sorts the long ones it finds
-    for (long long c0 = ((long long)blockIdx.x * 4 + w) * 64; c0 < n_list; c0 += n_waves * 64) {
+    for (long long c0 = ((long long)blockIdx.x * 4 + w) * CHUNK; c0 < n_list; c0 += n_waves * CHUNK) {
         const long long idx = c0 + lane;
         long long r_l = 0;
         int s0_l = 0, n_l = 0;
-        if (idx < n_list) {
+        if (lane < CHUNK && idx < n_list) {
             r_l = row_list != nullptr ? row_list[idx] : idx;
             s0_l = slot_ptr[r_l];
             n_l = slot_ptr[r_l + 1] - s0_l;
         }
-        unsigned long long todo = __ballot(n_l >= min_len && n_l <= kWaveSortCap);
+        unsigned long long todo = __ballot(n_l >= min_len && n_l <= CAPW);
         while (todo != 0ull) {
             const int b = __ffsll((long long)todo) - 1;
             todo &= todo - 1ull;
@@ -963,8 +965,8 @@ static int finish_rows(padne_ctx *ctx, Scratch &sc, long long n_rows, long long 
             PADNE_HIP_CHECK(hipStreamSynchronize(s));
         }
         if (h_long[ERR_LONG_ROWS]) {               // rows with more than kCap slots (hubs): wave sort, then the global-memory merge
-            hipLaunchKernelGGL(sort_long_rows_wave, dim3(std::min(nblk(n_merge, 256), 2048u)), dim3(256), 0, s, n_merge, row_list,
-                               slot_ptr, key, val, kCap + 1, 1);
+            hipLaunchKernelGGL(sort_long_rows_wave<kWaveSortCap>, dim3(std::min(nblk(n_merge, 256), 2048u)), dim3(256), 0, s, n_merge,
+                               row_list, slot_ptr, key, val, kCap + 1, 1);
             hipLaunchKernelGGL(merge_rows<MESH>, dim3(nblk(n_merge, 128)), dim3(128), 0, s, n_merge, n_vert, n_mesh, d_voff,
                                d_sigma, slot_ptr, key, val, row_len, d_err, kCap + 1, row_list, kWaveSortCap);
             PADNE_HIP_CHECK(hipGetLastError());
@@ -1011,8 +1013,8 @@ int merge_slots_generic(padne_ctx *ctx, long long n_rows, const int *slot_ptr, l
                        val, row_len);
     // rows beyond the LDS pass (transposed prolongators and products of the coarse levels: hundreds of entries): one
     // wave sorts each, the one-lane merge then walks a sorted row
-    hipLaunchKernelGGL(sort_long_rows_wave, dim3(std::min(nblk(n_rows, 256), 2048u)), dim3(256), 0, ctx->stream, n_rows,
-                       (const int *)nullptr, slot_ptr, key, val, kLdsCap + 1, 0);
+    hipLaunchKernelGGL(sort_long_rows_wave<kWaveSortCap>, dim3(std::min(nblk(n_rows, 256), 2048u)), dim3(256), 0, ctx->stream,
+                       n_rows, (const int *)nullptr, slot_ptr, key, val, kLdsCap + 1, 0);
     hipLaunchKernelGGL(merge_rows<false>, dim3(nblk(n_rows, 128)), dim3(128), 0, ctx->stream, n_rows, 0LL, 0,
                        (const long long *)nullptr, (const double *)nullptr, slot_ptr, key, val, row_len,
                        (int *)nullptr, kLdsCap + 1, (const int *)nullptr, kWaveSortCap);
@@ -1055,6 +1057,21 @@ __global__ void unpack_slots_kernel(long long nnz, const long long *__restrict__
         cols[k] = (int)(key[k] >> 32);
         vals[k] = val[k];
     }
+}
+
+// Slots that only need sorting (a transpose: no duplicates, nothing to add or drop): every row by one wave -- rank by
+// counting smaller keys in LDS, rows of up to 64 slots at full occupancy, longer ones with the 1024-slot variant, the
+// rare rest by the one-lane insertion sort.
+int sort_slots_exact(padne_ctx *ctx, long long n_rows, const int *slot_ptr, long long *key, double *val, int *row_len_scratch) {
+    hipLaunchKernelGGL((sort_long_rows_wave<64, 8>), dim3(std::min(nblk(n_rows, 32), 8192u)), dim3(256), 0, ctx->stream, n_rows,
+                       (const int *)nullptr, slot_ptr, key, val, 2, 0);
+    hipLaunchKernelGGL(sort_long_rows_wave<kWaveSortCap>, dim3(std::min(nblk(n_rows, 256), 2048u)), dim3(256), 0, ctx->stream, n_rows,
+                       (const int *)nullptr, slot_ptr, key, val, 65, 0);
+    hipLaunchKernelGGL(merge_rows<false>, dim3(nblk(n_rows, 128)), dim3(128), 0, ctx->stream, n_rows, 0LL, 0,
+                       (const long long *)nullptr, (const double *)nullptr, slot_ptr, key, val, row_len_scratch,
+                       (int *)nullptr, kWaveSortCap + 1);
+    PADNE_HIP_CHECK(hipGetLastError());
+    return PADNE_OK;
 }
 
 int csr_from_exact_slots(padne_ctx *ctx, long long n_rows, long long n_cols, long long nnz, const int *slot_ptr,

@@ -202,6 +202,8 @@ static inline unsigned nblk(long long n, int bs = 256) {
 // sort each row's slots by key = (col << 32 | seq), add duplicates in key order, compact in place
 int merge_slots_generic(padne_ctx *ctx, long long n_rows, const int *slot_ptr, long long *key, double *val,
                         int *row_len);
+// slots without duplicates (transposes): sort each row by key, nothing else
+int sort_slots_exact(padne_ctx *ctx, long long n_rows, const int *slot_ptr, long long *key, double *val, int *row_len_scratch);
 // rows already compacted at their slot offsets (key >> 32 = column) -> new CSR matrix
 int csr_from_slots(padne_ctx *ctx, long long n_rows, long long n_cols, const int *slot_ptr, const long long *key,
                    const double *val, const int *row_len, padne_csr **out);
