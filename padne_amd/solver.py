@@ -435,14 +435,24 @@ def _solve_reduced(A: _hip.CsrMatrix, b: np.ndarray, rtol: float):
     if not np.any(b):
         return np.zeros_like(b), 0, 0.0, 0.0
     res = A.solve_spd(b, rtol=rtol, max_iter=MAX_ITER, raise_on_fail=False)
-    if res.status != _hip.OK:
-        # The reference's direct solve always returns *an* answer and reports its quality through
-        # SolverInfo.residual_norm; an iteration that stalls above the requested tolerance (matrices with entry
-        # ratios beyond 1e12, e.g. needle triangles, put the floor of b - A x in binary64 there) does the same,
-        # with a warning in the reference's own soft-failure style (solver.py:880-888).
+    _warn_if_stalled(res, rtol)
+    return res.x, res.iterations, res.rel_residual, res.seconds
+
+
+STALL_WARN_ABOVE = 1e-9
+
+
+def _warn_if_stalled(res, rtol: float) -> None:
+    """The reference's direct solve always returns *an* answer and reports its quality through
+    SolverInfo.residual_norm; an iteration that stalls above the requested tolerance does the same, with a warning in
+    the reference's own soft-failure style (solver.py:880-888) when the residual is worse than 1e-9 relative (matrices
+    with entry ratios beyond 1e12, e.g. needle triangles).  A stall between the requested 1e-12 and 1e-9 is the
+    rounding floor of evaluating b - A x for a system whose solution is large against its right-hand side (a layer
+    held at hundreds of volts through a weak link: 1 of 1000 random systems of scripts/fuzz_parity.py, potentials
+    still within 4e-11 of the direct solve); it is reported in SolverInfo.residual_norm and not warned about."""
+    if res.status != _hip.OK and not res.rel_residual <= max(rtol, STALL_WARN_ABOVE):
         warnings.warn(f"iterative solve stopped at a relative residual of {res.rel_residual:.2e} "
                       f"(requested {rtol:.1e}) after {res.iterations} iterations", SolverWarning)
-    return res.x, res.iterations, res.rel_residual, res.seconds
 
 
 def _solve_reduced_many(A: _hip.CsrMatrix, bs: list, rtol: float):
@@ -455,9 +465,7 @@ def _solve_reduced_many(A: _hip.CsrMatrix, bs: list, rtol: float):
     if not live:
         return sols, 0, 0.0, 0.0
     res = A.solve_spd(np.stack([bs[k] for k in live]), rtol=rtol, max_iter=MAX_ITER, raise_on_fail=False)
-    if res.status != _hip.OK:
-        warnings.warn(f"iterative solve stopped at a relative residual of {res.rel_residual:.2e} "
-                      f"(requested {rtol:.1e}) after {res.iterations} iterations", SolverWarning)
+    _warn_if_stalled(res, rtol)
     for row, k in enumerate(live):
         sols[k] = res.x[row]
     return sols, res.iterations, res.rel_residual, res.seconds
