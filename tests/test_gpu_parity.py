@@ -921,6 +921,18 @@ def test_headline_config_at_full_size(ctx, monkeypatch):
     A.close()
 
 
+def test_randomised_assembly_is_the_oracle_bit_for_bit(ctx):
+    """scripts/fuzz_assembly.py: random Delaunay meshes (holes, fans with more triangles around a vertex than the
+    incidence lists hold), random conductances and stamps, a hub row -- structure and values identical to the oracle."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_assembly", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_assembly.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    assert fz.run(16, seed0=5, verbose=False) > 12          # the sweep reached vertices beyond the in-LDS path
+
+
 def test_randomised_systems_against_the_direct_solve(ctx):
     """scripts/fuzz_parity.py: random multi-layer systems with vias, internal nodes, current sources, forests of
     voltage sources and regulators, in the reference's KKT layout; the product path against the reference's direct
