@@ -124,12 +124,19 @@ __device__ __forceinline__ bool strong(double a, double di, double dj, double th
 __global__ __launch_bounds__(256) void strength_mark(int n, int n_wtiles, const int *__restrict__ rowptr,
                                                      const int *__restrict__ cols, const double *__restrict__ vals,
                                                      const double *__restrict__ dinv, double theta2,
-                                                     int *__restrict__ scol) {
+                                                     int *__restrict__ scol, double *__restrict__ bound_partial) {
+    // bound_partial (optional): per-workgroup maxima of the Gershgorin bound of D_F^-1 A_F, the filtered operator
+    // the prolongator is smoothed with -- the same sums, in the same order, as gershgorin_filtered_kernel forms them
+    // one lane per row, taken here from the values this pass streams anyway (a separate pass over A cost 0.4 ms).
     constexpr int CH = 512;
-    __shared__ unsigned char rid_all[4 * CH];
+    __shared__ unsigned char rid_all[4 * CH];      // bits 0-5: lane of the element's row, bit 6: diagonal, bit 7: strong
+    __shared__ double pv_all[4 * CH];
+    __shared__ double red[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     unsigned char *rid = rid_all + w * CH;
+    double *pv = pv_all + w * CH;
     const long long W = (long long)gridDim.x * 4, gw = (long long)blockIdx.x * 4 + w;
+    double my_max = 0.0;
     for (long long wt = gw; wt < n_wtiles; wt += W) {
         const int row0 = (int)wt * 64;
         const int row1 = min(row0 + 64, n);
@@ -143,6 +150,7 @@ __global__ __launch_bounds__(256) void strength_mark(int n, int n_wtiles, const 
         }
         const int k0 = __shfl(rs, 0, 64);
         const int k1 = __shfl(re, row1 - row0 - 1, 64);
+        double dF = r < row1 ? 1.0 / di : 1.0, off_strong = 0.0, off_all = 0.0;
         for (int base = k0; base < k1; base += CH) {
             const int lo = max(rs, base), hi = min(re, base + CH);
             for (int k = lo; k < hi; ++k) rid[k - base] = (unsigned char)lane;
@@ -156,13 +164,45 @@ __global__ __launch_bounds__(256) void strength_mark(int n, int n_wtiles, const 
                 if (e < k1) {
                     const int i = row0 + rl;
                     const int c = cols[e];
-                    const bool st = c != i && strong(vals[e], dr, dinv[c], theta2);
+                    const double v = vals[e];
+                    const bool st = c != i && strong(v, dr, dinv[c], theta2);
                     scol[e] = st ? c : i;
+                    if (bound_partial != nullptr) {
+                        rid[e - base] = (unsigned char)(rl | (c == i ? 0x40 : 0) | (st ? 0x80 : 0));
+                        pv[e - base] = v;
+                    }
+                }
+            }
+            if (bound_partial != nullptr) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                for (int k = lo; k < hi; ++k) {                // one lane per row, in CSR order
+                    const unsigned char f = rid[k - base];
+                    if (f & 0x40) continue;
+                    const double v = pv[k - base];
+                    off_all += fabs(v);
+                    if (f & 0x80) off_strong += fabs(v);
+                    else dF += v;
                 }
             }
             asm volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         }
+        if (bound_partial != nullptr && r < row1) {
+            double off = off_strong;
+            if (!(dF * di > 0.05)) {                           // same rule as prolong_fill: such a row is not filtered
+                dF = 1.0 / di;
+                off = off_all;
+            }
+            const double sgm = (off + fabs(dF)) / fabs(dF);
+            my_max = sgm > my_max ? sgm : my_max;
+        }
+    }
+    if (bound_partial != nullptr) {
+        for (int o = 32; o > 0; o >>= 1) my_max = fmax(my_max, __shfl_down(my_max, o, 64));
+        if (lane == 0) red[w] = my_max;
+        __syncthreads();
+        if (threadIdx.x == 0) bound_partial[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
     }
 }
 
@@ -1184,7 +1224,7 @@ static int gershgorin(padne_ctx *ctx, const padne_csr *A, double *lambda, bool f
 }
 
 // aggregates of A -> device array agg[n], count n_agg
-static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_out, int *n_agg) {
+static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_out, int *n_agg, double *lambda_f = nullptr) {
     hipStream_t s = ctx->stream;
     const int n = (int)A->n_rows;
     const double theta2 = kTheta * kTheta;
@@ -1208,8 +1248,14 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
     PADNE_TRY(sc.alloc(&scol, (size_t)(A->nnz > 0 ? A->nnz : 1)));
     const int n_wt = (n + 63) / 64;
     const dim3 gm((unsigned)std::min(2048, (n_wt + 3) / 4 > 0 ? (n_wt + 3) / 4 : 1));
-    hipLaunchKernelGGL(strength_mark, gm, b, 0, s, n, n_wt, A->rowptr, A->cols, A->vals, A->dinv, theta2, scol);
+    // lambda_f: the Gershgorin bound of the filtered operator comes out of the same pass (read back with the first
+    // open count below: no synchronisation of its own)
+    double *bound_part = lambda_f != nullptr ? ctx->partials + 6 * kMaxPartials : nullptr;
+    std::vector<double> h_bound(lambda_f != nullptr ? (size_t)gm.x : 0);
+    hipLaunchKernelGGL(strength_mark, gm, b, 0, s, n, n_wt, A->rowptr, A->cols, A->vals, A->dinv, theta2, scol, bound_part);
     PADNE_HIP_CHECK(hipGetLastError());
+    if (lambda_f != nullptr)
+        PADNE_HIP_CHECK(hipMemcpyAsync(h_bound.data(), bound_part, sizeof(double) * h_bound.size(), hipMemcpyDeviceToHost, s));
     hipLaunchKernelGGL(mis_init_words, g, b, 0, s, n, w0);
     int open_count = n;
     int round = 0;
@@ -1259,6 +1305,13 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
         open_count = cnt;
     }
     PADNE_REQUIRE(open_count == 0, "independent-set rounds did not terminate");
+    if (lambda_f != nullptr) {
+        if (round == 0) PADNE_HIP_CHECK(hipStreamSynchronize(s));       // no round ran (n == 0): the copy above is still in flight
+        double m = 0.0;
+        for (double v : h_bound) m = v > m ? v : m;
+        if (!(m > 0.0) || !(m < 1e6)) m = 2.0;                           // as gershgorin()
+        *lambda_f = m;
+    }
     // number the roots
     hipLaunchKernelGGL(flag_state, g, b, 0, s, n, state, flag, 1);
     int64_t n_roots = 0;
@@ -1683,14 +1736,13 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         Scratch sc(ctx);
         int *agg = nullptr, n_agg = 0;
         PhaseTimer pt(ctx, amg_verbose());
-        if ((rc = aggregate(ctx, sc, A, &agg, &n_agg)) != PADNE_OK) { amg->levels.push_back(L); break; }
+        double lambda_f = 2.0;      // Gershgorin bound of the filtered operator, a by-product of the strength pass
+        if ((rc = aggregate(ctx, sc, A, &agg, &n_agg, &lambda_f)) != PADNE_OK) { amg->levels.push_back(L); break; }
         pt.lap("aggregate");
         if (n_agg == 0 || (double)n_agg > 0.8 * (double)A->n_rows) {   // coarsening stalled: stop here
             amg->levels.push_back(L);
             break;
         }
-        double lambda_f = 2.0;
-        if ((rc = gershgorin(ctx, A, &lambda_f, true)) != PADNE_OK) { amg->levels.push_back(L); break; }
         // omega uses Gershgorin bounds (filtered operator, capped by the unfiltered one): the sharper Lanczos
         // estimate of lambda(D^-1 A) over-relaxes the prolongator (44 instead of 34 CG iterations at N = 0.5 M)
         const double lambda_g = lambda_gershgorin;
@@ -2164,8 +2216,7 @@ static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0) {
         Scratch sc(ctx);
         int *agg = nullptr, n_agg = 0;
         double lambda_f = 2.0, lambda_g = 2.0;
-        if ((rc = csr_build_dinv(ctx, blk)) == PADNE_OK && (rc = aggregate(ctx, sc, blk, &agg, &n_agg)) == PADNE_OK &&
-            (rc = gershgorin(ctx, blk, &lambda_f, true)) == PADNE_OK)
+        if ((rc = csr_build_dinv(ctx, blk)) == PADNE_OK && (rc = aggregate(ctx, sc, blk, &agg, &n_agg, &lambda_f)) == PADNE_OK)
             rc = gershgorin(ctx, blk, &lambda_g, false);
         if (rc != PADNE_OK) { padne_csr_destroy(blk); break; }
         std::vector<double> ag = {(double)n_agg}, ags;
