@@ -125,18 +125,18 @@ __global__ __launch_bounds__(256) void strength_mark(int n, int n_wtiles, const 
                                                      const int *__restrict__ cols, const double *__restrict__ vals,
                                                      const double *__restrict__ dinv, double theta2,
                                                      int *__restrict__ scol, double *__restrict__ bound_partial) {
-    // bound_partial (optional): per-workgroup maxima of the Gershgorin bound of D_F^-1 A_F, the filtered operator
+    // bound_partial (optional): per-workgroup maxima of the Gershgorin bounds of D^-1 A (second row of kMaxPartials) and of D_F^-1 A_F, the filtered operator
     // the prolongator is smoothed with -- the same sums, in the same order, as gershgorin_filtered_kernel forms them
     // one lane per row, taken here from the values this pass streams anyway (a separate pass over A cost 0.4 ms).
     constexpr int CH = 512;
     __shared__ unsigned char rid_all[4 * CH];      // bits 0-5: lane of the element's row, bit 6: diagonal, bit 7: strong
     __shared__ double pv_all[4 * CH];
-    __shared__ double red[4];
+    __shared__ double red[4], red2[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     unsigned char *rid = rid_all + w * CH;
     double *pv = pv_all + w * CH;
     const long long W = (long long)gridDim.x * 4, gw = (long long)blockIdx.x * 4 + w;
-    double my_max = 0.0;
+    double my_max = 0.0, my_plain = 0.0;
     for (long long wt = gw; wt < n_wtiles; wt += W) {
         const int row0 = (int)wt * 64;
         const int row1 = min(row0 + 64, n);
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void strength_mark(int n, int n_wtiles, const 
         }
         const int k0 = __shfl(rs, 0, 64);
         const int k1 = __shfl(re, row1 - row0 - 1, 64);
-        double dF = r < row1 ? 1.0 / di : 1.0, off_strong = 0.0, off_all = 0.0;
+        double dF = r < row1 ? 1.0 / di : 1.0, off_strong = 0.0, off_all = 0.0, abs_all = 0.0;
         for (int base = k0; base < k1; base += CH) {
             const int lo = max(rs, base), hi = min(re, base + CH);
             for (int k = lo; k < hi; ++k) rid[k - base] = (unsigned char)lane;
@@ -178,8 +178,9 @@ __global__ __launch_bounds__(256) void strength_mark(int n, int n_wtiles, const 
                 __builtin_amdgcn_wave_barrier();
                 for (int k = lo; k < hi; ++k) {                // one lane per row, in CSR order
                     const unsigned char f = rid[k - base];
-                    if (f & 0x40) continue;
                     const double v = pv[k - base];
+                    abs_all += fabs(v);                        // every entry, diagonal included: gershgorin_kernel's sum
+                    if (f & 0x40) continue;
                     off_all += fabs(v);
                     if (f & 0x80) off_strong += fabs(v);
                     else dF += v;
@@ -196,13 +197,24 @@ __global__ __launch_bounds__(256) void strength_mark(int n, int n_wtiles, const 
             }
             const double sgm = (off + fabs(dF)) / fabs(dF);
             my_max = sgm > my_max ? sgm : my_max;
+            const double plain = abs_all * fabs(di);           // bound of D^-1 A itself, as gershgorin_kernel forms it
+            my_plain = plain > my_plain ? plain : my_plain;
         }
     }
     if (bound_partial != nullptr) {
-        for (int o = 32; o > 0; o >>= 1) my_max = fmax(my_max, __shfl_down(my_max, o, 64));
-        if (lane == 0) red[w] = my_max;
+        for (int o = 32; o > 0; o >>= 1) {
+            my_max = fmax(my_max, __shfl_down(my_max, o, 64));
+            my_plain = fmax(my_plain, __shfl_down(my_plain, o, 64));
+        }
+        if (lane == 0) {
+            red[w] = my_max;
+            red2[w] = my_plain;
+        }
         __syncthreads();
-        if (threadIdx.x == 0) bound_partial[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        if (threadIdx.x == 0) {
+            bound_partial[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+            bound_partial[kMaxPartials + blockIdx.x] = fmax(fmax(red2[0], red2[1]), fmax(red2[2], red2[3]));
+        }
     }
 }
 
@@ -1224,7 +1236,8 @@ static int gershgorin(padne_ctx *ctx, const padne_csr *A, double *lambda, bool f
 }
 
 // aggregates of A -> device array agg[n], count n_agg
-static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_out, int *n_agg, double *lambda_f = nullptr) {
+static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_out, int *n_agg, double *lambda_f = nullptr,
+                     double *lambda_plain = nullptr) {
     hipStream_t s = ctx->stream;
     const int n = (int)A->n_rows;
     const double theta2 = kTheta * kTheta;
@@ -1251,7 +1264,7 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
     // lambda_f: the Gershgorin bound of the filtered operator comes out of the same pass (read back with the first
     // open count below: no synchronisation of its own)
     double *bound_part = lambda_f != nullptr ? ctx->partials + 6 * kMaxPartials : nullptr;
-    std::vector<double> h_bound(lambda_f != nullptr ? (size_t)gm.x : 0);
+    std::vector<double> h_bound(lambda_f != nullptr ? (size_t)kMaxPartials + gm.x : 0);     // filtered | plain
     hipLaunchKernelGGL(strength_mark, gm, b, 0, s, n, n_wt, A->rowptr, A->cols, A->vals, A->dinv, theta2, scol, bound_part);
     PADNE_HIP_CHECK(hipGetLastError());
     if (lambda_f != nullptr)
@@ -1307,10 +1320,15 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
     PADNE_REQUIRE(open_count == 0, "independent-set rounds did not terminate");
     if (lambda_f != nullptr) {
         if (round == 0) PADNE_HIP_CHECK(hipStreamSynchronize(s));       // no round ran (n == 0): the copy above is still in flight
-        double m = 0.0;
-        for (double v : h_bound) m = v > m ? v : m;
+        double m = 0.0, mp = 0.0;
+        for (unsigned q = 0; q < gm.x; ++q) {
+            m = h_bound[q] > m ? h_bound[q] : m;
+            mp = h_bound[(size_t)kMaxPartials + q] > mp ? h_bound[(size_t)kMaxPartials + q] : mp;
+        }
         if (!(m > 0.0) || !(m < 1e6)) m = 2.0;                           // as gershgorin()
+        if (!(mp > 0.0) || !(mp < 1e6)) mp = 2.0;
         *lambda_f = m;
+        if (lambda_plain != nullptr) *lambda_plain = mp;
     }
     // number the roots
     hipLaunchKernelGGL(flag_state, g, b, 0, s, n, state, flag, 1);
@@ -1713,23 +1731,27 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         L.A_owned = (lvl == 0) ? nullptr : const_cast<padne_csr *>(A);
         L.n = A->n_rows;
         nnz_total += (double)A->nnz;
-        if ((rc = gershgorin(ctx, A, &L.lambda)) != PADNE_OK) break;
-        const double lambda_gershgorin = L.lambda;       // kept for the prolongator damping below
-        if (lvl > 0 && A->n_rows > kCoarseN && getenv("PADNE_AMG_NO_LANCZOS") == nullptr) {   // level 0: the bound is tight (1.99 by Lanczos)
-            // the Gershgorin bound is loose on the coarse operators (2.8 against ~1.7): tighten it with the
-            // largest Ritz value of 12 Lanczos steps (converges from below; 8 % margin keeps the sweep stable)
-            double ritz = 0.0;
-            PhaseTimer pl(ctx, amg_verbose());
-            if ((rc = estimate_lambda_max(ctx, A, lanczos_steps(), &ritz)) != PADNE_OK) break;
-            pl.lap("lanczos");
-            const double est = 1.08 * ritz;
-            if (est > 0.0 && est < L.lambda) L.lambda = est;
-        }
-        L.jac = 1.0 / (0.5 * (L.lambda + L.lambda / kChebRatio));
         const bool coarsest = A->n_rows <= kCoarseN || lvl == kMaxLevels - 1;
+        // damping of the Jacobi sweeps: Gershgorin bound of D^-1 A (on the coarsest level from its own pass over A,
+        // otherwise a by-product of the strength pass of the aggregation), tightened below by a Lanczos estimate
+        auto finish_lambda = [&]() -> int {
+            if (lvl > 0 && A->n_rows > kCoarseN && getenv("PADNE_AMG_NO_LANCZOS") == nullptr) {   // level 0: the bound is tight (1.99 by Lanczos)
+                // the Gershgorin bound is loose on the coarse operators (2.8 against ~1.7): tighten it with the
+                // largest Ritz value of 12 Lanczos steps (converges from below; 8 % margin keeps the sweep stable)
+                double ritz = 0.0;
+                PhaseTimer pl(ctx, amg_verbose());
+                PADNE_TRY(estimate_lambda_max(ctx, A, lanczos_steps(), &ritz));
+                pl.lap("lanczos");
+                const double est = 1.08 * ritz;
+                if (est > 0.0 && est < L.lambda) L.lambda = est;
+            }
+            L.jac = 1.0 / (0.5 * (L.lambda + L.lambda / kChebRatio));
+            return PADNE_OK;
+        };
         if ((rc = alloc_vec(ctx, &L.xa, L.n)) != PADNE_OK || (rc = alloc_vec(ctx, &L.tmp, L.n)) != PADNE_OK) { amg->levels.push_back(L); break; }
         if (lvl > 0 && ((rc = alloc_vec(ctx, &L.b, L.n)) != PADNE_OK || (rc = alloc_vec(ctx, &L.xb, L.n)) != PADNE_OK)) { amg->levels.push_back(L); break; }
         if (coarsest) {
+            if ((rc = gershgorin(ctx, A, &L.lambda)) == PADNE_OK) rc = finish_lambda();
             amg->levels.push_back(L);
             break;
         }
@@ -1737,8 +1759,10 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         int *agg = nullptr, n_agg = 0;
         PhaseTimer pt(ctx, amg_verbose());
         double lambda_f = 2.0;      // Gershgorin bound of the filtered operator, a by-product of the strength pass
-        if ((rc = aggregate(ctx, sc, A, &agg, &n_agg, &lambda_f)) != PADNE_OK) { amg->levels.push_back(L); break; }
+        if ((rc = aggregate(ctx, sc, A, &agg, &n_agg, &lambda_f, &L.lambda)) != PADNE_OK) { amg->levels.push_back(L); break; }
         pt.lap("aggregate");
+        const double lambda_gershgorin = L.lambda;       // kept for the prolongator damping below
+        if ((rc = finish_lambda()) != PADNE_OK) { amg->levels.push_back(L); break; }
         if (n_agg == 0 || (double)n_agg > 0.8 * (double)A->n_rows) {   // coarsening stalled: stop here
             amg->levels.push_back(L);
             break;
