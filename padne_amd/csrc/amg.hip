@@ -1776,7 +1776,7 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
             fprintf(stderr, "[amg] level %d: n=%lld nnz=%lld lambda=%.3f (P: %.3f) -> %d aggregates\n", lvl,
                     (long long)A->n_rows, (long long)A->nnz, L.lambda, lambda_f, n_agg);
         padne_csr *AP = nullptr, *Ac = nullptr;
-        pt.lap("gershgorin");
+        pt.lap("smoother bound (Lanczos)");
         if ((rc = build_prolongator(ctx, A, agg, n_agg, omega, &L.P)) != PADNE_OK) { amg->levels.push_back(L); break; }
         pt.lap("prolongator");
         if (amg_verbose()) fprintf(stderr, "[amg]   P: %lld x %lld nnz=%lld\n", (long long)L.P->n_rows, (long long)L.P->n_cols, (long long)L.P->nnz);
