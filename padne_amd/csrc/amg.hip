@@ -1252,7 +1252,10 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
     PADNE_TRY(sc.alloc(&scan, (size_t)n + 1));
     PADNE_TRY(sc.alloc(&agg0, (size_t)n));
     PADNE_TRY(sc.alloc(&agg1, (size_t)n));
-    PADNE_TRY(sc.alloc(&counter, 1));
+    // one zeroed counter per round (at most 256 rounds) instead of a memset in front of every round
+    constexpr int kMaxRounds = 256;
+    PADNE_TRY(sc.alloc(&counter, (size_t)2 * kMaxRounds + 4));
+    PADNE_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(int) * ((size_t)2 * kMaxRounds + 4), s));
     PADNE_HIP_CHECK(hipMemsetAsync(state, 0, (size_t)n, s));
     const dim3 g(nblk(n)), b(256);
     // strength graph on the pattern of A, built once per level
@@ -1278,15 +1281,14 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
     // much as a round on a small level): one round per batch while a pass over the level is expensive, four on the
     // small levels, where a superfluous round after the last vertex was decided is cheaper than the wait.
     const int full_batch = n > 200000 ? 1 : 4;
-    while (round < 256 && open_count > 0 && (!compact_ok || round < 2 || open_count > n / 8)) {
-        for (int rep = 0; rep < full_batch; ++rep, ++round) {
+    while (round < kMaxRounds && open_count > 0 && (!compact_ok || round < 2 || open_count > n / 8)) {
+        for (int rep = 0; rep < full_batch && round < kMaxRounds; ++rep, ++round) {
             hipLaunchKernelGGL(nbr_max<unsigned int>, gm, b, 0, s, n, n_wt, srow, scol, w0, w1);
             hipLaunchKernelGGL(nbr_max<unsigned int>, gm, b, 0, s, n, n_wt, srow, scol, w1, w2);
-            PADNE_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(int), s));
-            hipLaunchKernelGGL(mis_decide, dim3(std::min<unsigned>(g.x, 1024u)), b, 0, s, n, w0, w2, state, counter);
+            hipLaunchKernelGGL(mis_decide, dim3(std::min<unsigned>(g.x, 1024u)), b, 0, s, n, w0, w2, state, counter + round);
         }
         PADNE_HIP_CHECK(hipGetLastError());
-        PADNE_HIP_CHECK(hipMemcpyAsync(&open_count, counter, sizeof(int), hipMemcpyDeviceToHost, s));
+        PADNE_HIP_CHECK(hipMemcpyAsync(&open_count, counter + round - 1, sizeof(int), hipMemcpyDeviceToHost, s));
         PADNE_HIP_CHECK(hipStreamSynchronize(s));
     }
     if (open_count > 0) {
@@ -1294,22 +1296,20 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
         // n entries each, the open vertices are fewer)
         int *list_a = (int *)w1, *list_b = (int *)w2;
         unsigned int *m2 = nullptr;
-        int *counters = nullptr;
         PADNE_TRY(sc.alloc(&m2, (size_t)open_count));
-        PADNE_TRY(sc.alloc(&counters, 2));
-        PADNE_HIP_CHECK(hipMemsetAsync(counters, 0, 2 * sizeof(int), s));
+        // list lengths: one (pre-zeroed) word per compact round behind the words of the full rounds
+        int *counters = counter + kMaxRounds;
         hipLaunchKernelGGL(mis_collect_open, dim3(std::min<unsigned>(g.x, 1024u)), b, 0, s, n, state, list_a, counters);
         PADNE_HIP_CHECK(hipGetLastError());
         int cnt = open_count, cur = 0;       // counters[cur]: length of list_a, on the device
-        while (round < 256 && cnt > 0) {
+        while (cur + 1 < kMaxRounds && cnt > 0) {
             const dim3 gl(nblk(cnt));
             const int batch = cnt > 200000 ? 1 : 3;
-            for (int rep = 0; rep < batch; ++rep, ++round) {
+            for (int rep = 0; rep < batch && cur + 1 < kMaxRounds; ++rep, ++round) {
                 hipLaunchKernelGGL(mis_two_hop_max, gl, b, 0, s, counters + cur, list_a, srow, scol, w0, m2);
-                PADNE_HIP_CHECK(hipMemsetAsync(counters + (cur ^ 1), 0, sizeof(int), s));
-                hipLaunchKernelGGL(mis_decide_list, gl, b, 0, s, counters + cur, list_a, m2, w0, state, list_b, counters + (cur ^ 1));
+                hipLaunchKernelGGL(mis_decide_list, gl, b, 0, s, counters + cur, list_a, m2, w0, state, list_b, counters + cur + 1);
                 std::swap(list_a, list_b);
-                cur ^= 1;
+                ++cur;
             }
             PADNE_HIP_CHECK(hipGetLastError());
             PADNE_HIP_CHECK(hipMemcpyAsync(&cnt, counters + cur, sizeof(int), hipMemcpyDeviceToHost, s));
