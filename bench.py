@@ -105,6 +105,21 @@ def cpu_baseline(nx: int):
     }
 
 
+def launch_ranks(n: int) -> int:
+    """Start one rank per GPU with torch.distributed.run (the command the driver uses) and wait for them."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] launching: " + " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def _time(fn):
     t0 = time.perf_counter()
     fn()
@@ -116,9 +131,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing has touched the GPU yet (no torch, no HIP
+        # call), the ranks are CHILD processes (never an exec), and rank 0 prints the JSON line on the inherited stdout.
+        sys.exit(launch_ranks(args.gpus))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 as `python -m torch.distributed.run "
-                         f"--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree")
     import torch  # plumbing only: rendezvous, barrier, max-over-ranks
     import torch.distributed as dist
     from padne_amd import _hip, synthetic

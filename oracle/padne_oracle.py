@@ -227,6 +227,80 @@ def assemble_system(meshes, n_internal: int, elements, i_gnd: int):
     return L.tocsr(), r
 
 
+# --------------------------------------------------------------------------
+# solver.py:398-466, 671-686   node numbering and ground choice, on tables
+# --------------------------------------------------------------------------
+# A network is ``dict(connections=[(layer, x, y, node)], elements=[(kind, t..., values...)])`` with ``node`` /
+# terminals small integers that identify network nodes (the reference's opaque ``NodeID``); kinds as above but
+# with node ids for terminals and no ``i_v``.
+
+_N_TERMINALS = {"R": 2, "I": 2, "V": 2, "REG": 4}
+
+
+def node_indexer_create(layer_points: dict, layer_gidx: dict, n_vertices: int, networks):
+    """``NodeIndexer.create`` (``solver.py:398-466``): snap every connection to the nearest vertex of its layer
+    (``scipy.spatial.KDTree(leafsize=32).query(k=1)``, as ``:389-392, 424``), number the nodes no connection
+    names after the vertices, then one extra unknown per voltage source / regulator, network by network.
+
+    Returns ``(node_to_global, extra_index_per_element, internal_node_count)``.  Internal nodes of ONE network
+    are numbered in order of first appearance; the reference iterates a ``set`` there (``problem.py:86-96``), so
+    with several internal nodes in a network its order is address-dependent (any order is the same system up to
+    a permutation)."""
+    import scipy.spatial
+    trees = {l: scipy.spatial.KDTree(np.asarray(p, dtype=DTYPE).reshape(-1, 2), leafsize=32)
+             for l, p in layer_points.items()}
+    node_to_global: dict = {}
+    for net in networks:
+        for layer, x, y, node in net["connections"]:
+            _, k = trees[int(layer)].query((x, y), k=1)
+            g = int(layer_gidx[int(layer)][k])
+            if node in node_to_global and node_to_global[node] != g:
+                raise ValueError("Duplicate connection vertices found, this should not happen.")
+            node_to_global[node] = g
+    i_at = int(n_vertices)
+    internal = 0
+    for net in networks:
+        for e in net["elements"]:
+            for t in e[1:1 + _N_TERMINALS[e[0]]]:
+                if t not in node_to_global:
+                    node_to_global[t] = i_at
+                    i_at += 1
+                    internal += 1
+    extra = []
+    for net in networks:
+        for e in net["elements"]:
+            if e[0] in ("V", "REG"):
+                extra.append(i_at)
+                i_at += 1
+            else:
+                extra.append(-1)
+    return node_to_global, extra, internal
+
+
+def find_best_ground_node_index(networks, node_to_global) -> int:
+    """``solver.py:671-686``: negative terminal of the voltage source with the highest voltage, else unknown 0."""
+    best, ground = float("-inf"), 0
+    for net in networks:
+        for e in net["elements"]:
+            if e[0] == "V" and e[3] > best:
+                best, ground = e[3], node_to_global[e[2]]
+    return ground
+
+
+def globalise_elements(networks, node_to_global, extra):
+    """Elements of all networks in stamping order with global unknown indices: the input of assemble_system."""
+    out, k = [], 0
+    for net in networks:
+        for e in net["elements"]:
+            nt = _N_TERMINALS[e[0]]
+            row = (e[0],) + tuple(node_to_global[t] for t in e[1:1 + nt]) + tuple(e[1 + nt:])
+            if extra[k] >= 0:
+                row = row + (extra[k],)
+            out.append(row)
+            k += 1
+    return out
+
+
 def solve_system(L, r):
     """``solver.py:767-780``: spsolve on CSC, residual norm, ground current."""
     L_csc = sp.csc_matrix(L)

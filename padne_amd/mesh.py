@@ -210,12 +210,39 @@ class Mesh:
 
         ``face.vertices`` yields (v3, v1, v2); rotate back to (v1, v2, v3).
         """
-        pts = np.array([[v.p.x, v.p.y] for v in ref_mesh.vertices], dtype=np.float64).reshape(-1, 2)
-        tri = []
-        for f in ref_mesh.faces:
-            c, a, b = [int(v.i) for v in f.vertices]
-            tri.append((a, b, c))
-        return cls(pts, np.array(tri, dtype=np.int32).reshape(-1, 3))
+        soup = getattr(ref_mesh, "_padne_hip_soup", None)
+        if soup is not None:
+            # the mesher stub of INTEGRATION.md kept the CGAL arrays next to the half-edge mesh: no object walk at all
+            return soup if isinstance(soup, cls) else cls.from_cgal_output(soup)
+        if isinstance(getattr(ref_mesh, "points", None), np.ndarray) and hasattr(ref_mesh, "triangles"):
+            return cls(ref_mesh.points, ref_mesh.triangles)
+        n_v, n_f = len(ref_mesh.vertices), len(ref_mesh.faces)
+        # one pass over the object graph per array, filled straight into numpy buffers (no intermediate lists of lists);
+        # the half-edge walk itself is the reference's data structure and cannot be avoided on this route
+        pts = np.fromiter((c for v in ref_mesh.vertices for c in (v.p.x, v.p.y)), dtype=np.float64,
+                          count=2 * n_v).reshape(-1, 2)
+        cab = np.fromiter((v.i for f in ref_mesh.faces for v in f.vertices), dtype=np.int64,
+                          count=3 * n_f).reshape(-1, 3)
+        return cls(pts, np.ascontiguousarray(cab[:, [1, 2, 0]], dtype=np.int32))
+
+    @classmethod
+    def from_cgal_output(cls, cgal_output, validate: bool = False) -> "Mesh":
+        """Array hand-off from the reference's mesher: ``cgal_output['vertices']`` (sequence of (x, y)) and
+        ``cgal_output['triangles']`` (sequence of (i, j, k)) exactly as ``padne._cgal.mesh`` returns them
+        (``_cgal.cpp:479-488``) and ``Mesher.poly_to_mesh`` feeds to ``Mesh.from_triangle_soup``
+        (``mesh.py:782-785``).  Two array conversions, no per-vertex objects; the manifold test of
+        ``from_triangle_soup`` (``mesh.py:335-345``) is performed by the device assembly (``ValueError("Non-manifold
+        mesh")`` from there), or here with ``validate=True``."""
+        verts = cgal_output["vertices"]
+        tris = cgal_output["triangles"]
+        pts = np.asarray(verts, dtype=np.float64).reshape(-1, 2)
+        tri = np.asarray(tris, dtype=np.int64).reshape(-1, 3)
+        if tri.size and (tri.min() < 0 or tri.max() >= len(pts)):
+            raise IndexError("triangle refers to a vertex that does not exist")
+        m = cls(pts, tri.astype(np.int32))
+        if validate:
+            check_manifold(len(m.points), m.triangles)
+        return m
 
     # -- views -------------------------------------------------------------------
     @property

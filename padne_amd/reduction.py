@@ -58,34 +58,39 @@ class KKTLayout:
         raise SingularSystemError("system has no ground row")
 
 
-def infer_layout(L_csr, r: np.ndarray) -> KKTLayout:
+def infer_layout(L_csr, r: np.ndarray, n_potential: int | None = None) -> KKTLayout:
     """Recover the KKT structure from a matrix in the reference's layout.
 
     Used when ``solve_system(L, r)`` is handed a bare scipy matrix (e.g. one produced by the
-    reference's own ``assemble_system``).  A multiplier unknown is recognised by a zero diagonal
-    together with a row of one or two +-1 entries; the reference numbers them after all
-    potentials (``solver.py:441-460, 757-760``).
+    reference's own ``assemble_system``).  The reference numbers the multiplier unknowns after all
+    potentials (``solver.py:441-460, 757-760``), so they are the longest *suffix* of rows that look
+    like constraint rows: zero diagonal, one or two entries of +-1, all of them in columns in front
+    of the row itself (the terminals are potentials).  A potential row can also have a zero diagonal
+    and +-1 entries -- an internal node that touches only source terminals, e.g. between two voltage
+    sources in series -- but its entries sit in multiplier *columns*, behind it, which ends the
+    suffix.  ``n_potential`` (if the caller knows it) fixes the split outright.
     """
     N = L_csr.shape[0]
     indptr, indices, data = L_csr.indptr, L_csr.indices, L_csr.data
     diag = L_csr.diagonal()
-    cand = np.flatnonzero(diag == 0)
-    row_len = np.diff(indptr)
-    mult = []
-    for k in cand:
-        n = row_len[k]
-        if n == 0 or n > 2:
-            continue
-        vals = data[indptr[k]:indptr[k + 1]]
-        if np.all(np.abs(vals) == 1.0):
-            mult.append(int(k))
+
+    def looks_like_constraint_row(k: int) -> bool:
+        a, b = indptr[k], indptr[k + 1]
+        return (diag[k] == 0 and 1 <= b - a <= 2 and bool(np.all(np.abs(data[a:b]) == 1.0))
+                and bool(np.all(indices[a:b] < k)))
+
+    if n_potential is None:
+        n_pot = N
+        while n_pot > 0 and looks_like_constraint_row(n_pot - 1):
+            n_pot -= 1
+    else:
+        n_pot = int(n_potential)
+        if not 0 <= n_pot <= N or not all(looks_like_constraint_row(k) for k in range(n_pot, N)):
+            raise SingularSystemError("rows behind n_potential are not constraint rows of the form v_p - v_n = U")
+    mult = list(range(n_pot, N))
     mult_set = set(mult)
     if not mult:
         raise SingularSystemError("no ground / multiplier rows found: not a padne system matrix")
-    n_pot = min(mult)
-    if sorted(mult) != list(range(n_pot, N)):
-        # multipliers must form the tail block
-        raise SingularSystemError("multiplier unknowns are not a trailing block")
     csc = L_csr.tocsc()
     cons = []
     for k in mult:
@@ -275,12 +280,17 @@ class Reduction:
         return out
 
 
-def build_reduction(layout: KKTLayout) -> Reduction:
+def build_reduction(layout: KKTLayout, pins: list | None = None) -> Reduction:
+    """``pins``: unknowns of *floating* components (copper that no path of resistors or sources ties to the ground,
+    see :func:`floating_component_pins`) that are held at 0 V like a second ground.  The reference's matrix is
+    singular there (its LU returns whatever the rounding leaves); a pin makes the component's block definite, and the
+    current it carries is the component's net injected current (reported in ``Reduction.pin_currents``)."""
     N, n_pot = layout.size, layout.n_potential
     uf = _UnionFind()
     ground = layout.ground_constraint
-    tied = {}
-    for cst in layout.constraints:
+    dirichlet = [ground] + [Constraint(index=-(k + 1), p=int(x), n=-1, value=0.0) for k, x in enumerate(pins or [])]
+    all_cons = list(layout.constraints) + dirichlet[1:]
+    for cst in all_cons:
         if cst.n < 0:
             uf.find(cst.p)
             continue
@@ -293,10 +303,18 @@ def build_reduction(layout: KKTLayout) -> Reduction:
     for x in list(uf.parent.keys()):
         members.setdefault(uf.find(x), []).append(x)
     gcons: dict = {root: [] for root in members}
-    for cst in layout.constraints:
+    for cst in all_cons:
         gcons[uf.find(cst.p)].append(cst)
-    ground_root = uf.find(ground.p)
-    v_ground_root = ground.value - uf.offset(ground.p)      # v[root] of the ground group
+    # groups whose potential is known outright: root -> (v[root], the unknown the Dirichlet row names)
+    known_roots: dict = {}
+    for cst in dirichlet:
+        root = uf.find(cst.p)
+        if root in known_roots:
+            if cst is not ground and cst.index < 0:
+                gcons[root].remove(cst)            # a pin inside an already grounded group is redundant
+                continue
+            raise SingularSystemError("two ground rows tie the same group of nodes")
+        known_roots[root] = (cst.value - uf.offset(cst.p), cst.p)
     index_map = np.full(N, -1, dtype=np.int32)
     c = np.zeros(N, dtype=np.float64)
     # representative of a free group = its smallest member, so singletons keep their place
@@ -304,10 +322,11 @@ def build_reduction(layout: KKTLayout) -> Reduction:
     eliminated = np.zeros(N, dtype=bool)
     eliminated[n_pot:] = True
     for root, mem in members.items():
-        if root == ground_root:
+        if root in known_roots:
+            v_root = known_roots[root][0]
             for x in mem:
                 eliminated[x] = True
-                c[x] = v_ground_root + uf.offset(x)
+                c[x] = v_root + uf.offset(x)
         else:
             rep = min(mem)
             rep_of[root] = rep
@@ -318,7 +337,7 @@ def build_reduction(layout: KKTLayout) -> Reduction:
     keep = ~eliminated
     index_map[keep] = np.arange(int(keep.sum()), dtype=np.int32)
     for root, mem in members.items():
-        if root == ground_root:
+        if root in known_roots:
             continue
         rep = rep_of[root]
         for x in mem:
@@ -326,10 +345,59 @@ def build_reduction(layout: KKTLayout) -> Reduction:
     n_free = int(keep.sum())
     groups = []
     for root, mem in members.items():
-        r_node = ground.p if root == ground_root else rep_of[root]
+        r_node = known_roots[root][1] if root in known_roots else rep_of[root]
         groups.append((sorted(mem), gcons[root], r_node))
     regs = [cst for cst in layout.constraints if cst.gamma]
     return Reduction(layout=layout, index_map=index_map, n_free=n_free, c=c, groups=groups, regulators=regs)
+
+
+def floating_component_pins(n_potential: int, ground: int, constraints, *, mesh_offsets=None, links=None,
+                            matrix=None) -> list:
+    """One unknown (the smallest) of every connected component of potentials that does not contain the ground.
+
+    Connectivity = shared mesh (a mesh is one connected triangulation), resistor stamps (``links``: pairs of
+    unknowns), voltage-source / regulator-output ties (constraints).  With a bare ``matrix`` (reference layout, host
+    CSR) the components are those of its potential block.  Work is O(#meshes + #lumped elements), or one
+    ``connected_components`` pass for a bare matrix."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import connected_components
+    ties = [(c.p, c.n) for c in constraints if c.n >= 0]
+    if matrix is not None:
+        blk = sp.csr_matrix(matrix)[:n_potential, :n_potential]
+        if ties:
+            t = np.asarray(ties, dtype=np.int64)
+            blk = blk + sp.coo_matrix((np.ones(len(t)), (t[:, 0], t[:, 1])), shape=blk.shape)
+        n_comp, label = connected_components(blk, directed=False)
+        if n_comp <= 1:
+            return []
+        first = np.full(n_comp, n_potential, dtype=np.int64)
+        np.minimum.at(first, label, np.arange(n_potential))
+        return [int(first[k]) for k in range(n_comp) if k != label[ground]]
+    offs = np.asarray(mesh_offsets if mesh_offsets is not None else [0], dtype=np.int64)
+    n_vert, n_mesh = int(offs[-1]), len(offs) - 1
+    n_super = n_mesh + (n_potential - n_vert)
+
+    def super_of(u):
+        u = np.asarray(u, dtype=np.int64)
+        return np.where(u < n_vert, np.searchsorted(offs, u, side="right") - 1, n_mesh + (u - n_vert))
+
+    pairs = [np.zeros((0, 2), dtype=np.int64)]
+    if links is not None and len(links):
+        pairs.append(np.asarray(links, dtype=np.int64).reshape(-1, 2))
+    if ties:
+        pairs.append(np.asarray(ties, dtype=np.int64))
+    e = np.concatenate(pairs)
+    a, b = super_of(e[:, 0]), super_of(e[:, 1])
+    n_comp, label = connected_components(sp.coo_matrix((np.ones(len(a)), (a, b)), shape=(n_super, n_super)), directed=False)
+    sizes = np.concatenate([np.diff(offs), np.ones(n_potential - n_vert, dtype=np.int64)])
+    first_unknown = np.concatenate([offs[:-1], np.arange(n_vert, n_potential, dtype=np.int64)])
+    g_label = label[int(super_of(ground))]
+    pins = {}
+    for sn in range(n_super):
+        if sizes[sn] == 0 or label[sn] == g_label:
+            continue
+        pins[label[sn]] = min(pins.get(label[sn], n_potential), int(first_unknown[sn]))
+    return sorted(pins.values())
 
 
 # ---- locality ordering ------------------------------------------------------------------------------------

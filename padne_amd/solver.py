@@ -34,7 +34,7 @@ import scipy.spatial
 
 from . import _hip, mesh, problem
 from .reduction import (Constraint, KKTLayout, Reduction, SingularSystemError, build_reduction,
-                        infer_layout)
+                        floating_component_pins, infer_layout)
 
 log = logging.getLogger(__name__)
 
@@ -243,21 +243,35 @@ def _stamp(L, i, j, v):
         L[i, j] = L[i, j] + v
 
 
+_ELEMENT_KINDS = ("Resistor", "CurrentSource", "VoltageSource", "VoltageRegulator")
+
+
+def element_kind(element) -> Optional[str]:
+    """Which of the reference's four lumped elements ``element`` is (``problem.py:98-171``), by class *name* along its
+    MRO: the seam receives padne's own ``padne.problem`` objects, which are not instances of the
+    classes in :mod:`padne_amd.problem`, so an ``isinstance`` test against those would reject every real problem."""
+    for cls in type(element).__mro__:
+        if cls.__name__ in _ELEMENT_KINDS:
+            return cls.__name__
+    return None
+
+
 def stamp_network_into_system(network, node_indexer: NodeIndexer, L, r: np.ndarray) -> None:
     """MNA stamps of one network, same entries in the same order as ``solver.py:469-541``."""
     idx = node_indexer.node_to_global_index
     for element in network.elements:
-        if isinstance(element, problem.Resistor):
+        kind = element_kind(element)
+        if kind == "Resistor":
             a, b = idx[element.a], idx[element.b]
             g = 1 / element.resistance
             _stamp(L, a, a, -g)
             _stamp(L, a, b, g)
             _stamp(L, b, b, -g)
             _stamp(L, b, a, g)
-        elif isinstance(element, problem.CurrentSource):
+        elif kind == "CurrentSource":
             r[idx[element.f]] += element.current
             r[idx[element.t]] += -element.current
-        elif isinstance(element, problem.VoltageSource):
+        elif kind == "VoltageSource":
             p, n = idx[element.p], idx[element.n]
             iv = node_indexer.extra_source_to_global_index[element]
             _stamp(L, iv, p, 1.0)
@@ -267,7 +281,7 @@ def stamp_network_into_system(network, node_indexer: NodeIndexer, L, r: np.ndarr
             _stamp(L, n, iv, -1.0)
             if isinstance(L, StampList):
                 L.constraints.append(Constraint(index=iv, p=p, n=n, value=float(element.voltage)))
-        elif isinstance(element, problem.VoltageRegulator):
+        elif kind == "VoltageRegulator":
             vp, vn = idx[element.v_p], idx[element.v_n]
             sf, st = idx[element.s_f], idx[element.s_t]
             iv = node_indexer.extra_source_to_global_index[element]
@@ -302,7 +316,7 @@ def find_best_ground_node_index(prob, node_indexer: NodeIndexer) -> int:
     best, ground = float("-inf"), 0
     for network in prob.networks:
         for element in network.elements:
-            if isinstance(element, problem.VoltageSource) and element.voltage > best:
+            if element_kind(element) == "VoltageSource" and element.voltage > best:
                 best = element.voltage
                 ground = node_indexer.node_to_global_index[element.n]
     return ground
@@ -328,13 +342,16 @@ class SystemMatrix:
     ``L @ v``.  Carries the KKT layout so that ``solve_system`` does not have to re-derive it.
     """
 
-    def __init__(self, dev: _hip.CsrMatrix, layout: Optional[KKTLayout], xy=None, tri=None, mesh_offsets=None):
+    def __init__(self, dev: _hip.CsrMatrix, layout: Optional[KKTLayout], xy=None, tri=None, mesh_offsets=None,
+                 links=None):
         self.dev = dev
         self.layout = layout
         self.shape = dev.shape
         self._host = None
         # geometry of the mesh unknowns (optional): lets solve_system pick a cache-friendly internal ordering
         self.xy, self.tri, self.mesh_offsets = xy, tri, mesh_offsets
+        # pairs of potentials coupled by lumped stamps (optional): lets solve_system find floating copper
+        self.links = links
 
     @property
     def nnz(self) -> int:
@@ -421,7 +438,9 @@ def assemble_from_arrays(meshes, conductances, stamps: StampList, n_potential: i
     rows, cols, vals = stamps.arrays()
     dev = ctx.assemble_system(stamps.shape[0], xy, tri, mvo, mto, sig, rows, cols, vals)
     layout = KKTLayout(size=stamps.shape[0], n_potential=n_potential, constraints=list(stamps.constraints))
-    return SystemMatrix(dev, layout, xy=xy, tri=tri, mesh_offsets=mvo)
+    off = (rows < cols) & (cols < n_potential)
+    links = np.unique(np.stack([rows[off], cols[off]], axis=1), axis=0) if off.any() else np.zeros((0, 2), np.int64)
+    return SystemMatrix(dev, layout, xy=xy, tri=tri, mesh_offsets=mvo, links=links)
 
 
 # --------------------------------------------------------------------------------------------
@@ -471,31 +490,48 @@ def _solve_reduced_many(A: _hip.CsrMatrix, bs: list, rtol: float):
     return sols, res.iterations, res.rel_residual, res.seconds
 
 
-def solve_system(L, r: np.ndarray, *, rtol: float = RTOL, reorder=None):
+def solve_system(L, r: np.ndarray, *, rtol: float = RTOL, reorder=None, n_potential: Optional[int] = None):
     """Solve ``L v = r`` and return ``(v, SolverInfo)`` like ``solver.py:767-780``.
 
     ``L`` is a :class:`SystemMatrix` from :func:`assemble_system`, or any scipy sparse matrix in the
-    reference's layout (it is uploaded and its multiplier structure inferred).  ``reorder``: None = solve in
-    Z-order when the mesh numbering is scattered (decided from the triangles), True / False = force.
+    reference's layout (it is uploaded and its multiplier structure inferred; ``n_potential`` = number of
+    potential unknowns in front of the multiplier block, if the caller knows it).  ``reorder``: None = solve in
+    a band numbering when the mesh numbering is scattered (decided from the triangles), True / False = force.
+
+    Copper that nothing ties to the ground node (the reference's matrix is singular there, its LU returns rounding
+    noise for those potentials) is held at 0 V at one vertex; ``ground_node_current`` is, as in the reference, the net
+    current injected into the grounded component (``tests/test_solver.py:1829-1833``: non-zero for an unterminated
+    current loop).
     """
     ctx = get_context()
     r = np.asarray(r, dtype=DTYPE)
     if isinstance(L, SystemMatrix):
         dev, layout = L.dev, L.layout
         owned = False
+        Lc = None
     else:
         Lc = sp.csr_matrix(L)
         Lc.sum_duplicates()
         Lc.eliminate_zeros()
         Lc.sort_indices()
         dev, layout, owned = ctx.csr_from_scipy(Lc), None, True
-        layout = infer_layout(Lc, r)
+        layout = infer_layout(Lc, r, n_potential)
     if layout is None or not layout.constraints:
         raise SingularSystemError("system has no ground constraint")
     # multiplier rows take their right-hand side from r (solver.py:505, 530, 560)
     for cst in layout.constraints:
         cst.value = float(r[cst.index])
-    red: Reduction = build_reduction(layout)
+    ground_p = layout.ground_constraint.p
+    if Lc is not None:
+        pins = floating_component_pins(layout.n_potential, ground_p, layout.constraints, matrix=Lc)
+    elif L.links is not None and L.mesh_offsets is not None:
+        pins = floating_component_pins(layout.n_potential, ground_p, layout.constraints,
+                                       mesh_offsets=L.mesh_offsets, links=L.links)
+    else:
+        pins = []
+    if pins:
+        log.info(f"{len(pins)} floating component(s) held at 0 V at unknown(s) {pins[:8]}")
+    red: Reduction = build_reduction(layout, pins)
     if isinstance(L, SystemMatrix) and L.xy is not None and reorder is not False:
         # CGAL numbers vertices in insertion order; when neighbours are far apart in the numbering the SpMV
         # gathers miss the caches, so the reduced system is solved in a band numbering by horizontal strips
@@ -544,7 +580,8 @@ def solve_system(L, r: np.ndarray, *, rtol: float = RTOL, reorder=None):
             mult_known = dict(zip(keys, i_reg))
         rho = r - dev.matvec(v)
         for idx, val in red.multipliers(rho, mult_known).items():
-            v[idx] = val
+            if idx >= 0:                        # negative: the current through the pin of a floating component
+                v[idx] = val
         residual_norm = dev.residual_norm(v, r)
     finally:
         A.close()

@@ -188,6 +188,151 @@ def run_reference(spec):
     return out
 
 
+# ---- Problem-level cases: everything solve() does after meshing, through the reference's own indexers ---------
+
+PKIND = {"R": 0, "I": 1, "V": 2, "REG": 3}
+PTERMS = {"R": 2, "I": 2, "V": 2, "REG": 4}
+C1_STACKUP_SEGMENTS = (0.1 + 0.035, 1.24 + 0.035, 0.1 + 0.035)   # dielectric + lower copper, kicad.py:1541-1544
+C1_LAYERS = ("F.Cu", "In1.Cu", "In2.Cu", "B.Cu")                  # tests/test_kicad.py:926-938
+
+
+def ring_points(x, y, drill, n=16):
+    """Boundary of ``Point(x, y).buffer(drill / 2, quad_segs=4)`` without the closing point (kicad.py:812, 1511):
+    16 points on the circle, starting at angle 0 and running clockwise."""
+    k = np.arange(n)
+    ang = -2.0 * np.pi * k / n
+    return [(x + drill / 2 * np.cos(a), y + drill / 2 * np.sin(a)) for a in ang]
+
+
+def problem_c1():
+    """Config C1 of BASELINE.json: a via_tht_4layer-like Problem built at API level.
+
+    Board outline, pad and via positions, drills, stackup and directives are those of
+    tests/kicad/via_tht_4layer/via_tht_4layer.kicad_pcb / .kicad_sch:514-544 (three 0.1 Ohm RESISTANCE, one 1 V
+    VOLTAGE); every through-hole becomes one 16-resistor ring per adjacent layer pair with R = 16 * R_via
+    (kicad.py:818-836, 1546-1576).  The copper is a full plane on each layer (the real traces need the Gerber
+    front-end and CGAL, which cannot run here)."""
+    sigma = synthetic.DEFAULT_SHEET_CONDUCTANCE
+    meshes = []
+    for l in range(4):
+        xy, tri = synthetic.jittered_grid(57, 49, 0.3, seed=l, origin=(110.6, 99.1))
+        meshes.append((xy, tri, l))
+    node = iter(range(10 ** 9))
+    networks = []
+    holes = [(118.8, 105.9, 0.3), (118.8, 110.4, 0.3),             # vias
+             (113.39, 104.25, 1.0), (113.39, 106.79, 1.0),         # J1 pins
+             (124.0, 100.82, 0.8), (124.0, 110.98, 0.8)]           # R2 (axial THT) pads
+    for x, y, drill in holes:
+        for l in range(3):
+            r_total = C1_STACKUP_SEGMENTS[l] / (synthetic.COPPER_CONDUCTIVITY * np.pi *
+                                                ((drill / 2 + 0.035) ** 2 - (drill / 2) ** 2))
+            conns, els = [], []
+            for px, py in ring_points(x, y, drill):
+                a, b = next(node), next(node)
+                conns += [(l, px, py, a), (l + 1, px, py, b)]
+                els.append(("R", a, b, r_total * 16))
+            networks.append(dict(connections=conns, elements=els))
+    p, n = next(node), next(node)
+    networks.append(dict(connections=[(0, 113.39, 104.25, p), (0, 113.39, 106.79, n)], elements=[("V", p, n, 1.0)]))
+    for (layer, xa, ya, xb, yb) in [(0, 118.9, 102.1875, 118.9, 104.0125),      # R1, 0805 on F.Cu
+                                    (0, 124.0, 100.82, 124.0, 110.98),          # R2, THT
+                                    (3, 118.8, 107.5875, 118.8, 109.4125)]:     # R3, 0805 on B.Cu
+        a, b = next(node), next(node)
+        networks.append(dict(connections=[(layer, xa, ya, a), (layer, xb, yb, b)], elements=[("R", a, b, 0.1)]))
+    return dict(layers=[(nm, sigma) for nm in C1_LAYERS], meshes=meshes, networks=networks)
+
+
+def problem_mixed():
+    """Two islands on two layers: every element kind, one internal node, connections shared between elements."""
+    xy0, tri0 = synthetic.jittered_grid(9, 7, 0.6, seed=11)
+    xy1, tri1 = synthetic.jittered_grid(8, 8, 0.6, seed=12, origin=(1.0, 0.5))
+    nets = [
+        dict(connections=[(0, 0.1, 0.1, 0), (0, 4.7, 3.5, 1)], elements=[("V", 1, 0, 2.5)]),
+        dict(connections=[(0, 2.4, 1.9, 2), (0, 0.7, 3.1, 3)], elements=[("R", 2, 4, 0.7), ("R", 4, 3, 1.1)]),   # node 4 internal
+        dict(connections=[(0, 4.1, 0.4, 5), (0, 0.5, 0.2, 6), (1, 1.3, 0.9, 7), (1, 4.9, 4.4, 8)],
+             elements=[("REG", 7, 8, 5, 6, 1.2, 0.4)]),
+        dict(connections=[(1, 2.0, 2.0, 9), (1, 4.0, 1.0, 10)], elements=[("I", 9, 10, 0.25), ("R", 9, 10, 3.0)]),
+        dict(connections=[(1, 1.1, 0.6, 11), (0, 0.3, 0.3, 12)], elements=[("R", 11, 12, 50.0)]),
+    ]
+    return dict(layers=[("top", 2082.5), ("bottom", 1041.25)], meshes=[(xy0, tri0, 0), (xy1, tri1, 1)], networks=nets)
+
+
+PROBLEM_CASES = {"problem_c1": problem_c1, "problem_mixed": problem_mixed}
+
+
+def encode_problem(spec):
+    d = dict(layer_sigma=np.array([s for _, s in spec["layers"]], float), n_mesh=np.int64(len(spec["meshes"])))
+    for mi, (xy, tri, layer) in enumerate(spec["meshes"]):
+        d[f"xy{mi}"] = np.asarray(xy, float)
+        d[f"tri{mi}"] = np.asarray(tri, np.int32)
+        d[f"layer{mi}"] = np.int64(layer)
+    conn, els = [], []
+    for ni, net in enumerate(spec["networks"]):
+        for layer, x, y, node in net["connections"]:
+            conn.append((ni, layer, x, y, node))
+        for e in net["elements"]:
+            nt = PTERMS[e[0]]
+            row = [ni, PKIND[e[0]]] + list(e[1:1 + nt]) + [-1] * (4 - nt) + list(e[1 + nt:]) + [0.0] * (2 - (len(e) - 1 - nt))
+            els.append(row)
+    d["connections"] = np.array(conn, float).reshape(-1, 5)
+    d["pelements"] = np.array(els, float).reshape(-1, 8)
+    return d
+
+
+def run_reference_problem(spec):
+    """Steps 4-11 of the reference's solve() (solver.py:846-902) on ready meshes, all by the reference's own code."""
+    ref = ref_loader.load_reference()
+    P, M, S = ref.problem, ref.mesh, ref.solver
+    layers = [P.Layer(shape=ref_loader.Geoms(1), name=nm, conductance=sg) for nm, sg in spec["layers"]]
+    meshes = [M.Mesh.from_triangle_soup([M.Point(float(x), float(y)) for x, y in xy], [tuple(int(i) for i in t) for t in tri])
+              for xy, tri, _ in spec["meshes"]]
+    m2l = [int(l) for _, _, l in spec["meshes"]]
+    nodes = {}
+    elements_flat = []
+    networks = []
+    for net in spec["networks"]:
+        conns = []
+        for layer, x, y, node in net["connections"]:
+            c = P.Connection(layer=layers[layer], point=ref_loader.XY(x, y))
+            nodes[node] = c.node_id
+            conns.append(c)
+        els = []
+        for e in net["elements"]:
+            t = [nodes.setdefault(k, P.NodeID()) for k in e[1:1 + PTERMS[e[0]]]]
+            if e[0] == "R":
+                el = P.Resistor(a=t[0], b=t[1], resistance=e[3])
+            elif e[0] == "I":
+                el = P.CurrentSource(f=t[0], t=t[1], current=e[3])
+            elif e[0] == "V":
+                el = P.VoltageSource(p=t[0], n=t[1], voltage=e[3])
+            else:
+                el = P.VoltageRegulator(v_p=t[0], v_n=t[1], s_f=t[2], s_t=t[3], voltage=e[5], gain=e[6])
+            els.append(el)
+            elements_flat.append(el)
+        networks.append(P.Network(connections=conns, elements=els))
+    prob = P.Problem(layers=layers, networks=networks)
+    vindex = S.VertexIndexer.create(meshes)
+    nix = S.NodeIndexer.create(prob, meshes, m2l, vindex, networks)
+    L, r = S.assemble_system(prob, meshes, m2l, vindex, networks, nix)
+    v, info = S.solve_system(L, r)
+    sols = S.produce_layer_solutions(layers, vindex, meshes, m2l, v, [[] for _ in layers])
+    Lc = L.tocsr()
+    Lc.sort_indices()
+    out = dict(L_indptr=Lc.indptr.astype(np.int64), L_indices=Lc.indices.astype(np.int64), L_data=Lc.data, r=r, v=v,
+               ground_node_current=np.float64(info.ground_node_current), residual_norm=np.float64(info.residual_norm),
+               N=np.int64(L.shape[0]), ground=np.int64(S.find_best_ground_node_index(prob, nix)),
+               node_global=np.array([nix.node_to_global_index[nodes[k]] for k in sorted(nodes)], np.int64),
+               node_ids=np.array(sorted(nodes), np.int64),
+               extra_index=np.array([nix.extra_source_to_global_index.get(el, -1) for el in elements_flat], np.int64),
+               internal_node_count=np.int64(nix.internal_node_count))
+    for li, ls in enumerate(sols):
+        for k, (zf, tf) in enumerate(zip(ls.potentials, ls.power_densities)):
+            mi = [i for i, l in enumerate(m2l) if l == li][k]
+            out[f"pot{mi}"] = zf.values
+            out[f"pow{mi}"] = tf.values
+    return out
+
+
 def encode_inputs(spec):
     d = dict(n_internal=np.int64(spec["n_internal"]), ground=np.int64(spec["ground"]),
              n_mesh=np.int64(len(spec["meshes"])))
@@ -213,6 +358,14 @@ def main():
         np.savez_compressed(path, **data)
         print(f"{name}: N={int(data['N'])} nnz={len(data['L_data'])} |v|max={np.abs(data['v']).max():.4g} "
               f"res={float(data['residual_norm']):.2e} -> {os.path.relpath(path, ROOT)}")
+    for name, fn in PROBLEM_CASES.items():
+        spec = fn()
+        data = encode_problem(spec)
+        data.update(run_reference_problem(spec))
+        path = os.path.join(HERE, f"{name}.npz")
+        np.savez_compressed(path, **data)
+        print(f"{name}: N={int(data['N'])} nnz={len(data['L_data'])} |v|max={np.abs(data['v']).max():.4g} "
+              f"res={float(data['residual_norm']):.2e} gc={float(data['ground_node_current']):.2e} -> {os.path.relpath(path, ROOT)}")
 
 
 if __name__ == "__main__":

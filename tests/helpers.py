@@ -15,7 +15,76 @@ INT_ARGS = {"R": 2, "I": 2, "V": 2, "REG": 4}
 
 
 def golden_names():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+    """Unknown-level fixtures (lumped elements given by global unknown index)."""
+    return sorted(n for n in (os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+                  if not n.startswith("problem_"))
+
+
+def problem_golden_names():
+    """Problem-level fixtures (layers, connections by coordinates, networks): the reference's whole post-meshing path."""
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "problem_*.npz")))
+
+
+PKIND = {0: "R", 1: "I", 2: "V", 3: "REG"}
+PTERMS = {"R": 2, "I": 2, "V": 2, "REG": 4}
+
+
+def problem_networks(g):
+    """Networks of a problem-level fixture as the oracle's tables: dict(connections=[(layer, x, y, node)],
+    elements=[(kind, terminal nodes..., values...)])."""
+    n_net = int(max(g["connections"][:, 0].max(initial=-1), g["pelements"][:, 0].max(initial=-1))) + 1
+    nets = [dict(connections=[], elements=[]) for _ in range(n_net)]
+    for ni, layer, x, y, node in g["connections"]:
+        nets[int(ni)]["connections"].append((int(layer), float(x), float(y), int(node)))
+    for row in g["pelements"]:
+        kind = PKIND[int(row[1])]
+        nt = PTERMS[kind]
+        terms = tuple(int(t) for t in row[2:2 + nt])
+        vals = (float(row[6]),) if kind != "REG" else (float(row[6]), float(row[7]))
+        nets[int(row[0])]["elements"].append((kind, *terms, *vals))
+    return nets
+
+
+def problem_meshes(g):
+    return [(g[f"xy{i}"], g[f"tri{i}"], int(g[f"layer{i}"])) for i in range(int(g["n_mesh"]))]
+
+
+class XY:
+    def __init__(self, x, y):
+        self.x, self.y = float(x), float(y)
+
+
+class Geoms:
+    def __init__(self, n=1):
+        self.geoms = tuple(object() for _ in range(n))
+
+
+def build_problem(g, P):
+    """The Problem of a problem-level fixture from the classes of module ``P`` (padne_amd.problem, the reference's
+    padne.problem, or any look-alike).  Returns (problem, networks, elements in stamping order)."""
+    layers = [P.Layer(shape=Geoms(1), name=f"L{i}", conductance=float(s)) for i, s in enumerate(g["layer_sigma"])]
+    nodes, flat, networks = {}, [], []
+    for net in problem_networks(g):
+        conns = []
+        for layer, x, y, node in net["connections"]:
+            c = P.Connection(layer=layers[layer], point=XY(x, y))
+            nodes[node] = c.node_id
+            conns.append(c)
+        els = []
+        for e in net["elements"]:
+            t = [nodes.setdefault(k, P.NodeID()) for k in e[1:1 + PTERMS[e[0]]]]
+            if e[0] == "R":
+                el = P.Resistor(a=t[0], b=t[1], resistance=e[3])
+            elif e[0] == "I":
+                el = P.CurrentSource(f=t[0], t=t[1], current=e[3])
+            elif e[0] == "V":
+                el = P.VoltageSource(p=t[0], n=t[1], voltage=e[3])
+            else:
+                el = P.VoltageRegulator(v_p=t[0], v_n=t[1], s_f=t[2], s_t=t[3], voltage=e[5], gain=e[6])
+            els.append(el)
+            flat.append(el)
+        networks.append(P.Network(connections=conns, elements=els))
+    return P.Problem(layers=layers, networks=networks), nodes, flat
 
 
 def load_golden(name):

@@ -395,6 +395,76 @@ def test_triangle_gradient_known_answers(ctx, values, expected):
         solver.compute_triangle_gradient(vs[:2], [0.0, 1.0])
 
 
+# ---- Problem-level fixtures produced by the reference's own post-meshing path (config C1 among them) ----------
+
+class FixtureMesher:
+    """Stands where the CGAL mesher stands: poly_to_mesh(geom, seeds) returns the fixture's mesh of that polygon."""
+
+    def __init__(self, by_geom):
+        self.by_geom = by_geom
+        self.seeds = {}
+
+    def poly_to_mesh(self, geom, seed_points=()):
+        self.seeds[id(geom)] = list(seed_points)
+        return self.by_geom[id(geom)]
+
+
+@pytest.mark.parametrize("family", ["padne_amd", "lookalike"])
+@pytest.mark.parametrize("name", H.problem_golden_names())
+def test_problem_fixture_through_solve(ctx, name, family):
+    """``solve(prob)`` on the Problem of a reference-generated fixture (``problem_c1`` = config C1 of BASELINE.json, the
+    via_tht_4layer-like 4-layer board): numbering, assembly, solve and post-processing against what the reference's
+    NodeIndexer.create / assemble_system / solve_system / produce_layer_solutions returned for the same Problem."""
+    import test_host_logic as TH
+    g = H.load_golden(name)
+    P = problem if family == "padne_amd" else TH._lookalike_problem_module()
+    prob, nodes, flat_elements = H.build_problem(g, P)
+    ms = H.problem_meshes(g)
+    # one polygon per mesh, in mesh order (meshes are listed layer by layer in these fixtures)
+    by_geom, per_layer = {}, {}
+    for xy, tri, layer in ms:
+        per_layer.setdefault(layer, []).append(mesh.Mesh(xy, tri))
+    layers = []
+    for li, lay in enumerate(prob.layers):
+        geoms = H.Geoms(len(per_layer.get(li, [])))
+        for token, m in zip(geoms.geoms, per_layer.get(li, [])):
+            by_geom[id(token)] = m
+        layers.append(P.Layer(shape=geoms, name=lay.name, conductance=lay.conductance) if family == "padne_amd"
+                      else type("LayerWithGeoms", (), dict(shape=geoms, geoms=geoms.geoms, name=lay.name,
+                                                           conductance=lay.conductance))())
+    # connections refer to the layer objects: rebuild the problem around the new layers
+    remap = {id(old): new for old, new in zip(prob.layers, layers)}
+    nets = [P.Network(connections=[P.Connection(layer=remap[id(c.layer)], point=c.point, node_id=c.node_id)
+                                   for c in net.connections], elements=list(net.elements)) for net in prob.networks]
+    prob = P.Problem(layers=layers, networks=nets)
+    mesher = FixtureMesher(by_geom)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", solver.SolverWarning)
+        sol = solver.solve(prob, mesher=mesher)
+    n_vert = sum(len(m[0]) for m in ms)
+    scale = np.abs(g["v"][:n_vert]).max()
+    worst = 0.0
+    for li, ls in enumerate(sol.layer_solutions):
+        idx = [i for i, m in enumerate(ms) if m[2] == li]
+        assert len(ls.potentials) == len(idx)
+        for i, zf, tf in zip(idx, ls.potentials, ls.power_densities):
+            worst = max(worst, np.abs(zf.values - g[f"pot{i}"]).max())
+            ref_pow = g[f"pow{i}"]
+            assert np.abs(tf.values - ref_pow).max() <= 1e-7 * max(ref_pow.max(), 1e-300)
+    assert worst <= REL_TOL * scale, f"potentials differ from the reference's direct solve by {worst / scale:.2e}"
+    assert abs(sol.solver_info.ground_node_current - float(g["ground_node_current"])) <= 1e-8 * np.abs(g["v"][n_vert:]).max()
+    assert sol.solver_info.residual_norm < 1e-9                      # the reference's own bar, tests/test_solver.py:2083-2089
+    if name == "problem_c1":
+        vs = next(e for e in flat_elements if solver.element_kind(e) == "VoltageSource")
+        ids = {int(k): int(v) for k, v in zip(g["node_ids"], g["node_global"])}
+        inv = {v: k for k, v in nodes.items()}
+        flat_v = np.concatenate([zf.values for ls in sol.layer_solutions for zf in ls.potentials])
+        assert abs(flat_v[ids[inv[vs.p]]] - flat_v[ids[inv[vs.n]]] - 1.0) < 1e-3     # tests/test_solver.py:1205
+        assert len(pickle.loads(pickle.dumps(sol)).layer_solutions) == 4             # tests/test_solver.py:2047-2080
+        # every connection point reached the mesher as a seed of its layer's polygons (solver.py:solve step 3)
+        assert sum(len(v) for v in mesher.seeds.values()) == len(g["connections"])
+
+
 # ---- Problem-level drop-in (the reference's synthetic end-to-end tests) --------------------------
 
 def strip_problem(n_src=5):
@@ -497,6 +567,34 @@ def test_floating_plane_stays_equipotential(ctx):
     assert np.abs(bot_s.power_densities[0].values).max() <= 1e-12
     # the 2 V source enters the reduced right-hand side as L c (norm ~1e4 here): rtol 1e-12 of that
     assert sol.solver_info.rel_residual <= 1e-12 and sol.solver_info.residual_norm < 1e-8
+
+
+def test_unterminated_current_loop_warns_about_the_ground_current(ctx):
+    """tests/test_solver.py:1829-1833: a current source drives one island from another island that nothing else
+    connects to it.  The reference warns "Ground node current is not zero" and still returns a Solution; so does this
+    path -- the floating island is held at one vertex instead of making the solve singular."""
+    top = problem.Layer(shape=structured.Shapes.of(structured.Rect(0, 0, 6, 4), structured.Rect(10, 0, 15, 4)),
+                        name="F.Cu", conductance=2082.5)
+    P = mesh.Point
+    f, t = problem.Connection(layer=top, point=P(1, 2)), problem.Connection(layer=top, point=P(13, 2))
+    nets = [problem.Network(connections=[f, t], elements=[problem.CurrentSource(f=f.node_id, t=t.node_id, current=1.5)])]
+    prob = problem.Problem(layers=[top], networks=nets)
+    mesher = structured.StructuredMesher(mesh.Mesher.Config(maximum_size=0.25), jitter=0.2, seed=5)
+    with pytest.warns(solver.SolverWarning, match="Ground node current is not zero"):
+        sol = solver.solve(prob, mesher=mesher)
+    assert abs(abs(sol.solver_info.ground_node_current) - 1.5) < 1e-9
+    ls = sol.layer_solutions[0]
+    assert len(ls.potentials) == 2 and all(np.all(np.isfinite(z.values)) for z in ls.potentials)
+    # each island carries its 1.5 A between the pad and the node that holds it: potentials stay of the order I / sigma
+    assert all(np.abs(z.values).max() < 1.5 / 2082.5 * 10 for z in ls.potentials)
+    # with a return path (a second source closing the loop) the same problem is regular and silent
+    f2, t2 = problem.Connection(layer=top, point=P(14, 3)), problem.Connection(layer=top, point=P(2, 3))
+    nets.append(problem.Network(connections=[f2, t2],
+                                elements=[problem.CurrentSource(f=f2.node_id, t=t2.node_id, current=1.5)]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", solver.SolverWarning)
+        sol = solver.solve(problem.Problem(layers=[top], networks=nets), mesher=mesher)
+    assert abs(sol.solver_info.ground_node_current) < 1e-9 and sol.solver_info.residual_norm < 1e-9
 
 
 def test_coaxial_structure_end_to_end(ctx):

@@ -181,28 +181,14 @@ def test_unknown_element_raises():
 
 # ---- reduction algebra -------------------------------------------------------------------------
 
-@pytest.mark.parametrize("name", ["unit_square", "two_layer_via", "voltage_source", "glue_sources", "regulator",
-                                  "lumped_only", "strip20"])
-def test_reduction_reproduces_the_direct_solve(name):
-    """The KKT -> SPD rewriting is exact algebra: with scipy doing the matrix work, the reduced
-    solve + multiplier recovery must reproduce the reference's v (incl. currents)."""
-    g = H.load_golden(name)
-    L = H.golden_L(g)
-    r = g["r"]
-    layout = reduction.infer_layout(L, r)
-    meshes, sig, stamps, r2, n_pot = H.product_system(g)
-    assert layout.n_potential == n_pot
-    assert sorted(c.index for c in layout.constraints) == sorted(c.index for c in stamps.constraints)
-    by_idx = {c.index: c for c in stamps.constraints}
-    for c in layout.constraints:
-        e = by_idx[c.index]
-        assert (c.p, c.n) == (e.p, e.n) and c.gamma == pytest.approx(e.gamma)
-    red = reduction.build_reduction(layout)
+def _solve_through_the_reduction(L, r, layout, pins=None):
+    """solve_system's algebra with scipy standing in for the device (matrix products and the SPD solve)."""
+    red = reduction.build_reduction(layout, pins)
     N = layout.size
     free = red.index_map >= 0
     P = sp.coo_matrix((np.ones(free.sum()), (np.flatnonzero(free), red.index_map[free])), shape=(N, red.n_free)).tocsr()
     A = (-(P.T @ L @ P)).tocsc()
-    assert abs(A - A.T).max() < 1e-9 * abs(A).max()
+    assert red.n_free == 0 or abs(A - A.T).max() < 1e-9 * abs(A).max()
     b0 = red.rhs(r, L @ red.c)
 
     def solve(b):
@@ -225,11 +211,90 @@ def test_reduction_reproduces_the_direct_solve(name):
         v = v + sum(i_reg[k] * Z[k] for k in range(K))
         known = dict(zip(keys, i_reg))
     for idx, val in red.multipliers(r - L @ v, known).items():
-        v[idx] = val
+        if idx >= 0:
+            v[idx] = val
+    return v
+
+
+@pytest.mark.parametrize("name", ["unit_square", "two_layer_via", "voltage_source", "glue_sources", "regulator",
+                                  "lumped_only", "strip20"])
+def test_reduction_reproduces_the_direct_solve(name):
+    """The KKT -> SPD rewriting is exact algebra: with scipy doing the matrix work, the reduced
+    solve + multiplier recovery must reproduce the reference's v (incl. currents)."""
+    g = H.load_golden(name)
+    L = H.golden_L(g)
+    r = g["r"]
+    layout = reduction.infer_layout(L, r)
+    meshes, sig, stamps, r2, n_pot = H.product_system(g)
+    assert layout.n_potential == n_pot
+    assert sorted(c.index for c in layout.constraints) == sorted(c.index for c in stamps.constraints)
+    by_idx = {c.index: c for c in stamps.constraints}
+    for c in layout.constraints:
+        e = by_idx[c.index]
+        assert (c.p, c.n) == (e.p, e.n) and c.gamma == pytest.approx(e.gamma)
+    v = _solve_through_the_reduction(L, r, layout)
     scale = np.abs(g["v"]).max()
     tol = 1e-7 if name == "regulator" else 1e-9
     np.testing.assert_allclose(v, g["v"], rtol=0, atol=tol * scale)
     assert np.linalg.norm(L @ v - r) < 1e-8 * max(scale, 1)
+
+
+@pytest.mark.parametrize("elements", [
+    # an internal node (1) between two voltage sources in series: its row is two +-1 entries on a zero diagonal
+    [("V", 1, 0, 1.0, 4), ("V", 2, 1, 2.0, 5), ("R", 2, 3, 4.0), ("R", 3, 0, 2.0)],
+    # a current source feeding the terminal (1) of a voltage source: that row is a single +1 on a zero diagonal
+    [("I", 0, 1, 0.5), ("V", 1, 0, 1.0, 4), ("R", 2, 0, 4.0), ("R", 2, 3, 1.0), ("R", 3, 0, 1.0)],
+])
+def test_layout_inference_does_not_mistake_source_only_nodes_for_multipliers(elements):
+    """Bare-matrix entry of solve_system: potential rows that touch only source terminals look like constraint rows
+    (zero diagonal, +-1 entries) but are not part of the trailing multiplier block."""
+    from oracle import padne_oracle as O
+    L, r = O.assemble_system([], 4, elements, 0)
+    layout = reduction.infer_layout(L, r)
+    n_extra = sum(1 for e in elements if e[0] == "V")
+    assert layout.n_potential == 4 and len(layout.constraints) == n_extra + 1
+    assert reduction.infer_layout(L, r, n_potential=4).n_potential == 4
+    with pytest.raises(reduction.SingularSystemError):
+        reduction.infer_layout(L, r, n_potential=3)
+    v = _solve_through_the_reduction(L, r, layout)
+    v_ref, _, _ = O.solve_system(L, r)
+    np.testing.assert_allclose(v, v_ref, rtol=0, atol=1e-12 * np.abs(v_ref).max())
+
+
+def test_floating_copper_is_found_and_pinned():
+    """An unterminated current loop (tests/test_solver.py:1829-1833): a source pushes current from the grounded island
+    into an island nothing else ties to it.  The reference's matrix is singular; here the floating island is found from
+    the meshes and the lumped links alone, held at 0 V at its first vertex, and the ground current is the net current
+    injected into the grounded island."""
+    from oracle import padne_oracle as O
+    xy0, tri0 = synthetic.jittered_grid(7, 6, seed=1)
+    xy1, tri1 = synthetic.jittered_grid(5, 5, seed=2)
+    n0, n1 = len(xy0), len(xy1)
+    els = [("I", 10, n0 + 7, 0.75), ("R", 3, n0 + n1, 2.0)]            # + a dangling resistor to an internal node
+    L, r = O.assemble_system([(xy0, tri0, 2082.5), (xy1, tri1, 2082.5)], 1, els, 0)
+    layout = reduction.infer_layout(L, r)
+    offs = np.array([0, n0, n0 + n1])
+    pins = reduction.floating_component_pins(layout.n_potential, 0, layout.constraints, mesh_offsets=offs,
+                                             links=np.array([[3, n0 + n1]]))
+    assert pins == [n0]
+    assert reduction.floating_component_pins(layout.n_potential, 0, layout.constraints, matrix=L) == [n0]
+    # tie the islands with a resistor, or with a voltage source: nothing floats any more
+    assert reduction.floating_component_pins(layout.n_potential, 0, layout.constraints, mesh_offsets=offs,
+                                             links=np.array([[3, n0 + n1], [5, n0 + 2]])) == []
+    tie = [reduction.Constraint(index=layout.size, p=n0 + 4, n=2, value=1.0)]
+    assert reduction.floating_component_pins(layout.n_potential, 0, layout.constraints + tie, mesh_offsets=offs,
+                                             links=np.zeros((0, 2), int)) == [n0 + n1]
+    v = _solve_through_the_reduction(L, r, layout, pins)
+    assert abs(abs(v[-1]) - 0.75) < 1e-12 and v[n0] == 0.0 and v[0] == 0.0
+    # each island on its own is a regular problem: same potentials
+    La, ra = O.assemble_system([(xy0, tri0, 2082.5)], 1, [("R", 3, n0, 2.0)], 0)
+    ra[10] += 0.75
+    va = O.solve_system(La, ra)[0]
+    np.testing.assert_allclose(v[:n0], va[:n0], rtol=0, atol=1e-12 * np.abs(va[:n0]).max())
+    Lb, rb = O.assemble_system([(xy1, tri1, 2082.5)], 0, [], 0)
+    rb[7] -= 0.75
+    vb = O.solve_system(Lb, rb)[0]
+    np.testing.assert_allclose(v[n0:n0 + n1], vb[:n1], rtol=0, atol=1e-12 * np.abs(vb[:n1]).max())
 
 
 def test_voltage_source_loop_is_rejected():
@@ -361,3 +426,183 @@ def test_strip_order_equals_the_three_key_sort_it_replaces():
     assert np.abs(k_x[order][:-7] - k_x[want][:-7]).max() <= 50 / 2.0 ** 31
     eq = (k_x[order][1:] == k_x[order][:-1]) & (strip[order][1:] == strip[order][:-1]) & (mesh_id[order][1:] == mesh_id[order][:-1])
     assert (order[1:][eq] > order[:-1][eq]).all()
+
+
+# ---- the Problem-level seam with OTHER people's classes (padne hands over its own padne.problem objects) ---
+
+def _lookalike_problem_module():
+    """Classes with the reference's names and fields that do NOT derive from padne_amd.problem (what padne's
+    own ``padne.problem`` objects are to this package)."""
+    import types
+    from dataclasses import dataclass, field
+
+    @dataclass(frozen=True)
+    class Layer:
+        shape: object
+        name: str
+        conductance: float
+
+    @dataclass(frozen=True, eq=False)
+    class NodeID:
+        pass
+
+    @dataclass(frozen=True)
+    class Connection:
+        layer: Layer
+        point: object
+        node_id: NodeID = field(default_factory=NodeID)
+
+    @dataclass(frozen=True)
+    class Resistor:
+        a: NodeID
+        b: NodeID
+        resistance: float
+        extra_variable_count = 0
+        terminals = property(lambda self: [self.a, self.b])
+
+    @dataclass(frozen=True)
+    class CurrentSource:
+        f: NodeID
+        t: NodeID
+        current: float
+        extra_variable_count = 0
+        terminals = property(lambda self: [self.f, self.t])
+
+    @dataclass(frozen=True)
+    class VoltageSource:
+        p: NodeID
+        n: NodeID
+        voltage: float
+        extra_variable_count = 1
+        terminals = property(lambda self: [self.p, self.n])
+
+    @dataclass(frozen=True)
+    class VoltageRegulator:
+        v_p: NodeID
+        v_n: NodeID
+        s_f: NodeID
+        s_t: NodeID
+        voltage: float
+        gain: float
+        extra_variable_count = 1
+        terminals = property(lambda self: [self.v_p, self.v_n, self.s_f, self.s_t])
+
+    @dataclass(frozen=True)
+    class Network:
+        connections: list
+        elements: list
+
+        @property
+        def nodes(self):
+            out = {}
+            for e in self.elements:
+                for t in e.terminals:
+                    out.setdefault(t, len(out))
+            return out
+
+    @dataclass(frozen=True)
+    class Problem:
+        layers: list
+        networks: list
+
+    return types.SimpleNamespace(Layer=Layer, NodeID=NodeID, Connection=Connection, Resistor=Resistor,
+                                 CurrentSource=CurrentSource, VoltageSource=VoltageSource,
+                                 VoltageRegulator=VoltageRegulator, Network=Network, Problem=Problem)
+
+
+def _index_and_stamp(g, P):
+    """The product's host half of solve_meshed (numbering + stamp listing) for a problem-level fixture."""
+    prob, nodes, flat = H.build_problem(g, P)
+    ms = H.problem_meshes(g)
+    meshes = [mesh.Mesh(xy, tri) for xy, tri, _ in ms]
+    m2l = [m[2] for m in ms]
+    vindex = solver.VertexIndexer.create(meshes)
+    nix = solver.NodeIndexer.create(prob, meshes, m2l, vindex, prob.networks)
+    stamps, r = solver.allocate_system(vindex, nix)
+    for net in prob.networks:
+        solver.stamp_network_into_system(net, nix, stamps, r)
+    ground = solver.find_best_ground_node_index(prob, nix)
+    solver.setup_ground_node(ground, stamps, r)
+    return prob, nodes, flat, nix, stamps, r, ground
+
+
+def _check_against_problem_golden(g, nodes, flat, nix, stamps, r, ground):
+    from oracle import padne_oracle as O
+    assert [nix.node_to_global_index[nodes[int(k)]] for k in g["node_ids"]] == [int(x) for x in g["node_global"]]
+    assert [nix.extra_source_to_global_index.get(el, -1) for el in flat] == [int(x) for x in g["extra_index"]]
+    assert nix.internal_node_count == int(g["internal_node_count"]) and ground == int(g["ground"])
+    assert np.array_equal(r, g["r"]) and stamps.shape[0] == int(g["N"])
+    # listed stamps + the oracle's mesh Laplacians = the matrix the reference assembled
+    N = int(g["N"])
+    rows, cols, vals = stamps.arrays()
+    S = sp.coo_matrix((vals, (rows, cols)), shape=(N, N)).tocsr()
+    off = 0
+    blocks = []
+    for xy, tri, layer in H.problem_meshes(g):
+        Lm = O.laplace_operator(xy, tri).tocoo()
+        blocks.append(sp.coo_matrix((float(g["layer_sigma"][layer]) * Lm.data, (Lm.row + off, Lm.col + off)), shape=(N, N)))
+        off += len(xy)
+    total = (S + sum(blocks)).tocsr()
+    total.eliminate_zeros()
+    ref = H.golden_L(g)
+    assert H.same_structure(total, ref)
+    np.testing.assert_allclose(total.data, ref.data, rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("name", H.problem_golden_names())
+@pytest.mark.parametrize("family", ["padne_amd", "lookalike"])
+def test_problem_seam_numbering_and_stamps_vs_reference_golden(name, family):
+    """Numbering (KD-tree snapping, internal nodes, extra unknowns), ground choice and the listed stamps equal what
+    the reference's NodeIndexer.create / assemble_system produced for the same Problem -- also when the Problem is
+    made of classes this package has never seen (duck typing by class name, not isinstance)."""
+    g = H.load_golden(name)
+    P = problem if family == "padne_amd" else _lookalike_problem_module()
+    prob, nodes, flat, nix, stamps, r, ground = _index_and_stamp(g, P)
+    _check_against_problem_golden(g, nodes, flat, nix, stamps, r, ground)
+    kinds = {solver.element_kind(e) for e in flat}
+    assert kinds <= {"Resistor", "CurrentSource", "VoltageSource", "VoltageRegulator"} and None not in kinds
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("name", H.problem_golden_names())
+def test_problem_seam_with_the_reference_own_objects(name):
+    """padne's solve() passes ITS OWN padne.problem / padne.mesh objects to solve_meshed.
+    Build the fixture's Problem and meshes from the reference's classes (build container only) and run the product's
+    numbering, stamping and Mesh.from_reference on them."""
+    from oracle import ref_loader
+    if not ref_loader.reference_available():
+        pytest.skip("reference not mounted (GPU box)")
+    ref = ref_loader.load_reference()
+    g = H.load_golden(name)
+    prob, nodes, flat, nix, stamps, r, ground = _index_and_stamp(g, ref.problem)
+    _check_against_problem_golden(g, nodes, flat, nix, stamps, r, ground)
+    assert all(type(e).__module__ == "padne.problem" for e in flat)
+    # half-edge meshes of the reference -> arrays
+    for xy, tri, _ in H.problem_meshes(g)[:1] if name == "problem_c1" else H.problem_meshes(g):
+        rm = ref.mesh.Mesh.from_triangle_soup([ref.mesh.Point(float(x), float(y)) for x, y in xy],
+                                              [tuple(int(i) for i in t) for t in tri])
+        m = mesh.Mesh.from_reference(rm)
+        assert np.array_equal(m.points, xy) and np.array_equal(m.triangles, tri)
+
+
+def test_mesh_from_cgal_output_is_the_array_hand_off():
+    """mesh.py:782-785 feeds cgal_output['vertices'] / ['triangles'] (lists of tuples, _cgal.cpp:479-488) to
+    from_triangle_soup; from_cgal_output takes the same dict without building per-vertex objects."""
+    xy, tri = synthetic.jittered_grid(6, 5, 0.6, seed=2)
+    out = {"vertices": [(float(x), float(y)) for x, y in xy], "triangles": [tuple(int(i) for i in t) for t in tri]}
+    m = mesh.Mesh.from_cgal_output(out)
+    assert m.points.dtype == np.float64 and m.triangles.dtype == np.int32
+    assert np.array_equal(m.points, xy) and np.array_equal(m.triangles, tri)
+    same = mesh.Mesh.from_triangle_soup([mesh.Point(*p) for p in out["vertices"]], out["triangles"])
+    assert np.array_equal(same.points, m.points) and np.array_equal(same.triangles, m.triangles)
+    assert len(mesh.Mesh.from_cgal_output({"vertices": [], "triangles": []}).points) == 0
+    with pytest.raises(IndexError):
+        mesh.Mesh.from_cgal_output({"vertices": [(0, 0), (1, 0), (0, 1)], "triangles": [(0, 1, 3)]})
+    with pytest.raises(ValueError, match="Non-manifold"):
+        mesh.Mesh.from_cgal_output({"vertices": [(0, 0), (1, 0), (0, 1), (0, -1)], "triangles": [(0, 1, 2), (0, 1, 3)]},
+                                   validate=True)
+
+    class HalfEdgeMeshWithSoup:              # what the mesher stub of INTEGRATION.md leaves behind
+        _padne_hip_soup = out
+        vertices = faces = ()
+    assert np.array_equal(mesh.Mesh.from_reference(HalfEdgeMeshWithSoup()).triangles, tri)
