@@ -448,12 +448,28 @@ def assemble_from_arrays(meshes, conductances, stamps: StampList, n_potential: i
 # --------------------------------------------------------------------------------------------
 
 
+# The reference judges a solve by the ABSOLUTE residual of the whole system, ||L v - r||_2 < 1e-9
+# (tests/test_solver.py:2083-2089).  The rows of the reduced system are rows of that system (the multiplier rows
+# hold exactly by construction), so its residual is driven to a quarter of that bar whenever 1e-12 ||b|| is looser
+# than that -- a voltage source across a copper plane puts kiloamperes into b.  Below RTOL_FLOOR nothing is gained:
+# that is what evaluating b - A y in binary64 can resolve (the solve stops at that floor and reports what it reached).
+ABS_RESIDUAL_TARGET = 2.5e-10
+RTOL_FLOOR = 2e-15
+
+
+def _effective_rtol(bs, rtol: float) -> float:
+    norm = max((float(np.linalg.norm(b)) for b in bs), default=0.0)
+    if norm > 0.0 and rtol * norm > ABS_RESIDUAL_TARGET:
+        return max(ABS_RESIDUAL_TARGET / norm, RTOL_FLOOR)
+    return rtol
+
+
 def _solve_reduced(A: _hip.CsrMatrix, b: np.ndarray, rtol: float):
     if A.shape[0] == 0:
         return np.zeros(0), 0, 0.0, 0.0
     if not np.any(b):
         return np.zeros_like(b), 0, 0.0, 0.0
-    res = A.solve_spd(b, rtol=rtol, max_iter=MAX_ITER, raise_on_fail=False)
+    res = A.solve_spd(b, rtol=_effective_rtol([b], rtol), max_iter=MAX_ITER, raise_on_fail=False)
     _warn_if_stalled(res, rtol)
     return res.x, res.iterations, res.rel_residual, res.seconds
 
@@ -483,7 +499,8 @@ def _solve_reduced_many(A: _hip.CsrMatrix, bs: list, rtol: float):
     sols = [np.zeros_like(b) for b in bs]
     if not live:
         return sols, 0, 0.0, 0.0
-    res = A.solve_spd(np.stack([bs[k] for k in live]), rtol=rtol, max_iter=MAX_ITER, raise_on_fail=False)
+    res = A.solve_spd(np.stack([bs[k] for k in live]), rtol=_effective_rtol([bs[k] for k in live], rtol),
+                      max_iter=MAX_ITER, raise_on_fail=False)
     _warn_if_stalled(res, rtol)
     for row, k in enumerate(live):
         sols[k] = res.x[row]

@@ -187,19 +187,43 @@ def test_spmv_linearity_at_full_size(ctx):
 
 # ---- solve ------------------------------------------------------------------------------------
 
+def fixture_conditioning(L, r, n_pot):
+    """How far one ulp in the diagonal moves the potentials of a system (relative to the largest): the accuracy to
+    which its solution is defined at all, measured with the checker's own direct solve."""
+    d = L.diagonal()
+    worst = 0.0
+    v0 = O.solve_system(L, r)[0]
+    for seed in (0, 1):
+        k = np.random.default_rng(seed).integers(-1, 2, len(d))
+        v1 = O.solve_system((L + sp.diags(d * (k * 2.220446049250313e-16))).tocsr(), r)[0]
+        worst = max(worst, np.abs(v1[:n_pot] - v0[:n_pot]).max() / max(np.abs(v0[:n_pot]).max(), 1e-300))
+    return worst, v0
+
+
 @pytest.mark.parametrize("name", NAMES)
 def test_solve_system_vs_reference_golden(ctx, name):
+    """Potentials within 1e-8 relative of the reference's direct solve (north star); residual of the ORIGINAL system
+    below the reference's absolute bar of 1e-9 (tests/test_solver.py:2083-2089).  One fixture, `regulator`, is defined
+    less sharply than 1e-8: it couples two islands through 100 kOhm next to a 2 kS sheet (as the reference's own
+    regulator test does, tests/test_solver.py:122-125), so a single ulp in the diagonal of L moves its potentials by
+    3e-7 -- the reference's LU and the checker's LU of the same system differ by 1.9e-7 there.  That fixture is held to
+    twice its own conditioning, and additionally to the checker's solve of the bit-identical device matrix."""
     g = H.load_golden(name)
     meshes, sig, stamps, r, n_pot = H.product_system(g)
     L = solver.assemble_from_arrays(meshes, sig, stamps, n_pot)
     v, info = solver.solve_system(L, r)
     scale_pot = np.abs(g["v"][:n_pot]).max()
-    tol = 1e-6 if name == "regulator" else REL_TOL       # regulator fixture: condition ~1e9, see test_oracle_golden
+    tol = REL_TOL
+    if name == "regulator":
+        sens, v_chk = fixture_conditioning(L.tocsr(), r, n_pot)
+        assert 1e-8 < sens < 1e-6                               # the fixture really is that ill-conditioned
+        tol = 2 * sens
+        assert np.abs(v[:n_pot] - v_chk[:n_pot]).max() <= tol * scale_pot
     assert np.abs(v[:n_pot] - g["v"][:n_pot]).max() <= tol * scale_pot
     scale_cur = max(np.abs(g["v"][n_pot:]).max(), 1e-30)
-    assert np.abs(v[n_pot:] - g["v"][n_pot:]).max() <= max(tol * scale_cur, 1e-9)
-    assert abs(info.ground_node_current - float(g["ground_node_current"])) <= max(tol * scale_cur, 1e-9)
-    assert info.residual_norm < 1e-9 * max(1.0, scale_cur)   # tests/test_solver.py:2083-2089 (amps-scaled)
+    assert np.abs(v[n_pot:] - g["v"][n_pot:]).max() <= max(REL_TOL * scale_cur, 1e-9)
+    assert abs(info.ground_node_current - float(g["ground_node_current"])) <= max(REL_TOL * scale_cur, 1e-9)
+    assert info.residual_norm < 1e-9                             # tests/test_solver.py:2083-2089, absolute
     L.dev.close()
 
 
@@ -209,8 +233,9 @@ def test_solve_system_accepts_a_bare_scipy_matrix(ctx, name):
     g = H.load_golden(name)
     v, info = solver.solve_system(H.golden_L(g).tolil(), g["r"])
     n_pot = int(g["N"]) - 1 - sum(1 for e in H.elements_of(g) if e[0] in ("V", "REG"))
-    tol = 1e-6 if name == "regulator" else REL_TOL
+    tol = 7e-7 if name == "regulator" else REL_TOL        # twice the fixture's conditioning, see fixture_conditioning
     assert np.abs(v[:n_pot] - g["v"][:n_pot]).max() <= tol * np.abs(g["v"][:n_pot]).max()
+    assert info.residual_norm < 1e-9
 
 
 def test_pcg_vs_direct_solve_on_layered_system(ctx):
@@ -460,7 +485,8 @@ def test_problem_fixture_through_solve(ctx, name, family):
         inv = {v: k for k, v in nodes.items()}
         flat_v = np.concatenate([zf.values for ls in sol.layer_solutions for zf in ls.potentials])
         assert abs(flat_v[ids[inv[vs.p]]] - flat_v[ids[inv[vs.n]]] - 1.0) < 1e-3     # tests/test_solver.py:1205
-        assert len(pickle.loads(pickle.dumps(sol)).layer_solutions) == 4             # tests/test_solver.py:2047-2080
+        if family == "padne_amd":                                                    # (the look-alike classes are test-local)
+            assert len(pickle.loads(pickle.dumps(sol)).layer_solutions) == 4         # tests/test_solver.py:2047-2080
         # every connection point reached the mesher as a seed of its layer's polygons (solver.py:solve step 3)
         assert sum(len(v) for v in mesher.seeds.values()) == len(g["connections"])
 
@@ -566,7 +592,7 @@ def test_floating_plane_stays_equipotential(ctx):
     assert np.abs(vb - vt[k]).max() <= 1e-10 * max(1.0, abs(vt[k]))
     assert np.abs(bot_s.power_densities[0].values).max() <= 1e-12
     # the 2 V source enters the reduced right-hand side as L c (norm ~1e4 here): rtol 1e-12 of that
-    assert sol.solver_info.rel_residual <= 1e-12 and sol.solver_info.residual_norm < 1e-8
+    assert sol.solver_info.rel_residual <= 1e-12 and sol.solver_info.residual_norm < 1e-9
 
 
 def test_unterminated_current_loop_warns_about_the_ground_current(ctx):
@@ -790,7 +816,7 @@ def test_strongly_graded_mesh_with_conductivity_jump(ctx):
     scale = np.abs(v_ref[:n]).max()
     assert np.abs(v[:n] - v_ref[:n]).max() <= REL_TOL * scale
     assert np.abs(v2[:n] - v_ref[:n]).max() <= REL_TOL * scale
-    assert info.residual_norm < 1e-8 and info.iterations < 80 and info2.iterations < 80
+    assert info.residual_norm < 1e-9 and info.iterations < 80 and info2.iterations < 80
     L.dev.close()
 
 
@@ -848,9 +874,10 @@ def test_regulator_star_and_multi_island_problem_end_to_end(ctx):
     sol = solver.solve(prob, mesher=mesher)
     assert len(sol.layer_solutions) == 2
     assert len(sol.layer_solutions[0].meshes) == 2 and len(sol.layer_solutions[1].meshes) == 1
-    # 5 V forced across a 2 kS sheet drives kilo-amps: scale the reference's absolute 1e-9 A bar accordingly
+    # 5 V forced across a 2 kS sheet drives kilo-amps: the residual still meets the reference's absolute 1e-9; the
+    # ground current (a difference of such currents) is held relative to them
     amps = 5.0 * 2082.5
-    assert sol.solver_info.residual_norm < 1e-9 * amps and abs(sol.solver_info.ground_node_current) < 1e-9 * amps
+    assert sol.solver_info.residual_norm < 1e-9 and abs(sol.solver_info.ground_node_current) < 1e-9 * amps
     # rebuild the same system through the reference-shaped seams and check against the oracle's direct solve
     meshes = [m for ls in sol.layer_solutions for m in ls.meshes]
     m2l = [0, 0, 1]
