@@ -37,6 +37,9 @@ extern "C" {
 #define PADNE_E_COMM       -6   /* RCCL not available / communicator failure */
 #define PADNE_E_BREAKDOWN  -7   /* PCG breakdown: matrix not SPD (p.Ap <= 0) or NaN */
 #define PADNE_E_TOOLARGE   -8   /* a count exceeds the 32-bit index space of the CSR structures (nnz, slot offsets) */
+#define PADNE_E_NOCOARSEN  -9   /* multigrid setup: the aggregation no longer shrinks the operator.  Internal to the
+                                   solve (which then preconditions with the diagonal, info.levels = 0); returned only by
+                                   the entry points that expose the hierarchy itself (padne_amg_apply, padne_amg_level) */
 
 typedef struct padne_ctx padne_ctx;   /* device, stream, workspaces, optional RCCL communicator */
 typedef struct padne_csr padne_csr;   /* device-resident CSR matrix (f64 values, i32 indices)  */

@@ -16,7 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpadne_hip.so")
 
 OK = 0
-E_INVALID, E_HIP, E_NOMEM, E_NONMANIFOLD, E_NOTCONVERGED, E_COMM, E_BREAKDOWN, E_TOOLARGE = -1, -2, -3, -4, -5, -6, -7, -8
+E_INVALID, E_HIP, E_NOMEM, E_NONMANIFOLD, E_NOTCONVERGED, E_COMM, E_BREAKDOWN, E_TOOLARGE, E_NOCOARSEN = \
+    -1, -2, -3, -4, -5, -6, -7, -8, -9
 
 
 class HipUnavailableError(RuntimeError):

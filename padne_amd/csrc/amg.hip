@@ -1453,6 +1453,7 @@ static int build_prolongator(padne_ctx *ctx, const padne_csr *A, const int *agg,
     return csr_from_slots(ctx, n, n_agg, slot_ptr, key, val, row_len, P);
 }
 
+// No host synchronisation (the number of entries is known): may be queued on the context's second stream.
 static int transpose(padne_ctx *ctx, const padne_csr *M, padne_csr **T) {
     hipStream_t s = ctx->stream;
     Scratch sc(ctx);
@@ -1468,8 +1469,7 @@ static int transpose(padne_ctx *ctx, const padne_csr *M, padne_csr **T) {
     PADNE_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)(nc + 1), s));
     if (M->nnz > 0) hipLaunchKernelGGL(transpose_count, dim3(nblk(M->nnz)), dim3(256), 0, s, (long long)M->nnz, M->cols, cnt);
     PADNE_HIP_CHECK(hipGetLastError());
-    int64_t tot = 0;
-    PADNE_TRY(exclusive_scan_i32(ctx, cnt, slot_ptr, nc, &tot));
+    PADNE_TRY(exclusive_scan_i32_async(ctx, cnt, slot_ptr, nc));
     PADNE_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)(nc + 1), s));
     if (M->n_rows > 0)
         hipLaunchKernelGGL(transpose_fill, dim3(nblk(M->n_rows)), dim3(256), 0, s, (int)M->n_rows, M->rowptr, M->cols,
@@ -1478,7 +1478,7 @@ static int transpose(padne_ctx *ctx, const padne_csr *M, padne_csr **T) {
     PADNE_TRY(sort_slots_exact(ctx, nc, slot_ptr, key, val, row_len));
     // a transpose has no duplicates: the counted slots are exact and, once sorted, already the CSR rows
     // (the scratch arrays go back to the pool without a synchronisation: reuse is ordered on the context's stream)
-    return csr_from_exact_slots(ctx, nc, M->n_rows, tot, slot_ptr, key, val, T);
+    return csr_from_exact_slots(ctx, nc, M->n_rows, M->nnz, slot_ptr, key, val, T);
 }
 
 static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_csr **C) {
@@ -1665,11 +1665,8 @@ static int host_allgather(padne_ctx *ctx, const std::vector<double> &mine, std::
 
 // Single-precision cycle (default; PADNE_AMG_F64=1 keeps double): float copies of every level operator.  Skipped
 // when 1/diag of the fine matrix leaves [1e-15, 1e15] (the cycle input is normalised, the operator is not).
-static int enable_f32(padne_ctx *ctx, Amg *amg) {
-    if (getenv("PADNE_AMG_F64") != nullptr || amg->levels.size() < 2) return PADNE_OK;
-    if (amg->levels[0].A->hierarchy_operator) return PADNE_OK;   // the gathered tail of a row-partitioned hierarchy
+static int f32_range(padne_ctx *ctx, const padne_csr *A0, double *lo_out, double *hi_out) {
     hipStream_t s = ctx->stream;
-    const padne_csr *A0 = amg->levels[0].A;
     const int g = (int)std::min<long long>((A0->n_rows + 255) / 256, 1024);
     double *mins = ctx->partials + 6 * kMaxPartials, *maxs = ctx->partials + 7 * kMaxPartials;
     hipLaunchKernelGGL(abs_range_kernel, dim3(g), dim3(256), 0, s, (long long)A0->n_rows, (const double *)A0->dinv, mins,
@@ -1684,6 +1681,17 @@ static int enable_f32(padne_ctx *ctx, Amg *amg) {
         lo = std::min(lo, h[(size_t)i]);
         if (h[(size_t)g + i] > hi || !(h[(size_t)g + i] == h[(size_t)g + i])) hi = h[(size_t)g + i];
     }
+    *lo_out = lo;
+    *hi_out = hi;
+    return PADNE_OK;
+}
+
+static int enable_f32(padne_ctx *ctx, Amg *amg) {
+    if (getenv("PADNE_AMG_F64") != nullptr || amg->levels.size() < 2) return PADNE_OK;
+    if (amg->levels[0].A->hierarchy_operator) return PADNE_OK;   // the gathered tail of a row-partitioned hierarchy
+    hipStream_t s = ctx->stream;
+    double lo = 0.0, hi = 0.0;
+    PADNE_TRY(f32_range(ctx, amg->levels[0].A, &lo, &hi));
     if (amg->dist) {
         // the same decision on every rank
         std::vector<double> mine = {lo, hi}, all;
@@ -1712,18 +1720,43 @@ static int enable_f32(padne_ctx *ctx, Amg *amg) {
     return PADNE_OK;
 }
 
+// Single-GPU setup.  Two chains run side by side on the context's two streams (the kernels of the coarse levels are
+// short and latency-bound, so a second queue is nearly free):
+//   main:    aggregate -> prolongator P -> A P ..................... -> R (A P) -> next level ... -> dense inverse
+//   second:  Lanczos bound of the level, float copy of A | wait P -> R = P^T, float copies of P and R
+// The smoother bounds are only read when the cycle is applied, so they are collected at the very end.
 int amg_setup(padne_ctx *ctx, padne_csr *A0) {
     if (A0->amg) return PADNE_OK;
     if (ctx->halo_on && A0->n_cols != A0->n_rows) return amg_setup_dist(ctx, A0);
     PADNE_REQUIRE(A0->n_rows == A0->n_cols, "multigrid needs a square matrix");
     PADNE_TRY(csr_build_dinv(ctx, A0));
     PADNE_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
+    padne_ctx *aux = getenv("PADNE_AMG_ONE_STREAM") != nullptr ? ctx : aux_context(ctx);
+    if (aux == nullptr) aux = ctx;
+    const bool two = aux != ctx;
+    // single-precision cycle?  (decided from 1/diag of the fine matrix, before anything is queued)
+    bool want_f32 = getenv("PADNE_AMG_F64") == nullptr && !A0->hierarchy_operator;
+    if (want_f32) {
+        double lo = 0.0, hi = 0.0;
+        PADNE_TRY(f32_range(ctx, A0, &lo, &hi));
+        want_f32 = lo >= 1e-15 && hi <= 1e15;
+    }
     Amg *amg = new Amg();
     amg->device = ctx->device;
     amg->ctx = ctx;
     int rc = PADNE_OK;
     const padne_csr *A = A0;
     double nnz_total = 0.0;
+    struct Pending { int level; LanczosJob job; };
+    std::vector<Pending *> pending;      // Lanczos estimates in flight on the second stream
+    auto drop_pending = [&]() {
+        for (Pending *pj : pending) {
+            double unused = 0.0;
+            (void)lanczos_finish(&pj->job, &unused);
+            delete pj;
+        }
+        pending.clear();
+    };
     for (int lvl = 0; lvl < kMaxLevels; ++lvl) {
         t_setup_level = lvl;
         AmgLevel L;
@@ -1732,26 +1765,23 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         L.n = A->n_rows;
         nnz_total += (double)A->nnz;
         const bool coarsest = A->n_rows <= kCoarseN || lvl == kMaxLevels - 1;
-        // damping of the Jacobi sweeps: Gershgorin bound of D^-1 A (on the coarsest level from its own pass over A,
-        // otherwise a by-product of the strength pass of the aggregation), tightened below by a Lanczos estimate
-        auto finish_lambda = [&]() -> int {
-            if (lvl > 0 && A->n_rows > kCoarseN && getenv("PADNE_AMG_NO_LANCZOS") == nullptr) {   // level 0: the bound is tight (1.99 by Lanczos)
-                // the Gershgorin bound is loose on the coarse operators (2.8 against ~1.7): tighten it with the
-                // largest Ritz value of 12 Lanczos steps (converges from below; 8 % margin keeps the sweep stable)
-                double ritz = 0.0;
-                PhaseTimer pl(ctx, amg_verbose());
-                PADNE_TRY(estimate_lambda_max(ctx, A, lanczos_steps(), &ritz));
-                pl.lap("lanczos");
-                const double est = 1.08 * ritz;
-                if (est > 0.0 && est < L.lambda) L.lambda = est;
-            }
-            L.jac = 1.0 / (0.5 * (L.lambda + L.lambda / kChebRatio));
-            return PADNE_OK;
-        };
         if ((rc = alloc_vec(ctx, &L.xa, L.n)) != PADNE_OK || (rc = alloc_vec(ctx, &L.tmp, L.n)) != PADNE_OK) { amg->levels.push_back(L); break; }
         if (lvl > 0 && ((rc = alloc_vec(ctx, &L.b, L.n)) != PADNE_OK || (rc = alloc_vec(ctx, &L.xb, L.n)) != PADNE_OK)) { amg->levels.push_back(L); break; }
+        // second stream: everything that needs only A_l
+        if (two && (rc = stream_order(ctx, aux)) != PADNE_OK) { amg->levels.push_back(L); break; }
+        const bool lanczos = lvl > 0 && A->n_rows > kCoarseN && getenv("PADNE_AMG_NO_LANCZOS") == nullptr;
+        if (lanczos) {
+            // the Gershgorin bound is loose on the coarse operators (2.8 against ~1.7): it is tightened with the largest
+            // Ritz value of 12 Lanczos steps (converges from below; 8 % margin keeps the sweep stable).  Level 0: the
+            // bound is tight (1.99 by Lanczos).
+            Pending *pj = new Pending();
+            pj->level = lvl;
+            pending.push_back(pj);
+            if ((rc = lanczos_enqueue(aux, A, lanczos_steps(), &pj->job)) != PADNE_OK) { amg->levels.push_back(L); break; }
+        }
+        if (want_f32 && (rc = csr_build_f32(aux, const_cast<padne_csr *>(A))) != PADNE_OK) { amg->levels.push_back(L); break; }
         if (coarsest) {
-            if ((rc = gershgorin(ctx, A, &L.lambda)) == PADNE_OK) rc = finish_lambda();
+            rc = gershgorin(ctx, A, &L.lambda);
             amg->levels.push_back(L);
             break;
         }
@@ -1761,30 +1791,30 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         double lambda_f = 2.0;      // Gershgorin bound of the filtered operator, a by-product of the strength pass
         if ((rc = aggregate(ctx, sc, A, &agg, &n_agg, &lambda_f, &L.lambda)) != PADNE_OK) { amg->levels.push_back(L); break; }
         pt.lap("aggregate");
-        const double lambda_gershgorin = L.lambda;       // kept for the prolongator damping below
-        if ((rc = finish_lambda()) != PADNE_OK) { amg->levels.push_back(L); break; }
         if (n_agg == 0 || (double)n_agg > 0.8 * (double)A->n_rows) {   // coarsening stalled: stop here
             amg->levels.push_back(L);
             break;
         }
         // omega uses Gershgorin bounds (filtered operator, capped by the unfiltered one): the sharper Lanczos
         // estimate of lambda(D^-1 A) over-relaxes the prolongator (44 instead of 34 CG iterations at N = 0.5 M)
-        const double lambda_g = lambda_gershgorin;
-        if (lambda_g < lambda_f) lambda_f = lambda_g;
+        if (L.lambda < lambda_f) lambda_f = L.lambda;
         const double omega = omega_num() / lambda_f;
         if (amg_verbose())
             fprintf(stderr, "[amg] level %d: n=%lld nnz=%lld lambda=%.3f (P: %.3f) -> %d aggregates\n", lvl,
                     (long long)A->n_rows, (long long)A->nnz, L.lambda, lambda_f, n_agg);
         padne_csr *AP = nullptr, *Ac = nullptr;
-        pt.lap("smoother bound (Lanczos)");
         if ((rc = build_prolongator(ctx, A, agg, n_agg, omega, &L.P)) != PADNE_OK) { amg->levels.push_back(L); break; }
         pt.lap("prolongator");
         if (amg_verbose()) fprintf(stderr, "[amg]   P: %lld x %lld nnz=%lld\n", (long long)L.P->n_rows, (long long)L.P->n_cols, (long long)L.P->nnz);
-        if ((rc = transpose(ctx, L.P, &L.R)) != PADNE_OK) { amg->levels.push_back(L); break; }
-        pt.lap("transpose");
+        // second stream: R = P^T and the float copies of both, next to A P on the main stream
+        if (two && (rc = stream_order(ctx, aux)) != PADNE_OK) { amg->levels.push_back(L); break; }
+        if ((rc = transpose(aux, L.P, &L.R)) != PADNE_OK) { amg->levels.push_back(L); break; }
+        if (want_f32 && ((rc = csr_build_f32(aux, L.R)) != PADNE_OK || (rc = csr_build_f32(aux, L.P)) != PADNE_OK)) { amg->levels.push_back(L); break; }
+        pt.lap(two ? "transpose (queued)" : "transpose");
         if ((rc = spgemm(ctx, A, L.P, &AP)) != PADNE_OK) { amg->levels.push_back(L); break; }
         pt.lap("A*P");
         if (amg_verbose()) fprintf(stderr, "[amg]   AP nnz=%lld\n", (long long)AP->nnz);
+        if (two && (rc = stream_order(aux, ctx)) != PADNE_OK) { padne_csr_destroy(AP); amg->levels.push_back(L); break; }
         rc = spgemm(ctx, L.R, AP, &Ac);
         pt.lap("R*(AP)");
         if (amg_verbose() && rc == PADNE_OK) fprintf(stderr, "[amg]   Ac: n=%lld nnz=%lld\n", (long long)Ac->n_rows, (long long)Ac->nnz);
@@ -1800,10 +1830,10 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
     if (rc == PADNE_OK) {
         const AmgLevel &last = amg->levels.back();
         if (last.P != nullptr) {
-            rc = PADNE_E_INVALID;
+            rc = PADNE_E_NOCOARSEN;
             set_error("multigrid setup did not reach a coarsest level");
         } else if (last.n > 4096) {
-            rc = PADNE_E_INVALID;
+            rc = PADNE_E_NOCOARSEN;
             set_error("multigrid coarsening stalled at %lld unknowns", last.n);
         } else {
             amg->n_coarse = (int)last.n;
@@ -1813,13 +1843,48 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         }
     }
     if (rc != PADNE_OK) {
+        drop_pending();
+        if (two) (void)hipStreamSynchronize(aux->stream);
+        amg_destroy(amg);
+        return rc;
+    }
+    // smoother damping of every level: first-degree Chebyshev on [lambda / ratio, lambda]
+    for (Pending *pj : pending) {
+        double ritz = 0.0;
+        const int rcl = lanczos_finish(&pj->job, &ritz);
+        if (rcl != PADNE_OK && rc == PADNE_OK) rc = rcl;
+        AmgLevel &L = amg->levels[(size_t)pj->level];
+        const double est = 1.08 * ritz;
+        if (rcl == PADNE_OK && est > 0.0 && est < L.lambda) L.lambda = est;
+        delete pj;
+    }
+    pending.clear();
+    for (AmgLevel &L : amg->levels) L.jac = 1.0 / (0.5 * (L.lambda + L.lambda / kChebRatio));
+    if (rc == PADNE_OK && two) rc = stream_order(aux, ctx);      // the cycle runs on the main stream
+    if (rc != PADNE_OK) {
+        if (two) (void)hipStreamSynchronize(aux->stream);
         amg_destroy(amg);
         return rc;
     }
     amg->operator_complexity = nnz_total / (double)(A0->nnz > 0 ? A0->nnz : 1);
-    if ((rc = enable_f32(ctx, amg)) != PADNE_OK) {
-        amg_destroy(amg);
-        return rc;
+    if (want_f32 && amg->levels.size() >= 2) {
+        hipStream_t s = ctx->stream;
+        if (amg->levels[0].b == nullptr && (rc = alloc_vec(ctx, &amg->levels[0].b, amg->levels[0].n)) != PADNE_OK) {
+            amg_destroy(amg);
+            return rc;
+        }
+        if (amg->n_coarse > 0) {
+            const size_t cnt = (size_t)amg->n_coarse * (size_t)amg->n_coarse;
+            amg->coarse_inv32 = (float *)pool_alloc(ctx, sizeof(float) * cnt);
+            if (amg->coarse_inv32 == nullptr) {
+                amg_destroy(amg);
+                return PADNE_E_NOMEM;
+            }
+            hipLaunchKernelGGL(f32_copy_amg, dim3(nblk((long long)cnt)), dim3(256), 0, s, (long long)cnt, amg->coarse_inv,
+                               amg->coarse_inv32);
+            PADNE_HIP_CHECK(hipGetLastError());
+        }
+        amg->f32 = true;
     }
     PADNE_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
     PADNE_HIP_CHECK(hipEventSynchronize(ctx->ev1));
@@ -2256,7 +2321,7 @@ static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0) {
             padne_csr_destroy(blk);
             stalled = true;
             if (lvl == 0) {
-                rc = PADNE_E_INVALID;
+                rc = PADNE_E_NOCOARSEN;
                 set_error("row-partitioned multigrid: no coarsening on the finest level");
             }
             break;
@@ -2306,7 +2371,7 @@ static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0) {
     if (export_owned != nullptr) pool_free(ctx, export_owned);
     if (rc == PADNE_OK) {
         if (amg->levels.back().P != nullptr && !stalled) {
-            rc = PADNE_E_INVALID;
+            rc = PADNE_E_NOCOARSEN;
             set_error("multigrid setup did not reach a coarsest level");
         } else {
             PhaseTimer pg(ctx, amg_verbose() && ctx->rank == 0);

@@ -28,6 +28,8 @@
 // round exactly like the reference's Python floats (no fused multiply-add).
 #include "common.hpp"
 
+#include <cmath>
+
 #include <algorithm>
 
 #include <string.h>
@@ -159,6 +161,27 @@ int exclusive_scan_i32(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t 
         return PADNE_E_TOOLARGE;
     }
     *total = h[0];
+    return PADNE_OK;
+}
+
+int exclusive_scan_i32_async(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t n) {
+    const int nb = (int)((n + kScanChunk - 1) / kScanChunk);
+    long long *bs = (long long *)pool_alloc(ctx, sizeof(long long) * (size_t)(nb + 2));
+    if (bs == nullptr) return PADNE_E_NOMEM;
+    long long *tot = bs + nb;
+    hipError_t e = hipMemsetAsync(tot, 0, 2 * sizeof(long long), ctx->stream);
+    if (e == hipSuccess && nb > 0) {
+        hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(256), 0, ctx->stream, in, (long long)n, bs, tot + 1);
+        hipLaunchKernelGGL(scan_block_offsets, dim3(1), dim3(256), 0, ctx->stream, bs, nb, tot);
+        hipLaunchKernelGGL(scan_apply, dim3(nb), dim3(256), 0, ctx->stream, in, (long long)n, bs, tot, out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && nb == 0) e = hipMemsetAsync(out, 0, sizeof(int32_t), ctx->stream);
+    pool_free(ctx, bs);      // reuse is ordered on the context's stream
+    if (e != hipSuccess) {
+        set_error("scan failed: %s", hipGetErrorString(e));
+        return PADNE_E_HIP;
+    }
     return PADNE_OK;
 }
 
@@ -1590,6 +1613,9 @@ extern "C" int padne_nearest_vertex(padne_ctx *ctx, int64_t n_points, const doub
     PADNE_REQUIRE(n_points >= 1 && xy_host, "at least one point is needed");
     PADNE_REQUIRE(n_query >= 0 && n_query < (1 << 24), "number of queries");
     if (n_query == 0) return PADNE_OK;
+    // a NaN / inf coordinate compares false with everything and would leave "no vertex" (INT64_MAX) in the output
+    for (int64_t k = 0; k < 2 * n_query; ++k) PADNE_REQUIRE(std::isfinite(query_host[k]), "query coordinates must be finite");
+    for (int64_t k = 0; k < 2 * n_points; ++k) PADNE_REQUIRE(std::isfinite(xy_host[k]), "vertex coordinates must be finite");
     PADNE_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     Scratch sc(ctx);

@@ -70,8 +70,13 @@ void *pool_alloc(padne_ctx *ctx, size_t bytes) {
 void pool_free(padne_ctx *ctx, void *p) {
     if (p == nullptr) return;
     auto it = ctx->pool_sizes.find(p);
-    if (it == ctx->pool_sizes.end()) {   // not ours: plain free
-        (void)hipFree(p);
+    if (it == ctx->pool_sizes.end()) {
+        padne_ctx *other = ctx->is_aux ? ctx->parent : ctx->aux;     // a block of the sibling stream's pool
+        if (other != nullptr && other->pool_sizes.count(p)) {
+            pool_free(other, p);
+            return;
+        }
+        (void)hipFree(p);                // not ours: plain free
         return;
     }
     if (ctx->pool_cached_bytes + it->second > kPoolCacheLimit) {
@@ -92,6 +97,48 @@ void pool_release_all(padne_ctx *ctx) {
     }
     ctx->pool_free_blocks.clear();
     ctx->pool_cached_bytes = 0;
+}
+
+static int ctx_init_resources(padne_ctx *ctx) {
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void **)&ctx->partials, sizeof(double) * 8 * kMaxPartials) != hipSuccess ||
+        hipMalloc((void **)&ctx->scalars, sizeof(double) * 64) != hipSuccess ||
+        hipMalloc((void **)&ctx->status, 1024) != hipSuccess ||
+        hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming) != hipSuccess) {
+        set_error("context creation failed: %s", hipGetErrorString(hipGetLastError()));
+        return PADNE_E_HIP;
+    }
+    hipMemsetAsync(ctx->partials, 0, sizeof(double) * 8 * kMaxPartials, ctx->stream);
+    hipMemsetAsync(ctx->scalars, 0, sizeof(double) * 64, ctx->stream);
+    hipMemsetAsync(ctx->status, 0, 1024, ctx->stream);
+    hipStreamSynchronize(ctx->stream);
+    return PADNE_OK;
+}
+
+padne_ctx *aux_context(padne_ctx *ctx) {
+    if (ctx->is_aux) return ctx;
+    if (ctx->aux != nullptr) return ctx->aux;
+    padne_ctx *a = new padne_ctx();
+    a->device = ctx->device;
+    a->is_aux = true;
+    a->parent = ctx;
+    a->rank = ctx->rank;
+    a->world = ctx->world;
+    if (ctx_init_resources(a) != PADNE_OK) {
+        padne_ctx_destroy(a);
+        return nullptr;
+    }
+    ctx->aux = a;
+    return a;
+}
+
+int stream_order(padne_ctx *earlier, padne_ctx *later) {
+    if (earlier == later) return PADNE_OK;
+    PADNE_HIP_CHECK(hipEventRecord(earlier->ev_order, earlier->stream));
+    PADNE_HIP_CHECK(hipStreamWaitEvent(later->stream, earlier->ev_order, 0));
+    return PADNE_OK;
 }
 
 int csr_alloc(padne_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, padne_csr **out) {
@@ -165,20 +212,10 @@ int padne_ctx_create(int device, padne_ctx **out) {
     PADNE_HIP_CHECK(hipSetDevice(device));
     padne_ctx *ctx = new padne_ctx();
     ctx->device = device;
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc((void **)&ctx->partials, sizeof(double) * 8 * kMaxPartials) != hipSuccess ||
-        hipMalloc((void **)&ctx->scalars, sizeof(double) * 64) != hipSuccess ||
-        hipMalloc((void **)&ctx->status, 1024) != hipSuccess ||
-        hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault) != hipSuccess ||
-        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
-        set_error("context creation failed: %s", hipGetErrorString(hipGetLastError()));
+    if (ctx_init_resources(ctx) != PADNE_OK) {
         padne_ctx_destroy(ctx);
         return PADNE_E_HIP;
     }
-    hipMemsetAsync(ctx->partials, 0, sizeof(double) * 8 * kMaxPartials, ctx->stream);
-    hipMemsetAsync(ctx->scalars, 0, sizeof(double) * 64, ctx->stream);
-    hipMemsetAsync(ctx->status, 0, 1024, ctx->stream);
-    hipStreamSynchronize(ctx->stream);
     *out = ctx;
     return PADNE_OK;
 }
@@ -187,6 +224,10 @@ int padne_ctx_destroy(padne_ctx *ctx) {
     if (!ctx) return PADNE_OK;
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    if (ctx->aux) {
+        padne_ctx_destroy(ctx->aux);
+        ctx->aux = nullptr;
+    }
     comm_destroy(ctx);
     pool_release_all(ctx);
     for (auto &kv : ctx->pool_sizes) (void)hipFree(kv.first);   // blocks still held by live matrices
@@ -199,6 +240,7 @@ int padne_ctx_destroy(padne_ctx *ctx) {
     if (ctx->pinned) hipHostFree(ctx->pinned);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    if (ctx->ev_order) hipEventDestroy(ctx->ev_order);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return PADNE_OK;

@@ -99,6 +99,12 @@ struct padne_ctx {
     int halo_m = 0, halo_n_export = 0;
     int32_t *halo_export = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // second stream of the context (its own pool, workspace and reduction scratch): independent chains of short,
+    // latency-bound kernels of the multigrid setup run there next to the main chain (aux_context, stream_order)
+    padne_ctx *aux = nullptr, *parent = nullptr;
+    bool is_aux = false;
+    unsigned pinned_next = 0;        // round-robin over the 512-byte slots of `pinned` (second stream only)
+    hipEvent_t ev_order = nullptr;
     // caching device allocator (see pool_alloc): hipMalloc/hipFree of GB-sized blocks cost up to hundreds of
     // milliseconds, which would dominate the multigrid setup that runs inside every solve
     std::multimap<size_t, void *> pool_free_blocks;
@@ -145,6 +151,15 @@ int interleave8(padne_ctx *ctx, long long n, const double *src, double *dst, boo
 
 // exclusive scan of int32 counts into int32 offsets (n+1 outputs); returns total via host
 int exclusive_scan_i32(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t n, int64_t *total);
+// the same without reading the total back (no host synchronisation; the caller knows the total fits 32 bits)
+int exclusive_scan_i32_async(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t n);
+
+// The context's second stream, as a context of its own (created on first use, destroyed with its parent).
+// Memory first touched on that stream must come from ITS pool: a block of the parent's pool may still be in use by
+// kernels queued on the parent's stream.  pool_free(parent, p) finds blocks of either pool.
+padne_ctx *aux_context(padne_ctx *ctx);
+// work queued on `later` after this call starts only when everything queued on `earlier` so far has finished
+int stream_order(padne_ctx *earlier, padne_ctx *later);
 
 // comm.cpp
 int comm_allreduce_sum_f64(padne_ctx *ctx, double *dev_buf, int count);
@@ -167,6 +182,16 @@ void amg_destroy(void *amg);
 // pcg.hip: largest eigenvalue of D^-1 A from `steps` Lanczos (Jacobi-PCG) steps; with a plan the matrix is
 // this rank's rows of a row-partitioned operator and the estimate (identical on all ranks) is the global one
 int estimate_lambda_max(padne_ctx *ctx, const padne_csr *a, int steps, double *lambda, const HaloPlan *plan = nullptr);
+// the same in two halves: queue the steps (no host synchronisation), later wait for them and evaluate
+struct LanczosJob {
+    padne_ctx *ctx = nullptr;
+    int steps = 0;
+    double *hist = nullptr;          // device history of the step scalars (pool of ctx)
+    std::vector<double> host;        // its host copy, valid after lanczos_finish
+    double *host_dst = nullptr;      // where the queue copies it first (pinned memory on the second stream)
+};
+int lanczos_enqueue(padne_ctx *ctx, const padne_csr *a, int steps, LanczosJob *job, const HaloPlan *plan = nullptr);
+int lanczos_finish(LanczosJob *job, double *lambda);
 // assemble.hip: rows of `top` followed by the rows of `bottom`, n_cols columns
 int csr_vstack(padne_ctx *ctx, const padne_csr *top, const padne_csr *bottom, int64_t n_cols, padne_csr **out);
 

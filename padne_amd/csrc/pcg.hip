@@ -905,24 +905,35 @@ static double tridiag_max_eig(const std::vector<double> &d, const std::vector<do
     return 0.5 * (lo + hi);
 }
 
-int estimate_lambda_max(padne_ctx *ctx, const padne_csr *a, int steps, double *lambda, const HaloPlan *plan) {
+// Enqueue `steps` Jacobi-PCG steps on a pseudo-random right-hand side; every step's scalars stay on the device
+// (kernels consume them there) and the whole history is copied to `job->host` at the end of the queue -- no host
+// synchronisation here, so a caller may queue this on the context's second stream and go on with other work.
+int lanczos_enqueue(padne_ctx *ctx, const padne_csr *a, int steps, LanczosJob *job, const HaloPlan *plan) {
     const bool dist = plan != nullptr;
     const long long n = dist ? plan->n_owned : a->n_rows;   // owned unknowns
     const long long nc = dist ? a->n_cols : n;              // length of the vector the matrix multiplies
     const long long nr = a->n_rows;
     PADNE_REQUIRE(nr >= n && nc >= n, "operator shape");
+    PADNE_REQUIRE(steps >= 1 && steps <= 60, "Lanczos steps");
     PADNE_TRY(csr_build_dinv(ctx, const_cast<padne_csr *>(a)));
     PADNE_TRY(ensure_workspace(ctx, sizeof(double) * (size_t)(3 * n + nc + nr) + 4096));
     double *r = (double *)ctx->ws, *x = r + n, *b = x + n, *p = b + n, *q = p + nc;
     PcgStatus *st = (PcgStatus *)ctx->status;
     hipStream_t s = ctx->stream;
     const int gv = vec_grid(n), gs = spmv_grid(a);
-    // every step's scalars stay on the device (kernels consume them there); the host reads the whole history
-    // once at the end instead of synchronising 12 times per level
-    PADNE_REQUIRE(steps >= 1 && steps <= 60, "Lanczos steps");
-    Scratch sc(ctx);
-    double *hist = nullptr;                 // (rz, rr)[0..steps] interleaved | pq[0..steps)
-    PADNE_TRY(sc.alloc(&hist, (size_t)3 * steps + 4));
+    job->ctx = ctx;
+    job->steps = steps;
+    job->host.assign((size_t)3 * steps + 4, 0.0);
+    // on the second stream the history lands in pinned memory (a copy to pageable memory would hold the host until the
+    // queue has drained, which is exactly what queuing there is meant to avoid): up to 8 jobs in flight, 512 bytes each
+    job->host_dst = job->host.data();
+    if (ctx->is_aux && sizeof(double) * job->host.size() <= 512) {
+        job->host_dst = (double *)((char *)ctx->pinned + 512 * (ctx->pinned_next++ % 8));
+    }
+    // (rz, rr)[0..steps] interleaved | pq[0..steps)
+    job->hist = (double *)pool_alloc(ctx, sizeof(double) * ((size_t)3 * steps + 4));
+    if (job->hist == nullptr) return PADNE_E_NOMEM;
+    double *hist = job->hist;
     double *H_rz = hist, *H_pq = hist + 2 * steps + 2;      // rz of step k at H_rz[2 k], its r.r right behind it
     PADNE_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(double) * ((size_t)3 * steps + 4), s));
     PADNE_HIP_CHECK(hipMemsetAsync(st, 0, sizeof(PcgStatus), s));
@@ -965,9 +976,23 @@ int estimate_lambda_max(padne_ctx *ctx, const padne_csr *a, int steps, double *l
         PADNE_HIP_CHECK(hipGetLastError());
         parity ^= 1;
     }
-    std::vector<double> hh((size_t)3 * steps + 4);
-    PADNE_HIP_CHECK(hipMemcpyAsync(hh.data(), hist, sizeof(double) * hh.size(), hipMemcpyDeviceToHost, s));
-    PADNE_HIP_CHECK(hipStreamSynchronize(s));
+    PADNE_HIP_CHECK(hipMemcpyAsync(job->host_dst, hist, sizeof(double) * job->host.size(), hipMemcpyDeviceToHost, s));
+    return PADNE_OK;
+}
+
+// Wait for the job's stream, then the largest Ritz value of the Lanczos tridiagonal.
+int lanczos_finish(LanczosJob *job, double *lambda) {
+    PADNE_REQUIRE(job->ctx != nullptr, "Lanczos job was not enqueued");
+    const hipError_t e = hipStreamSynchronize(job->ctx->stream);
+    pool_free(job->ctx, job->hist);
+    job->hist = nullptr;
+    if (e != hipSuccess) {
+        set_error("Lanczos estimate failed: %s", hipGetErrorString(e));
+        return PADNE_E_HIP;
+    }
+    const int steps = job->steps;
+    if (job->host_dst != job->host.data()) memcpy(job->host.data(), job->host_dst, sizeof(double) * job->host.size());
+    const std::vector<double> &hh = job->host;
     std::vector<double> alpha, beta;
     for (int k = 0; k < steps; ++k) {
         const double pqv = hh[(size_t)2 * steps + 2 + k], rzo = hh[(size_t)2 * k], rzn = hh[(size_t)2 * k + 2];
@@ -981,13 +1006,26 @@ int estimate_lambda_max(padne_ctx *ctx, const padne_csr *a, int steps, double *l
         *lambda = 2.0;
         return PADNE_OK;
     }
-    std::vector<double> d((size_t)m), e((size_t)(m > 1 ? m - 1 : 0));
+    std::vector<double> d((size_t)m), e2((size_t)(m > 1 ? m - 1 : 0));
     for (int k = 0; k < m; ++k) {
         d[(size_t)k] = 1.0 / alpha[(size_t)k] + (k > 0 ? beta[(size_t)k - 1] / alpha[(size_t)k - 1] : 0.0);
-        if (k + 1 < m) e[(size_t)k] = sqrt(beta[(size_t)k]) / alpha[(size_t)k];
+        if (k + 1 < m) e2[(size_t)k] = sqrt(beta[(size_t)k]) / alpha[(size_t)k];
     }
-    *lambda = tridiag_max_eig(d, e);
+    *lambda = tridiag_max_eig(d, e2);
     return PADNE_OK;
+}
+
+int estimate_lambda_max(padne_ctx *ctx, const padne_csr *a, int steps, double *lambda, const HaloPlan *plan) {
+    LanczosJob job;
+    const int rc = lanczos_enqueue(ctx, a, steps, &job, plan);
+    if (rc != PADNE_OK) {
+        if (job.hist != nullptr) {
+            (void)hipStreamSynchronize(ctx->stream);
+            pool_free(ctx, job.hist);
+        }
+        return rc;
+    }
+    return lanczos_finish(&job, lambda);
 }
 
 }  // namespace padne
@@ -1112,8 +1150,10 @@ extern "C" int padne_solve_spd_dev(padne_ctx *ctx, const padne_csr *a, const voi
             pm->amg = nullptr;
         }
         const int rc_setup = amg_setup(ctx, pm);
-        if (rc_setup == PADNE_E_INVALID) {
-            // coarsening stalled on this matrix: the solve proceeds with the diagonal preconditioner (levels = 0)
+        if (rc_setup == PADNE_E_NOCOARSEN) {
+            // coarsening stalled on this matrix (decided identically on every rank): the solve proceeds with the
+            // diagonal preconditioner (levels = 0).  Every other failure of the setup -- a shape check, a HIP error --
+            // is an error of the call, not a reason to run 200x more iterations quietly.
             use_amg = false;
         } else if (rc_setup != PADNE_OK) {
             return rc_setup;

@@ -516,10 +516,11 @@ __global__ void f32_copy_kernel(long long n, const double *__restrict__ src, flo
         dst[i] = (float)src[i];
 }
 
-// single-precision copies of the values and of 1/diag (kept with the matrix, freed with it)
+// single-precision copies of the values and of 1/diag (kept with the matrix, freed with it).  The copies come from
+// the pool of the context whose stream writes them first (pool_free of the matrix' owner finds either pool).
 int csr_build_f32(padne_ctx *ctx, padne_csr *m) {
     if (m->vals32 != nullptr) return PADNE_OK;
-    padne_ctx *owner = m->owner ? m->owner : ctx;
+    padne_ctx *owner = ctx->is_aux ? ctx : (m->owner ? m->owner : ctx);
     m->vals32 = (float *)pool_alloc(owner, sizeof(float) * ((size_t)m->nnz + kPadNnz));   // padded like vals
     if (m->vals32 == nullptr) return PADNE_E_NOMEM;
     if (m->nnz > 0)

@@ -1284,6 +1284,16 @@ def test_nearest_vertex_matches_the_kd_tree(ctx):
     # ties: the smallest index wins
     pts = np.array([[0.0, 0.0], [2.0, 0.0], [0.0, 0.0]])
     assert list(ctx.nearest_vertex(pts, np.array([[1.0, 0.0], [0.0, 0.0]]))) == [0, 0]
+    # a via in the centre of a grid cell is equidistant from its four corners: documented rule = smallest index
+    gx, gy = np.meshgrid(np.arange(4.0), np.arange(3.0), indexing="xy")
+    grid = np.stack([gx.reshape(-1), gy.reshape(-1)], axis=1)
+    assert list(ctx.nearest_vertex(grid, np.array([[1.5, 0.5], [2.5, 1.5]]))) == [1, 6]
+    # non-finite coordinates are an argument error, not an index of INT64_MAX
+    for bad in (np.nan, np.inf):
+        with pytest.raises(ValueError, match="finite"):
+            ctx.nearest_vertex(pts, np.array([[bad, 0.0]]))
+        with pytest.raises(ValueError, match="finite"):
+            ctx.nearest_vertex(np.array([[0.0, bad], [1.0, 1.0]]), np.array([[0.5, 0.5]]))
 
 
 def test_spmm8_columns_are_bitwise_the_single_vector_products(ctx):
