@@ -105,6 +105,35 @@ def cpu_baseline(nx: int):
     }
 
 
+def step_algorithmic_bytes(shapes, iterations: int):
+    """Bytes a whole step has to move at least, by the textbook CSR accounting of SURVEY.md section 8d (f64 values, i32
+    indices; 12 B per non-zero + 20 B per row for a product, x counted once): the multigrid setup reads every level
+    operator once and writes P, R = P^T and the next operator once; a CG iteration is the 232 N bytes of the textbook
+    loop with z = M r replaced by one V(1,1) cycle (per level two products with A_l, one with P_l and R_l each, five
+    vector passes).  An implementation that moves fewer real bytes (float cycle, 1-byte window positions) simply
+    scores a higher fraction, as the survey says for the PCG figure."""
+    def csr(t):                       # store / stream a matrix once
+        return 12 * t[2] + 4 * (t[0] + 1)
+
+    def product(t):                   # y = M x
+        return 12 * t[2] + 4 * (t[0] + 1) + 8 * t[0] + 8 * t[1]
+    setup = 0
+    cycle = 0
+    for lv in shapes:
+        setup += csr(lv["A"])                                        # read A_l (strength, smoothing, A P)
+        if "P" in lv:
+            setup += csr(lv["P"]) + csr(lv["R"])                     # write P, R
+            cycle += 2 * product(lv["A"]) + product(lv["P"]) + product(lv["R"]) + 5 * 8 * lv["A"][0]
+        else:
+            setup += 8 * lv["A"][0] * lv["A"][0]                     # dense inverse of the coarsest operator
+            cycle += 8 * lv["A"][0] * lv["A"][0]
+    setup += sum(csr(lv["A"]) for lv in shapes[1:])                   # write A_1 ... A_L
+    a0 = shapes[0]["A"]
+    n = a0[0]
+    cg = product(a0) + 16 * n + 24 * n + 24 * n + 16 * n + 24 * n     # q = A p, p.q, x, r, r.z / r.r, p  (232 N at 7 nnz/row)
+    return {"setup": int(setup), "per_iteration": int(cg + cycle), "total": int(setup + iterations * (cg + cycle))}
+
+
 def launch_ranks(n: int) -> int:
     """Start one rank per GPU with torch.distributed.run (the command the driver uses) and wait for them."""
     import socket
@@ -184,6 +213,7 @@ def main():
         standalone = lambda: A.spmv_time(b, x, 5, 50)  # noqa: E731   same matrix, back-to-back launches
         n_local, nnz_local = A.shape[0], A.nnz
         spmv_bytes = A.spmv_bytes
+        hierarchy_shapes = (lambda: A.amg_shapes()) if args.precond == "amg" else None
     else:
         from padne_amd import distributed
         plan = distributed.build_layer_partition(sysm, rank, world)
@@ -194,6 +224,7 @@ def main():
         n_local, nnz_local = dsolver.n_owned, dsolver.nnz
         spmv_bytes = dsolver.spmv_bytes
         standalone = None
+        hierarchy_shapes = None
     t_setup = time.perf_counter() - t_setup0
 
     # ---- warmup + timed steps ---------------------------------------------------------------------
@@ -259,6 +290,19 @@ def main():
                                  "kernel launched back to back (no dirty predecessor)",
                          "standalone_frac": (spmv_bytes / t_standalone / 1e9 / HBM_PEAK_GBS) if t_standalone else None},
         }
+        if hierarchy_shapes is not None:
+            try:
+                sb = step_algorithmic_bytes(hierarchy_shapes(), int(last.iterations))
+                ach = sb["total"] / (elapsed / args.steps) / 1e9
+                out["roofline"]["step"] = {
+                    "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "bytes_per_step": sb["total"], "setup_bytes": sb["setup"], "bytes_per_iteration": sb["per_iteration"],
+                    "setup_frac": sb["setup"] / max(float(last.setup_seconds), 1e-12) / 1e9 / HBM_PEAK_GBS,
+                    "iteration_frac": sb["per_iteration"] * int(last.iterations) / max(float(last.seconds), 1e-12) / 1e9 / HBM_PEAK_GBS,
+                    "note": "whole timed step (multigrid setup + all CG iterations) by the textbook CSR byte count of "
+                            "SURVEY 8d; the entry above is the dominant kernel alone"}
+            except Exception as exc:
+                out["roofline"]["step"] = {"error": repr(exc)}
         if args.gpus == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_sample_nx)

@@ -67,13 +67,6 @@ int padne_ctx_comm_rank(padne_ctx *ctx, int *rank, int *world_size);
  * scalars), all-gather of f64 values, all-gather of f32 values; bytes are this rank's contributions.  Bookkeeping for
  * DESIGN.md section 6 (how many launches a multi-GPU solve costs), also counted for the in-process team. */
 int padne_comm_call_counts(long long calls[3], long long bytes[3]);
-/* In-process team: several contexts of ONE process on ONE GPU act as ranks (one host thread per context drives
- * its solve); all-reduce / all-gather go through host barriers and peer copies instead of RCCL, which refuses two
- * ranks on one device.  For rehearsing the row-partitioned solver on a single-GPU box (tests); sums are formed in
- * rank order, so every rank sees the same bits, like with RCCL. */
-int padne_team_create(int world_size, void **team_out);
-int padne_team_destroy(void *team);
-int padne_ctx_join_team(padne_ctx *ctx, void *team, int rank);
 
 /* Halo plan of a row-partitioned matrix (layer partition).  Every vector the
  * local matrix multiplies is laid out [n_owned owned entries | world_size * m exchanged entries];

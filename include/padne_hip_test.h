@@ -1,0 +1,30 @@
+/* padne_hip_test.h -- TEST-ONLY entry points of libpadne_hip.so.  Not part of the drop-in boundary (include/padne_hip.h):
+ * nothing a padne integration binds lives here.  The library exports them so that the row-partitioned solver
+ * (halo plans, one multigrid hierarchy over all ranks, the collectives inside the CG loop) can be driven with several
+ * ranks on a ONE-GPU box, where RCCL refuses two ranks on the same device. */
+#ifndef PADNE_HIP_TEST_H
+#define PADNE_HIP_TEST_H
+
+#include "padne_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* In-process team: several contexts of ONE process on ONE GPU act as ranks (one host thread per context drives
+ * its solve); all-reduce / all-gather go through host barriers and peer copies instead of RCCL, which refuses two
+ * ranks on one device.  For rehearsing the row-partitioned solver on a single-GPU box (tests); sums are formed in
+ * rank order, so every rank sees the same bits, like with RCCL. */
+int padne_team_create(int world_size, void **team_out);
+int padne_team_destroy(void *team);
+int padne_ctx_join_team(padne_ctx *ctx, void *team, int rank);
+/* Marks the team failed and wakes every rank that waits in a collective: all pending and future team collectives
+ * return PADNE_E_COMM.  Called by the driver of a rank that leaves early (error, exception), so that its peers do not
+ * wait for it for ever. */
+int padne_team_abort(void *team);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* PADNE_HIP_TEST_H */

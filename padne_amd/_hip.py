@@ -65,9 +65,6 @@ SIGNATURES = {
     "padne_ctx_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "padne_ctx_comm_rank": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "padne_comm_call_counts": (C.c_int, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
-    "padne_team_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
-    "padne_team_destroy": (C.c_int, [_P]),
-    "padne_ctx_join_team": (C.c_int, [_P, _P, C.c_int]),
     "padne_ctx_set_halo": (C.c_int, [_P, _I64, C.c_int32, C.c_int32, _PI32]),
     "padne_dev_alloc": (C.c_int, [_P, _I64, C.POINTER(_P)]),
     "padne_dev_free": (C.c_int, [_P, _P]),
@@ -102,6 +99,14 @@ SIGNATURES = {
     "padne_spmv_time": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _PF64]),
 }
 
+# test-only entry points (include/padne_hip_test.h): the in-process team that rehearses several ranks on one GPU
+TEST_SIGNATURES = {
+    "padne_team_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "padne_team_destroy": (C.c_int, [_P]),
+    "padne_team_abort": (C.c_int, [_P]),
+    "padne_ctx_join_team": (C.c_int, [_P, _P, C.c_int]),
+}
+
 _lib = None
 
 
@@ -123,7 +128,7 @@ def load_library(path: str | None = None) -> C.CDLL:
         lib = C.CDLL(p, mode=C.RTLD_GLOBAL)
     except OSError as exc:
         raise HipUnavailableError(f"cannot load {p}: {exc}") from exc
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(TEST_SIGNATURES.items()):
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
@@ -349,6 +354,11 @@ class LocalTeam:
         _check(self._lib.padne_ctx_join_team(ctx._h, self._h, int(rank)))
         ctx._team = self       # keep the team alive as long as its members
 
+    def abort(self) -> None:
+        """Wake every rank that waits in a collective; all team collectives return E_COMM from now on."""
+        if getattr(self, "_h", None):
+            self._lib.padne_team_abort(self._h)
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.padne_team_destroy(self._h)
@@ -538,6 +548,24 @@ class CsrMatrix:
         data = np.empty(nnz.value, dtype=np.float64)
         _check(self.ctx._lib.padne_csr_to_host(self.ctx._h, h, _ptr(indptr, _PI32), _ptr(indices, _PI32), _ptr(data, _PF64)))
         return sp.csr_matrix((data, indices, indptr), shape=(nr.value, nc.value))
+
+    def amg_shapes(self):
+        """(rows, cols, nnz) of every operator of the cached hierarchy, level by level: [{"A": .., "P": .., "R": ..}, ...]
+        (the last level has only "A").  Shapes only, nothing is downloaded."""
+        out = []
+        for level in range(32):
+            entry = {}
+            for which, code in (("A", 0), ("P", 1), ("R", 2)):
+                h = _P()
+                if self.ctx._lib.padne_amg_level(self.ctx._h, self._h, level, code, C.byref(h)) != OK:
+                    continue
+                nr, nc, nnz = C.c_int64(), C.c_int64(), C.c_int64()
+                _check(self.ctx._lib.padne_csr_shape(h, C.byref(nr), C.byref(nc), C.byref(nnz)))
+                entry[which] = (nr.value, nc.value, nnz.value)
+            if "A" not in entry:
+                break
+            out.append(entry)
+        return out
 
     def amg_apply(self, r) -> np.ndarray:
         """z = M^-1 r: one multigrid V-cycle (the preconditioner of solve_spd)."""

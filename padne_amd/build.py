@@ -10,7 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpadne_hip.so")
 SOURCES = ["capi.hip", "spmv.hip", "spmm.hip", "pcg.hip", "assemble.hip", "comm.hip", "amg.hip"]
-HEADERS = ["common.hpp", os.path.join("..", "..", "include", "padne_hip.h")]
+HEADERS = ["common.hpp", os.path.join("..", "..", "include", "padne_hip.h"),
+           os.path.join("..", "..", "include", "padne_hip_test.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]

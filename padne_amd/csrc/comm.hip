@@ -88,38 +88,69 @@ struct Team {
     bool failed = false;
 };
 
-static void team_barrier(Team *t) {
+// A rank that leaves a solve early (an error return, an exception in its driver thread) must not leave its peers
+// waiting for ever: padne_team_abort marks the team failed and wakes everybody; from then on every barrier returns
+// PADNE_E_COMM at once.
+static int team_barrier(Team *t) {
     std::unique_lock<std::mutex> lk(t->mu);
+    if (t->failed) {
+        set_error("team aborted: another rank left the collective with an error");
+        return PADNE_E_COMM;
+    }
     const long long gen = t->generation;
     if (++t->arrived == t->world) {
         t->arrived = 0;
         ++t->generation;
         t->cv.notify_all();
     } else {
-        t->cv.wait(lk, [&] { return t->generation != gen; });
+        t->cv.wait(lk, [&] { return t->generation != gen || t->failed; });
+        if (t->generation == gen) {       // woken by an abort, not by the last arrival
+            set_error("team aborted: another rank left the collective with an error");
+            return PADNE_E_COMM;
+        }
     }
+    return PADNE_OK;
 }
+
+static void team_fail(Team *t) {
+    {
+        std::lock_guard<std::mutex> lk(t->mu);
+        t->failed = true;
+    }
+    t->cv.notify_all();
+}
+
+// a HIP error inside a team collective takes the whole team down (the peers would wait for this rank otherwise)
+#define PADNE_TEAM_HIP(t, expr)                                                            \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            team_fail(t);                                                                  \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return PADNE_E_HIP;                                                            \
+        }                                                                                  \
+    } while (0)
 
 static int team_allreduce(padne_ctx *ctx, double *dev_buf, int count) {
     Team *t = (Team *)ctx->team;
     PADNE_REQUIRE(count <= 16, "team all-reduce is for a handful of scalars");
     double mine[16];
-    PADNE_HIP_CHECK(hipMemcpyAsync(mine, dev_buf, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
-    PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    PADNE_TEAM_HIP(t, hipMemcpyAsync(mine, dev_buf, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
+    PADNE_TEAM_HIP(t, hipStreamSynchronize(ctx->stream));
     {
         std::lock_guard<std::mutex> lk(t->mu);
         for (int c = 0; c < count; ++c) t->stage[(size_t)ctx->rank * 16 + c] = mine[c];
     }
-    team_barrier(t);
+    PADNE_TRY(team_barrier(t));
     double sum[16];
     for (int c = 0; c < count; ++c) {
         double s = 0.0;
         for (int r = 0; r < t->world; ++r) s += t->stage[(size_t)r * 16 + c];   // rank order: same bits everywhere
         sum[c] = s;
     }
-    team_barrier(t);                 // everybody has read the stage before anyone overwrites it
-    PADNE_HIP_CHECK(hipMemcpyAsync(dev_buf, sum, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
-    PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    PADNE_TRY(team_barrier(t));      // everybody has read the stage before anyone overwrites it
+    PADNE_TEAM_HIP(t, hipMemcpyAsync(dev_buf, sum, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
+    PADNE_TEAM_HIP(t, hipStreamSynchronize(ctx->stream));
     return PADNE_OK;
 }
 
@@ -127,19 +158,19 @@ static int team_allgather(padne_ctx *ctx, const void *send_v, void *recv_v, size
     const char *send = (const char *)send_v;
     char *recv = (char *)recv_v;
     Team *t = (Team *)ctx->team;
-    PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));          // my segment is complete
+    PADNE_TEAM_HIP(t, hipStreamSynchronize(ctx->stream));          // my segment is complete
     {
         std::lock_guard<std::mutex> lk(t->mu);
         t->ptrs[(size_t)ctx->rank] = (const double *)send_v;
     }
-    team_barrier(t);
+    PADNE_TRY(team_barrier(t));
     for (int r = 0; r < t->world; ++r) {
         if (r == ctx->rank && send == recv + (size_t)r * bytes_per_rank) continue;   // in place
-        PADNE_HIP_CHECK(hipMemcpyAsync(recv + (size_t)r * bytes_per_rank, t->ptrs[(size_t)r], bytes_per_rank,
-                                       hipMemcpyDeviceToDevice, ctx->stream));
+        PADNE_TEAM_HIP(t, hipMemcpyAsync(recv + (size_t)r * bytes_per_rank, t->ptrs[(size_t)r], bytes_per_rank,
+                                         hipMemcpyDeviceToDevice, ctx->stream));
     }
-    PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    team_barrier(t);                 // peers may now overwrite their segments
+    PADNE_TEAM_HIP(t, hipStreamSynchronize(ctx->stream));
+    PADNE_TRY(team_barrier(t));      // peers may now overwrite their segments
     return PADNE_OK;
 }
 
@@ -176,6 +207,11 @@ int comm_allgather_f32(padne_ctx *ctx, const float *send, float *recv, int count
     if (ctx->comm == nullptr) return PADNE_OK;
     return check_nccl(g_rccl.AllGather(send, recv, (size_t)count_per_rank, ncclFloat32, (ncclComm_t)ctx->comm,
                                        ctx->stream), "ncclAllGather");
+}
+
+// a rank that fails locally (allocation, HIP error, argument check) inside a row-partitioned solve tells its team
+void comm_abort(padne_ctx *ctx) {
+    if (ctx->team != nullptr) team_fail((Team *)ctx->team);
 }
 
 void comm_destroy(padne_ctx *ctx) {
@@ -237,6 +273,12 @@ extern "C" int padne_team_create(int world_size, void **team_out) {
     t->ptrs.assign((size_t)world_size, nullptr);
     t->stage.assign((size_t)world_size * 16, 0.0);
     *team_out = t;
+    return PADNE_OK;
+}
+
+extern "C" int padne_team_abort(void *team) {
+    PADNE_REQUIRE(team != nullptr, "team");
+    team_fail((Team *)team);
     return PADNE_OK;
 }
 

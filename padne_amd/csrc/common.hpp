@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/padne_hip.h"
+#include "../../include/padne_hip_test.h"
 
 namespace padne {
 
@@ -166,6 +167,7 @@ int comm_allreduce_sum_f64(padne_ctx *ctx, double *dev_buf, int count);
 int comm_allgather_f64(padne_ctx *ctx, const double *send, double *recv, int count_per_rank);
 int comm_allgather_f32(padne_ctx *ctx, const float *send, float *recv, int count_per_rank);
 void comm_destroy(padne_ctx *ctx);
+void comm_abort(padne_ctx *ctx);   // in-process team only: wake the peers of a rank that leaves a collective phase with an error
 
 // exchange plan of a row-partitioned operator: vectors are [n_owned | world * m exchanged values]; every
 // rank packs its n_export (<= m) exported owned entries into its segment and one all-gather fills the rest

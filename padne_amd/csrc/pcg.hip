@@ -592,6 +592,280 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
     return PADNE_OK;
 }
 
+// ---- single-reduction CG (Chronopoulos / Gear) for row-partitioned runs ------------------------------------
+// The textbook loop needs two global reductions per iteration (p.q before the update of x and r; r.z and r.r after
+// the preconditioner), each an all-reduce of one or two doubles whose cost across ranks is pure latency.  Rearranged
+// so that the product follows the preconditioner,
+//     x += alpha p ; r -= alpha s ; z = M r ; w = A z ;
+//     gamma' = r.z , delta = z.w , rr = r.r              <- ONE all-reduce of three doubles
+//     beta = gamma' / gamma ; alpha = gamma' / (delta - beta gamma' / alpha) ; p = z + beta p ; s = w + beta s
+// (s = A p by recurrence), one iteration costs one all-reduce and one exchange of z.  The stopping test sees r.r only
+// together with the other two sums, i.e. after the cycle and the product of the iteration that converged: one
+// superfluous V-cycle + product per solve buys one collective less in every iteration.  Scalars live in `sr`:
+enum { SR_GAMMA = 0, SR_ALPHA = 1, SR_BETA = 2, SR_RED = 4 /* gamma', delta, rr */ };
+
+__global__ __launch_bounds__(256) void sr_fold3_kernel(const double *__restrict__ p0, int n0, const double *__restrict__ p1,
+                                                       int n1, const double *__restrict__ p2, int n2,
+                                                       double *__restrict__ out) {
+    __shared__ double red[4];
+    const double *src = blockIdx.x == 0 ? p0 : (blockIdx.x == 1 ? p1 : p2);
+    const int cnt = blockIdx.x == 0 ? n0 : (blockIdx.x == 1 ? n1 : n2);
+    const double t = block_total(src, cnt, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = t;
+}
+
+__global__ void sr_scalars_kernel(PcgStatus *__restrict__ st, double *__restrict__ sr, const int first, const int max_iter) {
+    if (st->done) return;
+    const double gn = sr[SR_RED + 0], delta = sr[SR_RED + 1], rr = sr[SR_RED + 2];
+    double alpha, beta = 0.0;
+    if (first) {
+        alpha = gn / delta;
+    } else {
+        beta = gn / sr[SR_GAMMA];
+        alpha = gn / (delta - beta * gn / sr[SR_ALPHA]);
+    }
+    sr[SR_GAMMA] = gn;
+    sr[SR_ALPHA] = alpha;
+    sr[SR_BETA] = beta;
+    if (!first) {
+        const int it = st->iters + 1;
+        st->iters = it;
+        st->rr = rr;
+        if (rr <= st->tol2 || it >= max_iter) st->done = 1;
+    }
+    if (!st->done && (!(alpha > 0.0) || !(alpha == alpha) || !(gn > 0.0) || !(rr == rr))) {
+        st->code = PADNE_E_BREAKDOWN;      // p.A p = gamma' / alpha <= 0, or the cycle lost definiteness, or NaN
+        st->done = 1;
+    }
+}
+
+// x += alpha p ; r -= alpha s ; partial r.r ; optionally the entry stage of the single-precision cycle (as
+// pcg_update_xr_entry_kernel)
+__global__ __launch_bounds__(256) void sr_update_xr_kernel(
+    const long long n, const double *__restrict__ sr, const double *__restrict__ p, const double *__restrict__ s,
+    double *__restrict__ x, double *__restrict__ r, double *__restrict__ part_rr, const PcgStatus *__restrict__ st,
+    const double *__restrict__ bb2, const float c, const float *__restrict__ dinv32, float *__restrict__ b32,
+    float *__restrict__ xa32) {
+    __shared__ double red[4];
+    if (st->done) return;
+    const double alpha = sr[SR_ALPHA];
+    double s_inv = 1.0;
+    if (b32 != nullptr) {
+        const double s2 = *bb2;
+        s_inv = s2 > 0.0 ? 1.0 / sqrt(s2) : 1.0;
+    }
+    double s_rr = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const double ri = r[i] - alpha * s[i];
+        x[i] += alpha * p[i];
+        r[i] = ri;
+        s_rr += ri * ri;
+        if (b32 != nullptr) {
+            const float v = (float)(ri * s_inv);
+            b32[i] = v;
+            xa32[i] = c * dinv32[i] * v;
+        }
+    }
+    block_store_partial(s_rr, red, part_rr + blockIdx.x);
+}
+
+// p = z + beta p ; s = w + beta s
+__global__ __launch_bounds__(256) void sr_update_ps_kernel(const long long n, const double *__restrict__ sr,
+                                                           const double *__restrict__ z, const double *__restrict__ w,
+                                                           double *__restrict__ p, double *__restrict__ s,
+                                                           const PcgStatus *__restrict__ st) {
+    if (st->done) return;
+    const double beta = sr[SR_BETA];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        p[i] = z[i] + beta * p[i];
+        s[i] = w[i] + beta * s[i];
+    }
+}
+
+static int solve_one_single_reduction(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, const double *b,
+                                      double *x, const padne_solve_opts *o, padne_solve_info *info, bool x_is_guess) {
+    t_last_solve_stagnated = false;
+    const bool dist = ctx->comm != nullptr || ctx->team != nullptr;
+    const bool halo = ctx->halo_on;
+    const long long nr = a->n_rows;
+    const long long n = halo ? ctx->halo_n_owned : nr;
+    const long long nc = a->n_cols;
+    if (halo) {
+        PADNE_REQUIRE(nc == ctx->halo_n_owned + (long long)ctx->world * ctx->halo_m && nr <= nc,
+                      "matrix shape does not match the halo plan");
+    } else {
+        PADNE_REQUIRE(nr == nc, "matrix must be square");
+    }
+    PADNE_REQUIRE(prec != nullptr && prec->n_rows == n && (prec->n_cols == n || prec == a),
+                  "preconditioner must be the matrix itself or its owned x owned block");
+    PADNE_TRY(ensure_workspace(ctx, sizeof(double) * (size_t)(3 * n + 2 * nc + 2 * nr) + 4096));
+    double *r = (double *)ctx->ws;
+    double *p = r + n;          // [n]
+    double *sv = p + n;         // [n]   s = A p (recurrence)
+    double *z = sv + n;         // [nc]  multigrid output with room for the exchanged values
+    double *w = z + nc;         // [nr]  A z
+    double *q = w + nr;         // [nr]  A x of the true-residual checks
+    double *xe = q + nr;        // [nc]
+    PcgStatus *st = (PcgStatus *)ctx->status;
+    PcgStatus *hst = (PcgStatus *)ctx->pinned;
+    hipStream_t s = ctx->stream;
+    const int gv = vec_grid(n);
+    const int gs = spmv_grid(a);
+    const int P_rz = spmv_grid(prec);
+    const int max_iter = o->max_iter > 0 ? o->max_iter : 100000;
+    const int check_every = o->check_every > 0 ? o->check_every : 4;
+    double *scal = ctx->scalars;
+    double *sr = scal + 16;                      // SR_* slots (ctx->scalars holds 64 doubles)
+    const double *bb_scalar = scal + S_BB;
+    float e_jac = 0.f;
+    const float *e_dinv32 = nullptr;
+    float *e_b32 = nullptr, *e_xa32 = nullptr;
+    const bool fuse_entry = amg_f32_entry_args(prec, &e_jac, &e_dinv32, &e_b32, &e_xa32);
+
+    PADNE_HIP_CHECK(hipMemsetAsync(st, 0, sizeof(PcgStatus), s));
+    if (halo) PADNE_HIP_CHECK(hipMemsetAsync(z + n, 0, sizeof(double) * (size_t)(nc - n), s));
+    PADNE_HIP_CHECK(hipEventRecord(ctx->ev0, s));
+    auto product_Ax = [&](double *out) -> int {
+        if (!halo) return launch_spmv(ctx, a, x, out, nullptr, nullptr, nullptr);
+        PADNE_HIP_CHECK(hipMemcpyAsync(xe, x, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+        PADNE_HIP_CHECK(hipMemsetAsync(xe + n, 0, sizeof(double) * (size_t)(nc - n), s));
+        PADNE_TRY(halo_exchange(ctx, xe, nullptr));
+        return launch_spmv(ctx, a, xe, out, nullptr, nullptr, nullptr);
+    };
+    auto fold = [&](const double *first_slot, int P, long long stride, int count, double *out) -> int {
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(256), 0, s, first_slot, P, (int)stride, count, out);
+        PADNE_HIP_CHECK(hipGetLastError());
+        return PADNE_OK;
+    };
+    auto allreduce = [&](double *buf, int count) -> int { return dist ? comm_allreduce_sum_f64(ctx, buf, count) : PADNE_OK; };
+    // z = M r, exchange, w = A z and the three sums of the iteration in one reduction
+    const bool sample_spmv = (o->flags & 2) != 0;
+    std::vector<hipEvent_t> ev_a, ev_b;
+    long long launched = 0;
+    auto cycle_product_reduce = [&](bool entry_done, const int32_t *done_flag) -> int {
+        PADNE_TRY(amg_apply(ctx, prec, r, z, slot(ctx, SLOT_RZ0), done_flag, bb_scalar, entry_done));
+        PADNE_TRY(halo_exchange(ctx, z, done_flag));
+        const bool sampled = sample_spmv && (launched++ % 4) == 1 && ev_a.size() < 512;
+        if (sampled) {
+            hipEvent_t e0, e1;
+            PADNE_HIP_CHECK(hipEventCreate(&e0));
+            PADNE_HIP_CHECK(hipEventCreate(&e1));
+            ev_a.push_back(e0);
+            ev_b.push_back(e1);
+            PADNE_HIP_CHECK(hipEventRecord(e0, s));
+        }
+        PADNE_TRY(launch_spmv(ctx, a, z, w, z, slot(ctx, SLOT_PQ), done_flag));
+        if (sampled) PADNE_HIP_CHECK(hipEventRecord(ev_b.back(), s));
+        hipLaunchKernelGGL(sr_fold3_kernel, dim3(3), dim3(256), 0, s, slot(ctx, SLOT_RZ0), P_rz, slot(ctx, SLOT_PQ), gs,
+                           slot(ctx, SLOT_RR), gv, sr + SR_RED);
+        PADNE_HIP_CHECK(hipGetLastError());
+        return allreduce(sr + SR_RED, 3);
+    };
+
+    int restarts = 0, total_iters = 0, code = PADNE_OK;
+    double true_rr = 0.0, bb = 0.0, tol2 = 0.0, prev_true_rr = 0.0;
+    bool have_ax = false, stagnated = false;
+    if (x_is_guess) {
+        PADNE_TRY(product_Ax(q));
+        have_ax = true;
+    } else {
+        PADNE_HIP_CHECK(hipMemsetAsync(x, 0, sizeof(double) * (size_t)n, s));
+    }
+    for (;;) {
+        // ---- (re)start: r = b - A x ; z = M r ; w = A z ; p = z ; s = w --------------------------------
+        hipLaunchKernelGGL(pcg_init_plain_kernel, dim3(gv), dim3(256), 0, s, n, b, have_ax ? q : nullptr, r,
+                           slot(ctx, SLOT_RR), slot(ctx, SLOT_BB));
+        PADNE_HIP_CHECK(hipGetLastError());
+        PADNE_TRY(fold(slot(ctx, SLOT_RR), gv, kMaxPartials, 2, scal + S_RR));   // RR, BB adjacent: ||b|| normalises the cycle
+        PADNE_TRY(allreduce(scal + S_RR, 2));
+        hipLaunchKernelGGL(pcg_set_tolerance_kernel, dim3(1), dim3(1), 0, s, st, scal + S_RR, o->rtol, o->atol,
+                           restarts > 0 ? 1 : 0);
+        PADNE_HIP_CHECK(hipGetLastError());
+        PADNE_TRY(cycle_product_reduce(false, &st->done));
+        hipLaunchKernelGGL(sr_scalars_kernel, dim3(1), dim3(1), 0, s, st, sr, 1, max_iter - total_iters);
+        hipLaunchKernelGGL(sr_update_ps_kernel, dim3(gv), dim3(256), 0, s, n, sr, z, w, p, sv, st);
+        PADNE_HIP_CHECK(hipGetLastError());
+        bool done = false;
+        while (!done) {
+            for (int k = 0; k < check_every; ++k) {
+                hipLaunchKernelGGL(sr_update_xr_kernel, dim3(gv), dim3(256), 0, s, n, sr, p, sv, x, r, slot(ctx, SLOT_RR), st,
+                                   bb_scalar, e_jac, e_dinv32, fuse_entry ? e_b32 : (float *)nullptr, e_xa32);
+                PADNE_HIP_CHECK(hipGetLastError());
+                PADNE_TRY(cycle_product_reduce(fuse_entry, &st->done));
+                hipLaunchKernelGGL(sr_scalars_kernel, dim3(1), dim3(1), 0, s, st, sr, 0, max_iter - total_iters);
+                hipLaunchKernelGGL(sr_update_ps_kernel, dim3(gv), dim3(256), 0, s, n, sr, z, w, p, sv, st);
+            }
+            PADNE_HIP_CHECK(hipGetLastError());
+            PADNE_HIP_CHECK(hipMemcpyAsync(hst, st, sizeof(PcgStatus), hipMemcpyDeviceToHost, s));
+            PADNE_HIP_CHECK(hipStreamSynchronize(s));
+            done = hst->done != 0;
+        }
+        total_iters += hst->iters;
+        code = hst->code;
+        bb = hst->bb;
+        tol2 = hst->tol2;
+        // ---- true residual ---------------------------------------------------------------------------
+        PADNE_TRY(product_Ax(q));
+        hipLaunchKernelGGL(residual_kernel, dim3(gv), dim3(256), 0, s, n, b, q, (double *)nullptr, slot(ctx, SLOT_TMP));
+        PADNE_TRY(fold(slot(ctx, SLOT_TMP), gv, kMaxPartials, 1, scal + S_TRUE));
+        PADNE_TRY(allreduce(scal + S_TRUE, 1));
+        PADNE_HIP_CHECK(hipMemcpyAsync(&hst[1], scal + S_TRUE, sizeof(double), hipMemcpyDeviceToHost, s));
+        PADNE_HIP_CHECK(hipStreamSynchronize(s));
+        memcpy(&true_rr, &hst[1], sizeof(double));
+        if (code != PADNE_OK) break;
+        if (true_rr <= tol2 * 1.0000001 || total_iters >= max_iter || restarts >= 8) break;
+        if (restarts > 0 && true_rr >= 0.25 * prev_true_rr) {      // the evaluation floor of b - A x (see solve_one)
+            stagnated = true;
+            t_last_solve_stagnated = true;
+            break;
+        }
+        prev_true_rr = true_rr;
+        ++restarts;
+        have_ax = true;
+        PADNE_HIP_CHECK(hipMemsetAsync(st, 0, 2 * sizeof(int32_t), s));
+        PADNE_HIP_CHECK(hipMemsetAsync(&st->iters, 0, sizeof(int32_t), s));
+    }
+    PADNE_HIP_CHECK(hipEventRecord(ctx->ev1, s));
+    PADNE_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    PADNE_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    if (!ev_a.empty()) {       // launches queued after convergence are no-ops: keep the samples within 2x of the median
+        std::vector<double> t_s;
+        for (size_t i = 0; i < ev_a.size(); ++i) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, ev_a[i], ev_b[i]) == hipSuccess) t_s.push_back(t * 1e-3);
+            hipEventDestroy(ev_a[i]);
+            hipEventDestroy(ev_b[i]);
+        }
+        if (info && !t_s.empty()) {
+            std::vector<double> sorted = t_s;
+            std::sort(sorted.begin(), sorted.end());
+            const double med = sorted[sorted.size() / 2];
+            double sum = 0.0;
+            int cnt = 0;
+            for (double t : t_s)
+                if (t >= 0.5 * med && t <= 2.0 * med) {
+                    sum += t;
+                    ++cnt;
+                }
+            if (cnt > 0) info->spmv_seconds = sum / cnt;
+        }
+    }
+    if (info) {
+        info->iterations += total_iters;
+        info->restarts += restarts;
+        const double rel = bb > 0 ? sqrt(true_rr / bb) : sqrt(true_rr);
+        if (rel > info->rel_residual) info->rel_residual = rel;
+        if (sqrt(true_rr) > info->abs_residual) info->abs_residual = sqrt(true_rr);
+        info->solve_seconds += ms * 1e-3;
+        if (code != PADNE_OK) info->status = code;
+        else if (true_rr > tol2 * 1.0000001 && info->status == PADNE_OK) {
+            if (!(stagnated && true_rr <= 100.0 * tol2)) info->status = PADNE_E_NOTCONVERGED;
+        }
+    }
+    return PADNE_OK;
+}
+
 // ---- 8 right-hand sides in lockstep (config C5) ----------------------------------------------------------
 // The same preconditioned CG recurrences, one per right-hand side, advanced together so that the matrix and the
 // multigrid operators are streamed once per iteration for all of them (spmm.hip; vectors interleaved [n][8]).
@@ -1105,8 +1379,20 @@ extern "C" int padne_ctx_set_halo(padne_ctx *ctx, int64_t n_owned, int32_t m, in
     return PADNE_OK;
 }
 
+static int solve_spd_dev_impl(padne_ctx *ctx, const padne_csr *a, const void *b_dev, void *x_dev, int32_t n_rhs,
+                              const padne_solve_opts *opts, padne_solve_info *info);
+
 extern "C" int padne_solve_spd_dev(padne_ctx *ctx, const padne_csr *a, const void *b_dev, void *x_dev,
                                    int32_t n_rhs, const padne_solve_opts *opts, padne_solve_info *info) {
+    const int rc = solve_spd_dev_impl(ctx, a, b_dev, x_dev, n_rhs, opts, info);
+    // "not converged" and "breakdown" are decided from globally reduced scalars, identically on every rank; any other
+    // failure is local to this rank, whose peers would wait for it in their next collective
+    if (rc != PADNE_OK && rc != PADNE_E_NOTCONVERGED && rc != PADNE_E_BREAKDOWN && ctx != nullptr) comm_abort(ctx);
+    return rc;
+}
+
+static int solve_spd_dev_impl(padne_ctx *ctx, const padne_csr *a, const void *b_dev, void *x_dev, int32_t n_rhs,
+                              const padne_solve_opts *opts, padne_solve_info *info) {
     PADNE_REQUIRE(ctx && a && b_dev && x_dev && opts, "null argument");
     PADNE_REQUIRE(n_rhs >= 1, "n_rhs");
     PADNE_REQUIRE(opts->precond == 0 || opts->precond == 1, "precond must be 0 (Jacobi) or 1 (multigrid)");
@@ -1210,10 +1496,19 @@ extern "C" int padne_solve_spd_dev(padne_ctx *ctx, const padne_csr *a, const voi
             }
         }
     }
+    // row-partitioned multigrid runs use the single-reduction loop (one all-reduce per iteration); PADNE_CG_SINGLE_REDUCTION
+    // = 1 / 0 forces it on (also on one GPU, for tests) or off
+    const char *sr_env = getenv("PADNE_CG_SINGLE_REDUCTION");
+    const bool dist_run = ctx->comm != nullptr || ctx->team != nullptr;
+    const bool single_reduction = use_amg && (sr_env != nullptr ? atoi(sr_env) != 0 : dist_run);
     for (int k = k_first; k < n_rhs; ++k) {
         const int status_before = local.status;
-        PADNE_TRY(solve_one(ctx, a, use_amg ? pm : nullptr, (const double *)b_dev + (size_t)k * n,
-                            (double *)x_dev + (size_t)k * n, opts, &local, (opts->flags & 1) != 0));
+        if (single_reduction)
+            PADNE_TRY(solve_one_single_reduction(ctx, a, pm, (const double *)b_dev + (size_t)k * n,
+                                                 (double *)x_dev + (size_t)k * n, opts, &local, (opts->flags & 1) != 0));
+        else
+            PADNE_TRY(solve_one(ctx, a, use_amg ? pm : nullptr, (const double *)b_dev + (size_t)k * n,
+                                (double *)x_dev + (size_t)k * n, opts, &local, (opts->flags & 1) != 0));
         // (a solve that stalled at the binary64 floor of b - A x is not redone: no preconditioner gets below it)
         if (use_amg && local.status != PADNE_OK && status_before == PADNE_OK &&
             !(local.status == PADNE_E_NOTCONVERGED && t_last_solve_stagnated)) {

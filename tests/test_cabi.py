@@ -10,8 +10,8 @@ from padne_amd import _hip, build
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "padne_hip.h")).read()
+def declared_symbols(header="padne_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(padne_[a-z0-9_]+)\s*\(", text)))
 
@@ -31,6 +31,13 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert name in _hip.SIGNATURES, f"{name} has no ctypes prototype in padne_amd/_hip.py"
     for name in _hip.SIGNATURES:
         assert name in names, f"{name} bound in _hip.py but not declared in the header"
+    # the in-process team (several ranks on one GPU) is test scaffolding: its own header, not the drop-in boundary
+    test_names = declared_symbols("padne_hip_test.h")
+    assert test_names and all(n.startswith(("padne_team_", "padne_ctx_join_team")) for n in test_names)
+    assert not set(test_names) & set(names)
+    for name in test_names:
+        assert hasattr(lib, name) and name in _hip.TEST_SIGNATURES
+    assert sorted(_hip.TEST_SIGNATURES) == test_names
 
 
 def test_abi_version_and_error_string():

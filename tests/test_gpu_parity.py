@@ -1134,11 +1134,19 @@ def run_team(sysm, world, precond, block=False):
             plan = distributed.build_layer_partition(sysm, rank, world)
             ds = distributed.DistributedSolver(c, plan, team=team, block_preconditioner=block)
             res = ds.solve(rtol=1e-12, precond=precond)
-            out[rank] = (plan, ds.solution(), res)
-        except Exception as exc:                                  # surface failures instead of dead-locking peers
+            sol = ds.solution()
+            # the same solve again with the hierarchy in place: what ONE solve's iterations cost in collectives
+            # (counters are per process: every rank of the team adds to them)
+            c0 = c.comm_call_counts()[0]
+            res2 = ds.solve(rtol=1e-12, precond=precond)
+            c1 = c.comm_call_counts()[0]
+            assert res2.iterations == res.iterations and np.array_equal(ds.solution(), sol)
+            res.collectives = [b - a for a, b in zip(c0, c1)]
+            out[rank] = (plan, sol, res)
+        except BaseException as exc:                              # wake the peers: they wait for this rank in a collective
             errors.append((rank, exc))
-            raise
-    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+            team.abort()
+    threads = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
     for t in threads:
         t.start()
     for t in threads:
@@ -1172,6 +1180,72 @@ def test_layer_partitioned_solver_with_several_ranks_on_one_gpu(world, precond):
     if precond == "amg":
         # one hierarchy over all ranks converges like the single-GPU one; block-Jacobi pays for the dropped couplings
         assert res.levels >= 2 and iters < (400 if block else 60)
+        # Collectives of one solve, per rank (the counters saw all ranks between two barriers; ranks are not
+        # synchronised at the read-out, hence the slack of one rank's worth).  Single-reduction CG: ONE all-reduce of
+        # three doubles and ONE exchange of z per iteration (+ start, true-residual check); inside the cycle two float
+        # exchanges per row-partitioned level and the gather of the tail -- none at all for block-Jacobi.
+        n_ar, n_ag64, n_ag32 = [c / world for c in res.collectives]
+        # iterations are queued four at a time between two looks at the status word; + cycle and product of the start
+        its = 4 * ((iters + 3) // 4) + 1
+        assert n_ar <= its + 3 + 2, (n_ar, iters)         # 1 per iteration; ||b||, true residual
+        assert n_ag64 <= its + 1 + 2, (n_ag64, iters)     # 1 per iteration; A x of the true residual
+        if block:
+            assert n_ag32 == 0
+        else:
+            assert n_ag32 <= (2 * 2 + 1) * its + 2, (n_ag32, iters)
+
+
+def test_single_reduction_cg_is_the_textbook_iteration(ctx, monkeypatch):
+    """The rearranged loop of the row-partitioned runs (one global reduction per iteration) on ONE GPU against the
+    textbook loop: same iterates up to rounding, same iteration count (+-1), same answer as the direct solve."""
+    A, b, Lo, ro, n = layered_spd(4, 120, 100, 6)
+    d = ctx.csr_from_scipy(A)
+    ref = d.solve_spd(b, precond="amg")
+    monkeypatch.setenv("PADNE_CG_SINGLE_REDUCTION", "1")
+    sr = d.solve_spd(b, precond="amg")
+    again = d.solve_spd(b, precond="amg")
+    assert sr.status == _hip.OK and abs(sr.iterations - ref.iterations) <= 1 and sr.rel_residual <= 1.1e-12
+    assert np.array_equal(sr.x, again.x)                               # bitwise reproducible like the other loop
+    assert np.abs(sr.x - ref.x).max() <= 1e-10 * np.abs(ref.x).max()
+    import scipy.sparse.linalg as spla
+    direct = spla.splu(A.tocsc()).solve(b)
+    assert np.abs(sr.x - direct).max() <= REL_TOL * np.abs(direct).max()
+    warm = d.solve_spd(b, precond="amg", x0=sr.x)
+    assert warm.iterations <= 2
+    with pytest.raises(_hip.NotConvergedError):
+        d.solve_spd(b, precond="amg", max_iter=3)
+    ind = ctx.csr_from_scipy(sp.csr_matrix(A - 2.0 * sp.diags(A.diagonal())))   # indefinite: breakdown, not a hang
+    with pytest.raises(_hip.HipError):
+        ind.solve_spd(b, precond="amg")
+
+
+def test_a_rank_that_fails_does_not_leave_its_peers_waiting():
+    """a rank that leaves a team collective early (here: its driver raises before the first solve) must not
+    block the others for ever -- the team is aborted and their collectives return E_COMM."""
+    import threading
+    from padne_amd import distributed
+    sysm = synthetic.layered_system(4, 40, 30, via_lattice=3)
+    team = _hip.LocalTeam(2)
+    seen = [None, None]
+
+    def rank_main(rank):
+        try:
+            c = _hip.Context(0)
+            plan = distributed.build_layer_partition(sysm, rank, 2)
+            ds = distributed.DistributedSolver(c, plan, team=team)
+            if rank == 1:
+                raise RuntimeError("rank 1 gives up before the solve")
+            ds.solve(rtol=1e-12, precond="amg")
+            seen[rank] = "finished"
+        except BaseException as exc:
+            seen[rank] = exc
+            team.abort()
+    th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(2)]
+    [t.start() for t in th]
+    [t.join(timeout=60) for t in th]
+    assert not any(t.is_alive() for t in th), "a rank is still waiting for its failed peer"
+    assert isinstance(seen[1], RuntimeError)
+    assert isinstance(seen[0], _hip.HipError) and seen[0].code == _hip.E_COMM
 
 
 def test_row_partitioned_hierarchy_with_several_exchanged_levels(monkeypatch):
