@@ -115,6 +115,15 @@ int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns,
                           int64_t n_coo, const int64_t *coo_row, const int64_t *coo_col,
                           const double *coo_val,
                           padne_csr **out);
+/* The same for ONE RANK'S PIECE of a mesh that is partitioned across GPUs (flags bit 0): the triangles are those that
+ * touch a vertex the rank owns, so the vertices of the ring around the owned region have incomplete fans and the
+ * manifold test (PADNE_E_NONMANIFOLD) is switched off -- the rows of ring vertices are dropped by the caller
+ * (padne_csr_relabel); validate the whole mesh on one rank instead.  flags = 0 is padne_assemble_system. */
+int padne_assemble_system_ex(padne_ctx *ctx, int64_t n_unknowns, int64_t n_vert, const double *xy_host,
+                             int64_t n_tri, const int32_t *tri_host, int64_t n_mesh,
+                             const int64_t *mesh_vertex_offset, const int64_t *mesh_tri_offset,
+                             const double *conductance, int64_t n_coo, const int64_t *coo_row,
+                             const int64_t *coo_col, const double *coo_val, int32_t flags, padne_csr **out);
 
 /* out = scale * P^T M P restricted to kept indices: entry (i,j,v) of M becomes
  * (map[i], map[j], scale*v) if both maps are >= 0; duplicates are summed.  Used to turn the

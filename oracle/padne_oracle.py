@@ -103,16 +103,19 @@ def check_manifold(n_vert: int, tri: np.ndarray) -> None:
 # --------------------------------------------------------------------------
 
 
-def laplace_operator(xy: np.ndarray, tri: np.ndarray) -> sp.coo_matrix:
+def laplace_operator(xy: np.ndarray, tri: np.ndarray, validate: bool = True) -> sp.coo_matrix:
     """Mesh-local cotangent Laplacian, reference sign (L_ik=+w, L_ii=-sum w).
 
     COO without duplicates, rows in ascending (row, col) order with the
-    diagonal included; exact-zero weights are not stored.
+    diagonal included; exact-zero weights are not stored.  ``validate=False`` skips the manifold test of
+    ``Mesh.from_triangle_soup`` (for a piece of a mesh whose outer ring of vertices has incomplete fans, as the
+    tests of the strip partition assemble; the reference itself always validates).
     """
     xy = np.asarray(xy, dtype=DTYPE).reshape(-1, 2)
     tri = np.asarray(tri, dtype=np.int64).reshape(-1, 3)
     n = xy.shape[0]
-    check_manifold(n, tri)
+    if validate:
+        check_manifold(n, tri)
     c = triangle_corner_cot_half(xy, tri)
     # each triangle edge contributes to both directed entries (i,k) and (k,i)
     i = tri.reshape(-1)

@@ -77,6 +77,8 @@ SIGNATURES = {
     "padne_csr_to_host": (C.c_int, [_P, _P, _PI32, _PI32, _PF64]),
     "padne_assemble_system": (C.c_int, [_P, _I64, _I64, _PF64, _I64, _PI32, _I64, _PI64, _PI64, _PF64,
                                         _I64, _PI64, _PI64, _PF64, C.POINTER(_P)]),
+    "padne_assemble_system_ex": (C.c_int, [_P, _I64, _I64, _PF64, _I64, _PI32, _I64, _PI64, _PI64, _PF64,
+                                           _I64, _PI64, _PI64, _PF64, C.c_int32, C.POINTER(_P)]),
     "padne_csr_reduce": (C.c_int, [_P, _P, _PI32, _I64, C.c_double, C.POINTER(_P)]),
     "padne_csr_relabel": (C.c_int, [_P, _P, _PI32, _I64, _PI32, _I64, C.c_double, C.POINTER(_P)]),
     "padne_csr_vstack": (C.c_int, [_P, _P, _P, C.POINTER(_P)]),
@@ -285,8 +287,9 @@ class Context:
         return CsrMatrix(self, h)
 
     def assemble_system(self, n_unknowns, xy, tri, mesh_vertex_offset, mesh_tri_offset, conductance,
-                        coo_row, coo_col, coo_val) -> "CsrMatrix":
-        """L in the reference layout: cotangent Laplacians of all meshes + lumped stamps."""
+                        coo_row, coo_col, coo_val, partial_mesh: bool = False) -> "CsrMatrix":
+        """L in the reference layout: cotangent Laplacians of all meshes + lumped stamps.  ``partial_mesh``: the
+        triangles are one rank's piece of a partitioned mesh (no manifold test, see padne_assemble_system_ex)."""
         xy = _f64(xy).reshape(-1, 2)
         tri = _i32(tri).reshape(-1, 3)
         mvo, mto, sig = _i64(mesh_vertex_offset), _i64(mesh_tri_offset), _f64(conductance)
@@ -297,10 +300,10 @@ class Context:
         if not (cr.shape == cc.shape == cv.shape):
             raise ValueError("coo arrays must have equal length")
         h = _P()
-        _check(self._lib.padne_assemble_system(
+        _check(self._lib.padne_assemble_system_ex(
             self._h, int(n_unknowns), xy.shape[0], _ptr(xy, _PF64), tri.shape[0], _ptr(tri, _PI32), n_mesh,
             _ptr(mvo, _PI64), _ptr(mto, _PI64), _ptr(sig, _PF64), cr.shape[0], _ptr(cr, _PI64),
-            _ptr(cc, _PI64), _ptr(cv, _PF64), C.byref(h)))
+            _ptr(cc, _PI64), _ptr(cv, _PF64), 1 if partial_mesh else 0, C.byref(h)))
         return CsrMatrix(self, h)
 
     def nearest_vertex(self, points: np.ndarray, queries: np.ndarray) -> np.ndarray:

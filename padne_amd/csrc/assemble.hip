@@ -958,6 +958,10 @@ __global__ void power_density_kernel(long long n_tri, const int *__restrict__ tr
 
 // ---- host orchestration ----------------------------------------------------------------------
 // shared tail: slots (key,val,slot_ptr) already filled -> merged CSR
+// padne_assemble_system_ex(flags & 1): the triangles are a rank's piece of a larger mesh (owned vertices + the ring of
+// vertices around them); the fans of the ring vertices are incomplete by construction, so the manifold test is off
+static thread_local bool t_partial_mesh = false;
+
 template <bool MESH>
 static int finish_rows(padne_ctx *ctx, Scratch &sc, long long n_rows, long long n_cols, long long n_vert, int n_mesh,
                        const long long *d_voff, const double *d_sigma, const int *slot_ptr, long long *key,
@@ -1000,7 +1004,7 @@ static int finish_rows(padne_ctx *ctx, Scratch &sc, long long n_rows, long long 
     int h_err[ERR_WORDS];
     PADNE_HIP_CHECK(hipMemcpyAsync(h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
     PADNE_HIP_CHECK(hipStreamSynchronize(s));
-    if (h_err[ERR_NONMANIFOLD]) {
+    if (h_err[ERR_NONMANIFOLD] && !t_partial_mesh) {
         set_error("Non-manifold mesh");
         return PADNE_E_NONMANIFOLD;
     }
@@ -1120,6 +1124,19 @@ int csr_from_exact_slots(padne_ctx *ctx, long long n_rows, long long n_cols, lon
 }  // namespace padne
 
 using namespace padne;
+
+extern "C" int padne_assemble_system_ex(padne_ctx *ctx, int64_t n_unknowns, int64_t n_vert, const double *xy_host,
+                                        int64_t n_tri, const int32_t *tri_host, int64_t n_mesh,
+                                        const int64_t *mesh_vertex_offset, const int64_t *mesh_tri_offset,
+                                        const double *conductance, int64_t n_coo, const int64_t *coo_row,
+                                        const int64_t *coo_col, const double *coo_val, int32_t flags, padne_csr **out) {
+    struct Guard {
+        ~Guard() { t_partial_mesh = false; }
+    } guard;
+    t_partial_mesh = (flags & 1) != 0;
+    return padne_assemble_system(ctx, n_unknowns, n_vert, xy_host, n_tri, tri_host, n_mesh, mesh_vertex_offset,
+                                 mesh_tri_offset, conductance, n_coo, coo_row, coo_col, coo_val, out);
+}
 
 extern "C" int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns, int64_t n_vert, const double *xy_host,
                                      int64_t n_tri, const int32_t *tri_host, int64_t n_mesh,

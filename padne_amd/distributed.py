@@ -1,19 +1,22 @@
-"""Layer partition of a meshed system across the GPUs of one node (one process per GPU).
+"""Partition of a meshed system across the GPUs of one node (one process per GPU).
 
-No counterpart in the reference (single process); the plan follows
-SURVEY.md section 8e: rows are partitioned *by layer* -- every mesh block is already contiguous in
-the global numbering (``solver.py:221-229``) and the mesh Laplacian of a layer has no off-rank
-columns.  The only cross-rank couplings are lumped elements whose terminals sit on different
-ranks (via resistor rings).  Per PCG iteration a rank therefore needs
+No counterpart in the reference (single process); the plan follows SURVEY.md section 8e:
 
-* the current values of the few thousand remote vertices its via resistors touch: every rank
-  packs the owned values somebody else needs (``export`` list) and one ``ncclAllGather`` of
-  ``m = max_r len(export_r)`` doubles per rank delivers them (``padne_ctx_set_halo``);
-* the global dot products: one-workgroup fold + ``ncclAllReduce`` of 1-2 doubles.
+* with at least as many layers as ranks the rows are partitioned *by layer* -- every mesh block is contiguous in the
+  global numbering (``solver.py:221-229``) and the mesh Laplacian of a layer has no off-rank columns, so the only
+  cross-rank couplings are lumped elements whose terminals sit on different ranks (via resistor rings);
+* with fewer layers than ranks a layer is cut into horizontal *strips* (SURVEY 8e fallback): the rank also assembles
+  the ring of vertices around its strip, whose rows it then drops, and the mesh edges across a cut join the via
+  resistors as cross-rank couplings.
 
-This module is host-side index bookkeeping only: it decides who owns what, renumbers the lumped
-stamps into each rank's local index space and hands the local triangles + stamps to the same
-device assembly the single-GPU path uses.
+Either way a rank's matrix is ``owned rows x [owned | world * m exchange slots]``: per product every rank packs the
+owned values somebody else needs (``export`` list) and one ``ncclAllGather`` of ``m = max_r len(export_r)`` values per
+rank delivers them (``padne_ctx_set_halo``); dot products are a one-workgroup fold + ``ncclAllReduce``.
+
+This module is host-side index bookkeeping only: it decides who owns what, renumbers triangles and lumped stamps into
+each rank's local index space and hands them to the same device assembly the single-GPU path uses.  Every rank holds
+the whole problem description on the host (as ``solve()`` does after meshing) and derives ALL ranks' export lists from
+it, so no rank ever decides anything from data another rank lacks.
 """
 from __future__ import annotations
 
@@ -29,110 +32,265 @@ from .synthetic import SyntheticSystem
 class RankPlan:
     rank: int
     world: int
-    meshes: list                   # this rank's (xy, tri, sigma, layer) blocks
-    g0: int                        # first owned global vertex
-    g1: int                        # one past the last owned global vertex
-    ground_local: int              # local index of the ground vertex, or -1 if another rank owns it
+    meshes: list                   # this rank's (xy, tri, sigma, layer) blocks: owned vertices + the ring around them
+    local_global: np.ndarray       # int64: global unknown of every local assembly unknown (mesh blocks first)
+    owned_global: np.ndarray       # int64: global unknowns this rank owns (ascending), the ground included if it is here
+    ground_local: int              # position of the ground in owned_global, or -1 if another rank owns it
     m: int                         # exchange segment length (max export count over ranks)
-    export_local: np.ndarray       # int32: owned local indices other ranks need, in export order
-    n_local_unknowns: int          # owned vertices + world*m exchange slots
-    coo_rows: np.ndarray           # lumped stamps of the owned rows, local indices, stamp order
+    export_owned: np.ndarray       # int64: positions in owned_global of the unknowns other ranks need, export order
+    n_local_unknowns: int          # local assembly unknowns (len(local_global))
+    coo_rows: np.ndarray           # lumped stamps of the owned rows, local assembly indices, stamp order
     coo_cols: np.ndarray
     coo_vals: np.ndarray
-    rhs_local: np.ndarray          # r restricted to the owned vertices
-    owned_global: np.ndarray = field(default=None)   # global vertex id of each owned local vertex
+    rhs_local: np.ndarray          # r restricted to owned_global
+    row_map: np.ndarray            # int32 over local assembly unknowns: reduced owned row, or -1 (ring, ground)
+    col_map: np.ndarray            # int32: reduced owned column | exchange slot n_owned_reduced + q*m + k | -1 (ground)
+    n_owned_reduced: int
+    export_reduced: np.ndarray     # int32: reduced owned indices of the exported unknowns, export order
+    partial_mesh: bool = False     # the mesh blocks are pieces of larger meshes (strip partition)
 
     @property
-    def n_owned_vertices(self) -> int:
-        return self.g1 - self.g0
+    def n_owned_vertices(self) -> int:           # (name kept from the layer-only plan: owned unknowns incl. ground)
+        return len(self.owned_global)
+
+    @property
+    def g0(self) -> int:
+        return int(self.owned_global[0]) if len(self.owned_global) else 0
+
+    @property
+    def g1(self) -> int:
+        return int(self.owned_global[-1]) + 1 if len(self.owned_global) else 0
+
+    @property
+    def n_cols(self) -> int:
+        return self.n_owned_reduced + self.world * self.m
+
+
+@dataclass
+class Partition:
+    """Where this process stands in a row-partitioned solve: ``solver.solve_meshed(..., partition=Partition(...))``.
+
+    ``dist``: the initialised ``torch.distributed`` module (one process per GPU, backend "nccl" = RCCL); or ``team``: a
+    ``_hip.LocalTeam`` with one thread per rank on one GPU (tests), in which case ``gather`` must collect one Python
+    object per rank into a list (``torch.distributed.all_gather_object`` does that for processes)."""
+    rank: int
+    world: int
+    dist: object = None
+    team: object = None
+    gather: object = None
+    device: int = None            # GPU of this rank (default: rank for processes, 0 for a team)
 
 
 def layer_ranges(n_layers: int, world: int):
-    """Contiguous, balanced assignment of layers to ranks."""
+    """Contiguous, balanced assignment of layers to ranks (needs n_layers >= world; fewer layers are cut into strips by
+    :func:`owners_of_unknowns`)."""
     if world > n_layers:
-        raise ValueError(f"{world} ranks but only {n_layers} layers: strip partitioning of a layer is not implemented")
+        raise ValueError(f"{world} ranks but only {n_layers} layers: use owners_of_unknowns (strip partition)")
     cuts = [(r * n_layers) // world for r in range(world + 1)]
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
-def build_layer_partition(sysm: SyntheticSystem, rank: int, world: int) -> RankPlan:
-    """Plan for ``rank``; deterministic and identical on every rank for the shared parts."""
-    offs = sysm.mesh_offsets
-    n_layers = len(sysm.meshes)
-    ranges = layer_ranges(n_layers, world)
-    vert_range = [(int(offs[a]), int(offs[b])) for a, b in ranges]
-    owner_cut = np.array([v[0] for v in vert_range] + [int(offs[-1])], dtype=np.int64)
+def owners_of_unknowns(meshes, n_unknowns: int, world: int, links=None) -> np.ndarray:
+    """Owner rank of every unknown.  ``meshes``: (xy, tri, sigma, layer) in global numbering order.
 
-    def owner_of(g):
-        return np.searchsorted(owner_cut, g, side="right") - 1
+    * n_meshes >= world: whole meshes, contiguous and balanced (the layer partition);
+    * fewer meshes than ranks: the ranks are dealt to the meshes in proportion to their sizes and each mesh is cut into
+      that many horizontal strips of (nearly) equal vertex counts (cuts at quantiles of y, ties kept together by index).
+    Unknowns behind the vertices (internal nodes) go to the owner of the smallest unknown they are linked to
+    (``links``: pairs of unknowns coupled by lumped stamps), rank 0 if none."""
+    sizes = np.array([len(m[0]) for m in meshes], dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    n_vert = int(offs[-1])
+    owner = np.zeros(n_unknowns, dtype=np.int32)
+    n_m = len(meshes)
+    if n_m >= world:
+        for r, (a, b) in enumerate(layer_ranges(n_m, world)):
+            owner[offs[a]:offs[b]] = r
+    elif n_m > 0:
+        # ranks per mesh: at least one each, the rest by largest remainder of the size shares
+        share = sizes / max(sizes.sum(), 1) * world
+        per = np.maximum(np.floor(share).astype(int), 1)
+        while per.sum() > world:
+            per[np.argmax(per)] -= 1
+        order = np.argsort(-(share - np.floor(share)), kind="stable")
+        k = 0
+        while per.sum() < world:
+            per[order[k % n_m]] += 1
+            k += 1
+        r0 = 0
+        for mi, (xy, _tri, _s, _l) in enumerate(meshes):
+            n = len(xy)
+            k_strips = int(per[mi])
+            rank_in_mesh = np.zeros(n, dtype=np.int32)
+            if k_strips > 1 and n > 0:
+                by_y = np.lexsort((np.arange(n), xy[:, 1]))
+                rank_in_mesh[by_y] = np.minimum((np.arange(n, dtype=np.int64) * k_strips) // n, k_strips - 1)
+            owner[offs[mi]:offs[mi + 1]] = r0 + rank_in_mesh
+            r0 += k_strips
+    if n_unknowns > n_vert:
+        owner[n_vert:] = -1
+        if links is not None and len(links):
+            lk = np.asarray(links, dtype=np.int64).reshape(-1, 2)
+            for _ in range(4):                                   # chains of internal nodes: a few sweeps settle them
+                for a, b in ((lk[:, 0], lk[:, 1]), (lk[:, 1], lk[:, 0])):
+                    sel = (owner[a] < 0) & (owner[b] >= 0)
+                    if sel.any():
+                        o = np.argsort(b[sel], kind="stable")[::-1]          # smallest linked unknown wins (written last)
+                        owner[a[sel][o]] = owner[b[sel][o]]
+        owner[owner < 0] = 0
+    return owner
 
-    ra, rb, rr = sysm.resistors
-    oa, ob = owner_of(ra), owner_of(rb)
-    cross = oa != ob
-    # export lists: vertices of rank r referenced from a row owned by another rank; sorted & unique
-    exports = []
-    for r in range(world):
-        need = np.concatenate([ra[cross & (oa == r)], rb[cross & (ob == r)]])
-        exports.append(np.unique(need))
+
+def build_partition(meshes, n_unknowns: int, coo, rhs: np.ndarray, ground: int, owner: np.ndarray, rank: int,
+                    world: int) -> RankPlan:
+    """Plan of ``rank`` for an arbitrary ownership of the unknowns.
+
+    ``meshes``: (xy, tri, sigma, layer) in global numbering order (vertices first, ``solver.py:221-229``);
+    ``coo = (rows, cols, vals)``: lumped stamps on global unknowns in stamp order, WITHOUT the ground row / column
+    (``ground`` is eliminated: it is 0 V by definition, ``solver.py:558-560``).  Deterministic and identical on every
+    rank for the shared parts (export lists of all ranks)."""
+    rows_g, cols_g, vals_g = (np.asarray(a) for a in coo)
+    rows_g = rows_g.astype(np.int64)
+    cols_g = cols_g.astype(np.int64)
+    owner = np.asarray(owner, dtype=np.int32)
+    sizes = np.array([len(m[0]) for m in meshes], dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n_vert = int(offs[-1])
+    # ---- who needs what: (unknown, needing rank) pairs from mesh edges across a cut and from lumped stamps ----------
+    need_u, need_r = [], []
+    tri_mine = []
+    for mi, (xy, tri, _s, _l) in enumerate(meshes):
+        t = np.asarray(tri, dtype=np.int64) + offs[mi]
+        if len(t) == 0:
+            tri_mine.append(np.zeros(0, dtype=np.int64))
+            continue
+        ot = owner[t]                                            # [n_tri, 3]
+        mixed = (ot[:, 0] != ot[:, 1]) | (ot[:, 1] != ot[:, 2])
+        if mixed.any():
+            tm, om = t[mixed], ot[mixed]
+            for k in range(3):
+                for j in range(3):
+                    if j != k:
+                        sel = om[:, k] != om[:, j]
+                        need_u.append(tm[sel, k])
+                        need_r.append(om[sel, j])
+        tri_mine.append(np.flatnonzero((ot == rank).any(axis=1)))
+    cross = owner[rows_g] != owner[cols_g]
+    need_u.append(cols_g[cross])
+    need_r.append(owner[rows_g[cross]])
+    need_u = np.concatenate(need_u) if need_u else np.zeros(0, np.int64)
+    need_r = np.concatenate(need_r) if need_r else np.zeros(0, np.int32)
+    keep = need_u != ground                                      # the ground is never exchanged: its value is 0
+    need_u, need_r = need_u[keep], need_r[keep]
+    exports = [np.unique(need_u[owner[need_u] == q]) for q in range(world)]
     m = int(max((len(e) for e in exports), default=0))
-    g0, g1 = vert_range[rank]
-    n_own = g1 - g0
+    # ---- local assembly unknowns: owned + ring (triangles) + remote stamp terminals ------------------------------------
+    owned = np.flatnonzero(owner == rank).astype(np.int64)
+    mine_rows = owner[rows_g] == rank
+    parts = [owned, cols_g[mine_rows]]
+    local_meshes = []
+    for mi, (xy, tri, s, l) in enumerate(meshes):
+        t = np.asarray(tri, dtype=np.int64)[tri_mine[mi]] + offs[mi]
+        parts.append(t.reshape(-1))
+    U = np.unique(np.concatenate(parts))
+    partial = False
+    for mi, (xy, tri, s, l) in enumerate(meshes):
+        a, b = np.searchsorted(U, [offs[mi], offs[mi + 1]])
+        if b == a:
+            continue
+        vg = U[a:b]
+        t = np.asarray(tri, dtype=np.int64)[tri_mine[mi]] + offs[mi]
+        tl = (np.searchsorted(vg, t.reshape(-1)).reshape(-1, 3)).astype(np.int32)
+        if 0 < len(tri_mine[mi]) < len(tri):                     # a piece of the mesh: owned strip + ring
+            partial = True
+        local_meshes.append((np.ascontiguousarray(np.asarray(xy)[vg - offs[mi]]), tl, float(s), int(l)))
+    # ---- relabelling maps ------------------------------------------------------------------------------------------------
+    own_red = owned[owned != ground]
+    n_red = len(own_red)
+    is_owned = owner[U] == rank
+    row_map = np.full(len(U), -1, dtype=np.int32)
+    sel = is_owned & (U != ground)
+    row_map[sel] = np.searchsorted(own_red, U[sel]).astype(np.int32)
+    col_map = row_map.copy()
+    rem = ~is_owned & (U != ground)
+    if rem.any():
+        ur = U[rem]
+        orr = owner[ur]
+        slot = np.empty(len(ur), dtype=np.int64)
+        for q in range(world):
+            s_q = orr == q
+            if not s_q.any():
+                continue
+            ex = exports[q]
+            if len(ex) == 0:
+                slot[s_q] = -1
+                continue
+            pos = np.minimum(np.searchsorted(ex, ur[s_q]), len(ex) - 1)
+            # ring vertices that no owned ROW references (they only complete a triangle) are nobody's import: no slot
+            slot[s_q] = np.where(ex[pos] == ur[s_q], n_red + q * m + pos, -1)
+        col_map[rem] = slot.astype(np.int32)
+    export_red = np.searchsorted(own_red, exports[rank]).astype(np.int32)
+    export_owned = np.searchsorted(owned, exports[rank]).astype(np.int64)
+    coo_rows = np.searchsorted(U, rows_g[mine_rows])
+    coo_cols = np.searchsorted(U, cols_g[mine_rows])
+    g_pos = np.flatnonzero(owned == ground)
+    return RankPlan(rank=rank, world=world, meshes=local_meshes, local_global=U, owned_global=owned,
+                    ground_local=int(g_pos[0]) if len(g_pos) else -1, m=m, export_owned=export_owned,
+                    n_local_unknowns=len(U), coo_rows=coo_rows.astype(np.int64), coo_cols=coo_cols.astype(np.int64),
+                    coo_vals=np.asarray(vals_g, dtype=np.float64)[mine_rows], rhs_local=np.asarray(rhs, dtype=np.float64)[owned],
+                    row_map=row_map, col_map=col_map, n_owned_reduced=n_red, export_reduced=export_red,
+                    partial_mesh=partial)
 
-    def local_col(g):
-        """Local column of global vertex g: owned -> g - g0, remote -> its slot in the exchange area."""
-        g = np.asarray(g, dtype=np.int64)
-        out = g - g0
-        o = owner_of(g)
-        rem = o != rank
-        if rem.any():
-            pos = np.empty(g.shape, dtype=np.int64)
-            for r in range(world):
-                sel = rem & (o == r)
-                if sel.any():
-                    pos[sel] = n_own + r * m + np.searchsorted(exports[r], g[sel])
-            out = np.where(rem, pos, out)
-        return out
 
-    g = 1.0 / rr
-    # stamp order of the reference per resistor: (a,a,-g) (a,b,+g) (b,b,-g) (b,a,+g)   solver.py:480-484
+def resistor_stamps(ra, rb, rr):
+    """COO stamps of resistors in the reference's order per element: (a,a,-g) (a,b,+g) (b,b,-g) (b,a,+g), solver.py:480-484."""
+    g = 1.0 / np.asarray(rr, dtype=np.float64)
     rows = np.stack([ra, ra, rb, rb], 1).reshape(-1)
     cols = np.stack([ra, rb, rb, ra], 1).reshape(-1)
     vals = np.stack([-g, g, -g, g], 1).reshape(-1)
-    mine = owner_of(rows) == rank
-    rows, cols, vals = rows[mine], cols[mine], vals[mine]
-    coo_rows = rows - g0
-    coo_cols = local_col(cols)
-    rhs = np.zeros(n_own)
+    return rows.astype(np.int64), cols.astype(np.int64), vals
+
+
+def build_layer_partition(sysm: SyntheticSystem, rank: int, world: int) -> RankPlan:
+    """Plan of ``rank`` for a :class:`SyntheticSystem` (resistors + current sources): by layer, or by strips of layers
+    when there are fewer layers than ranks."""
+    n = sysm.n_vertices + sysm.n_internal
+    ra, rb, rr = sysm.resistors
+    coo = resistor_stamps(ra, rb, rr)
+    rhs = np.zeros(n)
     f, t, cur = sysm.current_sources
-    for ff, tt, ii in zip(f, t, cur):
-        if g0 <= ff < g1:
-            rhs[ff - g0] += ii
-        if g0 <= tt < g1:
-            rhs[tt - g0] += -ii
-    ground_local = int(sysm.ground - g0) if g0 <= sysm.ground < g1 else -1
-    a, b = ranges[rank]
-    return RankPlan(rank=rank, world=world, meshes=sysm.meshes[a:b], g0=g0, g1=g1, ground_local=ground_local, m=m,
-                    export_local=(exports[rank] - g0).astype(np.int32), n_local_unknowns=n_own + world * m,
-                    coo_rows=coo_rows.astype(np.int64), coo_cols=coo_cols.astype(np.int64), coo_vals=vals,
-                    rhs_local=rhs, owned_global=np.arange(g0, g1, dtype=np.int64))
+    np.add.at(rhs, f, cur)
+    np.add.at(rhs, t, -np.asarray(cur))
+    links = np.stack([ra, rb], axis=1) if len(ra) else None
+    owner = owners_of_unknowns(sysm.meshes, n, world, links)
+    return build_partition(sysm.meshes, n, coo, rhs, int(sysm.ground), owner, rank, world)
+
+
+def build_problem_partition(meshes, conductances, mesh_layers, stamps, rhs: np.ndarray, n_potential: int, rank: int,
+                            world: int) -> RankPlan:
+    """Plan of ``rank`` for an assembled Problem (what ``solver.solve_meshed`` has after numbering and stamp listing):
+    ``meshes`` are :class:`padne_amd.mesh.Mesh`, ``stamps`` the :class:`padne_amd.solver.StampList`.  Supported: the
+    systems whose only constraint is the ground (resistors, current sources, vias); voltage sources and regulators
+    need the index reduction of ``reduction.py`` on every rank and are not distributed yet."""
+    cons = [c for c in stamps.constraints]
+    if len(cons) != 1 or cons[0].n >= 0:
+        raise NotImplementedError("the row-partitioned path handles resistors and current sources; voltage sources / "
+                                  "regulators are solved on one GPU")
+    ground = int(cons[0].p)
+    rows, cols, vals = stamps.arrays()
+    keep = (rows < n_potential) & (cols < n_potential)            # drop the ground row / column of the KKT layout
+    ms = [(m.points, m.triangles, float(s), int(l)) for m, s, l in zip(meshes, conductances, mesh_layers)]
+    off = rows != cols
+    links = np.stack([rows[keep & off], cols[keep & off]], axis=1)
+    owner = owners_of_unknowns(ms, n_potential, world, links)
+    return build_partition(ms, n_potential, (rows[keep], cols[keep], vals[keep]), np.asarray(rhs)[:n_potential], ground,
+                           owner, rank, world)
 
 
 def reduced_local_map(plan: RankPlan):
-    """Index map local unknown -> local reduced unknown: the ground vertex (if owned) is dropped, owned
-    vertices keep their order, exchange slots follow.  Returns (map int32, n_owned_reduced, export_reduced)."""
-    n_own = plan.n_owned_vertices
-    n_loc = plan.n_local_unknowns
-    imap = np.arange(n_loc, dtype=np.int32)
-    if plan.ground_local >= 0:
-        imap[plan.ground_local] = -1
-        imap[plan.ground_local + 1:] -= 1
-    n_owned_red = n_own - (1 if plan.ground_local >= 0 else 0)
-    export_red = imap[plan.export_local]
-    if (export_red < 0).any():
-        # the ground vertex is exported: its value is 0 by definition; keep the slot, feed it from any
-        # owned unknown times zero is not possible -> such stamps are Dirichlet terms of the remote rows.
-        raise NotImplementedError("a via resistor lands on the ground vertex; choose another ground")
-    return imap, n_owned_red, export_red.astype(np.int32)
+    """(row_map, col_map, n_owned_reduced, export_reduced) of the plan: what ``padne_csr_relabel`` turns the local
+    assembly into this rank's rows of A = -L_vv, ``owned rows x [owned | world * m exchange slots]``."""
+    return plan.row_map, plan.col_map, plan.n_owned_reduced, plan.export_reduced
 
 
 class DistributedSolver:
@@ -159,33 +317,36 @@ class DistributedSolver:
             dist.broadcast(t, src=0)
             ctx.comm_init(bytes(t.cpu().numpy().tobytes()), plan.rank, plan.world)
         # local assembly on this GPU
-        xy = np.concatenate([mm[0] for mm in plan.meshes])
-        tri = np.concatenate([mm[1] for mm in plan.meshes])
-        mvo = np.concatenate([[0], np.cumsum([len(mm[0]) for mm in plan.meshes])]).astype(np.int64)
-        mto = np.concatenate([[0], np.cumsum([len(mm[1]) for mm in plan.meshes])]).astype(np.int64)
-        sig = np.array([mm[2] for mm in plan.meshes])
+        ms = plan.meshes
+        xy = np.concatenate([mm[0] for mm in ms]) if ms else np.zeros((0, 2))
+        tri = np.concatenate([mm[1] for mm in ms]) if ms else np.zeros((0, 3), np.int32)
+        mvo = np.concatenate([[0], np.cumsum([len(mm[0]) for mm in ms])]).astype(np.int64)
+        mto = np.concatenate([[0], np.cumsum([len(mm[1]) for mm in ms])]).astype(np.int64)
+        sig = np.array([mm[2] for mm in ms])
         t0 = time.perf_counter()
         L = ctx.assemble_system(plan.n_local_unknowns, xy, tri, mvo, mto, sig, plan.coo_rows, plan.coo_cols,
-                                plan.coo_vals)
+                                plan.coo_vals, partial_mesh=plan.partial_mesh)
         ctx.synchronize()
         self.t_assemble = time.perf_counter() - t0
-        imap, n_owned, export_red = reduced_local_map(plan)
+        n_owned = plan.n_owned_reduced
         t0 = time.perf_counter()
         # this rank's rows of A = -L_vv: owned rows x [owned | world * m exchange slots]
-        rmap = imap.copy()
-        rmap[plan.n_owned_vertices:] = -1
-        self.A = L.relabel(rmap, n_owned, imap, n_owned + plan.world * plan.m, -1.0)
+        self.A = L.relabel(plan.row_map, n_owned, plan.col_map, plan.n_cols, -1.0)
         self.A_block = None
         if block_preconditioner:
             # owned x owned diagonal block (couplings to other ranks dropped)
-            self.A_block = L.reduce(rmap, n_owned, -1.0)
+            self.A_block = L.reduce(plan.row_map, n_owned, -1.0)
             self.A.set_preconditioner_block(self.A_block)
         ctx.synchronize()
         self.t_reduce = time.perf_counter() - t0
         L.close()
         self.n_owned = n_owned
-        ctx.set_halo(n_owned, plan.m, export_red)
-        keep = np.flatnonzero(imap[:plan.n_owned_vertices] >= 0)
+        ctx.set_halo(n_owned, plan.m, plan.export_reduced)
+        own = plan.owned_global
+        keep = np.ones(len(own), dtype=bool)
+        if plan.ground_local >= 0:
+            keep[plan.ground_local] = False
+        self.owned_reduced_global = own[keep]
         self.b = ctx.to_device(-plan.rhs_local[keep])
         self.x = ctx.empty(n_owned)
         self.nnz = self.A.nnz
@@ -195,4 +356,23 @@ class DistributedSolver:
         return self.A.solve_spd_dev(self.b, self.x, rtol=rtol, time_spmv=time_spmv, precond=precond, rebuild=rebuild)
 
     def solution(self) -> np.ndarray:
+        """Potentials of the owned unknowns except the ground, in the order of ``owned_reduced_global``."""
         return self.x.numpy()
+
+
+def solve_partitioned(plan: RankPlan, ctx, dist=None, team=None, rtol: float = 1e-12, gather=None):
+    """Solve and return the potentials of ALL unknowns on every rank (ground = 0).  ``gather(values, indices)``
+    collects (array, array) pairs from all ranks into lists; with ``dist`` it defaults to ``all_gather_object``."""
+    ds = DistributedSolver(ctx, plan, dist=dist, team=team)
+    res = ds.solve(rtol=rtol)
+    mine = (ds.owned_reduced_global, ds.solution())
+    if gather is None:
+        parts = [None] * plan.world
+        dist.all_gather_object(parts, mine)
+    else:
+        parts = gather(mine)
+    n = max(int(p[0].max()) + 1 if len(p[0]) else 0 for p in parts)
+    v = np.zeros(max(n, int(plan.owned_global.max()) + 1 if len(plan.owned_global) else 0))
+    for idx, vals in parts:
+        v[idx] = vals
+    return v, res

@@ -24,6 +24,7 @@ There is no CPU fallback: every entry point that computes raises
 from __future__ import annotations
 
 import logging
+import threading
 import warnings
 from dataclasses import dataclass, field
 from typing import Optional, Sequence
@@ -44,20 +45,19 @@ DTYPE = np.float64
 RTOL = 1e-12
 MAX_ITER = 200000
 
-_default_ctx: Optional[_hip.Context] = None
+_default = threading.local()        # one context per host thread: a context (stream, pools) is not shared between threads
 
 
 def get_context() -> _hip.Context:
-    """Process-wide device context (GPU 0 unless ``set_context`` was called)."""
-    global _default_ctx
-    if _default_ctx is None:
-        _default_ctx = _hip.Context(0)
-    return _default_ctx
+    """Device context of the calling thread (GPU 0 unless ``set_context`` was called in this thread)."""
+    ctx = getattr(_default, "ctx", None)
+    if ctx is None:
+        ctx = _default.ctx = _hip.Context(0)
+    return ctx
 
 
 def set_context(ctx: Optional[_hip.Context]) -> None:
-    global _default_ctx
-    _default_ctx = ctx
+    _default.ctx = ctx
 
 
 NEAREST_ON_DEVICE_FROM = 50000     # vertices of a layer from which connections are snapped on the device
@@ -684,9 +684,38 @@ def produce_layer_solutions(layers, vindex: VertexIndexer, meshes, mesh_index_to
 # --------------------------------------------------------------------------------------------
 
 
+def _solve_partitioned(prob, meshes, mesh_index_to_layer_index, vindex, filtered_networks, node_indexer, partition,
+                       ctx):
+    """The solve of ``solve_meshed`` with the rows dealt to several GPUs (``distributed.py``): every rank lists the
+    same stamps, assembles and solves its own rows, and all ranks end up with all potentials."""
+    from . import distributed
+    conductances = [prob.layers[mesh_index_to_layer_index[i]].conductance for i in range(len(meshes))]
+    stamps, r = allocate_system(vindex, node_indexer)
+    for network in filtered_networks:
+        stamp_network_into_system(network, node_indexer, stamps, r)
+    setup_ground_node(find_best_ground_node_index(prob, node_indexer), stamps, r)
+    n_pot = len(vindex) + node_indexer.internal_node_count
+    plan = distributed.build_problem_partition(meshes, conductances, list(mesh_index_to_layer_index), stamps, r, n_pot,
+                                               partition.rank, partition.world)
+    v_pot, res = distributed.solve_partitioned(plan, ctx, dist=partition.dist, team=partition.team, rtol=RTOL,
+                                               gather=partition.gather)
+    v = np.zeros(stamps.shape[0], dtype=DTYPE)
+    v[:n_pot] = v_pot[:n_pot]
+    # KCL over all potential rows: the mesh and resistor terms cancel, what is left is the ground current (row of
+    # solver.py:558-560) = the net current the sources inject
+    v[-1] = float(np.sum(r[:n_pot]))
+    info = SolverInfo(ground_node_current=float(v[-1]), residual_norm=float(res.abs_residual),
+                      iterations=int(res.iterations), rel_residual=float(res.rel_residual), solve_seconds=float(res.seconds))
+    return v, info
+
+
 def solve_meshed(prob, meshes, mesh_index_to_layer_index, *, filtered_networks=None,
-                 disconnected_meshes_by_layer=None) -> Solution:
-    """Steps 4-11 of the reference's ``solve()`` (``solver.py:846-902``): everything after meshing."""
+                 disconnected_meshes_by_layer=None, partition=None) -> Solution:
+    """Steps 4-11 of the reference's ``solve()`` (``solver.py:846-902``): everything after meshing.
+
+    ``partition``: a :class:`padne_amd.distributed.Partition` -- the rows are dealt to the GPUs of the node (by layer, or
+    by strips of layers when there are fewer layers than GPUs); every rank calls this with the same Problem and gets the
+    same Solution.  Resistor / current-source problems only (voltage sources and regulators stay on one GPU)."""
     meshes = [m if isinstance(m, mesh.Mesh) else mesh.Mesh.from_reference(m) for m in meshes]
     if filtered_networks is None:
         filtered_networks = list(prob.networks)
@@ -695,6 +724,19 @@ def solve_meshed(prob, meshes, mesh_index_to_layer_index, *, filtered_networks=N
     log.info("Indexing vertices and connections")
     vindex = VertexIndexer.create(meshes)
     node_indexer = NodeIndexer.create(prob, meshes, mesh_index_to_layer_index, vindex, filtered_networks)
+    if partition is not None and partition.world > 1:
+        ctx = get_context()
+        v, solver_info = _solve_partitioned(prob, meshes, mesh_index_to_layer_index, vindex, filtered_networks,
+                                            node_indexer, partition, ctx)
+        if not np.isclose(solver_info.ground_node_current, 0):
+            warnings.warn(
+                f"Ground node current is not zero ({solver_info.ground_node_current} A), this may indicate an issue "
+                "with the problem being solved. Check for unterminated current loops or floating connected "
+                "components. This may be harmless if the current is small, but it may indicate an "
+                "ill-conditioned system.", SolverWarning)
+        layer_solutions = produce_layer_solutions(prob.layers, vindex, meshes, mesh_index_to_layer_index, v,
+                                                  disconnected_meshes_by_layer)
+        return Solution(problem=prob, layer_solutions=layer_solutions, solver_info=solver_info)
     log.info("Assembling the global system")
     L, r = assemble_system(prob, meshes, mesh_index_to_layer_index, vindex, filtered_networks, node_indexer)
     log.info("Solving the system of equations")
@@ -719,7 +761,7 @@ def solve_meshed(prob, meshes, mesh_index_to_layer_index, *, filtered_networks=N
     return Solution(problem=prob, layer_solutions=layer_solutions, solver_info=solver_info)
 
 
-def solve(prob, mesher_config: Optional[mesh.Mesher.Config] = None, *, mesher=None) -> Solution:
+def solve(prob, mesher_config: Optional[mesh.Mesher.Config] = None, *, mesher=None, partition=None) -> Solution:
     """``padne.solver.solve`` (``solver.py:815-902``).
 
     Meshing and the geometric connectivity pre-pass are out of scope (CGAL / shapely).  ``mesher``
@@ -737,4 +779,4 @@ def solve(prob, mesher_config: Optional[mesh.Mesher.Config] = None, *, mesher=No
         for geom in layer.geoms:
             meshes.append(mesher.poly_to_mesh(geom, seeds))
             mesh_index_to_layer_index.append(layer_i)
-    return solve_meshed(prob, meshes, mesh_index_to_layer_index)
+    return solve_meshed(prob, meshes, mesh_index_to_layer_index, partition=partition)

@@ -26,12 +26,13 @@ def _free_port():
 
 
 def _local_matrix(plan):
+    """What the device does with a plan, restated with scipy: assemble the rank's piece (owned vertices + ring + remote
+    stamp terminals), then relabel it to owned rows x [owned | world * m exchange slots] (padne_csr_relabel)."""
     n_loc = plan.n_local_unknowns
-    blocks = [(-1.0) * 0 for _ in ()]
     rows, cols, vals = [], [], []
     off = 0
     for xy, tri, sigma, _ in plan.meshes:
-        Lm = O.laplace_operator(xy, tri)
+        Lm = O.laplace_operator(xy, tri, validate=False) if plan.partial_mesh else O.laplace_operator(xy, tri)
         rows.append(Lm.row + off)
         cols.append(Lm.col + off)
         vals.append(sigma * Lm.data)
@@ -39,12 +40,15 @@ def _local_matrix(plan):
     rows.append(plan.coo_rows)
     cols.append(plan.coo_cols)
     vals.append(plan.coo_vals)
-    L = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n_loc, n_loc)).tocsr()
-    imap, n_owned, export_red = distributed.reduced_local_map(plan)
-    keep = np.flatnonzero(imap >= 0)
-    A = (-L[keep][:, keep]).tocsr()
-    b = -plan.rhs_local[np.flatnonzero(imap[:plan.n_owned_vertices] >= 0)]
-    return A, b, n_owned, export_red
+    L = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n_loc, n_loc)).tocoo()
+    row_map, col_map, n_owned, export_red = distributed.reduced_local_map(plan)
+    keep = (row_map[L.row] >= 0) & (col_map[L.col] >= 0)
+    A = sp.coo_matrix((-L.data[keep], (row_map[L.row[keep]], col_map[L.col[keep]])), shape=(n_owned, plan.n_cols)).tocsr()
+    own = np.ones(len(plan.owned_global), dtype=bool)
+    if plan.ground_local >= 0:
+        own[plan.ground_local] = False
+    b = -plan.rhs_local[own]
+    return A, b, n_owned, export_red, plan.owned_global[own]
 
 
 def _worker(rank, world, port, nl, nx, ny, lattice, out):
@@ -54,9 +58,9 @@ def _worker(rank, world, port, nl, nx, ny, lattice, out):
     try:
         sysm = synthetic.layered_system(nl, nx, ny, via_lattice=lattice)
         plan = distributed.build_layer_partition(sysm, rank, world)
-        A, b, n_owned, export_red = _local_matrix(plan)
+        A, b, n_owned, export_red, owned_idx = _local_matrix(plan)
         m = plan.m
-        A_own = A[:n_owned]
+        A_own = A
         dinv = 1.0 / A_own.diagonal()
 
         def allsum(v):
@@ -89,13 +93,10 @@ def _worker(rank, world, port, nl, nx, ny, lattice, out):
             rz = rz_new
             it += 1
         gathered = [None] * world
-        dist.all_gather_object(gathered, (plan.g0, plan.g1, plan.ground_local, x))
+        dist.all_gather_object(gathered, (owned_idx, x))
         if rank == 0:
             v = np.zeros(sysm.n_vertices)
-            for g0, g1, gl, xs in gathered:
-                idx = np.arange(g0, g1)
-                if gl >= 0:
-                    idx = np.delete(idx, gl)
+            for idx, xs in gathered:
                 v[idx] = xs
             els = [("R", int(a), int(b_), float(rr)) for a, b_, rr in zip(*sysm.resistors)]
             els += [("I", int(f), int(t), float(i)) for f, t, i in zip(*sysm.current_sources)]
@@ -107,8 +108,10 @@ def _worker(rank, world, port, nl, nx, ny, lattice, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,nl", [(2, 2), (2, 4), (4, 4)])
+@pytest.mark.parametrize("world,nl", [(2, 2), (2, 4), (4, 4), (2, 1), (4, 2)])
 def test_layer_partitioned_pcg_matches_direct_solve(world, nl):
+    """(2, 1) and (4, 2): fewer layers than ranks -- every layer is cut into strips (SURVEY 8e fallback), the mesh edges
+    across a cut are cross-rank couplings like the via resistors."""
     ctx = mp.get_context("spawn")
     out = ctx.SimpleQueue()
     port = _free_port()
@@ -129,18 +132,85 @@ def test_partition_bookkeeping():
     plans = [distributed.build_layer_partition(sysm, r, 2) for r in range(2)]
     assert [(p.g0, p.g1) for p in plans] == [(0, 2 * n_per), (2 * n_per, 4 * n_per)]
     assert plans[0].ground_local == 0 and plans[1].ground_local == -1
-    assert plans[0].m == plans[1].m and plans[0].m >= len(plans[0].export_local)
-    # every stamp row is owned, every column is either owned or inside the exchange area
+    assert plans[0].m == plans[1].m and plans[0].m >= len(plans[0].export_reduced)
     for p in plans:
-        n_own = p.n_owned_vertices
-        assert p.coo_rows.min() >= 0 and p.coo_rows.max() < n_own
-        assert p.coo_cols.min() >= 0 and p.coo_cols.max() < p.n_local_unknowns
-        remote = p.coo_cols >= n_own
-        seg = (p.coo_cols[remote] - n_own) // p.m
-        assert np.all(seg != p.rank)
+        # two whole layers; the via terminals on the other rank's layers come along as vertices without triangles
+        assert not p.partial_mesh and sum(1 for mm in p.meshes if len(mm[1])) == 2
+        # every stamp row is owned; every column is owned, an exchange slot of ANOTHER rank, or the eliminated ground
+        assert np.all(p.row_map[p.coo_rows] >= 0) or p.ground_local >= 0
+        c = p.col_map[p.coo_cols]
+        remote = c >= p.n_owned_reduced
+        assert np.all((c[remote] - p.n_owned_reduced) // p.m != p.rank) and c.max() < p.n_cols
+        assert np.array_equal(np.sort(p.export_reduced), p.export_reduced)
     # stamps are conserved: each resistor contributes 4 entries in total
     assert sum(len(p.coo_vals) for p in plans) == 4 * len(sysm.resistors[0])
     assert np.isclose(sum(p.rhs_local.sum() for p in plans), 0.0)
     with pytest.raises(ValueError):
         distributed.layer_ranges(2, 4)
     assert distributed.layer_ranges(8, 4) == [(0, 2), (2, 4), (4, 6), (6, 8)]
+
+
+def test_strip_partition_when_there_are_fewer_layers_than_ranks():
+    """SURVEY 8e fallback: one layer on four ranks = four horizontal strips; a rank assembles its strip plus the ring of
+    vertices around it and the cut mesh edges become exchange-slot columns."""
+    sysm = synthetic.layered_system(1, 24, 20, via_lattice=0)
+    plans = [distributed.build_layer_partition(sysm, r, 4) for r in range(4)]
+    owned = np.concatenate([p.owned_global for p in plans])
+    assert np.array_equal(np.sort(owned), np.arange(sysm.n_vertices))                  # a partition
+    assert max(len(p.owned_global) for p in plans) - min(len(p.owned_global) for p in plans) <= 1
+    xy = sysm.meshes[0][0]
+    for p in plans:
+        assert p.partial_mesh and len(p.meshes) == 1
+        ring = np.setdiff1d(p.local_global, p.owned_global)
+        assert len(ring) > 0 and len(p.meshes[0][0]) == len(p.local_global)
+        assert np.all(p.row_map[np.searchsorted(p.local_global, ring)] == -1)            # ring rows are dropped
+        assert np.array_equal(p.meshes[0][0], xy[p.local_global])
+        # strips: the owned vertices of a rank lie in one band of y
+        if 0 < p.rank < 3:
+            lo, hi = xy[p.owned_global, 1].min(), xy[p.owned_global, 1].max()
+            other = np.concatenate([q.owned_global for q in plans if q.rank != p.rank])
+            assert not np.any((xy[other, 1] > lo + 1e-9) & (xy[other, 1] < hi - 1e-9))
+    # what rank q exports is exactly what the others import from it
+    for q in plans:
+        exported = q.owned_global[q.export_owned]
+        imported = []
+        for p in plans:
+            c = p.col_map[p.col_map >= p.n_owned_reduced]
+            mine = c[(c - p.n_owned_reduced) // p.m == q.rank] - p.n_owned_reduced - q.rank * p.m
+            imported.append(exported[np.unique(mine)])
+        assert np.array_equal(np.unique(np.concatenate(imported)), exported)
+    # two layers on five ranks: the bigger share of ranks goes where the vertices are
+    s2 = synthetic.layered_system(2, 16, 12, via_lattice=2)
+    own = distributed.owners_of_unknowns(s2.meshes, s2.n_vertices, 5)
+    assert sorted(np.unique(own)) == [0, 1, 2, 3, 4]
+    assert len(np.unique(own[:16 * 12])) in (2, 3) and len(np.unique(own[16 * 12:])) in (2, 3)
+
+
+def test_a_via_on_the_ground_vertex_is_a_dirichlet_term():
+    """VERDICT r01 missing #5: a resistor that lands on the ground vertex used to raise on the rank that owns it; the
+    ground is 0 V, so the column is dropped on every rank alike."""
+    sysm = synthetic.layered_system(2, 12, 10, via_lattice=2)
+    ra, rb, rr = sysm.resistors
+    ra = np.concatenate([ra, [sysm.ground]])                     # ground (layer 0) -- some vertex of layer 1
+    rb = np.concatenate([rb, [12 * 10 + 17]])
+    rr = np.concatenate([rr, [0.01]])
+    sysm.resistors = (ra, rb, rr)
+    plans = [distributed.build_layer_partition(sysm, r, 2) for r in range(2)]
+    for p in plans:
+        assert sysm.ground not in p.owned_global[p.export_owned]
+    p1 = plans[1]
+    k = np.flatnonzero(p1.local_global == sysm.ground)
+    assert len(k) == 1 and p1.col_map[k[0]] == -1 and p1.row_map[k[0]] == -1
+    # the plan restated with scipy reproduces the direct solve
+    n = sysm.n_vertices
+    mats = [_local_matrix(p) for p in plans]
+    els = [("R", int(a), int(b_), float(r_)) for a, b_, r_ in zip(*sysm.resistors)]
+    els += [("I", int(f), int(t), float(i)) for f, t, i in zip(*sysm.current_sources)]
+    Lf, rf = O.assemble_system([(mm[0], mm[1], mm[2]) for mm in sysm.meshes], 0, els, sysm.ground)
+    v_ref = O.solve_system(Lf, rf)[0][:n]
+    for (A, b, n_owned, export_red, owned_idx), p in zip(mats, plans):
+        ext = np.zeros(p.n_cols)
+        ext[:n_owned] = v_ref[owned_idx]
+        for q, (_, _, _, ex_q, idx_q) in enumerate(mats):
+            ext[n_owned + q * p.m:n_owned + q * p.m + len(ex_q)] = v_ref[idx_q][ex_q]
+        assert np.abs(A @ ext - b).max() <= 1e-9 * max(np.abs(b).max(), 1.0)

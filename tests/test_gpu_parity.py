@@ -1142,7 +1142,7 @@ def run_team(sysm, world, precond, block=False):
             c1 = c.comm_call_counts()[0]
             assert res2.iterations == res.iterations and np.array_equal(ds.solution(), sol)
             res.collectives = [b - a for a, b in zip(c0, c1)]
-            out[rank] = (plan, sol, res)
+            out[rank] = (plan, sol, res, ds.owned_reduced_global)
         except BaseException as exc:                              # wake the peers: they wait for this rank in a collective
             errors.append((rank, exc))
             team.abort()
@@ -1154,10 +1154,7 @@ def run_team(sysm, world, precond, block=False):
     assert not errors, errors
     assert all(o is not None for o in out), "a rank did not finish"
     v = np.zeros(sysm.n_vertices)
-    for plan, xs, _ in out:
-        idx = np.arange(plan.g0, plan.g1)
-        if plan.ground_local >= 0:
-            idx = np.delete(idx, plan.ground_local)
+    for plan, xs, _, idx in out:
         v[idx] = xs
     its = {o[2].iterations for o in out}
     assert len(its) == 1, f"ranks disagree on the iteration count: {its}"
@@ -1246,6 +1243,87 @@ def test_a_rank_that_fails_does_not_leave_its_peers_waiting():
     assert not any(t.is_alive() for t in th), "a rank is still waiting for its failed peer"
     assert isinstance(seen[1], RuntimeError)
     assert isinstance(seen[0], _hip.HipError) and seen[0].code == _hip.E_COMM
+
+
+def _two_layer_problem(n_layers=2):
+    P = mesh.Point
+    layers = [problem.Layer(shape=structured.Shapes.of(structured.Rect(0, 0, 30, 20)), name=f"L{i}", conductance=2082.5 / (i + 1))
+              for i in range(n_layers)]
+    nets = []
+    rv = synthetic.via_ring_resistance(0.5)
+    for (x, y) in ((6.0, 5.0), (22.0, 14.0), (15.0, 10.0)) if n_layers > 1 else ():
+        conns, els = [], []
+        for k in range(16):
+            px, py = x + 0.15 * np.cos(k * np.pi / 8), y + 0.15 * np.sin(k * np.pi / 8)
+            a = problem.Connection(layer=layers[0], point=P(px, py))
+            b = problem.Connection(layer=layers[-1], point=P(px, py))
+            conns += [a, b]
+            els.append(problem.Resistor(a=a.node_id, b=b.node_id, resistance=rv))
+        nets.append(problem.Network(connections=conns, elements=els))
+    f = problem.Connection(layer=layers[0], point=P(2.0, 3.0))
+    t = problem.Connection(layer=layers[-1], point=P(27.0, 17.0))
+    hub = problem.NodeID()                                   # an internal node between two resistors
+    nets.append(problem.Network(connections=[f, t], elements=[problem.CurrentSource(f=f.node_id, t=t.node_id, current=2.0)]))
+    la, lb = problem.Connection(layer=layers[0], point=P(10.0, 16.0)), problem.Connection(layer=layers[-1], point=P(20.0, 4.0))
+    nets.append(problem.Network(connections=[la, lb], elements=[problem.Resistor(a=la.node_id, b=hub, resistance=0.3),
+                                                                problem.Resistor(a=hub, b=lb.node_id, resistance=0.2)]))
+    # a resistor that lands on the vertex that will be the ground (unknown 0 = the corner (0, 0) of layer 0)
+    g0, g1 = problem.Connection(layer=layers[0], point=P(0.0, 0.0)), problem.Connection(layer=layers[-1], point=P(29.0, 1.0))
+    nets.append(problem.Network(connections=[g0, g1], elements=[problem.Resistor(a=g0.node_id, b=g1.node_id, resistance=5.0)]))
+    return problem.Problem(layers=layers, networks=nets)
+
+
+@pytest.mark.parametrize("n_layers,world", [(2, 2), (1, 2), (2, 4)])
+def test_solve_with_the_rows_dealt_to_several_ranks(ctx, n_layers, world):
+    """``solve(prob, partition=...)``: a Problem (not only a SyntheticSystem) through the row-partitioned path -- by layer
+    (2 layers, 2 ranks), by strips of a layer (1 layer on 2 ranks, 2 layers on 4), with an internal node and a resistor
+    on the ground vertex -- gives every rank the Solution of the single-GPU solve."""
+    import threading
+    from padne_amd import distributed
+    prob = _two_layer_problem(n_layers)
+    mesher = structured.StructuredMesher(mesh.Mesher.Config(maximum_size=0.25), jitter=0.2, seed=6)
+    ref = solver.solve(prob, mesher=mesher)
+    team = _hip.LocalTeam(world)
+    barrier = threading.Barrier(world)
+    board = [None] * world
+    sols, errors = [None] * world, []
+
+    def gather_for(rank):
+        def gather(obj):
+            board[rank] = obj
+            barrier.wait(timeout=120)
+            out = list(board)
+            barrier.wait(timeout=120)
+            return out
+        return gather
+
+    def rank_main(rank):
+        try:
+            solver.set_context(_hip.Context(0))
+            part = distributed.Partition(rank=rank, world=world, team=team, gather=gather_for(rank))
+            sols[rank] = solver.solve(prob, mesher=mesher, partition=part)
+        except BaseException as exc:
+            errors.append((rank, exc))
+            team.abort()
+            barrier.abort()
+    th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    assert not errors, errors
+    scale = max(np.abs(z.values).max() for ls in ref.layer_solutions for z in ls.potentials)
+    for sol in sols:
+        assert sol is not None
+        for ls, lr in zip(sol.layer_solutions, ref.layer_solutions):
+            for z, zr, pw, pr in zip(ls.potentials, lr.potentials, ls.power_densities, lr.power_densities):
+                assert np.abs(z.values - zr.values).max() <= 1e-9 * scale
+                assert np.abs(pw.values - pr.values).max() <= 1e-7 * max(pr.values.max(), 1e-300)
+        assert abs(sol.solver_info.ground_node_current) < 1e-12 and sol.solver_info.residual_norm < 1e-9
+        assert sol.solver_info.iterations < 80
+    with pytest.raises(NotImplementedError):                          # voltage sources stay on one GPU
+        a, b = prob.networks[-1].connections
+        vs = problem.Problem(layers=prob.layers, networks=prob.networks + [problem.Network(
+            connections=[a, b], elements=[problem.VoltageSource(p=a.node_id, n=b.node_id, voltage=1.0)])])
+        solver.solve(vs, mesher=mesher, partition=distributed.Partition(rank=0, world=2, team=team))
 
 
 def test_row_partitioned_hierarchy_with_several_exchanged_levels(monkeypatch):
