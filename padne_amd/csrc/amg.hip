@@ -121,10 +121,26 @@ __device__ __forceinline__ bool strong(double a, double di, double dj, double th
 // otherwise the row itself (a self loop is neutral for the neighbour maxima and is skipped by the joins).  No
 // compaction, no second array of weights (the joins read |a_ij| from A): one coalesced pass over the matrix.
 // Wave-private tiles of 64 rows as in the SpMV kernel; the row of every staged element comes from LDS.
+// Position of column `c` inside the staged x-window runs of a tile (spmv.hip, csr_build_xw_plan): the runs start at
+// d.x, d.y, d.z and hold `run` consecutive columns each.
+__device__ __forceinline__ int xw_position(const int4 d, const int run, const int c) {
+    int pos = 0;                       // where runs overlap the FIRST run wins, exactly as xw_plan_kernel numbers xw_lidx
+    if (c >= d.z && c < d.z + run) pos = 2 * run + (c - d.z);
+    if (c >= d.y && c < d.y + run) pos = run + (c - d.y);
+    if (c >= d.x && c < d.x + run) pos = c - d.x;
+    return pos;
+}
+
+// With an x-window plan of A (xw_desc / xw_lidx, runs of at most 85 columns so that a position fits a byte) the pass
+// also writes spos[k]: the window position of scol[k].  The neighbour-maximum passes of the independent-set rounds
+// then read one byte per entry and take the neighbours' words from LDS-staged runs instead of gathering them.
 __global__ __launch_bounds__(256) void strength_mark(int n, int n_wtiles, const int *__restrict__ rowptr,
                                                      const int *__restrict__ cols, const double *__restrict__ vals,
                                                      const double *__restrict__ dinv, double theta2,
-                                                     int *__restrict__ scol, double *__restrict__ bound_partial) {
+                                                     int *__restrict__ scol, double *__restrict__ bound_partial,
+                                                     const int4 *__restrict__ xw_desc = nullptr,
+                                                     const unsigned char *__restrict__ xw_lidx = nullptr,
+                                                     const int xw_run = 0, unsigned char *__restrict__ spos = nullptr) {
     // bound_partial (optional): per-workgroup maxima of the Gershgorin bounds of D^-1 A (second row of kMaxPartials) and of D_F^-1 A_F, the filtered operator
     // the prolongator is smoothed with -- the same sums, in the same order, as gershgorin_filtered_kernel forms them
     // one lane per row, taken here from the values this pass streams anyway (a separate pass over A cost 0.4 ms).
@@ -151,6 +167,10 @@ __global__ __launch_bounds__(256) void strength_mark(int n, int n_wtiles, const 
         const int k0 = __shfl(rs, 0, 64);
         const int k1 = __shfl(re, row1 - row0 - 1, 64);
         double dF = r < row1 ? 1.0 / di : 1.0, off_strong = 0.0, off_all = 0.0, abs_all = 0.0;
+        int4 dsc = make_int4(0, 0, 0, 0);
+        if (spos != nullptr) dsc = xw_desc[wt];
+        const bool windowed = spos != nullptr && dsc.w != 0;
+        const int self_pos = windowed ? xw_position(dsc, xw_run, r) : 0;
         for (int base = k0; base < k1; base += CH) {
             const int lo = max(rs, base), hi = min(re, base + CH);
             for (int k = lo; k < hi; ++k) rid[k - base] = (unsigned char)lane;
@@ -161,12 +181,14 @@ __global__ __launch_bounds__(256) void strength_mark(int n, int n_wtiles, const 
                 const int e = base + lane + 64 * q;
                 const int rl = e < k1 ? rid[e - base] : 0;
                 const double dr = __shfl(di, rl, 64);          // all lanes take part: the source lane may be past k1
+                const int sp = __shfl(self_pos, rl, 64);
                 if (e < k1) {
                     const int i = row0 + rl;
                     const int c = cols[e];
                     const double v = vals[e];
                     const bool st = c != i && strong(v, dr, dinv[c], theta2);
                     scol[e] = st ? c : i;
+                    if (windowed) spos[e] = st ? xw_lidx[e] : (unsigned char)sp;
                     if (bound_partial != nullptr) {
                         rid[e - base] = (unsigned char)(rl | (c == i ? 0x40 : 0) | (st ? 0x80 : 0));
                         pv[e - base] = v;
@@ -257,6 +279,89 @@ __global__ __launch_bounds__(256) void nbr_max(int n, int n_wtiles, const int *_
             }
             asm volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
+        }
+        if (r < row1) out[r] = m;
+    }
+}
+
+// The same pass over a matrix with an x-window plan: a tile's neighbours live in (at most) three runs of consecutive
+// vertices, which are staged in LDS with coalesced loads; an entry is then one byte (spos, written by strength_mark)
+// instead of a 4-byte column and a scattered 4-byte gather.  Tiles without a plan take the gather path above.
+template <typename T>
+__global__ __launch_bounds__(256) void nbr_max_xw(int n, int n_wtiles, const int *__restrict__ srow,
+                                                  const int *__restrict__ scol, const unsigned char *__restrict__ spos,
+                                                  const int4 *__restrict__ xw_desc, const int run,
+                                                  const T *__restrict__ in, T *__restrict__ out) {
+    constexpr int CH = 512;
+    __shared__ T park_all[4 * CH];
+    __shared__ T xs_all[4 * 3 * 88];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    T *park = park_all + w * CH;
+    T *xs = xs_all + w * 3 * 88;
+    const long long W = (long long)gridDim.x * 4, gw = (long long)blockIdx.x * 4 + w;
+    for (long long wt = gw; wt < n_wtiles; wt += W) {
+        const int row0 = (int)wt * 64;
+        const int row1 = min(row0 + 64, n);
+        const int r = row0 + lane;
+        int rs = 0, re = 0;
+        T m = 0;
+        if (r < row1) {
+            rs = srow[r];
+            re = srow[r + 1];
+            m = in[r];
+        }
+        const int4 d = xw_desc[wt];
+        const int k0 = __shfl(rs, 0, 64);
+        const int k1 = __shfl(re, row1 - row0 - 1, 64);
+        if (d.w != 0) {
+            const int st[3] = {d.x, d.y, d.z};
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int a = st[q] + lane, b = st[q] + 64 + lane;
+                xs[q * run + lane] = a < n ? in[a] : (T)0;
+                if (lane < run - 64) xs[q * run + 64 + lane] = b < n ? in[b] : (T)0;
+            }
+            const int top = 3 * run - 1;
+            for (int base = k0 & ~3; base < k1; base += CH) {
+                unsigned int cw[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int e = base + 4 * lane + 256 * j;
+                    cw[j] = e < k1 ? *reinterpret_cast<const unsigned int *>(spos + e) : 0u;     // (spos is padded like cols)
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) park[4 * lane + 256 * j + t] = xs[min((int)((cw[j] >> (8 * t)) & 255u), top)];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                const int lo = max(rs, base), hi = min(re, base + CH);
+                for (int k = lo; k < hi; ++k) {
+                    const T v = park[k - base];
+                    m = v > m ? v : m;
+                }
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else {
+            for (int base = k0; base < k1; base += CH) {
+#pragma unroll
+                for (int j = 0; j < CH / 64; ++j) {
+                    const int e = base + lane + 64 * j;
+                    park[lane + 64 * j] = (e < k1) ? in[scol[e]] : (T)0;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                const int lo = max(rs, base), hi = min(re, base + CH);
+                for (int k = lo; k < hi; ++k) {
+                    const T v = park[k - base];
+                    m = v > m ? v : m;
+                }
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
         }
         if (r < row1) out[r] = m;
     }
@@ -1237,7 +1342,7 @@ static int gershgorin(padne_ctx *ctx, const padne_csr *A, double *lambda, bool f
 
 // aggregates of A -> device array agg[n], count n_agg
 static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_out, int *n_agg, double *lambda_f = nullptr,
-                     double *lambda_plain = nullptr) {
+                     double *lambda_plain = nullptr, unsigned char **spos_out = nullptr, int **scol_out = nullptr) {
     hipStream_t s = ctx->stream;
     const int n = (int)A->n_rows;
     const double theta2 = kTheta * kTheta;
@@ -1268,8 +1373,23 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
     // open count below: no synchronisation of its own)
     double *bound_part = lambda_f != nullptr ? ctx->partials + 6 * kMaxPartials : nullptr;
     std::vector<double> h_bound(lambda_f != nullptr ? (size_t)kMaxPartials + gm.x : 0);     // filtered | plain
-    hipLaunchKernelGGL(strength_mark, gm, b, 0, s, n, n_wt, A->rowptr, A->cols, A->vals, A->dinv, theta2, scol, bound_part);
+    // x-window plan of A (fine-level band matrices): one byte per entry and LDS-staged neighbours in the rounds below
+    const bool xw = A->xw_state == 1 && A->xw_run <= 85 && getenv("PADNE_AMG_NO_XW") == nullptr;
+    unsigned char *spos = nullptr;
+    if (xw) {
+        PADNE_TRY(sc.alloc(&spos, (size_t)A->nnz + kPadNnz));
+        PADNE_HIP_CHECK(hipMemsetAsync(spos + A->nnz, 0, kPadNnz, s));
+    }
+    hipLaunchKernelGGL(strength_mark, gm, b, 0, s, n, n_wt, A->rowptr, A->cols, A->vals, A->dinv, theta2, scol, bound_part,
+                       xw ? A->xw_desc : (const int4 *)nullptr, xw ? (const unsigned char *)A->xw_lidx : (const unsigned char *)nullptr,
+                       xw ? A->xw_run : 0, spos);
     PADNE_HIP_CHECK(hipGetLastError());
+    auto launch_nbr_max = [&](const unsigned int *src, unsigned int *dst) {
+        if (xw)
+            hipLaunchKernelGGL(nbr_max_xw<unsigned int>, gm, b, 0, s, n, n_wt, srow, scol, spos, A->xw_desc, A->xw_run, src, dst);
+        else
+            hipLaunchKernelGGL(nbr_max<unsigned int>, gm, b, 0, s, n, n_wt, srow, scol, src, dst);
+    };
     if (lambda_f != nullptr)
         PADNE_HIP_CHECK(hipMemcpyAsync(h_bound.data(), bound_part, sizeof(double) * h_bound.size(), hipMemcpyDeviceToHost, s));
     hipLaunchKernelGGL(mis_init_words, g, b, 0, s, n, w0);
@@ -1283,8 +1403,8 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
     const int full_batch = n > 200000 ? 1 : 4;
     while (round < kMaxRounds && open_count > 0 && (!compact_ok || round < 2 || open_count > n / 8)) {
         for (int rep = 0; rep < full_batch && round < kMaxRounds; ++rep, ++round) {
-            hipLaunchKernelGGL(nbr_max<unsigned int>, gm, b, 0, s, n, n_wt, srow, scol, w0, w1);
-            hipLaunchKernelGGL(nbr_max<unsigned int>, gm, b, 0, s, n, n_wt, srow, scol, w1, w2);
+            launch_nbr_max(w0, w1);
+            launch_nbr_max(w1, w2);
             hipLaunchKernelGGL(mis_decide, dim3(std::min<unsigned>(g.x, 1024u)), b, 0, s, n, w0, w2, state, counter + round);
         }
         PADNE_HIP_CHECK(hipGetLastError());
@@ -1345,6 +1465,8 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
     PADNE_HIP_CHECK(hipGetLastError());
     *agg_out = agg0;
     *n_agg = (int)(n_roots + n_single);
+    if (spos_out != nullptr) *spos_out = spos;      // lives in the caller's scratch, like agg
+    if (scol_out != nullptr) *scol_out = scol;
     return PADNE_OK;
 }
 
@@ -1414,6 +1536,158 @@ __global__ __launch_bounds__(128) void prolong_rows_lds(int n, const int *__rest
     row_len[i] = o;
 }
 
+// The prolongator rows of a matrix with an x-window plan (the fine level: 10 M rows of 7 entries).  The one-thread-per-
+// row kernel above walks its row with strided, dependent global loads, merges by sorted insertion in LDS (a chain of
+// dependent LDS round trips with divergent trip counts) and parks the rows in 16-byte slots that a second kernel
+// compacts.  Here a wave streams the 64 rows of a tile into LDS with coalesced loads, stages the aggregates of the
+// tile's three runs of neighbours, and every lane merges its row IN REGISTERS without data-dependent control flow: the
+// row's contributions (aggregate, value) sit in fixed slots, `first` marks the first slot of every aggregate, its sum
+// runs over the later slots of the same aggregate in slot order (the order prolong_rows_lds adds them in), and the
+// rank of an aggregate among the kept ones is where its entry goes -- all O(m^2) compares on m <= 14 registers.
+// Two passes with the same arithmetic: COUNT leaves the row lengths, FILL writes the finished CSR rows in place: no
+// slots, no compaction.  Tiles without a plan (rows with far couplings) take cols / scol from global memory.
+constexpr int kPxSlots = 14;        // identity + up to 13 entries of the row of A (longer rows: the whole matrix falls back)
+constexpr int kPxChunk = 640;       // entries of a 64-row tile staged at once (10 per row)
+template <bool FILL, int SLOTS>
+__device__ __forceinline__ void prolong_row_regs(const int w, const int rs, const int re, const int k0, const int self,
+                                                 const bool windowed, const double di, const double omega, const int r,
+                                                 const unsigned char (*Ls)[kPxChunk], const unsigned char (*Ss)[kPxChunk],
+                                                 const double (*Vs)[kPxChunk], const int (*As)[3 * 88],
+                                                 const int *__restrict__ cols, const int *__restrict__ scol,
+                                                 const double *__restrict__ vals,
+                                                 const int *__restrict__ agg, int *__restrict__ row_len,
+                                                 const int *__restrict__ out_rowptr, int *__restrict__ out_cols,
+                                                 double *__restrict__ out_vals) {
+    const int len = re - rs;
+    // the row in registers: slot 0 is the identity part of P, slot k + 1 entry k of the row of A
+    int el[SLOTS - 1], es[SLOTS - 1];
+    double ev[SLOTS - 1];
+    double dF = 1.0 / di;
+#pragma unroll
+    for (int k = 0; k < SLOTS - 1; ++k) {
+        const bool in = k < len;
+        // (a tile without a plan -- rows with far couplings, one or two per cent of the tiles -- reads its row from global memory)
+        el[k] = in ? (windowed ? (int)Ls[w][rs - k0 + k] : cols[rs + k]) : -1;
+        es[k] = in ? (windowed ? (int)Ss[w][rs - k0 + k] : scol[rs + k]) : -1;
+        ev[k] = in ? (windowed ? Vs[w][rs - k0 + k] : vals[rs + k]) : 0.0;
+        if (in && el[k] != self && es[k] == self) dF += ev[k];       // weak entry: lumped into the diagonal
+    }
+    const bool keep_all = !(dF * di > 0.05);
+    if (keep_all) dF = 1.0 / di;
+    const double wgt = -omega / dF;
+    const int ai = windowed ? As[w][self] : agg[r];
+    int c[SLOTS];
+    double v[SLOTS];
+    c[0] = ai;
+    v[0] = 1.0;
+#pragma unroll
+    for (int k = 0; k < SLOTS - 1; ++k) {
+        const bool in = k < len;
+        const bool diag = in && el[k] == self;
+        const bool used = in && (diag || keep_all || es[k] != self);
+        int cj = 0x7fffffff;                                         // unused slot: sorts last, matches nothing
+        if (used && !diag) cj = windowed ? As[w][el[k]] : agg[el[k]];
+        c[k + 1] = diag ? ai : cj;
+        v[k + 1] = diag ? -omega : (used ? wgt * ev[k] : 0.0);
+    }
+    bool keep[SLOTS];
+    double sum[SLOTS];
+    int o = 0;
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k) {
+        bool first = c[k] != 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < k; ++j) first = first && c[j] != c[k];
+        double t = v[k];
+#pragma unroll
+        for (int j = k + 1; j < SLOTS; ++j) t = c[j] == c[k] ? t + v[j] : t;
+        sum[k] = t;
+        keep[k] = first && t != 0.0;
+        o += keep[k] ? 1 : 0;
+    }
+    if (!FILL) {
+        row_len[r] = o;
+    } else {
+        const int base = out_rowptr[r];
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) {
+            int rank = 0;
+#pragma unroll
+            for (int j = 0; j < SLOTS; ++j) rank += (keep[j] && c[j] < c[k]) ? 1 : 0;
+            if (keep[k]) {
+                out_cols[base + rank] = c[k];
+                out_vals[base + rank] = sum[k];
+            }
+        }
+    }
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void prolong_rows_xw(int n, int n_wtiles, const int *__restrict__ rowptr,
+                                                       const int *__restrict__ cols, const double *__restrict__ vals,
+                                                       const double *__restrict__ dinv, const int *__restrict__ scol,
+                                                       const unsigned char *__restrict__ lidx,
+                                                       const unsigned char *__restrict__ spos,
+                                                       const int4 *__restrict__ xw_desc, const int run, const double omega,
+                                                       const int *__restrict__ agg, int *__restrict__ row_len,
+                                                       const int *__restrict__ out_rowptr, int *__restrict__ out_cols,
+                                                       double *__restrict__ out_vals, int *__restrict__ gave_up) {
+    __shared__ unsigned char Ls[4][kPxChunk], Ss[4][kPxChunk];     // window position / strength position of an entry
+    __shared__ double Vs[4][kPxChunk];
+    __shared__ int As[4][3 * 88];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long W = (long long)gridDim.x * 4, gw = (long long)blockIdx.x * 4 + w;
+    for (long long wt = gw; wt < n_wtiles; wt += W) {
+        const int row0 = (int)wt * 64;
+        const int row1 = min(row0 + 64, n);
+        const int r = row0 + lane;
+        int rs = 0, re = 0;
+        double di = 1.0;
+        if (r < row1) {
+            rs = rowptr[r];
+            re = rowptr[r + 1];
+            di = dinv[r];
+        }
+        const int4 d = xw_desc[wt];
+        const int k0 = __shfl(rs, 0, 64);
+        const int k1 = __shfl(re, row1 - row0 - 1, 64);
+        const bool too_long = re - rs > kPxSlots - 1;
+        if (__any(too_long)) {                                // wave-uniform
+            if (!FILL && lane == 0) atomicExch(gave_up, 1);
+            continue;
+        }
+        const bool windowed = d.w != 0 && k1 - k0 <= kPxChunk;
+        if (windowed) {
+            const int st[3] = {d.x, d.y, d.z};
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int a = st[q] + lane, b = st[q] + 64 + lane;
+                As[w][q * run + lane] = a < n ? agg[a] : 0;
+                if (lane < run - 64) As[w][q * run + 64 + lane] = b < n ? agg[b] : 0;
+            }
+            for (int e = k0 + lane; e < k1; e += 64) {
+                Ls[w][e - k0] = lidx[e];
+                Ss[w][e - k0] = spos[e];
+                Vs[w][e - k0] = vals[e];
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (r < row1) {
+            const int self = windowed ? xw_position(d, run, r) : r;
+            // nearly every row of a mesh operator has at most 9 entries: the short instantiation does a third of the compares
+            if (__all(re - rs <= 9))
+                prolong_row_regs<FILL, 10>(w, rs, re, k0, self, windowed, di, omega, r, Ls, Ss, Vs, As, cols, scol, vals, agg,
+                                           row_len, out_rowptr, out_cols, out_vals);
+            else
+                prolong_row_regs<FILL, kPxSlots>(w, rs, re, k0, self, windowed, di, omega, r, Ls, Ss, Vs, As, cols, scol, vals,
+                                                 agg, row_len, out_rowptr, out_cols, out_vals);
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // fix-up of rows the LDS kernel gave up on: merge their slots (filled by prolong_fill) the slow way
 __global__ void prolong_redo_flag(int n, const int *__restrict__ row_len, int *__restrict__ any) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1421,10 +1695,42 @@ __global__ void prolong_redo_flag(int n, const int *__restrict__ row_len, int *_
 }
 
 static int build_prolongator(padne_ctx *ctx, const padne_csr *A, const int *agg, int n_agg, double omega,
-                             padne_csr **P) {
+                             padne_csr **P, const unsigned char *spos = nullptr, const int *scol = nullptr) {
     hipStream_t s = ctx->stream;
     const int n = (int)A->n_rows;
     Scratch sc(ctx);
+    if (spos != nullptr && scol != nullptr && A->xw_state == 1 && A->xw_run <= 85 && n > 0) {
+        // windowed fine level: count, scan, fill straight into the CSR arrays
+        int *row_len = nullptr, *rowptr_tmp = nullptr, *gave_up = nullptr;
+        PADNE_TRY(sc.alloc(&row_len, (size_t)n + 1));
+        PADNE_TRY(sc.alloc(&rowptr_tmp, (size_t)n + 1));
+        PADNE_TRY(sc.alloc(&gave_up, 1));
+        PADNE_HIP_CHECK(hipMemsetAsync(gave_up, 0, sizeof(int), s));
+        const int n_wt = (n + 63) / 64;
+        const dim3 g((unsigned)std::min((n_wt + 3) / 4, 8192)), b(256);
+        hipLaunchKernelGGL(prolong_rows_xw<false>, g, b, 0, s, n, n_wt, A->rowptr, A->cols, A->vals, A->dinv, scol,
+                           (const unsigned char *)A->xw_lidx, spos, A->xw_desc, A->xw_run, omega, agg, row_len,
+                           (const int *)nullptr, (int *)nullptr, (double *)nullptr, gave_up);
+        PADNE_HIP_CHECK(hipGetLastError());
+        int h_gave_up = 0;
+        PADNE_HIP_CHECK(hipMemcpyAsync(&h_gave_up, gave_up, sizeof(int), hipMemcpyDeviceToHost, s));
+        int64_t nnz = 0;
+        // (the scan synchronises: the flag is on the host afterwards; its result is only used if nobody gave up)
+        const int rc_scan = exclusive_scan_i32(ctx, row_len, rowptr_tmp, n, &nnz);
+        if (h_gave_up == 0) {
+            PADNE_TRY(rc_scan);
+            padne_csr *m = nullptr;
+            PADNE_TRY(csr_alloc(ctx, n, n_agg, nnz, &m));
+            PADNE_HIP_CHECK(hipMemcpyAsync(m->rowptr, rowptr_tmp, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyDeviceToDevice, s));
+            hipLaunchKernelGGL(prolong_rows_xw<true>, g, b, 0, s, n, n_wt, A->rowptr, A->cols, A->vals, A->dinv, scol,
+                               (const unsigned char *)A->xw_lidx, spos, A->xw_desc, A->xw_run, omega, agg, (int *)nullptr,
+                               (const int *)m->rowptr, m->cols, m->vals, gave_up);
+            PADNE_HIP_CHECK(hipGetLastError());
+            *P = m;
+            return PADNE_OK;
+        }
+        // a tile without a plan, or a row with more than kPxCap aggregates: the general path below
+    }
     const size_t n_slots = (size_t)A->nnz + (size_t)n;
     int *slot_ptr = nullptr, *row_len = nullptr, *any = nullptr;
     long long *key = nullptr;
@@ -1789,7 +2095,9 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         int *agg = nullptr, n_agg = 0;
         PhaseTimer pt(ctx, amg_verbose());
         double lambda_f = 2.0;      // Gershgorin bound of the filtered operator, a by-product of the strength pass
-        if ((rc = aggregate(ctx, sc, A, &agg, &n_agg, &lambda_f, &L.lambda)) != PADNE_OK) { amg->levels.push_back(L); break; }
+        unsigned char *spos = nullptr;
+        int *scol = nullptr;
+        if ((rc = aggregate(ctx, sc, A, &agg, &n_agg, &lambda_f, &L.lambda, &spos, &scol)) != PADNE_OK) { amg->levels.push_back(L); break; }
         pt.lap("aggregate");
         if (n_agg == 0 || (double)n_agg > 0.8 * (double)A->n_rows) {   // coarsening stalled: stop here
             amg->levels.push_back(L);
@@ -1803,7 +2111,7 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
             fprintf(stderr, "[amg] level %d: n=%lld nnz=%lld lambda=%.3f (P: %.3f) -> %d aggregates\n", lvl,
                     (long long)A->n_rows, (long long)A->nnz, L.lambda, lambda_f, n_agg);
         padne_csr *AP = nullptr, *Ac = nullptr;
-        if ((rc = build_prolongator(ctx, A, agg, n_agg, omega, &L.P)) != PADNE_OK) { amg->levels.push_back(L); break; }
+        if ((rc = build_prolongator(ctx, A, agg, n_agg, omega, &L.P, spos, scol)) != PADNE_OK) { amg->levels.push_back(L); break; }
         pt.lap("prolongator");
         if (amg_verbose()) fprintf(stderr, "[amg]   P: %lld x %lld nnz=%lld\n", (long long)L.P->n_rows, (long long)L.P->n_cols, (long long)L.P->nnz);
         // second stream: R = P^T and the float copies of both, next to A P on the main stream

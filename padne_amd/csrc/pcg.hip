@@ -673,8 +673,15 @@ __global__ __launch_bounds__(256) void sr_update_xr_kernel(
 __global__ __launch_bounds__(256) void sr_update_ps_kernel(const long long n, const double *__restrict__ sr,
                                                            const double *__restrict__ z, const double *__restrict__ w,
                                                            double *__restrict__ p, double *__restrict__ s,
-                                                           const PcgStatus *__restrict__ st) {
+                                                           const PcgStatus *__restrict__ st, const int first) {
     if (st->done) return;
+    if (first) {                            // p = z ; s = w  (p and s hold whatever the workspace held: never read them)
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+            p[i] = z[i];
+            s[i] = w[i];
+        }
+        return;
+    }
     const double beta = sr[SR_BETA];
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         p[i] = z[i] + beta * p[i];
@@ -783,7 +790,7 @@ static int solve_one_single_reduction(padne_ctx *ctx, const padne_csr *a, const 
         PADNE_HIP_CHECK(hipGetLastError());
         PADNE_TRY(cycle_product_reduce(false, &st->done));
         hipLaunchKernelGGL(sr_scalars_kernel, dim3(1), dim3(1), 0, s, st, sr, 1, max_iter - total_iters);
-        hipLaunchKernelGGL(sr_update_ps_kernel, dim3(gv), dim3(256), 0, s, n, sr, z, w, p, sv, st);
+        hipLaunchKernelGGL(sr_update_ps_kernel, dim3(gv), dim3(256), 0, s, n, sr, z, w, p, sv, st, 1);
         PADNE_HIP_CHECK(hipGetLastError());
         bool done = false;
         while (!done) {
@@ -793,7 +800,7 @@ static int solve_one_single_reduction(padne_ctx *ctx, const padne_csr *a, const 
                 PADNE_HIP_CHECK(hipGetLastError());
                 PADNE_TRY(cycle_product_reduce(fuse_entry, &st->done));
                 hipLaunchKernelGGL(sr_scalars_kernel, dim3(1), dim3(1), 0, s, st, sr, 0, max_iter - total_iters);
-                hipLaunchKernelGGL(sr_update_ps_kernel, dim3(gv), dim3(256), 0, s, n, sr, z, w, p, sv, st);
+                hipLaunchKernelGGL(sr_update_ps_kernel, dim3(gv), dim3(256), 0, s, n, sr, z, w, p, sv, st, 0);
             }
             PADNE_HIP_CHECK(hipGetLastError());
             PADNE_HIP_CHECK(hipMemcpyAsync(hst, st, sizeof(PcgStatus), hipMemcpyDeviceToHost, s));
