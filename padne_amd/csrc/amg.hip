@@ -654,22 +654,25 @@ __global__ void transpose_fill(int n_rows, const int *__restrict__ rowptr, const
     }
 }
 
-// C = X * Y, row-wise: upper bound of the row length, then sorted-insert accumulation
+// C = X * Y, row-wise: upper bound of the row length, then sorted-insert accumulation.  Row m of Y is [yr[m], ye[m]) with
+// its columns at yc[q * ycs]: a CSR matrix (ye = yr + 1, ycs = 1), or rows still sitting in their merge slots
+// (ye = slot start + length, columns in the upper halves of the 64-bit keys: ycs = 2) -- A P is consumed once, by
+// R (A P), which reads it by rows anyway, so it is never compacted.
 __global__ void spgemm_count(int n_rows, const int *__restrict__ xr, const int *__restrict__ xc,
-                             const int *__restrict__ yr, int *__restrict__ cnt) {
+                             const int *__restrict__ yr, const int *__restrict__ ye, int *__restrict__ cnt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rows) return;
     long long c = 0;
     for (int k = xr[i]; k < xr[i + 1]; ++k) {
         const int m = xc[k];
-        c += yr[m + 1] - yr[m];
+        c += ye[m] - yr[m];
     }
     cnt[i] = c > 2000000000LL ? 2000000000 : (int)c;   // the scan rejects totals beyond int32
 }
 
 __global__ void spgemm_rows(int n_rows, const int *__restrict__ xr, const int *__restrict__ xc,
                             const double *__restrict__ xv, const int *__restrict__ yr, const int *__restrict__ yc,
-                            const double *__restrict__ yv, const int *__restrict__ slot_ptr,
+                            const double *__restrict__ yv, const int *__restrict__ ye, const int ycs, const int *__restrict__ slot_ptr,
                             long long *__restrict__ key, double *__restrict__ val, int *__restrict__ row_len) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rows) return;
@@ -679,8 +682,8 @@ __global__ void spgemm_rows(int n_rows, const int *__restrict__ xr, const int *_
     for (int k = xr[i]; k < xr[i + 1]; ++k) {
         const int mid = xc[k];
         const double a = xv[k];
-        for (int q = yr[mid]; q < yr[mid + 1]; ++q) {
-            const long long c = (long long)yc[q] << 32;
+        for (int q = yr[mid]; q < ye[mid]; ++q) {
+            const long long c = (long long)yc[(long long)q * ycs] << 32;
             const double v = a * yv[q];
             // binary search for c in K[0..m)
             int lo = 0, hi = m;
@@ -710,7 +713,7 @@ __global__ void spgemm_rows(int n_rows, const int *__restrict__ xr, const int *_
 template <int CAP>
 __global__ __launch_bounds__(128) void spgemm_rows_lds(int n_rows, const int *__restrict__ xr, const int *__restrict__ xc,
                                                        const double *__restrict__ xv, const int *__restrict__ yr,
-                                                       const int *__restrict__ yc, const double *__restrict__ yv,
+                                                       const int *__restrict__ yc, const double *__restrict__ yv, const int *__restrict__ ye, const int ycs,
                                                        const int *__restrict__ slot_ptr, long long *__restrict__ key,
                                                        double *__restrict__ val, int *__restrict__ row_len) {
     __shared__ int Kc[CAP][128];
@@ -723,8 +726,8 @@ __global__ __launch_bounds__(128) void spgemm_rows_lds(int n_rows, const int *__
     for (int k = xr[i]; k < xr[i + 1] && !overflow; ++k) {
         const int mid = xc[k];
         const double a = xv[k];
-        for (int q = yr[mid]; q < yr[mid + 1]; ++q) {
-            const int c = yc[q];
+        for (int q = yr[mid]; q < ye[mid]; ++q) {
+            const int c = yc[(long long)q * ycs];
             const double v = a * yv[q];
             int lo = 0;
             while (lo < m && Kc[lo][t] < c) ++lo;          // lists are a handful of entries long
@@ -770,7 +773,7 @@ __global__ __launch_bounds__(128) void spgemm_rows_lds(int n_rows, const int *__
 template <int CAPP, int HT>
 __global__ __launch_bounds__(256) void spgemm_rows_wave(int n_rows, const int *__restrict__ xr, const int *__restrict__ xc,
                                                         const double *__restrict__ xv, const int *__restrict__ yr,
-                                                        const int *__restrict__ yc, const double *__restrict__ yv,
+                                                        const int *__restrict__ yc, const double *__restrict__ yv, const int *__restrict__ ye, const int ycs,
                                                         const int *__restrict__ slot_ptr, long long *__restrict__ key,
                                                         double *__restrict__ val, int *__restrict__ row_len,
                                                         const int only_flagged) {
@@ -800,7 +803,7 @@ __global__ __launch_bounds__(256) void spgemm_rows_wave(int n_rows, const int *_
                 const int mid = xc[x0 + lane];
                 a_n = xv[x0 + lane];
                 ystart_n = yr[mid];
-                len_n = yr[mid + 1] - ystart_n;
+                len_n = ye[mid] - ystart_n;
             }
         }
     };
@@ -843,7 +846,7 @@ __global__ __launch_bounds__(256) void spgemm_rows_wave(int n_rows, const int *_
                 if (off[m] <= p) lo = m; else hi = m;
             }
             const int q = ys[lo] + (p - off[lo]);
-            const int c = yc[q];
+            const int c = yc[(long long)q * ycs];
             pc[p] = c;
             pv[p] = xs[lo] * yv[q];
             unsigned h = ((unsigned)c * 2654435761u) >> 7;
@@ -915,7 +918,7 @@ __global__ __launch_bounds__(256) void spgemm_rows_wave(int n_rows, const int *_
 template <int CAPP, int HT, int LANES>
 __global__ __launch_bounds__(256) void spgemm_rows_sub(int n_rows, const int *__restrict__ xr, const int *__restrict__ xc,
                                                        const double *__restrict__ xv, const int *__restrict__ yr,
-                                                       const int *__restrict__ yc, const double *__restrict__ yv,
+                                                       const int *__restrict__ yc, const double *__restrict__ yv, const int *__restrict__ ye, const int ycs,
                                                        const int *__restrict__ slot_ptr, long long *__restrict__ key,
                                                        double *__restrict__ val, int *__restrict__ row_len) {
     constexpr int G = 256 / LANES;                    // rows (lane groups) per workgroup
@@ -945,7 +948,7 @@ __global__ __launch_bounds__(256) void spgemm_rows_sub(int n_rows, const int *__
                 const int mid = xc[x0 + sl];
                 a_n = xv[x0 + sl];
                 ystart_n = yr[mid];
-                len_n = yr[mid + 1] - ystart_n;
+                len_n = ye[mid] - ystart_n;
             }
         }
     };
@@ -984,7 +987,7 @@ __global__ __launch_bounds__(256) void spgemm_rows_sub(int n_rows, const int *__
                 if (off[m] <= p) lo = m; else hi = m;
             }
             const int q = ys[lo] + (p - off[lo]);
-            const int c = yc[q];
+            const int c = yc[(long long)q * ycs];
             pc[p] = c;
             pv[p] = xs[lo] * yv[q];
             unsigned h = ((unsigned)c * 2654435761u) >> 7;
@@ -1051,7 +1054,7 @@ __global__ __launch_bounds__(256) void spgemm_rows_sub(int n_rows, const int *__
 // columns are distinct, so every accumulator cell sees its products in the same order as spgemm_rows.
 __global__ __launch_bounds__(256) void spgemm_rows_dense(int n_cols, const int *__restrict__ xr, const int *__restrict__ xc,
                                                          const double *__restrict__ xv, const int *__restrict__ yr,
-                                                         const int *__restrict__ yc, const double *__restrict__ yv,
+                                                         const int *__restrict__ yc, const double *__restrict__ yv, const int *__restrict__ ye, const int ycs,
                                                          const int *__restrict__ slot_ptr, long long *__restrict__ key,
                                                          double *__restrict__ val, int *__restrict__ row_len) {
     extern __shared__ double acc_and_flag[];               // n_cols doubles + n_cols bytes
@@ -1067,8 +1070,8 @@ __global__ __launch_bounds__(256) void spgemm_rows_dense(int n_cols, const int *
     for (int k = xr[i]; k < xr[i + 1]; ++k) {
         const int mid = xc[k];
         const double a = xv[k];
-        for (int q = yr[mid] + threadIdx.x; q < yr[mid + 1]; q += 256) {
-            const int c = yc[q];
+        for (int q = yr[mid] + threadIdx.x; q < ye[mid]; q += 256) {
+            const int c = yc[(long long)q * ycs];
             acc[c] += a * yv[q];
             hit[c] = 1;
         }
@@ -1102,7 +1105,7 @@ __global__ __launch_bounds__(256) void spgemm_rows_dense(int n_cols, const int *
 // only the rows the LDS variant gave up on
 __global__ void spgemm_rows_redo(int n_rows, const int *__restrict__ xr, const int *__restrict__ xc,
                                  const double *__restrict__ xv, const int *__restrict__ yr, const int *__restrict__ yc,
-                                 const double *__restrict__ yv, const int *__restrict__ slot_ptr,
+                                 const double *__restrict__ yv, const int *__restrict__ ye, const int ycs, const int *__restrict__ slot_ptr,
                                  long long *__restrict__ key, double *__restrict__ val, int *__restrict__ row_len) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rows || row_len[i] >= 0) return;
@@ -1112,8 +1115,8 @@ __global__ void spgemm_rows_redo(int n_rows, const int *__restrict__ xr, const i
     for (int k = xr[i]; k < xr[i + 1]; ++k) {
         const int mid = xc[k];
         const double a = xv[k];
-        for (int q = yr[mid]; q < yr[mid + 1]; ++q) {
-            const long long c = (long long)yc[q] << 32;
+        for (int q = yr[mid]; q < ye[mid]; ++q) {
+            const long long c = (long long)yc[(long long)q * ycs] << 32;
             const double v = a * yv[q];
             int lo = 0, hi = m;
             while (lo < hi) {
@@ -1787,7 +1790,43 @@ static int transpose(padne_ctx *ctx, const padne_csr *M, padne_csr **T) {
     return csr_from_exact_slots(ctx, nc, M->n_rows, M->nnz, slot_ptr, key, val, T);
 }
 
-static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_csr **C) {
+// rows of a product left in their merge slots (row i = [begin[i], end[i]) of key / val), owned by this object
+struct SlotRows {
+    padne_ctx *ctx = nullptr;
+    long long n_rows = 0, n_cols = 0;
+    int *begin = nullptr, *end = nullptr;
+    long long *key = nullptr;
+    double *val = nullptr;
+    bool valid = false;
+    ~SlotRows() { release(); }
+    void release() {
+        if (ctx != nullptr) {
+            pool_free(ctx, begin);
+            pool_free(ctx, end);
+            pool_free(ctx, key);
+            pool_free(ctx, val);
+        }
+        begin = end = nullptr;
+        key = nullptr;
+        val = nullptr;
+        valid = false;
+    }
+};
+
+__global__ void slot_row_ends(int n, const int *__restrict__ slot_ptr, const int *__restrict__ row_len, int *__restrict__ end) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) end[i] = slot_ptr[i] + row_len[i];
+}
+
+// C = X * Y.  `y_slots`: Y is given by its uncompacted rows instead of the arrays of the handle (only n_rows / n_cols of
+// Y are read then).  `keep_slots`: leave the product in ITS slots (no scan, no compaction) and return no matrix.
+static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_csr **C, const SlotRows *y_slots = nullptr,
+                  SlotRows *keep_slots = nullptr) {
+    const int *y_begin = y_slots != nullptr ? y_slots->begin : Y->rowptr;
+    const int *y_end = y_slots != nullptr ? y_slots->end : Y->rowptr + 1;
+    const int *y_cols = y_slots != nullptr ? (const int *)y_slots->key + 1 : Y->cols;      // upper half of a little-endian key
+    const double *y_vals = y_slots != nullptr ? y_slots->val : Y->vals;
+    const int y_cs = y_slots != nullptr ? 2 : 1;
     hipStream_t s = ctx->stream;
     Scratch sc(ctx);
     const int n = (int)X->n_rows;
@@ -1796,7 +1835,7 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
     PADNE_TRY(sc.alloc(&slot_ptr, (size_t)n + 1));
     PADNE_TRY(sc.alloc(&row_len, (size_t)n + 1));
     PADNE_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)(n + 1), s));
-    if (n > 0) hipLaunchKernelGGL(spgemm_count, dim3(nblk(n)), dim3(256), 0, s, n, X->rowptr, X->cols, Y->rowptr, cnt);
+    if (n > 0) hipLaunchKernelGGL(spgemm_count, dim3(nblk(n)), dim3(256), 0, s, n, X->rowptr, X->cols, y_begin, y_end, cnt);
     PADNE_HIP_CHECK(hipGetLastError());
     int64_t n_slots = 0;
     const int rc_scan = exclusive_scan_i32(ctx, cnt, slot_ptr, n, &n_slots);
@@ -1817,8 +1856,8 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
         top.amg = bottom.amg = nullptr;
         if (amg_verbose()) fprintf(stderr, "[amg]   spgemm %lld rows: %lld product slots, split in two\n", (long long)n, (long long)n_slots);
         padne_csr *Ct = nullptr, *Cb = nullptr;
-        int rc = spgemm(ctx, &top, Y, &Ct);
-        if (rc == PADNE_OK) rc = spgemm(ctx, &bottom, Y, &Cb);
+        int rc = spgemm(ctx, &top, Y, &Ct, y_slots);
+        if (rc == PADNE_OK) rc = spgemm(ctx, &bottom, Y, &Cb, y_slots);
         if (rc == PADNE_OK) rc = csr_vstack(ctx, Ct, Cb, Y->n_cols, C);
         if (Ct) padne_csr_destroy(Ct);
         if (Cb) padne_csr_destroy(Cb);
@@ -1838,13 +1877,13 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
             (void)hipFuncSetAttribute((const void *)spgemm_rows_dense, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)dense_lds);
             hipLaunchKernelGGL(spgemm_rows_dense, dim3(n), dim3(256), dense_lds, s, (int)Y->n_cols, X->rowptr, X->cols,
-                               X->vals, Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len);
+                               X->vals, y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len);
         } else if (avg <= 24.0 && getenv("PADNE_SPGEMM_WAVE_ALL") == nullptr) {
             // A*P on the fine levels: a dozen products per row -> one thread per row with small sorted lists in LDS
             hipLaunchKernelGGL(spgemm_rows_lds<16>, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
-                               Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len);
+                               y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len);
             hipLaunchKernelGGL(spgemm_rows_redo, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
-                               Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len);
+                               y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len);
         } else if (avg <= 256.0) {
             // tens to hundreds of products per row: one wave per row, the rows that do not fit are redone in global memory
             const unsigned gw = (unsigned)std::min<long long>(((long long)n + 3) / 4, 16384);
@@ -1853,28 +1892,48 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
                 // CU), then one row per wave for the rows that did not fit
                 const unsigned gs = (unsigned)std::min<long long>(((long long)n + 7) / 8, 16384);
                 hipLaunchKernelGGL((spgemm_rows_sub<128, 64, 32>), dim3(gs), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
-                                   Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len);
+                                   y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len);
                 hipLaunchKernelGGL((spgemm_rows_wave<256, 128>), dim3(gw), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
-                                   Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len, 1);
+                                   y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len, 1);
                 if (n <= 500000)   // coarse levels: the few long rows stay away from the serial fallback
                     hipLaunchKernelGGL((spgemm_rows_wave<1024, 512>), dim3(gw), dim3(256), 0, s, n, X->rowptr, X->cols,
-                                       X->vals, Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len, 1);
+                                       X->vals, y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len, 1);
             } else {
                 // coarse levels: rows of a few hundred products, some of a thousand -- a second wave pass with doubled
                 // limits keeps those away from the serial fallback (0.5 ms for a handful of rows)
                 hipLaunchKernelGGL((spgemm_rows_wave<512, 256>), dim3(gw), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
-                                   Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len, 0);
+                                   y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len, 0);
                 hipLaunchKernelGGL((spgemm_rows_wave<1024, 512>), dim3(gw), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
-                                   Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len, 1);
+                                   y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len, 1);
             }
             hipLaunchKernelGGL(spgemm_rows_redo, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
-                               Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len);
+                               y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len);
         } else {
             hipLaunchKernelGGL(spgemm_rows, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
-                               Y->rowptr, Y->cols, Y->vals, slot_ptr, key, val, row_len);
+                               y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len);
         }
     }
     PADNE_HIP_CHECK(hipGetLastError());
+    if (keep_slots != nullptr) {
+        keep_slots->release();
+        int *end = (int *)pool_alloc(ctx, sizeof(int) * (size_t)(n > 0 ? n : 1));
+        if (end == nullptr) return PADNE_E_NOMEM;
+        if (n > 0) hipLaunchKernelGGL(slot_row_ends, dim3(nblk(n)), dim3(256), 0, s, n, slot_ptr, row_len, end);
+        PADNE_HIP_CHECK(hipGetLastError());
+        keep_slots->ctx = ctx;
+        keep_slots->n_rows = n;
+        keep_slots->n_cols = Y->n_cols;
+        keep_slots->begin = slot_ptr;
+        keep_slots->end = end;
+        keep_slots->key = key;
+        keep_slots->val = val;
+        keep_slots->valid = true;
+        sc.disown(slot_ptr);
+        sc.disown(key);
+        sc.disown(val);
+        if (C != nullptr) *C = nullptr;
+        return PADNE_OK;
+    }
     return csr_from_slots(ctx, n, Y->n_cols, slot_ptr, key, val, row_len, C);
 }
 
@@ -2119,14 +2178,25 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         if ((rc = transpose(aux, L.P, &L.R)) != PADNE_OK) { amg->levels.push_back(L); break; }
         if (want_f32 && ((rc = csr_build_f32(aux, L.R)) != PADNE_OK || (rc = csr_build_f32(aux, L.P)) != PADNE_OK)) { amg->levels.push_back(L); break; }
         pt.lap(two ? "transpose (queued)" : "transpose");
-        if ((rc = spgemm(ctx, A, L.P, &AP)) != PADNE_OK) { amg->levels.push_back(L); break; }
+        // A P stays in the slots its rows were merged in: R (A P) reads it by rows, a compacted copy would be written
+        // and read once for nothing (the product comes back as a matrix only when it had to be split, see spgemm)
+        SlotRows ap_rows;
+        if ((rc = spgemm(ctx, A, L.P, &AP, nullptr, &ap_rows)) != PADNE_OK) { amg->levels.push_back(L); break; }
         pt.lap("A*P");
-        if (amg_verbose()) fprintf(stderr, "[amg]   AP nnz=%lld\n", (long long)AP->nnz);
-        if (two && (rc = stream_order(aux, ctx)) != PADNE_OK) { padne_csr_destroy(AP); amg->levels.push_back(L); break; }
-        rc = spgemm(ctx, L.R, AP, &Ac);
+        if (amg_verbose() && AP != nullptr) fprintf(stderr, "[amg]   AP nnz=%lld\n", (long long)AP->nnz);
+        if (two && (rc = stream_order(aux, ctx)) != PADNE_OK) { if (AP) padne_csr_destroy(AP); amg->levels.push_back(L); break; }
+        if (ap_rows.valid) {
+            padne_csr ap_shape;
+            ap_shape.n_rows = ap_rows.n_rows;
+            ap_shape.n_cols = ap_rows.n_cols;
+            rc = spgemm(ctx, L.R, &ap_shape, &Ac, &ap_rows);
+        } else {
+            rc = spgemm(ctx, L.R, AP, &Ac);
+        }
         pt.lap("R*(AP)");
         if (amg_verbose() && rc == PADNE_OK) fprintf(stderr, "[amg]   Ac: n=%lld nnz=%lld\n", (long long)Ac->n_rows, (long long)Ac->nnz);
-        padne_csr_destroy(AP);
+        if (AP) padne_csr_destroy(AP);
+        ap_rows.release();
         amg->levels.push_back(L);
         if (rc != PADNE_OK) break;
         if ((rc = csr_build_dinv(ctx, Ac)) != PADNE_OK) { padne_csr_destroy(Ac); break; }

@@ -214,6 +214,9 @@ struct Scratch {   // device allocations returned to the pool on scope exit
         for (void *p : ptrs) if (p) pool_free(ctx, p);
         ptrs.clear();
     }
+    void disown(void *p) {          // the caller keeps p beyond this scope
+        for (void *&q : ptrs) if (q == p) q = nullptr;
+    }
     template <typename T> int alloc(T **out, size_t count) {
         void *p = pool_alloc(ctx, sizeof(T) * (count ? count : 1));
         if (p == nullptr) return PADNE_E_NOMEM;
