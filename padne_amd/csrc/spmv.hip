@@ -318,7 +318,10 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_wpr_kernel(
 }
 
 static inline bool use_wave_per_row(const padne_csr *m) {
-    return m->hierarchy_operator && m->n_rows > 0 && m->n_rows <= 65536 && m->nnz >= 24 * m->n_rows;
+    // (a few thousand rows are a handful of 256-row workgroups for the tile kernel: the restriction onto the coarsest
+    // level, 1617 rows of 21 entries, took 14 us there and takes 5 us with a wave per row)
+    return m->hierarchy_operator && m->n_rows > 0 && m->n_rows <= 65536 &&
+           (m->nnz >= 24 * m->n_rows || (m->n_rows <= 4096 && m->nnz >= 8 * m->n_rows));
 }
 
 int spmv_grid(const padne_csr *m) {
@@ -460,7 +463,10 @@ __global__ __launch_bounds__(256) void xw_plan_kernel(int n_rows, int n_wtiles, 
 int csr_build_xw_plan(padne_ctx *ctx, padne_csr *m) {
     if (m->xw_state != 0) return PADNE_OK;
     m->xw_state = -1;
-    // worth examining only for the big streaming operators; hierarchy operators are not band matrices
+    // worth examining only for the big streaming operators.  Hierarchy operators: the first coarse operators of a mesh
+    // problem do qualify with runs of 128 (96 % of the tiles of A_1 of config C4), the prolongators do not (five bands of
+    // aggregates); measured, the plan of A_1 / A_2 costs 0.3-0.8 ms of setup and buys nothing per iteration (1030 us
+    // either way: those passes are not gather-bound), so they keep the gather path.
     if (m->n_rows < 65536 || m->hierarchy_operator || m->nnz > 64LL * m->n_rows || getenv("PADNE_NO_XWINDOW") != nullptr)
         return PADNE_OK;
     padne_ctx *owner = m->owner ? m->owner : ctx;
