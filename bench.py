@@ -185,13 +185,17 @@ def main():
         ctx.synchronize()
 
     # ---- build the workload (untimed) -----------------------------------------------------------
-    sysm = synthetic.config(args.workload)
-    nv = sysm.n_vertices
-    N = nv + 1
     t_setup0 = time.perf_counter()
     if not distributed_path:
-        xy, tri, mvo, mto, sig = flat(sysm)
+        # meshes generated on the device (padne_generate_grid_mesh: the arrays of synthetic.config, bit for bit, without
+        # seconds of numpy and 0.4 GB of PCIe); the lumped elements are host-side index lists as before
+        sysm, xy, tri = synthetic.config_on_device(ctx, args.workload)
+        nv = sysm.n_vertices
+        N = nv + 1
+        mvo, mto = sysm.mesh_offsets, sysm._tri_offsets
+        sig = np.array([m[2] for m in sysm.meshes])
         rows, cols, vals, rhs = stamps_of(sysm, N)
+        ctx.synchronize()
         t0 = time.perf_counter()
         L = ctx.assemble_system(N, xy, tri, mvo, mto, sig, rows, cols, vals)
         ctx.synchronize()
@@ -216,6 +220,9 @@ def main():
         hierarchy_shapes = (lambda: A.amg_shapes()) if args.precond == "amg" else None
     else:
         from padne_amd import distributed
+        sysm = synthetic.config(args.workload)
+        nv = sysm.n_vertices
+        N = nv + 1
         plan = distributed.build_layer_partition(sysm, rank, world)
         dsolver = distributed.DistributedSolver(ctx, plan, dist)
         t_assemble, t_reduce = dsolver.t_assemble, dsolver.t_reduce

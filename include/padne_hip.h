@@ -115,10 +115,22 @@ int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns,
                           int64_t n_coo, const int64_t *coo_row, const int64_t *coo_col,
                           const double *coo_val,
                           padne_csr **out);
+/* Structured test / benchmark mesh generated on the device (no reference counterpart: it stands where the CGAL mesher
+ * stands, padne/mesh.py:662-795, for the synthetic configs of SURVEY.md section 8d): nx * ny vertices spaced h from
+ * (origin_x, origin_y), row-major, interior vertices displaced by U(-jitter h, +jitter h), cells split by alternating
+ * diagonals into counter-clockwise triangles.  The displacements are output 2 v + 1 and 2 v + 2 of numpy's PCG64
+ * stream whose 128-bit state and increment are pcg64_state_inc[0..3] = state hi, state lo, inc hi, inc lo
+ * (default_rng(seed).bit_generator.state), so the arrays equal padne_amd.synthetic.jittered_grid bit for bit.
+ * xy_dev: 2 nx ny doubles, tri_dev: 6 (nx-1)(ny-1) int32, both device memory (padne_dev_alloc). */
+int padne_generate_grid_mesh(padne_ctx *ctx, int64_t nx, int64_t ny, double h, double jitter, double origin_x,
+                             double origin_y, const uint64_t *pcg64_state_inc, void *xy_dev, void *tri_dev);
+
 /* The same for ONE RANK'S PIECE of a mesh that is partitioned across GPUs (flags bit 0): the triangles are those that
  * touch a vertex the rank owns, so the vertices of the ring around the owned region have incomplete fans and the
  * manifold test (PADNE_E_NONMANIFOLD) is switched off -- the rows of ring vertices are dropped by the caller
- * (padne_csr_relabel); validate the whole mesh on one rank instead.  flags = 0 is padne_assemble_system. */
+ * (padne_csr_relabel); validate the whole mesh on one rank instead.  flags = 0 is padne_assemble_system.
+ * With either entry point `xy_host` / `tri_host` may also be DEVICE pointers (e.g. filled by padne_generate_grid_mesh):
+ * the two big arrays are then copied device to device and nothing crosses PCIe. */
 int padne_assemble_system_ex(padne_ctx *ctx, int64_t n_unknowns, int64_t n_vert, const double *xy_host,
                              int64_t n_tri, const int32_t *tri_host, int64_t n_mesh,
                              const int64_t *mesh_vertex_offset, const int64_t *mesh_tri_offset,

@@ -79,6 +79,8 @@ SIGNATURES = {
                                         _I64, _PI64, _PI64, _PF64, C.POINTER(_P)]),
     "padne_assemble_system_ex": (C.c_int, [_P, _I64, _I64, _PF64, _I64, _PI32, _I64, _PI64, _PI64, _PF64,
                                            _I64, _PI64, _PI64, _PF64, C.c_int32, C.POINTER(_P)]),
+    "padne_generate_grid_mesh": (C.c_int, [_P, _I64, _I64, C.c_double, C.c_double, C.c_double, C.c_double,
+                                           C.POINTER(C.c_uint64), _P, _P]),
     "padne_csr_reduce": (C.c_int, [_P, _P, _PI32, _I64, C.c_double, C.POINTER(_P)]),
     "padne_csr_relabel": (C.c_int, [_P, _P, _PI32, _I64, _PI32, _I64, C.c_double, C.POINTER(_P)]),
     "padne_csr_vstack": (C.c_int, [_P, _P, _P, C.POINTER(_P)]),
@@ -290,8 +292,20 @@ class Context:
                         coo_row, coo_col, coo_val, partial_mesh: bool = False) -> "CsrMatrix":
         """L in the reference layout: cotangent Laplacians of all meshes + lumped stamps.  ``partial_mesh``: the
         triangles are one rank's piece of a partitioned mesh (no manifold test, see padne_assemble_system_ex)."""
-        xy = _f64(xy).reshape(-1, 2)
-        tri = _i32(tri).reshape(-1, 3)
+        # xy / tri: host arrays, or DeviceArrays (e.g. filled by generate_grid_mesh): then nothing crosses PCIe
+        xy_dev = isinstance(xy, DeviceArray)
+        tri_dev = isinstance(tri, DeviceArray)
+        if xy_dev != tri_dev:
+            raise ValueError("xy and tri must both be host arrays or both DeviceArrays")
+        if not xy_dev:
+            xy = _f64(xy).reshape(-1, 2)
+            tri = _i32(tri).reshape(-1, 3)
+        elif xy.dtype != np.float64 or tri.dtype != np.int32:
+            raise ValueError("device xy must be float64 and device tri int32")
+        n_xy = int(np.prod(xy.shape)) // 2
+        n_tr = int(np.prod(tri.shape)) // 3
+        p_xy = C.cast(_P(xy.ptr), _PF64) if xy_dev else _ptr(xy, _PF64)
+        p_tri = C.cast(_P(tri.ptr), _PI32) if tri_dev else _ptr(tri, _PI32)
         mvo, mto, sig = _i64(mesh_vertex_offset), _i64(mesh_tri_offset), _f64(conductance)
         cr, cc, cv = _i64(coo_row), _i64(coo_col), _f64(coo_val)
         n_mesh = sig.shape[0]
@@ -301,10 +315,26 @@ class Context:
             raise ValueError("coo arrays must have equal length")
         h = _P()
         _check(self._lib.padne_assemble_system_ex(
-            self._h, int(n_unknowns), xy.shape[0], _ptr(xy, _PF64), tri.shape[0], _ptr(tri, _PI32), n_mesh,
+            self._h, int(n_unknowns), n_xy, p_xy, n_tr, p_tri, n_mesh,
             _ptr(mvo, _PI64), _ptr(mto, _PI64), _ptr(sig, _PF64), cr.shape[0], _ptr(cr, _PI64),
             _ptr(cc, _PI64), _ptr(cv, _PF64), 1 if partial_mesh else 0, C.byref(h)))
         return CsrMatrix(self, h)
+
+    def generate_grid_mesh(self, nx: int, ny: int, h: float, seed: int = 0, jitter: float = 0.2, origin=(0.0, 0.0),
+                           xy_out: "DeviceArray | None" = None, tri_out: "DeviceArray | None" = None,
+                           vertex_offset: int = 0, tri_offset: int = 0):
+        """``synthetic.jittered_grid(nx, ny, h, seed, jitter, origin)`` generated on the device, bit for bit (the jitter is
+        numpy's ``default_rng(seed)`` stream, evaluated per vertex by jump-ahead).  Returns (xy, tri) DeviceArrays; with
+        ``xy_out`` / ``tri_out`` the mesh is written at ``vertex_offset`` / ``tri_offset`` of existing arrays."""
+        n_v, n_t = nx * ny, 2 * (nx - 1) * (ny - 1)
+        xy = xy_out if xy_out is not None else DeviceArray(self, (n_v, 2), np.float64)
+        tri = tri_out if tri_out is not None else DeviceArray(self, (n_t, 3), np.int32)
+        st = np.random.default_rng(seed).bit_generator.state["state"]
+        g = (C.c_uint64 * 4)(st["state"] >> 64, st["state"] & (2 ** 64 - 1), st["inc"] >> 64, st["inc"] & (2 ** 64 - 1))
+        _check(self._lib.padne_generate_grid_mesh(self._h, int(nx), int(ny), float(h), float(jitter), float(origin[0]),
+                                                  float(origin[1]), g, _P(xy.ptr + 16 * int(vertex_offset)),
+                                                  _P(tri.ptr + 12 * int(tri_offset))))
+        return xy, tri
 
     def nearest_vertex(self, points: np.ndarray, queries: np.ndarray) -> np.ndarray:
         """Index of the nearest of ``points`` (n, 2) for every row of ``queries`` (m, 2); ties to the smallest index."""
@@ -317,8 +347,20 @@ class Context:
         return out
 
     def power_density(self, xy, tri, mesh_vertex_offset, mesh_tri_offset, conductance, potential) -> np.ndarray:
-        xy = _f64(xy).reshape(-1, 2)
-        tri = _i32(tri).reshape(-1, 3)
+        # xy / tri: host arrays, or DeviceArrays (e.g. filled by generate_grid_mesh): then nothing crosses PCIe
+        xy_dev = isinstance(xy, DeviceArray)
+        tri_dev = isinstance(tri, DeviceArray)
+        if xy_dev != tri_dev:
+            raise ValueError("xy and tri must both be host arrays or both DeviceArrays")
+        if not xy_dev:
+            xy = _f64(xy).reshape(-1, 2)
+            tri = _i32(tri).reshape(-1, 3)
+        elif xy.dtype != np.float64 or tri.dtype != np.int32:
+            raise ValueError("device xy must be float64 and device tri int32")
+        n_xy = int(np.prod(xy.shape)) // 2
+        n_tr = int(np.prod(tri.shape)) // 3
+        p_xy = C.cast(_P(xy.ptr), _PF64) if xy_dev else _ptr(xy, _PF64)
+        p_tri = C.cast(_P(tri.ptr), _PI32) if tri_dev else _ptr(tri, _PI32)
         mvo, mto, sig = _i64(mesh_vertex_offset), _i64(mesh_tri_offset), _f64(conductance)
         pot = _f64(potential)
         if pot.shape[0] < xy.shape[0]:

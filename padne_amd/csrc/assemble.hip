@@ -1193,8 +1193,9 @@ extern "C" int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns, int64_t
     PADNE_TRY(sc.alloc(&d_slot, (size_t)n_unknowns + 1));
     PADNE_TRY(sc.alloc(&d_err, (size_t)ERR_WORDS));
     const long long zero_off[1] = {0};
-    PADNE_HIP_CHECK(hipMemcpyAsync(d_xy, xy_host, sizeof(double) * 2 * (size_t)n_vert, hipMemcpyHostToDevice, s));
-    PADNE_HIP_CHECK(hipMemcpyAsync(d_tri, tri_host, sizeof(int) * 3 * (size_t)n_tri, hipMemcpyHostToDevice, s));
+    // (hipMemcpyDefault: the two big arrays may already live on the device -- padne_generate_grid_mesh, padne_assemble_system_ex)
+    PADNE_HIP_CHECK(hipMemcpyAsync(d_xy, xy_host, sizeof(double) * 2 * (size_t)n_vert, hipMemcpyDefault, s));
+    PADNE_HIP_CHECK(hipMemcpyAsync(d_tri, tri_host, sizeof(int) * 3 * (size_t)n_tri, hipMemcpyDefault, s));
     if (n_mesh > 0) {
         PADNE_HIP_CHECK(hipMemcpyAsync(d_sigma, conductance, sizeof(double) * (size_t)n_mesh, hipMemcpyHostToDevice, s));
         PADNE_HIP_CHECK(hipMemcpyAsync(d_voff, mesh_vertex_offset, sizeof(long long) * (size_t)(n_mesh + 1), hipMemcpyHostToDevice, s));
@@ -1501,8 +1502,9 @@ static int face_fields(padne_ctx *ctx, int64_t n_vert, const double *xy_host, in
         PADNE_TRY(sc.alloc(&d_gx, (size_t)n_tri));
         PADNE_TRY(sc.alloc(&d_gy, (size_t)n_tri));
     }
-    PADNE_HIP_CHECK(hipMemcpyAsync(d_xy, xy_host, sizeof(double) * 2 * (size_t)n_vert, hipMemcpyHostToDevice, s));
-    PADNE_HIP_CHECK(hipMemcpyAsync(d_tri, tri_host, sizeof(int) * 3 * (size_t)n_tri, hipMemcpyHostToDevice, s));
+    // (hipMemcpyDefault: the two big arrays may already live on the device -- padne_generate_grid_mesh, padne_assemble_system_ex)
+    PADNE_HIP_CHECK(hipMemcpyAsync(d_xy, xy_host, sizeof(double) * 2 * (size_t)n_vert, hipMemcpyDefault, s));
+    PADNE_HIP_CHECK(hipMemcpyAsync(d_tri, tri_host, sizeof(int) * 3 * (size_t)n_tri, hipMemcpyDefault, s));
     if (conductance)
         PADNE_HIP_CHECK(hipMemcpyAsync(d_sigma, conductance, sizeof(double) * (size_t)n_mesh, hipMemcpyHostToDevice, s));
     PADNE_HIP_CHECK(hipMemcpyAsync(d_voff, mesh_vertex_offset, sizeof(long long) * (size_t)(n_mesh + 1), hipMemcpyHostToDevice, s));

@@ -112,10 +112,14 @@ class SyntheticSystem:
 
     @property
     def n_vertices(self) -> int:
+        if getattr(self, "_n_vertices", None) is not None:        # meshes live on the device (layered_system_on_device)
+            return self._n_vertices
         return int(sum(m[0].shape[0] for m in self.meshes))
 
     @property
     def mesh_offsets(self) -> np.ndarray:
+        if getattr(self, "_mesh_offsets", None) is not None:
+            return self._mesh_offsets
         return np.concatenate([[0], np.cumsum([m[0].shape[0] for m in self.meshes])]).astype(np.int64)
 
 
@@ -129,7 +133,7 @@ def _nearest_vertex_on_grid(nx, ny, h, pts):
 def layered_system(n_layers: int, nx: int, ny: int, *, h: float = DEFAULT_MAXIMUM_SIZE,
                    sigma: float = DEFAULT_SHEET_CONDUCTANCE, via_lattice: int = 32,
                    ring_points: int = 16, segment_length: float = 0.5,
-                   current: float = 1.0, name: str | None = None) -> SyntheticSystem:
+                   current: float = 1.0, name: str | None = None, _no_meshes: bool = False) -> SyntheticSystem:
     """C2/C3/C4 of SURVEY.md section 8d.
 
     ``n_layers`` jittered nx*ny grids (seeds 0..n_layers-1); adjacent layers are
@@ -139,6 +143,8 @@ def layered_system(n_layers: int, nx: int, ny: int, *, h: float = DEFAULT_MAXIMU
     """
     meshes = []
     for l in range(n_layers):
+        if _no_meshes:
+            break
         xy, tri = jittered_grid(nx, ny, h, seed=l)
         meshes.append((xy, tri, float(sigma), l))
     n_per = nx * ny
@@ -169,7 +175,37 @@ def layered_system(n_layers: int, nx: int, ny: int, *, h: float = DEFAULT_MAXIMU
                            name=name or f"{n_layers}-layer {nx}x{ny}")
 
 
+def layered_system_on_device(ctx, n_layers: int, nx: int, ny: int, *, h: float = DEFAULT_MAXIMUM_SIZE,
+                             sigma: float = DEFAULT_SHEET_CONDUCTANCE, name: str | None = None, **kw):
+    """:func:`layered_system` with the meshes generated ON THE DEVICE (``padne_generate_grid_mesh``): the same vertices
+    and triangles bit for bit, but no host array and no PCIe transfer -- at N = 10 M the numpy generation takes seconds
+    and the upload is two thirds of the assembly.  Returns ``(system, xy_dev, tri_dev)``: ``system.meshes`` carries no
+    arrays (``(None, None, sigma, layer)``), the lumped elements are the host-side index lists as before."""
+    n_v, n_t = nx * ny, 2 * (nx - 1) * (ny - 1)
+    xy = ctx.empty((n_layers * n_v, 2), np.float64)
+    tri = ctx.empty((n_layers * n_t, 3), np.int32)
+    for layer in range(n_layers):
+        ctx.generate_grid_mesh(nx, ny, h, seed=layer, xy_out=xy, tri_out=tri, vertex_offset=layer * n_v,
+                               tri_offset=layer * n_t)
+    host = layered_system(n_layers, nx, ny, h=h, sigma=sigma, name=name, _no_meshes=True, **kw)
+    host.meshes = [(None, None, float(sigma), layer) for layer in range(n_layers)]
+    host._n_vertices = n_layers * n_v
+    host._mesh_offsets = np.arange(n_layers + 1, dtype=np.int64) * n_v
+    host._tri_offsets = np.arange(n_layers + 1, dtype=np.int64) * n_t
+    return host, xy, tri
+
+
 # named configurations of BASELINE.json
+CONFIG_SHAPES = {"C2": (1, 1000, 1000, "C2 1-layer N=1M"), "C3": (4, 1118, 1118, "C3 4-layer N=5M"),
+                 "C4": (8, 1118, 1118, "C4 8-layer N=10M"), "C5": (4, 1118, 1118, "C5 4-layer N=5M x 8 rhs")}
+
+
+def config_on_device(ctx, name: str):
+    """A named configuration with its meshes generated on the device: ``(system, xy_dev, tri_dev)``."""
+    nl, nx, ny, label = CONFIG_SHAPES[name.upper()]
+    return layered_system_on_device(ctx, nl, nx, ny, name=label)
+
+
 def config(name: str) -> SyntheticSystem:
     name = name.upper()
     if name == "C2":

@@ -70,6 +70,41 @@ def test_assemble_system_vs_golden_and_oracle(ctx, name):
     L.dev.close()
 
 
+@pytest.mark.parametrize("nx,ny,seed,jitter,origin", [(2, 2, 0, 0.2, (0.0, 0.0)), (7, 5, 3, 0.2, (0.0, 0.0)),
+                                                   (57, 49, 2, 0.2, (110.6, 99.1)), (301, 177, 11, 0.35, (-3.5, 2.25)),
+                                                   (40, 30, 5, 0.0, (0.0, 0.0))])
+def test_device_mesh_generator_is_the_numpy_generator_bit_for_bit(ctx, nx, ny, seed, jitter, origin):
+    """padne_generate_grid_mesh (the structured stand-in for the CGAL mesher, off the host): same vertices,
+    same jitter (numpy's PCG64 stream evaluated per vertex by jump-ahead), same triangles as synthetic.jittered_grid."""
+    xy_d, tri_d = ctx.generate_grid_mesh(nx, ny, 0.6, seed=seed, jitter=jitter, origin=origin)
+    xy, tri = synthetic.jittered_grid(nx, ny, 0.6, seed=seed, jitter=jitter, origin=origin)
+    assert np.array_equal(xy_d.numpy(), xy) and np.array_equal(tri_d.numpy(), tri)
+
+
+def test_assembly_from_device_resident_meshes(ctx):
+    """The synthetic configs end to end without the mesh ever being on the host: generated on the device, assembled from
+    device pointers -- the matrix is the one the host arrays give, bit for bit (and therefore the oracle's)."""
+    host = synthetic.layered_system(3, 61, 47, via_lattice=4)
+    dev, xy_d, tri_d = synthetic.layered_system_on_device(ctx, 3, 61, 47, via_lattice=4)
+    assert dev.n_vertices == host.n_vertices and np.array_equal(dev.mesh_offsets, host.mesh_offsets)
+    for got, want in zip(dev.resistors + dev.current_sources, host.resistors + host.current_sources):
+        assert np.array_equal(got, want)
+    assert np.array_equal(xy_d.numpy(), np.concatenate([m[0] for m in host.meshes]))
+    assert np.array_equal(tri_d.numpy(), np.concatenate([m[1] for m in host.meshes]))
+    xy, tri, mvo, mto, sig = flat(host.meshes)
+    N = host.n_vertices + 1
+    a, b, rr = host.resistors
+    gg = 1 / rr
+    rows = np.concatenate([np.stack([a, a, b, b], 1).reshape(-1), [N - 1, 0]])
+    cols = np.concatenate([np.stack([a, b, b, a], 1).reshape(-1), [0, N - 1]])
+    vals = np.concatenate([np.stack([-gg, gg, -gg, gg], 1).reshape(-1), [1.0, 1.0]])
+    L_host = ctx.assemble_system(N, xy, tri, mvo, mto, sig, rows, cols, vals).to_scipy()
+    L_dev = ctx.assemble_system(N, xy_d, tri_d, dev.mesh_offsets, dev._tri_offsets, sig, rows, cols, vals).to_scipy()
+    assert H.same_structure(L_host, L_dev) and np.array_equal(L_host.data, L_dev.data)
+    with pytest.raises(ValueError):
+        ctx.assemble_system(N, xy_d, tri, mvo, mto, sig, rows, cols, vals)          # one on the device, one on the host
+
+
 def test_assembly_is_run_to_run_bitwise_reproducible(ctx):
     sysm = synthetic.layered_system(3, 70, 50, via_lattice=5)
     xy, tri, mvo, mto, sig = flat(sysm.meshes)
