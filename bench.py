@@ -101,8 +101,23 @@ def cpu_baseline(nx: int):
                   f"oracle assembly, then the reference's tocsc+spsolve+residual (solver.py:772-775), "
                   f"{dt:.2f} s, residual {res:.1e}; SuperLU is single-threaded ({os.cpu_count()} cores available)",
         "seconds": dt, "n": n, "cpu_spmv_gbs": spmv_gbs,
-        "extrapolated_full_size_seconds": dt * (n_full / n) ** 1.4,
+        "full_size": full_size_cpu_record(),
     }
+
+
+def full_size_cpu_record():
+    """The reference's solve call on the WHOLE workload, measured once on a GPU box host (scripts/direct_full.py ->
+    profiles/r02_direct_full.json; 11 minutes of one core, far beyond the bounded sample this bench may time)."""
+    path = os.path.join(ROOT, "profiles", "r02_direct_full.json")
+    try:
+        rec = json.load(open(path))["configs"]["C4"]
+        return {"source": "profiles/r02_direct_full.json (scripts/direct_full.py, measured, not extrapolated)",
+                "cpu": json.load(open(path))["host"]["cpu"], "n": rec["n"],
+                "spsolve_seconds": rec["reference_cpu"]["spsolve_seconds"], "total_seconds": rec["reference_cpu"]["total_seconds"],
+                "peak_rss_gb": rec["reference_cpu"]["peak_rss_gb"],
+                "max_rel_potential_error_of_the_hip_solve": rec["parity"]["max_rel_error"]}
+    except Exception:
+        return None
 
 
 def step_algorithmic_bytes(shapes, iterations: int):

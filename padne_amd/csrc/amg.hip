@@ -284,15 +284,39 @@ __global__ __launch_bounds__(256) void nbr_max(int n, int n_wtiles, const int *_
     }
 }
 
+__device__ __forceinline__ bool mis_decide_one(int i, unsigned int top, unsigned int *__restrict__ word,
+                                               signed char *__restrict__ state) {
+    // returns true if vertex i is still undecided after this round
+    const unsigned int mine = word[i];
+    if (top == kMisRoot) {
+        state[i] = 2;
+        word[i] = 0u;
+        return false;
+    }
+    if (top == mine) {
+        state[i] = 1;
+        word[i] = kMisRoot;
+        return false;
+    }
+    return true;
+}
+
 // The same pass over a matrix with an x-window plan: a tile's neighbours live in (at most) three runs of consecutive
 // vertices, which are staged in LDS with coalesced loads; an entry is then one byte (spos, written by strength_mark)
 // instead of a 4-byte column and a scattered 4-byte gather.  Tiles without a plan take the gather path above.
-template <typename T>
+// DECIDE: the second pass of a round ends with the decision of the round (mis_decide) while the two-hop maximum is in
+// a register: `out` is not written, the words / states are updated in place (the pass itself reads only `in`, the
+// one-hop maxima), the vertices still open are counted.
+template <typename T, bool DECIDE>
 __global__ __launch_bounds__(256) void nbr_max_xw(int n, int n_wtiles, const int *__restrict__ srow,
                                                   const int *__restrict__ scol, const unsigned char *__restrict__ spos,
                                                   const int4 *__restrict__ xw_desc, const int run,
-                                                  const T *__restrict__ in, T *__restrict__ out) {
+                                                  const T *__restrict__ in, T *__restrict__ out,
+                                                  unsigned int *__restrict__ word, signed char *__restrict__ state,
+                                                  int *__restrict__ undecided) {
     constexpr int CH = 512;
+    __shared__ int open_red[4];
+    int open = 0;
     __shared__ T park_all[4 * CH];
     __shared__ T xs_all[4 * 3 * 88];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -363,7 +387,22 @@ __global__ __launch_bounds__(256) void nbr_max_xw(int n, int n_wtiles, const int
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        if (r < row1) out[r] = m;
+        if (r < row1) {
+            if (DECIDE) {
+                if (state[r] == 0 && mis_decide_one(r, (unsigned int)m, word, state)) ++open;
+            } else {
+                out[r] = m;
+            }
+        }
+    }
+    if (DECIDE) {
+        for (int off = 32; off > 0; off >>= 1) open += __shfl_down(open, off, 64);
+        if (lane == 0) open_red[w] = open;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int t = open_red[0] + open_red[1] + open_red[2] + open_red[3];
+            if (t) atomicAdd(undecided, t);
+        }
     }
 }
 
@@ -373,23 +412,6 @@ __global__ __launch_bounds__(256) void nbr_max_xw(int n, int n_wtiles, const int
 __global__ void mis_init_words(int n, unsigned int *__restrict__ word) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) word[i] = prio32_of(i);
-}
-
-__device__ __forceinline__ bool mis_decide_one(int i, unsigned int top, unsigned int *__restrict__ word,
-                                               signed char *__restrict__ state) {
-    // returns true if vertex i is still undecided after this round
-    const unsigned int mine = word[i];
-    if (top == kMisRoot) {
-        state[i] = 2;
-        word[i] = 0u;
-        return false;
-    }
-    if (top == mine) {
-        state[i] = 1;
-        word[i] = kMisRoot;
-        return false;
-    }
-    return true;
 }
 
 // full round: every vertex looks at its two-hop maximum m2; *undecided = number of vertices still open
@@ -1387,11 +1409,18 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
                        xw ? A->xw_desc : (const int4 *)nullptr, xw ? (const unsigned char *)A->xw_lidx : (const unsigned char *)nullptr,
                        xw ? A->xw_run : 0, spos);
     PADNE_HIP_CHECK(hipGetLastError());
-    auto launch_nbr_max = [&](const unsigned int *src, unsigned int *dst) {
-        if (xw)
-            hipLaunchKernelGGL(nbr_max_xw<unsigned int>, gm, b, 0, s, n, n_wt, srow, scol, spos, A->xw_desc, A->xw_run, src, dst);
-        else
-            hipLaunchKernelGGL(nbr_max<unsigned int>, gm, b, 0, s, n, n_wt, srow, scol, src, dst);
+    // one round = one-hop maxima, two-hop maxima, decision; on a windowed matrix the decision rides on the second pass
+    auto launch_round = [&](int *open_counter) {
+        if (xw) {
+            hipLaunchKernelGGL((nbr_max_xw<unsigned int, false>), gm, b, 0, s, n, n_wt, srow, scol, spos, A->xw_desc, A->xw_run,
+                               (const unsigned int *)w0, w1, (unsigned int *)nullptr, (signed char *)nullptr, (int *)nullptr);
+            hipLaunchKernelGGL((nbr_max_xw<unsigned int, true>), gm, b, 0, s, n, n_wt, srow, scol, spos, A->xw_desc, A->xw_run,
+                               (const unsigned int *)w1, (unsigned int *)nullptr, w0, state, open_counter);
+        } else {
+            hipLaunchKernelGGL(nbr_max<unsigned int>, gm, b, 0, s, n, n_wt, srow, scol, w0, w1);
+            hipLaunchKernelGGL(nbr_max<unsigned int>, gm, b, 0, s, n, n_wt, srow, scol, w1, w2);
+            hipLaunchKernelGGL(mis_decide, dim3(std::min<unsigned>(g.x, 1024u)), b, 0, s, n, w0, w2, state, open_counter);
+        }
     };
     if (lambda_f != nullptr)
         PADNE_HIP_CHECK(hipMemcpyAsync(h_bound.data(), bound_part, sizeof(double) * h_bound.size(), hipMemcpyDeviceToHost, s));
@@ -1406,9 +1435,7 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
     const int full_batch = n > 200000 ? 1 : 4;
     while (round < kMaxRounds && open_count > 0 && (!compact_ok || round < 2 || open_count > n / 8)) {
         for (int rep = 0; rep < full_batch && round < kMaxRounds; ++rep, ++round) {
-            launch_nbr_max(w0, w1);
-            launch_nbr_max(w1, w2);
-            hipLaunchKernelGGL(mis_decide, dim3(std::min<unsigned>(g.x, 1024u)), b, 0, s, n, w0, w2, state, counter + round);
+            launch_round(counter + round);
         }
         PADNE_HIP_CHECK(hipGetLastError());
         PADNE_HIP_CHECK(hipMemcpyAsync(&open_count, counter + round - 1, sizeof(int), hipMemcpyDeviceToHost, s));

@@ -135,6 +135,13 @@ def main():
                          "ground_current_abs_diff": abs(float(v_hip[-1]) - float(v_lu[-1])), "bar": 1e-8,
                          "within_bar": bool(err <= 1e-8)}
         rec["speedup"] = {"vs_device_solve": total / info.solve_seconds, "vs_solve_system_wall": total / t_hip}
+        # a sample of the direct solve's potentials becomes a committed fixture (tests/golden/direct_<config>.npz): the
+        # full-size GPU test then checks the product against the reference's own solve call at BASELINE scale
+        pick = np.unique(np.concatenate([np.random.default_rng(2026).integers(0, nv, 4096),
+                                         [int(np.argmax(v_lu[:nv])), int(np.argmin(v_lu[:nv])), 0, nv - 1]]))
+        np.savez_compressed(os.path.join(os.path.dirname(args.out), f"direct_{name}.npz"), index=pick.astype(np.int64),
+                            potential=v_lu[pick], max_abs_potential=np.float64(scale), n_vertices=np.int64(nv),
+                            residual_norm=np.float64(res_lu), spsolve_seconds=np.float64(t_lu))
         # scipy CSR product on this host, same byte formula as the GPU figure
         x = np.random.default_rng(1).uniform(-1, 1, N)
         best = min(_t(lambda: Lh @ x) for _ in range(5))

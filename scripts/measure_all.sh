@@ -8,6 +8,6 @@ echo stats done
 timeout -k 10 600 bash scripts/pmc_bench.sh $O/pmc > $O/pmc.log 2>&1 || exit 3
 echo pmc done
 timeout -k 10 600 python scripts/run_configs.py > $O/configs.log 2>&1 || exit 4
-cp gpurun_out/r01_configs.json $O/ ; echo configs done
+cp gpurun_out/configs.json $O/ ; echo configs done
 timeout -k 10 300 python bench.py --precond jacobi --steps 1 --warmup 0 --no-cpu-baseline > $O/bench_jacobi.log 2>&1 || exit 5
 grep '^{' $O/bench_jacobi.log > $O/bench_c4_1gpu_jacobi.json; echo jacobi done

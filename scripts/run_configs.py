@@ -1,4 +1,4 @@
-"""Measure every BASELINE.json config that fits one GPU (C2, C3, C4, C5) and write profiles/r01_configs.json."""
+"""Measure every BASELINE.json config that fits one GPU (C2, C3, C4, C5) and write gpurun_out/configs.json (scripts/collect_profiles.py copies it to profiles/<round>_configs.json)."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,13 +11,21 @@ for name in ["C2", "C3", "C4", "C5"]:
     sysm = synthetic.config(name); nv = sysm.n_vertices; N = nv + 1
     xy, tri, mvo, mto, sig = bench.flat(sysm); rows, cols, vals, rhs = bench.stamps_of(sysm, N)
     t = time.perf_counter(); L = ctx.assemble_system(N, xy, tri, mvo, mto, sig, rows, cols, vals); ctx.synchronize(); t_asm = time.perf_counter() - t
+    # the same with the meshes generated on the device (no host arrays, no PCIe): generation, then assembly
+    t = time.perf_counter(); sd, xy_d, tri_d = synthetic.config_on_device(ctx, name); ctx.synchronize(); t_gen = time.perf_counter() - t
+    t_dev = 1e9
+    for _ in range(3):
+        t = time.perf_counter(); Ld = ctx.assemble_system(N, xy_d, tri_d, sd.mesh_offsets, sd._tri_offsets, sig, rows, cols, vals); ctx.synchronize()
+        t_dev = min(t_dev, time.perf_counter() - t); Ld.close()
+    xy_d.free(); tri_d.free(); del xy, tri
     imap = np.arange(N, dtype=np.int32); imap[sysm.ground] = -1; imap[imap > sysm.ground] -= 1; imap[N - 1] = -1
     t = time.perf_counter(); A = L.reduce(imap, nv - 1, -1.0); ctx.synchronize(); t_red = time.perf_counter() - t
     L.close()
     keep = np.flatnonzero(imap[:nv] >= 0)
     xr = ctx.to_device(np.random.default_rng(1).uniform(-1, 1, A.shape[1])); y = ctx.empty(A.shape[0])
     t_spmv = min(A.spmv_time(xr, y, 5, 50) for _ in range(3))
-    rec = {"n": A.shape[0], "nnz": A.nnz, "assemble_s_incl_h2d": t_asm, "reduce_s": t_red,
+    rec = {"n": A.shape[0], "nnz": A.nnz, "assemble_s_incl_h2d": t_asm, "assemble_s_device_resident": t_dev,
+           "generate_on_device_s": t_gen, "assembly_algorithmic_gbs": 124.0 * nv / t_dev / 1e9, "reduce_s": t_red,
            "spmv_us": t_spmv * 1e6, "spmv_gbs": A.spmv_bytes / t_spmv / 1e9, "spmv_frac_of_8TBs": A.spmv_bytes / t_spmv / 8e12}
     if name == "C5":
         f, tt = synthetic.multi_rhs_pairs(sysm, 8)
@@ -59,4 +67,4 @@ for name in ["C2", "C3", "C4", "C5"]:
     out[name] = rec
     print(name, json.dumps(rec), flush=True)
     del A, b, x, xr, y
-json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r01_configs.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "configs.json"), "w"), indent=1)

@@ -17,7 +17,7 @@ INT_ARGS = {"R": 2, "I": 2, "V": 2, "REG": 4}
 def golden_names():
     """Unknown-level fixtures (lumped elements given by global unknown index)."""
     return sorted(n for n in (os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
-                  if not n.startswith("problem_"))
+                  if not n.startswith(("problem_", "direct_")))
 
 
 def problem_golden_names():

@@ -1027,6 +1027,21 @@ def test_full_size_superposition_and_reciprocity(ctx, c3_system):
     assert abs(z21 - z12) <= 1e-9 * max(abs(z21), abs(v1[:nv]).max())
 
 
+def _check_against_the_direct_solve_samples(name, v):
+    """tests/golden/direct_<config>.npz: a few thousand potentials of the reference's own solve call
+    (scipy.sparse.linalg.spsolve on the un-reduced system, solver.py:772-775) at FULL size, produced once on a GPU box host
+    by scripts/direct_full.py (392 s for C3, 696 s for C4 on one EPYC core; profiles/r02_direct_full.json).  North star:
+    potentials within 1e-8 relative of the reference's direct solve."""
+    import os
+    path = os.path.join(H.GOLDEN, f"direct_{name}.npz")
+    assert os.path.exists(path), f"{path} missing (scripts/direct_full.py writes it)"
+    g = np.load(path)
+    assert int(g["n_vertices"]) == len(v)
+    err = np.abs(v[g["index"]] - g["potential"]).max() / float(g["max_abs_potential"])
+    assert err <= REL_TOL, f"{name}: potentials differ from the reference's direct solve by {err:.2e} relative"
+    assert float(g["residual_norm"]) < 1e-9
+
+
 def test_headline_config_at_full_size(ctx, monkeypatch):
     """Config C4 of BASELINE.json itself (8 layers of 1118x1118, N = 10 M, the bench workload), through the
     properties that need no direct solve: the windowed and the gather path of the product agree bit for bit, the
@@ -1076,9 +1091,66 @@ def test_headline_config_at_full_size(ctx, monkeypatch):
         sel = (a // n_per == l) & (b // n_per == l + 1)
         assert abs(np.sum((v[b[sel]] - v[a[sel]]) / rr[sel]) - 1.0) < 1e-7
     assert int(np.argmax(v)) == t and int(np.argmin(v)) == f
+    _check_against_the_direct_solve_samples("C4", v)
     res2 = A.solve_spd(-2.5 * full[keep], rtol=1e-12, precond="amg")
     assert np.abs(res2.x - 2.5 * res.x).max() <= 1e-9 * np.abs(res2.x).max()
     A.close()
+
+
+def test_config_c5_at_full_size(ctx):
+    """Config C5 of BASELINE.json at full size: 8 current-source configurations on the 4-layer N = 5 M mesh, advanced in
+    lockstep.  Every column reaches the tolerance; column 0 is the C3 right-hand side and is checked against the sampled
+    potentials of the reference's direct solve; every column equals its own one-at-a-time solve."""
+    sysm, xy_d, tri_d = synthetic.config_on_device(ctx, "C5")
+    nv = sysm.n_vertices
+    N = nv + 1
+    a, b, rr = sysm.resistors
+    gg = 1 / rr
+    rows = np.stack([a, a, b, b], 1).reshape(-1)
+    cols = np.stack([a, b, b, a], 1).reshape(-1)
+    vals = np.stack([-gg, gg, -gg, gg], 1).reshape(-1)
+    sig = np.array([m[2] for m in sysm.meshes])
+    Ld = ctx.assemble_system(N, xy_d, tri_d, sysm.mesh_offsets, sysm._tri_offsets, sig, rows, cols, vals)
+    xy_d.free()
+    tri_d.free()
+    imap = np.arange(N, dtype=np.int32)
+    imap[sysm.ground] = -1
+    imap[imap > sysm.ground] -= 1
+    imap[N - 1] = -1
+    A = Ld.reduce(imap, nv - 1, -1.0)
+    Ld.close()
+    keep = np.flatnonzero(imap[:nv] >= 0)
+    src, snk = synthetic.multi_rhs_pairs(sysm, 8)
+    src[0], snk[0] = int(sysm.current_sources[0][0]), int(sysm.current_sources[1][0])     # column 0 = config C3
+    B = np.zeros((8, len(keep)))
+    for k in range(8):
+        full = np.zeros(nv)
+        full[src[k]] += 1.0
+        full[snk[k]] -= 1.0
+        B[k] = -full[keep]
+    res = A.solve_spd(B, rtol=1e-12, precond="amg")
+    assert res.status == _hip.OK and res.rel_residual <= 1.1e-12 and res.precond_fallbacks == 0
+    v0 = np.zeros(nv)
+    v0[keep] = res.x[0]
+    _check_against_the_direct_solve_samples("C3", v0)
+    for k in (0, 5):
+        one = A.solve_spd(B[k], rtol=1e-12, precond="amg")
+        assert np.abs(one.x - res.x[k]).max() <= 1e-9 * np.abs(one.x).max()
+        vk = np.zeros(nv)
+        vk[keep] = res.x[k]
+        assert int(np.argmax(vk)) == snk[k] and int(np.argmin(vk)) == src[k]              # maximum principle
+    A.close()
+
+
+def test_headline_config_on_eight_ranks(ctx):
+    """Config C4 as BASELINE.json runs it -- one layer per rank, 8 ranks -- on ONE GPU through the in-process team:
+    the layer partition, three exchanged multigrid levels and the single-reduction loop at full size.  Checked against
+    the sampled potentials of the reference's direct solve; iteration count as on one GPU (28) within the spread seen
+    for 2-8 ranks."""
+    sysm = synthetic.config("C4")
+    v, iters, res = run_team(sysm, 8, "amg")
+    _check_against_the_direct_solve_samples("C4", v)
+    assert res.rel_residual <= 1.1e-12 and res.levels >= 4 and 20 <= iters <= 45
 
 
 def test_randomised_assembly_is_the_oracle_bit_for_bit(ctx):
