@@ -15,7 +15,10 @@
  *     addresses (hipMalloc / torch tensor.data_ptr()) valid on the context's GPU.
  *   - all calls are blocking unless the name ends in _async.
  *   - indices are int32 inside a matrix (nnz < 2^31), sizes are int64.
- *   - all floating point data is IEEE binary64 (solver.py:21, DTYPE = float64).
+ *   - all floating point data that crosses this boundary is IEEE binary64 (solver.py:21, DTYPE = float64), and so are
+ *     assembly, the solver's own products, residuals and dot products; only the multigrid V-cycle INSIDE the
+ *     preconditioner runs on single-precision copies of its operators (it has to be a fixed SPD operator, not an
+ *     accurate one; PADNE_AMG_F64=1 keeps it in binary64).
  */
 #ifndef PADNE_HIP_H
 #define PADNE_HIP_H

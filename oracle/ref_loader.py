@@ -24,8 +24,10 @@ The returned namespace gives the reference's own ``Mesh.from_triangle_soup``,
 ``HalfEdge.cotan``, ``laplace_operator``, ``stamp_network_into_system``,
 ``setup_ground_node``, ``solve_system``, ``compute_triangle_gradient``,
 ``compute_power_density``, ``produce_layer_solutions`` ... unmodified, which is
-what ``tests/golden/make_golden.py`` runs to emit the golden vectors and what
-``tests/test_oracle_vs_reference.py`` uses to pin the numpy oracle.
+what ``tests/golden/make_golden.py`` runs to emit the golden vectors (the numpy
+oracle is pinned against those: ``tests/test_oracle_golden.py``) and what
+``tests/test_host_logic.py::test_problem_seam_with_the_reference_own_objects``
+feeds to the product's host logic.
 """
 from __future__ import annotations
 

@@ -4,7 +4,7 @@
 // ||b - A x|| <= rtol ||b|| is reached, not what is solved.
 //
 // Setup per level (all deterministic -- priorities are hashes of the index, sums have a fixed order):
-//   strength   j is a strong neighbour of i  <=>  a_ij^2 >= theta^2 a_ii a_jj          (theta = 0.1)
+//   strength   j is a strong neighbour of i  <=>  a_ij^2 >= theta^2 a_ii a_jj          (theta = 0.08)
 //   aggregate  distance-2 maximal independent set of the strength graph (MIS-k rounds on unique 32-bit
 //              priority words, two neighbour-max passes per round) -> roots; every other vertex joins the
 //              aggregate of its strongest aggregated neighbour (two passes); vertices without strong
