@@ -355,6 +355,49 @@ def test_multigrid_hierarchy_is_galerkin_and_partition_of_unity(ctx):
         assert P.shape[1] < 0.5 * P.shape[0]
 
 
+@pytest.mark.parametrize("hub", [False, True])
+def test_windowed_setup_kernels_build_the_same_hierarchy(ctx, monkeypatch, hub):
+    """A fine level with an x-window plan (>= 65536 rows, band matrix) takes the windowed setup kernels: one-byte
+    neighbour positions in the independent-set rounds, the decision fused into the second pass, prolongator rows merged
+    in registers and written straight into CSR, A P consumed from its merge slots.  Same operations in the same order as
+    the general kernels: every operator of the hierarchy is BIT-IDENTICAL to the one PADNE_AMG_NO_XW=1 builds -- with
+    tiles that have no plan (via rows) inside the same launches, and (hub) with a row of more than 13 entries, which
+    sends the prolongator of the whole level back to the general kernel."""
+    sysm = synthetic.layered_system(2, 300, 240, via_lattice=6)
+    els = [("R", int(a), int(b), float(r)) for a, b, r in zip(*sysm.resistors)]
+    els += [("I", int(f), int(t), float(i)) for f, t, i in zip(*sysm.current_sources)]
+    if hub:
+        els += [("R", 300 * 120 + 150, 300 * 7 * k + 31 * k + 5, 0.05) for k in range(1, 17)]      # one vertex, 16 far resistors
+    Lo, ro = O.assemble_system([(m[0], m[1], m[2]) for m in sysm.meshes], 0, els, 0)
+    n = sysm.n_vertices
+    A = (-Lo[1:n, 1:n]).tocsr()
+    A.sort_indices()
+    b = -ro[1:n]
+    assert A.shape[0] >= 65536 and (np.diff(A.indptr).max() > 13) == hub
+
+    def hierarchy():
+        d = ctx.csr_from_scipy(A)
+        res = d.solve_spd(b, precond="amg")
+        ops = [(d.amg_level(l, "A"), d.amg_level(l, "P"), d.amg_level(l, "R")) for l in range(res.levels - 1)]
+        d.close()
+        return res, ops
+    monkeypatch.setenv("PADNE_XW_VERBOSE", "1")
+    res_w, ops_w = hierarchy()
+    monkeypatch.setenv("PADNE_AMG_NO_XW", "1")
+    res_g, ops_g = hierarchy()
+    assert res_w.levels == res_g.levels >= 3 and res_w.iterations == res_g.iterations
+    assert np.array_equal(res_w.x, res_g.x)
+    for (Aw, Pw, Rw), (Ag, Pg, Rg) in zip(ops_w, ops_g):
+        for W, G in ((Aw, Ag), (Pw, Pg), (Rw, Rg)):
+            assert W.shape == G.shape and np.array_equal(W.indptr, G.indptr) and np.array_equal(W.indices, G.indices)
+            assert np.array_equal(W.data, G.data)
+    # and the hierarchy is the one the properties ask for
+    A0, P0, R0 = ops_w[0]
+    assert abs(R0 - P0.T).max() == 0.0
+    ref = (P0.T @ A0 @ P0).tocsr()
+    assert abs(ops_w[1][0] - ref).max() <= 1e-12 * abs(ref).max()
+
+
 @pytest.mark.parametrize("precision", ["f32", "f64"])
 def test_multigrid_preconditioner_is_symmetric_positive_definite(ctx, monkeypatch, precision):
     """The cycle runs on single-precision copies of its operators by default (PADNE_AMG_F64=1: double): a fixed
