@@ -204,25 +204,80 @@ __device__ __forceinline__ int find_segment(const long long *__restrict__ offs, 
 // grid has 6 triangles around a vertex, Delaunay meshes rarely more than 10); the counter keeps counting beyond that,
 // such a vertex takes the slot path.  The order inside a list is left to the atomics: nothing below depends on it.
 constexpr int kIncCap = 12;
-__global__ void asm_count_tri(long long n_tri, const int *__restrict__ tri, int n_mesh,
-                              const long long *__restrict__ mesh_voff, const long long *__restrict__ mesh_toff,
-                              int *__restrict__ cnt, int *__restrict__ inc, int *__restrict__ err) {
+// The triangles of a workgroup usually touch a short range of vertices (256 consecutive triangles of a scan-line or
+// strip-ordered mesh: two mesh lines, about as many distinct vertices as triangles, each touched three times).  Then
+// the corners are counted with LDS atomics first and the global counter of a vertex is advanced ONCE per workgroup by
+// the number of its corners here: a third of the global atomics.  A workgroup whose vertices span more than
+// kCntRange indices (unordered triangle lists) counts every corner globally, as before.
+constexpr int kCntRange = 4096;
+__global__ __launch_bounds__(256) void asm_count_tri(long long n_tri, const int *__restrict__ tri, int n_mesh,
+                                                     const long long *__restrict__ mesh_voff,
+                                                     const long long *__restrict__ mesh_toff, int *__restrict__ cnt,
+                                                     int *__restrict__ inc, int *__restrict__ err) {
+    __shared__ int lcnt[kCntRange], lbase[kCntRange];
+    __shared__ long long s_min, s_max;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tri) return;
-    const int m = find_segment(mesh_toff, n_mesh, t);
-    const long long v0 = mesh_voff[m];
-    const long long nv = mesh_voff[m + 1] - v0;
-    const int a = tri[3 * t], b = tri[3 * t + 1], c = tri[3 * t + 2];
-    if (a < 0 || b < 0 || c < 0 || a >= nv || b >= nv || c >= nv || a == b || b == c || a == c) {
-        atomicExch(&err[ERR_BAD_INDEX], 1);
+    if (threadIdx.x == 0) {
+        s_min = 0x7fffffffffffffffLL;
+        s_max = -1;
+    }
+    __syncthreads();
+    bool ok = false;
+    long long g[3] = {0, 0, 0};
+    if (t < n_tri) {
+        const int m = find_segment(mesh_toff, n_mesh, t);
+        const long long v0 = mesh_voff[m];
+        const long long nv = mesh_voff[m + 1] - v0;
+        const int a = tri[3 * t], b = tri[3 * t + 1], c = tri[3 * t + 2];
+        if (a < 0 || b < 0 || c < 0 || a >= nv || b >= nv || c >= nv || a == b || b == c || a == c) {
+            atomicExch(&err[ERR_BAD_INDEX], 1);
+        } else {
+            ok = true;
+            g[0] = v0 + a;
+            g[1] = v0 + b;
+            g[2] = v0 + c;
+        }
+    }
+    long long lo = ok ? min(g[0], min(g[1], g[2])) : 0x7fffffffffffffffLL, hi = ok ? max(g[0], max(g[1], g[2])) : -1;
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, __shfl_down(lo, off, 64));
+        hi = max(hi, __shfl_down(hi, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&s_min, lo);
+        atomicMax(&s_max, hi);
+    }
+    __syncthreads();
+    const long long base = s_min;
+    const long long range = s_max - base + 1;
+    if (range <= 0) return;                               // no valid triangle in this workgroup
+    if (range > kCntRange) {
+        if (ok)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int pos = atomicAdd(&cnt[g[q]], 1);      // incident triangles per vertex; a row owns two slots per incidence
+                if (pos < kIncCap) inc[g[q] * kIncCap + pos] = (int)t;
+            }
         return;
     }
-    const long long g[3] = {v0 + a, v0 + b, v0 + c};
+    for (int j = threadIdx.x; j < (int)range; j += 256) lcnt[j] = 0;
+    __syncthreads();
+    int lpos[3] = {0, 0, 0};
+    if (ok)
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const int pos = atomicAdd(&cnt[g[q]], 1);      // incident triangles per vertex; a row owns two slots per incidence
-        if (pos < kIncCap) inc[g[q] * kIncCap + pos] = (int)t;
+        for (int q = 0; q < 3; ++q) lpos[q] = atomicAdd(&lcnt[(int)(g[q] - base)], 1);
+    __syncthreads();
+    for (int j = threadIdx.x; j < (int)range; j += 256) {
+        const int c = lcnt[j];
+        lbase[j] = c > 0 ? atomicAdd(&cnt[base + j], c) : 0;
     }
+    __syncthreads();
+    if (ok)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int pos = lbase[(int)(g[q] - base)] + lpos[q];
+            if (pos < kIncCap) inc[g[q] * kIncCap + pos] = (int)t;
+        }
 }
 
 // slots of a row.  A mesh vertex without stamps and with at most kIncCap triangles is finished by
