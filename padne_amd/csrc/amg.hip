@@ -40,6 +40,7 @@ struct AmgLevel {
     padne_csr *A_owned = nullptr;
     padne_csr *P = nullptr;         // n_l x n_{l+1}
     padne_csr *R = nullptr;         // n_{l+1} x n_l
+    padne_csr *W = nullptr;         // P - c D^-1 A P, single-precision values only (the fine level of the float cycle)
     double lambda = 2.0;            // Gershgorin bound of D^-1 A
     double jac = 0.0;               // Jacobi damping 1/theta_c
     long long n = 0;
@@ -1820,7 +1821,7 @@ static int transpose(padne_ctx *ctx, const padne_csr *M, padne_csr **T) {
 // rows of a product left in their merge slots (row i = [begin[i], end[i]) of key / val), owned by this object
 struct SlotRows {
     padne_ctx *ctx = nullptr;
-    long long n_rows = 0, n_cols = 0;
+    long long n_rows = 0, n_cols = 0, n_slots = 0;
     int *begin = nullptr, *end = nullptr;
     long long *key = nullptr;
     double *val = nullptr;
@@ -1950,6 +1951,7 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
         keep_slots->ctx = ctx;
         keep_slots->n_rows = n;
         keep_slots->n_cols = Y->n_cols;
+        keep_slots->n_slots = n_slots;
         keep_slots->begin = slot_ptr;
         keep_slots->end = end;
         keep_slots->key = key;
@@ -1962,6 +1964,96 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
         return PADNE_OK;
     }
     return csr_from_slots(ctx, n, Y->n_cols, slot_ptr, key, val, row_len, C);
+}
+
+// ---- W = P - c D^-1 (A P): coarse correction and post-smoothing of a level in ONE product ----------------------------
+// The up-leg of the V(1,1) cycle is  x2 = x1 + P e ;  x3 = x2 + c D^-1 (b - A x2).  With r1 = b - A x1 (the residual the
+// down-leg has just restricted, still in memory)
+//     x3 = x1 + c D^-1 r1 + (P - c D^-1 A P) e :
+// one product with W (the pattern of A P: 52 M entries on the fine level of C4) instead of one with P (24 M) and one
+// with A (70 M).  The setup forms A P anyway; W is built from its merge slots while they are still around, in single
+// precision only (it exists for the float cycle).  Algebraically the same operator, so still symmetric.
+__global__ void slot_row_lengths(int n, const int *__restrict__ begin, const int *__restrict__ end, int *__restrict__ len) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) len[i] = end[i] - begin[i];
+}
+
+// destination-ordered like compact_rows (assemble.hip): a wave owns 64 rows, its lanes walk the OUTPUT entries of those
+// rows (coalesced writes), find the row of an entry by bisection in the staged row pointers, read its slot and look the
+// column up in the (two or three entries of the) row of P
+__global__ __launch_bounds__(256) void w_from_slots_kernel(int n, const int *__restrict__ ap_begin,
+                                                           const long long *__restrict__ ap_key,
+                                                           const double *__restrict__ ap_val, const int *__restrict__ pr,
+                                                           const int *__restrict__ pc, const double *__restrict__ pv,
+                                                           const double *__restrict__ dinv, const double c,
+                                                           const int *__restrict__ wr, int *__restrict__ wc,
+                                                           float *__restrict__ wv) {
+    __shared__ int rp_all[4][65];
+    __shared__ int sp_all[4][65];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int *rp = rp_all[w], *sp = sp_all[w];
+    const long long n_wt = ((long long)n + 63) / 64;
+    for (long long wt = (long long)blockIdx.x * 4 + w; wt < n_wt; wt += (long long)gridDim.x * 4) {
+        const long long r0 = wt * 64;
+        const int nr = (int)((n - r0) < 64 ? (n - r0) : 64);
+        if (lane <= nr) rp[lane] = wr[r0 + lane];
+        if (lane < nr) sp[lane] = ap_begin[r0 + lane];
+        if (lane == 0 && nr == 64) rp[64] = wr[r0 + 64];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const int d0 = rp[0], d1 = rp[nr];
+        for (int k = d0 + lane; k < d1; k += 64) {
+            int lo = 0, hi = nr;                     // largest row with rp[row] <= k
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (rp[mid] <= k) lo = mid; else hi = mid;
+            }
+            const int i = (int)r0 + lo;
+            const int src = sp[lo] + (k - rp[lo]);
+            const int col = (int)(ap_key[src] >> 32);
+            double v = -c * dinv[i] * ap_val[src];
+            for (int q = pr[i]; q < pr[i + 1]; ++q)
+                if (pc[q] == col) v = pv[q] + v;
+            wc[k] = col;
+            wv[k] = (float)v;
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// No host synchronisation (the arrays are sized by the slot count, an upper bound of the entries): queued on the
+// context's second stream next to the next level's setup; the slots must stay alive until that stream has been joined.
+static int build_w_operator(padne_ctx *ctx, const padne_csr *A, const padne_csr *P, const SlotRows &ap, long long n_slots,
+                            double c, padne_csr **W_out) {
+    hipStream_t s = ctx->stream;
+    const int n = (int)A->n_rows;
+    Scratch sc(ctx);
+    int *len = nullptr;
+    PADNE_TRY(sc.alloc(&len, (size_t)n + 1));
+    padne_csr *W = new padne_csr();
+    W->n_rows = n;
+    W->n_cols = P->n_cols;
+    W->nnz = n_slots;                      // capacity; the row pointers hold the truth
+    W->device = ctx->device;
+    W->owner = ctx;
+    W->hierarchy_operator = true;
+    W->xw_state = -1;                      // five bands of aggregates: no x-window plan (measured on P)
+    W->rowptr = (int32_t *)pool_alloc(ctx, sizeof(int32_t) * ((size_t)n + 1));
+    W->cols = (int32_t *)pool_alloc(ctx, sizeof(int32_t) * ((size_t)n_slots + kPadNnz));
+    W->vals32 = (float *)pool_alloc(ctx, sizeof(float) * ((size_t)n_slots + kPadNnz));
+    if (!W->rowptr || !W->cols || !W->vals32) {
+        padne_csr_destroy(W);
+        return PADNE_E_NOMEM;
+    }
+    hipLaunchKernelGGL(slot_row_lengths, dim3(nblk(n)), dim3(256), 0, s, n, ap.begin, ap.end, len);
+    PADNE_HIP_CHECK(hipGetLastError());
+    PADNE_TRY(exclusive_scan_i32_async(ctx, len, W->rowptr, n));
+    hipLaunchKernelGGL(w_from_slots_kernel, dim3(nblk(((long long)n + 63) / 64, 4)), dim3(256), 0, s, n, ap.begin, ap.key, ap.val,
+                       P->rowptr, P->cols, P->vals, A->dinv, c, (const int *)W->rowptr, W->cols, W->vals32);
+    PADNE_HIP_CHECK(hipGetLastError());
+    *W_out = W;
+    return PADNE_OK;
 }
 
 static int dense_inverse(padne_ctx *ctx, const padne_csr *A, double **inv_out) {
@@ -2005,6 +2097,7 @@ void amg_destroy(void *p) {
         if (L.A_owned) padne_csr_destroy(L.A_owned);
         if (L.P) padne_csr_destroy(L.P);
         if (L.R) padne_csr_destroy(L.R);
+        if (L.W) padne_csr_destroy(L.W);
         pool_free(amg->ctx, L.b);
         pool_free(amg->ctx, L.xa);
         pool_free(amg->ctx, L.xb);
@@ -2141,6 +2234,7 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
     double nnz_total = 0.0;
     struct Pending { int level; LanczosJob job; };
     std::vector<Pending *> pending;      // Lanczos estimates in flight on the second stream
+    SlotRows ap_keep;                    // slots of the fine level's A P while W is built from them on the second stream
     auto drop_pending = [&]() {
         for (Pending *pj : pending) {
             double unused = 0.0;
@@ -2210,8 +2304,15 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         SlotRows ap_rows;
         if ((rc = spgemm(ctx, A, L.P, &AP, nullptr, &ap_rows)) != PADNE_OK) { amg->levels.push_back(L); break; }
         pt.lap("A*P");
+        // fine level of the float cycle: W = P - c D^-1 A P from the slots of A P, on the second stream
+        const bool with_w = lvl == 0 && want_f32 && ap_rows.valid && getenv("PADNE_AMG_NO_W") == nullptr;
         if (amg_verbose() && AP != nullptr) fprintf(stderr, "[amg]   AP nnz=%lld\n", (long long)AP->nnz);
         if (two && (rc = stream_order(aux, ctx)) != PADNE_OK) { if (AP) padne_csr_destroy(AP); amg->levels.push_back(L); break; }
+        if (with_w) {                       // after the join above: the main stream waits for R, not for W
+            const double c0 = 1.0 / (0.5 * (L.lambda + L.lambda / kChebRatio));      // level 0 keeps its Gershgorin bound: L.jac below
+            if (two && (rc = stream_order(ctx, aux)) != PADNE_OK) { amg->levels.push_back(L); break; }
+            if ((rc = build_w_operator(aux, A, L.P, ap_rows, ap_rows.n_slots, c0, &L.W)) != PADNE_OK) { amg->levels.push_back(L); break; }
+        }
         if (ap_rows.valid) {
             padne_csr ap_shape;
             ap_shape.n_rows = ap_rows.n_rows;
@@ -2223,6 +2324,13 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         pt.lap("R*(AP)");
         if (amg_verbose() && rc == PADNE_OK) fprintf(stderr, "[amg]   Ac: n=%lld nnz=%lld\n", (long long)Ac->n_rows, (long long)Ac->nnz);
         if (AP) padne_csr_destroy(AP);
+        if (with_w) {                       // the second stream may still be reading the slots: they go when it has been joined
+            std::swap(ap_keep.ctx, ap_rows.ctx);
+            std::swap(ap_keep.begin, ap_rows.begin);
+            std::swap(ap_keep.end, ap_rows.end);
+            std::swap(ap_keep.key, ap_rows.key);
+            std::swap(ap_keep.val, ap_rows.val);
+        }
         ap_rows.release();
         amg->levels.push_back(L);
         if (rc != PADNE_OK) break;
@@ -2854,6 +2962,13 @@ static int amg_apply_f32(padne_ctx *ctx, Amg *amg, const double *r, double *z, d
     for (int l = nl - 2; l >= 0; --l) {
         AmgLevel &L = amg->levels[l];
         float *b = (float *)L.b, *xa = (float *)L.xa;
+        if (l == 0 && L.W != nullptr && !amg->dist) {
+            // coarse correction + post-smoothing + exit in one product with W = P - c D^-1 A P (tmp still holds the
+            // residual of the pre-smoothed iterate that the down-leg restricted)
+            PADNE_TRY(launch_spmv_f32_wup_exit(ctx, L.W, (const float *)amg->levels[1].xb, z, r, partials_rz, done_flag, xa,
+                                               (const float *)L.tmp, L.A->dinv32, (float)L.jac, bb2));
+            continue;
+        }
         PADNE_TRY(launch_spmv_f32(ctx, L.P, SPMV_ADD, (const float *)amg->levels[l + 1].xb, xa, nullptr, done_flag,
                                   nullptr, nullptr, 0.f));
         if (amg->dist) PADNE_TRY(halo_exchange_plan_f32(ctx, L.halo, xa, done_flag));
@@ -2963,6 +3078,14 @@ bool amg_supports_batch8(const padne_csr *A0) {
 }
 
 // buffers of the single-precision entry stage, for callers that fuse it into their own kernel (false: double cycle)
+// number of per-workgroup r.z partials the last stage of the cycle writes (the grid of that launch)
+int amg_rz_partials(const padne_csr *A0) {
+    const Amg *amg = (const Amg *)A0->amg;
+    if (amg != nullptr && amg->f32 && !amg->dist && !amg->levels.empty() && amg->levels[0].W != nullptr)
+        return spmv_grid(amg->levels[0].W);
+    return spmv_grid(A0);
+}
+
 bool amg_f32_entry_args(const padne_csr *A0, float *jac, const float **dinv32, float **b32, float **xa32) {
     const Amg *amg = (const Amg *)A0->amg;
     if (amg == nullptr || !amg->f32 || amg->levels.size() < 2) return false;

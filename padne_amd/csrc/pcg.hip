@@ -350,6 +350,7 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0);
 int amg_apply(padne_ctx *ctx, const padne_csr *A0, const double *r, double *z, double *partials_rz,
               const int32_t *done_flag, const double *bb2 = nullptr, bool entry_done = false);
 bool amg_f32_entry_args(const padne_csr *A0, float *jac, const float **dinv32, float **b32, float **xa32);
+int amg_rz_partials(const padne_csr *A0);
 void amg_info(const padne_csr *A0, int *levels, double *complexity, double *setup_seconds, long long *coarse_n);
 const padne_csr *amg_level_matrix(const padne_csr *A0, int level, int which);
 
@@ -389,7 +390,7 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
     hipStream_t s = ctx->stream;
     const int gv = vec_grid(n);
     const int gs = spmv_grid(a);
-    const int P_rz = amg ? spmv_grid(prec) : gv;          // workgroups that emit r.z partials
+    const int P_rz = amg ? amg_rz_partials(prec) : gv;    // workgroups that emit r.z partials
     const int max_iter = o->max_iter > 0 ? o->max_iter : 100000;
     const int check_every = o->check_every > 0 ? o->check_every : (amg ? 4 : 50);
     const int sample_stride = amg ? 4 : 16;
@@ -718,7 +719,7 @@ static int solve_one_single_reduction(padne_ctx *ctx, const padne_csr *a, const 
     hipStream_t s = ctx->stream;
     const int gv = vec_grid(n);
     const int gs = spmv_grid(a);
-    const int P_rz = spmv_grid(prec);
+    const int P_rz = amg_rz_partials(prec);
     const int max_iter = o->max_iter > 0 ? o->max_iter : 100000;
     const int check_every = o->check_every > 0 ? o->check_every : 4;
     double *scal = ctx->scalars;

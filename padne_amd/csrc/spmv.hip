@@ -121,6 +121,8 @@ __device__ __forceinline__ XT xw_stream_tile(const VT *__restrict__ vals, const 
 //   SPMV_ADD     y += acc                                              (prolongation: x += P xc)
 //   SPMV_JACOBI  y = x[row] + scale * aux2[row] * (aux1[row] - acc)    (damped-Jacobi sweep, aux2 = 1/diag)
 //                optional partial sums of aux1[row] * y[row]           (r.z of the preconditioned CG)
+//   SPMV_WUP     y = aux0[row] + scale * aux2[row] * aux1[row] + acc   (coarse correction and post-smoothing in one
+//                product with W = P - c D^-1 A P, see amg.hip: aux0 = pre-smoothed iterate, aux1 = its residual)
 //
 // Scalar types: VT matrix values, XT the vectors x / aux1 / aux2 and the arithmetic, YT the output.  The solver's
 // own products are <double, double, double>; the multigrid cycle runs <float, float, float> (single-precision
@@ -135,8 +137,9 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
     const double *__restrict__ dot_with, double *__restrict__ partials,
     const int *__restrict__ done_flag, const XT *__restrict__ aux1,
     const XT *__restrict__ aux2, const XT scale, const double *__restrict__ out_scale2,
-    const int4 *__restrict__ xw_desc, const void *__restrict__ xw_lidx, const int xw_run) {
-    constexpr bool WITH_DOT = (MODE == SPMV_DOT) || (MODE == SPMV_DOT_AUX) || (MODE == SPMV_JACOBI);
+    const int4 *__restrict__ xw_desc, const void *__restrict__ xw_lidx, const int xw_run,
+    const XT *__restrict__ aux0) {
+    constexpr bool WITH_DOT = (MODE == SPMV_DOT) || (MODE == SPMV_DOT_AUX) || (MODE == SPMV_JACOBI) || (MODE == SPMV_WUP);
     __shared__ XT prod_all[4 * kWaveChunk];
     extern __shared__ unsigned char xs_dyn[];      // 4 * kXwRuns * xw_run entries of XT when the plan is in use
     XT *xs_all = reinterpret_cast<XT *>(xs_dyn);
@@ -241,6 +244,15 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
                 y[r] = (YT)(aux1[r] - acc);
             } else if (MODE == SPMV_ADD) {
                 y[r] += (YT)acc;
+            } else if (MODE == SPMV_WUP) {
+                const XT out = aux0[r] + scale * aux2[r] * aux1[r] + acc;
+                if (dot_with != nullptr) {
+                    const double outd = (double)out * out_mul;
+                    y[r] = (YT)outd;
+                    dot_acc += dot_with[r] * outd;
+                } else {
+                    y[r] = (YT)out;
+                }
             } else {
                 const XT b = aux1[r];
                 const XT out = x[r] + scale * aux2[r] * (b - acc);
@@ -342,11 +354,11 @@ int spmv_grid(const padne_csr *m) {
 template <typename VT, typename XT, typename YT>
 static int launch_spmv_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals, int mode, const XT *x, YT *y,
                              const double *dot_with, double *partials, const int32_t *done_flag, const XT *aux1,
-                             const XT *aux2, XT scale, const double *out_scale2) {
+                             const XT *aux2, XT scale, const double *out_scale2, const XT *aux0 = nullptr) {
     if (m->n_rows == 0) return PADNE_OK;
     const int n_tiles = (int)((m->n_rows + 63) / 64);   // wave-tiles of 64 rows
     const int g = spmv_grid(m);
-    if (use_wave_per_row(m)) {
+    if (use_wave_per_row(m) && mode != SPMV_WUP) {
 #define PADNE_SPMV_WPR(M)                                                                                           \
     hipLaunchKernelGGL((csr_spmv_wpr_kernel<M, VT, XT, YT>), dim3(g), dim3(kSpmvThreads), 0, ctx->stream,            \
                        (int)m->n_rows, m->rowptr, m->cols, vals, x, y, dot_with, partials, done_flag, aux1, aux2,    \
@@ -370,7 +382,7 @@ static int launch_spmv_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals,
 #define PADNE_SPMV_LAUNCH(M)                                                                                     \
     hipLaunchKernelGGL((csr_spmv_kernel<M, VT, XT, YT>), dim3(g), dim3(kSpmvThreads), xs_bytes, ctx->stream,      \
                        (int)m->n_rows, (int)m->n_cols, n_tiles, m->rowptr, m->cols, vals, x, y, dot_with,         \
-                       partials, done_flag, aux1, aux2, scale, out_scale2, xw_desc, xw_lidx, m->xw_run)
+                       partials, done_flag, aux1, aux2, scale, out_scale2, xw_desc, xw_lidx, m->xw_run, aux0)
     switch (mode) {
         case SPMV_PLAIN: PADNE_SPMV_LAUNCH(SPMV_PLAIN); break;
         case SPMV_DOT: PADNE_SPMV_LAUNCH(SPMV_DOT); break;
@@ -378,6 +390,7 @@ static int launch_spmv_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals,
         case SPMV_RESID: PADNE_SPMV_LAUNCH(SPMV_RESID); break;
         case SPMV_ADD: PADNE_SPMV_LAUNCH(SPMV_ADD); break;
         case SPMV_JACOBI: PADNE_SPMV_LAUNCH(SPMV_JACOBI); break;
+        case SPMV_WUP: PADNE_SPMV_LAUNCH(SPMV_WUP); break;
         default: set_error("bad SpMV mode %d", mode); return PADNE_E_INVALID;
     }
 #undef PADNE_SPMV_LAUNCH
@@ -408,6 +421,16 @@ int launch_spmv_f32_exit(padne_ctx *ctx, const padne_csr *m, const float *x, dou
     PADNE_REQUIRE(m->vals32 != nullptr && dot_with != nullptr, "single-precision exit stage");
     return launch_spmv_typed<float, float, double>(ctx, m, m->vals32, SPMV_JACOBI, x, y, dot_with, partials, done_flag,
                                                    aux1, aux2, scale, out_scale2);
+}
+
+// last stage of the single-precision cycle in the W form: z = (x_pre + c D^-1 r_pre + W e) * sqrt(*out_scale2) in double,
+// with partial sums of dot_with . z.  W carries single-precision values only (m->vals32).
+int launch_spmv_f32_wup_exit(padne_ctx *ctx, const padne_csr *w, const float *e, double *z, const double *dot_with,
+                             double *partials, const int32_t *done_flag, const float *x_pre, const float *r_pre,
+                             const float *dinv32, float scale, const double *out_scale2) {
+    PADNE_REQUIRE(w->vals32 != nullptr && dot_with != nullptr, "single-precision W stage");
+    return launch_spmv_typed<float, float, double>(ctx, w, w->vals32, SPMV_WUP, e, z, dot_with, partials, done_flag, r_pre,
+                                                   dinv32, scale, out_scale2, x_pre);
 }
 
 // ---- x-window plan -------------------------------------------------------------------------------------

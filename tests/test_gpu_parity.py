@@ -355,6 +355,38 @@ def test_multigrid_hierarchy_is_galerkin_and_partition_of_unity(ctx):
         assert P.shape[1] < 0.5 * P.shape[0]
 
 
+def test_fused_up_leg_of_the_fine_level_is_the_same_cycle(ctx, monkeypatch):
+    """Level 0 of the float cycle applies coarse correction, post-smoothing sweep and the exit product of r.z in ONE
+    sparse product with W = P - c D^-1 A P (built from the merge slots of A P on the second stream).  Algebraically the
+    same V(1,1) cycle as prolongation + damped Jacobi: same iteration count (one either way for float rounding), same
+    potentials to the solve tolerance, against PADNE_AMG_NO_W=1 on the same matrix."""
+    sysm = synthetic.layered_system(3, 260, 200, via_lattice=5)
+    els = [("R", int(a), int(b), float(r)) for a, b, r in zip(*sysm.resistors)]
+    els += [("I", int(f), int(t), float(i)) for f, t, i in zip(*sysm.current_sources)]
+    Lo, ro = O.assemble_system([(m[0], m[1], m[2]) for m in sysm.meshes], 0, els, 0)
+    n = sysm.n_vertices
+    A = (-Lo[1:n, 1:n]).tocsr()
+    A.sort_indices()
+    b = -ro[1:n]
+    assert A.shape[0] >= 65536
+
+    def run():
+        d = ctx.csr_from_scipy(A)
+        res = d.solve_spd(b, precond="amg", rtol=1e-12)
+        d.close()
+        return res
+    with_w = run()
+    monkeypatch.setenv("PADNE_AMG_NO_W", "1")
+    without = run()
+    assert with_w.precond_fallbacks == 0 and without.precond_fallbacks == 0
+    assert with_w.levels == without.levels >= 3
+    assert abs(with_w.iterations - without.iterations) <= 1
+    scale = np.abs(without.x).max()
+    assert np.abs(with_w.x - without.x).max() <= 1e-9 * scale
+    for res in (with_w, without):
+        assert np.linalg.norm(A @ res.x - b) <= 1e-11 * np.linalg.norm(b)
+
+
 @pytest.mark.parametrize("hub", [False, True])
 def test_windowed_setup_kernels_build_the_same_hierarchy(ctx, monkeypatch, hub):
     """A fine level with an x-window plan (>= 65536 rows, band matrix) takes the windowed setup kernels: one-byte
