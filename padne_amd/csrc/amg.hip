@@ -470,24 +470,38 @@ __global__ __launch_bounds__(256) void mis_collect_open(int n, const signed char
 
 // (the list length is read on the device: several rounds are enqueued per host synchronisation, on a grid sized by the
 // last length the host has seen; lists only shrink)
+// Eight lanes per list entry: lane q walks the neighbours q, q + 8, ... (each one's row serially) and the eight maxima are
+// folded by shuffles -- the chain of dependent loads of one thread per entry (row x row of them, hundreds next to a hub
+// row of a coarse level) was what the short lists of the late rounds waited for.
+constexpr int kHopLanes = 8;
 __global__ void mis_two_hop_max(const int *__restrict__ cnt_ptr, const int *__restrict__ list, const int *__restrict__ srow,
                                 const int *__restrict__ scol, const unsigned int *__restrict__ word,
                                 unsigned int *__restrict__ m2) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= *cnt_ptr) return;
-    const int i = list[t];
-    unsigned int m = word[i];
-    for (int a = srow[i]; a < srow[i + 1]; ++a) {
-        const int j = scol[a];
-        if (j == i) continue;
-        const unsigned int wj = word[j];
-        m = wj > m ? wj : m;
-        for (int b = srow[j]; b < srow[j + 1]; ++b) {
-            const unsigned int wk = word[scol[b]];
-            m = wk > m ? wk : m;
+    const int t = (blockIdx.x * blockDim.x + threadIdx.x) / kHopLanes;
+    const int q = threadIdx.x & (kHopLanes - 1);
+    const bool live = t < *cnt_ptr;
+    unsigned int m = 0u;
+    if (live) {
+        const int i = list[t];
+        m = word[i];
+        const int a1 = srow[i + 1];
+        for (int a = srow[i] + q; a < a1; a += kHopLanes) {
+            const int j = scol[a];
+            if (j == i) continue;
+            const unsigned int wj = word[j];
+            m = wj > m ? wj : m;
+            for (int b = srow[j]; b < srow[j + 1]; ++b) {
+                const unsigned int wk = word[scol[b]];
+                m = wk > m ? wk : m;
+            }
         }
     }
-    m2[t] = m;
+#pragma unroll
+    for (int d = 1; d < kHopLanes; d <<= 1) {
+        const unsigned int o = (unsigned int)__shfl_xor((int)m, d, 64);
+        m = o > m ? o : m;
+    }
+    if (live && q == 0) m2[t] = m;
 }
 
 __global__ void mis_decide_list(const int *__restrict__ cnt_ptr, const int *__restrict__ list, const unsigned int *__restrict__ m2,
@@ -1342,9 +1356,64 @@ __global__ __launch_bounds__(256) void abs_range_kernel(long long n, const doubl
     }
 }
 
+// smallest of mins, largest of maxs (NaN if any is NaN), by one workgroup: 16 bytes for the host
+__global__ __launch_bounds__(256) void fold_range_kernel(const double *__restrict__ mins, const double *__restrict__ maxs, int g,
+                                                         double *__restrict__ out2) {
+    __shared__ double lo_s[256], hi_s[256];
+    double lo = 1e300, hi = 0.0;
+    for (int q = threadIdx.x; q < g; q += 256) {
+        const double a = mins[q], b = maxs[q];
+        lo = a < lo ? a : lo;
+        if (b > hi || !(b == b)) hi = b;
+    }
+    lo_s[threadIdx.x] = lo;
+    hi_s[threadIdx.x] = hi;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            const double a = lo_s[threadIdx.x + off], b = hi_s[threadIdx.x + off];
+            if (a < lo_s[threadIdx.x]) lo_s[threadIdx.x] = a;
+            if (!(hi_s[threadIdx.x] == hi_s[threadIdx.x])) {
+            } else if (b > hi_s[threadIdx.x] || !(b == b)) {
+                hi_s[threadIdx.x] = b;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out2[0] = lo_s[0];
+        out2[1] = hi_s[0];
+    }
+}
+
 // ---- host side ----------------------------------------------------------------------------------
 
 static bool amg_verbose();
+
+// maxima of up to two arrays of non-negative partial results, by one workgroup (so that 16 bytes go to the host)
+__global__ __launch_bounds__(256) void fold_max2_kernel(const double *__restrict__ a, const double *__restrict__ b, int g,
+                                                        double *__restrict__ out2) {
+    __shared__ double red[2][256];
+    double ma = 0.0, mb = 0.0;
+    for (int q = threadIdx.x; q < g; q += 256) {
+        ma = a[q] > ma ? a[q] : ma;
+        if (b != nullptr) mb = b[q] > mb ? b[q] : mb;
+    }
+    red[0][threadIdx.x] = ma;
+    red[1][threadIdx.x] = mb;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            red[0][threadIdx.x] = fmax(red[0][threadIdx.x], red[0][threadIdx.x + off]);
+            red[1][threadIdx.x] = fmax(red[1][threadIdx.x], red[1][threadIdx.x + off]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out2[0] = red[0][0];
+        out2[1] = red[1][0];
+    }
+}
 
 static int gershgorin(padne_ctx *ctx, const padne_csr *A, double *lambda, bool filtered = false) {
     const int g = (int)std::min<long long>((A->n_rows + 255) / 256, 1024);
@@ -1355,12 +1424,12 @@ static int gershgorin(padne_ctx *ctx, const padne_csr *A, double *lambda, bool f
     else
         hipLaunchKernelGGL(gershgorin_kernel, dim3(g > 0 ? g : 1), dim3(256), 0, ctx->stream, (int)A->n_rows, A->rowptr,
                            A->vals, A->dinv, part);
+    hipLaunchKernelGGL(fold_max2_kernel, dim3(1), dim3(256), 0, ctx->stream, (const double *)part, (const double *)nullptr,
+                       g > 0 ? g : 1, part + kMaxPartials - 2);
     PADNE_HIP_CHECK(hipGetLastError());
-    std::vector<double> h((size_t)(g > 0 ? g : 1));
-    PADNE_HIP_CHECK(hipMemcpyAsync(h.data(), part, sizeof(double) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
-    PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    double m = 0.0;
-    for (double v : h) m = v > m ? v : m;
+    double h[2] = {0.0, 0.0};
+    PADNE_TRY(read_back(ctx, part + kMaxPartials - 2, sizeof(h), h));
+    double m = h[0];
     if (!(m > 0.0) || !(m < 1e6)) m = 2.0;
     *lambda = m;
     return PADNE_OK;
@@ -1395,10 +1464,10 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
     PADNE_TRY(sc.alloc(&scol, (size_t)(A->nnz > 0 ? A->nnz : 1)));
     const int n_wt = (n + 63) / 64;
     const dim3 gm((unsigned)std::min(2048, (n_wt + 3) / 4 > 0 ? (n_wt + 3) / 4 : 1));
-    // lambda_f: the Gershgorin bound of the filtered operator comes out of the same pass (read back with the first
-    // open count below: no synchronisation of its own)
+    // lambda_f: the Gershgorin bound of the filtered operator comes out of the same pass
     double *bound_part = lambda_f != nullptr ? ctx->partials + 6 * kMaxPartials : nullptr;
-    std::vector<double> h_bound(lambda_f != nullptr ? (size_t)kMaxPartials + gm.x : 0);     // filtered | plain
+    double *bound2 = nullptr;            // their maxima: filtered | plain
+    if (lambda_f != nullptr) PADNE_TRY(sc.alloc(&bound2, 2));
     // x-window plan of A (fine-level band matrices): one byte per entry and LDS-staged neighbours in the rounds below
     const bool xw = A->xw_state == 1 && A->xw_run <= 85 && getenv("PADNE_AMG_NO_XW") == nullptr;
     unsigned char *spos = nullptr;
@@ -1424,7 +1493,16 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
         }
     };
     if (lambda_f != nullptr)
-        PADNE_HIP_CHECK(hipMemcpyAsync(h_bound.data(), bound_part, sizeof(double) * h_bound.size(), hipMemcpyDeviceToHost, s));
+        hipLaunchKernelGGL(fold_max2_kernel, dim3(1), dim3(256), 0, s, (const double *)bound_part,
+                           (const double *)(bound_part + kMaxPartials), (int)gm.x, bound2);
+    // the two bounds travel to the host with the first open count
+    double h_bound2[2] = {0.0, 0.0};
+    bool bound_pending = lambda_f != nullptr;
+    auto count_back = [&](const int *dev_count, int *host_count) -> int {
+        if (!bound_pending) return read_back(ctx, dev_count, sizeof(int), host_count);
+        bound_pending = false;
+        return read_back2(ctx, dev_count, sizeof(int), host_count, bound2, sizeof(h_bound2), h_bound2);
+    };
     hipLaunchKernelGGL(mis_init_words, g, b, 0, s, n, w0);
     int open_count = n;
     int round = 0;
@@ -1439,8 +1517,7 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
             launch_round(counter + round);
         }
         PADNE_HIP_CHECK(hipGetLastError());
-        PADNE_HIP_CHECK(hipMemcpyAsync(&open_count, counter + round - 1, sizeof(int), hipMemcpyDeviceToHost, s));
-        PADNE_HIP_CHECK(hipStreamSynchronize(s));
+        PADNE_TRY(count_back(counter + round - 1, &open_count));
     }
     if (open_count > 0) {
         // compact rounds; the word buffers of the full passes are free now and serve as the two lists (w1, w2 hold
@@ -1457,25 +1534,20 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
             const dim3 gl(nblk(cnt));
             const int batch = cnt > 200000 ? 1 : 3;
             for (int rep = 0; rep < batch && cur + 1 < kMaxRounds; ++rep, ++round) {
-                hipLaunchKernelGGL(mis_two_hop_max, gl, b, 0, s, counters + cur, list_a, srow, scol, w0, m2);
+                hipLaunchKernelGGL(mis_two_hop_max, dim3(nblk((long long)cnt * kHopLanes)), b, 0, s, counters + cur, list_a, srow, scol, w0, m2);
                 hipLaunchKernelGGL(mis_decide_list, gl, b, 0, s, counters + cur, list_a, m2, w0, state, list_b, counters + cur + 1);
                 std::swap(list_a, list_b);
                 ++cur;
             }
             PADNE_HIP_CHECK(hipGetLastError());
-            PADNE_HIP_CHECK(hipMemcpyAsync(&cnt, counters + cur, sizeof(int), hipMemcpyDeviceToHost, s));
-            PADNE_HIP_CHECK(hipStreamSynchronize(s));
+            PADNE_TRY(count_back(counters + cur, &cnt));
         }
         open_count = cnt;
     }
     PADNE_REQUIRE(open_count == 0, "independent-set rounds did not terminate");
     if (lambda_f != nullptr) {
-        if (round == 0) PADNE_HIP_CHECK(hipStreamSynchronize(s));       // no round ran (n == 0): the copy above is still in flight
-        double m = 0.0, mp = 0.0;
-        for (unsigned q = 0; q < gm.x; ++q) {
-            m = h_bound[q] > m ? h_bound[q] : m;
-            mp = h_bound[(size_t)kMaxPartials + q] > mp ? h_bound[(size_t)kMaxPartials + q] : mp;
-        }
+        if (bound_pending) PADNE_TRY(read_back(ctx, bound2, sizeof(h_bound2), h_bound2));      // no round ran (n == 0)
+        double m = h_bound2[0], mp = h_bound2[1];
         if (!(m > 0.0) || !(m < 1e6)) m = 2.0;                           // as gershgorin()
         if (!(mp > 0.0) || !(mp < 1e6)) mp = 2.0;
         *lambda_f = m;
@@ -1683,8 +1755,8 @@ __global__ __launch_bounds__(256) void prolong_rows_xw(int n, int n_wtiles, cons
         const int k0 = __shfl(rs, 0, 64);
         const int k1 = __shfl(re, row1 - row0 - 1, 64);
         const bool too_long = re - rs > kPxSlots - 1;
-        if (__any(too_long)) {                                // wave-uniform
-            if (!FILL && lane == 0) atomicExch(gave_up, 1);
+        if (__any(too_long)) {                                // wave-uniform; the scan of the lengths reports the -1 to the host
+            if (!FILL && r < row1) row_len[r] = -1;
             continue;
         }
         const bool windowed = d.w != 0 && k1 - k0 <= kPxChunk;
@@ -1735,21 +1807,16 @@ static int build_prolongator(padne_ctx *ctx, const padne_csr *A, const int *agg,
         int *row_len = nullptr, *rowptr_tmp = nullptr, *gave_up = nullptr;
         PADNE_TRY(sc.alloc(&row_len, (size_t)n + 1));
         PADNE_TRY(sc.alloc(&rowptr_tmp, (size_t)n + 1));
-        PADNE_TRY(sc.alloc(&gave_up, 1));
-        PADNE_HIP_CHECK(hipMemsetAsync(gave_up, 0, sizeof(int), s));
         const int n_wt = (n + 63) / 64;
         const dim3 g((unsigned)std::min((n_wt + 3) / 4, 8192)), b(256);
         hipLaunchKernelGGL(prolong_rows_xw<false>, g, b, 0, s, n, n_wt, A->rowptr, A->cols, A->vals, A->dinv, scol,
                            (const unsigned char *)A->xw_lidx, spos, A->xw_desc, A->xw_run, omega, agg, row_len,
                            (const int *)nullptr, (int *)nullptr, (double *)nullptr, gave_up);
         PADNE_HIP_CHECK(hipGetLastError());
-        int h_gave_up = 0;
-        PADNE_HIP_CHECK(hipMemcpyAsync(&h_gave_up, gave_up, sizeof(int), hipMemcpyDeviceToHost, s));
         int64_t nnz = 0;
-        // (the scan synchronises: the flag is on the host afterwards; its result is only used if nobody gave up)
-        const int rc_scan = exclusive_scan_i32(ctx, row_len, rowptr_tmp, n, &nnz);
-        if (h_gave_up == 0) {
-            PADNE_TRY(rc_scan);
+        bool h_gave_up = false;          // a row that gave up left the length -1
+        PADNE_TRY(exclusive_scan_i32_flagged(ctx, row_len, rowptr_tmp, n, &nnz, &h_gave_up));
+        if (!h_gave_up) {
             padne_csr *m = nullptr;
             PADNE_TRY(csr_alloc(ctx, n, n_agg, nnz, &m));
             PADNE_HIP_CHECK(hipMemcpyAsync(m->rowptr, rowptr_tmp, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyDeviceToDevice, s));
@@ -1778,8 +1845,7 @@ static int build_prolongator(padne_ctx *ctx, const padne_csr *A, const int *agg,
     hipLaunchKernelGGL(prolong_redo_flag, dim3(nblk(n)), dim3(256), 0, s, n, row_len, any);
     PADNE_HIP_CHECK(hipGetLastError());
     int h_any = 0;
-    PADNE_HIP_CHECK(hipMemcpyAsync(&h_any, any, sizeof(int), hipMemcpyDeviceToHost, s));
-    PADNE_HIP_CHECK(hipStreamSynchronize(s));
+    PADNE_TRY(read_back(ctx, any, sizeof(int), &h_any));
     if (h_any) {
         // rare (rows touching more than 24 aggregates): redo everything through the slot + merge path
         hipLaunchKernelGGL(prolong_fill, dim3(nblk((long long)n + 1)), dim3(256), 0, s, n, A->rowptr, A->cols, A->vals,
@@ -2078,8 +2144,7 @@ static int dense_inverse(padne_ctx *ctx, const padne_csr *A, double **inv_out) {
             std::swap(src, dst);
         }
     }
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    const hipError_t e = hipGetLastError();      // (no synchronisation: the scratch goes back to the stream-ordered pool)
     if (e != hipSuccess) {
         pool_free(ctx, inv);
         set_error("coarse inverse failed: %s", hipGetErrorString(e));
@@ -2157,15 +2222,11 @@ static int f32_range(padne_ctx *ctx, const padne_csr *A0, double *lo_out, double
     hipLaunchKernelGGL(abs_range_kernel, dim3(g), dim3(256), 0, s, (long long)A0->n_rows, (const double *)A0->dinv, mins,
                        maxs);
     PADNE_HIP_CHECK(hipGetLastError());
-    std::vector<double> h((size_t)2 * g);
-    PADNE_HIP_CHECK(hipMemcpyAsync(h.data(), mins, sizeof(double) * (size_t)g, hipMemcpyDeviceToHost, s));
-    PADNE_HIP_CHECK(hipMemcpyAsync(h.data() + g, maxs, sizeof(double) * (size_t)g, hipMemcpyDeviceToHost, s));
-    PADNE_HIP_CHECK(hipStreamSynchronize(s));
-    double lo = 1e300, hi = 0.0;
-    for (int i = 0; i < g; ++i) {
-        lo = std::min(lo, h[(size_t)i]);
-        if (h[(size_t)g + i] > hi || !(h[(size_t)g + i] == h[(size_t)g + i])) hi = h[(size_t)g + i];
-    }
+    hipLaunchKernelGGL(fold_range_kernel, dim3(1), dim3(256), 0, s, (const double *)mins, (const double *)maxs, g, mins + g);
+    PADNE_HIP_CHECK(hipGetLastError());
+    double h[2] = {0.0, 0.0};
+    PADNE_TRY(read_back(ctx, mins + g, sizeof(h), h));
+    const double lo = h[0], hi = h[1];
     *lo_out = lo;
     *hi_out = hi;
     return PADNE_OK;

@@ -60,10 +60,14 @@ __device__ __forceinline__ int block_exclusive_scan_256(int v, int *lds /*[5]*/,
     return wave_off + inc - v;
 }
 
-// per-chunk sums in 64 bits (the counts may be saturated upper bounds) + a flag for negative inputs
+// per-chunk sums in 64 bits (the counts may be saturated upper bounds); a chunk with a negative input leaves a marker
+constexpr long long kScanNegative = (long long)0x8000000000000000ull;
 __global__ __launch_bounds__(256) void scan_block_sums(const int *__restrict__ in, long long n,
-                                                       long long *__restrict__ block_sums, long long *__restrict__ flags) {
+                                                       long long *__restrict__ block_sums) {
     __shared__ long long red[4];
+    __shared__ int any_neg;
+    if (threadIdx.x == 0) any_neg = 0;
+    __syncthreads();
     const long long base = (long long)blockIdx.x * kScanChunk + (long long)threadIdx.x * kScanItems;
     long long s = 0;
     bool neg = false;
@@ -75,19 +79,31 @@ __global__ __launch_bounds__(256) void scan_block_sums(const int *__restrict__ i
         }
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    if (neg) atomicExch((unsigned long long *)flags, 1ull);
+    if (neg) any_neg = 1;
     __syncthreads();
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = any_neg ? kScanNegative : (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// exclusive scan of the chunk sums by one workgroup: every thread takes a contiguous piece
-__global__ __launch_bounds__(256) void scan_block_offsets(long long *block_sums, int nb, long long *total_out) {
+// exclusive scan of the chunk sums by one workgroup: every thread takes a contiguous piece.  total_out[0] = the exact
+// total, [1] = 1 if some input was negative; both are also posted to the host's mailbox slot when there is one (the
+// host needs nothing else from the scan and does not wait for scan_apply).
+__global__ __launch_bounds__(256) void scan_block_offsets(long long *block_sums, int nb, long long *total_out,
+                                                          unsigned long long *mail_slot, unsigned long long mail_seq) {
     __shared__ long long piece[256];
+    __shared__ int any_neg;
+    if (threadIdx.x == 0) any_neg = 0;
+    __syncthreads();
     const int per = (nb + 255) / 256;
     const int b0 = threadIdx.x * per, b1 = min(b0 + per, nb);
     long long s = 0;
-    for (int i = b0; i < b1; ++i) s += block_sums[i];
+    bool neg = false;
+    for (int i = b0; i < b1; ++i) {
+        const long long v = block_sums[i];
+        neg |= v == kScanNegative;
+        s += v == kScanNegative ? 0 : v;
+    }
     piece[threadIdx.x] = s;
+    if (neg) any_neg = 1;
     __syncthreads();
     if (threadIdx.x == 0) {
         long long run = 0;
@@ -96,14 +112,19 @@ __global__ __launch_bounds__(256) void scan_block_offsets(long long *block_sums,
             piece[t] = run;
             run += v;
         }
-        *total_out = run;
+        total_out[0] = run;
+        total_out[1] = any_neg;
+        if (mail_slot != nullptr) {
+            const unsigned long long w[2] = {(unsigned long long)run, (unsigned long long)any_neg};
+            mail_post(mail_slot, mail_seq, w, 2);
+        }
     }
     __syncthreads();
     long long run = piece[threadIdx.x];
     for (int i = b0; i < b1; ++i) {
         const long long v = block_sums[i];
         block_sums[i] = run;
-        run += v;
+        run += v == kScanNegative ? 0 : v;
     }
 }
 
@@ -128,28 +149,48 @@ __global__ __launch_bounds__(256) void scan_apply(const int *__restrict__ in, lo
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = (int)(*total);
 }
 
-int exclusive_scan_i32(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t n, int64_t *total) {
+// want_total: the host waits for the total (mailbox slot, or memcpy + synchronise without one)
+static int scan_i32_impl(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t n, long long h[2], bool want_total) {
     const int nb = (int)((n + kScanChunk - 1) / kScanChunk);
+    hipStream_t s = ctx->stream;
+    if (nb == 0) {
+        h[0] = h[1] = 0;
+        const hipError_t e = hipMemsetAsync(out, 0, sizeof(int32_t), s);
+        if (e != hipSuccess) {
+            set_error("scan failed: %s", hipGetErrorString(e));
+            return PADNE_E_HIP;
+        }
+        return PADNE_OK;
+    }
     long long *bs = (long long *)pool_alloc(ctx, sizeof(long long) * (size_t)(nb + 2));
     if (bs == nullptr) return PADNE_E_NOMEM;
     long long *tot = bs + nb;          // [0] exact 64-bit total, [1] negative-input flag
-    hipError_t e = hipMemsetAsync(tot, 0, 2 * sizeof(long long), ctx->stream);
-    if (e == hipSuccess && nb > 0) {
-        hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(256), 0, ctx->stream, in, (long long)n, bs, tot + 1);
-        hipLaunchKernelGGL(scan_block_offsets, dim3(1), dim3(256), 0, ctx->stream, bs, nb, tot);
-        // a total beyond int32 makes the 32-bit offsets below meaningless: it is detected from the 64-bit total
-        hipLaunchKernelGGL(scan_apply, dim3(nb), dim3(256), 0, ctx->stream, in, (long long)n, bs, tot, out);
-        e = hipGetLastError();
+    const MailTicket ticket = want_total ? mail_ticket(ctx) : MailTicket();
+    hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(256), 0, s, in, (long long)n, bs);
+    hipLaunchKernelGGL(scan_block_offsets, dim3(1), dim3(256), 0, s, bs, nb, tot, ticket.slot_dev, ticket.seq);
+    // a total beyond int32 makes the 32-bit offsets below meaningless: it is detected from the 64-bit total
+    hipLaunchKernelGGL(scan_apply, dim3(nb), dim3(256), 0, s, in, (long long)n, bs, tot, out);
+    hipError_t e = hipGetLastError();
+    int rc = PADNE_OK;
+    if (e == hipSuccess && want_total) {
+        if (ticket.slot_dev != nullptr) {
+            rc = mail_wait(ctx, ticket, h, 2 * sizeof(long long));
+        } else {
+            e = hipMemcpyAsync(h, tot, 2 * sizeof(long long), hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+        }
     }
-    long long h[2] = {0, 0};
-    if (e == hipSuccess) e = hipMemcpyAsync(h, tot, 2 * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess && nb == 0) e = hipMemsetAsync(out, 0, sizeof(int32_t), ctx->stream);
-    pool_free(ctx, bs);
+    pool_free(ctx, bs);      // reuse is ordered on the context's stream
     if (e != hipSuccess) {
         set_error("scan failed: %s", hipGetErrorString(e));
         return PADNE_E_HIP;
     }
+    return rc;
+}
+
+int exclusive_scan_i32(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t n, int64_t *total) {
+    long long h[2] = {0, 0};
+    PADNE_TRY(scan_i32_impl(ctx, in, out, n, h, true));
     if (h[0] < 0 || h[1] != 0) {
         set_error("scan of negative counts");
         return PADNE_E_INVALID;
@@ -165,22 +206,18 @@ int exclusive_scan_i32(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t 
 }
 
 int exclusive_scan_i32_async(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t n) {
-    const int nb = (int)((n + kScanChunk - 1) / kScanChunk);
-    long long *bs = (long long *)pool_alloc(ctx, sizeof(long long) * (size_t)(nb + 2));
-    if (bs == nullptr) return PADNE_E_NOMEM;
-    long long *tot = bs + nb;
-    hipError_t e = hipMemsetAsync(tot, 0, 2 * sizeof(long long), ctx->stream);
-    if (e == hipSuccess && nb > 0) {
-        hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(256), 0, ctx->stream, in, (long long)n, bs, tot + 1);
-        hipLaunchKernelGGL(scan_block_offsets, dim3(1), dim3(256), 0, ctx->stream, bs, nb, tot);
-        hipLaunchKernelGGL(scan_apply, dim3(nb), dim3(256), 0, ctx->stream, in, (long long)n, bs, tot, out);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess && nb == 0) e = hipMemsetAsync(out, 0, sizeof(int32_t), ctx->stream);
-    pool_free(ctx, bs);      // reuse is ordered on the context's stream
-    if (e != hipSuccess) {
-        set_error("scan failed: %s", hipGetErrorString(e));
-        return PADNE_E_HIP;
+    long long h[2] = {0, 0};
+    return scan_i32_impl(ctx, in, out, n, h, false);
+}
+
+int exclusive_scan_i32_flagged(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t n, int64_t *total, bool *negative) {
+    long long h[2] = {0, 0};
+    PADNE_TRY(scan_i32_impl(ctx, in, out, n, h, true));
+    *negative = h[1] != 0;
+    *total = h[0];
+    if (!*negative && h[0] >= 2147483647LL) {
+        set_error("%lld entries exceed the 32-bit index space", h[0]);
+        return PADNE_E_TOOLARGE;
     }
     return PADNE_OK;
 }
@@ -1036,15 +1073,13 @@ static int finish_rows(padne_ctx *ctx, Scratch &sc, long long n_rows, long long 
                            d_voff, d_sigma, slot_ptr, key, val, row_len, d_err, 0, row_list);
         PADNE_HIP_CHECK(hipGetLastError());
         int h_long[ERR_WORDS];
-        PADNE_HIP_CHECK(hipMemcpyAsync(h_long, d_err, sizeof(h_long), hipMemcpyDeviceToHost, s));
-        PADNE_HIP_CHECK(hipStreamSynchronize(s));
+        PADNE_TRY(read_back(ctx, d_err, sizeof(h_long), h_long));
         if (h_long[ERR_LONG_ROWS]) {
             PADNE_HIP_CHECK(hipMemsetAsync(d_err + ERR_LONG_ROWS, 0, sizeof(int), s));
             hipLaunchKernelGGL(merge_rows_mesh_lds<kCap>, dim3(nblk(n_merge, 128)), dim3(128), 0, s, n_merge, n_vert, n_mesh,
                                d_voff, d_sigma, slot_ptr, key, val, row_len, d_err, kCapSmall, row_list);
             PADNE_HIP_CHECK(hipGetLastError());
-            PADNE_HIP_CHECK(hipMemcpyAsync(h_long, d_err, sizeof(h_long), hipMemcpyDeviceToHost, s));
-            PADNE_HIP_CHECK(hipStreamSynchronize(s));
+            PADNE_TRY(read_back(ctx, d_err, sizeof(h_long), h_long));
         }
         if (h_long[ERR_LONG_ROWS]) {               // rows with more than kCap slots (hubs): wave sort, then the global-memory merge
             hipLaunchKernelGGL(sort_long_rows_wave<kWaveSortCap>, dim3(std::min(nblk(n_merge, 256), 2048u)), dim3(256), 0, s, n_merge,
@@ -1057,8 +1092,7 @@ static int finish_rows(padne_ctx *ctx, Scratch &sc, long long n_rows, long long 
         PADNE_TRY(merge_slots_generic(ctx, n_rows, slot_ptr, key, val, row_len));
     }
     int h_err[ERR_WORDS];
-    PADNE_HIP_CHECK(hipMemcpyAsync(h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
-    PADNE_HIP_CHECK(hipStreamSynchronize(s));
+    PADNE_TRY(read_back(ctx, d_err, sizeof(h_err), h_err));
     if (h_err[ERR_NONMANIFOLD] && !t_partial_mesh) {
         set_error("Non-manifold mesh");
         return PADNE_E_NONMANIFOLD;
@@ -1285,8 +1319,7 @@ extern "C" int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns, int64_t
                        d_ninc, d_ncoo, d_cnt);
     PADNE_HIP_CHECK(hipGetLastError());
     int h_err[ERR_WORDS];
-    PADNE_HIP_CHECK(hipMemcpyAsync(h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
-    PADNE_HIP_CHECK(hipStreamSynchronize(s));
+    PADNE_TRY(read_back(ctx, d_err, sizeof(h_err), h_err));
     if (h_err[ERR_BAD_INDEX]) {
         set_error("triangle refers to a vertex outside its mesh, or repeats a vertex");
         return PADNE_E_INVALID;
@@ -1308,8 +1341,7 @@ extern "C" int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns, int64_t
                            d_rowlen, d_list, d_nslow);
     PADNE_HIP_CHECK(hipGetLastError());
     int h_slow = 0;
-    PADNE_HIP_CHECK(hipMemcpyAsync(&h_slow, d_nslow, sizeof(int), hipMemcpyDeviceToHost, s));
-    PADNE_HIP_CHECK(hipStreamSynchronize(s));
+    PADNE_TRY(read_back(ctx, d_nslow, sizeof(int), &h_slow));
     // 4 the listed rows through the slots (cursor = 1: slot 0 of each row is the diagonal placeholder)
     if (h_slow > 0) {
         hipLaunchKernelGGL(fill_value_i32, dim3(nblk(n_unknowns + 1)), dim3(256), 0, s, d_cnt, (long long)n_unknowns + 1, 1);
@@ -1406,8 +1438,7 @@ static int csr_relabel(padne_ctx *ctx, const padne_csr *m, const int32_t *row_ma
         PADNE_HIP_CHECK(hipGetLastError());
         int h_flags[2] = {0, 0};
         static_assert(ERR_LONG_ROWS + 1 < ERR_WORDS, "two flag words");
-        PADNE_HIP_CHECK(hipMemcpyAsync(h_flags, d_err + ERR_LONG_ROWS, sizeof(h_flags), hipMemcpyDeviceToHost, s));
-        PADNE_HIP_CHECK(hipStreamSynchronize(s));
+        PADNE_TRY(read_back(ctx, d_err + ERR_LONG_ROWS, sizeof(h_flags), h_flags));
         if (h_flags[1]) {
             set_error("invalid argument: index map entry out of range");
             return PADNE_E_INVALID;

@@ -105,6 +105,9 @@ struct padne_ctx {
     padne_ctx *aux = nullptr, *parent = nullptr;
     bool is_aux = false;
     unsigned pinned_next = 0;        // round-robin over the 512-byte slots of `pinned` (second stream only)
+    // mailbox: a page of host-coherent memory the device posts small results into (read_back / mail_ticket)
+    unsigned long long *mailbox = nullptr, *mailbox_dev = nullptr;
+    unsigned long long mail_seq = 0;
     hipEvent_t ev_order = nullptr;
     // caching device allocator (see pool_alloc): hipMalloc/hipFree of GB-sized blocks cost up to hundreds of
     // milliseconds, which would dominate the multigrid setup that runs inside every solve
@@ -156,8 +159,29 @@ int interleave8(padne_ctx *ctx, long long n, const double *src, double *dst, boo
 
 // exclusive scan of int32 counts into int32 offsets (n+1 outputs); returns total via host
 int exclusive_scan_i32(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t n, int64_t *total);
+// Small results the host has to see before it can go on (counts that size the next allocation, flags that choose the
+// next kernel).  hipMemcpyAsync to pageable memory + hipStreamSynchronize costs ~28 us of idle GPU per round trip and the
+// multigrid setup makes ~75 of them: instead the device stores the words into a host-coherent page (one 64-byte slot per
+// request: sequence number + up to 56 bytes) and the host polls the sequence number.  mail_ticket hands a kernel the slot
+// to post to (mail_post, from one thread, after the data is final); read_back queues a one-wave kernel that posts a
+// device buffer.  PADNE_NO_MAILBOX=1: memcpy + synchronise as before.
+struct MailTicket {
+    unsigned long long *slot_host = nullptr, *slot_dev = nullptr;   // slot_dev == nullptr: the mailbox is off
+    unsigned long long seq = 0;
+};
+MailTicket mail_ticket(padne_ctx *ctx);
+int mail_wait(padne_ctx *ctx, const MailTicket &t, void *out, size_t bytes);
+int read_back(padne_ctx *ctx, const void *dev, size_t bytes, void *host_out);
+int read_back2(padne_ctx *ctx, const void *dev, size_t bytes, void *host_out, const void *dev2, size_t bytes2, void *host_out2);
+__device__ __forceinline__ void mail_post(unsigned long long *slot, unsigned long long seq, const unsigned long long *words, int n_words) {
+    for (int k = 0; k < n_words; ++k) __hip_atomic_store(slot + 1 + k, words[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(slot, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // the same without reading the total back (no host synchronisation; the caller knows the total fits 32 bits)
 int exclusive_scan_i32_async(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t n);
+// negative inputs are a message from the producer (a row that asks for another path), not an error: reported, and the
+// offsets are meaningless then
+int exclusive_scan_i32_flagged(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t n, int64_t *total, bool *negative);
 
 // The context's second stream, as a context of its own (created on first use, destroyed with its parent).
 // Memory first touched on that stream must come from ITS pool: a block of the parent's pool may still be in use by

@@ -518,8 +518,7 @@ int csr_build_xw_plan(padne_ctx *ctx, padne_csr *m) {
             hipLaunchKernelGGL(xw_plan_kernel<unsigned short>, dim3(g), dim3(256), 0, ctx->stream, (int)m->n_rows, n_tiles, run,
                                m->rowptr, m->cols, desc, lidx, d_ok);
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(&h_ok, d_ok, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess && read_back(ctx, d_ok, sizeof(int), &h_ok) != PADNE_OK) e = hipErrorUnknown;
     }
     pool_free(ctx, d_ok);
     if (getenv("PADNE_XW_VERBOSE") != nullptr)
