@@ -813,7 +813,10 @@ __global__ __launch_bounds__(256) void spgemm_rows_wave(int n_rows, const int *_
                                                         const int *__restrict__ yc, const double *__restrict__ yv, const int *__restrict__ ye, const int ycs,
                                                         const int *__restrict__ slot_ptr, long long *__restrict__ key,
                                                         double *__restrict__ val, int *__restrict__ row_len,
-                                                        const int only_flagged) {
+                                                        const int only_flagged, const int *__restrict__ row_list = nullptr,
+                                                        const int *__restrict__ list_count = nullptr) {
+    // row_list / list_count: the kernel works through that list of rows (the ones an earlier pass left, collected by
+    // collect_pending_rows) instead of striding over all rows looking for them
     __shared__ int s_pc[4][CAPP];
     __shared__ double s_pv[4][CAPP];
     __shared__ int s_ht[4][HT];
@@ -829,27 +832,32 @@ __global__ __launch_bounds__(256) void spgemm_rows_wave(int n_rows, const int *_
     // The loads that lead to a row's products form a chain of four dependent global accesses (xr -> xc/xv -> yr ->
     // yc/yv); the first three are issued one row ahead so that only the last one is exposed.
     const int stride = gridDim.x * 4;
-    int nx_n = 0, len_n = 0, ystart_n = 0;
+    const int n_iter = row_list != nullptr ? *list_count : n_rows;
+    int nx_n = 0, len_n = 0, ystart_n = 0, row_n = 0;
     double a_n = 0.0;
-    auto prefetch = [&](int row) {
-        nx_n = 0; len_n = 0; ystart_n = 0; a_n = 0.0;
-        if (row < n_rows && !(only_flagged && row_len[row] >= 0)) {
-            const int x0 = xr[row];
-            nx_n = xr[row + 1] - x0;
-            if (nx_n <= 64 && lane < nx_n) {
-                const int mid = xc[x0 + lane];
-                a_n = xv[x0 + lane];
-                ystart_n = yr[mid];
-                len_n = ye[mid] - ystart_n;
+    auto prefetch = [&](int t) {
+        nx_n = 0; len_n = 0; ystart_n = 0; a_n = 0.0; row_n = 0;
+        if (t < n_iter) {
+            const int row = row_list != nullptr ? row_list[t] : t;
+            row_n = row;
+            if (!(only_flagged && row_len[row] >= 0)) {
+                const int x0 = xr[row];
+                nx_n = xr[row + 1] - x0;
+                if (nx_n <= 64 && lane < nx_n) {
+                    const int mid = xc[x0 + lane];
+                    a_n = xv[x0 + lane];
+                    ystart_n = yr[mid];
+                    len_n = ye[mid] - ystart_n;
+                }
             }
         }
     };
     prefetch(blockIdx.x * 4 + w);
-    for (int i = blockIdx.x * 4 + w; i < n_rows; i += stride) {
-        const int nx = nx_n, len = len_n, ystart = ystart_n;
+    for (int t = blockIdx.x * 4 + w; t < n_iter; t += stride) {
+        const int nx = nx_n, len = len_n, ystart = ystart_n, i = row_n;
         const double a = a_n;
         const bool skip = only_flagged && row_len[i] >= 0;      // finished by the sub-wave pass
-        prefetch(i + stride);
+        prefetch(t + stride);
         if (skip) continue;
         if (nx > 64) {
             if (lane == 0) row_len[i] = -1;
@@ -1093,12 +1101,14 @@ __global__ __launch_bounds__(256) void spgemm_rows_dense(int n_cols, const int *
                                                          const double *__restrict__ xv, const int *__restrict__ yr,
                                                          const int *__restrict__ yc, const double *__restrict__ yv, const int *__restrict__ ye, const int ycs,
                                                          const int *__restrict__ slot_ptr, long long *__restrict__ key,
-                                                         double *__restrict__ val, int *__restrict__ row_len) {
+                                                         double *__restrict__ val, int *__restrict__ row_len,
+                                                         const int only_pending) {
     extern __shared__ double acc_and_flag[];               // n_cols doubles + n_cols bytes
     double *acc = acc_and_flag;
     unsigned char *hit = (unsigned char *)(acc + n_cols);
     __shared__ int wave_cnt[4];
     const int i = blockIdx.x;
+    if (only_pending && row_len[i] >= 0) return;           // behind the wave kernels: the rows they left (-1)
     for (int c = threadIdx.x; c < n_cols; c += 256) {
         acc[c] = 0.0;
         hit[c] = 0;
@@ -1137,6 +1147,19 @@ __global__ __launch_bounds__(256) void spgemm_rows_dense(int n_cols, const int *
         __syncthreads();
     }
     if (threadIdx.x == 0) row_len[i] = base;
+}
+
+// rows an earlier pass left (-1), as a list: the passes behind it walk the list instead of all rows
+__global__ __launch_bounds__(256) void collect_pending_rows(int n, const int *__restrict__ row_len, int *__restrict__ list,
+                                                            int *__restrict__ count) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool pend = i < n && row_len[i] < 0;
+    const unsigned long long mask = __ballot(pend);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0 && mask != 0ull) base = atomicAdd(count, __popcll(mask));
+    base = __shfl(base, 0, 64);
+    if (pend) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = i;
 }
 
 // only the rows the LDS variant gave up on
@@ -1971,7 +1994,7 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
             (void)hipFuncSetAttribute((const void *)spgemm_rows_dense, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)dense_lds);
             hipLaunchKernelGGL(spgemm_rows_dense, dim3(n), dim3(256), dense_lds, s, (int)Y->n_cols, X->rowptr, X->cols,
-                               X->vals, y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len);
+                               X->vals, y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len, 0);
         } else if (avg <= 24.0 && getenv("PADNE_SPGEMM_WAVE_ALL") == nullptr) {
             // A*P on the fine levels: a dozen products per row -> one thread per row with small sorted lists in LDS
             hipLaunchKernelGGL(spgemm_rows_lds<16>, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
@@ -1981,24 +2004,38 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
         } else if (avg <= 256.0) {
             // tens to hundreds of products per row: one wave per row, the rows that do not fit are redone in global memory
             const unsigned gw = (unsigned)std::min<long long>(((long long)n + 3) / 4, 16384);
+            const unsigned gl = std::min(gw, 4096u);       // passes over the list of rows the first pass left
+            int *pend = nullptr, *pend_count = nullptr;
+            PADNE_TRY(sc.alloc(&pend, (size_t)n));
+            PADNE_TRY(sc.alloc(&pend_count, 1));
+            PADNE_HIP_CHECK(hipMemsetAsync(pend_count, 0, sizeof(int), s));
             if (avg <= 110.0) {
                 // short rows: two rows per wave with small limits first (2.5 KiB of LDS per row: 56 rows in flight per
                 // CU), then one row per wave for the rows that did not fit
                 const unsigned gs = (unsigned)std::min<long long>(((long long)n + 7) / 8, 16384);
                 hipLaunchKernelGGL((spgemm_rows_sub<128, 64, 32>), dim3(gs), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
                                    y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len);
-                hipLaunchKernelGGL((spgemm_rows_wave<256, 128>), dim3(gw), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
-                                   y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len, 1);
-                if (n <= 500000)   // coarse levels: the few long rows stay away from the serial fallback
-                    hipLaunchKernelGGL((spgemm_rows_wave<1024, 512>), dim3(gw), dim3(256), 0, s, n, X->rowptr, X->cols,
-                                       X->vals, y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len, 1);
+                hipLaunchKernelGGL(collect_pending_rows, dim3(nblk(n)), dim3(256), 0, s, n, (const int *)row_len, pend, pend_count);
+                hipLaunchKernelGGL((spgemm_rows_wave<256, 128>), dim3(gl), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
+                                   y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len, 1, (const int *)pend,
+                                   (const int *)pend_count);
             } else {
-                // coarse levels: rows of a few hundred products, some of a thousand -- a second wave pass with doubled
-                // limits keeps those away from the serial fallback (0.5 ms for a handful of rows)
+                // coarse levels: rows of a few hundred products, some of a thousand
                 hipLaunchKernelGGL((spgemm_rows_wave<512, 256>), dim3(gw), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
                                    y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len, 0);
-                hipLaunchKernelGGL((spgemm_rows_wave<1024, 512>), dim3(gw), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
-                                   y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len, 1);
+                hipLaunchKernelGGL(collect_pending_rows, dim3(nblk(n)), dim3(256), 0, s, n, (const int *)row_len, pend, pend_count);
+            }
+            // a second wave pass with doubled limits keeps the few long rows (aggregates next to a via hub) away from the
+            // serial fallback (0.5 ms for a handful of rows)
+            hipLaunchKernelGGL((spgemm_rows_wave<1024, 512>), dim3(std::min(gl, 1024u)), dim3(256), 0, s, n, X->rowptr, X->cols,
+                               X->vals, y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len, 1, (const int *)pend,
+                               (const int *)pend_count);
+            if (dense_lds <= 150 * 1024) {
+                // rows beyond the wave kernels' limits over a small column space: the dense accumulator, a workgroup each
+                (void)hipFuncSetAttribute((const void *)spgemm_rows_dense, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)dense_lds);
+                hipLaunchKernelGGL(spgemm_rows_dense, dim3(n), dim3(256), dense_lds, s, (int)Y->n_cols, X->rowptr, X->cols,
+                                   X->vals, y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len, 1);
             }
             hipLaunchKernelGGL(spgemm_rows_redo, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
                                y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len);
