@@ -3018,6 +3018,7 @@ static int amg_apply_f32(padne_ctx *ctx, Amg *amg, const double *r, double *z, d
         set_error("the single-precision cycle is only used as the CG preconditioner");
         return PADNE_E_INVALID;
     }
+    bool fused_start = false;      // the restriction onto this level has already written its pre-smoothed start
     for (int l = 0; l < nl; ++l) {
         AmgLevel &L = amg->levels[l];
         float *b = (float *)L.b, *xa = (float *)L.xa, *tmp = (float *)L.tmp;
@@ -3048,14 +3049,21 @@ static int amg_apply_f32(padne_ctx *ctx, Amg *amg, const double *r, double *z, d
         } else if (l == 0)
             hipLaunchKernelGGL(amg_entry_f32_kernel, dim3(gv > 0 ? gv : 1), dim3(256), 0, s, L.n, r, bb2, (float)L.jac,
                                (const float *)L.A->dinv32, b, xa, done_flag);
-        else
+        else if (!fused_start)
             hipLaunchKernelGGL(scale_dinv_kernel<float>, dim3(gv > 0 ? gv : 1), dim3(256), 0, s, L.n, (float)L.jac,
                                (const float *)L.A->dinv32, (const float *)b, xa, done_flag);
         PADNE_HIP_CHECK(hipGetLastError());
         if (amg->dist) PADNE_TRY(halo_exchange_plan_f32(ctx, L.halo, xa, done_flag));
         PADNE_TRY(launch_spmv_f32(ctx, L.A, SPMV_RESID, xa, tmp, nullptr, done_flag, b, nullptr, 0.f));
-        PADNE_TRY(launch_spmv_f32(ctx, L.R, SPMV_PLAIN, tmp, (float *)amg->levels[l + 1].b, nullptr, done_flag, nullptr,
-                                  nullptr, 0.f));
+        // the restriction also leaves the first sweep of the level below (from a zero start: x = c D^-1 b), unless that
+        // level is the coarsest (solved directly) -- one short launch less per level
+        AmgLevel &Lc = amg->levels[l + 1];
+        fused_start = l + 1 < nl - 1 && Lc.A->dinv32 != nullptr;
+        if (fused_start)
+            PADNE_TRY(launch_spmv_f32_restrict(ctx, L.R, tmp, (float *)Lc.b, (float *)Lc.xa, done_flag, Lc.A->dinv32,
+                                               (float)Lc.jac));
+        else
+            PADNE_TRY(launch_spmv_f32(ctx, L.R, SPMV_PLAIN, tmp, (float *)Lc.b, nullptr, done_flag, nullptr, nullptr, 0.f));
     }
     for (int l = nl - 2; l >= 0; --l) {
         AmgLevel &L = amg->levels[l];

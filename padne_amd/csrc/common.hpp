@@ -129,13 +129,16 @@ int launch_spmv(padne_ctx *ctx, const padne_csr *m, const double *x, double *y,
 int spmv_grid(const padne_csr *m);
 enum { SPMV_PLAIN = 0, SPMV_DOT = 1, SPMV_RESID = 2, SPMV_ADD = 3, SPMV_JACOBI = 4,
        SPMV_DOT_AUX = 5,     // same as SPMV_DOT; used outside the CG loop (Lanczos estimates) so that kernel profiles keep the two apart
-       SPMV_WUP = 6 };       // y = aux0 + scale * aux2 * aux1 + W x  (spmv.hip)
+       SPMV_WUP = 6,         // y = aux0 + scale * aux2 * aux1 + W x  (spmv.hip)
+       SPMV_RESTRICT = 7 };  // y = A x ; y2 = scale * aux2 * y
 int launch_spmv_mode(padne_ctx *ctx, const padne_csr *m, int mode, const double *x, double *y,
                      const double *dot_with, double *partials, const int32_t *done_flag, const double *aux1,
                      const double *aux2, double scale);
 
 int launch_spmv_f32(padne_ctx *ctx, const padne_csr *m, int mode, const float *x, float *y, double *partials,
                     const int32_t *done_flag, const float *aux1, const float *aux2, float scale);
+int launch_spmv_f32_restrict(padne_ctx *ctx, const padne_csr *R, const float *r, float *b_c, float *x_c,
+                             const int32_t *done_flag, const float *dinv_c, float c);
 int launch_spmv_f32_exit(padne_ctx *ctx, const padne_csr *m, const float *x, double *y, const double *dot_with,
                          double *partials, const int32_t *done_flag, const float *aux1, const float *aux2, float scale,
                          const double *out_scale2);

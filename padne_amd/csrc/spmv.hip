@@ -121,6 +121,8 @@ __device__ __forceinline__ XT xw_stream_tile(const VT *__restrict__ vals, const 
 //   SPMV_ADD     y += acc                                              (prolongation: x += P xc)
 //   SPMV_JACOBI  y = x[row] + scale * aux2[row] * (aux1[row] - acc)    (damped-Jacobi sweep, aux2 = 1/diag)
 //                optional partial sums of aux1[row] * y[row]           (r.z of the preconditioned CG)
+//   SPMV_RESTRICT y = acc ; y2 = scale * aux2[row] * acc                 (restriction, and the first damped-Jacobi sweep of
+//                the level it restricts to from a zero start: aux2 = that level's 1/diag)
 //   SPMV_WUP     y = aux0[row] + scale * aux2[row] * aux1[row] + acc   (coarse correction and post-smoothing in one
 //                product with W = P - c D^-1 A P, see amg.hip: aux0 = pre-smoothed iterate, aux1 = its residual)
 //
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
     const int *__restrict__ done_flag, const XT *__restrict__ aux1,
     const XT *__restrict__ aux2, const XT scale, const double *__restrict__ out_scale2,
     const int4 *__restrict__ xw_desc, const void *__restrict__ xw_lidx, const int xw_run,
-    const XT *__restrict__ aux0) {
+    const XT *__restrict__ aux0, XT *__restrict__ y2) {
     constexpr bool WITH_DOT = (MODE == SPMV_DOT) || (MODE == SPMV_DOT_AUX) || (MODE == SPMV_JACOBI) || (MODE == SPMV_WUP);
     __shared__ XT prod_all[4 * kWaveChunk];
     extern __shared__ unsigned char xs_dyn[];      // 4 * kXwRuns * xw_run entries of XT when the plan is in use
@@ -237,6 +239,9 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
         if (r < row1) {
             if (MODE == SPMV_PLAIN) {
                 y[r] = (YT)acc;
+            } else if (MODE == SPMV_RESTRICT) {
+                y[r] = (YT)acc;
+                y2[r] = scale * aux2[r] * acc;
             } else if (MODE == SPMV_DOT || MODE == SPMV_DOT_AUX) {
                 y[r] = (YT)acc;
                 dot_acc += dot_with[r] * (double)acc;
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_wpr_kernel(
     const int n_rows, const int *__restrict__ rowptr, const int *__restrict__ cols, const VT *__restrict__ vals,
     const XT *__restrict__ x, YT *__restrict__ y, const double *__restrict__ dot_with,
     double *__restrict__ partials, const int *__restrict__ done_flag, const XT *__restrict__ aux1,
-    const XT *__restrict__ aux2, const XT scale, const double *__restrict__ out_scale2) {
+    const XT *__restrict__ aux2, const XT scale, const double *__restrict__ out_scale2, XT *__restrict__ y2) {
     constexpr bool WITH_DOT = (MODE == SPMV_DOT) || (MODE == SPMV_DOT_AUX) || (MODE == SPMV_JACOBI);
     __shared__ double red[4];
     if (done_flag != nullptr && *done_flag != 0) return;
@@ -302,6 +307,9 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_wpr_kernel(
         if (lane == 0) {
             if (MODE == SPMV_PLAIN) {
                 y[r] = (YT)acc;
+            } else if (MODE == SPMV_RESTRICT) {
+                y[r] = (YT)acc;
+                y2[r] = scale * aux2[r] * acc;
             } else if (MODE == SPMV_DOT || MODE == SPMV_DOT_AUX) {
                 y[r] = (YT)acc;
                 dot_acc += dot_with[r] * (double)acc;
@@ -354,7 +362,7 @@ int spmv_grid(const padne_csr *m) {
 template <typename VT, typename XT, typename YT>
 static int launch_spmv_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals, int mode, const XT *x, YT *y,
                              const double *dot_with, double *partials, const int32_t *done_flag, const XT *aux1,
-                             const XT *aux2, XT scale, const double *out_scale2, const XT *aux0 = nullptr) {
+                             const XT *aux2, XT scale, const double *out_scale2, const XT *aux0 = nullptr, XT *y2 = nullptr) {
     if (m->n_rows == 0) return PADNE_OK;
     const int n_tiles = (int)((m->n_rows + 63) / 64);   // wave-tiles of 64 rows
     const int g = spmv_grid(m);
@@ -362,7 +370,7 @@ static int launch_spmv_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals,
 #define PADNE_SPMV_WPR(M)                                                                                           \
     hipLaunchKernelGGL((csr_spmv_wpr_kernel<M, VT, XT, YT>), dim3(g), dim3(kSpmvThreads), 0, ctx->stream,            \
                        (int)m->n_rows, m->rowptr, m->cols, vals, x, y, dot_with, partials, done_flag, aux1, aux2,    \
-                       scale, out_scale2)
+                       scale, out_scale2, y2)
         switch (mode) {
             case SPMV_PLAIN: PADNE_SPMV_WPR(SPMV_PLAIN); break;
             case SPMV_DOT: PADNE_SPMV_WPR(SPMV_DOT); break;
@@ -370,6 +378,7 @@ static int launch_spmv_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals,
             case SPMV_RESID: PADNE_SPMV_WPR(SPMV_RESID); break;
             case SPMV_ADD: PADNE_SPMV_WPR(SPMV_ADD); break;
             case SPMV_JACOBI: PADNE_SPMV_WPR(SPMV_JACOBI); break;
+            case SPMV_RESTRICT: PADNE_SPMV_WPR(SPMV_RESTRICT); break;
             default: set_error("bad SpMV mode %d", mode); return PADNE_E_INVALID;
         }
 #undef PADNE_SPMV_WPR
@@ -382,7 +391,7 @@ static int launch_spmv_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals,
 #define PADNE_SPMV_LAUNCH(M)                                                                                     \
     hipLaunchKernelGGL((csr_spmv_kernel<M, VT, XT, YT>), dim3(g), dim3(kSpmvThreads), xs_bytes, ctx->stream,      \
                        (int)m->n_rows, (int)m->n_cols, n_tiles, m->rowptr, m->cols, vals, x, y, dot_with,         \
-                       partials, done_flag, aux1, aux2, scale, out_scale2, xw_desc, xw_lidx, m->xw_run, aux0)
+                       partials, done_flag, aux1, aux2, scale, out_scale2, xw_desc, xw_lidx, m->xw_run, aux0, y2)
     switch (mode) {
         case SPMV_PLAIN: PADNE_SPMV_LAUNCH(SPMV_PLAIN); break;
         case SPMV_DOT: PADNE_SPMV_LAUNCH(SPMV_DOT); break;
@@ -391,6 +400,7 @@ static int launch_spmv_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals,
         case SPMV_ADD: PADNE_SPMV_LAUNCH(SPMV_ADD); break;
         case SPMV_JACOBI: PADNE_SPMV_LAUNCH(SPMV_JACOBI); break;
         case SPMV_WUP: PADNE_SPMV_LAUNCH(SPMV_WUP); break;
+        case SPMV_RESTRICT: PADNE_SPMV_LAUNCH(SPMV_RESTRICT); break;
         default: set_error("bad SpMV mode %d", mode); return PADNE_E_INVALID;
     }
 #undef PADNE_SPMV_LAUNCH
@@ -411,6 +421,14 @@ int launch_spmv_f32(padne_ctx *ctx, const padne_csr *m, int mode, const float *x
     PADNE_REQUIRE(m->vals32 != nullptr, "single-precision copy missing");
     return launch_spmv_typed<float, float, float>(ctx, m, m->vals32, mode, x, y, nullptr, partials, done_flag, aux1,
                                                   aux2, scale, nullptr);
+}
+
+// restriction b_c = R r and, in the same pass, the pre-smoothed start of the coarse level x_c = c D_c^-1 b_c
+int launch_spmv_f32_restrict(padne_ctx *ctx, const padne_csr *R, const float *r, float *b_c, float *x_c,
+                             const int32_t *done_flag, const float *dinv_c, float c) {
+    PADNE_REQUIRE(R->vals32 != nullptr && x_c != nullptr && dinv_c != nullptr, "single-precision restriction");
+    return launch_spmv_typed<float, float, float>(ctx, R, R->vals32, SPMV_RESTRICT, r, b_c, nullptr, nullptr, done_flag,
+                                                  nullptr, dinv_c, c, nullptr, nullptr, x_c);
 }
 
 // last stage of the single-precision cycle: damped-Jacobi sweep whose result goes out in double, multiplied by
