@@ -141,10 +141,10 @@ int launch_spmv_f32_restrict(padne_ctx *ctx, const padne_csr *R, const float *r,
                              const int32_t *done_flag, const float *dinv_c, float c);
 int launch_spmv_f32_exit(padne_ctx *ctx, const padne_csr *m, const float *x, double *y, const double *dot_with,
                          double *partials, const int32_t *done_flag, const float *aux1, const float *aux2, float scale,
-                         const double *out_scale2);
+                         const double *out_scale2, float *z32 = nullptr);
 int launch_spmv_f32_wup_exit(padne_ctx *ctx, const padne_csr *w, const float *e, double *z, const double *dot_with,
                              double *partials, const int32_t *done_flag, const float *x_pre, const float *r_pre,
-                             const float *dinv32, float scale, const double *out_scale2);
+                             const float *dinv32, float scale, const double *out_scale2, float *z32 = nullptr);
 int csr_build_f32(padne_ctx *ctx, padne_csr *m);
 int csr_build_xw_plan(padne_ctx *ctx, padne_csr *m);
 

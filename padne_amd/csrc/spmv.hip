@@ -253,7 +253,8 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
                 const XT out = aux0[r] + scale * aux2[r] * aux1[r] + acc;
                 if (dot_with != nullptr) {
                     const double outd = (double)out * out_mul;
-                    y[r] = (YT)outd;
+                    // a float result leaves unscaled (the consumer multiplies: the same double comes out)
+                    y[r] = sizeof(YT) == 4 ? (YT)out : (YT)outd;
                     dot_acc += dot_with[r] * outd;
                 } else {
                     y[r] = (YT)out;
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
                 const XT out = x[r] + scale * aux2[r] * (b - acc);
                 if (dot_with != nullptr) {
                     const double outd = (double)out * out_mul;
-                    y[r] = (YT)outd;
+                    y[r] = sizeof(YT) == 4 ? (YT)out : (YT)outd;
                     dot_acc += dot_with[r] * outd;
                 } else {
                     y[r] = (YT)out;
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_wpr_kernel(
                 const XT out = x[r] + scale * aux2[r] * (b - acc);
                 if (dot_with != nullptr) {
                     const double outd = (double)out * out_mul;
-                    y[r] = (YT)outd;
+                    y[r] = sizeof(YT) == 4 ? (YT)out : (YT)outd;
                     dot_acc += dot_with[r] * outd;
                 } else {
                     y[r] = (YT)out;
@@ -433,10 +434,14 @@ int launch_spmv_f32_restrict(padne_ctx *ctx, const padne_csr *R, const float *r,
 
 // last stage of the single-precision cycle: damped-Jacobi sweep whose result goes out in double, multiplied by
 // sqrt(*out_scale2), with partial sums of dot_with . y
+// z32 != nullptr: the result goes there in single precision and UNSCALED instead (the dot product is the same)
 int launch_spmv_f32_exit(padne_ctx *ctx, const padne_csr *m, const float *x, double *y, const double *dot_with,
                          double *partials, const int32_t *done_flag, const float *aux1, const float *aux2, float scale,
-                         const double *out_scale2) {
+                         const double *out_scale2, float *z32) {
     PADNE_REQUIRE(m->vals32 != nullptr && dot_with != nullptr, "single-precision exit stage");
+    if (z32 != nullptr)
+        return launch_spmv_typed<float, float, float>(ctx, m, m->vals32, SPMV_JACOBI, x, z32, dot_with, partials, done_flag,
+                                                      aux1, aux2, scale, out_scale2);
     return launch_spmv_typed<float, float, double>(ctx, m, m->vals32, SPMV_JACOBI, x, y, dot_with, partials, done_flag,
                                                    aux1, aux2, scale, out_scale2);
 }
@@ -445,8 +450,11 @@ int launch_spmv_f32_exit(padne_ctx *ctx, const padne_csr *m, const float *x, dou
 // with partial sums of dot_with . z.  W carries single-precision values only (m->vals32).
 int launch_spmv_f32_wup_exit(padne_ctx *ctx, const padne_csr *w, const float *e, double *z, const double *dot_with,
                              double *partials, const int32_t *done_flag, const float *x_pre, const float *r_pre,
-                             const float *dinv32, float scale, const double *out_scale2) {
+                             const float *dinv32, float scale, const double *out_scale2, float *z32) {
     PADNE_REQUIRE(w->vals32 != nullptr && dot_with != nullptr, "single-precision W stage");
+    if (z32 != nullptr)
+        return launch_spmv_typed<float, float, float>(ctx, w, w->vals32, SPMV_WUP, e, z32, dot_with, partials, done_flag,
+                                                      r_pre, dinv32, scale, out_scale2, x_pre);
     return launch_spmv_typed<float, float, double>(ctx, w, w->vals32, SPMV_WUP, e, z, dot_with, partials, done_flag, r_pre,
                                                    dinv32, scale, out_scale2, x_pre);
 }
