@@ -397,6 +397,7 @@ __global__ void asm_fill_tri(long long n_tri, const int *__restrict__ tri, const
 // order.  Rows it does not take (stamps, more than CAP triangles) are
 // marked row_len = -1, listed in slow_list, and go through the slots (asm_fill_tri with only_flagged, the merge
 // kernels over the list).
+struct __attribute__((packed, aligned(4))) Int3 { int a, b, c; };
 template <int CAP>
 __global__ __launch_bounds__(128) void asm_rows_from_incidence(
     long long n_vert, int n_mesh, const long long *__restrict__ mesh_voff, const double *__restrict__ sigma,
@@ -419,39 +420,79 @@ __global__ __launch_bounds__(128) void asm_rows_from_incidence(
     if (!slow) {
         const int m = find_segment(mesh_voff, n_mesh, r);
         const long long v0 = mesh_voff[m];
-        const double vx = xy[2 * r], vy = xy[2 * r + 1];
-        for (int q = 0; q < T; ++q) {
-            const long long tt = inc[i0 + q];
-            const int a = (int)(v0 + tri[3 * tt]), b = (int)(v0 + tri[3 * tt + 1]), c = (int)(v0 + tri[3 * tt + 2]);
-            int j, k;                       // r -> j is the edge leaving r in this triangle, k -> r the one arriving
-            if (a == (int)r) { j = b; k = c; } else if (b == (int)r) { j = c; k = a; } else { j = a; k = b; }
-            const double jx = xy[2 * (long long)j], jy = xy[2 * (long long)j + 1];
-            const double kx = xy[2 * (long long)k], ky = xy[2 * (long long)k + 1];
-            const double wf = cot_half(vx, vy, jx, jy, kx, ky);      // edge r -> j, opposite k
-            const double wb = cot_half(kx, ky, vx, vy, jx, jy);      // edge k -> r, opposite j
+        const double2 pv = reinterpret_cast<const double2 *>(xy)[r];
+        const double vx = pv.x, vy = pv.y;
+        // four triangles per turn: their list entries, then their corners, then the coordinates are requested together --
+        // one triangle at a time the lane waited for three dependent loads per triangle (list -> corners -> coordinates),
+        // 6-8 times in a row
+        for (int q0 = 0; q0 < T; q0 += 4) {
+            int cj[4], ck[4];
+            {
+                long long tt[4];
 #pragma unroll
-            for (int side = 0; side < 2; ++side) {
-                const int col = side == 0 ? j : k;
-                const double w = side == 0 ? wf : wb;
-                const int bit = 1 << side;
-                int u = 0;
-                while (u < nn && Cc[u][t] != col) ++u;
-                if (u < nn) {
-                    if (Fc[u][t] & bit) bad = true;                  // two triangles on the same side of an edge
-                    Wc[u][t] = (Fc[u][t] == 1) ? Wc[u][t] + w : w + Wc[u][t];      // forward + backward, as the merge adds them
-                    Fc[u][t] |= bit;
-                } else if (nn <= T) {                                // a manifold fan of T triangles has at most T + 1 neighbours: the row owns T + 2 slots
-                    Cc[nn][t] = col;
-                    Wc[nn][t] = w;
-                    Fc[nn][t] = bit;
-                    ++nn;
-                } else {
-                    bad = true;                                      // more neighbours than a manifold fan has
-                    nn = 0;
-                    q = T;
-                    break;
+                for (int u = 0; u < 4; ++u) tt[u] = q0 + u < T ? inc[i0 + q0 + u] : 0;
+                int ca[4], cb[4], cc[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    ca[u] = cb[u] = cc[u] = 0;
+                    if (q0 + u < T) {
+                        const Int3 c3 = *reinterpret_cast<const Int3 *>(tri + 3 * tt[u]);      // one 12-byte load
+                        ca[u] = c3.a;
+                        cb[u] = c3.b;
+                        cc[u] = c3.c;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int a = (int)(v0 + ca[u]), b = (int)(v0 + cb[u]), c = (int)(v0 + cc[u]);
+                    // r -> j is the edge leaving r in this triangle, k -> r the one arriving
+                    if (a == (int)r) { cj[u] = b; ck[u] = c; } else if (b == (int)r) { cj[u] = c; ck[u] = a; } else { cj[u] = a; ck[u] = b; }
                 }
             }
+            double jx[4], jy[4], kx[4], ky[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                jx[u] = jy[u] = kx[u] = ky[u] = 0.0;
+                if (q0 + u < T) {
+                    const double2 pj = reinterpret_cast<const double2 *>(xy)[cj[u]], pk = reinterpret_cast<const double2 *>(xy)[ck[u]];
+                    jx[u] = pj.x;
+                    jy[u] = pj.y;
+                    kx[u] = pk.x;
+                    ky[u] = pk.y;
+                }
+            }
+            bool stop = false;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (q0 + u >= T || stop) continue;
+                const int j = cj[u], k = ck[u];
+                const double wf = cot_half(vx, vy, jx[u], jy[u], kx[u], ky[u]);      // edge r -> j, opposite k
+                const double wb = cot_half(kx[u], ky[u], vx, vy, jx[u], jy[u]);      // edge k -> r, opposite j
+#pragma unroll
+                for (int side = 0; side < 2; ++side) {
+                    const int col = side == 0 ? j : k;
+                    const double w = side == 0 ? wf : wb;
+                    const int bit = 1 << side;
+                    int e = 0;
+                    while (e < nn && Cc[e][t] != col) ++e;
+                    if (e < nn) {
+                        if (Fc[e][t] & bit) bad = true;                  // two triangles on the same side of an edge
+                        Wc[e][t] = (Fc[e][t] == 1) ? Wc[e][t] + w : w + Wc[e][t];      // forward + backward, as the merge adds them
+                        Fc[e][t] |= bit;
+                    } else if (nn <= T) {                                // a manifold fan of T triangles has at most T + 1 neighbours: the row owns T + 2 slots
+                        Cc[nn][t] = col;
+                        Wc[nn][t] = w;
+                        Fc[nn][t] = bit;
+                        ++nn;
+                    } else {
+                        bad = true;                                      // more neighbours than a manifold fan has
+                        nn = 0;
+                        stop = true;
+                        break;
+                    }
+                }
+            }
+            if (stop) break;
         }
     }
     {
@@ -1082,8 +1123,10 @@ static int finish_rows(padne_ctx *ctx, Scratch &sc, long long n_rows, long long 
             PADNE_TRY(read_back(ctx, d_err, sizeof(h_long), h_long));
         }
         if (h_long[ERR_LONG_ROWS]) {               // rows with more than kCap slots (hubs): wave sort, then the global-memory merge
-            hipLaunchKernelGGL(sort_long_rows_wave<kWaveSortCap>, dim3(std::min(nblk(n_merge, 256), 2048u)), dim3(256), 0, s, n_merge,
-                               row_list, slot_ptr, key, val, kCap + 1, 1);
+            // (the hub rows sit next to each other in the list -- the vertices of a via ring: four rows per wave and turn
+            // spread them over the chip; with 64 a few waves sorted 64 long rows each, one after the other: 0.41 ms)
+            hipLaunchKernelGGL((sort_long_rows_wave<kWaveSortCap, 4>), dim3(std::min(nblk(n_merge, 16), 8192u)), dim3(256), 0, s,
+                               n_merge, row_list, slot_ptr, key, val, kCap + 1, 1);
             hipLaunchKernelGGL(merge_rows<MESH>, dim3(nblk(n_merge, 128)), dim3(128), 0, s, n_merge, n_vert, n_mesh, d_voff,
                                d_sigma, slot_ptr, key, val, row_len, d_err, kCap + 1, row_list, kWaveSortCap);
             PADNE_HIP_CHECK(hipGetLastError());

@@ -355,6 +355,37 @@ def test_multigrid_hierarchy_is_galerkin_and_partition_of_unity(ctx):
         assert P.shape[1] < 0.5 * P.shape[0]
 
 
+def test_mailbox_round_trips_change_nothing_but_the_waiting(ctx, monkeypatch):
+    """Counts and flags of the setup reach the host through a host-coherent page the device posts into (read_back,
+    mail_ticket in capi.hip) instead of memcpy + synchronise.  A context created with PADNE_NO_MAILBOX=1 takes the old
+    route: same hierarchy decisions, so the same iterations and bit-identical potentials -- also for the assembly and the
+    x-window plan, which use the same helper."""
+    sysm = synthetic.layered_system(2, 180, 150, via_lattice=5)
+    els = [("R", int(a), int(b), float(r)) for a, b, r in zip(*sysm.resistors)]
+    els += [("I", int(f), int(t), float(i)) for f, t, i in zip(*sysm.current_sources)]
+    Lo, ro = O.assemble_system([(m[0], m[1], m[2]) for m in sysm.meshes], 0, els, 0)
+    n = sysm.n_vertices
+    A = (-Lo[1:n, 1:n]).tocsr()
+    A.sort_indices()
+    b = -ro[1:n]
+
+    def run(c):
+        d = c.csr_from_scipy(A)
+        res = d.solve_spd(b, precond="amg", rtol=1e-12)
+        d.close()
+        return res
+    with_mail = run(ctx)
+    monkeypatch.setenv("PADNE_NO_MAILBOX", "1")
+    other = _hip.Context(0)
+    try:
+        without = run(other)
+    finally:
+        other.close()
+    assert with_mail.levels == without.levels >= 3 and with_mail.iterations == without.iterations
+    assert np.array_equal(with_mail.x, without.x)
+    assert np.linalg.norm(A @ with_mail.x - b) <= 1e-11 * np.linalg.norm(b)
+
+
 def test_fused_up_leg_of_the_fine_level_is_the_same_cycle(ctx, monkeypatch):
     """Level 0 of the float cycle applies coarse correction, post-smoothing sweep and the exit product of r.z in ONE
     sparse product with W = P - c D^-1 A P (built from the merge slots of A P on the second stream).  Algebraically the
