@@ -406,9 +406,8 @@ __global__ __launch_bounds__(128) void asm_rows_from_incidence(
     long long *__restrict__ key, double *__restrict__ val, int *__restrict__ row_len, int *__restrict__ err,
     int *__restrict__ slow_list, int *__restrict__ n_slow) {
     static_assert(CAP == kIncCap, "the incidence lists have kIncCap entries per vertex");
-    __shared__ int Cc[CAP + 1][128];
-    __shared__ double Wc[CAP + 1][128];
-    __shared__ int Fc[CAP + 1][128];      // bit 0: forward term seen, bit 1: backward term seen
+    __shared__ unsigned Cc[CAP + 1][128];      // column << 2 | bit 0: forward term seen | bit 1: backward term seen
+    __shared__ double Wc[CAP + 1][128];        // (20 KiB per workgroup: four waves per SIMD)
     const int t = threadIdx.x;
     const long long r = (long long)blockIdx.x * 128 + t;
     if (r >= n_vert) return;
@@ -474,15 +473,15 @@ __global__ __launch_bounds__(128) void asm_rows_from_incidence(
                     const double w = side == 0 ? wf : wb;
                     const int bit = 1 << side;
                     int e = 0;
-                    while (e < nn && Cc[e][t] != col) ++e;
+                    while (e < nn && (Cc[e][t] >> 2) != (unsigned)col) ++e;
                     if (e < nn) {
-                        if (Fc[e][t] & bit) bad = true;                  // two triangles on the same side of an edge
-                        Wc[e][t] = (Fc[e][t] == 1) ? Wc[e][t] + w : w + Wc[e][t];      // forward + backward, as the merge adds them
-                        Fc[e][t] |= bit;
+                        const unsigned cf = Cc[e][t];
+                        if (cf & bit) bad = true;                        // two triangles on the same side of an edge
+                        Wc[e][t] = ((cf & 3u) == 1u) ? Wc[e][t] + w : w + Wc[e][t];      // forward + backward, as the merge adds them
+                        Cc[e][t] = cf | bit;
                     } else if (nn <= T) {                                // a manifold fan of T triangles has at most T + 1 neighbours: the row owns T + 2 slots
-                        Cc[nn][t] = col;
+                        Cc[nn][t] = ((unsigned)col << 2) | bit;
                         Wc[nn][t] = w;
-                        Fc[nn][t] = bit;
                         ++nn;
                     } else {
                         bad = true;                                      // more neighbours than a manifold fan has
@@ -512,25 +511,23 @@ __global__ __launch_bounds__(128) void asm_rows_from_incidence(
     if (slow) return;
     // sort the neighbours by column (insertion sort, a handful of entries)
     for (int i = 1; i < nn; ++i) {
-        const int c = Cc[i][t], f = Fc[i][t];
+        const unsigned c = Cc[i][t];
         const double w = Wc[i][t];
         int u = i - 1;
         while (u >= 0 && Cc[u][t] > c) {
             Cc[u + 1][t] = Cc[u][t];
             Wc[u + 1][t] = Wc[u][t];
-            Fc[u + 1][t] = Fc[u][t];
             --u;
         }
         Cc[u + 1][t] = c;
         Wc[u + 1][t] = w;
-        Fc[u + 1][t] = f;
     }
     const double sig = sigma[find_segment(mesh_voff, n_mesh, r)];
     int fwd_only = 0, bwd_only = 0;
     double dacc = 0.0;
     for (int i = 0; i < nn; ++i) {
-        if (Fc[i][t] == 1) ++fwd_only;
-        if (Fc[i][t] == 2) ++bwd_only;
+        if ((Cc[i][t] & 3u) == 1u) ++fwd_only;
+        if ((Cc[i][t] & 3u) == 2u) ++bwd_only;
         const double wm = Wc[i][t];
         if (wm != 0.0) dacc = dacc - wm;
     }
@@ -539,7 +536,7 @@ __global__ __launch_bounds__(128) void asm_rows_from_incidence(
     int o = 0;
     bool diag_done = false;
     for (int i = 0; i <= nn; ++i) {
-        if (!diag_done && (i == nn || Cc[i][t] > (int)r)) {
+        if (!diag_done && (i == nn || (int)(Cc[i][t] >> 2) > (int)r)) {
             const double v = sig * dacc;
             if (v != 0.0) {
                 key[s0 + o] = (long long)r << 32;
@@ -551,7 +548,7 @@ __global__ __launch_bounds__(128) void asm_rows_from_incidence(
         if (i < nn) {
             const double v = sig * Wc[i][t];
             if (v != 0.0) {                                          // exact zeros are not stored
-                key[s0 + o] = (long long)Cc[i][t] << 32;
+                key[s0 + o] = (long long)(Cc[i][t] >> 2) << 32;
                 val[s0 + o] = v;
                 ++o;
             }
