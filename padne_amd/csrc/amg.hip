@@ -50,6 +50,11 @@ struct AmgLevel {
     HaloPlan halo;
     int32_t *export_owned = nullptr;   // device copy of the export list (levels >= 1; level 0 borrows the context's)
     std::vector<int> export_host;
+    // the other ranks' rows of P for the exchanged vertices ([world * halo.m] x [n_{l+1} | world * m_{l+1}]): kept on the
+    // last partitioned level, whose coarse level is the gathered one -- every rank holds the whole tail solution, so the
+    // neighbours' corrected values there are computed, not exchanged (amg_apply_f32)
+    padne_csr *P_halo = nullptr;
+    float *e_ext = nullptr;            // [n_{l+1} | world * m_{l+1}] coarse correction incl. the other ranks' exported aggregates
 };
 
 struct Amg {
@@ -69,6 +74,7 @@ struct Amg {
     int *seg_off = nullptr;            // device [world + 1]: first gathered row of every rank
     double *coarse_gather = nullptr;   // [world * n_pad] padded pieces as exchanged
     double *tail_r = nullptr, *tail_z = nullptr;   // [tail_n]
+    int *tail_slot_idx = nullptr;      // device [world * m]: gathered row of every exchange slot of the gather level
     double setup_seconds = 0.0;
     double operator_complexity = 0.0;
     int device = 0;
@@ -2198,6 +2204,8 @@ void amg_destroy(void *p) {
     for (AmgLevel &L : amg->levels) {
         if (L.A_owned) padne_csr_destroy(L.A_owned);
         if (L.P) padne_csr_destroy(L.P);
+        if (L.P_halo) padne_csr_destroy(L.P_halo);
+        pool_free(amg->ctx, L.e_ext);
         if (L.R) padne_csr_destroy(L.R);
         if (L.W) padne_csr_destroy(L.W);
         pool_free(amg->ctx, L.b);
@@ -2216,6 +2224,7 @@ void amg_destroy(void *p) {
     pool_free(amg->ctx, amg->seg_off);
     pool_free(amg->ctx, amg->tail_r);
     pool_free(amg->ctx, amg->tail_z);
+    pool_free(amg->ctx, amg->tail_slot_idx);
     if (amg->tail) padne_csr_destroy(amg->tail);
     delete amg;
 }
@@ -2288,6 +2297,7 @@ static int enable_f32(padne_ctx *ctx, Amg *amg) {
     for (AmgLevel &L : amg->levels) {
         PADNE_TRY(csr_build_f32(ctx, const_cast<padne_csr *>(L.A)));
         if (L.P) PADNE_TRY(csr_build_f32(ctx, L.P));
+        if (L.P_halo) PADNE_TRY(csr_build_f32(ctx, L.P_halo));
         if (L.R) PADNE_TRY(csr_build_f32(ctx, L.R));
     }
     if (amg->levels[0].b == nullptr) PADNE_TRY(alloc_vec(ctx, &amg->levels[0].b, amg->levels[0].n));
@@ -2719,6 +2729,16 @@ __global__ void compact_pieces(int world, int n_pad, const int *__restrict__ seg
         dst[seg_off[q] + i] = (double)src[(size_t)q * n_pad + i];
 }
 
+// the gathered solution as the level above sees its coarse vector: [this rank's piece | every exchange slot of the level]
+__global__ void tail_to_ext_kernel(long long n, int n_slots, const double *__restrict__ tail_z, long long tail_off,
+                                   const int *__restrict__ slot_idx, float *__restrict__ e_ext,
+                                   const int *__restrict__ done_flag) {
+    if (done_flag != nullptr && *done_flag != 0) return;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) e_ext[i] = (float)tail_z[tail_off + i];
+    else if (i < n + n_slots) e_ext[i] = (float)tail_z[slot_idx[i - n]];
+}
+
 __global__ void f32_from_f64_kernel(long long n, const double *__restrict__ src, float *__restrict__ dst,
                                     const int *__restrict__ done_flag) {
     if (done_flag != nullptr && *done_flag != 0) return;
@@ -2815,6 +2835,28 @@ static int gather_tail(padne_ctx *ctx, Amg *amg) {
     }
     amg->tail->hierarchy_operator = true;
     PADNE_TRY(amg_setup(ctx, amg->tail));
+    {
+        // the level above the gather level computes its neighbours' corrected values from the tail solution: where every
+        // exchange slot of the gather level lives in the gathered numbering, and room for [own aggregates | those slots]
+        const size_t nl = amg->levels.size();
+        for (size_t l = 0; l + 2 < nl; ++l)
+            if (amg->levels[l].P_halo != nullptr) {
+                padne_csr_destroy(amg->levels[l].P_halo);
+                amg->levels[l].P_halo = nullptr;
+            }
+        if (nl >= 2 && amg->levels[nl - 2].P_halo != nullptr && getenv("PADNE_AMG_EXCHANGE_ALL") != nullptr) {
+            padne_csr_destroy(amg->levels[nl - 2].P_halo);      // (A/B and tests: every level exchanges twice per cycle)
+            amg->levels[nl - 2].P_halo = nullptr;
+        }
+        if (nl >= 2 && amg->levels[nl - 2].P_halo != nullptr) {
+            amg->tail_slot_idx = (int *)pool_alloc(ctx, sizeof(int) * ((size_t)W * m + 1));
+            amg->levels[nl - 2].e_ext = (float *)pool_alloc(ctx, sizeof(float) * ((size_t)n + (size_t)W * m + 1));
+            if (amg->tail_slot_idx == nullptr || amg->levels[nl - 2].e_ext == nullptr) return PADNE_E_NOMEM;
+            PADNE_HIP_CHECK(hipMemcpyAsync(amg->tail_slot_idx, slot_to_global.data(), sizeof(int) * ((size_t)W * m + 1),
+                                           hipMemcpyHostToDevice, s));
+            PADNE_HIP_CHECK(hipStreamSynchronize(s));
+        }
+    }
     amg->n_pad = n_pad;
     amg->tail_n = N;
     amg->tail_off = off[(size_t)ctx->rank];
@@ -2949,7 +2991,8 @@ static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0) {
         int m_c = 0;
         if ((rc = exchange_prolongator_rows(ctx, Lr, Lr.P, n_agg, export_c, &m_c, &P_halo)) != PADNE_OK) break;
         rc = csr_vstack(ctx, Lr.P, P_halo, (long long)n_agg + (long long)W * m_c, &P_ext);
-        padne_csr_destroy(P_halo);
+        P_halo->hierarchy_operator = true;
+        Lr.P_halo = P_halo;                 // kept: see AmgLevel (dropped again below on all but the last partitioned level)
         if (rc != PADNE_OK) break;
         pt.lap("exchange P rows");
         rc = spgemm(ctx, A, P_ext, &AP);
@@ -3020,6 +3063,13 @@ static int amg_apply_f32(padne_ctx *ctx, Amg *amg, const double *r, double *z, d
         return PADNE_E_INVALID;
     }
     bool fused_start = false;      // the restriction onto this level has already written its pre-smoothed start
+    // last partitioned level of a row-partitioned hierarchy: the values of the other ranks' vertices after the coarse
+    // correction, x1 + P e, are computed here -- x1 came with the down-leg exchange, their rows of P with the setup, e is
+    // the tail solution every rank holds -- instead of a second exchange (same arithmetic as on the owning rank: bitwise
+    // the same cycle; PADNE_AMG_EXCHANGE_ALL=1 exchanges as before)
+    const bool local_halo = amg->dist && nl >= 2 && amg->levels[nl - 2].P_halo != nullptr &&
+                            amg->levels[nl - 2].P_halo->vals32 != nullptr && amg->levels[nl - 2].e_ext != nullptr &&
+                            amg->tail_slot_idx != nullptr;
     for (int l = 0; l < nl; ++l) {
         AmgLevel &L = amg->levels[l];
         float *b = (float *)L.b, *xa = (float *)L.xa, *tmp = (float *)L.tmp;
@@ -3036,6 +3086,12 @@ static int amg_apply_f32(padne_ctx *ctx, Amg *amg, const double *r, double *z, d
                 PADNE_TRY(amg_apply(ctx, amg->tail, amg->tail_r, amg->tail_z, nullptr, done_flag, nullptr, false));
                 hipLaunchKernelGGL(f32_from_f64_kernel, dim3(nblk(L.n)), dim3(256), 0, s, L.n,
                                    (const double *)(amg->tail_z + amg->tail_off), (float *)L.xb, done_flag);
+                if (local_halo) {
+                    const int n_slots = ctx->world * L.halo.m;
+                    hipLaunchKernelGGL(tail_to_ext_kernel, dim3(nblk(L.n + n_slots)), dim3(256), 0, s, L.n, n_slots,
+                                       (const double *)amg->tail_z, amg->tail_off, (const int *)amg->tail_slot_idx,
+                                       amg->levels[nl - 2].e_ext, done_flag);
+                }
                 PADNE_HIP_CHECK(hipGetLastError());
                 break;
             }
@@ -3078,7 +3134,11 @@ static int amg_apply_f32(padne_ctx *ctx, Amg *amg, const double *r, double *z, d
         }
         PADNE_TRY(launch_spmv_f32(ctx, L.P, SPMV_ADD, (const float *)amg->levels[l + 1].xb, xa, nullptr, done_flag,
                                   nullptr, nullptr, 0.f));
-        if (amg->dist) PADNE_TRY(halo_exchange_plan_f32(ctx, L.halo, xa, done_flag));
+        if (amg->dist && local_halo && l == nl - 2)
+            PADNE_TRY(launch_spmv_f32(ctx, L.P_halo, SPMV_ADD, (const float *)L.e_ext, xa + L.n, nullptr, done_flag, nullptr,
+                                      nullptr, 0.f));
+        else if (amg->dist)
+            PADNE_TRY(halo_exchange_plan_f32(ctx, L.halo, xa, done_flag));
         if (l > 0)
             PADNE_TRY(launch_spmv_f32(ctx, L.A, SPMV_JACOBI, xa, (float *)L.xb, nullptr, done_flag, b, L.A->dinv32,
                                       (float)L.jac));
