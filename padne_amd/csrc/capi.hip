@@ -53,6 +53,8 @@ void *pool_alloc(padne_ctx *ctx, size_t bytes) {
         return p;
     }
     void *p = nullptr;
+    static const bool trace = getenv("PADNE_POOL_TRACE") != nullptr;      // every miss of the cache (steady state: none)
+    if (trace) fprintf(stderr, "[pool] %s hipMalloc %zu bytes (cached %zu)\n", ctx->is_aux ? "aux" : "main", want, ctx->pool_cached_bytes);
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) {   // give cached blocks back to the driver and retry once
         (void)hipGetLastError();
@@ -81,6 +83,7 @@ void pool_free(padne_ctx *ctx, void *p) {
         return;
     }
     if (ctx->pool_cached_bytes + it->second > kPoolCacheLimit) {
+        if (getenv("PADNE_POOL_TRACE") != nullptr) fprintf(stderr, "[pool] cache limit: hipFree %zu bytes\n", it->second);
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipFree(p);
         ctx->pool_sizes.erase(it);
