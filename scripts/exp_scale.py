@@ -33,4 +33,4 @@ for nx in [int(a) for a in (sys.argv[1:] or ["2236", "3162"])]:
     out[str(nx)] = rec
     print(json.dumps(rec), flush=True)
     del A, b, x, xr, y, L
-json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r01_scale.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", os.environ.get("PADNE_ROUND", "r02") + "_scale.json"), "w"), indent=1)
