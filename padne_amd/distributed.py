@@ -48,6 +48,14 @@ class RankPlan:
     n_owned_reduced: int
     export_reduced: np.ndarray     # int32: reduced owned indices of the exported unknowns, export order
     partial_mesh: bool = False     # the mesh blocks are pieces of larger meshes (strip partition)
+    # index reduction (voltage sources, several known potentials): an unknown is either KNOWN (c = its potential) or a
+    # member of a free group, v[u] = y[group] + c[u]; a group is named by its smallest member (its representative) and
+    # owned -- all its members' rows -- by the representative's rank
+    reps_owned: np.ndarray = None  # int64: representatives this rank owns, ascending = order of the reduced owned rows
+    rhs_rows: np.ndarray = None    # r over the local assembly unknowns (zero on rows of other ranks)
+    c_local: np.ndarray = None     # known part over the local assembly unknowns
+    rep_global: np.ndarray = None  # int64 over all unknowns: representative, -1 = known
+    c_global: np.ndarray = None    # known part over all unknowns
 
     @property
     def n_owned_vertices(self) -> int:           # (name kept from the layer-only plan: owned unknowns incl. ground)
@@ -142,20 +150,42 @@ def owners_of_unknowns(meshes, n_unknowns: int, world: int, links=None) -> np.nd
 
 
 def build_partition(meshes, n_unknowns: int, coo, rhs: np.ndarray, ground: int, owner: np.ndarray, rank: int,
-                    world: int) -> RankPlan:
+                    world: int, index_map: np.ndarray = None, c: np.ndarray = None) -> RankPlan:
     """Plan of ``rank`` for an arbitrary ownership of the unknowns.
 
     ``meshes``: (xy, tri, sigma, layer) in global numbering order (vertices first, ``solver.py:221-229``);
     ``coo = (rows, cols, vals)``: lumped stamps on global unknowns in stamp order, WITHOUT the ground row / column
     (``ground`` is eliminated: it is 0 V by definition, ``solver.py:558-560``).  Deterministic and identical on every
-    rank for the shared parts (export lists of all ranks)."""
+    rank for the shared parts (export lists of all ranks).
+
+    ``index_map`` / ``c`` (``reduction.Reduction.index_map`` / ``.c`` over the potential unknowns): the index reduction of
+    a system with voltage sources -- unknowns with the same non-negative ``index_map`` form one reduced unknown
+    (``v[u] = y + c[u]``), negative ones are known (``v[u] = c[u]``: the ground, nodes tied to it by sources, pins of
+    floating copper).  The rows of a group are summed on the rank that owns its representative (smallest member); known
+    unknowns have no row and no exchange slot, their columns go into the right-hand side (``DistributedSolver``)."""
     rows_g, cols_g, vals_g = (np.asarray(a) for a in coo)
     rows_g = rows_g.astype(np.int64)
     cols_g = cols_g.astype(np.int64)
-    owner = np.asarray(owner, dtype=np.int32)
+    owner = np.array(owner, dtype=np.int32)
     sizes = np.array([len(m[0]) for m in meshes], dtype=np.int64)
     offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     n_vert = int(offs[-1])
+    if index_map is None:                                        # the only constraint is the ground
+        known = np.zeros(n_unknowns, dtype=bool)
+        known[ground] = True
+        rep = np.arange(n_unknowns, dtype=np.int64)
+        rep[ground] = -1
+        c = np.zeros(n_unknowns)
+    else:
+        imap = np.asarray(index_map)[:n_unknowns].astype(np.int64)
+        c = np.asarray(c, dtype=np.float64)[:n_unknowns]
+        known = imap < 0
+        free = np.flatnonzero(~known)
+        first = np.full(int(imap.max()) + 1 if len(free) else 0, n_unknowns, dtype=np.int64)
+        np.minimum.at(first, imap[free], free)
+        rep = np.full(n_unknowns, -1, dtype=np.int64)
+        rep[free] = first[imap[free]]
+        owner[free] = owner[rep[free]]                           # a group lives where its representative lives
     # ---- who needs what: (unknown, needing rank) pairs from mesh edges across a cut and from lumped stamps ----------
     need_u, need_r = [], []
     tri_mine = []
@@ -180,7 +210,9 @@ def build_partition(meshes, n_unknowns: int, coo, rhs: np.ndarray, ground: int, 
     need_r.append(owner[rows_g[cross]])
     need_u = np.concatenate(need_u) if need_u else np.zeros(0, np.int64)
     need_r = np.concatenate(need_r) if need_r else np.zeros(0, np.int32)
-    keep = need_u != ground                                      # the ground is never exchanged: its value is 0
+    keep = ~known[need_u]                                        # known potentials are never exchanged
+    need_u, need_r = rep[need_u[keep]], need_r[keep]             # what travels is the group's value: asked of its representative
+    keep = owner[need_u] != need_r                               # (a member of a group this very rank owns)
     need_u, need_r = need_u[keep], need_r[keep]
     exports = [np.unique(need_u[owner[need_u] == q]) for q in range(world)]
     m = int(max((len(e) for e in exports), default=0))
@@ -205,16 +237,16 @@ def build_partition(meshes, n_unknowns: int, coo, rhs: np.ndarray, ground: int, 
             partial = True
         local_meshes.append((np.ascontiguousarray(np.asarray(xy)[vg - offs[mi]]), tl, float(s), int(l)))
     # ---- relabelling maps ------------------------------------------------------------------------------------------------
-    own_red = owned[owned != ground]
+    own_red = np.unique(rep[owned][~known[owned]])               # representatives owned here = the reduced owned rows
     n_red = len(own_red)
     is_owned = owner[U] == rank
     row_map = np.full(len(U), -1, dtype=np.int32)
-    sel = is_owned & (U != ground)
-    row_map[sel] = np.searchsorted(own_red, U[sel]).astype(np.int32)
+    sel = is_owned & ~known[U]
+    row_map[sel] = np.searchsorted(own_red, rep[U[sel]]).astype(np.int32)
     col_map = row_map.copy()
-    rem = ~is_owned & (U != ground)
+    rem = ~is_owned & ~known[U]
     if rem.any():
-        ur = U[rem]
+        ur = rep[U[rem]]
         orr = owner[ur]
         slot = np.empty(len(ur), dtype=np.int64)
         for q in range(world):
@@ -234,12 +266,15 @@ def build_partition(meshes, n_unknowns: int, coo, rhs: np.ndarray, ground: int, 
     coo_rows = np.searchsorted(U, rows_g[mine_rows])
     coo_cols = np.searchsorted(U, cols_g[mine_rows])
     g_pos = np.flatnonzero(owned == ground)
+    rhs = np.asarray(rhs, dtype=np.float64)
+    rhs_rows = np.where(is_owned, rhs[U], 0.0)
     return RankPlan(rank=rank, world=world, meshes=local_meshes, local_global=U, owned_global=owned,
                     ground_local=int(g_pos[0]) if len(g_pos) else -1, m=m, export_owned=export_owned,
                     n_local_unknowns=len(U), coo_rows=coo_rows.astype(np.int64), coo_cols=coo_cols.astype(np.int64),
                     coo_vals=np.asarray(vals_g, dtype=np.float64)[mine_rows], rhs_local=np.asarray(rhs, dtype=np.float64)[owned],
                     row_map=row_map, col_map=col_map, n_owned_reduced=n_red, export_reduced=export_red,
-                    partial_mesh=partial)
+                    partial_mesh=partial, reps_owned=own_red, rhs_rows=rhs_rows, c_local=c[U].copy(), rep_global=rep,
+                    c_global=c)
 
 
 def resistor_stamps(ra, rb, rr):
@@ -269,22 +304,36 @@ def build_layer_partition(sysm: SyntheticSystem, rank: int, world: int) -> RankP
 def build_problem_partition(meshes, conductances, mesh_layers, stamps, rhs: np.ndarray, n_potential: int, rank: int,
                             world: int) -> RankPlan:
     """Plan of ``rank`` for an assembled Problem (what ``solver.solve_meshed`` has after numbering and stamp listing):
-    ``meshes`` are :class:`padne_amd.mesh.Mesh`, ``stamps`` the :class:`padne_amd.solver.StampList`.  Supported: the
-    systems whose only constraint is the ground (resistors, current sources, vias); voltage sources and regulators
-    need the index reduction of ``reduction.py`` on every rank and are not distributed yet."""
-    cons = [c for c in stamps.constraints]
-    if len(cons) != 1 or cons[0].n >= 0:
-        raise NotImplementedError("the row-partitioned path handles resistors and current sources; voltage sources / "
-                                  "regulators are solved on one GPU")
-    ground = int(cons[0].p)
+    ``meshes`` are :class:`padne_amd.mesh.Mesh`, ``stamps`` the :class:`padne_amd.solver.StampList``.
+
+    Resistors, current sources, vias and VOLTAGE SOURCES: the index reduction of ``reduction.py`` (ground, source-tied
+    groups, pins of floating copper) is computed on every rank -- it is index logic on the lumped elements -- and the
+    partition is one of the REDUCED unknowns (see :func:`build_partition`).  Regulators (constraints that couple other
+    rows through their multiplier, ``Constraint.gamma``) need one extra solve each and stay on one GPU."""
+    from .reduction import KKTLayout, build_reduction, floating_component_pins
+    cons = list(stamps.constraints)
+    if any(getattr(cst, "gamma", None) for cst in cons):
+        raise NotImplementedError("the row-partitioned path handles resistors, current and voltage sources; regulators "
+                                  "are solved on one GPU")
+    rhs = np.asarray(rhs, dtype=np.float64)
+    for cst in cons:                                             # multiplier rows take their right-hand side from r
+        cst.value = float(rhs[cst.index])
+    layout = KKTLayout(size=int(stamps.shape[0]), n_potential=int(n_potential), constraints=cons)
+    ground = int(layout.ground_constraint.p)
     rows, cols, vals = stamps.arrays()
-    keep = (rows < n_potential) & (cols < n_potential)            # drop the ground row / column of the KKT layout
+    keep = (rows < n_potential) & (cols < n_potential)            # drop the multiplier rows / columns of the KKT layout
     ms = [(m.points, m.triangles, float(s), int(l)) for m, s, l in zip(meshes, conductances, mesh_layers)]
     off = rows != cols
     links = np.stack([rows[keep & off], cols[keep & off]], axis=1)
-    owner = owners_of_unknowns(ms, n_potential, world, links)
-    return build_partition(ms, n_potential, (rows[keep], cols[keep], vals[keep]), np.asarray(rhs)[:n_potential], ground,
-                           owner, rank, world)
+    mesh_offsets = np.concatenate([[0], np.cumsum([len(m.points) for m in meshes])]).astype(np.int64)
+    pins = floating_component_pins(n_potential, ground, cons, mesh_offsets=mesh_offsets,
+                                   links=np.unique(np.sort(links, axis=1), axis=0) if len(links) else links)
+    red = build_reduction(layout, pins)
+    ties = np.array([[cst.p, cst.n] for cst in cons if cst.n >= 0], dtype=np.int64).reshape(-1, 2)
+    owner = owners_of_unknowns(ms, n_potential, world, np.concatenate([links, ties]) if len(ties) else links)
+    plain = len(cons) == 1 and not pins                           # only the ground: the plan of the earlier rounds, bit for bit
+    return build_partition(ms, n_potential, (rows[keep], cols[keep], vals[keep]), rhs[:n_potential], ground, owner, rank,
+                           world, None if plain else red.index_map[:n_potential], None if plain else red.c[:n_potential])
 
 
 def reduced_local_map(plan: RankPlan):
@@ -339,15 +388,19 @@ class DistributedSolver:
             self.A.set_preconditioner_block(self.A_block)
         ctx.synchronize()
         self.t_reduce = time.perf_counter() - t0
+        self._Lc = L.matvec(plan.c_local) if plan.c_local is not None and np.any(plan.c_local) else None
         L.close()
         self.n_owned = n_owned
         ctx.set_halo(n_owned, plan.m, plan.export_reduced)
-        own = plan.owned_global
-        keep = np.ones(len(own), dtype=bool)
-        if plan.ground_local >= 0:
-            keep[plan.ground_local] = False
-        self.owned_reduced_global = own[keep]
-        self.b = ctx.to_device(-plan.rhs_local[keep])
+        # b = sum over a group's rows of (L c - r): c = known part of the potentials (zero without sources)
+        resid = -np.asarray(plan.rhs_rows, dtype=np.float64)
+        if plan.c_local is not None and np.any(plan.c_local):
+            resid = resid + self._Lc
+        sel = plan.row_map >= 0
+        b_red = np.bincount(plan.row_map[sel], weights=resid[sel], minlength=n_owned).astype(np.float64)
+        self.owned_reduced_global = plan.reps_owned
+        self.b_norm2 = float(b_red @ b_red)                      # this rank's share of ||b||^2
+        self.b = ctx.to_device(b_red)
         self.x = ctx.empty(n_owned)
         self.nnz = self.A.nnz
         self.spmv_bytes = 12 * self.A.nnz + 20 * n_owned + 4
@@ -364,15 +417,31 @@ def solve_partitioned(plan: RankPlan, ctx, dist=None, team=None, rtol: float = 1
     """Solve and return the potentials of ALL unknowns on every rank (ground = 0).  ``gather(values, indices)``
     collects (array, array) pairs from all ranks into lists; with ``dist`` it defaults to ``all_gather_object``."""
     ds = DistributedSolver(ctx, plan, dist=dist, team=team)
-    res = ds.solve(rtol=rtol)
-    mine = (ds.owned_reduced_global, ds.solution())
-    if gather is None:
+
+    def collect(obj):
+        if gather is not None:
+            return gather(obj)
         parts = [None] * plan.world
-        dist.all_gather_object(parts, mine)
-    else:
-        parts = gather(mine)
+        dist.all_gather_object(parts, obj)
+        return parts
+    # the reference's absolute residual bar (1e-9, tests/test_solver.py:2083-2089) as on one GPU: a large right-hand side
+    # tightens the relative tolerance (solver._effective_rtol), decided from the global norm so that all ranks agree
+    from . import solver as _solver
+    b_norm = float(np.sqrt(sum(collect(ds.b_norm2))))
+    if b_norm > 0.0 and rtol * b_norm > _solver.ABS_RESIDUAL_TARGET:
+        rtol = max(_solver.ABS_RESIDUAL_TARGET / b_norm, _solver.RTOL_FLOOR)
+    res = ds.solve(rtol=rtol)
+    parts = collect((ds.owned_reduced_global, ds.solution()))
     n = max(int(p[0].max()) + 1 if len(p[0]) else 0 for p in parts)
-    v = np.zeros(max(n, int(plan.owned_global.max()) + 1 if len(plan.owned_global) else 0))
+    n = max(n, int(plan.owned_global.max()) + 1 if len(plan.owned_global) else 0,
+            len(plan.rep_global) if plan.rep_global is not None else 0)
+    y = np.zeros(n)                                              # value of every group at its representative
     for idx, vals in parts:
-        v[idx] = vals
+        y[idx] = vals
+    if plan.rep_global is None:
+        return y, res
+    v = np.zeros(n)
+    v[:len(plan.c_global)] = plan.c_global
+    free = np.flatnonzero(plan.rep_global >= 0)
+    v[free] += y[plan.rep_global[free]]
     return v, res

@@ -715,7 +715,7 @@ def solve_meshed(prob, meshes, mesh_index_to_layer_index, *, filtered_networks=N
 
     ``partition``: a :class:`padne_amd.distributed.Partition` -- the rows are dealt to the GPUs of the node (by layer, or
     by strips of layers when there are fewer layers than GPUs); every rank calls this with the same Problem and gets the
-    same Solution.  Resistor / current-source problems only (voltage sources and regulators stay on one GPU)."""
+    same Solution.  Resistors, current and voltage sources (regulators stay on one GPU)."""
     meshes = [m if isinstance(m, mesh.Mesh) else mesh.Mesh.from_reference(m) for m in meshes]
     if filtered_networks is None:
         filtered_networks = list(prob.networks)

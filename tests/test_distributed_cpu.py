@@ -10,6 +10,7 @@ import socket
 import numpy as np
 import pytest
 import scipy.sparse as sp
+import scipy.sparse.linalg as spla
 
 torch = pytest.importorskip("torch")
 import torch.distributed as dist  # noqa: E402
@@ -44,11 +45,18 @@ def _local_matrix(plan):
     row_map, col_map, n_owned, export_red = distributed.reduced_local_map(plan)
     keep = (row_map[L.row] >= 0) & (col_map[L.col] >= 0)
     A = sp.coo_matrix((-L.data[keep], (row_map[L.row[keep]], col_map[L.col[keep]])), shape=(n_owned, plan.n_cols)).tocsr()
+    # right-hand side as DistributedSolver forms it: a group's rows of (L c - r), c = known part of the potentials
+    resid = -plan.rhs_rows
+    if np.any(plan.c_local):
+        resid = resid + sp.csr_matrix(L) @ plan.c_local
+    sel = row_map >= 0
+    b = np.bincount(row_map[sel], weights=resid[sel], minlength=n_owned)
     own = np.ones(len(plan.owned_global), dtype=bool)
     if plan.ground_local >= 0:
         own[plan.ground_local] = False
-    b = -plan.rhs_local[own]
-    return A, b, n_owned, export_red, plan.owned_global[own]
+    if plan.rep_global is None or np.array_equal(plan.reps_owned, plan.owned_global[own]):
+        assert np.array_equal(b, -plan.rhs_local[own] + 0.0)      # the plan of a ground-only system: as before
+    return A, b, n_owned, export_red, plan.reps_owned
 
 
 def _worker(rank, world, port, nl, nx, ny, lattice, out):
@@ -214,3 +222,71 @@ def test_a_via_on_the_ground_vertex_is_a_dirichlet_term():
         for q, (_, _, _, ex_q, idx_q) in enumerate(mats):
             ext[n_owned + q * p.m:n_owned + q * p.m + len(ex_q)] = v_ref[idx_q][ex_q]
         assert np.abs(A @ ext - b).max() <= 1e-9 * max(np.abs(b).max(), 1.0)
+
+
+def _problem_stamps(name):
+    """Numbering and stamp list of a problem-level fixture, by the product's own host logic (no GPU involved)."""
+    import helpers as H
+    from padne_amd import mesh, problem, solver
+    g = H.load_golden(name)
+    prob, nodes, flat = H.build_problem(g, problem)
+    ms = H.problem_meshes(g)
+    meshes = [mesh.Mesh(xy, tri) for xy, tri, _ in ms]
+    mesh_layers = [int(l) for _, _, l in ms]
+    vindex = solver.VertexIndexer.create(meshes)
+    node_indexer = solver.NodeIndexer.create(prob, meshes, mesh_layers, vindex, list(prob.networks))
+    stamps, r = solver.allocate_system(vindex, node_indexer)
+    for network in prob.networks:
+        solver.stamp_network_into_system(network, node_indexer, stamps, r)
+    solver.setup_ground_node(solver.find_best_ground_node_index(prob, node_indexer), stamps, r)
+    n_pot = len(vindex) + node_indexer.internal_node_count
+    conductances = [prob.layers[l].conductance for l in mesh_layers]
+    return g, meshes, conductances, mesh_layers, stamps, r, n_pot
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_voltage_sources_in_the_row_partitioned_plan(world):
+    """Config C1 (four layers, via rings, three resistors, ONE VOLTAGE SOURCE: the reference's via_tht_4layer board) dealt
+    to several ranks.  The index reduction (the source ties two unknowns into one group, a group is owned -- all its
+    rows -- by its representative's rank, known potentials go into the right-hand side) is part of the plan: the ranks'
+    pieces, put together the way the exchange slots say, are a symmetric positive definite system whose solution,
+    expanded, is the reference's own ``v`` for this Problem."""
+    g, meshes, conductances, mesh_layers, stamps, r, n_pot = _problem_stamps("problem_c1")
+    assert sum(1 for c in stamps.constraints if c.n >= 0) == 1
+    plans = [distributed.build_problem_partition(meshes, conductances, mesh_layers, stamps, r, n_pot, rank, world)
+             for rank in range(world)]
+    pieces = [_local_matrix(p) for p in plans]
+    reps = np.concatenate([pc[4] for pc in pieces])
+    assert len(np.unique(reps)) == len(reps)                      # every group has one owner
+    order = np.argsort(reps)
+    glob = np.empty(len(reps), dtype=np.int64)
+    glob[order] = np.arange(len(reps))                            # global reduced number of (rank, owned row)
+    first = np.concatenate([[0], np.cumsum([pc[2] for pc in pieces])])
+    m = plans[0].m
+    rows, cols, vals, b = [], [], [], np.zeros(len(reps))
+    for q, (A, bq, n_owned, export_red, _) in enumerate(pieces):
+        A = A.tocoo()
+        col_glob = np.full(plans[q].n_cols, -1, dtype=np.int64)
+        col_glob[:n_owned] = glob[first[q]:first[q] + n_owned]
+        for p2, (_, _, _, ex2, _) in enumerate(pieces):
+            col_glob[n_owned + p2 * m:n_owned + p2 * m + len(ex2)] = glob[first[p2] + ex2]
+        assert (col_glob[A.col] >= 0).all()
+        rows.append(glob[first[q] + A.row])
+        cols.append(col_glob[A.col])
+        vals.append(A.data)
+        b[glob[first[q]:first[q] + n_owned]] = bq
+    Ag = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(len(reps),) * 2).tocsc()
+    assert abs(Ag - Ag.T).max() <= 1e-12 * abs(Ag).max()
+    y = spla.spsolve(Ag, b)
+    y_at_rep = np.zeros(n_pot)
+    y_at_rep[np.sort(reps)] = y
+    plan = plans[0]
+    v = plan.c_global.copy()
+    free = plan.rep_global >= 0
+    v[free] += y_at_rep[plan.rep_global[free]]
+    v_ref = g["v"][:n_pot]
+    assert np.abs(v - v_ref).max() <= 1e-9 * np.abs(v_ref).max()
+    # the source ties two unknowns that different ranks would own by layer: both rows went to one rank
+    vs = next(c for c in stamps.constraints if c.n >= 0)
+    assert plan.rep_global[vs.p] == plan.rep_global[vs.n] or plan.rep_global[vs.p] < 0 or plan.rep_global[vs.n] < 0
+    assert abs((v[vs.p] - v[vs.n]) - vs.value) <= 1e-12 * max(1.0, abs(vs.value))

@@ -1503,16 +1503,10 @@ def _two_layer_problem(n_layers=2):
     return problem.Problem(layers=layers, networks=nets)
 
 
-@pytest.mark.parametrize("n_layers,world", [(2, 2), (1, 2), (2, 4)])
-def test_solve_with_the_rows_dealt_to_several_ranks(ctx, n_layers, world):
-    """``solve(prob, partition=...)``: a Problem (not only a SyntheticSystem) through the row-partitioned path -- by layer
-    (2 layers, 2 ranks), by strips of a layer (1 layer on 2 ranks, 2 layers on 4), with an internal node and a resistor
-    on the ground vertex -- gives every rank the Solution of the single-GPU solve."""
+def solve_on_team(prob, mesher, world):
+    """``solver.solve(prob, partition=...)`` on ``world`` threads, one context each on GPU 0: the Solutions of all ranks."""
     import threading
     from padne_amd import distributed
-    prob = _two_layer_problem(n_layers)
-    mesher = structured.StructuredMesher(mesh.Mesher.Config(maximum_size=0.25), jitter=0.2, seed=6)
-    ref = solver.solve(prob, mesher=mesher)
     team = _hip.LocalTeam(world)
     barrier = threading.Barrier(world)
     board = [None] * world
@@ -1540,20 +1534,73 @@ def test_solve_with_the_rows_dealt_to_several_ranks(ctx, n_layers, world):
     [t.start() for t in th]
     [t.join(timeout=300) for t in th]
     assert not errors, errors
-    scale = max(np.abs(z.values).max() for ls in ref.layer_solutions for z in ls.potentials)
+    assert all(sol is not None for sol in sols)
+    return sols, team
+
+
+@pytest.mark.parametrize("n_layers,world", [(2, 2), (1, 2), (2, 4)])
+def test_solve_with_the_rows_dealt_to_several_ranks(ctx, n_layers, world):
+    """``solve(prob, partition=...)``: a Problem (not only a SyntheticSystem) through the row-partitioned path -- by layer
+    (2 layers, 2 ranks), by strips of a layer (1 layer on 2 ranks, 2 layers on 4), with an internal node and a resistor
+    on the ground vertex -- gives every rank the Solution of the single-GPU solve.  Also with a VOLTAGE SOURCE between the
+    layers (its two terminals become one unknown, owned by one rank)."""
+    from padne_amd import distributed
+    prob = _two_layer_problem(n_layers)
+    mesher = structured.StructuredMesher(mesh.Mesher.Config(maximum_size=0.25), jitter=0.2, seed=6)
+    a, b = prob.networks[-1].connections
+    ca, cb = problem.Connection(layer=a.layer, point=a.point), problem.Connection(layer=b.layer, point=b.point)
+    with_source = problem.Problem(layers=prob.layers, networks=prob.networks + [problem.Network(
+        connections=[ca, cb], elements=[problem.VoltageSource(p=ca.node_id, n=cb.node_id, voltage=0.25)])])
+    for pr, zero_ground_current in ((prob, True), (with_source, True)):
+        ref = solver.solve(pr, mesher=mesher)
+        sols, team = solve_on_team(pr, mesher, world)
+        scale = max(np.abs(z.values).max() for ls in ref.layer_solutions for z in ls.potentials)
+        for sol in sols:
+            for ls, lr in zip(sol.layer_solutions, ref.layer_solutions):
+                for z, zr, pw, pr_ in zip(ls.potentials, lr.potentials, ls.power_densities, lr.power_densities):
+                    assert np.abs(z.values - zr.values).max() <= 1e-9 * scale
+                    assert np.abs(pw.values - pr_.values).max() <= 1e-7 * max(pr_.values.max(), 1e-300)
+            assert abs(sol.solver_info.ground_node_current) < 1e-12 and sol.solver_info.residual_norm < 1e-9
+            assert sol.solver_info.iterations < 80
+    with pytest.raises(NotImplementedError):                          # regulators stay on one GPU
+        reg = problem.Problem(layers=prob.layers, networks=prob.networks + [problem.Network(
+            connections=[a, b], elements=[problem.VoltageRegulator(v_p=a.node_id, v_n=b.node_id, s_f=a.node_id,
+                                                                   s_t=b.node_id, voltage=1.0, gain=1.0)])])
+        solver.solve(reg, mesher=mesher, partition=distributed.Partition(rank=0, world=2, team=team))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_config_c1_with_its_voltage_source_on_several_ranks(ctx, world):
+    """Config C1 of BASELINE.json (the via_tht_4layer-like board: four layers, via rings, three resistors, one 1 V
+    source) through ``solve(prob, partition=...)``: every rank gets the potentials the reference's own direct solve
+    returned for this Problem (``tests/golden/problem_c1.npz``)."""
+    g = H.load_golden("problem_c1")
+    prob, nodes, flat_elements = H.build_problem(g, problem)
+    ms = H.problem_meshes(g)
+    by_geom, per_layer = {}, {}
+    for xy, tri, layer in ms:
+        per_layer.setdefault(layer, []).append(mesh.Mesh(xy, tri))
+    layers = []
+    for li, lay in enumerate(prob.layers):
+        geoms = H.Geoms(len(per_layer.get(li, [])))
+        for token, m in zip(geoms.geoms, per_layer.get(li, [])):
+            by_geom[id(token)] = m
+        layers.append(problem.Layer(shape=geoms, name=lay.name, conductance=lay.conductance))
+    remap = {id(old): new for old, new in zip(prob.layers, layers)}
+    nets = [problem.Network(connections=[problem.Connection(layer=remap[id(c.layer)], point=c.point, node_id=c.node_id)
+                                         for c in net.connections], elements=list(net.elements)) for net in prob.networks]
+    prob = problem.Problem(layers=layers, networks=nets)
+    sols, _ = solve_on_team(prob, FixtureMesher(by_geom), world)
+    n_vert = sum(len(m[0]) for m in ms)
+    scale = np.abs(g["v"][:n_vert]).max()
     for sol in sols:
-        assert sol is not None
-        for ls, lr in zip(sol.layer_solutions, ref.layer_solutions):
-            for z, zr, pw, pr in zip(ls.potentials, lr.potentials, ls.power_densities, lr.power_densities):
-                assert np.abs(z.values - zr.values).max() <= 1e-9 * scale
-                assert np.abs(pw.values - pr.values).max() <= 1e-7 * max(pr.values.max(), 1e-300)
-        assert abs(sol.solver_info.ground_node_current) < 1e-12 and sol.solver_info.residual_norm < 1e-9
-        assert sol.solver_info.iterations < 80
-    with pytest.raises(NotImplementedError):                          # voltage sources stay on one GPU
-        a, b = prob.networks[-1].connections
-        vs = problem.Problem(layers=prob.layers, networks=prob.networks + [problem.Network(
-            connections=[a, b], elements=[problem.VoltageSource(p=a.node_id, n=b.node_id, voltage=1.0)])])
-        solver.solve(vs, mesher=mesher, partition=distributed.Partition(rank=0, world=2, team=team))
+        for li, ls in enumerate(sol.layer_solutions):
+            idx = [i for i, m in enumerate(ms) if m[2] == li]
+            for i, zf, tf in zip(idx, ls.potentials, ls.power_densities):
+                assert np.abs(zf.values - g[f"pot{i}"]).max() <= REL_TOL * scale
+                assert np.abs(tf.values - g[f"pow{i}"]).max() <= 1e-7 * max(g[f"pow{i}"].max(), 1e-300)
+        assert abs(sol.solver_info.ground_node_current - float(g["ground_node_current"])) <= 1e-8 * np.abs(g["v"][n_vert:]).max()
+        assert sol.solver_info.residual_norm < 1e-9
 
 
 def test_row_partitioned_hierarchy_with_several_exchanged_levels(monkeypatch):
