@@ -53,9 +53,12 @@ class RankPlan:
     # owned -- all its members' rows -- by the representative's rank
     reps_owned: np.ndarray = None  # int64: representatives this rank owns, ascending = order of the reduced owned rows
     rhs_rows: np.ndarray = None    # r over the local assembly unknowns (zero on rows of other ranks)
+    rhs_owner_mask: np.ndarray = None   # bool over the local assembly unknowns: this rank assembled the whole row
     c_local: np.ndarray = None     # known part over the local assembly unknowns
     rep_global: np.ndarray = None  # int64 over all unknowns: representative, -1 = known
     c_global: np.ndarray = None    # known part over all unknowns
+    reduction: object = None       # the reduction.Reduction behind index_map / c (multiplier recovery, regulators)
+    rhs_full: np.ndarray = None    # r of the whole KKT system (multiplier rows included)
 
     @property
     def n_owned_vertices(self) -> int:           # (name kept from the layer-only plan: owned unknowns incl. ground)
@@ -273,8 +276,8 @@ def build_partition(meshes, n_unknowns: int, coo, rhs: np.ndarray, ground: int, 
                     n_local_unknowns=len(U), coo_rows=coo_rows.astype(np.int64), coo_cols=coo_cols.astype(np.int64),
                     coo_vals=np.asarray(vals_g, dtype=np.float64)[mine_rows], rhs_local=np.asarray(rhs, dtype=np.float64)[owned],
                     row_map=row_map, col_map=col_map, n_owned_reduced=n_red, export_reduced=export_red,
-                    partial_mesh=partial, reps_owned=own_red, rhs_rows=rhs_rows, c_local=c[U].copy(), rep_global=rep,
-                    c_global=c)
+                    partial_mesh=partial, reps_owned=own_red, rhs_rows=rhs_rows, rhs_owner_mask=is_owned,
+                    c_local=c[U].copy(), rep_global=rep, c_global=c)
 
 
 def resistor_stamps(ra, rb, rr):
@@ -306,15 +309,13 @@ def build_problem_partition(meshes, conductances, mesh_layers, stamps, rhs: np.n
     """Plan of ``rank`` for an assembled Problem (what ``solver.solve_meshed`` has after numbering and stamp listing):
     ``meshes`` are :class:`padne_amd.mesh.Mesh`, ``stamps`` the :class:`padne_amd.solver.StampList``.
 
-    Resistors, current sources, vias and VOLTAGE SOURCES: the index reduction of ``reduction.py`` (ground, source-tied
-    groups, pins of floating copper) is computed on every rank -- it is index logic on the lumped elements -- and the
-    partition is one of the REDUCED unknowns (see :func:`build_partition`).  Regulators (constraints that couple other
-    rows through their multiplier, ``Constraint.gamma``) need one extra solve each and stay on one GPU."""
+    Resistors, current sources, vias, VOLTAGE SOURCES and REGULATORS: the index reduction of ``reduction.py`` (ground,
+    source-tied groups, pins of floating copper) is computed on every rank -- it is index logic on the lumped elements --
+    and the partition is one of the REDUCED unknowns (see :func:`build_partition`).  A regulator (a constraint whose
+    multiplier also enters other rows, ``Constraint.gamma``) costs one extra solve with the same matrix
+    (:func:`solve_partitioned`)."""
     from .reduction import KKTLayout, build_reduction, floating_component_pins
     cons = list(stamps.constraints)
-    if any(getattr(cst, "gamma", None) for cst in cons):
-        raise NotImplementedError("the row-partitioned path handles resistors, current and voltage sources; regulators "
-                                  "are solved on one GPU")
     rhs = np.asarray(rhs, dtype=np.float64)
     for cst in cons:                                             # multiplier rows take their right-hand side from r
         cst.value = float(rhs[cst.index])
@@ -332,8 +333,12 @@ def build_problem_partition(meshes, conductances, mesh_layers, stamps, rhs: np.n
     ties = np.array([[cst.p, cst.n] for cst in cons if cst.n >= 0], dtype=np.int64).reshape(-1, 2)
     owner = owners_of_unknowns(ms, n_potential, world, np.concatenate([links, ties]) if len(ties) else links)
     plain = len(cons) == 1 and not pins                           # only the ground: the plan of the earlier rounds, bit for bit
-    return build_partition(ms, n_potential, (rows[keep], cols[keep], vals[keep]), rhs[:n_potential], ground, owner, rank,
+    plan = build_partition(ms, n_potential, (rows[keep], cols[keep], vals[keep]), rhs[:n_potential], ground, owner, rank,
                            world, None if plain else red.index_map[:n_potential], None if plain else red.c[:n_potential])
+    if not plain:
+        plan.reduction = red
+        plan.rhs_full = rhs
+    return plan
 
 
 def reduced_local_map(plan: RankPlan):
@@ -345,7 +350,8 @@ def reduced_local_map(plan: RankPlan):
 class DistributedSolver:
     """Per-rank driver: local assembly, reduction, halo plan, RCCL communicator, solve."""
 
-    def __init__(self, ctx, plan: RankPlan, dist=None, team=None, block_preconditioner: bool = False):
+    def __init__(self, ctx, plan: RankPlan, dist=None, team=None, block_preconditioner: bool = False,
+                 keep_assembly: bool = False):
         """``dist``: an initialised ``torch.distributed`` module (one process per GPU, RCCL), or ``team``: a
         ``_hip.LocalTeam`` whose members are contexts of this process (single-GPU rehearsal, one thread per rank).
 
@@ -389,7 +395,9 @@ class DistributedSolver:
         ctx.synchronize()
         self.t_reduce = time.perf_counter() - t0
         self._Lc = L.matvec(plan.c_local) if plan.c_local is not None and np.any(plan.c_local) else None
-        L.close()
+        self.L_local = L if keep_assembly else None               # kept for the residual rows of the multiplier recovery
+        if not keep_assembly:
+            L.close()
         self.n_owned = n_owned
         ctx.set_halo(n_owned, plan.m, plan.export_reduced)
         # b = sum over a group's rows of (L c - r): c = known part of the potentials (zero without sources)
@@ -408,40 +416,152 @@ class DistributedSolver:
     def solve(self, rtol=1e-12, time_spmv=False, precond="amg", rebuild=False):
         return self.A.solve_spd_dev(self.b, self.x, rtol=rtol, time_spmv=time_spmv, precond=precond, rebuild=rebuild)
 
+    def set_rhs(self, b_owned: np.ndarray):
+        """Another right-hand side over this rank's reduced rows (same matrix, same hierarchy)."""
+        self.b.set(np.ascontiguousarray(b_owned, dtype=np.float64))
+
+    def project_rows(self, rows: dict) -> np.ndarray:
+        """P^T of a sparse vector {unknown: value} restricted to this rank's reduced rows."""
+        plan = self.plan
+        out = np.zeros(self.n_owned)
+        for x, val in rows.items():
+            rep = int(plan.rep_global[x]) if plan.rep_global is not None else int(x)
+            if rep < 0:
+                continue
+            pos = int(np.searchsorted(plan.reps_owned, rep))
+            if pos < len(plan.reps_owned) and plan.reps_owned[pos] == rep:
+                out[pos] += val
+        return out
+
+    def residual_rows(self, v_all: np.ndarray, rows) -> dict:
+        """rho_x = r_x - (L v)_x for the listed unknowns whose rows this rank assembled completely (its own)."""
+        plan = self.plan
+        Lv = self.L_local.matvec(np.ascontiguousarray(v_all[plan.local_global]))
+        out = {}
+        for x in rows:
+            pos = int(np.searchsorted(plan.local_global, x))
+            if pos < len(plan.local_global) and plan.local_global[pos] == x and plan.rhs_owner_mask[pos]:
+                out[int(x)] = float(plan.rhs_rows[pos] - Lv[pos])
+        return out
+
+    def close(self):
+        if self.L_local is not None:
+            self.L_local.close()
+            self.L_local = None
+
     def solution(self) -> np.ndarray:
         """Potentials of the owned unknowns except the ground, in the order of ``owned_reduced_global``."""
         return self.x.numpy()
 
 
-def solve_partitioned(plan: RankPlan, ctx, dist=None, team=None, rtol: float = 1e-12, gather=None):
-    """Solve and return the potentials of ALL unknowns on every rank (ground = 0).  ``gather(values, indices)``
-    collects (array, array) pairs from all ranks into lists; with ``dist`` it defaults to ``all_gather_object``."""
-    ds = DistributedSolver(ctx, plan, dist=dist, team=team)
+class _NoSolve:
+    """Result of a solve whose right-hand side vanishes on every rank."""
+    abs_residual = 0.0
+    iterations = 0
+    rel_residual = 0.0
+    seconds = 0.0
 
-    def collect(obj):
-        if gather is not None:
-            return gather(obj)
-        parts = [None] * plan.world
-        dist.all_gather_object(parts, obj)
-        return parts
-    # the reference's absolute residual bar (1e-9, tests/test_solver.py:2083-2089) as on one GPU: a large right-hand side
-    # tightens the relative tolerance (solver._effective_rtol), decided from the global norm so that all ranks agree
-    from . import solver as _solver
-    b_norm = float(np.sqrt(sum(collect(ds.b_norm2))))
-    if b_norm > 0.0 and rtol * b_norm > _solver.ABS_RESIDUAL_TARGET:
-        rtol = max(_solver.ABS_RESIDUAL_TARGET / b_norm, _solver.RTOL_FLOOR)
-    res = ds.solve(rtol=rtol)
-    parts = collect((ds.owned_reduced_global, ds.solution()))
-    n = max(int(p[0].max()) + 1 if len(p[0]) else 0 for p in parts)
-    n = max(n, int(plan.owned_global.max()) + 1 if len(plan.owned_global) else 0,
-            len(plan.rep_global) if plan.rep_global is not None else 0)
-    y = np.zeros(n)                                              # value of every group at its representative
-    for idx, vals in parts:
-        y[idx] = vals
-    if plan.rep_global is None:
-        return y, res
-    v = np.zeros(n)
-    v[:len(plan.c_global)] = plan.c_global
-    free = np.flatnonzero(plan.rep_global >= 0)
-    v[free] += y[plan.rep_global[free]]
-    return v, res
+
+def solve_partitioned(plan: RankPlan, ctx, dist=None, team=None, rtol: float = 1e-12, gather=None):
+    """Solve and return ``(v, result)`` on every rank.  ``gather(obj)`` collects one Python object per rank into a list;
+    with ``dist`` it defaults to ``all_gather_object``.
+
+    Plans without an index reduction (the ground is the only constraint): ``v`` = potentials of all unknowns, ground 0.
+    Plans of :func:`build_problem_partition` with sources: ``v`` is the whole solution vector of the KKT system like
+    ``solver.solve_system`` returns it -- potentials, then the multiplier currents (sources, regulators, ground row),
+    recovered from the residual rows r - L v of the source-tied unknowns, each computed by the rank that assembled that
+    row.  Every regulator adds one solve with the same matrix and hierarchy (``solver.py`` module docstring, step 3)."""
+    red = plan.reduction
+    ds = DistributedSolver(ctx, plan, dist=dist, team=team, keep_assembly=red is not None)
+    try:
+        def collect(obj):
+            if gather is not None:
+                return gather(obj)
+            parts = [None] * plan.world
+            dist.all_gather_object(parts, obj)
+            return parts
+        # the reference's absolute residual bar (1e-9, tests/test_solver.py:2083-2089) as on one GPU: a large right-hand
+        # side tightens the relative tolerance (solver._effective_rtol), decided from the global norm so that all ranks agree
+        from . import solver as _solver
+
+        def solve_for(b_norm2_local):
+            b_norm = float(np.sqrt(sum(collect(b_norm2_local))))
+            tol = rtol
+            if b_norm > 0.0 and rtol * b_norm > _solver.ABS_RESIDUAL_TARGET:
+                tol = max(_solver.ABS_RESIDUAL_TARGET / b_norm, _solver.RTOL_FLOOR)
+            if b_norm == 0.0:                                     # nothing to solve for (all ranks agree)
+                return _NoSolve(), np.zeros(ds.n_owned)
+            result = ds.solve(rtol=tol)
+            return result, ds.solution()
+
+        n = len(plan.rep_global) if plan.rep_global is not None else 0
+
+        def at_representatives(y_owned):
+            parts = collect((ds.owned_reduced_global, y_owned))
+            size = max([n, int(plan.owned_global.max()) + 1 if len(plan.owned_global) else 0] +
+                       [int(p[0].max()) + 1 if len(p[0]) else 0 for p in parts])
+            y = np.zeros(size)                                    # value of every group at its representative
+            for idx, vals in parts:
+                y[idx] = vals
+            return y
+        res, y_owned = solve_for(ds.b_norm2)
+        y = at_representatives(y_owned)
+        if plan.rep_global is None:
+            return y, res
+        free = np.flatnonzero(plan.rep_global >= 0)
+
+        def expand(y_rep, with_known):
+            v = np.zeros(len(y_rep))
+            if with_known:
+                v[:len(plan.c_global)] = plan.c_global
+            v[free] += y_rep[plan.rep_global[free]]
+            return v
+        v_pot = expand(y, True)
+        if red is None:
+            return v_pot, res
+        # ---- regulators and multiplier currents, as solver.solve_system does on one GPU ----------------------------------
+        N = red.layout.size
+        n_pot = red.layout.n_potential
+        members = sorted({int(x) for mem, cons, _ in red.groups if cons for x in mem})
+
+        def residual_at_members(v_potentials):
+            rho = np.zeros(N)
+            for part in collect(ds.residual_rows(v_potentials, members)):
+                for x, val in part.items():
+                    rho[x] = val
+            return rho
+        Z = []
+        for cst in red.regulators:
+            b_k = ds.project_rows(cst.gamma)
+            ds.set_rhs(b_k)
+            _, z_owned = solve_for(float(b_k @ b_k))
+            Z.append(expand(at_representatives(z_owned), False))
+        mult_known = {}
+        if red.regulators:
+            keys = [cst.index for cst in red.regulators]
+            K = len(keys)
+
+            def currents_for(i_vec):
+                vv = v_pot + sum(i_vec[k] * Z[k] for k in range(K))
+                return red.multipliers(residual_at_members(vv), dict(zip(keys, i_vec)))
+            base = currents_for(np.zeros(K))
+            F0 = np.array([base[k] for k in keys])
+            J = np.zeros((K, K))
+            for k in range(K):
+                e = np.zeros(K)
+                e[k] = 1.0
+                ck = currents_for(e)
+                J[:, k] = np.array([ck[q] for q in keys]) - F0
+            i_reg = np.linalg.solve(np.eye(K) - J, F0)
+            v_pot = v_pot + sum(i_reg[k] * Z[k] for k in range(K))
+            mult_known = dict(zip(keys, i_reg))
+        v = np.zeros(N)
+        v[:n_pot] = v_pot[:n_pot]
+        for idx, val in red.multipliers(residual_at_members(v_pot), mult_known).items():
+            if idx >= 0:                        # negative: the current through the pin of a floating component
+                v[idx] = val
+        for idx, val in mult_known.items():
+            v[idx] = val
+        return v, res
+    finally:
+        ds.close()

@@ -700,10 +700,15 @@ def _solve_partitioned(prob, meshes, mesh_index_to_layer_index, vindex, filtered
     v_pot, res = distributed.solve_partitioned(plan, ctx, dist=partition.dist, team=partition.team, rtol=RTOL,
                                                gather=partition.gather)
     v = np.zeros(stamps.shape[0], dtype=DTYPE)
-    v[:n_pot] = v_pot[:n_pot]
-    # KCL over all potential rows: the mesh and resistor terms cancel, what is left is the ground current (row of
-    # solver.py:558-560) = the net current the sources inject
-    v[-1] = float(np.sum(r[:n_pot]))
+    if plan.reduction is not None:
+        # sources or regulators: the whole solution vector came back -- potentials and the multiplier currents recovered
+        # from the residual rows of the source-tied unknowns (distributed.solve_partitioned)
+        v[:] = v_pot[:len(v)]
+    else:
+        v[:n_pot] = v_pot[:n_pot]
+        # KCL over all potential rows: the mesh and resistor terms cancel, what is left is the ground current (row of
+        # solver.py:558-560) = the net current the sources inject
+        v[-1] = float(np.sum(r[:n_pot]))
     info = SolverInfo(ground_node_current=float(v[-1]), residual_norm=float(res.abs_residual),
                       iterations=int(res.iterations), rel_residual=float(res.rel_residual), solve_seconds=float(res.seconds))
     return v, info
@@ -715,7 +720,7 @@ def solve_meshed(prob, meshes, mesh_index_to_layer_index, *, filtered_networks=N
 
     ``partition``: a :class:`padne_amd.distributed.Partition` -- the rows are dealt to the GPUs of the node (by layer, or
     by strips of layers when there are fewer layers than GPUs); every rank calls this with the same Problem and gets the
-    same Solution.  Resistors, current and voltage sources (regulators stay on one GPU)."""
+    same Solution."""
     meshes = [m if isinstance(m, mesh.Mesh) else mesh.Mesh.from_reference(m) for m in meshes]
     if filtered_networks is None:
         filtered_networks = list(prob.networks)
