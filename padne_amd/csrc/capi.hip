@@ -109,8 +109,6 @@ static int ctx_init_resources(padne_ctx *ctx) {
         hipMalloc((void **)&ctx->scalars, sizeof(double) * 64) != hipSuccess ||
         hipMalloc((void **)&ctx->status, 1024) != hipSuccess ||
         hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void **)&ctx->mailbox, 4096, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
-        hipHostGetDevicePointer((void **)&ctx->mailbox_dev, ctx->mailbox, 0) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming) != hipSuccess) {
         set_error("context creation failed: %s", hipGetErrorString(hipGetLastError()));
@@ -120,8 +118,18 @@ static int ctx_init_resources(padne_ctx *ctx) {
     hipMemsetAsync(ctx->scalars, 0, sizeof(double) * 64, ctx->stream);
     hipMemsetAsync(ctx->status, 0, 1024, ctx->stream);
     hipStreamSynchronize(ctx->stream);
-    memset(ctx->mailbox, 0, 4096);
-    if (getenv("PADNE_NO_MAILBOX") != nullptr) ctx->mailbox_dev = nullptr;
+    // the mailbox is an optimisation: without host-coherent memory (or with PADNE_NO_MAILBOX=1) read_back copies and synchronises
+    if (getenv("PADNE_NO_MAILBOX") == nullptr &&
+        hipHostMalloc((void **)&ctx->mailbox, 4096, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess) {
+        if (hipHostGetDevicePointer((void **)&ctx->mailbox_dev, ctx->mailbox, 0) == hipSuccess) {
+            memset(ctx->mailbox, 0, 4096);
+        } else {
+            (void)hipHostFree(ctx->mailbox);
+            ctx->mailbox = nullptr;
+            ctx->mailbox_dev = nullptr;
+        }
+    }
+    (void)hipGetLastError();
     return PADNE_OK;
 }
 
