@@ -149,7 +149,9 @@ __global__ __launch_bounds__(256) void pcg_update_p_kernel(
     const int P_rz, const double *__restrict__ part_rr, const int P_rr,
     const double *__restrict__ part_pq, const int P_pq, const double *__restrict__ r,
     const double *__restrict__ dinv, double *__restrict__ p, PcgStatus *__restrict__ st,
-    const int max_iter) {
+    const int max_iter, double *__restrict__ rec_next = nullptr, double *__restrict__ rec_pq = nullptr) {
+    // rec_next / rec_pq (the Lanczos estimates of the multigrid setup): the step's scalars are left for the host --
+    // r.z and r.r after the step, p.q of the step -- instead of two one-workgroup fold launches per step
     __shared__ double red[4];
     if (st->done) return;
     const double rz_new = block_total(part_rz_new, P_rz, red);
@@ -161,6 +163,11 @@ __global__ __launch_bounds__(256) void pcg_update_p_kernel(
     if (blockIdx.x == 0) {
         const double rr = block_total(part_rr, P_rr, red);
         const double pq = block_total(part_pq, P_pq, red);
+        if (threadIdx.x == 0 && rec_next != nullptr) {
+            rec_next[0] = rz_new;
+            rec_next[1] = rr;
+            rec_pq[0] = pq;
+        }
         // all other workgroups have already passed (or will pass) their own `done` read with the
         // value 0 only if they were dispatched before this store lands; either way x and r are
         // complete (K2), and p is dead once `done` is set.
@@ -1264,23 +1271,27 @@ int lanczos_enqueue(padne_ctx *ctx, const padne_csr *a, int steps, LanczosJob *j
         double *rz_new_part = slot(ctx, parity ? SLOT_RZ0 : SLOT_RZ1);
         if (dist) PADNE_TRY(halo_exchange_plan(ctx, *plan, p, nullptr));
         PADNE_TRY(launch_spmv_mode(ctx, a, SPMV_DOT_AUX, p, q, p, slot(ctx, SLOT_PQ), nullptr, nullptr, nullptr, 0.0));
-        PADNE_TRY(fold(slot(ctx, SLOT_PQ), gs, H_pq + k));
-        if (dist) PADNE_TRY(comm_allreduce_sum_f64(ctx, H_pq + k, 1));
+        if (dist) {
+            PADNE_TRY(fold(slot(ctx, SLOT_PQ), gs, H_pq + k));
+            PADNE_TRY(comm_allreduce_sum_f64(ctx, H_pq + k, 1));
+        }
         // consumers read per-workgroup partials on one GPU and the reduced scalars across ranks
         const double *rz_old = dist ? H_rz + 2 * k : rz_old_part, *pq = dist ? H_pq + k : slot(ctx, SLOT_PQ);
         const int Pz = dist ? 1 : gv, Pq = dist ? 1 : gs;
         hipLaunchKernelGGL(pcg_update_xr_kernel, dim3(gv), dim3(256), 0, s, n, rz_old, Pz, pq, Pq, p, q, a->dinv, x, r,
                            rz_new_part, slot(ctx, SLOT_RR), st);
         PADNE_HIP_CHECK(hipGetLastError());
-        PADNE_TRY(fold(rz_new_part, gv, H_rz + 2 * (k + 1)));
         if (dist) {
             // r.z and r.r of the step travel in ONE all-reduce (two per Lanczos step in all, three before)
+            PADNE_TRY(fold(rz_new_part, gv, H_rz + 2 * (k + 1)));
             PADNE_TRY(fold(slot(ctx, SLOT_RR), gv, H_rz + 2 * (k + 1) + 1));
             PADNE_TRY(comm_allreduce_sum_f64(ctx, H_rz + 2 * (k + 1), 2));
         }
         const double *rz_new = dist ? H_rz + 2 * (k + 1) : rz_new_part, *rr = dist ? H_rz + 2 * (k + 1) + 1 : slot(ctx, SLOT_RR);
+        // (one GPU: the kernel leaves the step's scalars in the history itself)
         hipLaunchKernelGGL(pcg_update_p_kernel, dim3(gv), dim3(256), 0, s, n, rz_new, rz_old, Pz, rr, Pz, pq, Pq, r,
-                           a->dinv, p, st, 1 << 30);
+                           a->dinv, p, st, 1 << 30, dist ? (double *)nullptr : H_rz + 2 * (k + 1),
+                           dist ? (double *)nullptr : H_pq + k);
         PADNE_HIP_CHECK(hipGetLastError());
         parity ^= 1;
     }
