@@ -635,7 +635,7 @@ class CsrMatrix:
         k = 1 if b.ndim == 1 else b.shape[0]
         if b.shape[-1] != n:
             raise ValueError("right-hand side has the wrong length")
-        x = np.zeros_like(b) if x0 is None else _f64(x0).copy()
+        x = np.empty_like(b) if x0 is None else _f64(x0).copy()      # (no guess: the device starts from zero and writes all of x)
         opts = self._opts(rtol, atol, max_iter, check_every, x0 is not None, precond=precond, rebuild=rebuild)
         info = SolveInfo()
         rc = self.ctx._lib.padne_solve_spd(self.ctx._h, self._h, _ptr(b, _PF64), _ptr(x, _PF64), k,

@@ -1588,11 +1588,11 @@ extern "C" int padne_solve_spd(padne_ctx *ctx, const padne_csr *a, const double 
     PADNE_REQUIRE(n_rhs >= 1, "n_rhs");
     PADNE_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t bytes = sizeof(double) * (size_t)(ctx->halo_on ? ctx->halo_n_owned : a->n_rows) * (size_t)n_rhs;
-    double *b = nullptr, *x = nullptr;
-    PADNE_HIP_CHECK(hipMalloc((void **)&b, bytes ? bytes : 8));
-    if (hipMalloc((void **)&x, bytes ? bytes : 8) != hipSuccess) {
-        hipFree(b);
-        set_error("hipMalloc failed");
+    // (from the context's cache: hipMalloc / hipFree of two 80 MB vectors cost several milliseconds per call at 10 M unknowns)
+    double *b = (double *)pool_alloc(ctx, bytes ? bytes : 8), *x = (double *)pool_alloc(ctx, bytes ? bytes : 8);
+    if (b == nullptr || x == nullptr) {
+        pool_free(ctx, b);
+        pool_free(ctx, x);
         return PADNE_E_NOMEM;
     }
     int rc = PADNE_OK;
@@ -1608,7 +1608,8 @@ extern "C" int padne_solve_spd(padne_ctx *ctx, const padne_csr *a, const double 
             rc = PADNE_E_HIP;
         }
     }
-    hipFree(b);
-    hipFree(x);
+    if (rc != PADNE_OK && rc != PADNE_E_NOTCONVERGED) (void)hipStreamSynchronize(ctx->stream);
+    pool_free(ctx, b);
+    pool_free(ctx, x);
     return rc;
 }

@@ -407,7 +407,7 @@ class DistributedSolver:
         sel = plan.row_map >= 0
         b_red = np.bincount(plan.row_map[sel], weights=resid[sel], minlength=n_owned).astype(np.float64)
         self.owned_reduced_global = plan.reps_owned
-        self.b_norm2 = float(b_red @ b_red)                      # this rank's share of ||b||^2
+        self.b_norm2 = float(np.einsum("i,i->", b_red, b_red))    # this rank's share of ||b||^2 (no threaded BLAS: solver._effective_rtol)
         self.b = ctx.to_device(b_red)
         self.x = ctx.empty(n_owned)
         self.nnz = self.A.nnz
@@ -534,7 +534,7 @@ def solve_partitioned(plan: RankPlan, ctx, dist=None, team=None, rtol: float = 1
         for cst in red.regulators:
             b_k = ds.project_rows(cst.gamma)
             ds.set_rhs(b_k)
-            _, z_owned = solve_for(float(b_k @ b_k))
+            _, z_owned = solve_for(float(np.einsum("i,i->", b_k, b_k)))
             Z.append(expand(at_representatives(z_owned), False))
         mult_known = {}
         if red.regulators:

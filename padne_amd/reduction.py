@@ -168,6 +168,15 @@ class Reduction:
     groups: list                   # list of (members list[int], constraint list[Constraint], root or None)
     regulators: list               # constraints with a non-empty gamma
 
+    @property
+    def has_known_part(self) -> bool:
+        """Is c non-zero anywhere?  c lives on the members of the constraint groups only: a handful of entries."""
+        cached = getattr(self, "_has_c", None)
+        if cached is None:
+            cached = any(self.c[x] != 0.0 for mem, _cons, _root in self.groups for x in mem)
+            self._has_c = cached
+        return cached
+
     def _plan(self):
         """Split the index map into long contiguous runs (index_map[i0:i1] == arange(t0, t0 + i1 - i0)), which are
         copied with slices, and the few remaining entries (ground, source-tied groups, run borders).  A reduced
