@@ -7,7 +7,11 @@ No counterpart in the reference (single process); the plan
   cross-rank couplings are lumped elements whose terminals sit on different ranks (via resistor rings);
 * with fewer layers than ranks a layer is cut into horizontal *strips* (SURVEY 8e fallback): the rank also assembles
   the ring of vertices around its strip, whose rows it then drops, and the mesh edges across a cut join the via
-  resistors as cross-rank couplings.
+  resistors as cross-rank couplings;
+* voltage sources and regulators: what is partitioned are the unknowns of the REDUCED system (``reduction.py``: the
+  unknowns a source ties together are one unknown, known potentials none) -- a group's rows all live on the rank of
+  its smallest member, and the multiplier currents come back from the residual rows of the group members, each
+  evaluated where that row was assembled (:func:`build_problem_partition`, :func:`solve_partitioned`).
 
 Either way a rank's matrix is ``owned rows x [owned | world * m exchange slots]``: per product every rank packs the
 owned values somebody else needs (``export`` list) and one ``ncclAllGather`` of ``m = max_r len(export_r)`` values per
