@@ -550,8 +550,10 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
                 parity ^= 1;
             }
             PADNE_HIP_CHECK(hipGetLastError());
-            PADNE_HIP_CHECK(hipMemcpyAsync(hst, st, sizeof(PcgStatus), hipMemcpyDeviceToHost, s));
-            PADNE_HIP_CHECK(hipStreamSynchronize(s));
+            // (through the mailbox: the host polls instead of sleeping in hipStreamSynchronize, whose wake-up is at the mercy of
+            // whatever else keeps the cores busy -- spinning BLAS workers of the caller tripled this loop's wall time)
+            static_assert(sizeof(PcgStatus) <= 56, "one mailbox slot");
+            PADNE_TRY(read_back(ctx, st, sizeof(PcgStatus), hst));
             done = hst->done != 0;
         }
         total_iters += hst->iters;
@@ -837,8 +839,10 @@ static int solve_one_single_reduction(padne_ctx *ctx, const padne_csr *a, const 
                 hipLaunchKernelGGL(sr_update_ps_kernel, dim3(gv), dim3(256), 0, s, n, sr, z, w, p, sv, st, 0);
             }
             PADNE_HIP_CHECK(hipGetLastError());
-            PADNE_HIP_CHECK(hipMemcpyAsync(hst, st, sizeof(PcgStatus), hipMemcpyDeviceToHost, s));
-            PADNE_HIP_CHECK(hipStreamSynchronize(s));
+            // (through the mailbox: the host polls instead of sleeping in hipStreamSynchronize, whose wake-up is at the mercy of
+            // whatever else keeps the cores busy -- spinning BLAS workers of the caller tripled this loop's wall time)
+            static_assert(sizeof(PcgStatus) <= 56, "one mailbox slot");
+            PADNE_TRY(read_back(ctx, st, sizeof(PcgStatus), hst));
             done = hst->done != 0;
         }
         total_iters += hst->iters;

@@ -41,3 +41,9 @@ for variant in ("reduce+solve", "+matvec", "+residual_norm"):
             L.residual_norm(v, rfull)
         A.close()
         print(f"{variant:16s}: wall {w*1e3:7.1f} ms  setup {r.setup_seconds*1e3:6.1f}  solve {r.seconds*1e3:6.1f}  it {r.iterations}", flush=True)
+print("a threaded BLAS call (np.linalg.norm of 10 M doubles) right before the solve:", flush=True)
+A = L.reduce(imap, nv - 1, -1.0)
+for k in range(4):
+    nb = np.linalg.norm(b)
+    t = time.perf_counter(); r = A.solve_spd_dev(bd, xd, precond="amg", rebuild=True); w = time.perf_counter() - t
+    print(f"after norm: wall {w*1e3:7.1f} ms  setup {r.setup_seconds*1e3:6.1f}  solve {r.seconds*1e3:6.1f}  it {r.iterations}", flush=True)
