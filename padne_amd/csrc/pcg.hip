@@ -565,9 +565,7 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
         hipLaunchKernelGGL(residual_kernel, dim3(gv), dim3(256), 0, s, n, b, q, (double *)nullptr, slot(ctx, SLOT_TMP));
         PADNE_TRY(fold(slot(ctx, SLOT_TMP), gv, kMaxPartials, 1, scal + S_TRUE));
         PADNE_TRY(allreduce(scal + S_TRUE, 1));
-        PADNE_HIP_CHECK(hipMemcpyAsync(&hst[1], scal + S_TRUE, sizeof(double), hipMemcpyDeviceToHost, s));
-        PADNE_HIP_CHECK(hipStreamSynchronize(s));
-        memcpy(&true_rr, &hst[1], sizeof(double));
+        PADNE_TRY(read_back(ctx, scal + S_TRUE, sizeof(double), &true_rr));
         if (code != PADNE_OK) break;
         if (true_rr <= tol2 * 1.0000001 || total_iters >= max_iter || restarts >= 8) break;
         // A restart that does not even halve the true residual means b - A x has reached what binary64 can
@@ -854,9 +852,7 @@ static int solve_one_single_reduction(padne_ctx *ctx, const padne_csr *a, const 
         hipLaunchKernelGGL(residual_kernel, dim3(gv), dim3(256), 0, s, n, b, q, (double *)nullptr, slot(ctx, SLOT_TMP));
         PADNE_TRY(fold(slot(ctx, SLOT_TMP), gv, kMaxPartials, 1, scal + S_TRUE));
         PADNE_TRY(allreduce(scal + S_TRUE, 1));
-        PADNE_HIP_CHECK(hipMemcpyAsync(&hst[1], scal + S_TRUE, sizeof(double), hipMemcpyDeviceToHost, s));
-        PADNE_HIP_CHECK(hipStreamSynchronize(s));
-        memcpy(&true_rr, &hst[1], sizeof(double));
+        PADNE_TRY(read_back(ctx, scal + S_TRUE, sizeof(double), &true_rr));
         if (code != PADNE_OK) break;
         if (true_rr <= tol2 * 1.0000001 || total_iters >= max_iter || restarts >= 8) break;
         if (restarts > 0 && true_rr >= 0.25 * prev_true_rr) {      // the evaluation floor of b - A x (see solve_one)
