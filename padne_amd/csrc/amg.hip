@@ -1968,7 +1968,7 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
     PADNE_TRY(sc.alloc(&cnt, (size_t)n + 1));
     PADNE_TRY(sc.alloc(&slot_ptr, (size_t)n + 1));
     PADNE_TRY(sc.alloc(&row_len, (size_t)n + 1));
-    PADNE_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)(n + 1), s));
+    // (no zeroing: spgemm_count stores every one of the n entries the scan reads)
     if (n > 0) hipLaunchKernelGGL(spgemm_count, dim3(nblk(n)), dim3(256), 0, s, n, X->rowptr, X->cols, y_begin, y_end, cnt);
     PADNE_HIP_CHECK(hipGetLastError());
     int64_t n_slots = 0;

@@ -225,6 +225,12 @@ int stream_order(padne_ctx *earlier, padne_ctx *later) {
     return PADNE_OK;
 }
 
+__global__ void csr_zero_pads(int32_t *__restrict__ cols_pad, double *__restrict__ vals_pad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // grid = kPadNnz threads
+    cols_pad[i] = 0;
+    vals_pad[i] = 0.0;
+}
+
 int csr_alloc(padne_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, padne_csr **out) {
     PADNE_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0, "negative size");
     PADNE_REQUIRE(nnz < (int64_t)2147483647 - kPadNnz && n_rows < 2147483647 && n_cols < 2147483647,
@@ -243,9 +249,9 @@ int csr_alloc(padne_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, padne
         padne_csr_destroy(m);
         return PADNE_E_NOMEM;
     }
-    // zero the padding (column 0 / value 0.0) so the SpMV tile loads never need a bounds check
-    PADNE_HIP_CHECK(hipMemsetAsync(m->cols + nnz, 0, sizeof(int32_t) * kPadNnz, ctx->stream));
-    PADNE_HIP_CHECK(hipMemsetAsync(m->vals + nnz, 0, sizeof(double) * kPadNnz, ctx->stream));
+    // zero the padding (column 0 / value 0.0) so the SpMV tile loads never need a bounds check: one launch for both arrays
+    hipLaunchKernelGGL(csr_zero_pads, dim3(kPadNnz / 256), dim3(256), 0, ctx->stream, m->cols + nnz, m->vals + nnz);
+    PADNE_HIP_CHECK(hipGetLastError());
     *out = m;
     return PADNE_OK;
 }
