@@ -27,6 +27,8 @@
 // Row-partitioned runs (one rank per GPU): one hierarchy over all ranks, see amg_setup_dist below.
 #include "common.hpp"
 
+#include <functional>
+
 #include <algorithm>
 #include <chrono>
 #include <math.h>
@@ -1954,8 +1956,10 @@ __global__ void slot_row_ends(int n, const int *__restrict__ slot_ptr, const int
 
 // C = X * Y.  `y_slots`: Y is given by its uncompacted rows instead of the arrays of the handle (only n_rows / n_cols of
 // Y are read then).  `keep_slots`: leave the product in ITS slots (no scan, no compaction) and return no matrix.
+// while_counting: called once the count and the scan of the slot offsets are queued and before the host waits for their
+// total -- what it launches (on another stream) is launched while they run instead of in front of them
 static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_csr **C, const SlotRows *y_slots = nullptr,
-                  SlotRows *keep_slots = nullptr) {
+                  SlotRows *keep_slots = nullptr, const std::function<int()> *while_counting = nullptr) {
     const int *y_begin = y_slots != nullptr ? y_slots->begin : Y->rowptr;
     const int *y_end = y_slots != nullptr ? y_slots->end : Y->rowptr + 1;
     const int *y_cols = y_slots != nullptr ? (const int *)y_slots->key + 1 : Y->cols;      // upper half of a little-endian key
@@ -1972,7 +1976,25 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
     if (n > 0) hipLaunchKernelGGL(spgemm_count, dim3(nblk(n)), dim3(256), 0, s, n, X->rowptr, X->cols, y_begin, y_end, cnt);
     PADNE_HIP_CHECK(hipGetLastError());
     int64_t n_slots = 0;
-    const int rc_scan = exclusive_scan_i32(ctx, cnt, slot_ptr, n, &n_slots);
+    int rc_scan = PADNE_OK;
+    {
+        ScanTicket ticket;
+        long long h[2] = {0, 0};
+        PADNE_TRY(scan_i32_begin(ctx, cnt, slot_ptr, n, &ticket, true));
+        const int rc_cb = while_counting != nullptr ? (*while_counting)() : PADNE_OK;
+        rc_scan = scan_i32_end(ctx, &ticket, h);
+        PADNE_TRY(rc_cb);
+        if (rc_scan == PADNE_OK) {
+            if (h[0] < 0 || h[1] != 0) {
+                set_error("scan of negative counts");
+                rc_scan = PADNE_E_INVALID;
+            } else if (h[0] >= 2147483647LL) {
+                set_error("%lld entries exceed the 32-bit index space", h[0]);
+                rc_scan = PADNE_E_TOOLARGE;
+            }
+            n_slots = h[0];
+        }
+    }
     // (PADNE_SPGEMM_SPLIT_SLOTS lowers the limit so that tests reach the split path on small systems)
     const char *split_env = getenv("PADNE_SPGEMM_SPLIT_SLOTS");
     const long long split_limit = split_env ? atoll(split_env) : 0;
@@ -2372,20 +2394,29 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         const bool coarsest = A->n_rows <= kCoarseN || lvl == kMaxLevels - 1;
         if ((rc = alloc_vec(ctx, &L.xa, L.n)) != PADNE_OK || (rc = alloc_vec(ctx, &L.tmp, L.n)) != PADNE_OK) { amg->levels.push_back(L); break; }
         if (lvl > 0 && ((rc = alloc_vec(ctx, &L.b, L.n)) != PADNE_OK || (rc = alloc_vec(ctx, &L.xb, L.n)) != PADNE_OK)) { amg->levels.push_back(L); break; }
-        // second stream: everything that needs only A_l
-        if (two && (rc = stream_order(ctx, aux)) != PADNE_OK) { amg->levels.push_back(L); break; }
+        // second stream, everything that needs only A_l: the Lanczos bound and the float copy.  Neither is read before the
+        // cycle runs, so they are queued LATE in the level -- behind the transposes the main stream waits for, and while
+        // the main stream is busy with R (A P): the one host thread that launches for both streams then starts the level's
+        // aggregation without first spending 30 launches on the other stream (the small levels are launch-bound)
         const bool lanczos = lvl > 0 && A->n_rows > kCoarseN && getenv("PADNE_AMG_NO_LANCZOS") == nullptr;
-        if (lanczos) {
-            // the Gershgorin bound is loose on the coarse operators (2.8 against ~1.7): it is tightened with the largest
-            // Ritz value of 8 Lanczos steps (converges from below; 8 % margin keeps the sweep stable; 12 steps gave the same
-            // iteration counts on the configs, on 300 random systems and at 40 / 160 M unknowns, for 0.6 ms more).  Level 0: the
-            // bound is tight (1.99 by Lanczos).
-            Pending *pj = new Pending();
-            pj->level = lvl;
-            pending.push_back(pj);
-            if ((rc = lanczos_enqueue(aux, A, lanczos_steps(), &pj->job)) != PADNE_OK) { amg->levels.push_back(L); break; }
-        }
-        if (want_f32 && (rc = csr_build_f32(aux, const_cast<padne_csr *>(A))) != PADNE_OK) { amg->levels.push_back(L); break; }
+        auto queue_level_extras = [&]() -> int {
+            if (two) PADNE_TRY(stream_order(ctx, aux));
+            if (lanczos) {
+                // the Gershgorin bound is loose on the coarse operators (2.8 against ~1.7): it is tightened with the largest
+                // Ritz value of 8 Lanczos steps (converges from below; 8 % margin keeps the sweep stable; 12 steps gave the
+                // same iteration counts on the configs, on 300 random systems and at 40 / 160 M unknowns, for 0.6 ms more).
+                // Level 0: the bound is tight (1.99 by Lanczos).
+                Pending *pj = new Pending();
+                pj->level = lvl;
+                pending.push_back(pj);
+                PADNE_TRY(lanczos_enqueue(aux, A, lanczos_steps(), &pj->job));
+            }
+            if (want_f32) PADNE_TRY(csr_build_f32(aux, const_cast<padne_csr *>(A)));
+            if (want_f32 && L.P != nullptr) PADNE_TRY(csr_build_f32(aux, L.P));      // (and of the level's P and R, once they exist)
+            if (want_f32 && L.R != nullptr) PADNE_TRY(csr_build_f32(aux, L.R));
+            return PADNE_OK;
+        };
+        if (coarsest && (rc = queue_level_extras()) != PADNE_OK) { amg->levels.push_back(L); break; }
         if (coarsest) {
             rc = gershgorin(ctx, A, &L.lambda);
             amg->levels.push_back(L);
@@ -2400,6 +2431,7 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         if ((rc = aggregate(ctx, sc, A, &agg, &n_agg, &lambda_f, &L.lambda, &spos, &scol)) != PADNE_OK) { amg->levels.push_back(L); break; }
         pt.lap("aggregate");
         if (n_agg == 0 || (double)n_agg > 0.8 * (double)A->n_rows) {   // coarsening stalled: stop here
+            rc = queue_level_extras();
             amg->levels.push_back(L);
             break;
         }
@@ -2414,16 +2446,17 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         if ((rc = build_prolongator(ctx, A, agg, n_agg, omega, &L.P, spos, scol)) != PADNE_OK) { amg->levels.push_back(L); break; }
         pt.lap("prolongator");
         if (amg_verbose()) fprintf(stderr, "[amg]   P: %lld x %lld nnz=%lld\n", (long long)L.P->n_rows, (long long)L.P->n_cols, (long long)L.P->nnz);
-        // second stream: R = P^T and the float copies of both, next to A P on the main stream
+        // second stream: R = P^T next to A P on the main stream.  Its dozen launches are made after the count pass of A P
+        // has been queued (the host would otherwise sit in front of the scan's total anyway): P is complete at the event
+        // recorded here
         if (two && (rc = stream_order(ctx, aux)) != PADNE_OK) { amg->levels.push_back(L); break; }
-        if ((rc = transpose(aux, L.P, &L.R)) != PADNE_OK) { amg->levels.push_back(L); break; }
-        if (want_f32 && ((rc = csr_build_f32(aux, L.R)) != PADNE_OK || (rc = csr_build_f32(aux, L.P)) != PADNE_OK)) { amg->levels.push_back(L); break; }
-        pt.lap(two ? "transpose (queued)" : "transpose");
+        const std::function<int()> queue_transpose = [&]() -> int { return transpose(aux, L.P, &L.R); };
         // A P stays in the slots its rows were merged in: R (A P) reads it by rows, a compacted copy would be written
         // and read once for nothing (the product comes back as a matrix only when it had to be split, see spgemm)
         SlotRows ap_rows;
-        if ((rc = spgemm(ctx, A, L.P, &AP, nullptr, &ap_rows)) != PADNE_OK) { amg->levels.push_back(L); break; }
-        pt.lap("A*P");
+        if ((rc = spgemm(ctx, A, L.P, &AP, nullptr, &ap_rows, &queue_transpose)) != PADNE_OK) { amg->levels.push_back(L); break; }
+        if (L.R == nullptr && (rc = transpose(aux, L.P, &L.R)) != PADNE_OK) { amg->levels.push_back(L); break; }   // (the product was split: its halves do not call back)
+        pt.lap("A*P (P^T queued beside it)");
         // fine level of the float cycle: W = P - c D^-1 A P from the slots of A P, on the second stream
         const bool with_w = lvl == 0 && want_f32 && ap_rows.valid && getenv("PADNE_AMG_NO_W") == nullptr;
         if (amg_verbose() && AP != nullptr) fprintf(stderr, "[amg]   AP nnz=%lld\n", (long long)AP->nnz);
@@ -2433,6 +2466,7 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
             if (two && (rc = stream_order(ctx, aux)) != PADNE_OK) { amg->levels.push_back(L); break; }
             if ((rc = build_w_operator(aux, A, L.P, ap_rows, ap_rows.n_slots, c0, &L.W)) != PADNE_OK) { amg->levels.push_back(L); break; }
         }
+        if ((rc = queue_level_extras()) != PADNE_OK) { if (AP) padne_csr_destroy(AP); amg->levels.push_back(L); break; }
         if (ap_rows.valid) {
             padne_csr ap_shape;
             ap_shape.n_rows = ap_rows.n_rows;

@@ -149,12 +149,16 @@ __global__ __launch_bounds__(256) void scan_apply(const int *__restrict__ in, lo
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = (int)(*total);
 }
 
-// want_total: the host waits for the total (mailbox slot, or memcpy + synchronise without one)
-static int scan_i32_impl(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t n, long long h[2], bool want_total) {
+// Two halves: scan_i32_begin queues the three kernels (and the mailbox post of the total), scan_i32_end waits for the total
+// -- whatever the caller launches in between (on any stream) is launched while the scan runs.
+int scan_i32_begin(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t n, ScanTicket *t, bool want_total) {
     const int nb = (int)((n + kScanChunk - 1) / kScanChunk);
     hipStream_t s = ctx->stream;
+    t->nb = nb;
+    t->bs = nullptr;
+    t->want_total = want_total;
+    t->mail = MailTicket();
     if (nb == 0) {
-        h[0] = h[1] = 0;
         const hipError_t e = hipMemsetAsync(out, 0, sizeof(int32_t), s);
         if (e != hipSuccess) {
             set_error("scan failed: %s", hipGetErrorString(e));
@@ -164,28 +168,51 @@ static int scan_i32_impl(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_
     }
     long long *bs = (long long *)pool_alloc(ctx, sizeof(long long) * (size_t)(nb + 2));
     if (bs == nullptr) return PADNE_E_NOMEM;
+    t->bs = bs;
     long long *tot = bs + nb;          // [0] exact 64-bit total, [1] negative-input flag
-    const MailTicket ticket = want_total ? mail_ticket(ctx) : MailTicket();
+    if (want_total) t->mail = mail_ticket(ctx);
     hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(256), 0, s, in, (long long)n, bs);
-    hipLaunchKernelGGL(scan_block_offsets, dim3(1), dim3(256), 0, s, bs, nb, tot, ticket.slot_dev, ticket.seq);
+    hipLaunchKernelGGL(scan_block_offsets, dim3(1), dim3(256), 0, s, bs, nb, tot, t->mail.slot_dev, t->mail.seq);
     // a total beyond int32 makes the 32-bit offsets below meaningless: it is detected from the 64-bit total
     hipLaunchKernelGGL(scan_apply, dim3(nb), dim3(256), 0, s, in, (long long)n, bs, tot, out);
-    hipError_t e = hipGetLastError();
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        pool_free(ctx, bs);
+        t->bs = nullptr;
+        set_error("scan failed: %s", hipGetErrorString(e));
+        return PADNE_E_HIP;
+    }
+    return PADNE_OK;
+}
+
+int scan_i32_end(padne_ctx *ctx, ScanTicket *t, long long h[2]) {
+    h[0] = h[1] = 0;
+    if (t->nb == 0) return PADNE_OK;
+    hipStream_t s = ctx->stream;
+    long long *tot = t->bs + t->nb;
+    hipError_t e = hipSuccess;
     int rc = PADNE_OK;
-    if (e == hipSuccess && want_total) {
-        if (ticket.slot_dev != nullptr) {
-            rc = mail_wait(ctx, ticket, h, 2 * sizeof(long long));
+    if (t->want_total) {
+        if (t->mail.slot_dev != nullptr) {
+            rc = mail_wait(ctx, t->mail, h, 2 * sizeof(long long));
         } else {
             e = hipMemcpyAsync(h, tot, 2 * sizeof(long long), hipMemcpyDeviceToHost, s);
             if (e == hipSuccess) e = hipStreamSynchronize(s);
         }
     }
-    pool_free(ctx, bs);      // reuse is ordered on the context's stream
+    pool_free(ctx, t->bs);      // reuse is ordered on the context's stream
+    t->bs = nullptr;
     if (e != hipSuccess) {
         set_error("scan failed: %s", hipGetErrorString(e));
         return PADNE_E_HIP;
     }
     return rc;
+}
+
+static int scan_i32_impl(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t n, long long h[2], bool want_total) {
+    ScanTicket t;
+    PADNE_TRY(scan_i32_begin(ctx, in, out, n, &t, want_total));
+    return scan_i32_end(ctx, &t, h);
 }
 
 int exclusive_scan_i32(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t n, int64_t *total) {

@@ -176,6 +176,15 @@ MailTicket mail_ticket(padne_ctx *ctx);
 int mail_wait(padne_ctx *ctx, const MailTicket &t, void *out, size_t bytes);
 int read_back(padne_ctx *ctx, const void *dev, size_t bytes, void *host_out);
 int read_back2(padne_ctx *ctx, const void *dev, size_t bytes, void *host_out, const void *dev2, size_t bytes2, void *host_out2);
+// the exclusive scan in two halves (assemble.hip): what the caller launches between them overlaps with the scan
+struct ScanTicket {
+    int nb = 0;
+    long long *bs = nullptr;
+    bool want_total = false;
+    MailTicket mail;
+};
+int scan_i32_begin(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t n, ScanTicket *t, bool want_total);
+int scan_i32_end(padne_ctx *ctx, ScanTicket *t, long long total_and_negative[2]);
 __device__ __forceinline__ void mail_post(unsigned long long *slot, unsigned long long seq, const unsigned long long *words, int n_words) {
     for (int k = 0; k < n_words; ++k) __hip_atomic_store(slot + 1 + k, words[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(slot, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
