@@ -477,12 +477,28 @@ __global__ __launch_bounds__(256) void xw_plan_kernel(int n_rows, int n_wtiles, 
         int start[kXwRuns];
         int bound = -1;                      // columns <= bound are covered
         bool fits = true;
+        // the tile's columns in registers when there are at most 512 of them (a mesh Laplacian: ~450): the four passes
+        // for the run starts and the pass that writes the positions then need no memory round trip of their own
+        constexpr int kReg = 8;
+        const bool in_regs = k1 - k0 <= 64 * kReg;      // wave-uniform
+        int creg[kReg];
+#pragma unroll
+        for (int j = 0; j < kReg; ++j) {
+            const int e = k0 + lane + 64 * j;
+            creg[j] = (in_regs && e < k1) ? cols[e] : 0x7fffffff;
+        }
 #pragma unroll
         for (int q = 0; q <= kXwRuns; ++q) {
             int mn = 0x7fffffff;
-            for (int e = k0 + lane; e < k1; e += 64) {
-                const int c = cols[e];
-                if (c > bound && c < mn) mn = c;
+            if (in_regs) {
+#pragma unroll
+                for (int j = 0; j < kReg; ++j)
+                    if (creg[j] > bound && creg[j] < mn) mn = creg[j];
+            } else {
+                for (int e = k0 + lane; e < k1; e += 64) {
+                    const int c = cols[e];
+                    if (c > bound && c < mn) mn = c;
+                }
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) mn = min(mn, __shfl_xor(mn, off, 64));
@@ -494,13 +510,28 @@ __global__ __launch_bounds__(256) void xw_plan_kernel(int n_rows, int n_wtiles, 
             }
         }
         if (fits) {
-            for (int e = k0 + lane; e < k1; e += 64) {
-                const int c = cols[e];
-                int pos = 0;
+            if (in_regs) {
 #pragma unroll
-                for (int q = kXwRuns - 1; q >= 0; --q)
-                    if (c >= start[q] && c < start[q] + run) pos = q * run + (c - start[q]);
-                lidx[e] = (IT)pos;
+                for (int j = 0; j < kReg; ++j) {
+                    const int e = k0 + lane + 64 * j;
+                    if (e < k1) {
+                        const int c = creg[j];
+                        int pos = 0;
+#pragma unroll
+                        for (int q = kXwRuns - 1; q >= 0; --q)
+                            if (c >= start[q] && c < start[q] + run) pos = q * run + (c - start[q]);
+                        lidx[e] = (IT)pos;
+                    }
+                }
+            } else {
+                for (int e = k0 + lane; e < k1; e += 64) {
+                    const int c = cols[e];
+                    int pos = 0;
+#pragma unroll
+                    for (int q = kXwRuns - 1; q >= 0; --q)
+                        if (c >= start[q] && c < start[q] + run) pos = q * run + (c - start[q]);
+                    lidx[e] = (IT)pos;
+                }
             }
             ++ok_count;
         }
