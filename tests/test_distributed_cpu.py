@@ -224,6 +224,43 @@ def test_a_via_on_the_ground_vertex_is_a_dirichlet_term():
         assert np.abs(A @ ext - b).max() <= 1e-9 * max(np.abs(b).max(), 1.0)
 
 
+def _solve_through_the_plans(plans, n_pot):
+    """The ranks' pieces put together the way the exchange slots say, solved directly, expanded to all potentials."""
+    world = len(plans)
+    pieces = [_local_matrix(p) for p in plans]
+    reps = np.concatenate([pc[4] for pc in pieces])
+    assert len(np.unique(reps)) == len(reps)                      # every group has one owner
+    order = np.argsort(reps)
+    glob = np.empty(len(reps), dtype=np.int64)
+    glob[order] = np.arange(len(reps))                            # global reduced number of (rank, owned row)
+    first = np.concatenate([[0], np.cumsum([pc[2] for pc in pieces])])
+    m = plans[0].m
+    rows, cols, vals, b = [], [], [], np.zeros(len(reps))
+    for q, (A, bq, n_owned, export_red, _) in enumerate(pieces):
+        A = A.tocoo()
+        col_glob = np.full(plans[q].n_cols, -1, dtype=np.int64)
+        col_glob[:n_owned] = glob[first[q]:first[q] + n_owned]
+        for p2, (_, _, _, ex2, _) in enumerate(pieces):
+            col_glob[n_owned + p2 * m:n_owned + p2 * m + len(ex2)] = glob[first[p2] + ex2]
+        assert (col_glob[A.col] >= 0).all()
+        rows.append(glob[first[q] + A.row])
+        cols.append(col_glob[A.col])
+        vals.append(A.data)
+        b[glob[first[q]:first[q] + n_owned]] = bq
+    Ag = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(len(reps),) * 2).tocsc()
+    assert abs(Ag - Ag.T).max() <= 1e-12 * abs(Ag).max()
+    y = spla.spsolve(Ag, b)
+    y_at_rep = np.zeros(n_pot)
+    y_at_rep[np.sort(reps)] = y
+    plan = plans[0]
+    if plan.rep_global is None:
+        return y_at_rep, plan
+    v = plan.c_global.copy()
+    free = plan.rep_global >= 0
+    v[free] += y_at_rep[plan.rep_global[free]]
+    return v, plan
+
+
 def _problem_stamps(name):
     """Numbering and stamp list of a problem-level fixture, by the product's own host logic (no GPU involved)."""
     import helpers as H
@@ -255,38 +292,53 @@ def test_voltage_sources_in_the_row_partitioned_plan(world):
     assert sum(1 for c in stamps.constraints if c.n >= 0) == 1
     plans = [distributed.build_problem_partition(meshes, conductances, mesh_layers, stamps, r, n_pot, rank, world)
              for rank in range(world)]
-    pieces = [_local_matrix(p) for p in plans]
-    reps = np.concatenate([pc[4] for pc in pieces])
-    assert len(np.unique(reps)) == len(reps)                      # every group has one owner
-    order = np.argsort(reps)
-    glob = np.empty(len(reps), dtype=np.int64)
-    glob[order] = np.arange(len(reps))                            # global reduced number of (rank, owned row)
-    first = np.concatenate([[0], np.cumsum([pc[2] for pc in pieces])])
-    m = plans[0].m
-    rows, cols, vals, b = [], [], [], np.zeros(len(reps))
-    for q, (A, bq, n_owned, export_red, _) in enumerate(pieces):
-        A = A.tocoo()
-        col_glob = np.full(plans[q].n_cols, -1, dtype=np.int64)
-        col_glob[:n_owned] = glob[first[q]:first[q] + n_owned]
-        for p2, (_, _, _, ex2, _) in enumerate(pieces):
-            col_glob[n_owned + p2 * m:n_owned + p2 * m + len(ex2)] = glob[first[p2] + ex2]
-        assert (col_glob[A.col] >= 0).all()
-        rows.append(glob[first[q] + A.row])
-        cols.append(col_glob[A.col])
-        vals.append(A.data)
-        b[glob[first[q]:first[q] + n_owned]] = bq
-    Ag = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(len(reps),) * 2).tocsc()
-    assert abs(Ag - Ag.T).max() <= 1e-12 * abs(Ag).max()
-    y = spla.spsolve(Ag, b)
-    y_at_rep = np.zeros(n_pot)
-    y_at_rep[np.sort(reps)] = y
-    plan = plans[0]
-    v = plan.c_global.copy()
-    free = plan.rep_global >= 0
-    v[free] += y_at_rep[plan.rep_global[free]]
+    v, plan = _solve_through_the_plans(plans, n_pot)
     v_ref = g["v"][:n_pot]
     assert np.abs(v - v_ref).max() <= 1e-9 * np.abs(v_ref).max()
     # the source ties two unknowns that different ranks would own by layer: both rows went to one rank
     vs = next(c for c in stamps.constraints if c.n >= 0)
     assert plan.rep_global[vs.p] == plan.rep_global[vs.n] or plan.rep_global[vs.p] < 0 or plan.rep_global[vs.n] < 0
     assert abs((v[vs.p] - v[vs.n]) - vs.value) <= 1e-12 * max(1.0, abs(vs.value))
+
+
+def test_floating_copper_in_the_row_partitioned_plan():
+    """A layer that nothing ties to the ground (its own source / load loop) is held at 0 V at one vertex, as on one GPU
+    (``reduction.floating_component_pins``): the pin is a known potential of the plan -- no row, no exchange slot -- and
+    the ranks' pieces give the same potentials however many ranks there are."""
+    from padne_amd import mesh, problem, solver, structured
+    layers = [problem.Layer(shape=structured.Shapes.of(structured.Rect(0, 0, 6, 4)), name=f"L{i}", conductance=2000.0 / (i + 1))
+              for i in range(2)]
+    def conn(layer, x, y):
+        return problem.Connection(layer=layers[layer], point=mesh.Point(x, y))
+    a0, b0, a1, b1 = conn(0, 1.0, 1.0), conn(0, 5.0, 3.0), conn(1, 1.5, 2.0), conn(1, 4.5, 2.5)
+    nets = [problem.Network(connections=[a0, b0], elements=[problem.CurrentSource(f=a0.node_id, t=b0.node_id, current=1.0)]),
+            problem.Network(connections=[a1, b1], elements=[problem.CurrentSource(f=a1.node_id, t=b1.node_id, current=0.5)])]
+    prob = problem.Problem(layers=layers, networks=nets)
+    mesher = structured.StructuredMesher(mesh.Mesher.Config(maximum_size=0.25), jitter=0.2, seed=3)
+    meshes, mesh_layers = [], []
+    for li, lay in enumerate(layers):
+        for geom in lay.shape.geoms:
+            meshes.append(mesher.poly_to_mesh(geom))
+            mesh_layers.append(li)
+    vindex = solver.VertexIndexer.create(meshes)
+    node_indexer = solver.NodeIndexer.create(prob, meshes, mesh_layers, vindex, list(prob.networks))
+    stamps, r = solver.allocate_system(vindex, node_indexer)
+    for network in prob.networks:
+        solver.stamp_network_into_system(network, node_indexer, stamps, r)
+    solver.setup_ground_node(solver.find_best_ground_node_index(prob, node_indexer), stamps, r)
+    n_pot = len(vindex) + node_indexer.internal_node_count
+    cond = [lay.conductance for lay in layers]
+    sols = []
+    for world in (1, 2, 3):
+        plans = [distributed.build_problem_partition(meshes, cond, mesh_layers, stamps, r, n_pot, rank, world)
+                 for rank in range(world)]
+        v, plan = _solve_through_the_plans(plans, n_pot)
+        assert plan.rep_global is not None and int((plan.rep_global < 0).sum()) == 2      # the ground and the pin
+        sols.append(v)
+    scale = np.abs(sols[0]).max()
+    assert scale > 0
+    for v in sols[1:]:
+        assert np.abs(v - sols[0]).max() <= 1e-9 * scale
+    # both layers carry their own current: neither is flat
+    n0 = len(meshes[0].points)
+    assert np.ptp(sols[0][:n0]) > 1e-6 and np.ptp(sols[0][n0:n_pot]) > 1e-6
