@@ -2479,8 +2479,13 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         if (two && (rc = stream_order(aux, ctx)) != PADNE_OK) { if (AP) padne_csr_destroy(AP); amg->levels.push_back(L); break; }
         if (with_w) {                       // after the join above: the main stream waits for R, not for W
             const double c0 = 1.0 / (0.5 * (L.lambda + L.lambda / kChebRatio));      // level 0 keeps its Gershgorin bound: L.jac below
-            if (two && (rc = stream_order(ctx, aux)) != PADNE_OK) { amg->levels.push_back(L); break; }
-            if ((rc = build_w_operator(aux, A, L.P, ap_rows, ap_rows.n_slots, c0, &L.W)) != PADNE_OK) { amg->levels.push_back(L); break; }
+            if (two && (rc = stream_order(ctx, aux)) != PADNE_OK) { if (AP) padne_csr_destroy(AP); amg->levels.push_back(L); break; }
+            if ((rc = build_w_operator(aux, A, L.P, ap_rows, ap_rows.n_slots, c0, &L.W)) != PADNE_OK) {
+                if (two) (void)hipStreamSynchronize(aux->stream);      // it may have queued reads of the slots that go with this scope
+                if (AP) padne_csr_destroy(AP);
+                amg->levels.push_back(L);
+                break;
+            }
         }
         if ((rc = queue_level_extras()) != PADNE_OK) { if (AP) padne_csr_destroy(AP); amg->levels.push_back(L); break; }
         if (ap_rows.valid) {
@@ -2565,14 +2570,23 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
             }
             hipLaunchKernelGGL(f32_copy_amg, dim3(nblk((long long)cnt)), dim3(256), 0, s, (long long)cnt, amg->coarse_inv,
                                amg->coarse_inv32);
-            PADNE_HIP_CHECK(hipGetLastError());
         }
         amg->f32 = true;
     }
-    PADNE_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
-    PADNE_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+    // (every exit below leaves through one place: a hierarchy that is not handed to the matrix is destroyed, after both
+    // streams have drained)
     float ms = 0.f;
-    PADNE_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    hipError_t he = hipGetLastError();
+    if (he == hipSuccess) he = hipEventRecord(ctx->ev1, ctx->stream);
+    if (he == hipSuccess) he = hipEventSynchronize(ctx->ev1);
+    if (he == hipSuccess) he = hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    if (he != hipSuccess) {
+        set_error("multigrid setup: %s", hipGetErrorString(he));
+        (void)hipStreamSynchronize(ctx->stream);
+        if (two) (void)hipStreamSynchronize(aux->stream);
+        amg_destroy(amg);
+        return PADNE_E_HIP;
+    }
     amg->setup_seconds = ms * 1e-3;
     A0->amg = amg;
     return PADNE_OK;

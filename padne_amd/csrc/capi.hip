@@ -108,7 +108,7 @@ static int ctx_init_resources(padne_ctx *ctx) {
         hipMalloc((void **)&ctx->partials, sizeof(double) * 8 * kMaxPartials) != hipSuccess ||
         hipMalloc((void **)&ctx->scalars, sizeof(double) * 64) != hipSuccess ||
         hipMalloc((void **)&ctx->status, 1024) != hipSuccess ||
-        hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc(&ctx->pinned, kPinnedBytes, hipHostMallocDefault) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming) != hipSuccess) {
         set_error("context creation failed: %s", hipGetErrorString(hipGetLastError()));

@@ -24,6 +24,7 @@ struct Rccl {
     int (*GetUniqueId)(ncclUniqueId *) = nullptr;
     int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*CommAbort)(ncclComm_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
@@ -55,6 +56,7 @@ static int load_rccl() {
     g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
     g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+    g_rccl.CommAbort = (decltype(g_rccl.CommAbort))dlsym(h, "ncclCommAbort");      // optional
     g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
     g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
@@ -210,8 +212,16 @@ int comm_allgather_f32(padne_ctx *ctx, const float *send, float *recv, int count
 }
 
 // a rank that fails locally (allocation, HIP error, argument check) inside a row-partitioned solve tells its team
+// (in-process team: the peers' barriers return PADNE_E_COMM at once).  Over RCCL a rank cannot reach into its peers: it
+// aborts ITS communicator -- queued collectives are torn down instead of waiting for ever, the context is left without one,
+// and the error return makes the Python driver raise, so the process ends non-zero and the launcher (torchrun) ends the
+// other ranks, which are blocked in a collective this rank will never enter.
 void comm_abort(padne_ctx *ctx) {
     if (ctx->team != nullptr) team_fail((Team *)ctx->team);
+    if (ctx->comm != nullptr && g_rccl.CommAbort != nullptr) {
+        (void)g_rccl.CommAbort((ncclComm_t)ctx->comm);
+        ctx->comm = nullptr;
+    }
 }
 
 void comm_destroy(padne_ctx *ctx) {

@@ -49,6 +49,11 @@ constexpr int kPadNnz = 4096;        // cols/vals allocations are padded by this
 
 // number of partial sums every reduction kernel emits (one per workgroup)
 constexpr int kMaxPartials = 2048;
+// pinned polling buffer of a context: [0, 4096) status mirrors of the CG loops, then kPinnedSlots slots of 512 bytes for
+// the Lanczos histories queued on the second stream (one per possible level of a hierarchy, kMaxLevels = 16 in amg.hip)
+constexpr int kPinnedSlots = 16;
+constexpr int kPinnedSlotBase = 4096;
+constexpr int kPinnedBytes = kPinnedSlotBase + 512 * kPinnedSlots;
 
 constexpr int kSpmmK = 8;            // right-hand sides of the batched path (spmm.hip), interleaved [n][8]
 
@@ -104,7 +109,7 @@ struct padne_ctx {
     // latency-bound kernels of the multigrid setup run there next to the main chain (aux_context, stream_order)
     padne_ctx *aux = nullptr, *parent = nullptr;
     bool is_aux = false;
-    unsigned pinned_next = 0;        // round-robin over the 512-byte slots of `pinned` (second stream only)
+    unsigned pinned_busy = 0;        // bit k: the k-th 512-byte Lanczos slot of `pinned` holds a job in flight (second stream only)
     // mailbox: a page of host-coherent memory the device posts small results into (read_back / mail_ticket)
     unsigned long long *mailbox = nullptr, *mailbox_dev = nullptr;
     unsigned long long mail_seq = 0;
@@ -231,6 +236,7 @@ struct LanczosJob {
     double *hist = nullptr;          // device history of the step scalars (pool of ctx)
     std::vector<double> host;        // its host copy, valid after lanczos_finish
     double *host_dst = nullptr;      // where the queue copies it first (pinned memory on the second stream)
+    int pinned_slot = -1;            // its slot there, released by lanczos_finish
 };
 int lanczos_enqueue(padne_ctx *ctx, const padne_csr *a, int steps, LanczosJob *job, const HaloPlan *plan = nullptr);
 int lanczos_finish(LanczosJob *job, double *lambda);

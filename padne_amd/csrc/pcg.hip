@@ -61,7 +61,9 @@ struct PcgStatus {       // lives in device memory, mirrored to pinned host memo
     int32_t done;        // 1 = stop iterating
     int32_t code;        // PADNE_OK / PADNE_E_BREAKDOWN
     int32_t iters;       // iterations completed
-    int32_t pad;
+    int32_t done_seen;   // `done` as the x/r update of the current iteration read it.  The p update of the multigrid loop
+                         // (which sets `done` itself, in its workgroup 0) takes its early exit from THIS word: a workgroup of
+                         // that launch dispatched after workgroup 0's store must still apply its share of x += alpha p
     double rr;           // recurrence ||r||^2 after the last completed iteration
     double tol2;         // stop when rr <= tol2
     double bb;           // ||b||^2
@@ -207,7 +209,9 @@ __global__ __launch_bounds__(256) void pcg_update_xr_plain_kernel(
     const int P_pq, const double *__restrict__ p, const double *__restrict__ q, double *__restrict__ x,
     double *__restrict__ r, double *__restrict__ part_rr, PcgStatus *__restrict__ st) {
     __shared__ double red[4];
-    if (st->done) return;
+    const int stop = st->done;              // written by an EARLIER launch: every workgroup of this one reads the same value
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->done_seen = stop;
+    if (stop) return;
     const double rz = block_total(part_rz, P_rz, red);
     const double pq = block_total(part_pq, P_pq, red);
     const double alpha = rz / pq;
@@ -229,7 +233,9 @@ __global__ __launch_bounds__(256) void pcg_update_xr_entry_kernel(
     double *__restrict__ r, double *__restrict__ part_rr, PcgStatus *__restrict__ st, const double *__restrict__ bb2,
     const float c, const float *__restrict__ dinv32, float *__restrict__ b32, float *__restrict__ xa32) {
     __shared__ double red[4];
-    if (st->done) return;
+    const int stop = st->done;              // written by an EARLIER launch: every workgroup of this one reads the same value
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->done_seen = stop;
+    if (stop) return;
     const double rz = block_total(part_rz, P_rz, red);
     const double pq = block_total(part_pq, P_pq, red);
     const double alpha = rz / pq;
@@ -255,7 +261,10 @@ __global__ __launch_bounds__(256) void pcg_update_p_z_kernel(
     const int P_pq, const double *__restrict__ z, double *__restrict__ p, PcgStatus *__restrict__ st,
     const int max_iter, double *__restrict__ x_deferred, const float *__restrict__ z32, const double *__restrict__ bb2) {
     __shared__ double red[4];
-    if (st->done) return;
+    // NOT st->done: workgroup 0 of this very launch sets it, and this kernel carries the deferred x += alpha p -- a
+    // workgroup dispatched after that store would skip its slice of the last update.  done_seen is what the x/r update of
+    // this iteration read, i.e. a value from before this launch
+    if (st->done_seen) return;
     const double rz_new = block_total(part_rz_new, P_rz, red);
     const double rz_old = block_total(part_rz_old, P_rz, red);
     const double beta = rz_new / rz_old;
@@ -579,8 +588,7 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
         // the recurrence residual drifted from the true one: restart from the true residual
         ++restarts;
         have_ax = true;  // q = A x is current
-        PADNE_HIP_CHECK(hipMemsetAsync(st, 0, 2 * sizeof(int32_t), s));   // done = code = 0
-        PADNE_HIP_CHECK(hipMemsetAsync(&st->iters, 0, sizeof(int32_t), s));
+        PADNE_HIP_CHECK(hipMemsetAsync(st, 0, 4 * sizeof(int32_t), s));   // done = code = iters = done_seen = 0
     }
     PADNE_HIP_CHECK(hipEventRecord(ctx->ev1, s));
     PADNE_HIP_CHECK(hipEventSynchronize(ctx->ev1));
@@ -863,8 +871,7 @@ static int solve_one_single_reduction(padne_ctx *ctx, const padne_csr *a, const 
         prev_true_rr = true_rr;
         ++restarts;
         have_ax = true;
-        PADNE_HIP_CHECK(hipMemsetAsync(st, 0, 2 * sizeof(int32_t), s));
-        PADNE_HIP_CHECK(hipMemsetAsync(&st->iters, 0, sizeof(int32_t), s));
+        PADNE_HIP_CHECK(hipMemsetAsync(st, 0, 4 * sizeof(int32_t), s));
     }
     PADNE_HIP_CHECK(hipEventRecord(ctx->ev1, s));
     PADNE_HIP_CHECK(hipEventSynchronize(ctx->ev1));
@@ -1240,10 +1247,19 @@ int lanczos_enqueue(padne_ctx *ctx, const padne_csr *a, int steps, LanczosJob *j
     job->steps = steps;
     job->host.assign((size_t)3 * steps + 4, 0.0);
     // on the second stream the history lands in pinned memory (a copy to pageable memory would hold the host until the
-    // queue has drained, which is exactly what queuing there is meant to avoid): up to 8 jobs in flight, 512 bytes each
+    // queue has drained, which is exactly what queuing there is meant to avoid): one 512-byte slot per job in flight,
+    // kPinnedSlots of them (one per possible level of a hierarchy: the setup keeps every job pending until its end); a job
+    // that finds no free slot copies to its own pageable buffer -- slower, never another job's data
     job->host_dst = job->host.data();
+    job->pinned_slot = -1;
     if (ctx->is_aux && sizeof(double) * job->host.size() <= 512) {
-        job->host_dst = (double *)((char *)ctx->pinned + 512 * (ctx->pinned_next++ % 8));
+        for (int k = 0; k < kPinnedSlots; ++k)
+            if (!(ctx->pinned_busy & (1u << k))) {
+                ctx->pinned_busy |= 1u << k;
+                job->pinned_slot = k;
+                job->host_dst = (double *)((char *)ctx->pinned + kPinnedSlotBase + 512 * k);
+                break;
+            }
     }
     // (rz, rr)[0..steps] interleaved | pq[0..steps)
     job->hist = (double *)pool_alloc(ctx, sizeof(double) * ((size_t)3 * steps + 4));
@@ -1305,12 +1321,17 @@ int lanczos_finish(LanczosJob *job, double *lambda) {
     const hipError_t e = hipStreamSynchronize(job->ctx->stream);
     pool_free(job->ctx, job->hist);
     job->hist = nullptr;
+    if (job->pinned_slot >= 0) {
+        if (e == hipSuccess) memcpy(job->host.data(), job->host_dst, sizeof(double) * job->host.size());
+        job->ctx->pinned_busy &= ~(1u << job->pinned_slot);
+        job->pinned_slot = -1;
+        job->host_dst = job->host.data();
+    }
     if (e != hipSuccess) {
         set_error("Lanczos estimate failed: %s", hipGetErrorString(e));
         return PADNE_E_HIP;
     }
     const int steps = job->steps;
-    if (job->host_dst != job->host.data()) memcpy(job->host.data(), job->host_dst, sizeof(double) * job->host.size());
     const std::vector<double> &hh = job->host;
     std::vector<double> alpha, beta;
     for (int k = 0; k < steps; ++k) {

@@ -448,6 +448,19 @@ class DistributedSolver:
                 out[int(x)] = float(plan.rhs_rows[pos] - Lv[pos])
         return out
 
+    def residual_sq_of_own_rows(self, v_all: np.ndarray, corrections: dict) -> float:
+        """Sum over the potential rows this rank assembled completely of (r_x - (L v)_x - corrections[x])^2: this rank's
+        share of ||L v - r||^2 on the ORIGINAL system (``solver.py:775``).  ``corrections``: what the multiplier columns
+        add to (L v)_x -- they are not part of the local assembly -- as {unknown: value}."""
+        plan = self.plan
+        Lv = self.L_local.matvec(np.ascontiguousarray(v_all[plan.local_global]))
+        rho = np.where(plan.rhs_owner_mask, plan.rhs_rows - Lv, 0.0)
+        for x, val in corrections.items():
+            pos = int(np.searchsorted(plan.local_global, x))
+            if pos < len(plan.local_global) and plan.local_global[pos] == x and plan.rhs_owner_mask[pos]:
+                rho[pos] -= val
+        return float(np.einsum("i,i->", rho, rho))
+
     def close(self):
         if self.L_local is not None:
             self.L_local.close()
@@ -509,6 +522,7 @@ def solve_partitioned(plan: RankPlan, ctx, dist=None, team=None, rtol: float = 1
                 y[idx] = vals
             return y
         res, y_owned = solve_for(ds.b_norm2)
+        totals = {"iterations": int(res.iterations), "seconds": float(res.seconds), "rel_residual": float(res.rel_residual)}
         y = at_representatives(y_owned)
         if plan.rep_global is None:
             return y, res
@@ -538,7 +552,10 @@ def solve_partitioned(plan: RankPlan, ctx, dist=None, team=None, rtol: float = 1
         for cst in red.regulators:
             b_k = ds.project_rows(cst.gamma)
             ds.set_rhs(b_k)
-            _, z_owned = solve_for(float(np.einsum("i,i->", b_k, b_k)))
+            res_k, z_owned = solve_for(float(np.einsum("i,i->", b_k, b_k)))
+            totals["iterations"] += int(res_k.iterations)
+            totals["seconds"] += float(res_k.seconds)
+            totals["rel_residual"] = max(totals["rel_residual"], float(res_k.rel_residual))
             Z.append(expand(at_representatives(z_owned), False))
         mult_known = {}
         if red.regulators:
@@ -566,6 +583,30 @@ def solve_partitioned(plan: RankPlan, ctx, dist=None, team=None, rtol: float = 1
                 v[idx] = val
         for idx, val in mult_known.items():
             v[idx] = val
-        return v, res
+        # ||L v - r||_2 of the RETURNED vector on the original KKT system, as solve_system reports it on one GPU
+        # (solver.py:775): every rank evaluates the potential rows it assembled, the multiplier columns
+        # (+i at p, -i at n, gain entries, the ground column) are added from the constraint list, the multiplier rows
+        # v_p - v_n = U are evaluated on every rank alike
+        corr: dict = {}
+        sq_rows = 0.0
+        for cst in red.layout.constraints:
+            i_c = float(v[cst.index])
+            corr[cst.p] = corr.get(cst.p, 0.0) + i_c
+            if cst.n >= 0:
+                corr[cst.n] = corr.get(cst.n, 0.0) - i_c
+            for row, gain in cst.gamma.items():
+                corr[row] = corr.get(row, 0.0) + gain * i_c
+            lhs = v[cst.p] - (v[cst.n] if cst.n >= 0 else 0.0)
+            sq_rows += float(lhs - plan.rhs_full[cst.index]) ** 2
+        v_ext = v_pot if len(v_pot) >= n_pot else np.concatenate([v_pot, np.zeros(n_pot - len(v_pot))])
+        sq = sum(collect(ds.residual_sq_of_own_rows(v_ext, corr))) + sq_rows
+        import types
+        out = types.SimpleNamespace(**{k: getattr(res, k, None) for k in
+                                       ("restarts", "status", "spmv_seconds", "setup_seconds", "operator_complexity", "levels",
+                                        "precond_fallbacks")})
+        out.abs_residual = float(np.sqrt(sq))
+        out.reduced_abs_residual = float(res.abs_residual)
+        out.iterations, out.seconds, out.rel_residual = totals["iterations"], totals["seconds"], totals["rel_residual"]
+        return v, out
     finally:
         ds.close()

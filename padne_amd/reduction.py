@@ -159,23 +159,81 @@ class _UnionFind:
         return True
 
 
-@dataclass
 class Reduction:
-    layout: KKTLayout
-    index_map: np.ndarray          # int32[N]: reduced unknown of each potential, -1 = eliminated
-    n_free: int
-    c: np.ndarray                  # f64[N]: known part of v (offsets / Dirichlet values), 0 on multipliers
-    groups: list                   # list of (members list[int], constraint list[Constraint], root or None)
-    regulators: list               # constraints with a non-empty gamma
+    """The index reduction of one KKT system.  SPARSE first: what distinguishes it from the identity is listed --
+    ``elim`` (sorted potentials that have no reduced unknown of their own: known potentials and the non-representative
+    members of source-tied groups), ``tied`` (member, representative) pairs of the free groups, ``known`` {unknown: known
+    part c of its potential} -- in O(#constraints); the device builds its index map from these lists
+    (``padne_kkt_create``).  The dense ``index_map`` (int32[N]: reduced unknown of each unknown, -1 = eliminated) and
+    ``c`` (f64[N]) of the host restatement (``expand`` / ``rhs``, the row-partitioned plan, the locality ordering) are
+    made on first access."""
+
+    def __init__(self, layout: KKTLayout, n_free: int, elim: np.ndarray, tied: list, known: dict, groups: list,
+                 regulators: list):
+        self.layout = layout
+        self.n_free = int(n_free)
+        self.elim = np.asarray(elim, dtype=np.int64)     # sorted, < n_potential
+        self.tied = list(tied)                           # [(member, representative)], member > representative
+        self.known = dict(known)                         # {unknown: c}, members of constraint groups with c != 0
+        self.groups = groups                             # list of (members list[int], constraint list[Constraint], root or None)
+        self.regulators = regulators                     # constraints with a non-empty gamma
+        self._index_map = None
+        self._c = None
+        self.reordered = False                           # apply_locality_ordering relabelled the dense map
+
+    @classmethod
+    def from_dense(cls, index_map: np.ndarray, n_free: int, c: np.ndarray, layout=None, groups=(), regulators=()):
+        """A reduction given by its dense arrays (tests of the host restatement)."""
+        red = cls(layout, n_free, np.zeros(0, np.int64), [], {int(i): float(c[i]) for i in np.flatnonzero(c)},
+                  list(groups), list(regulators))
+        red._index_map = np.asarray(index_map, dtype=np.int32)
+        red._c = np.asarray(c, dtype=np.float64)
+        red.reordered = True                       # the sparse lists do not describe this map
+        return red
+
+    @property
+    def index_map(self) -> np.ndarray:
+        if self._index_map is None:
+            N, n_pot = self.layout.size, self.layout.n_potential
+            eliminated = np.zeros(N, dtype=bool)
+            eliminated[n_pot:] = True
+            eliminated[self.elim] = True
+            imap = np.full(N, -1, dtype=np.int32)
+            keep = ~eliminated
+            imap[keep] = np.arange(int(keep.sum()), dtype=np.int32)
+            for member, rep in self.tied:
+                imap[member] = imap[rep]
+            self._index_map = imap
+        return self._index_map
+
+    @property
+    def c(self) -> np.ndarray:
+        if self._c is None:
+            c = np.zeros(self.layout.size, dtype=np.float64)
+            for x, val in self.known.items():
+                c[x] = val
+            self._c = c
+        return self._c
+
+    def index_of(self, x: int) -> int:
+        """Reduced unknown of potential ``x`` (-1: known / multiplier) without the dense map."""
+        if self._index_map is not None:
+            return int(self._index_map[x])
+        if x >= self.layout.n_potential:
+            return -1
+        for member, rep in self.tied:
+            if member == x:
+                x = rep
+                break
+        k = int(np.searchsorted(self.elim, x))
+        if k < len(self.elim) and self.elim[k] == x:
+            return -1
+        return int(x - k)
 
     @property
     def has_known_part(self) -> bool:
         """Is c non-zero anywhere?  c lives on the members of the constraint groups only: a handful of entries."""
-        cached = getattr(self, "_has_c", None)
-        if cached is None:
-            cached = any(self.c[x] != 0.0 for mem, _cons, _root in self.groups for x in mem)
-            self._has_c = cached
-        return cached
+        return any(val != 0.0 for val in self.known.values())
 
     def _plan(self):
         """Split the index map into long contiguous runs (index_map[i0:i1] == arange(t0, t0 + i1 - i0)), which are
@@ -232,7 +290,7 @@ class Reduction:
         """P^T applied to a sparse row-indexed vector {row: value}."""
         out = np.zeros(self.n_free)
         for row, val in vec_rows.items():
-            t = self.index_map[row]
+            t = self.index_of(row)
             if t >= 0:
                 out[t] += val
         return out
@@ -324,40 +382,38 @@ def build_reduction(layout: KKTLayout, pins: list | None = None) -> Reduction:
                 continue
             raise SingularSystemError("two ground rows tie the same group of nodes")
         known_roots[root] = (cst.value - uf.offset(cst.p), cst.p)
-    index_map = np.full(N, -1, dtype=np.int32)
-    c = np.zeros(N, dtype=np.float64)
     # representative of a free group = its smallest member, so singletons keep their place
     rep_of = {}
-    eliminated = np.zeros(N, dtype=bool)
-    eliminated[n_pot:] = True
+    elim, tied, known = [], [], {}
     for root, mem in members.items():
         if root in known_roots:
             v_root = known_roots[root][0]
             for x in mem:
-                eliminated[x] = True
-                c[x] = v_root + uf.offset(x)
+                elim.append(x)
+                val = v_root + uf.offset(x)
+                if val != 0.0:
+                    known[x] = val
         else:
             rep = min(mem)
             rep_of[root] = rep
             for x in mem:
-                c[x] = uf.offset(x) - uf.offset(rep)
+                val = uf.offset(x) - uf.offset(rep)
+                if val != 0.0:
+                    known[x] = val
                 if x != rep:
-                    eliminated[x] = True          # numbered through its representative below
-    keep = ~eliminated
-    index_map[keep] = np.arange(int(keep.sum()), dtype=np.int32)
-    for root, mem in members.items():
-        if root in known_roots:
-            continue
-        rep = rep_of[root]
-        for x in mem:
-            index_map[x] = index_map[rep]
-    n_free = int(keep.sum())
+                    elim.append(x)                # numbered through its representative
+                    tied.append((x, rep))
+    for x in elim:
+        if not 0 <= x < n_pot:
+            raise SingularSystemError("constraint names an unknown that is not a potential")
+    elim = np.unique(np.asarray(elim, dtype=np.int64))
+    n_free = n_pot - len(elim)
     groups = []
     for root, mem in members.items():
         r_node = known_roots[root][1] if root in known_roots else rep_of[root]
         groups.append((sorted(mem), gcons[root], r_node))
     regs = [cst for cst in layout.constraints if cst.gamma]
-    return Reduction(layout=layout, index_map=index_map, n_free=n_free, c=c, groups=groups, regulators=regs)
+    return Reduction(layout=layout, n_free=n_free, elim=elim, tied=sorted(tied), known=known, groups=groups, regulators=regs)
 
 
 def floating_component_pins(n_potential: int, ground: int, constraints, *, mesh_offsets=None, links=None,
@@ -537,3 +593,4 @@ def apply_locality_ordering(red: "Reduction", xy: np.ndarray, mesh_offsets: np.n
     new_of_old[order] = np.arange(red.n_free, dtype=np.int32)
     free = imap >= 0
     imap[free] = new_of_old[imap[free]]
+    red.reordered = True

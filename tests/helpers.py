@@ -87,6 +87,33 @@ def build_problem(g, P):
     return P.Problem(layers=layers, networks=networks), nodes, flat
 
 
+class HalfEdgeLikeMesh:
+    """Duck-typed stand-in for the reference's half-edge ``padne.mesh.Mesh`` as ``solve()`` hands it on
+    (``mesh.py:778-786``): ``vertices`` = objects with ``.p.x``, ``.p.y`` and ``.i``; ``faces`` = objects whose
+    ``.vertices`` iterate in the order the reference visits a face, (v3, v1, v2) (``mesh.py:320-325``).  No ``points`` /
+    ``triangles`` arrays: ``Mesh.from_reference`` has to walk the objects.  ``soup``: what the mesher stub of
+    INTEGRATION.md leaves next to the half-edge mesh (``_padne_hip_soup``: the CGAL output dict)."""
+
+    class _V:
+        __slots__ = ("p", "i")
+
+        def __init__(self, x, y, i):
+            self.p, self.i = XY(x, y), i
+
+    class _F:
+        __slots__ = ("vertices",)
+
+        def __init__(self, vs):
+            self.vertices = vs
+
+    def __init__(self, xy, tri, soup=None):
+        self.vertices = [self._V(float(x), float(y), i) for i, (x, y) in enumerate(xy)]
+        self.faces = [self._F((self.vertices[c], self.vertices[a], self.vertices[b])) for a, b, c in
+                      (tuple(int(k) for k in t) for t in tri)]
+        if soup is not None:
+            self._padne_hip_soup = soup
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, f"{name}.npz")))
 

@@ -324,6 +324,48 @@ def test_solves_are_bitwise_reproducible(ctx, precond):
     assert np.array_equal(x1, x2)
 
 
+def test_converging_iteration_is_complete_when_the_gpu_is_shared(ctx):
+    """the deferred ``x += alpha p`` rides on the p update, whose workgroup 0 also sets ``done``.  A
+    workgroup of that launch that is dispatched late -- the card is shared with another stream or process -- must not
+    take the early exit on the flag its own launch just set, or its slice of x misses the last update (the true-residual
+    check would then restart: same tolerance, but timing-dependent iteration counts and bits).  The p update now reads the
+    flag as the x/r update of the same iteration saw it.  Here: the same solve on a quiet card and while a second stream
+    keeps every CU busy with streaming kernels; no restart, same iteration count, same bits."""
+    import threading
+    import torch
+    xy, tri = synthetic.jittered_grid(700, 700, seed=6)               # 490 k unknowns: the vector kernels fill their grid
+    A = (-O.laplace_operator(xy, tri).tocsr()[1:, 1:]).tocsr()
+    b = np.random.default_rng(3).uniform(-1, 1, A.shape[0])
+    d = ctx.csr_from_scipy(A)
+    quiet = d.solve_spd(b, precond="amg")
+    assert quiet.status == _hip.OK and quiet.restarts == 0
+    stop = threading.Event()
+    launched = []
+
+    def hog():
+        t = torch.ones(64 * 1024 * 1024, dtype=torch.float32, device="cuda:0")     # 256 MB, streamed over and over
+        n = 0
+        while not stop.is_set():
+            for _ in range(20):
+                t.mul_(1.0000001)
+            torch.cuda.synchronize()
+            n += 20
+        launched.append(n)
+
+    th = threading.Thread(target=hog, daemon=True)
+    th.start()
+    try:
+        busy = [d.solve_spd(b, precond="amg") for _ in range(6)]
+    finally:
+        stop.set()
+        th.join(60)
+    assert launched and launched[0] > 0
+    for res in busy:
+        assert res.status == _hip.OK and res.restarts == 0
+        assert res.iterations == quiet.iterations
+        assert np.array_equal(res.x, quiet.x)
+
+
 # ---- multigrid preconditioner ----------------------------------------------------------------------
 
 def layered_spd(nl=3, nx=90, ny=70, lattice=5):
@@ -630,6 +672,46 @@ def test_problem_fixture_through_solve(ctx, name, family):
             assert len(pickle.loads(pickle.dumps(sol)).layer_solutions) == 4         # tests/test_solver.py:2047-2080
         # every connection point reached the mesher as a seed of its layer's polygons (solver.py:solve step 3)
         assert sum(len(v) for v in mesher.seeds.values()) == len(g["connections"])
+
+
+@pytest.mark.parametrize("route", ["object_walk", "soup_dict", "cgal_dict"])
+def test_config_c1_through_the_reference_shaped_mesh_hand_off(ctx, route):
+    """SURVEY 8 f3 on the GPU: ``solve_meshed`` receives what padne's ``solve()`` holds after meshing
+    (``mesh.py:778-786``) -- half-edge mesh OBJECTS, not arrays -- and must return the reference's potentials for config
+    C1.  ``object_walk``: ``Mesh.from_reference`` walks vertices / faces ((v3, v1, v2) per face, ``mesh.py:320-325``);
+    ``soup_dict``: the mesher stub of INTEGRATION.md left CGAL's output dict on the mesh (``_padne_hip_soup``), no walk;
+    ``cgal_dict``: ``Mesh.from_cgal_output`` on the dict ``padne._cgal.mesh`` returns (``_cgal.cpp:479-488``)."""
+    g = H.load_golden("problem_c1")
+    prob, nodes, flat_elements = H.build_problem(g, problem)
+    ms = H.problem_meshes(g)
+    layer_of = [m[2] for m in ms]
+    handed = []
+    for xy, tri, _ in ms:
+        out = {"vertices": [(float(x), float(y)) for x, y in xy], "triangles": [tuple(int(i) for i in t) for t in tri]}
+        if route == "object_walk":
+            he = H.HalfEdgeLikeMesh(xy, tri)
+            assert not hasattr(he, "points") and not hasattr(he, "triangles")
+            handed.append(he)
+        elif route == "soup_dict":
+            handed.append(H.HalfEdgeLikeMesh(xy[:0], tri[:0], soup=out))      # the walk would find nothing: the dict is used
+        else:
+            handed.append(mesh.Mesh.from_cgal_output(out))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", solver.SolverWarning)
+        sol = solver.solve_meshed(prob, handed, layer_of)
+    n_vert = sum(len(m[0]) for m in ms)
+    scale = np.abs(g["v"][:n_vert]).max()
+    worst = 0.0
+    for li, ls in enumerate(sol.layer_solutions):
+        idx = [i for i, m in enumerate(ms) if m[2] == li]
+        assert len(ls.potentials) == len(idx)
+        for i, zf, tf in zip(idx, ls.potentials, ls.power_densities):
+            assert np.array_equal(zf.mesh.points, ms[i][0]) and np.array_equal(zf.mesh.triangles, ms[i][1])
+            worst = max(worst, np.abs(zf.values - g[f"pot{i}"]).max())
+            assert np.abs(tf.values - g[f"pow{i}"]).max() <= 1e-7 * max(g[f"pow{i}"].max(), 1e-300)
+    assert worst <= REL_TOL * scale, f"{route}: potentials differ from the reference's solve by {worst / scale:.2e}"
+    assert sol.solver_info.residual_norm < 1e-9
+    assert abs(sol.solver_info.ground_node_current - float(g["ground_node_current"])) <= 1e-8 * np.abs(g["v"][n_vert:]).max()
 
 
 # ---- Problem-level drop-in (the reference's synthetic end-to-end tests) --------------------------
@@ -1146,6 +1228,45 @@ def _check_against_the_direct_solve_samples(name, v):
     err = np.abs(v[g["index"]] - g["potential"]).max() / float(g["max_abs_potential"])
     assert err <= REL_TOL, f"{name}: potentials differ from the reference's direct solve by {err:.2e} relative"
     assert float(g["residual_norm"]) < 1e-9
+
+
+def test_config_c2_assembly_bit_for_bit_and_solve_at_full_size(ctx):
+    """Config C2 of BASELINE.json at full size (one layer of 1000x1000, N = 1 M, 7 non-zeros per row), pinned
+    INDEPENDENTLY of the device on both halves of the north star:
+      * assembly: the device-assembled system (``asm_*`` kernels, mesh generated on the host) equals the CPU oracle's
+        ``assemble_system`` (``mesh.py:124-139``, ``solver.py:171-213, 563-575`` restated) in structure and BIT FOR BIT
+        in every value, at 1 M rows / 7 M entries;
+      * solve: potentials within 1e-8 of ``tests/golden/direct_C2.npz`` -- samples of the reference's solve call
+        (``tocsc + spsolve``, ``solver.py:772-775``) on the ORACLE-assembled matrix (``scripts/direct_cpu.py``, no device
+        code on that side) -- and the reference's absolute residual bar ``||L v - r|| < 1e-9``
+        (``tests/test_solver.py:2083-2089``)."""
+    sysm = synthetic.config("C2")
+    nv = sysm.n_vertices
+    N = nv + 1
+    xy, tri, mvo, mto, sig = flat(sysm.meshes)
+    rows = np.array([N - 1, sysm.ground], dtype=np.int64)
+    cols = np.array([sysm.ground, N - 1], dtype=np.int64)
+    vals = np.array([1.0, 1.0])
+    assert len(sysm.resistors[0]) == 0                                 # one layer: no via rings
+    Ld = ctx.assemble_system(N, xy, tri, mvo, mto, sig, rows, cols, vals)
+    els = [("I", int(f), int(t), float(i)) for f, t, i in zip(*sysm.current_sources)]
+    Lo, ro = O.assemble_system([(m[0], m[1], m[2]) for m in sysm.meshes], 0, els, sysm.ground)
+    Lo.sort_indices()
+    Lg = Ld.to_scipy()
+    assert Lg.shape == Lo.shape == (N, N) and Lg.nnz == Lo.nnz and Lo.nnz > 6.9e6
+    assert np.array_equal(Lg.indptr, Lo.indptr) and np.array_equal(Lg.indices, Lo.indices)
+    assert np.array_equal(Lg.data, Lo.data), "device assembly of C2 differs from the oracle"
+    del Lg, Lo
+    from padne_amd.reduction import Constraint, KKTLayout
+    L = solver.SystemMatrix(Ld, KKTLayout(size=N, n_potential=nv,
+                                          constraints=[Constraint(index=N - 1, p=sysm.ground, n=-1, value=0.0)]))
+    v, info = solver.solve_system(L, ro)
+    Ld.close()
+    assert info.residual_norm < 1e-9 and abs(info.ground_node_current) < 1e-9
+    assert 10 < info.iterations < 60 and info.rel_residual <= 1.1e-12
+    _check_against_the_direct_solve_samples("C2", v[:nv])
+    f, t = int(sysm.current_sources[0][0]), int(sysm.current_sources[1][0])
+    assert int(np.argmax(v[:nv])) == t and int(np.argmin(v[:nv])) == f
 
 
 def test_headline_config_at_full_size(ctx, monkeypatch):

@@ -380,7 +380,7 @@ def test_reduction_run_plan_matches_the_plain_formulas():
     n_free = int(keep.sum())
     c = np.zeros(n + 3)
     c[merged] = rng.uniform(-1, 1, 15)
-    red = Reduction(layout=None, index_map=imap, n_free=n_free, c=c, groups=[], regulators=[])
+    red = Reduction.from_dense(imap, n_free, c)
     y = rng.uniform(-1, 1, n_free)
     r = rng.uniform(-1, 1, n + 3)
     free = imap >= 0
@@ -392,8 +392,7 @@ def test_reduction_run_plan_matches_the_plain_formulas():
     assert np.allclose(red.rhs(r, None), b_ref, rtol=0, atol=1e-15)
     # a scattered map (after the locality reordering) takes the generic path
     perm = rng.permutation(n_free).astype(np.int32)
-    red2 = Reduction(layout=None, index_map=np.where(imap >= 0, perm[np.maximum(imap, 0)], -1).astype(np.int32),
-                     n_free=n_free, c=c, groups=[], regulators=[])
+    red2 = Reduction.from_dense(np.where(imap >= 0, perm[np.maximum(imap, 0)], -1).astype(np.int32), n_free, c)
     v2 = c.copy()
     v2[free] += y[red2.index_map[free]]
     assert np.array_equal(red2.expand(y), v2)
