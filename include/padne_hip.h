@@ -46,6 +46,7 @@ extern "C" {
 
 typedef struct padne_ctx padne_ctx;   /* device, stream, workspaces, optional RCCL communicator */
 typedef struct padne_csr padne_csr;   /* device-resident CSR matrix (f64 values, i32 indices)  */
+typedef struct padne_kkt padne_kkt;   /* device-resident plan of solve_system for one assembled system */
 
 /* ---- library / context ------------------------------------------------------------------- */
 int         padne_abi_version(void);
@@ -214,6 +215,45 @@ int padne_solve_spd(padne_ctx *ctx, const padne_csr *a, const double *b_host, do
 /* same with device-resident b and x */
 int padne_solve_spd_dev(padne_ctx *ctx, const padne_csr *a, const void *b_dev, void *x_dev,
                         int32_t n_rhs, const padne_solve_opts *opts, padne_solve_info *info);
+
+/* ---- solve_system as a whole (solver.py:767-780: L.tocsc(), spsolve, residual) ---------------------------------------
+ * The reference hands the indefinite KKT matrix (multiplier rows of voltage sources / regulators / the ground,
+ * solver.py:493-538, 544-560) to SuperLU.  Here it is reduced to the SPD system A y = b on the free potentials
+ *  and a padne_kkt plan keeps that reduction on the device: the index map, A = -P^T L P with its
+ * multigrid hierarchy, and the N-vectors r, v.  The host describes the reduction by O(#constraints) lists:
+ *   elim_sorted[n_elim]   potentials without a reduced unknown of their own, ascending: potentials known outright (the
+ *                         ground, nodes tied to it by sources, pins of floating copper) and the members of source-tied
+ *                         groups other than the group's representative;
+ *   tied_member / tied_rep[n_tied]  those members (ascending) and the representative they are numbered through;
+ *   index_map_host        optional int32[N] (NULL: built on the device as  i - #{e in elim : e < i}): a map the caller
+ *                         made itself, e.g. after a locality reordering; n_free = number of reduced unknowns.
+ * `L` is borrowed and must outlive the plan. */
+int padne_kkt_create(padne_ctx *ctx, const padne_csr *L, int64_t n_potential, int64_t n_elim,
+                     const int64_t *elim_sorted, int64_t n_tied, const int64_t *tied_member, const int64_t *tied_rep,
+                     const int32_t *index_map_host, int64_t n_free, padne_kkt **out);
+int padne_kkt_destroy(padne_kkt *plan);
+/* borrowed handle of the reduced SPD matrix (for introspection; do not destroy) */
+int padne_kkt_matrix(const padne_kkt *plan, const padne_csr **reduced_out);
+/* Stage 1 of a solve.  r_host[N]: the right-hand side (solver.py:757-760, 478-541), uploaded ONCE and in parallel with the
+ * multigrid setup of A (built on the first call and kept with the plan; opts.flags bit 2 rebuilds it).
+ * known_idx / known_val: the known part c of the potentials (v = c + P y): non-zero only on members of constraint groups.
+ * Extra right-hand sides k = 0..n_extra-1 (regulator gain columns gamma_k, solver.py:537-538) as sparse columns in
+ * ORIGINAL row indices, CSR-like: entries extra_ptr[k]..extra_ptr[k+1] of extra_row / extra_val; b_k = P^T gamma_k.
+ * The device forms b = -P^T (r - L c), solves A y = b and A z_k = b_k (zero right-hand sides are skipped; the relative
+ * tolerance is tightened so that ||b - A y|| <= abs_residual_target where opts.rtol ||b|| would be looser: the reference's
+ * absolute residual bar, tests/test_solver.py:2083-2089; 0 = off), expands v = c + P y and Z_k = P z_k, and returns
+ * probe_out[(1 + n_extra)][n_probe]: rho = r - L v, then L Z_k, at the probed unknowns (the members of the constraint
+ * groups) -- what the host needs to peel the multiplier currents from.  v stays on the device.
+ * Returns PADNE_E_NOTCONVERGED like padne_solve_spd (the iterate is kept, padne_kkt_finish may follow). */
+int padne_kkt_solve(padne_ctx *ctx, padne_kkt *plan, const double *r_host, int64_t n_known, const int64_t *known_idx,
+                    const double *known_val, int32_t n_extra, const int64_t *extra_ptr, const int64_t *extra_row,
+                    const double *extra_val, int64_t n_probe, const int64_t *probe_idx, double *probe_out,
+                    const padne_solve_opts *opts, double abs_residual_target, padne_solve_info *info);
+/* Stage 2: v += sum_k extra_coeff[k] Z_k (regulator currents), v[mult_idx] = mult_val (the recovered multiplier
+ * currents: sources, regulators, ground row), then residual_norm = ||L v - r||_2 on the ORIGINAL system
+ * (solver.py:775) while v[N] travels to v_host -- its only crossing of PCIe. */
+int padne_kkt_finish(padne_ctx *ctx, padne_kkt *plan, int32_t n_extra, const double *extra_coeff, int64_t n_mult,
+                     const int64_t *mult_idx, const double *mult_val, double *v_host, double *residual_norm_out);
 
 /* Row-partitioned runs, optional: attach the rank's owned x owned diagonal block; with precond = 1 the
  * multigrid hierarchy is then built on that block only (block-Jacobi with multigrid blocks, no

@@ -92,6 +92,12 @@ SIGNATURES = {
     "padne_residual_norm": (C.c_int, [_P, _P, _PF64, _PF64, _PF64]),
     "padne_solve_spd": (C.c_int, [_P, _P, _PF64, _PF64, C.c_int32, C.POINTER(SolveOpts), C.POINTER(SolveInfo)]),
     "padne_solve_spd_dev": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(SolveOpts), C.POINTER(SolveInfo)]),
+    "padne_kkt_create": (C.c_int, [_P, _P, _I64, _I64, _PI64, _I64, _PI64, _PI64, _PI32, _I64, C.POINTER(_P)]),
+    "padne_kkt_destroy": (C.c_int, [_P]),
+    "padne_kkt_matrix": (C.c_int, [_P, C.POINTER(_P)]),
+    "padne_kkt_solve": (C.c_int, [_P, _P, _PF64, _I64, _PI64, _PF64, C.c_int32, _PI64, _PI64, _PF64, _I64, _PI64, _PF64,
+                                  C.POINTER(SolveOpts), C.c_double, C.POINTER(SolveInfo)]),
+    "padne_kkt_finish": (C.c_int, [_P, _P, C.c_int32, _PF64, _I64, _PI64, _PF64, _PF64, _PF64]),
     "padne_amg_apply": (C.c_int, [_P, _P, _PF64, _PF64]),
     "padne_csr_set_preconditioner_block": (C.c_int, [_P, _P]),
     "padne_amg_level": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
@@ -458,6 +464,89 @@ class SolveResult:
     precond_fallbacks: int = 0      # right-hand sides redone with the Jacobi preconditioner after a multigrid failure
 
 
+class KktPlan:
+    """``padne_kkt``: the reduction of one assembled KKT system to its SPD core, resident on the device (index map,
+    reduced matrix with its multigrid hierarchy, the N-vectors).  ``solve`` + ``finish`` are the two device stages of
+    ``solver.solve_system``; the multiplier recovery between them is O(#constraints) host work."""
+
+    def __init__(self, L: "CsrMatrix", n_potential: int, elim, tied, n_free: int, index_map=None):
+        self.ctx, self.L = L.ctx, L
+        elim = _i64(elim)
+        tm = _i64([m for m, _ in tied])
+        tr = _i64([r for _, r in tied])
+        imap = None if index_map is None else _i32(index_map)
+        if imap is not None and imap.shape[0] != L.shape[0]:
+            raise ValueError("index map length must equal the matrix dimension")
+        h = _P()
+        _check(self.ctx._lib.padne_kkt_create(self.ctx._h, L._h, int(n_potential), elim.shape[0], _ptr(elim, _PI64), tm.shape[0],
+                                              _ptr(tm, _PI64), _ptr(tr, _PI64), None if imap is None else _ptr(imap, _PI32),
+                                              int(n_free), C.byref(h)))
+        self._h = h
+        self.n_free = int(n_free)
+        self.N = L.shape[0]
+
+    def close(self):
+        if getattr(self, "_h", None) and self.ctx._h:
+            self.ctx._lib.padne_kkt_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reduced_matrix(self) -> "CsrMatrix":
+        """Borrowed view of A = -P^T L P (valid while the plan lives)."""
+        h = _P()
+        _check(self.ctx._lib.padne_kkt_matrix(self._h, C.byref(h)))
+        m = CsrMatrix(self.ctx, h)
+        m._borrowed = True
+        return m
+
+    def solve(self, r, known: dict, extras: list, probes, *, rtol=1e-12, max_iter=200000, precond="amg",
+              abs_residual_target=0.0, rebuild=False):
+        """Stage 1.  ``known`` {unknown: c}; ``extras``: list of {row: value} columns; ``probes``: unknowns whose residual
+        rows come back.  Returns (probe values [(1 + len(extras)), len(probes)], SolveResult)."""
+        r = _f64(r)
+        if r.shape[0] != self.N:
+            raise ValueError("right-hand side has the wrong length")
+        kidx = _i64(sorted(known))
+        kval = _f64([known[int(i)] for i in kidx])
+        ptr, rows, vals = [0], [], []
+        for col in extras:
+            for row, val in col.items():
+                rows.append(int(row))
+                vals.append(float(val))
+            ptr.append(len(rows))
+        ptr, rows, vals = _i64(ptr), _i64(rows), _f64(vals)
+        pidx = _i64(list(probes))
+        out = np.zeros((1 + len(extras), max(len(pidx), 1)), dtype=np.float64)
+        opts = CsrMatrix._opts(rtol, 0.0, max_iter, 0, False, precond=precond, rebuild=rebuild)
+        info = SolveInfo()
+        rc = self.ctx._lib.padne_kkt_solve(self.ctx._h, self._h, _ptr(r, _PF64), kidx.shape[0], _ptr(kidx, _PI64),
+                                           _ptr(kval, _PF64), len(extras), _ptr(ptr, _PI64), _ptr(rows, _PI64),
+                                           _ptr(vals, _PF64), pidx.shape[0], _ptr(pidx, _PI64), _ptr(out, _PF64),
+                                           C.byref(opts), float(abs_residual_target), C.byref(info))
+        if rc != OK and rc != E_NOTCONVERGED:
+            _check(rc)
+        res = SolveResult(None, info.iterations, info.restarts, info.rel_residual, info.abs_residual, info.solve_seconds,
+                          info.status, info.spmv_seconds, info.precond_setup_seconds, info.operator_complexity, info.levels,
+                          info.precond_fallbacks)
+        return out[:, :len(pidx)], res
+
+    def finish(self, extra_coeff, multipliers: dict):
+        """Stage 2: (v, ||L v - r||)."""
+        coeff = _f64(extra_coeff)
+        midx = _i64(sorted(multipliers))
+        mval = _f64([multipliers[int(i)] for i in midx])
+        v = np.empty(self.N, dtype=np.float64)
+        norm = C.c_double()
+        _check(self.ctx._lib.padne_kkt_finish(self.ctx._h, self._h, coeff.shape[0], _ptr(coeff, _PF64), midx.shape[0],
+                                              _ptr(midx, _PI64), _ptr(mval, _PF64), _ptr(v, _PF64), C.byref(norm)))
+        return v, norm.value
+
+
 class CsrMatrix:
     """Device-resident CSR matrix (opaque handle of the C ABI)."""
 
@@ -470,7 +559,7 @@ class CsrMatrix:
         self.nnz = nnz.value
 
     def close(self):
-        if getattr(self, "_h", None) and self.ctx._h:
+        if getattr(self, "_h", None) and self.ctx._h and not getattr(self, "_borrowed", False):
             self.ctx._lib.padne_csr_destroy(self._h)
         self._h = None
 

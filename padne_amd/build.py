@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpadne_hip.so")
-SOURCES = ["capi.hip", "spmv.hip", "spmm.hip", "pcg.hip", "assemble.hip", "comm.hip", "amg.hip", "generate.hip"]
+SOURCES = ["capi.hip", "spmv.hip", "spmm.hip", "pcg.hip", "assemble.hip", "comm.hip", "amg.hip", "generate.hip", "kkt.hip"]
 HEADERS = ["common.hpp", os.path.join("..", "..", "include", "padne_hip.h"),
            os.path.join("..", "..", "include", "padne_hip_test.h")]
 ARCH = "gfx950"

@@ -1465,8 +1465,10 @@ extern "C" int padne_csr_power_density(padne_ctx *ctx, const padne_csr *m, const
 
 // out = scale * R^T M C: entry (i, j, v) becomes (row_map[i], col_map[j], scale*v) when both maps are >= 0,
 // duplicates are added in the order of their position in M.
-static int csr_relabel(padne_ctx *ctx, const padne_csr *m, const int32_t *row_map_host, int64_t n_rows_out,
-                       const int32_t *col_map_host, int64_t n_cols_out, double scale, padne_csr **out) {
+// The maps may be host or device arrays (hipMemcpyDefault): padne_kkt_create builds its map on the device.
+namespace padne {
+int csr_relabel(padne_ctx *ctx, const padne_csr *m, const int32_t *row_map_host, int64_t n_rows_out,
+                const int32_t *col_map_host, int64_t n_cols_out, double scale, padne_csr **out) {
     PADNE_REQUIRE(n_rows_out >= 0 && n_rows_out < 2147483647LL && n_cols_out >= 0 && n_cols_out < 2147483647LL,
                   "output shape");
     PADNE_HIP_CHECK(hipSetDevice(ctx->device));
@@ -1477,12 +1479,12 @@ static int csr_relabel(padne_ctx *ctx, const padne_csr *m, const int32_t *row_ma
     PADNE_TRY(sc.alloc(&d_cnt, (size_t)n_rows_out + 1));
     PADNE_TRY(sc.alloc(&d_slot, (size_t)n_rows_out + 1));
     PADNE_TRY(sc.alloc(&d_err, (size_t)ERR_WORDS));
-    PADNE_HIP_CHECK(hipMemcpyAsync(d_map, row_map_host, sizeof(int) * (size_t)m->n_rows, hipMemcpyHostToDevice, s));
+    PADNE_HIP_CHECK(hipMemcpyAsync(d_map, row_map_host, sizeof(int) * (size_t)m->n_rows, hipMemcpyDefault, s));
     if (col_map_host == row_map_host) {
         d_cmap = d_map;
     } else {
         PADNE_TRY(sc.alloc(&d_cmap, (size_t)m->n_cols));
-        PADNE_HIP_CHECK(hipMemcpyAsync(d_cmap, col_map_host, sizeof(int) * (size_t)m->n_cols, hipMemcpyHostToDevice, s));
+        PADNE_HIP_CHECK(hipMemcpyAsync(d_cmap, col_map_host, sizeof(int) * (size_t)m->n_cols, hipMemcpyDefault, s));
     }
     PADNE_HIP_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(int) * (size_t)(n_rows_out + 1), s));
     PADNE_HIP_CHECK(hipMemsetAsync(d_err, 0, sizeof(int) * ERR_WORDS, s));
@@ -1561,6 +1563,7 @@ static int csr_relabel(padne_ctx *ctx, const padne_csr *m, const int32_t *row_ma
     PADNE_HIP_CHECK(hipGetLastError());
     return finish_rows<false>(ctx, sc, n_rows_out, n_cols_out, 0, 0, nullptr, nullptr, d_slot, d_key, d_val, d_err, out);
 }
+}  // namespace padne
 
 extern "C" int padne_csr_relabel(padne_ctx *ctx, const padne_csr *m, const int32_t *row_map_host, int64_t n_rows_out,
                                  const int32_t *col_map_host, int64_t n_cols_out, double scale, padne_csr **out) {

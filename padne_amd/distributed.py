@@ -411,7 +411,7 @@ class DistributedSolver:
         sel = plan.row_map >= 0
         b_red = np.bincount(plan.row_map[sel], weights=resid[sel], minlength=n_owned).astype(np.float64)
         self.owned_reduced_global = plan.reps_owned
-        self.b_norm2 = float(np.einsum("i,i->", b_red, b_red))    # this rank's share of ||b||^2 (no threaded BLAS: solver._effective_rtol)
+        self.b_norm2 = float(np.einsum("i,i->", b_red, b_red))    # this rank's share of ||b||^2 (einsum, not a threaded BLAS call: its spinning workers delay the HIP runtime)
         self.b = ctx.to_device(b_red)
         self.x = ctx.empty(n_owned)
         self.nnz = self.A.nnz
@@ -498,7 +498,7 @@ def solve_partitioned(plan: RankPlan, ctx, dist=None, team=None, rtol: float = 1
             dist.all_gather_object(parts, obj)
             return parts
         # the reference's absolute residual bar (1e-9, tests/test_solver.py:2083-2089) as on one GPU: a large right-hand
-        # side tightens the relative tolerance (solver._effective_rtol), decided from the global norm so that all ranks agree
+        # side tightens the relative tolerance (solver.ABS_RESIDUAL_TARGET), decided from the global norm so that all ranks agree
         from . import solver as _solver
 
         def solve_for(b_norm2_local):

@@ -352,10 +352,18 @@ class SystemMatrix:
         self.xy, self.tri, self.mesh_offsets = xy, tri, mesh_offsets
         # pairs of potentials coupled by lumped stamps (optional): lets solve_system find floating copper
         self.links = links
+        self._plans = {}            # device plans of solve_system by the structure of the reduction (see there)
 
     @property
     def nnz(self) -> int:
         return self.dev.nnz
+
+    def close(self):
+        """Release the device memory of the system and of the solve plans kept with it."""
+        for plan in self._plans.values():
+            plan.close()
+        self._plans.clear()
+        self.dev.close()
 
     def tocsr(self):
         if self._host is None:
@@ -453,30 +461,10 @@ def assemble_from_arrays(meshes, conductances, stamps: StampList, n_potential: i
 # hold exactly by construction), so its residual is driven to a quarter of that bar whenever 1e-12 ||b|| is looser
 # than that -- a voltage source across a copper plane puts kiloamperes into b.  Below RTOL_FLOOR nothing is gained:
 # that is what evaluating b - A y in binary64 can resolve (the solve stops at that floor and reports what it reached).
+# The rule itself is applied where ||b|| is known: on the device (padne_kkt_solve, abs_residual_target), and from the
+# globally reduced norm in the row-partitioned path (distributed.solve_partitioned).
 ABS_RESIDUAL_TARGET = 2.5e-10
 RTOL_FLOOR = 2e-15
-
-
-def _effective_rtol(bs, rtol: float, norms=None) -> float:
-    # (einsum, not linalg.norm / dot: a threaded BLAS leaves its worker threads spinning afterwards, which delays the HIP
-    # runtime's completion handling -- measured: 65-72 ms instead of 25 ms for the 28 iterations of config C4 on a box that
-    # shows 256 cores to a 16-core share)
-    norm = max((float(x) for x in norms), default=0.0) if norms is not None else \
-        max((float(np.sqrt(np.einsum("i,i->", b, b))) for b in bs), default=0.0)
-    if norm > 0.0 and rtol * norm > ABS_RESIDUAL_TARGET:
-        return max(ABS_RESIDUAL_TARGET / norm, RTOL_FLOOR)
-    return rtol
-
-
-def _solve_reduced(A: _hip.CsrMatrix, b: np.ndarray, rtol: float):
-    if A.shape[0] == 0:
-        return np.zeros(0), 0, 0.0, 0.0
-    norm2 = float(np.einsum("i,i->", b, b))                      # one pass: the zero test and the tolerance below
-    if norm2 == 0.0 and not np.any(b):
-        return np.zeros_like(b), 0, 0.0, 0.0
-    res = A.solve_spd(b, rtol=_effective_rtol([b], rtol, norms=[np.sqrt(norm2)]), max_iter=MAX_ITER, raise_on_fail=False)
-    _warn_if_stalled(res, rtol)
-    return res.x, res.iterations, res.rel_residual, res.seconds
 
 
 STALL_WARN_ABOVE = 1e-9
@@ -495,23 +483,6 @@ def _warn_if_stalled(res, rtol: float) -> None:
                       f"(requested {rtol:.1e}) after {res.iterations} iterations", SolverWarning)
 
 
-def _solve_reduced_many(A: _hip.CsrMatrix, bs: list, rtol: float):
-    """Solve A y_k = b_k for every right-hand side of the list (zero right-hand sides cost nothing)."""
-    if len(bs) == 1:
-        y, it, rr, sec = _solve_reduced(A, bs[0], rtol)
-        return [y], it, rr, sec
-    live = [k for k, b in enumerate(bs) if A.shape[0] > 0 and np.any(b)]
-    sols = [np.zeros_like(b) for b in bs]
-    if not live:
-        return sols, 0, 0.0, 0.0
-    res = A.solve_spd(np.stack([bs[k] for k in live]), rtol=_effective_rtol([bs[k] for k in live], rtol),
-                      max_iter=MAX_ITER, raise_on_fail=False)
-    _warn_if_stalled(res, rtol)
-    for row, k in enumerate(live):
-        sols[k] = res.x[row]
-    return sols, res.iterations, res.rel_residual, res.seconds
-
-
 def solve_system(L, r: np.ndarray, *, rtol: float = RTOL, reorder=None, n_potential: Optional[int] = None):
     """Solve ``L v = r`` and return ``(v, SolverInfo)`` like ``solver.py:767-780``.
 
@@ -526,7 +497,7 @@ def solve_system(L, r: np.ndarray, *, rtol: float = RTOL, reorder=None, n_potent
     current loop).
     """
     ctx = get_context()
-    r = np.asarray(r, dtype=DTYPE)
+    r = np.ascontiguousarray(r, dtype=DTYPE)
     if isinstance(L, SystemMatrix):
         dev, layout = L.dev, L.layout
         owned = False
@@ -553,42 +524,55 @@ def solve_system(L, r: np.ndarray, *, rtol: float = RTOL, reorder=None, n_potent
         pins = []
     if pins:
         log.info(f"{len(pins)} floating component(s) held at 0 V at unknown(s) {pins[:8]}")
+    # O(#constraints): what the reduction eliminates, ties and knows; the index map itself is made on the device
     red: Reduction = build_reduction(layout, pins)
+    want_reorder = False
     if isinstance(L, SystemMatrix) and L.xy is not None and reorder is not False:
         # CGAL numbers vertices in insertion order; when neighbours are far apart in the numbering the SpMV
         # gathers miss the caches, so the reduced system is solved in a band numbering by horizontal strips
         # (internal: v comes back unpermuted)
-        from .reduction import apply_locality_ordering, ordering_is_scattered
-        if reorder is True or ordering_is_scattered(L.tri, len(L.xy)):
+        from .reduction import ordering_is_scattered
+        want_reorder = reorder is True or ordering_is_scattered(L.tri, len(L.xy))
+    # the plan -- index map, A = -P^T L P and its multigrid hierarchy on the device -- depends on the STRUCTURE of the
+    # reduction only (the values of the sources enter through c and r): kept with the assembled system, so a second
+    # right-hand side on the same system finds everything in place, like a second solve with a kept factorisation
+    key = (red.elim.tobytes(), tuple(red.tied), bool(want_reorder))
+    plan = L._plans.get(key) if isinstance(L, SystemMatrix) else None
+    if plan is None:
+        imap = None
+        if want_reorder:
+            from .reduction import apply_locality_ordering
             apply_locality_ordering(red, L.xy, L.mesh_offsets)
-    N = layout.size
-    A = dev.reduce(red.index_map, red.n_free, -1.0)
+            imap = red.index_map
+        plan = _hip.KktPlan(dev, layout.n_potential, red.elim, red.tied, red.n_free, index_map=imap)
+        if isinstance(L, SystemMatrix):
+            for old in L._plans.values():             # one structure at a time: a plan holds GBs at N = 10 M
+                old.close()
+            L._plans.clear()
+            L._plans[key] = plan
     try:
-        Lc_vec = dev.matvec(red.c) if red.has_known_part else None
-        b0 = red.rhs(r, Lc_vec)
-        # all right-hand sides of this system in one call: the library advances groups of 5-8 of them in lockstep
-        gks = [red.project({row: val for row, val in cst.gamma.items()}) for cst in red.regulators]
-        sols, iters, relres, secs = _solve_reduced_many(A, [b0] + gks, rtol)
-        y0 = sols[0]
-        v = red.expand(y0)
-        mult_known = {}
-        if red.regulators:
+        members = sorted({int(x) for mem, cons, _ in red.groups if cons for x in mem})
+        probes, res = plan.solve(r, red.known, [dict(cst.gamma) for cst in red.regulators], members, rtol=rtol,
+                                 max_iter=MAX_ITER, abs_residual_target=ABS_RESIDUAL_TARGET)
+        _warn_if_stalled(res, rtol)
+        at = {x: k for k, x in enumerate(members)}
+
+        class _Rows:                                   # rho_x of a member x, for Reduction.multipliers
+            def __init__(self, i_vec):
+                self.i_vec = i_vec
+
+            def __getitem__(self, x):
+                k = at[int(x)]
+                # rho(v + sum_k i_k Z_k) = rho(v) - sum_k i_k (L Z_k): the device returned both at the members
+                return probes[0, k] - sum(self.i_vec[j] * probes[1 + j, k] for j in range(len(self.i_vec)))
+        K = len(red.regulators)
+        keys = [cst.index for cst in red.regulators]
+        i_reg = np.zeros(K)
+        if K:
             # y = y0 + sum_k i_k z_k with A z_k = P^T gamma_k:  row x reads L_x.v + gamma_k[x] i_k = r_x, so
             # summing a group's rows gives  -P^T L P y = -P^T (r - L c) + sum_k i_k P^T gamma_k
-            Z = []
-            for zk in sols[1:]:
-                w = np.zeros(N)
-                free = red.index_map >= 0
-                w[free] = zk[red.index_map[free]]
-                Z.append(w)
-            K = len(red.regulators)
-            keys = [cst.index for cst in red.regulators]
-
             def currents_for(i_vec):
-                vv = v + sum(i_vec[k] * Z[k] for k in range(K))
-                rho = r - dev.matvec(vv)
-                return red.multipliers(rho, dict(zip(keys, i_vec)))
-
+                return red.multipliers(_Rows(i_vec), dict(zip(keys, i_vec)))
             base = currents_for(np.zeros(K))
             F0 = np.array([base[k] for k in keys])
             J = np.zeros((K, K))
@@ -598,19 +582,16 @@ def solve_system(L, r: np.ndarray, *, rtol: float = RTOL, reorder=None, n_potent
                 ck = currents_for(e)
                 J[:, k] = np.array([ck[q] for q in keys]) - F0
             i_reg = np.linalg.solve(np.eye(K) - J, F0)
-            v = v + sum(i_reg[k] * Z[k] for k in range(K))
-            mult_known = dict(zip(keys, i_reg))
-        rho = r - dev.matvec(v)
-        for idx, val in red.multipliers(rho, mult_known).items():
-            if idx >= 0:                        # negative: the current through the pin of a floating component
-                v[idx] = val
-        residual_norm = dev.residual_norm(v, r)
+        mult_known = dict(zip(keys, i_reg))
+        mult = {idx: val for idx, val in red.multipliers(_Rows(i_reg), mult_known).items() if idx >= 0}
+        # (negative index: the current through the pin of a floating component, not an unknown of the system)
+        v, residual_norm = plan.finish(i_reg, mult)
     finally:
-        A.close()
         if owned:
+            plan.close()
             dev.close()
     info = SolverInfo(ground_node_current=float(v[-1]), residual_norm=float(residual_norm),
-                      iterations=int(iters), rel_residual=float(relres), solve_seconds=float(secs))
+                      iterations=int(res.iterations), rel_residual=float(res.rel_residual), solve_seconds=float(res.seconds))
     return v, info
 
 
@@ -753,7 +734,7 @@ def solve_meshed(prob, meshes, mesh_index_to_layer_index, *, filtered_networks=N
     try:
         v, solver_info = solve_system(L, r)
     except BaseException:
-        L.dev.close()
+        L.close()
         raise
     if not np.isclose(solver_info.ground_node_current, 0):
         warnings.warn(
@@ -767,7 +748,7 @@ def solve_meshed(prob, meshes, mesh_index_to_layer_index, *, filtered_networks=N
         layer_solutions = produce_layer_solutions(prob.layers, vindex, meshes, mesh_index_to_layer_index, v,
                                                   disconnected_meshes_by_layer, system=L)
     finally:
-        L.dev.close()
+        L.close()
     return Solution(problem=prob, layer_solutions=layer_solutions, solver_info=solver_info)
 
 

@@ -273,6 +273,38 @@ def test_solve_system_accepts_a_bare_scipy_matrix(ctx, name):
     assert info.residual_norm < 1e-9
 
 
+def test_solve_system_keeps_its_device_plan_with_the_assembled_system(ctx):
+    """``solve_system`` (solver.py:767-780) on the device: the reduction plan (index map built from the O(#constraints)
+    lists, A = -P^T L P, its hierarchy, the N-vectors) is kept with the assembled system by the STRUCTURE of the
+    reduction.  A second right-hand side on the same system -- other source currents, another source voltage -- reuses
+    it and still equals the reference's direct solve; a system with another structure (a further voltage source) gets a new
+    plan; ``close`` releases it."""
+    g = H.load_golden("voltage_source")
+    meshes, sig, stamps, r, n_pot = H.product_system(g)
+    L = solver.assemble_from_arrays(meshes, sig, stamps, n_pot)
+    Lh = H.golden_L(g)
+    v, info = solver.solve_system(L, r)
+    assert len(L._plans) == 1
+    plan = next(iter(L._plans.values()))
+    scale = np.abs(g["v"]).max()
+    assert np.abs(v - g["v"]).max() <= REL_TOL * scale and info.residual_norm < 1e-9
+    A = plan.reduced_matrix().to_scipy()
+    assert A.shape[0] == plan.n_free and abs(A - A.T).max() <= 1e-12 * abs(A).max()
+    r2 = r.copy()
+    iv = [c.index for c in L.layout.constraints if c.n >= 0][0]
+    r2[iv] = 2.5 * r[iv] + 0.125                                     # another source voltage: c changes, the structure not
+    r2[3] += 0.75
+    r2[n_pot - 2] -= 0.75
+    v2, info2 = solver.solve_system(L, r2)
+    assert next(iter(L._plans.values())) is plan and len(L._plans) == 1
+    v2_ref = O.solve_system(Lh, r2)[0]
+    assert np.abs(v2 - v2_ref).max() <= REL_TOL * np.abs(v2_ref).max() and info2.residual_norm < 1e-9
+    again, _ = solver.solve_system(L, r)                             # and back: nothing of the second solve sticks
+    assert np.array_equal(again, v)
+    L.close()
+    assert not L._plans
+
+
 def test_pcg_vs_direct_solve_on_layered_system(ctx):
     sysm = synthetic.layered_system(4, 150, 150, via_lattice=8)
     els = [("R", int(a), int(b), float(r)) for a, b, r in zip(*sysm.resistors)]
@@ -335,7 +367,8 @@ def test_converging_iteration_is_complete_when_the_gpu_is_shared(ctx):
     import torch
     xy, tri = synthetic.jittered_grid(700, 700, seed=6)               # 490 k unknowns: the vector kernels fill their grid
     A = (-O.laplace_operator(xy, tri).tocsr()[1:, 1:]).tocsr()
-    b = np.random.default_rng(3).uniform(-1, 1, A.shape[0])
+    b = np.zeros(A.shape[0])                                         # 1 A in, 1 A out: the right-hand side of the configs
+    b[200 * 700 + 150], b[500 * 700 + 560] = 1.0, -1.0
     d = ctx.csr_from_scipy(A)
     quiet = d.solve_spd(b, precond="amg")
     assert quiet.status == _hip.OK and quiet.restarts == 0

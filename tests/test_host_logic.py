@@ -216,6 +216,35 @@ def _solve_through_the_reduction(L, r, layout, pins=None):
     return v
 
 
+@pytest.mark.parametrize("name", H.golden_names())
+def test_sparse_description_of_the_reduction_is_the_dense_index_map(name):
+    """padne_kkt_create builds its index map on the device from the O(#constraints) lists of the reduction:
+    imap[i] = i - #{e in elim : e < i} for the potentials that are not eliminated, tied members through their
+    representative.  The same formula in numpy must give the dense map of the host restatement, and ``index_of`` (single
+    lookups without the dense map) must agree with it; the known part c lives on the listed unknowns only."""
+    g = H.load_golden(name)
+    L = H.golden_L(g)
+    layout = reduction.infer_layout(L, g["r"])
+    red = reduction.build_reduction(layout)
+    N, n_pot = layout.size, layout.n_potential
+    assert red._index_map is None                                       # nothing dense was made to build it
+    assert np.all(np.diff(red.elim) > 0) and (len(red.elim) == 0 or red.elim[-1] < n_pot)
+    assert red.n_free == n_pot - len(red.elim)
+    i = np.arange(N)
+    pos = np.searchsorted(red.elim, i)
+    hit = (pos < len(red.elim)) & (red.elim[np.minimum(pos, max(len(red.elim) - 1, 0))] == i) if len(red.elim) else np.zeros(N, bool)
+    dev = np.where((i < n_pot) & ~hit, i - pos, -1).astype(np.int32)
+    for member, rep in red.tied:
+        assert member > rep and dev[rep] >= 0
+        dev[member] = dev[rep]
+    lookups = [red.index_of(x) for x in range(N)]
+    assert np.array_equal(dev, red.index_map) and lookups == list(red.index_map)
+    c = np.zeros(N)
+    for x, val in red.known.items():
+        c[x] = val
+    assert np.array_equal(c, red.c) and all(val != 0.0 for val in red.known.values())
+
+
 @pytest.mark.parametrize("name", ["unit_square", "two_layer_via", "voltage_source", "glue_sources", "regulator",
                                   "lumped_only", "strip20"])
 def test_reduction_reproduces_the_direct_solve(name):
