@@ -276,6 +276,12 @@ int padne_amg_level(padne_ctx *ctx, padne_csr *a, int level, int which, const pa
  * the KD-tree build is two thirds of the host time of solve(). */
 int padne_nearest_vertex(padne_ctx *ctx, int64_t n_points, const double *xy_host, int64_t n_query,
                          const double *query_host, int64_t *index_out_host);
+/* The same, and for every query the number of points at EXACTLY the minimum distance (tie_count_out_host, >= 1).  The
+ * reference's KD-tree (solver.py:389-392, query :425) returns whichever of several equidistant vertices its traversal meets
+ * first; a caller that wants the reference's choice re-resolves the queries with a count above 1 with that tree (they are
+ * rare: a connection exactly between vertices of an unjittered grid) -- NodeIndexer.create does. */
+int padne_nearest_vertex_ties(padne_ctx *ctx, int64_t n_points, const double *xy_host, int64_t n_query,
+                              const double *query_host, int64_t *index_out_host, int32_t *tie_count_out_host);
 
 /* ---- post-processing ----------------------------------------------------------------------- */
 /* per-face power density  p = sigma*|grad V|^2 with the reference's barycentric difference

@@ -102,6 +102,7 @@ SIGNATURES = {
     "padne_csr_set_preconditioner_block": (C.c_int, [_P, _P]),
     "padne_amg_level": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
     "padne_nearest_vertex": (C.c_int, [_P, _I64, _PF64, _I64, _PF64, _PI64]),
+    "padne_nearest_vertex_ties": (C.c_int, [_P, _I64, _PF64, _I64, _PF64, _PI64, _PI32]),
     "padne_power_density": (C.c_int, [_P, _I64, _PF64, _I64, _PI32, _I64, _PI64, _PI64, _PF64, _PF64, _PF64]),
     "padne_csr_power_density": (C.c_int, [_P, _P, _PF64, _PF64]),
     "padne_face_gradient": (C.c_int, [_P, _I64, _PF64, _I64, _PI32, _I64, _PI64, _PI64, _PF64, _PF64, _PF64]),
@@ -342,15 +343,17 @@ class Context:
                                                   _P(tri.ptr + 12 * int(tri_offset))))
         return xy, tri
 
-    def nearest_vertex(self, points: np.ndarray, queries: np.ndarray) -> np.ndarray:
-        """Index of the nearest of ``points`` (n, 2) for every row of ``queries`` (m, 2); ties to the smallest index."""
+    def nearest_vertex(self, points: np.ndarray, queries: np.ndarray, with_ties: bool = False):
+        """Index of the nearest of ``points`` (n, 2) for every row of ``queries`` (m, 2); ties to the smallest index.
+        ``with_ties``: also the number of points at exactly the minimum distance, per query."""
         pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 2)
         q = np.ascontiguousarray(queries, dtype=np.float64).reshape(-1, 2)
         out = np.empty(len(q), dtype=np.int64)
+        ties = np.ones(len(q), dtype=np.int32)
         if len(q):
-            _check(self._lib.padne_nearest_vertex(self._h, len(pts), _ptr(pts, _PF64), len(q), _ptr(q, _PF64),
-                                                  _ptr(out, _PI64)))
-        return out
+            _check(self._lib.padne_nearest_vertex_ties(self._h, len(pts), _ptr(pts, _PF64), len(q), _ptr(q, _PF64),
+                                                       _ptr(out, _PI64), _ptr(ties, _PI32)))
+        return (out, ties) if with_ties else out
 
     def power_density(self, xy, tri, mesh_vertex_offset, mesh_tri_offset, conductance, potential) -> np.ndarray:
         # xy / tri: host arrays, or DeviceArrays (e.g. filled by generate_grid_mesh): then nothing crosses PCIe

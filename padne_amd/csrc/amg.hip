@@ -105,6 +105,35 @@ static double theta_val() {
     return th;
 }
 
+// ---- XCD-aware row order --------------------------------------------------------------------------------------------
+// Workgroups are dealt to the 8 XCDs round-robin (b, b + 8, b + 16, ... share an XCD and its private 4 MiB L2).  A kernel
+// that walks the rows in workgroup order therefore shows every XCD rows from all over the matrix, and whatever the rows
+// of a mesh neighbourhood share -- the rows of P around an aggregate, the slots of A P a coarse row gathers, 1/diag of
+// the neighbours -- is fetched by up to 8 L2s and has left each of them long before the neighbouring scan line comes by
+// (rocprofv3 FETCH_SIZE: 19x the algorithmic bytes over the setup of round 2).  As in the SpMV kernel (spmv.hip) every XCD
+// gets one contiguous eighth of the rows and sweeps it front to back: xcd_bid maps the hardware workgroup index to the
+// logical one (a bijection; the last gridDim % 8 workgroups keep their place).  PADNE_NO_XCD_MAP=1 switches it off (A/B).
+__device__ int g_xcd_map = 1;
+__device__ __forceinline__ unsigned xcd_bid() {
+    const unsigned b = blockIdx.x, per = gridDim.x >> 3;
+    if (!g_xcd_map || b >= (per << 3)) return b;
+    return (b & 7u) * per + (b >> 3);
+}
+// the same for kernels whose waves stride over 64-row tiles: [first, last) tile range of this workgroup's XCD, the wave's
+// start inside it and its stride (gridDim a multiple of 8, else one slab)
+struct XcdSweep { long long t0, t1, stride; };
+__device__ __forceinline__ XcdSweep xcd_sweep(const long long n_tiles, const int waves_per_block, const int w) {
+    const unsigned G = gridDim.x;
+    const unsigned nslab = (g_xcd_map && G % kNumXcd == 0) ? kNumXcd : 1;
+    const unsigned slab = blockIdx.x % nslab;
+    XcdSweep sw;
+    const long long s0 = (long long)slab * n_tiles / nslab;
+    sw.t1 = (long long)(slab + 1) * n_tiles / nslab;
+    sw.t0 = s0 + (long long)(blockIdx.x / nslab) * waves_per_block + w;
+    sw.stride = (long long)(G / nslab) * waves_per_block;
+    return sw;
+}
+
 // ---- small kernels -----------------------------------------------------------------------------
 
 
@@ -160,9 +189,9 @@ __global__ __launch_bounds__(256) void strength_mark(int n, int n_wtiles, const 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     unsigned char *rid = rid_all + w * CH;
     double *pv = pv_all + w * CH;
-    const long long W = (long long)gridDim.x * 4, gw = (long long)blockIdx.x * 4 + w;
+    const XcdSweep sw = xcd_sweep(n_wtiles, 4, w);
     double my_max = 0.0, my_plain = 0.0;
-    for (long long wt = gw; wt < n_wtiles; wt += W) {
+    for (long long wt = sw.t0; wt < sw.t1; wt += sw.stride) {
         const int row0 = (int)wt * 64;
         const int row1 = min(row0 + 64, n);
         const int r = row0 + lane;
@@ -552,7 +581,7 @@ __global__ void agg_from_roots(int n, const signed char *__restrict__ state, con
 
 __global__ void agg_join(int n, const int *__restrict__ srow, const int *__restrict__ scol,
                          const double *__restrict__ vals, const int *__restrict__ agg_in, int *__restrict__ agg_out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = xcd_bid() * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int a = agg_in[i];
     if (a < 0) {
@@ -698,7 +727,7 @@ __global__ void transpose_count(long long nnz, const int *__restrict__ cols, int
 __global__ void transpose_fill(int n_rows, const int *__restrict__ rowptr, const int *__restrict__ cols,
                                const double *__restrict__ vals, const int *__restrict__ slot_ptr,
                                int *__restrict__ cursor, long long *__restrict__ key, double *__restrict__ val) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = xcd_bid() * blockDim.x + threadIdx.x;
     if (i >= n_rows) return;
     for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
         const int c = cols[k];
@@ -714,7 +743,7 @@ __global__ void transpose_fill(int n_rows, const int *__restrict__ rowptr, const
 // R (A P), which reads it by rows anyway, so it is never compacted.
 __global__ void spgemm_count(int n_rows, const int *__restrict__ xr, const int *__restrict__ xc,
                              const int *__restrict__ yr, const int *__restrict__ ye, int *__restrict__ cnt) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = xcd_bid() * blockDim.x + threadIdx.x;
     if (i >= n_rows) return;
     long long c = 0;
     for (int k = xr[i]; k < xr[i + 1]; ++k) {
@@ -773,7 +802,7 @@ __global__ __launch_bounds__(128) void spgemm_rows_lds(int n_rows, const int *__
     __shared__ int Kc[CAP][128];
     __shared__ double Vc[CAP][128];
     const int t = threadIdx.x;
-    const int i = blockIdx.x * 128 + t;
+    const int i = xcd_bid() * 128 + t;
     if (i >= n_rows) return;
     int m = 0;
     bool overflow = false;
@@ -951,20 +980,40 @@ __global__ __launch_bounds__(256) void spgemm_rows_wave(int n_rows, const int *_
         // 4. every lane sums the products of its column(s) in generation order
         long long *K = key + slot_ptr[i];
         double *V = val + slot_ptr[i];
+        // (ranks by bisection + one ballot per rank instead of every lane walking the whole product list: see
+        // spgemm_rows_sub, step 4)
         for (int q0 = 0; q0 < nd; q0 += 64) {
             const int q = q0 + lane;
-            const int col = q < nd ? sk[q] : EMPTY;
+            const int q1 = min(q0 + 64, nd);
             double acc = 0.0;
             bool first = true;
-            for (int p = 0; p < np; ++p) {
-                if (pc[p] == col) {
-                    const double v = pv[p];
+            for (int base = 0; base < np; base += 64) {
+                const int p = base + lane;
+                int rk = -1;
+                if (p < np) {
+                    const int c = pc[p];
+                    int lo = 0, hi = nd;                   // largest t with sk[t] <= c (c is one of them)
+                    while (hi - lo > 1) {
+                        const int m = (lo + hi) >> 1;
+                        if (sk[m] <= c) lo = m; else hi = m;
+                    }
+                    rk = lo;
+                }
+                unsigned long long mine = 0ull;
+                for (int t = q0; t < q1; ++t) {
+                    const unsigned long long m = __ballot(rk == t);
+                    if (q == t) mine = m;
+                }
+                while (mine != 0ull) {
+                    const int b = __ffsll((long long)mine) - 1;
+                    const double v = pv[base + b];
                     acc = first ? v : acc + v;
                     first = false;
+                    mine &= mine - 1ull;
                 }
             }
             if (q < nd) {
-                K[q] = (long long)col << 32;
+                K[q] = (long long)sk[q] << 32;
                 V[q] = acc;
             }
         }
@@ -998,12 +1047,18 @@ __global__ __launch_bounds__(256) void spgemm_rows_sub(int n_rows, const int *__
     int *pc = s_pc[g], *ht = s_ht[g], *dk = s_dk[g], *sk = s_sk[g], *off = s_off[g], *ys = s_ys[g];
     double *pv = s_pv[g], *xs = s_xv[g];
     constexpr int EMPTY = -1;
-    const int stride = gridDim.x * G;
+    // every XCD sweeps its own contiguous eighth of the rows (see xcd_bid): the rows of Y that neighbouring rows of X
+    // gather (the slots of A P around an aggregate) are then still in that XCD's L2 when the next row asks for them
+    const int nslab = (g_xcd_map && gridDim.x % kNumXcd == 0) ? kNumXcd : 1;
+    const int slab = blockIdx.x % nslab;
+    const int row_end = (int)((long long)(slab + 1) * n_rows / nslab);
+    const int row_first = (int)((long long)slab * n_rows / nslab) + (int)(blockIdx.x / nslab) * G + g;
+    const int stride = (int)(gridDim.x / nslab) * G;
     int nx_n = 0, len_n = 0, ystart_n = 0;
     double a_n = 0.0;
     auto prefetch = [&](int row) {
         nx_n = 0; len_n = 0; ystart_n = 0; a_n = 0.0;
-        if (row < n_rows) {
+        if (row < row_end) {
             const int x0 = xr[row];
             nx_n = xr[row + 1] - x0;
             if (nx_n <= LANES && sl < nx_n) {
@@ -1014,8 +1069,8 @@ __global__ __launch_bounds__(256) void spgemm_rows_sub(int n_rows, const int *__
             }
         }
     };
-    prefetch(blockIdx.x * G + g);
-    for (int i = blockIdx.x * G + g; i < n_rows; i += stride) {
+    prefetch(row_first);
+    for (int i = row_first; i < row_end; i += stride) {
         const int nx = nx_n, len = len_n, ystart = ystart_n;
         const double a = a_n;
         prefetch(i + stride);
@@ -1089,22 +1144,44 @@ __global__ __launch_bounds__(256) void spgemm_rows_sub(int n_rows, const int *__
         __builtin_amdgcn_wave_barrier();
         long long *K = key + slot_ptr[i];
         double *V = val + slot_ptr[i];
-        for (int q0 = 0; q0 < nd; q0 += LANES) {
-            const int q = q0 + sl;
-            const int col = q < nd ? sk[q] : EMPTY;
-            double acc = 0.0;
-            bool first = true;
-            for (int p = 0; p < np; ++p) {
-                if (pc[p] == col) {
-                    const double v = pv[p];
-                    acc = first ? v : acc + v;
-                    first = false;
+        // 4. lane q owns the q-th distinct column (nd <= HT / 2 <= LANES) and adds ITS products in generation order.
+        //    Every lane walking the whole product list (np broadcast reads and compares per lane, nd of LANES lanes with
+        //    anything to add) was instruction-bound: ~550 wave instructions for the 92 products of a row of R (A P) on the
+        //    fine level, 1.5 of the kernel's 2.7 ms.  Instead the products find the rank of their column by bisection in
+        //    the sorted list, a ballot per rank tells lane q which products of the chunk are its own, and it adds just
+        //    those -- still in generation order (chunks in order, bits of a ballot in lane order).
+        static_assert(HT / 2 <= LANES, "one lane per distinct column");
+        double acc = 0.0;
+        bool first = true;
+        for (int base = 0; base < np; base += LANES) {
+            const int p = base + sl;
+            int rk = -1;
+            if (p < np) {
+                const int c = pc[p];
+                int lo = 0, hi = nd;                       // largest q with sk[q] <= c (c is one of them)
+                while (hi - lo > 1) {
+                    const int m = (lo + hi) >> 1;
+                    if (sk[m] <= c) lo = m; else hi = m;
                 }
+                rk = lo;
             }
-            if (q < nd) {
-                K[q] = (long long)col << 32;
-                V[q] = acc;
+            unsigned long long mine = 0ull;
+            for (int q = 0; q < nd; ++q) {
+                const unsigned long long m = __ballot(rk == q);
+                if (sl == q) mine = m;
             }
+            mine = (mine >> (sub * LANES)) & sub_mask;
+            while (mine != 0ull) {
+                const int b = __ffsll((long long)mine) - 1;
+                const double v = pv[base + b];
+                acc = first ? v : acc + v;
+                first = false;
+                mine &= mine - 1ull;
+            }
+        }
+        if (sl < nd) {
+            K[sl] = (long long)sk[sl] << 32;
+            V[sl] = acc;
         }
         if (sl == 0) row_len[i] = nd;
         __builtin_amdgcn_wave_barrier();
@@ -2067,7 +2144,8 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
             if (avg <= 110.0) {
                 // short rows: two rows per wave with small limits first (2.5 KiB of LDS per row: 56 rows in flight per
                 // CU), then one row per wave for the rows that did not fit
-                const unsigned gs = (unsigned)std::min<long long>(((long long)n + 7) / 8, 16384);
+                unsigned gs = (unsigned)std::min<long long>(((long long)n + 7) / 8, 16384);
+                if (const char *ge = getenv("PADNE_SPGEMM_SUB_GRID")) gs = std::min(gs, (unsigned)std::max(8, atoi(ge)));
                 hipLaunchKernelGGL((spgemm_rows_sub<128, 64, 32>), dim3(gs), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
                                    y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len);
                 hipLaunchKernelGGL(collect_pending_rows, dim3(nblk(n)), dim3(256), 0, s, n, (const int *)row_len, pend, pend_count);
@@ -2382,6 +2460,16 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         double lo = 0.0, hi = 0.0;
         PADNE_TRY(f32_range(ctx, A0, &lo, &hi));
         want_f32 = lo >= 1e-15 && hi <= 1e15;
+    }
+    {
+        // A/B switch of the XCD-aware row order (xcd_bid): the device copy of the flag follows the environment
+        static int applied[64] = {0};
+        const int want = getenv("PADNE_NO_XCD_MAP") != nullptr ? 0 : 1;
+        if (ctx->device >= 0 && ctx->device < 64 && applied[ctx->device] != want + 1) {
+            PADNE_HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_xcd_map), &want, sizeof(int), 0, hipMemcpyHostToDevice, ctx->stream));
+            PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            applied[ctx->device] = want + 1;
+        }
     }
     Amg *amg = new Amg();
     amg->device = ctx->device;

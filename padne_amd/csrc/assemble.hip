@@ -1713,9 +1713,12 @@ constexpr int kNnChunk = 4096;
 
 __global__ __launch_bounds__(256) void nn_chunk_kernel(long long n, const double *__restrict__ xy, int nq,
                                                        const double *__restrict__ q, double *__restrict__ part_d,
-                                                       long long *__restrict__ part_i) {
+                                                       long long *__restrict__ part_i, int *__restrict__ part_c) {
+    // part_c: how many vertices of the chunk sit at exactly the minimum distance (ties: the reference's KD-tree resolves
+    // them by traversal order, the caller re-resolves those queries with the tree -- padne_nearest_vertex_ties)
     __shared__ double sd[4];
     __shared__ long long si[4];
+    __shared__ int sc[4];
     const long long base = (long long)blockIdx.x * kNnChunk;
     double px[kNnChunk / 256], py[kNnChunk / 256];
 #pragma unroll
@@ -1729,61 +1732,92 @@ __global__ __launch_bounds__(256) void nn_chunk_kernel(long long n, const double
         const double qx = q[2 * j], qy = q[2 * j + 1];
         double best = 1e300;
         long long bi = 0x7fffffffffffffffLL;
+        int cnt = 0;
 #pragma unroll
         for (int k = 0; k < kNnChunk / 256; ++k) {
             const long long i = base + threadIdx.x + 256LL * k;
             const double dx = px[k] - qx, dy = py[k] - qy;
             const double d = dx * dx + dy * dy;
-            if (i < n && (d < best || (d == best && i < bi))) {
-                best = d;
-                bi = i;
+            if (i < n) {
+                if (d < best) {
+                    best = d;
+                    bi = i;
+                    cnt = 1;
+                } else if (d == best) {
+                    cnt += 1;
+                    if (i < bi) bi = i;
+                }
             }
         }
         for (int off = 32; off > 0; off >>= 1) {
             const double od = __shfl_down(best, off, 64);
             const long long oi = __shfl_down(bi, off, 64);
-            if (od < best || (od == best && oi < bi)) {
+            const int oc = __shfl_down(cnt, off, 64);
+            if (od < best) {
                 best = od;
                 bi = oi;
+                cnt = oc;
+            } else if (od == best) {
+                cnt += oc;
+                if (oi < bi) bi = oi;
             }
         }
         if (lane == 0) {
             sd[w] = best;
             si[w] = bi;
+            sc[w] = cnt;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            for (int t = 1; t < 4; ++t)
-                if (sd[t] < best || (sd[t] == best && si[t] < bi)) {
+            for (int t = 1; t < 4; ++t) {
+                if (sd[t] < best) {
                     best = sd[t];
                     bi = si[t];
+                    cnt = sc[t];
+                } else if (sd[t] == best) {
+                    cnt += sc[t];
+                    if (si[t] < bi) bi = si[t];
                 }
+            }
             part_d[(size_t)blockIdx.x * nq + j] = best;
             part_i[(size_t)blockIdx.x * nq + j] = bi;
+            part_c[(size_t)blockIdx.x * nq + j] = cnt;
         }
         __syncthreads();
     }
 }
 
 __global__ void nn_reduce_kernel(int n_chunks, int nq, const double *__restrict__ part_d,
-                                 const long long *__restrict__ part_i, long long *__restrict__ out) {
+                                 const long long *__restrict__ part_i, const int *__restrict__ part_c,
+                                 long long *__restrict__ out, int *__restrict__ out_c) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nq) return;
     double best = 1e300;
     long long bi = 0x7fffffffffffffffLL;
+    int cnt = 0;
     for (int c = 0; c < n_chunks; ++c) {
         const double d = part_d[(size_t)c * nq + j];
         const long long i = part_i[(size_t)c * nq + j];
-        if (d < best || (d == best && i < bi)) {
+        if (d < best) {
             best = d;
             bi = i;
+            cnt = part_c[(size_t)c * nq + j];
+        } else if (d == best) {
+            cnt += part_c[(size_t)c * nq + j];
+            if (i < bi) bi = i;
         }
     }
     out[j] = bi;
+    out_c[j] = cnt;
 }
 
 extern "C" int padne_nearest_vertex(padne_ctx *ctx, int64_t n_points, const double *xy_host, int64_t n_query,
                                     const double *query_host, int64_t *index_out_host) {
+    return padne_nearest_vertex_ties(ctx, n_points, xy_host, n_query, query_host, index_out_host, nullptr);
+}
+
+extern "C" int padne_nearest_vertex_ties(padne_ctx *ctx, int64_t n_points, const double *xy_host, int64_t n_query,
+                                         const double *query_host, int64_t *index_out_host, int32_t *tie_count_out_host) {
     PADNE_REQUIRE(ctx && (n_query == 0 || (query_host && index_out_host)), "null argument");
     PADNE_REQUIRE(n_points >= 1 && xy_host, "at least one point is needed");
     PADNE_REQUIRE(n_query >= 0 && n_query < (1 << 24), "number of queries");
@@ -1797,6 +1831,9 @@ extern "C" int padne_nearest_vertex(padne_ctx *ctx, int64_t n_points, const doub
     const int n_chunks = (int)((n_points + kNnChunk - 1) / kNnChunk);
     double *d_xy = nullptr, *d_q = nullptr, *d_pd = nullptr;
     long long *d_pi = nullptr, *d_out = nullptr;
+    int *d_pc = nullptr, *d_outc = nullptr;
+    PADNE_TRY(sc.alloc(&d_pc, (size_t)n_chunks * n_query));
+    PADNE_TRY(sc.alloc(&d_outc, (size_t)n_query));
     PADNE_TRY(sc.alloc(&d_xy, (size_t)2 * n_points));
     PADNE_TRY(sc.alloc(&d_q, (size_t)2 * n_query));
     PADNE_TRY(sc.alloc(&d_pd, (size_t)n_chunks * n_query));
@@ -1805,10 +1842,13 @@ extern "C" int padne_nearest_vertex(padne_ctx *ctx, int64_t n_points, const doub
     PADNE_HIP_CHECK(hipMemcpyAsync(d_xy, xy_host, sizeof(double) * 2 * (size_t)n_points, hipMemcpyHostToDevice, s));
     PADNE_HIP_CHECK(hipMemcpyAsync(d_q, query_host, sizeof(double) * 2 * (size_t)n_query, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(nn_chunk_kernel, dim3(n_chunks), dim3(256), 0, s, (long long)n_points, d_xy, (int)n_query, d_q, d_pd,
-                       d_pi);
-    hipLaunchKernelGGL(nn_reduce_kernel, dim3(nblk(n_query)), dim3(256), 0, s, n_chunks, (int)n_query, d_pd, d_pi, d_out);
+                       d_pi, d_pc);
+    hipLaunchKernelGGL(nn_reduce_kernel, dim3(nblk(n_query)), dim3(256), 0, s, n_chunks, (int)n_query, d_pd, d_pi, d_pc, d_out,
+                       d_outc);
     PADNE_HIP_CHECK(hipGetLastError());
     PADNE_HIP_CHECK(hipMemcpyAsync(index_out_host, d_out, sizeof(long long) * (size_t)n_query, hipMemcpyDeviceToHost, s));
+    if (tie_count_out_host != nullptr)
+        PADNE_HIP_CHECK(hipMemcpyAsync(tie_count_out_host, d_outc, sizeof(int) * (size_t)n_query, hipMemcpyDeviceToHost, s));
     PADNE_HIP_CHECK(hipStreamSynchronize(s));
     return PADNE_OK;
 }

@@ -168,7 +168,15 @@ class NodeIndexer:
         for layer_i, pts in wanted.items():
             q = np.asarray(pts, dtype=np.float64).reshape(-1, 2)
             if len(points[layer_i]) >= NEAREST_ON_DEVICE_FROM:
-                k = get_context().nearest_vertex(points[layer_i], q)
+                k, ties = get_context().nearest_vertex(points[layer_i], q, with_ties=True)
+                tied = np.flatnonzero(ties > 1)
+                if len(tied):
+                    # several vertices at exactly the minimum distance (a connection midway between vertices of a regular
+                    # grid): the reference takes whichever its KD-tree meets first (solver.py:389-392, 425).  Only then is
+                    # the tree built, and only those queries go through it
+                    _, kt = scipy.spatial.KDTree(points[layer_i], leafsize=32).query(q[tied], k=1)
+                    k = np.array(k, dtype=np.int64)
+                    k[tied] = kt
             else:
                 _, k = scipy.spatial.KDTree(points[layer_i], leafsize=32).query(q, k=1)
             snapped[layer_i] = iter(np.asarray(k, dtype=np.int64))

@@ -1878,6 +1878,41 @@ def test_nearest_vertex_matches_the_kd_tree(ctx):
             ctx.nearest_vertex(np.array([[0.0, bad], [1.0, 1.0]]), np.array([[0.5, 0.5]]))
 
 
+def test_connections_equidistant_from_several_vertices_snap_like_the_kd_tree(ctx):
+    """a connection exactly midway between vertices of an UNJITTERED grid (a via in the centre of a
+    cell, a pad on the middle of an edge) above the 50 000-vertex switch to the device brute force.  The device reports
+    how many vertices sit at exactly the minimum distance; ``NodeIndexer.create`` re-resolves those queries -- and only
+    those -- with the reference's KD-tree (solver.py:389-392, 425), so the snapped node is the reference's."""
+    import scipy.spatial
+    nx, ny, h = 320, 260, 0.5                                          # 83 200 vertices > NEAREST_ON_DEVICE_FROM
+    assert nx * ny >= solver.NEAREST_ON_DEVICE_FROM
+    xy, tri = synthetic.jittered_grid(nx, ny, h, jitter=0.0)
+    rng = np.random.default_rng(8)
+    cx, cy = rng.integers(1, nx - 2, 40), rng.integers(1, ny - 2, 40)
+    centres = np.stack([(cx + 0.5) * h, (cy + 0.5) * h], axis=1)       # 4 equidistant corners
+    edges = np.stack([(cx + 0.5) * h, cy * h], axis=1)                 # 2 equidistant end points
+    unique = np.stack([(cx + 0.3) * h, (cy + 0.2) * h], axis=1)        # one nearest vertex
+    q = np.vstack([centres, edges, unique])
+    got, ties = ctx.nearest_vertex(xy, q, with_ties=True)
+    assert list(ties[:40]) == [4] * 40 and list(ties[40:80]) == [2] * 40 and list(ties[80:]) == [1] * 40
+    tree = scipy.spatial.KDTree(xy, leafsize=32)
+    _, ref = tree.query(q, k=1)
+    assert np.array_equal(got[80:], ref[80:])                          # unique nearest vertex: the same everywhere
+    d_got = np.hypot(*(xy[got] - q).T)
+    d_ref = np.hypot(*(xy[ref] - q).T)
+    assert np.array_equal(d_got, d_ref)                                # ties: another vertex at the same distance ...
+    assert np.any(got[:80] != ref[:80])                                # ... and not always the tree's (smallest index here)
+    # through the seam: the node numbering is the reference's
+    layer = problem.Layer(shape=H.Geoms(1), name="F.Cu", conductance=1.0)
+    conns = [problem.Connection(layer=layer, point=H.XY(x, y)) for x, y in q]
+    els = [problem.Resistor(a=conns[k].node_id, b=conns[k + 1].node_id, resistance=1.0) for k in range(0, len(conns) - 1, 2)]
+    prob = problem.Problem(layers=[layer], networks=[problem.Network(connections=conns, elements=els)])
+    m = mesh.Mesh(xy, tri)
+    ni = solver.NodeIndexer.create(prob, [m], [0], solver.VertexIndexer.create([m]), prob.networks)
+    snapped = np.array([ni.node_to_global_index[c.node_id] for c in conns])
+    assert np.array_equal(snapped, ref)
+
+
 def test_spmm8_columns_are_bitwise_the_single_vector_products(ctx):
     """8 interleaved right-hand sides through one pass over the matrix; ragged rows, empty rows, long rows."""
     rng = np.random.default_rng(3)
