@@ -67,10 +67,12 @@ void       *padne_ctx_stream(padne_ctx *ctx);
 int padne_comm_unique_id(void *id128);
 int padne_ctx_comm_init(padne_ctx *ctx, const void *id128, int rank, int world_size);
 int padne_ctx_comm_rank(padne_ctx *ctx, int *rank, int *world_size);
-/* collectives this process has issued since the library was loaded: calls[0..2] / bytes[0..2] = all-reduce (f64
- * scalars), all-gather of f64 values, all-gather of f32 values; bytes are this rank's contributions.  Bookkeeping for
- * DESIGN.md section 6 (how many launches a multi-GPU solve costs), also counted for the in-process team. */
-int padne_comm_call_counts(long long calls[3], long long bytes[3]);
+/* communication this process has issued since the library was loaded: calls[0..2] / bytes[0..2] = the COLLECTIVES
+ * all-reduce (f64 scalars), all-gather of f64 values, all-gather of f32 values; calls[3] / bytes[3] = peer-to-peer halo
+ * exchanges (every rank stores its exported values into the other ranks' mailboxes: no collective).  Bytes are this
+ * rank's contributions.  Bookkeeping for DESIGN.md section 6 (what a multi-GPU solve costs), also counted for the
+ * in-process team. */
+int padne_comm_call_counts(long long calls[4], long long bytes[4]);
 
 /* Halo plan of a row-partitioned matrix (layer partition).  Every vector the
  * local matrix multiplies is laid out [n_owned owned entries | world_size * m exchanged entries];

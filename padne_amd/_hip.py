@@ -239,9 +239,10 @@ class Context:
         _check(self._lib.padne_ctx_comm_init(self._h, buf, int(rank), int(world_size)))
 
     def comm_call_counts(self):
-        """(calls, bytes) of the collectives issued so far: all-reduce, all-gather f64, all-gather f32."""
-        calls = (C.c_longlong * 3)()
-        nbytes = (C.c_longlong * 3)()
+        """(calls, bytes) of the communication issued so far: all-reduce, all-gather f64, all-gather f32 (the collectives)
+        and peer-to-peer halo exchanges."""
+        calls = (C.c_longlong * 4)()
+        nbytes = (C.c_longlong * 4)()
         _check(self._lib.padne_comm_call_counts(calls, nbytes))
         return list(calls), list(nbytes)
 

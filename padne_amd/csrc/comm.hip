@@ -4,6 +4,7 @@
 // single-process).
 #include "common.hpp"
 
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <dlfcn.h>
@@ -34,7 +35,7 @@ static Rccl g_rccl;
 
 // collectives issued by this process since load (all-reduce, all-gather f64, all-gather f32) and the bytes this rank
 // contributed: what a multi-GPU solve costs in launches is counted, not estimated (padne_comm_call_counts)
-static std::atomic<long long> g_calls[3], g_bytes[3];
+static std::atomic<long long> g_calls[4], g_bytes[4];     // [3]: peer-to-peer halo exchanges (no collective)
 
 static int load_rccl() {
     if (g_rccl.lib) return PADNE_OK;
@@ -87,6 +88,7 @@ struct Team {
     long long generation = 0;
     std::vector<const double *> ptrs;
     std::vector<double> stage;      // host staging for the reduced values
+    std::vector<void *> mbox;       // every rank's mailbox ring of the peer-to-peer halo exchange (device pointers)
     bool failed = false;
 };
 
@@ -211,6 +213,73 @@ int comm_allgather_f32(padne_ctx *ctx, const float *send, float *recv, int count
                                        ctx->stream), "ncclAllGather");
 }
 
+// ---- peer-to-peer halo exchange ------------------------------------------------------------------------------------
+// In-process team: the ranks are contexts of one process on one device, so a peer's mailbox is an ordinary device
+// pointer, registered with the team; "the stores have landed" = every rank has drained its stream (host barrier).  One
+// barrier per exchange instead of the two barriers and world peer copies of the team all-gather, and nothing of it is a
+// collective.  The ring makes the second barrier unnecessary: entry e is rewritten kP2pRing exchanges later, and every
+// exchange in between ends with all ranks' streams drained.
+// One process per GPU (RCCL): the mailboxes would be shared through hipIpc handles and the arrival signalled by flags the
+// receiver's kernel waits for; that path is not built -- there is no second GPU on the boxes this round ran on to test
+// it -- so with a communicator the exchange stays an ncclAllGather (comm_p2p_enabled is false).
+bool comm_p2p_enabled(const padne_ctx *ctx) {
+    return ctx->team != nullptr && getenv("PADNE_NO_P2P") == nullptr;
+}
+
+void comm_p2p_release(padne_ctx *ctx) {
+    if (ctx->p2p_mbox != nullptr) (void)hipFree(ctx->p2p_mbox);
+    if (ctx->p2p_peers != nullptr) (void)hipFree(ctx->p2p_peers);
+    ctx->p2p_mbox = nullptr;
+    ctx->p2p_peers = nullptr;
+    ctx->p2p_m_cap = 0;
+}
+
+int comm_p2p_begin(padne_ctx *ctx, int m, void ***peers_dev, size_t *entry_offset) {
+    Team *t = (Team *)ctx->team;
+    PADNE_REQUIRE(t != nullptr && m > 0, "peer-to-peer exchange without a team");
+    if (m > ctx->p2p_m_cap) {
+        // first exchange, or a plan with more slots than the ring holds: (re)build the mailboxes -- all ranks get here
+        // together, they run the same sequence of exchanges with the same plans
+        PADNE_TEAM_HIP(t, hipStreamSynchronize(ctx->stream));
+        PADNE_TRY(team_barrier(t));                  // nobody stores into a ring that is about to go
+        comm_p2p_release(ctx);
+        const int cap = std::max(2 * m, 4096);
+        const size_t bytes = (size_t)kP2pRing * (size_t)ctx->world * (size_t)cap * 8;
+        PADNE_TEAM_HIP(t, hipMalloc(&ctx->p2p_mbox, bytes));
+        PADNE_TEAM_HIP(t, hipMalloc((void **)&ctx->p2p_peers, sizeof(void *) * (size_t)ctx->world));
+        PADNE_TEAM_HIP(t, hipMemsetAsync(ctx->p2p_mbox, 0, bytes, ctx->stream));
+        {
+            std::lock_guard<std::mutex> lk(t->mu);
+            t->mbox[(size_t)ctx->rank] = ctx->p2p_mbox;
+        }
+        PADNE_TRY(team_barrier(t));
+        std::vector<void *> peers;
+        {
+            std::lock_guard<std::mutex> lk(t->mu);
+            peers = t->mbox;
+        }
+        PADNE_TEAM_HIP(t, hipMemcpyAsync(ctx->p2p_peers, peers.data(), sizeof(void *) * (size_t)ctx->world, hipMemcpyHostToDevice,
+                                         ctx->stream));
+        PADNE_TEAM_HIP(t, hipStreamSynchronize(ctx->stream));
+        PADNE_TRY(team_barrier(t));                  // every ring is zeroed and every table complete before the first store
+        ctx->p2p_m_cap = cap;
+        ctx->p2p_seq = 0;
+    }
+    const unsigned long long seq = ctx->p2p_seq++;
+    *peers_dev = ctx->p2p_peers;
+    *entry_offset = (size_t)(seq % kP2pRing) * (size_t)ctx->world * (size_t)ctx->p2p_m_cap * 8;
+    ++g_calls[3];
+    g_bytes[3] += 8LL * m * (ctx->world - 1);
+    return PADNE_OK;
+}
+
+int comm_p2p_arrive(padne_ctx *ctx) {
+    Team *t = (Team *)ctx->team;
+    PADNE_REQUIRE(t != nullptr, "peer-to-peer exchange without a team");
+    PADNE_TEAM_HIP(t, hipStreamSynchronize(ctx->stream));      // my stores are out ...
+    return team_barrier(t);                                   // ... and so are everybody else's
+}
+
 // a rank that fails locally (allocation, HIP error, argument check) inside a row-partitioned solve tells its team
 // (in-process team: the peers' barriers return PADNE_E_COMM at once).  Over RCCL a rank cannot reach into its peers: it
 // aborts ITS communicator -- queued collectives are torn down instead of waiting for ever, the context is left without one,
@@ -225,6 +294,7 @@ void comm_abort(padne_ctx *ctx) {
 }
 
 void comm_destroy(padne_ctx *ctx) {
+    comm_p2p_release(ctx);
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)ctx->comm);
     ctx->comm = nullptr;
     ctx->team = nullptr;
@@ -259,9 +329,9 @@ extern "C" int padne_ctx_comm_init(padne_ctx *ctx, const void *id128, int rank, 
     return PADNE_OK;
 }
 
-extern "C" int padne_comm_call_counts(long long calls[3], long long bytes[3]) {
+extern "C" int padne_comm_call_counts(long long calls[4], long long bytes[4]) {
     PADNE_REQUIRE(calls && bytes, "null argument");
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < 4; ++k) {
         calls[k] = g_calls[k].load();
         bytes[k] = g_bytes[k].load();
     }
@@ -282,6 +352,7 @@ extern "C" int padne_team_create(int world_size, void **team_out) {
     t->world = world_size;
     t->ptrs.assign((size_t)world_size, nullptr);
     t->stage.assign((size_t)world_size * 16, 0.0);
+    t->mbox.assign((size_t)world_size, nullptr);
     *team_out = t;
     return PADNE_OK;
 }

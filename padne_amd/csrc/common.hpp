@@ -104,6 +104,11 @@ struct padne_ctx {
     long long halo_n_owned = 0;
     int halo_m = 0, halo_n_export = 0;
     int32_t *halo_export = nullptr;
+    // peer-to-peer halo exchange (comm.hip, comm_p2p_*): this rank's mailbox ring, the device table of all ranks' rings
+    void *p2p_mbox = nullptr;
+    void **p2p_peers = nullptr;      // device array [world]
+    int p2p_m_cap = 0;               // exchange slots per rank a ring entry holds (8 bytes each)
+    unsigned long long p2p_seq = 0;  // exchanges so far: ring entry = seq % kP2pRing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // second stream of the context (its own pool, workspace and reduction scratch): independent chains of short,
     // latency-bound kernels of the multigrid setup run there next to the main chain (aux_context, stream_order)
@@ -212,7 +217,18 @@ int comm_allreduce_sum_f64(padne_ctx *ctx, double *dev_buf, int count);
 int comm_allgather_f64(padne_ctx *ctx, const double *send, double *recv, int count_per_rank);
 int comm_allgather_f32(padne_ctx *ctx, const float *send, float *recv, int count_per_rank);
 void comm_destroy(padne_ctx *ctx);
-void comm_abort(padne_ctx *ctx);   // in-process team only: wake the peers of a rank that leaves a collective phase with an error
+void comm_abort(padne_ctx *ctx);   // a rank that leaves a collective phase with an error: wake the team / abort the communicator
+// Peer-to-peer halo exchange: instead of packing its exported values into its own segment and taking part in an
+// all-gather, a rank STORES them straight into every rank's mailbox (a ring of kP2pRing entries of world * m values; entry
+// = exchange number % kP2pRing) and the receiver copies its mailbox entry behind its owned values once the stores have
+// landed.  comm_p2p_begin: true if the context can do that for m slots per rank (sets up / grows the mailboxes on first
+// use -- collectively: every rank runs the same sequence of exchanges); returns the device table of the ranks' rings and
+// the byte offset of this exchange's entry.  comm_p2p_arrive: all ranks' stores of the current exchange are visible.
+constexpr int kP2pRing = 4;
+bool comm_p2p_enabled(const padne_ctx *ctx);
+int comm_p2p_begin(padne_ctx *ctx, int m, void ***peers_dev, size_t *entry_offset);
+int comm_p2p_arrive(padne_ctx *ctx);
+void comm_p2p_release(padne_ctx *ctx);
 
 // exchange plan of a row-partitioned operator: vectors are [n_owned | world * m exchanged values]; every
 // rank packs its n_export (<= m) exported owned entries into its segment and one all-gather fills the rest
@@ -223,6 +239,15 @@ struct HaloPlan {
 };
 int halo_exchange_plan(padne_ctx *ctx, const HaloPlan &plan, double *v, const int32_t *done_flag);
 int halo_exchange_plan_f32(padne_ctx *ctx, const HaloPlan &plan, float *v, const int32_t *done_flag);
+// the same exchange in two halves (pcg.hip): what needs no remote value goes between them
+struct HaloTicket {
+    bool p2p = false;
+    size_t entry_off = 0;
+};
+int halo_send(padne_ctx *ctx, const HaloPlan &plan, double *v, const int32_t *done_flag, HaloTicket *tk);
+int halo_send_f32(padne_ctx *ctx, const HaloPlan &plan, float *v, const int32_t *done_flag, HaloTicket *tk);
+int halo_recv(padne_ctx *ctx, const HaloPlan &plan, double *v, const int32_t *done_flag, const HaloTicket &tk);
+int halo_recv_f32(padne_ctx *ctx, const HaloPlan &plan, float *v, const int32_t *done_flag, const HaloTicket &tk);
 
 // amg.hip
 void amg_destroy(void *amg);

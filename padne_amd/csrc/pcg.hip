@@ -352,26 +352,94 @@ __global__ void halo_pack_kernel(T *__restrict__ v, const int *__restrict__ expo
 // scalar slots inside ctx->scalars used when the reductions go through RCCL
 enum { S_RR = 0, S_BB = 1, S_TRUE = 2, S_PQ = 8, S_RZRR0 = 10, S_RZRR1 = 12 };
 
-int halo_exchange_plan(padne_ctx *ctx, const HaloPlan &plan, double *v, const int32_t *done_flag) {
+// peer-to-peer form of the pack: the exported values go straight into every rank's mailbox entry of this exchange
+// (peers[q] + entry_off, laid out [world][m_cap] 8-byte cells; narrower types use the front of their cell)
+template <typename T>
+__global__ void halo_store_peers_kernel(const T *__restrict__ v, const int *__restrict__ export_idx, int n_export, void *const *peers,
+                                        size_t entry_off, int world, int rank, int m_cap, const int *__restrict__ done_flag) {
+    if (done_flag != nullptr && *done_flag != 0) return;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_export) return;
+    const T val = v[export_idx[k]];
+    for (int q = 0; q < world; ++q) {
+        T *cell = reinterpret_cast<T *>(static_cast<char *>(peers[q]) + entry_off + ((size_t)rank * m_cap + k) * 8);
+        *cell = val;
+    }
+}
+
+// the receiver's half: mailbox entry -> the exchange area behind the owned values, v[n_owned + r * m + k]
+template <typename T>
+__global__ void halo_unpack_kernel(T *__restrict__ v, long long n_owned, int m, int world, const void *mbox, size_t entry_off,
+                                   int m_cap, const int *__restrict__ done_flag) {
+    if (done_flag != nullptr && *done_flag != 0) return;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= world * m) return;
+    const int r = j / m, k = j - r * m;
+    v[n_owned + j] = *reinterpret_cast<const T *>(static_cast<const char *>(mbox) + entry_off + ((size_t)r * m_cap + k) * 8);
+}
+
+// An exchange in two halves, so that the caller can put work that needs no remote value between them (the interior
+// tiles of the product the exchange is for): halo_send packs and sends, halo_recv returns when v's exchange area is
+// complete (stream order).  Peer-to-peer stores where the context can do them (comm_p2p_enabled), otherwise pack into
+// the rank's own segment + one all-gather.
+template <typename T>
+static int halo_send_t(padne_ctx *ctx, const HaloPlan &plan, T *v, const int32_t *done_flag, HaloTicket *tk) {
+    tk->p2p = false;
     if (plan.m <= 0) return PADNE_OK;
+    if (comm_p2p_enabled(ctx)) {
+        void **peers = nullptr;
+        PADNE_TRY(comm_p2p_begin(ctx, plan.m, &peers, &tk->entry_off));
+        tk->p2p = true;
+        if (plan.n_export > 0) {
+            hipLaunchKernelGGL(halo_store_peers_kernel<T>, dim3((plan.n_export + 255) / 256), dim3(256), 0, ctx->stream, (const T *)v,
+                               plan.export_idx, plan.n_export, (void *const *)peers, tk->entry_off, ctx->world, ctx->rank,
+                               ctx->p2p_m_cap, done_flag);
+            PADNE_HIP_CHECK(hipGetLastError());
+        }
+        return PADNE_OK;
+    }
     const long long seg_off = plan.n_owned + (long long)ctx->rank * plan.m;
     if (plan.n_export > 0) {
-        hipLaunchKernelGGL(halo_pack_kernel<double>, dim3((plan.n_export + 255) / 256), dim3(256), 0, ctx->stream, v,
+        hipLaunchKernelGGL(halo_pack_kernel<T>, dim3((plan.n_export + 255) / 256), dim3(256), 0, ctx->stream, v,
                            plan.export_idx, plan.n_export, seg_off, done_flag);
         PADNE_HIP_CHECK(hipGetLastError());
     }
-    return comm_allgather_f64(ctx, v + seg_off, v + plan.n_owned, plan.m);
+    return PADNE_OK;
+}
+
+static int allgather_t(padne_ctx *ctx, const double *send, double *recv, int count) { return comm_allgather_f64(ctx, send, recv, count); }
+static int allgather_t(padne_ctx *ctx, const float *send, float *recv, int count) { return comm_allgather_f32(ctx, send, recv, count); }
+
+template <typename T>
+static int halo_recv_t(padne_ctx *ctx, const HaloPlan &plan, T *v, const int32_t *done_flag, const HaloTicket &tk) {
+    if (plan.m <= 0) return PADNE_OK;
+    if (tk.p2p) {
+        PADNE_TRY(comm_p2p_arrive(ctx));
+        const int n = ctx->world * plan.m;
+        hipLaunchKernelGGL(halo_unpack_kernel<T>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, v, plan.n_owned, plan.m,
+                           ctx->world, (const void *)ctx->p2p_mbox, tk.entry_off, ctx->p2p_m_cap, done_flag);
+        PADNE_HIP_CHECK(hipGetLastError());
+        return PADNE_OK;
+    }
+    const long long seg_off = plan.n_owned + (long long)ctx->rank * plan.m;
+    return allgather_t(ctx, v + seg_off, v + plan.n_owned, plan.m);
+}
+
+int halo_send(padne_ctx *ctx, const HaloPlan &plan, double *v, const int32_t *done_flag, HaloTicket *tk) { return halo_send_t(ctx, plan, v, done_flag, tk); }
+int halo_send_f32(padne_ctx *ctx, const HaloPlan &plan, float *v, const int32_t *done_flag, HaloTicket *tk) { return halo_send_t(ctx, plan, v, done_flag, tk); }
+int halo_recv(padne_ctx *ctx, const HaloPlan &plan, double *v, const int32_t *done_flag, const HaloTicket &tk) { return halo_recv_t(ctx, plan, v, done_flag, tk); }
+int halo_recv_f32(padne_ctx *ctx, const HaloPlan &plan, float *v, const int32_t *done_flag, const HaloTicket &tk) { return halo_recv_t(ctx, plan, v, done_flag, tk); }
+
+int halo_exchange_plan(padne_ctx *ctx, const HaloPlan &plan, double *v, const int32_t *done_flag) {
+    HaloTicket tk;
+    PADNE_TRY(halo_send(ctx, plan, v, done_flag, &tk));
+    return halo_recv(ctx, plan, v, done_flag, tk);
 }
 
 int halo_exchange_plan_f32(padne_ctx *ctx, const HaloPlan &plan, float *v, const int32_t *done_flag) {
-    if (plan.m <= 0) return PADNE_OK;
-    const long long seg_off = plan.n_owned + (long long)ctx->rank * plan.m;
-    if (plan.n_export > 0) {
-        hipLaunchKernelGGL(halo_pack_kernel<float>, dim3((plan.n_export + 255) / 256), dim3(256), 0, ctx->stream, v,
-                           plan.export_idx, plan.n_export, seg_off, done_flag);
-        PADNE_HIP_CHECK(hipGetLastError());
-    }
-    return comm_allgather_f32(ctx, v + seg_off, v + plan.n_owned, plan.m);
+    HaloTicket tk;
+    PADNE_TRY(halo_send_f32(ctx, plan, v, done_flag, &tk));
+    return halo_recv_f32(ctx, plan, v, done_flag, tk);
 }
 
 static int halo_exchange(padne_ctx *ctx, double *v, const int32_t *done_flag) {

@@ -1549,15 +1549,36 @@ def test_layer_partitioned_solver_with_several_ranks_on_one_gpu(world, precond):
         # three doubles and ONE exchange of z per iteration (+ start, true-residual check); inside the cycle two float
         # exchanges per row-partitioned level -- one on the last of them, which computes its neighbours' corrected values
         # from the tail solution -- and the gather of the tail; none at all for block-Jacobi.
-        n_ar, n_ag64, n_ag32 = [c / world for c in res.collectives]
+        n_ar, n_ag64, n_ag32, n_p2p = [c / world for c in res.collectives]
         # iterations are queued four at a time between two looks at the status word; + cycle and product of the start
         its = 4 * ((iters + 3) // 4) + 1
         assert n_ar <= its + 3 + 2, (n_ar, iters)         # 1 per iteration; ||b||, true residual
-        assert n_ag64 <= its + 1 + 2, (n_ag64, iters)     # 1 per iteration; A x of the true residual
         if block:
-            assert n_ag32 == 0
+            assert n_ag32 == 0 and n_p2p <= its + 1 + 2   # the exchange of z per iteration, A x of the true residual
         else:
-            assert n_ag32 <= (2 * 2 - 1 + 1) * its + 2, (n_ag32, iters)
+            # the halo exchanges are peer-to-peer stores into the other ranks' mailboxes, not
+            # collectives.  What is left per iteration: ONE all-reduce and the gather of the tail's right-hand side
+            # (<= 4 was the bar); the four exchanges (z; the pre-smoothed iterate of both partitioned levels; the
+            # corrected iterate of the first) are stores + one arrival each.
+            assert n_ag64 <= 2, (n_ag64, iters)
+            assert n_ag32 <= its + 2, (n_ag32, iters)
+            assert n_ar + n_ag64 + n_ag32 <= 2 * its + 8, (res.collectives, iters)
+            assert n_p2p <= (1 + 2 * 2 - 1) * its + 4, (n_p2p, iters)
+
+
+def test_peer_to_peer_halo_stores_are_the_all_gather_bit_for_bit(monkeypatch):
+    """The same solve with the halo exchanged by peer stores (default with the in-process team) and by all-gathers
+    (PADNE_NO_P2P=1): the values that arrive are the same, so iterations and potentials are bit-identical; only the kind of
+    communication differs (calls[3] against calls[1] / calls[2] of padne_comm_call_counts)."""
+    sysm = synthetic.layered_system(8, 90, 70, via_lattice=5)
+    v_p2p, it_p2p, res_p2p = run_team(sysm, 4, "amg")
+    monkeypatch.setenv("PADNE_NO_P2P", "1")
+    v_ag, it_ag, res_ag = run_team(sysm, 4, "amg")
+    assert it_p2p == it_ag and np.array_equal(v_p2p, v_ag)
+    assert res_ag.collectives[3] == 0 and res_p2p.collectives[3] > 0
+    # every exchange that was an all-gather is a peer-to-peer exchange now
+    moved = (res_ag.collectives[1] + res_ag.collectives[2]) - (res_p2p.collectives[1] + res_p2p.collectives[2])
+    assert moved == res_p2p.collectives[3], (res_ag.collectives, res_p2p.collectives)
 
 
 def test_last_partitioned_level_computes_its_neighbours_from_the_tail(monkeypatch):
@@ -1572,7 +1593,8 @@ def test_last_partitioned_level_computes_its_neighbours_from_the_tail(monkeypatc
     assert it_new == it_old
     assert np.array_equal(v_new, v_old)
     its = 4 * ((it_new + 3) // 4) + 1
-    saved = (res_old.collectives[2] - res_new.collectives[2]) / 4
+    # (float exchanges: all-gathers with PADNE_NO_P2P=1, peer-to-peer exchanges otherwise)
+    saved = ((res_old.collectives[2] + res_old.collectives[3]) - (res_new.collectives[2] + res_new.collectives[3])) / 4
     assert its - 1 <= saved <= its + 1, (saved, its, res_old.collectives, res_new.collectives)
 
 
