@@ -22,6 +22,10 @@ int padne_ctx_join_team(padne_ctx *ctx, void *team, int rank);
  * return PADNE_E_COMM.  Called by the driver of a rank that leaves early (error, exception), so that its peers do not
  * wait for it for ever. */
 int padne_team_abort(void *team);
+/* Interior / boundary tiles of a row-partitioned operator once a solve has examined it (64-row tiles whose columns are
+ * all owned / that read an exchange slot); both 0 while there is no split plan.  level < 0: the matrix itself, otherwise
+ * the operator A_level of its cached hierarchy. */
+int padne_csr_split_tiles(const padne_csr *m, int level, int64_t *interior, int64_t *boundary);
 
 #ifdef __cplusplus
 }

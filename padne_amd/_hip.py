@@ -116,6 +116,7 @@ TEST_SIGNATURES = {
     "padne_team_destroy": (C.c_int, [_P]),
     "padne_team_abort": (C.c_int, [_P]),
     "padne_ctx_join_team": (C.c_int, [_P, _P, C.c_int]),
+    "padne_csr_split_tiles": (C.c_int, [_P, C.c_int, _PI64, _PI64]),
 }
 
 _lib = None
@@ -704,6 +705,13 @@ class CsrMatrix:
                 break
             out.append(entry)
         return out
+
+    def split_tiles(self, level: int = -1):
+        """(interior, boundary) 64-row tiles of the split plan of this row-partitioned operator (level >= 0: of the
+        level operator of its hierarchy); (0, 0) without one.  Test-only introspection."""
+        a, b = C.c_int64(), C.c_int64()
+        _check(self.ctx._lib.padne_csr_split_tiles(self._h, int(level), C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def amg_apply(self, r) -> np.ndarray:
         """z = M^-1 r: one multigrid V-cycle (the preconditioner of solve_spd)."""

@@ -3088,6 +3088,8 @@ static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0) {
         nnz_total += (double)A->nnz;
         amg->levels.push_back(L);
         AmgLevel &Lr = amg->levels.back();
+        // interior / boundary tiles of this level's operator: its products overlap the halo exchange (amg_apply_f32)
+        if (lvl > 0 && (rc = csr_build_split_plan(ctx, const_cast<padne_csr *>(A), plan.n_owned)) != PADNE_OK) break;
         double lam = 2.0;
         if ((rc = gershgorin(ctx, A, &lam)) != PADNE_OK) break;
         std::vector<double> st = {(double)Lr.n, lam}, sts;
@@ -3274,8 +3276,16 @@ static int amg_apply_f32(padne_ctx *ctx, Amg *amg, const double *r, double *z, d
             hipLaunchKernelGGL(scale_dinv_kernel<float>, dim3(gv > 0 ? gv : 1), dim3(256), 0, s, L.n, (float)L.jac,
                                (const float *)L.A->dinv32, (const float *)b, xa, done_flag);
         PADNE_HIP_CHECK(hipGetLastError());
-        if (amg->dist) PADNE_TRY(halo_exchange_plan_f32(ctx, L.halo, xa, done_flag));
-        PADNE_TRY(launch_spmv_f32(ctx, L.A, SPMV_RESID, xa, tmp, nullptr, done_flag, b, nullptr, 0.f));
+        if (amg->dist) {
+            // the pre-smoothed iterate goes out, the interior tiles of the residual run while it travels
+            HaloTicket tk;
+            PADNE_TRY(halo_send_f32(ctx, L.halo, xa, done_flag, &tk));
+            PADNE_TRY(launch_spmv_f32_part(ctx, L.A, SPMV_RESID, SPMV_INTERIOR, xa, tmp, nullptr, done_flag, b, nullptr, 0.f));
+            PADNE_TRY(halo_recv_f32(ctx, L.halo, xa, done_flag, tk));
+            PADNE_TRY(launch_spmv_f32_part(ctx, L.A, SPMV_RESID, SPMV_BOUNDARY, xa, tmp, nullptr, done_flag, b, nullptr, 0.f));
+        } else {
+            PADNE_TRY(launch_spmv_f32(ctx, L.A, SPMV_RESID, xa, tmp, nullptr, done_flag, b, nullptr, 0.f));
+        }
         // the restriction also leaves the first sweep of the level below (from a zero start: x = c D^-1 b), unless that
         // level is the coarsest (solved directly) -- one short launch less per level
         AmgLevel &Lc = amg->levels[l + 1];
@@ -3298,16 +3308,22 @@ static int amg_apply_f32(padne_ctx *ctx, Amg *amg, const double *r, double *z, d
         }
         PADNE_TRY(launch_spmv_f32(ctx, L.P, SPMV_ADD, (const float *)amg->levels[l + 1].xb, xa, nullptr, done_flag,
                                   nullptr, nullptr, 0.f));
-        if (amg->dist && local_halo && l == nl - 2)
+        HaloTicket tk;
+        const bool exchange = amg->dist && !(local_halo && l == nl - 2);
+        if (amg->dist && !exchange)
             PADNE_TRY(launch_spmv_f32(ctx, L.P_halo, SPMV_ADD, (const float *)L.e_ext, xa + L.n, nullptr, done_flag, nullptr,
                                       nullptr, 0.f));
-        else if (amg->dist)
-            PADNE_TRY(halo_exchange_plan_f32(ctx, L.halo, xa, done_flag));
-        if (l > 0)
-            PADNE_TRY(launch_spmv_f32(ctx, L.A, SPMV_JACOBI, xa, (float *)L.xb, nullptr, done_flag, b, L.A->dinv32,
-                                      (float)L.jac));
-        else
-            PADNE_TRY(launch_spmv_f32_exit(ctx, L.A, xa, z, r, partials_rz, done_flag, b, L.A->dinv32, (float)L.jac, bb2, z32));
+        // post-smoothing: with an exchange of the corrected iterate its interior tiles run while the halo travels
+        for (int part = exchange ? SPMV_INTERIOR : SPMV_ALL; part <= (exchange ? SPMV_BOUNDARY : SPMV_ALL); ++part) {
+            if (exchange && part == SPMV_INTERIOR) PADNE_TRY(halo_send_f32(ctx, L.halo, xa, done_flag, &tk));
+            if (exchange && part == SPMV_BOUNDARY) PADNE_TRY(halo_recv_f32(ctx, L.halo, xa, done_flag, tk));
+            if (l > 0)
+                PADNE_TRY(launch_spmv_f32_part(ctx, L.A, SPMV_JACOBI, part, xa, (float *)L.xb, nullptr, done_flag, b, L.A->dinv32,
+                                               (float)L.jac));
+            else
+                PADNE_TRY(launch_spmv_f32_exit_part(ctx, L.A, part, xa, z, r, partials_rz, done_flag, b, L.A->dinv32,
+                                                    (float)L.jac, bb2, z32));
+        }
     }
     return PADNE_OK;
 }
@@ -3414,7 +3430,7 @@ int amg_rz_partials(const padne_csr *A0) {
     const Amg *amg = (const Amg *)A0->amg;
     if (amg != nullptr && amg->f32 && !amg->dist && !amg->levels.empty() && amg->levels[0].W != nullptr)
         return spmv_grid(amg->levels[0].W);
-    return spmv_grid(A0);
+    return spmv_partials(A0);
 }
 
 bool amg_f32_entry_args(const padne_csr *A0, float *jac, const float **dinv32, float **b32, float **xa32) {
@@ -3493,6 +3509,7 @@ const padne_csr *amg_level_matrix(const padne_csr *A0, int level, int which) {
 }
 
 int csr_matmul(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_csr **C) { return spgemm(ctx, X, Y, C); }
+const padne_csr *amg_level_matrix(const padne_csr *A0, int level, int which);
 int csr_transpose(padne_ctx *ctx, const padne_csr *M, padne_csr **T) { return transpose(ctx, M, T); }
 
 void amg_info(const padne_csr *A0, int *levels, double *complexity, double *setup_seconds, long long *coarse_n) {
@@ -3508,3 +3525,14 @@ void amg_info(const padne_csr *A0, int *levels, double *complexity, double *setu
 }
 
 }  // namespace padne
+
+extern "C" int padne_csr_split_tiles(const padne_csr *m, int level, int64_t *interior, int64_t *boundary) {
+    PADNE_REQUIRE(m && interior && boundary, "null argument");
+    const padne_csr *a = level < 0 ? m : padne::amg_level_matrix(m, level, 0);
+    *interior = *boundary = 0;
+    if (a != nullptr && a->split_state == 1) {
+        *interior = a->split_n_int;
+        *boundary = a->split_n_bnd;
+    }
+    return PADNE_OK;
+}

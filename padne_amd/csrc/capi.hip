@@ -436,6 +436,7 @@ int padne_csr_destroy(padne_csr *m) {
         pool_free(m->owner, m->mesh_voff);
         pool_free(m->owner, m->mesh_toff);
         pool_free(m->owner, m->xw_lidx);
+        pool_free(m->owner, m->split_tiles);
     }
     delete m;
     return PADNE_OK;

@@ -74,6 +74,12 @@ struct padne_csr {
     unsigned short *xw_lidx = nullptr;   // [nnz + pad] position of every column inside its tile's staged runs (bytes when xw_run == 72)
     int xw_state = 0;                    // 0 = not examined, 1 = in use, -1 = examined and not worth it
     int xw_run = 0;                      // entries per staged run (72 for scan-line meshes, 128 for strip-ordered ones)
+    // interior / boundary split of a row-partitioned operator (csr_build_split_plan): the 64-row tiles whose columns are all
+    // owned, and the tiles that read an exchange slot.  The product of the interior tiles needs no remote value and is
+    // launched while the halo exchange is under way; the boundary tiles follow once it has landed.
+    int *split_tiles = nullptr;          // [n_tiles]: interior tiles first, then the boundary tiles
+    int split_n_int = 0, split_n_bnd = 0;
+    int split_state = 0;                 // 0 = not examined, 1 = in use, -1 = not a row-partitioned operator / switched off
     bool hierarchy_operator = false;   // multigrid-internal operator: may use the wave-per-row SpMV
     padne_csr *prec_block = nullptr;   // borrowed: owned x owned diagonal block for the preconditioner
     // the mesh the system was assembled from stays on the device with it (padne_assemble_system), so that the
@@ -157,6 +163,21 @@ int launch_spmv_f32_wup_exit(padne_ctx *ctx, const padne_csr *w, const float *e,
                              const float *dinv32, float scale, const double *out_scale2, float *z32 = nullptr);
 int csr_build_f32(padne_ctx *ctx, padne_csr *m);
 int csr_build_xw_plan(padne_ctx *ctx, padne_csr *m);
+// interior / boundary tiles of a row-partitioned operator whose first n_owned columns are the rank's own unknowns
+int csr_build_split_plan(padne_ctx *ctx, padne_csr *m, long long n_owned);
+// number of per-workgroup partial sums a product with a dot epilogue on `m` writes (spmv_grid, or the grids of the
+// interior and the boundary launch together)
+int spmv_partials(const padne_csr *m);
+// which part of a split operator a launch covers: everything (one after the other), the interior tiles, the boundary
+// tiles.  On an operator without a split plan SPMV_INTERIOR does nothing and SPMV_BOUNDARY is the whole product.
+enum { SPMV_ALL = 0, SPMV_INTERIOR = 1, SPMV_BOUNDARY = 2 };
+int launch_spmv_part(padne_ctx *ctx, const padne_csr *m, int mode, int part, const double *x, double *y, const double *dot_with,
+                     double *partials, const int32_t *done_flag, const double *aux1, const double *aux2, double scale);
+int launch_spmv_f32_part(padne_ctx *ctx, const padne_csr *m, int mode, int part, const float *x, float *y, double *partials,
+                         const int32_t *done_flag, const float *aux1, const float *aux2, float scale);
+int launch_spmv_f32_exit_part(padne_ctx *ctx, const padne_csr *m, int part, const float *x, double *y, const double *dot_with,
+                              double *partials, const int32_t *done_flag, const float *aux1, const float *aux2, float scale,
+                              const double *out_scale2, float *z32 = nullptr);
 
 // spmm.hip: the same products for 8 interleaved right-hand sides (vectors [n][8]; aux2 = 1/diag stays [n]);
 // dot partials are [8][kMaxPartials]

@@ -452,6 +452,22 @@ static int halo_exchange(padne_ctx *ctx, double *v, const int32_t *done_flag) {
     return halo_exchange_plan(ctx, plan, v, done_flag);
 }
 
+// q = A v for a vector whose exchange area has to be refreshed first: the halo goes out, the interior tiles of the product
+// (no remote value in their columns) run while it travels, the boundary tiles follow when it has landed
+static int halo_product_dot(padne_ctx *ctx, const padne_csr *a, double *v, double *q, double *partials, const int32_t *done_flag) {
+    if (!ctx->halo_on) return launch_spmv(ctx, a, v, q, v, partials, done_flag);
+    HaloPlan plan;
+    plan.n_owned = ctx->halo_n_owned;
+    plan.m = ctx->halo_m;
+    plan.n_export = ctx->halo_n_export;
+    plan.export_idx = ctx->halo_export;
+    HaloTicket tk;
+    PADNE_TRY(halo_send(ctx, plan, v, done_flag, &tk));
+    PADNE_TRY(launch_spmv_part(ctx, a, SPMV_DOT, SPMV_INTERIOR, v, q, v, partials, done_flag, nullptr, nullptr, 0.0));
+    PADNE_TRY(halo_recv(ctx, plan, v, done_flag, tk));
+    return launch_spmv_part(ctx, a, SPMV_DOT, SPMV_BOUNDARY, v, q, v, partials, done_flag, nullptr, nullptr, 0.0);
+}
+
 int amg_setup(padne_ctx *ctx, padne_csr *A0);
 int amg_apply(padne_ctx *ctx, const padne_csr *A0, const double *r, double *z, double *partials_rz,
               const int32_t *done_flag, const double *bb2 = nullptr, bool entry_done = false, float *z32 = nullptr);
@@ -495,7 +511,7 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
     PcgStatus *hst = (PcgStatus *)ctx->pinned;
     hipStream_t s = ctx->stream;
     const int gv = vec_grid(n);
-    const int gs = spmv_grid(a);
+    const int gs = spmv_partials(a);
     const int P_rz = amg ? amg_rz_partials(prec) : gv;    // workgroups that emit r.z partials
     const int max_iter = o->max_iter > 0 ? o->max_iter : 100000;
     const int check_every = o->check_every > 0 ? o->check_every : (amg ? 4 : 50);
@@ -579,7 +595,6 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
                 const double *rr = dist ? s_new + 1 : slot(ctx, SLOT_RR);
                 const int Pz = dist ? 1 : P_rz, Pq = dist ? 1 : gs, Pr = dist ? 1 : gv;
 
-                PADNE_TRY(halo_exchange(ctx, p, &st->done));
                 const bool sampled = sample_spmv && (launched++ % sample_stride) == 1 && ev_a.size() < 512;
                 if (sampled) {
                     hipEvent_t e0, e1;
@@ -589,7 +604,7 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
                     ev_b.push_back(e1);
                     PADNE_HIP_CHECK(hipEventRecord(e0, s));
                 }
-                PADNE_TRY(launch_spmv(ctx, a, p, q, p, slot(ctx, SLOT_PQ), &st->done));
+                PADNE_TRY(halo_product_dot(ctx, a, p, q, slot(ctx, SLOT_PQ), &st->done));
                 if (sampled) PADNE_HIP_CHECK(hipEventRecord(ev_b.back(), s));
                 if (dist) {
                     PADNE_TRY(fold(slot(ctx, SLOT_PQ), gs, kMaxPartials, 1, scal + S_PQ));
@@ -827,7 +842,7 @@ static int solve_one_single_reduction(padne_ctx *ctx, const padne_csr *a, const 
     PcgStatus *hst = (PcgStatus *)ctx->pinned;
     hipStream_t s = ctx->stream;
     const int gv = vec_grid(n);
-    const int gs = spmv_grid(a);
+    const int gs = spmv_partials(a);
     const int P_rz = amg_rz_partials(prec);
     const int max_iter = o->max_iter > 0 ? o->max_iter : 100000;
     const int check_every = o->check_every > 0 ? o->check_every : 4;
@@ -861,7 +876,6 @@ static int solve_one_single_reduction(padne_ctx *ctx, const padne_csr *a, const 
     long long launched = 0;
     auto cycle_product_reduce = [&](bool entry_done, const int32_t *done_flag) -> int {
         PADNE_TRY(amg_apply(ctx, prec, r, z, slot(ctx, SLOT_RZ0), done_flag, bb_scalar, entry_done));
-        PADNE_TRY(halo_exchange(ctx, z, done_flag));
         const bool sampled = sample_spmv && (launched++ % 4) == 1 && ev_a.size() < 512;
         if (sampled) {
             hipEvent_t e0, e1;
@@ -871,7 +885,7 @@ static int solve_one_single_reduction(padne_ctx *ctx, const padne_csr *a, const 
             ev_b.push_back(e1);
             PADNE_HIP_CHECK(hipEventRecord(e0, s));
         }
-        PADNE_TRY(launch_spmv(ctx, a, z, w, z, slot(ctx, SLOT_PQ), done_flag));
+        PADNE_TRY(halo_product_dot(ctx, a, z, w, slot(ctx, SLOT_PQ), done_flag));
         if (sampled) PADNE_HIP_CHECK(hipEventRecord(ev_b.back(), s));
         hipLaunchKernelGGL(sr_fold3_kernel, dim3(3), dim3(256), 0, s, slot(ctx, SLOT_RZ0), P_rz, slot(ctx, SLOT_PQ), gs,
                            slot(ctx, SLOT_RR), gv, sr + SR_RED);
@@ -1310,7 +1324,7 @@ int lanczos_enqueue(padne_ctx *ctx, const padne_csr *a, int steps, LanczosJob *j
     double *r = (double *)ctx->ws, *x = r + n, *b = x + n, *p = b + n, *q = p + nc;
     PcgStatus *st = (PcgStatus *)ctx->status;
     hipStream_t s = ctx->stream;
-    const int gv = vec_grid(n), gs = spmv_grid(a);
+    const int gv = vec_grid(n), gs = spmv_partials(a);
     job->ctx = ctx;
     job->steps = steps;
     job->host.assign((size_t)3 * steps + 4, 0.0);
@@ -1541,14 +1555,18 @@ static int solve_spd_dev_impl(padne_ctx *ctx, const padne_csr *a, const void *b_
         pool_free(owner, m->dinv32);
         pool_free(owner, m->xw_desc);
         pool_free(owner, m->xw_lidx);
+        pool_free(owner, m->split_tiles);
         m->vals32 = nullptr;
         m->dinv32 = nullptr;
         m->xw_desc = nullptr;
         m->xw_lidx = nullptr;
         m->xw_state = 0;
+        m->split_tiles = nullptr;
+        m->split_state = 0;
     }
     PADNE_TRY(csr_build_dinv(ctx, const_cast<padne_csr *>(a)));
     PADNE_TRY(csr_build_xw_plan(ctx, const_cast<padne_csr *>(a)));
+    if (ctx->halo_on) PADNE_TRY(csr_build_split_plan(ctx, const_cast<padne_csr *>(a), ctx->halo_n_owned));
     padne_solve_info local;
     memset(&local, 0, sizeof(local));
     local.n_rhs = n_rhs;

@@ -140,7 +140,10 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
     const int *__restrict__ done_flag, const XT *__restrict__ aux1,
     const XT *__restrict__ aux2, const XT scale, const double *__restrict__ out_scale2,
     const int4 *__restrict__ xw_desc, const void *__restrict__ xw_lidx, const int xw_run,
-    const XT *__restrict__ aux0, XT *__restrict__ y2) {
+    const XT *__restrict__ aux0, XT *__restrict__ y2, const int *__restrict__ tile_list, const int n_list,
+    const int partial_off) {
+    // tile_list (optional): the launch covers the n_list tiles listed there (interior or boundary tiles of a
+    // row-partitioned operator, csr_build_split_plan) instead of all n_wtiles; its partial sums start at partial_off
     constexpr bool WITH_DOT = (MODE == SPMV_DOT) || (MODE == SPMV_DOT_AUX) || (MODE == SPMV_JACOBI) || (MODE == SPMV_WUP);
     __shared__ XT prod_all[4 * kWaveChunk];
     extern __shared__ unsigned char xs_dyn[];      // 4 * kXwRuns * xw_run entries of XT when the plan is in use
@@ -163,13 +166,15 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
     const int slab = blockIdx.x % nslab;
     const int wx = (blockIdx.x / nslab) * 4 + w;       // wave index inside the slab
     const int wps = (G / nslab) * 4;                   // waves per slab
-    const int s0 = (int)((long long)slab * n_wtiles / nslab);
-    const int s1 = (int)((long long)(slab + 1) * n_wtiles / nslab);
+    const int n_sweep = tile_list != nullptr ? n_list : n_wtiles;
+    const int s0 = (int)((long long)slab * n_sweep / nslab);
+    const int s1 = (int)((long long)(slab + 1) * n_sweep / nslab);
 
     double dot_acc = 0.0;
     int rs = 0, re = 0;
     int4 d = make_int4(0, 0, 0, 0);
-    for (int wt = s0 + wx; wt < s1; wt += wps) {
+    for (int it = s0 + wx; it < s1; it += wps) {
+        const int wt = tile_list != nullptr ? tile_list[it] : it;
         const int row0 = wt * 64;
         const int row1 = min(row0 + 64, n_rows);
         const int r = row0 + lane;
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
     }
     if (WITH_DOT && partials != nullptr) {
         const double s = block_sum_256(dot_acc, red);
-        if (threadIdx.x == 0) partials[blockIdx.x] = s;
+        if (threadIdx.x == 0) partials[partial_off + blockIdx.x] = s;
     }
 }
 
@@ -360,13 +365,55 @@ int spmv_grid(const padne_csr *m) {
     return (int)g;
 }
 
+static int split_grid(const padne_csr *m, int n_list) {
+    long long g = ((long long)n_list + 3) / 4;               // four wave-tiles per workgroup turn
+    const int cap = spmv_grid(m);
+    if (g > cap) g = cap;
+    if (g >= kNumXcd) g -= g % kNumXcd;
+    return (int)(g < 1 ? 1 : g);
+}
+
+static bool split_in_use(const padne_csr *m) { return m->split_state == 1 && !use_wave_per_row(m); }
+
+int spmv_partials(const padne_csr *m) {
+    if (!split_in_use(m)) return spmv_grid(m);
+    return split_grid(m, m->split_n_int) + (m->split_n_bnd > 0 ? split_grid(m, m->split_n_bnd) : 0);
+}
+
 template <typename VT, typename XT, typename YT>
 static int launch_spmv_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals, int mode, const XT *x, YT *y,
                              const double *dot_with, double *partials, const int32_t *done_flag, const XT *aux1,
-                             const XT *aux2, XT scale, const double *out_scale2, const XT *aux0 = nullptr, XT *y2 = nullptr) {
+                             const XT *aux2, XT scale, const double *out_scale2, const XT *aux0 = nullptr, XT *y2 = nullptr,
+                             int part = SPMV_ALL) {
     if (m->n_rows == 0) return PADNE_OK;
     const int n_tiles = (int)((m->n_rows + 63) / 64);   // wave-tiles of 64 rows
-    const int g = spmv_grid(m);
+    if (!split_in_use(m)) {
+        if (part == SPMV_INTERIOR) return PADNE_OK;      // no split plan: the whole product follows the exchange
+        part = SPMV_ALL;
+    } else if (part == SPMV_ALL && partials == nullptr) {
+        part = -1;                                       // one sweep over all tiles: nobody counts partial sums
+    }
+    if (part == SPMV_ALL && split_in_use(m)) {
+        // a product with partial sums on a split operator always leaves them in the layout of the two launches
+        PADNE_TRY((launch_spmv_typed<VT, XT, YT>(ctx, m, vals, mode, x, y, dot_with, partials, done_flag, aux1, aux2, scale,
+                                                 out_scale2, aux0, y2, SPMV_INTERIOR)));
+        return launch_spmv_typed<VT, XT, YT>(ctx, m, vals, mode, x, y, dot_with, partials, done_flag, aux1, aux2, scale,
+                                             out_scale2, aux0, y2, SPMV_BOUNDARY);
+    }
+    int g = spmv_grid(m);
+    const int *tile_list = nullptr;
+    int n_list = 0, partial_off = 0;
+    if (part == SPMV_INTERIOR) {
+        tile_list = m->split_tiles;
+        n_list = m->split_n_int;
+        g = split_grid(m, n_list);
+    } else if (part == SPMV_BOUNDARY) {
+        if (m->split_n_bnd == 0) return PADNE_OK;
+        tile_list = m->split_tiles + m->split_n_int;
+        n_list = m->split_n_bnd;
+        partial_off = split_grid(m, m->split_n_int);
+        g = split_grid(m, n_list);
+    }
     if (use_wave_per_row(m) && mode != SPMV_WUP) {
 #define PADNE_SPMV_WPR(M)                                                                                           \
     hipLaunchKernelGGL((csr_spmv_wpr_kernel<M, VT, XT, YT>), dim3(g), dim3(kSpmvThreads), 0, ctx->stream,            \
@@ -392,7 +439,8 @@ static int launch_spmv_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals,
 #define PADNE_SPMV_LAUNCH(M)                                                                                     \
     hipLaunchKernelGGL((csr_spmv_kernel<M, VT, XT, YT>), dim3(g), dim3(kSpmvThreads), xs_bytes, ctx->stream,      \
                        (int)m->n_rows, (int)m->n_cols, n_tiles, m->rowptr, m->cols, vals, x, y, dot_with,         \
-                       partials, done_flag, aux1, aux2, scale, out_scale2, xw_desc, xw_lidx, m->xw_run, aux0, y2)
+                       partials, done_flag, aux1, aux2, scale, out_scale2, xw_desc, xw_lidx, m->xw_run, aux0, y2, \
+                       tile_list, n_list, partial_off)
     switch (mode) {
         case SPMV_PLAIN: PADNE_SPMV_LAUNCH(SPMV_PLAIN); break;
         case SPMV_DOT: PADNE_SPMV_LAUNCH(SPMV_DOT); break;
@@ -414,6 +462,30 @@ int launch_spmv_mode(padne_ctx *ctx, const padne_csr *m, int mode, const double 
                      const double *aux2, double scale) {
     return launch_spmv_typed<double, double, double>(ctx, m, m->vals, mode, x, y, dot_with, partials, done_flag, aux1,
                                                      aux2, scale, nullptr);
+}
+
+int launch_spmv_part(padne_ctx *ctx, const padne_csr *m, int mode, int part, const double *x, double *y, const double *dot_with,
+                     double *partials, const int32_t *done_flag, const double *aux1, const double *aux2, double scale) {
+    return launch_spmv_typed<double, double, double>(ctx, m, m->vals, mode, x, y, dot_with, partials, done_flag, aux1,
+                                                     aux2, scale, nullptr, nullptr, nullptr, part);
+}
+
+int launch_spmv_f32_part(padne_ctx *ctx, const padne_csr *m, int mode, int part, const float *x, float *y, double *partials,
+                         const int32_t *done_flag, const float *aux1, const float *aux2, float scale) {
+    PADNE_REQUIRE(m->vals32 != nullptr, "single-precision copy missing");
+    return launch_spmv_typed<float, float, float>(ctx, m, m->vals32, mode, x, y, nullptr, partials, done_flag, aux1,
+                                                  aux2, scale, nullptr, nullptr, nullptr, part);
+}
+
+int launch_spmv_f32_exit_part(padne_ctx *ctx, const padne_csr *m, int part, const float *x, double *y, const double *dot_with,
+                              double *partials, const int32_t *done_flag, const float *aux1, const float *aux2, float scale,
+                              const double *out_scale2, float *z32) {
+    PADNE_REQUIRE(m->vals32 != nullptr && dot_with != nullptr, "single-precision exit stage");
+    if (z32 != nullptr)
+        return launch_spmv_typed<float, float, float>(ctx, m, m->vals32, SPMV_JACOBI, x, z32, dot_with, partials, done_flag,
+                                                      aux1, aux2, scale, out_scale2, nullptr, nullptr, part);
+    return launch_spmv_typed<float, float, double>(ctx, m, m->vals32, SPMV_JACOBI, x, y, dot_with, partials, done_flag,
+                                                   aux1, aux2, scale, out_scale2, nullptr, nullptr, part);
 }
 
 // single-precision operator copy (csr_build_f32) on single-precision vectors
@@ -603,6 +675,66 @@ int csr_build_xw_plan(padne_ctx *ctx, padne_csr *m) {
     m->xw_desc = desc;
     m->xw_lidx = lidx;
     m->xw_state = 1;
+    return PADNE_OK;
+}
+
+// ---- interior / boundary tiles of a row-partitioned operator -------------------------------------------------------
+// flag[t] = 1 if tile t reads an exchange slot (a column >= n_owned), one wave per tile
+__global__ __launch_bounds__(256) void split_flag_kernel(int n_rows, int n_wtiles, int n_owned, const int *__restrict__ rowptr,
+                                                         const int *__restrict__ cols, int *__restrict__ flag) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (long long wt = (long long)blockIdx.x * 4 + w; wt < n_wtiles; wt += (long long)gridDim.x * 4) {
+        const int row0 = (int)wt * 64, row1 = min(row0 + 64, n_rows);
+        const int k0 = rowptr[row0], k1 = rowptr[row1];
+        int far = 0;
+        for (int e = k0 + lane; e < k1; e += 64) far |= cols[e] >= n_owned ? 1 : 0;
+        far = __any(far) ? 1 : 0;
+        if (lane == 0) flag[wt] = far;
+    }
+}
+
+// interior tiles to the front (in order), boundary tiles behind them (in order): pos = exclusive scan of the flags
+__global__ void split_scatter_kernel(int n_wtiles, const int *__restrict__ flag, const int *__restrict__ pos, int n_bnd,
+                                     int *__restrict__ tiles) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_wtiles) return;
+    const int n_int = n_wtiles - n_bnd;
+    if (flag[t]) tiles[n_int + pos[t]] = t;
+    else tiles[t - pos[t]] = t;
+}
+
+int csr_build_split_plan(padne_ctx *ctx, padne_csr *m, long long n_owned) {
+    if (m->split_state != 0) return PADNE_OK;
+    m->split_state = -1;
+    if (m->n_cols <= n_owned || m->n_rows < 64 * 64 || getenv("PADNE_NO_SPLIT") != nullptr) return PADNE_OK;
+    padne_ctx *owner = m->owner ? m->owner : ctx;
+    const int n_tiles = (int)((m->n_rows + 63) / 64);
+    int *tiles = (int *)pool_alloc(owner, sizeof(int) * (size_t)n_tiles);
+    int *flag = (int *)pool_alloc(ctx, sizeof(int) * ((size_t)n_tiles + 1));
+    int *pos = (int *)pool_alloc(ctx, sizeof(int) * ((size_t)n_tiles + 1));
+    int rc = (!tiles || !flag || !pos) ? PADNE_E_NOMEM : PADNE_OK;
+    int64_t n_bnd = 0;
+    if (rc == PADNE_OK) {
+        const unsigned g = (unsigned)std::min<long long>(((long long)n_tiles + 3) / 4, 4096);
+        hipLaunchKernelGGL(split_flag_kernel, dim3(g), dim3(256), 0, ctx->stream, (int)m->n_rows, n_tiles, (int)n_owned, m->rowptr,
+                           m->cols, flag);
+        rc = exclusive_scan_i32(ctx, flag, pos, n_tiles, &n_bnd);
+    }
+    if (rc == PADNE_OK) {
+        hipLaunchKernelGGL(split_scatter_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, ctx->stream, n_tiles,
+                           (const int *)flag, (const int *)pos, (int)n_bnd, tiles);
+        if (hipGetLastError() != hipSuccess) rc = PADNE_E_HIP;
+    }
+    pool_free(ctx, flag);
+    pool_free(ctx, pos);
+    if (rc != PADNE_OK) {
+        pool_free(owner, tiles);
+        return rc;
+    }
+    m->split_tiles = tiles;
+    m->split_n_bnd = (int)n_bnd;
+    m->split_n_int = n_tiles - (int)n_bnd;
+    m->split_state = 1;
     return PADNE_OK;
 }
 

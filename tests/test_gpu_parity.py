@@ -1509,6 +1509,7 @@ def run_team(sysm, world, precond, block=False):
             c1 = c.comm_call_counts()[0]
             assert res2.iterations == res.iterations and np.array_equal(ds.solution(), sol)
             res.collectives = [b - a for a, b in zip(c0, c1)]
+            res.split_tiles = [ds.A.split_tiles(-1)] + ([ds.A.split_tiles(1)] if precond == "amg" and not block else [])
             out[rank] = (plan, sol, res, ds.owned_reduced_global)
         except BaseException as exc:                              # wake the peers: they wait for this rank in a collective
             errors.append((rank, exc))
@@ -1579,6 +1580,27 @@ def test_peer_to_peer_halo_stores_are_the_all_gather_bit_for_bit(monkeypatch):
     # every exchange that was an all-gather is a peer-to-peer exchange now
     moved = (res_ag.collectives[1] + res_ag.collectives[2]) - (res_p2p.collectives[1] + res_p2p.collectives[2])
     assert moved == res_p2p.collectives[3], (res_ag.collectives, res_p2p.collectives)
+
+
+def test_products_split_into_interior_and_boundary_tiles_around_the_exchange(monkeypatch):
+    """every product of a row-partitioned level that follows a halo exchange is launched in two parts
+    -- the 64-row tiles whose columns are all owned while the exchange is under way, the tiles that read an exchange slot
+    once it has landed (csr_build_split_plan).  Same products, same sums per row; only the grouping of the dot-product
+    partials differs from the one-launch form (PADNE_NO_SPLIT=1): same iteration count, potentials equal to rounding, and
+    the split run itself is bitwise reproducible."""
+    sysm = synthetic.layered_system(8, 150, 120, via_lattice=6)        # 18 000 rows per layer: 282 tiles per rank at world 8
+    v_split, it_split, res_split = run_team(sysm, 4, "amg")
+    v_again, it_again, _ = run_team(sysm, 4, "amg")
+    assert it_again == it_split and np.array_equal(v_again, v_split)
+    (int0, bnd0), (int1, bnd1) = res_split.split_tiles            # the fine operator and the first coarse one are split
+    assert bnd0 > 0 and int0 > 4 * bnd0 and int0 + bnd0 == (36000 + 63) // 64
+    assert bnd1 > 0 and int1 > 0
+    monkeypatch.setenv("PADNE_NO_SPLIT", "1")
+    v_one, it_one, res_one = run_team(sysm, 4, "amg")
+    assert res_one.split_tiles[0] == (0, 0)
+    assert abs(it_split - it_one) <= 1
+    assert np.abs(v_split - v_one).max() <= 1e-10 * np.abs(v_one).max()
+    assert res_split.rel_residual <= 1.1e-12 and res_one.rel_residual <= 1.1e-12
 
 
 def test_last_partitioned_level_computes_its_neighbours_from_the_tail(monkeypatch):
