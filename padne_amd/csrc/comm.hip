@@ -189,28 +189,52 @@ int comm_allreduce_sum_f64(padne_ctx *ctx, double *dev_buf, int count) {
                                        ctx->stream), "ncclAllReduce");
 }
 
-int comm_allgather_f64(padne_ctx *ctx, const double *send, double *recv, int count_per_rank) {
+static int allgather_impl(padne_ctx *ctx, const void *send, void *recv, int count_per_rank, bool f64, hipStream_t stream) {
     if (count_per_rank == 0) return PADNE_OK;
+    const int kind = f64 ? 1 : 2;
+    const size_t elem = f64 ? sizeof(double) : sizeof(float);
     if (ctx->team != nullptr || ctx->comm != nullptr) {
-        ++g_calls[1];
-        g_bytes[1] += 8LL * count_per_rank;
+        ++g_calls[kind];
+        g_bytes[kind] += (long long)elem * count_per_rank;
     }
-    if (ctx->team != nullptr) return team_allgather(ctx, send, recv, sizeof(double) * (size_t)count_per_rank);
+    if (ctx->team != nullptr) return team_allgather(ctx, send, recv, elem * (size_t)count_per_rank);
     if (ctx->comm == nullptr) return PADNE_OK;
-    return check_nccl(g_rccl.AllGather(send, recv, (size_t)count_per_rank, ncclFloat64, (ncclComm_t)ctx->comm,
-                                       ctx->stream), "ncclAllGather");
+    return check_nccl(g_rccl.AllGather(send, recv, (size_t)count_per_rank, f64 ? ncclFloat64 : ncclFloat32, (ncclComm_t)ctx->comm,
+                                       stream), "ncclAllGather");
+}
+
+int comm_allgather_f64(padne_ctx *ctx, const double *send, double *recv, int count_per_rank) {
+    return allgather_impl(ctx, send, recv, count_per_rank, true, ctx->stream);
 }
 
 int comm_allgather_f32(padne_ctx *ctx, const float *send, float *recv, int count_per_rank) {
-    if (count_per_rank == 0) return PADNE_OK;
-    if (ctx->team != nullptr || ctx->comm != nullptr) {
-        ++g_calls[2];
-        g_bytes[2] += 4LL * count_per_rank;
+    return allgather_impl(ctx, send, recv, count_per_rank, false, ctx->stream);
+}
+
+// The halo all-gather of a communicator run on the context's SECOND stream, between two events: queued right behind the
+// pack kernel, it travels while the main stream computes the interior tiles of the product it is for; the main stream
+// waits for it (comm_allgather_side_join) in front of the boundary tiles.  Collectives of one communicator never overlap
+// each other this way: the next one on the main stream is queued behind the join.  false: not available (no
+// communicator, the team, PADNE_NO_COMM_OVERLAP=1) -- the caller gathers on the main stream as before.
+bool comm_allgather_side(padne_ctx *ctx, const void *send, void *recv, int count_per_rank, bool f64, int *rc) {
+    *rc = PADNE_OK;
+    if (ctx->comm == nullptr || ctx->team != nullptr || ctx->is_aux || getenv("PADNE_NO_COMM_OVERLAP") != nullptr) return false;
+    padne_ctx *aux = aux_context(ctx);
+    if (aux == nullptr) return false;
+    if ((*rc = stream_order(ctx, aux)) != PADNE_OK) return true;               // behind the pack kernel
+    if ((*rc = allgather_impl(ctx, send, recv, count_per_rank, f64, aux->stream)) != PADNE_OK) return true;
+    if (hipEventRecord(aux->ev_order, aux->stream) != hipSuccess) {
+        set_error("event record failed");
+        *rc = PADNE_E_HIP;
     }
-    if (ctx->team != nullptr) return team_allgather(ctx, send, recv, sizeof(float) * (size_t)count_per_rank);
-    if (ctx->comm == nullptr) return PADNE_OK;
-    return check_nccl(g_rccl.AllGather(send, recv, (size_t)count_per_rank, ncclFloat32, (ncclComm_t)ctx->comm,
-                                       ctx->stream), "ncclAllGather");
+    return true;
+}
+
+int comm_allgather_side_join(padne_ctx *ctx) {
+    padne_ctx *aux = ctx->aux;
+    PADNE_REQUIRE(aux != nullptr, "no side stream");
+    PADNE_HIP_CHECK(hipStreamWaitEvent(ctx->stream, aux->ev_order, 0));
+    return PADNE_OK;
 }
 
 // ---- peer-to-peer halo exchange ------------------------------------------------------------------------------------

@@ -237,6 +237,8 @@ int stream_order(padne_ctx *earlier, padne_ctx *later);
 int comm_allreduce_sum_f64(padne_ctx *ctx, double *dev_buf, int count);
 int comm_allgather_f64(padne_ctx *ctx, const double *send, double *recv, int count_per_rank);
 int comm_allgather_f32(padne_ctx *ctx, const float *send, float *recv, int count_per_rank);
+bool comm_allgather_side(padne_ctx *ctx, const void *send, void *recv, int count_per_rank, bool f64, int *rc);   // comm.hip
+int comm_allgather_side_join(padne_ctx *ctx);
 void comm_destroy(padne_ctx *ctx);
 void comm_abort(padne_ctx *ctx);   // a rank that leaves a collective phase with an error: wake the team / abort the communicator
 // Peer-to-peer halo exchange: instead of packing its exported values into its own segment and taking part in an
@@ -263,6 +265,7 @@ int halo_exchange_plan_f32(padne_ctx *ctx, const HaloPlan &plan, float *v, const
 // the same exchange in two halves (pcg.hip): what needs no remote value goes between them
 struct HaloTicket {
     bool p2p = false;
+    bool side = false;               // the all-gather is already under way on the second stream
     size_t entry_off = 0;
 };
 int halo_send(padne_ctx *ctx, const HaloPlan &plan, double *v, const int32_t *done_flag, HaloTicket *tk);

@@ -385,6 +385,7 @@ __global__ void halo_unpack_kernel(T *__restrict__ v, long long n_owned, int m, 
 template <typename T>
 static int halo_send_t(padne_ctx *ctx, const HaloPlan &plan, T *v, const int32_t *done_flag, HaloTicket *tk) {
     tk->p2p = false;
+    tk->side = false;
     if (plan.m <= 0) return PADNE_OK;
     if (comm_p2p_enabled(ctx)) {
         void **peers = nullptr;
@@ -404,7 +405,11 @@ static int halo_send_t(padne_ctx *ctx, const HaloPlan &plan, T *v, const int32_t
                            plan.export_idx, plan.n_export, seg_off, done_flag);
         PADNE_HIP_CHECK(hipGetLastError());
     }
-    return PADNE_OK;
+    // with a communicator the all-gather starts NOW, on the second stream: what the caller queues before halo_recv (the
+    // interior tiles of the product) runs beside it
+    int rc = PADNE_OK;
+    tk->side = comm_allgather_side(ctx, v + seg_off, v + plan.n_owned, plan.m, sizeof(T) == 8, &rc);
+    return rc;
 }
 
 static int allgather_t(padne_ctx *ctx, const double *send, double *recv, int count) { return comm_allgather_f64(ctx, send, recv, count); }
@@ -421,6 +426,7 @@ static int halo_recv_t(padne_ctx *ctx, const HaloPlan &plan, T *v, const int32_t
         PADNE_HIP_CHECK(hipGetLastError());
         return PADNE_OK;
     }
+    if (tk.side) return comm_allgather_side_join(ctx);
     const long long seg_off = plan.n_owned + (long long)ctx->rank * plan.m;
     return allgather_t(ctx, v + seg_off, v + plan.n_owned, plan.m);
 }
