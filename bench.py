@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--precond", default="amg", choices=["amg", "jacobi"],
                     help="amg: smoothed-aggregation multigrid V-cycle (rebuilt inside every step); jacobi: diagonal")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-seam", action="store_true",
+                    help="skip the solve_system(L, r) wall-time measurement behind the timed steps (profiling runs)")
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the row-partitioned code path (RCCL communicator, halo plan) even on 1 GPU")
     ap.add_argument("--cpu-sample-nx", type=int, default=400,
@@ -305,7 +307,7 @@ def main():
     barrier()
     t_standalone = standalone() if standalone is not None else None
     seam = None
-    if not distributed_path and args.precond == "amg":
+    if not distributed_path and args.precond == "amg" and not args.no_seam:
         seam = seam_timing(ctx, L_full, sysm, rhs, max(2, min(args.steps, 5)))
 
     if rank == 0:
