@@ -131,7 +131,7 @@ __device__ __forceinline__ XT xw_stream_tile(const VT *__restrict__ vals, const 
 // copies of its operators: 8 instead of 12 bytes per non-zero, half the vector traffic), and its last stage
 // <float, float, double> hands z back to CG in double, multiplied by sqrt(*out_scale2) (the cycle works on
 // r / ||b||, see amg.hip) and with the r.z partials taken against the double residual `dot_with`.
-template <int MODE, typename VT, typename XT, typename YT>
+template <int MODE, typename VT, typename XT, typename YT, bool LIST = false>
 __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
     const int n_rows, const int n_cols, const int n_wtiles, const int *__restrict__ rowptr,
     const int *__restrict__ cols, const VT *__restrict__ vals,
@@ -142,8 +142,9 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
     const int4 *__restrict__ xw_desc, const void *__restrict__ xw_lidx, const int xw_run,
     const XT *__restrict__ aux0, XT *__restrict__ y2, const int *__restrict__ tile_list, const int n_list,
     const int partial_off) {
-    // tile_list (optional): the launch covers the n_list tiles listed there (interior or boundary tiles of a
-    // row-partitioned operator, csr_build_split_plan) instead of all n_wtiles; its partial sums start at partial_off
+    // LIST: the launch covers the n_list tiles of tile_list (interior or boundary tiles of a row-partitioned operator,
+    // csr_build_split_plan) instead of all n_wtiles, and its partial sums start at partial_off.  A template parameter, not a
+    // run-time test: with the test in the sweep loop the one-GPU kernels lost 6 % (the W product 45 %)
     constexpr bool WITH_DOT = (MODE == SPMV_DOT) || (MODE == SPMV_DOT_AUX) || (MODE == SPMV_JACOBI) || (MODE == SPMV_WUP);
     __shared__ XT prod_all[4 * kWaveChunk];
     extern __shared__ unsigned char xs_dyn[];      // 4 * kXwRuns * xw_run entries of XT when the plan is in use
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
     const int slab = blockIdx.x % nslab;
     const int wx = (blockIdx.x / nslab) * 4 + w;       // wave index inside the slab
     const int wps = (G / nslab) * 4;                   // waves per slab
-    const int n_sweep = tile_list != nullptr ? n_list : n_wtiles;
+    const int n_sweep = LIST ? n_list : n_wtiles;
     const int s0 = (int)((long long)slab * n_sweep / nslab);
     const int s1 = (int)((long long)(slab + 1) * n_sweep / nslab);
 
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
     int rs = 0, re = 0;
     int4 d = make_int4(0, 0, 0, 0);
     for (int it = s0 + wx; it < s1; it += wps) {
-        const int wt = tile_list != nullptr ? tile_list[it] : it;
+        const int wt = LIST ? tile_list[it] : it;
         const int row0 = wt * 64;
         const int row1 = min(row0 + 64, n_rows);
         const int r = row0 + lane;
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
     }
     if (WITH_DOT && partials != nullptr) {
         const double s = block_sum_256(dot_acc, red);
-        if (threadIdx.x == 0) partials[partial_off + blockIdx.x] = s;
+        if (threadIdx.x == 0) partials[(LIST ? partial_off : 0) + blockIdx.x] = s;
     }
 }
 
@@ -436,11 +437,26 @@ static int launch_spmv_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals,
     const size_t xs_bytes = m->xw_state == 1 ? sizeof(XT) * 4 * kXwRuns * (size_t)m->xw_run : 0;
     const int4 *xw_desc = m->xw_state == 1 ? m->xw_desc : nullptr;
     const void *xw_lidx = m->xw_state == 1 ? (const void *)m->xw_lidx : nullptr;
+#define PADNE_SPMV_ARGS                                                                                          \
+    (int)m->n_rows, (int)m->n_cols, n_tiles, m->rowptr, m->cols, vals, x, y, dot_with, partials, done_flag, aux1, aux2, \
+        scale, out_scale2, xw_desc, xw_lidx, m->xw_run, aux0, y2, tile_list, n_list, partial_off
 #define PADNE_SPMV_LAUNCH(M)                                                                                     \
-    hipLaunchKernelGGL((csr_spmv_kernel<M, VT, XT, YT>), dim3(g), dim3(kSpmvThreads), xs_bytes, ctx->stream,      \
-                       (int)m->n_rows, (int)m->n_cols, n_tiles, m->rowptr, m->cols, vals, x, y, dot_with,         \
-                       partials, done_flag, aux1, aux2, scale, out_scale2, xw_desc, xw_lidx, m->xw_run, aux0, y2, \
-                       tile_list, n_list, partial_off)
+    hipLaunchKernelGGL((csr_spmv_kernel<M, VT, XT, YT, false>), dim3(g), dim3(kSpmvThreads), xs_bytes, ctx->stream, PADNE_SPMV_ARGS)
+#define PADNE_SPMV_LAUNCH_LIST(M)                                                                                \
+    hipLaunchKernelGGL((csr_spmv_kernel<M, VT, XT, YT, true>), dim3(g), dim3(kSpmvThreads), xs_bytes, ctx->stream, PADNE_SPMV_ARGS)
+    if (tile_list != nullptr) {
+        // the products that follow a halo exchange: q = A p of the CG loop, the Lanczos steps, residual and smoothing of the cycle
+        switch (mode) {
+            case SPMV_PLAIN: PADNE_SPMV_LAUNCH_LIST(SPMV_PLAIN); break;
+            case SPMV_DOT: PADNE_SPMV_LAUNCH_LIST(SPMV_DOT); break;
+            case SPMV_DOT_AUX: PADNE_SPMV_LAUNCH_LIST(SPMV_DOT_AUX); break;
+            case SPMV_RESID: PADNE_SPMV_LAUNCH_LIST(SPMV_RESID); break;
+            case SPMV_JACOBI: PADNE_SPMV_LAUNCH_LIST(SPMV_JACOBI); break;
+            default: set_error("SpMV mode %d has no interior / boundary form", mode); return PADNE_E_INVALID;
+        }
+        PADNE_HIP_CHECK(hipGetLastError());
+        return PADNE_OK;
+    }
     switch (mode) {
         case SPMV_PLAIN: PADNE_SPMV_LAUNCH(SPMV_PLAIN); break;
         case SPMV_DOT: PADNE_SPMV_LAUNCH(SPMV_DOT); break;
@@ -452,6 +468,8 @@ static int launch_spmv_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals,
         case SPMV_RESTRICT: PADNE_SPMV_LAUNCH(SPMV_RESTRICT); break;
         default: set_error("bad SpMV mode %d", mode); return PADNE_E_INVALID;
     }
+#undef PADNE_SPMV_LAUNCH_LIST
+#undef PADNE_SPMV_ARGS
 #undef PADNE_SPMV_LAUNCH
     PADNE_HIP_CHECK(hipGetLastError());
     return PADNE_OK;
