@@ -2253,6 +2253,12 @@ __global__ __launch_bounds__(256) void w_from_slots_kernel(int n, const int *__r
             wc[k] = col;
             wv[k] = (float)v;
         }
+        // the SpMV streams four non-zeros per lane and load: the three entries behind the last one must be valid columns
+        // (csr_alloc zeroes the padding of ordinary matrices; W's arrays are sized by the slot count, its end is known here)
+        if (r0 + nr == n && lane < 4) {
+            wc[d1 + lane] = 0;
+            wv[d1 + lane] = 0.f;
+        }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
     }

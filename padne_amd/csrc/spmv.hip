@@ -114,6 +114,55 @@ __device__ __forceinline__ XT xw_stream_tile(const VT *__restrict__ vals, const 
     return acc;
 }
 
+// The gather path of a tile in the same shape: four consecutive non-zeros per lane and load (one 16-byte load of columns,
+// one or two of values) instead of eight 4-byte loads of each, x gathered from global memory, products parked four at a time.
+// A pass starts on a multiple of 4; stray elements in front of k0 / behind k1 are multiplied (their columns are valid: both
+// arrays are padded with column 0 / value 0) but never summed.  Same products, same order of the row sums.
+template <typename VT, typename XT>
+__device__ __forceinline__ XT gather_stream_tile(const int *__restrict__ cols, const VT *__restrict__ vals, const XT *__restrict__ x,
+                                                 XT *prod, const int k0, const int k1, const int rs, const int re, const int lane) {
+    constexpr int G = 4, NJ = kEpl / G;
+    struct alignas(16) VG { VT v[G]; };
+    int4 cw[NJ];
+    VG vg[NJ];
+    XT acc = 0;
+    for (int base = k0 & ~(G - 1);;) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int e = base + G * lane + 64 * G * j;
+            cw[j] = make_int4(0, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < G; ++t) vg[j].v[t] = 0;
+            if (e < k1) {
+                cw[j] = *reinterpret_cast<const int4 *>(cols + e);
+                vg[j] = *reinterpret_cast<const VG *>(vals + e);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int e = base + G * lane + 64 * G * j;
+            XT xv[G] = {0, 0, 0, 0};
+            if (e < k1) {
+                xv[0] = x[cw[j].x];
+                xv[1] = x[cw[j].y];
+                xv[2] = x[cw[j].z];
+                xv[3] = x[cw[j].w];
+            }
+#pragma unroll
+            for (int t = 0; t < G; ++t) prod[G * lane + 64 * G * j + t] = (XT)vg[j].v[t] * xv[t];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const int lo = max(rs, base), hi = min(re, base + kWaveChunk);
+        for (int k = lo; k < hi; ++k) acc += prod[k - base];
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        base += kWaveChunk;
+        if (base >= k1) break;
+    }
+    return acc;
+}
+
 // Epilogues (acc = (A x)[row]):
 //   SPMV_PLAIN   y = acc
 //   SPMV_DOT     y = acc ; partial sums of dot_with[row] * acc
@@ -213,34 +262,8 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
                 acc = xw_stream_tile<4, unsigned char, VT, XT>(vals, (const unsigned char *)xw_lidx, xs, prod, k0, k1, rs, re, lane, top);
             else
                 acc = xw_stream_tile<2, unsigned short, VT, XT>(vals, (const unsigned short *)xw_lidx, xs, prod, k0, k1, rs, re, lane, top);
-        } else {
-            for (int base = k0; base < k1; base += kWaveChunk) {
-                int c[kEpl];
-                VT v[kEpl];
-#pragma unroll
-                for (int j = 0; j < kEpl; ++j) {
-                    const int e = base + lane + 64 * j;
-                    c[j] = 0;
-                    v[j] = 0;
-                    if (e < k1) {
-                        c[j] = cols[e];
-                        v[j] = vals[e];
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < kEpl; ++j) {
-                    const int e = base + lane + 64 * j;
-                    XT xv = 0;
-                    if (e < k1) xv = x[c[j]];
-                    prod[lane + 64 * j] = (XT)v[j] * xv;
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                const int lo = max(rs, base), hi = min(re, base + kWaveChunk);
-                for (int k = lo; k < hi; ++k) acc += prod[k - base];
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-            }
+        } else if (k1 > k0) {
+            acc = gather_stream_tile<VT, XT>(cols, vals, x, prod, k0, k1, rs, re, lane);
         }
         if (r < row1) {
             if (MODE == SPMV_PLAIN) {
