@@ -118,10 +118,10 @@ __device__ __forceinline__ XT xw_stream_tile(const VT *__restrict__ vals, const 
 // one or two of values) instead of eight 4-byte loads of each, x gathered from global memory, products parked four at a time.
 // A pass starts on a multiple of 4; stray elements in front of k0 / behind k1 are multiplied (their columns are valid: both
 // arrays are padded with column 0 / value 0) but never summed.  Same products, same order of the row sums.
-template <typename VT, typename XT>
+template <typename VT, typename XT, int EPL>
 __device__ __forceinline__ XT gather_stream_tile(const int *__restrict__ cols, const VT *__restrict__ vals, const XT *__restrict__ x,
                                                  XT *prod, const int k0, const int k1, const int rs, const int re, const int lane) {
-    constexpr int G = 4, NJ = kEpl / G;
+    constexpr int G = 4, NJ = EPL / G, CHUNK = 64 * EPL;
     struct alignas(16) VG { VT v[G]; };
     int4 cw[NJ];
     VG vg[NJ];
@@ -153,11 +153,11 @@ __device__ __forceinline__ XT gather_stream_tile(const int *__restrict__ cols, c
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        const int lo = max(rs, base), hi = min(re, base + kWaveChunk);
+        const int lo = max(rs, base), hi = min(re, base + CHUNK);
         for (int k = lo; k < hi; ++k) acc += prod[k - base];
         asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        base += kWaveChunk;
+        base += CHUNK;
         if (base >= k1) break;
     }
     return acc;
@@ -180,7 +180,7 @@ __device__ __forceinline__ XT gather_stream_tile(const int *__restrict__ cols, c
 // copies of its operators: 8 instead of 12 bytes per non-zero, half the vector traffic), and its last stage
 // <float, float, double> hands z back to CG in double, multiplied by sqrt(*out_scale2) (the cycle works on
 // r / ||b||, see amg.hip) and with the r.z partials taken against the double residual `dot_with`.
-template <int MODE, typename VT, typename XT, typename YT, bool LIST = false>
+template <int MODE, typename VT, typename XT, typename YT, bool LIST = false, bool LONG = false>
 __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
     const int n_rows, const int n_cols, const int n_wtiles, const int *__restrict__ rowptr,
     const int *__restrict__ cols, const VT *__restrict__ vals,
@@ -195,7 +195,12 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
     // csr_build_split_plan) instead of all n_wtiles, and its partial sums start at partial_off.  A template parameter, not a
     // run-time test: with the test in the sweep loop the one-GPU kernels lost 6 % (the W product 45 %)
     constexpr bool WITH_DOT = (MODE == SPMV_DOT) || (MODE == SPMV_DOT_AUX) || (MODE == SPMV_JACOBI) || (MODE == SPMV_WUP);
-    __shared__ XT prod_all[4 * kWaveChunk];
+    // LONG (single-precision operators with more than 8 entries per row on average: restrictions, coarse operators): 16
+    // elements per lane and pass of the gather path -- the same 4 KiB of LDS per wave as 8 doubles, one pass less per tile.
+    // Not for shorter rows: the passes are unrolled, and the W product (5 entries per row) lost 30 % to the idle half
+    constexpr int kEplGather = LONG ? 2 * kEpl : kEpl;
+    static_assert(!LONG || sizeof(XT) == 4, "16 elements per lane only for single-precision vectors");
+    __shared__ XT prod_all[4 * 64 * kEplGather];
     extern __shared__ unsigned char xs_dyn[];      // 4 * kXwRuns * xw_run entries of XT when the plan is in use
     XT *xs_all = reinterpret_cast<XT *>(xs_dyn);
     __shared__ double red[4];
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
     if (done_flag != nullptr && *done_flag != 0) return;
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    XT *prod = prod_all + w * kWaveChunk;
+    XT *prod = prod_all + w * 64 * kEplGather;
     XT *xs = xs_all + w * kXwRuns * xw_run;
     double out_mul = 1.0;
     if (out_scale2 != nullptr) {
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
             else
                 acc = xw_stream_tile<2, unsigned short, VT, XT>(vals, (const unsigned short *)xw_lidx, xs, prod, k0, k1, rs, re, lane, top);
         } else if (k1 > k0) {
-            acc = gather_stream_tile<VT, XT>(cols, vals, x, prod, k0, k1, rs, re, lane);
+            acc = gather_stream_tile<VT, XT, kEplGather>(cols, vals, x, prod, k0, k1, rs, re, lane);
         }
         if (r < row1) {
             if (MODE == SPMV_PLAIN) {
@@ -465,6 +470,8 @@ static int launch_spmv_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals,
         scale, out_scale2, xw_desc, xw_lidx, m->xw_run, aux0, y2, tile_list, n_list, partial_off
 #define PADNE_SPMV_LAUNCH(M)                                                                                     \
     hipLaunchKernelGGL((csr_spmv_kernel<M, VT, XT, YT, false>), dim3(g), dim3(kSpmvThreads), xs_bytes, ctx->stream, PADNE_SPMV_ARGS)
+#define PADNE_SPMV_LAUNCH_LONG(M)                                                                                \
+    hipLaunchKernelGGL((csr_spmv_kernel<M, VT, XT, YT, false, sizeof(XT) == 4 && sizeof(YT) == 4>), dim3(g), dim3(kSpmvThreads), xs_bytes, ctx->stream, PADNE_SPMV_ARGS)
 #define PADNE_SPMV_LAUNCH_LIST(M)                                                                                \
     hipLaunchKernelGGL((csr_spmv_kernel<M, VT, XT, YT, true>), dim3(g), dim3(kSpmvThreads), xs_bytes, ctx->stream, PADNE_SPMV_ARGS)
     if (tile_list != nullptr) {
@@ -480,6 +487,22 @@ static int launch_spmv_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals,
         PADNE_HIP_CHECK(hipGetLastError());
         return PADNE_OK;
     }
+    // single-precision operators of the cycle with long rows, no x windows and few tiles per wave (the levels below the
+    // first coarse one: 139 k rows at C4): the 16-per-lane form of the gather path, -11 us per cycle there.  On the million-row
+    // operators (the fine restriction, the first coarse level) it loses 2-5 us each: the shorter form stays
+    const bool long_rows = sizeof(XT) == 4 && sizeof(YT) == 4 && xw_desc == nullptr && m->n_rows < 500000 &&
+                           m->nnz > 8 * m->n_rows + 4 * (m->n_rows >> 3);
+    if (long_rows && (mode == SPMV_PLAIN || mode == SPMV_RESID || mode == SPMV_ADD || mode == SPMV_JACOBI || mode == SPMV_RESTRICT)) {
+        switch (mode) {
+            case SPMV_PLAIN: PADNE_SPMV_LAUNCH_LONG(SPMV_PLAIN); break;
+            case SPMV_RESID: PADNE_SPMV_LAUNCH_LONG(SPMV_RESID); break;
+            case SPMV_ADD: PADNE_SPMV_LAUNCH_LONG(SPMV_ADD); break;
+            case SPMV_JACOBI: PADNE_SPMV_LAUNCH_LONG(SPMV_JACOBI); break;
+            default: PADNE_SPMV_LAUNCH_LONG(SPMV_RESTRICT); break;
+        }
+        PADNE_HIP_CHECK(hipGetLastError());
+        return PADNE_OK;
+    }
     switch (mode) {
         case SPMV_PLAIN: PADNE_SPMV_LAUNCH(SPMV_PLAIN); break;
         case SPMV_DOT: PADNE_SPMV_LAUNCH(SPMV_DOT); break;
@@ -491,6 +514,7 @@ static int launch_spmv_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals,
         case SPMV_RESTRICT: PADNE_SPMV_LAUNCH(SPMV_RESTRICT); break;
         default: set_error("bad SpMV mode %d", mode); return PADNE_E_INVALID;
     }
+#undef PADNE_SPMV_LAUNCH_LONG
 #undef PADNE_SPMV_LAUNCH_LIST
 #undef PADNE_SPMV_ARGS
 #undef PADNE_SPMV_LAUNCH
