@@ -105,7 +105,15 @@ __device__ __forceinline__ XT xw_stream_tile(const VT *__restrict__ vals, const 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         const int lo = max(rs, base), hi = min(re, base + kWaveChunk);
-        for (int k = lo; k < hi; ++k) acc += prod[k - base];
+        {
+            int k = lo;                                    // two entries per turn (one 8-byte LDS read where they pair up)
+            for (; k + 1 < hi; k += 2) {
+                const XT p0 = prod[k - base], p1 = prod[k + 1 - base];
+                acc += p0;
+                acc += p1;
+            }
+            if (k < hi) acc += prod[k - base];
+        }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         base += kWaveChunk;
@@ -154,13 +162,50 @@ __device__ __forceinline__ XT gather_stream_tile(const int *__restrict__ cols, c
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         const int lo = max(rs, base), hi = min(re, base + CHUNK);
-        for (int k = lo; k < hi; ++k) acc += prod[k - base];
+        {
+            int k = lo;                                    // two entries per turn (one 8-byte LDS read where they pair up)
+            for (; k + 1 < hi; k += 2) {
+                const XT p0 = prod[k - base], p1 = prod[k + 1 - base];
+                acc += p0;
+                acc += p1;
+            }
+            if (k < hi) acc += prod[k - base];
+        }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         base += CHUNK;
         if (base >= k1) break;
     }
     return acc;
+}
+
+// The tile's three runs of x into the wave's LDS slice in 16-byte pieces: 54 lanes of ONE load and ONE store instruction
+// bring the 216 single-precision entries of three runs of 72 (two rounds for doubles or runs of 128) where lane-per-entry
+// loads took six of each.  A piece that would reach past the end of x is fetched entry by entry.
+template <int RUN, typename XT>
+__device__ __forceinline__ void stage_windows(const XT *__restrict__ x, const int n_cols, const int4 d, XT *xs, const int lane) {
+    constexpr int PER = 16 / (int)sizeof(XT), PPR = RUN / PER, NP = kXwRuns * PPR;
+    static_assert(RUN % PER == 0, "runs are whole 16-byte pieces");
+    struct alignas(sizeof(XT)) PieceG { XT v[PER]; };      // in global memory a run starts at any entry
+    struct alignas(16) PieceL { XT v[PER]; };
+#pragma unroll
+    for (int c0 = 0; c0 < NP; c0 += 64) {
+        const int c = c0 + lane;
+        if (c < NP) {
+            const int q = c / PPR, i = c - q * PPR;
+            const int g0 = (q == 0 ? d.x : (q == 1 ? d.y : d.z)) + PER * i;
+            PieceL pl;
+            if (g0 + PER - 1 < n_cols) {
+                const PieceG pg = *reinterpret_cast<const PieceG *>(x + g0);
+#pragma unroll
+                for (int t = 0; t < PER; ++t) pl.v[t] = pg.v[t];
+            } else {
+#pragma unroll
+                for (int t = 0; t < PER; ++t) pl.v[t] = (g0 + t < n_cols) ? x[g0 + t] : (XT)0;
+            }
+            *reinterpret_cast<PieceL *>(xs + q * RUN + PER * i) = pl;
+        }
+    }
 }
 
 // Epilogues (acc = (A x)[row]):
@@ -201,7 +246,7 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
     constexpr int kEplGather = LONG ? 2 * kEpl : kEpl;
     static_assert(!LONG || sizeof(XT) == 4, "16 elements per lane only for single-precision vectors");
     __shared__ XT prod_all[4 * 64 * kEplGather];
-    extern __shared__ unsigned char xs_dyn[];      // 4 * kXwRuns * xw_run entries of XT when the plan is in use
+    extern __shared__ __attribute__((aligned(16))) unsigned char xs_dyn[];      // 4 * kXwRuns * xw_run entries of XT when the plan is in use
     XT *xs_all = reinterpret_cast<XT *>(xs_dyn);
     __shared__ double red[4];
 
@@ -245,22 +290,9 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
         XT acc = 0;
         const bool windowed = xw_desc != nullptr && d.w != 0;      // wave-uniform
         if (windowed) {
-            // the tile's runs of x: two loads per run (64 + the rest)
-            const int st[kXwRuns] = {d.x, d.y, d.z};
-            XT xa[kXwRuns], xb[kXwRuns];
-#pragma unroll
-            for (int q = 0; q < kXwRuns; ++q) {
-                const int a = st[q] + lane, b = st[q] + 64 + lane;
-                xa[q] = (a < n_cols) ? x[a] : (XT)0;
-                xb[q] = (lane < xw_run - 64 && b < n_cols) ? x[b] : (XT)0;
-            }
-            // (issuing the first pass of non-zeros ahead of these LDS stores, or fetching the next tile's header one
-            // tile early, gains nothing: the kernel is not bound by the dependent latencies of one tile)
-#pragma unroll
-            for (int q = 0; q < kXwRuns; ++q) {
-                xs[q * xw_run + lane] = xa[q];
-                if (lane < xw_run - 64) xs[q * xw_run + 64 + lane] = xb[q];
-            }
+            // the tile's runs of x (stage_windows; the stream loops wait for these LDS stores before their first read)
+            if (xw_run <= kXwRunShort) stage_windows<kXwRunShort, XT>(x, n_cols, d, xs, lane);
+            else stage_windows<kXwRunLong, XT>(x, n_cols, d, xs, lane);
             const int top = kXwRuns * xw_run - 1;
             // three runs of 72 are 216 positions: one byte each, four non-zeros per lane and load; runs of 128 need 16 bits
             if (xw_run <= kXwRunShort)
