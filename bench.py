@@ -113,11 +113,22 @@ def full_size_cpu_record():
     path = os.path.join(ROOT, "profiles", "r02_direct_full.json")
     try:
         rec = json.load(open(path))["configs"]["C4"]
-        return {"source": "profiles/r02_direct_full.json (scripts/direct_full.py, measured, not extrapolated)",
+        return {"static_from": "profiles/r02_direct_full.json",
+                "source": "profiles/r02_direct_full.json (scripts/direct_full.py, measured once in round 2 on a GPU-box host, not "
+                          "extrapolated, NOT re-measured in this run)",
                 "cpu": json.load(open(path))["host"]["cpu"], "n": rec["n"],
                 "spsolve_seconds": rec["reference_cpu"]["spsolve_seconds"], "total_seconds": rec["reference_cpu"]["total_seconds"],
                 "peak_rss_gb": rec["reference_cpu"]["peak_rss_gb"],
                 "max_rel_potential_error_of_the_hip_solve": rec["parity"]["max_rel_error"]}
+    except Exception:
+        return None
+
+
+def step_counter_traffic():
+    """HBM-side bytes of one timed step by the hardware counters (profiles/r03_step_traffic.json, written by
+    scripts/pmc_setup_sum.py from separate rocprofv3 --pmc passes of the same command); None if the file is missing."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r03_step_traffic.json")))
     except Exception:
         return None
 
@@ -349,6 +360,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "csr_spmv_kernel<SPMV_DOT, double, double, double> (q = A p with p.q epilogue)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_static_from": "profiles/spmv_traffic.json (rocprofv3 --pmc passes of the round's final build, "
+                                                "scripts/pmc_bench.sh; not collected in this run)" if traffic is not None else None,
                          "bytes_per_launch": int(spmv_bytes), "seconds_per_launch": t_spmv,
                          "note": "achieved/frac: kernel timed in situ inside the CG loop; standalone_frac: the same "
                                  "kernel launched back to back (no dirty predecessor)",
@@ -365,6 +378,16 @@ def main():
                     "iteration_frac": sb["per_iteration"] * int(last.iterations) / max(float(last.seconds), 1e-12) / 1e9 / HBM_PEAK_GBS,
                     "note": "whole timed step (multigrid setup + all CG iterations) by the textbook CSR byte count of "
                             "SURVEY 8d; the entry above is the dominant kernel alone"}
+                step_traffic = step_counter_traffic()
+                if step_traffic is not None:
+                    # what the implementation really moves (float cycle, one-byte window positions; but also every re-fetch):
+                    # counter bytes of one step over the time of one step
+                    out["roofline"]["step"].update({
+                        "traffic": step_traffic["step_bytes"], "traffic_setup": step_traffic["setup_bytes"],
+                        "traffic_loop": step_traffic["loop_bytes"],
+                        "traffic_frac": step_traffic["step_bytes"] / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                        "traffic_static_from": "profiles/r03_step_traffic.json (scripts/pmc_setup_sum.py over the --pmc passes of "
+                                               "the round's final build; not collected in this run)"})
             except Exception as exc:
                 out["roofline"]["step"] = {"error": repr(exc)}
         if seam is not None:

@@ -2,11 +2,12 @@
 table and the SpMV-by-grid summary from the raw csv files."""
 import csv, glob, json, collections, shutil, os
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RD = os.environ.get("PADNE_ROUND", "r02")        # prefix of the files written under profiles/
+RD = os.environ.get("PADNE_ROUND", "r03")        # prefix of the files written under profiles/
 F = os.path.join(R, "gpurun_out", "final"); P = os.path.join(R, "profiles")
 for src, dst in (("bench_c4_1gpu_amg.json", RD + "_bench_c4_1gpu_amg.json"), ("bench_c4_1gpu_amg.json", RD + "_bench_c4_1gpu.json"),
                  ("bench_c4_1gpu_jacobi.json", RD + "_bench_c4_1gpu_jacobi.json"), ("stats/run_kernel_stats.csv", RD + "_bench_c4_amg_kernel_stats.csv"),
-                 ("pmc/spmv_traffic.json", "spmv_traffic.json"), ("configs.json", RD + "_configs.json")):
+                 ("pmc/spmv_traffic.json", "spmv_traffic.json"), ("configs.json", RD + "_configs.json"),
+                 ("step_traffic.json", RD + "_step_traffic.json"), ("pmc_per_kernel_per_solve.csv", RD + "_pmc_per_kernel_per_solve.csv")):
     shutil.copy(os.path.join(F, src), os.path.join(P, dst))
 acc = {}
 for C in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -26,9 +27,9 @@ with open(os.path.join(P, RD + "_pmc_fetch_write_per_kernel.csv"), "w") as f:
         f.write('"%s",%d,%.1f,%.1f,%.1f,%.1f,separate --pmc passes over `bench.py --steps 1 --warmup 0`; HBM bytes = 2*FETCH*1024 + WRITE*1024 (gfx950)\n' % (k, n, fm, fx, wm, wx))
 per = collections.defaultdict(list)
 for row in csv.DictReader(open(f"{F}/stats/run_kernel_trace.csv")):
-    if "csr_spmv_kernel<1, double, double, double>" in row["Kernel_Name"]:
+    if "csr_spmv_kernel<1, double, double, double" in row["Kernel_Name"]:
         per[int(row.get("Grid_Size_X", row.get("Grid_Size", 0)))].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
-st = [r for r in csv.DictReader(open(f"{F}/stats/run_kernel_stats.csv")) if "csr_spmv_kernel<1, double, double, double>" in r["Name"]][0]
+st = [r for r in csv.DictReader(open(f"{F}/stats/run_kernel_stats.csv")) if "csr_spmv_kernel<1, double, double, double" in r["Name"]][0]
 rec = {"source": "rocprofv3 --kernel-trace --stats --output-format csv of `python bench.py --no-cpu-baseline` (profiles/" + RD + "_bench_c4_amg_kernel_stats.csv is the --stats table of the same run)",
        "kernel": "padne::csr_spmv_kernel<SPMV_DOT = 1, double, double, double>  (the CG loop's q = A p; the Lanczos estimates of the setup use the twin instantiation <5, ...>)",
        "stats": {"calls": int(st["Calls"]), "average_us": float(st["AverageNs"]) / 1e3, "min_us": float(st["MinNs"]) / 1e3, "max_us": float(st["MaxNs"]) / 1e3},

@@ -20,7 +20,7 @@ def big(name, C):      # mean over the launches on the finest level (the largest
     v = sorted(acc[C].get(name, []))
     v = [x for x in v if x > 0.5 * v[-1]] if v else []
     return sum(v) / len(v) if v else float("nan"), len(v)
-names = [k for k in acc["FETCH_SIZE"] if "csr_spmv_kernel<1, double, double, double>" in k]
+names = [k for k in acc["FETCH_SIZE"] if "csr_spmv_kernel<1, double, double, double" in k]
 dot = names[0]
 # calibration kernel: the p update of the multigrid loop (pcg.hip, pcg_update_p_z_kernel with the deferred x update and the
 # single-precision z): per row it READS p (8 B), z32 (4 B), x (8 B) = 20 B and WRITES x (8 B), p (8 B) = 16 B, nothing else
