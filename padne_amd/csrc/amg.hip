@@ -844,6 +844,96 @@ __global__ __launch_bounds__(128) void spgemm_rows_lds(int n_rows, const int *__
     row_len[i] = m;
 }
 
+// The same kernel with its loads taken out of the dependent chain.  spgemm_rows_lds walks  xc[k] -> yr[mid] -> yc / yv[q]  one
+// entry at a time and waits for every load before it issues the next: ~5 dependent global round trips per entry of the X
+// row, ~40 per row of a mesh operator, at three waves per SIMD (the lists take the LDS) -- the kernel is bound by exactly
+// that latency (rocprofv3: L1 pending-request stall 57 %, texture addresser 5 %).  Here a thread takes KC entries of its X row
+// at once: all their columns and values, then all the row bounds of Y they select, then the products of entry u + 1 are
+// requested while those of entry u go into the list -- three to four round trips per KC entries.  Register arrays are
+// indexed by unrolled constants only.  Same products in the same order: bit-identical lists.  (Round 2 had tried ALL loads
+// of a row up front: 212 VGPRs, two waves per SIMD, no gain; this form needs 90.)
+template <int CAP, int KC, int QC, int YCS>
+__global__ __launch_bounds__(128) void spgemm_rows_lds_pipe(int n_rows, const int *__restrict__ xr, const int *__restrict__ xc,
+                                                            const double *__restrict__ xv, const int *__restrict__ yr,
+                                                            const int *__restrict__ yc, const double *__restrict__ yv,
+                                                            const int *__restrict__ ye, const int *__restrict__ slot_ptr,
+                                                            long long *__restrict__ key, double *__restrict__ val,
+                                                            int *__restrict__ row_len) {
+    __shared__ int Kc[CAP][128];
+    __shared__ double Vc[CAP][128];
+    const int t = threadIdx.x;
+    const int i = xcd_bid() * 128 + t;
+    if (i >= n_rows) return;
+    int m = 0;
+    bool overflow = false;
+    auto insert = [&](const int c, const double v) {
+        int lo = 0;
+        while (lo < m && Kc[lo][t] < c) ++lo;          // lists are a handful of entries long
+        if (lo < m && Kc[lo][t] == c) {
+            Vc[lo][t] += v;
+        } else if (m == CAP) {
+            overflow = true;
+        } else {
+            for (int u = m; u > lo; --u) {
+                Kc[u][t] = Kc[u - 1][t];
+                Vc[u][t] = Vc[u - 1][t];
+            }
+            Kc[lo][t] = c;
+            Vc[lo][t] = v;
+            ++m;
+        }
+    };
+    const int x0 = xr[i], x1 = xr[i + 1];
+    for (int kb = x0; kb < x1 && !overflow; kb += KC) {
+        const int nk = min(KC, x1 - kb);
+        int mid[KC], ys[KC], ln[KC];
+        double a[KC];
+#pragma unroll
+        for (int u = 0; u < KC; ++u) {
+            mid[u] = u < nk ? xc[kb + u] : 0;
+            a[u] = u < nk ? xv[kb + u] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < KC; ++u) {
+            ys[u] = u < nk ? yr[mid[u]] : 0;
+            ln[u] = u < nk ? ye[mid[u]] - ys[u] : 0;
+        }
+        int cb[2][QC];
+        double vb[2][QC];
+#pragma unroll
+        for (int w = 0; w < QC; ++w) {
+            cb[0][w] = w < ln[0] ? yc[(long long)(ys[0] + w) * YCS] : 0;
+            vb[0][w] = w < ln[0] ? yv[ys[0] + w] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < KC; ++u) {
+            if (u + 1 < KC) {
+#pragma unroll
+                for (int w = 0; w < QC; ++w) {
+                    cb[(u + 1) & 1][w] = w < ln[u + 1] ? yc[(long long)(ys[u + 1] + w) * YCS] : 0;
+                    vb[(u + 1) & 1][w] = w < ln[u + 1] ? yv[ys[u + 1] + w] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < QC; ++w)
+                if (w < ln[u] && !overflow) insert(cb[u & 1][w], a[u] * vb[u & 1][w]);
+            for (int q = QC; q < ln[u] && !overflow; ++q)          // a Y row longer than the buffer: the rest one by one
+                insert(yc[(long long)(ys[u] + q) * YCS], a[u] * yv[ys[u] + q]);
+        }
+    }
+    if (overflow) {
+        row_len[i] = -1;                                   // redo in global memory
+        return;
+    }
+    long long *K = key + slot_ptr[i];
+    double *V = val + slot_ptr[i];
+    for (int u = 0; u < m; ++u) {
+        K[u] = (long long)Kc[u][t] << 32;
+        V[u] = Vc[u][t];
+    }
+    row_len[i] = m;
+}
+
 // Wave-per-row variant for rows with tens to hundreds of products (R * (A P) on every level, A * P below the
 // finest): the thread-per-row list kernels above serialise ~100 sorted insertions per thread, this one spreads a
 // row over the 64 lanes of a wave.
@@ -2129,8 +2219,15 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
                                X->vals, y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len, 0);
         } else if (avg <= 24.0 && getenv("PADNE_SPGEMM_WAVE_ALL") == nullptr) {
             // A*P on the fine levels: a dozen products per row -> one thread per row with small sorted lists in LDS
-            hipLaunchKernelGGL(spgemm_rows_lds<16>, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
-                               y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len);
+            if (getenv("PADNE_SPGEMM_NO_PIPE") != nullptr)
+                hipLaunchKernelGGL(spgemm_rows_lds<16>, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
+                                   y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len);
+            else if (y_cs == 1)
+                hipLaunchKernelGGL((spgemm_rows_lds_pipe<16, 9, 4, 1>), dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols,
+                                   X->vals, y_begin, y_cols, y_vals, y_end, slot_ptr, key, val, row_len);
+            else
+                hipLaunchKernelGGL((spgemm_rows_lds_pipe<16, 9, 4, 2>), dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols,
+                                   X->vals, y_begin, y_cols, y_vals, y_end, slot_ptr, key, val, row_len);
             hipLaunchKernelGGL(spgemm_rows_redo, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
                                y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len);
         } else if (avg <= 256.0) {

@@ -661,9 +661,15 @@ template <int CAPW, int CHUNK = 64>      // slots per wave in LDS (1024 for the 
                                           // this way); rows a wave examines per turn (few when most of them qualify)
 __global__ __launch_bounds__(256) void sort_long_rows_wave(long long n_list, const int *__restrict__ row_list,
                                                            const int *__restrict__ slot_ptr, long long *__restrict__ key,
-                                                           double *__restrict__ val, const int min_len, const int mesh) {
+                                                           double *__restrict__ val, const int min_len, const int mesh,
+                                                           int *__restrict__ longer_count = nullptr,
+                                                           const int *__restrict__ run_if_nonzero = nullptr,
+                                                           int *__restrict__ longer_list = nullptr) {
+    // longer_count / longer_list: the pass counts and lists the rows that exceed its capacity (left to the next pass);
+    // run_if_nonzero: a pass behind such a count returns at once when there is nothing for it to do
     __shared__ long long Ks[4][CAPW];
     __shared__ double Vs[4][CAPW];
+    if (run_if_nonzero != nullptr && *run_if_nonzero == 0) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long long n_waves = (long long)gridDim.x * 4;
     // a wave looks at 64 rows at a time (one lane each, coalesced reads of the offsets) and sorts the long ones it finds
@@ -677,6 +683,16 @@ __global__ __launch_bounds__(256) void sort_long_rows_wave(long long n_list, con
             n_l = slot_ptr[r_l + 1] - s0_l;
         }
         unsigned long long todo = __ballot(n_l >= min_len && n_l <= CAPW);
+        if (longer_count != nullptr) {
+            const unsigned long long longer = __ballot(n_l > CAPW);
+            if (longer != 0ull) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(longer_count, __popcll(longer));
+                base = __shfl(base, 0, 64);
+                if (longer_list != nullptr && n_l > CAPW)
+                    longer_list[base + __popcll(longer & ((1ull << lane) - 1ull))] = (int)r_l;
+            }
+        }
         while (todo != 0ull) {
             const int b = __ffsll((long long)todo) - 1;
             todo &= todo - 1ull;
@@ -702,6 +718,39 @@ __global__ __launch_bounds__(256) void sort_long_rows_wave(long long n_list, con
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // LDS is reused by the next row
             __builtin_amdgcn_wave_barrier();
         }
+    }
+}
+
+// The listed rows, one WORKGROUP each (rows of up to 1024 slots): keys and values into LDS, every thread ranks its elements
+// by counting smaller keys, sorted slots back in place -- the rank sort of sort_long_rows_wave over 256 threads.  The long
+// rows of a transposed prolongator (aggregates next to a via ring: several hundred fine rows interpolate from them) are a
+// few dozen; a wave that met them one after the other in its chunk took 1.2 ms, spread over workgroups they take 60 us.
+__global__ __launch_bounds__(256) void sort_listed_rows_block(const int *__restrict__ n_list, const int *__restrict__ row_list,
+                                                              const int *__restrict__ slot_ptr, long long *__restrict__ key,
+                                                              double *__restrict__ val) {
+    __shared__ long long Ks[kWaveSortCap];
+    __shared__ double Vs[kWaveSortCap];
+    const int cnt = *n_list;
+    for (int j = blockIdx.x; j < cnt; j += gridDim.x) {
+        const int r = row_list[j];
+        const int s0 = slot_ptr[r], n = slot_ptr[r + 1] - s0;
+        if (n > kWaveSortCap) continue;               // beyond the LDS: the one-lane merge sorts it
+        for (int e = threadIdx.x; e < n; e += 256) {
+            Ks[e] = key[s0 + e];
+            Vs[e] = val[s0 + e];
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < n; e += 256) {
+            const long long k = Ks[e];
+            int rank = 0;
+            for (int f = 0; f < n; ++f) {
+                const long long kf = Ks[f];
+                rank += (kf < k || (kf == k && f < e)) ? 1 : 0;
+            }
+            key[s0 + rank] = k;
+            val[s0 + rank] = Vs[e];
+        }
+        __syncthreads();
     }
 }
 
@@ -1277,10 +1326,18 @@ __global__ void unpack_slots_kernel(long long nnz, const long long *__restrict__
 // counting smaller keys in LDS, rows of up to 64 slots at full occupancy, longer ones with the 1024-slot variant, the
 // rare rest by the one-lane insertion sort.
 int sort_slots_exact(padne_ctx *ctx, long long n_rows, const int *slot_ptr, long long *key, double *val, int *row_len_scratch) {
+    // rows of up to 64 slots: eight rows per wave and turn, sorted in 2 KiB of LDS per wave; the rows beyond that are
+    // listed and sorted by a workgroup each (sort_listed_rows_block); what exceeds even its 1024 slots is left to the
+    // one-lane merge.  Nothing here needs the host.
+    Scratch sc(ctx);
+    int *long_list = nullptr;
+    PADNE_TRY(sc.alloc(&long_list, (size_t)n_rows + 1));
+    int *n_long = row_len_scratch + n_rows;          // the scratch has n_rows + 1 entries
+    PADNE_HIP_CHECK(hipMemsetAsync(n_long, 0, sizeof(int), ctx->stream));
     hipLaunchKernelGGL((sort_long_rows_wave<64, 8>), dim3(std::min(nblk(n_rows, 32), 8192u)), dim3(256), 0, ctx->stream, n_rows,
-                       (const int *)nullptr, slot_ptr, key, val, 2, 0);
-    hipLaunchKernelGGL(sort_long_rows_wave<kWaveSortCap>, dim3(std::min(nblk(n_rows, 256), 2048u)), dim3(256), 0, ctx->stream, n_rows,
-                       (const int *)nullptr, slot_ptr, key, val, 65, 0);
+                       (const int *)nullptr, slot_ptr, key, val, 2, 0, n_long, (const int *)nullptr, long_list);
+    hipLaunchKernelGGL(sort_listed_rows_block, dim3(1024), dim3(256), 0, ctx->stream, (const int *)n_long, (const int *)long_list,
+                       slot_ptr, key, val);
     hipLaunchKernelGGL(merge_rows<false>, dim3(nblk(n_rows, 128)), dim3(128), 0, ctx->stream, n_rows, 0LL, 0,
                        (const long long *)nullptr, (const double *)nullptr, slot_ptr, key, val, row_len_scratch,
                        (int *)nullptr, kWaveSortCap + 1);
