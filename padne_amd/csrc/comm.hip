@@ -215,10 +215,13 @@ int comm_allgather_f32(padne_ctx *ctx, const float *send, float *recv, int count
 // pack kernel, it travels while the main stream computes the interior tiles of the product it is for; the main stream
 // waits for it (comm_allgather_side_join) in front of the boundary tiles.  Collectives of one communicator never overlap
 // each other this way: the next one on the main stream is queued behind the join.  false: not available (no
-// communicator, the team, PADNE_NO_COMM_OVERLAP=1) -- the caller gathers on the main stream as before.
+// communicator, the team) or not asked for -- the caller gathers on the main stream as before.  OPT-IN
+// (PADNE_COMM_OVERLAP=1): collectives of one communicator on two streams have only been run with a one-rank communicator
+// here -- no box of this round had a second GPU -- and the default of a path the multi-GPU bench takes must be what has
+// run on several GPUs.
 bool comm_allgather_side(padne_ctx *ctx, const void *send, void *recv, int count_per_rank, bool f64, int *rc) {
     *rc = PADNE_OK;
-    if (ctx->comm == nullptr || ctx->team != nullptr || ctx->is_aux || getenv("PADNE_NO_COMM_OVERLAP") != nullptr) return false;
+    if (ctx->comm == nullptr || ctx->team != nullptr || ctx->is_aux || getenv("PADNE_COMM_OVERLAP") == nullptr) return false;
     padne_ctx *aux = aux_context(ctx);
     if (aux == nullptr) return false;
     if ((*rc = stream_order(ctx, aux)) != PADNE_OK) return true;               // behind the pack kernel

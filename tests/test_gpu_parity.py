@@ -912,10 +912,14 @@ def test_coaxial_structure_end_to_end(ctx):
 
 # ---- multi-GPU code path on one GPU ---------------------------------------------------------------
 
-def test_halo_and_rccl_path_with_one_rank_communicator():
+@pytest.mark.parametrize("side_stream", [False, True])
+def test_halo_and_rccl_path_with_one_rank_communicator(monkeypatch, side_stream):
     """Exercises pack -> ncclAllGather -> SpMV on exchange columns -> fold -> ncclAllReduce with a
     1-rank RCCL communicator: off-diagonal couplings to a subset of unknowns are re-routed through
-    the exchange area, which must not change the solution."""
+    the exchange area, which must not change the solution.  ``side_stream``: the all-gather queued on the context's second
+    stream between two events (PADNE_COMM_OVERLAP=1), beside whatever the main stream computes in between."""
+    if side_stream:
+        monkeypatch.setenv("PADNE_COMM_OVERLAP", "1")
     xy, tri = synthetic.jittered_grid(70, 50, seed=6)
     A = (-2082.5 * O.laplace_operator(xy, tri).tocsr()[1:, 1:]).tocsr()
     n = A.shape[0]
