@@ -253,6 +253,15 @@ bool comm_p2p_enabled(const padne_ctx *ctx) {
     return ctx->team != nullptr && getenv("PADNE_NO_P2P") == nullptr;
 }
 
+// does a halo exchange of this context run beside what is queued between its two halves?  (peer-to-peer stores: the
+// arrival is all that is left for the second half; a communicator: only with the all-gather on the second stream.)  Where
+// it does not, splitting a product into interior and boundary tiles buys nothing and costs a launch: the split plans are
+// built only where this holds
+bool comm_exchange_overlaps(const padne_ctx *ctx) {
+    if (comm_p2p_enabled(ctx)) return true;
+    return ctx->comm != nullptr && ctx->team == nullptr && getenv("PADNE_COMM_OVERLAP") != nullptr;
+}
+
 void comm_p2p_release(padne_ctx *ctx) {
     if (ctx->p2p_mbox != nullptr) (void)hipFree(ctx->p2p_mbox);
     if (ctx->p2p_peers != nullptr) (void)hipFree(ctx->p2p_peers);

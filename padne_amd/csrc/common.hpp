@@ -249,6 +249,7 @@ void comm_abort(padne_ctx *ctx);   // a rank that leaves a collective phase with
 // the byte offset of this exchange's entry.  comm_p2p_arrive: all ranks' stores of the current exchange are visible.
 constexpr int kP2pRing = 4;
 bool comm_p2p_enabled(const padne_ctx *ctx);
+bool comm_exchange_overlaps(const padne_ctx *ctx);
 int comm_p2p_begin(padne_ctx *ctx, int m, void ***peers_dev, size_t *entry_offset);
 int comm_p2p_arrive(padne_ctx *ctx);
 void comm_p2p_release(padne_ctx *ctx);

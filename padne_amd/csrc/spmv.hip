@@ -803,7 +803,9 @@ __global__ void split_scatter_kernel(int n_wtiles, const int *__restrict__ flag,
 int csr_build_split_plan(padne_ctx *ctx, padne_csr *m, long long n_owned) {
     if (m->split_state != 0) return PADNE_OK;
     m->split_state = -1;
-    if (m->n_cols <= n_owned || m->n_rows < 64 * 64 || getenv("PADNE_NO_SPLIT") != nullptr) return PADNE_OK;
+    // (only where the exchange really runs beside the interior tiles: otherwise the second launch is pure overhead)
+    if (m->n_cols <= n_owned || m->n_rows < 64 * 64 || getenv("PADNE_NO_SPLIT") != nullptr || !comm_exchange_overlaps(ctx))
+        return PADNE_OK;
     padne_ctx *owner = m->owner ? m->owner : ctx;
     const int n_tiles = (int)((m->n_rows + 63) / 64);
     int *tiles = (int *)pool_alloc(owner, sizeof(int) * (size_t)n_tiles);

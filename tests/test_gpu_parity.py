@@ -1574,8 +1574,11 @@ def test_layer_partitioned_solver_with_several_ranks_on_one_gpu(world, precond):
 def test_peer_to_peer_halo_stores_are_the_all_gather_bit_for_bit(monkeypatch):
     """The same solve with the halo exchanged by peer stores (default with the in-process team) and by all-gathers
     (PADNE_NO_P2P=1): the values that arrive are the same, so iterations and potentials are bit-identical; only the kind of
-    communication differs (calls[3] against calls[1] / calls[2] of padne_comm_call_counts)."""
+    communication differs (calls[3] against calls[1] / calls[2] of padne_comm_call_counts).  (Both runs with one launch per
+    product: the interior / boundary split, which regroups the dot-product partials, is only built where the exchange
+    overlaps the interior tiles, i.e. not for the all-gather form.)"""
     sysm = synthetic.layered_system(8, 90, 70, via_lattice=5)
+    monkeypatch.setenv("PADNE_NO_SPLIT", "1")
     v_p2p, it_p2p, res_p2p = run_team(sysm, 4, "amg")
     monkeypatch.setenv("PADNE_NO_P2P", "1")
     v_ag, it_ag, res_ag = run_team(sysm, 4, "amg")
@@ -1584,6 +1587,7 @@ def test_peer_to_peer_halo_stores_are_the_all_gather_bit_for_bit(monkeypatch):
     # every exchange that was an all-gather is a peer-to-peer exchange now
     moved = (res_ag.collectives[1] + res_ag.collectives[2]) - (res_p2p.collectives[1] + res_p2p.collectives[2])
     assert moved == res_p2p.collectives[3], (res_ag.collectives, res_p2p.collectives)
+    assert res_ag.split_tiles[0] == (0, 0)                # no overlap, no split
 
 
 def test_products_split_into_interior_and_boundary_tiles_around_the_exchange(monkeypatch):
