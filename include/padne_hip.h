@@ -228,11 +228,17 @@ int padne_solve_spd_dev(padne_ctx *ctx, const padne_csr *a, const void *b_dev, v
  *                         groups other than the group's representative;
  *   tied_member / tied_rep[n_tied]  those members (ascending) and the representative they are numbered through;
  *   index_map_host        optional int32[N] (NULL: built on the device as  i - #{e in elim : e < i}): a map the caller
- *                         made itself, e.g. after a locality reordering; n_free = number of reduced unknowns.
+ *                         made itself; n_free = number of reduced unknowns.
+ *   flags                 bit 0: number the reduced unknowns by horizontal strips of the meshes `L` was assembled from
+ *                         (mesh, strip of about three vertex spacings, x; unknowns that are no vertex behind them) -- the
+ *                         band numbering the SpMV's x windows need when the mesher numbered the vertices in insertion
+ *                         order (CGAL).  Internal to the plan: r and v keep the caller's numbering.  Needs a matrix from
+ *                         padne_assemble_system (it carries its mesh); PADNE_E_INVALID if the keys do not fit
+ *                         (>= 65535 meshes, > 65535 strips in a mesh): the caller may then pass its own map.
  * `L` is borrowed and must outlive the plan. */
 int padne_kkt_create(padne_ctx *ctx, const padne_csr *L, int64_t n_potential, int64_t n_elim,
                      const int64_t *elim_sorted, int64_t n_tied, const int64_t *tied_member, const int64_t *tied_rep,
-                     const int32_t *index_map_host, int64_t n_free, padne_kkt **out);
+                     const int32_t *index_map_host, int64_t n_free, int32_t flags, padne_kkt **out);
 int padne_kkt_destroy(padne_kkt *plan);
 /* borrowed handle of the reduced SPD matrix (for introspection; do not destroy) */
 int padne_kkt_matrix(const padne_kkt *plan, const padne_csr **reduced_out);

@@ -92,7 +92,7 @@ SIGNATURES = {
     "padne_residual_norm": (C.c_int, [_P, _P, _PF64, _PF64, _PF64]),
     "padne_solve_spd": (C.c_int, [_P, _P, _PF64, _PF64, C.c_int32, C.POINTER(SolveOpts), C.POINTER(SolveInfo)]),
     "padne_solve_spd_dev": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(SolveOpts), C.POINTER(SolveInfo)]),
-    "padne_kkt_create": (C.c_int, [_P, _P, _I64, _I64, _PI64, _I64, _PI64, _PI64, _PI32, _I64, C.POINTER(_P)]),
+    "padne_kkt_create": (C.c_int, [_P, _P, _I64, _I64, _PI64, _I64, _PI64, _PI64, _PI32, _I64, C.c_int32, C.POINTER(_P)]),
     "padne_kkt_destroy": (C.c_int, [_P]),
     "padne_kkt_matrix": (C.c_int, [_P, C.POINTER(_P)]),
     "padne_kkt_solve": (C.c_int, [_P, _P, _PF64, _I64, _PI64, _PF64, C.c_int32, _PI64, _PI64, _PF64, _I64, _PI64, _PF64,
@@ -474,7 +474,7 @@ class KktPlan:
     reduced matrix with its multigrid hierarchy, the N-vectors).  ``solve`` + ``finish`` are the two device stages of
     ``solver.solve_system``; the multiplier recovery between them is O(#constraints) host work."""
 
-    def __init__(self, L: "CsrMatrix", n_potential: int, elim, tied, n_free: int, index_map=None):
+    def __init__(self, L: "CsrMatrix", n_potential: int, elim, tied, n_free: int, index_map=None, strip_order: bool = False):
         self.ctx, self.L = L.ctx, L
         elim = _i64(elim)
         tm = _i64([m for m, _ in tied])
@@ -485,7 +485,7 @@ class KktPlan:
         h = _P()
         _check(self.ctx._lib.padne_kkt_create(self.ctx._h, L._h, int(n_potential), elim.shape[0], _ptr(elim, _PI64), tm.shape[0],
                                               _ptr(tm, _PI64), _ptr(tr, _PI64), None if imap is None else _ptr(imap, _PI32),
-                                              int(n_free), C.byref(h)))
+                                              int(n_free), 1 if strip_order else 0, C.byref(h)))
         self._h = h
         self.n_free = int(n_free)
         self.N = L.shape[0]

@@ -7,6 +7,9 @@
 // built), v once.
 #include "common.hpp"
 
+#include <string.h>
+#include <rocprim/device/device_radix_sort.hpp>      // the one stable key-value sort of the locality ordering (section "ordering")
+
 #include <algorithm>
 #include <math.h>
 #include <string.h>
@@ -192,6 +195,183 @@ __global__ __launch_bounds__(256) void kkt_diff2(const long long n, const double
     if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// ---- locality ordering of the reduced unknowns ("Ordering") ----------------------------------------
+// CGAL numbers vertices in insertion order; the reduced system is solved in a band numbering by horizontal strips: the mesh
+// unknowns sorted by (mesh, strip of about three vertex spacings, x), the others behind them in their old order.  The host
+// form (reduction.apply_locality_ordering: numpy sorts over N-element arrays) was 0.09 s of a 0.14 s solve_system call on a
+// 2 M-vertex mesh; here the keys are formed and sorted on the device from the mesh the system was assembled from.  Per-mesh
+// constants (bounding box of the owners, strip height) come from a small reduction and the host's own formula, so that
+// the keys -- and with a stable sort the permutation -- are the host's bit for bit (tested).
+// stats[m] = {x min, x max, y min, y max, count} over the mesh vertices that represent a reduced unknown
+__global__ __launch_bounds__(256) void kkt_mesh_stats(const long long *__restrict__ voff, const double *__restrict__ xy,
+                                                      const int32_t *__restrict__ imap, const int32_t *__restrict__ src_of,
+                                                      double *__restrict__ stats) {
+    __shared__ double red[5][4];
+    const int m = blockIdx.x;
+    double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300, cnt = 0.0;
+    for (long long v = voff[m] + threadIdx.x; v < voff[m + 1]; v += 256) {
+        const int32_t t = imap[v];
+        if (t < 0 || src_of[t] != (int32_t)v) continue;
+        const double x = xy[2 * v], y = xy[2 * v + 1];
+        xmin = fmin(xmin, x);
+        xmax = fmax(xmax, x);
+        ymin = fmin(ymin, y);
+        ymax = fmax(ymax, y);
+        cnt += 1.0;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        xmin = fmin(xmin, __shfl_down(xmin, off, 64));
+        xmax = fmax(xmax, __shfl_down(xmax, off, 64));
+        ymin = fmin(ymin, __shfl_down(ymin, off, 64));
+        ymax = fmax(ymax, __shfl_down(ymax, off, 64));
+        cnt += __shfl_down(cnt, off, 64);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[0][w] = xmin; red[1][w] = xmax; red[2][w] = ymin; red[3][w] = ymax; red[4][w] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        stats[5 * m + 0] = fmin(fmin(red[0][0], red[0][1]), fmin(red[0][2], red[0][3]));
+        stats[5 * m + 1] = fmax(fmax(red[1][0], red[1][1]), fmax(red[1][2], red[1][3]));
+        stats[5 * m + 2] = fmin(fmin(red[2][0], red[2][1]), fmin(red[2][2], red[2][3]));
+        stats[5 * m + 3] = fmax(fmax(red[3][0], red[3][1]), fmax(red[3][2], red[3][3]));
+        stats[5 * m + 4] = (red[4][0] + red[4][1]) + (red[4][2] + red[4][3]);
+    }
+}
+
+// key[t] = mesh << 48 | strip << 32 | x quantised to 32 bits inside the mesh; unknowns that are no mesh vertex: 0xFFFF << 48 | t.
+// par[m] = {x lo, x span, y0, strip height} as the host computes them (reduction._strip_order / strip_index)
+__global__ __launch_bounds__(256) void kkt_strip_keys(const long long n_free, const long long n_vert, const int n_mesh,
+                                                      const long long *__restrict__ voff, const double *__restrict__ xy,
+                                                      const int32_t *__restrict__ src_of, const double *__restrict__ par,
+                                                      unsigned long long *__restrict__ key, int *__restrict__ val, int *__restrict__ bad) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_free) return;
+    val[t] = (int)t;
+    const long long v = src_of[t];
+    if (v >= n_vert) {
+        key[t] = (0xFFFFull << 48) | (unsigned long long)t;
+        return;
+    }
+    int lo = 0, hi = n_mesh;                       // mesh of v: largest m with voff[m] <= v
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (voff[mid] <= v) lo = mid; else hi = mid;
+    }
+    const int m = lo;
+    const double x = xy[2 * v], y = xy[2 * v + 1];
+    const double x_lo = par[4 * m], span = par[4 * m + 1], y0 = par[4 * m + 2], height = par[4 * m + 3];
+    long long strip = 0;
+    if (height > 0.0) strip = (long long)floor((y - y0) / height);
+    if (strip < 0 || strip >= 0x10000) {
+        atomicExch(bad, 1);
+        strip = 0;
+    }
+    double q = (x - x_lo) / span * 4294967295.0;
+    if (q > 4294967295.0) q = 4294967295.0;
+    const unsigned long long xq = (unsigned long long)q;
+    key[t] = ((unsigned long long)m << 48) | ((unsigned long long)strip << 32) | xq;
+}
+
+__global__ void kkt_invert_perm(const long long n, const int *__restrict__ order, int32_t *__restrict__ new_of_old) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) new_of_old[order[k]] = (int32_t)k;
+}
+
+__global__ void kkt_relabel_map(const long long N, const int32_t *__restrict__ new_of_old, int32_t *__restrict__ imap) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int32_t t = imap[i];
+    if (t >= 0) imap[i] = new_of_old[t];
+}
+
+__global__ void kkt_permute_i32(const long long n, const int *__restrict__ order, const int32_t *__restrict__ src, int32_t *__restrict__ dst) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) dst[k] = src[order[k]];
+}
+
+__global__ void kkt_relabel_list(const int n, const int32_t *__restrict__ new_of_old, int32_t *__restrict__ list) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) list[k] = new_of_old[list[k]];
+}
+
+// relabels k->imap / src_of / tied_target in place; PADNE_E_INVALID (nothing changed) when the keys do not fit their fields
+static int kkt_apply_strip_order(padne_kkt *k) {
+    padne_ctx *ctx = k->ctx;
+    const padne_csr *L = k->L;
+    hipStream_t s = ctx->stream;
+    const long long nf = k->n_free, nv = L->mesh_n_vert;
+    const int n_mesh = (int)L->mesh_n_mesh;
+    if (nf == 0) return PADNE_OK;
+    PADNE_REQUIRE(n_mesh > 0 && L->mesh_xy != nullptr && L->mesh_voff != nullptr, "the system matrix carries no mesh to order by");
+    PADNE_REQUIRE(n_mesh < 0xFFFF && nf < 2147483647LL && nv <= k->n_pot, "mesh count / size beyond the key fields");
+    Scratch sc(ctx);
+    double *d_stats = nullptr, *d_par = nullptr;
+    unsigned long long *key_a = nullptr, *key_b = nullptr;
+    int *val_a = nullptr, *val_b = nullptr, *d_bad = nullptr;
+    int32_t *new_of_old = nullptr, *src_new = nullptr;
+    PADNE_TRY(sc.alloc(&d_stats, (size_t)5 * n_mesh));
+    PADNE_TRY(sc.alloc(&d_par, (size_t)4 * n_mesh));
+    PADNE_TRY(sc.alloc(&key_a, (size_t)nf));
+    PADNE_TRY(sc.alloc(&key_b, (size_t)nf));
+    PADNE_TRY(sc.alloc(&val_a, (size_t)nf));
+    PADNE_TRY(sc.alloc(&val_b, (size_t)nf));
+    PADNE_TRY(sc.alloc(&d_bad, 1));
+    PADNE_TRY(sc.alloc(&new_of_old, (size_t)nf));
+    PADNE_TRY(sc.alloc(&src_new, (size_t)nf));
+    hipLaunchKernelGGL(kkt_mesh_stats, dim3(n_mesh), dim3(256), 0, s, L->mesh_voff, L->mesh_xy, k->imap, k->src_of, d_stats);
+    PADNE_HIP_CHECK(hipGetLastError());
+    std::vector<double> st((size_t)5 * n_mesh), par((size_t)4 * n_mesh);
+    PADNE_HIP_CHECK(hipMemcpyAsync(st.data(), d_stats, sizeof(double) * st.size(), hipMemcpyDeviceToHost, s));
+    PADNE_HIP_CHECK(hipStreamSynchronize(s));
+    for (int m = 0; m < n_mesh; ++m) {
+        const double xmin = st[5 * m], xmax = st[5 * m + 1], ymin = st[5 * m + 2], ymax = st[5 * m + 3], cnt = st[5 * m + 4];
+        double x_lo = 0.0, span = 1.0, y0 = 0.0, height = 0.0;
+        if (cnt >= 1.0) {
+            x_lo = xmin;
+            span = std::max(xmax - xmin, 1e-300);                               // reduction._strip_order
+            y0 = ymin;
+            if (cnt >= 2.0) {                                                   // reduction.strip_index (a single point: strip 0)
+                const double area = std::max((xmax - xmin) * (ymax - y0), 1e-300);
+                height = 3.4 * sqrt(area / cnt);
+            }
+        }
+        par[4 * m] = x_lo;
+        par[4 * m + 1] = span;
+        par[4 * m + 2] = y0;
+        par[4 * m + 3] = height;
+    }
+    PADNE_HIP_CHECK(hipMemcpyAsync(d_par, par.data(), sizeof(double) * par.size(), hipMemcpyHostToDevice, s));
+    PADNE_HIP_CHECK(hipMemsetAsync(d_bad, 0, sizeof(int), s));
+    hipLaunchKernelGGL(kkt_strip_keys, dim3(nblk(nf)), dim3(256), 0, s, nf, nv, n_mesh, L->mesh_voff, L->mesh_xy, k->src_of, d_par,
+                       key_a, val_a, d_bad);
+    PADNE_HIP_CHECK(hipGetLastError());
+    int h_bad = 0;
+    PADNE_HIP_CHECK(hipMemcpyAsync(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, s));
+    PADNE_HIP_CHECK(hipStreamSynchronize(s));              // (also: par's host buffer may go)
+    if (h_bad) {
+        set_error("strip index beyond 16 bits: the host orders this system");
+        return PADNE_E_INVALID;
+    }
+    // stable sort of (key, old index): equal keys keep their index order, as the host's tie repair leaves them
+    size_t tmp_bytes = 0;
+    PADNE_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key_a, key_b, val_a, val_b, (size_t)nf, 0, 64, s));
+    void *tmp = nullptr;
+    PADNE_TRY(sc.alloc((char **)&tmp, tmp_bytes));
+    PADNE_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, key_a, key_b, val_a, val_b, (size_t)nf, 0, 64, s));
+    const int *order = val_b;                              // new position -> old reduced index
+    hipLaunchKernelGGL(kkt_invert_perm, dim3(nblk(nf)), dim3(256), 0, s, nf, order, new_of_old);
+    hipLaunchKernelGGL(kkt_relabel_map, dim3(nblk(k->N)), dim3(256), 0, s, k->N, (const int32_t *)new_of_old, k->imap);
+    hipLaunchKernelGGL(kkt_permute_i32, dim3(nblk(nf)), dim3(256), 0, s, nf, order, (const int32_t *)k->src_of, src_new);
+    if (k->n_tied > 0)
+        hipLaunchKernelGGL(kkt_relabel_list, dim3(nblk(k->n_tied)), dim3(256), 0, s, (int)k->n_tied, (const int32_t *)new_of_old,
+                           k->tied_target);
+    PADNE_HIP_CHECK(hipGetLastError());
+    PADNE_HIP_CHECK(hipMemcpyAsync(k->src_of, src_new, sizeof(int32_t) * (size_t)nf, hipMemcpyDeviceToDevice, s));
+    return PADNE_OK;
+}
+
 static int vgrid(long long n) {
     long long g = (n + 255) / 256;
     if (g > 1024) g = 1024;
@@ -254,7 +434,8 @@ using namespace padne;
 
 extern "C" int padne_kkt_create(padne_ctx *ctx, const padne_csr *L, int64_t n_potential, int64_t n_elim,
                                 const int64_t *elim_sorted, int64_t n_tied, const int64_t *tied_member,
-                                const int64_t *tied_rep, const int32_t *index_map_host, int64_t n_free, padne_kkt **out) {
+                                const int64_t *tied_rep, const int32_t *index_map_host, int64_t n_free, int32_t flags,
+                                padne_kkt **out) {
     PADNE_REQUIRE(ctx && L && out, "null argument");
     PADNE_REQUIRE(L->n_rows == L->n_cols, "the system matrix must be square");
     const long long N = L->n_rows;
@@ -345,6 +526,10 @@ extern "C" int padne_kkt_create(padne_ctx *ctx, const padne_csr *L, int64_t n_po
     if (e != hipSuccess) {
         set_error("building the index map failed: %s", hipGetErrorString(e));
         return fail(PADNE_E_HIP);
+    }
+    if ((flags & 1) != 0 && index_map_host == nullptr) {
+        // the reduced unknowns in the strip numbering (mesh, strip, x) of the mesh the system was assembled from
+        if ((rc = kkt_apply_strip_order(k)) != PADNE_OK) return fail(rc);
     }
     // A = -P^T L P from the device-resident map (csr_relabel takes host or device maps)
     if ((rc = csr_relabel(ctx, L, k->imap, n_free, k->imap, n_free, -1.0, &k->A)) != PADNE_OK) return fail(rc);

@@ -1465,6 +1465,58 @@ def test_locality_reordering_is_transparent(ctx):
     L.dev.close()
 
 
+def test_strip_numbering_on_the_device_is_the_hosts_permutation(ctx):
+    """The locality ordering of the reduced unknowns (mesh, strip, x) is made on the device from the mesh the system was
+    assembled from (``padne_kkt_create``, flags bit 0: per-mesh bounding boxes of the owners, 64-bit keys, one stable
+    key-value sort).  It must be the permutation of ``reduction.apply_locality_ordering`` (numpy sorts over N-element
+    arrays: 0.09 s of a 0.14 s ``solve_system`` call at 2 M vertices): the reduced matrices of the two plans are compared
+    bit for bit -- two shuffled Delaunay meshes of different size, a voltage source that ties a vertex of one to a vertex
+    of the other, an internal node, the ground."""
+    from padne_amd import reduction as red_mod
+    rng = np.random.default_rng(12)
+    m1 = delaunay_mesh(9000, seed=5, hole=True)
+    m2 = delaunay_mesh(5000, seed=6, hole=False)
+    meshes = [mesh.Mesh(*m1), mesh.Mesh(m2[0] * 0.7 + 3.0, m2[1])]
+    n1, n2 = len(meshes[0].points), len(meshes[1].points)
+    nv = n1 + n2
+    n_pot = nv + 1                                                    # one internal node
+    N = n_pot + 2                                                     # a source current, the ground row
+    stamps = solver.StampList(N)
+    r = np.zeros(N)
+    hub = nv
+    for a in (17, n1 + 40, n1 + 333):                                 # the internal node hangs on three resistors
+        g = 1 / 0.25
+        stamps.add(a, a, -g); stamps.add(a, hub, g); stamps.add(hub, hub, -g); stamps.add(hub, a, g)
+    iv = n_pot
+    p_, n_ = 4321, n1 + 1234                                          # voltage source across the two meshes
+    stamps.add(iv, p_, 1.0); stamps.add(iv, n_, -1.0); stamps.add(p_, iv, 1.0); stamps.add(n_, iv, -1.0)
+    r[iv] = 0.5
+    stamps.constraints.append(red_mod.Constraint(index=iv, p=p_, n=n_, value=0.5))
+    r[100] += 1.0
+    r[n1 + 7] -= 1.0
+    solver.setup_ground_node(3, stamps, r)
+    L = solver.assemble_from_arrays(meshes, [2082.5, 1041.25], stamps, n_pot)
+    red = red_mod.build_reduction(L.layout)
+    on_device = _hip.KktPlan(L.dev, n_pot, red.elim, red.tied, red.n_free, strip_order=True)
+    red_mod.apply_locality_ordering(red, L.xy, L.mesh_offsets)
+    on_host = _hip.KktPlan(L.dev, n_pot, red.elim, red.tied, red.n_free, index_map=red.index_map)
+    A_dev, A_host = on_device.reduced_matrix().to_scipy(), on_host.reduced_matrix().to_scipy()
+    assert A_dev.shape == A_host.shape == (red.n_free, red.n_free)
+    assert np.array_equal(A_dev.indptr, A_host.indptr) and np.array_equal(A_dev.indices, A_host.indices)
+    assert np.array_equal(A_dev.data, A_host.data)
+    # and it is a band numbering: the x-window plan of the SpMV engages on it, which it does not in the mesher's numbering
+    plain = _hip.KktPlan(L.dev, n_pot, red.elim, red.tied, red.n_free)
+    bw = lambda A: float(np.mean(np.abs(A.tocoo().row - A.tocoo().col)))
+    assert bw(A_dev) < 0.05 * bw(plain.reduced_matrix().to_scipy())
+    v, info = solver.solve_system(L, r)                               # the whole call, through the device ordering
+    v_ref = O.solve_system(L.tocsr(), r)[0]
+    # (the 0.5 V source across two 2 kS sheets drives kiloamperes: 1e-9 absolute is the rounding floor of this system)
+    assert np.abs(v - v_ref).max() <= REL_TOL * np.abs(v_ref).max() and info.rel_residual < 2e-12 and info.residual_norm < 1e-8
+    for pl in (on_device, on_host, plain):
+        pl.close()
+    L.close()
+
+
 def test_multigrid_with_hubs_and_strong_lumped_couplings(ctx):
     """Star hubs (hundreds of 1 mOhm resistors into one internal node, kicad.py:535-556) and very stiff
     layer-to-layer links next to the sheet Laplacian: rows of very different length and weight."""
