@@ -322,6 +322,29 @@ __global__ __launch_bounds__(256) void nbr_max(int n, int n_wtiles, const int *_
     }
 }
 
+// Wave-per-row form for the small levels with long rows (level 3 of config C4: 14 k rows of 50-100 entries).  The tile
+// kernel above gives a wave 64 rows, i.e. eight passes of 512 entries one after the other, and all of a 14 k-row level is
+// 224 waves: 23 us per pass, forty passes per aggregation.  Here the lanes stride over one row and fold with shuffles.
+template <typename T>
+__global__ __launch_bounds__(256) void nbr_max_wpr(int n, const int *__restrict__ srow, const int *__restrict__ scol,
+                                                   const T *__restrict__ in, T *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const int rs = srow[r], re = srow[r + 1];
+    T m = in[r];
+    for (int k = rs + lane; k < re; k += 64) {
+        const T v = in[scol[k]];
+        m = v > m ? v : m;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const T o = __shfl_down(m, off, 64);
+        m = o > m ? o : m;
+    }
+    if (lane == 0) out[r] = m;
+}
+
 __device__ __forceinline__ bool mis_decide_one(int i, unsigned int top, unsigned int *__restrict__ word,
                                                signed char *__restrict__ state) {
     // returns true if vertex i is still undecided after this round
@@ -1286,13 +1309,19 @@ __global__ __launch_bounds__(256) void spgemm_rows_dense(int n_cols, const int *
                                                          const int *__restrict__ yc, const double *__restrict__ yv, const int *__restrict__ ye, const int ycs,
                                                          const int *__restrict__ slot_ptr, long long *__restrict__ key,
                                                          double *__restrict__ val, int *__restrict__ row_len,
-                                                         const int only_pending) {
+                                                         const int only_pending, const int *__restrict__ row_list = nullptr,
+                                                         const int *__restrict__ list_count = nullptr) {
+    // row_list / list_count: behind the wave kernels the workgroups walk the list of the rows those left (collected by
+    // collect_pending_rows) -- one workgroup per row of the level just to find that its row was done cost 150 us on 140 k rows
     extern __shared__ double acc_and_flag[];               // n_cols doubles + n_cols bytes
     double *acc = acc_and_flag;
     unsigned char *hit = (unsigned char *)(acc + n_cols);
     __shared__ int wave_cnt[4];
-    const int i = blockIdx.x;
-    if (only_pending && row_len[i] >= 0) return;           // behind the wave kernels: the rows they left (-1)
+    const int n_turns = row_list != nullptr ? *list_count : 1;
+    for (int turn = row_list != nullptr ? (int)blockIdx.x : 0; turn < n_turns; turn += row_list != nullptr ? (int)gridDim.x : 1) {
+    const int i = row_list != nullptr ? row_list[turn] : (int)blockIdx.x;
+    if (only_pending && row_len[i] >= 0) continue;         // behind the wave kernels: the rows they left (-1)
+    __syncthreads();                                       // (the previous turn's compaction has read acc / hit)
     for (int c = threadIdx.x; c < n_cols; c += 256) {
         acc[c] = 0.0;
         hit[c] = 0;
@@ -1331,6 +1360,7 @@ __global__ __launch_bounds__(256) void spgemm_rows_dense(int n_cols, const int *
         __syncthreads();
     }
     if (threadIdx.x == 0) row_len[i] = base;
+    }
 }
 
 // rows an earlier pass left (-1), as a list: the passes behind it walk the list instead of all rows
@@ -1704,13 +1734,21 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
                        xw ? A->xw_desc : (const int4 *)nullptr, xw ? (const unsigned char *)A->xw_lidx : (const unsigned char *)nullptr,
                        xw ? A->xw_run : 0, spos);
     PADNE_HIP_CHECK(hipGetLastError());
-    // one round = one-hop maxima, two-hop maxima, decision; on a windowed matrix the decision rides on the second pass
+    // one round = one-hop maxima, two-hop maxima, decision; on a windowed matrix the decision rides on the second pass;
+    // small levels with long rows (a few thousand rows of dozens of entries) take a wave per row
+    const bool long_rows = !xw && n <= 65536 && A->nnz >= 24LL * n && getenv("PADNE_AMG_NO_WPR") == nullptr;
     auto launch_round = [&](int *open_counter) {
         if (xw) {
             hipLaunchKernelGGL((nbr_max_xw<unsigned int, false>), gm, b, 0, s, n, n_wt, srow, scol, spos, A->xw_desc, A->xw_run,
                                (const unsigned int *)w0, w1, (unsigned int *)nullptr, (signed char *)nullptr, (int *)nullptr);
             hipLaunchKernelGGL((nbr_max_xw<unsigned int, true>), gm, b, 0, s, n, n_wt, srow, scol, spos, A->xw_desc, A->xw_run,
                                (const unsigned int *)w1, (unsigned int *)nullptr, w0, state, open_counter);
+        } else if (long_rows) {
+            hipLaunchKernelGGL(nbr_max_wpr<unsigned int>, dim3((unsigned)((n + 3) / 4)), b, 0, s, n, srow, (const int *)scol,
+                               (const unsigned int *)w0, w1);
+            hipLaunchKernelGGL(nbr_max_wpr<unsigned int>, dim3((unsigned)((n + 3) / 4)), b, 0, s, n, srow, (const int *)scol,
+                               (const unsigned int *)w1, w2);
+            hipLaunchKernelGGL(mis_decide, dim3(std::min<unsigned>(g.x, 1024u)), b, 0, s, n, w0, w2, state, open_counter);
         } else {
             hipLaunchKernelGGL(nbr_max<unsigned int>, gm, b, 0, s, n, n_wt, srow, scol, w0, w1);
             hipLaunchKernelGGL(nbr_max<unsigned int>, gm, b, 0, s, n, n_wt, srow, scol, w1, w2);
@@ -2264,8 +2302,9 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
                 // rows beyond the wave kernels' limits over a small column space: the dense accumulator, a workgroup each
                 (void)hipFuncSetAttribute((const void *)spgemm_rows_dense, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)dense_lds);
-                hipLaunchKernelGGL(spgemm_rows_dense, dim3(n), dim3(256), dense_lds, s, (int)Y->n_cols, X->rowptr, X->cols,
-                                   X->vals, y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len, 1);
+                hipLaunchKernelGGL(spgemm_rows_dense, dim3(std::min(n, 1024)), dim3(256), dense_lds, s, (int)Y->n_cols, X->rowptr, X->cols,
+                                   X->vals, y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len, 1, (const int *)pend,
+                                   (const int *)pend_count);
             }
             hipLaunchKernelGGL(spgemm_rows_redo, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
                                y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len);

@@ -979,18 +979,25 @@ __global__ __launch_bounds__(128) void merge_rows_lds(long long n_rows, const in
 // Rows already compacted at their slot offsets -> final CSR arrays.  A wave moves 64 consecutive rows: both the
 // source span [slot_ptr[r0], slot_ptr[r0+64]) and the destination span [rowptr[r0], rowptr[r0+64]) are
 // contiguous, lanes walk the destination (coalesced stores) and find their row by bisection in LDS.
+static int compact_rows_per_wave(long long n_rows, long long nnz) {
+    if (n_rows <= 0 || n_rows > 100000 || nnz <= 16 * n_rows) return 64;     // big levels: bandwidth-bound, 64 rows per wave
+    return nnz <= 128 * n_rows ? 8 : 1;
+}
+
 __global__ __launch_bounds__(256) void compact_rows(long long n_rows, const int *__restrict__ slot_ptr,
                                                     const int *__restrict__ rowptr, const long long *__restrict__ key,
                                                     const double *__restrict__ val, int *__restrict__ cols,
-                                                    double *__restrict__ vals) {
+                                                    double *__restrict__ vals, const int rpw) {
+    // rpw: rows per wave and turn (64 for mesh-like rows; 8 or 1 for the long rows of the small coarse operators, where 64
+    // rows of hundreds of entries kept a wave busy for 80 us while most of the chip had nothing to do)
     __shared__ int rp_all[4][65];
     __shared__ int sp_all[4][65];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int *rp = rp_all[w], *sp = sp_all[w];
-    const long long n_wt = (n_rows + 63) / 64;
+    const long long n_wt = (n_rows + rpw - 1) / rpw;
     for (long long wt = (long long)blockIdx.x * 4 + w; wt < n_wt; wt += (long long)gridDim.x * 4) {
-        const long long r0 = wt * 64;
-        const int nr = (int)((n_rows - r0) < 64 ? (n_rows - r0) : 64);
+        const long long r0 = wt * rpw;
+        const int nr = (int)((n_rows - r0) < rpw ? (n_rows - r0) : rpw);
         if (lane <= nr) rp[lane] = rowptr[r0 + lane];
         if (lane < nr) sp[lane] = slot_ptr[r0 + lane];
         if (lane == 0 && nr == 64) rp[64] = rowptr[r0 + 64];
@@ -1253,8 +1260,9 @@ static int finish_rows(padne_ctx *ctx, Scratch &sc, long long n_rows, long long 
     hipError_t e = hipMemcpyAsync(m->rowptr, rowptr_tmp, sizeof(int32_t) * (size_t)(n_rows + 1),
                                   hipMemcpyDeviceToDevice, s);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(compact_rows, dim3(nblk((n_rows + 63) / 64, 4)), dim3(256), 0, s, n_rows, slot_ptr, m->rowptr, key, val,
-                           m->cols, m->vals);
+        const int rpw = compact_rows_per_wave(n_rows, nnz);
+        hipLaunchKernelGGL(compact_rows, dim3(std::min(nblk((n_rows + rpw - 1) / rpw, 4), 65536u)), dim3(256), 0, s, n_rows, slot_ptr,
+                           m->rowptr, key, val, m->cols, m->vals, rpw);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -1298,8 +1306,9 @@ int csr_from_slots(padne_ctx *ctx, long long n_rows, long long n_cols, const int
     hipError_t e = hipMemcpyAsync(m->rowptr, rowptr_tmp, sizeof(int32_t) * (size_t)(n_rows + 1),
                                   hipMemcpyDeviceToDevice, s);
     if (e == hipSuccess && n_rows > 0) {
-        hipLaunchKernelGGL(compact_rows, dim3(nblk((n_rows + 63) / 64, 4)), dim3(256), 0, s, n_rows, slot_ptr, m->rowptr, key, val,
-                           m->cols, m->vals);
+        const int rpw = compact_rows_per_wave(n_rows, nnz);
+        hipLaunchKernelGGL(compact_rows, dim3(std::min(nblk((n_rows + rpw - 1) / rpw, 4), 65536u)), dim3(256), 0, s, n_rows, slot_ptr,
+                           m->rowptr, key, val, m->cols, m->vals, rpw);
         e = hipGetLastError();
     }
     // no synchronisation: the caller's scratch goes back to the pool, whose reuse is ordered on the same stream

@@ -881,6 +881,20 @@ __global__ void csr_dinv_kernel(int n_rows, const int *__restrict__ rowptr,
     dinv[r] = 1.0 / d;
 }
 
+// the same with a wave per row, for the small operators with long rows at the bottom of a hierarchy (a thread walking a
+// row of a hundred entries on its own: 28-39 us for the two coarsest levels of config C4)
+__global__ __launch_bounds__(256) void csr_dinv_wpr_kernel(int n_rows, const int *__restrict__ rowptr, const int *__restrict__ cols,
+                                                           const double *__restrict__ vals, double *__restrict__ dinv) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    double d = 0.0;
+    for (int k = rowptr[r] + lane; k < rowptr[r + 1]; k += 64)
+        if (cols[k] == r) d += vals[k];           // columns are unique in a row: exactly one lane finds the diagonal
+    d = wave_sum(d);                              // (zeros from the other lanes: the sum is that entry, bit for bit)
+    if (lane == 0) dinv[r] = 1.0 / d;
+}
+
 int csr_build_dinv(padne_ctx *ctx, padne_csr *m) {
     if (m->dinv != nullptr) return PADNE_OK;
     PADNE_REQUIRE(m->n_rows <= m->n_cols, "Jacobi needs a diagonal");
@@ -888,8 +902,12 @@ int csr_build_dinv(padne_ctx *ctx, padne_csr *m) {
     if (m->dinv == nullptr) return PADNE_E_NOMEM;
     if (m->n_rows > 0) {
         const int bs = 256;
-        hipLaunchKernelGGL(csr_dinv_kernel, dim3((unsigned)((m->n_rows + bs - 1) / bs)), dim3(bs), 0,
-                           ctx->stream, (int)m->n_rows, m->rowptr, m->cols, m->vals, m->dinv);
+        if (m->n_rows <= 65536 && m->nnz >= 24 * m->n_rows)
+            hipLaunchKernelGGL(csr_dinv_wpr_kernel, dim3((unsigned)((m->n_rows + 3) / 4)), dim3(bs), 0, ctx->stream, (int)m->n_rows,
+                               m->rowptr, m->cols, m->vals, m->dinv);
+        else
+            hipLaunchKernelGGL(csr_dinv_kernel, dim3((unsigned)((m->n_rows + bs - 1) / bs)), dim3(bs), 0,
+                               ctx->stream, (int)m->n_rows, m->rowptr, m->cols, m->vals, m->dinv);
         PADNE_HIP_CHECK(hipGetLastError());
     }
     return PADNE_OK;
