@@ -283,7 +283,7 @@ int exclusive_scan_i32_flagged(padne_ctx *ctx, const int32_t *in, int32_t *out, 
 // ------------------------------------------------------------------------------------------
 // assembly kernels
 // ------------------------------------------------------------------------------------------
-enum { ERR_BAD_INDEX = 0, ERR_NONMANIFOLD = 1, ERR_LONG_ROWS = 2, ERR_WORDS = 4 };
+enum { ERR_BAD_INDEX = 0, ERR_NONMANIFOLD = 1, ERR_LONG_ROWS = 2, ERR_HUB = 4, ERR_SCAN = 5, ERR_WORDS = 8 };
 
 __device__ __forceinline__ int find_segment(const long long *__restrict__ offs, int n_seg, long long i) {
     // largest m with offs[m] <= i   (offs has n_seg+1 entries, offs[0] = 0)
@@ -297,7 +297,11 @@ __device__ __forceinline__ int find_segment(const long long *__restrict__ offs, 
 
 // Vertex -> incident triangles, counted and listed in ONE pass: every vertex owns kIncCap list entries (a structured
 // grid has 6 triangles around a vertex, Delaunay meshes rarely more than 10); the counter keeps counting beyond that,
-// such a vertex takes the slot path.  The order inside a list is left to the atomics: nothing below depends on it.
+// such a vertex takes the slot path.  A list entry is the triangle as the vertex sees it: (j, k), the corner the edge
+// leaving the vertex points at and the corner the arriving edge comes from, as global vertex numbers -- the row kernel
+// then goes from the list straight to the coordinates (with the triangle's number in the list it went list -> corners ->
+// coordinates, three dependent gathers, and read every triangle three times).  The order inside a list is left to the
+// atomics: nothing below depends on it.
 constexpr int kIncCap = 12;
 // The triangles of a workgroup usually touch a short range of vertices (256 consecutive triangles of a scan-line or
 // strip-ordered mesh: two mesh lines, about as many distinct vertices as triangles, each touched three times).  Then
@@ -308,7 +312,7 @@ constexpr int kCntRange = 4096;
 __global__ __launch_bounds__(256) void asm_count_tri(long long n_tri, const int *__restrict__ tri, int n_mesh,
                                                      const long long *__restrict__ mesh_voff,
                                                      const long long *__restrict__ mesh_toff, int *__restrict__ cnt,
-                                                     int *__restrict__ inc, int *__restrict__ err) {
+                                                     int2 *__restrict__ inc, int *__restrict__ err) {
     __shared__ int lcnt[kCntRange], lbase[kCntRange];
     __shared__ long long s_min, s_max;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(256) void asm_count_tri(long long n_tri, const int 
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const int pos = atomicAdd(&cnt[g[q]], 1);      // incident triangles per vertex; a row owns two slots per incidence
-                if (pos < kIncCap) inc[g[q] * kIncCap + pos] = (int)t;
+                if (pos < kIncCap) inc[g[q] * kIncCap + pos] = make_int2((int)g[(q + 1) % 3], (int)g[(q + 2) % 3]);
             }
         return;
     }
@@ -371,20 +375,44 @@ __global__ __launch_bounds__(256) void asm_count_tri(long long n_tri, const int 
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int pos = lbase[(int)(g[q] - base)] + lpos[q];
-            if (pos < kIncCap) inc[g[q] * kIncCap + pos] = (int)t;
+            if (pos < kIncCap) inc[g[q] * kIncCap + pos] = make_int2((int)g[(q + 1) % 3], (int)g[(q + 2) % 3]);
         }
 }
 
-// slots of a row.  A mesh vertex without stamps and with at most kIncCap triangles is finished by
-// asm_rows_from_incidence, which writes at most one entry per neighbour plus the diagonal: a manifold fan of T triangles
-// has at most T + 1 neighbours.  Every other row goes through the slots: its diagonal placeholder, two per incident
-// triangle, one per stamp.  (Half the slot memory, and the 32-bit offsets last for 1.5 times as many vertices.)
-__global__ void asm_slot_counts(long long n, long long n_vert, const int *__restrict__ n_inc, const int *__restrict__ n_coo,
-                                int *__restrict__ cnt) {
+// Which rows go through the slots.  A mesh vertex without stamps and with at most kFanShort triangles is built by
+// asm_rows_in_place straight from its incidence list and takes no slots.  One with up to kIncCap triangles (its list is
+// still complete) is built the same way by asm_rows_long_fans, into T + 2 slots.  Every other row (stamps, a hub of more
+// than kIncCap triangles, internal nodes and extra unknowns behind the vertices) owns its diagonal placeholder, two slots
+// per incident triangle and one per stamp, and is merged by the slot kernels.  Two lists, one append per wave and list.
+constexpr int kFanShort = 8;
+__global__ __launch_bounds__(256) void asm_classify_rows(long long n, long long n_rows, long long n_vert,
+                                                         const int *__restrict__ n_inc, const int *__restrict__ n_coo,
+                                                         int *__restrict__ cnt, int *__restrict__ slow_list,
+                                                         int *__restrict__ fan_list, int *__restrict__ n_listed /*[2]*/,
+                                                         int *__restrict__ err) {
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const bool direct = r < n_vert && n_coo[r] == 0 && n_inc[r] <= kIncCap;
-    cnt[r] = direct ? n_inc[r] + 2 : 1 + 2 * n_inc[r] + n_coo[r];
+    const int T = r < n_vert ? n_inc[r] : 0;
+    const int stamps = r < n_rows ? n_coo[r] : 0;
+    const bool fan = r < n_vert && stamps == 0 && T > kFanShort && T <= kIncCap;
+    const bool slow = r < n_rows && !fan && (r >= n_vert || stamps != 0 || T > kIncCap);
+    if (r < n) cnt[r] = slow ? 1 + 2 * T + stamps : fan ? T + 2 : 0;      // n = n_rows + 1: the scan wants the entry behind the end
+    const int lane = threadIdx.x & 63;
+    const unsigned long long ms = __ballot(slow), mf = __ballot(fan);
+    if (ms != 0ull) {
+        const int first = __ffsll((long long)ms) - 1;
+        int base = 0;
+        if (lane == first) base = atomicAdd(&n_listed[0], __popcll(ms));
+        base = __shfl(base, first, 64);
+        if (slow) slow_list[base + __popcll(ms & ((1ull << lane) - 1ull))] = (int)r;
+        if (__ballot(slow && T > kIncCap) != 0ull && lane == first) *(volatile int *)&err[ERR_HUB] = 1;
+    }
+    if (mf != 0ull) {
+        const int first = __ffsll((long long)mf) - 1;
+        int base = 0;
+        if (lane == first) base = atomicAdd(&n_listed[1], __popcll(mf));
+        base = __shfl(base, first, 64);
+        if (fan) fan_list[base + __popcll(mf & ((1ull << lane) - 1ull))] = (int)r;
+    }
 }
 
 __global__ void asm_count_coo(long long n_coo, const int *__restrict__ row, int *__restrict__ cnt) {
@@ -411,16 +439,17 @@ __global__ void asm_fill_tri(long long n_tri, const int *__restrict__ tri, const
                              int n_mesh, const long long *__restrict__ mesh_voff,
                              const long long *__restrict__ mesh_toff, const int *__restrict__ slot_ptr,
                              int *__restrict__ cursor, long long *__restrict__ key, double *__restrict__ val,
-                             const int *__restrict__ only_flagged) {
+                             const int *__restrict__ hubs_of) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tri) return;
     const int m = find_segment(mesh_toff, n_mesh, t);
     const long long v0 = mesh_voff[m];
     const int ga = (int)(v0 + tri[3 * t]), gb = (int)(v0 + tri[3 * t + 1]), gc = (int)(v0 + tri[3 * t + 2]);
-    // only_flagged: rows already finished by asm_rows_from_incidence (row_len >= 0) take no slots
-    const bool fa = only_flagged == nullptr || only_flagged[ga] == -1;
-    const bool fb = only_flagged == nullptr || only_flagged[gb] == -1;
-    const bool fc = only_flagged == nullptr || only_flagged[gc] == -1;
+    // hubs_of (the triangle counts of the vertices): only the rows of more than kIncCap triangles take slots here -- the
+    // incidence list of such a vertex is incomplete; every other listed row is filled from its list (asm_fill_listed)
+    const bool fa = hubs_of == nullptr || hubs_of[ga] > kIncCap;
+    const bool fb = hubs_of == nullptr || hubs_of[gb] > kIncCap;
+    const bool fc = hubs_of == nullptr || hubs_of[gc] > kIncCap;
     if (!(fa || fb || fc)) return;
     const double ax = xy[2 * (long long)ga], ay = xy[2 * (long long)ga + 1];
     const double bx = xy[2 * (long long)gb], by = xy[2 * (long long)gb + 1];
@@ -447,180 +476,516 @@ __global__ void asm_fill_tri(long long n_tri, const int *__restrict__ tri, const
     }
 }
 
-// Rows of mesh vertices without stamps, straight from the incidence lists: the lane of vertex r walks its triangles,
-// computes the two cotangent terms that land in row r (the same cot_half calls with the same arguments as
-// asm_fill_tri), keeps one entry per neighbour in LDS, sorts the few entries by column and writes the finished row at
-// its slot offset -- no slot traffic, no float atomics.  Bit-identical to the slot path: an entry is the sum of at
-// most one forward and one backward term (a + b == b + a), the diagonal is -(w_1 + w_2 + ...) in ascending column
-// order.  Rows it does not take (stamps, more than CAP triangles) are
-// marked row_len = -1, listed in slow_list, and go through the slots (asm_fill_tri with only_flagged, the merge
-// kernels over the list).
-struct __attribute__((packed, aligned(4))) Int3 { int a, b, c; };
-template <int CAP>
-__global__ __launch_bounds__(128) void asm_rows_from_incidence(
-    long long n_vert, int n_mesh, const long long *__restrict__ mesh_voff, const double *__restrict__ sigma,
-    const int *__restrict__ tri, const double *__restrict__ xy, const int *__restrict__ n_inc,
-    const int *__restrict__ inc, const int *__restrict__ n_coo, const int *__restrict__ slot_ptr,
-    long long *__restrict__ key, double *__restrict__ val, int *__restrict__ row_len, int *__restrict__ err,
-    int *__restrict__ slow_list, int *__restrict__ n_slow) {
-    static_assert(CAP == kIncCap, "the incidence lists have kIncCap entries per vertex");
-    __shared__ unsigned Cc[CAP + 1][128];      // column << 2 | bit 0: forward term seen | bit 1: backward term seen
-    __shared__ double Wc[CAP + 1][128];        // (20 KiB per workgroup: four waves per SIMD)
-    const int t = threadIdx.x;
-    const long long r = (long long)blockIdx.x * 128 + t;
-    if (r >= n_vert) return;
-    const long long i0 = r * CAP;
-    const int T = n_inc[r];
-    const bool slow = n_coo[r] != 0 || T > CAP;
-    int nn = 0;
-    bool bad = false;
-    if (!slow) {
-        const int m = find_segment(mesh_voff, n_mesh, r);
-        const long long v0 = mesh_voff[m];
-        const double2 pv = reinterpret_cast<const double2 *>(xy)[r];
-        const double vx = pv.x, vy = pv.y;
-        // four triangles per turn: their list entries, then their corners, then the coordinates are requested together --
-        // one triangle at a time the lane waited for three dependent loads per triangle (list -> corners -> coordinates),
-        // 6-8 times in a row
-        for (int q0 = 0; q0 < T; q0 += 4) {
-            int cj[4], ck[4];
-            {
-                long long tt[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) tt[u] = q0 + u < T ? inc[i0 + q0 + u] : 0;
-                int ca[4], cb[4], cc[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    ca[u] = cb[u] = cc[u] = 0;
-                    if (q0 + u < T) {
-                        const Int3 c3 = *reinterpret_cast<const Int3 *>(tri + 3 * tt[u]);      // one 12-byte load
-                        ca[u] = c3.a;
-                        cb[u] = c3.b;
-                        cc[u] = c3.c;
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int a = (int)(v0 + ca[u]), b = (int)(v0 + cb[u]), c = (int)(v0 + cc[u]);
-                    // r -> j is the edge leaving r in this triangle, k -> r the one arriving
-                    if (a == (int)r) { cj[u] = b; ck[u] = c; } else if (b == (int)r) { cj[u] = c; ck[u] = a; } else { cj[u] = a; ck[u] = b; }
-                }
-            }
-            double jx[4], jy[4], kx[4], ky[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                jx[u] = jy[u] = kx[u] = ky[u] = 0.0;
-                if (q0 + u < T) {
-                    const double2 pj = reinterpret_cast<const double2 *>(xy)[cj[u]], pk = reinterpret_cast<const double2 *>(xy)[ck[u]];
-                    jx[u] = pj.x;
-                    jy[u] = pj.y;
-                    kx[u] = pk.x;
-                    ky[u] = pk.y;
-                }
-            }
-            bool stop = false;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (q0 + u >= T || stop) continue;
-                const int j = cj[u], k = ck[u];
-                const double wf = cot_half(vx, vy, jx[u], jy[u], kx[u], ky[u]);      // edge r -> j, opposite k
-                const double wb = cot_half(kx[u], ky[u], vx, vy, jx[u], jy[u]);      // edge k -> r, opposite j
-#pragma unroll
-                for (int side = 0; side < 2; ++side) {
-                    const int col = side == 0 ? j : k;
-                    const double w = side == 0 ? wf : wb;
-                    const int bit = 1 << side;
-                    int e = 0;
-                    while (e < nn && (Cc[e][t] >> 2) != (unsigned)col) ++e;
-                    if (e < nn) {
-                        const unsigned cf = Cc[e][t];
-                        if (cf & bit) bad = true;                        // two triangles on the same side of an edge
-                        Wc[e][t] = ((cf & 3u) == 1u) ? Wc[e][t] + w : w + Wc[e][t];      // forward + backward, as the merge adds them
-                        Cc[e][t] = cf | bit;
-                    } else if (nn <= T) {                                // a manifold fan of T triangles has at most T + 1 neighbours: the row owns T + 2 slots
-                        Cc[nn][t] = ((unsigned)col << 2) | bit;
-                        Wc[nn][t] = w;
-                        ++nn;
-                    } else {
-                        bad = true;                                      // more neighbours than a manifold fan has
-                        nn = 0;
-                        stop = true;
-                        break;
-                    }
-                }
-            }
-            if (stop) break;
-        }
+// The listed rows of mesh vertices with a complete incidence list: their two cotangent terms per triangle go to fixed
+// slots (1 + 2q, 2 + 2q; slot 0 is the diagonal placeholder), the stamps follow from the cursor.  The same cot_half calls
+// with the same arguments as asm_fill_tri, which now only serves the hubs.
+__global__ __launch_bounds__(256) void asm_fill_listed(const int *__restrict__ n_list, const int *__restrict__ row_list,
+                                                       long long n_vert, const double *__restrict__ xy,
+                                                       const int *__restrict__ n_inc, const int2 *__restrict__ inc,
+                                                       const int *__restrict__ slot_ptr, int *__restrict__ cursor,
+                                                       long long *__restrict__ key, double *__restrict__ val) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= *n_list) return;
+    const int r = row_list[idx];
+    const int T = r < n_vert ? n_inc[r] : 0;
+    if (T > kIncCap) {                                     // a hub: asm_fill_tri appends its terms
+        cursor[r] = 1;
+        return;
     }
-    {
-        // rows for the slot path are listed (one atomic per wave), the merge kernels then run over the list only
-        const unsigned long long mk = __ballot(slow);
-        if (mk != 0ull) {
-            const int lane = threadIdx.x & 63;
-            int base = 0;
-            if (lane == __ffsll((long long)mk) - 1) base = atomicAdd(n_slow, __popcll(mk));
-            base = __shfl(base, __ffsll((long long)mk) - 1, 64);
-            if (slow) {
-                slow_list[base + __popcll(mk & ((1ull << lane) - 1ull))] = (int)r;
-                row_len[r] = -1;
-            }
-        }
-    }
-    if (slow) return;
-    // sort the neighbours by column (insertion sort, a handful of entries)
-    for (int i = 1; i < nn; ++i) {
-        const unsigned c = Cc[i][t];
-        const double w = Wc[i][t];
-        int u = i - 1;
-        while (u >= 0 && Cc[u][t] > c) {
-            Cc[u + 1][t] = Cc[u][t];
-            Wc[u + 1][t] = Wc[u][t];
-            --u;
-        }
-        Cc[u + 1][t] = c;
-        Wc[u + 1][t] = w;
-    }
-    const double sig = sigma[find_segment(mesh_voff, n_mesh, r)];
-    int fwd_only = 0, bwd_only = 0;
-    double dacc = 0.0;
-    for (int i = 0; i < nn; ++i) {
-        if ((Cc[i][t] & 3u) == 1u) ++fwd_only;
-        if ((Cc[i][t] & 3u) == 2u) ++bwd_only;
-        const double wm = Wc[i][t];
-        if (wm != 0.0) dacc = dacc - wm;
-    }
-    if (bad || fwd_only > 1 || bwd_only > 1) atomicExch(&err[ERR_NONMANIFOLD], 1);
+    cursor[r] = 1 + 2 * T;
+    if (T == 0) return;
+    const double2 pv = reinterpret_cast<const double2 *>(xy)[r];
     const int s0 = slot_ptr[r];
+    for (int q = 0; q < T; ++q) {
+        const int2 jk = inc[(long long)r * kIncCap + q];
+        const double2 pj = reinterpret_cast<const double2 *>(xy)[jk.x], pk = reinterpret_cast<const double2 *>(xy)[jk.y];
+        key[s0 + 1 + 2 * q] = make_key(jk.x, 0);
+        val[s0 + 1 + 2 * q] = cot_half(pv.x, pv.y, pj.x, pj.y, pk.x, pk.y);      // edge r -> j, opposite k
+        key[s0 + 2 + 2 * q] = make_key(jk.y, 1);
+        val[s0 + 2 + 2 * q] = cot_half(pk.x, pk.y, pv.x, pv.y, pj.x, pj.y);      // edge k -> r, opposite j
+    }
+}
+
+// Offsets of the row tiles without a second pass.  A worker workgroup publishes the number of entries of a tile as soon as
+// it has built the tile's rows (tile_agg), parks the rows, builds its NEXT tile, and only then asks for the first tile's
+// offset -- by then it is almost always there; nobody waits for the slowest workgroup of the chip the way a look-back
+// inside every workgroup does (that cost 0.6 ms of 1.4).  Two levels: tiles form chunks of 64; the worker that completes
+// a chunk (a counter per chunk) adds up its 64 counts and publishes the chunk's; one scanner wave (block 0) walks the
+// chunk counts in order, 64 chunks a look, and publishes the chunk offsets; a tile's offset is its chunk's plus the
+// counts of the earlier tiles of the chunk (one 64-lane look).  Tiles are handed out by a ticket, so a tile somebody waits
+// for is always in the hands of a running workgroup, and an offset depends on earlier tiles only.  Every wait is bounded
+// (kScanMaxPolls); a wait that gives up raises the abort word, which ends all other waits and fails the assembly loudly.
+constexpr unsigned long long kScanValueMask = (1ull << 62) - 1ull;
+constexpr unsigned long long kScanKnown = 1ull << 62;
+constexpr int kScanMaxPolls = 1 << 22;
+constexpr int kChunkTiles = 64;
+__device__ __forceinline__ unsigned long long scan_word_load(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void scan_word_store(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+struct TileScan {
+    unsigned long long *tile_agg;        // [n_tiles]   known | entries of the tile
+    unsigned long long *chunk_agg;       // [n_chunks]  known | entries of the chunk
+    unsigned long long *chunk_prefix;    // [n_chunks + 1]  known | entries before the chunk
+    int *chunk_count;                    // [n_chunks]  tiles of the chunk that have published
+    int *ticket, *abort_word;
+    long long *nnz_out;
+    int n_tiles, n_chunks;
+};
+
+// block 0 of asm_rows_in_place, one wave
+__device__ __forceinline__ void chunk_offset_scanner(const TileScan sc) {
+    const int lane = threadIdx.x & 63;
+    long long running = 0;
+    int done = 0;                                          // chunk_prefix[0 .. done] are out
+    if (lane == 0) scan_word_store(&sc.chunk_prefix[0], kScanKnown);
+    int idle = 0;
+    while (done < sc.n_chunks) {
+        const int idx = done + lane;
+        const unsigned long long w = idx < sc.n_chunks ? scan_word_load(&sc.chunk_agg[idx]) : 0ull;
+        const unsigned long long gaps = __ballot((w >> 62) == 0ull);
+        const int lead = gaps != 0ull ? __ffsll((long long)gaps) - 1 : 64;
+        if (lead == 0) {
+            // (the abort word is looked at now and then only: a word every waiting wave of the chip reads at every poll is a
+            //  hot spot that slowed the whole kernel sevenfold)
+            if (++idle > kScanMaxPolls || ((idle & 255) == 0 && __hip_atomic_load(sc.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                if (lane == 0) __hip_atomic_store(sc.abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+        }
+        idle = 0;
+        long long incl = lane < lead ? (long long)(w & kScanValueMask) : 0;
+        for (int off = 1; off < 64; off <<= 1) {
+            const long long up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        if (lane < lead) scan_word_store(&sc.chunk_prefix[idx + 1], kScanKnown | (unsigned long long)(running + incl));
+        running += __shfl(incl, 63, 64);
+        done += lead;
+    }
+    if (lane == 0) *sc.nnz_out = running;
+}
+
+// a worker's wave 0 publishes a tile's count; the wave that completes the chunk publishes the chunk's
+__device__ __forceinline__ void tile_publish(const TileScan sc, const int tile, const int total, const int lane) {
+    const int c = tile / kChunkTiles;
+    int arrived = 0;
+    if (lane == 0) {
+        scan_word_store(&sc.tile_agg[tile], kScanKnown | (unsigned long long)total);
+        // the count is an agent-scope atomic store that goes to the coherent level itself; the arrival must not overtake it:
+        // wait for the store (a workgroup-scope fence is exactly that wait -- an agent-scope release would write back the
+        // whole L2 of the XCD, with a few hundred MB of fresh rows in it, once per tile: 6.5 ms instead of 0.8)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        arrived = __hip_atomic_fetch_add(&sc.chunk_count[c], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    }
+    arrived = __shfl(arrived, 0, 64);
+    const int in_chunk = min(kChunkTiles, sc.n_tiles - c * kChunkTiles);
+    if (arrived != in_chunk) return;
+    // (the counts are looked at with their known bit all the same: nothing here relies on the order in which another
+    //  workgroup's count and its arrival reach memory)
+    unsigned long long w = lane < in_chunk ? scan_word_load(&sc.tile_agg[c * kChunkTiles + lane]) : kScanKnown;
+    for (int polls = 0; __ballot((w >> 62) == 0ull) != 0ull; ++polls) {
+        if (polls > kScanMaxPolls) {
+            if (lane == 0) __hip_atomic_store(sc.abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        if ((w >> 62) == 0ull) w = scan_word_load(&sc.tile_agg[c * kChunkTiles + lane]);
+    }
+    long long v = (long long)(w & kScanValueMask);
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) scan_word_store(&sc.chunk_agg[c], kScanKnown | (unsigned long long)v);
+}
+
+// a worker's wave 0 asks for a tile's offset: false when the wait was given up
+__device__ __forceinline__ bool tile_offset(const TileScan sc, const int tile, const int lane, long long *before) {
+    const int c = tile / kChunkTiles, pos = tile % kChunkTiles;
+    const unsigned long long *p = lane == 63 ? &sc.chunk_prefix[c] : &sc.tile_agg[c * kChunkTiles + lane];
+    const bool mine = lane == 63 || lane < pos;            // (pos <= 63: lane 63 never holds a tile of the sum)
+    unsigned long long w = mine ? scan_word_load(p) : kScanKnown;
+    int polls = 0;
+    while (__ballot((w >> 62) == 0ull) != 0ull) {
+        if (++polls > kScanMaxPolls || ((polls & 255) == 0 && __hip_atomic_load(sc.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            if (lane == 0) __hip_atomic_store(sc.abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(8);
+        if ((w >> 62) == 0ull) w = scan_word_load(p);
+    }
+    long long v = (long long)(w & kScanValueMask);
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    *before = v;
+    return true;
+}
+
+// Compare-exchange network over N (column, value) pairs held in registers (merge exchange, Knuth 5.2.2 M: any N, about
+// N log^2 N / 4 exchanges, the list is made at compile time so that every index below is a constant).
+template <int N>
+struct SortNet {
+    int a[N * N], b[N * N], n;
+    constexpr SortNet() : a(), b(), n(0) {
+        int t = 0;
+        while ((1 << t) < N) ++t;
+        for (int p = t > 0 ? 1 << (t - 1) : 0; p > 0; p >>= 1) {
+            int q = 1 << (t - 1), r = 0, d = p;
+            for (;;) {
+                for (int i = 0; i + d < N; ++i)
+                    if ((i & p) == r) {
+                        a[n] = i;
+                        b[n] = i + d;
+                        ++n;
+                    }
+                if (q == p) break;
+                d = q - p;
+                q >>= 1;
+                r = p;
+            }
+        }
+    }
+};
+
+// The row of mesh vertex r from its incidence list, in registers: the fan's triangles (j_u, k_u) with their two terms
+// wf_u (edge r -> j_u) and wb_u (edge k_u -> r).  The neighbour j_u holds wf_u plus the backward term of the triangle on
+// the other side of that edge (the u' with k_u' == j_u), found by comparing every pair -- no search loop, no LDS, no
+// divergence; a boundary fan has one j without partner and one k without partner, which is the extra entry.  Sorted by
+// column with a compare-exchange network.  The additions are those of the slot path (forward + backward; the diagonal
+// -(w_1 + w_2 + ...) in ascending column order), hence the same bits.  RC: list entries examined (8 covers almost every
+// vertex of a triangulation, 12 is the capacity of a list); the unused ones carry distinct negative numbers and match
+// nothing.  Out: col/w[0..RC] sorted, INT_MAX behind the last neighbour; w already scaled by the conductance.
+template <int RC>
+__device__ __forceinline__ void fan_row(const int T, const double vx, const double vy, const int4 *__restrict__ pairs,
+                                        const double *__restrict__ xy, const double sig, int (&col)[RC + 1], double (&w)[RC + 1],
+                                        double &dval, int &len, bool &bad) {
+    // pairs: the list, two entries per int4 (what lies behind entry T - 1 is never looked at)
+    int cj[RC], ck[RC];
+#pragma unroll
+    for (int q = 0; q < RC / 2; ++q) {
+        cj[2 * q] = pairs[q].x;
+        ck[2 * q] = pairs[q].y;
+        cj[2 * q + 1] = pairs[q].z;
+        ck[2 * q + 1] = pairs[q].w;
+    }
+    double wf[RC], wb[RC];
+#pragma unroll
+    for (int u = 0; u < RC; ++u) {
+        wf[u] = wb[u] = 0.0;
+        if (u < T) {
+            const double2 pj = reinterpret_cast<const double2 *>(xy)[cj[u]], pk = reinterpret_cast<const double2 *>(xy)[ck[u]];
+            wf[u] = cot_half(vx, vy, pj.x, pj.y, pk.x, pk.y);      // edge r -> j, opposite k
+            wb[u] = cot_half(pk.x, pk.y, vx, vy, pj.x, pj.y);      // edge k -> r, opposite j
+        } else {
+            cj[u] = -1 - u;
+            ck[u] = -101 - u;
+        }
+    }
+    // hit(a, b): triangle a arrives over the edge triangle b leaves by.  A manifold fan has at most one partner per edge on
+    // either side; a count beyond one (two triangles on the same side of an edge) is the non-manifold mesh of mesh.py:342
+    int src[RC];
+#pragma unroll
+    for (int u = 0; u < RC; ++u) src[u] = 0;
+    int over = 0, fwd_only = 0, bwd_only = 0;
+#pragma unroll
+    for (int u = 0; u < RC; ++u) {
+        int partners = 0;
+        double wbm = 0.0;
+#pragma unroll
+        for (int u2 = 0; u2 < RC; ++u2) {
+            const bool hit = ck[u2] == cj[u];
+            partners += hit ? 1 : 0;
+            src[u2] += hit ? 1 : 0;
+            wbm = hit ? wb[u2] : wbm;
+        }
+        over |= partners;
+        col[u] = u < T ? cj[u] : 0x7fffffff;
+        w[u] = wf[u] + wbm;                                 // forward + backward, as the merge adds them (w + 0.0 == w: w >= +0)
+        fwd_only += (u < T && partners == 0) ? 1 : 0;
+    }
+    int extra_col = 0x7fffffff;
+    double extra_w = 0.0;
+#pragma unroll
+    for (int u = 0; u < RC; ++u) {
+        over |= src[u];
+        const bool alone = u < T && src[u] == 0;            // nobody leaves by the edge k_u - r: the boundary on that side
+        bwd_only += alone ? 1 : 0;
+        extra_col = alone ? ck[u] : extra_col;
+        extra_w = alone ? wb[u] : extra_w;
+    }
+    col[RC] = extra_col;
+    w[RC] = extra_w;
+    if ((over & ~1) != 0 || fwd_only > 1 || bwd_only > 1) bad = true;      // (more than one boundary on a side: not a manifold fan)
+    constexpr SortNet<RC + 1> net;
+#pragma unroll
+    for (int e = 0; e < net.n; ++e) {
+        const int ia = net.a[e], ib = net.b[e];
+        const bool swap = col[ia] > col[ib];
+        const int ca = col[ia], cb = col[ib];
+        const double wa = w[ia], wbb = w[ib];
+        col[ia] = swap ? cb : ca;
+        col[ib] = swap ? ca : cb;
+        w[ia] = swap ? wbb : wa;
+        w[ib] = swap ? wa : wbb;
+    }
+    double dacc = 0.0;
+    len = 0;
+#pragma unroll
+    for (int i = 0; i <= RC; ++i) {
+        if (col[i] != 0x7fffffff) {
+            const double wm = w[i];
+            if (wm != 0.0) dacc = dacc - wm;
+            const double v = sig * wm;
+            w[i] = v;                                       // what the row stores
+            if (v != 0.0) ++len;                            // exact zeros are not stored
+        }
+    }
+    dval = sig * dacc;
+    if (dval != 0.0) ++len;
+}
+
+__device__ __forceinline__ void put_col(int *p, int c) { *p = c; }
+__device__ __forceinline__ void put_col(long long *p, int c) { *p = (long long)c << 32; }      // a slot key: column in the high word
+
+template <int RC, typename CT>
+__device__ __forceinline__ void fan_row_store(const int r, const int (&col)[RC + 1], const double (&w)[RC + 1], const double dval,
+                                              CT *__restrict__ cols, double *__restrict__ vals) {
     int o = 0;
     bool diag_done = false;
-    for (int i = 0; i <= nn; ++i) {
-        if (!diag_done && (i == nn || (int)(Cc[i][t] >> 2) > (int)r)) {
-            const double v = sig * dacc;
-            if (v != 0.0) {
-                key[s0 + o] = (long long)r << 32;
-                val[s0 + o] = v;
+#pragma unroll
+    for (int i = 0; i <= RC + 1; ++i) {
+        const int c = i <= RC ? col[i <= RC ? i : RC] : 0x7fffffff;
+        if (!diag_done && c > r) {                          // (INT_MAX behind the last neighbour)
+            if (dval != 0.0) {
+                put_col(cols + o, r);
+                vals[o] = dval;
                 ++o;
             }
             diag_done = true;
         }
-        if (i < nn) {
-            const double v = sig * Wc[i][t];
-            if (v != 0.0) {                                          // exact zeros are not stored
-                key[s0 + o] = (long long)(Cc[i][t] >> 2) << 32;
-                val[s0 + o] = v;
+        if (i <= RC && c != 0x7fffffff) {
+            const double v = w[i <= RC ? i : RC];
+            if (v != 0.0) {
+                put_col(cols + o, c);
+                vals[o] = v;
                 ++o;
             }
         }
     }
-    row_len[r] = o;
 }
 
-__global__ void asm_list_tail_rows(int n_vert, int n_unknowns, int *__restrict__ row_len, int *__restrict__ slow_list,
-                                   int *__restrict__ n_slow) {
-    const int r = n_vert + blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_unknowns) return;
-    row_len[r] = -1;
-    slow_list[atomicAdd(n_slow, 1)] = r;
+// Vertices with more than kFanShort triangles and no stamps (a few per cent of a Delaunay mesh, none of a structured
+// one): the same register algorithm over the whole list, the row goes to the vertex's slots -- finished, nothing left to
+// merge -- and is placed with the listed rows.  Keeps the long variant's registers out of the kernel every row runs.
+__global__ __launch_bounds__(128) void asm_rows_long_fans(const int *__restrict__ n_list, const int *__restrict__ row_list,
+                                                          int n_mesh, const long long *__restrict__ mesh_voff,
+                                                          const double *__restrict__ sigma, const double *__restrict__ xy,
+                                                          const int *__restrict__ n_inc, const int2 *__restrict__ inc,
+                                                          const int *__restrict__ slot_ptr, long long *__restrict__ key,
+                                                          double *__restrict__ val, int *__restrict__ row_len,
+                                                          int *__restrict__ err) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= *n_list) return;
+    const int r = row_list[idx];
+    const int T = n_inc[r];
+    int4 pairs[kIncCap / 2];
+    const int4 *lst = reinterpret_cast<const int4 *>(inc + (long long)r * kIncCap);
+#pragma unroll
+    for (int q = 0; q < kIncCap / 2; ++q) pairs[q] = lst[q];
+    const double2 pv = reinterpret_cast<const double2 *>(xy)[r];
+    const double sig = sigma[find_segment(mesh_voff, n_mesh, r)];
+    int col[kIncCap + 1];
+    double w[kIncCap + 1];
+    double dval = 0.0;
+    int len = 0;
+    bool bad = false;
+    fan_row<kIncCap>(T, pv.x, pv.y, pairs, xy, sig, col, w, dval, len, bad);
+    if (bad) atomicExch(&err[ERR_NONMANIFOLD], 1);
+    const int s0 = slot_ptr[r];
+    fan_row_store<kIncCap>(r, col, w, dval, key + s0, val + s0);
+    row_len[r] = len;
+}
+
+// The rows of the assembled system, written once and in place.  Worker workgroups take tiles of 128 rows by ticket; the
+// lane of mesh vertex r builds its row from the incidence list (fan_row) and counts what it will store; the tile's count
+// is published, the rows wait in registers while the workgroup builds its next tile, then learn their offset from the
+// scanner (above) and are written straight into the CSR arrays -- no slots, no second scan, no compaction pass.  The
+// listed rows (stamps, hubs, long fans, the unknowns behind the vertices) were merged at their slot offsets before this
+// kernel runs; it leaves room for them, asm_place_listed moves them in.
+struct RowsInPlace {
+    long long n_rows, n_vert;
+    int n_mesh;
+    const long long *mesh_voff;
+    const double *sigma, *xy;
+    const int *n_inc;
+    const int2 *inc;
+    const int *slot_ptr, *row_len;
+    int *rowptr, *cols;
+    double *vals;
+    int *err;
+    TileScan scan;
+};
+
+__global__ __launch_bounds__(128) void asm_rows_in_place(const RowsInPlace a) {
+    static_assert(kFanShort == 8, "the first 64 bytes of a list are its first eight entries");
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < 64) chunk_offset_scanner(a.scan);
+        return;
+    }
+    __shared__ int held_col[kFanShort + 1][128];           // the rows of the tile that waits for its offset (14 KiB)
+    __shared__ double held_w[kFanShort + 1][128];
+    __shared__ int s_ticket[2], s_wave_total[2][2], s_abort;      // (ticket and wave totals alternate between two sets by turn)
+    __shared__ long long s_before;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int n_tiles = a.scan.n_tiles;
+    if (t == 0) {
+        s_ticket[0] = atomicAdd(a.scan.ticket, 1);
+        s_abort = 0;
+    }
+    __syncthreads();
+    int tile = s_ticket[0];
+    bool held = false, held_direct = false;
+    int held_tile = 0, held_len = 0, held_local = 0;
+    double held_dval = 0.0;
+    for (int turn = 0;; ++turn) {
+        const bool work = tile < n_tiles;
+        if (!work && !held) break;
+        if (work && t == 0) s_ticket[(turn + 1) & 1] = atomicAdd(a.scan.ticket, 1);      // the next ticket travels while this tile is built
+        bool direct = false;
+        int len = 0, local = 0;
+        int col[kFanShort + 1];
+        double w[kFanShort + 1], dval = 0.0;
+#pragma unroll
+        for (int i = 0; i <= kFanShort; ++i) {
+            col[i] = 0x7fffffff;
+            w[i] = 0.0;
+        }
+        if (work) {
+            const long long r = (long long)tile * 128 + t;
+            const bool live = r < a.n_rows;
+            // everything that does not depend on another load is requested at once: the row's slot span, its triangle count,
+            // its own coordinates and the first eight list entries (whether they are needed or not)
+            int sp0 = 0, sp1 = 1, T = 0, listed_len = 0;
+            int4 pairs[kFanShort / 2];
+            double2 pv = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int q = 0; q < kFanShort / 2; ++q) pairs[q] = make_int4(0, 0, 0, 0);
+            if (live) {
+                sp0 = a.slot_ptr[r];
+                sp1 = a.slot_ptr[r + 1];
+                listed_len = a.row_len[r];
+                if (r < a.n_vert) {
+                    T = a.n_inc[r];
+                    pv = reinterpret_cast<const double2 *>(a.xy)[r];
+                    const int4 *lst = reinterpret_cast<const int4 *>(a.inc + r * kIncCap);
+#pragma unroll
+                    for (int q = 0; q < kFanShort / 2; ++q) pairs[q] = lst[q];
+                }
+            }
+            direct = live && sp1 == sp0;                   // a listed row owns at least its diagonal placeholder
+            len = live && !direct ? listed_len : 0;
+            if (len < 0) {                                 // a listed row no merge pass reached: never expected
+                atomicExch(&a.err[ERR_SCAN], 1);
+                len = 0;
+            }
+            if (!direct) T = 0;
+            const bool six = __ballot(T > 6) == 0ull;      // (one code path per wave; a structured mesh never needs the other)
+            bool bad = false;
+            if (direct) {
+                const double sig = a.sigma[find_segment(a.mesh_voff, a.n_mesh, r)];
+                if (six) {
+                    int c6[7];
+                    double w6[7];
+                    fan_row<6>(T, pv.x, pv.y, pairs, a.xy, sig, c6, w6, dval, len, bad);
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) {
+                        col[i] = c6[i];
+                        w[i] = w6[i];
+                    }
+                } else {
+                    fan_row<kFanShort>(T, pv.x, pv.y, pairs, a.xy, sig, col, w, dval, len, bad);
+                }
+                if (bad) atomicExch(&a.err[ERR_NONMANIFOLD], 1);
+            }
+            int incl = len;                                // offsets inside the wave
+            for (int off = 1; off < 64; off <<= 1) {
+                const int up = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += up;
+            }
+            if (lane == 63) s_wave_total[turn & 1][wv] = incl;
+            local = incl - len;
+        }
+        __syncthreads();                                   // wave totals, the next ticket
+        const int next_tile = work ? s_ticket[(turn + 1) & 1] : tile;
+        if (work) {
+            if (wv == 1) local += s_wave_total[turn & 1][0];
+            if (wv == 0) tile_publish(a.scan, tile, s_wave_total[turn & 1][0] + s_wave_total[turn & 1][1], lane);
+        }
+        if (held) {
+            if (wv == 0) {
+                long long before = 0;
+                const bool ok = tile_offset(a.scan, held_tile, lane, &before);
+                if (lane == 0) {
+                    s_before = before;
+                    if (!ok) s_abort = 1;
+                }
+            }
+            __syncthreads();
+            if (s_abort) {
+                if (t == 0) atomicExch(&a.err[ERR_SCAN], 1);
+                return;
+            }
+            const long long hr = (long long)held_tile * 128 + t;
+            if (hr < a.n_rows) {
+                const long long at = s_before + held_local;
+                a.rowptr[hr] = (int)at;
+                if (hr == a.n_rows - 1) a.rowptr[a.n_rows] = (int)(at + held_len);
+                if (held_direct) {
+                    int hc[kFanShort + 1];
+                    double hw[kFanShort + 1];
+#pragma unroll
+                    for (int i = 0; i <= kFanShort; ++i) {
+                        hc[i] = held_col[i][t];
+                        hw[i] = held_w[i][t];
+                    }
+                    fan_row_store<kFanShort>((int)hr, hc, hw, held_dval, a.cols + at, a.vals + at);
+                }
+            }
+            __syncthreads();                               // s_before is rewritten in the next turn
+        }
+        held = work;
+        held_tile = tile;
+        held_direct = direct;
+        held_len = len;
+        held_local = local;
+        held_dval = dval;
+        if (work && direct) {                              // (every lane reads back only what it parked itself)
+#pragma unroll
+            for (int i = 0; i <= kFanShort; ++i) {
+                held_col[i][t] = col[i];
+                held_w[i][t] = w[i];
+            }
+        }
+        tile = next_tile;
+    }
+}
+
+// the listed rows, merged at their slot offsets, move to the place asm_rows_in_place left for them: one wave per row
+__global__ __launch_bounds__(256) void asm_place_listed(const int *__restrict__ n_list, const int *__restrict__ row_list,
+                                                        const int *__restrict__ slot_ptr, const long long *__restrict__ key,
+                                                        const double *__restrict__ val, const int *__restrict__ rowptr,
+                                                        int *__restrict__ cols, double *__restrict__ vals) {
+    const int lane = threadIdx.x & 63;
+    const int n = *n_list;
+    for (int idx = blockIdx.x * 4 + (threadIdx.x >> 6); idx < n; idx += gridDim.x * 4) {
+        const int r = row_list[idx];
+        const int s0 = slot_ptr[r], at = rowptr[r], len = rowptr[r + 1] - at;
+        for (int i = lane; i < len; i += 64) {
+            cols[at + i] = (int)(key[s0 + i] >> 32);
+            vals[at + i] = val[s0 + i];
+        }
+    }
 }
 
 __global__ void asm_fill_coo(long long n_coo, const int *__restrict__ row, const int *__restrict__ col,
@@ -1206,51 +1571,46 @@ __global__ void power_density_kernel(long long n_tri, const int *__restrict__ tr
 // vertices around them); the fans of the ring vertices are incomplete by construction, so the manifold test is off
 static thread_local bool t_partial_mesh = false;
 
-template <bool MESH>
-static int finish_rows(padne_ctx *ctx, Scratch &sc, long long n_rows, long long n_cols, long long n_vert, int n_mesh,
-                       const long long *d_voff, const double *d_sigma, const int *slot_ptr, long long *key,
-                       double *val, int *d_err, padne_csr **out, int *row_len_in = nullptr,
-                       const int *row_list = nullptr, long long n_list = 0) {
-    // row_len_in + row_list: rows with row_len >= 0 are already merged at their slot offsets
-    // (asm_rows_from_incidence); the merge kernels run over the n_list rows of row_list only
+// the listed rows of the assembled system, merged in place at their slot offsets (row_len = what each keeps)
+static int merge_listed_mesh_rows(padne_ctx *ctx, long long n_vert, int n_mesh, const long long *d_voff, const double *d_sigma,
+                                  const int *slot_ptr, long long *key, double *val, int *row_len, int *d_err,
+                                  const int *row_list, long long n_merge) {
     hipStream_t s = ctx->stream;
-    int *row_len = row_len_in;
-    if (row_len == nullptr) PADNE_TRY(sc.alloc(&row_len, (size_t)n_rows + 1));
-    const long long n_merge = row_len_in != nullptr ? n_list : n_rows;
-    if (MESH && n_merge > 0) {
-        // rows of up to 20 slots (vertices of degree <= 9) first: 40 KiB of LDS per 128 rows, twice the waves per CU of the
-        // 32-slot pass, which only runs for meshes that have longer rows; beyond that (hubs) the global-memory merge
-        constexpr int kCapSmall = 20, kCap = 32;
-        hipLaunchKernelGGL(merge_rows_mesh_lds<kCapSmall>, dim3(nblk(n_merge, 128)), dim3(128), 0, s, n_merge, n_vert, n_mesh,
-                           d_voff, d_sigma, slot_ptr, key, val, row_len, d_err, 0, row_list);
+    if (n_merge <= 0) return PADNE_OK;
+    // rows of up to 20 slots (vertices of degree <= 9) first: 40 KiB of LDS per 128 rows, twice the waves per CU of the
+    // 32-slot pass, which only runs for meshes that have longer rows; beyond that (hubs) the global-memory merge
+    constexpr int kCapSmall = 20, kCap = 32;
+    hipLaunchKernelGGL(merge_rows_mesh_lds<kCapSmall>, dim3(nblk(n_merge, 128)), dim3(128), 0, s, n_merge, n_vert, n_mesh,
+                       d_voff, d_sigma, slot_ptr, key, val, row_len, d_err, 0, row_list);
+    PADNE_HIP_CHECK(hipGetLastError());
+    int h_long[ERR_WORDS];
+    PADNE_TRY(read_back(ctx, d_err, sizeof(h_long), h_long));
+    if (h_long[ERR_LONG_ROWS]) {
+        PADNE_HIP_CHECK(hipMemsetAsync(d_err + ERR_LONG_ROWS, 0, sizeof(int), s));
+        hipLaunchKernelGGL(merge_rows_mesh_lds<kCap>, dim3(nblk(n_merge, 128)), dim3(128), 0, s, n_merge, n_vert, n_mesh,
+                           d_voff, d_sigma, slot_ptr, key, val, row_len, d_err, kCapSmall, row_list);
         PADNE_HIP_CHECK(hipGetLastError());
-        int h_long[ERR_WORDS];
         PADNE_TRY(read_back(ctx, d_err, sizeof(h_long), h_long));
-        if (h_long[ERR_LONG_ROWS]) {
-            PADNE_HIP_CHECK(hipMemsetAsync(d_err + ERR_LONG_ROWS, 0, sizeof(int), s));
-            hipLaunchKernelGGL(merge_rows_mesh_lds<kCap>, dim3(nblk(n_merge, 128)), dim3(128), 0, s, n_merge, n_vert, n_mesh,
-                               d_voff, d_sigma, slot_ptr, key, val, row_len, d_err, kCapSmall, row_list);
-            PADNE_HIP_CHECK(hipGetLastError());
-            PADNE_TRY(read_back(ctx, d_err, sizeof(h_long), h_long));
-        }
-        if (h_long[ERR_LONG_ROWS]) {               // rows with more than kCap slots (hubs): wave sort, then the global-memory merge
-            // (the hub rows sit next to each other in the list -- the vertices of a via ring: four rows per wave and turn
-            // spread them over the chip; with 64 a few waves sorted 64 long rows each, one after the other: 0.41 ms)
-            hipLaunchKernelGGL((sort_long_rows_wave<kWaveSortCap, 4>), dim3(std::min(nblk(n_merge, 16), 8192u)), dim3(256), 0, s,
-                               n_merge, row_list, slot_ptr, key, val, kCap + 1, 1);
-            hipLaunchKernelGGL(merge_rows<MESH>, dim3(nblk(n_merge, 128)), dim3(128), 0, s, n_merge, n_vert, n_mesh, d_voff,
-                               d_sigma, slot_ptr, key, val, row_len, d_err, kCap + 1, row_list, kWaveSortCap);
-            PADNE_HIP_CHECK(hipGetLastError());
-        }
-    } else if (!MESH) {
-        PADNE_TRY(merge_slots_generic(ctx, n_rows, slot_ptr, key, val, row_len));
     }
-    int h_err[ERR_WORDS];
-    PADNE_TRY(read_back(ctx, d_err, sizeof(h_err), h_err));
-    if (h_err[ERR_NONMANIFOLD] && !t_partial_mesh) {
-        set_error("Non-manifold mesh");
-        return PADNE_E_NONMANIFOLD;
+    if (h_long[ERR_LONG_ROWS]) {               // rows with more than kCap slots (hubs): wave sort, then the global-memory merge
+        // (the hub rows sit next to each other in the list -- the vertices of a via ring: four rows per wave and turn
+        // spread them over the chip; with 64 a few waves sorted 64 long rows each, one after the other: 0.41 ms)
+        hipLaunchKernelGGL((sort_long_rows_wave<kWaveSortCap, 4>), dim3(std::min(nblk(n_merge, 16), 8192u)), dim3(256), 0, s,
+                           n_merge, row_list, slot_ptr, key, val, kCap + 1, 1);
+        hipLaunchKernelGGL(merge_rows<true>, dim3(nblk(n_merge, 128)), dim3(128), 0, s, n_merge, n_vert, n_mesh, d_voff,
+                           d_sigma, slot_ptr, key, val, row_len, d_err, kCap + 1, row_list, kWaveSortCap);
+        PADNE_HIP_CHECK(hipGetLastError());
     }
+    return PADNE_OK;
+}
+
+// shared tail of the generic merge (padne_csr_reduce): slots already filled -> merged CSR
+static int finish_rows(padne_ctx *ctx, Scratch &sc, long long n_rows, long long n_cols, const int *slot_ptr, long long *key,
+                       double *val, padne_csr **out) {
+    hipStream_t s = ctx->stream;
+    int *row_len = nullptr;
+    PADNE_TRY(sc.alloc(&row_len, (size_t)n_rows + 1));
+    PADNE_TRY(merge_slots_generic(ctx, n_rows, slot_ptr, key, val, row_len));
     int *rowptr_tmp = nullptr;
     PADNE_TRY(sc.alloc(&rowptr_tmp, (size_t)n_rows + 1));
     int64_t nnz = 0;
@@ -1464,62 +1824,157 @@ extern "C" int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns, int64_t
     }
     PADNE_HIP_CHECK(hipMemsetAsync(d_err, 0, sizeof(int) * ERR_WORDS, s));
     // 1 one pass over the triangles: validation, incident triangles per vertex and their lists; stamps per row
-    int *d_ninc = nullptr, *d_ncoo = nullptr, *d_inc = nullptr, *d_rowlen = nullptr, *d_list = nullptr, *d_nslow = nullptr;
+    int *d_ninc = nullptr, *d_ncoo = nullptr, *d_rowlen = nullptr, *d_list = nullptr, *d_fans = nullptr, *d_nlisted = nullptr;
+    int2 *d_inc = nullptr;
     PADNE_TRY(sc.alloc(&d_ninc, (size_t)n_unknowns + 1));
     PADNE_TRY(sc.alloc(&d_ncoo, (size_t)n_unknowns + 1));
-    PADNE_TRY(sc.alloc(&d_inc, (size_t)n_vert * kIncCap));
+    PADNE_TRY(sc.alloc(&d_inc, (size_t)n_vert * kIncCap + 2));
     PADNE_TRY(sc.alloc(&d_rowlen, (size_t)n_unknowns + 1));
     PADNE_TRY(sc.alloc(&d_list, (size_t)n_unknowns + 1));
-    PADNE_TRY(sc.alloc(&d_nslow, 1));
+    PADNE_TRY(sc.alloc(&d_fans, (size_t)n_vert + 1));
+    PADNE_TRY(sc.alloc(&d_nlisted, 2));
     PADNE_HIP_CHECK(hipMemsetAsync(d_ninc, 0, sizeof(int) * (size_t)(n_unknowns + 1), s));
     PADNE_HIP_CHECK(hipMemsetAsync(d_ncoo, 0, sizeof(int) * (size_t)(n_unknowns + 1), s));
-    PADNE_HIP_CHECK(hipMemsetAsync(d_nslow, 0, sizeof(int), s));
+    PADNE_HIP_CHECK(hipMemsetAsync(d_nlisted, 0, sizeof(int) * 2, s));
     if (n_tri > 0)
         hipLaunchKernelGGL(asm_count_tri, dim3(nblk(n_tri)), dim3(256), 0, s, (long long)n_tri, d_tri, (int)n_mesh,
                            d_voff, d_toff, d_ninc, d_inc, d_err);
     if (n_coo > 0)
         hipLaunchKernelGGL(asm_count_coo, dim3(nblk(n_coo)), dim3(256), 0, s, (long long)n_coo, d_crow, d_ncoo);
-    hipLaunchKernelGGL(asm_slot_counts, dim3(nblk(n_unknowns + 1)), dim3(256), 0, s, (long long)n_unknowns + 1, (long long)n_vert,
-                       d_ninc, d_ncoo, d_cnt);
+    // 2 the rows that go through the slots (stamps, hubs, the unknowns behind the vertices; long fans): lists, slot counts, offsets
+    hipLaunchKernelGGL(asm_classify_rows, dim3(nblk(n_unknowns + 1)), dim3(256), 0, s, (long long)n_unknowns + 1,
+                       (long long)n_unknowns, (long long)n_vert, d_ninc, d_ncoo, d_cnt, d_list, d_fans, d_nlisted, d_err);
     PADNE_HIP_CHECK(hipGetLastError());
+    int64_t n_slots = 0;
+    PADNE_TRY(exclusive_scan_i32(ctx, d_cnt, d_slot, n_unknowns, &n_slots));
     int h_err[ERR_WORDS];
-    PADNE_TRY(read_back(ctx, d_err, sizeof(h_err), h_err));
+    int h_listed[2] = {0, 0};
+    PADNE_TRY(read_back2(ctx, d_err, sizeof(h_err), h_err, d_nlisted, sizeof(h_listed), h_listed));
     if (h_err[ERR_BAD_INDEX]) {
         set_error("triangle refers to a vertex outside its mesh, or repeats a vertex");
         return PADNE_E_INVALID;
     }
-    // 2 scan: slot offsets of the rows (a finished row is written at its slot offset, whichever path produces it)
-    int64_t n_slots = 0;
-    PADNE_TRY(exclusive_scan_i32(ctx, d_cnt, d_slot, n_unknowns, &n_slots));
+    const int h_slow = h_listed[0], h_fans = h_listed[1];
     long long *d_key = nullptr;
     double *d_val = nullptr;
-    PADNE_TRY(sc.alloc(&d_key, (size_t)n_slots));
-    PADNE_TRY(sc.alloc(&d_val, (size_t)n_slots));
-    // 3 mesh rows without stamps straight from the incidence lists; the others are listed for the slot path
-    if (n_vert > 0)
-        hipLaunchKernelGGL(asm_rows_from_incidence<kIncCap>, dim3(nblk(n_vert, 128)), dim3(128), 0, s, (long long)n_vert,
-                           (int)n_mesh, d_voff, d_sigma, d_tri, d_xy, d_ninc, d_inc, d_ncoo, d_slot, d_key, d_val, d_rowlen,
-                           d_err, d_list, d_nslow);
-    if (n_unknowns > n_vert)       // rows of internal nodes and extra unknowns: stamps only
-        hipLaunchKernelGGL(asm_list_tail_rows, dim3(nblk(n_unknowns - n_vert)), dim3(256), 0, s, (int)n_vert, (int)n_unknowns,
-                           d_rowlen, d_list, d_nslow);
-    PADNE_HIP_CHECK(hipGetLastError());
-    int h_slow = 0;
-    PADNE_TRY(read_back(ctx, d_nslow, sizeof(int), &h_slow));
-    // 4 the listed rows through the slots (cursor = 1: slot 0 of each row is the diagonal placeholder)
+    PADNE_TRY(sc.alloc(&d_key, (size_t)n_slots + 1));
+    PADNE_TRY(sc.alloc(&d_val, (size_t)n_slots + 1));
+    // 3 the listed rows: mesh terms from the incidence lists (the triangles again only when a hub's list is incomplete),
+    //   stamps behind them, merged in place at their slot offsets.  d_cnt has been scanned; it now serves as the cursor.
+    if (h_fans > 0)
+        hipLaunchKernelGGL(asm_rows_long_fans, dim3(nblk(h_fans, 128)), dim3(128), 0, s, (const int *)(d_nlisted + 1),
+                           (const int *)d_fans, (int)n_mesh, d_voff, d_sigma, d_xy, d_ninc, d_inc, d_slot, d_key, d_val, d_rowlen,
+                           d_err);
     if (h_slow > 0) {
-        hipLaunchKernelGGL(fill_value_i32, dim3(nblk(n_unknowns + 1)), dim3(256), 0, s, d_cnt, (long long)n_unknowns + 1, 1);
-        if (n_tri > 0)
+        hipLaunchKernelGGL(asm_fill_listed, dim3(nblk(h_slow)), dim3(256), 0, s, (const int *)d_nlisted, (const int *)d_list,
+                           (long long)n_vert, d_xy, d_ninc, d_inc, d_slot, d_cnt, d_key, d_val);
+        if (h_err[ERR_HUB] && n_tri > 0)
             hipLaunchKernelGGL(asm_fill_tri, dim3(nblk(n_tri)), dim3(256), 0, s, (long long)n_tri, d_tri, d_xy, (int)n_mesh,
-                               d_voff, d_toff, d_slot, d_cnt, d_key, d_val, (const int *)d_rowlen);
+                               d_voff, d_toff, d_slot, d_cnt, d_key, d_val, (const int *)d_ninc);
         if (n_coo > 0)
             hipLaunchKernelGGL(asm_fill_coo, dim3(nblk(n_coo)), dim3(256), 0, s, (long long)n_coo, d_crow, d_ccol, d_cval,
                                d_slot, d_cnt, d_key, d_val);
         PADNE_HIP_CHECK(hipGetLastError());
+        PADNE_TRY(merge_listed_mesh_rows(ctx, (long long)n_vert, (int)n_mesh, d_voff, d_sigma, d_slot, d_key, d_val, d_rowlen,
+                                         d_err, d_list, (long long)h_slow));
     }
-    // 5-7 merge of the slot rows, scan, compaction
-    PADNE_TRY(finish_rows<true>(ctx, sc, n_unknowns, n_unknowns, n_vert, (int)n_mesh, d_voff, d_sigma, d_slot, d_key,
-                                d_val, d_err, out, d_rowlen, d_list, (long long)h_slow));
+    // 4 every row, written once and in place: a mesh row holds at most one entry per triangle plus two, a listed row at
+    //   most its slots -- the arrays are sized by that bound, the single-pass scan inside the kernel finds the offsets
+    const long long nnz_bound = 3LL * n_tri + 2LL * n_vert + n_slots;
+    PADNE_REQUIRE(nnz_bound < 2147483647LL - kPadNnz, "too many entries for int32 indices");
+    padne_csr *m = nullptr;
+    PADNE_TRY(csr_alloc(ctx, n_unknowns, n_unknowns, nnz_bound, &m));
+    long long h_nnz = 0;
+    long long *d_nnz = nullptr;
+    int rc = PADNE_OK;
+    if (n_unknowns > 0) {
+        const long long n_tiles = (n_unknowns + 127) / 128, n_chunks = (n_tiles + kChunkTiles - 1) / kChunkTiles;
+        // one block of scan state: tile counts, chunk counts, chunk offsets (64-bit words), arrivals per chunk, ticket, abort
+        const size_t words64 = (size_t)n_tiles + 2 * (size_t)n_chunks + 64 + 2;
+        const size_t state_bytes = words64 * 8 + ((size_t)n_chunks + 4) * 4;
+        unsigned char *d_state = nullptr;
+        rc = sc.alloc(&d_state, state_bytes);
+        hipError_t e = hipSuccess;
+        if (rc == PADNE_OK) e = hipMemsetAsync(d_state, 0, state_bytes, s);
+        if (rc == PADNE_OK && e == hipSuccess) {
+            RowsInPlace args;
+            args.scan.tile_agg = (unsigned long long *)d_state;
+            args.scan.chunk_agg = args.scan.tile_agg + n_tiles;
+            args.scan.chunk_prefix = args.scan.chunk_agg + n_chunks + 64;     // (the scanner looks 64 chunks ahead)
+            args.scan.nnz_out = (long long *)(args.scan.chunk_prefix + n_chunks + 1);
+            args.scan.chunk_count = (int *)(d_state + words64 * 8);
+            args.scan.ticket = args.scan.chunk_count + n_chunks;
+            args.scan.abort_word = args.scan.ticket + 1;
+            args.scan.n_tiles = (int)n_tiles;
+            args.scan.n_chunks = (int)n_chunks;
+            // as many workers as the chip holds at once (a worker that is not resident simply takes no tickets), one scanner
+            int per_cu = 0, n_cu = 0;
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, asm_rows_in_place, 128, 0);
+            if (e == hipSuccess) e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+            const long long resident = (long long)std::max(per_cu, 1) * std::max(n_cu, 1);
+            const unsigned workers = (unsigned)std::max(1LL, std::min(n_tiles, resident - 1));
+            args.n_rows = n_unknowns;
+            args.n_vert = n_vert;
+            args.n_mesh = (int)n_mesh;
+            args.mesh_voff = d_voff;
+            args.sigma = d_sigma;
+            args.xy = d_xy;
+            args.n_inc = d_ninc;
+            args.inc = d_inc;
+            args.slot_ptr = d_slot;
+            args.row_len = d_rowlen;
+            args.rowptr = m->rowptr;
+            args.cols = m->cols;
+            args.vals = m->vals;
+            args.err = d_err;
+            d_nnz = args.scan.nnz_out;
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(asm_rows_in_place, dim3(workers + 1), dim3(128), 0, s, args);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess && h_slow > 0)
+                hipLaunchKernelGGL(asm_place_listed, dim3(std::min(nblk(h_slow, 4), 4096u)), dim3(256), 0, s, (const int *)d_nlisted,
+                                   (const int *)d_list, (const int *)d_slot, (const long long *)d_key, (const double *)d_val,
+                                   (const int *)m->rowptr, m->cols, m->vals);
+            if (e == hipSuccess && h_fans > 0)
+                hipLaunchKernelGGL(asm_place_listed, dim3(std::min(nblk(h_fans, 4), 4096u)), dim3(256), 0, s,
+                                   (const int *)(d_nlisted + 1), (const int *)d_fans, (const int *)d_slot, (const long long *)d_key,
+                                   (const double *)d_val, (const int *)m->rowptr, m->cols, m->vals);
+            if (e == hipSuccess) e = hipGetLastError();
+        }
+        if (rc == PADNE_OK && e != hipSuccess) {
+            set_error("row kernel failed: %s", hipGetErrorString(e));
+            rc = PADNE_E_HIP;
+        }
+        if (rc == PADNE_OK) rc = read_back2(ctx, d_err, sizeof(h_err), h_err, d_nnz, sizeof(long long), &h_nnz);
+        if (rc == PADNE_OK && h_err[ERR_SCAN]) {
+            set_error("the row offsets of the assembled system were not found (single-pass scan gave up)");
+            rc = PADNE_E_HIP;
+        }
+        if (rc == PADNE_OK && h_err[ERR_NONMANIFOLD] && !t_partial_mesh) {
+            set_error("Non-manifold mesh");
+            rc = PADNE_E_NONMANIFOLD;
+        }
+    } else {
+        PADNE_HIP_CHECK(hipMemsetAsync(m->rowptr, 0, sizeof(int32_t), s));
+    }
+    if (rc == PADNE_OK && (h_nnz < 0 || h_nnz > nnz_bound)) {
+        set_error("assembled %lld entries where at most %lld fit", h_nnz, nnz_bound);
+        rc = PADNE_E_HIP;
+    }
+    if (rc == PADNE_OK) {
+        // the padding behind the real end (column 0 / value 0.0, see csr_alloc), then the scratch goes back to the pool
+        rc = csr_shrink_nnz(ctx, m, h_nnz);
+        if (rc == PADNE_OK && hipStreamSynchronize(s) != hipSuccess) {
+            set_error("assembly failed: %s", hipGetErrorString(hipGetLastError()));
+            rc = PADNE_E_HIP;
+        }
+    }
+    if (rc != PADNE_OK) {
+        padne_csr_destroy(m);
+        return rc;
+    }
+    *out = m;
     padne_csr *res = *out;
     res->mesh_xy = d_xy;
     res->mesh_tri = d_tri;
@@ -1658,7 +2113,7 @@ int csr_relabel(padne_ctx *ctx, const padne_csr *m, const int32_t *row_map_host,
         hipLaunchKernelGGL(reduce_fill, dim3(nblk(m->n_rows)), dim3(256), 0, s, (long long)m->n_rows, m->rowptr, m->cols,
                            m->vals, d_map, d_cmap, scale, d_slot, d_cnt, d_key, d_val);
     PADNE_HIP_CHECK(hipGetLastError());
-    return finish_rows<false>(ctx, sc, n_rows_out, n_cols_out, 0, 0, nullptr, nullptr, d_slot, d_key, d_val, d_err, out);
+    return finish_rows(ctx, sc, n_rows_out, n_cols_out, d_slot, d_key, d_val, out);
 }
 }  // namespace padne
 

@@ -256,6 +256,15 @@ int csr_alloc(padne_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, padne
     return PADNE_OK;
 }
 
+// a matrix allocated for an upper bound of its entries learns the real count: the padding moves behind the real end
+int csr_shrink_nnz(padne_ctx *ctx, padne_csr *m, int64_t nnz) {
+    PADNE_REQUIRE(nnz >= 0 && nnz <= m->nnz, "entry count beyond the allocation");
+    m->nnz = nnz;
+    hipLaunchKernelGGL(csr_zero_pads, dim3(kPadNnz / 256), dim3(256), 0, ctx->stream, m->cols + nnz, m->vals + nnz);
+    PADNE_HIP_CHECK(hipGetLastError());
+    return PADNE_OK;
+}
+
 __global__ void dot_partial_kernel(const long long n, const double *__restrict__ a, const double *__restrict__ b,
                                    double *__restrict__ partials) {
     __shared__ double red[4];

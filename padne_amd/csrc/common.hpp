@@ -136,6 +136,7 @@ namespace padne {
 
 int ensure_workspace(padne_ctx *ctx, size_t bytes);
 int csr_alloc(padne_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, padne_csr **out);
+int csr_shrink_nnz(padne_ctx *ctx, padne_csr *m, int64_t nnz);      // allocated for a bound, nnz known later
 int csr_build_dinv(padne_ctx *ctx, padne_csr *m);
 
 // kernels launched from several translation units

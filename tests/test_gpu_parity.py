@@ -1417,6 +1417,57 @@ def test_headline_config_on_eight_ranks(ctx):
     assert res.rel_residual <= 1.1e-12 and res.levels >= 4 and 20 <= iters <= 45
 
 
+def test_assemblies_running_side_by_side_on_one_gpu_are_the_serial_result(ctx):
+    """The row kernel finds its offsets with a scan that runs INSIDE it (workgroups publish counts, a scanner wave the
+    offsets; `asm_rows_in_place`).  Six contexts assemble six different systems on the same GPU at the same time --
+    their workgroups share the chip, none of the kernels has it to itself -- and each result is the one the same
+    context produces alone, bit for bit; twice, so that a wrong order of two memory operations has chances to show."""
+    import threading
+    systems = [synthetic.layered_system(3, 260 + 7 * k, 230 + 5 * k, via_lattice=9) for k in range(6)]
+
+    def arrays(sysm):
+        N = sysm.n_vertices + 1
+        a, b, r = sysm.resistors                             # stamps in the reference's order (solver.py:475-492, 558-560)
+        g = 1.0 / r
+        rows = np.concatenate([np.stack([a, a, b, b], 1).reshape(-1), [N - 1, sysm.ground]])
+        cols = np.concatenate([np.stack([a, b, b, a], 1).reshape(-1), [sysm.ground, N - 1]])
+        vals = np.concatenate([np.stack([-g, g, -g, g], 1).reshape(-1), [1.0, 1.0]])
+        return N, (rows, cols, vals)
+
+    def assemble(c, sysm, prepared):
+        N, (rows, cols, vals) = prepared
+        xy = np.concatenate([m[0] for m in sysm.meshes])
+        tri = np.concatenate([m[1] for m in sysm.meshes]).astype(np.int32)
+        mvo = np.cumsum([0] + [len(m[0]) for m in sysm.meshes]).astype(np.int64)
+        mto = np.cumsum([0] + [len(m[1]) for m in sysm.meshes]).astype(np.int64)
+        sig = np.array([m[2] for m in sysm.meshes], dtype=np.float64)
+        L = c.assemble_system(N, xy, tri, mvo, mto, sig, rows, cols, vals)
+        A = L.to_scipy()
+        L.close()
+        return A
+
+    prepared = [arrays(sm) for sm in systems]
+    alone = [assemble(ctx, sm, p) for sm, p in zip(systems, prepared)]
+    for _ in range(2):
+        out, errors = [None] * len(systems), []
+
+        def worker(k):
+            try:
+                out[k] = assemble(_hip.Context(0), systems[k], prepared[k])
+            except BaseException as exc:
+                errors.append((k, exc))
+        threads = [threading.Thread(target=worker, args=(k,), daemon=True) for k in range(len(systems))]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join(timeout=120)
+        assert not errors, errors
+        for A, B in zip(alone, out):
+            assert B is not None
+            assert np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices)
+            assert np.array_equal(A.data.view(np.int64), B.data.view(np.int64))
+
+
 def test_randomised_assembly_is_the_oracle_bit_for_bit(ctx):
     """scripts/fuzz_assembly.py: random Delaunay meshes (holes, fans with more triangles around a vertex than the
     incidence lists hold), random conductances and stamps, a hub row -- structure and values identical to the oracle."""
