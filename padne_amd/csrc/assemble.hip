@@ -1203,99 +1203,132 @@ __global__ void merge_rows(long long n_rows, long long n_vert, int n_mesh,
     row_len[r] = o;
 }
 
-// LDS variant of merge_rows<true> for the (overwhelmingly common) mesh rows with at most CAP slots: the row's
-// slots are insertion-sorted while being loaded into LDS ([slot][thread] layout) and then walked exactly like
-// merge_rows<true> does -- same operations in the same order, hence bit-identical matrices.  Rows with more
-// slots (hubs of lumped elements) are left to merge_rows<true> (min_len = CAP + 1).
-template <int CAP>
-__global__ __launch_bounds__(128) void merge_rows_mesh_lds(long long n_rows, long long n_vert, int n_mesh,
-                                                           const long long *__restrict__ mesh_voff,
-                                                           const double *__restrict__ sigma,
-                                                           const int *__restrict__ slot_ptr, long long *__restrict__ key,
-                                                           double *__restrict__ val, int *__restrict__ row_len,
-                                                           int *__restrict__ err, const int skip_upto,
-                                                           const int *__restrict__ row_list) {
-    __shared__ long long Kc[CAP][128];
-    __shared__ double Vc[CAP][128];
-    const int t = threadIdx.x;
-    const long long idx = (long long)blockIdx.x * 128 + t;
-    if (idx >= n_rows) return;
-    const long long r = row_list != nullptr ? row_list[idx] : idx;
-    const int s0 = slot_ptr[r];
-    const int n = slot_ptr[r + 1] - s0;
-    if (n <= skip_upto) return;                    // merged by the previous, smaller pass
-    if (n > CAP) {
-        // the host then launches the next larger pass for these rows.  A plain store of the same value by one lane per
-        // wave: on an unstructured mesh a few per cent of the rows land here, and as many atomics on one address serialise
-        const unsigned long long m = __ballot(true);
-        if ((threadIdx.x & 63) == __ffsll((long long)m) - 1) *(volatile int *)&err[ERR_LONG_ROWS] = 1;
-        return;
-    }
-    for (int i = 0; i < n; ++i) {
-        // slot 0 is the row's diagonal placeholder (sequence 2, value 0): it is never written to global memory,
-        // every merge kernel supplies it itself
-        const long long k = i == 0 ? make_key((int)r, 2) : key[s0 + i];
-        const double v = i == 0 ? 0.0 : val[s0 + i];
-        int j = i - 1;
-        while (j >= 0 && Kc[j][t] > k) {
-            Kc[j + 1][t] = Kc[j][t];
-            Vc[j + 1][t] = Vc[j][t];
-            --j;
+// The listed rows of the assembled system, one WAVE per row (rows of up to kMergeWaveCap slots; the few beyond it are
+// flagged and go through sort_long_rows_wave + merge_rows<true>).  The slots are rank-sorted by key in LDS, every lane
+// that holds the first slot of a column walks that column's slots in key order -- the two mesh terms, then the stamps,
+// exactly as merge_rows<true> adds them -- one lane adds up the diagonal over the columns in ascending order, the kept
+// entries are written back compactly at the slot offset.  Same operations in the same order as the one-lane kernels,
+// hence the same bits; it replaces three passes of one lane per row (33 + 64 + 91 us for the 18 k listed rows of config
+// C4, each followed by a look at a flag on the host) by one of a few us per wave.
+constexpr int kMergeWaveCap = 256;
+__global__ __launch_bounds__(256) void merge_rows_mesh_wave(const int *__restrict__ n_list, const int *__restrict__ row_list,
+                                                            long long n_vert, int n_mesh, const long long *__restrict__ mesh_voff,
+                                                            const double *__restrict__ sigma, const int *__restrict__ slot_ptr,
+                                                            long long *__restrict__ key, double *__restrict__ val,
+                                                            int *__restrict__ row_len, int *__restrict__ err) {
+    __shared__ long long Ku[4][kMergeWaveCap], Ks[4][kMergeWaveCap];      // unsorted (later: mesh sums per column) / sorted keys
+    __shared__ double Vu[4][kMergeWaveCap], Vs[4][kMergeWaveCap];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    long long *ku = Ku[wv], *ks = Ks[wv];
+    double *vu = Vu[wv], *vs = Vs[wv];
+    double *gm = reinterpret_cast<double *>(ku);            // mesh sum of the column that starts at a slot
+    const int n_rows = *n_list;
+    for (int idx = blockIdx.x * 4 + wv; idx < n_rows; idx += gridDim.x * 4) {
+        const int r = row_list[idx];
+        const int s0 = slot_ptr[r], n = slot_ptr[r + 1] - s0;
+        if (n > kMergeWaveCap) {
+            if (lane == 0) *(volatile int *)&err[ERR_LONG_ROWS] = 1;
+            continue;
         }
-        Kc[j + 1][t] = k;
-        Vc[j + 1][t] = v;
-    }
-    double sig = 0.0;
-    double dacc = 0.0;
-    if (r < n_vert) {
-        sig = sigma[find_segment(mesh_voff, n_mesh, r)];
+        for (int e = lane; e < n; e += 64) {
+            // slot 0 is the row's diagonal placeholder (sequence 2, value 0): nobody wrote it
+            ku[e] = e == 0 ? make_key(r, 2) : key[s0 + e];
+            vu[e] = e == 0 ? 0.0 : val[s0 + e];
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        for (int e = lane; e < n; e += 64) {
+            const long long k = ku[e];
+            int rank = 0;
+            for (int f = 0; f < n; ++f) {
+                const long long kf = ku[f];
+                rank += (kf < k || (kf == k && f < e)) ? 1 : 0;
+            }
+            ks[rank] = k;
+            vs[rank] = vu[e];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const bool mesh_row = r < n_vert;
+        const double sig = mesh_row ? sigma[find_segment(mesh_voff, n_mesh, r)] : 0.0;
+        // pass 1: the mesh terms of every column (held by the lane of the column's first slot)
         int fwd_only = 0, bwd_only = 0;
-        int i = 0;
-        while (i < n) {
-            const int col = (int)(Kc[i][t] >> 32);
-            int terms = 0, seq_sum = 0;
+        bool bad = false;
+        for (int e = lane; e < n; e += 64) {
+            const int c = (int)(ks[e] >> 32);
+            const bool head = e == 0 || (int)(ks[e - 1] >> 32) != c;
             double wm = 0.0;
-            while (i < n && (int)(Kc[i][t] >> 32) == col && (unsigned)(Kc[i][t] & 0xffffffffLL) < 2u) {
-                wm = (terms == 0) ? Vc[i][t] : wm + Vc[i][t];
-                seq_sum += (int)(Kc[i][t] & 0xffffffffLL);
-                ++terms;
-                ++i;
+            if (head && mesh_row) {
+                int terms = 0, seq_sum = 0, i = e;
+                while (i < n && (int)(ks[i] >> 32) == c && (unsigned)(ks[i] & 0xffffffffLL) < 2u) {
+                    wm = (terms == 0) ? vs[i] : wm + vs[i];              // 0. + c1 + c2   mesh.py:131-138
+                    seq_sum += (int)(ks[i] & 0xffffffffLL);
+                    ++terms;
+                    ++i;
+                }
+                // an interior edge has one forward and one backward term; anything else is the "Non-manifold mesh" of
+                // mesh.py:342-343 (or a doubly used directed edge)
+                if (terms > 2 || (terms == 2 && seq_sum != 1)) bad = true;
+                if (terms == 1) { if (seq_sum == 0) ++fwd_only; else ++bwd_only; }
+                if (terms == 0) wm = 0.0;
             }
-            while (i < n && (int)(Kc[i][t] >> 32) == col) ++i;
-            if (terms > 2 || (terms == 2 && seq_sum != 1)) atomicExch(&err[ERR_NONMANIFOLD], 1);
-            if (terms == 1) { if (seq_sum == 0) ++fwd_only; else ++bwd_only; }
-            if (terms > 0 && wm != 0.0) dacc = dacc - wm;
+            gm[e] = wm;                                                 // (0 where no column starts: adds nothing below)
         }
-        if (fwd_only > 1 || bwd_only > 1) atomicExch(&err[ERR_NONMANIFOLD], 1);
-    }
-    int o = 0;
-    int i = 0;
-    while (i < n) {
-        const int col = (int)(Kc[i][t] >> 32);
-        double v = 0.0;
-        if (col == (int)r) {
-            v = sig * dacc;
-        } else {
-            int terms = 0;
-            double wm = 0.0;
-            while (i < n && (int)(Kc[i][t] >> 32) == col && (unsigned)(Kc[i][t] & 0xffffffffLL) < 2u) {
-                wm = (terms == 0) ? Vc[i][t] : wm + Vc[i][t];
-                ++terms;
-                ++i;
+        for (int off = 32; off > 0; off >>= 1) {
+            fwd_only += __shfl_xor(fwd_only, off, 64);
+            bwd_only += __shfl_xor(bwd_only, off, 64);
+        }
+        if (__ballot(bad) != 0ull || fwd_only > 1 || bwd_only > 1) {
+            if (lane == 0) atomicExch(&err[ERR_NONMANIFOLD], 1);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // the diagonal: -(w_1 + w_2 + ...) in ascending column order, zero weights skipped   (solver.py:187-190, 203)
+        double dacc = 0.0;
+        if (mesh_row) {
+            if (lane == 0)
+                for (int e = 0; e < n; ++e) {
+                    const double wm = gm[e];
+                    if (wm != 0.0) dacc = dacc - wm;
+                }
+            dacc = __shfl(dacc, 0, 64);
+        }
+        // pass 2: value of every column, stamps added in stamp order; exact zeros are not stored
+        int base = 0;
+        for (int e0 = 0; e0 < n; e0 += 64) {
+            const int e = e0 + lane;
+            bool keep = false;
+            int c = 0;
+            double v = 0.0;
+            if (e < n) {
+                c = (int)(ks[e] >> 32);
+                const bool head = e == 0 || (int)(ks[e - 1] >> 32) != c;
+                if (head) {
+                    int i = e;
+                    while (i < n && (int)(ks[i] >> 32) == c && (unsigned)(ks[i] & 0xffffffffLL) < 2u) ++i;
+                    if (mesh_row) {
+                        if (c == r) v = sig * dacc;                     // conductance * (diagonal entry)
+                        else if (i > e) v = sig * gm[e];                // conductance * laplace_operator(msh)
+                    }
+                    while (i < n && (int)(ks[i] >> 32) == c) {          // L[i,j] += stamp, in stamp order
+                        v = v + vs[i];
+                        ++i;
+                    }
+                    keep = v != 0.0;
+                }
             }
-            if (terms > 0) v = sig * wm;
+            const unsigned long long mk = __ballot(keep);
+            if (keep) {
+                const int o = base + __popcll(mk & ((1ull << lane) - 1ull));
+                key[s0 + o] = (long long)c << 32;
+                val[s0 + o] = v;
+            }
+            base += __popcll(mk);
         }
-        while (i < n && (int)(Kc[i][t] >> 32) == col) {
-            v = v + Vc[i][t];
-            ++i;
-        }
-        if (v != 0.0) {
-            key[s0 + o] = (long long)col << 32;
-            val[s0 + o] = v;
-            ++o;
-        }
+        if (lane == 0) row_len[r] = base;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // LDS is reused by the next row
+        __builtin_amdgcn_wave_barrier();
     }
-    row_len[r] = o;
 }
 
 // Short rows of the generic merge: sort and add duplicates inside LDS ([slot][thread] layout), one lane per row.
@@ -1574,31 +1607,21 @@ static thread_local bool t_partial_mesh = false;
 // the listed rows of the assembled system, merged in place at their slot offsets (row_len = what each keeps)
 static int merge_listed_mesh_rows(padne_ctx *ctx, long long n_vert, int n_mesh, const long long *d_voff, const double *d_sigma,
                                   const int *slot_ptr, long long *key, double *val, int *row_len, int *d_err,
-                                  const int *row_list, long long n_merge) {
+                                  const int *row_list, const int *n_list_dev, long long n_merge) {
     hipStream_t s = ctx->stream;
     if (n_merge <= 0) return PADNE_OK;
-    // rows of up to 20 slots (vertices of degree <= 9) first: 40 KiB of LDS per 128 rows, twice the waves per CU of the
-    // 32-slot pass, which only runs for meshes that have longer rows; beyond that (hubs) the global-memory merge
-    constexpr int kCapSmall = 20, kCap = 32;
-    hipLaunchKernelGGL(merge_rows_mesh_lds<kCapSmall>, dim3(nblk(n_merge, 128)), dim3(128), 0, s, n_merge, n_vert, n_mesh,
-                       d_voff, d_sigma, slot_ptr, key, val, row_len, d_err, 0, row_list);
+    // one wave per row; a row beyond its capacity (a hub of hundreds of lumped elements) is flagged and takes the wave
+    // sort + the one-lane global-memory merge
+    hipLaunchKernelGGL(merge_rows_mesh_wave, dim3(std::min(nblk(n_merge, 4), 8192u)), dim3(256), 0, s, n_list_dev, row_list,
+                       n_vert, n_mesh, d_voff, d_sigma, slot_ptr, key, val, row_len, d_err);
     PADNE_HIP_CHECK(hipGetLastError());
     int h_long[ERR_WORDS];
     PADNE_TRY(read_back(ctx, d_err, sizeof(h_long), h_long));
     if (h_long[ERR_LONG_ROWS]) {
-        PADNE_HIP_CHECK(hipMemsetAsync(d_err + ERR_LONG_ROWS, 0, sizeof(int), s));
-        hipLaunchKernelGGL(merge_rows_mesh_lds<kCap>, dim3(nblk(n_merge, 128)), dim3(128), 0, s, n_merge, n_vert, n_mesh,
-                           d_voff, d_sigma, slot_ptr, key, val, row_len, d_err, kCapSmall, row_list);
-        PADNE_HIP_CHECK(hipGetLastError());
-        PADNE_TRY(read_back(ctx, d_err, sizeof(h_long), h_long));
-    }
-    if (h_long[ERR_LONG_ROWS]) {               // rows with more than kCap slots (hubs): wave sort, then the global-memory merge
-        // (the hub rows sit next to each other in the list -- the vertices of a via ring: four rows per wave and turn
-        // spread them over the chip; with 64 a few waves sorted 64 long rows each, one after the other: 0.41 ms)
         hipLaunchKernelGGL((sort_long_rows_wave<kWaveSortCap, 4>), dim3(std::min(nblk(n_merge, 16), 8192u)), dim3(256), 0, s,
-                           n_merge, row_list, slot_ptr, key, val, kCap + 1, 1);
+                           n_merge, row_list, slot_ptr, key, val, kMergeWaveCap + 1, 1);
         hipLaunchKernelGGL(merge_rows<true>, dim3(nblk(n_merge, 128)), dim3(128), 0, s, n_merge, n_vert, n_mesh, d_voff,
-                           d_sigma, slot_ptr, key, val, row_len, d_err, kCap + 1, row_list, kWaveSortCap);
+                           d_sigma, slot_ptr, key, val, row_len, d_err, kMergeWaveCap + 1, row_list, kWaveSortCap);
         PADNE_HIP_CHECK(hipGetLastError());
     }
     return PADNE_OK;
@@ -1876,7 +1899,7 @@ extern "C" int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns, int64_t
                                d_slot, d_cnt, d_key, d_val);
         PADNE_HIP_CHECK(hipGetLastError());
         PADNE_TRY(merge_listed_mesh_rows(ctx, (long long)n_vert, (int)n_mesh, d_voff, d_sigma, d_slot, d_key, d_val, d_rowlen,
-                                         d_err, d_list, (long long)h_slow));
+                                         d_err, d_list, d_nlisted, (long long)h_slow));
     }
     // 4 every row, written once and in place: a mesh row holds at most one entry per triangle plus two, a listed row at
     //   most its slots -- the arrays are sized by that bound, the single-pass scan inside the kernel finds the offsets
