@@ -10,19 +10,21 @@
 // compute_triangle_gradient / compute_power_density (solver.py:689-745).
 //
 // Pipeline (no global sort, no float atomics, bitwise reproducible):
-//   1 count   every triangle adds 2 slots to each of its 3 vertex rows, every stamp 1 slot
-//   2 scan    exclusive scan of the slot counts
-//   3 fill    every triangle computes its three |cot|/2 terms once and scatters the 6 directed
-//             entries into the row slots (an int atomic only hands out the slot number; the
-//             values are plain stores); stamps follow with their sequence number
-//   4 merge   one lane per row: sort the handful of slots by (column, sequence), add the (at
-//             most two) mesh terms of an edge, scale by the sheet conductance, add stamps in
-//             stamp order, form the diagonal -(w_1 + w_2 + ...) in ascending column order,
-//             drop exact zeros, compact in place
-//   5 scan    row lengths -> row pointers
-//   6 copy    compacted rows -> final CSR arrays
-// Because the sort key fixes the summation order, the values do not depend on the order in
-// which the atomics handed out slots.
+//   1 lists   one pass over the triangles validates them and gives every vertex the list of its incident triangles,
+//             each as the pair of its two other corners (integer atomics hand out list positions; nothing depends on
+//             the order inside a list)
+//   2 listed  rows that cannot be built from a list alone -- stamps, hubs of more triangles than a list holds, the
+//             unknowns behind the vertices -- get slots (diagonal placeholder, two per triangle, one per stamp); their
+//             terms are sorted by (column, sequence) and merged by one wave per row: the two mesh terms of an edge,
+//             scaled by the sheet conductance, stamps in stamp order, the diagonal -(w_1 + w_2 + ...) in ascending
+//             column order, exact zeros dropped.  Vertices with 9..12 triangles are built like step 3 into slots.
+//   3 rows    one lane per mesh vertex builds its row in registers from the list (pairwise match of the fan's edges,
+//             compare-exchange network by column) -- the same additions in the same order as step 2 -- and the rows
+//             are written ONCE, in place: the row kernel is persistent, a scanner wave inside it turns the entry counts
+//             its workgroups publish into offsets while they build their next tile (asm_rows_in_place)
+//   4 place   the listed rows move from their slots to the room step 3 left for them
+// Because the sort key fixes the summation order, the values do not depend on the order in which the atomics handed out
+// list positions or slots.
 //
 // This file is compiled with -ffp-contract=off: the cotangent and gradient expressions must
 // round exactly like the reference's Python floats (no fused multiply-add).
@@ -303,41 +305,67 @@ __device__ __forceinline__ int find_segment(const long long *__restrict__ offs, 
 // coordinates, three dependent gathers, and read every triangle three times).  The order inside a list is left to the
 // atomics: nothing below depends on it.
 constexpr int kIncCap = 12;
-// The triangles of a workgroup usually touch a short range of vertices (256 consecutive triangles of a scan-line or
+// The first kFanShort entries of all lists lie together, 64 bytes per vertex -- what almost every vertex needs and all the
+// row kernel reads; the remaining entries of all lists follow behind them (touched for the few vertices that have more).
+constexpr int kFanShort = 8;
+__device__ __forceinline__ long long inc_at(const long long v, const int pos, const long long n_vert) {
+    return pos < kFanShort ? v * kFanShort + pos : n_vert * kFanShort + v * (kIncCap - kFanShort) + (pos - kFanShort);
+}
+// The triangles of a workgroup usually touch a short range of vertices (512 consecutive triangles of a scan-line or
 // strip-ordered mesh: two mesh lines, about as many distinct vertices as triangles, each touched three times).  Then
 // the corners are counted with LDS atomics first and the global counter of a vertex is advanced ONCE per workgroup by
 // the number of its corners here: a third of the global atomics.  A workgroup whose vertices span more than
 // kCntRange indices (unordered triangle lists) counts every corner globally, as before.
 constexpr int kCntRange = 4096;
+struct __attribute__((packed, aligned(4))) Int3 { int a, b, c; };
+constexpr int kCntTris = 2;           // triangles per thread (1: 441 us, 2: 417 us, 4: 443 us at N = 10 M): the dependent steps below (range,
+                                      // LDS counts, global counters, list entries) are paid once per 512 triangles
 __global__ __launch_bounds__(256) void asm_count_tri(long long n_tri, const int *__restrict__ tri, int n_mesh,
                                                      const long long *__restrict__ mesh_voff,
                                                      const long long *__restrict__ mesh_toff, int *__restrict__ cnt,
                                                      int2 *__restrict__ inc, int *__restrict__ err) {
     __shared__ int lcnt[kCntRange], lbase[kCntRange];
-    __shared__ long long s_min, s_max;
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ int s_min, s_max;
     if (threadIdx.x == 0) {
-        s_min = 0x7fffffffffffffffLL;
+        s_min = 0x7fffffff;
         s_max = -1;
     }
     __syncthreads();
-    bool ok = false;
-    long long g[3] = {0, 0, 0};
-    if (t < n_tri) {
-        const int m = find_segment(mesh_toff, n_mesh, t);
-        const long long v0 = mesh_voff[m];
-        const long long nv = mesh_voff[m + 1] - v0;
-        const int a = tri[3 * t], b = tri[3 * t + 1], c = tri[3 * t + 2];
-        if (a < 0 || b < 0 || c < 0 || a >= nv || b >= nv || c >= nv || a == b || b == c || a == c) {
-            atomicExch(&err[ERR_BAD_INDEX], 1);
-        } else {
-            ok = true;
-            g[0] = v0 + a;
-            g[1] = v0 + b;
-            g[2] = v0 + c;
+    // every XCD takes one contiguous eighth of the triangles (workgroups are dealt to the XCDs round robin): the two or
+    // three workgroups that fill a vertex's list then share an L2, and the list leaves it once, complete
+    const long long n_vert = mesh_voff[n_mesh];
+    const unsigned per_xcd = gridDim.x >> 3;
+    const unsigned wg = blockIdx.x >= (per_xcd << 3) ? blockIdx.x : (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    bool ok[kCntTris];
+    int g[kCntTris][3];
+    int lo = 0x7fffffff, hi = -1;
+    // the mesh of the workgroup's first and last triangle: almost always the same one, then nobody searches the table
+    const long long t_first = (long long)wg * kCntTris * 256;
+    const long long t_last = min(t_first + kCntTris * 256, n_tri) - 1;
+    const int m_first = find_segment(mesh_toff, n_mesh, t_first), m_last = find_segment(mesh_toff, n_mesh, t_last);
+#pragma unroll
+    for (int u = 0; u < kCntTris; ++u) {
+        const long long t = t_first + u * 256 + threadIdx.x;
+        ok[u] = false;
+        g[u][0] = g[u][1] = g[u][2] = 0;
+        if (t < n_tri) {
+            const int m = m_first == m_last ? m_first : find_segment(mesh_toff, n_mesh, t);
+            const long long v0 = mesh_voff[m];
+            const long long nv = mesh_voff[m + 1] - v0;
+            const Int3 c3 = *reinterpret_cast<const Int3 *>(tri + 3 * t);      // one 12-byte load
+            const int a = c3.a, b = c3.b, c = c3.c;
+            if (a < 0 || b < 0 || c < 0 || a >= nv || b >= nv || c >= nv || a == b || b == c || a == c) {
+                atomicExch(&err[ERR_BAD_INDEX], 1);
+            } else {
+                ok[u] = true;
+                g[u][0] = (int)(v0 + a);
+                g[u][1] = (int)(v0 + b);
+                g[u][2] = (int)(v0 + c);
+                lo = min(lo, min(g[u][0], min(g[u][1], g[u][2])));
+                hi = max(hi, max(g[u][0], max(g[u][1], g[u][2])));
+            }
         }
     }
-    long long lo = ok ? min(g[0], min(g[1], g[2])) : 0x7fffffffffffffffLL, hi = ok ? max(g[0], max(g[1], g[2])) : -1;
     for (int off = 32; off > 0; off >>= 1) {
         lo = min(lo, __shfl_down(lo, off, 64));
         hi = max(hi, __shfl_down(hi, off, 64));
@@ -347,36 +375,41 @@ __global__ __launch_bounds__(256) void asm_count_tri(long long n_tri, const int 
         atomicMax(&s_max, hi);
     }
     __syncthreads();
-    const long long base = s_min;
-    const long long range = s_max - base + 1;
-    if (range <= 0) return;                               // no valid triangle in this workgroup
+    const int base = s_min;
+    const long long range = (long long)s_max - base + 1;
+    if (s_max < 0) return;                                // no valid triangle in this workgroup
     if (range > kCntRange) {
-        if (ok)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int pos = atomicAdd(&cnt[g[q]], 1);      // incident triangles per vertex; a row owns two slots per incidence
-                if (pos < kIncCap) inc[g[q] * kIncCap + pos] = make_int2((int)g[(q + 1) % 3], (int)g[(q + 2) % 3]);
-            }
+        for (int u = 0; u < kCntTris; ++u)
+            if (ok[u])
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int pos = atomicAdd(&cnt[g[u][q]], 1);      // incident triangles per vertex
+                    if (pos < kIncCap) inc[inc_at(g[u][q], pos, n_vert)] = make_int2(g[u][(q + 1) % 3], g[u][(q + 2) % 3]);
+                }
         return;
     }
     for (int j = threadIdx.x; j < (int)range; j += 256) lcnt[j] = 0;
     __syncthreads();
-    int lpos[3] = {0, 0, 0};
-    if (ok)
+    int lpos[kCntTris][3];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) lpos[q] = atomicAdd(&lcnt[(int)(g[q] - base)], 1);
+    for (int u = 0; u < kCntTris; ++u)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) lpos[u][q] = ok[u] ? atomicAdd(&lcnt[g[u][q] - base], 1) : 0;
     __syncthreads();
     for (int j = threadIdx.x; j < (int)range; j += 256) {
         const int c = lcnt[j];
         lbase[j] = c > 0 ? atomicAdd(&cnt[base + j], c) : 0;
     }
     __syncthreads();
-    if (ok)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int pos = lbase[(int)(g[q] - base)] + lpos[q];
-            if (pos < kIncCap) inc[g[q] * kIncCap + pos] = make_int2((int)g[(q + 1) % 3], (int)g[(q + 2) % 3]);
-        }
+    for (int u = 0; u < kCntTris; ++u)
+        if (ok[u])
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int pos = lbase[g[u][q] - base] + lpos[u][q];
+                if (pos < kIncCap) inc[inc_at(g[u][q], pos, n_vert)] = make_int2(g[u][(q + 1) % 3], g[u][(q + 2) % 3]);
+            }
 }
 
 // Which rows go through the slots.  A mesh vertex without stamps and with at most kFanShort triangles is built by
@@ -384,7 +417,6 @@ __global__ __launch_bounds__(256) void asm_count_tri(long long n_tri, const int 
 // still complete) is built the same way by asm_rows_long_fans, into T + 2 slots.  Every other row (stamps, a hub of more
 // than kIncCap triangles, internal nodes and extra unknowns behind the vertices) owns its diagonal placeholder, two slots
 // per incident triangle and one per stamp, and is merged by the slot kernels.  Two lists, one append per wave and list.
-constexpr int kFanShort = 8;
 __global__ __launch_bounds__(256) void asm_classify_rows(long long n, long long n_rows, long long n_vert,
                                                          const int *__restrict__ n_inc, const int *__restrict__ n_coo,
                                                          int *__restrict__ cnt, int *__restrict__ slow_list,
@@ -497,7 +529,7 @@ __global__ __launch_bounds__(256) void asm_fill_listed(const int *__restrict__ n
     const double2 pv = reinterpret_cast<const double2 *>(xy)[r];
     const int s0 = slot_ptr[r];
     for (int q = 0; q < T; ++q) {
-        const int2 jk = inc[(long long)r * kIncCap + q];
+        const int2 jk = inc[inc_at(r, q, n_vert)];
         const double2 pj = reinterpret_cast<const double2 *>(xy)[jk.x], pk = reinterpret_cast<const double2 *>(xy)[jk.y];
         key[s0 + 1 + 2 * q] = make_key(jk.x, 0);
         val[s0 + 1 + 2 * q] = cot_half(pv.x, pv.y, pj.x, pj.y, pk.x, pk.y);      // edge r -> j, opposite k
@@ -779,7 +811,7 @@ __device__ __forceinline__ void fan_row_store(const int r, const int (&col)[RC +
 // one): the same register algorithm over the whole list, the row goes to the vertex's slots -- finished, nothing left to
 // merge -- and is placed with the listed rows.  Keeps the long variant's registers out of the kernel every row runs.
 __global__ __launch_bounds__(128) void asm_rows_long_fans(const int *__restrict__ n_list, const int *__restrict__ row_list,
-                                                          int n_mesh, const long long *__restrict__ mesh_voff,
+                                                          long long n_vert, int n_mesh, const long long *__restrict__ mesh_voff,
                                                           const double *__restrict__ sigma, const double *__restrict__ xy,
                                                           const int *__restrict__ n_inc, const int2 *__restrict__ inc,
                                                           const int *__restrict__ slot_ptr, long long *__restrict__ key,
@@ -790,9 +822,11 @@ __global__ __launch_bounds__(128) void asm_rows_long_fans(const int *__restrict_
     const int r = row_list[idx];
     const int T = n_inc[r];
     int4 pairs[kIncCap / 2];
-    const int4 *lst = reinterpret_cast<const int4 *>(inc + (long long)r * kIncCap);
+    const int4 *lst = reinterpret_cast<const int4 *>(inc + inc_at(r, 0, n_vert)), *more = reinterpret_cast<const int4 *>(inc + inc_at(r, kFanShort, n_vert));
 #pragma unroll
-    for (int q = 0; q < kIncCap / 2; ++q) pairs[q] = lst[q];
+    for (int q = 0; q < kFanShort / 2; ++q) pairs[q] = lst[q];
+#pragma unroll
+    for (int q = kFanShort / 2; q < kIncCap / 2; ++q) pairs[q] = more[q - kFanShort / 2];
     const double2 pv = reinterpret_cast<const double2 *>(xy)[r];
     const double sig = sigma[find_segment(mesh_voff, n_mesh, r)];
     int col[kIncCap + 1];
@@ -878,7 +912,7 @@ __global__ __launch_bounds__(128) void asm_rows_in_place(const RowsInPlace a) {
                 if (r < a.n_vert) {
                     T = a.n_inc[r];
                     pv = reinterpret_cast<const double2 *>(a.xy)[r];
-                    const int4 *lst = reinterpret_cast<const int4 *>(a.inc + r * kIncCap);
+                    const int4 *lst = reinterpret_cast<const int4 *>(a.inc + r * kFanShort);
 #pragma unroll
                     for (int q = 0; q < kFanShort / 2; ++q) pairs[q] = lst[q];
                 }
@@ -1860,7 +1894,7 @@ extern "C" int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns, int64_t
     PADNE_HIP_CHECK(hipMemsetAsync(d_ncoo, 0, sizeof(int) * (size_t)(n_unknowns + 1), s));
     PADNE_HIP_CHECK(hipMemsetAsync(d_nlisted, 0, sizeof(int) * 2, s));
     if (n_tri > 0)
-        hipLaunchKernelGGL(asm_count_tri, dim3(nblk(n_tri)), dim3(256), 0, s, (long long)n_tri, d_tri, (int)n_mesh,
+        hipLaunchKernelGGL(asm_count_tri, dim3(nblk(n_tri, 256 * kCntTris)), dim3(256), 0, s, (long long)n_tri, d_tri, (int)n_mesh,
                            d_voff, d_toff, d_ninc, d_inc, d_err);
     if (n_coo > 0)
         hipLaunchKernelGGL(asm_count_coo, dim3(nblk(n_coo)), dim3(256), 0, s, (long long)n_coo, d_crow, d_ncoo);
@@ -1886,7 +1920,7 @@ extern "C" int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns, int64_t
     //   stamps behind them, merged in place at their slot offsets.  d_cnt has been scanned; it now serves as the cursor.
     if (h_fans > 0)
         hipLaunchKernelGGL(asm_rows_long_fans, dim3(nblk(h_fans, 128)), dim3(128), 0, s, (const int *)(d_nlisted + 1),
-                           (const int *)d_fans, (int)n_mesh, d_voff, d_sigma, d_xy, d_ninc, d_inc, d_slot, d_key, d_val, d_rowlen,
+                           (const int *)d_fans, (long long)n_vert, (int)n_mesh, d_voff, d_sigma, d_xy, d_ninc, d_inc, d_slot, d_key, d_val, d_rowlen,
                            d_err);
     if (h_slow > 0) {
         hipLaunchKernelGGL(asm_fill_listed, dim3(nblk(h_slow)), dim3(256), 0, s, (const int *)d_nlisted, (const int *)d_list,
