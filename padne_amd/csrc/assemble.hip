@@ -602,28 +602,27 @@ __device__ __forceinline__ void chunk_offset_scanner(const TileScan sc) {
     if (lane == 0) *sc.nnz_out = running;
 }
 
-// a worker's wave 0 publishes a tile's count; the wave that completes the chunk publishes the chunk's
-__device__ __forceinline__ void tile_publish(const TileScan sc, const int tile, const int total, const int lane) {
-    const int c = tile / kChunkTiles;
+// a worker wave publishes a tile's count and arrives at the tile's chunk; returns how many tiles of the chunk have arrived
+// (in lane 0; the caller looks at it later, the round trip of the counter travels behind other work)
+__device__ __forceinline__ int tile_publish(const TileScan sc, const int tile, const int total, const int lane) {
     int arrived = 0;
     if (lane == 0) {
         scan_word_store(&sc.tile_agg[tile], kScanKnown | (unsigned long long)total);
-        // the count is an agent-scope atomic store that goes to the coherent level itself; the arrival must not overtake it:
-        // wait for the store (a workgroup-scope fence is exactly that wait -- an agent-scope release would write back the
-        // whole L2 of the XCD, with a few hundred MB of fresh rows in it, once per tile: 6.5 ms instead of 0.8)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        arrived = __hip_atomic_fetch_add(&sc.chunk_count[c], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+        arrived = __hip_atomic_fetch_add(&sc.chunk_count[tile / kChunkTiles], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
     }
-    arrived = __shfl(arrived, 0, 64);
+    return arrived;
+}
+// ... and the wave that arrived last adds up the chunk.  Nothing relies on the order in which another wave's count and its
+// arrival reach memory: the counts are read with their known bit, and waited for if need be.
+__device__ __forceinline__ bool chunk_publish(const TileScan sc, const int tile, const int arrived_lane0, const int lane) {
+    const int c = tile / kChunkTiles;
     const int in_chunk = min(kChunkTiles, sc.n_tiles - c * kChunkTiles);
-    if (arrived != in_chunk) return;
-    // (the counts are looked at with their known bit all the same: nothing here relies on the order in which another
-    //  workgroup's count and its arrival reach memory)
+    if (__shfl(arrived_lane0, 0, 64) != in_chunk) return true;
     unsigned long long w = lane < in_chunk ? scan_word_load(&sc.tile_agg[c * kChunkTiles + lane]) : kScanKnown;
     for (int polls = 0; __ballot((w >> 62) == 0ull) != 0ull; ++polls) {
         if (polls > kScanMaxPolls) {
             if (lane == 0) __hip_atomic_store(sc.abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
+            return false;
         }
         __builtin_amdgcn_s_sleep(1);
         if ((w >> 62) == 0ull) w = scan_word_load(&sc.tile_agg[c * kChunkTiles + lane]);
@@ -631,24 +630,28 @@ __device__ __forceinline__ void tile_publish(const TileScan sc, const int tile, 
     long long v = (long long)(w & kScanValueMask);
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     if (lane == 0) scan_word_store(&sc.chunk_agg[c], kScanKnown | (unsigned long long)v);
+    return true;
 }
 
-// a worker's wave 0 asks for a tile's offset: false when the wait was given up
-__device__ __forceinline__ bool tile_offset(const TileScan sc, const int tile, const int lane, long long *before) {
+// a worker wave asks for a tile's offset: the words are requested early (first look), examined after other work, and
+// waited for only if they were not there yet; false when the wait was given up
+__device__ __forceinline__ const unsigned long long *tile_offset_word(const TileScan sc, const int tile, const int lane, bool *mine) {
     const int c = tile / kChunkTiles, pos = tile % kChunkTiles;
-    const unsigned long long *p = lane == 63 ? &sc.chunk_prefix[c] : &sc.tile_agg[c * kChunkTiles + lane];
-    const bool mine = lane == 63 || lane < pos;            // (pos <= 63: lane 63 never holds a tile of the sum)
-    unsigned long long w = mine ? scan_word_load(p) : kScanKnown;
+    *mine = lane == 63 || lane < pos;                       // (pos <= 63: lane 63 never holds a tile of the sum)
+    return lane == 63 ? &sc.chunk_prefix[c] : &sc.tile_agg[c * kChunkTiles + lane];
+}
+__device__ __forceinline__ bool tile_offset_collect(const TileScan sc, const unsigned long long *p, const bool mine,
+                                                    unsigned long long w, const int lane, long long *before) {
     int polls = 0;
-    while (__ballot((w >> 62) == 0ull) != 0ull) {
+    while (__ballot(mine && (w >> 62) == 0ull) != 0ull) {
         if (++polls > kScanMaxPolls || ((polls & 255) == 0 && __hip_atomic_load(sc.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
             if (lane == 0) __hip_atomic_store(sc.abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
         }
         __builtin_amdgcn_s_sleep(8);
-        if ((w >> 62) == 0ull) w = scan_word_load(p);
+        if (mine && (w >> 62) == 0ull) w = scan_word_load(p);
     }
-    long long v = (long long)(w & kScanValueMask);
+    long long v = mine ? (long long)(w & kScanValueMask) : 0;
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     *before = v;
     return true;
@@ -847,6 +850,24 @@ __global__ __launch_bounds__(128) void asm_rows_long_fans(const int *__restrict_
 // scanner (above) and are written straight into the CSR arrays -- no slots, no second scan, no compaction pass.  The
 // listed rows (stamps, hubs, long fans, the unknowns behind the vertices) were merged at their slot offsets before this
 // kernel runs; it leaves room for them, asm_place_listed moves them in.
+// Tickets.  One counter for all workgroups limits the kernel: an agent-scope atomic on ONE address is served about every
+// 12 ns.  kTicketSeqs counters, each on a line of its own, hand out interleaved sequences of tiles (sequence q owns the
+// tiles q, q + kTicketSeqs, ...); a workgroup starts with the sequence of its number and moves on to the next when one
+// is used up, so every tile is taken as long as anybody runs, and as the sequences advance together the tiles still start
+// nearly in order -- which is all the scan needs to be quick; its correctness needs no order at all.
+constexpr int kTicketSeqs = 32, kTicketStride = 16;
+__device__ __forceinline__ int next_tile(int *__restrict__ counters, int &seq, int &tried, const int n_tiles) {
+    // one thread; n_tiles when every sequence is used up
+    while (tried < kTicketSeqs) {
+        const int k = atomicAdd(&counters[seq * kTicketStride], 1);
+        const long long tile = (long long)k * kTicketSeqs + seq;
+        if (tile < n_tiles) return (int)tile;
+        seq = (seq + 1) % kTicketSeqs;
+        ++tried;
+    }
+    return n_tiles;
+}
+
 struct RowsInPlace {
     long long n_rows, n_vert;
     int n_mesh;
@@ -857,6 +878,7 @@ struct RowsInPlace {
     const int *slot_ptr, *row_len;
     int *rowptr, *cols;
     double *vals;
+    long long nnz_cap;              // entries cols / vals hold: an offset beyond it is refused (and reported), never written to
     int *err;
     TileScan scan;
 };
@@ -867,27 +889,43 @@ __global__ __launch_bounds__(128) void asm_rows_in_place(const RowsInPlace a) {
         if (threadIdx.x < 64) chunk_offset_scanner(a.scan);
         return;
     }
-    __shared__ int held_col[kFanShort + 1][128];           // the rows of the tile that waits for its offset (14 KiB)
-    __shared__ double held_w[kFanShort + 1][128];
-    __shared__ int s_ticket[2], s_wave_total[2][2], s_abort;      // (ticket and wave totals alternate between two sets by turn)
+    // the rows this kernel built of the tile that waits for its offset, one behind the other.  A tile without listed rows
+    // (four in five) lies in the matrix exactly like that, and the whole workgroup copies it out with consecutive lanes on
+    // consecutive entries (every lane storing its own row, 28 and 56 bytes from its neighbour's, cost 275 us of 1030);
+    // in a tile with listed rows every lane moves its own row past the room of the listed ones.
+    constexpr int kStage = 128 * (kFanShort + 2);           // a row of this kernel holds at most kFanShort + 1 neighbours and the diagonal
+    __shared__ int stage_c[kStage];
+    __shared__ double stage_v[kStage];
+    __shared__ int s_ticket[2], s_wave_total[2][2], s_wave_built[2][2], s_abort;      // (tickets and wave totals alternate between two sets by turn)
     __shared__ long long s_before;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int n_tiles = a.scan.n_tiles;
-    if (t == 0) {
-        s_ticket[0] = atomicAdd(a.scan.ticket, 1);
+    // the slow words of the protocol (agent-scope atomics and loads, a few us each) are asked for early and looked at late,
+    // and the two waves share them: wave 1 fetches the tickets, wave 0 publishes and collects the offsets
+    int seq = blockIdx.x % kTicketSeqs, tried = 0;          // (thread 64's)
+    int ticket_ahead = n_tiles;                             // (thread 64's) the ticket of the turn after this one
+    if (t == 64) {
+        s_ticket[0] = next_tile(a.scan.ticket, seq, tried, n_tiles);
         s_abort = 0;
+        ticket_ahead = s_ticket[0] < n_tiles ? next_tile(a.scan.ticket, seq, tried, n_tiles) : n_tiles;
     }
     __syncthreads();
     int tile = s_ticket[0];
     bool held = false, held_direct = false;
-    int held_tile = 0, held_len = 0, held_local = 0;
-    double held_dval = 0.0;
+    int held_tile = 0, held_len = 0, held_local = 0, held_total = 0, held_blocal = 0, held_built = 0;
     for (int turn = 0;; ++turn) {
         const bool work = tile < n_tiles;
         if (!work && !held) break;
-        if (work && t == 0) s_ticket[(turn + 1) & 1] = atomicAdd(a.scan.ticket, 1);      // the next ticket travels while this tile is built
+        // first look at the offset of the tile that waits: asked for now, examined after this tile's rows are built
+        bool off_mine = false;
+        const unsigned long long *off_p = nullptr;
+        unsigned long long off_w = kScanKnown;
+        if (held && wv == 0) {
+            off_p = tile_offset_word(a.scan, held_tile, lane, &off_mine);
+            if (off_mine) off_w = scan_word_load(off_p);
+        }
         bool direct = false;
-        int len = 0, local = 0;
+        int len = 0, local = 0, blocal = 0;                  // (blocal: offset among the rows this kernel builds)
         int col[kFanShort + 1];
         double w[kFanShort + 1], dval = 0.0;
 #pragma unroll
@@ -949,17 +987,37 @@ __global__ __launch_bounds__(128) void asm_rows_in_place(const RowsInPlace a) {
             }
             if (lane == 63) s_wave_total[turn & 1][wv] = incl;
             local = incl - len;
+            const int blen = direct ? len : 0;
+            int bincl = blen;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int up = __shfl_up(bincl, off, 64);
+                if (lane >= off) bincl += up;
+            }
+            if (lane == 63) s_wave_built[turn & 1][wv] = bincl;
+            blocal = bincl - blen;
         }
+        if (t == 64) s_ticket[(turn + 1) & 1] = ticket_ahead;      // (asked for at the end of the previous turn)
         __syncthreads();                                   // wave totals, the next ticket
-        const int next_tile = work ? s_ticket[(turn + 1) & 1] : tile;
+        const int tile_after = work ? s_ticket[(turn + 1) & 1] : tile;
+        int arrived = 0;
         if (work) {
             if (wv == 1) local += s_wave_total[turn & 1][0];
-            if (wv == 0) tile_publish(a.scan, tile, s_wave_total[turn & 1][0] + s_wave_total[turn & 1][1], lane);
+            if (wv == 1) blocal += s_wave_built[turn & 1][0];
+            if (wv == 0) arrived = tile_publish(a.scan, tile, s_wave_total[turn & 1][0] + s_wave_total[turn & 1][1], lane);
         }
+        bool chunk_done = !work;
         if (held) {
             if (wv == 0) {
+                // Before this wave WAITS for anything it does its own duty: if it arrived last at its tile's chunk, the chunk's
+                // count is what the offset it is about to wait for may depend on (at the end of the tiles a workgroup can hold
+                // a tile of a later chunk than the one it has just built).  When the first look found everything, nothing waits.
+                bool ok = true;
+                if (!chunk_done && __ballot(off_mine && (off_w >> 62) == 0ull) != 0ull) {
+                    ok = chunk_publish(a.scan, tile, arrived, lane);
+                    chunk_done = true;
+                }
                 long long before = 0;
-                const bool ok = tile_offset(a.scan, held_tile, lane, &before);
+                ok = ok && tile_offset_collect(a.scan, off_p, off_mine, off_w, lane, &before);
                 if (lane == 0) {
                     s_before = before;
                     if (!ok) s_abort = 1;
@@ -971,37 +1029,46 @@ __global__ __launch_bounds__(128) void asm_rows_in_place(const RowsInPlace a) {
                 return;
             }
             const long long hr = (long long)held_tile * 128 + t;
-            if (hr < a.n_rows) {
-                const long long at = s_before + held_local;
-                a.rowptr[hr] = (int)at;
-                if (hr == a.n_rows - 1) a.rowptr[a.n_rows] = (int)(at + held_len);
-                if (held_direct) {
-                    int hc[kFanShort + 1];
-                    double hw[kFanShort + 1];
-#pragma unroll
-                    for (int i = 0; i <= kFanShort; ++i) {
-                        hc[i] = held_col[i][t];
-                        hw[i] = held_w[i][t];
+            const long long base = s_before;
+            if (base < 0 || base + held_total > a.nnz_cap) {      // refused and reported, never written
+                if (t == 0) atomicExch(&a.err[ERR_SCAN], 1);
+            } else {
+                if (hr < a.n_rows) {
+                    a.rowptr[hr] = (int)(base + held_local);
+                    if (hr == a.n_rows - 1) a.rowptr[a.n_rows] = (int)(base + held_local + held_len);
+                }
+                if (held_built == held_total) {
+                    for (int i = t; i < held_total; i += 128) {
+                        a.cols[base + i] = stage_c[i];
+                        a.vals[base + i] = stage_v[i];
                     }
-                    fan_row_store<kFanShort>((int)hr, hc, hw, held_dval, a.cols + at, a.vals + at);
+                } else if (held_direct) {
+                    for (int i = 0; i < held_len; ++i) {
+                        a.cols[base + held_local + i] = stage_c[held_blocal + i];
+                        a.vals[base + held_local + i] = stage_v[held_blocal + i];
+                    }
                 }
             }
-            __syncthreads();                               // s_before is rewritten in the next turn
+            __syncthreads();                               // the stage is rewritten below
         }
+        if (!chunk_done && wv == 0 && !chunk_publish(a.scan, tile, arrived, lane)) {
+            if (lane == 0) {                                     // (the other wave learns it behind its next barrier)
+                atomicExch(&a.err[ERR_SCAN], 1);
+                s_abort = 1;
+            }
+            return;
+        }
+        if (t == 64) ticket_ahead = tile_after < n_tiles ? next_tile(a.scan.ticket, seq, tried, n_tiles) : n_tiles;
         held = work;
         held_tile = tile;
-        held_direct = direct;
         held_len = len;
         held_local = local;
-        held_dval = dval;
-        if (work && direct) {                              // (every lane reads back only what it parked itself)
-#pragma unroll
-            for (int i = 0; i <= kFanShort; ++i) {
-                held_col[i][t] = col[i];
-                held_w[i][t] = w[i];
-            }
-        }
-        tile = next_tile;
+        held_direct = direct;
+        held_blocal = blocal;
+        held_total = work ? s_wave_total[turn & 1][0] + s_wave_total[turn & 1][1] : 0;
+        held_built = work ? s_wave_built[turn & 1][0] + s_wave_built[turn & 1][1] : 0;
+        if (work && direct) fan_row_store<kFanShort>((int)((long long)tile * 128 + t), col, w, dval, stage_c + blocal, stage_v + blocal);
+        tile = tile_after;
     }
 }
 
@@ -1009,12 +1076,17 @@ __global__ __launch_bounds__(128) void asm_rows_in_place(const RowsInPlace a) {
 __global__ __launch_bounds__(256) void asm_place_listed(const int *__restrict__ n_list, const int *__restrict__ row_list,
                                                         const int *__restrict__ slot_ptr, const long long *__restrict__ key,
                                                         const double *__restrict__ val, const int *__restrict__ rowptr,
-                                                        int *__restrict__ cols, double *__restrict__ vals) {
+                                                        int *__restrict__ cols, double *__restrict__ vals, const long long nnz_cap,
+                                                        int *__restrict__ err) {
     const int lane = threadIdx.x & 63;
     const int n = *n_list;
     for (int idx = blockIdx.x * 4 + (threadIdx.x >> 6); idx < n; idx += gridDim.x * 4) {
         const int r = row_list[idx];
         const int s0 = slot_ptr[r], at = rowptr[r], len = rowptr[r + 1] - at;
+        if (at < 0 || len < 0 || len > slot_ptr[r + 1] - s0 || (long long)at + len > nnz_cap) {      // refused and reported, never written
+            if (lane == 0) atomicExch(&err[ERR_SCAN], 1);
+            continue;
+        }
         for (int i = lane; i < len; i += 64) {
             cols[at + i] = (int)(key[s0 + i] >> 32);
             vals[at + i] = val[s0 + i];
@@ -1948,7 +2020,7 @@ extern "C" int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns, int64_t
         const long long n_tiles = (n_unknowns + 127) / 128, n_chunks = (n_tiles + kChunkTiles - 1) / kChunkTiles;
         // one block of scan state: tile counts, chunk counts, chunk offsets (64-bit words), arrivals per chunk, ticket, abort
         const size_t words64 = (size_t)n_tiles + 2 * (size_t)n_chunks + 64 + 2;
-        const size_t state_bytes = words64 * 8 + ((size_t)n_chunks + 4) * 4;
+        const size_t state_bytes = words64 * 8 + ((size_t)n_chunks + 16 + (size_t)kTicketSeqs * kTicketStride + 16) * 4;
         unsigned char *d_state = nullptr;
         rc = sc.alloc(&d_state, state_bytes);
         hipError_t e = hipSuccess;
@@ -1960,8 +2032,8 @@ extern "C" int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns, int64_t
             args.scan.chunk_prefix = args.scan.chunk_agg + n_chunks + 64;     // (the scanner looks 64 chunks ahead)
             args.scan.nnz_out = (long long *)(args.scan.chunk_prefix + n_chunks + 1);
             args.scan.chunk_count = (int *)(d_state + words64 * 8);
-            args.scan.ticket = args.scan.chunk_count + n_chunks;
-            args.scan.abort_word = args.scan.ticket + 1;
+            args.scan.ticket = args.scan.chunk_count + ((n_chunks + 15) / 16) * 16;      // kTicketSeqs counters, a line apart
+            args.scan.abort_word = args.scan.ticket + kTicketSeqs * kTicketStride;
             args.scan.n_tiles = (int)n_tiles;
             args.scan.n_chunks = (int)n_chunks;
             // as many workers as the chip holds at once (a worker that is not resident simply takes no tickets), one scanner
@@ -1984,6 +2056,7 @@ extern "C" int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns, int64_t
             args.cols = m->cols;
             args.vals = m->vals;
             args.err = d_err;
+            args.nnz_cap = nnz_bound;
             d_nnz = args.scan.nnz_out;
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(asm_rows_in_place, dim3(workers + 1), dim3(128), 0, s, args);
@@ -1992,11 +2065,11 @@ extern "C" int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns, int64_t
             if (e == hipSuccess && h_slow > 0)
                 hipLaunchKernelGGL(asm_place_listed, dim3(std::min(nblk(h_slow, 4), 4096u)), dim3(256), 0, s, (const int *)d_nlisted,
                                    (const int *)d_list, (const int *)d_slot, (const long long *)d_key, (const double *)d_val,
-                                   (const int *)m->rowptr, m->cols, m->vals);
+                                   (const int *)m->rowptr, m->cols, m->vals, nnz_bound, d_err);
             if (e == hipSuccess && h_fans > 0)
                 hipLaunchKernelGGL(asm_place_listed, dim3(std::min(nblk(h_fans, 4), 4096u)), dim3(256), 0, s,
                                    (const int *)(d_nlisted + 1), (const int *)d_fans, (const int *)d_slot, (const long long *)d_key,
-                                   (const double *)d_val, (const int *)m->rowptr, m->cols, m->vals);
+                                   (const double *)d_val, (const int *)m->rowptr, m->cols, m->vals, nnz_bound, d_err);
             if (e == hipSuccess) e = hipGetLastError();
         }
         if (rc == PADNE_OK && e != hipSuccess) {
