@@ -875,6 +875,12 @@ __global__ __launch_bounds__(128) void spgemm_rows_lds(int n_rows, const int *__
 // requested while those of entry u go into the list -- three to four round trips per KC entries.  Register arrays are
 // indexed by unrolled constants only.  Same products in the same order: bit-identical lists.  (Round 2 had tried ALL loads
 // of a row up front: 212 VGPRs, two waves per SIMD, no gain; this form needs 90.)
+// (unaligned multi-dword loads: global loads of 8 and 16 bytes only need their address to be a multiple of 4)
+struct __attribute__((packed, aligned(4))) I4u { int x, y, z, w; };
+struct __attribute__((packed, aligned(4))) I2u { int x, y; };
+struct __attribute__((packed, aligned(4))) D2u { double x, y; };
+struct __attribute__((packed, aligned(4))) L2u { long long x, y; };
+
 template <int CAP, int KC, int QC, int YCS>
 __global__ __launch_bounds__(128) void spgemm_rows_lds_pipe(int n_rows, const int *__restrict__ xr, const int *__restrict__ xc,
                                                             const double *__restrict__ xv, const int *__restrict__ yr,
@@ -911,32 +917,49 @@ __global__ __launch_bounds__(128) void spgemm_rows_lds_pipe(int n_rows, const in
         const int nk = min(KC, x1 - kb);
         int mid[KC], ys[KC], ln[KC];
         double a[KC];
+        // What bounds the loads is their number: every lane reads somewhere else, and the address unit takes about a cycle
+        // per lane and instruction whatever the width.  So the rows are read four indices / two doubles at a time (unaligned
+        // 16-byte loads; past a row's end lies the next row or the zero padding of the arrays, and is not used).
+        static_assert(KC % 4 == 1 && QC == 4, "the loads below are written for 4 k + 1 entries of X and rows of Y read four at a time");
 #pragma unroll
-        for (int u = 0; u < KC; ++u) {
-            mid[u] = u < nk ? xc[kb + u] : 0;
-            a[u] = u < nk ? xv[kb + u] : 0.0;
+        for (int u = 0; u < KC - 1; u += 4) {
+            const I4u c4 = *reinterpret_cast<const I4u *>(xc + kb + u);
+            mid[u] = c4.x; mid[u + 1] = c4.y; mid[u + 2] = c4.z; mid[u + 3] = c4.w;
+            const D2u v0 = *reinterpret_cast<const D2u *>(xv + kb + u), v1 = *reinterpret_cast<const D2u *>(xv + kb + u + 2);
+            a[u] = v0.x; a[u + 1] = v0.y; a[u + 2] = v1.x; a[u + 3] = v1.y;
         }
+        mid[KC - 1] = xc[kb + KC - 1];
+        a[KC - 1] = xv[kb + KC - 1];
 #pragma unroll
         for (int u = 0; u < KC; ++u) {
-            ys[u] = u < nk ? yr[mid[u]] : 0;
-            ln[u] = u < nk ? ye[mid[u]] - ys[u] : 0;
+            mid[u] = u < nk ? mid[u] : 0;                  // (behind the row's end: row 0 of Y, not used)
+            if (ye == yr + 1) {
+                const I2u be = *reinterpret_cast<const I2u *>(yr + mid[u]);
+                ys[u] = be.x;
+                ln[u] = u < nk ? be.y - be.x : 0;
+            } else {
+                ys[u] = yr[mid[u]];
+                ln[u] = u < nk ? ye[mid[u]] - ys[u] : 0;
+            }
         }
         int cb[2][QC];
         double vb[2][QC];
-#pragma unroll
-        for (int w = 0; w < QC; ++w) {
-            cb[0][w] = w < ln[0] ? yc[(long long)(ys[0] + w) * YCS] : 0;
-            vb[0][w] = w < ln[0] ? yv[ys[0] + w] : 0.0;
-        }
+        auto fetch = [&](const int u, int (&c)[QC], double (&v)[QC]) {
+            if (YCS == 1) {
+                const I4u c4 = *reinterpret_cast<const I4u *>(yc + ys[u]);
+                c[0] = c4.x; c[1] = c4.y; c[2] = c4.z; c[3] = c4.w;
+            } else {                                       // slots: yc points at the high word of the first 64-bit key, the column
+                const L2u k0 = *reinterpret_cast<const L2u *>(reinterpret_cast<const long long *>(yc) + ys[u]);
+                const L2u k1 = *reinterpret_cast<const L2u *>(reinterpret_cast<const long long *>(yc) + ys[u] + 2);
+                c[0] = (int)k0.x; c[1] = (int)k0.y; c[2] = (int)k1.x; c[3] = (int)k1.y;      // (the low word of a read that starts there)
+            }
+            const D2u v0 = *reinterpret_cast<const D2u *>(yv + ys[u]), v1 = *reinterpret_cast<const D2u *>(yv + ys[u] + 2);
+            v[0] = v0.x; v[1] = v0.y; v[2] = v1.x; v[3] = v1.y;
+        };
+        fetch(0, cb[0], vb[0]);
 #pragma unroll
         for (int u = 0; u < KC; ++u) {
-            if (u + 1 < KC) {
-#pragma unroll
-                for (int w = 0; w < QC; ++w) {
-                    cb[(u + 1) & 1][w] = w < ln[u + 1] ? yc[(long long)(ys[u + 1] + w) * YCS] : 0;
-                    vb[(u + 1) & 1][w] = w < ln[u + 1] ? yv[ys[u + 1] + w] : 0.0;
-                }
-            }
+            if (u + 1 < KC) fetch(u + 1, cb[(u + 1) & 1], vb[(u + 1) & 1]);
 #pragma unroll
             for (int w = 0; w < QC; ++w)
                 if (w < ln[u] && !overflow) insert(cb[u & 1][w], a[u] * vb[u & 1][w]);
@@ -2244,8 +2267,8 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
     if (amg_verbose()) fprintf(stderr, "[amg]   spgemm %lld rows, %lld product slots\n", (long long)n, (long long)n_slots);
     long long *key = nullptr;
     double *val = nullptr;
-    PADNE_TRY(sc.alloc(&key, (size_t)n_slots));
-    PADNE_TRY(sc.alloc(&val, (size_t)n_slots));
+    PADNE_TRY(sc.alloc(&key, (size_t)n_slots + 4));      // (+4: kernels that read a row four slots at a time, as the Y of a later product)
+    PADNE_TRY(sc.alloc(&val, (size_t)n_slots + 4));
     if (n > 0) {
         const double avg = (double)n_slots / (double)n;
         const size_t dense_lds = (size_t)Y->n_cols * 9 + 16;

@@ -9,6 +9,12 @@ for src, dst in (("bench_c4_1gpu_amg.json", RD + "_bench_c4_1gpu_amg.json"), ("b
                  ("pmc/spmv_traffic.json", "spmv_traffic.json"), ("configs.json", RD + "_configs.json"),
                  ("step_traffic.json", RD + "_step_traffic.json"), ("pmc_per_kernel_per_solve.csv", RD + "_pmc_per_kernel_per_solve.csv")):
     shutil.copy(os.path.join(F, src), os.path.join(P, dst))
+with open(os.path.join(P, RD + "_assembly_timeline.txt"), "w") as f:
+    f.write("Kernel timeline of the device-resident assembly (scripts/asm_prof.sh: rocprofv3 --kernel-trace of scripts/asm_only.py), last of four runs\n")
+    for c in ("C2", "C3", "C4"):
+        f.write(f"\n== config {c} ==\n" + open(os.path.join(F, f"asm_{c}_timeline.txt")).read())
+    f.write("\n== config C4: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KB, separate passes, mean of four runs; scripts/pmc_asm.sh) ==\n")
+    f.write(open(os.path.join(F, "asm_C4_pmc.txt")).read())
 acc = {}
 for C in ("FETCH_SIZE", "WRITE_SIZE"):
     per = collections.defaultdict(list)

@@ -12,3 +12,6 @@ timeout -k 10 600 python scripts/run_configs.py > $O/configs.log 2>&1 || exit 4
 cp gpurun_out/configs.json $O/ ; echo configs done
 timeout -k 10 300 python bench.py --precond jacobi --steps 1 --warmup 0 --no-cpu-baseline > $O/bench_jacobi.log 2>&1 || exit 5
 grep '^{' $O/bench_jacobi.log > $O/bench_c4_1gpu_jacobi.json; echo jacobi done
+for c in C2 C3 C4; do bash scripts/asm_prof.sh $c > $O/asm_$c.log 2>&1 || exit 6; cp gpurun_out/asm_${c}_timeline.txt $O/; done
+timeout -k 10 400 bash scripts/pmc_asm.sh $O/pmc_asm C4 "FETCH_SIZE" "WRITE_SIZE" > $O/asm_C4_pmc.txt 2>&1 || exit 7
+echo assembly done
