@@ -105,6 +105,23 @@ static double theta_val() {
     return th;
 }
 
+// unaligned multi-dword loads: global loads of 8 and 16 bytes only need their address to be a multiple of 4.  What bounds a
+// kernel of gathers is the number of its memory instructions (the address unit takes about a cycle per lane and instruction
+// whatever the width), so rows are read four indices / two values at a time; what lies behind a row's end is the next row
+// or the zero padding of the arrays, and is not used.
+struct __attribute__((packed, aligned(4))) I4u { int x, y, z, w; };
+struct __attribute__((packed, aligned(4))) I2u { int x, y; };
+struct __attribute__((packed, aligned(4))) D2u { double x, y; };
+struct __attribute__((packed, aligned(4))) L2u { long long x, y; };
+__device__ __forceinline__ int4 load_i4_unaligned(const int *p) {
+    const I4u v = *reinterpret_cast<const I4u *>(p);
+    return make_int4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ double2 load_d2_unaligned(const double *p) {
+    const D2u v = *reinterpret_cast<const D2u *>(p);
+    return make_double2(v.x, v.y);
+}
+
 // ---- XCD-aware row order --------------------------------------------------------------------------------------------
 // Workgroups are dealt to the 8 XCDs round-robin (b, b + 8, b + 16, ... share an XCD and its private 4 MiB L2).  A kernel
 // that walks the rows in workgroup order therefore shows every XCD rows from all over the matrix, and whatever the rows
@@ -609,13 +626,34 @@ __global__ void agg_join(int n, const int *__restrict__ srow, const int *__restr
     int a = agg_in[i];
     if (a < 0) {
         double best = -1.0;
-        for (int k = srow[i]; k < srow[i + 1]; ++k) {
+        const int k0 = srow[i], k1 = srow[i + 1];
+        // the first eight entries together (columns and values in six loads, then eight independent looks at the
+        // neighbours' aggregates); one entry after the other every entry waited for its own chain of three loads
+        {
+            const int4 ca = load_i4_unaligned(scol + k0), cb = load_i4_unaligned(scol + k0 + 4);
+            const double2 v0 = load_d2_unaligned(vals + k0), v1 = load_d2_unaligned(vals + k0 + 2),
+                          v2 = load_d2_unaligned(vals + k0 + 4), v3 = load_d2_unaligned(vals + k0 + 6);
+            const int j[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+            const double v[8] = {v0.x, v0.y, v1.x, v1.y, v2.x, v2.y, v3.x, v3.y};
+            int aj[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) aj[u] = (k0 + u < k1 && j[u] != i) ? agg_in[j[u]] : -1;      // (j == i: weak or diagonal entry)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double w = fabs(v[u]);
+                if (aj[u] >= 0 && w > best) {   // ties: columns are sorted, the smaller index wins
+                    best = w;
+                    a = aj[u];
+                }
+            }
+        }
+        for (int k = k0 + 8; k < k1; ++k) {
             const int j = scol[k];
-            if (j == i) continue;                 // weak or diagonal entry
+            if (j == i) continue;
             const int aj = agg_in[j];
             if (aj < 0) continue;
             const double w = fabs(vals[k]);
-            if (w > best) {   // ties: columns are sorted, the smaller index wins
+            if (w > best) {
                 best = w;
                 a = aj;
             }
@@ -752,10 +790,32 @@ __global__ void transpose_fill(int n_rows, const int *__restrict__ rowptr, const
                                int *__restrict__ cursor, long long *__restrict__ key, double *__restrict__ val) {
     const int i = xcd_bid() * blockDim.x + threadIdx.x;
     if (i >= n_rows) return;
-    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+    const int k0 = rowptr[i], k1 = rowptr[i + 1];
+    // the first four entries of the row together: their columns and values in three loads, then four independent
+    // (slot offset, cursor) pairs -- one entry after the other every entry waited for its own load, gather and atomic,
+    // two or three times in a row (1.46 ms for the prolongator of 10 M rows)
+    {
+        const int4 c4 = load_i4_unaligned(cols + k0);
+        const double2 v01 = load_d2_unaligned(vals + k0), v23 = load_d2_unaligned(vals + k0 + 2);
+        const int ln = k1 - k0;
+        const int c[4] = {c4.x, c4.y, c4.z, c4.w};
+        const double v[4] = {v01.x, v01.y, v23.x, v23.y};
+        int sp[4], at[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sp[u] = u < ln ? slot_ptr[c[u]] : 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) at[u] = u < ln ? atomicAdd(&cursor[c[u]], 1) : 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (u < ln) {
+                key[sp[u] + at[u]] = (long long)i << 32;      // rows are unique inside a column: the sort makes the order canonical
+                val[sp[u] + at[u]] = v[u];
+            }
+    }
+    for (int k = k0 + 4; k < k1; ++k) {
         const int c = cols[k];
         const int s = slot_ptr[c] + atomicAdd(&cursor[c], 1);
-        key[s] = (long long)i << 32;      // rows are unique inside a column: the sort makes the order canonical
+        key[s] = (long long)i << 32;
         val[s] = vals[k];
     }
 }
@@ -875,11 +935,6 @@ __global__ __launch_bounds__(128) void spgemm_rows_lds(int n_rows, const int *__
 // requested while those of entry u go into the list -- three to four round trips per KC entries.  Register arrays are
 // indexed by unrolled constants only.  Same products in the same order: bit-identical lists.  (Round 2 had tried ALL loads
 // of a row up front: 212 VGPRs, two waves per SIMD, no gain; this form needs 90.)
-// (unaligned multi-dword loads: global loads of 8 and 16 bytes only need their address to be a multiple of 4)
-struct __attribute__((packed, aligned(4))) I4u { int x, y, z, w; };
-struct __attribute__((packed, aligned(4))) I2u { int x, y; };
-struct __attribute__((packed, aligned(4))) D2u { double x, y; };
-struct __attribute__((packed, aligned(4))) L2u { long long x, y; };
 
 template <int CAP, int KC, int QC, int YCS>
 __global__ __launch_bounds__(128) void spgemm_rows_lds_pipe(int n_rows, const int *__restrict__ xr, const int *__restrict__ xc,
@@ -2407,8 +2462,20 @@ __global__ __launch_bounds__(256) void w_from_slots_kernel(int n, const int *__r
             const int src = sp[lo] + (k - rp[lo]);
             const int col = (int)(ap_key[src] >> 32);
             double v = -c * dinv[i] * ap_val[src];
-            for (int q = pr[i]; q < pr[i + 1]; ++q)
-                if (pc[q] == col) v = pv[q] + v;
+            const I2u be = *reinterpret_cast<const I2u *>(pr + i);
+            if (be.y - be.x <= 4) {
+                // the row of P in three loads instead of a dependent pair per entry (behind its end: the next row or the padding)
+                const I4u c4 = *reinterpret_cast<const I4u *>(pc + be.x);
+                const D2u p0 = *reinterpret_cast<const D2u *>(pv + be.x), p1 = *reinterpret_cast<const D2u *>(pv + be.x + 2);
+                const int ln = be.y - be.x;
+                if (ln > 0 && c4.x == col) v = p0.x + v;      // (the columns of a row are distinct: at most one of these)
+                if (ln > 1 && c4.y == col) v = p0.y + v;
+                if (ln > 2 && c4.z == col) v = p1.x + v;
+                if (ln > 3 && c4.w == col) v = p1.y + v;
+            } else {
+                for (int q = be.x; q < be.y; ++q)
+                    if (pc[q] == col) v = pv[q] + v;
+            }
             wc[k] = col;
             wv[k] = (float)v;
         }
