@@ -2055,7 +2055,10 @@ extern "C" int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns, int64_t
     // 4 every row, written once and in place: a mesh row holds at most one entry per triangle plus two, a listed row at
     //   most its slots -- the arrays are sized by that bound, the single-pass scan inside the kernel finds the offsets
     const long long nnz_bound = 3LL * n_tri + 2LL * n_vert + n_slots;
-    PADNE_REQUIRE(nnz_bound < 2147483647LL - kPadNnz, "too many entries for int32 indices");
+    if (nnz_bound >= 2147483647LL - kPadNnz) {
+        set_error("%lld entries exceed the 32-bit index space", nnz_bound);
+        return PADNE_E_TOOLARGE;
+    }
     padne_csr *m = nullptr;
     PADNE_TRY(csr_alloc(ctx, n_unknowns, n_unknowns, nnz_bound, &m));
     long long h_nnz = 0;
