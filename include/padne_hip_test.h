@@ -26,6 +26,9 @@ int padne_team_abort(void *team);
  * all owned / that read an exchange slot); both 0 while there is no split plan.  level < 0: the matrix itself, otherwise
  * the operator A_level of its cached hierarchy. */
 int padne_csr_split_tiles(const padne_csr *m, int level, int64_t *interior, int64_t *boundary);
+/* Groups of right-hand sides (eight, or five to seven zero-padded) this context has advanced in lockstep through the
+ * batched multigrid-PCG so far -- what tells a test that the K + 1 right-hand sides of K regulators took that path. */
+int padne_ctx_lockstep_groups(const padne_ctx *ctx, int64_t *groups);
 
 #ifdef __cplusplus
 }

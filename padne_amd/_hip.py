@@ -117,6 +117,7 @@ TEST_SIGNATURES = {
     "padne_team_abort": (C.c_int, [_P]),
     "padne_ctx_join_team": (C.c_int, [_P, _P, C.c_int]),
     "padne_csr_split_tiles": (C.c_int, [_P, C.c_int, _PI64, _PI64]),
+    "padne_ctx_lockstep_groups": (C.c_int, [_P, _PI64]),
 }
 
 _lib = None
@@ -246,6 +247,12 @@ class Context:
         nbytes = (C.c_longlong * 4)()
         _check(self._lib.padne_comm_call_counts(calls, nbytes))
         return list(calls), list(nbytes)
+
+    def lockstep_groups(self) -> int:
+        """Groups of right-hand sides this context has advanced in lockstep so far (test introspection)."""
+        g = C.c_int64(0)
+        _check(self._lib.padne_ctx_lockstep_groups(self._h, C.byref(g)))
+        return int(g.value)
 
     def set_halo(self, n_owned: int, m: int, export_idx) -> None:
         e = _i32(export_idx)

@@ -120,6 +120,7 @@ struct padne_ctx {
     // latency-bound kernels of the multigrid setup run there next to the main chain (aux_context, stream_order)
     padne_ctx *aux = nullptr, *parent = nullptr;
     bool is_aux = false;
+    unsigned long long lockstep_groups = 0;      // groups of right-hand sides this context has solved in lockstep (test introspection)
     unsigned pinned_busy = 0;        // bit k: the k-th 512-byte Lanczos slot of `pinned` holds a job in flight (second stream only)
     // mailbox: a page of host-coherent memory the device posts small results into (read_back / mail_ticket)
     unsigned long long *mailbox = nullptr, *mailbox_dev = nullptr;

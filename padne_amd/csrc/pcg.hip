@@ -1627,6 +1627,7 @@ static int solve_spd_dev_impl(padne_ctx *ctx, const padne_csr *a, const void *b_
             const int keep = local.status;
             local = grp;
             local.status = keep;
+            ++ctx->lockstep_groups;
         }
         // a remainder of 5-7 right-hand sides is still cheaper in lockstep (padded with zero columns, which are
         // converged from the start) than one at a time: a lockstep iteration costs about 2.4 single ones
@@ -1651,6 +1652,7 @@ static int solve_spd_dev_impl(padne_ctx *ctx, const padne_csr *a, const void *b_
                 PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
                 local = grp;
                 k_first = n_rhs;
+                ++ctx->lockstep_groups;
             }
         }
     }
@@ -1725,4 +1727,11 @@ extern "C" int padne_solve_spd(padne_ctx *ctx, const padne_csr *a, const double 
     pool_free(ctx, b);
     pool_free(ctx, x);
     return rc;
+}
+
+// test introspection (include/padne_hip_test.h): groups of right-hand sides this context has solved in lockstep so far
+extern "C" int padne_ctx_lockstep_groups(const padne_ctx *ctx, int64_t *groups) {
+    PADNE_REQUIRE(ctx && groups, "null argument");
+    *groups = (int64_t)ctx->lockstep_groups;
+    return PADNE_OK;
 }

@@ -1177,6 +1177,52 @@ def test_regulator_star_and_multi_island_problem_end_to_end(ctx):
     L.dev.close()
 
 
+def test_five_regulators_advance_in_lockstep_and_match_the_direct_solve(ctx, monkeypatch):
+    """K regulators add K right-hand sides to a solve (the gain columns, `solver.py:512-538`).  With K + 1 >= 5 they advance
+    in lockstep through the batched cycle (a group of up to eight, zero-padded), one pass over the matrix and the hierarchy
+    per iteration for all of them; fewer are solved one after the other (a lockstep iteration costs about 2.4 single
+    ones).  Five regulators across two layers of 90 x 80 vertices: potentials and branch currents against the reference's
+    direct solve; `padne_ctx_lockstep_groups` (test header) tells which path a solve took."""
+    rng = np.random.default_rng(11)
+    meshes, offs = [], [0]
+    for layer, (nx, ny) in enumerate(((90, 80), (90, 80))):
+        xy, tri = synthetic.jittered_grid(nx, ny, seed=20 + layer)
+        meshes.append((xy, tri, 2082.5))
+        offs.append(offs[-1] + len(xy))
+    n_vert = offs[-1]
+    vert = lambda l: int(rng.integers(offs[l], offs[l + 1]))
+    els = [("R", vert(0), vert(1), float(10 ** rng.uniform(-3, -1))) for _ in range(12)]      # vias
+    els.append(("I", vert(0), vert(1), 1.5))
+    used = set()
+
+    def fresh(l):
+        while True:
+            v = vert(l)
+            if v not in used:
+                used.add(v)
+                return v
+    n_extra = 0
+    for k in range(5):
+        vp, vn, sf, st = fresh(0), fresh(1), fresh(0), fresh(1)
+        els.append(("REG", vp, vn, sf, st, 1.0 + 0.5 * k, 0.6 + 0.1 * k, n_vert + n_extra))
+        n_extra += 1
+        els.append(("R", vp, vn, 1.0 + k))                  # a load, so that the regulator delivers something
+    Lo, ro = O.assemble_system(meshes, 0, els, 0)
+    v_ref, _, _ = O.solve_system(Lo, ro)
+    groups_before = ctx.lockstep_groups()
+    v, info = solver.solve_system(Lo, ro)
+    assert ctx.lockstep_groups() == groups_before + 1      # the six right-hand sides went as ONE zero-padded group
+    n_pot = n_vert
+    assert np.abs(v[:n_pot] - v_ref[:n_pot]).max() <= REL_TOL * np.abs(v_ref[:n_pot]).max()
+    assert np.abs(v[n_pot:] - v_ref[n_pot:]).max() <= 1e-7 * np.abs(v_ref[n_pot:]).max()
+    assert info.residual_norm < 1e-9
+    monkeypatch.setenv("PADNE_NO_BATCH", "1")
+    v1, info1 = solver.solve_system(Lo, ro)
+    assert ctx.lockstep_groups() == groups_before + 1      # ... and one at a time with the batched path switched off
+    assert np.abs(v1[:n_pot] - v_ref[:n_pot]).max() <= REL_TOL * np.abs(v_ref[:n_pot]).max()
+    assert np.abs(v1 - v).max() <= 1e-9 * np.abs(v_ref).max()      # the grouping does not show beyond the tolerance
+
+
 # ---- size-independent properties at BASELINE scale (direct solve unaffordable there) --------------------
 
 @pytest.fixture(scope="module")
