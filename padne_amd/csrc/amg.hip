@@ -938,7 +938,29 @@ __global__ void spgemm_count(int n_rows, const int *__restrict__ xr, const int *
     const int i = xcd_bid() * blockDim.x + threadIdx.x;
     if (i >= n_rows) return;
     long long c = 0;
-    for (int k = xr[i]; k < xr[i + 1]; ++k) {
+    const int k0 = xr[i], k1 = xr[i + 1];
+    // the first eight entries of the row together: their columns in two loads, then eight independent looks at the row
+    // pointers of Y (one 8-byte load each when Y is a CSR matrix); the rest one by one
+    {
+        const int4 ca = load_i4_unaligned(xc + k0), cb = load_i4_unaligned(xc + k0 + 4);
+        const int m[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+        int ln[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            ln[u] = 0;
+            if (k0 + u < k1) {
+                if (ye == yr + 1) {
+                    const I2u be = *reinterpret_cast<const I2u *>(yr + m[u]);
+                    ln[u] = be.y - be.x;
+                } else {
+                    ln[u] = ye[m[u]] - yr[m[u]];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c += ln[u];
+    }
+    for (int k = k0 + 8; k < k1; ++k) {
         const int m = xc[k];
         c += ye[m] - yr[m];
     }
@@ -2039,9 +2061,22 @@ __global__ __launch_bounds__(128) void prolong_rows_lds(int n, const int *__rest
     if (i >= n) return;
     const double di = dinv[i];
     double dF = 1.0 / di;
-    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
-        const int j = cols[k];
-        if (j != i && !strong(vals[k], di, dinv[j], theta2)) dF += vals[k];
+    const int k0 = rowptr[i], k1 = rowptr[i + 1];
+    // Both walks over the row take eight entries at a time: their columns and values in six loads, then the eight
+    // neighbours' 1/diag (and aggregates) asked for together -- entry by entry every entry waited for its own chain of
+    // loads, twice per row.  Same operations in the same order on the same values.
+    for (int kb = k0; kb < k1; kb += 8) {
+        const int4 ca = load_i4_unaligned(cols + kb), cb = load_i4_unaligned(cols + kb + 4);
+        const double2 v0 = load_d2_unaligned(vals + kb), v1 = load_d2_unaligned(vals + kb + 2),
+                      v2 = load_d2_unaligned(vals + kb + 4), v3 = load_d2_unaligned(vals + kb + 6);
+        const int j[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+        const double a[8] = {v0.x, v0.y, v1.x, v1.y, v2.x, v2.y, v3.x, v3.y};
+        double dj[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dj[u] = kb + u < k1 ? dinv[j[u]] : 1.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (kb + u < k1 && j[u] != i && !strong(a[u], di, dj[u], theta2)) dF += a[u];
     }
     const bool keep_all = !(dF * di > 0.05);
     if (keep_all) dF = 1.0 / di;
@@ -2051,26 +2086,42 @@ __global__ __launch_bounds__(128) void prolong_rows_lds(int n, const int *__rest
     Kc[0][t] = ai;
     Vc[0][t] = 1.0;
     bool overflow = false;
-    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
-        const int j = cols[k];
-        int c;
-        double v;
-        if (j == i) { c = ai; v = -omega; }
-        else if (keep_all || strong(vals[k], di, dinv[j], theta2)) { c = agg[j]; v = w * vals[k]; }
-        else continue;
-        int lo = 0;
-        while (lo < m && Kc[lo][t] < c) ++lo;
-        if (lo < m && Kc[lo][t] == c) {
-            Vc[lo][t] = Vc[lo][t] + v;
-        } else {
-            if (m == CAP) { overflow = true; break; }
-            for (int u = m; u > lo; --u) {
-                Kc[u][t] = Kc[u - 1][t];
-                Vc[u][t] = Vc[u - 1][t];
+    for (int kb = k0; kb < k1 && !overflow; kb += 8) {
+        const int4 ca = load_i4_unaligned(cols + kb), cb = load_i4_unaligned(cols + kb + 4);
+        const double2 v0 = load_d2_unaligned(vals + kb), v1 = load_d2_unaligned(vals + kb + 2),
+                      v2 = load_d2_unaligned(vals + kb + 4), v3 = load_d2_unaligned(vals + kb + 6);
+        const int j[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+        const double a[8] = {v0.x, v0.y, v1.x, v1.y, v2.x, v2.y, v3.x, v3.y};
+        double dj[8];
+        int aj[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool on = kb + u < k1;
+            dj[u] = on ? dinv[j[u]] : 1.0;
+            aj[u] = on ? agg[j[u]] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (kb + u >= k1 || overflow) continue;
+            int c;
+            double v;
+            if (j[u] == i) { c = ai; v = -omega; }
+            else if (keep_all || strong(a[u], di, dj[u], theta2)) { c = aj[u]; v = w * a[u]; }
+            else continue;
+            int lo = 0;
+            while (lo < m && Kc[lo][t] < c) ++lo;
+            if (lo < m && Kc[lo][t] == c) {
+                Vc[lo][t] = Vc[lo][t] + v;
+            } else {
+                if (m == CAP) { overflow = true; continue; }
+                for (int q = m; q > lo; --q) {
+                    Kc[q][t] = Kc[q - 1][t];
+                    Vc[q][t] = Vc[q - 1][t];
+                }
+                Kc[lo][t] = c;
+                Vc[lo][t] = v;
+                ++m;
             }
-            Kc[lo][t] = c;
-            Vc[lo][t] = v;
-            ++m;
         }
     }
     if (overflow) {
