@@ -876,8 +876,17 @@ __global__ void csr_dinv_kernel(int n_rows, const int *__restrict__ rowptr,
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
     double d = 0.0;
-    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k)
-        if (cols[k] == r) d += vals[k];
+    const int k0 = rowptr[r], k1 = rowptr[r + 1];
+    // eight columns per look (two unaligned 16-byte loads; behind the row's end lies the next row or the zero padding of the
+    // array, and is not used): entry by entry the thirteen entries of a first-coarse-level row were thirteen dependent steps
+    struct __attribute__((packed, aligned(4))) I4u { int x, y, z, w; };
+    for (int kb = k0; kb < k1; kb += 8) {
+        const I4u a = *reinterpret_cast<const I4u *>(cols + kb), b = *reinterpret_cast<const I4u *>(cols + kb + 4);
+        const int c[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (kb + u < k1 && c[u] == r) d += vals[kb + u];
+    }
     dinv[r] = 1.0 / d;
 }
 
