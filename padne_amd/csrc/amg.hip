@@ -785,6 +785,7 @@ __global__ __launch_bounds__(256) void gershgorin_filtered_kernel(int n, const i
 // of one per entry (0.56 ms for the 24 M entries of config C4's finest prolongator).  A workgroup whose columns span more
 // than kTcRange counts every entry globally.
 constexpr int kTcRange = 4096, kTcPer = 4;
+constexpr int kTfRange = 2048;        // transpose_fill: the columns of 256 rows; 16 KiB of LDS, eight workgroups per CU
 __global__ __launch_bounds__(256) void transpose_count(long long nnz, const int *__restrict__ cols, int *__restrict__ cnt) {
     __shared__ int lcnt[kTcRange];
     __shared__ int s_min, s_max;
@@ -847,8 +848,9 @@ __global__ __launch_bounds__(256) void transpose_fill(int n_rows, const int *__r
     // places in the columns are handed out like transpose_count counts: inside the workgroup by LDS atomics, and one
     // atomic per column met advances the column's cursor in memory -- an entry at a time every entry waited for its own
     // load, gather and atomic round trip, two or three times in a row.  (The kernel runs next to the product A P on the
-    // other stream; what it gains there shows in the setup as a whole -- 17.7 -> 16.95 ms on config C4 -- not in its own time.)
-    __shared__ int lcnt[kTcRange], lbase[kTcRange];
+    // other stream; with 32 KiB of LDS -- kTcRange columns -- it took 2.2 ms by its own clock and still shortened the setup,
+    // 17.7 -> 16.95 ms on config C4, because A P no longer waited for its atomics; with 16 KiB it takes 0.46 ms.)
+    __shared__ int lcnt[kTfRange], lbase[kTfRange];
     __shared__ int s_min, s_max;
     if (threadIdx.x == 0) {
         s_min = 0x7fffffff;
@@ -886,7 +888,7 @@ __global__ __launch_bounds__(256) void transpose_fill(int n_rows, const int *__r
     const int base = s_min;
     const long long range = (long long)s_max - base + 1;
     int at[4] = {0, 0, 0, 0};
-    if (s_max >= 0 && range <= kTcRange) {
+    if (s_max >= 0 && range <= kTfRange) {
         for (int j = threadIdx.x; j < (int)range; j += 256) lcnt[j] = 0;
         __syncthreads();
 #pragma unroll
