@@ -2496,15 +2496,17 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
             hipLaunchKernelGGL(spgemm_rows_dense, dim3(n), dim3(256), dense_lds, s, (int)Y->n_cols, X->rowptr, X->cols,
                                X->vals, y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len, 0);
         } else if (avg <= 24.0 && getenv("PADNE_SPGEMM_WAVE_ALL") == nullptr) {
-            // A*P on the fine levels: a dozen products per row -> one thread per row with small sorted lists in LDS
+            // A*P on the fine levels: a dozen products per row -> one thread per row with small sorted lists in LDS (12 entries:
+            // 18 KiB per workgroup, four waves per SIMD -- with 16 the LDS allowed three: 2.47 -> 2.16 ms on the fine level of config C4;
+            // the rare longer row is redone in global memory)
             if (getenv("PADNE_SPGEMM_NO_PIPE") != nullptr)
                 hipLaunchKernelGGL(spgemm_rows_lds<16>, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
                                    y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len);
             else if (y_cs == 1)
-                hipLaunchKernelGGL((spgemm_rows_lds_pipe<16, 9, 4, 1>), dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols,
+                hipLaunchKernelGGL((spgemm_rows_lds_pipe<12, 9, 4, 1>), dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols,
                                    X->vals, y_begin, y_cols, y_vals, y_end, slot_ptr, key, val, row_len);
             else
-                hipLaunchKernelGGL((spgemm_rows_lds_pipe<16, 9, 4, 2>), dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols,
+                hipLaunchKernelGGL((spgemm_rows_lds_pipe<12, 9, 4, 2>), dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols,
                                    X->vals, y_begin, y_cols, y_vals, y_end, slot_ptr, key, val, row_len);
             hipLaunchKernelGGL(spgemm_rows_redo, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
                                y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len);
