@@ -1463,6 +1463,40 @@ def test_headline_config_on_eight_ranks(ctx):
     assert res.rel_residual <= 1.1e-12 and res.levels >= 4 and 20 <= iters <= 45
 
 
+@pytest.mark.parametrize("shape,jitter", [((128, 64), True), ((129, 127), True), ((127, 129), False), ((256, 256), False),
+                                           ((255, 257), True), ((64, 2), False), ((2, 64), True), ((91, 90), False)])
+def test_assembly_at_the_edges_of_its_tiles_and_chunks(ctx, shape, jitter):
+    """The row kernel works in tiles of 128 rows and chunks of 64 tiles (8192 rows), its scan hands offsets from tile to
+    tile: vertex counts on, one below and one above those boundaries, plus one extra unknown behind the vertices.  The
+    unjittered grids have right angles -- exact zero weights that are not stored, so the rows are SHORTER than their
+    fans suggest and only the in-kernel scan knows where they go.  Structure and values bit for bit against the oracle."""
+    nx, ny = shape
+    if jitter:
+        xy, tri = synthetic.jittered_grid(nx, ny, seed=nx * 1000 + ny)
+    else:
+        gx, gy = np.meshgrid(np.arange(nx, dtype=np.float64), np.arange(ny, dtype=np.float64), indexing="xy")
+        xy = np.stack([gx.ravel(), gy.ravel()], 1) * 0.25
+        q = (np.arange(ny - 1)[:, None] * nx + np.arange(nx - 1)[None, :]).ravel()
+        tri = np.concatenate([np.stack([q, q + 1, q + nx + 1], 1), np.stack([q, q + nx + 1, q + nx], 1)]).astype(np.int32)
+    n = len(xy)
+    els = [("R", 3, n - 2, 0.5), ("R", n // 2, n, 2.0), ("R", n, 7, 1.0)]      # two stamps on vertices, one internal node
+    Lo, _ = O.assemble_system([(xy, tri, 2082.5)], 1, els, 0)
+    Lo.sort_indices()
+    N = Lo.shape[0]
+    rows, cols, vals = [], [], []
+    for _, a, b, res in els:
+        g = 1.0 / res
+        rows += [a, a, b, b]; cols += [a, b, b, a]; vals += [-g, g, -g, g]
+    rows += [N - 1, 0]; cols += [0, N - 1]; vals += [1.0, 1.0]
+    L = ctx.assemble_system(N, xy, tri.astype(np.int32), np.array([0, n], np.int64), np.array([0, len(tri)], np.int64),
+                            np.array([2082.5]), np.array(rows, np.int64), np.array(cols, np.int64), np.array(vals))
+    got = L.to_scipy()
+    L.close()
+    assert H.same_structure(got, Lo) and np.array_equal(got.data.view(np.int64), Lo.data.view(np.int64))
+    if not jitter:
+        assert got.nnz < 7 * n                                 # the diagonals of the squares carry no weight
+
+
 def test_assemblies_running_side_by_side_on_one_gpu_are_the_serial_result(ctx):
     """The row kernel finds its offsets with a scan that runs INSIDE it (workgroups publish counts, a scanner wave the
     offsets; `asm_rows_in_place`).  Six contexts assemble six different systems on the same GPU at the same time --
