@@ -897,18 +897,22 @@ __global__ __launch_bounds__(128) void asm_rows_long_fans(const int *__restrict_
 // kernel runs; it leaves room for them, asm_place_listed moves them in.
 // Tickets.  One counter for all workgroups limits the kernel: an agent-scope atomic on ONE address is served about every
 // 12 ns.  kTicketSeqs counters, each on a line of its own, hand out interleaved sequences of tiles (sequence q owns the
-// tiles q, q + kTicketSeqs, ...); a workgroup starts with the sequence of its number and moves on to the next when one
-// is used up, so every tile is taken as long as anybody runs, and as the sequences advance together the tiles still start
-// nearly in order -- which is all the scan needs to be quick; its correctness needs no order at all.
+// tiles q, q + kTicketSeqs, ...); a workgroup takes its tickets from the sequences in turn (starting with the one of its
+// number), so all sequences advance together whatever the number of workgroups and the tiles still start nearly in order
+// -- which is all the scan needs to be quick; its correctness needs no order at all.  A used-up sequence is skipped from
+// then on; every tile is taken as long as anybody runs.
 constexpr int kTicketSeqs = 32, kTicketStride = 16;
-__device__ __forceinline__ int next_tile(int *__restrict__ counters, int &seq, int &tried, const int n_tiles) {
+__device__ __forceinline__ int next_tile(int *__restrict__ counters, int &seq, unsigned &used_up, const int n_tiles) {
     // one thread; n_tiles when every sequence is used up
-    while (tried < kTicketSeqs) {
-        const int k = atomicAdd(&counters[seq * kTicketStride], 1);
-        const long long tile = (long long)k * kTicketSeqs + seq;
-        if (tile < n_tiles) return (int)tile;
+    static_assert(kTicketSeqs == 32, "one bit per sequence in used_up");
+    while (used_up != 0xffffffffu) {
+        const int q = seq;
         seq = (seq + 1) % kTicketSeqs;
-        ++tried;
+        if ((used_up >> q) & 1u) continue;
+        const int k = atomicAdd(&counters[q * kTicketStride], 1);
+        const long long tile = (long long)k * kTicketSeqs + q;
+        if (tile < n_tiles) return (int)tile;
+        used_up |= 1u << q;
     }
     return n_tiles;
 }
@@ -947,7 +951,8 @@ __global__ __launch_bounds__(128) void asm_rows_in_place(const RowsInPlace a) {
     const int n_tiles = a.scan.n_tiles;
     // the slow words of the protocol (agent-scope atomics and loads, a few us each) are asked for early and looked at late,
     // and the two waves share them: wave 1 fetches the tickets, wave 0 publishes and collects the offsets
-    int seq = blockIdx.x % kTicketSeqs, tried = 0;          // (thread 64's)
+    int seq = blockIdx.x % kTicketSeqs;                    // (thread 64's)
+    unsigned tried = 0u;                                    // (thread 64's) sequences found used up
     int ticket_ahead = n_tiles;                             // (thread 64's) the ticket of the turn after this one
     if (t == 64) {
         s_ticket[0] = next_tile(a.scan.ticket, seq, tried, n_tiles);
