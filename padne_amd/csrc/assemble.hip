@@ -897,13 +897,23 @@ __global__ __launch_bounds__(128) void asm_rows_long_fans(const int *__restrict_
 // kernel runs; it leaves room for them, asm_place_listed moves them in.
 // Tickets.  One counter for all workgroups limits the kernel: an agent-scope atomic on ONE address is served about every
 // 12 ns.  kTicketSeqs counters, each on a line of its own, hand out interleaved sequences of tiles (sequence q owns the
-// tiles q, q + kTicketSeqs, ...); a workgroup takes its tickets from the sequences in turn (starting with the one of its
-// number), so all sequences advance together whatever the number of workgroups and the tiles still start nearly in order
-// -- which is all the scan needs to be quick; its correctness needs no order at all.  A used-up sequence is skipped from
-// then on; every tile is taken as long as anybody runs.
-constexpr int kTicketSeqs = 32, kTicketStride = 16;
-__device__ __forceinline__ int next_tile(int *__restrict__ counters, int &seq, unsigned &used_up, const int n_tiles) {
-    // one thread; n_tiles when every sequence is used up
+// tiles q, q + kTicketSeqs, ...), a workgroup draws from the sequence of its number: the sequences advance together, so
+// the tiles still start nearly in order, which is all the scan needs to be quick.
+// What its CORRECTNESS needs: a workgroup must never wait for an offset that depends on a tile it holds itself and has not
+// published.  While it waits for the offset of tile H it has published everything it built; what it may still hold is a
+// ticket drawn ahead of time.  Drawn from its own sequence that ticket is larger than H (a sequence only grows) and H's
+// offset does not depend on it.  When the own sequence is used up the workgroup draws from the others -- those tickets
+// can be smaller than H -- and then only at the top of a turn, when everything it holds is published (kLateTicket marks
+// a turn whose ticket is drawn that way).  (Tickets drawn ahead from all sequences in turn made six assemblies side by
+// side wait for themselves until the poll limit.)
+constexpr int kTicketSeqs = 32, kTicketStride = 16, kLateTicket = -1;
+__device__ __forceinline__ int take_own_ticket(int *__restrict__ counters, const int seq, const int n_tiles) {
+    const int k = atomicAdd(&counters[seq * kTicketStride], 1);
+    const long long tile = (long long)k * kTicketSeqs + seq;
+    return tile < n_tiles ? (int)tile : kLateTicket;
+}
+__device__ __forceinline__ int take_any_ticket(int *__restrict__ counters, int &seq, unsigned &used_up, const int n_tiles) {
+    // n_tiles when every sequence is used up
     static_assert(kTicketSeqs == 32, "one bit per sequence in used_up");
     while (used_up != 0xffffffffu) {
         const int q = seq;
@@ -945,25 +955,32 @@ __global__ __launch_bounds__(128) void asm_rows_in_place(const RowsInPlace a) {
     constexpr int kStage = 128 * (kFanShort + 2);           // a row of this kernel holds at most kFanShort + 1 neighbours and the diagonal
     __shared__ int stage_c[kStage];
     __shared__ double stage_v[kStage];
-    __shared__ int s_ticket[2], s_wave_total[2][2], s_wave_built[2][2], s_abort;      // (tickets and wave totals alternate between two sets by turn)
+    __shared__ int s_ticket[2], s_late, s_wave_total[2][2], s_wave_built[2][2], s_abort;      // (tickets and wave totals alternate between two sets by turn)
     __shared__ long long s_before;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int n_tiles = a.scan.n_tiles;
     // the slow words of the protocol (agent-scope atomics and loads, a few us each) are asked for early and looked at late,
     // and the two waves share them: wave 1 fetches the tickets, wave 0 publishes and collects the offsets
-    int seq = blockIdx.x % kTicketSeqs;                    // (thread 64's)
-    unsigned tried = 0u;                                    // (thread 64's) sequences found used up
-    int ticket_ahead = n_tiles;                             // (thread 64's) the ticket of the turn after this one
+    const int own_seq = blockIdx.x % kTicketSeqs;
+    int any_seq = (own_seq + 1) % kTicketSeqs;              // (thread 64's) where the late tickets come from next
+    unsigned used_up = 1u << own_seq;                       // (thread 64's) sequences found used up (the own one is never asked late)
+    int ticket_ahead = kLateTicket;                         // (thread 64's) the ticket of the turn after this one
     if (t == 64) {
-        s_ticket[0] = next_tile(a.scan.ticket, seq, tried, n_tiles);
+        s_ticket[0] = take_own_ticket(a.scan.ticket, own_seq, n_tiles);
         s_abort = 0;
-        ticket_ahead = s_ticket[0] < n_tiles ? next_tile(a.scan.ticket, seq, tried, n_tiles) : n_tiles;
+        ticket_ahead = s_ticket[0] != kLateTicket ? take_own_ticket(a.scan.ticket, own_seq, n_tiles) : kLateTicket;
     }
     __syncthreads();
     int tile = s_ticket[0];
     bool held = false, held_direct = false;
     int held_tile = 0, held_len = 0, held_local = 0, held_total = 0, held_blocal = 0, held_built = 0;
     for (int turn = 0;; ++turn) {
+        if (tile == kLateTicket) {                          // (uniform) the own sequence is used up: see above
+            if (t == 64) s_late = take_any_ticket(a.scan.ticket, any_seq, used_up, n_tiles);
+            __syncthreads();
+            tile = s_late;
+            __syncthreads();                                // (s_late is rewritten at the top of a later turn)
+        }
         const bool work = tile < n_tiles;
         if (!work && !held) break;
         // first look at the offset of the tile that waits: asked for now, examined after this tile's rows are built
@@ -1108,7 +1125,11 @@ __global__ __launch_bounds__(128) void asm_rows_in_place(const RowsInPlace a) {
             }
             return;
         }
-        if (t == 64) ticket_ahead = tile_after < n_tiles ? next_tile(a.scan.ticket, seq, tried, n_tiles) : n_tiles;
+        // the ticket after the next: ahead of time from the own sequence only (larger than everything held); once that is
+        // used up every ticket is drawn late.  Nothing is drawn behind the end.
+        if (t == 64)
+            ticket_ahead = !work ? n_tiles : (tile_after == kLateTicket || tile_after >= n_tiles) ? tile_after
+                                               : take_own_ticket(a.scan.ticket, own_seq, n_tiles);
         held = work;
         held_tile = tile;
         held_len = len;

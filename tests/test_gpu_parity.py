@@ -1501,9 +1501,12 @@ def test_assemblies_running_side_by_side_on_one_gpu_are_the_serial_result(ctx):
     """The row kernel finds its offsets with a scan that runs INSIDE it (workgroups publish counts, a scanner wave the
     offsets; `asm_rows_in_place`).  Six contexts assemble six different systems on the same GPU at the same time --
     their workgroups share the chip, none of the kernels has it to itself -- and each result is the one the same
-    context produces alone, bit for bit; twice, so that a wrong order of two memory operations has chances to show."""
+    context produces alone, bit for bit; four times, so that a wrong order of two memory operations -- or a workgroup that
+    waits for a tile it holds itself -- has chances to show."""
     import threading
-    systems = [synthetic.layered_system(3, 260 + 7 * k, 230 + 5 * k, via_lattice=9) for k in range(6)]
+    # (four large systems -- a thousand tiles each -- and two of a few tiles, whose workgroups draw most of their tickets late)
+    systems = [synthetic.layered_system(3, 260 + 7 * k, 230 + 5 * k, via_lattice=9) for k in range(4)]
+    systems += [synthetic.layered_system(2, 40 + 3 * k, 30 + k, via_lattice=3) for k in range(2)]
 
     def arrays(sysm):
         N = sysm.n_vertices + 1
@@ -1528,7 +1531,7 @@ def test_assemblies_running_side_by_side_on_one_gpu_are_the_serial_result(ctx):
 
     prepared = [arrays(sm) for sm in systems]
     alone = [assemble(ctx, sm, p) for sm, p in zip(systems, prepared)]
-    for _ in range(2):
+    for _ in range(4):
         out, errors = [None] * len(systems), []
 
         def worker(k):
