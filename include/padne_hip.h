@@ -112,7 +112,10 @@ int padne_csr_to_host(padne_ctx *ctx, const padne_csr *m, int32_t *indptr, int32
  * [mesh_vertex_offset[m], mesh_vertex_offset[m+1]) (VertexIndexer, solver.py:221-229) and
  * triangles [mesh_tri_offset[m], mesh_tri_offset[m+1]).  Duplicate (row, col) stamps are summed
  * in stamp order after the mesh contribution; exact zeros are not stored (solver.py:187-190).
- * Returns PADNE_E_NONMANIFOLD where Mesh.from_triangle_soup raises ValueError (mesh.py:342-343). */
+ * Returns PADNE_E_NONMANIFOLD where Mesh.from_triangle_soup raises ValueError (mesh.py:342-343).
+ * The matrix arrays are allocated for an upper bound of the entries (one per triangle corner, two per vertex, the
+ * stamps) and the rows are written once, in place; padne_csr_shape reports the exact count.  PADNE_E_TOOLARGE when
+ * that bound exceeds the 32-bit index space of a CSR matrix (about 268 M mesh vertices). */
 int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns,
                           int64_t n_vert, const double *xy_host,
                           int64_t n_tri, const int32_t *tri_host,
