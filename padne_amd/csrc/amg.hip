@@ -786,7 +786,8 @@ __global__ __launch_bounds__(256) void gershgorin_filtered_kernel(int n, const i
 // than kTcRange counts every entry globally.
 constexpr int kTcRange = 4096, kTcPer = 4;
 constexpr int kTfRange = 2048;        // transpose_fill: the columns of 256 rows; 16 KiB of LDS, eight workgroups per CU
-__global__ __launch_bounds__(256) void transpose_count(long long nnz, const int *__restrict__ cols, int *__restrict__ cnt) {
+__global__ __launch_bounds__(256) void transpose_count(long long nnz, const int *__restrict__ cols, int *__restrict__ cnt, const int no_range) {
+    // no_range (PADNE_TRANSPOSE_HASH, tests): every workgroup takes the hash path of the wide ranges
     __shared__ int lcnt[kTcRange];
     __shared__ int s_min, s_max;
     if (threadIdx.x == 0) {
@@ -822,10 +823,30 @@ __global__ __launch_bounds__(256) void transpose_count(long long nnz, const int 
     const int base = s_min;
     if (s_max < 0) return;
     const long long range = (long long)s_max - base + 1;
-    if (range > kTcRange) {
+    if (range > kTcRange || no_range) {
+        // columns spread over a wider range (a mesh line longer than the table: 160 M unknowns): the same through a hash
+        // table of the columns met -- at most 1024 of them, 2048 places -- instead of one atomic per entry in memory
+        int *keys = lcnt, *num = lcnt + kTcRange / 2;
+        for (int j = threadIdx.x; j < kTcRange / 2; j += 256) {
+            keys[j] = -1;
+            num[j] = 0;
+        }
+        __syncthreads();
 #pragma unroll
         for (int u = 0; u < kTcPer; ++u)
-            if (c[u] >= 0) atomicAdd(&cnt[c[u]], 1);
+            if (c[u] >= 0) {
+                unsigned h = ((unsigned)c[u] * 2654435761u) >> 21;
+                for (;;) {
+                    h &= kTcRange / 2 - 1;
+                    const int old = atomicCAS(&keys[h], -1, c[u]);
+                    if (old == -1 || old == c[u]) break;
+                    ++h;
+                }
+                atomicAdd(&num[h], 1);
+            }
+        __syncthreads();
+        for (int j = threadIdx.x; j < kTcRange / 2; j += 256)
+            if (num[j] > 0) atomicAdd(&cnt[keys[j]], num[j]);
         return;
     }
     for (int j = threadIdx.x; j < (int)range; j += 256) lcnt[j] = 0;
@@ -843,7 +864,7 @@ __global__ __launch_bounds__(256) void transpose_count(long long nnz, const int 
 __global__ __launch_bounds__(256) void transpose_fill(int n_rows, const int *__restrict__ rowptr, const int *__restrict__ cols,
                                                       const double *__restrict__ vals, const int *__restrict__ slot_ptr,
                                                       int *__restrict__ cursor, long long *__restrict__ key,
-                                                      double *__restrict__ val) {
+                                                      double *__restrict__ val, const int no_range) {
     // One lane per row; the first four entries of every row together (their columns and values in three loads).  Their
     // places in the columns are handed out like transpose_count counts: inside the workgroup by LDS atomics, and one
     // atomic per column met advances the column's cursor in memory -- an entry at a time every entry waited for its own
@@ -888,7 +909,7 @@ __global__ __launch_bounds__(256) void transpose_fill(int n_rows, const int *__r
     const int base = s_min;
     const long long range = (long long)s_max - base + 1;
     int at[4] = {0, 0, 0, 0};
-    if (s_max >= 0 && range <= kTfRange) {
+    if (s_max >= 0 && range <= kTfRange && !no_range) {
         for (int j = threadIdx.x; j < (int)range; j += 256) lcnt[j] = 0;
         __syncthreads();
 #pragma unroll
@@ -909,10 +930,42 @@ __global__ __launch_bounds__(256) void transpose_fill(int n_rows, const int *__r
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             if (u < ln) at[u] += lbase[c[u] - base];
-    } else {
+    } else if (s_max >= 0) {
+        // columns spread over a wider range: the same through a hash table of the columns met (at most 1024, 2048 places)
+        static_assert(kTfRange == 2048, "hash of 11 bits");
+        int slot[4] = {0, 0, 0, 0};
+        for (int j = threadIdx.x; j < kTfRange; j += 256) {
+            lbase[j] = -1;                                 // (the keys, while the entries are counted)
+            lcnt[j] = 0;
+        }
+        __syncthreads();
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (u < ln) at[u] = atomicAdd(&cursor[c[u]], 1);
+            if (u < ln) {
+                unsigned h = ((unsigned)c[u] * 2654435761u) >> 21;
+                for (;;) {
+                    h &= kTfRange - 1;
+                    const int old = atomicCAS(&lbase[h], -1, c[u]);
+                    if (old == -1 || old == c[u]) break;
+                    ++h;
+                }
+                slot[u] = (int)h;
+                at[u] = atomicAdd(&lcnt[h], 1);
+            }
+        __syncthreads();
+        for (int j0 = threadIdx.x; j0 < kTfRange; j0 += 4 * 256) {
+            int n_here[4], got[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) n_here[q] = lcnt[j0 + 256 * q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) got[q] = n_here[q] > 0 ? atomicAdd(&cursor[lbase[j0 + 256 * q]], n_here[q]) : 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) lcnt[j0 + 256 * q] = got[q];      // (in place: the counts are in the lanes' registers)
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (u < ln) at[u] += lcnt[slot[u]];
     }
     int sp[4];
 #pragma unroll
@@ -2372,14 +2425,15 @@ static int transpose(padne_ctx *ctx, const padne_csr *M, padne_csr **T) {
     PADNE_TRY(sc.alloc(&row_len, (size_t)nc + 1));
     PADNE_TRY(sc.alloc(&key, (size_t)M->nnz));
     PADNE_TRY(sc.alloc(&val, (size_t)M->nnz));
+    const int no_range = getenv("PADNE_TRANSPOSE_HASH") != nullptr ? 1 : 0;
     PADNE_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)(nc + 1), s));
-    if (M->nnz > 0) hipLaunchKernelGGL(transpose_count, dim3(nblk(M->nnz, 256 * kTcPer)), dim3(256), 0, s, (long long)M->nnz, M->cols, cnt);
+    if (M->nnz > 0) hipLaunchKernelGGL(transpose_count, dim3(nblk(M->nnz, 256 * kTcPer)), dim3(256), 0, s, (long long)M->nnz, M->cols, cnt, no_range);
     PADNE_HIP_CHECK(hipGetLastError());
     PADNE_TRY(exclusive_scan_i32_async(ctx, cnt, slot_ptr, nc));
     PADNE_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)(nc + 1), s));
     if (M->n_rows > 0)
         hipLaunchKernelGGL(transpose_fill, dim3(nblk(M->n_rows)), dim3(256), 0, s, (int)M->n_rows, M->rowptr, M->cols,
-                           M->vals, slot_ptr, cnt, key, val);
+                           M->vals, slot_ptr, cnt, key, val, no_range);
     PADNE_HIP_CHECK(hipGetLastError());
     PADNE_TRY(sort_slots_exact(ctx, nc, slot_ptr, key, val, row_len));
     // a transpose has no duplicates: the counted slots are exact and, once sorted, already the CSR rows

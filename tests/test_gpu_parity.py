@@ -587,6 +587,20 @@ def test_sparse_products_of_the_setup_split_their_rows_when_the_slots_exceed_the
     assert np.abs(res.x - base.x).max() <= 1e-9 * np.abs(base.x).max()
 
 
+def test_transposes_of_the_setup_through_the_hash_table_of_wide_column_ranges(ctx, monkeypatch):
+    """The transposition of a prolongator counts and places its entries through LDS, indexed by column while the columns
+    of a workgroup's entries lie within a few thousand of each other, through a hash table of the columns met when they
+    do not (a mesh line longer than that: 160 M unknowns).  PADNE_TRANSPOSE_HASH sends every workgroup through the hash
+    table: the restriction operators -- and with them the hierarchy and the solve -- must be the same bit for bit."""
+    A, b, _, _, _ = layered_spd(3, 150, 110, 5)
+    base = ctx.csr_from_scipy(A).solve_spd(b, precond="amg")
+    monkeypatch.setenv("PADNE_TRANSPOSE_HASH", "1")
+    res = ctx.csr_from_scipy(A).solve_spd(b, precond="amg")
+    assert res.levels == base.levels and res.levels >= 3 and res.precond_fallbacks == 0
+    assert res.operator_complexity == base.operator_complexity and res.iterations == base.iterations
+    assert np.array_equal(res.x, base.x)
+
+
 def test_multigrid_and_jacobi_agree_with_the_direct_solve(ctx):
     A, b, Lo, ro, n = layered_spd(4, 120, 100, 6)
     v_ref = O.solve_system(Lo, ro)[0]
