@@ -315,7 +315,8 @@ __device__ __forceinline__ long long inc_at(const long long v, const int pos, co
 // strip-ordered mesh: two mesh lines, about as many distinct vertices as triangles, each touched three times).  Then
 // the corners are counted with LDS atomics first and the global counter of a vertex is advanced ONCE per workgroup by
 // the number of its corners here: a third of the global atomics.  A workgroup whose vertices span more than
-// kCntRange indices (unordered triangle lists) counts every corner globally, as before.
+// kCntRange indices (unordered triangle lists, very long mesh lines) does the same through a hash table of the vertices
+// it meets.
 constexpr int kCntRange = 4096;
 struct __attribute__((packed, aligned(4))) Int3 { int a, b, c; };
 constexpr int kCntTris = 2;           // triangles per thread (1: 441 us, 2: 417 us, 4: 443 us at N = 10 M): the dependent steps below (range,
@@ -323,7 +324,8 @@ constexpr int kCntTris = 2;           // triangles per thread (1: 441 us, 2: 417
 __global__ __launch_bounds__(256) void asm_count_tri(long long n_tri, const int *__restrict__ tri, int n_mesh,
                                                      const long long *__restrict__ mesh_voff,
                                                      const long long *__restrict__ mesh_toff, int *__restrict__ cnt,
-                                                     int2 *__restrict__ inc, int *__restrict__ err) {
+                                                     int2 *__restrict__ inc, int *__restrict__ err, const int no_range) {
+    // no_range (PADNE_ASM_HASH, tests): every workgroup takes the hash path of the wide ranges
     __shared__ int lcnt[kCntRange], lbase[kCntRange];
     __shared__ int s_min, s_max;
     if (threadIdx.x == 0) {
@@ -378,13 +380,46 @@ __global__ __launch_bounds__(256) void asm_count_tri(long long n_tri, const int 
     const int base = s_min;
     const long long range = (long long)s_max - base + 1;
     if (s_max < 0) return;                                // no valid triangle in this workgroup
-    if (range > kCntRange) {
+    if (range > kCntRange || no_range) {
+        // vertices spread over a wider range (unordered triangle lists; a mesh line longer than the table: 160 M vertices):
+        // the same through a hash table of the vertices met -- at most 3 * 256 * kCntTris of them, kCntRange places
+        static_assert(3 * 256 * kCntTris <= kCntRange / 2 && kCntRange == 4096, "hash of 12 bits, load at most 3/8");
+        int slot[kCntTris][3], hpos[kCntTris][3];
+        for (int j = threadIdx.x; j < kCntRange; j += 256) {
+            lbase[j] = -1;                                 // (the keys, while the corners are counted)
+            lcnt[j] = 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kCntTris; ++u)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                slot[u][q] = 0;
+                hpos[u][q] = 0;
+                if (ok[u]) {
+                    unsigned h = ((unsigned)g[u][q] * 2654435761u) >> 20;
+                    for (;;) {
+                        h &= kCntRange - 1;
+                        const int old = atomicCAS(&lbase[h], -1, g[u][q]);
+                        if (old == -1 || old == g[u][q]) break;
+                        ++h;
+                    }
+                    slot[u][q] = (int)h;
+                    hpos[u][q] = atomicAdd(&lcnt[h], 1);
+                }
+            }
+        __syncthreads();
+        for (int j = threadIdx.x; j < kCntRange; j += 256) {
+            const int c = lcnt[j];
+            lcnt[j] = c > 0 ? atomicAdd(&cnt[lbase[j]], c) : 0;      // (in place: the counts are in the lanes' registers)
+        }
+        __syncthreads();
 #pragma unroll
         for (int u = 0; u < kCntTris; ++u)
             if (ok[u])
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
-                    const int pos = atomicAdd(&cnt[g[u][q]], 1);      // incident triangles per vertex
+                    const int pos = lcnt[slot[u][q]] + hpos[u][q];
                     if (pos < kIncCap) inc[inc_at(g[u][q], pos, n_vert)] = make_int2(g[u][(q + 1) % 3], g[u][(q + 2) % 3]);
                 }
         return;
@@ -2038,7 +2073,7 @@ extern "C" int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns, int64_t
     PADNE_HIP_CHECK(hipMemsetAsync(d_nlisted, 0, sizeof(int) * 2, s));
     if (n_tri > 0)
         hipLaunchKernelGGL(asm_count_tri, dim3(nblk(n_tri, 256 * kCntTris)), dim3(256), 0, s, (long long)n_tri, d_tri, (int)n_mesh,
-                           d_voff, d_toff, d_ninc, d_inc, d_err);
+                           d_voff, d_toff, d_ninc, d_inc, d_err, getenv("PADNE_ASM_HASH") != nullptr ? 1 : 0);
     if (n_coo > 0)
         hipLaunchKernelGGL(asm_count_coo, dim3(nblk(n_coo)), dim3(256), 0, s, (long long)n_coo, d_crow, d_ncoo);
     // 2 the rows that go through the slots (stamps, hubs, the unknowns behind the vertices; long fans): lists, slot counts, offsets

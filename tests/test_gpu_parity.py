@@ -1577,6 +1577,20 @@ def test_randomised_assembly_is_the_oracle_bit_for_bit(ctx):
     assert fz.run(16, seed0=5, verbose=False) > 12          # the sweep reached vertices beyond the in-LDS path
 
 
+def test_incidence_pass_through_the_hash_table_of_wide_vertex_ranges(ctx, monkeypatch):
+    """The incidence pass counts the corners of a workgroup's triangles in LDS, indexed by vertex while the vertices lie
+    within 4096 of each other, through a hash table of the vertices met when they do not (unordered triangle lists, mesh
+    lines longer than that).  PADNE_ASM_HASH sends every workgroup through the hash table: the same matrices bit for bit."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_assembly", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_assembly.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    monkeypatch.setenv("PADNE_ASM_HASH", "1")
+    assert fz.run(10, seed0=9, verbose=False) > 12
+
+
 def test_randomised_systems_against_the_direct_solve(ctx):
     """scripts/fuzz_parity.py: random multi-layer systems with vias, internal nodes, current sources, forests of
     voltage sources and regulators, in the reference's KKT layout; the product path against the reference's direct
