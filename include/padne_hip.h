@@ -73,6 +73,32 @@ int padne_ctx_comm_rank(padne_ctx *ctx, int *rank, int *world_size);
  * rank's contributions.  Bookkeeping for DESIGN.md section 6 (what a multi-GPU solve costs), also counted for the
  * in-process team. */
 int padne_comm_call_counts(long long calls[4], long long bytes[4]);
+/* The same collectives through a transport of the CALLER (gloo, MPI, ...) instead of RCCL: ranks RCCL cannot connect
+ * -- two processes on one GPU -- or a host that has no RCCL.  `allgather(user, send, recv, bytes_per_rank)` gathers
+ * bytes_per_rank bytes of HOST memory from every rank into recv (rank order; send may lie inside recv) and returns 0;
+ * any other value fails the call that needed it with PADNE_E_COMM.  Every collective of the library then goes device ->
+ * host -> callback -> device (sums are formed in rank order: the same bits on every rank, as with RCCL); it is the
+ * slow path by construction -- what makes it usable is the peer-to-peer halo exchange below, which takes the four
+ * exchanges of a CG iteration out of the collectives. */
+typedef int (*padne_allgather_fn)(void *user, const void *send, void *recv, int64_t bytes_per_rank);
+int padne_ctx_comm_init_host(padne_ctx *ctx, int rank, int world_size, padne_allgather_fn allgather, void *user);
+/* Peer-to-peer halo exchange between PROCESSES (one per GPU, or several on one GPU): every rank owns a mailbox in
+ * device memory -- a ring of exchange entries of world_size * slots_per_rank 8-byte cells behind a page of arrival
+ * flags -- allocated uncached and shared through hipIpc.  A halo exchange is then: every rank STORES its exported
+ * values straight into every rank's mailbox and, when its stores are out (system-scope release), writes the exchange's
+ * sequence number into its flag there; the receiver's next kernel on the stream waits for the flags of all senders
+ * (bounded: PADNE_P2P_TIMEOUT_MS, default 20 s, then the solve returns PADNE_E_COMM) and copies the entry behind its
+ * owned values.  No collective, no host involvement, and the interior tiles of the product the exchange is for run
+ * while the stores travel.  Protocol, collective over the ranks of a communicator (RCCL or host):
+ *   padne_ctx_p2p_export   allocate this rank's mailbox, write its 64-byte hipIpc handle to handle64
+ *   -- the caller all-gathers the handles (rank order) --
+ *   padne_ctx_p2p_import   open the other ranks' mailboxes (handles = world_size * 64 bytes); from here on exchanges
+ *                          whose plan has at most slots_per_rank slots per rank go peer to peer
+ *   padne_ctx_p2p_close    back to the all-gather (also done by padne_ctx_destroy); collective like the two above
+ * PADNE_NO_P2P=1 keeps the all-gather although mailboxes exist (A/B, tests). */
+int padne_ctx_p2p_export(padne_ctx *ctx, int32_t slots_per_rank, void *handle64);
+int padne_ctx_p2p_import(padne_ctx *ctx, const void *handles, int32_t n_handles);
+int padne_ctx_p2p_close(padne_ctx *ctx);
 
 /* Halo plan of a row-partitioned matrix (layer partition).  Every vector the
  * local matrix multiplies is laid out [n_owned owned entries | world_size * m exchanged entries];

@@ -29,6 +29,9 @@ int padne_csr_split_tiles(const padne_csr *m, int level, int64_t *interior, int6
 /* Groups of right-hand sides (eight, or five to seven zero-padded) this context has advanced in lockstep through the
  * batched multigrid-PCG so far -- what tells a test that the K + 1 right-hand sides of K regulators took that path. */
 int padne_ctx_lockstep_groups(const padne_ctx *ctx, int64_t *groups);
+/* Assemblies of this process whose rows were built by the two-pass second path of the row kernel (count, scan, fill):
+ * forced with PADNE_ASM_TWO_PASS=1, or taken after the single-pass kernel's in-kernel scan gave up on a shared chip. */
+int padne_asm_second_path_count(int64_t *count);
 
 #ifdef __cplusplus
 }

@@ -65,6 +65,10 @@ SIGNATURES = {
     "padne_ctx_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "padne_ctx_comm_rank": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "padne_comm_call_counts": (C.c_int, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "padne_ctx_comm_init_host": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
+    "padne_ctx_p2p_export": (C.c_int, [_P, C.c_int32, _P]),
+    "padne_ctx_p2p_import": (C.c_int, [_P, _P, C.c_int32]),
+    "padne_ctx_p2p_close": (C.c_int, [_P]),
     "padne_ctx_set_halo": (C.c_int, [_P, _I64, C.c_int32, C.c_int32, _PI32]),
     "padne_dev_alloc": (C.c_int, [_P, _I64, C.POINTER(_P)]),
     "padne_dev_free": (C.c_int, [_P, _P]),
@@ -118,6 +122,7 @@ TEST_SIGNATURES = {
     "padne_ctx_join_team": (C.c_int, [_P, _P, C.c_int]),
     "padne_csr_split_tiles": (C.c_int, [_P, C.c_int, _PI64, _PI64]),
     "padne_ctx_lockstep_groups": (C.c_int, [_P, _PI64]),
+    "padne_asm_second_path_count": (C.c_int, [_PI64]),
 }
 
 _lib = None
@@ -190,6 +195,16 @@ def device_count() -> int:
     return max(n, 0)
 
 
+def asm_second_path_count() -> int:
+    """Assemblies of this process that took the two-pass second path of the row kernel (test introspection)."""
+    n = C.c_int64(0)
+    _check(load_library().padne_asm_second_path_count(C.byref(n)))
+    return int(n.value)
+
+
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, _P, _P, _P, C.c_int64)      # padne_allgather_fn
+
+
 class Context:
     """Device context: GPU, stream, workspaces, optional RCCL communicator."""
 
@@ -239,6 +254,37 @@ class Context:
     def comm_init(self, unique_id: bytes, rank: int, world_size: int):
         buf = C.create_string_buffer(bytes(unique_id), 128)
         _check(self._lib.padne_ctx_comm_init(self._h, buf, int(rank), int(world_size)))
+
+    def comm_init_host(self, rank: int, world_size: int, allgather):
+        """Collectives through a transport of the caller (gloo, MPI): ``allgather(send: np.ndarray[uint8]) -> bytes-like`` of
+        ``world_size * len(send)`` bytes in rank order.  An exception in it fails the collective with PADNE_E_COMM."""
+        world_size = int(world_size)
+
+        def cb(_user, send, recv, nbytes):
+            try:
+                src = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_ubyte)), shape=(int(nbytes),)).copy()
+                out = np.frombuffer(allgather(src), dtype=np.uint8)
+                if out.size != world_size * int(nbytes):
+                    return 2
+                C.memmove(recv, out.ctypes.data, out.size)
+                return 0
+            except BaseException:      # noqa: BLE001 -- whatever the transport raises: the collective failed
+                return 1
+        self._host_allgather = ALLGATHER_FN(cb)             # (kept alive with the context)
+        _check(self._lib.padne_ctx_comm_init_host(self._h, int(rank), world_size, C.cast(self._host_allgather, _P), None))
+
+    def p2p_export(self, slots_per_rank: int) -> bytes:
+        """This rank's mailbox of the peer-to-peer halo exchange between processes: allocate, return the 64-byte hipIpc handle."""
+        buf = C.create_string_buffer(64)
+        _check(self._lib.padne_ctx_p2p_export(self._h, int(slots_per_rank), buf))
+        return buf.raw
+
+    def p2p_import(self, handles: bytes, world_size: int) -> None:
+        buf = C.create_string_buffer(bytes(handles), 64 * int(world_size))
+        _check(self._lib.padne_ctx_p2p_import(self._h, buf, int(world_size)))
+
+    def p2p_close(self) -> None:
+        _check(self._lib.padne_ctx_p2p_close(self._h))
 
     def comm_call_counts(self):
         """(calls, bytes) of the communication issued so far: all-reduce, all-gather f64, all-gather f32 (the collectives)

@@ -30,6 +30,8 @@
 // round exactly like the reference's Python floats (no fused multiply-add).
 #include "common.hpp"
 
+#include <atomic>
+
 #include <cmath>
 
 #include <algorithm>
@@ -285,7 +287,10 @@ int exclusive_scan_i32_flagged(padne_ctx *ctx, const int32_t *in, int32_t *out, 
 // ------------------------------------------------------------------------------------------
 // assembly kernels
 // ------------------------------------------------------------------------------------------
-enum { ERR_BAD_INDEX = 0, ERR_NONMANIFOLD = 1, ERR_LONG_ROWS = 2, ERR_HUB = 4, ERR_SCAN = 5, ERR_WORDS = 8 };
+enum { ERR_BAD_INDEX = 0, ERR_NONMANIFOLD = 1, ERR_LONG_ROWS = 2, ERR_HUB = 4, ERR_SCAN = 5,
+       ERR_GAVE_UP = 6,      // a bounded wait of asm_rows_in_place's in-kernel scan ran out: not an error of the input, the
+                             // host builds the rows again in two passes (asm_rows_two_pass)
+       ERR_WORDS = 8 };
 
 __device__ __forceinline__ int find_segment(const long long *__restrict__ offs, int n_seg, long long i) {
     // largest m with offs[m] <= i   (offs has n_seg+1 entries, offs[0] = 0)
@@ -991,6 +996,7 @@ __global__ __launch_bounds__(128) void asm_rows_in_place(const RowsInPlace a) {
     __shared__ int stage_c[kStage];
     __shared__ double stage_v[kStage];
     __shared__ int s_ticket[2], s_late, s_wave_total[2][2], s_wave_built[2][2], s_abort;      // (tickets and wave totals alternate between two sets by turn)
+    __shared__ int s_gave_up[2];                            // a wait given up at the END of a turn, by turn parity: read behind the next turn's barrier
     __shared__ long long s_before;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int n_tiles = a.scan.n_tiles;
@@ -1003,6 +1009,7 @@ __global__ __launch_bounds__(128) void asm_rows_in_place(const RowsInPlace a) {
     if (t == 64) {
         s_ticket[0] = take_own_ticket(a.scan.ticket, own_seq, n_tiles);
         s_abort = 0;
+        s_gave_up[0] = s_gave_up[1] = 0;
         ticket_ahead = s_ticket[0] != kLateTicket ? take_own_ticket(a.scan.ticket, own_seq, n_tiles) : kLateTicket;
     }
     __syncthreads();
@@ -1100,6 +1107,10 @@ __global__ __launch_bounds__(128) void asm_rows_in_place(const RowsInPlace a) {
         }
         if (t == 64) s_ticket[(turn + 1) & 1] = ticket_ahead;      // (asked for at the end of the previous turn)
         __syncthreads();                                   // wave totals, the next ticket
+        if (turn > 0 && s_gave_up[(turn - 1) & 1]) {        // (uniform: written before this barrier, and the word of THIS
+            if (t == 0) atomicExch(&a.err[ERR_GAVE_UP], 1);   //  turn's parity is not written before the next one)
+            return;
+        }
         const int tile_after = work ? s_ticket[(turn + 1) & 1] : tile;
         int arrived = 0;
         if (work) {
@@ -1126,8 +1137,8 @@ __global__ __launch_bounds__(128) void asm_rows_in_place(const RowsInPlace a) {
                 }
             }
             __syncthreads();
-            if (s_abort) {
-                if (t == 0) atomicExch(&a.err[ERR_SCAN], 1);
+            if (s_abort) {                                  // (uniform: read behind the barrier by both waves)
+                if (t == 0) atomicExch(&a.err[ERR_GAVE_UP], 1);
                 return;
             }
             const long long hr = (long long)held_tile * 128 + t;
@@ -1154,11 +1165,9 @@ __global__ __launch_bounds__(128) void asm_rows_in_place(const RowsInPlace a) {
             __syncthreads();                               // the stage is rewritten below
         }
         if (!chunk_done && wv == 0 && !chunk_publish(a.scan, tile, arrived, lane)) {
-            if (lane == 0) {                                     // (the other wave learns it behind its next barrier)
-                atomicExch(&a.err[ERR_SCAN], 1);
-                s_abort = 1;
-            }
-            return;
+            // the wait was given up: both waves leave TOGETHER, behind the next barrier they share (the one in front of
+            // the publish of the next turn), never one wave alone in front of a barrier the other still goes to
+            if (lane == 0) s_gave_up[turn & 1] = 1;
         }
         // the ticket after the next: ahead of time from the own sequence only (larger than everything held); once that is
         // used up every ticket is drawn late.  Nothing is drawn behind the end.
@@ -1176,6 +1185,61 @@ __global__ __launch_bounds__(128) void asm_rows_in_place(const RowsInPlace a) {
         if (work && direct) fan_row_store<kFanShort>((int)((long long)tile * 128 + t), col, w, dval, stage_c + blocal, stage_v + blocal);
         tile = tile_after;
     }
+    __syncthreads();                                       // (the loop is left by both waves in the same turn)
+    if ((s_gave_up[0] | s_gave_up[1]) != 0 && t == 0) atomicExch(&a.err[ERR_GAVE_UP], 1);
+}
+
+// The second path of the row kernel: the same rows in two passes, for when the in-kernel scan gives up (a chip shared
+// with other work can starve its scanner or a ticket holder until a bounded wait runs out -- that is a property of the
+// moment, not of the input).  COUNT leaves every row's length (a listed row's is its merged length), an ordinary
+// exclusive scan turns the lengths into the row pointer, FILL builds the rows again -- the same fan_row, hence the same
+// bits -- and every lane stores its row at its offset.  Twice the arithmetic and uncoalesced stores: about 3x the time of
+// the single pass, which is why it is the second path and not the first.
+template <bool FILL>
+__global__ __launch_bounds__(128) void asm_rows_two_pass(const RowsInPlace a, int *__restrict__ len_out) {
+    const long long r = (long long)blockIdx.x * 128 + threadIdx.x;
+    if (r >= a.n_rows) return;
+    const bool direct = a.slot_ptr[r + 1] == a.slot_ptr[r];      // a listed row owns at least its diagonal placeholder
+    if (!direct) {
+        if (!FILL) {
+            int len = a.row_len[r];
+            if (len < 0) {                                 // a listed row no merge pass reached: never expected
+                atomicExch(&a.err[ERR_SCAN], 1);
+                len = 0;
+            }
+            len_out[r] = len;
+        }
+        return;
+    }
+    int T = 0;
+    int4 pairs[kFanShort / 2];
+    double2 pv = make_double2(0.0, 0.0);
+    double sig = 0.0;
+#pragma unroll
+    for (int q = 0; q < kFanShort / 2; ++q) pairs[q] = make_int4(0, 0, 0, 0);
+    if (r < a.n_vert) {
+        T = a.n_inc[r];
+        pv = reinterpret_cast<const double2 *>(a.xy)[r];
+        const int4 *lst = reinterpret_cast<const int4 *>(a.inc + r * kFanShort);
+#pragma unroll
+        for (int q = 0; q < kFanShort / 2; ++q) pairs[q] = lst[q];
+        sig = a.sigma[find_segment(a.mesh_voff, a.n_mesh, r)];
+    }
+    int col[kFanShort + 1], len = 0;
+    double w[kFanShort + 1], dval = 0.0;
+    bool bad = false;
+    fan_row<kFanShort>(T, pv.x, pv.y, pairs, a.xy, sig, col, w, dval, len, bad);
+    if (bad) atomicExch(&a.err[ERR_NONMANIFOLD], 1);
+    if (!FILL) {
+        len_out[r] = len;
+        return;
+    }
+    const long long at = a.rowptr[r];
+    if (at < 0 || at + len > a.nnz_cap || a.rowptr[r + 1] - at != len) {      // refused and reported, never written
+        atomicExch(&a.err[ERR_SCAN], 1);
+        return;
+    }
+    fan_row_store<kFanShort>((int)r, col, w, dval, a.cols + at, a.vals + at);
 }
 
 // the listed rows, merged at their slot offsets, move to the place asm_rows_in_place left for them: one wave per row
@@ -1815,6 +1879,8 @@ __global__ void power_density_kernel(long long n_tri, const int *__restrict__ tr
 // padne_assemble_system_ex(flags & 1): the triangles are a rank's piece of a larger mesh (owned vertices + the ring of
 // vertices around them); the fans of the ring vertices are incomplete by construction, so the manifold test is off
 static thread_local bool t_partial_mesh = false;
+// assemblies of this process whose rows were built by the two-pass second path (forced, or after the single pass gave up)
+static std::atomic<long long> g_two_pass_fallbacks{0};
 
 // the listed rows of the assembled system, merged in place at their slot offsets (row_len = what each keeps)
 static int merge_listed_mesh_rows(padne_ctx *ctx, long long n_vert, int n_mesh, const long long *d_voff, const double *d_sigma,
@@ -2167,27 +2233,65 @@ extern "C" int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns, int64_t
             args.err = d_err;
             args.nnz_cap = nnz_bound;
             d_nnz = args.scan.nnz_out;
-            if (e == hipSuccess) {
+            auto place_listed_rows = [&]() {
+                if (h_slow > 0)
+                    hipLaunchKernelGGL(asm_place_listed, dim3(std::min(nblk(h_slow, 4), 4096u)), dim3(256), 0, s, (const int *)d_nlisted,
+                                       (const int *)d_list, (const int *)d_slot, (const long long *)d_key, (const double *)d_val,
+                                       (const int *)m->rowptr, m->cols, m->vals, nnz_bound, d_err);
+                if (h_fans > 0)
+                    hipLaunchKernelGGL(asm_place_listed, dim3(std::min(nblk(h_fans, 4), 4096u)), dim3(256), 0, s,
+                                       (const int *)(d_nlisted + 1), (const int *)d_fans, (const int *)d_slot, (const long long *)d_key,
+                                       (const double *)d_val, (const int *)m->rowptr, m->cols, m->vals, nnz_bound, d_err);
+            };
+            // PADNE_ASM_TWO_PASS=1 takes the second path at once (its test; a caller that knows the chip is oversubscribed)
+            bool two_pass = getenv("PADNE_ASM_TWO_PASS") != nullptr;
+            if (e == hipSuccess && !two_pass) {
                 hipLaunchKernelGGL(asm_rows_in_place, dim3(workers + 1), dim3(128), 0, s, args);
+                place_listed_rows();
                 e = hipGetLastError();
+                if (e == hipSuccess) {
+                    rc = read_back2(ctx, d_err, sizeof(h_err), h_err, d_nnz, sizeof(long long), &h_nnz);
+                    // gave up: the abort word is the diagnostic, not the result.  (What asm_place_listed refused on the
+                    // unfinished row pointer is not an error either: both words are cleared for the second path, which
+                    // finds a real inconsistency again.)
+                    if (rc == PADNE_OK && h_err[ERR_GAVE_UP]) {
+                        two_pass = true;
+                        ++g_two_pass_fallbacks;
+                        e = hipMemsetAsync(d_err + ERR_SCAN, 0, sizeof(int) * 2, s);
+                        static_assert(ERR_GAVE_UP == ERR_SCAN + 1, "the two words are cleared together");
+                    }
+                }
             }
-            if (e == hipSuccess && h_slow > 0)
-                hipLaunchKernelGGL(asm_place_listed, dim3(std::min(nblk(h_slow, 4), 4096u)), dim3(256), 0, s, (const int *)d_nlisted,
-                                   (const int *)d_list, (const int *)d_slot, (const long long *)d_key, (const double *)d_val,
-                                   (const int *)m->rowptr, m->cols, m->vals, nnz_bound, d_err);
-            if (e == hipSuccess && h_fans > 0)
-                hipLaunchKernelGGL(asm_place_listed, dim3(std::min(nblk(h_fans, 4), 4096u)), dim3(256), 0, s,
-                                   (const int *)(d_nlisted + 1), (const int *)d_fans, (const int *)d_slot, (const long long *)d_key,
-                                   (const double *)d_val, (const int *)m->rowptr, m->cols, m->vals, nnz_bound, d_err);
-            if (e == hipSuccess) e = hipGetLastError();
+            if (rc == PADNE_OK && e == hipSuccess && two_pass) {
+                if (!h_err[ERR_GAVE_UP]) ++g_two_pass_fallbacks;      // (forced; a give-up was counted above)
+                h_err[ERR_GAVE_UP] = 0;
+                int *d_len = nullptr;
+                rc = sc.alloc(&d_len, (size_t)n_unknowns + 1);
+                if (rc == PADNE_OK) {
+                    hipLaunchKernelGGL(asm_rows_two_pass<false>, dim3(nblk(n_unknowns, 128)), dim3(128), 0, s, args, d_len);
+                    e = hipGetLastError();
+                }
+                int64_t total = 0;
+                if (rc == PADNE_OK && e == hipSuccess) rc = exclusive_scan_i32(ctx, d_len, m->rowptr, n_unknowns, &total);
+                if (rc == PADNE_OK && e == hipSuccess && total > nnz_bound) {
+                    set_error("assembled %lld entries where at most %lld fit", (long long)total, nnz_bound);
+                    rc = PADNE_E_HIP;
+                }
+                if (rc == PADNE_OK && e == hipSuccess) {
+                    hipLaunchKernelGGL(asm_rows_two_pass<true>, dim3(nblk(n_unknowns, 128)), dim3(128), 0, s, args, d_len);
+                    place_listed_rows();
+                    e = hipGetLastError();
+                    h_nnz = total;
+                }
+                if (rc == PADNE_OK && e == hipSuccess) rc = read_back(ctx, d_err, sizeof(h_err), h_err);
+            }
         }
         if (rc == PADNE_OK && e != hipSuccess) {
             set_error("row kernel failed: %s", hipGetErrorString(e));
             rc = PADNE_E_HIP;
         }
-        if (rc == PADNE_OK) rc = read_back2(ctx, d_err, sizeof(h_err), h_err, d_nnz, sizeof(long long), &h_nnz);
-        if (rc == PADNE_OK && h_err[ERR_SCAN]) {
-            set_error("the row offsets of the assembled system were not found (single-pass scan gave up)");
+        if (rc == PADNE_OK && (h_err[ERR_SCAN] || h_err[ERR_GAVE_UP])) {
+            set_error("the rows of the assembled system do not fit their offsets (inconsistent row lengths)");
             rc = PADNE_E_HIP;
         }
         if (rc == PADNE_OK && h_err[ERR_NONMANIFOLD] && !t_partial_mesh) {
@@ -2224,6 +2328,12 @@ extern "C" int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns, int64_t
     res->mesh_n_tri = n_tri;
     res->mesh_n_mesh = n_mesh;
     keep.released = true;
+    return PADNE_OK;
+}
+
+extern "C" int padne_asm_second_path_count(int64_t *count) {
+    PADNE_REQUIRE(count != nullptr, "count");
+    *count = (int64_t)g_two_pass_fallbacks.load();
     return PADNE_OK;
 }
 

@@ -178,12 +178,51 @@ static int team_allgather(padne_ctx *ctx, const void *send_v, void *recv_v, size
     return PADNE_OK;
 }
 
+// ---- collectives through a transport of the caller (padne_ctx_comm_init_host): device -> host -> callback -> device ----
+static int hostcoll_call(padne_ctx *ctx, const void *send, void *recv, size_t bytes_per_rank) {
+    const int rc = ctx->hostcoll_fn(ctx->hostcoll_user, send, recv, (int64_t)bytes_per_rank);
+    if (rc != 0) {
+        set_error("the caller's all-gather failed (%d): a rank has left the collective", rc);
+        return PADNE_E_COMM;
+    }
+    return PADNE_OK;
+}
+
+static int hostcoll_allreduce(padne_ctx *ctx, double *dev_buf, int count) {
+    PADNE_REQUIRE(count <= 16, "all-reduce is for a handful of scalars");
+    std::vector<double> all((size_t)ctx->world * 16, 0.0);
+    double mine[16];
+    PADNE_HIP_CHECK(hipMemcpyAsync(mine, dev_buf, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
+    PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    PADNE_TRY(hostcoll_call(ctx, mine, all.data(), sizeof(double) * (size_t)count));
+    double sum[16];
+    for (int c = 0; c < count; ++c) {
+        double t = 0.0;
+        for (int r = 0; r < ctx->world; ++r) t += all[(size_t)r * count + c];      // rank order: same bits everywhere
+        sum[c] = t;
+    }
+    PADNE_HIP_CHECK(hipMemcpyAsync(dev_buf, sum, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
+    PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PADNE_OK;
+}
+
+static int hostcoll_allgather(padne_ctx *ctx, const void *send, void *recv, size_t bytes_per_rank, hipStream_t stream) {
+    std::vector<char> mine(bytes_per_rank), all(bytes_per_rank * (size_t)ctx->world);
+    PADNE_HIP_CHECK(hipMemcpyAsync(mine.data(), send, bytes_per_rank, hipMemcpyDeviceToHost, stream));
+    PADNE_HIP_CHECK(hipStreamSynchronize(stream));
+    PADNE_TRY(hostcoll_call(ctx, mine.data(), all.data(), bytes_per_rank));
+    PADNE_HIP_CHECK(hipMemcpyAsync(recv, all.data(), all.size(), hipMemcpyHostToDevice, stream));
+    PADNE_HIP_CHECK(hipStreamSynchronize(stream));
+    return PADNE_OK;
+}
+
 int comm_allreduce_sum_f64(padne_ctx *ctx, double *dev_buf, int count) {
-    if (ctx->team != nullptr || ctx->comm != nullptr) {
+    if (comm_active(ctx)) {
         ++g_calls[0];
         g_bytes[0] += 8LL * count;
     }
     if (ctx->team != nullptr) return team_allreduce(ctx, dev_buf, count);
+    if (ctx->hostcoll_fn != nullptr) return hostcoll_allreduce(ctx, dev_buf, count);
     if (ctx->comm == nullptr) return PADNE_OK;
     return check_nccl(g_rccl.AllReduce(dev_buf, dev_buf, (size_t)count, ncclFloat64, ncclSum, (ncclComm_t)ctx->comm,
                                        ctx->stream), "ncclAllReduce");
@@ -193,11 +232,12 @@ static int allgather_impl(padne_ctx *ctx, const void *send, void *recv, int coun
     if (count_per_rank == 0) return PADNE_OK;
     const int kind = f64 ? 1 : 2;
     const size_t elem = f64 ? sizeof(double) : sizeof(float);
-    if (ctx->team != nullptr || ctx->comm != nullptr) {
+    if (comm_active(ctx)) {
         ++g_calls[kind];
         g_bytes[kind] += (long long)elem * count_per_rank;
     }
     if (ctx->team != nullptr) return team_allgather(ctx, send, recv, elem * (size_t)count_per_rank);
+    if (ctx->hostcoll_fn != nullptr) return hostcoll_allgather(ctx, send, recv, elem * (size_t)count_per_rank, stream);
     if (ctx->comm == nullptr) return PADNE_OK;
     return check_nccl(g_rccl.AllGather(send, recv, (size_t)count_per_rank, f64 ? ncclFloat64 : ncclFloat32, (ncclComm_t)ctx->comm,
                                        stream), "ncclAllGather");
@@ -246,11 +286,20 @@ int comm_allgather_side_join(padne_ctx *ctx) {
 // barrier per exchange instead of the two barriers and world peer copies of the team all-gather, and nothing of it is a
 // collective.  The ring makes the second barrier unnecessary: entry e is rewritten kP2pRing exchanges later, and every
 // exchange in between ends with all ranks' streams drained.
-// One process per GPU (RCCL): the mailboxes would be shared through hipIpc handles and the arrival signalled by flags the
-// receiver's kernel waits for; that path is not built -- there is no second GPU on the boxes this round ran on to test
-// it -- so with a communicator the exchange stays an ncclAllGather (comm_p2p_enabled is false).
+// One process per GPU (RCCL, or a host transport): the mailboxes are uncached device memory shared through hipIpc handles
+// (padne_ctx_p2p_export / _import below) and the arrival is signalled by flags the receiver's unpack kernel waits for
+// (pcg.hip: halo_store_peers_kernel / halo_unpack_kernel with their IPC arguments) -- no barrier, no host.  The ring makes
+// reuse safe there too: a rank stores exchange e + 1 only after its own unpack of exchange e (stream order), so when a
+// sender has completed its receive of e + 1 every rank has consumed e, and entry e % kP2pRing is rewritten at e + kP2pRing.
+// Tested with two PROCESSES on one GPU (tests/test_two_processes_gpu.py); between two GPUs the same stores cross xGMI.
 bool comm_p2p_enabled(const padne_ctx *ctx) {
-    return ctx->team != nullptr && getenv("PADNE_NO_P2P") == nullptr;
+    return (ctx->team != nullptr || ctx->p2p_ipc) && getenv("PADNE_NO_P2P") == nullptr;
+}
+
+// the in-process team regrows its rings on demand; mailboxes shared between processes have the size they were exported
+// with, a plan with more slots per rank keeps the all-gather (m is the same number on every rank: all take the same path)
+bool comm_p2p_fits(const padne_ctx *ctx, int m) {
+    return ctx->team != nullptr || (ctx->p2p_ipc && m <= ctx->p2p_m_cap);
 }
 
 // does a halo exchange of this context run beside what is queued between its two halves?  (peer-to-peer stores: the
@@ -263,6 +312,10 @@ bool comm_exchange_overlaps(const padne_ctx *ctx) {
 }
 
 void comm_p2p_release(padne_ctx *ctx) {
+    for (void *p : ctx->p2p_ipc_mapped)
+        if (p != nullptr) (void)hipIpcCloseMemHandle(p);
+    ctx->p2p_ipc_mapped.clear();
+    ctx->p2p_ipc = false;
     if (ctx->p2p_mbox != nullptr) (void)hipFree(ctx->p2p_mbox);
     if (ctx->p2p_peers != nullptr) (void)hipFree(ctx->p2p_peers);
     ctx->p2p_mbox = nullptr;
@@ -270,7 +323,30 @@ void comm_p2p_release(padne_ctx *ctx) {
     ctx->p2p_m_cap = 0;
 }
 
+// a receiver of this context gave up waiting for a sender's flag (the sender died, or never got to its stores): the
+// values it unpacked are not the exchange's, the solve that contains it must fail
+int comm_p2p_check(padne_ctx *ctx) {
+    if (!ctx->p2p_ipc || ctx->p2p_mbox == nullptr) return PADNE_OK;
+    unsigned long long err = 0;
+    PADNE_TRY(read_back(ctx, (const char *)ctx->p2p_mbox + kP2pErrorOff, sizeof(err), &err));
+    if (err != 0) {
+        set_error("peer-to-peer halo exchange: rank %d waited more than %u ms for the stores of rank %llu (exchange %llu)",
+                  ctx->rank, ctx->p2p_timeout_ms, (err >> 48) - 1, err & 0xffffffffffffull);
+        return PADNE_E_COMM;
+    }
+    return PADNE_OK;
+}
+
 int comm_p2p_begin(padne_ctx *ctx, int m, void ***peers_dev, size_t *entry_offset) {
+    if (ctx->p2p_ipc) {
+        PADNE_REQUIRE(m > 0 && m <= ctx->p2p_m_cap, "peer-to-peer exchange larger than the shared mailboxes");
+        const unsigned long long seq = ctx->p2p_seq++;
+        *peers_dev = ctx->p2p_peers;
+        *entry_offset = (size_t)kP2pHeaderBytes + (size_t)(seq % kP2pRing) * (size_t)ctx->world * (size_t)ctx->p2p_m_cap * 8;
+        ++g_calls[3];
+        g_bytes[3] += 8LL * m * (ctx->world - 1);
+        return PADNE_OK;
+    }
     Team *t = (Team *)ctx->team;
     PADNE_REQUIRE(t != nullptr && m > 0, "peer-to-peer exchange without a team");
     if (m > ctx->p2p_m_cap) {
@@ -310,6 +386,7 @@ int comm_p2p_begin(padne_ctx *ctx, int m, void ***peers_dev, size_t *entry_offse
 }
 
 int comm_p2p_arrive(padne_ctx *ctx) {
+    if (ctx->p2p_ipc) return PADNE_OK;      // the unpack kernel waits for the senders' flags itself
     Team *t = (Team *)ctx->team;
     PADNE_REQUIRE(t != nullptr, "peer-to-peer exchange without a team");
     PADNE_TEAM_HIP(t, hipStreamSynchronize(ctx->stream));      // my stores are out ...
@@ -334,6 +411,8 @@ void comm_destroy(padne_ctx *ctx) {
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)ctx->comm);
     ctx->comm = nullptr;
     ctx->team = nullptr;
+    ctx->hostcoll_fn = nullptr;
+    ctx->hostcoll_user = nullptr;
 }
 
 }  // namespace padne
@@ -352,7 +431,7 @@ extern "C" int padne_comm_unique_id(void *id128) {
 extern "C" int padne_ctx_comm_init(padne_ctx *ctx, const void *id128, int rank, int world_size) {
     PADNE_REQUIRE(ctx && id128, "null argument");
     PADNE_REQUIRE(world_size >= 1 && rank >= 0 && rank < world_size, "rank/world_size");
-    PADNE_REQUIRE(ctx->comm == nullptr, "communicator already initialised");
+    PADNE_REQUIRE(!comm_active(ctx), "communicator already initialised");
     PADNE_TRY(load_rccl());
     PADNE_HIP_CHECK(hipSetDevice(ctx->device));
     ncclUniqueId id;
@@ -362,6 +441,104 @@ extern "C" int padne_ctx_comm_init(padne_ctx *ctx, const void *id128, int rank, 
     ctx->comm = comm;
     ctx->rank = rank;
     ctx->world = world_size;
+    return PADNE_OK;
+}
+
+extern "C" int padne_ctx_comm_init_host(padne_ctx *ctx, int rank, int world_size, padne_allgather_fn allgather, void *user) {
+    PADNE_REQUIRE(ctx && allgather, "null argument");
+    PADNE_REQUIRE(world_size >= 1 && world_size <= kP2pMaxWorld && rank >= 0 && rank < world_size, "rank/world_size");
+    PADNE_REQUIRE(!comm_active(ctx), "context already has a communicator");
+    ctx->hostcoll_fn = allgather;
+    ctx->hostcoll_user = user;
+    ctx->rank = rank;
+    ctx->world = world_size;
+    return PADNE_OK;
+}
+
+// ---- mailboxes shared between processes (hipIpc) -------------------------------------------------------------------
+extern "C" int padne_ctx_p2p_export(padne_ctx *ctx, int32_t slots_per_rank, void *handle64) {
+    PADNE_REQUIRE(ctx && handle64, "null argument");
+    PADNE_REQUIRE((ctx->comm != nullptr || ctx->hostcoll_fn != nullptr) && ctx->team == nullptr,
+                  "mailboxes are shared between the processes of a communicator");
+    PADNE_REQUIRE(slots_per_rank > 0 && ctx->world <= kP2pMaxWorld, "slots_per_rank / world size");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the handle travels as 64 bytes");
+    PADNE_HIP_CHECK(hipSetDevice(ctx->device));
+    PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    comm_p2p_release(ctx);
+    const size_t bytes = (size_t)kP2pHeaderBytes + (size_t)kP2pRing * (size_t)ctx->world * (size_t)slots_per_rank * 8;
+    // uncached (MTYPE_UC) device memory: a peer's stores go to memory and this rank's polls read memory -- a line of
+    // ordinary (coarse-grained) device memory may sit in an XCD's L2 for the whole kernel that polls it.  It is what
+    // RCCL allocates for its own flags and buffers; fine-grained memory is the second choice, ordinary memory is refused.
+    void *p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("no uncached / fine-grained device memory for the mailbox: %s", hipGetErrorString(e));
+        return PADNE_E_COMM;
+    }
+    ctx->p2p_mbox = p;
+    e = hipMemsetAsync(p, 0, bytes, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipIpcMemHandle_t h;
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        comm_p2p_release(ctx);
+        set_error("the mailbox cannot be shared (hipIpcGetMemHandle: %s)", hipGetErrorString(e));
+        return PADNE_E_COMM;
+    }
+    memcpy(handle64, &h, 64);
+    ctx->p2p_m_cap = slots_per_rank;
+    ctx->p2p_seq = 0;
+    if (const char *t = getenv("PADNE_P2P_TIMEOUT_MS")) {
+        const long v = atol(t);
+        if (v > 0 && v <= 600000) ctx->p2p_timeout_ms = (unsigned)v;
+    }
+    return PADNE_OK;
+}
+
+extern "C" int padne_ctx_p2p_import(padne_ctx *ctx, const void *handles, int32_t n_handles) {
+    PADNE_REQUIRE(ctx && handles, "null argument");
+    PADNE_REQUIRE(ctx->p2p_mbox != nullptr && ctx->p2p_m_cap > 0 && !ctx->p2p_ipc, "padne_ctx_p2p_export comes first");
+    PADNE_REQUIRE(n_handles == ctx->world, "one handle per rank");
+    PADNE_HIP_CHECK(hipSetDevice(ctx->device));
+    std::vector<void *> peers((size_t)ctx->world, nullptr);
+    for (int r = 0; r < ctx->world; ++r) {
+        if (r == ctx->rank) {
+            peers[(size_t)r] = ctx->p2p_mbox;
+            continue;
+        }
+        hipIpcMemHandle_t h;
+        memcpy(&h, (const char *)handles + (size_t)r * 64, 64);
+        void *p = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            for (void *q : ctx->p2p_ipc_mapped) (void)hipIpcCloseMemHandle(q);
+            ctx->p2p_ipc_mapped.clear();
+            set_error("the mailbox of rank %d cannot be mapped (hipIpcOpenMemHandle: %s)", r, hipGetErrorString(e));
+            return PADNE_E_COMM;
+        }
+        ctx->p2p_ipc_mapped.push_back(p);
+        peers[(size_t)r] = p;
+    }
+    if (ctx->p2p_peers == nullptr) PADNE_HIP_CHECK(hipMalloc((void **)&ctx->p2p_peers, sizeof(void *) * (size_t)ctx->world));
+    PADNE_HIP_CHECK(hipMemcpyAsync(ctx->p2p_peers, peers.data(), sizeof(void *) * (size_t)ctx->world, hipMemcpyHostToDevice, ctx->stream));
+    PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->p2p_ipc = true;
+    return PADNE_OK;
+}
+
+extern "C" int padne_ctx_p2p_close(padne_ctx *ctx) {
+    PADNE_REQUIRE(ctx, "ctx");
+    if (ctx->team != nullptr) return PADNE_OK;      // (the team's rings belong to the team path)
+    PADNE_HIP_CHECK(hipSetDevice(ctx->device));
+    PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    comm_p2p_release(ctx);
     return PADNE_OK;
 }
 
@@ -408,7 +585,7 @@ extern "C" int padne_ctx_join_team(padne_ctx *ctx, void *team, int rank) {
     PADNE_REQUIRE(ctx && team, "null argument");
     Team *t = (Team *)team;
     PADNE_REQUIRE(rank >= 0 && rank < t->world, "rank");
-    PADNE_REQUIRE(ctx->comm == nullptr && ctx->team == nullptr, "context already has a communicator");
+    PADNE_REQUIRE(!comm_active(ctx), "context already has a communicator");
     ctx->team = t;
     ctx->rank = rank;
     ctx->world = t->world;

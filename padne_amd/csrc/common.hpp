@@ -115,6 +115,14 @@ struct padne_ctx {
     void **p2p_peers = nullptr;      // device array [world]
     int p2p_m_cap = 0;               // exchange slots per rank a ring entry holds (8 bytes each)
     unsigned long long p2p_seq = 0;  // exchanges so far: ring entry = seq % kP2pRing
+    // the same between processes (padne_ctx_p2p_export / _import): the mailbox is uncached device memory shared through
+    // hipIpc, [kP2pHeaderBytes of arrival flags | ring]; p2p_ipc is set once every peer's mailbox is mapped
+    bool p2p_ipc = false;
+    std::vector<void *> p2p_ipc_mapped;   // what hipIpcOpenMemHandle returned for the other ranks (closed with the mailbox)
+    unsigned p2p_timeout_ms = 20000;
+    // collectives through a transport of the caller (padne_ctx_comm_init_host)
+    int (*hostcoll_fn)(void *, const void *, void *, int64_t) = nullptr;
+    void *hostcoll_user = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // second stream of the context (its own pool, workspace and reduction scratch): independent chains of short,
     // latency-bound kernels of the multigrid setup run there next to the main chain (aux_context, stream_order)
@@ -250,7 +258,14 @@ void comm_abort(padne_ctx *ctx);   // a rank that leaves a collective phase with
 // use -- collectively: every rank runs the same sequence of exchanges); returns the device table of the ranks' rings and
 // the byte offset of this exchange's entry.  comm_p2p_arrive: all ranks' stores of the current exchange are visible.
 constexpr int kP2pRing = 4;
+// header of a mailbox shared between processes: [0, 1024) one 8-byte arrival flag per sender (the sequence number + 1 of
+// the last exchange whose stores of that sender have landed), [1024] the block counter of the sender's store kernel,
+// [1536] the error word a receiver sets when a wait runs out
+constexpr int kP2pHeaderBytes = 4096, kP2pCounterOff = 1024, kP2pErrorOff = 1536, kP2pMaxWorld = 128;
+inline bool comm_active(const padne_ctx *c) { return c->comm != nullptr || c->team != nullptr || c->hostcoll_fn != nullptr; }
 bool comm_p2p_enabled(const padne_ctx *ctx);
+bool comm_p2p_fits(const padne_ctx *ctx, int m);       // can an exchange with m slots per rank go peer to peer?
+int comm_p2p_check(padne_ctx *ctx);                    // PADNE_E_COMM if a receiver of this context gave up waiting
 bool comm_exchange_overlaps(const padne_ctx *ctx);
 int comm_p2p_begin(padne_ctx *ctx, int m, void ***peers_dev, size_t *entry_offset);
 int comm_p2p_arrive(padne_ctx *ctx);
@@ -270,6 +285,7 @@ struct HaloTicket {
     bool p2p = false;
     bool side = false;               // the all-gather is already under way on the second stream
     size_t entry_off = 0;
+    unsigned long long seq1 = 0;     // mailboxes shared between processes: the exchange's sequence number + 1 (0: in-process team)
 };
 int halo_send(padne_ctx *ctx, const HaloPlan &plan, double *v, const int32_t *done_flag, HaloTicket *tk);
 int halo_send_f32(padne_ctx *ctx, const HaloPlan &plan, float *v, const int32_t *done_flag, HaloTicket *tk);

@@ -354,28 +354,76 @@ enum { S_RR = 0, S_BB = 1, S_TRUE = 2, S_PQ = 8, S_RZRR0 = 10, S_RZRR1 = 12 };
 
 // peer-to-peer form of the pack: the exported values go straight into every rank's mailbox entry of this exchange
 // (peers[q] + entry_off, laid out [world][m_cap] 8-byte cells; narrower types use the front of their cell)
+// seq1 != 0: the mailboxes are shared between PROCESSES (comm.hip, padne_ctx_p2p_export): when all stores of this launch are
+// out, the sender writes seq1 -- the exchange's sequence number + 1 -- into its arrival flag in every rank's mailbox.  Every
+// thread fences its own stores at system scope; the workgroup that counts itself last (an agent-scope counter in the
+// sender's own mailbox header) therefore signals after ALL stores of the launch, with system-scope release stores.  A
+// launch with nothing to export (grid of one workgroup, n_export = 0) signals just the same: the receivers wait for
+// every rank's flag.
 template <typename T>
 __global__ void halo_store_peers_kernel(const T *__restrict__ v, const int *__restrict__ export_idx, int n_export, void *const *peers,
-                                        size_t entry_off, int world, int rank, int m_cap, const int *__restrict__ done_flag) {
+                                        size_t entry_off, int world, int rank, int m_cap, const int *__restrict__ done_flag,
+                                        unsigned long long seq1) {
     if (done_flag != nullptr && *done_flag != 0) return;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_export) return;
-    const T val = v[export_idx[k]];
-    for (int q = 0; q < world; ++q) {
-        T *cell = reinterpret_cast<T *>(static_cast<char *>(peers[q]) + entry_off + ((size_t)rank * m_cap + k) * 8);
-        *cell = val;
+    if (k < n_export) {
+        const T val = v[export_idx[k]];
+        for (int q = 0; q < world; ++q) {
+            T *cell = reinterpret_cast<T *>(static_cast<char *>(peers[q]) + entry_off + ((size_t)rank * m_cap + k) * 8);
+            if (seq1 != 0ull)
+                __hip_atomic_store(cell, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            else
+                *cell = val;
+        }
+    }
+    if (seq1 == 0ull) return;
+    __threadfence_system();
+    __syncthreads();
+    __shared__ int s_last;
+    if (threadIdx.x == 0) {
+        unsigned int *counter = reinterpret_cast<unsigned int *>(static_cast<char *>(peers[rank]) + kP2pCounterOff);
+        const unsigned int prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = prev + 1u == gridDim.x ? 1 : 0;
+        if (s_last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (for the next exchange: stream order)
+    }
+    __syncthreads();
+    if (s_last && (int)threadIdx.x < world) {
+        unsigned long long *flag = reinterpret_cast<unsigned long long *>(static_cast<char *>(peers[threadIdx.x])) + rank;
+        __hip_atomic_store(flag, seq1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
-// the receiver's half: mailbox entry -> the exchange area behind the owned values, v[n_owned + r * m + k]
+// the receiver's half: mailbox entry -> the exchange area behind the owned values, v[n_owned + r * m + k].  seq1 != 0
+// (mailboxes shared between processes): first wait until every sender's flag has reached seq1 -- a flag only grows, so a
+// sender that is already an exchange ahead passes too.  The wait is bounded by the wall clock (timeout_ticks of the
+// 100 MHz constant clock); a wait that runs out leaves (sender + 1) << 48 | seq1 in the header's error word, which fails
+// the solve (comm_p2p_check), and the kernel goes on so that the stream drains.
 template <typename T>
 __global__ void halo_unpack_kernel(T *__restrict__ v, long long n_owned, int m, int world, const void *mbox, size_t entry_off,
-                                   int m_cap, const int *__restrict__ done_flag) {
+                                   int m_cap, const int *__restrict__ done_flag, unsigned long long seq1,
+                                   unsigned long long timeout_ticks) {
     if (done_flag != nullptr && *done_flag != 0) return;
+    if (seq1 != 0ull) {
+        if ((int)threadIdx.x < world) {
+            const unsigned long long *flag = static_cast<const unsigned long long *>(mbox) + threadIdx.x;
+            const unsigned long long t0 = wall_clock64();
+            while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq1) {
+                if (wall_clock64() - t0 > timeout_ticks) {
+                    unsigned long long *err = reinterpret_cast<unsigned long long *>(const_cast<char *>(static_cast<const char *>(mbox)) + kP2pErrorOff);
+                    __hip_atomic_store(err, ((unsigned long long)(threadIdx.x + 1) << 48) | (seq1 & 0xffffffffffffull), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(32);
+            }
+        }
+        __syncthreads();
+    }
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= world * m) return;
     const int r = j / m, k = j - r * m;
-    v[n_owned + j] = *reinterpret_cast<const T *>(static_cast<const char *>(mbox) + entry_off + ((size_t)r * m_cap + k) * 8);
+    const T *cell = reinterpret_cast<const T *>(static_cast<const char *>(mbox) + entry_off + ((size_t)r * m_cap + k) * 8);
+    v[n_owned + j] = seq1 != 0ull ? __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : *cell;
 }
 
 // An exchange in two halves, so that the caller can put work that needs no remote value between them (the interior
@@ -387,14 +435,15 @@ static int halo_send_t(padne_ctx *ctx, const HaloPlan &plan, T *v, const int32_t
     tk->p2p = false;
     tk->side = false;
     if (plan.m <= 0) return PADNE_OK;
-    if (comm_p2p_enabled(ctx)) {
+    if (comm_p2p_enabled(ctx) && comm_p2p_fits(ctx, plan.m)) {
         void **peers = nullptr;
         PADNE_TRY(comm_p2p_begin(ctx, plan.m, &peers, &tk->entry_off));
         tk->p2p = true;
-        if (plan.n_export > 0) {
-            hipLaunchKernelGGL(halo_store_peers_kernel<T>, dim3((plan.n_export + 255) / 256), dim3(256), 0, ctx->stream, (const T *)v,
-                               plan.export_idx, plan.n_export, (void *const *)peers, tk->entry_off, ctx->world, ctx->rank,
-                               ctx->p2p_m_cap, done_flag);
+        tk->seq1 = ctx->p2p_ipc ? ctx->p2p_seq : 0ull;      // (p2p_seq was advanced by comm_p2p_begin: this exchange's number + 1)
+        if (plan.n_export > 0 || ctx->p2p_ipc) {             // between processes a rank with nothing to export still signals
+            hipLaunchKernelGGL(halo_store_peers_kernel<T>, dim3(plan.n_export > 0 ? (plan.n_export + 255) / 256 : 1), dim3(256), 0,
+                               ctx->stream, (const T *)v, plan.export_idx, plan.n_export, (void *const *)peers, tk->entry_off,
+                               ctx->world, ctx->rank, ctx->p2p_m_cap, done_flag, tk->seq1);
             PADNE_HIP_CHECK(hipGetLastError());
         }
         return PADNE_OK;
@@ -422,7 +471,8 @@ static int halo_recv_t(padne_ctx *ctx, const HaloPlan &plan, T *v, const int32_t
         PADNE_TRY(comm_p2p_arrive(ctx));
         const int n = ctx->world * plan.m;
         hipLaunchKernelGGL(halo_unpack_kernel<T>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, v, plan.n_owned, plan.m,
-                           ctx->world, (const void *)ctx->p2p_mbox, tk.entry_off, ctx->p2p_m_cap, done_flag);
+                           ctx->world, (const void *)ctx->p2p_mbox, tk.entry_off, ctx->p2p_m_cap, done_flag, tk.seq1,
+                           (unsigned long long)ctx->p2p_timeout_ms * 100000ull);
         PADNE_HIP_CHECK(hipGetLastError());
         return PADNE_OK;
     }
@@ -492,7 +542,7 @@ static thread_local bool t_last_solve_stagnated = false;   // the last solve_one
 static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, const double *b, double *x,
                      const padne_solve_opts *o, padne_solve_info *info, bool x_is_guess) {
     t_last_solve_stagnated = false;
-    const bool dist = ctx->comm != nullptr || ctx->team != nullptr;
+    const bool dist = comm_active(ctx);
     const bool halo = ctx->halo_on;
     const bool amg = prec != nullptr;
     const long long nr = a->n_rows;                       // matrix rows (owned rows + empty exchange rows)
@@ -681,6 +731,7 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
     }
     PADNE_HIP_CHECK(hipEventRecord(ctx->ev1, s));
     PADNE_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+    PADNE_TRY(comm_p2p_check(ctx));      // (mailboxes shared between processes: did a receiver give up waiting?)
     float ms = 0.f;
     PADNE_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     if (!ev_a.empty()) {
@@ -823,7 +874,7 @@ __global__ __launch_bounds__(256) void sr_update_ps_kernel(const long long n, co
 static int solve_one_single_reduction(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, const double *b,
                                       double *x, const padne_solve_opts *o, padne_solve_info *info, bool x_is_guess) {
     t_last_solve_stagnated = false;
-    const bool dist = ctx->comm != nullptr || ctx->team != nullptr;
+    const bool dist = comm_active(ctx);
     const bool halo = ctx->halo_on;
     const long long nr = a->n_rows;
     const long long n = halo ? ctx->halo_n_owned : nr;
@@ -963,6 +1014,7 @@ static int solve_one_single_reduction(padne_ctx *ctx, const padne_csr *a, const 
     }
     PADNE_HIP_CHECK(hipEventRecord(ctx->ev1, s));
     PADNE_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+    PADNE_TRY(comm_p2p_check(ctx));      // (mailboxes shared between processes: did a receiver give up waiting?)
     float ms = 0.f;
     PADNE_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     if (!ev_a.empty()) {       // launches queued after convergence are no-ops: keep the samples within 2x of the median
@@ -1614,7 +1666,7 @@ static int solve_spd_dev_impl(padne_ctx *ctx, const padne_csr *a, const void *b_
     }
     const long long n = ctx->halo_on ? ctx->halo_n_owned : a->n_rows;
     int k_first = 0;
-    if (use_amg && !ctx->halo_on && ctx->comm == nullptr && ctx->team == nullptr && pm == a && amg_supports_batch8(a) &&
+    if (use_amg && !ctx->halo_on && !comm_active(ctx) && pm == a && amg_supports_batch8(a) &&
         getenv("PADNE_NO_BATCH") == nullptr) {
         // groups of 8 right-hand sides advance in lockstep (one pass over the operators per iteration for all of
         // them); a group whose cycle breaks down falls through to the one-at-a-time path below
@@ -1659,7 +1711,7 @@ static int solve_spd_dev_impl(padne_ctx *ctx, const padne_csr *a, const void *b_
     // row-partitioned multigrid runs use the single-reduction loop (one all-reduce per iteration); PADNE_CG_SINGLE_REDUCTION
     // = 1 / 0 forces it on (also on one GPU, for tests) or off
     const char *sr_env = getenv("PADNE_CG_SINGLE_REDUCTION");
-    const bool dist_run = ctx->comm != nullptr || ctx->team != nullptr;
+    const bool dist_run = comm_active(ctx);
     const bool single_reduction = use_amg && (sr_env != nullptr ? atoi(sr_env) != 0 : dist_run);
     for (int k = k_first; k < n_rhs; ++k) {
         const int status_before = local.status;

@@ -29,6 +29,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
+from . import _hip
 from .synthetic import SyntheticSystem
 
 
@@ -363,18 +364,32 @@ class DistributedSolver:
         has its own exchange plan).  ``block_preconditioner=True`` selects block-Jacobi instead: one V-cycle of
         each rank's own diagonal block with no communication inside the cycle (3-6x more CG iterations)."""
         self.ctx, self.plan = ctx, plan
+        self.p2p = False                                      # halo exchanges as peer-to-peer stores into shared mailboxes?
         if team is not None:
             team.join(ctx, plan.rank)
+            self.p2p = True
         else:
-            # RCCL communicator: rank 0 creates the id, torch.distributed broadcasts the 128 bytes
             import torch
-            if plan.rank == 0:
-                uid = np.frombuffer(ctx.comm_unique_id(), dtype=np.uint8).copy()
+            backend = dist.get_backend() if hasattr(dist, "get_backend") else "nccl"
+            if backend == "gloo":
+                # ranks RCCL cannot connect (two processes on one GPU) or a host without RCCL: the library's collectives go
+                # through this process group's all-gather on host memory (padne_ctx_comm_init_host)
+                def allgather(send):
+                    t = torch.from_numpy(send)
+                    parts = [torch.empty_like(t) for _ in range(plan.world)]
+                    dist.all_gather(parts, t)
+                    return torch.cat(parts).numpy().tobytes()
+                ctx.comm_init_host(plan.rank, plan.world, allgather)
             else:
-                uid = np.zeros(128, dtype=np.uint8)
-            t = torch.from_numpy(uid).cuda()
-            dist.broadcast(t, src=0)
-            ctx.comm_init(bytes(t.cpu().numpy().tobytes()), plan.rank, plan.world)
+                # RCCL communicator: rank 0 creates the id, torch.distributed broadcasts the 128 bytes
+                if plan.rank == 0:
+                    uid = np.frombuffer(ctx.comm_unique_id(), dtype=np.uint8).copy()
+                else:
+                    uid = np.zeros(128, dtype=np.uint8)
+                t = torch.from_numpy(uid).cuda()
+                dist.broadcast(t, src=0)
+                ctx.comm_init(bytes(t.cpu().numpy().tobytes()), plan.rank, plan.world)
+            self.p2p = self._share_mailboxes(dist)
         # local assembly on this GPU
         ms = plan.meshes
         xy = np.concatenate([mm[0] for mm in ms]) if ms else np.zeros((0, 2))
@@ -416,6 +431,35 @@ class DistributedSolver:
         self.x = ctx.empty(n_owned)
         self.nnz = self.A.nnz
         self.spmv_bytes = 12 * self.A.nnz + 20 * n_owned + 4
+
+    def _share_mailboxes(self, dist) -> bool:
+        """The peer-to-peer halo exchange between processes (include/padne_hip.h, padne_ctx_p2p_*): every rank allocates its
+        mailbox and all-gathers the hipIpc handles; if ANY rank cannot allocate, export or map one, all ranks close theirs and
+        the exchanges stay all-gathers -- the decision is taken from gathered flags, so every rank takes the same path."""
+        ctx, plan = self.ctx, self.plan
+        if plan.world < 2 or plan.m <= 0:
+            return False
+        slots = max(4 * int(plan.m), 16384)                   # the levels of the hierarchy exchange fewer values than the matrix
+
+        def gather(obj):
+            parts = [None] * plan.world
+            dist.all_gather_object(parts, obj)
+            return parts
+        try:
+            handle = ctx.p2p_export(slots)
+        except _hip.HipError:
+            handle = None
+        handles = gather(handle)
+        ok = all(h is not None for h in handles)
+        if ok:
+            try:
+                ctx.p2p_import(b"".join(handles), plan.world)
+            except _hip.HipError:
+                ok = False
+        if not all(gather(ok)):
+            ctx.p2p_close()
+            return False
+        return True
 
     def solve(self, rtol=1e-12, time_spmv=False, precond="amg", rebuild=False):
         return self.A.solve_spd_dev(self.b, self.x, rtol=rtol, time_spmv=time_spmv, precond=precond, rebuild=rebuild)

@@ -1545,24 +1545,83 @@ def test_assemblies_running_side_by_side_on_one_gpu_are_the_serial_result(ctx):
 
     prepared = [arrays(sm) for sm in systems]
     alone = [assemble(ctx, sm, p) for sm, p in zip(systems, prepared)]
-    for _ in range(4):
+    for _ in range(2):
         out, errors = [None] * len(systems), []
 
         def worker(k):
+            c = None
             try:
-                out[k] = assemble(_hip.Context(0), systems[k], prepared[k])
+                c = _hip.Context(0)
+                out[k] = assemble(c, systems[k], prepared[k])
             except BaseException as exc:
                 errors.append((k, exc))
+            finally:
+                if c is not None:                            # stream, pinned buffer, pool: back at once, not at interpreter exit
+                    c.close()
         threads = [threading.Thread(target=worker, args=(k,), daemon=True) for k in range(len(systems))]
         for th in threads:
             th.start()
         for th in threads:
             th.join(timeout=120)
+        stuck = [k for k, th in enumerate(threads) if th.is_alive()]
+        assert not stuck, f"assemblies {stuck} did not come back (their kernels still hold the GPU)"
         assert not errors, errors
         for A, B in zip(alone, out):
             assert B is not None
             assert np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices)
             assert np.array_equal(A.data.view(np.int64), B.data.view(np.int64))
+
+
+@pytest.mark.parametrize("case", ["grid_with_stamps", "delaunay_fans"])
+def test_second_path_of_the_row_kernel_is_the_first_bit_for_bit(ctx, monkeypatch, case):
+    """When the in-kernel scan of `asm_rows_in_place` gives up (a chip shared with other work can starve its scanner until
+    a bounded wait runs out) the host builds the rows again in two passes -- lengths, an ordinary scan, fill -- instead of
+    failing the assembly.  PADNE_ASM_TWO_PASS=1 takes that path at once: structure and
+    values of the single-pass result and of the oracle bit for bit, right angles (rows shorter than their fans), stamps,
+    an internal node, fans of up to 12 triangles and a hub among them; the counter of the test header shows that the
+    second path really ran."""
+    if case == "grid_with_stamps":
+        nx, ny = 257, 131
+        gx, gy = np.meshgrid(np.arange(nx, dtype=np.float64), np.arange(ny, dtype=np.float64), indexing="xy")
+        xy = np.stack([gx.ravel(), gy.ravel()], 1) * 0.25
+        xy[nx + 1::2] += np.random.default_rng(4).uniform(-0.03, 0.03, xy[nx + 1::2].shape)   # every other vertex off the lattice
+        q = (np.arange(ny - 1)[:, None] * nx + np.arange(nx - 1)[None, :]).ravel()
+        tri = np.concatenate([np.stack([q, q + 1, q + nx + 1], 1), np.stack([q, q + nx + 1, q + nx], 1)]).astype(np.int32)
+        xy[:nx] = np.stack([np.arange(nx) * 0.25, np.zeros(nx)], 1)                            # (the first line keeps right angles)
+    else:
+        from scipy.spatial import Delaunay
+        rng = np.random.default_rng(11)
+        pts = rng.uniform(0, 40, (9000, 2))
+        hub = np.array([[20.0, 20.0]]) + 1e-3 * np.stack([np.cos(np.arange(30) * 2 * np.pi / 30), np.sin(np.arange(30) * 2 * np.pi / 30)], 1)
+        xy = np.concatenate([pts, [[20.0, 20.0]], hub])                                      # a vertex with ~30 triangles around it
+        tri = Delaunay(xy).simplices.astype(np.int32)
+        a, b, c = xy[tri[:, 0]], xy[tri[:, 1]], xy[tri[:, 2]]
+        cross = (b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (b[:, 1] - a[:, 1]) * (c[:, 0] - a[:, 0])
+        tri[cross < 0] = tri[cross < 0][:, [0, 2, 1]]
+    n = len(xy)
+    els = [("R", 3, n - 2, 0.5), ("R", n // 2, n, 2.0), ("R", n, 7, 1.0)]
+    Lo, _ = O.assemble_system([(xy, tri, 2082.5)], 1, els, 0)
+    Lo.sort_indices()
+    N = Lo.shape[0]
+    rows, cols, vals = [], [], []
+    for _, a_, b_, res in els:
+        g = 1.0 / res
+        rows += [a_, a_, b_, b_]; cols += [a_, b_, b_, a_]; vals += [-g, g, -g, g]
+    rows += [N - 1, 0]; cols += [0, N - 1]; vals += [1.0, 1.0]
+
+    def assemble():
+        L = ctx.assemble_system(N, xy, tri, np.array([0, n], np.int64), np.array([0, len(tri)], np.int64),
+                                np.array([2082.5]), np.array(rows, np.int64), np.array(cols, np.int64), np.array(vals))
+        got = L.to_scipy()
+        L.close()
+        return got
+    first = assemble()
+    before = _hip.asm_second_path_count()
+    monkeypatch.setenv("PADNE_ASM_TWO_PASS", "1")
+    second = assemble()
+    assert _hip.asm_second_path_count() == before + 1
+    for got in (first, second):
+        assert H.same_structure(got, Lo) and np.array_equal(got.data.view(np.int64), Lo.data.view(np.int64))
 
 
 def test_randomised_assembly_is_the_oracle_bit_for_bit(ctx):
