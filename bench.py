@@ -318,6 +318,8 @@ def main():
         spmv_bytes = dsolver.spmv_bytes
         standalone = None
         hierarchy_shapes = None
+        halo_exchange = ("peer-to-peer stores into hipIpc mailboxes, device-side arrival flags" if dsolver.p2p
+                         else "ncclAllGather (the mailboxes could not be shared or did not pass their self-test)")
     t_setup = time.perf_counter() - t_setup0
 
     # ---- warmup + timed steps ---------------------------------------------------------------------
@@ -369,7 +371,8 @@ def main():
             "config": {"workload": f"{sysm.name}: {len(sysm.meshes)}-layer jittered triangular Laplacian, "
                                    f"{nv} nodes, via-ring stitched, 1 A source/sink, {args.precond}-PCG to rtol {RTOL:g}",
                        "n_unknowns": int(nv - 1), "nnz_per_rank": int(nnz_local), "rows_per_rank": int(n_local),
-                       "parallelism": f"layer-partitioned x{args.gpus}"},
+                       "parallelism": f"layer-partitioned x{args.gpus}",
+                       **({"halo_exchange": halo_exchange} if distributed_path else {})},
             "preconditioner": {"kind": args.precond, "levels": int(last.levels),
                                "operator_complexity": float(last.operator_complexity),
                                "setup_ms_per_step": float(last.setup_seconds) * 1e3,

@@ -94,10 +94,13 @@ int padne_ctx_comm_init_host(padne_ctx *ctx, int rank, int world_size, padne_all
  *   -- the caller all-gathers the handles (rank order) --
  *   padne_ctx_p2p_import   open the other ranks' mailboxes (handles = world_size * 64 bytes); from here on exchanges
  *                          whose plan has at most slots_per_rank slots per rank go peer to peer
- *   padne_ctx_p2p_close    back to the all-gather (also done by padne_ctx_destroy); collective like the two above
+ *   padne_ctx_p2p_selftest one real exchange of known values through the mailboxes (2 s bound): *ok = 1 if every rank's
+ *                          stores and flags arrived here -- the caller gathers the verdicts and closes unless all say yes
+ *   padne_ctx_p2p_close    back to the all-gather (also done by padne_ctx_destroy); collective like the ones above
  * PADNE_NO_P2P=1 keeps the all-gather although mailboxes exist (A/B, tests). */
 int padne_ctx_p2p_export(padne_ctx *ctx, int32_t slots_per_rank, void *handle64);
 int padne_ctx_p2p_import(padne_ctx *ctx, const void *handles, int32_t n_handles);
+int padne_ctx_p2p_selftest(padne_ctx *ctx, int32_t *ok);
 int padne_ctx_p2p_close(padne_ctx *ctx);
 
 /* Halo plan of a row-partitioned matrix (layer partition).  Every vector the

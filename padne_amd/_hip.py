@@ -68,6 +68,7 @@ SIGNATURES = {
     "padne_ctx_comm_init_host": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
     "padne_ctx_p2p_export": (C.c_int, [_P, C.c_int32, _P]),
     "padne_ctx_p2p_import": (C.c_int, [_P, _P, C.c_int32]),
+    "padne_ctx_p2p_selftest": (C.c_int, [_P, _PI32]),
     "padne_ctx_p2p_close": (C.c_int, [_P]),
     "padne_ctx_set_halo": (C.c_int, [_P, _I64, C.c_int32, C.c_int32, _PI32]),
     "padne_dev_alloc": (C.c_int, [_P, _I64, C.POINTER(_P)]),
@@ -282,6 +283,12 @@ class Context:
     def p2p_import(self, handles: bytes, world_size: int) -> None:
         buf = C.create_string_buffer(bytes(handles), 64 * int(world_size))
         _check(self._lib.padne_ctx_p2p_import(self._h, buf, int(world_size)))
+
+    def p2p_selftest(self) -> bool:
+        """One real exchange of known values through the shared mailboxes (collective): did every rank's stores arrive here?"""
+        ok = C.c_int32(0)
+        _check(self._lib.padne_ctx_p2p_selftest(self._h, C.byref(ok)))
+        return bool(ok.value)
 
     def p2p_close(self) -> None:
         _check(self._lib.padne_ctx_p2p_close(self._h))

@@ -533,6 +533,62 @@ extern "C" int padne_ctx_p2p_import(padne_ctx *ctx, const void *handles, int32_t
     return PADNE_OK;
 }
 
+// One real exchange through the shared mailboxes -- the kernels, flags and ring entry a solve uses -- with values every rank
+// can check: rank r exports 100 r + k.  A node on which the peers' stores or flags do not arrive (peer access that maps but
+// does not deliver, a runtime that ignores the memory type) shows here, within 2 s and before any solve depends on it:
+// the caller gathers the verdicts and keeps the all-gather unless every rank says yes.
+extern "C" int padne_ctx_p2p_selftest(padne_ctx *ctx, int32_t *ok_out) {
+    PADNE_REQUIRE(ctx && ok_out, "null argument");
+    *ok_out = 0;
+    PADNE_REQUIRE(ctx->p2p_ipc, "padne_ctx_p2p_import comes first");
+    constexpr int kM = 4;
+    PADNE_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)kM + (size_t)ctx->world * kM;
+    std::vector<double> h(n, -1.0);
+    for (int k = 0; k < kM; ++k) h[(size_t)k] = 100.0 * ctx->rank + k;
+    const int idx[kM] = {0, 1, 2, 3};
+    double *d_v = (double *)pool_alloc(ctx, sizeof(double) * n);
+    int *d_idx = (int *)pool_alloc(ctx, sizeof(int) * kM);
+    if (d_v == nullptr || d_idx == nullptr) {
+        pool_free(ctx, d_v);
+        pool_free(ctx, d_idx);
+        return PADNE_E_NOMEM;
+    }
+    int rc = PADNE_OK;
+    hipError_t e = hipMemcpyAsync(d_v, h.data(), sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_idx, idx, sizeof(idx), hipMemcpyHostToDevice, ctx->stream);
+    const unsigned keep_timeout = ctx->p2p_timeout_ms;
+    if (e == hipSuccess) {
+        ctx->p2p_timeout_ms = 2000;
+        HaloPlan plan;
+        plan.n_owned = kM;
+        plan.m = kM;
+        plan.n_export = kM;
+        plan.export_idx = d_idx;
+        rc = halo_exchange_plan(ctx, plan, d_v, nullptr);
+        ctx->p2p_timeout_ms = keep_timeout;
+    }
+    if (e == hipSuccess && rc == PADNE_OK) e = hipMemcpyAsync(h.data(), d_v, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && rc == PADNE_OK) e = hipStreamSynchronize(ctx->stream);
+    pool_free(ctx, d_v);
+    pool_free(ctx, d_idx);
+    if (e != hipSuccess) {
+        set_error("mailbox self-test failed: %s", hipGetErrorString(e));
+        return PADNE_E_HIP;
+    }
+    PADNE_TRY(rc);
+    bool ok = comm_p2p_enabled(ctx) ? true : false;          // (PADNE_NO_P2P: the exchange above was an all-gather; nothing was tested)
+    for (int r = 0; r < ctx->world && ok; ++r)
+        for (int k = 0; k < kM; ++k) ok = ok && h[(size_t)kM + (size_t)r * kM + k] == 100.0 * r + k;
+    if (comm_p2p_check(ctx) != PADNE_OK) {                   // a wait ran out: report it here, not in the first solve
+        ok = false;
+        (void)hipMemsetAsync((char *)ctx->p2p_mbox + kP2pErrorOff, 0, 8, ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    *ok_out = ok || !comm_p2p_enabled(ctx) ? 1 : 0;
+    return PADNE_OK;
+}
+
 extern "C" int padne_ctx_p2p_close(padne_ctx *ctx) {
     PADNE_REQUIRE(ctx, "ctx");
     if (ctx->team != nullptr) return PADNE_OK;      // (the team's rings belong to the team path)

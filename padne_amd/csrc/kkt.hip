@@ -36,6 +36,10 @@ struct padne_kkt {
     int32_t *tied_member = nullptr;      // [n_tied] further members of source-tied groups, ascending ...
     int32_t *tied_target = nullptr;      // [n_tied] ... and the reduced unknown they add into
     long long n_tied = 0;
+    // the same list grouped by target (= by representative): entries tied_order[tied_gptr[g] .. tied_gptr[g + 1]) of the
+    // two arrays above add into one reduced unknown, in ascending member order (kkt_rhs_tied: one thread per group)
+    int32_t *tied_order = nullptr, *tied_gptr = nullptr;
+    long long n_tied_groups = 0;
     padne_csr *A = nullptr;              // -P^T L P, owned (with its hierarchy once a solve has built it)
     double *r = nullptr, *v = nullptr, *w = nullptr, *c = nullptr;      // [N] device vectors: right-hand side, solution, scratch, known part
     double *b = nullptr, *y = nullptr;   // [(1 + n_extra) * n_free]
@@ -105,13 +109,23 @@ __global__ __launch_bounds__(256) void kkt_rhs(const long long n_free, const int
     }
 }
 
-__global__ void kkt_rhs_tied(const int n_tied, const int32_t *__restrict__ member, const int32_t *__restrict__ target,
-                             const double *__restrict__ r, const double *__restrict__ Lc, double *__restrict__ b) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    for (int k = 0; k < n_tied; ++k) {
-        const int32_t i = member[k];
-        b[target[k]] -= (Lc != nullptr ? r[i] - Lc[i] : r[i]);
+// One thread per tied GROUP (all further members of one representative): it subtracts its members' terms from the
+// group's reduced row one after the other in ascending member order -- the additions of a single thread walking the whole
+// list in index order (what this kernel was: 0.2 s for 1e5 tied members, a chain of dependent read-modify-writes), in
+// the same order per row, hence the same bits, in parallel over the rows.
+__global__ __launch_bounds__(256) void kkt_rhs_tied(const int n_groups, const int32_t *__restrict__ gptr, const int32_t *__restrict__ order,
+                                                    const int32_t *__restrict__ member, const int32_t *__restrict__ target,
+                                                    const double *__restrict__ r, const double *__restrict__ Lc, double *__restrict__ b) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    const int e0 = gptr[g], e1 = gptr[g + 1];
+    const int32_t t = target[order[e0]];
+    double acc = b[t];
+    for (int e = e0; e < e1; ++e) {
+        const int32_t i = member[order[e]];
+        acc -= (Lc != nullptr ? r[i] - Lc[i] : r[i]);
     }
+    b[t] = acc;
 }
 
 // extra right-hand sides (regulator gain columns): b_k = P^T gamma_k, a handful of entries each, added in list order
@@ -240,18 +254,22 @@ __global__ __launch_bounds__(256) void kkt_mesh_stats(const long long *__restric
     }
 }
 
-// key[t] = mesh << 48 | strip << 32 | x quantised to 32 bits inside the mesh; unknowns that are no mesh vertex: 0xFFFF << 48 | t.
+// key[t] = mesh << (32 + strip_bits) | strip << 32 | x quantised to 32 bits inside the mesh; unknowns that are no mesh
+// vertex: n_mesh in the mesh field | t.  The same ORDER as the host's keys [mesh 16 | strip 16 | x 32] with 0xFFFF for the
+// unknowns behind the vertices -- every field keeps its rank -- in as few bits as the system needs, so that the radix
+// sort behind it walks 40-odd bits instead of 64.
 // par[m] = {x lo, x span, y0, strip height} as the host computes them (reduction._strip_order / strip_index)
 __global__ __launch_bounds__(256) void kkt_strip_keys(const long long n_free, const long long n_vert, const int n_mesh,
                                                       const long long *__restrict__ voff, const double *__restrict__ xy,
                                                       const int32_t *__restrict__ src_of, const double *__restrict__ par,
-                                                      unsigned long long *__restrict__ key, int *__restrict__ val, int *__restrict__ bad) {
+                                                      unsigned long long *__restrict__ key, int *__restrict__ val, int *__restrict__ bad,
+                                                      const int strip_bits) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= n_free) return;
     val[t] = (int)t;
     const long long v = src_of[t];
     if (v >= n_vert) {
-        key[t] = (0xFFFFull << 48) | (unsigned long long)t;
+        key[t] = ((unsigned long long)n_mesh << (32 + strip_bits)) | (unsigned long long)t;
         return;
     }
     int lo = 0, hi = n_mesh;                       // mesh of v: largest m with voff[m] <= v
@@ -264,14 +282,14 @@ __global__ __launch_bounds__(256) void kkt_strip_keys(const long long n_free, co
     const double x_lo = par[4 * m], span = par[4 * m + 1], y0 = par[4 * m + 2], height = par[4 * m + 3];
     long long strip = 0;
     if (height > 0.0) strip = (long long)floor((y - y0) / height);
-    if (strip < 0 || strip >= 0x10000) {
+    if (strip < 0 || strip >= (1ll << strip_bits)) {        // (the host's bound of the field, computed from the same numbers)
         atomicExch(bad, 1);
         strip = 0;
     }
     double q = (x - x_lo) / span * 4294967295.0;
     if (q > 4294967295.0) q = 4294967295.0;
     const unsigned long long xq = (unsigned long long)q;
-    key[t] = ((unsigned long long)m << 48) | ((unsigned long long)strip << 32) | xq;
+    key[t] = ((unsigned long long)m << (32 + strip_bits)) | ((unsigned long long)strip << 32) | xq;
 }
 
 __global__ void kkt_invert_perm(const long long n, const int *__restrict__ order, int32_t *__restrict__ new_of_old) {
@@ -325,6 +343,7 @@ static int kkt_apply_strip_order(padne_kkt *k) {
     std::vector<double> st((size_t)5 * n_mesh), par((size_t)4 * n_mesh);
     PADNE_HIP_CHECK(hipMemcpyAsync(st.data(), d_stats, sizeof(double) * st.size(), hipMemcpyDeviceToHost, s));
     PADNE_HIP_CHECK(hipStreamSynchronize(s));
+    double strips_max = 1.0;                                // largest strip index any mesh can produce (+ 1 of slack for the rounding of floor)
     for (int m = 0; m < n_mesh; ++m) {
         const double xmin = st[5 * m], xmax = st[5 * m + 1], ymin = st[5 * m + 2], ymax = st[5 * m + 3], cnt = st[5 * m + 4];
         double x_lo = 0.0, span = 1.0, y0 = 0.0, height = 0.0;
@@ -337,6 +356,7 @@ static int kkt_apply_strip_order(padne_kkt *k) {
                 height = 3.4 * sqrt(area / cnt);
             }
         }
+        if (height > 0.0) strips_max = std::max(strips_max, floor((ymax - y0) / height) + 2.0);
         par[4 * m] = x_lo;
         par[4 * m + 1] = span;
         par[4 * m + 2] = y0;
@@ -344,8 +364,13 @@ static int kkt_apply_strip_order(padne_kkt *k) {
     }
     PADNE_HIP_CHECK(hipMemcpyAsync(d_par, par.data(), sizeof(double) * par.size(), hipMemcpyHostToDevice, s));
     PADNE_HIP_CHECK(hipMemsetAsync(d_bad, 0, sizeof(int), s));
+    // the fields of the sort key, as narrow as this system allows: strips (at most 16 bits, the host's field), meshes + 1
+    int strip_bits = 1, mesh_bits = 1;
+    while (strip_bits < 16 && (double)(1ll << strip_bits) <= strips_max) ++strip_bits;
+    while ((1ll << mesh_bits) <= (long long)n_mesh) ++mesh_bits;
+    const int key_bits = 32 + strip_bits + mesh_bits;      // <= 32 + 16 + 16
     hipLaunchKernelGGL(kkt_strip_keys, dim3(nblk(nf)), dim3(256), 0, s, nf, nv, n_mesh, L->mesh_voff, L->mesh_xy, k->src_of, d_par,
-                       key_a, val_a, d_bad);
+                       key_a, val_a, d_bad, strip_bits);
     PADNE_HIP_CHECK(hipGetLastError());
     int h_bad = 0;
     PADNE_HIP_CHECK(hipMemcpyAsync(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -356,10 +381,10 @@ static int kkt_apply_strip_order(padne_kkt *k) {
     }
     // stable sort of (key, old index): equal keys keep their index order, as the host's tie repair leaves them
     size_t tmp_bytes = 0;
-    PADNE_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key_a, key_b, val_a, val_b, (size_t)nf, 0, 64, s));
+    PADNE_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key_a, key_b, val_a, val_b, (size_t)nf, 0, key_bits, s));
     void *tmp = nullptr;
     PADNE_TRY(sc.alloc((char **)&tmp, tmp_bytes));
-    PADNE_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, key_a, key_b, val_a, val_b, (size_t)nf, 0, 64, s));
+    PADNE_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, key_a, key_b, val_a, val_b, (size_t)nf, 0, key_bits, s));
     const int *order = val_b;                              // new position -> old reduced index
     hipLaunchKernelGGL(kkt_invert_perm, dim3(nblk(nf)), dim3(256), 0, s, nf, order, new_of_old);
     hipLaunchKernelGGL(kkt_relabel_map, dim3(nblk(k->N)), dim3(256), 0, s, k->N, (const int32_t *)new_of_old, k->imap);
@@ -422,7 +447,8 @@ static void kkt_free(padne_kkt *k) {
             s = nullptr;
         }
     if (k->A != nullptr) padne_csr_destroy(k->A);
-    for (void *p : {(void *)k->imap, (void *)k->src_of, (void *)k->tied_member, (void *)k->tied_target, (void *)k->r, (void *)k->v,
+    for (void *p : {(void *)k->imap, (void *)k->src_of, (void *)k->tied_member, (void *)k->tied_target, (void *)k->tied_order,
+                    (void *)k->tied_gptr, (void *)k->r, (void *)k->v,
                     (void *)k->w, (void *)k->c, (void *)k->b, (void *)k->y, (void *)k->Z})
         if (p != nullptr) pool_free(ctx, p);
     delete k;
@@ -494,9 +520,23 @@ extern "C" int padne_kkt_create(padne_ctx *ctx, const padne_csr *L, int64_t n_po
         (rc = sc.alloc(&d_rep, (size_t)n_tied)) != PADNE_OK)
         return fail(rc);
     hipError_t e = hipSuccess;
+    std::vector<int32_t> h_order, h_gptr;                  // (outlive the asynchronous copies below: synchronised before return)
     if (n_tied > 0) {
         e = hipMemcpyAsync(d_mem, tied_member, sizeof(long long) * (size_t)n_tied, hipMemcpyHostToDevice, s);
         if (e == hipSuccess) e = hipMemcpyAsync(d_rep, tied_rep, sizeof(long long) * (size_t)n_tied, hipMemcpyHostToDevice, s);
+        // the list grouped by representative; inside a group the members keep their (ascending) order
+        h_order.resize((size_t)n_tied);
+        for (int64_t q = 0; q < n_tied; ++q) h_order[(size_t)q] = (int32_t)q;
+        std::stable_sort(h_order.begin(), h_order.end(), [&](int32_t a, int32_t b) { return tied_rep[a] < tied_rep[b]; });
+        for (int64_t q = 0; q < n_tied; ++q)
+            if (q == 0 || tied_rep[h_order[(size_t)q]] != tied_rep[h_order[(size_t)q - 1]]) h_gptr.push_back((int32_t)q);
+        k->n_tied_groups = (long long)h_gptr.size();
+        h_gptr.push_back((int32_t)n_tied);
+        k->tied_order = (int32_t *)pool_alloc(ctx, sizeof(int32_t) * h_order.size());
+        k->tied_gptr = (int32_t *)pool_alloc(ctx, sizeof(int32_t) * h_gptr.size());
+        if (!k->tied_order || !k->tied_gptr) return fail(PADNE_E_NOMEM);
+        if (e == hipSuccess) e = hipMemcpyAsync(k->tied_order, h_order.data(), sizeof(int32_t) * h_order.size(), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(k->tied_gptr, h_gptr.data(), sizeof(int32_t) * h_gptr.size(), hipMemcpyHostToDevice, s);
     }
     if (e == hipSuccess && index_map_host != nullptr) {
         // a map the host made (locality reordering of a scattered numbering): used as it is
@@ -560,7 +600,7 @@ extern "C" int padne_kkt_solve(padne_ctx *ctx, padne_kkt *k, const double *r_hos
     PADNE_REQUIRE(ctx && k && r_host && opts, "null argument");
     PADNE_REQUIRE(k->ctx == ctx, "the plan belongs to another context");
     PADNE_REQUIRE(n_known >= 0 && (n_known == 0 || (known_idx && known_val)), "known potentials");
-    PADNE_REQUIRE(n_extra >= 0 && n_extra <= 64 && (n_extra == 0 || (extra_ptr && extra_ptr[0] == 0)), "extra right-hand sides");
+    PADNE_REQUIRE(n_extra >= 0 && n_extra <= 4096 && (n_extra == 0 || (extra_ptr && extra_ptr[0] == 0)), "extra right-hand sides");
     PADNE_REQUIRE(n_probe >= 0 && (n_probe == 0 || (probe_idx && probe_out)), "probes");
     const long long N = k->N, nf = k->n_free;
     for (int64_t j = 0; j < n_known; ++j) PADNE_REQUIRE(known_idx[j] >= 0 && known_idx[j] < k->n_pot, "known potential out of range");
@@ -637,12 +677,13 @@ extern "C" int padne_kkt_solve(padne_ctx *ctx, padne_kkt *k, const double *r_hos
     PADNE_TRY(up_rc);
     // 2. b = -P^T (r - L c), the extra right-hand sides, their norms
     const double *Lc = k->has_c ? k->w : nullptr;
-    double h_norm2[65];
-    for (double &x : h_norm2) x = 0.0;
+    std::vector<double> norm2_buf((size_t)n_extra + 8, 0.0);      // (one per right-hand side: any number of regulators)
+    double *h_norm2 = norm2_buf.data();
     if (nf > 0) {
         hipLaunchKernelGGL(kkt_rhs, dim3(vgrid(nf)), dim3(256), 0, s, nf, k->src_of, k->r, Lc, k->b);
         if (k->n_tied > 0)
-            hipLaunchKernelGGL(kkt_rhs_tied, dim3(1), dim3(1), 0, s, (int)k->n_tied, k->tied_member, k->tied_target, k->r, Lc, k->b);
+            hipLaunchKernelGGL(kkt_rhs_tied, dim3(nblk(k->n_tied_groups)), dim3(256), 0, s, (int)k->n_tied_groups, k->tied_gptr,
+                               k->tied_order, k->tied_member, k->tied_target, k->r, Lc, k->b);
         PADNE_HIP_CHECK(hipGetLastError());
         if (n_extra > 0) {
             long long *d_ptr = nullptr, *d_row = nullptr;

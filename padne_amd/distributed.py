@@ -459,6 +459,14 @@ class DistributedSolver:
         if not all(gather(ok)):
             ctx.p2p_close()
             return False
+        # ... and one real exchange of known values through them before any solve depends on it (2 s bound)
+        try:
+            ok = ctx.p2p_selftest()
+        except _hip.HipError:
+            ok = False
+        if not all(gather(ok)):
+            ctx.p2p_close()
+            return False
         return True
 
     def solve(self, rtol=1e-12, time_spmv=False, precond="amg", rebuild=False):

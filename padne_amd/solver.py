@@ -547,17 +547,25 @@ def solve_system(L, r: np.ndarray, *, rtol: float = RTOL, reorder=None, n_potent
     key = (red.elim.tobytes(), tuple(red.tied), bool(want_reorder))
     plan = L._plans.get(key) if isinstance(L, SystemMatrix) else None
     if plan is None:
-        if want_reorder:
-            # the strip numbering is made on the device from the mesh that was assembled (padne_kkt_create, flags bit 0);
-            # key fields that do not fit (65535 meshes / strips) fall back to the host's sort of the same keys
-            try:
-                plan = _hip.KktPlan(dev, layout.n_potential, red.elim, red.tied, red.n_free, strip_order=True)
-            except ValueError:
-                from .reduction import apply_locality_ordering
-                apply_locality_ordering(red, L.xy, L.mesh_offsets)
-                plan = _hip.KktPlan(dev, layout.n_potential, red.elim, red.tied, red.n_free, index_map=red.index_map)
-        else:
-            plan = _hip.KktPlan(dev, layout.n_potential, red.elim, red.tied, red.n_free)
+        try:
+            if want_reorder:
+                # the strip numbering is made on the device from the mesh that was assembled (padne_kkt_create, flags bit 0);
+                # key fields that do not fit (65535 meshes / strips) fall back to the host's sort of the same keys -- on THAT
+                # refusal only: any other invalid argument is the caller's error and is raised as it is
+                try:
+                    plan = _hip.KktPlan(dev, layout.n_potential, red.elim, red.tied, red.n_free, strip_order=True)
+                except ValueError as exc:
+                    if "the host orders this system" not in str(exc) and "beyond the key fields" not in str(exc):
+                        raise
+                    from .reduction import apply_locality_ordering
+                    apply_locality_ordering(red, L.xy, L.mesh_offsets)
+                    plan = _hip.KktPlan(dev, layout.n_potential, red.elim, red.tied, red.n_free, index_map=red.index_map)
+            else:
+                plan = _hip.KktPlan(dev, layout.n_potential, red.elim, red.tied, red.n_free)
+        except BaseException:
+            if owned:                                 # a scipy matrix uploaded for this call: it must not outlive a failed plan
+                dev.close()
+            raise
         if isinstance(L, SystemMatrix):
             for old in L._plans.values():             # one structure at a time: a plan holds GBs at N = 10 M
                 old.close()

@@ -1237,6 +1237,34 @@ def test_five_regulators_advance_in_lockstep_and_match_the_direct_solve(ctx, mon
     assert np.abs(v1 - v).max() <= 1e-9 * np.abs(v_ref).max()      # the grouping does not show beyond the tolerance
 
 
+def test_more_regulators_than_the_former_cap_of_the_device_plan(ctx):
+    """`padne_kkt_solve` took at most 64 extra right-hand sides; the host path it replaced, like the
+    reference (`solver.py:512-538`), takes any number.  66 regulators on two small layers: 67 right-hand sides in groups
+    of eight, potentials and regulator currents against the reference's direct solve."""
+    rng = np.random.default_rng(23)
+    meshes, offs = [], [0]
+    for layer in range(2):
+        xy, tri = synthetic.jittered_grid(60, 50, seed=40 + layer)
+        meshes.append((xy, tri, 2082.5))
+        offs.append(offs[-1] + len(xy))
+    n_vert = offs[-1]
+    picks = iter(rng.permutation(offs[1]))
+    picks1 = iter(offs[1] + rng.permutation(offs[2] - offs[1]))
+    els = [("R", int(next(picks)), int(next(picks1)), float(10 ** rng.uniform(-3, -1))) for _ in range(10)]
+    els.append(("I", int(next(picks)), int(next(picks1)), 1.5))
+    K = 66
+    for k in range(K):
+        vp, vn, sf, st = int(next(picks)), int(next(picks1)), int(next(picks)), int(next(picks1))
+        els.append(("REG", vp, vn, sf, st, 1.0 + 0.01 * k, 0.3 + 0.005 * k, n_vert + k))
+        els.append(("R", vp, vn, 1.0 + 0.1 * k))
+    Lo, ro = O.assemble_system(meshes, 0, els, 0)
+    v_ref, _, _ = O.solve_system(Lo, ro)
+    v, info = solver.solve_system(Lo, ro)
+    assert np.abs(v[:n_vert] - v_ref[:n_vert]).max() <= REL_TOL * np.abs(v_ref[:n_vert]).max()
+    assert np.abs(v[n_vert:] - v_ref[n_vert:]).max() <= 1e-7 * np.abs(v_ref[n_vert:]).max()
+    assert info.residual_norm < 1e-9
+
+
 # ---- size-independent properties at BASELINE scale (direct solve unaffordable there) --------------------
 
 @pytest.fixture(scope="module")
