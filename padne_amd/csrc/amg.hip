@@ -3778,57 +3778,61 @@ static int amg_apply_f32(padne_ctx *ctx, Amg *amg, const double *r, double *z, d
     return PADNE_OK;
 }
 
-// ---- the single-precision cycle on 8 interleaved right-hand sides ([n][8] vectors, spmm.hip) ---------------
-__global__ void amg_entry_f32x8_kernel(long long n, const double *__restrict__ r, const double *__restrict__ bb2, float c,
+// ---- the single-precision cycle on K = 8, 4 or 2 interleaved right-hand sides ([n][K] vectors, spmm.hip) ---------------
+template <int K>
+__global__ void amg_entry_f32xk_kernel(long long n, const double *__restrict__ r, const double *__restrict__ bb2, float c,
                                        const float *__restrict__ dinv, float *__restrict__ b, float *__restrict__ x,
                                        const int *__restrict__ done_flag) {
     if (done_flag != nullptr && *done_flag != 0) return;
-    const int j = threadIdx.x & 7;
+    const int j = threadIdx.x & (K - 1);
     double s_inv = 1.0;
     if (bb2 != nullptr) {
         const double s2 = bb2[j];
         if (s2 > 0.0) s_inv = 1.0 / sqrt(s2);
     }
-    // blockDim.x is a multiple of 8 and so is every stride: a thread keeps its right-hand side j
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n * 8; t += (long long)gridDim.x * blockDim.x) {
+    // blockDim.x is a multiple of K and so is every stride: a thread keeps its right-hand side j
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n * K; t += (long long)gridDim.x * blockDim.x) {
         const float v = (float)(r[t] * s_inv);
         b[t] = v;
-        x[t] = c * dinv[t >> 3] * v;
+        x[t] = c * dinv[t / K] * v;
     }
 }
 
-__global__ void scale_dinv_x8_kernel(long long n, float c, const float *__restrict__ dinv, const float *__restrict__ b,
+template <int K>
+__global__ void scale_dinv_xk_kernel(long long n, float c, const float *__restrict__ dinv, const float *__restrict__ b,
                                      float *__restrict__ x, const int *__restrict__ done_flag) {
     if (done_flag != nullptr && *done_flag != 0) return;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n * 8; t += (long long)gridDim.x * blockDim.x)
-        x[t] = c * dinv[t >> 3] * b[t];
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n * K; t += (long long)gridDim.x * blockDim.x)
+        x[t] = c * dinv[t / K] * b[t];
 }
 
-// Y[row][j] = sum_c Inv[row][c] B[c][j] : one wave per row, lane = (c mod 8, j)
-__global__ __launch_bounds__(256) void dense_gemm_x8(int n, const float *__restrict__ inv, const float *__restrict__ b,
+// Y[row][j] = sum_c Inv[row][c] B[c][j] : one wave per row, lane = (c mod 64 / K, j)
+template <int K>
+__global__ __launch_bounds__(256) void dense_gemm_xk(int n, const float *__restrict__ inv, const float *__restrict__ b,
                                                      float *__restrict__ y) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= n) return;
-    const int cs = lane >> 3, j = lane & 7;
+    constexpr int CS = 64 / K;                              // columns of Inv a wave takes per turn
+    const int cs = lane / K, j = lane & (K - 1);
     float s = 0.f;
-    for (int c = cs; c < n; c += 8) s += inv[(size_t)row * n + c] * b[(size_t)c * 8 + j];
-    s += __shfl_xor(s, 8, 64);
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
-    if (lane < 8) y[(size_t)row * 8 + j] = s;
+    for (int c = cs; c < n; c += CS) s += inv[(size_t)row * n + c] * b[(size_t)c * K + j];
+#pragma unroll
+    for (int d = K; d < 64; d <<= 1) s += __shfl_xor(s, d, 64);
+    if (lane < K) y[(size_t)row * K + j] = s;
 }
 
-// z8 = M^-1 r8 for 8 interleaved right-hand sides; partials_rz [8][kMaxPartials]; bb2 [8]
-int amg_apply_batch8(padne_ctx *ctx, const padne_csr *A0, const double *r8, double *z8, double *partials_rz,
-                     const int32_t *done_flag, const double *bb2) {
+// z8 = M^-1 r8 for k interleaved right-hand sides; partials_rz [k][kMaxPartials]; bb2 [k]
+template <int K>
+static int amg_apply_batch_k(padne_ctx *ctx, const padne_csr *A0, const double *r8, double *z8, double *partials_rz,
+                             const int32_t *done_flag, const double *bb2) {
     Amg *amg = (Amg *)A0->amg;
     PADNE_REQUIRE(amg != nullptr && amg->f32 && !amg->dist, "the batched cycle needs the single-GPU single-precision hierarchy");
     hipStream_t s = ctx->stream;
     const int nl = (int)amg->levels.size();
     for (AmgLevel &L : amg->levels) {
         if (L.b8 != nullptr) continue;
-        const size_t bytes = sizeof(float) * 8 * (size_t)(L.n > 0 ? L.n : 1);
+        const size_t bytes = sizeof(float) * 8 * (size_t)(L.n > 0 ? L.n : 1);      // (room for the widest form)
         L.b8 = (float *)pool_alloc(ctx, bytes);
         L.xa8 = (float *)pool_alloc(ctx, bytes);
         L.xb8 = (float *)pool_alloc(ctx, bytes);
@@ -3838,35 +3842,45 @@ int amg_apply_batch8(padne_ctx *ctx, const padne_csr *A0, const double *r8, doub
     for (int l = 0; l < nl; ++l) {
         AmgLevel &L = amg->levels[l];
         if (l == nl - 1) {
-            hipLaunchKernelGGL(dense_gemm_x8, dim3((amg->n_coarse + 3) / 4), dim3(256), 0, s, amg->n_coarse,
+            hipLaunchKernelGGL(dense_gemm_xk<K>, dim3((amg->n_coarse + 3) / 4), dim3(256), 0, s, amg->n_coarse,
                                (const float *)amg->coarse_inv32, (const float *)L.b8, L.xb8);
             PADNE_HIP_CHECK(hipGetLastError());
             break;
         }
-        const int gv = (int)std::min<long long>((L.n * 8 + 255) / 256, 2048);
+        const int gv = (int)std::min<long long>((L.n * K + 255) / 256, 2048);
         if (l == 0)
-            hipLaunchKernelGGL(amg_entry_f32x8_kernel, dim3(gv > 0 ? gv : 1), dim3(256), 0, s, L.n, r8, bb2, (float)L.jac,
+            hipLaunchKernelGGL(amg_entry_f32xk_kernel<K>, dim3(gv > 0 ? gv : 1), dim3(256), 0, s, L.n, r8, bb2, (float)L.jac,
                                (const float *)L.A->dinv32, L.b8, L.xa8, done_flag);
         else
-            hipLaunchKernelGGL(scale_dinv_x8_kernel, dim3(gv > 0 ? gv : 1), dim3(256), 0, s, L.n, (float)L.jac,
+            hipLaunchKernelGGL(scale_dinv_xk_kernel<K>, dim3(gv > 0 ? gv : 1), dim3(256), 0, s, L.n, (float)L.jac,
                                (const float *)L.A->dinv32, (const float *)L.b8, L.xa8, done_flag);
         PADNE_HIP_CHECK(hipGetLastError());
-        PADNE_TRY(launch_spmm8_f32(ctx, L.A, SPMV_RESID, L.xa8, L.tmp8, nullptr, done_flag, L.b8, nullptr, 0.f));
-        PADNE_TRY(launch_spmm8_f32(ctx, L.R, SPMV_PLAIN, L.tmp8, amg->levels[l + 1].b8, nullptr, done_flag, nullptr,
-                                   nullptr, 0.f));
+        PADNE_TRY(launch_spmm_f32(ctx, L.A, K, SPMV_RESID, L.xa8, L.tmp8, nullptr, done_flag, L.b8, nullptr, 0.f));
+        PADNE_TRY(launch_spmm_f32(ctx, L.R, K, SPMV_PLAIN, L.tmp8, amg->levels[l + 1].b8, nullptr, done_flag, nullptr,
+                                  nullptr, 0.f));
     }
     for (int l = nl - 2; l >= 0; --l) {
         AmgLevel &L = amg->levels[l];
-        PADNE_TRY(launch_spmm8_f32(ctx, L.P, SPMV_ADD, amg->levels[l + 1].xb8, L.xa8, nullptr, done_flag, nullptr, nullptr,
-                                   0.f));
+        PADNE_TRY(launch_spmm_f32(ctx, L.P, K, SPMV_ADD, amg->levels[l + 1].xb8, L.xa8, nullptr, done_flag, nullptr, nullptr,
+                                  0.f));
         if (l > 0)
-            PADNE_TRY(launch_spmm8_f32(ctx, L.A, SPMV_JACOBI, L.xa8, L.xb8, nullptr, done_flag, L.b8, L.A->dinv32,
-                                       (float)L.jac));
+            PADNE_TRY(launch_spmm_f32(ctx, L.A, K, SPMV_JACOBI, L.xa8, L.xb8, nullptr, done_flag, L.b8, L.A->dinv32,
+                                      (float)L.jac));
         else
-            PADNE_TRY(launch_spmm8_f32_exit(ctx, L.A, L.xa8, z8, r8, partials_rz, done_flag, L.b8, L.A->dinv32,
-                                            (float)L.jac, bb2));
+            PADNE_TRY(launch_spmm_f32_exit(ctx, L.A, K, L.xa8, z8, r8, partials_rz, done_flag, L.b8, L.A->dinv32,
+                                           (float)L.jac, bb2));
     }
     return PADNE_OK;
+}
+
+int amg_apply_batch(padne_ctx *ctx, const padne_csr *A0, int k, const double *r8, double *z8, double *partials_rz,
+                    const int32_t *done_flag, const double *bb2) {
+    switch (k) {
+        case 8: return amg_apply_batch_k<8>(ctx, A0, r8, z8, partials_rz, done_flag, bb2);
+        case 4: return amg_apply_batch_k<4>(ctx, A0, r8, z8, partials_rz, done_flag, bb2);
+        case 2: return amg_apply_batch_k<2>(ctx, A0, r8, z8, partials_rz, done_flag, bb2);
+        default: set_error("lockstep width %d", k); return PADNE_E_INVALID;
+    }
 }
 
 bool amg_supports_batch8(const padne_csr *A0) {

@@ -2107,9 +2107,36 @@ extern "C" int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns, int64_t
     PADNE_TRY(sc.alloc(&d_slot, (size_t)n_unknowns + 1));
     PADNE_TRY(sc.alloc(&d_err, (size_t)ERR_WORDS));
     const long long zero_off[1] = {0};
-    // (hipMemcpyDefault: the two big arrays may already live on the device -- padne_generate_grid_mesh, padne_assemble_system_ex)
-    PADNE_HIP_CHECK(hipMemcpyAsync(d_xy, xy_host, sizeof(double) * 2 * (size_t)n_vert, hipMemcpyDefault, s));
-    PADNE_HIP_CHECK(hipMemcpyAsync(d_tri, tri_host, sizeof(int) * 3 * (size_t)n_tri, hipMemcpyDefault, s));
+    // The two big arrays may already live on the device (padne_generate_grid_mesh, a caller with device-resident meshes).
+    // Then the kernels read the CALLER's arrays, and the copy the matrix keeps for the post-processing (400 MB at N = 10 M:
+    // 0.19 ms of copy engine in front of the first kernel) is made on the context's second stream beside them; it is joined
+    // before this call returns.  Host arrays cross PCIe into the kept arrays first, as before.
+    auto on_device = [&](const void *p) {
+        hipPointerAttribute_t at;
+        if (p == nullptr || hipPointerGetAttributes(&at, p) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        return at.type == hipMemoryTypeDevice && at.device == ctx->device;
+    };
+    padne_ctx *side = nullptr;
+    if (n_vert > 0 && n_tri > 0 && on_device(xy_host) && on_device(tri_host) && !ctx->is_aux) side = aux_context(ctx);
+    double *keep_xy = d_xy;
+    int *keep_tri = d_tri;
+    if (side != nullptr) {
+        PADNE_TRY(stream_order(ctx, side));                  // (what filled the caller's arrays was queued on this context's stream, or is complete)
+        PADNE_HIP_CHECK(hipMemcpyAsync(keep_xy, xy_host, sizeof(double) * 2 * (size_t)n_vert, hipMemcpyDeviceToDevice, side->stream));
+        PADNE_HIP_CHECK(hipMemcpyAsync(keep_tri, tri_host, sizeof(int) * 3 * (size_t)n_tri, hipMemcpyDeviceToDevice, side->stream));
+        d_xy = const_cast<double *>(xy_host);               // read-only from here on
+        d_tri = const_cast<int *>(tri_host);
+    } else {
+        PADNE_HIP_CHECK(hipMemcpyAsync(d_xy, xy_host, sizeof(double) * 2 * (size_t)n_vert, hipMemcpyDefault, s));
+        PADNE_HIP_CHECK(hipMemcpyAsync(d_tri, tri_host, sizeof(int) * 3 * (size_t)n_tri, hipMemcpyDefault, s));
+    }
+    struct SideJoin {                                       // every return path waits for the side stream's copies: they read
+        padne_ctx *side;                                    // the caller's arrays and write blocks MeshKeep may hand back
+        ~SideJoin() { if (side != nullptr) (void)hipStreamSynchronize(side->stream); }
+    } side_join{side};
     if (n_mesh > 0) {
         PADNE_HIP_CHECK(hipMemcpyAsync(d_sigma, conductance, sizeof(double) * (size_t)n_mesh, hipMemcpyHostToDevice, s));
         PADNE_HIP_CHECK(hipMemcpyAsync(d_voff, mesh_vertex_offset, sizeof(long long) * (size_t)(n_mesh + 1), hipMemcpyHostToDevice, s));
@@ -2319,8 +2346,8 @@ extern "C" int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns, int64_t
     }
     *out = m;
     padne_csr *res = *out;
-    res->mesh_xy = d_xy;
-    res->mesh_tri = d_tri;
+    res->mesh_xy = keep_xy;
+    res->mesh_tri = keep_tri;
     res->mesh_sigma = d_sigma;
     res->mesh_voff = d_voff;
     res->mesh_toff = d_toff;

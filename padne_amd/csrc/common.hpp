@@ -194,12 +194,15 @@ int launch_spmv_f32_exit_part(padne_ctx *ctx, const padne_csr *m, int part, cons
 int spmm8_grid(const padne_csr *m);
 int launch_spmm8_mode(padne_ctx *ctx, const padne_csr *m, int mode, const double *x, double *y, const double *dot_with,
                       double *partials, const int32_t *done_flag, const double *aux1, const double *aux2, double scale);
-int launch_spmm8_f32(padne_ctx *ctx, const padne_csr *m, int mode, const float *x, float *y, double *partials,
-                     const int32_t *done_flag, const float *aux1, const float *aux2, float scale);
-int launch_spmm8_f32_exit(padne_ctx *ctx, const padne_csr *m, const float *x, double *y, const double *dot_with,
-                          double *partials, const int32_t *done_flag, const float *aux1, const float *aux2,
-                          float scale, const double *out_scale2);
-int interleave8(padne_ctx *ctx, long long n, const double *src, double *dst, bool to_interleaved);
+// the same for k = 8, 4 or 2 interleaved right-hand sides (vectors [n][k]; dot partials [k][kMaxPartials])
+int launch_spmm_mode(padne_ctx *ctx, const padne_csr *m, int k, int mode, const double *x, double *y, const double *dot_with,
+                     double *partials, const int32_t *done_flag, const double *aux1, const double *aux2, double scale);
+int launch_spmm_f32(padne_ctx *ctx, const padne_csr *m, int k, int mode, const float *x, float *y, double *partials,
+                    const int32_t *done_flag, const float *aux1, const float *aux2, float scale);
+int launch_spmm_f32_exit(padne_ctx *ctx, const padne_csr *m, int k, const float *x, double *y, const double *dot_with,
+                         double *partials, const int32_t *done_flag, const float *aux1, const float *aux2,
+                         float scale, const double *out_scale2);
+int interleave(padne_ctx *ctx, long long n, int k, const double *src, double *dst, bool to_interleaved);
 
 // exclusive scan of int32 counts into int32 offsets (n+1 outputs); returns total via host
 int exclusive_scan_i32(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t n, int64_t *total);

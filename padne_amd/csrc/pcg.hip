@@ -1060,8 +1060,11 @@ static int solve_one_single_reduction(padne_ctx *ctx, const padne_csr *a, const 
 // Every column keeps its own alpha / beta / stopping test; a column that has converged is frozen (alpha = 0)
 // while the others go on.  Reductions: per-workgroup partials [8][kMaxPartials] folded by an 8-workgroup kernel
 // into 8 device scalars that the consumers read.
-int amg_apply_batch8(padne_ctx *ctx, const padne_csr *A0, const double *r8, double *z8, double *partials_rz,
-                     const int32_t *done_flag, const double *bb2);
+// (K = 8: config C5, groups of regulators; K = 4 / 2: the two to four right-hand sides of one to three regulators, whose
+// lockstep iteration costs less than as many single ones -- the width is a template parameter of every kernel below and a
+// run-time argument of the host functions)
+int amg_apply_batch(padne_ctx *ctx, const padne_csr *A0, int k, const double *r8, double *z8, double *partials_rz,
+                    const int32_t *done_flag, const double *bb2);
 bool amg_supports_batch8(const padne_csr *A0);
 
 struct Pcg8Status {
@@ -1071,16 +1074,16 @@ struct Pcg8Status {
     double rr[8], tol2[8], bb[8];
 };
 
-// sums over this thread's strided share of an interleaved vector end up per column j = threadIdx.x & 7;
-// combine the 32 threads of a workgroup that share j and store one partial per column
-__device__ __forceinline__ void block_store_partial8(double v, double (*red)[8], double *part /* [8][kMaxPartials] */) {
-    v += __shfl_xor(v, 8, 64);
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
+// sums over this thread's strided share of an interleaved vector end up per column j = threadIdx.x & (K - 1);
+// combine the threads of a workgroup that share j and store one partial per column
+template <int K>
+__device__ __forceinline__ void block_store_partial8(double v, double (*red)[8], double *part /* [K][kMaxPartials] */) {
+#pragma unroll
+    for (int d = K; d < 64; d <<= 1) v += __shfl_xor(v, d, 64);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane < 8) red[w][lane] = v;
+    if (lane < K) red[w][lane] = v;
     __syncthreads();
-    if (threadIdx.x < 8)
+    if (threadIdx.x < K)
         part[(size_t)threadIdx.x * kMaxPartials + blockIdx.x] =
             (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
     __syncthreads();
@@ -1092,26 +1095,27 @@ __global__ __launch_bounds__(256) void fold8_kernel(const double *__restrict__ p
     if (threadIdx.x == 0) out[blockIdx.x] = t;
 }
 
+template <int K>
 __global__ __launch_bounds__(256) void pcg8_init_kernel(const long long n, const double *__restrict__ b,
                                                         const double *__restrict__ ax, double *__restrict__ r,
                                                         double *__restrict__ part_rr, double *__restrict__ part_bb) {
     __shared__ double red[4][8];
     double rr = 0.0, bb = 0.0;
-    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n * 8; t += (long long)gridDim.x * 256) {
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n * K; t += (long long)gridDim.x * 256) {
         const double bi = b[t];
         const double ri = ax ? bi - ax[t] : bi;
         r[t] = ri;
         rr += ri * ri;
         bb += bi * bi;
     }
-    block_store_partial8(rr, red, part_rr);
-    block_store_partial8(bb, red, part_bb);
+    block_store_partial8<K>(rr, red, part_rr);
+    block_store_partial8<K>(bb, red, part_bb);
 }
 
 __global__ void pcg8_set_tolerance_kernel(Pcg8Status *st, const double *__restrict__ rr, const double *__restrict__ bbv,
-                                          double rtol, double atol, int use_existing_bb) {
+                                          double rtol, double atol, int use_existing_bb, const int K) {
     const int j = threadIdx.x;
-    if (j < 8) {
+    if (j < K) {
         const double bb = use_existing_bb ? st->bb[j] : bbv[j];
         double tol = rtol * sqrt(bb);
         if (atol > tol) tol = atol;
@@ -1124,11 +1128,12 @@ __global__ void pcg8_set_tolerance_kernel(Pcg8Status *st, const double *__restri
     __syncthreads();
     if (j == 0) {
         int all = 1;
-        for (int c = 0; c < 8; ++c) all &= st->col_done[c];
+        for (int c = 0; c < K; ++c) all &= st->col_done[c];
         st->done = (all || st->code != PADNE_OK) ? 1 : 0;
     }
 }
 
+template <int K>
 __global__ __launch_bounds__(256) void pcg8_update_xr_kernel(const long long n, const double *__restrict__ rz,
                                                              const double *__restrict__ pq, const double *__restrict__ p,
                                                              const double *__restrict__ q, double *__restrict__ x,
@@ -1136,27 +1141,28 @@ __global__ __launch_bounds__(256) void pcg8_update_xr_kernel(const long long n, 
                                                              const Pcg8Status *__restrict__ st) {
     __shared__ double red[4][8];
     if (st->done) return;
-    const int j = threadIdx.x & 7;
+    const int j = threadIdx.x & (K - 1);
     const double alpha = st->col_done[j] ? 0.0 : rz[j] / pq[j];
     double s_rr = 0.0;
-    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n * 8; t += (long long)gridDim.x * 256) {
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n * K; t += (long long)gridDim.x * 256) {
         const double ri = r[t] - alpha * q[t];
         x[t] += alpha * p[t];
         r[t] = ri;
         s_rr += ri * ri;
     }
-    block_store_partial8(s_rr, red, part_rr);
+    block_store_partial8<K>(s_rr, red, part_rr);
 }
 
+template <int K>
 __global__ __launch_bounds__(256) void pcg8_update_p_kernel(const long long n, const double *__restrict__ rz_new,
                                                             const double *__restrict__ rz_old, const double *__restrict__ rr,
                                                             const double *__restrict__ pq, const double *__restrict__ z,
                                                             double *__restrict__ p, Pcg8Status *__restrict__ st,
                                                             const int max_iter) {
     if (st->done) return;
-    const int j = threadIdx.x & 7;
+    const int j = threadIdx.x & (K - 1);
     const double beta = st->col_done[j] ? 0.0 : rz_new[j] / rz_old[j];
-    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n * 8; t += (long long)gridDim.x * 256)
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n * K; t += (long long)gridDim.x * 256)
         p[t] = z[t] + beta * p[t];
     if (blockIdx.x == 0) {
         __syncthreads();
@@ -1164,7 +1170,7 @@ __global__ __launch_bounds__(256) void pcg8_update_p_kernel(const long long n, c
             const int it = st->iters + 1;
             st->iters = it;
             int all = 1;
-            for (int c = 0; c < 8; ++c) {
+            for (int c = 0; c < K; ++c) {
                 if (st->col_done[c]) continue;
                 st->col_iters[c] += 1;
                 st->rr[c] = rr[c];
@@ -1181,27 +1187,29 @@ __global__ __launch_bounds__(256) void pcg8_update_p_kernel(const long long n, c
     }
 }
 
+template <int K>
 __global__ __launch_bounds__(256) void residual8_kernel(const long long n, const double *__restrict__ b,
                                                         const double *__restrict__ ax, double *__restrict__ part_rr) {
     __shared__ double red[4][8];
     double rr = 0.0;
-    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n * 8; t += (long long)gridDim.x * 256) {
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n * K; t += (long long)gridDim.x * 256) {
         const double ri = ax[t] - b[t];
         rr += ri * ri;
     }
-    block_store_partial8(rr, red, part_rr);
+    block_store_partial8<K>(rr, red, part_rr);
 }
 
-// b_cols / x_cols: 8 vectors of n doubles one after the other (the C ABI layout)
-static int solve_batch8(padne_ctx *ctx, const padne_csr *a, const double *b_cols, double *x_cols,
-                        const padne_solve_opts *o, padne_solve_info *info, bool x_is_guess) {
+// b_cols / x_cols: K vectors of n doubles one after the other (the C ABI layout)
+template <int K>
+static int solve_batch(padne_ctx *ctx, const padne_csr *a, const double *b_cols, double *x_cols,
+                       const padne_solve_opts *o, padne_solve_info *info, bool x_is_guess) {
     const long long n = a->n_rows;
     PADNE_REQUIRE(a->n_rows == a->n_cols && !ctx->halo_on, "the batched solve is single-GPU");
     hipStream_t s = ctx->stream;
     Scratch sc(ctx);
     double *b8 = nullptr, *x8 = nullptr, *r8 = nullptr, *z8 = nullptr, *p8 = nullptr, *q8 = nullptr, *part = nullptr,
            *scal = nullptr;
-    const size_t nv = (size_t)n * 8;
+    const size_t nv = (size_t)n * K;
     PADNE_TRY(sc.alloc(&b8, nv));
     PADNE_TRY(sc.alloc(&x8, nv));
     PADNE_TRY(sc.alloc(&r8, nv));
@@ -1215,22 +1223,22 @@ static int solve_batch8(padne_ctx *ctx, const padne_csr *a, const double *b_cols
     enum { C_PQ = 0, C_RZ0 = 8, C_RZ1 = 16, C_RR = 24, C_BB = 32, C_TRUE = 40 };
     Pcg8Status *st = (Pcg8Status *)ctx->status;
     Pcg8Status *hst = (Pcg8Status *)ctx->pinned;
-    const int gv = vec_grid(n * 8);
+    const int gv = vec_grid(n * K);
     const int gs = spmm8_grid(a);
     const int max_iter = o->max_iter > 0 ? o->max_iter : 100000;
     const int check_every = o->check_every > 0 ? o->check_every : 4;
     auto fold = [&](const double *partials, int P, double *out) -> int {
-        hipLaunchKernelGGL(fold8_kernel, dim3(8), dim3(256), 0, s, partials, P, out);
+        hipLaunchKernelGGL(fold8_kernel, dim3(K), dim3(256), 0, s, partials, P, out);
         PADNE_HIP_CHECK(hipGetLastError());
         return PADNE_OK;
     };
     PADNE_HIP_CHECK(hipMemsetAsync(st, 0, sizeof(Pcg8Status), s));
-    PADNE_TRY(interleave8(ctx, n, b_cols, b8, true));
+    PADNE_TRY(interleave(ctx, n, K, b_cols, b8, true));
     PADNE_HIP_CHECK(hipEventRecord(ctx->ev0, s));
     bool have_ax = false;
     if (x_is_guess) {
-        PADNE_TRY(interleave8(ctx, n, x_cols, x8, true));
-        PADNE_TRY(launch_spmm8_mode(ctx, a, SPMV_PLAIN, x8, q8, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0));
+        PADNE_TRY(interleave(ctx, n, K, x_cols, x8, true));
+        PADNE_TRY(launch_spmm_mode(ctx, a, K, SPMV_PLAIN, x8, q8, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0));
         have_ax = true;
     } else {
         PADNE_HIP_CHECK(hipMemsetAsync(x8, 0, sizeof(double) * nv, s));
@@ -1240,16 +1248,16 @@ static int solve_batch8(padne_ctx *ctx, const padne_csr *a, const double *b_cols
     int col_iters[8] = {0};
     bool stagnated[8] = {false};
     for (;;) {
-        hipLaunchKernelGGL(pcg8_init_kernel, dim3(gv), dim3(256), 0, s, n, b8, have_ax ? q8 : nullptr, r8, pslot(P_RR),
+        hipLaunchKernelGGL(pcg8_init_kernel<K>, dim3(gv), dim3(256), 0, s, n, b8, have_ax ? q8 : nullptr, r8, pslot(P_RR),
                            pslot(P_BB));
         PADNE_HIP_CHECK(hipGetLastError());
         PADNE_TRY(fold(pslot(P_RR), gv, scal + C_RR));
         PADNE_TRY(fold(pslot(P_BB), gv, scal + C_BB));
-        PADNE_TRY(amg_apply_batch8(ctx, a, r8, z8, pslot(P_RZ0), nullptr, scal + C_BB));
+        PADNE_TRY(amg_apply_batch(ctx, a, K, r8, z8, pslot(P_RZ0), nullptr, scal + C_BB));
         PADNE_TRY(fold(pslot(P_RZ0), gs, scal + C_RZ0));
         PADNE_HIP_CHECK(hipMemcpyAsync(p8, z8, sizeof(double) * nv, hipMemcpyDeviceToDevice, s));
         hipLaunchKernelGGL(pcg8_set_tolerance_kernel, dim3(1), dim3(64), 0, s, st, scal + C_RR, scal + C_BB, o->rtol,
-                           o->atol, restarts > 0 ? 1 : 0);
+                           o->atol, restarts > 0 ? 1 : 0, K);
         PADNE_HIP_CHECK(hipGetLastError());
         int parity = 0;
         bool done = false;
@@ -1257,15 +1265,15 @@ static int solve_batch8(padne_ctx *ctx, const padne_csr *a, const double *b_cols
             for (int k = 0; k < check_every; ++k) {
                 double *rz_old = scal + (parity ? C_RZ1 : C_RZ0), *rz_new = scal + (parity ? C_RZ0 : C_RZ1);
                 const int rz_new_slot = parity ? P_RZ0 : P_RZ1;
-                PADNE_TRY(launch_spmm8_mode(ctx, a, SPMV_DOT, p8, q8, p8, pslot(P_PQ), &st->done, nullptr, nullptr, 0.0));
+                PADNE_TRY(launch_spmm_mode(ctx, a, K, SPMV_DOT, p8, q8, p8, pslot(P_PQ), &st->done, nullptr, nullptr, 0.0));
                 PADNE_TRY(fold(pslot(P_PQ), gs, scal + C_PQ));
-                hipLaunchKernelGGL(pcg8_update_xr_kernel, dim3(gv), dim3(256), 0, s, n, rz_old, scal + C_PQ, p8, q8, x8, r8,
+                hipLaunchKernelGGL(pcg8_update_xr_kernel<K>, dim3(gv), dim3(256), 0, s, n, rz_old, scal + C_PQ, p8, q8, x8, r8,
                                    pslot(P_RR), st);
                 PADNE_HIP_CHECK(hipGetLastError());
-                PADNE_TRY(amg_apply_batch8(ctx, a, r8, z8, pslot(rz_new_slot), &st->done, scal + C_BB));
+                PADNE_TRY(amg_apply_batch(ctx, a, K, r8, z8, pslot(rz_new_slot), &st->done, scal + C_BB));
                 PADNE_TRY(fold(pslot(rz_new_slot), gs, rz_new));
                 PADNE_TRY(fold(pslot(P_RR), gv, scal + C_RR));
-                hipLaunchKernelGGL(pcg8_update_p_kernel, dim3(gv), dim3(256), 0, s, n, rz_new, rz_old, scal + C_RR,
+                hipLaunchKernelGGL(pcg8_update_p_kernel<K>, dim3(gv), dim3(256), 0, s, n, rz_new, rz_old, scal + C_RR,
                                    scal + C_PQ, z8, p8, st, max_iter - total_iters);
                 PADNE_HIP_CHECK(hipGetLastError());
                 parity ^= 1;
@@ -1276,21 +1284,21 @@ static int solve_batch8(padne_ctx *ctx, const padne_csr *a, const double *b_cols
         }
         total_iters += hst->iters;
         code = hst->code;
-        for (int c = 0; c < 8; ++c) {
+        for (int c = 0; c < K; ++c) {
             bb[c] = hst->bb[c];
             tol2[c] = hst->tol2[c];
             col_iters[c] += hst->col_iters[c];
         }
         // true residuals
-        PADNE_TRY(launch_spmm8_mode(ctx, a, SPMV_PLAIN, x8, q8, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0));
-        hipLaunchKernelGGL(residual8_kernel, dim3(gv), dim3(256), 0, s, n, b8, q8, pslot(P_TMP));
+        PADNE_TRY(launch_spmm_mode(ctx, a, K, SPMV_PLAIN, x8, q8, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0));
+        hipLaunchKernelGGL(residual8_kernel<K>, dim3(gv), dim3(256), 0, s, n, b8, q8, pslot(P_TMP));
         PADNE_HIP_CHECK(hipGetLastError());
         PADNE_TRY(fold(pslot(P_TMP), gv, scal + C_TRUE));
         double *hd = (double *)((char *)ctx->pinned + 1024);
-        PADNE_HIP_CHECK(hipMemcpyAsync(hd, scal + C_TRUE, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
+        PADNE_HIP_CHECK(hipMemcpyAsync(hd, scal + C_TRUE, K * sizeof(double), hipMemcpyDeviceToHost, s));
         PADNE_HIP_CHECK(hipStreamSynchronize(s));
         bool all_final = true;
-        for (int c = 0; c < 8; ++c) {
+        for (int c = 0; c < K; ++c) {
             true_rr[c] = hd[c];
             if (true_rr[c] <= tol2[c] * 1.0000001) continue;
             if (restarts > 0 && true_rr[c] >= 0.25 * prev_true_rr[c]) {
@@ -1300,18 +1308,18 @@ static int solve_batch8(padne_ctx *ctx, const padne_csr *a, const double *b_cols
             all_final = false;
         }
         if (code != PADNE_OK || all_final || total_iters >= max_iter || restarts >= 8) break;
-        for (int c = 0; c < 8; ++c) prev_true_rr[c] = true_rr[c];
+        for (int c = 0; c < K; ++c) prev_true_rr[c] = true_rr[c];
         ++restarts;
         have_ax = true;
         PADNE_HIP_CHECK(hipMemsetAsync(st, 0, 4 * sizeof(int32_t) + 16 * sizeof(int32_t), s));   // flags and counters
     }
-    PADNE_TRY(interleave8(ctx, n, x8, x_cols, false));
+    PADNE_TRY(interleave(ctx, n, K, x8, x_cols, false));
     PADNE_HIP_CHECK(hipEventRecord(ctx->ev1, s));
     PADNE_HIP_CHECK(hipEventSynchronize(ctx->ev1));
     float ms = 0.f;
     PADNE_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     if (info) {
-        for (int c = 0; c < 8; ++c) {
+        for (int c = 0; c < K; ++c) {
             info->iterations += col_iters[c];
             const double rel = bb[c] > 0 ? sqrt(true_rr[c] / bb[c]) : sqrt(true_rr[c]);
             if (rel > info->rel_residual) info->rel_residual = rel;
@@ -1668,44 +1676,64 @@ static int solve_spd_dev_impl(padne_ctx *ctx, const padne_csr *a, const void *b_
     int k_first = 0;
     if (use_amg && !ctx->halo_on && !comm_active(ctx) && pm == a && amg_supports_batch8(a) &&
         getenv("PADNE_NO_BATCH") == nullptr) {
-        // groups of 8 right-hand sides advance in lockstep (one pass over the operators per iteration for all of
-        // them); a group whose cycle breaks down falls through to the one-at-a-time path below
-        for (; k_first + 8 <= n_rhs; k_first += 8) {
+        // Groups of right-hand sides advance in lockstep (one pass over the operators per iteration for all of them); a
+        // group whose cycle breaks down falls through to the one-at-a-time path below.  The kernels exist in widths 8, 4
+        // and 2; MEASURED at N = 5 M (scripts/exp_lockstep_widths.py, profiles/r04_lockstep_widths.json) a lockstep solve
+        // of 8 / 4 / 2 right-hand sides costs 5.3 / 3.3 / 2.3 single solves -- the single path has the x windows, the fused
+        // W up-leg and the fused vector kernels, the lockstep cycle is the plain V(1,1) on interleaved vectors -- so:
+        // eight at a time while they last, a remainder of 5-7 zero-padded to eight (zero columns are converged from the
+        // start), exactly 4 (three regulators, solver.py:512-538) in width 4, and 2-3 one at a time, where lockstep LOSES
+        // (2.3 against 2.0, 3.3 against 3.0).  PADNE_LOCKSTEP_NARROW=2 sends 2-3 through the narrow widths anyway (tests),
+        // =0 switches width 4 off as well.
+        auto solve_group = [&](const int width, const int first, const int count, bool *ok) -> int {
+            *ok = false;
+            Scratch pad(ctx);
+            const double *bsrc = (const double *)b_dev + (size_t)first * n;
+            double *xdst = (double *)x_dev + (size_t)first * n;
+            double *bp = nullptr, *xp = nullptr;
+            if (count < width) {
+                PADNE_TRY(pad.alloc(&bp, (size_t)width * n));
+                PADNE_TRY(pad.alloc(&xp, (size_t)width * n));
+                PADNE_HIP_CHECK(hipMemsetAsync(bp, 0, sizeof(double) * (size_t)width * n, ctx->stream));
+                PADNE_HIP_CHECK(hipMemsetAsync(xp, 0, sizeof(double) * (size_t)width * n, ctx->stream));
+                PADNE_HIP_CHECK(hipMemcpyAsync(bp, bsrc, sizeof(double) * (size_t)count * n, hipMemcpyDeviceToDevice, ctx->stream));
+                if ((opts->flags & 1) != 0)
+                    PADNE_HIP_CHECK(hipMemcpyAsync(xp, xdst, sizeof(double) * (size_t)count * n, hipMemcpyDeviceToDevice, ctx->stream));
+            }
             padne_solve_info grp = local;
             grp.status = PADNE_OK;
-            PADNE_TRY(solve_batch8(ctx, a, (const double *)b_dev + (size_t)k_first * n, (double *)x_dev + (size_t)k_first * n,
-                                   opts, &grp, (opts->flags & 1) != 0));
-            if (grp.status != PADNE_OK) break;
+            const double *bb = count < width ? bp : bsrc;
+            double *xx = count < width ? xp : xdst;
+            const bool guess = (opts->flags & 1) != 0;
+            if (width == 8) PADNE_TRY(solve_batch<8>(ctx, a, bb, xx, opts, &grp, guess));
+            else if (width == 4) PADNE_TRY(solve_batch<4>(ctx, a, bb, xx, opts, &grp, guess));
+            else PADNE_TRY(solve_batch<2>(ctx, a, bb, xx, opts, &grp, guess));
+            if (grp.status != PADNE_OK) return PADNE_OK;             // (not ok: the caller solves these one at a time)
+            if (count < width) {
+                PADNE_HIP_CHECK(hipMemcpyAsync(xdst, xp, sizeof(double) * (size_t)count * n, hipMemcpyDeviceToDevice, ctx->stream));
+                PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // (the padded copies go back to the pool)
+            }
             const int keep = local.status;
             local = grp;
             local.status = keep;
             ++ctx->lockstep_groups;
-        }
-        // a remainder of 5-7 right-hand sides is still cheaper in lockstep (padded with zero columns, which are
-        // converged from the start) than one at a time: a lockstep iteration costs about 2.4 single ones
-        const int rest = n_rhs - k_first;
-        if (rest >= 5 && rest < 8 && local.status == PADNE_OK) {
-            Scratch pad(ctx);
-            double *bp = nullptr, *xp = nullptr;
-            PADNE_TRY(pad.alloc(&bp, (size_t)8 * n));
-            PADNE_TRY(pad.alloc(&xp, (size_t)8 * n));
-            PADNE_HIP_CHECK(hipMemsetAsync(bp, 0, sizeof(double) * (size_t)8 * n, ctx->stream));
-            PADNE_HIP_CHECK(hipMemsetAsync(xp, 0, sizeof(double) * (size_t)8 * n, ctx->stream));
-            PADNE_HIP_CHECK(hipMemcpyAsync(bp, (const double *)b_dev + (size_t)k_first * n, sizeof(double) * (size_t)rest * n,
-                                           hipMemcpyDeviceToDevice, ctx->stream));
-            if ((opts->flags & 1) != 0)
-                PADNE_HIP_CHECK(hipMemcpyAsync(xp, (const double *)x_dev + (size_t)k_first * n,
-                                               sizeof(double) * (size_t)rest * n, hipMemcpyDeviceToDevice, ctx->stream));
-            padne_solve_info grp = local;
-            PADNE_TRY(solve_batch8(ctx, a, bp, xp, opts, &grp, (opts->flags & 1) != 0));
-            if (grp.status == PADNE_OK) {
-                PADNE_HIP_CHECK(hipMemcpyAsync((double *)x_dev + (size_t)k_first * n, xp, sizeof(double) * (size_t)rest * n,
-                                               hipMemcpyDeviceToDevice, ctx->stream));
-                PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-                local = grp;
-                k_first = n_rhs;
-                ++ctx->lockstep_groups;
-            }
+            *ok = true;
+            return PADNE_OK;
+        };
+        const char *narrow_env = getenv("PADNE_LOCKSTEP_NARROW");
+        const int narrow = narrow_env == nullptr ? 1 : atoi(narrow_env);
+        bool ok = true;
+        while (ok && n_rhs - k_first >= 2) {
+            const int rest = n_rhs - k_first;
+            int width = 0, count = 0;
+            if (rest >= 8) { width = 8; count = 8; }
+            else if (rest >= 5) { width = 8; count = rest; }
+            else if (rest == 4 && narrow >= 1) { width = 4; count = 4; }
+            else if (rest == 3 && narrow >= 2) { width = 4; count = 3; }
+            else if (rest == 2 && narrow >= 2) { width = 2; count = 2; }
+            else break;
+            PADNE_TRY(solve_group(width, k_first, count, &ok));
+            if (ok) k_first += count;
         }
     }
     // row-partitioned multigrid runs use the single-reduction loop (one all-reduce per iteration); PADNE_CG_SINGLE_REDUCTION

@@ -20,14 +20,19 @@ namespace padne {
 
 constexpr int kSpmmChunk = 512;      // non-zeros staged per wave per pass (6 KiB: 4 B col + 8 B val)
 
-template <int MODE, typename VT, typename XT, typename YT>
-__global__ __launch_bounds__(kSpmvThreads) void csr_spmm8_kernel(
+// K = 8, 4 or 2 right-hand sides (the narrow forms serve one to three regulators, pcg.hip): K / 2 lanes share a row,
+// 128 / K rows form a group, a wave works through its 64 rows in K / 2 groups.
+template <int K, int MODE, typename VT, typename XT, typename YT>
+__global__ __launch_bounds__(kSpmvThreads) void csr_spmm_kernel(
     const int n_rows, const int n_wtiles, const int *__restrict__ rowptr, const int *__restrict__ cols,
     const VT *__restrict__ vals, const XT *__restrict__ x, YT *__restrict__ y, const double *__restrict__ dot_with,
     double *__restrict__ partials /* [8][kMaxPartials] */, const int *__restrict__ done_flag,
     const XT *__restrict__ aux1, const XT *__restrict__ aux2, const XT scale,
-    const double *__restrict__ out_scale2 /* [8] or null */) {
-    constexpr int K = kSpmmK;
+    const double *__restrict__ out_scale2 /* [K] or null */) {
+    static_assert(K == 8 || K == 4 || K == 2, "lockstep widths");
+    constexpr int LPR = K / 2;                              // lanes per row (each takes two right-hand sides)
+    constexpr int RPG = 64 / LPR;                           // rows per group
+    constexpr int NG = LPR;                                 // groups per 64-row tile
     constexpr bool WITH_DOT = (MODE == SPMV_DOT) || (MODE == SPMV_JACOBI);
     __shared__ int cs_all[4 * kSpmmChunk];
     __shared__ VT vs_all[4 * kSpmmChunk];
@@ -36,7 +41,7 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmm8_kernel(
     if (done_flag != nullptr && *done_flag != 0) return;
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int rsub = lane >> 2, j = (lane & 3) * 2;        // this lane's columns: j, j + 1
+    const int rsub = lane / LPR, j = (lane % LPR) * 2;     // this lane's columns: j, j + 1
     int *cs = cs_all + w * kSpmmChunk;
     VT *vs = vs_all + w * kSpmmChunk;
     double out_mul0 = 1.0, out_mul1 = 1.0;
@@ -66,14 +71,14 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmm8_kernel(
         }
         const int k0 = __shfl(rs, 0, 64);
         const int k1 = __shfl(re, row1 - row0 - 1, 64);
-        XT acc0[4], acc1[4];
-        int grs[4], gre[4];
+        XT acc0[NG], acc1[NG];
+        int grs[NG], gre[NG];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < NG; ++g) {
             acc0[g] = 0;
             acc1[g] = 0;
-            grs[g] = __shfl(rs, g * 16 + rsub, 64);
-            gre[g] = __shfl(re, g * 16 + rsub, 64);
+            grs[g] = __shfl(rs, g * RPG + rsub, 64);
+            gre[g] = __shfl(re, g * RPG + rsub, 64);
         }
         for (int base = k0; base < k1; base += kSpmmChunk) {
 #pragma unroll
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmm8_kernel(
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            for (int g = 0; g < NG; ++g) {
                 const int lo = max(grs[g], base), hi = min(gre[g], base + kSpmmChunk);
                 XT a0 = acc0[g], a1 = acc1[g];
                 for (int k = lo; k < hi; k += 8) {             // up to eight 16-byte gathers in flight per lane
@@ -117,8 +122,8 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmm8_kernel(
             __builtin_amdgcn_wave_barrier();
         }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int r = row0 + g * 16 + rsub;
+        for (int g = 0; g < NG; ++g) {
+            const int r = row0 + g * RPG + rsub;
             if (r >= row1) continue;
             const size_t o = (size_t)r * K + j;
             const XT a0 = acc0[g], a1 = acc1[g];
@@ -161,13 +166,13 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmm8_kernel(
         }
     }
     if (WITH_DOT && partials != nullptr) {
-        // lanes with the same column pair: 4, 8, 16, 32 apart
+        // lanes with the same column pair: LPR, 2 LPR, ... 32 apart
 #pragma unroll
-        for (int d = 4; d < 64; d <<= 1) {
+        for (int d = LPR; d < 64; d <<= 1) {
             dot0 += __shfl_xor(dot0, d, 64);
             dot1 += __shfl_xor(dot1, d, 64);
         }
-        if (lane < 4) {
+        if (lane < LPR) {
             red[w][lane * 2] = dot0;
             red[w][lane * 2 + 1] = dot1;
         }
@@ -178,10 +183,10 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmm8_kernel(
     }
 }
 
-template <typename VT, typename XT, typename YT>
-static int launch_spmm8_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals, int mode, const XT *x, YT *y,
-                              const double *dot_with, double *partials, const int32_t *done_flag, const XT *aux1,
-                              const XT *aux2, XT scale, const double *out_scale2) {
+template <int K, typename VT, typename XT, typename YT>
+static int launch_spmm_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals, int mode, const XT *x, YT *y,
+                             const double *dot_with, double *partials, const int32_t *done_flag, const XT *aux1,
+                             const XT *aux2, XT scale, const double *out_scale2) {
     if (m->n_rows == 0) return PADNE_OK;
     const int n_tiles = (int)((m->n_rows + 63) / 64);
     long long g = (m->n_rows + kSpmvRows - 1) / kSpmvRows;
@@ -189,7 +194,7 @@ static int launch_spmm8_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals
     if (g >= kNumXcd) g -= g % kNumXcd;
     if (g < 1) g = 1;
 #define PADNE_SPMM_LAUNCH(M)                                                                                      \
-    hipLaunchKernelGGL((csr_spmm8_kernel<M, VT, XT, YT>), dim3((unsigned)g), dim3(kSpmvThreads), 0, ctx->stream,   \
+    hipLaunchKernelGGL((csr_spmm_kernel<K, M, VT, XT, YT>), dim3((unsigned)g), dim3(kSpmvThreads), 0, ctx->stream, \
                        (int)m->n_rows, n_tiles, m->rowptr, m->cols, vals, x, y, dot_with, partials, done_flag,     \
                        aux1, aux2, scale, out_scale2)
     switch (mode) {
@@ -212,41 +217,61 @@ int spmm8_grid(const padne_csr *m) {
     return (int)(g < 1 ? 1 : g);
 }
 
+// the width is a run-time choice of the caller (8 for config C5 and groups of regulators, 4 / 2 for one to three)
+#define PADNE_SPMM_WIDTH(k, CALL8, CALL4, CALL2)                       \
+    switch (k) {                                                       \
+        case 8: return CALL8;                                          \
+        case 4: return CALL4;                                          \
+        case 2: return CALL2;                                          \
+        default: set_error("lockstep width %d", k); return PADNE_E_INVALID; \
+    }
+
+int launch_spmm_mode(padne_ctx *ctx, const padne_csr *m, int k, int mode, const double *x, double *y, const double *dot_with,
+                     double *partials, const int32_t *done_flag, const double *aux1, const double *aux2, double scale) {
+#define ARGS ctx, m, m->vals, mode, x, y, dot_with, partials, done_flag, aux1, aux2, scale, nullptr
+    PADNE_SPMM_WIDTH(k, (launch_spmm_typed<8, double, double, double>(ARGS)), (launch_spmm_typed<4, double, double, double>(ARGS)),
+                     (launch_spmm_typed<2, double, double, double>(ARGS)))
+#undef ARGS
+}
+
+int launch_spmm_f32(padne_ctx *ctx, const padne_csr *m, int k, int mode, const float *x, float *y, double *partials,
+                    const int32_t *done_flag, const float *aux1, const float *aux2, float scale) {
+    PADNE_REQUIRE(m->vals32 != nullptr, "single-precision copy missing");
+#define ARGS ctx, m, m->vals32, mode, x, y, nullptr, partials, done_flag, aux1, aux2, scale, nullptr
+    PADNE_SPMM_WIDTH(k, (launch_spmm_typed<8, float, float, float>(ARGS)), (launch_spmm_typed<4, float, float, float>(ARGS)),
+                     (launch_spmm_typed<2, float, float, float>(ARGS)))
+#undef ARGS
+}
+
+int launch_spmm_f32_exit(padne_ctx *ctx, const padne_csr *m, int k, const float *x, double *y, const double *dot_with,
+                         double *partials, const int32_t *done_flag, const float *aux1, const float *aux2,
+                         float scale, const double *out_scale2) {
+    PADNE_REQUIRE(m->vals32 != nullptr && dot_with != nullptr, "single-precision exit stage");
+#define ARGS ctx, m, m->vals32, SPMV_JACOBI, x, y, dot_with, partials, done_flag, aux1, aux2, scale, out_scale2
+    PADNE_SPMM_WIDTH(k, (launch_spmm_typed<8, float, float, double>(ARGS)), (launch_spmm_typed<4, float, float, double>(ARGS)),
+                     (launch_spmm_typed<2, float, float, double>(ARGS)))
+#undef ARGS
+}
+
 int launch_spmm8_mode(padne_ctx *ctx, const padne_csr *m, int mode, const double *x, double *y, const double *dot_with,
                       double *partials, const int32_t *done_flag, const double *aux1, const double *aux2,
                       double scale) {
-    return launch_spmm8_typed<double, double, double>(ctx, m, m->vals, mode, x, y, dot_with, partials, done_flag, aux1,
-                                                      aux2, scale, nullptr);
-}
-
-int launch_spmm8_f32(padne_ctx *ctx, const padne_csr *m, int mode, const float *x, float *y, double *partials,
-                     const int32_t *done_flag, const float *aux1, const float *aux2, float scale) {
-    PADNE_REQUIRE(m->vals32 != nullptr, "single-precision copy missing");
-    return launch_spmm8_typed<float, float, float>(ctx, m, m->vals32, mode, x, y, nullptr, partials, done_flag, aux1,
-                                                   aux2, scale, nullptr);
-}
-
-int launch_spmm8_f32_exit(padne_ctx *ctx, const padne_csr *m, const float *x, double *y, const double *dot_with,
-                          double *partials, const int32_t *done_flag, const float *aux1, const float *aux2,
-                          float scale, const double *out_scale2) {
-    PADNE_REQUIRE(m->vals32 != nullptr && dot_with != nullptr, "single-precision exit stage");
-    return launch_spmm8_typed<float, float, double>(ctx, m, m->vals32, SPMV_JACOBI, x, y, dot_with, partials, done_flag,
-                                                    aux1, aux2, scale, out_scale2);
+    return launch_spmm_mode(ctx, m, kSpmmK, mode, x, y, dot_with, partials, done_flag, aux1, aux2, scale);
 }
 
 // [k][n] (one vector after the other) <-> [n][k] (interleaved)
-__global__ void interleave8_kernel(long long n, const double *__restrict__ src, double *__restrict__ dst, int to_interleaved) {
+__global__ void interleave_kernel(long long n, int k, const double *__restrict__ src, double *__restrict__ dst, int to_interleaved) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n * kSpmmK) return;
-    const long long i = t / kSpmmK;
-    const int j = (int)(t % kSpmmK);
+    if (t >= n * k) return;
+    const long long i = t / k;
+    const int j = (int)(t % k);
     if (to_interleaved) dst[t] = src[(size_t)j * n + i];
     else dst[(size_t)j * n + i] = src[t];
 }
 
-int interleave8(padne_ctx *ctx, long long n, const double *src, double *dst, bool to_interleaved) {
+int interleave(padne_ctx *ctx, long long n, int k, const double *src, double *dst, bool to_interleaved) {
     if (n <= 0) return PADNE_OK;
-    hipLaunchKernelGGL(interleave8_kernel, dim3((unsigned)((n * kSpmmK + 255) / 256)), dim3(256), 0, ctx->stream, n, src,
+    hipLaunchKernelGGL(interleave_kernel, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, ctx->stream, n, k, src,
                        dst, to_interleaved ? 1 : 0);
     PADNE_HIP_CHECK(hipGetLastError());
     return PADNE_OK;

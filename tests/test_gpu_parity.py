@@ -1237,6 +1237,53 @@ def test_five_regulators_advance_in_lockstep_and_match_the_direct_solve(ctx, mon
     assert np.abs(v1 - v).max() <= 1e-9 * np.abs(v_ref).max()      # the grouping does not show beyond the tolerance
 
 
+@pytest.mark.parametrize("n_reg", [1, 2, 3])
+def test_one_to_three_regulators_in_the_narrow_lockstep_widths(ctx, monkeypatch, n_reg):
+    """One to three regulators are two to four right-hand sides (`solver.py:512-538`).  The lockstep kernels exist in
+    widths 2 and 4 as well as 8; measured, only exactly four right-hand sides gain from them (3.3
+    against 4.0 single solves; two cost 2.3 against 2.0 -- profiles/r04_lockstep_widths.json), so that is what the default
+    does: three regulators go as ONE group of width 4, one or two regulators one right-hand side at a time.
+    PADNE_LOCKSTEP_NARROW=2 sends those through width 2 / a zero-padded width 4 too: potentials and regulator currents
+    of every path against the reference's direct solve and against each other."""
+    rng = np.random.default_rng(31 + n_reg)
+    meshes, offs = [], [0]
+    for layer, (nx, ny) in enumerate(((90, 80), (80, 90))):
+        xy, tri = synthetic.jittered_grid(nx, ny, seed=50 + layer)
+        meshes.append((xy, tri, 2082.5))
+        offs.append(offs[-1] + len(xy))
+    n_vert = offs[-1]
+    p0 = iter(rng.permutation(offs[1]))
+    p1 = iter(offs[1] + rng.permutation(offs[2] - offs[1]))
+    els = [("R", int(next(p0)), int(next(p1)), float(10 ** rng.uniform(-3, -1))) for _ in range(12)]
+    els.append(("I", int(next(p0)), int(next(p1)), 1.5))
+    for k in range(n_reg):
+        vp, vn, sf, st = int(next(p0)), int(next(p1)), int(next(p0)), int(next(p1))
+        els.append(("REG", vp, vn, sf, st, 1.0 + 0.5 * k, 0.6 + 0.1 * k, n_vert + k))
+        els.append(("R", vp, vn, 1.0 + k))
+    Lo, ro = O.assemble_system(meshes, 0, els, 0)
+    v_ref, _, _ = O.solve_system(Lo, ro)
+
+    def check(v, info):
+        assert np.abs(v[:n_vert] - v_ref[:n_vert]).max() <= REL_TOL * np.abs(v_ref[:n_vert]).max()
+        assert np.abs(v[n_vert:] - v_ref[n_vert:]).max() <= 1e-7 * np.abs(v_ref[n_vert:]).max()
+        assert info.residual_norm < 1e-9
+    before = ctx.lockstep_groups()
+    v, info = solver.solve_system(Lo, ro)
+    check(v, info)
+    assert ctx.lockstep_groups() == before + (1 if n_reg == 3 else 0)
+    monkeypatch.setenv("PADNE_LOCKSTEP_NARROW", "2")
+    before = ctx.lockstep_groups()
+    v2, info2 = solver.solve_system(Lo, ro)
+    check(v2, info2)
+    assert ctx.lockstep_groups() == before + 1             # width 2, or width 4 (zero-padded for two regulators)
+    monkeypatch.setenv("PADNE_LOCKSTEP_NARROW", "0")
+    before = ctx.lockstep_groups()
+    v0, info0 = solver.solve_system(Lo, ro)
+    check(v0, info0)
+    assert ctx.lockstep_groups() == before                 # everything one at a time
+    assert np.abs(v2 - v0).max() <= 1e-9 * np.abs(v_ref).max() and np.abs(v - v0).max() <= 1e-9 * np.abs(v_ref).max()
+
+
 def test_more_regulators_than_the_former_cap_of_the_device_plan(ctx):
     """`padne_kkt_solve` took at most 64 extra right-hand sides; the host path it replaced, like the
     reference (`solver.py:512-538`), takes any number.  66 regulators on two small layers: 67 right-hand sides in groups
