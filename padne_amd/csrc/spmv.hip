@@ -62,6 +62,14 @@ __device__ __forceinline__ double block_sum_256(double v, double *red) {
 constexpr int kXwRuns = 3;              // staged runs of x per tile
 constexpr int kXwRunShort = 72;         // entries per run: 64 rows + the mesh neighbours on both sides (scan-line grids),
 constexpr int kXwRunLong = 128;         // or twice the tile for strip-ordered unstructured meshes
+// The wide plan (csr_build_xw_plan_wide): ten short runs.  The rows of the fused up-leg operator W = P - c D^-1 A P are fine
+// rows, its columns aggregates: 64 consecutive fine rows reach the aggregates rooted within four mesh lines of theirs, and
+// with the aggregates numbered in root order every mesh line contributes ONE short run of consecutive columns -- up to
+// nine or ten runs of about ten, far apart.  Three runs of 72 never cover that; ten runs of 24 do, and 240 positions
+// still fit one byte: 5 instead of 8 bytes per non-zero and no scattered loads for the largest product of the cycle.
+constexpr int kXwRunsWide = 10;
+constexpr int kXwRunWide = 24;
+constexpr int kXwDescWide = 12;         // ints per tile: ten run starts, one spare, the flag
 constexpr int kEpl = 8;                 // elements per lane per pass
 constexpr int kWaveChunk = 64 * kEpl;   // non-zeros parked in LDS per wave per pass (4 KiB)
 
@@ -208,6 +216,33 @@ __device__ __forceinline__ void stage_windows(const XT *__restrict__ x, const in
     }
 }
 
+// the same for the wide plan: lane k < 10 holds the start of run k (`mine`), a piece asks its run's start by shuffle
+template <typename XT>
+__device__ __forceinline__ void stage_windows_wide(const XT *__restrict__ x, const int n_cols, const int mine, XT *xs, const int lane) {
+    constexpr int PER = 16 / (int)sizeof(XT), PPR = kXwRunWide / PER, NP = kXwRunsWide * PPR;
+    static_assert(kXwRunWide % PER == 0, "runs are whole 16-byte pieces");
+    struct alignas(sizeof(XT)) PieceG { XT v[PER]; };
+    struct alignas(16) PieceL { XT v[PER]; };
+#pragma unroll
+    for (int c0 = 0; c0 < NP; c0 += 64) {
+        const int c = c0 + lane;
+        const int q = min(c / PPR, kXwRunsWide - 1), i = c - q * PPR;
+        const int g0 = __shfl(mine, q, 64) + PER * i;       // (every lane takes part in the shuffle)
+        if (c < NP) {
+            PieceL pl;
+            if (g0 + PER - 1 < n_cols) {
+                const PieceG pg = *reinterpret_cast<const PieceG *>(x + g0);
+#pragma unroll
+                for (int t = 0; t < PER; ++t) pl.v[t] = pg.v[t];
+            } else {
+#pragma unroll
+                for (int t = 0; t < PER; ++t) pl.v[t] = (g0 + t < n_cols) ? x[g0 + t] : (XT)0;
+            }
+            *reinterpret_cast<PieceL *>(xs + q * kXwRunWide + PER * i) = pl;
+        }
+    }
+}
+
 // Epilogues (acc = (A x)[row]):
 //   SPMV_PLAIN   y = acc
 //   SPMV_DOT     y = acc ; partial sums of dot_with[row] * acc
@@ -225,7 +260,7 @@ __device__ __forceinline__ void stage_windows(const XT *__restrict__ x, const in
 // copies of its operators: 8 instead of 12 bytes per non-zero, half the vector traffic), and its last stage
 // <float, float, double> hands z back to CG in double, multiplied by sqrt(*out_scale2) (the cycle works on
 // r / ||b||, see amg.hip) and with the r.z partials taken against the double residual `dot_with`.
-template <int MODE, typename VT, typename XT, typename YT, bool LIST = false, bool LONG = false>
+template <int MODE, typename VT, typename XT, typename YT, bool LIST = false, bool LONG = false, bool WIDE = false>
 __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
     const int n_rows, const int n_cols, const int n_wtiles, const int *__restrict__ rowptr,
     const int *__restrict__ cols, const VT *__restrict__ vals,
@@ -254,7 +289,7 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     XT *prod = prod_all + w * 64 * kEplGather;
-    XT *xs = xs_all + w * kXwRuns * xw_run;
+    XT *xs = xs_all + w * (WIDE ? kXwRunsWide * kXwRunWide : kXwRuns * xw_run);
     double out_mul = 1.0;
     if (out_scale2 != nullptr) {
         const double s2 = *out_scale2;
@@ -284,12 +319,22 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
             rs = rowptr[r];
             re = rowptr[r + 1];
         }
-        if (xw_desc != nullptr) d = xw_desc[wt];
+        int wide_mine = 0;                                  // WIDE: lane k holds int k of the tile's descriptor
+        if (WIDE) {
+            if (lane < kXwDescWide) wide_mine = reinterpret_cast<const int *>(xw_desc)[(size_t)wt * kXwDescWide + lane];
+            d.w = __shfl(wide_mine, kXwDescWide - 1, 64);
+        } else if (xw_desc != nullptr) {
+            d = xw_desc[wt];
+        }
         const int k0 = __shfl(rs, 0, 64);
         const int k1 = __shfl(re, row1 - row0 - 1, 64);
         XT acc = 0;
         const bool windowed = xw_desc != nullptr && d.w != 0;      // wave-uniform
-        if (windowed) {
+        if (WIDE && windowed) {
+            stage_windows_wide<XT>(x, n_cols, wide_mine, xs, lane);
+            acc = xw_stream_tile<4, unsigned char, VT, XT>(vals, (const unsigned char *)xw_lidx, xs, prod, k0, k1, rs, re, lane,
+                                                           kXwRunsWide * kXwRunWide - 1);
+        } else if (windowed) {
             // the tile's runs of x (stage_windows; the stream loops wait for these LDS stores before their first read)
             if (xw_run <= kXwRunShort) stage_windows<kXwRunShort, XT>(x, n_cols, d, xs, lane);
             else stage_windows<kXwRunLong, XT>(x, n_cols, d, xs, lane);
@@ -420,7 +465,8 @@ int spmv_grid(const padne_csr *m) {
     long long g = n_tiles < kMaxPartials ? n_tiles : kMaxPartials;
     // with the x windows a double-precision workgroup holds 23 KiB of LDS: six fit on a CU, so the persistent
     // sweep uses 6 x 256 workgroups (a seventh and eighth would run as a second wave of work)
-    if (m->xw_state == 1 && g > (m->xw_run > kXwRunShort ? 1280 : 1536)) g = m->xw_run > kXwRunShort ? 1280 : 1536;
+    // (the wide plan of a single-precision operator stages under 4 KiB per workgroup: the full grid)
+    if (m->xw_state == 1 && m->xw_nruns == kXwRuns && g > (m->xw_run > kXwRunShort ? 1280 : 1536)) g = m->xw_run > kXwRunShort ? 1280 : 1536;
     if (g >= kNumXcd) g -= g % kNumXcd;
     if (g < 1) g = 1;
     return (int)g;
@@ -494,7 +540,8 @@ static int launch_spmv_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals,
         PADNE_HIP_CHECK(hipGetLastError());
         return PADNE_OK;
     }
-    const size_t xs_bytes = m->xw_state == 1 ? sizeof(XT) * 4 * kXwRuns * (size_t)m->xw_run : 0;
+    const bool wide = m->xw_state == 1 && m->xw_nruns == kXwRunsWide;
+    const size_t xs_bytes = m->xw_state == 1 ? sizeof(XT) * 4 * (wide ? (size_t)kXwRunsWide * kXwRunWide : kXwRuns * (size_t)m->xw_run) : 0;
     const int4 *xw_desc = m->xw_state == 1 ? m->xw_desc : nullptr;
     const void *xw_lidx = m->xw_state == 1 ? (const void *)m->xw_lidx : nullptr;
 #define PADNE_SPMV_ARGS                                                                                          \
@@ -532,6 +579,14 @@ static int launch_spmv_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals,
             case SPMV_JACOBI: PADNE_SPMV_LAUNCH_LONG(SPMV_JACOBI); break;
             default: PADNE_SPMV_LAUNCH_LONG(SPMV_RESTRICT); break;
         }
+        PADNE_HIP_CHECK(hipGetLastError());
+        return PADNE_OK;
+    }
+    if (wide) {
+        // the wide plan exists for the fused up-leg product only (single-precision values, csr_build_xw_plan_wide)
+        PADNE_REQUIRE(mode == SPMV_WUP && sizeof(VT) == 4 && sizeof(XT) == 4, "the wide x-window plan serves the W product");
+        hipLaunchKernelGGL((csr_spmv_kernel<SPMV_WUP, VT, XT, YT, false, false, true>), dim3(g), dim3(kSpmvThreads), xs_bytes,
+                           ctx->stream, PADNE_SPMV_ARGS);
         PADNE_HIP_CHECK(hipGetLastError());
         return PADNE_OK;
     }
@@ -769,6 +824,116 @@ int csr_build_xw_plan(padne_ctx *ctx, padne_csr *m) {
         return PADNE_OK;
     }
     m->xw_run = run;
+    m->xw_desc = desc;
+    m->xw_lidx = lidx;
+    m->xw_state = 1;
+    return PADNE_OK;
+}
+
+// The wide plan: greedy cover of a tile's columns by up to ten runs of 24; every tile decides for itself (no count comes
+// back to the host: the plan is built on the second stream beside the Galerkin product, a look at the host there would
+// hold the main chain up), tiles that need more runs -- the two mesh lines a tile at a line's end touches -- keep the
+// gather path inside the same launch.
+__global__ __launch_bounds__(256) void xw_plan_wide_kernel(int n_rows, int n_wtiles, const int *__restrict__ rowptr,
+                                                           const int *__restrict__ cols, int *__restrict__ desc,
+                                                           unsigned char *__restrict__ lidx) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long W = (long long)gridDim.x * 4, gw = (long long)blockIdx.x * 4 + w;
+    for (long long wt = gw; wt < n_wtiles; wt += W) {
+        const int row0 = (int)wt * 64;
+        const int row1 = min(row0 + 64, n_rows);
+        const int k0 = rowptr[row0], k1 = rowptr[row1];
+        constexpr int kReg = 8;
+        const bool in_regs = k1 - k0 <= 64 * kReg;      // wave-uniform
+        int creg[kReg];
+#pragma unroll
+        for (int j = 0; j < kReg; ++j) {
+            const int e = k0 + lane + 64 * j;
+            creg[j] = (in_regs && e < k1) ? cols[e] : 0x7fffffff;
+        }
+        int start[kXwRunsWide];
+        int bound = -1;
+        bool fits = true;
+#pragma unroll
+        for (int q = 0; q <= kXwRunsWide; ++q) {
+            int mn = 0x7fffffff;
+            if (in_regs) {
+#pragma unroll
+                for (int j = 0; j < kReg; ++j)
+                    if (creg[j] > bound && creg[j] < mn) mn = creg[j];
+            } else {
+                for (int e = k0 + lane; e < k1; e += 64) {
+                    const int c = cols[e];
+                    if (c > bound && c < mn) mn = c;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mn = min(mn, __shfl_xor(mn, off, 64));
+            if (q == kXwRunsWide) {
+                fits = mn == 0x7fffffff;
+            } else {
+                start[q] = mn == 0x7fffffff ? (q > 0 ? start[q - 1] : 0) : mn;
+                if (mn != 0x7fffffff) bound = mn + kXwRunWide - 1;
+            }
+        }
+        if (fits) {
+            if (in_regs) {
+#pragma unroll
+                for (int j = 0; j < kReg; ++j) {
+                    const int e = k0 + lane + 64 * j;
+                    if (e < k1) {
+                        const int c = creg[j];
+                        int pos = 0;
+#pragma unroll
+                        for (int q = kXwRunsWide - 1; q >= 0; --q)
+                            if (c >= start[q] && c < start[q] + kXwRunWide) pos = q * kXwRunWide + (c - start[q]);
+                        lidx[e] = (unsigned char)pos;
+                    }
+                }
+            } else {
+                for (int e = k0 + lane; e < k1; e += 64) {
+                    const int c = cols[e];
+                    int pos = 0;
+#pragma unroll
+                    for (int q = kXwRunsWide - 1; q >= 0; --q)
+                        if (c >= start[q] && c < start[q] + kXwRunWide) pos = q * kXwRunWide + (c - start[q]);
+                    lidx[e] = (unsigned char)pos;
+                }
+            }
+        }
+        if (lane < kXwDescWide) {
+            int v = 0;
+#pragma unroll
+            for (int q = 0; q < kXwRunsWide; ++q) v = lane == q ? start[q] : v;
+            if (lane == kXwDescWide - 1) v = fits ? 1 : 0;
+            desc[(size_t)wt * kXwDescWide + lane] = v;
+        }
+    }
+}
+
+int csr_build_xw_plan_wide(padne_ctx *ctx, padne_csr *m) {
+    static_assert(kXwRunsWide * kXwRunWide <= 256, "8-bit positions");
+    if (m->xw_state == 1 || m->n_rows < 65536 || m->vals32 == nullptr || getenv("PADNE_NO_XWINDOW") != nullptr ||
+        getenv("PADNE_NO_XWINDOW_WIDE") != nullptr)
+        return PADNE_OK;
+    padne_ctx *owner = m->owner ? m->owner : ctx;
+    const int n_tiles = (int)((m->n_rows + 63) / 64);
+    int4 *desc = (int4 *)pool_alloc(owner, sizeof(int) * kXwDescWide * (size_t)n_tiles);
+    unsigned short *lidx = (unsigned short *)pool_alloc(owner, (size_t)m->nnz + kPadNnz);      // (bytes: one per entry)
+    if (!desc || !lidx) {
+        pool_free(owner, desc);
+        pool_free(owner, lidx);
+        return PADNE_E_NOMEM;
+    }
+    // (positions of the tiles that keep the gather path, and of the padding, are never read as positions; zeroed so that
+    //  a stray word of a pass's last load is a valid index)
+    PADNE_HIP_CHECK(hipMemsetAsync(lidx, 0, (size_t)m->nnz + kPadNnz, ctx->stream));
+    const unsigned g = (unsigned)std::min<long long>(((long long)n_tiles + 3) / 4, 8192);
+    hipLaunchKernelGGL(xw_plan_wide_kernel, dim3(g), dim3(256), 0, ctx->stream, (int)m->n_rows, n_tiles, m->rowptr, m->cols,
+                       (int *)desc, (unsigned char *)lidx);
+    PADNE_HIP_CHECK(hipGetLastError());
+    m->xw_run = kXwRunWide;
+    m->xw_nruns = kXwRunsWide;
     m->xw_desc = desc;
     m->xw_lidx = lidx;
     m->xw_state = 1;
