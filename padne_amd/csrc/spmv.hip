@@ -932,6 +932,14 @@ int csr_build_xw_plan_wide(padne_ctx *ctx, padne_csr *m) {
     hipLaunchKernelGGL(xw_plan_wide_kernel, dim3(g), dim3(256), 0, ctx->stream, (int)m->n_rows, n_tiles, m->rowptr, m->cols,
                        (int *)desc, (unsigned char *)lidx);
     PADNE_HIP_CHECK(hipGetLastError());
+    if (getenv("PADNE_XW_VERBOSE") != nullptr) {            // (diagnostics only: this look at the host stalls the stream)
+        std::vector<int> h((size_t)n_tiles * kXwDescWide);
+        PADNE_HIP_CHECK(hipMemcpyAsync(h.data(), desc, sizeof(int) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
+        PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        long long ok = 0;
+        for (int t = 0; t < n_tiles; ++t) ok += h[(size_t)t * kXwDescWide + kXwDescWide - 1];
+        fprintf(stderr, "[spmv] wide x-window plan: %lld of %d tiles qualify with %d runs of %d\n", ok, n_tiles, kXwRunsWide, kXwRunWide);
+    }
     m->xw_run = kXwRunWide;
     m->xw_nruns = kXwRunsWide;
     m->xw_desc = desc;
