@@ -864,8 +864,10 @@ __global__ __launch_bounds__(256) void transpose_count(long long nnz, const int 
 
 __global__ __launch_bounds__(256) void transpose_fill(int n_rows, const int *__restrict__ rowptr, const int *__restrict__ cols,
                                                       const double *__restrict__ vals, const int *__restrict__ slot_ptr,
-                                                      int *__restrict__ cursor, long long *__restrict__ key,
+                                                      int *__restrict__ cursor, int *__restrict__ key,
                                                       double *__restrict__ val, const int no_range) {
+    // (key / val: the cols / vals arrays of the transposed matrix -- an entry lands in its row at the place the atomics
+    //  hand out, sort_csr_rows_seg then puts every row in column order: no slots, no unpacking pass)
     // One lane per row; the first four entries of every row together (their columns and values in three loads).  Their
     // places in the columns are handed out like transpose_count counts: inside the workgroup by LDS atomics, and one
     // atomic per column met advances the column's cursor in memory -- an entry at a time every entry waited for its own
@@ -974,14 +976,132 @@ __global__ __launch_bounds__(256) void transpose_fill(int n_rows, const int *__r
 #pragma unroll
     for (int u = 0; u < 4; ++u)
         if (u < ln) {
-            key[sp[u] + at[u]] = (long long)i << 32;      // rows are unique inside a column: the sort makes the order canonical
+            key[sp[u] + at[u]] = i;                       // rows are unique inside a column: the sort makes the order canonical
             val[sp[u] + at[u]] = v[u];
         }
     for (int k = k0 + 4; k < k1; ++k) {                  // (behind every barrier: a lane may leave the others here)
         const int cc = cols[k];
         const int s = slot_ptr[cc] + atomicAdd(&cursor[cc], 1);
-        key[s] = (long long)i << 32;
+        key[s] = i;
         val[s] = vals[k];
+    }
+}
+
+// The rows of a freshly transposed matrix into column order, in place.  A wave takes kSegRows consecutive rows at a time:
+// their entries are ONE contiguous range of cols / vals, loaded lane-consecutively into LDS (one round trip for ~140
+// entries of a transposed prolongator, every lane busy), every ENTRY then counts the smaller columns of its own row --
+// rows of a transpose hold no column twice -- and goes back to memory at row start + rank.  (The slot-based predecessor
+// sorted one row at a time, 17 of 64 lanes at work and two memory round trips per row: 0.8 + 0.4 ms for the 1.4 M rows of
+// config C4's first restriction, then 0.4 ms to unpack the slots; the main stream waited 0.4-0.5 ms per level for it.)
+// Rows of more than kSegCap entries are listed for sort_listed_csr_rows (a workgroup each).
+constexpr int kSegRows = 8, kSegCap = 64;
+__global__ __launch_bounds__(256) void sort_csr_rows_seg(const int n_rows, const int *__restrict__ rowptr, int *__restrict__ cols,
+                                                         double *__restrict__ vals, int *__restrict__ n_long,
+                                                         int *__restrict__ long_list) {
+    __shared__ int Cs[4][kSegRows * kSegCap];
+    __shared__ double Vs[4][kSegRows * kSegCap];
+    __shared__ int Rs[4][kSegRows + 1];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long n_chunks = ((long long)n_rows + kSegRows - 1) / kSegRows;
+    const XcdSweep sw = xcd_sweep(n_chunks, 4, w);
+    for (long long ch = sw.t0; ch < sw.t1; ch += sw.stride) {
+        const int r0 = (int)(ch * kSegRows);
+        int rp = 0;
+        if (lane <= kSegRows) rp = rowptr[min(r0 + lane, n_rows)];
+        // a chunk with a row beyond the LDS capacity (rare: aggregates next to a via ring, hubs) is listed as a whole --
+        // its entries need not fit the wave's window then -- and sorted row by row by sort_listed_csr_rows
+        const int len = __shfl_down(rp, 1, 64) - rp;
+        const bool is_row = lane < kSegRows && r0 + lane < n_rows;
+        if (__ballot(is_row && len > kSegCap) != 0ull) {       // (wave-uniform)
+            const unsigned long long rows = __ballot(is_row);
+            int base = 0;
+            if (lane == 0) base = atomicAdd(n_long, __popcll(rows));
+            base = __shfl(base, 0, 64);
+            if (is_row) long_list[base + lane] = r0 + lane;
+            continue;
+        }
+        if (lane <= kSegRows) Rs[w][lane] = rp;
+        const int e0 = __shfl(rp, 0, 64), e1 = __shfl(rp, kSegRows, 64);
+        // (LDS position of an entry: its row's slot of kSegCap places + its place in the row)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        int my_row[ (kSegRows * kSegCap) / 64 ], my_pos[ (kSegRows * kSegCap) / 64 ];
+#pragma unroll
+        for (int j = 0; j < (kSegRows * kSegCap) / 64; ++j) {
+            const int e = e0 + lane + 64 * j;
+            my_row[j] = -1;
+            my_pos[j] = 0;
+            if (e < e1) {
+                int q = 0;                                   // the entry's row: the last of the chunk's rows that starts at or before e
+#pragma unroll
+                for (int t = 1; t < kSegRows; ++t) q += (Rs[w][t] <= e) ? 1 : 0;
+                const int rs = Rs[w][q];
+                my_row[j] = q;
+                my_pos[j] = e - rs;
+                Cs[w][q * kSegCap + (e - rs)] = cols[e];
+                Vs[w][q * kSegCap + (e - rs)] = vals[e];
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // every entry of the chunk is in LDS before one goes back
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < (kSegRows * kSegCap) / 64; ++j) {
+            const int q = my_row[j];
+            if (q >= 0) {
+                const int rs = Rs[w][q], rl = Rs[w][q + 1] - rs;
+                const int c = Cs[w][q * kSegCap + my_pos[j]];
+                int rank = 0;
+                for (int f = 0; f < rl; ++f) rank += Cs[w][q * kSegCap + f] < c ? 1 : 0;
+                cols[rs + rank] = c;
+                vals[rs + rank] = Vs[w][q * kSegCap + my_pos[j]];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // LDS is rewritten by the next chunk
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// the listed rows (more than kSegCap entries: aggregates next to a via ring, hubs), a workgroup each: rank sort in LDS up to
+// kListCap entries; what exceeds even that is sorted by one thread's insertion sort in memory (a handful of rows at most)
+constexpr int kListCap = 2048;
+__global__ __launch_bounds__(256) void sort_listed_csr_rows(const int *__restrict__ n_list, const int *__restrict__ row_list,
+                                                            const int *__restrict__ rowptr, int *__restrict__ cols,
+                                                            double *__restrict__ vals) {
+    __shared__ int Cs[kListCap];
+    __shared__ double Vs[kListCap];
+    const int cnt = *n_list;
+    for (int j = blockIdx.x; j < cnt; j += gridDim.x) {
+        const int r = row_list[j];
+        const int s0 = rowptr[r], n = rowptr[r + 1] - s0;
+        if (n > kListCap) {
+            if (threadIdx.x == 0) {
+                for (int a = 1; a < n; ++a) {
+                    const int c = cols[s0 + a];
+                    const double v = vals[s0 + a];
+                    int b = a - 1;
+                    for (; b >= 0 && cols[s0 + b] > c; --b) {
+                        cols[s0 + b + 1] = cols[s0 + b];
+                        vals[s0 + b + 1] = vals[s0 + b];
+                    }
+                    cols[s0 + b + 1] = c;
+                    vals[s0 + b + 1] = v;
+                }
+            }
+            continue;                                  // (uniform over the workgroup)
+        }
+        for (int e = threadIdx.x; e < n; e += 256) {
+            Cs[e] = cols[s0 + e];
+            Vs[e] = vals[s0 + e];
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < n; e += 256) {
+            const int c = Cs[e];
+            int rank = 0;
+            for (int f = 0; f < n; ++f) rank += Cs[f] < c ? 1 : 0;
+            cols[s0 + rank] = c;
+            vals[s0 + rank] = Vs[e];
+        }
+        __syncthreads();
     }
 }
 
@@ -2415,31 +2535,48 @@ static int build_prolongator(padne_ctx *ctx, const padne_csr *A, const int *agg,
 
 // No host synchronisation (the number of entries is known): may be queued on the context's second stream.
 static int transpose(padne_ctx *ctx, const padne_csr *M, padne_csr **T) {
+    // count the entries per column, scan the counts into the row pointer of the transpose, place every entry in its row
+    // (transpose_fill: LDS counting, one atomic per column and workgroup), sort the rows in place -- straight into the CSR
+    // arrays of the result, nothing of it needs the host
     hipStream_t s = ctx->stream;
     Scratch sc(ctx);
     const long long nc = M->n_cols;
-    int *cnt = nullptr, *slot_ptr = nullptr, *row_len = nullptr;
-    long long *key = nullptr;
-    double *val = nullptr;
-    PADNE_TRY(sc.alloc(&cnt, (size_t)nc + 1));
-    PADNE_TRY(sc.alloc(&slot_ptr, (size_t)nc + 1));
-    PADNE_TRY(sc.alloc(&row_len, (size_t)nc + 1));
-    PADNE_TRY(sc.alloc(&key, (size_t)M->nnz));
-    PADNE_TRY(sc.alloc(&val, (size_t)M->nnz));
+    PADNE_REQUIRE(M->n_rows < 2147483647LL && nc < 2147483647LL, "transpose of a matrix beyond 32-bit indices");
+    int *cnt = nullptr, *long_list = nullptr;
+    PADNE_TRY(sc.alloc(&cnt, (size_t)nc + 2));
+    PADNE_TRY(sc.alloc(&long_list, (size_t)nc + 1));
+    padne_csr *m = nullptr;
+    PADNE_TRY(csr_alloc(ctx, nc, M->n_rows, M->nnz, &m));
     const int no_range = getenv("PADNE_TRANSPOSE_HASH") != nullptr ? 1 : 0;
-    PADNE_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)(nc + 1), s));
-    if (M->nnz > 0) hipLaunchKernelGGL(transpose_count, dim3(nblk(M->nnz, 256 * kTcPer)), dim3(256), 0, s, (long long)M->nnz, M->cols, cnt, no_range);
-    PADNE_HIP_CHECK(hipGetLastError());
-    PADNE_TRY(exclusive_scan_i32_async(ctx, cnt, slot_ptr, nc));
-    PADNE_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)(nc + 1), s));
-    if (M->n_rows > 0)
-        hipLaunchKernelGGL(transpose_fill, dim3(nblk(M->n_rows)), dim3(256), 0, s, (int)M->n_rows, M->rowptr, M->cols,
-                           M->vals, slot_ptr, cnt, key, val, no_range);
-    PADNE_HIP_CHECK(hipGetLastError());
-    PADNE_TRY(sort_slots_exact(ctx, nc, slot_ptr, key, val, row_len));
-    // a transpose has no duplicates: the counted slots are exact and, once sorted, already the CSR rows
+    hipError_t e = hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)(nc + 2), s);
+    if (e == hipSuccess && M->nnz > 0)
+        hipLaunchKernelGGL(transpose_count, dim3(nblk(M->nnz, 256 * kTcPer)), dim3(256), 0, s, (long long)M->nnz, M->cols, cnt, no_range);
+    int rc = e == hipSuccess ? exclusive_scan_i32_async(ctx, cnt, m->rowptr, nc) : PADNE_E_HIP;
+    if (rc == PADNE_OK) e = hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)(nc + 2), s);
+    int *n_long = cnt + nc + 1;                                        // (behind the cursors, zeroed with them)
+    if (rc == PADNE_OK && e == hipSuccess && M->n_rows > 0) {
+        hipLaunchKernelGGL(transpose_fill, dim3(nblk(M->n_rows)), dim3(256), 0, s, (int)M->n_rows, M->rowptr, M->cols, M->vals,
+                           (const int *)m->rowptr, cnt, m->cols, m->vals, no_range);
+        const long long n_chunks = (nc + kSegRows - 1) / kSegRows;
+        unsigned g = (unsigned)std::min<long long>((n_chunks + 3) / 4, 8192);
+        if (g >= (unsigned)kNumXcd) g -= g % kNumXcd;
+        hipLaunchKernelGGL(sort_csr_rows_seg, dim3(g > 0 ? g : 1), dim3(256), 0, s, (int)nc, (const int *)m->rowptr, m->cols, m->vals,
+                           n_long, long_list);
+        hipLaunchKernelGGL(sort_listed_csr_rows, dim3(256), dim3(256), 0, s, (const int *)n_long, (const int *)long_list,
+                           (const int *)m->rowptr, m->cols, m->vals);
+        e = hipGetLastError();
+    }
+    if (rc == PADNE_OK && e != hipSuccess) {
+        set_error("transpose failed: %s", hipGetErrorString(e));
+        rc = PADNE_E_HIP;
+    }
+    if (rc != PADNE_OK) {
+        padne_csr_destroy(m);
+        return rc;
+    }
     // (the scratch arrays go back to the pool without a synchronisation: reuse is ordered on the context's stream)
-    return csr_from_exact_slots(ctx, nc, M->n_rows, M->nnz, slot_ptr, key, val, T);
+    *T = m;
+    return PADNE_OK;
 }
 
 // rows of a product left in their merge slots (row i = [begin[i], end[i]) of key / val), owned by this object

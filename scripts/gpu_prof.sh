@@ -10,4 +10,4 @@ python scripts/prof_iteration.py $DB iteration > gpurun_out/${TAG}_iteration.txt
 python scripts/prof_iteration.py $DB setup > gpurun_out/${TAG}_setup.txt
 head -60 gpurun_out/${TAG}_summary.txt
 grep '^{' gpurun_out/${TAG}_bench.log | cut -c1-200
-rm -f gpurun_out/prof_${TAG}/*.db
+python scripts/prof_streams.py $DB > gpurun_out/${TAG}_streams.txt 2>&1; rm -f gpurun_out/prof_${TAG}/*.db
