@@ -22,5 +22,12 @@ for q, v in per.items():
     gaps = sorted(((v[i + 1][0] - v[i][1]) / 1e3, v[i][2].replace("padne::", "").split("(")[0][:40], v[i + 1][2].replace("padne::", "").split("(")[0][:40]) for i in range(len(v) - 1))
     print(f"stream {q}: {len(v)} kernels, busy {busy / 1e3:.1f} us, first {(v[0][0] - t0) / 1e3:.1f} us, last end {(v[-1][1] - t0) / 1e3:.1f} us, idle inside {((v[-1][1] - v[0][0]) - busy) / 1e3:.1f} us")
     print("   largest gaps:", [(round(gp, 1), x, y) for gp, x, y in gaps[-12:]])
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for st_, en, nm in v:
+        k2 = nm.replace("padne::", "").replace("void ", "").split("(")[0][:52]
+        agg[k2][0] += 1; agg[k2][1] += (en - st_) / 1e3
+    print("   kernels by time:")
+    for k2, (cnt, tt) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
+        print(f"      {k2:54s} n={cnt:4d} {tt:9.1f} us")
     hist = collections.Counter(int(gp // 5) * 5 for gp, _, _ in gaps if gp > 0)
     print("   gap histogram (us bucket: count):", sorted(hist.items())[:14])
