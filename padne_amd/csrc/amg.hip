@@ -1831,10 +1831,32 @@ __device__ __forceinline__ double Rsel(const double (&R)[kGjBlock], int a) {
     for (int b = 0; b < kGjBlock; ++b) v = (a == b) ? R[b] : v;
     return v;
 }
+// The 16 x 16 pivot block, inverted in place by ONE wave: entry (a, b) sits in lane (a & 3) << 4 | b, register a >> 2, and
+// travels between the lanes by shuffles (per pivot one look at the pivot, one at the pivot row, four at the pivot column).
+// The arithmetic of gj_block_step's inversion, entry for entry.
+__device__ __forceinline__ void gj_invert_block16(double (&dd)[4], const int lane) {
+    const int eb = lane & 15, ea0 = lane >> 4;
+#pragma unroll
+    for (int p = 0; p < kGjBlock; ++p) {
+        const double dpp = __shfl(dd[p >> 2], ((p & 3) << 4) | p, 64);
+        const double drow = __shfl(dd[p >> 2], ((p & 3) << 4) | eb, 64);
+        double dcol[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dcol[q] = __shfl(dd[q], (lane & 48) | p, 64);
+        const double inv = 1.0 / dpp;
+        const double rp = drow * inv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ea = ea0 + 4 * q;
+            const double cp = dcol[q];
+            dd[q] = (ea == p) ? (eb == p ? inv : rp) : (eb == p ? -cp * inv : dd[q] - cp * rp);
+        }
+    }
+}
+
 template <bool kFull>      // kFull: all 16 pivots exist (every launch but possibly the last)
 __global__ __launch_bounds__(256) void gj_block_step(int n, int k0, const double *__restrict__ in, double *__restrict__ out) {
     static_assert(kGjBlock == 16, "the pivot block inversion below maps a 16 x 16 block onto one wave");
-    __shared__ double Dsh[kGjBlock][kGjBlock + 1];
     __shared__ __attribute__((aligned(16))) double Dinv[kGjBlock][kGjBlock];      // read as broadcasts: no padding, 16-byte reads
     __shared__ __attribute__((aligned(16))) double Lcol[kGjStrip][kGjBlock];     // W[i, K] of the strip's rows
     const int bs = kFull ? kGjBlock : min(kGjBlock, n - k0);
@@ -1868,22 +1890,7 @@ __global__ __launch_bounds__(256) void gj_block_step(int n, int k0, const double
             const int ea = ea0 + 4 * q;
             dd[q] = (ea < bs && eb < bs) ? in[(size_t)(k0 + ea) * n + k0 + eb] : (ea == eb ? 1.0 : 0.0);
         }
-        for (int p = 0; p < kGjBlock; ++p) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) Dsh[ea0 + 4 * q][eb] = dd[q];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            const double inv = 1.0 / Dsh[p][p];
-            const double rp = Dsh[p][eb] * inv;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int ea = ea0 + 4 * q;
-                const double cp = Dsh[ea][p];
-                dd[q] = (ea == p) ? (eb == p ? inv : rp) : (eb == p ? -cp * inv : dd[q] - cp * rp);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-        }
+        gj_invert_block16(dd, lane);      // (by shuffles: no store / wait / load round trip through LDS per pivot)
 #pragma unroll
         for (int q = 0; q < 4; ++q) Dinv[ea0 + 4 * q][eb] = dd[q];
     }
@@ -1909,6 +1916,166 @@ __global__ __launch_bounds__(256) void gj_block_step(int n, int k0, const double
 #pragma unroll
         for (int b = 0; b < kGjBlock; ++b) v = fma(-Lcol[q][b], R[b], v);
         if (i >= k0 && i < k0 + bs) v = Rsel(R, i - k0);
+        if (i < n) out[(size_t)i * n + c] = v;
+    }
+}
+
+// TWO steps of gj_block_step in one launch (pivot blocks K1 = [k0, k0 + 16) and K2 = [k0 + 16, k0 + 16 + bs2)).  A launch of
+// the one-step kernel moves the whole matrix through the memory system once -- 57 MB at n = 1617, 13 us of its 19.8 at what
+// the Infinity Cache delivers (the L2s keep nothing across a kernel boundary) -- so 101 launches cost 2.0 ms whatever the
+// pivot block's inversion takes (by shuffles instead of LDS round trips: 1.98 -> 1.93 ms).  Here a workgroup applies step
+// 1 to its tile in registers and step 2 right behind it: what step 2 reads of OTHER tiles as they are after step 1 -- the
+// pivot rows K2 in its columns, the pivot columns K2 in its rows, the pivot block D22 -- it computes itself from the old
+// matrix (a rank-16 update of 16 values per thread, of a 32 x 16 and of a 16 x 16 block per workgroup).  Every entry goes
+// through the operations of two consecutive one-step launches in their order: the same bits (tested), half the launches
+// and 0.6 of the traffic.
+__global__ __launch_bounds__(256) void gj_block_step2(int n, int k0, int bs2, const double *__restrict__ in, double *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) double Dinv1[kGjBlock][kGjBlock], Dinv2[kGjBlock][kGjBlock];
+    __shared__ __attribute__((aligned(16))) double D12[kGjBlock][kGjBlock], D21[kGjBlock][kGjBlock], T12[kGjBlock][kGjBlock];
+    __shared__ __attribute__((aligned(16))) double L1col[kGjStrip][kGjBlock], L2col[kGjStrip][kGjBlock];
+    const int t = threadIdx.x;
+    const int r0 = blockIdx.y * kGjStrip;
+    const int c = blockIdx.x * blockDim.x + t;
+    const int k1 = k0 + kGjBlock;                           // first pivot of the second block
+    const bool live = c < n;
+    const bool pc1 = c >= k0 && c < k1, pc2 = c >= k1 && c < k1 + bs2;
+    // everything of the old matrix is asked for up front
+    double P1[kGjBlock], P2[kGjBlock], V[kGjStrip];
+#pragma unroll
+    for (int b = 0; b < kGjBlock; ++b) P1[b] = (live && !pc1) ? in[(size_t)(k0 + b) * n + c] : 0.0;
+#pragma unroll
+    for (int b = 0; b < kGjBlock; ++b) P2[b] = (live && !pc1 && b < bs2) ? in[(size_t)(k1 + b) * n + c] : 0.0;
+#pragma unroll
+    for (int q = 0; q < kGjStrip; ++q) V[q] = (live && r0 + q < n && !pc1) ? in[(size_t)(r0 + q) * n + c] : 0.0;
+    for (int e = t; e < kGjStrip * kGjBlock; e += 256) {
+        const int i = r0 + e / kGjBlock, b = e % kGjBlock;
+        L1col[e / kGjBlock][b] = i < n ? in[(size_t)i * n + k0 + b] : 0.0;
+        L2col[e / kGjBlock][b] = (i < n && b < bs2) ? in[(size_t)i * n + k1 + b] : 0.0;
+    }
+    {
+        const int a = t / kGjBlock, b = t % kGjBlock;       // 256 threads, one entry of each 16 x 16 block
+        D12[a][b] = b < bs2 ? in[(size_t)(k0 + a) * n + k1 + b] : 0.0;
+        D21[a][b] = a < bs2 ? in[(size_t)(k1 + a) * n + k0 + b] : 0.0;
+    }
+    const int lane = t & 63, eb = lane & 15, ea0 = lane >> 4;
+    double dd[4], d22[4] = {0.0, 0.0, 0.0, 0.0};
+    if (t < 64) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ea = ea0 + 4 * q;
+            dd[q] = in[(size_t)(k0 + ea) * n + k0 + eb];
+            d22[q] = (ea < bs2 && eb < bs2) ? in[(size_t)(k1 + ea) * n + k1 + eb] : 0.0;
+        }
+        gj_invert_block16(dd, lane);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Dinv1[ea0 + 4 * q][eb] = dd[q];
+    }
+    __syncthreads();                                        // Dinv1, D12, D21, L1col, L2col
+    if (t < 64) {
+        // T12 = R of step 1 in the columns K2 (= Dinv1 D12), then the pivot block of step 2 as step 1 leaves it
+        // (D22 - D21 T12), inverted
+        double tt[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double sum = 0.0;
+#pragma unroll
+            for (int b = 0; b < kGjBlock; ++b) sum = fma(Dinv1[ea0 + 4 * q][b], D12[b][eb], sum);
+            tt[q] = sum;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) T12[ea0 + 4 * q][eb] = tt[q];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ea = ea0 + 4 * q;
+            double v = d22[q];
+#pragma unroll
+            for (int b = 0; b < kGjBlock; ++b) v = fma(-D21[ea][b], T12[b][eb], v);
+            dd[q] = (ea < bs2 && eb < bs2) ? v : (ea == eb ? 1.0 : 0.0);      // padded with the identity like gj_block_step<false>
+        }
+        gj_invert_block16(dd, lane);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Dinv2[ea0 + 4 * q][eb] = dd[q];
+    }
+    // ---- step 1 on this thread's column
+    double R[kGjBlock];
+    if (pc1) {
+#pragma unroll
+        for (int a = 0; a < kGjBlock; ++a) R[a] = Dinv1[a][c - k0];
+    } else {
+#pragma unroll
+        for (int a = 0; a < kGjBlock; ++a) {
+            double sum = 0.0;
+#pragma unroll
+            for (int b = 0; b < kGjBlock; ++b) sum = fma(Dinv1[a][b], P1[b], sum);
+            R[a] = sum;
+            asm volatile("" : "+v"(R[a]) : : "memory");     // (keeps hipcc from issuing all LDS reads first: see below)
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < kGjStrip; ++q) {
+        const int i = r0 + q;
+        double v = V[q];
+#pragma unroll
+        for (int b = 0; b < kGjBlock; ++b) v = fma(-L1col[q][b], R[b], v);
+        if (i >= k0 && i < k1) v = Rsel(R, i - k0);
+        V[q] = v;
+        // (ties the row's result to a point in the instruction stream: without it hipcc issues all 512 LDS reads of the
+        //  strip first -- a thousand live registers -- and the sums afterwards)
+        asm volatile("" : "+v"(V[q]) : : "memory");
+    }
+    // the pivot rows K2 in this column as step 1 leaves them (their multipliers are D21's rows)
+#pragma unroll
+    for (int b2 = 0; b2 < kGjBlock; ++b2) {
+        double v = P2[b2];
+#pragma unroll
+        for (int a = 0; a < kGjBlock; ++a) v = fma(-D21[b2][a], R[a], v);
+        P2[b2] = (b2 < bs2 && !pc2) ? v : 0.0;
+        asm volatile("" : "+v"(P2[b2]) : : "memory");
+    }
+    __syncthreads();                                        // T12 (wave 0) before L2col is rewritten; Dinv2
+    // the pivot columns K2 in this strip's rows as step 1 leaves them: two entries per thread
+    double l2[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int e = t + 256 * h, q = e / kGjBlock, b = e % kGjBlock, i = r0 + q;
+        double v = L2col[q][b];
+#pragma unroll
+        for (int a = 0; a < kGjBlock; ++a) v = fma(-L1col[q][a], T12[a][b], v);
+        if (i >= k0 && i < k1) v = T12[i - k0][b];
+        l2[h] = (i < n && b < bs2) ? v : 0.0;
+    }
+    __syncthreads();                                        // every thread has read the old L2col
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int e = t + 256 * h;
+        L2col[e / kGjBlock][e % kGjBlock] = l2[h];
+    }
+    __syncthreads();
+    if (!live) return;
+    // ---- step 2
+    if (pc2) {
+#pragma unroll
+        for (int a = 0; a < kGjBlock; ++a) R[a] = Dinv2[a][c - k1];
+    } else {
+#pragma unroll
+        for (int a = 0; a < kGjBlock; ++a) {
+            double sum = 0.0;
+#pragma unroll
+            for (int b = 0; b < kGjBlock; ++b) sum = fma(Dinv2[a][b], P2[b], sum);
+            R[a] = sum;
+            asm volatile("" : "+v"(R[a]) : : "memory");
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < kGjStrip; ++q) {
+        const int i = r0 + q;
+        double v = pc2 ? 0.0 : V[q];
+#pragma unroll
+        for (int b = 0; b < kGjBlock; ++b) v = fma(-L2col[q][b], R[b], v);
+        if (i >= k1 && i < k1 + bs2) v = Rsel(R, i - k1);
+        asm volatile("" : "+v"(v) : : "memory");
         if (i < n) out[(size_t)i * n + c] = v;
     }
 }
@@ -2901,12 +3068,23 @@ static int dense_inverse(padne_ctx *ctx, const padne_csr *A, double **inv_out) {
         hipLaunchKernelGGL(dense_from_csr, dim3(n), dim3(256), 0, s, n, A->rowptr, A->cols, A->vals, W);
         const dim3 ge(nblk(n), (unsigned)((n + kGjStrip - 1) / kGjStrip));
         double *src = W, *dst = W2;
-        for (int k = 0; k < n; k += kGjBlock) {
+        // two pivot blocks per launch while more than one is left (gj_block_step2), the one-step kernel for a single last
+        // block; PADNE_GJ_ONE_STEP=1: one block per launch throughout (the form the fused kernel is tested against)
+        const bool fused = getenv("PADNE_GJ_ONE_STEP") == nullptr;
+        for (int k = 0; k < n;) {
+            const int left = n - k;
             // the last step writes the finished inverse where it stays
-            if (k + kGjBlock <= n)
+            if (fused && left > kGjBlock) {
+                const int bs2 = std::min(kGjBlock, left - kGjBlock);
+                hipLaunchKernelGGL(gj_block_step2, ge, dim3(256), 0, s, n, k, bs2, src, k + kGjBlock + bs2 >= n ? inv : dst);
+                k += kGjBlock + bs2;
+            } else if (left >= kGjBlock) {
                 hipLaunchKernelGGL(gj_block_step<true>, ge, dim3(256), 0, s, n, k, src, k + kGjBlock >= n ? inv : dst);
-            else
+                k += kGjBlock;
+            } else {
                 hipLaunchKernelGGL(gj_block_step<false>, ge, dim3(256), 0, s, n, k, src, inv);
+                k += kGjBlock;
+            }
             std::swap(src, dst);
         }
     }

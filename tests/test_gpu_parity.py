@@ -461,6 +461,46 @@ def test_mailbox_round_trips_change_nothing_but_the_waiting(ctx, monkeypatch):
     assert np.linalg.norm(A @ with_mail.x - b) <= 1e-11 * np.linalg.norm(b)
 
 
+@pytest.mark.parametrize("layers,nx,ny,coarse_n", [(2, 180, 150, None), (2, 180, 150, 200), (8, 240, 200, None), (3, 90, 70, 40)])
+def test_two_pivot_blocks_per_launch_of_the_dense_inverse_are_the_same_bits(ctx, monkeypatch, layers, nx, ny, coarse_n):
+    """The coarsest operator is inverted by a blocked Gauss-Jordan without pivoting: 16 pivots per launch (`gj_block_step`),
+    or 32 -- two steps fused in one launch (`gj_block_step2`: what the second step reads of other tiles as the first leaves
+    it is recomputed from the old matrix).  Every entry goes through the same operations in the same order: the
+    double-precision cycle built on either inverse applies to a random vector with the same bits, for coarsest levels of
+    a handful to ~1100 unknowns (odd and even numbers of pivot blocks, a last block of fewer than 16 pivots)."""
+    monkeypatch.setenv("PADNE_AMG_F64", "1")
+    if coarse_n is not None:
+        monkeypatch.setenv("PADNE_AMG_COARSE_N", str(coarse_n))
+    sysm = synthetic.layered_system(layers, nx, ny, via_lattice=5)
+    els = [("R", int(a), int(b), float(r)) for a, b, r in zip(*sysm.resistors)]
+    els += [("I", int(f), int(t), float(i)) for f, t, i in zip(*sysm.current_sources)]
+    Lo, ro = O.assemble_system([(m[0], m[1], m[2]) for m in sysm.meshes], 0, els, 0)
+    n = sysm.n_vertices
+    A = (-Lo[1:n, 1:n]).tocsr()
+    A.sort_indices()
+    b = -ro[1:n]
+    probe = np.random.default_rng(7).uniform(-1, 1, n - 1)
+
+    def run(c):
+        d = c.csr_from_scipy(A)
+        res = d.solve_spd(b, precond="amg", rtol=1e-12)
+        n_coarse = d.amg_shapes()[-1]["A"][0]
+        z = d.amg_apply(probe)
+        d.close()
+        return res, n_coarse, z
+    two, n_two, z_two = run(ctx)
+    monkeypatch.setenv("PADNE_GJ_ONE_STEP", "1")
+    other = _hip.Context(0)
+    try:
+        one, n_one, z_one = run(other)
+    finally:
+        other.close()
+    assert n_one == n_two and n_one <= 2048, n_one
+    assert one.levels == two.levels and one.iterations == two.iterations
+    assert np.array_equal(z_one, z_two) and np.array_equal(one.x, two.x), f"coarsest level of {n_one} unknowns"
+    assert np.linalg.norm(A @ two.x - b) <= 1e-11 * np.linalg.norm(b)
+
+
 def test_fused_up_leg_of_the_fine_level_is_the_same_cycle(ctx, monkeypatch):
     """Level 0 of the float cycle applies coarse correction, post-smoothing sweep and the exit product of r.z in ONE
     sparse product with W = P - c D^-1 A P (built from the merge slots of A P on the second stream).  Algebraically the
