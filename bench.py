@@ -126,12 +126,15 @@ def full_size_cpu_record():
 
 
 def step_counter_traffic():
-    """HBM-side bytes of one timed step by the hardware counters (profiles/r03_step_traffic.json, written by
-    scripts/pmc_setup_sum.py from separate rocprofv3 --pmc passes of the same command); None if the file is missing."""
-    try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r03_step_traffic.json")))
-    except Exception:
-        return None
+    """HBM-side bytes of one timed step by the hardware counters (profiles/<round>_step_traffic.json, written by
+    scripts/pmc_setup_sum.py from separate rocprofv3 --pmc passes of the same command; the newest round that has one);
+    (None, None) if there is none."""
+    for rd in ("r04", "r03"):
+        try:
+            return json.load(open(os.path.join(ROOT, "profiles", rd + "_step_traffic.json"))), f"profiles/{rd}_step_traffic.json"
+        except Exception:
+            continue
+    return None, None
 
 
 def step_algorithmic_bytes(shapes, iterations: int):
@@ -404,7 +407,7 @@ def main():
                     "iteration_frac": sb["per_iteration"] * int(last.iterations) / max(float(last.seconds), 1e-12) / 1e9 / HBM_PEAK_GBS,
                     "note": "whole timed step (multigrid setup + all CG iterations) by the textbook CSR byte count of "
                             "SURVEY 8d; the entry above is the dominant kernel alone"}
-                step_traffic = step_counter_traffic()
+                step_traffic, step_traffic_file = step_counter_traffic()
                 if step_traffic is not None:
                     # what the implementation really moves (float cycle, one-byte window positions; but also every re-fetch):
                     # counter bytes of one step over the time of one step
@@ -412,8 +415,8 @@ def main():
                         "traffic": step_traffic["step_bytes"], "traffic_setup": step_traffic["setup_bytes"],
                         "traffic_loop": step_traffic["loop_bytes"],
                         "traffic_frac": step_traffic["step_bytes"] / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
-                        "traffic_static_from": "profiles/r03_step_traffic.json (scripts/pmc_setup_sum.py over the --pmc passes of "
-                                               "the round's final build; not collected in this run)"})
+                        "traffic_static_from": step_traffic_file + " (scripts/pmc_setup_sum.py over the --pmc passes of "
+                                               "that round's final build; not collected in this run)"})
             except Exception as exc:
                 out["roofline"]["step"] = {"error": repr(exc)}
         if not distributed_path:

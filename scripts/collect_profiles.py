@@ -2,7 +2,7 @@
 table and the SpMV-by-grid summary from the raw csv files."""
 import csv, glob, json, collections, shutil, os
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RD = os.environ.get("PADNE_ROUND", "r03")        # prefix of the files written under profiles/
+RD = os.environ.get("PADNE_ROUND", "r04")        # prefix of the files written under profiles/
 F = os.path.join(R, "gpurun_out", "final"); P = os.path.join(R, "profiles")
 for src, dst in (("bench_c4_1gpu_amg.json", RD + "_bench_c4_1gpu_amg.json"), ("bench_c4_1gpu_amg.json", RD + "_bench_c4_1gpu.json"),
                  ("bench_c4_1gpu_jacobi.json", RD + "_bench_c4_1gpu_jacobi.json"), ("stats/run_kernel_stats.csv", RD + "_bench_c4_amg_kernel_stats.csv"),
@@ -15,6 +15,15 @@ with open(os.path.join(P, RD + "_assembly_timeline.txt"), "w") as f:
         f.write(f"\n== config {c} ==\n" + open(os.path.join(F, f"asm_{c}_timeline.txt")).read())
     f.write("\n== config C4: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KB, separate passes, mean of four runs; scripts/pmc_asm.sh) ==\n")
     f.write(open(os.path.join(F, "asm_C4_pmc.txt")).read())
+# counter traffic of one assembly (the bench line's assembly.traffic): 2 x FETCH_SIZE + WRITE_SIZE over the assembly kernels
+try:
+    rows_a = [l.split() for l in open(os.path.join(F, "asm_C4_pmc.txt")) if l.startswith(("asm_", "merge_rows"))]
+    tot = sum(2 * float(r[-2]) * 1024 + float(r[-1]) * 1024 for r in rows_a)
+    json.dump({"workload": "C4", "bytes_per_assembly": tot, "kernels": {" ".join(r[:-2]): {"FETCH_SIZE_KB": float(r[-2]), "WRITE_SIZE_KB": float(r[-1])} for r in rows_a},
+               "source": "scripts/pmc_asm.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over scripts/asm_only.py C4, mean of four assemblies; bytes = 2 * FETCH_SIZE + WRITE_SIZE (gfx950)",
+               "algorithmic_bytes": 1239009368}, open(os.path.join(P, RD + "_assembly_traffic.json"), "w"), indent=1)
+except Exception as exc:
+    print("assembly traffic not written:", exc)
 acc = {}
 for C in ("FETCH_SIZE", "WRITE_SIZE"):
     per = collections.defaultdict(list)

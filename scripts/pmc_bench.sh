@@ -27,7 +27,7 @@ dot = names[0]
 cal = [k for k in acc["FETCH_SIZE"] if "pcg_update_p_z_kernel" in k][0]
 f_dot, n_dot = big(dot, "FETCH_SIZE"); w_dot, _ = big(dot, "WRITE_SIZE")
 f_cal, n_cal = big(cal, "FETCH_SIZE"); w_cal, _ = big(cal, "WRITE_SIZE")
-rec = {"kernel": dot, "workload": "C4 (N=10M, nnz=70M)", "round": 3, "launches_averaged": n_dot,
+rec = {"kernel": dot, "workload": "C4 (N=10M, nnz=70M)", "round": 4, "launches_averaged": n_dot,
        "FETCH_SIZE_KB": f_dot, "WRITE_SIZE_KB": w_dot,
        "bytes_per_launch": 2 * f_dot * 1024 + w_dot * 1024,
        "algorithmic_bytes_per_launch": 1039450524,
