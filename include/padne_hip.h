@@ -144,7 +144,10 @@ int padne_csr_to_host(padne_ctx *ctx, const padne_csr *m, int32_t *indptr, int32
  * Returns PADNE_E_NONMANIFOLD where Mesh.from_triangle_soup raises ValueError (mesh.py:342-343).
  * The matrix arrays are allocated for an upper bound of the entries (one per triangle corner, two per vertex, the
  * stamps) and the rows are written once, in place; padne_csr_shape reports the exact count.  PADNE_E_TOOLARGE when
- * that bound exceeds the 32-bit index space of a CSR matrix (about 268 M mesh vertices). */
+ * that bound exceeds the 32-bit index space of a CSR matrix (about 268 M mesh vertices).  The single-pass row kernel
+ * finds its offsets with a scan that runs inside it and whose waits are bounded; on a chip shared with other work such a
+ * wait can run out -- the rows are then built again in two passes (lengths, scan, fill: the same bits, about three times
+ * the time), never an error of the call. */
 int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns,
                           int64_t n_vert, const double *xy_host,
                           int64_t n_tri, const int32_t *tri_host,
@@ -168,7 +171,8 @@ int padne_generate_grid_mesh(padne_ctx *ctx, int64_t nx, int64_t ny, double h, d
  * manifold test (PADNE_E_NONMANIFOLD) is switched off -- the rows of ring vertices are dropped by the caller
  * (padne_csr_relabel); validate the whole mesh on one rank instead.  flags = 0 is padne_assemble_system.
  * With either entry point `xy_host` / `tri_host` may also be DEVICE pointers (e.g. filled by padne_generate_grid_mesh):
- * the two big arrays are then copied device to device and nothing crosses PCIe. */
+ * the kernels then read the caller's arrays, the copy the matrix keeps for padne_csr_power_density is made device to device
+ * on the context's second stream beside them, and nothing crosses PCIe (the arrays must stay valid until the call returns). */
 int padne_assemble_system_ex(padne_ctx *ctx, int64_t n_unknowns, int64_t n_vert, const double *xy_host,
                              int64_t n_tri, const int32_t *tri_host, int64_t n_mesh,
                              const int64_t *mesh_vertex_offset, const int64_t *mesh_tri_offset,
@@ -241,9 +245,9 @@ typedef struct padne_solve_info {
 /* Preconditioned CG on an SPD CSR matrix: replaces scipy.sparse.linalg.spsolve in
  * solve_system (solver.py:773) once the system is reduced.  b, x: host f64[n_rhs][n]
  * (row-major, one right-hand side after another).  With the multigrid preconditioner on one GPU, groups of
- * 8 right-hand sides (and remainders of 5-7, zero-padded) advance in lockstep: one pass over the matrix
- * and the hierarchy per iteration for the whole group; results do not depend on the grouping beyond the
- * tolerance.  PADNE_E_NOTCONVERGED still returns the best iterate in x and the residual reached in info. */
+ * 8 right-hand sides (remainders of 5-7 zero-padded to 8, a remainder of exactly 4 in a group of width 4) advance in
+ * lockstep: one pass over the matrix and the hierarchy per iteration for the whole group; results do not depend on the
+ * grouping beyond the tolerance.  PADNE_E_NOTCONVERGED still returns the best iterate in x and the residual reached in info. */
 int padne_solve_spd(padne_ctx *ctx, const padne_csr *a, const double *b_host, double *x_host,
                     int32_t n_rhs, const padne_solve_opts *opts, padne_solve_info *info);
 /* same with device-resident b and x */

@@ -95,7 +95,6 @@ constexpr int kMaxLevels = 16;
 static double cheb_ratio() { const char *e = getenv("PADNE_AMG_CHEB_RATIO"); return e ? atof(e) : 10.0; }
 #define kChebRatio cheb_ratio()
 static int lanczos_steps() { const char *e = getenv("PADNE_AMG_LANCZOS_STEPS"); const int v = e ? atoi(e) : 8; return v < 2 ? 2 : (v > 60 ? 60 : v); }
-static long long lanczos_min_n() { const char *e = getenv("PADNE_AMG_LANCZOS_MIN_N"); return e ? atoll(e) : 0; }
 static double omega_num() { const char *e = getenv("PADNE_AMG_OMEGA"); return e ? atof(e) : 1.5; }
 static thread_local int t_setup_level = 0;     // level whose operators are being built (strength threshold decays with it)
 static double theta_val() {
@@ -3276,7 +3275,7 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         // cycle runs, so they are queued LATE in the level -- behind the transposes the main stream waits for, and while
         // the main stream is busy with R (A P): the one host thread that launches for both streams then starts the level's
         // aggregation without first spending 30 launches on the other stream (the small levels are launch-bound)
-        const bool lanczos = lvl > 0 && A->n_rows > kCoarseN && A->n_rows >= lanczos_min_n() && getenv("PADNE_AMG_NO_LANCZOS") == nullptr;
+        const bool lanczos = lvl > 0 && A->n_rows > kCoarseN && getenv("PADNE_AMG_NO_LANCZOS") == nullptr;
         auto queue_level_extras = [&]() -> int {
             if (two) PADNE_TRY(stream_order(ctx, aux));
             if (lanczos) {

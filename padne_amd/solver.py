@@ -540,7 +540,14 @@ def solve_system(L, r: np.ndarray, *, rtol: float = RTOL, reorder=None, n_potent
         # gathers miss the caches, so the reduced system is solved in a band numbering by horizontal strips
         # (internal: v comes back unpermuted)
         from .reduction import ordering_is_scattered
-        want_reorder = reorder is True or ordering_is_scattered(L.tri, len(L.xy))
+        if reorder is True:
+            want_reorder = True
+        else:
+            # (a property of the mesh, not of the right-hand side: looked at once per assembled system -- 4 ms of a 34 ms
+            #  call at 20 M triangles otherwise)
+            if getattr(L, "_scattered", None) is None:
+                L._scattered = bool(ordering_is_scattered(L.tri, len(L.xy)))
+            want_reorder = L._scattered
     # the plan -- index map, A = -P^T L P and its multigrid hierarchy on the device -- depends on the STRUCTURE of the
     # reduction only (the values of the sources enter through c and r): kept with the assembled system, so a second
     # right-hand side on the same system finds everything in place, like a second solve with a kept factorisation
