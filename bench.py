@@ -322,6 +322,7 @@ def main():
         standalone = None
         hierarchy_shapes = None
         halo_exchange = ("peer-to-peer stores into hipIpc mailboxes, device-side arrival flags" if dsolver.p2p
+                         else "none (one rank)" if world == 1
                          else "ncclAllGather (the mailboxes could not be shared or did not pass their self-test)")
     t_setup = time.perf_counter() - t_setup0
 
