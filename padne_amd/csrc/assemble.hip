@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256) void asm_fill_listed(const int *__restrict__ n
 // (kScanMaxPolls); a wait that gives up raises the abort word, which ends all other waits and fails the assembly loudly.
 constexpr unsigned long long kScanValueMask = (1ull << 62) - 1ull;
 constexpr unsigned long long kScanKnown = 1ull << 62;
-constexpr int kScanMaxPolls = 1 << 22;
+constexpr int kScanMaxPolls = 1 << 20;      // (about a second of polling: a wait that runs out costs a second pass, not the call)
 constexpr int kChunkTiles = 64;
 __device__ __forceinline__ unsigned long long scan_word_load(const unsigned long long *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

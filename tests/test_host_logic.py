@@ -634,3 +634,27 @@ def test_mesh_from_cgal_output_is_the_array_hand_off():
         _padne_hip_soup = out
         vertices = faces = ()
     assert np.array_equal(mesh.Mesh.from_reference(HalfEdgeMeshWithSoup()).triangles, tri)
+
+
+def test_rank_launcher_starts_ranks_and_reports_exit_codes_and_timeouts(tmp_path):
+    """tests/rank_launcher.py starts the rank processes of the two-process GPU tests from a process that never touches the
+    GPU: every rank gets RANK / WORLD_SIZE / MASTER_PORT, exit codes and output come back per rank, a rank that outlives
+    the time limit is killed (and only the processes started here)."""
+    import importlib.util
+    import os
+    import sys
+    spec = importlib.util.spec_from_file_location("rank_launcher", os.path.join(os.path.dirname(os.path.abspath(__file__)), "rank_launcher.py"))
+    rl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rl)
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys, time\n"
+                      "r = int(os.environ['RANK'])\n"
+                      "print('rank', r, 'of', os.environ['WORLD_SIZE'], 'port', os.environ['MASTER_PORT'], sys.argv[1], flush=True)\n"
+                      "if sys.argv[1] == 'hang' and r == 1: time.sleep(60)\n"
+                      "sys.exit(3 * r)\n")
+    ans = rl.run({"script": str(script), "args": ["go"], "n": 3, "env": {"EXTRA": "1"}, "timeout": 60})
+    assert ans["rc"] == [0, 3, 6] and not ans["timed_out"]
+    assert all(f"rank {r} of 3" in ans["out"][r] for r in range(3))
+    ans = rl.run({"script": str(script), "args": ["hang"], "n": 2, "timeout": 2})
+    assert ans["timed_out"] and ans["rc"][0] == 0 and ans["rc"][1] != 0
+
