@@ -3042,7 +3042,7 @@ static int build_w_operator(padne_ctx *ctx, const padne_csr *A, const padne_csr 
     hipLaunchKernelGGL(w_from_slots_kernel, dim3(nblk(((long long)n + 63) / 64, 4)), dim3(256), 0, s, n, ap.begin, ap.key, ap.val,
                        P->rowptr, P->cols, P->vals, A->dinv, c, (const int *)W->rowptr, W->cols, W->vals32);
     PADNE_HIP_CHECK(hipGetLastError());
-    // its x-window plan: ten short runs per tile (spmv.hip, csr_build_xw_plan_wide), on this stream, no look at the host
+    // its x-window plan: twelve short runs per tile (spmv.hip, csr_build_xw_plan_wide), on this stream, no look at the host
     W->xw_state = 0;
     const int rc_plan = csr_build_xw_plan_wide(ctx, W);
     if (rc_plan != PADNE_OK) {

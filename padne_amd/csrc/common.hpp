@@ -74,8 +74,8 @@ struct padne_csr {
     unsigned short *xw_lidx = nullptr;   // [nnz + pad] position of every column inside its tile's staged runs (bytes when xw_run == 72)
     int xw_state = 0;                    // 0 = not examined, 1 = in use, -1 = examined and not worth it
     int xw_run = 0;                      // entries per staged run (72 for scan-line meshes, 128 for strip-ordered ones)
-    int xw_nruns = 3;                    // staged runs per tile: 3, or 10 short ones of 24 (the wide plan of a fused up-leg operator W,
-                                         // csr_build_xw_plan_wide: xw_desc then holds three int4 per tile -- ten run starts, spare, flag)
+    int xw_nruns = 3;                    // staged runs per tile: 3, or 12 short ones of 20 (the wide plan of a fused up-leg operator W,
+                                         // csr_build_xw_plan_wide: xw_desc then holds four int4 per tile -- twelve run starts, spare, flag)
     // interior / boundary split of a row-partitioned operator (csr_build_split_plan): the 64-row tiles whose columns are all
     // owned, and the tiles that read an exchange slot.  The product of the interior tiles needs no remote value and is
     // launched while the halo exchange is under way; the boundary tiles follow once it has landed.
@@ -175,7 +175,7 @@ int launch_spmv_f32_wup_exit(padne_ctx *ctx, const padne_csr *w, const float *e,
                              const float *dinv32, float scale, const double *out_scale2, float *z32 = nullptr);
 int csr_build_f32(padne_ctx *ctx, padne_csr *m);
 int csr_build_xw_plan(padne_ctx *ctx, padne_csr *m);
-int csr_build_xw_plan_wide(padne_ctx *ctx, padne_csr *m);      // ten runs of 24 (single-precision operators with float values only: W)
+int csr_build_xw_plan_wide(padne_ctx *ctx, padne_csr *m);      // twelve runs of 20 (single-precision operators with float values only: W)
 // interior / boundary tiles of a row-partitioned operator whose first n_owned columns are the rank's own unknowns
 int csr_build_split_plan(padne_ctx *ctx, padne_csr *m, long long n_owned);
 // number of per-workgroup partial sums a product with a dot epilogue on `m` writes (spmv_grid, or the grids of the

@@ -62,14 +62,15 @@ __device__ __forceinline__ double block_sum_256(double v, double *red) {
 constexpr int kXwRuns = 3;              // staged runs of x per tile
 constexpr int kXwRunShort = 72;         // entries per run: 64 rows + the mesh neighbours on both sides (scan-line grids),
 constexpr int kXwRunLong = 128;         // or twice the tile for strip-ordered unstructured meshes
-// The wide plan (csr_build_xw_plan_wide): ten short runs.  The rows of the fused up-leg operator W = P - c D^-1 A P are fine
+// The wide plan (csr_build_xw_plan_wide): twelve short runs.  The rows of the fused up-leg operator W = P - c D^-1 A P are fine
 // rows, its columns aggregates: 64 consecutive fine rows reach the aggregates rooted within four mesh lines of theirs, and
 // with the aggregates numbered in root order every mesh line contributes ONE short run of consecutive columns -- up to
-// nine or ten runs of about ten, far apart.  Three runs of 72 never cover that; ten runs of 24 do, and 240 positions
+// nine or ten runs of about ten, far apart.  Three runs of 72 never cover that; twelve runs of 20 do (ten of 24 covered
+// 91 % of the tiles of config C4, twelve of 20 cover 95 %, fifteen of 16 97 % at the same speed), and 240 positions
 // still fit one byte: 5 instead of 8 bytes per non-zero and no scattered loads for the largest product of the cycle.
-constexpr int kXwRunsWide = 10;
-constexpr int kXwRunWide = 24;
-constexpr int kXwDescWide = 12;         // ints per tile: ten run starts, one spare, the flag
+constexpr int kXwRunsWide = 12;
+constexpr int kXwRunWide = 20;
+constexpr int kXwDescWide = 16;         // ints per tile: twelve run starts, three spare, the flag
 constexpr int kEpl = 8;                 // elements per lane per pass
 constexpr int kWaveChunk = 64 * kEpl;   // non-zeros parked in LDS per wave per pass (4 KiB)
 
@@ -830,7 +831,7 @@ int csr_build_xw_plan(padne_ctx *ctx, padne_csr *m) {
     return PADNE_OK;
 }
 
-// The wide plan: greedy cover of a tile's columns by up to ten runs of 24; every tile decides for itself (no count comes
+// The wide plan: greedy cover of a tile's columns by up to twelve runs of 20; every tile decides for itself (no count comes
 // back to the host: the plan is built on the second stream beside the Galerkin product, a look at the host there would
 // hold the main chain up), tiles that need more runs -- the two mesh lines a tile at a line's end touches -- keep the
 // gather path inside the same launch.
