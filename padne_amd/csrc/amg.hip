@@ -4184,6 +4184,14 @@ static int amg_apply_batch_k(padne_ctx *ctx, const padne_csr *A0, const double *
     }
     for (int l = nl - 2; l >= 0; --l) {
         AmgLevel &L = amg->levels[l];
+        if (l == 0 && L.W != nullptr) {
+            // coarse correction + post-smoothing + exit in one product with W = P - c D^-1 A P, as in the single cycle (tmp8
+            // still holds the residual of the pre-smoothed iterate that the down-leg restricted): 52 M instead of 24 + 70 M
+            // non-zeros of the fine level per lockstep iteration
+            PADNE_TRY(launch_spmm_f32_wup_exit(ctx, L.W, K, amg->levels[1].xb8, z8, r8, partials_rz, done_flag, L.xa8, L.tmp8,
+                                               L.A->dinv32, (float)L.jac, bb2));
+            continue;
+        }
         PADNE_TRY(launch_spmm_f32(ctx, L.P, K, SPMV_ADD, amg->levels[l + 1].xb8, L.xa8, nullptr, done_flag, nullptr, nullptr,
                                   0.f));
         if (l > 0)

@@ -205,6 +205,9 @@ int launch_spmm_f32(padne_ctx *ctx, const padne_csr *m, int k, int mode, const f
 int launch_spmm_f32_exit(padne_ctx *ctx, const padne_csr *m, int k, const float *x, double *y, const double *dot_with,
                          double *partials, const int32_t *done_flag, const float *aux1, const float *aux2,
                          float scale, const double *out_scale2);
+int launch_spmm_f32_wup_exit(padne_ctx *ctx, const padne_csr *w, int k, const float *e, double *z, const double *dot_with,
+                             double *partials, const int32_t *done_flag, const float *x_pre, const float *r_pre,
+                             const float *dinv32, float scale, const double *out_scale2);
 int interleave(padne_ctx *ctx, long long n, int k, const double *src, double *dst, bool to_interleaved);
 
 // exclusive scan of int32 counts into int32 offsets (n+1 outputs); returns total via host

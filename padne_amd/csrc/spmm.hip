@@ -28,12 +28,12 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmm_kernel(
     const VT *__restrict__ vals, const XT *__restrict__ x, YT *__restrict__ y, const double *__restrict__ dot_with,
     double *__restrict__ partials /* [8][kMaxPartials] */, const int *__restrict__ done_flag,
     const XT *__restrict__ aux1, const XT *__restrict__ aux2, const XT scale,
-    const double *__restrict__ out_scale2 /* [K] or null */) {
+    const double *__restrict__ out_scale2 /* [K] or null */, const XT *__restrict__ aux0 /* SPMV_WUP: [n][K] */) {
     static_assert(K == 8 || K == 4 || K == 2, "lockstep widths");
     constexpr int LPR = K / 2;                              // lanes per row (each takes two right-hand sides)
     constexpr int RPG = 64 / LPR;                           // rows per group
     constexpr int NG = LPR;                                 // groups per 64-row tile
-    constexpr bool WITH_DOT = (MODE == SPMV_DOT) || (MODE == SPMV_JACOBI);
+    constexpr bool WITH_DOT = (MODE == SPMV_DOT) || (MODE == SPMV_JACOBI) || (MODE == SPMV_WUP);
     __shared__ int cs_all[4 * kSpmmChunk];
     __shared__ VT vs_all[4 * kSpmmChunk];
     __shared__ double red[4][K];
@@ -144,6 +144,16 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmm_kernel(
                 const Y2 old = *reinterpret_cast<const Y2 *>(y + o);
                 out2.a = old.a + (YT)a0;
                 out2.b = old.b + (YT)a1;
+            } else if (MODE == SPMV_WUP) {
+                // exit stage of the cycle in the W form (spmv.hip): z = x_pre + c D^-1 r_pre + W e, r.z partials
+                const X2 xp = *reinterpret_cast<const X2 *>(aux0 + o), rp = *reinterpret_cast<const X2 *>(aux1 + o);
+                const XT d = scale * aux2[r];
+                const XT o0 = xp.a + d * rp.a + a0, o1 = xp.b + d * rp.b + a1;
+                const double d0 = (double)o0 * out_mul0, d1 = (double)o1 * out_mul1;
+                out2.a = (YT)d0;
+                out2.b = (YT)d1;
+                dot0 += dot_with[o] * d0;
+                dot1 += dot_with[o + 1] * d1;
             } else {
                 const X2 b = *reinterpret_cast<const X2 *>(aux1 + o);
                 const X2 xo = *reinterpret_cast<const X2 *>(x + o);
@@ -186,7 +196,7 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmm_kernel(
 template <int K, typename VT, typename XT, typename YT>
 static int launch_spmm_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals, int mode, const XT *x, YT *y,
                              const double *dot_with, double *partials, const int32_t *done_flag, const XT *aux1,
-                             const XT *aux2, XT scale, const double *out_scale2) {
+                             const XT *aux2, XT scale, const double *out_scale2, const XT *aux0 = nullptr) {
     if (m->n_rows == 0) return PADNE_OK;
     const int n_tiles = (int)((m->n_rows + 63) / 64);
     long long g = (m->n_rows + kSpmvRows - 1) / kSpmvRows;
@@ -196,13 +206,14 @@ static int launch_spmm_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals,
 #define PADNE_SPMM_LAUNCH(M)                                                                                      \
     hipLaunchKernelGGL((csr_spmm_kernel<K, M, VT, XT, YT>), dim3((unsigned)g), dim3(kSpmvThreads), 0, ctx->stream, \
                        (int)m->n_rows, n_tiles, m->rowptr, m->cols, vals, x, y, dot_with, partials, done_flag,     \
-                       aux1, aux2, scale, out_scale2)
+                       aux1, aux2, scale, out_scale2, aux0)
     switch (mode) {
         case SPMV_PLAIN: PADNE_SPMM_LAUNCH(SPMV_PLAIN); break;
         case SPMV_DOT: PADNE_SPMM_LAUNCH(SPMV_DOT); break;
         case SPMV_RESID: PADNE_SPMM_LAUNCH(SPMV_RESID); break;
         case SPMV_ADD: PADNE_SPMM_LAUNCH(SPMV_ADD); break;
         case SPMV_JACOBI: PADNE_SPMM_LAUNCH(SPMV_JACOBI); break;
+        case SPMV_WUP: PADNE_SPMM_LAUNCH(SPMV_WUP); break;
         default: set_error("bad SpMM mode %d", mode); return PADNE_E_INVALID;
     }
 #undef PADNE_SPMM_LAUNCH
@@ -248,6 +259,18 @@ int launch_spmm_f32_exit(padne_ctx *ctx, const padne_csr *m, int k, const float 
                          float scale, const double *out_scale2) {
     PADNE_REQUIRE(m->vals32 != nullptr && dot_with != nullptr, "single-precision exit stage");
 #define ARGS ctx, m, m->vals32, SPMV_JACOBI, x, y, dot_with, partials, done_flag, aux1, aux2, scale, out_scale2
+    PADNE_SPMM_WIDTH(k, (launch_spmm_typed<8, float, float, double>(ARGS)), (launch_spmm_typed<4, float, float, double>(ARGS)),
+                     (launch_spmm_typed<2, float, float, double>(ARGS)))
+#undef ARGS
+}
+
+// last stage of the lockstep cycle in the W form: z = (x_pre + c D^-1 r_pre + W e) * sqrt(out_scale2[j]) in double, with the
+// partial sums of dot_with . z per right-hand side (the lockstep counterpart of launch_spmv_f32_wup_exit)
+int launch_spmm_f32_wup_exit(padne_ctx *ctx, const padne_csr *w, int k, const float *e, double *z, const double *dot_with,
+                             double *partials, const int32_t *done_flag, const float *x_pre, const float *r_pre,
+                             const float *dinv32, float scale, const double *out_scale2) {
+    PADNE_REQUIRE(w->vals32 != nullptr && dot_with != nullptr, "single-precision W stage");
+#define ARGS ctx, w, w->vals32, SPMV_WUP, e, z, dot_with, partials, done_flag, r_pre, dinv32, scale, out_scale2, x_pre
     PADNE_SPMM_WIDTH(k, (launch_spmm_typed<8, float, float, double>(ARGS)), (launch_spmm_typed<4, float, float, double>(ARGS)),
                      (launch_spmm_typed<2, float, float, double>(ARGS)))
 #undef ARGS
