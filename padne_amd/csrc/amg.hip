@@ -28,6 +28,7 @@
 #include "common.hpp"
 
 #include <functional>
+#include <memory>
 
 #include <algorithm>
 #include <chrono>
@@ -3014,8 +3015,11 @@ __global__ __launch_bounds__(256) void w_from_slots_kernel(int n, const int *__r
 
 // No host synchronisation (the arrays are sized by the slot count, an upper bound of the entries): queued on the
 // context's second stream next to the next level's setup; the slots must stay alive until that stream has been joined.
+// grid_cap > 0: the two large kernels use that many workgroups at most -- the W of the inner levels are built while the
+// other stream inverts the coarsest operator, 51 dependent launches of seven workgroups each, and a launch that finds every
+// CU full of this build's waves waits for them (149 instead of 36 us behind the full grid of level 1)
 static int build_w_operator(padne_ctx *ctx, const padne_csr *A, const padne_csr *P, const SlotRows &ap, long long n_slots,
-                            double c, padne_csr **W_out) {
+                            double c, padne_csr **W_out, int grid_cap = 0) {
     hipStream_t s = ctx->stream;
     const int n = (int)A->n_rows;
     Scratch sc(ctx);
@@ -3039,12 +3043,14 @@ static int build_w_operator(padne_ctx *ctx, const padne_csr *A, const padne_csr 
     hipLaunchKernelGGL(slot_row_lengths, dim3(nblk(n)), dim3(256), 0, s, n, ap.begin, ap.end, len);
     PADNE_HIP_CHECK(hipGetLastError());
     PADNE_TRY(exclusive_scan_i32_async(ctx, len, W->rowptr, n));
-    hipLaunchKernelGGL(w_from_slots_kernel, dim3(nblk(((long long)n + 63) / 64, 4)), dim3(256), 0, s, n, ap.begin, ap.key, ap.val,
+    unsigned gw = nblk(((long long)n + 63) / 64, 4);
+    if (grid_cap > 0 && gw > (unsigned)grid_cap) gw = (unsigned)grid_cap;
+    hipLaunchKernelGGL(w_from_slots_kernel, dim3(gw), dim3(256), 0, s, n, ap.begin, ap.key, ap.val,
                        P->rowptr, P->cols, P->vals, A->dinv, c, (const int *)W->rowptr, W->cols, W->vals32);
     PADNE_HIP_CHECK(hipGetLastError());
     // its x-window plan: twelve short runs per tile (spmv.hip, csr_build_xw_plan_wide), on this stream, no look at the host
     W->xw_state = 0;
-    const int rc_plan = csr_build_xw_plan_wide(ctx, W);
+    const int rc_plan = csr_build_xw_plan_wide(ctx, W, grid_cap);
     if (rc_plan != PADNE_OK) {
         padne_csr_destroy(W);
         return rc_plan;
@@ -3253,6 +3259,11 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
     struct Pending { int level; LanczosJob job; };
     std::vector<Pending *> pending;      // Lanczos estimates in flight on the second stream
     SlotRows ap_keep;                    // slots of the fine level's A P while W is built from them on the second stream
+    // slots of A P of the levels below it: their W needs the level's damping, which the Lanczos estimate settles at the
+    // end of the setup -- built there, on the second stream, next to the dense inverse of the coarsest operator
+    struct KeptSlots { int level; SlotRows rows; };
+    std::vector<std::unique_ptr<KeptSlots>> ap_inner;
+    const bool w_inner = getenv("PADNE_AMG_W_FINE_ONLY") == nullptr && getenv("PADNE_AMG_NO_W") == nullptr;
     auto drop_pending = [&]() {
         for (Pending *pj : pending) {
             double unused = 0.0;
@@ -3360,12 +3371,23 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         pt.lap("R*(AP)");
         if (amg_verbose() && rc == PADNE_OK) fprintf(stderr, "[amg]   Ac: n=%lld nnz=%lld\n", (long long)Ac->n_rows, (long long)Ac->nnz);
         if (AP) padne_csr_destroy(AP);
+        auto take_slots = [](SlotRows &to, SlotRows &from) {
+            std::swap(to.ctx, from.ctx);
+            std::swap(to.begin, from.begin);
+            std::swap(to.end, from.end);
+            std::swap(to.key, from.key);
+            std::swap(to.val, from.val);
+            to.n_rows = from.n_rows;
+            to.n_cols = from.n_cols;
+            to.n_slots = from.n_slots;
+            to.valid = from.valid;
+        };
         if (with_w) {                       // the second stream may still be reading the slots: they go when it has been joined
-            std::swap(ap_keep.ctx, ap_rows.ctx);
-            std::swap(ap_keep.begin, ap_rows.begin);
-            std::swap(ap_keep.end, ap_rows.end);
-            std::swap(ap_keep.key, ap_rows.key);
-            std::swap(ap_keep.val, ap_rows.val);
+            take_slots(ap_keep, ap_rows);
+        } else if (lvl > 0 && rc == PADNE_OK && want_f32 && w_inner && ap_rows.valid) {
+            ap_inner.emplace_back(new KeptSlots());
+            ap_inner.back()->level = lvl;
+            take_slots(ap_inner.back()->rows, ap_rows);
         }
         ap_rows.release();
         amg->levels.push_back(L);
@@ -3409,6 +3431,13 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
     }
     pending.clear();
     for (AmgLevel &L : amg->levels) L.jac = 1.0 / (0.5 * (L.lambda + L.lambda / kChebRatio));
+    // W of the inner levels (the second stream is idle here, the main one is inverting the coarsest operator)
+    for (auto &ks : ap_inner) {
+        if (rc != PADNE_OK) break;
+        AmgLevel &L = amg->levels[(size_t)ks->level];
+        if (L.P == nullptr || L.A->dinv == nullptr) continue;
+        rc = build_w_operator(aux, L.A, L.P, ks->rows, ks->rows.n_slots, L.jac, &L.W, 512);
+    }
     if (rc == PADNE_OK && two) rc = stream_order(aux, ctx);      // the cycle runs on the main stream
     if (rc != PADNE_OK) {
         if (two) (void)hipStreamSynchronize(aux->stream);
@@ -4072,11 +4101,15 @@ static int amg_apply_f32(padne_ctx *ctx, Amg *amg, const double *r, double *z, d
     for (int l = nl - 2; l >= 0; --l) {
         AmgLevel &L = amg->levels[l];
         float *b = (float *)L.b, *xa = (float *)L.xa;
-        if (l == 0 && L.W != nullptr && !amg->dist) {
-            // coarse correction + post-smoothing + exit in one product with W = P - c D^-1 A P (tmp still holds the
+        if (L.W != nullptr && !amg->dist) {
+            // coarse correction + post-smoothing (+ exit) in one product with W = P - c D^-1 A P (tmp still holds the
             // residual of the pre-smoothed iterate that the down-leg restricted)
-            PADNE_TRY(launch_spmv_f32_wup_exit(ctx, L.W, (const float *)amg->levels[1].xb, z, r, partials_rz, done_flag, xa,
-                                               (const float *)L.tmp, L.A->dinv32, (float)L.jac, bb2, z32));
+            if (l == 0)
+                PADNE_TRY(launch_spmv_f32_wup_exit(ctx, L.W, (const float *)amg->levels[1].xb, z, r, partials_rz, done_flag, xa,
+                                                   (const float *)L.tmp, L.A->dinv32, (float)L.jac, bb2, z32));
+            else
+                PADNE_TRY(launch_spmv_f32_wup(ctx, L.W, (const float *)amg->levels[l + 1].xb, (float *)L.xb, done_flag, xa,
+                                              (const float *)L.tmp, L.A->dinv32, (float)L.jac));
             continue;
         }
         PADNE_TRY(launch_spmv_f32(ctx, L.P, SPMV_ADD, (const float *)amg->levels[l + 1].xb, xa, nullptr, done_flag,
@@ -4184,12 +4217,16 @@ static int amg_apply_batch_k(padne_ctx *ctx, const padne_csr *A0, const double *
     }
     for (int l = nl - 2; l >= 0; --l) {
         AmgLevel &L = amg->levels[l];
-        if (l == 0 && L.W != nullptr) {
-            // coarse correction + post-smoothing + exit in one product with W = P - c D^-1 A P, as in the single cycle (tmp8
+        if (L.W != nullptr) {
+            // coarse correction + post-smoothing (+ exit) in one product with W = P - c D^-1 A P, as in the single cycle (tmp8
             // still holds the residual of the pre-smoothed iterate that the down-leg restricted): 52 M instead of 24 + 70 M
             // non-zeros of the fine level per lockstep iteration
-            PADNE_TRY(launch_spmm_f32_wup_exit(ctx, L.W, K, amg->levels[1].xb8, z8, r8, partials_rz, done_flag, L.xa8, L.tmp8,
-                                               L.A->dinv32, (float)L.jac, bb2));
+            if (l == 0)
+                PADNE_TRY(launch_spmm_f32_wup_exit(ctx, L.W, K, amg->levels[1].xb8, z8, r8, partials_rz, done_flag, L.xa8,
+                                                   L.tmp8, L.A->dinv32, (float)L.jac, bb2));
+            else
+                PADNE_TRY(launch_spmm_f32_wup(ctx, L.W, K, amg->levels[l + 1].xb8, L.xb8, done_flag, L.xa8, L.tmp8,
+                                              L.A->dinv32, (float)L.jac));
             continue;
         }
         PADNE_TRY(launch_spmm_f32(ctx, L.P, K, SPMV_ADD, amg->levels[l + 1].xb8, L.xa8, nullptr, done_flag, nullptr, nullptr,

@@ -175,7 +175,7 @@ int launch_spmv_f32_wup_exit(padne_ctx *ctx, const padne_csr *w, const float *e,
                              const float *dinv32, float scale, const double *out_scale2, float *z32 = nullptr);
 int csr_build_f32(padne_ctx *ctx, padne_csr *m);
 int csr_build_xw_plan(padne_ctx *ctx, padne_csr *m);
-int csr_build_xw_plan_wide(padne_ctx *ctx, padne_csr *m);      // twelve runs of 20 (single-precision operators with float values only: W)
+int csr_build_xw_plan_wide(padne_ctx *ctx, padne_csr *m, int grid_cap = 0);      // grid_cap: workgroups at most (a build that runs beside latency-bound work of the other stream)      // twelve runs of 20 (single-precision operators with float values only: W)
 // interior / boundary tiles of a row-partitioned operator whose first n_owned columns are the rank's own unknowns
 int csr_build_split_plan(padne_ctx *ctx, padne_csr *m, long long n_owned);
 // number of per-workgroup partial sums a product with a dot epilogue on `m` writes (spmv_grid, or the grids of the
@@ -208,6 +208,10 @@ int launch_spmm_f32_exit(padne_ctx *ctx, const padne_csr *m, int k, const float 
 int launch_spmm_f32_wup_exit(padne_ctx *ctx, const padne_csr *w, int k, const float *e, double *z, const double *dot_with,
                              double *partials, const int32_t *done_flag, const float *x_pre, const float *r_pre,
                              const float *dinv32, float scale, const double *out_scale2);
+int launch_spmv_f32_wup(padne_ctx *ctx, const padne_csr *w, const float *e, float *x_out, const int32_t *done_flag,
+                        const float *x_pre, const float *r_pre, const float *dinv32, float scale);
+int launch_spmm_f32_wup(padne_ctx *ctx, const padne_csr *w, int k, const float *e, float *x_out, const int32_t *done_flag,
+                        const float *x_pre, const float *r_pre, const float *dinv32, float scale);
 int interleave(padne_ctx *ctx, long long n, int k, const double *src, double *dst, bool to_interleaved);
 
 // exclusive scan of int32 counts into int32 offsets (n+1 outputs); returns total via host

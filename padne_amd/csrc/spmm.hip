@@ -149,11 +149,16 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmm_kernel(
                 const X2 xp = *reinterpret_cast<const X2 *>(aux0 + o), rp = *reinterpret_cast<const X2 *>(aux1 + o);
                 const XT d = scale * aux2[r];
                 const XT o0 = xp.a + d * rp.a + a0, o1 = xp.b + d * rp.b + a1;
-                const double d0 = (double)o0 * out_mul0, d1 = (double)o1 * out_mul1;
-                out2.a = (YT)d0;
-                out2.b = (YT)d1;
-                dot0 += dot_with[o] * d0;
-                dot1 += dot_with[o + 1] * d1;
+                if (dot_with != nullptr) {
+                    const double d0 = (double)o0 * out_mul0, d1 = (double)o1 * out_mul1;
+                    out2.a = (YT)d0;
+                    out2.b = (YT)d1;
+                    dot0 += dot_with[o] * d0;
+                    dot1 += dot_with[o + 1] * d1;
+                } else {      // inner level of the cycle
+                    out2.a = (YT)o0;
+                    out2.b = (YT)o1;
+                }
             } else {
                 const X2 b = *reinterpret_cast<const X2 *>(aux1 + o);
                 const X2 xo = *reinterpret_cast<const X2 *>(x + o);
@@ -273,6 +278,16 @@ int launch_spmm_f32_wup_exit(padne_ctx *ctx, const padne_csr *w, int k, const fl
 #define ARGS ctx, w, w->vals32, SPMV_WUP, e, z, dot_with, partials, done_flag, r_pre, dinv32, scale, out_scale2, x_pre
     PADNE_SPMM_WIDTH(k, (launch_spmm_typed<8, float, float, double>(ARGS)), (launch_spmm_typed<4, float, float, double>(ARGS)),
                      (launch_spmm_typed<2, float, float, double>(ARGS)))
+#undef ARGS
+}
+
+// up-leg of an inner level in the W form: x = x_pre + c D^-1 r_pre + W e, single precision throughout
+int launch_spmm_f32_wup(padne_ctx *ctx, const padne_csr *w, int k, const float *e, float *x_out, const int32_t *done_flag,
+                        const float *x_pre, const float *r_pre, const float *dinv32, float scale) {
+    PADNE_REQUIRE(w->vals32 != nullptr, "single-precision W stage");
+#define ARGS ctx, w, w->vals32, SPMV_WUP, e, x_out, nullptr, nullptr, done_flag, r_pre, dinv32, scale, nullptr, x_pre
+    PADNE_SPMM_WIDTH(k, (launch_spmm_typed<8, float, float, float>(ARGS)), (launch_spmm_typed<4, float, float, float>(ARGS)),
+                     (launch_spmm_typed<2, float, float, float>(ARGS)))
 #undef ARGS
 }
 

@@ -400,7 +400,8 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_wpr_kernel(
     const int n_rows, const int *__restrict__ rowptr, const int *__restrict__ cols, const VT *__restrict__ vals,
     const XT *__restrict__ x, YT *__restrict__ y, const double *__restrict__ dot_with,
     double *__restrict__ partials, const int *__restrict__ done_flag, const XT *__restrict__ aux1,
-    const XT *__restrict__ aux2, const XT scale, const double *__restrict__ out_scale2, XT *__restrict__ y2) {
+    const XT *__restrict__ aux2, const XT scale, const double *__restrict__ out_scale2, XT *__restrict__ y2,
+    const XT *__restrict__ aux0) {
     constexpr bool WITH_DOT = (MODE == SPMV_DOT) || (MODE == SPMV_DOT_AUX) || (MODE == SPMV_JACOBI);
     __shared__ double red[4];
     if (done_flag != nullptr && *done_flag != 0) return;
@@ -430,6 +431,8 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_wpr_kernel(
                 y[r] = (YT)(aux1[r] - acc);
             } else if (MODE == SPMV_ADD) {
                 y[r] += (YT)acc;
+            } else if (MODE == SPMV_WUP) {      // inner levels only: no exit stage here
+                y[r] = (YT)(aux0[r] + scale * aux2[r] * aux1[r] + acc);
             } else {
                 const XT b = aux1[r];
                 const XT out = x[r] + scale * aux2[r] * (b - acc);
@@ -522,11 +525,11 @@ static int launch_spmv_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals,
         partial_off = split_grid(m, m->split_n_int);
         g = split_grid(m, n_list);
     }
-    if (use_wave_per_row(m) && mode != SPMV_WUP) {
+    if (use_wave_per_row(m) && !(mode == SPMV_WUP && dot_with != nullptr)) {
 #define PADNE_SPMV_WPR(M)                                                                                           \
     hipLaunchKernelGGL((csr_spmv_wpr_kernel<M, VT, XT, YT>), dim3(g), dim3(kSpmvThreads), 0, ctx->stream,            \
                        (int)m->n_rows, m->rowptr, m->cols, vals, x, y, dot_with, partials, done_flag, aux1, aux2,    \
-                       scale, out_scale2, y2)
+                       scale, out_scale2, y2, aux0)
         switch (mode) {
             case SPMV_PLAIN: PADNE_SPMV_WPR(SPMV_PLAIN); break;
             case SPMV_DOT: PADNE_SPMV_WPR(SPMV_DOT); break;
@@ -535,6 +538,7 @@ static int launch_spmv_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals,
             case SPMV_ADD: PADNE_SPMV_WPR(SPMV_ADD); break;
             case SPMV_JACOBI: PADNE_SPMV_WPR(SPMV_JACOBI); break;
             case SPMV_RESTRICT: PADNE_SPMV_WPR(SPMV_RESTRICT); break;
+            case SPMV_WUP: PADNE_SPMV_WPR(SPMV_WUP); break;
             default: set_error("bad SpMV mode %d", mode); return PADNE_E_INVALID;
         }
 #undef PADNE_SPMV_WPR
@@ -682,6 +686,14 @@ int launch_spmv_f32_wup_exit(padne_ctx *ctx, const padne_csr *w, const float *e,
                                                       r_pre, dinv32, scale, out_scale2, x_pre);
     return launch_spmv_typed<float, float, double>(ctx, w, w->vals32, SPMV_WUP, e, z, dot_with, partials, done_flag, r_pre,
                                                    dinv32, scale, out_scale2, x_pre);
+}
+
+// up-leg of an inner level in the W form: x = x_pre + c D^-1 r_pre + W e, single precision throughout
+int launch_spmv_f32_wup(padne_ctx *ctx, const padne_csr *w, const float *e, float *x_out, const int32_t *done_flag,
+                        const float *x_pre, const float *r_pre, const float *dinv32, float scale) {
+    PADNE_REQUIRE(w->vals32 != nullptr, "single-precision W stage");
+    return launch_spmv_typed<float, float, float>(ctx, w, w->vals32, SPMV_WUP, e, x_out, nullptr, nullptr, done_flag, r_pre,
+                                                  dinv32, scale, nullptr, x_pre);
 }
 
 // ---- x-window plan -------------------------------------------------------------------------------------
@@ -912,7 +924,7 @@ __global__ __launch_bounds__(256) void xw_plan_wide_kernel(int n_rows, int n_wti
     }
 }
 
-int csr_build_xw_plan_wide(padne_ctx *ctx, padne_csr *m) {
+int csr_build_xw_plan_wide(padne_ctx *ctx, padne_csr *m, int grid_cap) {
     static_assert(kXwRunsWide * kXwRunWide <= 256, "8-bit positions");
     if (m->xw_state == 1 || m->n_rows < 65536 || m->vals32 == nullptr || getenv("PADNE_NO_XWINDOW") != nullptr ||
         getenv("PADNE_NO_XWINDOW_WIDE") != nullptr)
@@ -929,7 +941,7 @@ int csr_build_xw_plan_wide(padne_ctx *ctx, padne_csr *m) {
     // (positions of the tiles that keep the gather path, and of the padding, are never read as positions; zeroed so that
     //  a stray word of a pass's last load is a valid index)
     PADNE_HIP_CHECK(hipMemsetAsync(lidx, 0, (size_t)m->nnz + kPadNnz, ctx->stream));
-    const unsigned g = (unsigned)std::min<long long>(((long long)n_tiles + 3) / 4, 8192);
+    const unsigned g = (unsigned)std::min<long long>(((long long)n_tiles + 3) / 4, grid_cap > 0 ? grid_cap : 8192);
     hipLaunchKernelGGL(xw_plan_wide_kernel, dim3(g), dim3(256), 0, ctx->stream, (int)m->n_rows, n_tiles, m->rowptr, m->cols,
                        (int *)desc, (unsigned char *)lidx);
     PADNE_HIP_CHECK(hipGetLastError());

@@ -533,6 +533,46 @@ def test_fused_up_leg_of_the_fine_level_is_the_same_cycle(ctx, monkeypatch):
         assert np.linalg.norm(A @ res.x - b) <= 1e-11 * np.linalg.norm(b)
 
 
+def test_fused_up_leg_of_the_inner_levels_is_the_same_cycle(ctx, monkeypatch):
+    """The inner levels take the same W form of the up-leg (built at the end of the setup, when the Lanczos estimate has
+    settled the level's damping): against PADNE_AMG_W_FINE_ONLY=1 (W on the fine level only) one cycle applied to a probe
+    agrees to float rounding, the single solve and the lockstep solve of four and eight right-hand sides take the same
+    iterations (one either way) and give the same potentials to the solve tolerance."""
+    sysm = synthetic.layered_system(3, 260, 200, via_lattice=5)
+    els = [("R", int(a), int(b), float(r)) for a, b, r in zip(*sysm.resistors)]
+    els += [("I", int(f), int(t), float(i)) for f, t, i in zip(*sysm.current_sources)]
+    Lo, ro = O.assemble_system([(m[0], m[1], m[2]) for m in sysm.meshes], 0, els, 0)
+    n = sysm.n_vertices
+    A = (-Lo[1:n, 1:n]).tocsr()
+    A.sort_indices()
+    b = -ro[1:n]
+    rng = np.random.default_rng(11)
+    B = np.stack([b] + [A @ rng.uniform(-1, 1, n - 1) for _ in range(7)])
+    probe = rng.uniform(-1, 1, n - 1)
+
+    def run():
+        d = ctx.csr_from_scipy(A)
+        one = d.solve_spd(b, precond="amg", rtol=1e-12)
+        z = d.amg_apply(probe)
+        four = d.solve_spd(B[:4], precond="amg", rtol=1e-12)
+        eight = d.solve_spd(B, precond="amg", rtol=1e-12)
+        d.close()
+        return one, z, four, eight
+    inner = run()
+    monkeypatch.setenv("PADNE_AMG_W_FINE_ONLY", "1")
+    fine_only = run()
+    assert inner[0].levels == fine_only[0].levels >= 4      # at least two inner levels carry a W
+    assert np.abs(inner[1] - fine_only[1]).max() <= 2e-5 * np.abs(fine_only[1]).max()
+    assert not np.array_equal(inner[1], fine_only[1]), "the switch did not change the cycle: is the inner W built at all?"
+    for a, c, rhs in ((inner[0], fine_only[0], b), (inner[2], fine_only[2], B[:4]), (inner[3], fine_only[3], B)):
+        assert a.precond_fallbacks == 0 and c.precond_fallbacks == 0
+        k = 1 if rhs.ndim == 1 else rhs.shape[0]
+        assert abs(a.iterations - c.iterations) <= k
+        assert np.abs(a.x - c.x).max() <= 1e-9 * np.abs(c.x).max()
+        R = (A @ a.x.T).T - rhs
+        assert np.linalg.norm(R) <= 1e-11 * np.linalg.norm(rhs)
+
+
 @pytest.mark.parametrize("hub", [False, True])
 def test_windowed_setup_kernels_build_the_same_hierarchy(ctx, monkeypatch, hub):
     """A fine level with an x-window plan (>= 65536 rows, band matrix) takes the windowed setup kernels: one-byte
