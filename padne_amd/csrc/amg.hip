@@ -1929,15 +1929,104 @@ __global__ __launch_bounds__(256) void gj_block_step(int n, int k0, const double
 // matrix (a rank-16 update of 16 values per thread, of a 32 x 16 and of a 16 x 16 block per workgroup).  Every entry goes
 // through the operations of two consecutive one-step launches in their order: the same bits (tested), half the launches
 // and 0.6 of the traffic.
-__global__ __launch_bounds__(256) void gj_block_step2(int n, int k0, int bs2, const double *__restrict__ in, double *__restrict__ out) {
+// The pivot work of a fused step, by ONE wave, from 16 x 16 blocks in LDS (complete before the call: the caller's barrier):
+//     Dinv1 = D11^-1 ;  T12 = Dinv1 D12 (the rows R of step 1 in the columns K2) ;  Dinv2 = (D22 - D21 T12)^-1,
+// the last padded with the identity where fewer than 16 pivots are left, like gj_block_step<false>.  dd comes in with D11 and
+// d22 with D22 (zero outside the bs2 live pivots), entry (a, b) in lane (a & 3) << 4 | b, register a >> 2.
+__device__ __forceinline__ void gj_pivot_pair(const int lane, const int bs2, double (&dd)[4], const double (&d22)[4],
+                                              double (*Dinv1)[kGjBlock], const double (*D12)[kGjBlock],
+                                              const double (*D21)[kGjBlock], double (*T12)[kGjBlock], double (*Dinv2)[kGjBlock]) {
+    const int eb = lane & 15, ea0 = lane >> 4;
+    gj_invert_block16(dd, lane);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Dinv1[ea0 + 4 * q][eb] = dd[q];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    double tt[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double sum = 0.0;
+#pragma unroll
+        for (int b = 0; b < kGjBlock; ++b) sum = fma(Dinv1[ea0 + 4 * q][b], D12[b][eb], sum);
+        tt[q] = sum;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) T12[ea0 + 4 * q][eb] = tt[q];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ea = ea0 + 4 * q;
+        double v = d22[q];
+#pragma unroll
+        for (int b = 0; b < kGjBlock; ++b) v = fma(-D21[ea][b], T12[b][eb], v);
+        dd[q] = (ea < bs2 && eb < bs2) ? v : (ea == eb ? 1.0 : 0.0);
+    }
+    gj_invert_block16(dd, lane);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Dinv2[ea0 + 4 * q][eb] = dd[q];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// What a fused step needs of its pivot blocks, for the launch that follows: Dinv1 | T12 | Dinv2, 3 x 256 doubles.
+constexpr int kGjSide = 3 * kGjBlock * kGjBlock;
+
+// The pivot work of the FIRST fused step (the later ones get theirs from the launch before them, see gj_block_step2<true>).
+__global__ __launch_bounds__(256) void gj_pivot_prepare(int n, int k0, int bs2, const double *__restrict__ in, double *__restrict__ side) {
+    __shared__ __attribute__((aligned(16))) double Dinv1[kGjBlock][kGjBlock], Dinv2[kGjBlock][kGjBlock];
+    __shared__ __attribute__((aligned(16))) double D12[kGjBlock][kGjBlock], D21[kGjBlock][kGjBlock], T12[kGjBlock][kGjBlock];
+    const int t = threadIdx.x, k1 = k0 + kGjBlock;
+    {
+        const int a = t / kGjBlock, b = t % kGjBlock;
+        D12[a][b] = b < bs2 ? in[(size_t)(k0 + a) * n + k1 + b] : 0.0;
+        D21[a][b] = a < bs2 ? in[(size_t)(k1 + a) * n + k0 + b] : 0.0;
+    }
+    __syncthreads();
+    if (t >= 64) return;
+    const int lane = t, eb = lane & 15, ea0 = lane >> 4;
+    double dd[4], d22[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ea = ea0 + 4 * q;
+        dd[q] = in[(size_t)(k0 + ea) * n + k0 + eb];
+        d22[q] = (ea < bs2 && eb < bs2) ? in[(size_t)(k1 + ea) * n + k1 + eb] : 0.0;
+    }
+    gj_pivot_pair(lane, bs2, dd, d22, Dinv1, D12, D21, T12, Dinv2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = (ea0 + 4 * q) * kGjBlock + eb;
+        side[e] = Dinv1[ea0 + 4 * q][eb];
+        side[kGjBlock * kGjBlock + e] = T12[ea0 + 4 * q][eb];
+        side[2 * kGjBlock * kGjBlock + e] = Dinv2[ea0 + 4 * q][eb];
+    }
+}
+
+// LOOK = false: every workgroup does the pivot work itself, one wave, before anything else -- two dependent 16 x 16 inversions,
+// 10 of the launch's 35 us with the other three waves waiting at the barrier (measured by leaving it out; with the pivot
+// work prepared the launch takes 32 us, 29 without the extra workgroup: the tiles themselves, 42 MB through the Infinity
+// Cache and the two rank-16 updates at two waves per SIMD, are what is left).
+// LOOK = true: the pivot work comes in through `side` (gj_pivot_prepare for the first step), and ONE extra workgroup -- block
+// (0, 0), dispatched first; the strips are the blocks with y >= 1 -- prepares the step that FOLLOWS: it takes the 32 x 32 block
+// of the next pivots through this launch's two steps like any other tile (same code, same bits as the workgroup that owns
+// that tile), keeps the result in LDS, does the pivot work on it and leaves it in `side_next`.  The chain of inversions runs
+// beside the update of the matrix instead of in front of it.  next_bs2: pivots of the second block of the following fused
+// step, 0 when none follows (then block (0, 0) has nothing to do).
+template <bool LOOK>
+__global__ __launch_bounds__(256) void gj_block_step2(int n, int k0, int bs2, const double *__restrict__ in, double *__restrict__ out,
+                                                      const double *__restrict__ side, double *__restrict__ side_next,
+                                                      int next_bs2) {
     __shared__ __attribute__((aligned(16))) double Dinv1[kGjBlock][kGjBlock], Dinv2[kGjBlock][kGjBlock];
     __shared__ __attribute__((aligned(16))) double D12[kGjBlock][kGjBlock], D21[kGjBlock][kGjBlock], T12[kGjBlock][kGjBlock];
     __shared__ __attribute__((aligned(16))) double L1col[kGjStrip][kGjBlock], L2col[kGjStrip][kGjBlock];
     const int t = threadIdx.x;
-    const int r0 = blockIdx.y * kGjStrip;
-    const int c = blockIdx.x * blockDim.x + t;
     const int k1 = k0 + kGjBlock;                           // first pivot of the second block
-    const bool live = c < n;
+    const bool ahead = LOOK && blockIdx.y == 0;             // the workgroup that prepares the next step
+    if (ahead && (blockIdx.x != 0 || next_bs2 <= 0)) return;
+    const int kn = k1 + kGjBlock;                           // first pivot of the next step
+    const int r0 = ahead ? kn : ((int)blockIdx.y - (LOOK ? 1 : 0)) * kGjStrip;
+    const int c = ahead ? kn + t : blockIdx.x * blockDim.x + t;
+    const bool live = ahead ? (t < 2 * kGjBlock && c < n) : c < n;
     const bool pc1 = c >= k0 && c < k1, pc2 = c >= k1 && c < k1 + bs2;
     // everything of the old matrix is asked for up front
     double P1[kGjBlock], P2[kGjBlock], V[kGjStrip];
@@ -1956,48 +2045,27 @@ __global__ __launch_bounds__(256) void gj_block_step2(int n, int k0, int bs2, co
         const int a = t / kGjBlock, b = t % kGjBlock;       // 256 threads, one entry of each 16 x 16 block
         D12[a][b] = b < bs2 ? in[(size_t)(k0 + a) * n + k1 + b] : 0.0;
         D21[a][b] = a < bs2 ? in[(size_t)(k1 + a) * n + k0 + b] : 0.0;
+        if (LOOK) {
+            Dinv1[a][b] = side[t];
+            T12[a][b] = side[kGjBlock * kGjBlock + t];
+            Dinv2[a][b] = side[2 * kGjBlock * kGjBlock + t];
+        }
     }
     const int lane = t & 63, eb = lane & 15, ea0 = lane >> 4;
-    double dd[4], d22[4] = {0.0, 0.0, 0.0, 0.0};
-    if (t < 64) {
+    if (!LOOK) {
+        double dd[4], d22[4] = {0.0, 0.0, 0.0, 0.0};
+        if (t < 64) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int ea = ea0 + 4 * q;
-            dd[q] = in[(size_t)(k0 + ea) * n + k0 + eb];
-            d22[q] = (ea < bs2 && eb < bs2) ? in[(size_t)(k1 + ea) * n + k1 + eb] : 0.0;
+            for (int q = 0; q < 4; ++q) {
+                const int ea = ea0 + 4 * q;
+                dd[q] = in[(size_t)(k0 + ea) * n + k0 + eb];
+                d22[q] = (ea < bs2 && eb < bs2) ? in[(size_t)(k1 + ea) * n + k1 + eb] : 0.0;
+            }
         }
-        gj_invert_block16(dd, lane);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) Dinv1[ea0 + 4 * q][eb] = dd[q];
+        __syncthreads();                                    // D12, D21
+        if (t < 64) gj_pivot_pair(lane, bs2, dd, d22, Dinv1, D12, D21, T12, Dinv2);
     }
-    __syncthreads();                                        // Dinv1, D12, D21, L1col, L2col
-    if (t < 64) {
-        // T12 = R of step 1 in the columns K2 (= Dinv1 D12), then the pivot block of step 2 as step 1 leaves it
-        // (D22 - D21 T12), inverted
-        double tt[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            double sum = 0.0;
-#pragma unroll
-            for (int b = 0; b < kGjBlock; ++b) sum = fma(Dinv1[ea0 + 4 * q][b], D12[b][eb], sum);
-            tt[q] = sum;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) T12[ea0 + 4 * q][eb] = tt[q];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int ea = ea0 + 4 * q;
-            double v = d22[q];
-#pragma unroll
-            for (int b = 0; b < kGjBlock; ++b) v = fma(-D21[ea][b], T12[b][eb], v);
-            dd[q] = (ea < bs2 && eb < bs2) ? v : (ea == eb ? 1.0 : 0.0);      // padded with the identity like gj_block_step<false>
-        }
-        gj_invert_block16(dd, lane);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) Dinv2[ea0 + 4 * q][eb] = dd[q];
-    }
+    __syncthreads();                                        // Dinv1, Dinv2, T12, D12, D21, L1col, L2col
     // ---- step 1 on this thread's column
     double R[kGjBlock];
     if (pc1) {
@@ -2034,7 +2102,6 @@ __global__ __launch_bounds__(256) void gj_block_step2(int n, int k0, int bs2, co
         P2[b2] = (b2 < bs2 && !pc2) ? v : 0.0;
         asm volatile("" : "+v"(P2[b2]) : : "memory");
     }
-    __syncthreads();                                        // T12 (wave 0) before L2col is rewritten; Dinv2
     // the pivot columns K2 in this strip's rows as step 1 leaves them: two entries per thread
     double l2[2];
 #pragma unroll
@@ -2053,7 +2120,7 @@ __global__ __launch_bounds__(256) void gj_block_step2(int n, int k0, int bs2, co
         L2col[e / kGjBlock][e % kGjBlock] = l2[h];
     }
     __syncthreads();
-    if (!live) return;
+    if (!live && !ahead) return;
     // ---- step 2
     if (pc2) {
 #pragma unroll
@@ -2068,15 +2135,58 @@ __global__ __launch_bounds__(256) void gj_block_step2(int n, int k0, int bs2, co
             asm volatile("" : "+v"(R[a]) : : "memory");
         }
     }
+    if (!ahead) {
 #pragma unroll
-    for (int q = 0; q < kGjStrip; ++q) {
-        const int i = r0 + q;
-        double v = pc2 ? 0.0 : V[q];
+        for (int q = 0; q < kGjStrip; ++q) {
+            const int i = r0 + q;
+            double v = pc2 ? 0.0 : V[q];
 #pragma unroll
-        for (int b = 0; b < kGjBlock; ++b) v = fma(-L2col[q][b], R[b], v);
-        if (i >= k1 && i < k1 + bs2) v = Rsel(R, i - k1);
-        asm volatile("" : "+v"(v) : : "memory");
-        if (i < n) out[(size_t)i * n + c] = v;
+            for (int b = 0; b < kGjBlock; ++b) v = fma(-L2col[q][b], R[b], v);
+            if (i >= k1 && i < k1 + bs2) v = Rsel(R, i - k1);
+            asm volatile("" : "+v"(v) : : "memory");
+            if (i < n) out[(size_t)i * n + c] = v;
+        }
+        return;
+    }
+    // ---- the workgroup that prepares the next step: its 32 x 32 tile is the next step's D11 | D12 / D21 | D22 (no pivot row or
+    // column of THIS step is in it).  The blocks of this step are done with: they take the next step's, zero outside its pivots.
+    __syncthreads();                                        // every wave has read Dinv2, D21, T12 for the last time
+    double d11n[4] = {0.0, 0.0, 0.0, 0.0}, d22n[4] = {0.0, 0.0, 0.0, 0.0};
+    {
+        const int nb = next_bs2;
+#pragma unroll
+        for (int q = 0; q < kGjStrip; ++q) {
+            double v = V[q];
+#pragma unroll
+            for (int b = 0; b < kGjBlock; ++b) v = fma(-L2col[q][b], R[b], v);
+            asm volatile("" : "+v"(v) : : "memory");
+            // (q, t): row kn + q, column kn + t of the matrix after this launch
+            if (t < 2 * kGjBlock) {
+                const bool in_n = kn + q < n && kn + t < n;
+                const double w = in_n ? v : 0.0;
+                if (q < kGjBlock && t < kGjBlock) Dinv1[q][t] = w;                                   // D11 of the next step, inverted below
+                else if (q < kGjBlock) D12[q][t - kGjBlock] = (t - kGjBlock < nb) ? w : 0.0;
+                else if (t < kGjBlock) D21[q - kGjBlock][t] = (q - kGjBlock < nb) ? w : 0.0;
+                else Dinv2[q - kGjBlock][t - kGjBlock] = (q - kGjBlock < nb && t - kGjBlock < nb) ? w : 0.0;
+            }
+        }
+    }
+    __syncthreads();
+    if (t >= 64) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        d11n[q] = Dinv1[ea0 + 4 * q][eb];
+        d22n[q] = Dinv2[ea0 + 4 * q][eb];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    gj_pivot_pair(lane, next_bs2, d11n, d22n, Dinv1, D12, D21, T12, Dinv2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = (ea0 + 4 * q) * kGjBlock + eb;
+        side_next[e] = Dinv1[ea0 + 4 * q][eb];
+        side_next[kGjBlock * kGjBlock + e] = T12[ea0 + 4 * q][eb];
+        side_next[2 * kGjBlock * kGjBlock + e] = Dinv2[ea0 + 4 * q][eb];
     }
 }
 
@@ -3072,16 +3182,34 @@ static int dense_inverse(padne_ctx *ctx, const padne_csr *A, double **inv_out) {
     if (n > 0) {
         hipLaunchKernelGGL(dense_from_csr, dim3(n), dim3(256), 0, s, n, A->rowptr, A->cols, A->vals, W);
         const dim3 ge(nblk(n), (unsigned)((n + kGjStrip - 1) / kGjStrip));
+        const dim3 ge_look(ge.x, ge.y + 1);                 // block row 0: the workgroup that prepares the next step
         double *src = W, *dst = W2;
         // two pivot blocks per launch while more than one is left (gj_block_step2), the one-step kernel for a single last
-        // block; PADNE_GJ_ONE_STEP=1: one block per launch throughout (the form the fused kernel is tested against)
+        // block; PADNE_GJ_ONE_STEP=1: one block per launch throughout (the form the fused kernel is tested against);
+        // PADNE_GJ_NO_LOOKAHEAD=1: every workgroup of a fused step does the pivot work itself (the same bits, tested)
         const bool fused = getenv("PADNE_GJ_ONE_STEP") == nullptr;
+        const bool look = fused && getenv("PADNE_GJ_NO_LOOKAHEAD") == nullptr;
+        double *side = nullptr;
+        if (look) PADNE_TRY(sc.alloc(&side, (size_t)2 * kGjSide));
+        int parity = 0;
+        if (look && n > kGjBlock) {
+            hipLaunchKernelGGL(gj_pivot_prepare, dim3(1), dim3(256), 0, s, n, 0, std::min(kGjBlock, n - kGjBlock), (const double *)src, side);
+        }
         for (int k = 0; k < n;) {
             const int left = n - k;
             // the last step writes the finished inverse where it stays
             if (fused && left > kGjBlock) {
                 const int bs2 = std::min(kGjBlock, left - kGjBlock);
-                hipLaunchKernelGGL(gj_block_step2, ge, dim3(256), 0, s, n, k, bs2, src, k + kGjBlock + bs2 >= n ? inv : dst);
+                const int left_next = left - kGjBlock - bs2;
+                const int next_bs2 = left_next > kGjBlock ? std::min(kGjBlock, left_next - kGjBlock) : 0;
+                double *to = k + kGjBlock + bs2 >= n ? inv : dst;
+                if (look)
+                    hipLaunchKernelGGL(gj_block_step2<true>, ge_look, dim3(256), 0, s, n, k, bs2, (const double *)src, to,
+                                       (const double *)(side + parity * kGjSide), side + (parity ^ 1) * kGjSide, next_bs2);
+                else
+                    hipLaunchKernelGGL(gj_block_step2<false>, ge, dim3(256), 0, s, n, k, bs2, (const double *)src, to,
+                                       (const double *)nullptr, (double *)nullptr, 0);
+                parity ^= 1;
                 k += kGjBlock + bs2;
             } else if (left >= kGjBlock) {
                 hipLaunchKernelGGL(gj_block_step<true>, ge, dim3(256), 0, s, n, k, src, k + kGjBlock >= n ? inv : dst);

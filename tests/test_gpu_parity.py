@@ -465,9 +465,11 @@ def test_mailbox_round_trips_change_nothing_but_the_waiting(ctx, monkeypatch):
 def test_two_pivot_blocks_per_launch_of_the_dense_inverse_are_the_same_bits(ctx, monkeypatch, layers, nx, ny, coarse_n):
     """The coarsest operator is inverted by a blocked Gauss-Jordan without pivoting: 16 pivots per launch (`gj_block_step`),
     or 32 -- two steps fused in one launch (`gj_block_step2`: what the second step reads of other tiles as the first leaves
-    it is recomputed from the old matrix).  Every entry goes through the same operations in the same order: the
-    double-precision cycle built on either inverse applies to a random vector with the same bits, for coarsest levels of
-    a handful to ~1100 unknowns (odd and even numbers of pivot blocks, a last block of fewer than 16 pivots)."""
+    it is recomputed from the old matrix), with the two 16 x 16 inversions of a fused step done once, by an extra workgroup
+    of the launch BEFORE it (`gj_block_step2<true>`; PADNE_GJ_NO_LOOKAHEAD=1: by every workgroup itself).  Every entry goes
+    through the same operations in the same order: the double-precision cycle built on any of the three inverses applies
+    to a random vector with the same bits, for coarsest levels of a handful to ~1100 unknowns (odd and even numbers of
+    pivot blocks, a last block of fewer than 16 pivots)."""
     monkeypatch.setenv("PADNE_AMG_F64", "1")
     if coarse_n is not None:
         monkeypatch.setenv("PADNE_AMG_COARSE_N", str(coarse_n))
@@ -489,15 +491,16 @@ def test_two_pivot_blocks_per_launch_of_the_dense_inverse_are_the_same_bits(ctx,
         d.close()
         return res, n_coarse, z
     two, n_two, z_two = run(ctx)
-    monkeypatch.setenv("PADNE_GJ_ONE_STEP", "1")
-    other = _hip.Context(0)
-    try:
-        one, n_one, z_one = run(other)
-    finally:
-        other.close()
-    assert n_one == n_two and n_one <= 2048, n_one
-    assert one.levels == two.levels and one.iterations == two.iterations
-    assert np.array_equal(z_one, z_two) and np.array_equal(one.x, two.x), f"coarsest level of {n_one} unknowns"
+    for switch in ("PADNE_GJ_NO_LOOKAHEAD", "PADNE_GJ_ONE_STEP"):
+        monkeypatch.setenv(switch, "1")
+        other = _hip.Context(0)
+        try:
+            one, n_one, z_one = run(other)
+        finally:
+            other.close()
+        assert n_one == n_two and n_one <= 2048, n_one
+        assert one.levels == two.levels and one.iterations == two.iterations
+        assert np.array_equal(z_one, z_two) and np.array_equal(one.x, two.x), f"{switch}: coarsest level of {n_one} unknowns"
     assert np.linalg.norm(A @ two.x - b) <= 1e-11 * np.linalg.norm(b)
 
 
