@@ -2190,6 +2190,225 @@ __global__ __launch_bounds__(256) void gj_block_step2(int n, int k0, int bs2, co
     }
 }
 
+// ---- the same inversion with 64 pivots per launch, the rank-64 updates on the double-precision matrix cores ------------------
+// With K the 64 pivots of a step, D = W[K, K], the step is  W' = C~ - L~ (D^-1 P~)  with the inputs modified so that one formula
+// serves every entry:  C~ = W with the pivot rows and columns zeroed,  P~ = W[K, :] with the identity in the pivot columns,
+// L~ = W[:, K] with MINUS the identity in the pivot rows  (pivot block: 0 + I D^-1 I = D^-1; pivot rows: D^-1 W[K, j]; pivot
+// columns: -W[i, K] D^-1; elsewhere the rank-64 update).  One WAVE owns a tile of 96 x 32 entries: it forms U = D^-1 P~ for its
+// 32 columns (4 x 2 blocks of v_mfma_f64_16x16x4_f64, D^-1 read from the side buffer in operand order) and then takes its six
+// row blocks through 16 k-steps each, operands straight from global memory into registers -- no LDS, no barrier.  The result
+// of the first product leaves the matrix cores in the register layout the second one wants its B operand in.
+// Order of the 64 pivots inside the products: the A operand of the update (the tile's rows of the pivot columns, contiguous
+// in memory along k) is read 16 bytes per lane, lane (i, g) taking k = 16 q + 4 g + {0..3}; the k-step (q, m) therefore pairs
+// lane group g with pivot 16 q + 4 g + m, and U must come out of the first product with row 4 g + m of block q in register m of
+// lane group g: its A operand (D^-1) has its rows permuted, row i of a block standing for pivot 4 (i & 3) + (i >> 2)
+// (gj64_side_off).
+// Measured (scripts/lab/gj_mfma_lab.hip, mfma_f64_rate.hip; n = 1617): the instruction issues every 62 ns per SIMD with one wave
+// there, 45 ns with two -- 33 to 47 TFLOP/s over the chip, not above the vector rate -- and a launch of 64 pivots takes 40 us
+// against 2 x 32 us of the vector kernel above: what it saves is a pass over the matrix, not arithmetic.
+// The pivot block of the NEXT step is prepared by workgroup 0 of the launch (as in gj_block_step2<true>): its four waves take
+// the next 64 x 64 block through this step, invert it in LDS by four 16-pivot block steps and leave D^-1 in the other side buffer.
+// Sums are formed in the order of the matrix cores: the result agrees with the vector kernels to rounding, not bit for bit
+// (PADNE_GJ_VECTOR=1 selects those).
+typedef double gj_v4d __attribute__((ext_vector_type(4)));
+constexpr int kGjM = 64;                      // pivots per launch
+constexpr int kGjTR = 96, kGjTC = 32;         // a wave's tile
+__device__ __host__ inline int gj64_side_off(int a, int b) {      // D^-1[a][b] -> position in the side buffer
+    const int blk = a >> 4, w = a & 15, i = ((w & 3) << 2) | (w >> 2);      // row i of the block stands for pivot 4 (i & 3) + (i >> 2)
+    return (blk * 16 + (b >> 2)) * 64 + (b & 3) * 16 + i;
+}
+
+// One wave: the tile of 16 NRB rows from r0, 16 NCB columns from c0, through the step with the pivots [k0, k0 + bs).
+// sink(row, col, value) receives every entry of the tile (also those outside the matrix: the caller decides).
+template <int NRB, int NCB, typename Sink>
+__device__ __forceinline__ void gj64_tile(const int n, const int k0, const int bs, const double *__restrict__ in,
+                                          const double *__restrict__ side, const int r0, const int c0, const int lane, Sink sink) {
+    const int j = lane & 15, g = lane >> 4;
+    auto load_a = [&](int rb, double (&a)[16]) {
+        const int row = r0 + 16 * rb + j;
+        const bool prow = row >= k0 && row < k0 + kGjM;
+        const double *p = in + (size_t)(row < n ? row : 0) * n + k0 + 4 * g;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (!prow && row < n && 16 * q + 4 * g + 3 < bs) {
+                const D2u lo = *reinterpret_cast<const D2u *>(p + 16 * q), hi = *reinterpret_cast<const D2u *>(p + 16 * q + 2);
+                a[4 * q + 0] = -lo.x; a[4 * q + 1] = -lo.y; a[4 * q + 2] = -hi.x; a[4 * q + 3] = -hi.y;
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int k = 16 * q + 4 * g + m;
+                    double v = 0.0;
+                    if (prow) v = (row - k0 == k) ? 1.0 : 0.0;            // -(-I)
+                    else if (row < n && k < bs) v = -p[16 * q + m];
+                    a[4 * q + m] = v;
+                }
+            }
+        }
+    };
+    auto load_c = [&](int rb, gj_v4d (&C)[NCB]) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = r0 + 16 * rb + g + 4 * r, col = c0 + 16 * cb + j;
+                const bool piv = (row >= k0 && row < k0 + kGjM) || (col >= k0 && col < k0 + kGjM);
+                C[cb][r] = (row < n && col < n && !piv) ? in[(size_t)row * n + col] : 0.0;
+            }
+    };
+    double a_cur[16], a_nxt[16];
+    gj_v4d C_cur[NCB], C_nxt[NCB];
+    load_c(0, C_cur);
+    load_a(0, a_cur);
+    // U = D^-1 P~ for the tile's columns
+    gj_v4d U[4][NCB];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) U[kb][cb] = (gj_v4d){0.0, 0.0, 0.0, 0.0};
+    double pb[16][NCB];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            const int col = c0 + 16 * cb + j, k = 4 * ks + g;
+            double v = 0.0;
+            if (col >= k0 && col < k0 + kGjM) v = (col - k0 == k) ? 1.0 : 0.0;
+            else if (col < n && k < bs) v = in[(size_t)(k0 + k) * n + col];
+            pb[ks][cb] = v;
+        }
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const double a = side[(kb * 16 + ks) * 64 + lane];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) U[kb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, pb[ks][cb], U[kb][cb], 0, 0, 0);
+        }
+    // the tile, a row block at a time, the next block's operands in flight
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+        if (rb + 1 < NRB) {
+            load_c(rb + 1, C_nxt);
+            load_a(rb + 1, a_nxt);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb)
+                    C_cur[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[4 * q + m], U[q][cb][m], C_cur[cb], 0, 0, 0);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sink(r0 + 16 * rb + g + 4 * r, c0 + 16 * cb + j, C_cur[cb][r]);
+        if (rb + 1 < NRB) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) a_cur[e] = a_nxt[e];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) C_cur[cb] = C_nxt[cb];
+        }
+    }
+}
+
+// In-place inversion of a 64 x 64 block in LDS by one workgroup: four block steps of 16 pivots, the 16 x 16 pivot block by
+// wave 0 (gj_invert_block16), the rest of the block by everybody.  N0 holds the block and receives the inverse; N1, R, D16 are
+// scratch.  Ends with a barrier.
+constexpr int kGjLd = kGjM + 1;
+__device__ __forceinline__ void gj64_invert_lds(double (*N0)[kGjLd], double (*N1)[kGjLd], double (*R)[kGjM], double (*D16)[kGjBlock]) {
+    const int t = threadIdx.x, lane = t & 63, eb = lane & 15, ea0 = lane >> 4;
+    double (*cur)[kGjLd] = N0, (*nxt)[kGjLd] = N1;
+    for (int bb = 0; bb < kGjM / kGjBlock; ++bb) {
+        const int pb = bb * kGjBlock;
+        if (t < 64) {
+            double dd[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dd[q] = cur[pb + ea0 + 4 * q][pb + eb];
+            gj_invert_block16(dd, lane);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) D16[ea0 + 4 * q][eb] = dd[q];
+        }
+        __syncthreads();
+        // the new pivot rows: R = D16 * [pivot rows with the identity in the pivot columns]
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int e = t + 256 * h, a = e / kGjM, j = e % kGjM;
+            double v;
+            if (j >= pb && j < pb + kGjBlock) {
+                v = D16[a][j - pb];
+            } else {
+                v = 0.0;
+#pragma unroll
+                for (int b = 0; b < kGjBlock; ++b) v = fma(D16[a][b], cur[pb + b][j], v);
+            }
+            R[a][j] = v;
+        }
+        __syncthreads();
+        {
+            const int j = t & 63, i0 = 16 * (t >> 6);
+            const bool pcol = j >= pb && j < pb + kGjBlock;
+            double rj[kGjBlock];
+#pragma unroll
+            for (int b = 0; b < kGjBlock; ++b) rj[b] = R[b][j];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int i = i0 + q;
+                double v = pcol ? 0.0 : cur[i][j];
+#pragma unroll
+                for (int b = 0; b < kGjBlock; ++b) v = fma(-cur[i][pb + b], rj[b], v);
+                if (i >= pb && i < pb + kGjBlock) v = R[i - pb][j];
+                nxt[i][j] = v;
+            }
+        }
+        __syncthreads();
+        double (*sw)[kGjLd] = cur;
+        cur = nxt;
+        nxt = sw;
+    }
+    // (four steps: the result is back in N0)
+}
+
+// D^-1 of the first step's pivot block -> side (operand order)
+__global__ __launch_bounds__(256) void gj64_prepare(int n, int k0, int bs, const double *__restrict__ in, double *__restrict__ side) {
+    __shared__ double N0[kGjM][kGjLd], N1[kGjM][kGjLd], R[kGjBlock][kGjM], D16[kGjBlock][kGjBlock];
+    const int t = threadIdx.x;
+    for (int e = t; e < kGjM * kGjM; e += 256) {
+        const int a = e / kGjM, b = e % kGjM;
+        N0[a][b] = (a < bs && b < bs) ? in[(size_t)(k0 + a) * n + k0 + b] : (a == b ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    gj64_invert_lds(N0, N1, R, D16);
+    for (int e = t; e < kGjM * kGjM; e += 256) side[gj64_side_off(e / kGjM, e % kGjM)] = N0[e / kGjM][e % kGjM];
+}
+
+// One step: workgroups 1.. carry four wave tiles each; workgroup 0 prepares the pivot block of the next step (next_bs of its
+// pivots exist; 0: there is no next step).
+__global__ __launch_bounds__(256) void gj64_step(int n, int k0, int bs, const double *__restrict__ in, double *__restrict__ out,
+                                                 const double *__restrict__ side, double *__restrict__ side_next, int next_bs,
+                                                 int n_ct, int n_tiles) {
+    __shared__ double N0[kGjM][kGjLd], N1[kGjM][kGjLd], R[kGjBlock][kGjM], D16[kGjBlock][kGjBlock];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (blockIdx.x > 0) {
+        const int tile = ((int)blockIdx.x - 1) * 4 + w;
+        if (tile >= n_tiles) return;
+        const int r0 = (tile / n_ct) * kGjTR, c0 = (tile % n_ct) * kGjTC;
+        gj64_tile<kGjTR / 16, kGjTC / 16>(n, k0, bs, in, side, r0, c0, lane, [&](int row, int col, double v) {
+            if (row < n && col < n) out[(size_t)row * n + col] = v;
+        });
+        return;
+    }
+    if (next_bs <= 0) return;
+    // the next pivot block as this step leaves it: 64 rows x 16 columns per wave, into LDS, padded with the identity
+    const int kn = k0 + kGjM;
+    gj64_tile<kGjM / 16, 1>(n, k0, bs, in, side, kn, kn + 16 * w, lane, [&](int row, int col, double v) {
+        const int a = row - kn, b = col - kn;
+        N0[a][b] = (a < next_bs && b < next_bs) ? v : (a == b ? 1.0 : 0.0);
+    });
+    __syncthreads();
+    gj64_invert_lds(N0, N1, R, D16);
+    for (int e = t; e < kGjM * kGjM; e += 256) side_next[gj64_side_off(e / kGjM, e % kGjM)] = N0[e / kGjM][e % kGjM];
+}
+
 // y = Inv * b : one wave per row
 template <typename T>
 __global__ __launch_bounds__(256) void dense_gemv(int n_rows, int n, const T *__restrict__ inv,
@@ -3189,13 +3408,32 @@ static int dense_inverse(padne_ctx *ctx, const padne_csr *A, double **inv_out) {
         // PADNE_GJ_NO_LOOKAHEAD=1: every workgroup of a fused step does the pivot work itself (the same bits, tested)
         const bool fused = getenv("PADNE_GJ_ONE_STEP") == nullptr;
         const bool look = fused && getenv("PADNE_GJ_NO_LOOKAHEAD") == nullptr;
+        // default: 64 pivots per launch on the matrix cores (gj64_step); PADNE_GJ_VECTOR=1 (or one of the two switches above):
+        // the vector kernels, 32 or 16 pivots per launch
+        const bool mfma = look && getenv("PADNE_GJ_VECTOR") == nullptr && n > kGjM;
         double *side = nullptr;
-        if (look) PADNE_TRY(sc.alloc(&side, (size_t)2 * kGjSide));
+        if (mfma) {
+            PADNE_TRY(sc.alloc(&side, (size_t)2 * kGjM * kGjM));
+            const int n_ct = (n + kGjTC - 1) / kGjTC, n_tiles = n_ct * ((n + kGjTR - 1) / kGjTR);
+            const unsigned g64 = 1u + (unsigned)((n_tiles + 3) / 4);
+            hipLaunchKernelGGL(gj64_prepare, dim3(1), dim3(256), 0, s, n, 0, std::min(kGjM, n), (const double *)src, side);
+            int par = 0;
+            for (int k = 0; k < n; k += kGjM) {
+                const int bs = std::min(kGjM, n - k);
+                const int next_bs = k + kGjM < n ? std::min(kGjM, n - k - kGjM) : 0;
+                double *to = k + kGjM >= n ? inv : dst;
+                hipLaunchKernelGGL(gj64_step, dim3(g64), dim3(256), 0, s, n, k, bs, (const double *)src, to,
+                                   (const double *)(side + (size_t)par * kGjM * kGjM), side + (size_t)(par ^ 1) * kGjM * kGjM,
+                                   next_bs, n_ct, n_tiles);
+                par ^= 1;
+                std::swap(src, dst);
+            }
+        } else if (look) PADNE_TRY(sc.alloc(&side, (size_t)2 * kGjSide));
         int parity = 0;
-        if (look && n > kGjBlock) {
+        if (look && !mfma && n > kGjBlock) {
             hipLaunchKernelGGL(gj_pivot_prepare, dim3(1), dim3(256), 0, s, n, 0, std::min(kGjBlock, n - kGjBlock), (const double *)src, side);
         }
-        for (int k = 0; k < n;) {
+        for (int k = mfma ? n : 0; k < n;) {
             const int left = n - k;
             // the last step writes the finished inverse where it stays
             if (fused && left > kGjBlock) {

@@ -471,6 +471,7 @@ def test_two_pivot_blocks_per_launch_of_the_dense_inverse_are_the_same_bits(ctx,
     to a random vector with the same bits, for coarsest levels of a handful to ~1100 unknowns (odd and even numbers of
     pivot blocks, a last block of fewer than 16 pivots)."""
     monkeypatch.setenv("PADNE_AMG_F64", "1")
+    monkeypatch.setenv("PADNE_GJ_VECTOR", "1")      # (the default form runs on the matrix cores: its own test below)
     if coarse_n is not None:
         monkeypatch.setenv("PADNE_AMG_COARSE_N", str(coarse_n))
     sysm = synthetic.layered_system(layers, nx, ny, via_lattice=5)
@@ -490,7 +491,11 @@ def test_two_pivot_blocks_per_launch_of_the_dense_inverse_are_the_same_bits(ctx,
         z = d.amg_apply(probe)
         d.close()
         return res, n_coarse, z
-    two, n_two, z_two = run(ctx)
+    other = _hip.Context(0)
+    try:
+        two, n_two, z_two = run(other)
+    finally:
+        other.close()
     for switch in ("PADNE_GJ_NO_LOOKAHEAD", "PADNE_GJ_ONE_STEP"):
         monkeypatch.setenv(switch, "1")
         other = _hip.Context(0)
@@ -502,6 +507,50 @@ def test_two_pivot_blocks_per_launch_of_the_dense_inverse_are_the_same_bits(ctx,
         assert one.levels == two.levels and one.iterations == two.iterations
         assert np.array_equal(z_one, z_two) and np.array_equal(one.x, two.x), f"{switch}: coarsest level of {n_one} unknowns"
     assert np.linalg.norm(A @ two.x - b) <= 1e-11 * np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("layers,nx,ny,coarse_n", [(2, 180, 150, None), (2, 180, 150, 200), (8, 240, 200, None), (3, 90, 70, 400),
+                                                  (8, 400, 330, None)])
+def test_dense_inverse_on_the_matrix_cores_against_the_vector_kernels(monkeypatch, layers, nx, ny, coarse_n):
+    """Default form of the coarsest-level inverse: 64 pivots per launch, the rank-64 updates as v_mfma_f64_16x16x4_f64 products
+    (`gj64_step`), the next pivot block inverted by workgroup 0 of the launch before.  Against the vector kernels
+    (PADNE_GJ_VECTOR=1): the sums are formed in another order, so the double-precision cycle built on either inverse agrees to
+    rounding times the conditioning of the coarsest operator -- not bit for bit --, the solves take the same iterations and give
+    the same potentials; coarsest levels from 65 unknowns (below that the vector kernels run anyway) to ~1900, sizes that are
+    and are not multiples of 64 and of the 96 x 32 tile."""
+    monkeypatch.setenv("PADNE_AMG_F64", "1")
+    if coarse_n is not None:
+        monkeypatch.setenv("PADNE_AMG_COARSE_N", str(coarse_n))
+    sysm = synthetic.layered_system(layers, nx, ny, via_lattice=5)
+    els = [("R", int(a), int(b), float(r)) for a, b, r in zip(*sysm.resistors)]
+    els += [("I", int(f), int(t), float(i)) for f, t, i in zip(*sysm.current_sources)]
+    Lo, ro = O.assemble_system([(m[0], m[1], m[2]) for m in sysm.meshes], 0, els, 0)
+    n = sysm.n_vertices
+    A = (-Lo[1:n, 1:n]).tocsr()
+    A.sort_indices()
+    b = -ro[1:n]
+    probe = np.random.default_rng(7).uniform(-1, 1, n - 1)
+
+    def run():
+        c = _hip.Context(0)
+        try:
+            d = c.csr_from_scipy(A)
+            res = d.solve_spd(b, precond="amg", rtol=1e-12)
+            n_coarse = d.amg_shapes()[-1]["A"][0]
+            z = d.amg_apply(probe)
+            d.close()
+        finally:
+            c.close()
+        return res, n_coarse, z
+    cores, n_cores, z_cores = run()
+    monkeypatch.setenv("PADNE_GJ_VECTOR", "1")
+    vec, n_vec, z_vec = run()
+    assert n_cores == n_vec and 64 < n_vec <= 2048, n_vec
+    assert cores.levels == vec.levels and abs(cores.iterations - vec.iterations) <= 1
+    assert np.abs(z_cores - z_vec).max() <= 1e-9 * np.abs(z_vec).max(), f"coarsest level of {n_vec} unknowns"
+    assert not np.array_equal(z_cores, z_vec), "the switch changed nothing: which kernels ran?"
+    assert np.abs(cores.x - vec.x).max() <= 1e-9 * np.abs(vec.x).max()
+    assert np.linalg.norm(A @ cores.x - b) <= 1e-11 * np.linalg.norm(b)
 
 
 def test_fused_up_leg_of_the_fine_level_is_the_same_cycle(ctx, monkeypatch):
