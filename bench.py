@@ -353,6 +353,13 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         t_spmv = prof.spmv_seconds
+        # the product of the multigrid-preconditioned loop on one GPU multiplies a search direction STORED in single precision
+        # (pcg.hip): 4 instead of 8 bytes of x per row; the standalone launches (and every other path) multiply doubles
+        p_stored_f32 = (args.precond == "amg" and not distributed_path and "PADNE_PCG_P64" not in os.environ
+                        and "PADNE_AMG_F64" not in os.environ)
+        spmv_bytes_standalone = spmv_bytes
+        if p_stored_f32:
+            spmv_bytes = spmv_bytes - 4 * n_local
         achieved = spmv_bytes / t_spmv / 1e9 if t_spmv > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "spmv_traffic.json")
@@ -387,7 +394,8 @@ def main():
             "pcg_textbook_gbs": (232.0 * n_local * last.iterations / last.seconds / 1e9
                                  if last.seconds > 0 and args.precond == "jacobi" else None),
             "setup_seconds": {"total": t_setup, "assemble": t_assemble, "reduce": t_reduce},
-            "roofline": {"bound": "hbm", "kernel": "csr_spmv_kernel<SPMV_DOT, double, double, double> (q = A p with p.q epilogue)",
+            "roofline": {"bound": "hbm", "kernel": "csr_spmv_kernel<SPMV_DOT, double, double, double" +
+                                                   (", x stored as float" if p_stored_f32 else "") + "> (q = A p with p.q epilogue)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_static_from": "profiles/spmv_traffic.json (rocprofv3 --pmc passes of the round's final build, "
@@ -395,7 +403,9 @@ def main():
                          "bytes_per_launch": int(spmv_bytes), "seconds_per_launch": t_spmv,
                          "note": "achieved/frac: kernel timed in situ inside the CG loop; standalone_frac: the same "
                                  "kernel launched back to back (no dirty predecessor)",
-                         "standalone_frac": (spmv_bytes / t_standalone / 1e9 / HBM_PEAK_GBS) if t_standalone else None},
+                         "bytes_rule": ("12 nnz + 16 n + 4 (values 8 + columns 4 per non-zero; row pointer 4, x 4, y 8 per row)"
+                                        if p_stored_f32 else "12 nnz + 20 n + 4 (values 8 + columns 4 per non-zero; row pointer 4, x 8, y 8 per row)"),
+                         "standalone_frac": (spmv_bytes_standalone / t_standalone / 1e9 / HBM_PEAK_GBS) if t_standalone else None},
         }
         if hierarchy_shapes is not None:
             try:

@@ -208,6 +208,8 @@ int launch_spmm_f32_exit(padne_ctx *ctx, const padne_csr *m, int k, const float 
 int launch_spmm_f32_wup_exit(padne_ctx *ctx, const padne_csr *w, int k, const float *e, double *z, const double *dot_with,
                              double *partials, const int32_t *done_flag, const float *x_pre, const float *r_pre,
                              const float *dinv32, float scale, const double *out_scale2);
+bool spmv_x32_ok(const padne_csr *m);
+int launch_spmv_dot_x32(padne_ctx *ctx, const padne_csr *m, const float *x, double *y, double *partials, const int32_t *done_flag);
 int launch_spmv_f32_wup(padne_ctx *ctx, const padne_csr *w, const float *e, float *x_out, const int32_t *done_flag,
                         const float *x_pre, const float *r_pre, const float *dinv32, float scale);
 int launch_spmm_f32_wup(padne_ctx *ctx, const padne_csr *w, int k, const float *e, float *x_out, const int32_t *done_flag,

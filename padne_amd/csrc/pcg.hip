@@ -231,16 +231,18 @@ __global__ __launch_bounds__(256) void pcg_update_xr_entry_kernel(
     const long long n, const double *__restrict__ part_rz, const int P_rz, const double *__restrict__ part_pq,
     const int P_pq, const double *__restrict__ p, const double *__restrict__ q, double *__restrict__ x,
     double *__restrict__ r, double *__restrict__ part_rr, PcgStatus *__restrict__ st, const double *__restrict__ bb2,
-    const float c, const float *__restrict__ dinv32, float *__restrict__ b32, float *__restrict__ xa32) {
+    const float c, const float *__restrict__ dinv32, float *__restrict__ b32, float *__restrict__ xa32, const int p_hat) {
     __shared__ double red[4];
     const int stop = st->done;              // written by an EARLIER launch: every workgroup of this one reads the same value
     if (blockIdx.x == 0 && threadIdx.x == 0) st->done_seen = stop;
     if (stop) return;
     const double rz = block_total(part_rz, P_rz, red);
     const double pq = block_total(part_pq, P_pq, red);
-    const double alpha = rz / pq;
     const double s2 = *bb2;
     const double s_inv = s2 > 0.0 ? 1.0 / sqrt(s2) : 1.0;
+    // p_hat: the search direction is stored as p / ||b|| in single precision (solve_one), q and p.q are those of the stored
+    // vector: the step along it is alpha ||b||
+    const double alpha = p_hat ? rz / (pq * (s2 > 0.0 ? sqrt(s2) : 1.0)) : rz / pq;
     double s_rr = 0.0;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const double ri = r[i] - alpha * q[i];
@@ -254,12 +256,21 @@ __global__ __launch_bounds__(256) void pcg_update_xr_entry_kernel(
     block_store_partial(s_rr, red, part_rr + blockIdx.x);
 }
 
+// p^ = z / ||b|| in single precision (the first search direction of a (re)start)
+__global__ void p_hat_from_z_kernel(const long long n, const double *__restrict__ z, const double *__restrict__ bb2, float *__restrict__ p32) {
+    const double s2 = *bb2;
+    const double s_inv = s2 > 0.0 ? 1.0 / sqrt(s2) : 1.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        p32[i] = (float)(z[i] * s_inv);
+}
+
 // beta = rz'/rz ; p = z + beta p ; bookkeeping
 __global__ __launch_bounds__(256) void pcg_update_p_z_kernel(
     const long long n, const double *__restrict__ part_rz_new, const double *__restrict__ part_rz_old,
     const int P_rz, const double *__restrict__ part_rr, const int P_rr, const double *__restrict__ part_pq,
     const int P_pq, const double *__restrict__ z, double *__restrict__ p, PcgStatus *__restrict__ st,
-    const int max_iter, double *__restrict__ x_deferred, const float *__restrict__ z32, const double *__restrict__ bb2) {
+    const int max_iter, double *__restrict__ x_deferred, const float *__restrict__ z32, const double *__restrict__ bb2,
+    float *__restrict__ p32) {
     __shared__ double red[4];
     // NOT st->done: workgroup 0 of this very launch sets it, and this kernel carries the deferred x += alpha p -- a
     // workgroup dispatched after that store would skip its slice of the last update.  done_seen is what the x/r update of
@@ -274,10 +285,23 @@ __global__ __launch_bounds__(256) void pcg_update_p_z_kernel(
         const double s2 = *bb2;
         const double z_mul = s2 > 0.0 ? sqrt(s2) : 1.0;
         const double alpha = rz_old / block_total(part_pq, P_pq, red);
-        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-            const double pi = p[i];
-            x_deferred[i] += alpha * pi;
-            p[i] = (double)z32[i] * z_mul + beta * pi;
+        if (p32 != nullptr) {
+            // the search direction is KEPT in single precision, in the units of the cycle (p^ = p / ||b||, like z32: right-hand
+            // sides of 1e-30 A or 1e+30 A stay in range): q = A p^ was formed from this very float, so x += alpha^ p^ and
+            // r -= alpha^ q (alpha^ = alpha ||b||) stay consistent to double rounding; what the rounding of p costs is conjugacy
+            // at the 1e-7 level, which the cycle's own single precision costs already
+            const double alpha_hat = alpha / z_mul;
+            for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+                const double pi = (double)p32[i];
+                x_deferred[i] += alpha_hat * pi;
+                p32[i] = (float)((double)z32[i] + beta * pi);
+            }
+        } else {
+            for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+                const double pi = p[i];
+                x_deferred[i] += alpha * pi;
+                p[i] = (double)z32[i] * z_mul + beta * pi;
+            }
         }
     } else if (x_deferred != nullptr) {
         // x += alpha p of this iteration (the alpha pcg_update_xr_entry_kernel applied to r), with the p that is about to be
@@ -580,6 +604,9 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
     const bool fuse_entry = amg && amg_f32_entry_args(prec, &e_jac, &e_dinv32, &e_b32, &e_xa32);
     const bool defer_x = fuse_entry;      // x += alpha p rides on the p update (12 us per iteration at 10 M unknowns)
     float *z32 = defer_x && !dist && !halo ? (float *)z : nullptr;      // z of the loop: single precision, in z's own memory
+    // ... and the search direction with it: p is stored as floats (in p's own memory), multiplied in double (csr_spmv_kernel
+    // <..., float>): 8 bytes per row less in q = A p and in the p update, the same iteration counts (scripts/exp_p32.py)
+    float *p32 = z32 != nullptr && spmv_x32_ok(a) ? (float *)p : nullptr;
 
     PADNE_HIP_CHECK(hipMemsetAsync(st, 0, sizeof(PcgStatus), s));
     if (halo) PADNE_HIP_CHECK(hipMemsetAsync(p + n, 0, sizeof(double) * (size_t)(nc - n), s));
@@ -621,7 +648,12 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
             PADNE_TRY(fold(slot(ctx, SLOT_RR), gv, kMaxPartials, 2, scal + S_RR));   // RR, BB adjacent
             PADNE_TRY(allreduce(scal + S_RR, 2));
             PADNE_TRY(amg_apply(ctx, prec, r, z, slot(ctx, SLOT_RZ0), nullptr, bb_scalar));
-            PADNE_HIP_CHECK(hipMemcpyAsync(p, z, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+            if (p32 != nullptr) {
+                hipLaunchKernelGGL(p_hat_from_z_kernel, dim3(gv), dim3(256), 0, s, n, (const double *)z, bb_scalar, p32);
+                PADNE_HIP_CHECK(hipGetLastError());
+            } else {
+                PADNE_HIP_CHECK(hipMemcpyAsync(p, z, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+            }
         } else {
             hipLaunchKernelGGL(pcg_init_kernel, dim3(gv), dim3(256), 0, s, n, b, have_ax ? q : nullptr, a->dinv, r, p,
                                slot(ctx, SLOT_RZ0), slot(ctx, SLOT_RR), slot(ctx, SLOT_BB));
@@ -660,7 +692,8 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
                     ev_b.push_back(e1);
                     PADNE_HIP_CHECK(hipEventRecord(e0, s));
                 }
-                PADNE_TRY(halo_product_dot(ctx, a, p, q, slot(ctx, SLOT_PQ), &st->done));
+                if (p32 != nullptr) PADNE_TRY(launch_spmv_dot_x32(ctx, a, p32, q, slot(ctx, SLOT_PQ), &st->done));
+                else PADNE_TRY(halo_product_dot(ctx, a, p, q, slot(ctx, SLOT_PQ), &st->done));
                 if (sampled) PADNE_HIP_CHECK(hipEventRecord(ev_b.back(), s));
                 if (dist) {
                     PADNE_TRY(fold(slot(ctx, SLOT_PQ), gs, kMaxPartials, 1, scal + S_PQ));
@@ -670,7 +703,7 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
                     if (fuse_entry)
                         hipLaunchKernelGGL(pcg_update_xr_entry_kernel, dim3(gv), dim3(256), 0, s, n, rz_old, Pz, pq, Pq, p, q,
                                            defer_x ? (double *)nullptr : x, r, slot(ctx, SLOT_RR), st, bb_scalar, e_jac, e_dinv32,
-                                           e_b32, e_xa32);
+                                           e_b32, e_xa32, p32 != nullptr ? 1 : 0);
                     else
                         hipLaunchKernelGGL(pcg_update_xr_plain_kernel, dim3(gv), dim3(256), 0, s, n, rz_old, Pz, pq, Pq, p, q,
                                            x, r, slot(ctx, SLOT_RR), st);
@@ -683,7 +716,7 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
                     }
                     hipLaunchKernelGGL(pcg_update_p_z_kernel, dim3(gv), dim3(256), 0, s, n, rz_new, rz_old, Pz, rr, Pr,
                                        pq, Pq, z, p, st, max_iter - total_iters, defer_x ? x : (double *)nullptr,
-                                       (const float *)z32, bb_scalar);
+                                       (const float *)z32, bb_scalar, p32);
                 } else {
                     hipLaunchKernelGGL(pcg_update_xr_kernel, dim3(gv), dim3(256), 0, s, n, rz_old, Pz, pq, Pq, p, q,
                                        a->dinv, x, r, slot(ctx, rz_new_slot), slot(ctx, SLOT_RR), st);

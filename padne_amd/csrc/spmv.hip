@@ -78,8 +78,8 @@ constexpr int kWaveChunk = 64 * kEpl;   // non-zeros parked in LDS per wave per 
 // 16-bit ones in pairs, 8-bit ones in fours -- and one or two 16-byte loads of G values), products parked in the
 // wave's LDS slice, one lane per row summing its segment in CSR order.  A pass starts on a multiple of G; the stray
 // elements in front of k0 or behind k1 are multiplied like the others but never summed (both arrays are padded).
-template <int G, typename IT, typename VT, typename XT>
-__device__ __forceinline__ XT xw_stream_tile(const VT *__restrict__ vals, const IT *__restrict__ lidx, const XT *xs, XT *prod,
+template <int G, typename IT, typename VT, typename XT, typename ST = XT>      // ST: the type x is stored in (float under a double product: pcg.hip)
+__device__ __forceinline__ XT xw_stream_tile(const VT *__restrict__ vals, const IT *__restrict__ lidx, const ST *xs, XT *prod,
                                              const int k0, const int k1, const int rs, const int re, const int lane,
                                              const int top) {
     static_assert(G * sizeof(IT) == 4, "one index word per lane and load");
@@ -107,7 +107,7 @@ __device__ __forceinline__ XT xw_stream_tile(const VT *__restrict__ vals, const 
 #pragma unroll
             for (int t = 0; t < G; ++t) {
                 const int pos = min((int)((cw[j] >> (8 * sizeof(IT) * t)) & ((1u << (8 * sizeof(IT))) - 1u)), top);
-                prod[G * lane + 64 * G * j + t] = (XT)vg[j].v[t] * xs[pos];
+                prod[G * lane + 64 * G * j + t] = (XT)vg[j].v[t] * (XT)xs[pos];
             }
         }
         // same-wave LDS traffic is processed in issue order; keep the compiler from reordering
@@ -135,8 +135,8 @@ __device__ __forceinline__ XT xw_stream_tile(const VT *__restrict__ vals, const 
 // one or two of values) instead of eight 4-byte loads of each, x gathered from global memory, products parked four at a time.
 // A pass starts on a multiple of 4; stray elements in front of k0 / behind k1 are multiplied (their columns are valid: both
 // arrays are padded with column 0 / value 0) but never summed.  Same products, same order of the row sums.
-template <typename VT, typename XT, int EPL>
-__device__ __forceinline__ XT gather_stream_tile(const int *__restrict__ cols, const VT *__restrict__ vals, const XT *__restrict__ x,
+template <typename VT, typename XT, int EPL, typename ST = XT>
+__device__ __forceinline__ XT gather_stream_tile(const int *__restrict__ cols, const VT *__restrict__ vals, const ST *__restrict__ x,
                                                  XT *prod, const int k0, const int k1, const int rs, const int re, const int lane) {
     constexpr int G = 4, NJ = EPL / G, CHUNK = 64 * EPL;
     struct alignas(16) VG { VT v[G]; };
@@ -160,10 +160,10 @@ __device__ __forceinline__ XT gather_stream_tile(const int *__restrict__ cols, c
             const int e = base + G * lane + 64 * G * j;
             XT xv[G] = {0, 0, 0, 0};
             if (e < k1) {
-                xv[0] = x[cw[j].x];
-                xv[1] = x[cw[j].y];
-                xv[2] = x[cw[j].z];
-                xv[3] = x[cw[j].w];
+                xv[0] = (XT)x[cw[j].x];
+                xv[1] = (XT)x[cw[j].y];
+                xv[2] = (XT)x[cw[j].z];
+                xv[3] = (XT)x[cw[j].w];
             }
 #pragma unroll
             for (int t = 0; t < G; ++t) prod[G * lane + 64 * G * j + t] = (XT)vg[j].v[t] * xv[t];
@@ -261,11 +261,15 @@ __device__ __forceinline__ void stage_windows_wide(const XT *__restrict__ x, con
 // copies of its operators: 8 instead of 12 bytes per non-zero, half the vector traffic), and its last stage
 // <float, float, double> hands z back to CG in double, multiplied by sqrt(*out_scale2) (the cycle works on
 // r / ||b||, see amg.hip) and with the r.z partials taken against the double residual `dot_with`.
-template <int MODE, typename VT, typename XT, typename YT, bool LIST = false, bool LONG = false, bool WIDE = false>
+// ST (default XT): the type the multiplied vector is STORED in.  <SPMV_DOT, double, double, double, ..., float> is the CG loop's
+// q = A p with the search direction kept in single precision (pcg.hip): staged and gathered as floats, multiplied in double,
+// and the p.q partials taken against x itself.
+template <int MODE, typename VT, typename XT, typename YT, bool LIST = false, bool LONG = false, bool WIDE = false,
+          typename ST = XT>
 __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
     const int n_rows, const int n_cols, const int n_wtiles, const int *__restrict__ rowptr,
     const int *__restrict__ cols, const VT *__restrict__ vals,
-    const XT *__restrict__ x, YT *__restrict__ y,
+    const ST *__restrict__ x, YT *__restrict__ y,
     const double *__restrict__ dot_with, double *__restrict__ partials,
     const int *__restrict__ done_flag, const XT *__restrict__ aux1,
     const XT *__restrict__ aux2, const XT scale, const double *__restrict__ out_scale2,
@@ -283,14 +287,14 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
     static_assert(!LONG || sizeof(XT) == 4, "16 elements per lane only for single-precision vectors");
     __shared__ XT prod_all[4 * 64 * kEplGather];
     extern __shared__ __attribute__((aligned(16))) unsigned char xs_dyn[];      // 4 * kXwRuns * xw_run entries of XT when the plan is in use
-    XT *xs_all = reinterpret_cast<XT *>(xs_dyn);
+    ST *xs_all = reinterpret_cast<ST *>(xs_dyn);
     __shared__ double red[4];
 
     if (done_flag != nullptr && *done_flag != 0) return;
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     XT *prod = prod_all + w * 64 * kEplGather;
-    XT *xs = xs_all + w * (WIDE ? kXwRunsWide * kXwRunWide : kXwRuns * xw_run);
+    ST *xs = xs_all + w * (WIDE ? kXwRunsWide * kXwRunWide : kXwRuns * xw_run);
     double out_mul = 1.0;
     if (out_scale2 != nullptr) {
         const double s2 = *out_scale2;
@@ -332,21 +336,21 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
         XT acc = 0;
         const bool windowed = xw_desc != nullptr && d.w != 0;      // wave-uniform
         if (WIDE && windowed) {
-            stage_windows_wide<XT>(x, n_cols, wide_mine, xs, lane);
-            acc = xw_stream_tile<4, unsigned char, VT, XT>(vals, (const unsigned char *)xw_lidx, xs, prod, k0, k1, rs, re, lane,
-                                                           kXwRunsWide * kXwRunWide - 1);
+            stage_windows_wide<ST>(x, n_cols, wide_mine, xs, lane);
+            acc = xw_stream_tile<4, unsigned char, VT, XT, ST>(vals, (const unsigned char *)xw_lidx, xs, prod, k0, k1, rs, re, lane,
+                                                               kXwRunsWide * kXwRunWide - 1);
         } else if (windowed) {
             // the tile's runs of x (stage_windows; the stream loops wait for these LDS stores before their first read)
-            if (xw_run <= kXwRunShort) stage_windows<kXwRunShort, XT>(x, n_cols, d, xs, lane);
-            else stage_windows<kXwRunLong, XT>(x, n_cols, d, xs, lane);
+            if (xw_run <= kXwRunShort) stage_windows<kXwRunShort, ST>(x, n_cols, d, xs, lane);
+            else stage_windows<kXwRunLong, ST>(x, n_cols, d, xs, lane);
             const int top = kXwRuns * xw_run - 1;
             // three runs of 72 are 216 positions: one byte each, four non-zeros per lane and load; runs of 128 need 16 bits
             if (xw_run <= kXwRunShort)
-                acc = xw_stream_tile<4, unsigned char, VT, XT>(vals, (const unsigned char *)xw_lidx, xs, prod, k0, k1, rs, re, lane, top);
+                acc = xw_stream_tile<4, unsigned char, VT, XT, ST>(vals, (const unsigned char *)xw_lidx, xs, prod, k0, k1, rs, re, lane, top);
             else
-                acc = xw_stream_tile<2, unsigned short, VT, XT>(vals, (const unsigned short *)xw_lidx, xs, prod, k0, k1, rs, re, lane, top);
+                acc = xw_stream_tile<2, unsigned short, VT, XT, ST>(vals, (const unsigned short *)xw_lidx, xs, prod, k0, k1, rs, re, lane, top);
         } else if (k1 > k0) {
-            acc = gather_stream_tile<VT, XT, kEplGather>(cols, vals, x, prod, k0, k1, rs, re, lane);
+            acc = gather_stream_tile<VT, XT, kEplGather, ST>(cols, vals, x, prod, k0, k1, rs, re, lane);
         }
         if (r < row1) {
             if (MODE == SPMV_PLAIN) {
@@ -356,7 +360,8 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
                 y2[r] = scale * aux2[r] * acc;
             } else if (MODE == SPMV_DOT || MODE == SPMV_DOT_AUX) {
                 y[r] = (YT)acc;
-                dot_acc += dot_with[r] * (double)acc;
+                if (sizeof(ST) != sizeof(XT)) dot_acc += (double)x[r] * (double)acc;      // p.q with the stored p
+                else dot_acc += dot_with[r] * (double)acc;
             } else if (MODE == SPMV_RESID) {
                 y[r] = (YT)(aux1[r] - acc);
             } else if (MODE == SPMV_ADD) {
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
                 }
             } else {
                 const XT b = aux1[r];
-                const XT out = x[r] + scale * aux2[r] * (b - acc);
+                const XT out = (XT)x[r] + scale * aux2[r] * (b - acc);
                 if (dot_with != nullptr) {
                     const double outd = (double)out * out_mul;
                     y[r] = sizeof(YT) == 4 ? (YT)out : (YT)outd;
@@ -610,6 +615,29 @@ static int launch_spmv_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals,
 #undef PADNE_SPMV_LAUNCH_LIST
 #undef PADNE_SPMV_ARGS
 #undef PADNE_SPMV_LAUNCH
+    PADNE_HIP_CHECK(hipGetLastError());
+    return PADNE_OK;
+}
+
+// q = A p with p stored in single precision, p.q partials (one GPU, no split plan; same grid and partial layout as the
+// double form).  false from spmv_x32_ok: the caller keeps p in double.
+bool spmv_x32_ok(const padne_csr *m) {
+    return m->vals != nullptr && !split_in_use(m) && !use_wave_per_row(m) && !(m->xw_state == 1 && m->xw_nruns == kXwRunsWide) &&
+           getenv("PADNE_PCG_P64") == nullptr;
+}
+int launch_spmv_dot_x32(padne_ctx *ctx, const padne_csr *m, const float *x, double *y, double *partials, const int32_t *done_flag) {
+    PADNE_REQUIRE(spmv_x32_ok(m), "single-precision search direction on this operator");
+    if (m->n_rows == 0) return PADNE_OK;
+    const int n_tiles = (int)((m->n_rows + 63) / 64);
+    const int g = spmv_grid(m);      // (= spmv_partials: the consumers of the p.q partials count on it)
+    const size_t xs_bytes = m->xw_state == 1 ? sizeof(float) * 4 * kXwRuns * (size_t)m->xw_run : 0;
+    const int4 *xw_desc = m->xw_state == 1 ? m->xw_desc : nullptr;
+    const void *xw_lidx = m->xw_state == 1 ? (const void *)m->xw_lidx : nullptr;
+    hipLaunchKernelGGL((csr_spmv_kernel<SPMV_DOT, double, double, double, false, false, false, float>), dim3(g), dim3(kSpmvThreads),
+                       xs_bytes, ctx->stream, (int)m->n_rows, (int)m->n_cols, n_tiles, m->rowptr, m->cols, m->vals, x, y,
+                       (const double *)nullptr, partials, done_flag, (const double *)nullptr, (const double *)nullptr, 0.0,
+                       (const double *)nullptr, xw_desc, xw_lidx, m->xw_run, (const double *)nullptr, (double *)nullptr,
+                       (const int *)nullptr, 0, 0);
     PADNE_HIP_CHECK(hipGetLastError());
     return PADNE_OK;
 }

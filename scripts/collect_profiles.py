@@ -46,10 +46,10 @@ for row in csv.DictReader(open(f"{F}/stats/run_kernel_trace.csv")):
         per[int(row.get("Grid_Size_X", row.get("Grid_Size", 0)))].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
 st = [r for r in csv.DictReader(open(f"{F}/stats/run_kernel_stats.csv")) if "csr_spmv_kernel<1, double, double, double" in r["Name"]][0]
 rec = {"source": "rocprofv3 --kernel-trace --stats --output-format csv of `python bench.py --no-cpu-baseline` (profiles/" + RD + "_bench_c4_amg_kernel_stats.csv is the --stats table of the same run)",
-       "kernel": "padne::csr_spmv_kernel<SPMV_DOT = 1, double, double, double>  (the CG loop's q = A p; the Lanczos estimates of the setup use the twin instantiation <5, ...>)",
+       "kernel": "padne::csr_spmv_kernel<SPMV_DOT = 1, double, double, double, ..., float>  (the CG loop's q = A p with p stored in single precision; the Lanczos estimates of the setup use the twin instantiation <5, ...>)",
        "stats": {"calls": int(st["Calls"]), "average_us": float(st["AverageNs"]) / 1e3, "min_us": float(st["MinNs"]) / 1e3, "max_us": float(st["MaxNs"]) / 1e3},
        "by_grid": {str(g): {"launches": len(v), "mean_us": sum(v) / len(v)} for g, v in per.items()},
-       "algorithmic_bytes_per_launch": 1039450524,
-       "achieved_GBs_from_stats_average": 1039450524 / (float(st["AverageNs"]) * 1e-9) / 1e9}
+       "algorithmic_bytes_per_launch": 999452960,      # 12 nnz + 16 n + 4: p is stored in single precision since the second half of round 4
+       "achieved_GBs_from_stats_average": 999452960 / (float(st["AverageNs"]) * 1e-9) / 1e9}
 json.dump(rec, open(os.path.join(P, RD + "_spmv_dot_by_level.json"), "w"), indent=1)
 print(json.dumps(rec["stats"]), rec["achieved_GBs_from_stats_average"])

@@ -693,6 +693,36 @@ def test_multigrid_preconditioner_is_symmetric_positive_definite(ctx, monkeypatc
         assert np.abs(d64.amg_apply(r1) - z1).max() <= 2e-5 * np.abs(z1).max()
 
 
+def test_search_direction_stored_in_single_precision_solves_the_same_system(monkeypatch):
+    """On one GPU the multigrid-preconditioned loop keeps its search direction as p / ||b|| in single precision
+    (`csr_spmv_kernel<SPMV_DOT, double, double, double, ..., float>` multiplies it in double; x += alpha p and r -= alpha A p
+    use the very same stored vector, so b - A x is tracked to double rounding).  Against PADNE_PCG_P64=1 (p in double): the
+    same iteration count (one either way), the same potentials to the solve tolerance, a true residual at the tolerance -- on
+    a system with an x-window plan and on one without (gather path), and with right-hand sides of 1e-30 and 1e+30 A."""
+    cases = [layered_spd(2, 70, 60, 4), layered_spd(3, 260, 200, 5)]
+
+    def run(A, b):
+        c = _hip.Context(0)
+        try:
+            d = c.csr_from_scipy(A)
+            out = [d.solve_spd(b * s, precond="amg", rtol=1e-12) for s in (1.0, 1e-30, 1e30)]
+            d.close()
+        finally:
+            c.close()
+        return out
+    for A, b, _, _, _ in cases:
+        f32 = run(A, b)
+        monkeypatch.setenv("PADNE_PCG_P64", "1")
+        f64 = run(A, b)
+        monkeypatch.delenv("PADNE_PCG_P64")
+        for a, c, s in zip(f32, f64, (1.0, 1e-30, 1e30)):
+            assert a.precond_fallbacks == 0 and c.precond_fallbacks == 0
+            assert abs(a.iterations - c.iterations) <= 1, (a.iterations, c.iterations)
+            assert np.abs(a.x - c.x).max() <= 1e-9 * np.abs(c.x).max()
+            assert np.linalg.norm(A @ a.x - b * s) <= 2e-12 * np.linalg.norm(b * s)
+        assert not np.array_equal(f32[0].x, f64[0].x), "the switch changed nothing"
+
+
 def test_single_precision_cycle_is_independent_of_the_units_of_the_system(ctx):
     """The cycle input is normalised by ||b||, so right-hand sides of 1e-30 A or 1e+30 A converge like 1 A ones."""
     A, b, _, _, _ = layered_spd(2, 70, 60, 4)
