@@ -1243,18 +1243,25 @@ __global__ __launch_bounds__(128) void spgemm_rows_lds(int n_rows, const int *__
 // indexed by unrolled constants only.  Same products in the same order: bit-identical lists.  (Round 2 had tried ALL loads
 // of a row up front: 212 VGPRs, two waves per SIMD, no gain; this form needs 90.)
 
+// `begin` (may be null): the rows of a wave's 64-row tile are written BACK TO BACK from the start of the tile's slot range
+// instead of each into its own range of product-count size -- the merged rows are a third of their products (5.2 of 17 on
+// the fine level of C4), and what reads them afterwards (R (A P) by rows, the W build) touched every line of a 2.6 GB arena
+// for 0.83 GB of entries.  begin[i] receives the row's place; a row that overflows its list (redone later, up to its product
+// count long) gets its place from the END of the tile's range: merged lengths from the front and product counts from the
+// back cannot meet, their sum is at most the range.
 template <int CAP, int KC, int QC, int YCS>
 __global__ __launch_bounds__(128) void spgemm_rows_lds_pipe(int n_rows, const int *__restrict__ xr, const int *__restrict__ xc,
                                                             const double *__restrict__ xv, const int *__restrict__ yr,
                                                             const int *__restrict__ yc, const double *__restrict__ yv,
                                                             const int *__restrict__ ye, const int *__restrict__ slot_ptr,
                                                             long long *__restrict__ key, double *__restrict__ val,
-                                                            int *__restrict__ row_len) {
+                                                            int *__restrict__ row_len, int *__restrict__ begin) {
     __shared__ int Kc[CAP][128];
     __shared__ double Vc[CAP][128];
     const int t = threadIdx.x;
     const int i = xcd_bid() * 128 + t;
-    if (i >= n_rows) return;
+    const bool live = i < n_rows;
+    if (begin == nullptr && !live) return;
     int m = 0;
     bool overflow = false;
     auto insert = [&](const int c, const double v) {
@@ -1274,7 +1281,7 @@ __global__ __launch_bounds__(128) void spgemm_rows_lds_pipe(int n_rows, const in
             ++m;
         }
     };
-    const int x0 = xr[i], x1 = xr[i + 1];
+    const int x0 = live ? xr[i] : 0, x1 = live ? xr[i + 1] : 0;
     for (int kb = x0; kb < x1 && !overflow; kb += KC) {
         const int nk = min(KC, x1 - kb);
         int mid[KC], ys[KC], ln[KC];
@@ -1329,12 +1336,33 @@ __global__ __launch_bounds__(128) void spgemm_rows_lds_pipe(int n_rows, const in
                 insert(yc[(long long)(ys[u] + q) * YCS], a[u] * yv[ys[u] + q]);
         }
     }
+    int place = live ? slot_ptr[i] : 0;
+    if (begin != nullptr) {
+        // (every lane of the wave is here: the tile's rows back to back, the overflowed ones from the end of its range)
+        const int lane = t & 63;
+        const int tile0 = i - lane, tile1 = min(tile0 + 64, n_rows);
+        const int len = (live && !overflow) ? m : 0;
+        const int bound = (live && overflow) ? slot_ptr[i + 1] - slot_ptr[i] : 0;
+        int incl = len, back = bound;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int a1 = __shfl_up(incl, d, 64), b1 = __shfl_down(back, d, 64);
+            if (lane >= d) incl += a1;
+            if (lane + d < 64) back += b1;
+        }
+        if (tile0 < n_rows) {
+            const int r_begin = slot_ptr[tile0], r_end = slot_ptr[tile1];
+            place = overflow ? r_end - back : r_begin + (incl - len);
+        }
+        if (live) begin[i] = place;
+    }
+    if (!live) return;
     if (overflow) {
         row_len[i] = -1;                                   // redo in global memory
         return;
     }
-    long long *K = key + slot_ptr[i];
-    double *V = val + slot_ptr[i];
+    long long *K = key + place;
+    double *V = val + place;
     for (int u = 0; u < m; ++u) {
         K[u] = (long long)Kc[u][t] << 32;
         V[u] = Vc[u][t];
@@ -3172,6 +3200,7 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
     if (amg_verbose()) fprintf(stderr, "[amg]   spgemm %lld rows, %lld product slots\n", (long long)n, (long long)n_slots);
     long long *key = nullptr;
     double *val = nullptr;
+    int *row_begin = nullptr;      // where the rows start when that is not slot_ptr (spgemm_rows_lds_pipe)
     PADNE_TRY(sc.alloc(&key, (size_t)n_slots + 4));      // (+4: kernels that read a row four slots at a time, as the Y of a later product)
     PADNE_TRY(sc.alloc(&val, (size_t)n_slots + 4));
     if (n > 0) {
@@ -3190,14 +3219,32 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
             if (getenv("PADNE_SPGEMM_NO_PIPE") != nullptr)
                 hipLaunchKernelGGL(spgemm_rows_lds<16>, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
                                    y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len);
-            else if (y_cs == 1)
-                hipLaunchKernelGGL((spgemm_rows_lds_pipe<12, 9, 4, 1>), dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols,
-                                   X->vals, y_begin, y_cols, y_vals, y_end, slot_ptr, key, val, row_len);
-            else
-                hipLaunchKernelGGL((spgemm_rows_lds_pipe<12, 9, 4, 2>), dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols,
-                                   X->vals, y_begin, y_cols, y_vals, y_end, slot_ptr, key, val, row_len);
-            hipLaunchKernelGGL(spgemm_rows_redo, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
-                               y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len);
+            else {
+                // the rows of a 64-row tile back to back (PADNE_SPGEMM_NO_COMPACT=1: every row in its own slot range)
+                if (getenv("PADNE_SPGEMM_NO_COMPACT") == nullptr) {
+                    PADNE_TRY(sc.alloc(&row_begin, (size_t)n + 1));
+                }
+                if (y_cs == 1)
+                    hipLaunchKernelGGL((spgemm_rows_lds_pipe<12, 9, 4, 1>), dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols,
+                                       X->vals, y_begin, y_cols, y_vals, y_end, slot_ptr, key, val, row_len, row_begin);
+                else
+                    hipLaunchKernelGGL((spgemm_rows_lds_pipe<12, 9, 4, 2>), dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols,
+                                       X->vals, y_begin, y_cols, y_vals, y_end, slot_ptr, key, val, row_len, row_begin);
+            }
+            {
+                // the rows whose list overflowed (next to a via ring: hundreds of products): collected, a wave each; one thread per
+                // row in global memory (spgemm_rows_redo: 98 us on the fine level of C4 for a few hundred rows) only for what is left
+                const int *place = row_begin != nullptr ? row_begin : slot_ptr;
+                int *pend = nullptr, *pend_count = nullptr;
+                PADNE_TRY(sc.alloc(&pend, (size_t)n));
+                PADNE_TRY(sc.alloc(&pend_count, 1));
+                PADNE_HIP_CHECK(hipMemsetAsync(pend_count, 0, sizeof(int), s));
+                hipLaunchKernelGGL(collect_pending_rows, dim3(nblk(n)), dim3(256), 0, s, n, (const int *)row_len, pend, pend_count);
+                hipLaunchKernelGGL((spgemm_rows_wave<1024, 512>), dim3(256), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals, y_begin,
+                                   y_cols, y_vals, y_end, y_cs, place, key, val, row_len, 1, (const int *)pend, (const int *)pend_count);
+                hipLaunchKernelGGL(spgemm_rows_redo, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
+                                   y_begin, y_cols, y_vals, y_end, y_cs, place, key, val, row_len);
+            }
         } else if (avg <= 256.0) {
             // tens to hundreds of products per row: one wave per row, the rows that do not fit are redone in global memory
             const unsigned gw = (unsigned)std::min<long long>(((long long)n + 3) / 4, 16384);
@@ -3248,24 +3295,25 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
         keep_slots->release();
         int *end = (int *)pool_alloc(ctx, sizeof(int) * (size_t)(n > 0 ? n : 1));
         if (end == nullptr) return PADNE_E_NOMEM;
-        if (n > 0) hipLaunchKernelGGL(slot_row_ends, dim3(nblk(n)), dim3(256), 0, s, n, slot_ptr, row_len, end);
+        int *first = row_begin != nullptr ? row_begin : slot_ptr;
+        if (n > 0) hipLaunchKernelGGL(slot_row_ends, dim3(nblk(n)), dim3(256), 0, s, n, (const int *)first, row_len, end);
         PADNE_HIP_CHECK(hipGetLastError());
         keep_slots->ctx = ctx;
         keep_slots->n_rows = n;
         keep_slots->n_cols = Y->n_cols;
         keep_slots->n_slots = n_slots;
-        keep_slots->begin = slot_ptr;
+        keep_slots->begin = first;
         keep_slots->end = end;
         keep_slots->key = key;
         keep_slots->val = val;
         keep_slots->valid = true;
-        sc.disown(slot_ptr);
+        sc.disown(first);
         sc.disown(key);
         sc.disown(val);
         if (C != nullptr) *C = nullptr;
         return PADNE_OK;
     }
-    return csr_from_slots(ctx, n, Y->n_cols, slot_ptr, key, val, row_len, C);
+    return csr_from_slots(ctx, n, Y->n_cols, row_begin != nullptr ? row_begin : slot_ptr, key, val, row_len, C);
 }
 
 // ---- W = P - c D^-1 (A P): coarse correction and post-smoothing of a level in ONE product ----------------------------
