@@ -4520,7 +4520,8 @@ static int amg_apply_f32(padne_ctx *ctx, Amg *amg, const double *r, double *z, d
             // residual of the pre-smoothed iterate that the down-leg restricted)
             if (l == 0)
                 PADNE_TRY(launch_spmv_f32_wup_exit(ctx, L.W, (const float *)amg->levels[1].xb, z, r, partials_rz, done_flag, xa,
-                                                   (const float *)L.tmp, L.A->dinv32, (float)L.jac, bb2, z32));
+                                                   (const float *)L.tmp, L.A->dinv32, (float)L.jac, bb2, z32,
+                                                   z32 != nullptr && getenv("PADNE_PCG_RZ64") == nullptr ? (const float *)b : nullptr));
             else
                 PADNE_TRY(launch_spmv_f32_wup(ctx, L.W, (const float *)amg->levels[l + 1].xb, (float *)L.xb, done_flag, xa,
                                               (const float *)L.tmp, L.A->dinv32, (float)L.jac));

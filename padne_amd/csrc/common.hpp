@@ -172,7 +172,8 @@ int launch_spmv_f32_exit(padne_ctx *ctx, const padne_csr *m, const float *x, dou
                          const double *out_scale2, float *z32 = nullptr);
 int launch_spmv_f32_wup_exit(padne_ctx *ctx, const padne_csr *w, const float *e, double *z, const double *dot_with,
                              double *partials, const int32_t *done_flag, const float *x_pre, const float *r_pre,
-                             const float *dinv32, float scale, const double *out_scale2, float *z32 = nullptr);
+                             const float *dinv32, float scale, const double *out_scale2, float *z32 = nullptr,
+                             const float *dot_b32 = nullptr);
 int csr_build_f32(padne_ctx *ctx, padne_csr *m);
 int csr_build_xw_plan(padne_ctx *ctx, padne_csr *m);
 int csr_build_xw_plan_wide(padne_ctx *ctx, padne_csr *m, int grid_cap = 0);      // grid_cap: workgroups at most (a build that runs beside latency-bound work of the other stream)      // twelve runs of 20 (single-precision operators with float values only: W)

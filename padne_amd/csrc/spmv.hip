@@ -372,7 +372,9 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
                     const double outd = (double)out * out_mul;
                     // a float result leaves unscaled (the consumer multiplies: the same double comes out)
                     y[r] = sizeof(YT) == 4 ? (YT)out : (YT)outd;
-                    dot_acc += dot_with[r] * outd;
+                    // y2 (optional): the residual as the cycle holds it, r / ||b|| in single precision -- 4 instead of 8 bytes
+                    // per row for r.z; its rounding (6e-8 of every term) goes into alpha and beta like the cycle's own
+                    dot_acc += (y2 != nullptr ? (double)y2[r] * out_mul : dot_with[r]) * outd;
                 } else {
                     y[r] = (YT)out;
                 }
@@ -707,11 +709,11 @@ int launch_spmv_f32_exit(padne_ctx *ctx, const padne_csr *m, const float *x, dou
 // with partial sums of dot_with . z.  W carries single-precision values only (m->vals32).
 int launch_spmv_f32_wup_exit(padne_ctx *ctx, const padne_csr *w, const float *e, double *z, const double *dot_with,
                              double *partials, const int32_t *done_flag, const float *x_pre, const float *r_pre,
-                             const float *dinv32, float scale, const double *out_scale2, float *z32) {
+                             const float *dinv32, float scale, const double *out_scale2, float *z32, const float *dot_b32) {
     PADNE_REQUIRE(w->vals32 != nullptr && dot_with != nullptr, "single-precision W stage");
     if (z32 != nullptr)
         return launch_spmv_typed<float, float, float>(ctx, w, w->vals32, SPMV_WUP, e, z32, dot_with, partials, done_flag,
-                                                      r_pre, dinv32, scale, out_scale2, x_pre);
+                                                      r_pre, dinv32, scale, out_scale2, x_pre, const_cast<float *>(dot_b32));
     return launch_spmv_typed<float, float, double>(ctx, w, w->vals32, SPMV_WUP, e, z, dot_with, partials, done_flag, r_pre,
                                                    dinv32, scale, out_scale2, x_pre);
 }
