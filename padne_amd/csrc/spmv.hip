@@ -367,14 +367,17 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
             } else if (MODE == SPMV_ADD) {
                 y[r] += (YT)acc;
             } else if (MODE == SPMV_WUP) {
-                const XT out = aux0[r] + scale * aux2[r] * aux1[r] + acc;
+                // y2 (optional, exit stage of the fine level): the level's right-hand side, r / ||b|| in single precision.  The
+                // pre-smoothed iterate is c D^-1 of it (a sweep from zero), so x_pre + c D^-1 r_pre = c D^-1 (b + r_pre) and x_pre
+                // need not be read; and r.z is taken against it -- 4 instead of 8 bytes per row, its rounding (6e-8 of every term)
+                // goes into alpha and beta like the cycle's own
+                const XT rhs = y2 != nullptr ? y2[r] : (XT)0;
+                const XT out = y2 != nullptr ? scale * aux2[r] * (rhs + aux1[r]) + acc : aux0[r] + scale * aux2[r] * aux1[r] + acc;
                 if (dot_with != nullptr) {
                     const double outd = (double)out * out_mul;
                     // a float result leaves unscaled (the consumer multiplies: the same double comes out)
                     y[r] = sizeof(YT) == 4 ? (YT)out : (YT)outd;
-                    // y2 (optional): the residual as the cycle holds it, r / ||b|| in single precision -- 4 instead of 8 bytes
-                    // per row for r.z; its rounding (6e-8 of every term) goes into alpha and beta like the cycle's own
-                    dot_acc += (y2 != nullptr ? (double)y2[r] * out_mul : dot_with[r]) * outd;
+                    dot_acc += (y2 != nullptr ? (double)rhs * out_mul : dot_with[r]) * outd;
                 } else {
                     y[r] = (YT)out;
                 }
