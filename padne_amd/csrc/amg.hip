@@ -4499,6 +4499,10 @@ static int amg_apply_f32(padne_ctx *ctx, Amg *amg, const double *r, double *z, d
             PADNE_TRY(launch_spmv_f32_part(ctx, L.A, SPMV_RESID, SPMV_INTERIOR, xa, tmp, nullptr, done_flag, b, nullptr, 0.f));
             PADNE_TRY(halo_recv_f32(ctx, L.halo, xa, done_flag, tk));
             PADNE_TRY(launch_spmv_f32_part(ctx, L.A, SPMV_RESID, SPMV_BOUNDARY, xa, tmp, nullptr, done_flag, b, nullptr, 0.f));
+        } else if (l == 0 && L.W != nullptr && spmv_resid_pre_ok(L.A)) {
+            // the fine level never looks at its pre-smoothed iterate: the residual is formed from the right-hand side alone
+            // (xa = c D^-1 b inside the staging of the product), the up-leg takes c D^-1 (b + residual) (spmv.hip)
+            PADNE_TRY(launch_spmv_f32_resid_pre(ctx, L.A, b, tmp, done_flag, L.A->dinv32, (float)L.jac));
         } else {
             PADNE_TRY(launch_spmv_f32(ctx, L.A, SPMV_RESID, xa, tmp, nullptr, done_flag, b, nullptr, 0.f));
         }
@@ -4521,7 +4525,7 @@ static int amg_apply_f32(padne_ctx *ctx, Amg *amg, const double *r, double *z, d
             if (l == 0)
                 PADNE_TRY(launch_spmv_f32_wup_exit(ctx, L.W, (const float *)amg->levels[1].xb, z, r, partials_rz, done_flag, xa,
                                                    (const float *)L.tmp, L.A->dinv32, (float)L.jac, bb2, z32,
-                                                   z32 != nullptr && getenv("PADNE_PCG_RZ64") == nullptr ? (const float *)b : nullptr));
+                                                   spmv_resid_pre_ok(L.A) ? (const float *)b : nullptr));      // (as the down-leg decided)
             else
                 PADNE_TRY(launch_spmv_f32_wup(ctx, L.W, (const float *)amg->levels[l + 1].xb, (float *)L.xb, done_flag, xa,
                                               (const float *)L.tmp, L.A->dinv32, (float)L.jac));
@@ -4687,7 +4691,8 @@ bool amg_f32_entry_args(const padne_csr *A0, float *jac, const float **dinv32, f
     *jac = (float)L.jac;
     *dinv32 = L.A->dinv32;
     *b32 = (float *)L.b;
-    *xa32 = (float *)L.xa;
+    // (null: nothing reads the pre-smoothed iterate of the fine level -- residual and up-leg form it from b, amg_apply_f32)
+    *xa32 = (!amg->dist && L.W != nullptr && spmv_resid_pre_ok(L.A)) ? nullptr : (float *)L.xa;
     return true;
 }
 

@@ -158,7 +158,8 @@ int spmv_grid(const padne_csr *m);
 enum { SPMV_PLAIN = 0, SPMV_DOT = 1, SPMV_RESID = 2, SPMV_ADD = 3, SPMV_JACOBI = 4,
        SPMV_DOT_AUX = 5,     // same as SPMV_DOT; used outside the CG loop (Lanczos estimates) so that kernel profiles keep the two apart
        SPMV_WUP = 6,         // y = aux0 + scale * aux2 * aux1 + W x  (spmv.hip)
-       SPMV_RESTRICT = 7 };  // y = A x ; y2 = scale * aux2 * y
+       SPMV_RESTRICT = 7,    // y = A x ; y2 = scale * aux2 * y
+       SPMV_RESID_PRE = 8 }; // y = x - A (scale * aux2 .* x): residual of the sweep from zero, x the right-hand side (spmv.hip)
 int launch_spmv_mode(padne_ctx *ctx, const padne_csr *m, int mode, const double *x, double *y,
                      const double *dot_with, double *partials, const int32_t *done_flag, const double *aux1,
                      const double *aux2, double scale);
@@ -209,6 +210,9 @@ int launch_spmm_f32_exit(padne_ctx *ctx, const padne_csr *m, int k, const float 
 int launch_spmm_f32_wup_exit(padne_ctx *ctx, const padne_csr *w, int k, const float *e, double *z, const double *dot_with,
                              double *partials, const int32_t *done_flag, const float *x_pre, const float *r_pre,
                              const float *dinv32, float scale, const double *out_scale2);
+bool spmv_resid_pre_ok(const padne_csr *m);
+int launch_spmv_f32_resid_pre(padne_ctx *ctx, const padne_csr *m, const float *b, float *resid, const int32_t *done_flag,
+                              const float *dinv32, float c);
 bool spmv_x32_ok(const padne_csr *m);
 int launch_spmv_dot_x32(padne_ctx *ctx, const padne_csr *m, const float *x, double *y, double *partials, const int32_t *done_flag);
 int launch_spmv_f32_wup(padne_ctx *ctx, const padne_csr *w, const float *e, float *x_out, const int32_t *done_flag,

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void pcg_update_xr_entry_kernel(
         s_rr += ri * ri;
         const float v = (float)(ri * s_inv);
         b32[i] = v;
-        xa32[i] = c * dinv32[i] * v;
+        if (xa32 != nullptr) xa32[i] = c * dinv32[i] * v;      // (null: the cycle forms its first sweep from b32 itself)
     }
     block_store_partial(s_rr, red, part_rr + blockIdx.x);
 }
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(256) void sr_update_xr_kernel(
         if (b32 != nullptr) {
             const float v = (float)(ri * s_inv);
             b32[i] = v;
-            xa32[i] = c * dinv32[i] * v;
+            if (xa32 != nullptr) xa32[i] = c * dinv32[i] * v;
         }
     }
     block_store_partial(s_rr, red, part_rr + blockIdx.x);

@@ -135,9 +135,10 @@ __device__ __forceinline__ XT xw_stream_tile(const VT *__restrict__ vals, const 
 // one or two of values) instead of eight 4-byte loads of each, x gathered from global memory, products parked four at a time.
 // A pass starts on a multiple of 4; stray elements in front of k0 / behind k1 are multiplied (their columns are valid: both
 // arrays are padded with column 0 / value 0) but never summed.  Same products, same order of the row sums.
-template <typename VT, typename XT, int EPL, typename ST = XT>
+template <typename VT, typename XT, int EPL, typename ST = XT, bool PRE = false>      // PRE: x stands for scale * mul .* x
 __device__ __forceinline__ XT gather_stream_tile(const int *__restrict__ cols, const VT *__restrict__ vals, const ST *__restrict__ x,
-                                                 XT *prod, const int k0, const int k1, const int rs, const int re, const int lane) {
+                                                 XT *prod, const int k0, const int k1, const int rs, const int re, const int lane,
+                                                 const XT *__restrict__ mul = nullptr, const XT scale = 0) {
     constexpr int G = 4, NJ = EPL / G, CHUNK = 64 * EPL;
     struct alignas(16) VG { VT v[G]; };
     int4 cw[NJ];
@@ -164,6 +165,12 @@ __device__ __forceinline__ XT gather_stream_tile(const int *__restrict__ cols, c
                 xv[1] = (XT)x[cw[j].y];
                 xv[2] = (XT)x[cw[j].z];
                 xv[3] = (XT)x[cw[j].w];
+                if (PRE) {
+                    xv[0] *= scale * mul[cw[j].x];
+                    xv[1] *= scale * mul[cw[j].y];
+                    xv[2] *= scale * mul[cw[j].z];
+                    xv[3] *= scale * mul[cw[j].w];
+                }
             }
 #pragma unroll
             for (int t = 0; t < G; ++t) prod[G * lane + 64 * G * j + t] = (XT)vg[j].v[t] * xv[t];
@@ -191,8 +198,9 @@ __device__ __forceinline__ XT gather_stream_tile(const int *__restrict__ cols, c
 // The tile's three runs of x into the wave's LDS slice in 16-byte pieces: 54 lanes of ONE load and ONE store instruction
 // bring the 216 single-precision entries of three runs of 72 (two rounds for doubles or runs of 128) where lane-per-entry
 // loads took six of each.  A piece that would reach past the end of x is fetched entry by entry.
-template <int RUN, typename XT>
-__device__ __forceinline__ void stage_windows(const XT *__restrict__ x, const int n_cols, const int4 d, XT *xs, const int lane) {
+template <int RUN, typename XT, bool PRE = false>      // PRE: what is staged is scale * mul .* x
+__device__ __forceinline__ void stage_windows(const XT *__restrict__ x, const int n_cols, const int4 d, XT *xs, const int lane,
+                                              const XT *__restrict__ mul = nullptr, const XT scale = 0) {
     constexpr int PER = 16 / (int)sizeof(XT), PPR = RUN / PER, NP = kXwRuns * PPR;
     static_assert(RUN % PER == 0, "runs are whole 16-byte pieces");
     struct alignas(sizeof(XT)) PieceG { XT v[PER]; };      // in global memory a run starts at any entry
@@ -208,9 +216,14 @@ __device__ __forceinline__ void stage_windows(const XT *__restrict__ x, const in
                 const PieceG pg = *reinterpret_cast<const PieceG *>(x + g0);
 #pragma unroll
                 for (int t = 0; t < PER; ++t) pl.v[t] = pg.v[t];
+                if (PRE) {
+                    const PieceG mg = *reinterpret_cast<const PieceG *>(mul + g0);
+#pragma unroll
+                    for (int t = 0; t < PER; ++t) pl.v[t] *= scale * mg.v[t];
+                }
             } else {
 #pragma unroll
-                for (int t = 0; t < PER; ++t) pl.v[t] = (g0 + t < n_cols) ? x[g0 + t] : (XT)0;
+                for (int t = 0; t < PER; ++t) pl.v[t] = (g0 + t < n_cols) ? (PRE ? scale * mul[g0 + t] * x[g0 + t] : x[g0 + t]) : (XT)0;
             }
             *reinterpret_cast<PieceL *>(xs + q * RUN + PER * i) = pl;
         }
@@ -341,8 +354,9 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
                                                                kXwRunsWide * kXwRunWide - 1);
         } else if (windowed) {
             // the tile's runs of x (stage_windows; the stream loops wait for these LDS stores before their first read)
-            if (xw_run <= kXwRunShort) stage_windows<kXwRunShort, ST>(x, n_cols, d, xs, lane);
-            else stage_windows<kXwRunLong, ST>(x, n_cols, d, xs, lane);
+            constexpr bool PRE = MODE == SPMV_RESID_PRE && sizeof(ST) == sizeof(XT);
+            if (xw_run <= kXwRunShort) stage_windows<kXwRunShort, ST, PRE>(x, n_cols, d, xs, lane, (const ST *)aux2, (ST)scale);
+            else stage_windows<kXwRunLong, ST, PRE>(x, n_cols, d, xs, lane, (const ST *)aux2, (ST)scale);
             const int top = kXwRuns * xw_run - 1;
             // three runs of 72 are 216 positions: one byte each, four non-zeros per lane and load; runs of 128 need 16 bits
             if (xw_run <= kXwRunShort)
@@ -350,7 +364,7 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
             else
                 acc = xw_stream_tile<2, unsigned short, VT, XT, ST>(vals, (const unsigned short *)xw_lidx, xs, prod, k0, k1, rs, re, lane, top);
         } else if (k1 > k0) {
-            acc = gather_stream_tile<VT, XT, kEplGather, ST>(cols, vals, x, prod, k0, k1, rs, re, lane);
+            acc = gather_stream_tile<VT, XT, kEplGather, ST, MODE == SPMV_RESID_PRE>(cols, vals, x, prod, k0, k1, rs, re, lane, aux2, scale);
         }
         if (r < row1) {
             if (MODE == SPMV_PLAIN) {
@@ -364,6 +378,8 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
                 else dot_acc += dot_with[r] * (double)acc;
             } else if (MODE == SPMV_RESID) {
                 y[r] = (YT)(aux1[r] - acc);
+            } else if (MODE == SPMV_RESID_PRE) {
+                y[r] = (YT)((XT)x[r] - acc);
             } else if (MODE == SPMV_ADD) {
                 y[r] += (YT)acc;
             } else if (MODE == SPMV_WUP) {
@@ -614,6 +630,7 @@ static int launch_spmv_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals,
         case SPMV_JACOBI: PADNE_SPMV_LAUNCH(SPMV_JACOBI); break;
         case SPMV_WUP: PADNE_SPMV_LAUNCH(SPMV_WUP); break;
         case SPMV_RESTRICT: PADNE_SPMV_LAUNCH(SPMV_RESTRICT); break;
+        case SPMV_RESID_PRE: PADNE_SPMV_LAUNCH(SPMV_RESID_PRE); break;
         default: set_error("bad SpMV mode %d", mode); return PADNE_E_INVALID;
     }
 #undef PADNE_SPMV_LAUNCH_LONG
@@ -622,6 +639,22 @@ static int launch_spmv_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals,
 #undef PADNE_SPMV_LAUNCH
     PADNE_HIP_CHECK(hipGetLastError());
     return PADNE_OK;
+}
+
+// Residual of the first sweep of a level from a zero start, without that sweep's result in memory: the iterate is
+// c D^-1 b, so  r = b - A (c D^-1 b)  is formed from b alone -- the windows of x are staged as c * dinv .* b (gathered entries
+// likewise).  What it saves is the store and the staged read of the iterate (amg.hip: the fine level of the float cycle, whose
+// up-leg does not read the iterate either).  Plain tile kernel only (spmv_resid_pre_ok).
+bool spmv_resid_pre_ok(const padne_csr *m) {
+    const bool long_rows = m->xw_state != 1 && m->n_rows < 500000 && m->nnz > 8 * m->n_rows + 4 * (m->n_rows >> 3);
+    return m->vals32 != nullptr && m->dinv32 != nullptr && !split_in_use(m) && !use_wave_per_row(m) && !long_rows &&
+           !(m->xw_state == 1 && m->xw_nruns == kXwRunsWide) && getenv("PADNE_AMG_RESID_XA") == nullptr;
+}
+int launch_spmv_f32_resid_pre(padne_ctx *ctx, const padne_csr *m, const float *b, float *resid, const int32_t *done_flag,
+                              const float *dinv32, float c) {
+    PADNE_REQUIRE(spmv_resid_pre_ok(m), "residual of the sweep from zero on this operator");
+    return launch_spmv_typed<float, float, float>(ctx, m, m->vals32, SPMV_RESID_PRE, b, resid, nullptr, nullptr, done_flag, nullptr,
+                                                  dinv32, c, nullptr);
 }
 
 // q = A p with p stored in single precision, p.q partials (one GPU, no split plan; same grid and partial layout as the
@@ -718,7 +751,7 @@ int launch_spmv_f32_wup_exit(padne_ctx *ctx, const padne_csr *w, const float *e,
         return launch_spmv_typed<float, float, float>(ctx, w, w->vals32, SPMV_WUP, e, z32, dot_with, partials, done_flag,
                                                       r_pre, dinv32, scale, out_scale2, x_pre, const_cast<float *>(dot_b32));
     return launch_spmv_typed<float, float, double>(ctx, w, w->vals32, SPMV_WUP, e, z, dot_with, partials, done_flag, r_pre,
-                                                   dinv32, scale, out_scale2, x_pre);
+                                                   dinv32, scale, out_scale2, x_pre, const_cast<float *>(dot_b32));
 }
 
 // up-leg of an inner level in the W form: x = x_pre + c D^-1 r_pre + W e, single precision throughout

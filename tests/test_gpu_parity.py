@@ -723,6 +723,38 @@ def test_search_direction_stored_in_single_precision_solves_the_same_system(monk
         assert not np.array_equal(f32[0].x, f64[0].x), "the switch changed nothing"
 
 
+def test_fine_level_of_the_cycle_formed_from_its_right_hand_side_alone(monkeypatch):
+    """The fine level of the float cycle never stores its pre-smoothed iterate x = c D^-1 b: the residual product stages
+    c * dinv .* b instead of x (`SPMV_RESID_PRE`), the up-leg takes c D^-1 (b + residual) + W e and r.z against b.  Against
+    PADNE_AMG_RESID_XA=1 (iterate stored and read, r.z against the double residual): the cycle applied to a probe agrees to
+    float rounding, single and lockstep solves take the same iterations (one either way) and give the same potentials -- on
+    a system with an x-window plan, on one without, and through a one-rank halo plan with the hierarchy on the owned block
+    (the path where CG keeps z in double)."""
+    for A, b, _, _, _ in (layered_spd(2, 70, 60, 4), layered_spd(3, 260, 200, 5)):
+        probe = np.random.default_rng(3).uniform(-1, 1, A.shape[0])
+
+        def run():
+            c = _hip.Context(0)
+            try:
+                d = c.csr_from_scipy(A)
+                one = d.solve_spd(b, precond="amg", rtol=1e-12)
+                z = d.amg_apply(probe)
+                four = d.solve_spd(np.stack([b, 2.0 * b, -b, 0.5 * b]), precond="amg", rtol=1e-12)
+                d.close()
+            finally:
+                c.close()
+            return one, z, four
+        new = run()
+        monkeypatch.setenv("PADNE_AMG_RESID_XA", "1")
+        old = run()
+        monkeypatch.delenv("PADNE_AMG_RESID_XA")
+        assert abs(new[0].iterations - old[0].iterations) <= 1 and abs(new[2].iterations - old[2].iterations) <= 4
+        assert np.abs(new[1] - old[1]).max() <= 2e-5 * np.abs(old[1]).max()
+        assert np.abs(new[0].x - old[0].x).max() <= 1e-9 * np.abs(old[0].x).max()
+        assert np.abs(new[2].x - old[2].x).max() <= 1e-9 * np.abs(old[2].x).max()
+        assert np.linalg.norm(A @ new[0].x - b) <= 2e-12 * np.linalg.norm(b)
+
+
 def test_single_precision_cycle_is_independent_of_the_units_of_the_system(ctx):
     """The cycle input is normalised by ||b||, so right-hand sides of 1e-30 A or 1e+30 A converge like 1 A ones."""
     A, b, _, _, _ = layered_spd(2, 70, 60, 4)
