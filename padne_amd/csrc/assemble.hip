@@ -184,6 +184,59 @@ __global__ __launch_bounds__(256) void scan_apply(const int *__restrict__ in, lo
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = (int)(*total);
 }
 
+// Short inputs (the coarse levels of a multigrid setup, lists of a few thousand rows: two dozen scans per setup): ONE workgroup
+// of 1024 threads does all three steps -- every thread a contiguous piece, the pieces scanned over the workgroup -- in one
+// launch instead of three that took 5 us each whatever the length.  Same results as the three kernels where no input is
+// negative; with a negative input the flag is what the callers look at.
+constexpr int kScanSmall = 32768;
+__global__ __launch_bounds__(1024) void scan_small(const int *in, const int n, int *out,      // (in == out is allowed)
+                                                   long long *__restrict__ total_out, unsigned long long *mail_slot,
+                                                   unsigned long long mail_seq) {
+    __shared__ long long wave_tot[16];
+    __shared__ int any_neg;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (t == 0) any_neg = 0;
+    __syncthreads();
+    const int per = (n + 1023) / 1024;
+    const int b0 = min(t * per, n), b1 = min(b0 + per, n);
+    long long s = 0;
+    bool neg = false;
+    for (int i = b0; i < b1; ++i) {
+        const int v = in[i];
+        neg |= v < 0;
+        s += v;
+    }
+    if (neg) any_neg = 1;
+    long long inc = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const long long u = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += u;
+    }
+    if (lane == 63) wave_tot[w] = inc;
+    __syncthreads();
+    long long run = inc - s, total = 0;
+    for (int q = 0; q < 16; ++q) {
+        if (q < w) run += wave_tot[q];
+        total += wave_tot[q];
+    }
+    for (int i = b0; i < b1; ++i) {
+        const int v = in[i];
+        out[i] = (int)run;
+        run += v;
+    }
+    if (t == 0) {
+        const long long tot = any_neg ? 0 : total;
+        out[n] = (int)tot;
+        total_out[0] = tot;
+        total_out[1] = any_neg;
+        if (mail_slot != nullptr) {
+            const unsigned long long wd[2] = {(unsigned long long)tot, (unsigned long long)any_neg};
+            mail_post(mail_slot, mail_seq, wd, 2);
+        }
+    }
+}
+
 // Two halves: scan_i32_begin queues the three kernels (and the mailbox post of the total), scan_i32_end waits for the total
 // -- whatever the caller launches in between (on any stream) is launched while the scan runs.
 int scan_i32_begin(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t n, ScanTicket *t, bool want_total) {
@@ -206,10 +259,15 @@ int scan_i32_begin(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t n, S
     t->bs = bs;
     long long *tot = bs + nb;          // [0] exact 64-bit total, [1] negative-input flag
     if (want_total) t->mail = mail_ticket(ctx);
-    hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(256), 0, s, in, (long long)n, bs);
-    hipLaunchKernelGGL(scan_block_offsets, dim3(1), dim3(256), 0, s, bs, nb, tot, t->mail.slot_dev, t->mail.seq);
-    // a total beyond int32 makes the 32-bit offsets below meaningless: it is detected from the 64-bit total
-    hipLaunchKernelGGL(scan_apply, dim3(nb), dim3(256), 0, s, in, (long long)n, bs, tot, out);
+    static const bool small_ok = getenv("PADNE_SCAN_THREE_KERNELS") == nullptr;
+    if (n <= kScanSmall && small_ok) {
+        hipLaunchKernelGGL(scan_small, dim3(1), dim3(1024), 0, s, in, (int)n, out, tot, t->mail.slot_dev, t->mail.seq);
+    } else {
+        hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(256), 0, s, in, (long long)n, bs);
+        hipLaunchKernelGGL(scan_block_offsets, dim3(1), dim3(256), 0, s, bs, nb, tot, t->mail.slot_dev, t->mail.seq);
+        // a total beyond int32 makes the 32-bit offsets below meaningless: it is detected from the 64-bit total
+        hipLaunchKernelGGL(scan_apply, dim3(nb), dim3(256), 0, s, in, (long long)n, bs, tot, out);
+    }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         pool_free(ctx, bs);
