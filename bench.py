@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-seam", action="store_true",
                     help="skip the solve_system(L, r) wall-time measurement behind the timed steps (profiling runs)")
+    ap.add_argument("--no-rank-proxy", action="store_true",
+                    help="skip the one-rank-of-eight measurement (one layer of C4 through the row-partitioned path)")
+    ap.add_argument("--no-c5", action="store_true", help="skip the batched right-hand sides of config C5")
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the row-partitioned code path (RCCL communicator, halo plan) even on 1 GPU")
     ap.add_argument("--cpu-sample-nx", type=int, default=400,
@@ -203,6 +206,147 @@ def seam_timing(ctx, L_dev, sysm, rhs, repeats: int):
                     "rebuilt per call; never part of `value`"}
 
 
+def rank_proxy(steps: int):
+    """What ONE rank of an 8-GPU run has to do per solve, measured on this GPU: one layer of config C4 (1118 x 1118 vertices,
+    a rank's share of the 10 M unknowns) through the ROW-PARTITIONED path -- the hierarchy of amg_setup_dist, the
+    single-reduction CG loop, the collectives of an RCCL communicator of one rank -- next to the same layer through the
+    one-GPU path.  No other rank exists, so nothing waits for a peer: ``ms_per_step`` is the part of an 8-GPU step that
+    no communication is in, and ms_per_step(C4 on one GPU) / rank_proxy.ms_per_step is an UPPER BOUND of the 8-GPU speed-up
+    (the exchanges, the gathered tail of the hierarchy and load imbalance only lower it).  A bound, not a scaling claim."""
+    import torch
+    import torch.distributed as dist
+    from padne_amd import _hip, distributed, synthetic
+    sysm = synthetic.layered_system(1, 1118, 1118, name="one layer of C4")
+    nv = sysm.n_vertices
+    N = nv + 1
+    out = {"workload": f"one layer of config C4: {nv} vertices, 1 A source/sink, amg-PCG to rtol {RTOL:g}, hierarchy rebuilt "
+                       "in every step", "rows": int(nv - 1)}
+
+    def timed(solve, sync):
+        solve(rebuild=True)
+        solve(rebuild=True)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last = solve(rebuild=True)
+        sync()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        # launches: a whole step, a solve on the cached hierarchy, a shorter solve on it
+        c0 = _hip.launch_count()
+        full = solve(rebuild=True)
+        sync()
+        c1 = _hip.launch_count()
+        cached = solve(rebuild=False)
+        sync()
+        c2 = _hip.launch_count()
+        short = solve(rebuild=False, rtol=1e-5)
+        sync()
+        c3 = _hip.launch_count()
+        d_it = max(int(cached.iterations) - int(short.iterations), 1)
+        return {"ms_per_step": ms, "setup_ms": float(last.setup_seconds) * 1e3,
+                "us_per_iteration": float(last.seconds) / max(int(last.iterations), 1) * 1e6, "iterations": int(last.iterations),
+                "launches_per_step": int(c1 - c0), "launches_per_setup": int((c1 - c0) - (c2 - c1)),
+                "launches_per_iteration": round(((c2 - c1) - (c3 - c2)) / d_it, 1)}
+
+    # (a) the one-GPU path
+    ctx1 = _hip.Context(0)
+    xy, tri, mvo, mto, sig = flat(sysm)
+    rows, cols, vals, rhs = stamps_of(sysm, N)
+    L = ctx1.assemble_system(N, xy, tri, mvo, mto, sig, rows, cols, vals)
+    imap = np.arange(N, dtype=np.int32)
+    imap[sysm.ground] = -1
+    imap[imap > sysm.ground] -= 1
+    imap[N - 1] = -1
+    A = L.reduce(imap, nv - 1, -1.0)
+    L.close()
+    keep = np.flatnonzero(imap[:nv] >= 0)
+    b = ctx1.to_device(-rhs[keep])
+    x = ctx1.empty(A.shape[0])
+    out["one_gpu_path"] = timed(lambda rebuild, rtol=RTOL: A.solve_spd_dev(b, x, rtol=rtol, precond="amg", rebuild=rebuild),
+                                ctx1.synchronize)
+    A.close()
+    b.free()
+    x.free()
+    ctx1.close()
+    # (b) the row-partitioned path with a communicator of one rank
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if not dist.is_initialized():
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    ctx2 = _hip.Context(0)
+    plan = distributed.build_layer_partition(sysm, 0, 1)
+    ds = distributed.DistributedSolver(ctx2, plan, dist)
+    rec = timed(lambda rebuild, rtol=RTOL: ds.solve(rtol=rtol, precond="amg", rebuild=rebuild), ctx2.synchronize)
+    out.update(rec)
+    out["path"] = "row-partitioned (amg_setup_dist, single-reduction CG, RCCL communicator of one rank)"
+    try:
+        out["p2p_exchange"] = json.load(open(os.path.join(ROOT, "profiles", "r05_p2p_exchange.json")))
+        out["p2p_exchange"]["static_from"] = "profiles/r05_p2p_exchange.json (tests/two_process_rank.py, two processes on one GPU; not measured in this run)"
+    except Exception:
+        out["p2p_exchange"] = None
+    ctx2.close()
+    dist.destroy_process_group()
+    return out
+
+
+def c5_block(ctx, steps: int):
+    """Config C5: 8 current-source configurations on the N = 5 M matrix of C3, advanced in lockstep (one pass over every
+    operator per iteration for all eight), next to ONE of them solved alone; hierarchy rebuilt in every call as in the
+    headline step.  ``solves_equiv`` = what the eight cost in single solves."""
+    from padne_amd import synthetic
+    sysm, xy, tri = synthetic.config_on_device(ctx, "C5")
+    nv = sysm.n_vertices
+    N = nv + 1
+    sig = np.array([m[2] for m in sysm.meshes])
+    rows, cols, vals, rhs = stamps_of(sysm, N)
+    L = ctx.assemble_system(N, xy, tri, sysm.mesh_offsets, sysm._tri_offsets, sig, rows, cols, vals)
+    xy.free()
+    tri.free()
+    imap = np.arange(N, dtype=np.int32)
+    imap[sysm.ground] = -1
+    imap[imap > sysm.ground] -= 1
+    imap[N - 1] = -1
+    A = L.reduce(imap, nv - 1, -1.0)
+    L.close()
+    keep = np.flatnonzero(imap[:nv] >= 0)
+    f, t = synthetic.multi_rhs_pairs(sysm, 8)
+    B = np.zeros((8, nv - 1))
+    for k in range(8):
+        full = np.zeros(nv)
+        full[f[k]] += 1.0
+        full[t[k]] -= 1.0
+        B[k] = full[keep]
+    b8 = ctx.to_device(B)
+    x8 = ctx.empty((8, nv - 1))
+    b1 = ctx.to_device(B[0])
+    x1 = ctx.empty(nv - 1)
+
+    def run(bb, xx, k):
+        A.solve_spd_dev(bb, xx, n_rhs=k, rtol=RTOL, precond="amg", rebuild=True)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = A.solve_spd_dev(bb, xx, n_rhs=k, rtol=RTOL, precond="amg", rebuild=True)
+        ctx.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3, r
+    ms8, r8 = run(b8, x8, 8)
+    ms1, r1 = run(b1, x1, 1)
+    xs8 = ctx.to_device(np.random.default_rng(2).uniform(-1, 1, A.shape[1] * 8))
+    ys8 = ctx.empty(A.shape[0] * 8)
+    t8 = min(A.spmm8_time(xs8, ys8, 5, 30) for _ in range(3))
+    rec = {"workload": f"{sysm.name}: {nv} nodes, 8 right-hand sides in lockstep, amg-PCG to rtol {RTOL:g}",
+           "ms": ms8, "setup_ms": float(r8.setup_seconds) * 1e3, "iterations_total": int(r8.iterations),
+           "rel_residual_max": float(r8.rel_residual), "single_solve_ms": ms1, "single_iterations": int(r1.iterations),
+           "solves_equiv": ms8 / ms1, "rhs_per_s": 8e3 / ms8,
+           "spmm8_us": t8 * 1e6, "spmm8_gbs_algorithmic": A.spmm8_bytes / t8 / 1e9,
+           "spmm8_frac": A.spmm8_bytes / t8 / 1e9 / HBM_PEAK_GBS, "spmm8_bytes_rule": "12 nnz + 4 N + 16 N k (= 216 N at k = 8)"}
+    for d in (b8, x8, b1, x1, xs8, ys8):
+        d.free()
+    A.close()
+    return rec
+
+
 def launch_ranks(n: int) -> int:
     """Start one rank per GPU with torch.distributed.run (the command the driver uses) and wait for them."""
     import socket
@@ -288,14 +432,18 @@ def main():
         A = L.reduce(imap, nv - 1, -1.0)
         ctx.synchronize()
         t_reduce = time.perf_counter() - t0
-        red_warm = []
-        for _ in range(ASSEMBLY_REPEATS):
-            ctx.synchronize()
-            t0 = time.perf_counter()
-            A_again = L.reduce(imap, nv - 1, -1.0)
-            ctx.synchronize()
-            red_warm.append(time.perf_counter() - t0)
-            A_again.close()
+        red_warm, red_warm_host = [], []
+        imap_dev = ctx.to_device(imap)      # the index map is an input like the mesh: resident in HBM when the timed region starts
+        for host_map in (True, False):
+            for _ in range(ASSEMBLY_REPEATS):
+                ctx.synchronize()
+                t0 = time.perf_counter()
+                A_again = L.reduce(imap if host_map else imap_dev, nv - 1, -1.0)
+                ctx.synchronize()
+                (red_warm_host if host_map else red_warm).append(time.perf_counter() - t0)
+                assert A_again.nnz == A.nnz
+                A_again.close()
+        imap_dev.free()
         L_nnz = L.nnz
         L_full = L                   # kept for the seam measurement below (solve_system on host vectors)
         keep = np.flatnonzero(imap[:nv] >= 0)
@@ -349,6 +497,27 @@ def main():
         seam = seam_timing(ctx, L_full, sysm, rhs, max(2, min(args.steps, 5)))
     if not distributed_path:
         L_full.close()               # (the assembled KKT matrix, ~1 GB at C4: only the seam measurement needed it)
+    shapes_now = None
+    if hierarchy_shapes is not None:
+        try:
+            shapes_now = hierarchy_shapes()      # (of the last timed step's hierarchy, while the matrix is alive)
+        except Exception:
+            shapes_now = None
+    c5 = proxy = None
+    if not distributed_path and args.precond == "amg" and args.workload == "C4":
+        A.close()
+        b.free()
+        x.free()
+        if not args.no_c5:
+            try:
+                c5 = c5_block(ctx, max(2, min(args.steps, 5)))
+            except Exception as exc:
+                c5 = {"error": repr(exc)}
+        if not args.no_rank_proxy:
+            try:
+                proxy = rank_proxy(max(3, min(args.steps, 10)))
+            except Exception as exc:
+                proxy = {"error": repr(exc)}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -407,9 +576,9 @@ def main():
                                         if p_stored_f32 else "12 nnz + 20 n + 4 (values 8 + columns 4 per non-zero; row pointer 4, x 8, y 8 per row)"),
                          "standalone_frac": (spmv_bytes_standalone / t_standalone / 1e9 / HBM_PEAK_GBS) if t_standalone else None},
         }
-        if hierarchy_shapes is not None:
+        if shapes_now is not None:
             try:
-                sb = step_algorithmic_bytes(hierarchy_shapes(), int(last.iterations))
+                sb = step_algorithmic_bytes(shapes_now, int(last.iterations))
                 ach = sb["total"] / (elapsed / args.steps) / 1e9
                 out["roofline"]["step"] = {
                     "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
@@ -449,14 +618,24 @@ def main():
                 "traffic": asm_traffic.get("bytes_per_assembly") if asm_traffic else None,
                 "traffic_static_from": "profiles/r04_assembly_traffic.json (rocprofv3 --pmc passes, scripts/pmc_asm.sh; not collected in "
                                        "this run)" if asm_traffic else None,
-                "reduce_ms": red_ms,
+                "reduce_ms": red_ms, "reduce_ms_host_map": float(np.mean(red_warm_host)) * 1e3,
                 "what": "padne_assemble_system on device-resident meshes + host stamp lists -> CSR L (wall time per call, warm, "
-                        "host looks included); reduce_ms: L -> A = -P^T L P (padne_csr_reduce, 40 MB index map uploaded per call)"}
+                        "host looks included); reduce_ms: L -> A = -P^T L P (padne_csr_reduce: drop the ground vertex and the "
+                        "multiplier row, flip the sign) with the index map resident on the device, reduce_ms_host_map: the same "
+                        "with the 40 MB map uploaded from pageable host memory in every call"}
             out["value_with_assembly"] = 1e3 / (ms_per_step + asm_ms + red_ms)
             out["ms_per_step_with_assembly"] = ms_per_step + asm_ms + red_ms
         if seam is not None:
             out["seam"] = seam
             out["seam_ms_per_solve"] = seam["ms_per_solve"]
+        if c5 is not None:
+            out["c5"] = c5
+        if proxy is not None:
+            if "ms_per_step" in proxy:
+                proxy["speedup_bound_at_8_gpus"] = ms_per_step / proxy["ms_per_step"]
+                proxy["note"] = ("ms_per_step of the headline config on this GPU / ms_per_step of one rank's share with nothing to "
+                                 "wait for: an upper bound of the 8-GPU speed-up, not a measurement of it")
+            out["rank_proxy"] = proxy
         if args.gpus == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_sample_nx)

@@ -73,6 +73,10 @@ int padne_ctx_comm_rank(padne_ctx *ctx, int *rank, int *world_size);
  * rank's contributions.  Bookkeeping for DESIGN.md section 6 (what a multi-GPU solve costs), also counted for the
  * in-process team. */
 int padne_comm_call_counts(long long calls[4], long long bytes[4]);
+/* kernels and asynchronous fills this process has queued through the library since it was loaded (all contexts).  What a
+ * solve costs in LAUNCHES is read off the difference around it: below a million unknowns per GPU a solve is bound by its
+ * launches, not by bytes (bench.py: rank_proxy). */
+int padne_launch_count(long long *count);
 /* The same collectives through a transport of the CALLER (gloo, MPI, ...) instead of RCCL: ranks RCCL cannot connect
  * -- two processes on one GPU -- or a host that has no RCCL.  `allgather(user, send, recv, bytes_per_rank)` gathers
  * bytes_per_rank bytes of HOST memory from every rank into recv (rank order; send may lie inside recv) and returns 0;

@@ -32,6 +32,10 @@ int padne_ctx_lockstep_groups(const padne_ctx *ctx, int64_t *groups);
 /* Assemblies of this process whose rows were built by the two-pass second path of the row kernel (count, scan, fill):
  * forced with PADNE_ASM_TWO_PASS=1, or taken after the single-pass kernel's in-kernel scan gave up on a shared chip. */
 int padne_asm_second_path_count(int64_t *count);
+/* Average device time of one halo exchange of the context's plan (padne_ctx_set_halo) over `repeats` exchanges queued back to
+ * back -- peer-to-peer stores into the shared mailboxes with their device-side flags, or the all-gather.  Collective: every
+ * rank calls it with the same count (tests/two_process_rank.py, bench.py rank_proxy.p2p_exchange). */
+int padne_ctx_halo_exchange_time(padne_ctx *ctx, int32_t repeats, double *seconds_out);
 
 #ifdef __cplusplus
 }

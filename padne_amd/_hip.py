@@ -65,6 +65,7 @@ SIGNATURES = {
     "padne_ctx_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "padne_ctx_comm_rank": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "padne_comm_call_counts": (C.c_int, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "padne_launch_count": (C.c_int, [C.POINTER(C.c_longlong)]),
     "padne_ctx_comm_init_host": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
     "padne_ctx_p2p_export": (C.c_int, [_P, C.c_int32, _P]),
     "padne_ctx_p2p_import": (C.c_int, [_P, _P, C.c_int32]),
@@ -124,6 +125,7 @@ TEST_SIGNATURES = {
     "padne_csr_split_tiles": (C.c_int, [_P, C.c_int, _PI64, _PI64]),
     "padne_ctx_lockstep_groups": (C.c_int, [_P, _PI64]),
     "padne_asm_second_path_count": (C.c_int, [_PI64]),
+    "padne_ctx_halo_exchange_time": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double)]),
 }
 
 _lib = None
@@ -194,6 +196,13 @@ def _ptr(a: np.ndarray, typ):
 def device_count() -> int:
     n = load_library().padne_device_count()
     return max(n, 0)
+
+
+def launch_count() -> int:
+    """Kernels and asynchronous fills this process has queued through the library so far (all contexts)."""
+    n = C.c_longlong(0)
+    _check(load_library().padne_launch_count(C.byref(n)))
+    return int(n.value)
 
 
 def asm_second_path_count() -> int:
@@ -300,6 +309,12 @@ class Context:
         nbytes = (C.c_longlong * 4)()
         _check(self._lib.padne_comm_call_counts(calls, nbytes))
         return list(calls), list(nbytes)
+
+    def halo_exchange_time(self, repeats: int = 200) -> float:
+        """Average device seconds of one halo exchange of this context's plan (collective; test introspection)."""
+        t = C.c_double(0.0)
+        _check(self._lib.padne_ctx_halo_exchange_time(self._h, int(repeats), C.byref(t)))
+        return float(t.value)
 
     def lockstep_groups(self) -> int:
         """Groups of right-hand sides this context has advanced in lockstep so far (test introspection)."""
@@ -648,12 +663,19 @@ class CsrMatrix:
         return sp.csr_matrix((data, indices, indptr), shape=self.shape)
 
     def reduce(self, index_map, n_out: int, scale: float = 1.0) -> "CsrMatrix":
-        m = _i32(index_map)
-        if m.shape[0] != self.shape[0]:
-            raise ValueError("index map length must equal the matrix dimension")
+        """``scale * P^T M P``.  ``index_map``: a host array, or a ``DeviceArray`` of int32 already on this GPU (the
+        library reads a device-resident map where it lies: no upload per call)."""
+        if isinstance(index_map, DeviceArray):
+            if index_map.dtype != np.int32 or int(np.prod(index_map.shape)) != self.shape[0]:
+                raise ValueError("index map must be int32 of the matrix dimension")
+            mp = C.cast(_P(index_map.ptr), _PI32)
+        else:
+            m = _i32(index_map)
+            if m.shape[0] != self.shape[0]:
+                raise ValueError("index map length must equal the matrix dimension")
+            mp = _ptr(m, _PI32)
         h = _P()
-        _check(self.ctx._lib.padne_csr_reduce(self.ctx._h, self._h, _ptr(m, _PI32), int(n_out), float(scale),
-                                              C.byref(h)))
+        _check(self.ctx._lib.padne_csr_reduce(self.ctx._h, self._h, mp, int(n_out), float(scale), C.byref(h)))
         return CsrMatrix(self.ctx, h)
 
     def relabel(self, row_map: np.ndarray, n_rows_out: int, col_map: np.ndarray, n_cols_out: int,

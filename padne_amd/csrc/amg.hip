@@ -780,112 +780,141 @@ __global__ __launch_bounds__(256) void gershgorin_filtered_kernel(int n, const i
     if (threadIdx.x == 0) partial_max[blockIdx.x] = red[0];
 }
 
-// transpose: count / fill
-// Entries per column.  The columns of 1024 consecutive entries of a prolongator (the rows of a few mesh lines) lie in a
-// short range: they are counted in LDS first, and every column met sends ONE atomic to memory -- a tenth of the atomics
-// of one per entry (0.56 ms for the 24 M entries of config C4's finest prolongator).  A workgroup whose columns span more
-// than kTcRange counts every entry globally.
-constexpr int kTcRange = 4096, kTcPer = 4;
-constexpr int kTfRange = 2048;        // transpose_fill: the columns of 256 rows; 16 KiB of LDS, eight workgroups per CU
-__global__ __launch_bounds__(256) void transpose_count(long long nnz, const int *__restrict__ cols, int *__restrict__ cnt, const int no_range) {
-    // no_range (PADNE_TRANSPOSE_HASH, tests): every workgroup takes the hash path of the wide ranges
-    __shared__ int lcnt[kTcRange];
-    __shared__ int s_min, s_max;
-    if (threadIdx.x == 0) {
-        s_min = 0x7fffffff;
-        s_max = -1;
-    }
-    __syncthreads();
-    const long long k0 = ((long long)blockIdx.x * 256 + threadIdx.x) * kTcPer;
-    int c[kTcPer];
-    if (k0 + kTcPer <= nnz) {
-        const int4 c4 = *reinterpret_cast<const int4 *>(cols + k0);      // (k0 is a multiple of four)
-        c[0] = c4.x; c[1] = c4.y; c[2] = c4.z; c[3] = c4.w;
-    } else {
-#pragma unroll
-        for (int u = 0; u < kTcPer; ++u) c[u] = k0 + u < nnz ? cols[k0 + u] : -1;
-    }
-    int lo = 0x7fffffff, hi = -1;
-#pragma unroll
-    for (int u = 0; u < kTcPer; ++u)
-        if (c[u] >= 0) {
-            lo = min(lo, c[u]);
-            hi = max(hi, c[u]);
-        }
-    for (int off = 32; off > 0; off >>= 1) {
-        lo = min(lo, __shfl_down(lo, off, 64));
-        hi = max(hi, __shfl_down(hi, off, 64));
-    }
-    if ((threadIdx.x & 63) == 0) {
-        atomicMin(&s_min, lo);
-        atomicMax(&s_max, hi);
-    }
-    __syncthreads();
-    const int base = s_min;
-    if (s_max < 0) return;
-    const long long range = (long long)s_max - base + 1;
-    if (range > kTcRange || no_range) {
-        // columns spread over a wider range (a mesh line longer than the table: 160 M unknowns): the same through a hash
-        // table of the columns met -- at most 1024 of them, 2048 places -- instead of one atomic per entry in memory
-        int *keys = lcnt, *num = lcnt + kTcRange / 2;
-        for (int j = threadIdx.x; j < kTcRange / 2; j += 256) {
-            keys[j] = -1;
-            num[j] = 0;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < kTcPer; ++u)
-            if (c[u] >= 0) {
-                unsigned h = ((unsigned)c[u] * 2654435761u) >> 21;
-                for (;;) {
-                    h &= kTcRange / 2 - 1;
-                    const int old = atomicCAS(&keys[h], -1, c[u]);
-                    if (old == -1 || old == c[u]) break;
-                    ++h;
-                }
-                atomicAdd(&num[h], 1);
-            }
-        __syncthreads();
-        for (int j = threadIdx.x; j < kTcRange / 2; j += 256)
-            if (num[j] > 0) atomicAdd(&cnt[keys[j]], num[j]);
-        return;
-    }
-    for (int j = threadIdx.x; j < (int)range; j += 256) lcnt[j] = 0;
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < kTcPer; ++u)
-        if (c[u] >= 0) atomicAdd(&lcnt[c[u] - base], 1);
-    __syncthreads();
-    for (int j = threadIdx.x; j < (int)range; j += 256) {
-        const int v = lcnt[j];
-        if (v > 0) atomicAdd(&cnt[base + j], v);
+// ---- transposes whose rows come out in column order: no sort ---------------------------------------------------------
+// Entry (i, c) of M lands in row c of M^T behind every row i' < i that holds c.  A wave takes 64 consecutive rows of M (one
+// lane per row) and knows the order of ITS rows; what it does not know is how many entries the waves before it put into
+// the same row of M^T.  One atomic on a cursor per (block, column) hands out places in the order the blocks happen to
+// run -- the rows then had to be sorted afterwards (sort_csr_rows_seg: 1.6 ms beside the product A P of config C4's fine
+// level, the main stream waited 1.1 ms per setup for the restrictions).  Instead the counting pass leaves, per column,
+// the list of the waves that hold it with their counts -- (wave << 6 | count - 1), in the order of arrival, at most kTpK
+// of them: the rows of a mesh neighbourhood lie in a few runs of consecutive rows -- and the filling pass adds up the
+// counts of the waves in front of its own: a place that depends on nothing but the matrix.  Inside a wave the rows that
+// hold a column are a 64-bit MASK in a wave-private LDS hash table of the columns met (atomic OR: the result does not
+// depend on the order of the lanes); an entry's place among them is the number of lower bits.  No workgroup barrier, no
+// scan, nothing to sort.  Columns met by more than kTpK waves (hubs, scattered numberings) take a cursor as before and
+// are sorted by sort_csr_rows_seg, which skips all other rows; a wave whose rows hold more entries than its table takes
+// marks all its columns as such.  Same matrix either way, bit for bit.
+constexpr int kTpK = 16;              // waves per column the lists hold (64 bytes per column)
+constexpr int kTpSlots = 320;         // places of a wave's hash table: 16 bytes each, 20 KiB per workgroup of four waves
+constexpr int kTpMaxEntries = 240;    // entries of a wave's 64 rows the table takes (3.75 per row)
+
+__device__ __forceinline__ unsigned tp_hash(const int c) {
+    return (unsigned)(((unsigned long long)((unsigned)c * 2654435761u) * (unsigned long long)kTpSlots) >> 32);
+}
+__device__ __forceinline__ int tp_insert(int *key, const int c) {
+    unsigned h = tp_hash(c);
+    for (;;) {
+        const int old = atomicCAS(&key[h], -1, c);
+        if (old == -1 || old == c) return (int)h;
+        h = h + 1 == (unsigned)kTpSlots ? 0u : h + 1;
     }
 }
-
-__global__ __launch_bounds__(256) void transpose_fill(int n_rows, const int *__restrict__ rowptr, const int *__restrict__ cols,
-                                                      const double *__restrict__ vals, const int *__restrict__ slot_ptr,
-                                                      int *__restrict__ cursor, int *__restrict__ key,
-                                                      double *__restrict__ val, const int no_range) {
-    // (key / val: the cols / vals arrays of the transposed matrix -- an entry lands in its row at the place the atomics
-    //  hand out, sort_csr_rows_seg then puts every row in column order: no slots, no unpacking pass)
-    // One lane per row; the first four entries of every row together (their columns and values in three loads).  Their
-    // places in the columns are handed out like transpose_count counts: inside the workgroup by LDS atomics, and one
-    // atomic per column met advances the column's cursor in memory -- an entry at a time every entry waited for its own
-    // load, gather and atomic round trip, two or three times in a row.  (The kernel runs next to the product A P on the
-    // other stream; with 32 KiB of LDS -- kTcRange columns -- it took 2.2 ms by its own clock and still shortened the setup,
-    // 17.7 -> 16.95 ms on config C4, because A P no longer waited for its atomics; with 16 KiB it takes 0.46 ms.)
-    __shared__ int lcnt[kTfRange], lbase[kTfRange];
-    __shared__ int s_min, s_max;
-    if (threadIdx.x == 0) {
-        s_min = 0x7fffffff;
-        s_max = -1;
+__device__ __forceinline__ int tp_find(const int *key, const int c) {
+    unsigned h = tp_hash(c);
+    while (key[h] != c) h = h + 1 == (unsigned)kTpSlots ? 0u : h + 1;
+    return (int)h;
+}
+// the wave's table: every column its rows hold -> the lanes that hold it.  slot[0..3]: places of the row's first entries
+__device__ __forceinline__ void tp_build(int *key, unsigned long long *mask, const int *__restrict__ cols, const int k0,
+                                         const int k1, const int c[4], int slot[4]) {
+    const int lane = threadIdx.x & 63;
+    for (int j = lane; j < kTpSlots; j += 64) {
+        key[j] = -1;
+        mask[j] = 0ull;
     }
-    __syncthreads();
-    const int i = xcd_bid() * blockDim.x + threadIdx.x;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long bit = 1ull << lane;
+    const int ln = k1 - k0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        slot[u] = 0;
+        if (u < ln) {
+            slot[u] = tp_insert(key, c[u]);
+            atomicOr(&mask[slot[u]], bit);
+        }
+    }
+    for (int k = k0 + 4; k < k1; ++k) atomicOr(&mask[tp_insert(key, cols[k])], bit);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(256) void transpose_count_pairs(int n_rows, const int *__restrict__ rowptr,
+                                                             const int *__restrict__ cols, int *__restrict__ cnt,
+                                                             int *__restrict__ npairs, int *__restrict__ pairs,
+                                                             const int all_cursors) {
+    // all_cursors (PADNE_TRANSPOSE_CURSORS, tests): every wave takes the path of the waves whose rows exceed the table
+    __shared__ int Key[4][kTpSlots];
+    __shared__ unsigned long long Mask[4][kTpSlots];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wb = (int)xcd_bid() * 4 + w;
+    const int r0 = wb * 64, i = r0 + lane;
+    if (r0 >= n_rows) return;
     const bool live = i < n_rows;
     const int k0 = live ? rowptr[i] : 0, k1 = live ? rowptr[i + 1] : 0;
     const int ln = k1 - k0;
-    int c[4] = {0, 0, 0, 0};
+    const int tot = __shfl(live ? k1 : 0, min(63, n_rows - 1 - r0), 64) - __shfl(k0, 0, 64);
+    if (tot > kTpMaxEntries || all_cursors) {
+        // more entries than the table takes: every column of these rows goes through its cursor, in every wave that holds it
+        for (int k = k0; k < k1; ++k) {
+            const int cc = cols[k];
+            atomicAdd(&cnt[cc], 1);
+            atomicAdd(&npairs[cc], kTpK + 1);
+        }
+        return;
+    }
+    int c[4] = {0, 0, 0, 0}, slot[4];
+    if (ln > 0) {
+        const int4 c4 = load_i4_unaligned(cols + k0);
+        c[0] = c4.x; c[1] = c4.y; c[2] = c4.z; c[3] = c4.w;
+    }
+    tp_build(Key[w], Mask[w], cols, k0, k1, c, slot);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    // the first row that holds a column reports the wave's count of it
+    auto report = [&](const int cc, const int sl) {
+        const unsigned long long m = Mask[w][sl];
+        if ((m & below) != 0ull) return;
+        const int n_here = __popcll(m);
+        atomicAdd(&cnt[cc], n_here);
+        const int at = atomicAdd(&npairs[cc], 1);
+        if (at < kTpK) pairs[(long long)cc * kTpK + at] = (int)(((unsigned)wb << 6) | (unsigned)(n_here - 1));
+    };
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (u < ln) report(c[u], slot[u]);
+    for (int k = k0 + 4; k < k1; ++k) {
+        const int cc = cols[k];
+        report(cc, tp_find(Key[w], cc));
+    }
+}
+
+__global__ __launch_bounds__(256) void transpose_fill_ordered(int n_rows, const int *__restrict__ rowptr,
+                                                              const int *__restrict__ cols, const double *__restrict__ vals,
+                                                              const int *__restrict__ t_rowptr, const int *__restrict__ npairs,
+                                                              const int *__restrict__ pairs, int *__restrict__ cursor,
+                                                              int *__restrict__ key, double *__restrict__ val,
+                                                              const int all_cursors) {
+    // (key / val: the cols / vals arrays of the transposed matrix)
+    __shared__ int Key[4][kTpSlots], Base[4][kTpSlots];
+    __shared__ unsigned long long Mask[4][kTpSlots];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wb = (int)xcd_bid() * 4 + w;
+    const int r0 = wb * 64, i = r0 + lane;
+    if (r0 >= n_rows) return;
+    const bool live = i < n_rows;
+    const int k0 = live ? rowptr[i] : 0, k1 = live ? rowptr[i + 1] : 0;
+    const int ln = k1 - k0;
+    const int tot = __shfl(live ? k1 : 0, min(63, n_rows - 1 - r0), 64) - __shfl(k0, 0, 64);
+    if (tot > kTpMaxEntries || all_cursors) {
+        for (int k = k0; k < k1; ++k) {                    // (the counting pass has sent all these columns to their cursors)
+            const int cc = cols[k];
+            const int at = t_rowptr[cc] + atomicAdd(&cursor[cc], 1);
+            key[at] = i;
+            val[at] = vals[k];
+        }
+        return;
+    }
+    int c[4] = {0, 0, 0, 0}, slot[4];
     double v[4] = {0.0, 0.0, 0.0, 0.0};
     if (ln > 0) {
         const int4 c4 = load_i4_unaligned(cols + k0);
@@ -893,97 +922,57 @@ __global__ __launch_bounds__(256) void transpose_fill(int n_rows, const int *__r
         c[0] = c4.x; c[1] = c4.y; c[2] = c4.z; c[3] = c4.w;
         v[0] = v01.x; v[1] = v01.y; v[2] = v23.x; v[3] = v23.y;
     }
-    int lo = 0x7fffffff, hi = -1;
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-        if (u < ln) {
-            lo = min(lo, c[u]);
-            hi = max(hi, c[u]);
-        }
-    for (int off = 32; off > 0; off >>= 1) {
-        lo = min(lo, __shfl_down(lo, off, 64));
-        hi = max(hi, __shfl_down(hi, off, 64));
-    }
-    if ((threadIdx.x & 63) == 0) {
-        atomicMin(&s_min, lo);
-        atomicMax(&s_max, hi);
-    }
-    __syncthreads();
-    const int base = s_min;
-    const long long range = (long long)s_max - base + 1;
-    int at[4] = {0, 0, 0, 0};
-    if (s_max >= 0 && range <= kTfRange && !no_range) {
-        for (int j = threadIdx.x; j < (int)range; j += 256) lcnt[j] = 0;
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (u < ln) at[u] = atomicAdd(&lcnt[c[u] - base], 1);
-        __syncthreads();
-        for (int j0 = threadIdx.x; j0 < (int)range; j0 += 4 * 256) {      // four columns per lane in flight, not one after the other
-            int n_here[4], got[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) n_here[q] = j0 + 256 * q < (int)range ? lcnt[j0 + 256 * q] : 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) got[q] = n_here[q] > 0 ? atomicAdd(&cursor[base + j0 + 256 * q], n_here[q]) : 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (j0 + 256 * q < (int)range) lbase[j0 + 256 * q] = got[q];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (u < ln) at[u] += lbase[c[u] - base];
-    } else if (s_max >= 0) {
-        // columns spread over a wider range: the same through a hash table of the columns met (at most 1024, 2048 places)
-        static_assert(kTfRange == 2048, "hash of 11 bits");
-        int slot[4] = {0, 0, 0, 0};
-        for (int j = threadIdx.x; j < kTfRange; j += 256) {
-            lbase[j] = -1;                                 // (the keys, while the entries are counted)
-            lcnt[j] = 0;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (u < ln) {
-                unsigned h = ((unsigned)c[u] * 2654435761u) >> 21;
-                for (;;) {
-                    h &= kTfRange - 1;
-                    const int old = atomicCAS(&lbase[h], -1, c[u]);
-                    if (old == -1 || old == c[u]) break;
-                    ++h;
-                }
-                slot[u] = (int)h;
-                at[u] = atomicAdd(&lcnt[h], 1);
-            }
-        __syncthreads();
-        for (int j0 = threadIdx.x; j0 < kTfRange; j0 += 4 * 256) {
-            int n_here[4], got[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) n_here[q] = lcnt[j0 + 256 * q];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) got[q] = n_here[q] > 0 ? atomicAdd(&cursor[lbase[j0 + 256 * q]], n_here[q]) : 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) lcnt[j0 + 256 * q] = got[q];      // (in place: the counts are in the lanes' registers)
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (u < ln) at[u] += lcnt[slot[u]];
-    }
     int sp[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) sp[u] = u < ln ? slot_ptr[c[u]] : 0;
+    for (int u = 0; u < 4; ++u) sp[u] = u < ln ? t_rowptr[c[u]] : 0;      // (on their way while the table is built)
+    tp_build(Key[w], Mask[w], cols, k0, k1, c, slot);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    // the first row that holds a column finds out how many entries the waves in front of this one put into it: from the
+    // column's list of (wave, count), or from its cursor
+    auto fetch = [&](const int cc, const int sl) {
+        const unsigned long long m = Mask[w][sl];
+        if ((m & below) != 0ull) return;
+        // (the list is requested with its length, not behind it: one round trip)
+        const int4 *pp = reinterpret_cast<const int4 *>(pairs + (long long)cc * kTpK);
+        const int np = npairs[cc];
+        int4 q[kTpK / 4];
+#pragma unroll
+        for (int t = 0; t < kTpK / 4; ++t) q[t] = pp[t];
+        int got = 0;
+        if (np <= kTpK) {
+#pragma unroll
+            for (int t = 0; t < kTpK / 4; ++t) {
+                const int kk[4] = {q[t].x, q[t].y, q[t].z, q[t].w};
+#pragma unroll
+                for (int z = 0; z < 4; ++z)
+                    if (4 * t + z < np && (int)((unsigned)kk[z] >> 6) < wb) got += (kk[z] & 63) + 1;
+            }
+        } else {
+            got = atomicAdd(&cursor[cc], __popcll(m));
+        }
+        Base[w][sl] = got;
+    };
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (u < ln) fetch(c[u], slot[u]);
+    for (int k = k0 + 4; k < k1; ++k) {
+        const int cc = cols[k];
+        fetch(cc, tp_find(Key[w], cc));
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int u = 0; u < 4; ++u)
         if (u < ln) {
-            key[sp[u] + at[u]] = i;                       // rows are unique inside a column: the sort makes the order canonical
-            val[sp[u] + at[u]] = v[u];
+            const int at = sp[u] + Base[w][slot[u]] + __popcll(Mask[w][slot[u]] & below);
+            key[at] = i;
+            val[at] = v[u];
         }
-    for (int k = k0 + 4; k < k1; ++k) {                  // (behind every barrier: a lane may leave the others here)
-        const int cc = cols[k];
-        const int s = slot_ptr[cc] + atomicAdd(&cursor[cc], 1);
-        key[s] = i;
-        val[s] = vals[k];
+    for (int k = k0 + 4; k < k1; ++k) {
+        const int cc = cols[k], sl = tp_find(Key[w], cc);
+        const int at = t_rowptr[cc] + Base[w][sl] + __popcll(Mask[w][sl] & below);
+        key[at] = i;
+        val[at] = vals[k];
     }
 }
 
@@ -997,7 +986,8 @@ __global__ __launch_bounds__(256) void transpose_fill(int n_rows, const int *__r
 constexpr int kSegRows = 8, kSegCap = 64;
 __global__ __launch_bounds__(256) void sort_csr_rows_seg(const int n_rows, const int *__restrict__ rowptr, int *__restrict__ cols,
                                                          double *__restrict__ vals, int *__restrict__ n_long,
-                                                         int *__restrict__ long_list) {
+                                                         int *__restrict__ long_list, const int *__restrict__ npairs) {
+    // (behind transpose_fill_ordered only the rows that took a cursor -- more than kTpK waves -- are out of order)
     __shared__ int Cs[4][kSegRows * kSegCap];
     __shared__ double Vs[4][kSegRows * kSegCap];
     __shared__ int Rs[4][kSegRows + 1];
@@ -1006,6 +996,7 @@ __global__ __launch_bounds__(256) void sort_csr_rows_seg(const int n_rows, const
     const XcdSweep sw = xcd_sweep(n_chunks, 4, w);
     for (long long ch = sw.t0; ch < sw.t1; ch += sw.stride) {
         const int r0 = (int)(ch * kSegRows);
+        if (__ballot(lane < kSegRows && r0 + lane < n_rows && npairs[r0 + lane] > kTpK) == 0ull) continue;
         int rp = 0;
         if (lane <= kSegRows) rp = rowptr[min(r0 + lane, n_rows)];
         // a chunk with a row beyond the LDS capacity (rare: aggregates next to a via ring, hubs) is listed as a whole --
@@ -3059,33 +3050,37 @@ static int build_prolongator(padne_ctx *ctx, const padne_csr *A, const int *agg,
 
 // No host synchronisation (the number of entries is known): may be queued on the context's second stream.
 static int transpose(padne_ctx *ctx, const padne_csr *M, padne_csr **T) {
-    // count the entries per column, scan the counts into the row pointer of the transpose, place every entry in its row
-    // (transpose_fill: LDS counting, one atomic per column and workgroup), sort the rows in place -- straight into the CSR
-    // arrays of the result, nothing of it needs the host
+    // count the entries per column -- and, per column, the waves of 64 rows that hold it (transpose_count_pairs) --, scan
+    // the counts into the row pointer of the transpose, place every entry in its row in the order of the rows
+    // (transpose_fill_ordered): straight into the CSR arrays of the result, in column order, nothing of it needs the
+    // host.  The sort behind it touches only the rows that went through a cursor (see above).
     hipStream_t s = ctx->stream;
     Scratch sc(ctx);
     const long long nc = M->n_cols;
     PADNE_REQUIRE(M->n_rows < 2147483647LL && nc < 2147483647LL, "transpose of a matrix beyond 32-bit indices");
-    int *cnt = nullptr, *long_list = nullptr;
-    PADNE_TRY(sc.alloc(&cnt, (size_t)nc + 2));
+    int *zeroed = nullptr, *long_list = nullptr, *pairs = nullptr;
+    const size_t n_zero = 3 * (size_t)nc + 4;
+    PADNE_TRY(sc.alloc(&zeroed, n_zero));                  // [counts nc + 1 | cursors nc | waves per column nc | n_long]
     PADNE_TRY(sc.alloc(&long_list, (size_t)nc + 1));
+    PADNE_TRY(sc.alloc(&pairs, (size_t)nc * kTpK + 4));
+    int *cnt = zeroed, *cursor = zeroed + nc + 1, *npairs = cursor + nc, *n_long = npairs + nc;
     padne_csr *m = nullptr;
     PADNE_TRY(csr_alloc(ctx, nc, M->n_rows, M->nnz, &m));
-    const int no_range = getenv("PADNE_TRANSPOSE_HASH") != nullptr ? 1 : 0;
-    hipError_t e = hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)(nc + 2), s);
-    if (e == hipSuccess && M->nnz > 0)
-        hipLaunchKernelGGL(transpose_count, dim3(nblk(M->nnz, 256 * kTcPer)), dim3(256), 0, s, (long long)M->nnz, M->cols, cnt, no_range);
+    const int all_cursors = getenv("PADNE_TRANSPOSE_CURSORS") != nullptr ? 1 : 0;
+    hipError_t e = hipMemsetAsync(zeroed, 0, sizeof(int) * n_zero, s);
+    if (e == hipSuccess && M->n_rows > 0)
+        hipLaunchKernelGGL(transpose_count_pairs, dim3(nblk(M->n_rows)), dim3(256), 0, s, (int)M->n_rows, M->rowptr, M->cols, cnt,
+                           npairs, pairs, all_cursors);
     int rc = e == hipSuccess ? exclusive_scan_i32_async(ctx, cnt, m->rowptr, nc) : PADNE_E_HIP;
-    if (rc == PADNE_OK) e = hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)(nc + 2), s);
-    int *n_long = cnt + nc + 1;                                        // (behind the cursors, zeroed with them)
     if (rc == PADNE_OK && e == hipSuccess && M->n_rows > 0) {
-        hipLaunchKernelGGL(transpose_fill, dim3(nblk(M->n_rows)), dim3(256), 0, s, (int)M->n_rows, M->rowptr, M->cols, M->vals,
-                           (const int *)m->rowptr, cnt, m->cols, m->vals, no_range);
+        hipLaunchKernelGGL(transpose_fill_ordered, dim3(nblk(M->n_rows)), dim3(256), 0, s, (int)M->n_rows, M->rowptr, M->cols,
+                           M->vals, (const int *)m->rowptr, (const int *)npairs, (const int *)pairs, cursor, m->cols, m->vals,
+                           all_cursors);
         const long long n_chunks = (nc + kSegRows - 1) / kSegRows;
         unsigned g = (unsigned)std::min<long long>((n_chunks + 3) / 4, 8192);
         if (g >= (unsigned)kNumXcd) g -= g % kNumXcd;
         hipLaunchKernelGGL(sort_csr_rows_seg, dim3(g > 0 ? g : 1), dim3(256), 0, s, (int)nc, (const int *)m->rowptr, m->cols, m->vals,
-                           n_long, long_list);
+                           n_long, long_list, (const int *)npairs);
         hipLaunchKernelGGL(sort_listed_csr_rows, dim3(256), dim3(256), 0, s, (const int *)n_long, (const int *)long_list,
                            (const int *)m->rowptr, m->cols, m->vals);
         e = hipGetLastError();
@@ -3402,7 +3397,9 @@ static int build_w_operator(padne_ctx *ctx, const padne_csr *A, const padne_csr 
     Scratch sc(ctx);
     int *len = nullptr;
     PADNE_TRY(sc.alloc(&len, (size_t)n + 1));
-    padne_csr *W = new padne_csr();
+    struct CsrDrop { void operator()(padne_csr *m) const { if (m) padne_csr_destroy(m); } };
+    std::unique_ptr<padne_csr, CsrDrop> w_owner(new padne_csr());      // (every way out but the last destroys it)
+    padne_csr *W = w_owner.get();
     W->n_rows = n;
     W->n_cols = P->n_cols;
     W->nnz = n_slots;                      // capacity; the row pointers hold the truth
@@ -3413,10 +3410,7 @@ static int build_w_operator(padne_ctx *ctx, const padne_csr *A, const padne_csr 
     W->rowptr = (int32_t *)pool_alloc(ctx, sizeof(int32_t) * ((size_t)n + 1));
     W->cols = (int32_t *)pool_alloc(ctx, sizeof(int32_t) * ((size_t)n_slots + kPadNnz));
     W->vals32 = (float *)pool_alloc(ctx, sizeof(float) * ((size_t)n_slots + kPadNnz));
-    if (!W->rowptr || !W->cols || !W->vals32) {
-        padne_csr_destroy(W);
-        return PADNE_E_NOMEM;
-    }
+    if (!W->rowptr || !W->cols || !W->vals32) return PADNE_E_NOMEM;
     hipLaunchKernelGGL(slot_row_lengths, dim3(nblk(n)), dim3(256), 0, s, n, ap.begin, ap.end, len);
     PADNE_HIP_CHECK(hipGetLastError());
     PADNE_TRY(exclusive_scan_i32_async(ctx, len, W->rowptr, n));
@@ -3427,13 +3421,9 @@ static int build_w_operator(padne_ctx *ctx, const padne_csr *A, const padne_csr 
     PADNE_HIP_CHECK(hipGetLastError());
     // its x-window plan: twelve short runs per tile (spmv.hip, csr_build_xw_plan_wide), on this stream, no look at the host
     W->xw_state = 0;
-    const int rc_plan = csr_build_xw_plan_wide(ctx, W, grid_cap);
-    if (rc_plan != PADNE_OK) {
-        padne_csr_destroy(W);
-        return rc_plan;
-    }
+    PADNE_TRY(csr_build_xw_plan_wide(ctx, W, grid_cap));
     if (W->xw_state != 1) W->xw_state = -1;
-    *W_out = W;
+    *W_out = w_owner.release();
     return PADNE_OK;
 }
 
@@ -3823,7 +3813,11 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         } else {
             amg->n_coarse = (int)last.n;
             PhaseTimer pd(ctx, amg_verbose());
-            rc = dense_inverse(ctx, last.A, &amg->coarse_inv);
+            // the W operators of the inner levels are built on the second stream while this stream inverts: they read P,
+            // 1/diag and the kept slots of A P, all written on this stream -- ordered behind what is queued here so far (an
+            // event wait in front of the inverse, not behind it)
+            if (two && !ap_inner.empty()) rc = stream_order(ctx, aux);
+            if (rc == PADNE_OK) rc = dense_inverse(ctx, last.A, &amg->coarse_inv);
             pd.lap("dense inverse");
         }
     }
@@ -4329,7 +4323,11 @@ static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0) {
         Lr.jac = 1.0 / (0.5 * (Lr.lambda + Lr.lambda / kChebRatio));
         if ((rc = alloc_vec(ctx, &Lr.xa, Lr.n + (long long)W * plan.m)) != PADNE_OK) break;
         if ((rc = alloc_vec(ctx, &Lr.tmp, A->n_rows)) != PADNE_OK) break;
-        if (lvl > 0 && ((rc = alloc_vec(ctx, &Lr.b, Lr.n)) != PADNE_OK || (rc = alloc_vec(ctx, &Lr.xb, Lr.n)) != PADNE_OK)) break;
+        // (xb: the level's solution WITH its exchange area -- the W up-leg of the level above multiplies it)
+        if (lvl > 0 && ((rc = alloc_vec(ctx, &Lr.b, Lr.n)) != PADNE_OK ||
+                        (rc = alloc_vec(ctx, &Lr.xb, Lr.n + (long long)W * plan.m)) != PADNE_OK)) break;
+        if (lvl > 0 && (rc = hipMemsetAsync(Lr.xb, 0, sizeof(double) * (size_t)(Lr.n + (long long)W * plan.m), s) == hipSuccess
+                                 ? PADNE_OK : PADNE_E_HIP) != PADNE_OK) break;
         if ((rc = hipMemsetAsync(Lr.xa, 0, sizeof(double) * (size_t)(Lr.n + (long long)W * plan.m), s) == hipSuccess
                       ? PADNE_OK : PADNE_E_HIP) != PADNE_OK) break;
         if (coarsest) break;
@@ -4377,11 +4375,29 @@ static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0) {
         Lr.P_halo = P_halo;                 // kept: see AmgLevel (dropped again below on all but the last partitioned level)
         if (rc != PADNE_OK) break;
         pt.lap("exchange P rows");
-        rc = spgemm(ctx, A, P_ext, &AP);
+        // A [P ; P_halo] stays in its merge slots as on one GPU (consumed by R (A P) row by row), and the up-leg operator of
+        // the float cycle is formed from them: W = [P | 0] - c D^-1 A [P ; P_halo], columns [aggregates | exchange slots of
+        // the coarse level] -- coarse correction and post-smoothing of the owned rows in ONE product with the coarse
+        // solution and its exchanged values (amg_apply_f32), instead of prolongation, exchange of the corrected iterate and
+        // a product with A
+        SlotRows ap_rows;
+        rc = spgemm(ctx, A, P_ext, &AP, nullptr, &ap_rows);
+        if (rc != PADNE_OK) { padne_csr_destroy(P_ext); break; }
+        if (ap_rows.valid) {
+            padne_csr ap_shape;
+            ap_shape.n_rows = ap_rows.n_rows;
+            ap_shape.n_cols = ap_rows.n_cols;
+            rc = spgemm(ctx, Lr.R, &ap_shape, &Ac, &ap_rows);
+            if (rc == PADNE_OK && A->dinv != nullptr && getenv("PADNE_AMG_NO_W") == nullptr) {
+                rc = build_w_operator(ctx, A, Lr.P, ap_rows, ap_rows.n_slots, Lr.jac, &Lr.W);
+                if (rc == PADNE_OK) Lr.W->n_cols = P_ext->n_cols;
+            }
+        } else {
+            rc = spgemm(ctx, Lr.R, AP, &Ac);
+        }
+        ap_rows.release();
         padne_csr_destroy(P_ext);
-        if (rc != PADNE_OK) break;
-        rc = spgemm(ctx, Lr.R, AP, &Ac);
-        padne_csr_destroy(AP);
+        if (AP) padne_csr_destroy(AP);
         if (rc != PADNE_OK) break;
         if ((rc = csr_build_dinv(ctx, Ac)) != PADNE_OK) { padne_csr_destroy(Ac); break; }
         pt.lap("galerkin");
@@ -4519,6 +4535,23 @@ static int amg_apply_f32(padne_ctx *ctx, Amg *amg, const double *r, double *z, d
     for (int l = nl - 2; l >= 0; --l) {
         AmgLevel &L = amg->levels[l];
         float *b = (float *)L.b, *xa = (float *)L.xa;
+        if (L.W != nullptr && amg->dist) {
+            // row-partitioned level: the same product, its input the coarse solution with the other ranks' exported values
+            // behind it -- computed from the tail solution on the last partitioned level (e_ext), exchanged otherwise: one
+            // exchange of the COARSE level's vector instead of one of this level's corrected iterate
+            float *e = (float *)amg->levels[l + 1].xb;
+            if (local_halo && l == nl - 2)
+                e = L.e_ext;
+            else
+                PADNE_TRY(halo_exchange_plan_f32(ctx, amg->levels[l + 1].halo, e, done_flag));
+            if (l == 0)
+                PADNE_TRY(launch_spmv_f32_wup_exit(ctx, L.W, e, z, r, partials_rz, done_flag, xa, (const float *)L.tmp,
+                                                   L.A->dinv32, (float)L.jac, bb2, z32, nullptr));
+            else
+                PADNE_TRY(launch_spmv_f32_wup(ctx, L.W, e, (float *)L.xb, done_flag, xa, (const float *)L.tmp, L.A->dinv32,
+                                              (float)L.jac));
+            continue;
+        }
         if (L.W != nullptr && !amg->dist) {
             // coarse correction + post-smoothing (+ exit) in one product with W = P - c D^-1 A P (tmp still holds the
             // residual of the pre-smoothed iterate that the down-leg restricted)
@@ -4679,7 +4712,7 @@ bool amg_supports_batch8(const padne_csr *A0) {
 // number of per-workgroup r.z partials the last stage of the cycle writes (the grid of that launch)
 int amg_rz_partials(const padne_csr *A0) {
     const Amg *amg = (const Amg *)A0->amg;
-    if (amg != nullptr && amg->f32 && !amg->dist && !amg->levels.empty() && amg->levels[0].W != nullptr)
+    if (amg != nullptr && amg->f32 && !amg->levels.empty() && amg->levels[0].W != nullptr)
         return spmv_grid(amg->levels[0].W);
     return spmv_partials(A0);
 }

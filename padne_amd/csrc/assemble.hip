@@ -1886,6 +1886,117 @@ __global__ __launch_bounds__(128) void relabel_fill_direct(long long n_rows, con
     }
 }
 
+// ---- order-preserving maps: eliminations without a permutation -------------------------------------------------
+// The reduction of the reference's system to its potential block (solver.py:544-560: drop the ground vertex and the
+// multiplier row, flip the sign) is a map that only DROPS indices: the kept ones keep their order.  Then a row's kept entries
+// are in column order as they stand -- nothing to sort, nothing to check for duplicates -- and the relabel is a copy with
+// holes: count, scan, copy.  (Through the general direct path the same call cost 1.8 ms at 10 M rows: a histogram for the
+// injectivity test, a thread walking every row entry by entry, an insertion sort in LDS per row.)
+// flag[0] = 1: not such a map; flag[1] = 1: an entry outside [-1, n_out); flag[2] = 1: some index maps to 0
+__global__ void map_is_compaction(long long n, const int *__restrict__ map, int n_out, int *__restrict__ flag) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int t = map[i];
+    if (t < -1 || t >= n_out) {
+        *(volatile int *)(flag + 1) = 1;
+        return;
+    }
+    if (t < 0) return;
+    if (t == 0) *(volatile int *)(flag + 2) = 1;
+    // the next kept index carries t + 1 (the last one n_out - 1): with an index that maps to 0 this makes the kept values
+    // 0, 1, ..., n_out - 1 in order.  A run of more than 64 dropped indices is not followed: the general path takes such maps
+    long long j = i + 1;
+    int tn = -1;
+    for (int step = 0; step < 64 && j < n; ++step, ++j) {
+        tn = map[j];
+        if (tn >= 0) break;
+    }
+    if (j >= n) {
+        if (t != n_out - 1) *(volatile int *)flag = 1;
+    } else if (tn < 0 || tn != t + 1) {
+        *(volatile int *)flag = 1;
+    }
+}
+
+struct __attribute__((packed, aligned(4))) RlI4 { int x, y, z, w; };
+struct __attribute__((packed, aligned(4))) RlD2 { double x, y; };
+
+// kept entries per row, one lane per row, eight entries per step (two unaligned 16-byte loads)
+__global__ __launch_bounds__(256) void relabel_count_ordered(long long n_rows, const int *__restrict__ rowptr,
+                                                             const int *__restrict__ cols, const int *__restrict__ map,
+                                                             const int *__restrict__ cmap, int *__restrict__ cnt) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const int t = map[r];
+    if (t < 0) return;
+    const int k0 = rowptr[r], k1 = rowptr[r + 1];
+    int c = 0;
+    for (int k = k0; k < k1; k += 8) {
+        const RlI4 a = *reinterpret_cast<const RlI4 *>(cols + k), b = *reinterpret_cast<const RlI4 *>(cols + k + 4);   // (the arrays are padded)
+        const int cc[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        int tc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tc[u] = k + u < k1 ? cmap[cc[u]] : -1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c += tc[u] >= 0 ? 1 : 0;
+    }
+    cnt[t] = c;
+}
+
+// the copy: a lane takes its row eight entries at a time, maps the columns, closes the holes in registers and writes the
+// kept entries at the row's place in the result
+__global__ __launch_bounds__(256) void relabel_fill_ordered(long long n_rows, const int *__restrict__ rowptr,
+                                                            const int *__restrict__ cols, const double *__restrict__ vals,
+                                                            const int *__restrict__ map, const int *__restrict__ cmap,
+                                                            double scale, const int *__restrict__ out_rowptr,
+                                                            int *__restrict__ out_cols, double *__restrict__ out_vals,
+                                                            int *__restrict__ zero_seen) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const int t = map[r];
+    if (t < 0) return;
+    const int k0 = rowptr[r], k1 = rowptr[r + 1];
+    int o = out_rowptr[t];
+    bool zero = false;
+    for (int k = k0; k < k1; k += 8) {
+        const RlI4 a = *reinterpret_cast<const RlI4 *>(cols + k), b = *reinterpret_cast<const RlI4 *>(cols + k + 4);
+        const RlD2 v0 = *reinterpret_cast<const RlD2 *>(vals + k), v1 = *reinterpret_cast<const RlD2 *>(vals + k + 2),
+                   v2 = *reinterpret_cast<const RlD2 *>(vals + k + 4), v3 = *reinterpret_cast<const RlD2 *>(vals + k + 6);
+        const int cc[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        const double vv[8] = {v0.x, v0.y, v1.x, v1.y, v2.x, v2.y, v3.x, v3.y};
+        int tc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tc[u] = k + u < k1 ? cmap[cc[u]] : -1;
+#pragma unroll
+        for (int h = 0; h < 8; h += 4) {
+            if (tc[h] >= 0 && tc[h + 1] >= 0 && tc[h + 2] >= 0 && tc[h + 3] >= 0) {
+                // no hole in these four (all rows but those next to a dropped unknown): wide stores
+                double w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    w[u] = scale * vv[h + u];
+                    zero = zero || w[u] == 0.0;
+                }
+                *reinterpret_cast<RlI4 *>(out_cols + o) = RlI4{tc[h], tc[h + 1], tc[h + 2], tc[h + 3]};
+                *reinterpret_cast<RlD2 *>(out_vals + o) = RlD2{w[0], w[1]};
+                *reinterpret_cast<RlD2 *>(out_vals + o + 2) = RlD2{w[2], w[3]};
+                o += 4;
+            } else {
+#pragma unroll
+                for (int u = h; u < h + 4; ++u)
+                    if (tc[u] >= 0) {
+                        const double w = scale * vv[u];
+                        zero = zero || w == 0.0;
+                        out_cols[o] = tc[u];
+                        out_vals[o] = w;
+                        ++o;
+                    }
+            }
+        }
+    }
+    if (zero) *(volatile int *)zero_seen = 1;
+}
+
 // ---- power density ---------------------------------------------------------------------------
 // compute_triangle_gradient (solver.py:689-725) with the face vertex order of the reference:
 // Face.edge is the last interior half-edge created (v3->v1, mesh.py:320-325) so face.vertices
@@ -2465,15 +2576,79 @@ int csr_relabel(padne_ctx *ctx, const padne_csr *m, const int32_t *row_map_host,
     PADNE_TRY(sc.alloc(&d_cnt, (size_t)n_rows_out + 1));
     PADNE_TRY(sc.alloc(&d_slot, (size_t)n_rows_out + 1));
     PADNE_TRY(sc.alloc(&d_err, (size_t)ERR_WORDS));
-    PADNE_HIP_CHECK(hipMemcpyAsync(d_map, row_map_host, sizeof(int) * (size_t)m->n_rows, hipMemcpyDefault, s));
+    // a map that already lies on this device is read where it is (padne_kkt_create builds its maps there; a caller that
+    // reduces one layout again and again keeps the map resident): no 40 MB copy per call at 10 M unknowns
+    auto on_this_device = [&](const int32_t *p) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        return at.type == hipMemoryTypeDevice && at.device == ctx->device;
+    };
+    if (on_this_device(row_map_host)) {
+        d_map = const_cast<int *>(row_map_host);
+    } else {
+        PADNE_HIP_CHECK(hipMemcpyAsync(d_map, row_map_host, sizeof(int) * (size_t)m->n_rows, hipMemcpyDefault, s));
+    }
     if (col_map_host == row_map_host) {
         d_cmap = d_map;
+    } else if (on_this_device(col_map_host)) {
+        d_cmap = const_cast<int *>(col_map_host);
     } else {
         PADNE_TRY(sc.alloc(&d_cmap, (size_t)m->n_cols));
         PADNE_HIP_CHECK(hipMemcpyAsync(d_cmap, col_map_host, sizeof(int) * (size_t)m->n_cols, hipMemcpyDefault, s));
     }
-    PADNE_HIP_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(int) * (size_t)(n_rows_out + 1), s));
     PADNE_HIP_CHECK(hipMemsetAsync(d_err, 0, sizeof(int) * ERR_WORDS, s));
+    if (m->n_rows > 0 && m->n_cols > 0 && n_rows_out > 0 && n_cols_out > 0 && getenv("PADNE_RELABEL_SLOTS") == nullptr) {
+        // maps that only drop indices (the reduction to the potential block): count, scan, copy -- see map_is_compaction
+        static_assert(ERR_WORDS >= 6, "two triples of flag words");
+        hipLaunchKernelGGL(map_is_compaction, dim3(nblk(m->n_rows)), dim3(256), 0, s, (long long)m->n_rows, (const int *)d_map,
+                           (int)n_rows_out, d_err);
+        if (d_cmap != d_map)
+            hipLaunchKernelGGL(map_is_compaction, dim3(nblk(m->n_cols)), dim3(256), 0, s, (long long)m->n_cols,
+                               (const int *)d_cmap, (int)n_cols_out, d_err + 3);
+        // (the counts are those of any one-to-one map; taken before the verdict is known, for one look at the host less)
+        hipLaunchKernelGGL(relabel_count_ordered, dim3(nblk(m->n_rows)), dim3(256), 0, s, (long long)m->n_rows, m->rowptr, m->cols,
+                           (const int *)d_map, (const int *)d_cmap, d_cnt);
+        PADNE_HIP_CHECK(hipGetLastError());
+        int h_flags[6] = {0, 0, 0, 0, 0, 0};
+        PADNE_TRY(read_back(ctx, d_err, sizeof(h_flags), h_flags));
+        if (h_flags[1] || h_flags[4]) {
+            set_error("invalid argument: index map entry out of range");
+            return PADNE_E_INVALID;
+        }
+        const bool rows_ok = h_flags[0] == 0 && h_flags[2] == 1;
+        const bool cols_ok = d_cmap == d_map ? rows_ok && n_rows_out <= n_cols_out : (h_flags[3] == 0 && h_flags[5] == 1);
+        if (rows_ok && cols_ok) {
+            int64_t nnz = 0;
+            PADNE_TRY(exclusive_scan_i32(ctx, d_cnt, d_slot, n_rows_out, &nnz));
+            padne_csr *res = nullptr;
+            PADNE_TRY(csr_alloc(ctx, n_rows_out, n_cols_out, nnz, &res));
+            hipError_t e = hipMemcpyAsync(res->rowptr, d_slot, sizeof(int32_t) * (size_t)(n_rows_out + 1), hipMemcpyDeviceToDevice, s);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(relabel_fill_ordered, dim3(nblk(m->n_rows)), dim3(256), 0, s, (long long)m->n_rows, m->rowptr,
+                                   m->cols, m->vals, (const int *)d_map, (const int *)d_cmap, scale, (const int *)res->rowptr,
+                                   res->cols, res->vals, d_err + 6);
+                e = hipGetLastError();
+            }
+            int h_zero = 0;
+            int rc = e == hipSuccess ? read_back(ctx, d_err + 6, sizeof(int), &h_zero) : PADNE_E_HIP;
+            if (rc != PADNE_OK) {
+                if (e != hipSuccess) set_error("relabel failed: %s", hipGetErrorString(e));
+                (void)hipStreamSynchronize(s);
+                padne_csr_destroy(res);
+                return rc;
+            }
+            if (h_zero == 0) {
+                *out = res;
+                return PADNE_OK;
+            }
+            padne_csr_destroy(res);           // explicit zeros in the source: the slot path drops them
+        }
+        PADNE_HIP_CHECK(hipMemsetAsync(d_err, 0, sizeof(int) * ERR_WORDS, s));
+    }
+    PADNE_HIP_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(int) * (size_t)(n_rows_out + 1), s));
     {
         // injective row and column maps (everything but tied groups of unknowns): direct relabel, no slots
         int *d_hist = nullptr;

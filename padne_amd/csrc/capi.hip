@@ -8,6 +8,8 @@
 
 namespace padne {
 
+std::atomic<long long> g_launch_count{0};
+
 static thread_local char g_err[1024] = "";
 
 void set_error(const char *fmt, ...) {
@@ -104,7 +106,14 @@ void pool_release_all(padne_ctx *ctx) {
 }
 
 static int ctx_init_resources(padne_ctx *ctx) {
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    int prio = prio_least;
+    if (ctx->is_aux) {
+        const char *e = getenv("PADNE_AUX_PRIO");          // (experiment)
+        if (e != nullptr && e[0] == 'h') prio = prio_greatest;
+    }
+    if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio) != hipSuccess ||
         hipMalloc((void **)&ctx->partials, sizeof(double) * 8 * kMaxPartials) != hipSuccess ||
         hipMalloc((void **)&ctx->scalars, sizeof(double) * 64) != hipSuccess ||
         hipMalloc((void **)&ctx->status, 1024) != hipSuccess ||
@@ -282,6 +291,12 @@ __global__ void dot_partial_kernel(const long long n, const double *__restrict__
 }  // namespace padne
 
 using namespace padne;
+
+extern "C" int padne_launch_count(long long *count) {
+    PADNE_REQUIRE(count, "null argument");
+    *count = g_launch_count.load(std::memory_order_relaxed);
+    return PADNE_OK;
+}
 
 extern "C" {
 

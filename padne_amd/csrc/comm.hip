@@ -332,6 +332,10 @@ int comm_p2p_check(padne_ctx *ctx) {
     if (err != 0) {
         set_error("peer-to-peer halo exchange: rank %d waited more than %u ms for the stores of rank %llu (exchange %llu)",
                   ctx->rank, ctx->p2p_timeout_ms, (err >> 48) - 1, err & 0xffffffffffffull);
+        // reported once: a peer that was slow rather than dead must not fail every later solve of this context with the
+        // stale rank and exchange number
+        (void)hipMemsetAsync((char *)ctx->p2p_mbox + kP2pErrorOff, 0, 8, ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream);
         return PADNE_E_COMM;
     }
     return PADNE_OK;
@@ -533,43 +537,67 @@ extern "C" int padne_ctx_p2p_import(padne_ctx *ctx, const void *handles, int32_t
     return PADNE_OK;
 }
 
-// One real exchange through the shared mailboxes -- the kernels, flags and ring entry a solve uses -- with values every rank
-// can check: rank r exports 100 r + k.  A node on which the peers' stores or flags do not arrive (peer access that maps but
-// does not deliver, a runtime that ignores the memory type) shows here, within 2 s and before any solve depends on it:
-// the caller gathers the verdicts and keeps the all-gather unless every rank says yes.
+// Real exchanges through the shared mailboxes -- the kernels, flags and ring entries a solve uses -- with values every rank
+// can check: nine of them (twice around the ring and once more), as WIDE as the mailboxes were exported (every cell of every
+// ring entry is written and read), doubles and floats in turn; in exchange t rank r exports f(r, t, k) for its k-th cell.
+// A node on which the peers' stores or flags do not arrive (peer access that maps but does not deliver, a runtime that
+// ignores the memory type, a link that reorders the flag in front of the data) shows here, within 2 s per exchange and
+// before any solve depends on it: the caller gathers the verdicts and keeps the all-gather unless every rank says yes.
 extern "C" int padne_ctx_p2p_selftest(padne_ctx *ctx, int32_t *ok_out) {
     PADNE_REQUIRE(ctx && ok_out, "null argument");
     *ok_out = 0;
     PADNE_REQUIRE(ctx->p2p_ipc, "padne_ctx_p2p_import comes first");
-    constexpr int kM = 4;
+    const int m = ctx->p2p_m_cap;
+    constexpr int kRounds = 2 * kP2pRing + 1;
     PADNE_HIP_CHECK(hipSetDevice(ctx->device));
-    const size_t n = (size_t)kM + (size_t)ctx->world * kM;
+    const size_t n = (size_t)m + (size_t)ctx->world * (size_t)m;
+    auto value = [](int r, int t, int k) { return 131072.0 * (r + 1) + 16384.0 * (t % 8) + (double)(k % 16384); };   // (integers below 2^24 up to 126 ranks: exact in single precision too)
     std::vector<double> h(n, -1.0);
-    for (int k = 0; k < kM; ++k) h[(size_t)k] = 100.0 * ctx->rank + k;
-    const int idx[kM] = {0, 1, 2, 3};
+    std::vector<float> hf(n, -1.f);
+    std::vector<int> idx((size_t)m);
+    for (int k = 0; k < m; ++k) idx[(size_t)k] = k;
     double *d_v = (double *)pool_alloc(ctx, sizeof(double) * n);
-    int *d_idx = (int *)pool_alloc(ctx, sizeof(int) * kM);
+    int *d_idx = (int *)pool_alloc(ctx, sizeof(int) * (size_t)m);
     if (d_v == nullptr || d_idx == nullptr) {
         pool_free(ctx, d_v);
         pool_free(ctx, d_idx);
         return PADNE_E_NOMEM;
     }
     int rc = PADNE_OK;
-    hipError_t e = hipMemcpyAsync(d_v, h.data(), sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_idx, idx, sizeof(idx), hipMemcpyHostToDevice, ctx->stream);
+    bool ok = comm_p2p_enabled(ctx);                         // (PADNE_NO_P2P: the exchanges below are all-gathers; nothing is tested)
+    hipError_t e = hipMemcpyAsync(d_idx, idx.data(), sizeof(int) * (size_t)m, hipMemcpyHostToDevice, ctx->stream);
     const unsigned keep_timeout = ctx->p2p_timeout_ms;
-    if (e == hipSuccess) {
-        ctx->p2p_timeout_ms = 2000;
-        HaloPlan plan;
-        plan.n_owned = kM;
-        plan.m = kM;
-        plan.n_export = kM;
-        plan.export_idx = d_idx;
-        rc = halo_exchange_plan(ctx, plan, d_v, nullptr);
-        ctx->p2p_timeout_ms = keep_timeout;
+    ctx->p2p_timeout_ms = 2000;
+    HaloPlan plan;
+    plan.n_owned = m;
+    plan.m = m;
+    plan.n_export = m;
+    plan.export_idx = d_idx;
+    for (int t = 0; t < kRounds && e == hipSuccess && rc == PADNE_OK && ok; ++t) {
+        const bool f64 = (t & 1) == 0;
+        if (f64) {
+            std::fill(h.begin(), h.end(), -1.0);
+            for (int k = 0; k < m; ++k) h[(size_t)k] = value(ctx->rank, t, k);
+            e = hipMemcpyAsync(d_v, h.data(), sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) rc = halo_exchange_plan(ctx, plan, d_v, nullptr);
+            if (e == hipSuccess && rc == PADNE_OK) e = hipMemcpyAsync(h.data(), d_v, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream);
+        } else {
+            std::fill(hf.begin(), hf.end(), -1.f);
+            for (int k = 0; k < m; ++k) hf[(size_t)k] = (float)value(ctx->rank, t, k);
+            e = hipMemcpyAsync(d_v, hf.data(), sizeof(float) * n, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) rc = halo_exchange_plan_f32(ctx, plan, (float *)d_v, nullptr);
+            if (e == hipSuccess && rc == PADNE_OK) e = hipMemcpyAsync(hf.data(), d_v, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream);
+        }
+        if (e == hipSuccess && rc == PADNE_OK) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess || rc != PADNE_OK) break;
+        for (int r = 0; r < ctx->world && ok; ++r)
+            for (int k = 0; k < m && ok; ++k) {
+                const size_t at = (size_t)m + (size_t)r * (size_t)m + (size_t)k;
+                ok = f64 ? h[at] == value(r, t, k) : hf[at] == (float)value(r, t, k);
+            }
+        if (comm_p2p_check(ctx) != PADNE_OK) ok = false;     // a wait ran out (the word is cleared with the report): here, not in the first solve
     }
-    if (e == hipSuccess && rc == PADNE_OK) e = hipMemcpyAsync(h.data(), d_v, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess && rc == PADNE_OK) e = hipStreamSynchronize(ctx->stream);
+    ctx->p2p_timeout_ms = keep_timeout;
     pool_free(ctx, d_v);
     pool_free(ctx, d_idx);
     if (e != hipSuccess) {
@@ -577,14 +605,6 @@ extern "C" int padne_ctx_p2p_selftest(padne_ctx *ctx, int32_t *ok_out) {
         return PADNE_E_HIP;
     }
     PADNE_TRY(rc);
-    bool ok = comm_p2p_enabled(ctx) ? true : false;          // (PADNE_NO_P2P: the exchange above was an all-gather; nothing was tested)
-    for (int r = 0; r < ctx->world && ok; ++r)
-        for (int k = 0; k < kM; ++k) ok = ok && h[(size_t)kM + (size_t)r * kM + k] == 100.0 * r + k;
-    if (comm_p2p_check(ctx) != PADNE_OK) {                   // a wait ran out: report it here, not in the first solve
-        ok = false;
-        (void)hipMemsetAsync((char *)ctx->p2p_mbox + kP2pErrorOff, 0, 8, ctx->stream);
-        (void)hipStreamSynchronize(ctx->stream);
-    }
     *ok_out = ok || !comm_p2p_enabled(ctx) ? 1 : 0;
     return PADNE_OK;
 }

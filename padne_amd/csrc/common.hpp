@@ -12,7 +12,13 @@
 #include "../../include/padne_hip.h"
 #include "../../include/padne_hip_test.h"
 
+#include <atomic>
+
 namespace padne {
+
+// Kernels and asynchronous fills this library has queued since it was loaded (padne_launch_count, test header): what a
+// solve costs in launches is read off this counter -- the floor of a small system is launches, not bytes.
+extern std::atomic<long long> g_launch_count;
 
 void set_error(const char *fmt, ...);
 
@@ -39,6 +45,16 @@ void set_error(const char *fmt, ...);
         int _rc = (expr);                                                                  \
         if (_rc != PADNE_OK) return _rc;                                                   \
     } while (0)
+
+}  // namespace padne
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, ...)                                                 \
+    do {                                                                                   \
+        ::padne::g_launch_count.fetch_add(1, std::memory_order_relaxed);                   \
+        hipLaunchKernelGGLInternal((kernelName), __VA_ARGS__);                             \
+    } while (0)
+#define hipMemsetAsync(...) (::padne::g_launch_count.fetch_add(1, std::memory_order_relaxed), hipMemsetAsync(__VA_ARGS__))
+namespace padne {
 
 constexpr int kNumXcd = 8;           // MI355X: 8 XCDs, each with a private L2
 

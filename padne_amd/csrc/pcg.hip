@@ -374,7 +374,9 @@ __global__ void halo_pack_kernel(T *__restrict__ v, const int *__restrict__ expo
 }
 
 // scalar slots inside ctx->scalars used when the reductions go through RCCL
-enum { S_RR = 0, S_BB = 1, S_TRUE = 2, S_PQ = 8, S_RZRR0 = 10, S_RZRR1 = 12 };
+enum { S_RR = 0, S_BB = 1, S_TRUE = 2,
+       S_NRM = 3,      // what the single-precision cycle and the stored search direction are normalised with: ||r_0||^2 of a warm start
+       S_PQ = 8, S_RZRR0 = 10, S_RZRR1 = 12 };
 
 // peer-to-peer form of the pack: the exported values go straight into every rank's mailbox entry of this exchange
 // (peers[q] + entry_off, laid out [world][m_cap] 8-byte cells; narrower types use the front of their cell)
@@ -532,6 +534,39 @@ static int halo_exchange(padne_ctx *ctx, double *v, const int32_t *done_flag) {
     return halo_exchange_plan(ctx, plan, v, done_flag);
 }
 
+}  // namespace padne
+// (test header) average device time of one halo exchange of the context's plan -- pack / store to the peers / wait / unpack,
+// or pack / all-gather -- over `repeats` exchanges queued back to back between two events.  Collective: every rank calls it
+// with the same count.
+extern "C" int padne_ctx_halo_exchange_time(padne_ctx *ctx, int32_t repeats, double *seconds_out) {
+    using namespace padne;
+    PADNE_REQUIRE(ctx && seconds_out && repeats > 0, "argument");
+    PADNE_REQUIRE(ctx->halo_on, "no halo plan on this context");
+    PADNE_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)ctx->halo_n_owned + (size_t)ctx->world * (size_t)ctx->halo_m;
+    double *v = (double *)pool_alloc(ctx, sizeof(double) * (n ? n : 1));
+    if (v == nullptr) return PADNE_E_NOMEM;
+    int rc = PADNE_OK;
+    hipError_t e = hipMemsetAsync(v, 0, sizeof(double) * n, ctx->stream);
+    for (int k = 0; k < 3 && rc == PADNE_OK && e == hipSuccess; ++k) rc = halo_exchange(ctx, v, nullptr);
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev0, ctx->stream);
+    for (int k = 0; k < repeats && rc == PADNE_OK && e == hipSuccess; ++k) rc = halo_exchange(ctx, v, nullptr);
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev1, ctx->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(ctx->ev1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    pool_free(ctx, v);
+    if (e != hipSuccess) {
+        set_error("halo exchange timing failed: %s", hipGetErrorString(e));
+        return PADNE_E_HIP;
+    }
+    PADNE_TRY(rc);
+    PADNE_TRY(comm_p2p_check(ctx));
+    *seconds_out = (double)ms * 1e-3 / repeats;
+    return PADNE_OK;
+}
+namespace padne {
+
 // q = A v for a vector whose exchange area has to be refreshed first: the halo goes out, the interior tiles of the product
 // (no remote value in their columns) run while it travels, the boundary tiles follow when it has landed
 static int halo_product_dot(padne_ctx *ctx, const padne_csr *a, double *v, double *q, double *partials, const int32_t *done_flag) {
@@ -562,6 +597,21 @@ const padne_csr *amg_level_matrix(const padne_csr *A0, int level, int which);
 // Reductions go through RCCL when the context has a communicator; the halo plan (if any) is applied
 // before every product.
 static thread_local bool t_last_solve_stagnated = false;   // the last solve_one ended at the evaluation floor of b - A x
+
+// the sampled events of a timed solve: destroyed on every way out of the function that made them
+struct EventList {
+    std::vector<hipEvent_t> ev;
+    ~EventList() { clear(); }
+    void clear() {
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        ev.clear();
+    }
+    bool empty() const { return ev.empty(); }
+    size_t size() const { return ev.size(); }
+    hipEvent_t operator[](size_t i) const { return ev[i]; }
+    void push_back(hipEvent_t e) { ev.push_back(e); }
+    hipEvent_t back() const { return ev.back(); }
+};
 
 static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, const double *b, double *x,
                      const padne_solve_opts *o, padne_solve_info *info, bool x_is_guess) {
@@ -597,7 +647,10 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
     const int check_every = o->check_every > 0 ? o->check_every : (amg ? 4 : 50);
     const int sample_stride = amg ? 4 : 16;
     double *scal = ctx->scalars;
-    const double *bb_scalar = scal + S_BB;
+    // the single-precision vectors of the loop (cycle input, z, the stored search direction) are kept in units of ||b||.  From
+    // an initial guess the first residual may lie dozens of orders below ||b|| (1e-30 ||b||: its floats would be denormals
+    // or zero and p.q = 0 a breakdown where the double loop iterated): the unit is then ||r_0|| of that start.
+    const double *bb_scalar = x_is_guess ? scal + S_NRM : scal + S_BB;
     float e_jac = 0.f;
     const float *e_dinv32 = nullptr;
     float *e_b32 = nullptr, *e_xa32 = nullptr;
@@ -628,7 +681,7 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
 
     int restarts = 0, total_iters = 0, code = PADNE_OK;
     const bool sample_spmv = (o->flags & 2) != 0;
-    std::vector<hipEvent_t> ev_a, ev_b;
+    EventList ev_a, ev_b;
     long long launched = 0;
     double true_rr = 0.0, bb = 0.0, tol2 = 0.0, prev_true_rr = 0.0;
     bool have_ax = false, stagnated = false;
@@ -647,6 +700,8 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
             // ||b||^2 first: the single-precision cycle normalises its input with it
             PADNE_TRY(fold(slot(ctx, SLOT_RR), gv, kMaxPartials, 2, scal + S_RR));   // RR, BB adjacent
             PADNE_TRY(allreduce(scal + S_RR, 2));
+            if (x_is_guess && restarts == 0)
+                PADNE_HIP_CHECK(hipMemcpyAsync(scal + S_NRM, scal + S_RR, sizeof(double), hipMemcpyDeviceToDevice, s));
             PADNE_TRY(amg_apply(ctx, prec, r, z, slot(ctx, SLOT_RZ0), nullptr, bb_scalar));
             if (p32 != nullptr) {
                 hipLaunchKernelGGL(p_hat_from_z_kernel, dim3(gv), dim3(256), 0, s, n, (const double *)z, bb_scalar, p32);
@@ -660,6 +715,8 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
             PADNE_HIP_CHECK(hipGetLastError());
             PADNE_TRY(fold(slot(ctx, SLOT_RR), gv, kMaxPartials, 2, scal + S_RR));   // RR, BB adjacent
             PADNE_TRY(allreduce(scal + S_RR, 2));
+            if (x_is_guess && restarts == 0)
+                PADNE_HIP_CHECK(hipMemcpyAsync(scal + S_NRM, scal + S_RR, sizeof(double), hipMemcpyDeviceToDevice, s));
         }
         if (dist) {
             PADNE_TRY(fold(slot(ctx, SLOT_RZ0), P_rz, kMaxPartials, 1, scal + S_RZRR0));
@@ -773,8 +830,6 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
         for (size_t i = 0; i < ev_a.size(); ++i) {
             float t = 0.f;
             if (hipEventElapsedTime(&t, ev_a[i], ev_b[i]) == hipSuccess) t_s.push_back(t * 1e-3);
-            hipEventDestroy(ev_a[i]);
-            hipEventDestroy(ev_b[i]);
         }
         if (info && !t_s.empty()) {
             std::vector<double> sorted = t_s;
@@ -817,7 +872,9 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
 // (s = A p by recurrence), one iteration costs one all-reduce and one exchange of z.  The stopping test sees r.r only
 // together with the other two sums, i.e. after the cycle and the product of the iteration that converged: one
 // superfluous V-cycle + product per solve buys one collective less in every iteration.  Scalars live in `sr`:
-enum { SR_GAMMA = 0, SR_ALPHA = 1, SR_BETA = 2, SR_RED = 4 /* gamma', delta, rr */ };
+// (gamma and alpha of the previous iteration in two alternating pairs: the kernel that forms the new ones reads the old ones
+// in all its workgroups while its first workgroup writes)
+enum { SR_STATE = 0 /* [2][2]: gamma, alpha */, SR_RED = 4 /* gamma', delta, rr */ };
 
 __global__ __launch_bounds__(256) void sr_fold3_kernel(const double *__restrict__ p0, int n0, const double *__restrict__ p1,
                                                        int n1, const double *__restrict__ p2, int n2,
@@ -829,41 +886,48 @@ __global__ __launch_bounds__(256) void sr_fold3_kernel(const double *__restrict_
     if (threadIdx.x == 0) out[blockIdx.x] = t;
 }
 
-__global__ void sr_scalars_kernel(PcgStatus *__restrict__ st, double *__restrict__ sr, const int first, const int max_iter) {
-    if (st->done) return;
+// One iteration's scalar and vector work in ONE launch (the three reduced sums are in, the next cycle needs r):
+//     beta = gamma' / gamma ; alpha = gamma' / (delta - beta gamma' / alpha)      (first step of a start: alpha = gamma' / delta)
+//     p = z + beta p ; s = w + beta s ; x += alpha p ; r -= alpha s ; partial r.r ;
+//     optionally the entry stage of the single-precision cycle (as pcg_update_xr_entry_kernel)
+// Every workgroup forms the scalars and the stopping decision from the same numbers (the reduced sums, the previous gamma and
+// alpha, the launch's number `j` -- nothing this launch writes), the first one records them.  Until round 5 these were three
+// launches (scalars; p, s; x, r -- the latter two on either side of NO reduction) and p and s crossed memory twice.
+__global__ __launch_bounds__(256) void sr_step_kernel(
+    const long long n, double *__restrict__ sr, const double *__restrict__ z, const double *__restrict__ w,
+    double *__restrict__ p, double *__restrict__ s, double *__restrict__ x, double *__restrict__ r,
+    double *__restrict__ part_rr, PcgStatus *__restrict__ st, const int first, const int j, const int max_iter,
+    const double *__restrict__ bb2, const float c, const float *__restrict__ dinv32, float *__restrict__ b32,
+    float *__restrict__ xa32) {
+    __shared__ double red[4];
+    if (st->done) return;                              // (set by an EARLIER launch: every workgroup reads the same value)
     const double gn = sr[SR_RED + 0], delta = sr[SR_RED + 1], rr = sr[SR_RED + 2];
+    const double *old = sr + SR_STATE + 2 * (j & 1);
     double alpha, beta = 0.0;
     if (first) {
         alpha = gn / delta;
     } else {
-        beta = gn / sr[SR_GAMMA];
-        alpha = gn / (delta - beta * gn / sr[SR_ALPHA]);
+        beta = gn / old[0];
+        alpha = gn / (delta - beta * gn / old[1]);
     }
-    sr[SR_GAMMA] = gn;
-    sr[SR_ALPHA] = alpha;
-    sr[SR_BETA] = beta;
-    if (!first) {
-        const int it = st->iters + 1;
-        st->iters = it;
-        st->rr = rr;
-        if (rr <= st->tol2 || it >= max_iter) st->done = 1;
+    bool stop = !first && (rr <= st->tol2 || j >= max_iter);
+    int code = PADNE_OK;
+    if (!stop && (!(alpha > 0.0) || !(alpha == alpha) || !(gn > 0.0) || !(rr == rr))) {
+        code = PADNE_E_BREAKDOWN;      // p.A p = gamma' / alpha <= 0, or the cycle lost definiteness, or NaN
+        stop = true;
     }
-    if (!st->done && (!(alpha > 0.0) || !(alpha == alpha) || !(gn > 0.0) || !(rr == rr))) {
-        st->code = PADNE_E_BREAKDOWN;      // p.A p = gamma' / alpha <= 0, or the cycle lost definiteness, or NaN
-        st->done = 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double *nw = sr + SR_STATE + 2 * ((j & 1) ^ 1);
+        nw[0] = gn;
+        nw[1] = alpha;
+        if (!first) {
+            st->iters = j;
+            st->rr = rr;
+        }
+        if (code != PADNE_OK) st->code = code;
+        if (stop) st->done = 1;
     }
-}
-
-// x += alpha p ; r -= alpha s ; partial r.r ; optionally the entry stage of the single-precision cycle (as
-// pcg_update_xr_entry_kernel)
-__global__ __launch_bounds__(256) void sr_update_xr_kernel(
-    const long long n, const double *__restrict__ sr, const double *__restrict__ p, const double *__restrict__ s,
-    double *__restrict__ x, double *__restrict__ r, double *__restrict__ part_rr, const PcgStatus *__restrict__ st,
-    const double *__restrict__ bb2, const float c, const float *__restrict__ dinv32, float *__restrict__ b32,
-    float *__restrict__ xa32) {
-    __shared__ double red[4];
-    if (st->done) return;
-    const double alpha = sr[SR_ALPHA];
+    if (stop) return;
     double s_inv = 1.0;
     if (b32 != nullptr) {
         const double s2 = *bb2;
@@ -871,8 +935,13 @@ __global__ __launch_bounds__(256) void sr_update_xr_kernel(
     }
     double s_rr = 0.0;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const double ri = r[i] - alpha * s[i];
-        x[i] += alpha * p[i];
+        // (first step: p and s hold whatever the workspace held -- never read)
+        const double pi = first ? z[i] : z[i] + beta * p[i];
+        const double si = first ? w[i] : w[i] + beta * s[i];
+        p[i] = pi;
+        s[i] = si;
+        const double ri = r[i] - alpha * si;
+        x[i] += alpha * pi;
         r[i] = ri;
         s_rr += ri * ri;
         if (b32 != nullptr) {
@@ -884,25 +953,6 @@ __global__ __launch_bounds__(256) void sr_update_xr_kernel(
     block_store_partial(s_rr, red, part_rr + blockIdx.x);
 }
 
-// p = z + beta p ; s = w + beta s
-__global__ __launch_bounds__(256) void sr_update_ps_kernel(const long long n, const double *__restrict__ sr,
-                                                           const double *__restrict__ z, const double *__restrict__ w,
-                                                           double *__restrict__ p, double *__restrict__ s,
-                                                           const PcgStatus *__restrict__ st, const int first) {
-    if (st->done) return;
-    if (first) {                            // p = z ; s = w  (p and s hold whatever the workspace held: never read them)
-        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-            p[i] = z[i];
-            s[i] = w[i];
-        }
-        return;
-    }
-    const double beta = sr[SR_BETA];
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        p[i] = z[i] + beta * p[i];
-        s[i] = w[i] + beta * s[i];
-    }
-}
 
 static int solve_one_single_reduction(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, const double *b,
                                       double *x, const padne_solve_opts *o, padne_solve_info *info, bool x_is_guess) {
@@ -938,7 +988,10 @@ static int solve_one_single_reduction(padne_ctx *ctx, const padne_csr *a, const 
     const int check_every = o->check_every > 0 ? o->check_every : 4;
     double *scal = ctx->scalars;
     double *sr = scal + 16;                      // SR_* slots (ctx->scalars holds 64 doubles)
-    const double *bb_scalar = scal + S_BB;
+    // the single-precision vectors of the loop (cycle input, z, the stored search direction) are kept in units of ||b||.  From
+    // an initial guess the first residual may lie dozens of orders below ||b|| (1e-30 ||b||: its floats would be denormals
+    // or zero and p.q = 0 a breakdown where the double loop iterated): the unit is then ||r_0|| of that start.
+    const double *bb_scalar = x_is_guess ? scal + S_NRM : scal + S_BB;
     float e_jac = 0.f;
     const float *e_dinv32 = nullptr;
     float *e_b32 = nullptr, *e_xa32 = nullptr;
@@ -962,7 +1015,7 @@ static int solve_one_single_reduction(padne_ctx *ctx, const padne_csr *a, const 
     auto allreduce = [&](double *buf, int count) -> int { return dist ? comm_allreduce_sum_f64(ctx, buf, count) : PADNE_OK; };
     // z = M r, exchange, w = A z and the three sums of the iteration in one reduction
     const bool sample_spmv = (o->flags & 2) != 0;
-    std::vector<hipEvent_t> ev_a, ev_b;
+    EventList ev_a, ev_b;
     long long launched = 0;
     auto cycle_product_reduce = [&](bool entry_done, const int32_t *done_flag) -> int {
         PADNE_TRY(amg_apply(ctx, prec, r, z, slot(ctx, SLOT_RZ0), done_flag, bb_scalar, entry_done));
@@ -999,22 +1052,25 @@ static int solve_one_single_reduction(padne_ctx *ctx, const padne_csr *a, const 
         PADNE_HIP_CHECK(hipGetLastError());
         PADNE_TRY(fold(slot(ctx, SLOT_RR), gv, kMaxPartials, 2, scal + S_RR));   // RR, BB adjacent: ||b|| normalises the cycle
         PADNE_TRY(allreduce(scal + S_RR, 2));
+        if (x_is_guess && restarts == 0)
+            PADNE_HIP_CHECK(hipMemcpyAsync(scal + S_NRM, scal + S_RR, sizeof(double), hipMemcpyDeviceToDevice, s));
         hipLaunchKernelGGL(pcg_set_tolerance_kernel, dim3(1), dim3(1), 0, s, st, scal + S_RR, o->rtol, o->atol,
                            restarts > 0 ? 1 : 0);
         PADNE_HIP_CHECK(hipGetLastError());
         PADNE_TRY(cycle_product_reduce(false, &st->done));
-        hipLaunchKernelGGL(sr_scalars_kernel, dim3(1), dim3(1), 0, s, st, sr, 1, max_iter - total_iters);
-        hipLaunchKernelGGL(sr_update_ps_kernel, dim3(gv), dim3(256), 0, s, n, sr, z, w, p, sv, st, 1);
+        int step_no = 0;                       // steps queued since this (re)start: the j-th one completes iteration j
+        hipLaunchKernelGGL(sr_step_kernel, dim3(gv), dim3(256), 0, s, n, sr, (const double *)z, (const double *)w, p, sv, x, r,
+                           slot(ctx, SLOT_RR), st, 1, step_no, max_iter - total_iters, bb_scalar, e_jac, e_dinv32,
+                           fuse_entry ? e_b32 : (float *)nullptr, e_xa32);
         PADNE_HIP_CHECK(hipGetLastError());
         bool done = false;
         while (!done) {
             for (int k = 0; k < check_every; ++k) {
-                hipLaunchKernelGGL(sr_update_xr_kernel, dim3(gv), dim3(256), 0, s, n, sr, p, sv, x, r, slot(ctx, SLOT_RR), st,
-                                   bb_scalar, e_jac, e_dinv32, fuse_entry ? e_b32 : (float *)nullptr, e_xa32);
-                PADNE_HIP_CHECK(hipGetLastError());
                 PADNE_TRY(cycle_product_reduce(fuse_entry, &st->done));
-                hipLaunchKernelGGL(sr_scalars_kernel, dim3(1), dim3(1), 0, s, st, sr, 0, max_iter - total_iters);
-                hipLaunchKernelGGL(sr_update_ps_kernel, dim3(gv), dim3(256), 0, s, n, sr, z, w, p, sv, st, 0);
+                ++step_no;
+                hipLaunchKernelGGL(sr_step_kernel, dim3(gv), dim3(256), 0, s, n, sr, (const double *)z, (const double *)w, p, sv, x,
+                                   r, slot(ctx, SLOT_RR), st, 0, step_no, max_iter - total_iters, bb_scalar, e_jac, e_dinv32,
+                                   fuse_entry ? e_b32 : (float *)nullptr, e_xa32);
             }
             PADNE_HIP_CHECK(hipGetLastError());
             // (through the mailbox: the host polls instead of sleeping in hipStreamSynchronize, whose wake-up is at the mercy of
@@ -1055,8 +1111,6 @@ static int solve_one_single_reduction(padne_ctx *ctx, const padne_csr *a, const 
         for (size_t i = 0; i < ev_a.size(); ++i) {
             float t = 0.f;
             if (hipEventElapsedTime(&t, ev_a[i], ev_b[i]) == hipSuccess) t_s.push_back(t * 1e-3);
-            hipEventDestroy(ev_a[i]);
-            hipEventDestroy(ev_b[i]);
         }
         if (info && !t_s.empty()) {
             std::vector<double> sorted = t_s;

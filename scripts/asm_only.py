@@ -15,3 +15,13 @@ for k in range(4):
     L = ctx.assemble_system(N, xy, tri, sysm.mesh_offsets, sysm._tri_offsets, sig, rows, cols, vals); ctx.synchronize()
     print(f"assemble {name}: {(time.perf_counter() - t) * 1e3:.2f} ms", flush=True)
     L.close()
+# ... and the reduction of the assembled system to its potential block (index map resident on the device)
+L = ctx.assemble_system(N, xy, tri, sysm.mesh_offsets, sysm._tri_offsets, sig, rows, cols, vals)
+nv = sysm.n_vertices
+imap = np.arange(N, dtype=np.int32); imap[sysm.ground] = -1; imap[imap > sysm.ground] -= 1; imap[N - 1] = -1
+dm = ctx.to_device(imap)
+for k in range(3):
+    ctx.synchronize(); t = time.perf_counter()
+    A = L.reduce(dm, nv - 1, -1.0); ctx.synchronize()
+    print(f"reduce {name}: {(time.perf_counter() - t) * 1e3:.2f} ms", flush=True)
+    A.close()

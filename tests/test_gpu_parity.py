@@ -421,6 +421,7 @@ def test_multigrid_hierarchy_is_galerkin_and_partition_of_unity(ctx):
         Al, P, R = d.amg_level(lvl, "A"), d.amg_level(lvl, "P"), d.amg_level(lvl, "R")
         Ac = d.amg_level(lvl + 1, "A")
         assert abs(R - P.T).max() == 0.0                               # R is exactly P^T
+        assert R.has_sorted_indices                                   # ... with its rows in column order (placed in order, not sorted)
         ref = (P.T @ Al @ P).tocsr()
         assert abs(Ac - ref).max() <= 1e-12 * abs(ref).max()           # Galerkin product
         assert abs(Ac - Ac.T).max() <= 1e-12 * abs(Ac).max()
@@ -723,6 +724,38 @@ def test_search_direction_stored_in_single_precision_solves_the_same_system(monk
         assert not np.array_equal(f32[0].x, f64[0].x), "the switch changed nothing"
 
 
+def test_warm_start_whose_residual_lies_thirty_orders_below_the_right_hand_side(monkeypatch):
+    """The single-precision vectors of the loop (cycle input, z, the stored search direction) are kept in units of ||b||;
+    from an initial guess whose residual is 1e-30 ||b|| they would be denormals or zero (p.q = 0: a breakdown where the
+    double loop iterated).  The unit of a warm start is therefore ||r_0||.  Two islands: the guess solves the first one
+    exactly (its right-hand side is the device's own product A x_0, so r_0 vanishes there bit for bit), the second one has
+    x_0 = 0 and a right-hand side of 1e-30: the solve has to reduce that residual by twelve orders like a cold solve of the
+    second island alone."""
+    A1, b1, _, _, _ = layered_spd(1, 90, 70, 5)
+    n1 = A1.shape[0]
+    A = sp.block_diag([A1, A1]).tocsr()
+    A.sort_indices()
+    x1 = np.random.default_rng(3).uniform(-1, 1, n1)
+    x0 = np.concatenate([x1, np.zeros(n1)])
+    delta = 1e-30 * b1 / np.abs(b1).max()
+    for p64 in (False, True):
+        if p64:
+            monkeypatch.setenv("PADNE_PCG_P64", "1")
+        c = _hip.Context(0)
+        try:
+            d = c.csr_from_scipy(A)
+            b = d.matvec(x0)
+            assert not b[n1:].any() and np.abs(b[:n1]).max() > 1.0
+            b[n1:] = delta
+            ref = c.csr_from_scipy(A1).solve_spd(delta, rtol=1e-12, precond="amg")
+            res = d.solve_spd(b, rtol=0.0, atol=1e-12 * np.linalg.norm(delta), x0=x0, precond="amg")
+            assert res.status == _hip.OK and abs(res.iterations - ref.iterations) <= 3 and res.iterations > 10
+            assert np.array_equal(res.x[:n1], x1)                    # nothing moves where the residual is zero
+            assert np.abs(res.x[n1:] - ref.x).max() <= 1e-8 * np.abs(ref.x).max()
+        finally:
+            c.close()
+
+
 def test_fine_level_of_the_cycle_formed_from_its_right_hand_side_alone(monkeypatch):
     """The fine level of the float cycle never stores its pre-smoothed iterate x = c D^-1 b: the residual product stages
     c * dinv .* b instead of x (`SPMV_RESID_PRE`), the up-leg takes c D^-1 (b + residual) + W e and r.z against b.  Against
@@ -781,14 +814,15 @@ def test_sparse_products_of_the_setup_split_their_rows_when_the_slots_exceed_the
     assert np.abs(res.x - base.x).max() <= 1e-9 * np.abs(base.x).max()
 
 
-def test_transposes_of_the_setup_through_the_hash_table_of_wide_column_ranges(ctx, monkeypatch):
-    """The transposition of a prolongator counts and places its entries through LDS, indexed by column while the columns
-    of a workgroup's entries lie within a few thousand of each other, through a hash table of the columns met when they
-    do not (a mesh line longer than that: 160 M unknowns).  PADNE_TRANSPOSE_HASH sends every workgroup through the hash
-    table: the restriction operators -- and with them the hierarchy and the solve -- must be the same bit for bit."""
+def test_transposes_of_the_setup_through_cursors_and_the_sort(ctx, monkeypatch):
+    """The transposition of a prolongator places every entry in the order of its row (per column the list of the 64-row
+    waves that hold it, inside a wave a mask of the rows in a hash table of the columns met): the rows of the restriction
+    come out in column order.  Columns met by more waves than a list holds, and the rows of a wave with more entries than
+    its table takes, go through a cursor per column and are sorted afterwards.  PADNE_TRANSPOSE_CURSORS sends every wave
+    that way: the restriction operators -- and with them the hierarchy and the solve -- must be the same bit for bit."""
     A, b, _, _, _ = layered_spd(3, 150, 110, 5)
     base = ctx.csr_from_scipy(A).solve_spd(b, precond="amg")
-    monkeypatch.setenv("PADNE_TRANSPOSE_HASH", "1")
+    monkeypatch.setenv("PADNE_TRANSPOSE_CURSORS", "1")
     res = ctx.csr_from_scipy(A).solve_spd(b, precond="amg")
     assert res.levels == base.levels and res.levels >= 3 and res.precond_fallbacks == 0
     assert res.operator_complexity == base.operator_complexity and res.iterations == base.iterations
@@ -2556,6 +2590,53 @@ def test_relabel_with_injective_maps_is_the_slot_path_bit_for_bit(ctx, monkeypat
             assert direct.shape == slots.shape and np.array_equal(direct.indptr, slots.indptr), name
             assert np.array_equal(direct.indices, slots.indices) and np.array_equal(direct.data, slots.data), name
             assert direct.has_sorted_indices and direct.nnz > 0 and np.all(direct.data != 0.0)
+
+
+def test_maps_that_only_drop_indices_are_relabelled_by_a_copy_with_holes(ctx, monkeypatch):
+    """The reduction to the potential block drops indices and keeps the order of the rest (solver.py:544-560: no ground
+    vertex, no multiplier row): count, scan, copy -- no histogram, no sort.  Against scipy and against the slot path, bit for
+    bit: one hole, holes at both ends, scattered holes, a run of holes longer than the look-ahead of the map test (which the
+    general path takes), rows of 0 to 40 entries, explicit zeros; the map as a host array and resident on the device."""
+    rng = np.random.default_rng(5)
+    n = 7000
+    M = H.random_csr(n, n, 7, 31).tolil()
+    M[33, 100:140] = rng.uniform(-1, 1, 40)
+    M = M.tocsr()
+    M.sort_indices()
+
+    def cmap_of(drop):
+        m = np.arange(n, dtype=np.int32)
+        m[list(drop)] = -1
+        keep = m >= 0
+        m[keep] = np.arange(int(keep.sum()), dtype=np.int32)
+        return m, keep
+    drops = {"ground": [0], "last": [n - 1], "both ends": [0, n - 1], "scattered": sorted(rng.choice(n, 200, replace=False)),
+             "long run": list(range(500, 600)), "none": []}
+    Mz = M.copy()
+    Mz.data[::41] = 0.0
+    for src in (M, Mz):
+        d = ctx.csr_from_scipy(src)
+        for name, drop in drops.items():
+            m, keep = cmap_of(drop)
+            n_out = int(keep.sum())
+            ref = (-1.0 * src[keep][:, keep]).tocsr()
+            ref.eliminate_zeros()
+            ref.sort_indices()
+            host = d.reduce(m, n_out, -1.0).to_scipy()
+            dm = ctx.to_device(m)
+            dev = d.reduce(dm, n_out, -1.0).to_scipy()
+            dm.free()
+            monkeypatch.setenv("PADNE_RELABEL_SLOTS", "1")
+            slots = d.reduce(m, n_out, -1.0).to_scipy()
+            monkeypatch.delenv("PADNE_RELABEL_SLOTS")
+            for got in (host, dev, slots):
+                assert got.shape == ref.shape and got.has_sorted_indices, name
+                assert np.array_equal(got.indptr, ref.indptr) and np.array_equal(got.indices, ref.indices), name
+                assert np.array_equal(got.data, ref.data), name
+    bad, _ = cmap_of([3])
+    bad[9] = n                        # out of range
+    with pytest.raises(ValueError):
+        ctx.csr_from_scipy(M).reduce(bad, n - 1, 1.0)
 
 
 def test_relabel_and_vstack_against_scipy(ctx):

@@ -77,6 +77,12 @@ def main():
     out["calls_per_solve_allgather"] = [int(b - a) for a, b in zip(c0, c1)]
     out["iterations_allgather"] = int(res3.iterations)
     sol_ag = ds.solution().copy()
+    # what one exchange costs on the device: peer-to-peer stores + flags, and the all-gather (through gloo and the host here)
+    out["p2p_exchange_us"] = ctx.halo_exchange_time(300) * 1e6
+    out["exchange_slots_per_rank"] = int(plan.m)
+    os.environ["PADNE_NO_P2P"] = "1"
+    out["allgather_exchange_us_gloo"] = ctx.halo_exchange_time(30) * 1e6
+    del os.environ["PADNE_NO_P2P"]
     out["max_abs_difference"] = float(np.abs(sol - sol_ag).max())
     out["bit_identical"] = bool(np.array_equal(sol, sol_ag))
     # potentials of all ranks against the reference's direct solve on the oracle-assembled system (rank 0)
