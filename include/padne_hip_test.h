@@ -30,8 +30,11 @@ int padne_csr_split_tiles(const padne_csr *m, int level, int64_t *interior, int6
  * batched multigrid-PCG so far -- what tells a test that the K + 1 right-hand sides of K regulators took that path. */
 int padne_ctx_lockstep_groups(const padne_ctx *ctx, int64_t *groups);
 /* Assemblies of this process whose rows were built by the two-pass second path of the row kernel (count, scan, fill):
- * forced with PADNE_ASM_TWO_PASS=1, or taken after the single-pass kernel's in-kernel scan gave up on a shared chip. */
+ * forced with PADNE_FORCE=asm_two_pass, or taken after the single-pass kernel's in-kernel scan gave up on a shared chip. */
 int padne_asm_second_path_count(int64_t *count);
+/* Reads the PADNE_* environment switches again for a context that lives across a change of them (the library reads them
+ * once, when a context is created): the tests flip a switch, reload, and compare the two paths on one context. */
+int padne_ctx_reload_options(padne_ctx *ctx);
 /* Average device time of one halo exchange of the context's plan (padne_ctx_set_halo) over `repeats` exchanges queued back to
  * back -- peer-to-peer stores into the shared mailboxes with their device-side flags, or the all-gather.  Collective: every
  * rank calls it with the same count (tests/two_process_rank.py, bench.py rank_proxy.p2p_exchange). */

@@ -6,6 +6,7 @@ GPU is visible, the first call raises ``HipUnavailableError``.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 import os
 import sys
 from dataclasses import dataclass
@@ -126,6 +127,7 @@ TEST_SIGNATURES = {
     "padne_ctx_lockstep_groups": (C.c_int, [_P, _PI64]),
     "padne_asm_second_path_count": (C.c_int, [_PI64]),
     "padne_ctx_halo_exchange_time": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double)]),
+    "padne_ctx_reload_options": (C.c_int, [_P]),
 }
 
 _lib = None
@@ -215,6 +217,17 @@ def asm_second_path_count() -> int:
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, _P, _P, _P, C.c_int64)      # padne_allgather_fn
 
 
+_live_contexts = weakref.WeakSet()
+
+
+def reload_options_everywhere() -> None:
+    """Every live context reads the PADNE_* environment switches again (test scaffolding: the library reads them once,
+    when a context is created)."""
+    for c in list(_live_contexts):
+        if getattr(c, "_h", None):
+            c.reload_options()
+
+
 class Context:
     """Device context: GPU, stream, workspaces, optional RCCL communicator."""
 
@@ -229,6 +242,7 @@ class Context:
         self._h = h
         self.device = int(device)
         self.halo_n_owned = None      # length of b / x when a halo plan is active
+        _live_contexts.add(self)
 
     # -- lifetime ------------------------------------------------------------
     def close(self):
@@ -309,6 +323,10 @@ class Context:
         nbytes = (C.c_longlong * 4)()
         _check(self._lib.padne_comm_call_counts(calls, nbytes))
         return list(calls), list(nbytes)
+
+    def reload_options(self) -> None:
+        """Read the PADNE_* environment switches again (they are read once, at creation; test scaffolding)."""
+        _check(self._lib.padne_ctx_reload_options(self._h))
 
     def halo_exchange_time(self, repeats: int = 200) -> float:
         """Average device seconds of one halo exchange of this context's plan (collective; test introspection)."""

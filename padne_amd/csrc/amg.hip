@@ -83,28 +83,13 @@ struct Amg {
     int device = 0;
 };
 
-#define kTheta theta_val()
-static int coarse_n_limit() {   // coarsest-level size below which the dense inverse takes over
-    const char *e = getenv("PADNE_AMG_COARSE_N");
-    int v = e ? atoi(e) : 2048;
-    if (v < 16) v = 16;
-    if (v > 4096) v = 4096;
-    return v;
-}
-#define kCoarseN coarse_n_limit()
+// strength threshold, prolongator smoothing, smoother interval, Lanczos steps: the values the parameter studies of rounds
+// 1-4 settled on (DESIGN_HISTORY.md); the size the dense inverse takes comes from the context's options (tests vary it)
+constexpr double kTheta = 0.08;
+constexpr double kOmegaNum = 1.5;
+constexpr double kChebRatio = 10.0;
+constexpr int kLanczosSteps = 8;
 constexpr int kMaxLevels = 16;
-static double cheb_ratio() { const char *e = getenv("PADNE_AMG_CHEB_RATIO"); return e ? atof(e) : 10.0; }
-#define kChebRatio cheb_ratio()
-static int lanczos_steps() { const char *e = getenv("PADNE_AMG_LANCZOS_STEPS"); const int v = e ? atoi(e) : 8; return v < 2 ? 2 : (v > 60 ? 60 : v); }
-static double omega_num() { const char *e = getenv("PADNE_AMG_OMEGA"); return e ? atof(e) : 1.5; }
-static thread_local int t_setup_level = 0;     // level whose operators are being built (strength threshold decays with it)
-static double theta_val() {
-    const char *e = getenv("PADNE_AMG_THETA"), *d = getenv("PADNE_AMG_THETA_DECAY");
-    double th = e ? atof(e) : 0.08;
-    const double decay = d ? atof(d) : 1.0;
-    for (int l = 0; l < t_setup_level; ++l) th *= decay;
-    return th;
-}
 
 // unaligned multi-dword loads: global loads of 8 and 16 bytes only need their address to be a multiple of 4.  What bounds a
 // kernel of gathers is the number of its memory instructions (the address unit takes about a cycle per lane and instruction
@@ -130,11 +115,10 @@ __device__ __forceinline__ double2 load_d2_unaligned(const double *p) {
 // the neighbours -- is fetched by up to 8 L2s and has left each of them long before the neighbouring scan line comes by
 // (rocprofv3 FETCH_SIZE: 19x the algorithmic bytes over the setup of round 2).  As in the SpMV kernel (spmv.hip) every XCD
 // gets one contiguous eighth of the rows and sweeps it front to back: xcd_bid maps the hardware workgroup index to the
-// logical one (a bijection; the last gridDim % 8 workgroups keep their place).  PADNE_NO_XCD_MAP=1 switches it off (A/B).
-__device__ int g_xcd_map = 1;
+// logical one (a bijection; the last gridDim % 8 workgroups keep their place).
 __device__ __forceinline__ unsigned xcd_bid() {
     const unsigned b = blockIdx.x, per = gridDim.x >> 3;
-    if (!g_xcd_map || b >= (per << 3)) return b;
+    if (b >= (per << 3)) return b;
     return (b & 7u) * per + (b >> 3);
 }
 // the same for kernels whose waves stride over 64-row tiles: [first, last) tile range of this workgroup's XCD, the wave's
@@ -142,7 +126,7 @@ __device__ __forceinline__ unsigned xcd_bid() {
 struct XcdSweep { long long t0, t1, stride; };
 __device__ __forceinline__ XcdSweep xcd_sweep(const long long n_tiles, const int waves_per_block, const int w) {
     const unsigned G = gridDim.x;
-    const unsigned nslab = (g_xcd_map && G % kNumXcd == 0) ? kNumXcd : 1;
+    const unsigned nslab = (G % kNumXcd == 0) ? kNumXcd : 1;
     const unsigned slab = blockIdx.x % nslab;
     XcdSweep sw;
     const long long s0 = (long long)slab * n_tiles / nslab;
@@ -488,9 +472,75 @@ __global__ __launch_bounds__(256) void nbr_max_xw(int n, int n_wtiles, const int
 // One round of the distance-2 independent set on the competition words (Bell, Dalton, Olson: MIS-k).  m2 is the
 // maximum of the words within two strong hops.  An undecided vertex that sees a root is covered; one that sees
 // nothing above its own priority becomes a root (the vertices around it are covered in the next round).
-__global__ void mis_init_words(int n, unsigned int *__restrict__ word) {
+// start of a level's aggregation in one launch: the competition words, the states, the (pre-zeroed) counters of the rounds
+// and the padding behind the window positions -- three memsets and a kernel before
+__global__ void mis_init_words(int n, unsigned int *__restrict__ word, signed char *__restrict__ state,
+                               int *__restrict__ counters, int n_counters, unsigned char *__restrict__ pad, int n_pad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) word[i] = prio32_of(i);
+    if (i < n) {
+        word[i] = prio32_of(i);
+        state[i] = 0;
+    }
+    if (i < n_counters) counters[i] = 0;
+    if (pad != nullptr && i < n_pad) pad[i] = 0;
+}
+
+// The LAST rounds of a level in one launch: once a few thousand vertices are open, a round is two launches of a handful
+// of workgroups and every third round a look at the host -- half a dozen rounds per level, four levels per setup.  One
+// workgroup takes the list through all remaining rounds: two-hop maxima of the open vertices (eight lanes per vertex as in
+// mis_two_hop_max), barrier, decisions (mis_decide_one) and the next list, barrier.  Same words, same decisions.
+constexpr int kMisTailCap = 512;
+__global__ __launch_bounds__(1024) void mis_tail_rounds(const int *__restrict__ cnt_ptr, int *list_a, int *list_b,
+                                                        const int *__restrict__ srow, const int *__restrict__ scol,
+                                                        unsigned int *word, signed char *state, unsigned int *m2,
+                                                        int *__restrict__ count_out, const int max_rounds) {
+    __shared__ int s_next;
+    int cnt = *cnt_ptr;
+    if (threadIdx.x == 0) s_next = 0;
+    __syncthreads();
+    const int q = threadIdx.x & 7, slot = threadIdx.x >> 3;      // 128 vertices per pass, eight lanes each
+    for (int round = 0; round < max_rounds && cnt > 0; ++round) {
+        for (int t0 = 0; t0 < cnt; t0 += 128) {
+            const int t = t0 + slot;
+            const bool live = t < cnt;
+            unsigned int m = 0u;
+            if (live) {
+                const int i = list_a[t];
+                m = word[i];
+                const int a1 = srow[i + 1];
+                for (int a = srow[i] + q; a < a1; a += 8) {
+                    const int j = scol[a];
+                    if (j == i) continue;
+                    const unsigned int wj = word[j];
+                    m = wj > m ? wj : m;
+                    for (int b = srow[j]; b < srow[j + 1]; ++b) {
+                        const unsigned int wk = word[scol[b]];
+                        m = wk > m ? wk : m;
+                    }
+                }
+            }
+#pragma unroll
+            for (int d = 1; d < 8; d <<= 1) {
+                const unsigned int o = (unsigned int)__shfl_xor((int)m, d, 64);
+                m = o > m ? o : m;
+            }
+            if (live && q == 0) m2[t] = m;
+        }
+        __syncthreads();                                  // every maximum is taken from the words of the round's start
+        for (int t = threadIdx.x; t < cnt; t += 1024) {
+            const int i = list_a[t];
+            if (mis_decide_one(i, m2[t], word, state)) list_b[atomicAdd(&s_next, 1)] = i;
+        }
+        __syncthreads();
+        cnt = s_next;
+        __syncthreads();
+        if (threadIdx.x == 0) s_next = 0;
+        int *tmp = list_a;
+        list_a = list_b;
+        list_b = tmp;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count_out = cnt;
 }
 
 // full round: every vertex looks at its two-hop maximum m2; *undecided = number of vertices still open
@@ -843,7 +893,7 @@ __global__ __launch_bounds__(256) void transpose_count_pairs(int n_rows, const i
                                                              const int *__restrict__ cols, int *__restrict__ cnt,
                                                              int *__restrict__ npairs, int *__restrict__ pairs,
                                                              const int all_cursors) {
-    // all_cursors (PADNE_TRANSPOSE_CURSORS, tests): every wave takes the path of the waves whose rows exceed the table
+    // all_cursors (PADNE_FORCE=transpose_cursors, tests): every wave takes the path of the waves whose rows exceed the table
     __shared__ int Key[4][kTpSlots];
     __shared__ unsigned long long Mask[4][kTpSlots];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1171,69 +1221,10 @@ __global__ void spgemm_rows(int n_rows, const int *__restrict__ xr, const int *_
     row_len[i] = m;
 }
 
-// Short-row variant: the sorted distinct list of every row lives in LDS ([slot][thread] layout, bank-conflict
-// free), rows that would exceed CAP distinct columns are flagged and redone by spgemm_rows.  Same products
-// in the same order as spgemm_rows, so the two paths give bit-identical results.
-template <int CAP>
-__global__ __launch_bounds__(128) void spgemm_rows_lds(int n_rows, const int *__restrict__ xr, const int *__restrict__ xc,
-                                                       const double *__restrict__ xv, const int *__restrict__ yr,
-                                                       const int *__restrict__ yc, const double *__restrict__ yv, const int *__restrict__ ye, const int ycs,
-                                                       const int *__restrict__ slot_ptr, long long *__restrict__ key,
-                                                       double *__restrict__ val, int *__restrict__ row_len) {
-    __shared__ int Kc[CAP][128];
-    __shared__ double Vc[CAP][128];
-    const int t = threadIdx.x;
-    const int i = xcd_bid() * 128 + t;
-    if (i >= n_rows) return;
-    int m = 0;
-    bool overflow = false;
-    for (int k = xr[i]; k < xr[i + 1] && !overflow; ++k) {
-        const int mid = xc[k];
-        const double a = xv[k];
-        for (int q = yr[mid]; q < ye[mid]; ++q) {
-            const int c = yc[(long long)q * ycs];
-            const double v = a * yv[q];
-            int lo = 0;
-            while (lo < m && Kc[lo][t] < c) ++lo;          // lists are a handful of entries long
-            if (lo < m && Kc[lo][t] == c) {
-                Vc[lo][t] += v;
-            } else {
-                if (m == CAP) {
-                    overflow = true;
-                    break;
-                }
-                for (int u = m; u > lo; --u) {
-                    Kc[u][t] = Kc[u - 1][t];
-                    Vc[u][t] = Vc[u - 1][t];
-                }
-                Kc[lo][t] = c;
-                Vc[lo][t] = v;
-                ++m;
-            }
-        }
-    }
-    if (overflow) {
-        row_len[i] = -1;                                   // redo in global memory
-        return;
-    }
-    long long *K = key + slot_ptr[i];
-    double *V = val + slot_ptr[i];
-    for (int u = 0; u < m; ++u) {
-        K[u] = (long long)Kc[u][t] << 32;
-        V[u] = Vc[u][t];
-    }
-    row_len[i] = m;
-}
-
-// The same kernel with its loads taken out of the dependent chain.  spgemm_rows_lds walks  xc[k] -> yr[mid] -> yc / yv[q]  one
-// entry at a time and waits for every load before it issues the next: ~5 dependent global round trips per entry of the X
-// row, ~40 per row of a mesh operator, at three waves per SIMD (the lists take the LDS) -- the kernel is bound by exactly
-// that latency (rocprofv3: L1 pending-request stall 57 %, texture addresser 5 %).  Here a thread takes KC entries of its X row
-// at once: all their columns and values, then all the row bounds of Y they select, then the products of entry u + 1 are
-// requested while those of entry u go into the list -- three to four round trips per KC entries.  Register arrays are
-// indexed by unrolled constants only.  Same products in the same order: bit-identical lists.  (Round 2 had tried ALL loads
-// of a row up front: 212 VGPRs, two waves per SIMD, no gain; this form needs 90.)
-
+// Short rows (A P on the fine levels: a dozen products per row): one thread per row, the sorted distinct list of the row in
+// LDS ([slot][thread] layout, bank-conflict free), a thread takes KC entries of its row of X at once -- columns and values,
+// then the row bounds of Y they select -- and requests the products of entry u + 1 while those of entry u go into the list.
+// Rows that would exceed CAP distinct columns are flagged (row_len = -1) and redone by the wave kernels / spgemm_rows_redo.
 // `begin` (may be null): the rows of a wave's 64-row tile are written BACK TO BACK from the start of the tile's slot range
 // instead of each into its own range of product-count size -- the merged rows are a third of their products (5.2 of 17 on
 // the fine level of C4), and what reads them afterwards (R (A P) by rows, the W build) touched every line of a 2.6 GB arena
@@ -1566,7 +1557,7 @@ __global__ __launch_bounds__(256) void spgemm_rows_sub(int n_rows, const int *__
     constexpr int EMPTY = -1;
     // every XCD sweeps its own contiguous eighth of the rows (see xcd_bid): the rows of Y that neighbouring rows of X
     // gather (the slots of A P around an aggregate) are then still in that XCD's L2 when the next row asks for them
-    const int nslab = (g_xcd_map && gridDim.x % kNumXcd == 0) ? kNumXcd : 1;
+    const int nslab = (gridDim.x % kNumXcd == 0) ? kNumXcd : 1;
     const int slab = blockIdx.x % nslab;
     const int row_end = (int)((long long)(slab + 1) * n_rows / nslab);
     const int row_first = (int)((long long)slab * n_rows / nslab) + (int)(blockIdx.x / nslab) * G + g;
@@ -1939,276 +1930,6 @@ __global__ __launch_bounds__(256) void gj_block_step(int n, int k0, const double
     }
 }
 
-// TWO steps of gj_block_step in one launch (pivot blocks K1 = [k0, k0 + 16) and K2 = [k0 + 16, k0 + 16 + bs2)).  A launch of
-// the one-step kernel moves the whole matrix through the memory system once -- 57 MB at n = 1617, 13 us of its 19.8 at what
-// the Infinity Cache delivers (the L2s keep nothing across a kernel boundary) -- so 101 launches cost 2.0 ms whatever the
-// pivot block's inversion takes (by shuffles instead of LDS round trips: 1.98 -> 1.93 ms).  Here a workgroup applies step
-// 1 to its tile in registers and step 2 right behind it: what step 2 reads of OTHER tiles as they are after step 1 -- the
-// pivot rows K2 in its columns, the pivot columns K2 in its rows, the pivot block D22 -- it computes itself from the old
-// matrix (a rank-16 update of 16 values per thread, of a 32 x 16 and of a 16 x 16 block per workgroup).  Every entry goes
-// through the operations of two consecutive one-step launches in their order: the same bits (tested), half the launches
-// and 0.6 of the traffic.
-// The pivot work of a fused step, by ONE wave, from 16 x 16 blocks in LDS (complete before the call: the caller's barrier):
-//     Dinv1 = D11^-1 ;  T12 = Dinv1 D12 (the rows R of step 1 in the columns K2) ;  Dinv2 = (D22 - D21 T12)^-1,
-// the last padded with the identity where fewer than 16 pivots are left, like gj_block_step<false>.  dd comes in with D11 and
-// d22 with D22 (zero outside the bs2 live pivots), entry (a, b) in lane (a & 3) << 4 | b, register a >> 2.
-__device__ __forceinline__ void gj_pivot_pair(const int lane, const int bs2, double (&dd)[4], const double (&d22)[4],
-                                              double (*Dinv1)[kGjBlock], const double (*D12)[kGjBlock],
-                                              const double (*D21)[kGjBlock], double (*T12)[kGjBlock], double (*Dinv2)[kGjBlock]) {
-    const int eb = lane & 15, ea0 = lane >> 4;
-    gj_invert_block16(dd, lane);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) Dinv1[ea0 + 4 * q][eb] = dd[q];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    double tt[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        double sum = 0.0;
-#pragma unroll
-        for (int b = 0; b < kGjBlock; ++b) sum = fma(Dinv1[ea0 + 4 * q][b], D12[b][eb], sum);
-        tt[q] = sum;
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) T12[ea0 + 4 * q][eb] = tt[q];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int ea = ea0 + 4 * q;
-        double v = d22[q];
-#pragma unroll
-        for (int b = 0; b < kGjBlock; ++b) v = fma(-D21[ea][b], T12[b][eb], v);
-        dd[q] = (ea < bs2 && eb < bs2) ? v : (ea == eb ? 1.0 : 0.0);
-    }
-    gj_invert_block16(dd, lane);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) Dinv2[ea0 + 4 * q][eb] = dd[q];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-}
-
-// What a fused step needs of its pivot blocks, for the launch that follows: Dinv1 | T12 | Dinv2, 3 x 256 doubles.
-constexpr int kGjSide = 3 * kGjBlock * kGjBlock;
-
-// The pivot work of the FIRST fused step (the later ones get theirs from the launch before them, see gj_block_step2<true>).
-__global__ __launch_bounds__(256) void gj_pivot_prepare(int n, int k0, int bs2, const double *__restrict__ in, double *__restrict__ side) {
-    __shared__ __attribute__((aligned(16))) double Dinv1[kGjBlock][kGjBlock], Dinv2[kGjBlock][kGjBlock];
-    __shared__ __attribute__((aligned(16))) double D12[kGjBlock][kGjBlock], D21[kGjBlock][kGjBlock], T12[kGjBlock][kGjBlock];
-    const int t = threadIdx.x, k1 = k0 + kGjBlock;
-    {
-        const int a = t / kGjBlock, b = t % kGjBlock;
-        D12[a][b] = b < bs2 ? in[(size_t)(k0 + a) * n + k1 + b] : 0.0;
-        D21[a][b] = a < bs2 ? in[(size_t)(k1 + a) * n + k0 + b] : 0.0;
-    }
-    __syncthreads();
-    if (t >= 64) return;
-    const int lane = t, eb = lane & 15, ea0 = lane >> 4;
-    double dd[4], d22[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int ea = ea0 + 4 * q;
-        dd[q] = in[(size_t)(k0 + ea) * n + k0 + eb];
-        d22[q] = (ea < bs2 && eb < bs2) ? in[(size_t)(k1 + ea) * n + k1 + eb] : 0.0;
-    }
-    gj_pivot_pair(lane, bs2, dd, d22, Dinv1, D12, D21, T12, Dinv2);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int e = (ea0 + 4 * q) * kGjBlock + eb;
-        side[e] = Dinv1[ea0 + 4 * q][eb];
-        side[kGjBlock * kGjBlock + e] = T12[ea0 + 4 * q][eb];
-        side[2 * kGjBlock * kGjBlock + e] = Dinv2[ea0 + 4 * q][eb];
-    }
-}
-
-// LOOK = false: every workgroup does the pivot work itself, one wave, before anything else -- two dependent 16 x 16 inversions,
-// 10 of the launch's 35 us with the other three waves waiting at the barrier (measured by leaving it out; with the pivot
-// work prepared the launch takes 32 us, 29 without the extra workgroup: the tiles themselves, 42 MB through the Infinity
-// Cache and the two rank-16 updates at two waves per SIMD, are what is left).
-// LOOK = true: the pivot work comes in through `side` (gj_pivot_prepare for the first step), and ONE extra workgroup -- block
-// (0, 0), dispatched first; the strips are the blocks with y >= 1 -- prepares the step that FOLLOWS: it takes the 32 x 32 block
-// of the next pivots through this launch's two steps like any other tile (same code, same bits as the workgroup that owns
-// that tile), keeps the result in LDS, does the pivot work on it and leaves it in `side_next`.  The chain of inversions runs
-// beside the update of the matrix instead of in front of it.  next_bs2: pivots of the second block of the following fused
-// step, 0 when none follows (then block (0, 0) has nothing to do).
-template <bool LOOK>
-__global__ __launch_bounds__(256) void gj_block_step2(int n, int k0, int bs2, const double *__restrict__ in, double *__restrict__ out,
-                                                      const double *__restrict__ side, double *__restrict__ side_next,
-                                                      int next_bs2) {
-    __shared__ __attribute__((aligned(16))) double Dinv1[kGjBlock][kGjBlock], Dinv2[kGjBlock][kGjBlock];
-    __shared__ __attribute__((aligned(16))) double D12[kGjBlock][kGjBlock], D21[kGjBlock][kGjBlock], T12[kGjBlock][kGjBlock];
-    __shared__ __attribute__((aligned(16))) double L1col[kGjStrip][kGjBlock], L2col[kGjStrip][kGjBlock];
-    const int t = threadIdx.x;
-    const int k1 = k0 + kGjBlock;                           // first pivot of the second block
-    const bool ahead = LOOK && blockIdx.y == 0;             // the workgroup that prepares the next step
-    if (ahead && (blockIdx.x != 0 || next_bs2 <= 0)) return;
-    const int kn = k1 + kGjBlock;                           // first pivot of the next step
-    const int r0 = ahead ? kn : ((int)blockIdx.y - (LOOK ? 1 : 0)) * kGjStrip;
-    const int c = ahead ? kn + t : blockIdx.x * blockDim.x + t;
-    const bool live = ahead ? (t < 2 * kGjBlock && c < n) : c < n;
-    const bool pc1 = c >= k0 && c < k1, pc2 = c >= k1 && c < k1 + bs2;
-    // everything of the old matrix is asked for up front
-    double P1[kGjBlock], P2[kGjBlock], V[kGjStrip];
-#pragma unroll
-    for (int b = 0; b < kGjBlock; ++b) P1[b] = (live && !pc1) ? in[(size_t)(k0 + b) * n + c] : 0.0;
-#pragma unroll
-    for (int b = 0; b < kGjBlock; ++b) P2[b] = (live && !pc1 && b < bs2) ? in[(size_t)(k1 + b) * n + c] : 0.0;
-#pragma unroll
-    for (int q = 0; q < kGjStrip; ++q) V[q] = (live && r0 + q < n && !pc1) ? in[(size_t)(r0 + q) * n + c] : 0.0;
-    for (int e = t; e < kGjStrip * kGjBlock; e += 256) {
-        const int i = r0 + e / kGjBlock, b = e % kGjBlock;
-        L1col[e / kGjBlock][b] = i < n ? in[(size_t)i * n + k0 + b] : 0.0;
-        L2col[e / kGjBlock][b] = (i < n && b < bs2) ? in[(size_t)i * n + k1 + b] : 0.0;
-    }
-    {
-        const int a = t / kGjBlock, b = t % kGjBlock;       // 256 threads, one entry of each 16 x 16 block
-        D12[a][b] = b < bs2 ? in[(size_t)(k0 + a) * n + k1 + b] : 0.0;
-        D21[a][b] = a < bs2 ? in[(size_t)(k1 + a) * n + k0 + b] : 0.0;
-        if (LOOK) {
-            Dinv1[a][b] = side[t];
-            T12[a][b] = side[kGjBlock * kGjBlock + t];
-            Dinv2[a][b] = side[2 * kGjBlock * kGjBlock + t];
-        }
-    }
-    const int lane = t & 63, eb = lane & 15, ea0 = lane >> 4;
-    if (!LOOK) {
-        double dd[4], d22[4] = {0.0, 0.0, 0.0, 0.0};
-        if (t < 64) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int ea = ea0 + 4 * q;
-                dd[q] = in[(size_t)(k0 + ea) * n + k0 + eb];
-                d22[q] = (ea < bs2 && eb < bs2) ? in[(size_t)(k1 + ea) * n + k1 + eb] : 0.0;
-            }
-        }
-        __syncthreads();                                    // D12, D21
-        if (t < 64) gj_pivot_pair(lane, bs2, dd, d22, Dinv1, D12, D21, T12, Dinv2);
-    }
-    __syncthreads();                                        // Dinv1, Dinv2, T12, D12, D21, L1col, L2col
-    // ---- step 1 on this thread's column
-    double R[kGjBlock];
-    if (pc1) {
-#pragma unroll
-        for (int a = 0; a < kGjBlock; ++a) R[a] = Dinv1[a][c - k0];
-    } else {
-#pragma unroll
-        for (int a = 0; a < kGjBlock; ++a) {
-            double sum = 0.0;
-#pragma unroll
-            for (int b = 0; b < kGjBlock; ++b) sum = fma(Dinv1[a][b], P1[b], sum);
-            R[a] = sum;
-            asm volatile("" : "+v"(R[a]) : : "memory");     // (keeps hipcc from issuing all LDS reads first: see below)
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < kGjStrip; ++q) {
-        const int i = r0 + q;
-        double v = V[q];
-#pragma unroll
-        for (int b = 0; b < kGjBlock; ++b) v = fma(-L1col[q][b], R[b], v);
-        if (i >= k0 && i < k1) v = Rsel(R, i - k0);
-        V[q] = v;
-        // (ties the row's result to a point in the instruction stream: without it hipcc issues all 512 LDS reads of the
-        //  strip first -- a thousand live registers -- and the sums afterwards)
-        asm volatile("" : "+v"(V[q]) : : "memory");
-    }
-    // the pivot rows K2 in this column as step 1 leaves them (their multipliers are D21's rows)
-#pragma unroll
-    for (int b2 = 0; b2 < kGjBlock; ++b2) {
-        double v = P2[b2];
-#pragma unroll
-        for (int a = 0; a < kGjBlock; ++a) v = fma(-D21[b2][a], R[a], v);
-        P2[b2] = (b2 < bs2 && !pc2) ? v : 0.0;
-        asm volatile("" : "+v"(P2[b2]) : : "memory");
-    }
-    // the pivot columns K2 in this strip's rows as step 1 leaves them: two entries per thread
-    double l2[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int e = t + 256 * h, q = e / kGjBlock, b = e % kGjBlock, i = r0 + q;
-        double v = L2col[q][b];
-#pragma unroll
-        for (int a = 0; a < kGjBlock; ++a) v = fma(-L1col[q][a], T12[a][b], v);
-        if (i >= k0 && i < k1) v = T12[i - k0][b];
-        l2[h] = (i < n && b < bs2) ? v : 0.0;
-    }
-    __syncthreads();                                        // every thread has read the old L2col
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int e = t + 256 * h;
-        L2col[e / kGjBlock][e % kGjBlock] = l2[h];
-    }
-    __syncthreads();
-    if (!live && !ahead) return;
-    // ---- step 2
-    if (pc2) {
-#pragma unroll
-        for (int a = 0; a < kGjBlock; ++a) R[a] = Dinv2[a][c - k1];
-    } else {
-#pragma unroll
-        for (int a = 0; a < kGjBlock; ++a) {
-            double sum = 0.0;
-#pragma unroll
-            for (int b = 0; b < kGjBlock; ++b) sum = fma(Dinv2[a][b], P2[b], sum);
-            R[a] = sum;
-            asm volatile("" : "+v"(R[a]) : : "memory");
-        }
-    }
-    if (!ahead) {
-#pragma unroll
-        for (int q = 0; q < kGjStrip; ++q) {
-            const int i = r0 + q;
-            double v = pc2 ? 0.0 : V[q];
-#pragma unroll
-            for (int b = 0; b < kGjBlock; ++b) v = fma(-L2col[q][b], R[b], v);
-            if (i >= k1 && i < k1 + bs2) v = Rsel(R, i - k1);
-            asm volatile("" : "+v"(v) : : "memory");
-            if (i < n) out[(size_t)i * n + c] = v;
-        }
-        return;
-    }
-    // ---- the workgroup that prepares the next step: its 32 x 32 tile is the next step's D11 | D12 / D21 | D22 (no pivot row or
-    // column of THIS step is in it).  The blocks of this step are done with: they take the next step's, zero outside its pivots.
-    __syncthreads();                                        // every wave has read Dinv2, D21, T12 for the last time
-    double d11n[4] = {0.0, 0.0, 0.0, 0.0}, d22n[4] = {0.0, 0.0, 0.0, 0.0};
-    {
-        const int nb = next_bs2;
-#pragma unroll
-        for (int q = 0; q < kGjStrip; ++q) {
-            double v = V[q];
-#pragma unroll
-            for (int b = 0; b < kGjBlock; ++b) v = fma(-L2col[q][b], R[b], v);
-            asm volatile("" : "+v"(v) : : "memory");
-            // (q, t): row kn + q, column kn + t of the matrix after this launch
-            if (t < 2 * kGjBlock) {
-                const bool in_n = kn + q < n && kn + t < n;
-                const double w = in_n ? v : 0.0;
-                if (q < kGjBlock && t < kGjBlock) Dinv1[q][t] = w;                                   // D11 of the next step, inverted below
-                else if (q < kGjBlock) D12[q][t - kGjBlock] = (t - kGjBlock < nb) ? w : 0.0;
-                else if (t < kGjBlock) D21[q - kGjBlock][t] = (q - kGjBlock < nb) ? w : 0.0;
-                else Dinv2[q - kGjBlock][t - kGjBlock] = (q - kGjBlock < nb && t - kGjBlock < nb) ? w : 0.0;
-            }
-        }
-    }
-    __syncthreads();
-    if (t >= 64) return;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        d11n[q] = Dinv1[ea0 + 4 * q][eb];
-        d22n[q] = Dinv2[ea0 + 4 * q][eb];
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    gj_pivot_pair(lane, next_bs2, d11n, d22n, Dinv1, D12, D21, T12, Dinv2);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int e = (ea0 + 4 * q) * kGjBlock + eb;
-        side_next[e] = Dinv1[ea0 + 4 * q][eb];
-        side_next[kGjBlock * kGjBlock + e] = T12[ea0 + 4 * q][eb];
-        side_next[2 * kGjBlock * kGjBlock + e] = Dinv2[ea0 + 4 * q][eb];
-    }
-}
-
 // ---- the same inversion with 64 pivots per launch, the rank-64 updates on the double-precision matrix cores ------------------
 // With K the 64 pivots of a step, D = W[K, K], the step is  W' = C~ - L~ (D^-1 P~)  with the inputs modified so that one formula
 // serves every entry:  C~ = W with the pivot rows and columns zeroed,  P~ = W[K, :] with the identity in the pivot columns,
@@ -2225,7 +1946,7 @@ __global__ __launch_bounds__(256) void gj_block_step2(int n, int k0, int bs2, co
 // Measured (scripts/lab/gj_mfma_lab.hip, mfma_f64_rate.hip; n = 1617): the instruction issues every 62 ns per SIMD with one wave
 // there, 45 ns with two -- 33 to 47 TFLOP/s over the chip, not above the vector rate -- and a launch of 64 pivots takes 40 us
 // against 2 x 32 us of the vector kernel above: what it saves is a pass over the matrix, not arithmetic.
-// The pivot block of the NEXT step is prepared by workgroup 0 of the launch (as in gj_block_step2<true>): its four waves take
+// The pivot block of the NEXT step is prepared by workgroup 0 of the launch: its four waves take
 // the next 64 x 64 block through this step, invert it in LDS by four 16-pivot block steps and leave D^-1 in the other side buffer.
 // Sums are formed in the order of the matrix cores: the result agrees with the vector kernels to rounding, not bit for bit
 // (PADNE_GJ_VECTOR=1 selects those).
@@ -2610,8 +2331,6 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
     // one zeroed counter per round (at most 256 rounds) instead of a memset in front of every round
     constexpr int kMaxRounds = 256;
     PADNE_TRY(sc.alloc(&counter, (size_t)2 * kMaxRounds + 4));
-    PADNE_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(int) * ((size_t)2 * kMaxRounds + 4), s));
-    PADNE_HIP_CHECK(hipMemsetAsync(state, 0, (size_t)n, s));
     const dim3 g(nblk(n)), b(256);
     // strength graph on the pattern of A, built once per level
     const int *srow = A->rowptr;
@@ -2624,19 +2343,21 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
     double *bound2 = nullptr;            // their maxima: filtered | plain
     if (lambda_f != nullptr) PADNE_TRY(sc.alloc(&bound2, 2));
     // x-window plan of A (fine-level band matrices): one byte per entry and LDS-staged neighbours in the rounds below
-    const bool xw = A->xw_state == 1 && A->xw_run <= 85 && getenv("PADNE_AMG_NO_XW") == nullptr;
+    const bool xw = A->xw_state == 1 && A->xw_run <= 85;
     unsigned char *spos = nullptr;
     if (xw) {
         PADNE_TRY(sc.alloc(&spos, (size_t)A->nnz + kPadNnz));
-        PADNE_HIP_CHECK(hipMemsetAsync(spos + A->nnz, 0, kPadNnz, s));
     }
+    static_assert(kPadNnz >= 2 * kMaxRounds + 4, "one grid for everything the start clears");
+    hipLaunchKernelGGL(mis_init_words, dim3(nblk(std::max(n, kPadNnz))), b, 0, s, n, w0, state, counter, 2 * kMaxRounds + 4,
+                       spos != nullptr ? spos + A->nnz : (unsigned char *)nullptr, kPadNnz);
     hipLaunchKernelGGL(strength_mark, gm, b, 0, s, n, n_wt, A->rowptr, A->cols, A->vals, A->dinv, theta2, scol, bound_part,
                        xw ? A->xw_desc : (const int4 *)nullptr, xw ? (const unsigned char *)A->xw_lidx : (const unsigned char *)nullptr,
                        xw ? A->xw_run : 0, spos);
     PADNE_HIP_CHECK(hipGetLastError());
     // one round = one-hop maxima, two-hop maxima, decision; on a windowed matrix the decision rides on the second pass;
     // small levels with long rows (a few thousand rows of dozens of entries) take a wave per row
-    const bool long_rows = !xw && n <= 65536 && A->nnz >= 24LL * n && getenv("PADNE_AMG_NO_WPR") == nullptr;
+    const bool long_rows = !xw && n <= 65536 && A->nnz >= 24LL * n;
     auto launch_round = [&](int *open_counter) {
         if (xw) {
             hipLaunchKernelGGL((nbr_max_xw<unsigned int, false>), gm, b, 0, s, n, n_wt, srow, scol, spos, A->xw_desc, A->xw_run,
@@ -2666,7 +2387,6 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
         bound_pending = false;
         return read_back2(ctx, dev_count, sizeof(int), host_count, bound2, sizeof(h_bound2), h_bound2);
     };
-    hipLaunchKernelGGL(mis_init_words, g, b, 0, s, n, w0);
     int open_count = n;
     int round = 0;
     // the compact rounds pay off on sparse rows only: a direct two-hop maximum visits (nnz/row)^2 words per vertex
@@ -2694,6 +2414,16 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
         PADNE_HIP_CHECK(hipGetLastError());
         int cnt = open_count, cur = 0;       // counters[cur]: length of list_a, on the device
         while (cur + 1 < kMaxRounds && cnt > 0) {
+            if (cnt <= kMisTailCap) {
+                // the rest of the rounds in one launch of one workgroup
+                hipLaunchKernelGGL(mis_tail_rounds, dim3(1), dim3(1024), 0, s, (const int *)(counters + cur), list_a, list_b, srow,
+                                   (const int *)scol, w0, state, m2, counters + cur + 1, kMaxRounds - cur - 1);
+                PADNE_HIP_CHECK(hipGetLastError());
+                ++cur;
+                round += kMaxRounds;                       // (not counted one by one: `round` only bounds the loops here)
+                PADNE_TRY(count_back(counters + cur, &cnt));
+                break;
+            }
             const dim3 gl(nblk(cnt));
             const int batch = cnt > 200000 ? 1 : 3;
             for (int rep = 0; rep < batch && cur + 1 < kMaxRounds; ++rep, ++round) {
@@ -3066,7 +2796,7 @@ static int transpose(padne_ctx *ctx, const padne_csr *M, padne_csr **T) {
     int *cnt = zeroed, *cursor = zeroed + nc + 1, *npairs = cursor + nc, *n_long = npairs + nc;
     padne_csr *m = nullptr;
     PADNE_TRY(csr_alloc(ctx, nc, M->n_rows, M->nnz, &m));
-    const int all_cursors = getenv("PADNE_TRANSPOSE_CURSORS") != nullptr ? 1 : 0;
+    const int all_cursors = ctx->opt.force_transpose_cursors ? 1 : 0;
     hipError_t e = hipMemsetAsync(zeroed, 0, sizeof(int) * n_zero, s);
     if (e == hipSuccess && M->n_rows > 0)
         hipLaunchKernelGGL(transpose_count_pairs, dim3(nblk(M->n_rows)), dim3(256), 0, s, (int)M->n_rows, M->rowptr, M->cols, cnt,
@@ -3167,9 +2897,8 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
             n_slots = h[0];
         }
     }
-    // (PADNE_SPGEMM_SPLIT_SLOTS lowers the limit so that tests reach the split path on small systems)
-    const char *split_env = getenv("PADNE_SPGEMM_SPLIT_SLOTS");
-    const long long split_limit = split_env ? atoll(split_env) : 0;
+    // (PADNE_FORCE=spgemm_split:<slots> lowers the limit so that tests reach the split path on small systems)
+    const long long split_limit = ctx->opt.force_spgemm_split;
     if ((rc_scan == PADNE_E_TOOLARGE || (rc_scan == PADNE_OK && split_limit > 0 && n_slots > split_limit)) && n >= 2) {
         // more product slots than 32-bit offsets address (A*P of a 130 M-row mesh Laplacian: 17 per row) although the
         // product itself fits: multiply the two halves of the rows separately and stack the results.  A half is a
@@ -3207,18 +2936,13 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
                                       (int)dense_lds);
             hipLaunchKernelGGL(spgemm_rows_dense, dim3(n), dim3(256), dense_lds, s, (int)Y->n_cols, X->rowptr, X->cols,
                                X->vals, y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len, 0);
-        } else if (avg <= 24.0 && getenv("PADNE_SPGEMM_WAVE_ALL") == nullptr) {
+        } else if (avg <= 24.0) {
             // A*P on the fine levels: a dozen products per row -> one thread per row with small sorted lists in LDS (12 entries:
             // 18 KiB per workgroup, four waves per SIMD -- with 16 the LDS allowed three: 2.47 -> 2.16 ms on the fine level of config C4;
             // the rare longer row is redone in global memory)
-            if (getenv("PADNE_SPGEMM_NO_PIPE") != nullptr)
-                hipLaunchKernelGGL(spgemm_rows_lds<16>, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
-                                   y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len);
-            else {
-                // the rows of a 64-row tile back to back (PADNE_SPGEMM_NO_COMPACT=1: every row in its own slot range)
-                if (getenv("PADNE_SPGEMM_NO_COMPACT") == nullptr) {
-                    PADNE_TRY(sc.alloc(&row_begin, (size_t)n + 1));
-                }
+            {
+                // the rows of a 64-row tile back to back
+                PADNE_TRY(sc.alloc(&row_begin, (size_t)n + 1));
                 if (y_cs == 1)
                     hipLaunchKernelGGL((spgemm_rows_lds_pipe<12, 9, 4, 1>), dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols,
                                        X->vals, y_begin, y_cols, y_vals, y_end, slot_ptr, key, val, row_len, row_begin);
@@ -3252,7 +2976,6 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
                 // short rows: two rows per wave with small limits first (2.5 KiB of LDS per row: 56 rows in flight per
                 // CU), then one row per wave for the rows that did not fit
                 unsigned gs = (unsigned)std::min<long long>(((long long)n + 7) / 8, 16384);
-                if (const char *ge = getenv("PADNE_SPGEMM_SUB_GRID")) gs = std::min(gs, (unsigned)std::max(8, atoi(ge)));
                 hipLaunchKernelGGL((spgemm_rows_sub<128, 64, 32>), dim3(gs), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
                                    y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len);
                 hipLaunchKernelGGL(collect_pending_rows, dim3(nblk(n)), dim3(256), 0, s, n, (const int *)row_len, pend, pend_count);
@@ -3439,18 +3162,12 @@ static int dense_inverse(padne_ctx *ctx, const padne_csr *A, double **inv_out) {
     if (n > 0) {
         hipLaunchKernelGGL(dense_from_csr, dim3(n), dim3(256), 0, s, n, A->rowptr, A->cols, A->vals, W);
         const dim3 ge(nblk(n), (unsigned)((n + kGjStrip - 1) / kGjStrip));
-        const dim3 ge_look(ge.x, ge.y + 1);                 // block row 0: the workgroup that prepares the next step
         double *src = W, *dst = W2;
-        // two pivot blocks per launch while more than one is left (gj_block_step2), the one-step kernel for a single last
-        // block; PADNE_GJ_ONE_STEP=1: one block per launch throughout (the form the fused kernel is tested against);
-        // PADNE_GJ_NO_LOOKAHEAD=1: every workgroup of a fused step does the pivot work itself (the same bits, tested)
-        const bool fused = getenv("PADNE_GJ_ONE_STEP") == nullptr;
-        const bool look = fused && getenv("PADNE_GJ_NO_LOOKAHEAD") == nullptr;
-        // default: 64 pivots per launch on the matrix cores (gj64_step); PADNE_GJ_VECTOR=1 (or one of the two switches above):
-        // the vector kernels, 32 or 16 pivots per launch
-        const bool mfma = look && getenv("PADNE_GJ_VECTOR") == nullptr && n > kGjM;
-        double *side = nullptr;
+        // 64 pivots per launch on the matrix cores (gj64_step); PADNE_GJ_VECTOR=1, or a matrix of at most 64 unknowns: the
+        // vector kernel, 16 pivots per launch -- the form the matrix-core inverse is tested against
+        const bool mfma = !ctx->opt.gj_vector && n > kGjM;
         if (mfma) {
+            double *side = nullptr;
             PADNE_TRY(sc.alloc(&side, (size_t)2 * kGjM * kGjM));
             const int n_ct = (n + kGjTC - 1) / kGjTC, n_tiles = n_ct * ((n + kGjTR - 1) / kGjTR);
             const unsigned g64 = 1u + (unsigned)((n_tiles + 3) / 4);
@@ -3466,35 +3183,15 @@ static int dense_inverse(padne_ctx *ctx, const padne_csr *A, double **inv_out) {
                 par ^= 1;
                 std::swap(src, dst);
             }
-        } else if (look) PADNE_TRY(sc.alloc(&side, (size_t)2 * kGjSide));
-        int parity = 0;
-        if (look && !mfma && n > kGjBlock) {
-            hipLaunchKernelGGL(gj_pivot_prepare, dim3(1), dim3(256), 0, s, n, 0, std::min(kGjBlock, n - kGjBlock), (const double *)src, side);
-        }
-        for (int k = mfma ? n : 0; k < n;) {
-            const int left = n - k;
-            // the last step writes the finished inverse where it stays
-            if (fused && left > kGjBlock) {
-                const int bs2 = std::min(kGjBlock, left - kGjBlock);
-                const int left_next = left - kGjBlock - bs2;
-                const int next_bs2 = left_next > kGjBlock ? std::min(kGjBlock, left_next - kGjBlock) : 0;
-                double *to = k + kGjBlock + bs2 >= n ? inv : dst;
-                if (look)
-                    hipLaunchKernelGGL(gj_block_step2<true>, ge_look, dim3(256), 0, s, n, k, bs2, (const double *)src, to,
-                                       (const double *)(side + parity * kGjSide), side + (parity ^ 1) * kGjSide, next_bs2);
+        } else {
+            for (int k = 0; k < n; k += kGjBlock) {
+                // the last step writes the finished inverse where it stays
+                if (n - k >= kGjBlock)
+                    hipLaunchKernelGGL(gj_block_step<true>, ge, dim3(256), 0, s, n, k, src, k + kGjBlock >= n ? inv : dst);
                 else
-                    hipLaunchKernelGGL(gj_block_step2<false>, ge, dim3(256), 0, s, n, k, bs2, (const double *)src, to,
-                                       (const double *)nullptr, (double *)nullptr, 0);
-                parity ^= 1;
-                k += kGjBlock + bs2;
-            } else if (left >= kGjBlock) {
-                hipLaunchKernelGGL(gj_block_step<true>, ge, dim3(256), 0, s, n, k, src, k + kGjBlock >= n ? inv : dst);
-                k += kGjBlock;
-            } else {
-                hipLaunchKernelGGL(gj_block_step<false>, ge, dim3(256), 0, s, n, k, src, inv);
-                k += kGjBlock;
+                    hipLaunchKernelGGL(gj_block_step<false>, ge, dim3(256), 0, s, n, k, src, inv);
+                std::swap(src, dst);
             }
-            std::swap(src, dst);
         }
     }
     const hipError_t e = hipGetLastError();      // (no synchronisation: the scratch goes back to the stream-ordered pool)
@@ -3560,11 +3257,8 @@ struct PhaseTimer {   // wall-clock phase timing, only when PADNE_AMG_VERBOSE is
     }
 };
 
-static bool amg_verbose() {
-    static int v = -1;
-    if (v < 0) v = getenv("PADNE_AMG_VERBOSE") != nullptr ? 1 : 0;
-    return v == 1;
-}
+static thread_local bool t_amg_verbose = false;      // PADNE_VERBOSE=amg of the context whose setup runs on this thread
+static bool amg_verbose() { return t_amg_verbose; }
 
 static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0);
 static int host_allgather(padne_ctx *ctx, const std::vector<double> &mine, std::vector<double> &all);
@@ -3589,7 +3283,7 @@ static int f32_range(padne_ctx *ctx, const padne_csr *A0, double *lo_out, double
 }
 
 static int enable_f32(padne_ctx *ctx, Amg *amg) {
-    if (getenv("PADNE_AMG_F64") != nullptr || amg->levels.size() < 2) return PADNE_OK;
+    if (ctx->opt.amg_f64 || amg->levels.size() < 2) return PADNE_OK;
     if (amg->levels[0].A->hierarchy_operator) return PADNE_OK;   // the gathered tail of a row-partitioned hierarchy
     hipStream_t s = ctx->stream;
     double lo = 0.0, hi = 0.0;
@@ -3634,25 +3328,16 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
     PADNE_REQUIRE(A0->n_rows == A0->n_cols, "multigrid needs a square matrix");
     PADNE_TRY(csr_build_dinv(ctx, A0));
     PADNE_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
-    padne_ctx *aux = getenv("PADNE_AMG_ONE_STREAM") != nullptr ? ctx : aux_context(ctx);
+    t_amg_verbose = ctx->opt.verbose_amg;
+    padne_ctx *aux = aux_context(ctx);
     if (aux == nullptr) aux = ctx;
     const bool two = aux != ctx;
     // single-precision cycle?  (decided from 1/diag of the fine matrix, before anything is queued)
-    bool want_f32 = getenv("PADNE_AMG_F64") == nullptr && !A0->hierarchy_operator;
+    bool want_f32 = !ctx->opt.amg_f64 && !A0->hierarchy_operator;
     if (want_f32) {
         double lo = 0.0, hi = 0.0;
         PADNE_TRY(f32_range(ctx, A0, &lo, &hi));
         want_f32 = lo >= 1e-15 && hi <= 1e15;
-    }
-    {
-        // A/B switch of the XCD-aware row order (xcd_bid): the device copy of the flag follows the environment
-        static int applied[64] = {0};
-        const int want = getenv("PADNE_NO_XCD_MAP") != nullptr ? 0 : 1;
-        if (ctx->device >= 0 && ctx->device < 64 && applied[ctx->device] != want + 1) {
-            PADNE_HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_xcd_map), &want, sizeof(int), 0, hipMemcpyHostToDevice, ctx->stream));
-            PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-            applied[ctx->device] = want + 1;
-        }
     }
     Amg *amg = new Amg();
     amg->device = ctx->device;
@@ -3667,7 +3352,7 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
     // end of the setup -- built there, on the second stream, next to the dense inverse of the coarsest operator
     struct KeptSlots { int level; SlotRows rows; };
     std::vector<std::unique_ptr<KeptSlots>> ap_inner;
-    const bool w_inner = getenv("PADNE_AMG_W_FINE_ONLY") == nullptr && getenv("PADNE_AMG_NO_W") == nullptr;
+    const bool w_inner = ctx->opt.amg_w == 2;
     auto drop_pending = [&]() {
         for (Pending *pj : pending) {
             double unused = 0.0;
@@ -3677,20 +3362,19 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         pending.clear();
     };
     for (int lvl = 0; lvl < kMaxLevels; ++lvl) {
-        t_setup_level = lvl;
         AmgLevel L;
         L.A = A;
         L.A_owned = (lvl == 0) ? nullptr : const_cast<padne_csr *>(A);
         L.n = A->n_rows;
         nnz_total += (double)A->nnz;
-        const bool coarsest = A->n_rows <= kCoarseN || lvl == kMaxLevels - 1;
+        const bool coarsest = A->n_rows <= ctx->opt.amg_coarse_n || lvl == kMaxLevels - 1;
         if ((rc = alloc_vec(ctx, &L.xa, L.n)) != PADNE_OK || (rc = alloc_vec(ctx, &L.tmp, L.n)) != PADNE_OK) { amg->levels.push_back(L); break; }
         if (lvl > 0 && ((rc = alloc_vec(ctx, &L.b, L.n)) != PADNE_OK || (rc = alloc_vec(ctx, &L.xb, L.n)) != PADNE_OK)) { amg->levels.push_back(L); break; }
         // second stream, everything that needs only A_l: the Lanczos bound and the float copy.  Neither is read before the
         // cycle runs, so they are queued LATE in the level -- behind the transposes the main stream waits for, and while
         // the main stream is busy with R (A P): the one host thread that launches for both streams then starts the level's
         // aggregation without first spending 30 launches on the other stream (the small levels are launch-bound)
-        const bool lanczos = lvl > 0 && A->n_rows > kCoarseN && getenv("PADNE_AMG_NO_LANCZOS") == nullptr;
+        const bool lanczos = lvl > 0 && A->n_rows > ctx->opt.amg_coarse_n;
         auto queue_level_extras = [&]() -> int {
             if (two) PADNE_TRY(stream_order(ctx, aux));
             if (lanczos) {
@@ -3701,7 +3385,7 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
                 Pending *pj = new Pending();
                 pj->level = lvl;
                 pending.push_back(pj);
-                PADNE_TRY(lanczos_enqueue(aux, A, lanczos_steps(), &pj->job));
+                PADNE_TRY(lanczos_enqueue(aux, A, kLanczosSteps, &pj->job));
             }
             if (want_f32) PADNE_TRY(csr_build_f32(aux, const_cast<padne_csr *>(A)));
             if (want_f32 && L.P != nullptr) PADNE_TRY(csr_build_f32(aux, L.P));      // (and of the level's P and R, once they exist)
@@ -3730,7 +3414,7 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         // omega uses Gershgorin bounds (filtered operator, capped by the unfiltered one): the sharper Lanczos
         // estimate of lambda(D^-1 A) over-relaxes the prolongator (44 instead of 34 CG iterations at N = 0.5 M)
         if (L.lambda < lambda_f) lambda_f = L.lambda;
-        const double omega = omega_num() / lambda_f;
+        const double omega = kOmegaNum / lambda_f;
         if (amg_verbose())
             fprintf(stderr, "[amg] level %d: n=%lld nnz=%lld lambda=%.3f (P: %.3f) -> %d aggregates\n", lvl,
                     (long long)A->n_rows, (long long)A->nnz, L.lambda, lambda_f, n_agg);
@@ -3750,7 +3434,7 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         if (L.R == nullptr && (rc = transpose(aux, L.P, &L.R)) != PADNE_OK) { amg->levels.push_back(L); break; }   // (the product was split: its halves do not call back)
         pt.lap("A*P (P^T queued beside it)");
         // fine level of the float cycle: W = P - c D^-1 A P from the slots of A P, on the second stream
-        const bool with_w = lvl == 0 && want_f32 && ap_rows.valid && getenv("PADNE_AMG_NO_W") == nullptr;
+        const bool with_w = lvl == 0 && want_f32 && ap_rows.valid && ctx->opt.amg_w >= 1;
         if (amg_verbose() && AP != nullptr) fprintf(stderr, "[amg]   AP nnz=%lld\n", (long long)AP->nnz);
         if (two && (rc = stream_order(aux, ctx)) != PADNE_OK) { if (AP) padne_csr_destroy(AP); amg->levels.push_back(L); break; }
         if (with_w) {                       // after the join above: the main stream waits for R, not for W
@@ -4218,7 +3902,7 @@ static int gather_tail(padne_ctx *ctx, Amg *amg) {
                 padne_csr_destroy(amg->levels[l].P_halo);
                 amg->levels[l].P_halo = nullptr;
             }
-        if (nl >= 2 && amg->levels[nl - 2].P_halo != nullptr && getenv("PADNE_AMG_EXCHANGE_ALL") != nullptr) {
+        if (nl >= 2 && amg->levels[nl - 2].P_halo != nullptr && ctx->opt.amg_exchange_all) {
             padne_csr_destroy(amg->levels[nl - 2].P_halo);      // (A/B and tests: every level exchanges twice per cycle)
             amg->levels[nl - 2].P_halo = nullptr;
         }
@@ -4248,9 +3932,8 @@ static int gather_tail(padne_ctx *ctx, Amg *amg) {
 // global size at which the row-partitioned levels hand over to the gathered tail: the tail is replicated work (a
 // fixed cost per rank), a partitioned level costs two exchanges per cycle -- with 4+ ranks the 100 k-unknown level
 // is still cheaper partitioned
-static int gather_n_limit(int world) {
-    const char *e = getenv("PADNE_AMG_GATHER_N");
-    int v = e ? atoi(e) : (world >= 4 ? 65536 : 262144);
+static int gather_n_limit(const padne_ctx *ctx, int world) {
+    int v = ctx->opt.amg_gather_n > 0 ? (int)std::min<long long>(ctx->opt.amg_gather_n, 1LL << 30) : (world >= 4 ? 65536 : 262144);
     if (v < 64) v = 64;
     return v;
 }
@@ -4263,7 +3946,8 @@ static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0) {
     hipStream_t s = ctx->stream;
     PADNE_HIP_CHECK(hipStreamSynchronize(s));
     const auto t_begin = std::chrono::steady_clock::now();
-    const long long gather_n = gather_n_limit(W);
+    t_amg_verbose = ctx->opt.verbose_amg;
+    const long long gather_n = gather_n_limit(ctx, W);
     Amg *amg = new Amg();
     amg->device = ctx->device;
     amg->ctx = ctx;
@@ -4286,7 +3970,6 @@ static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0) {
     double nnz_total = 0.0;
     bool stalled = false;
     for (int lvl = 0; lvl < kMaxLevels && rc == PADNE_OK; ++lvl) {
-        t_setup_level = lvl;
         AmgLevel L;
         L.A = A;
         L.A_owned = (lvl == 0) ? nullptr : const_cast<padne_csr *>(A);
@@ -4314,9 +3997,9 @@ static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0) {
         // level 0 always stays row-partitioned (the CG vectors are); below it the levels are gathered as soon
         // as they are small enough to run redundantly
         const bool coarsest = lvl > 0 && (n_glob <= gather_n || lvl == kMaxLevels - 1);
-        if (lvl > 0 && !coarsest && getenv("PADNE_AMG_NO_LANCZOS") == nullptr) {
+        if (lvl > 0 && !coarsest) {
             double ritz = 0.0;
-            if ((rc = estimate_lambda_max(ctx, A, lanczos_steps(), &ritz, &plan)) != PADNE_OK) break;
+            if ((rc = estimate_lambda_max(ctx, A, kLanczosSteps, &ritz, &plan)) != PADNE_OK) break;
             const double est = 1.08 * ritz;
             if (est > 0.0 && est < Lr.lambda) Lr.lambda = est;
         }
@@ -4361,7 +4044,7 @@ static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0) {
         }
         if (lambda_g < lambda_f) lambda_f = lambda_g;
         pt.lap("block+aggregate");
-        rc = build_prolongator(ctx, blk, agg, n_agg, omega_num() / lambda_f, &Lr.P);
+        rc = build_prolongator(ctx, blk, agg, n_agg, kOmegaNum / lambda_f, &Lr.P);
         padne_csr_destroy(blk);
         if (rc != PADNE_OK) break;
         if ((rc = transpose(ctx, Lr.P, &Lr.R)) != PADNE_OK) break;
@@ -4388,7 +4071,7 @@ static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0) {
             ap_shape.n_rows = ap_rows.n_rows;
             ap_shape.n_cols = ap_rows.n_cols;
             rc = spgemm(ctx, Lr.R, &ap_shape, &Ac, &ap_rows);
-            if (rc == PADNE_OK && A->dinv != nullptr && getenv("PADNE_AMG_NO_W") == nullptr) {
+            if (rc == PADNE_OK && A->dinv != nullptr && (ctx->opt.amg_w == 2 || (ctx->opt.amg_w == 1 && lvl == 0))) {
                 rc = build_w_operator(ctx, A, Lr.P, ap_rows, ap_rows.n_slots, Lr.jac, &Lr.W);
                 if (rc == PADNE_OK) Lr.W->n_cols = P_ext->n_cols;
             }

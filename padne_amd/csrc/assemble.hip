@@ -259,8 +259,7 @@ int scan_i32_begin(padne_ctx *ctx, const int32_t *in, int32_t *out, int64_t n, S
     t->bs = bs;
     long long *tot = bs + nb;          // [0] exact 64-bit total, [1] negative-input flag
     if (want_total) t->mail = mail_ticket(ctx);
-    static const bool small_ok = getenv("PADNE_SCAN_THREE_KERNELS") == nullptr;
-    if (n <= kScanSmall && small_ok) {
+    if (n <= kScanSmall) {
         hipLaunchKernelGGL(scan_small, dim3(1), dim3(1024), 0, s, in, (int)n, out, tot, t->mail.slot_dev, t->mail.seq);
     } else {
         hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(256), 0, s, in, (long long)n, bs);
@@ -388,7 +387,7 @@ __global__ __launch_bounds__(256) void asm_count_tri(long long n_tri, const int 
                                                      const long long *__restrict__ mesh_voff,
                                                      const long long *__restrict__ mesh_toff, int *__restrict__ cnt,
                                                      int2 *__restrict__ inc, int *__restrict__ err, const int no_range) {
-    // no_range (PADNE_ASM_HASH, tests): every workgroup takes the hash path of the wide ranges
+    // no_range (PADNE_FORCE=asm_hash, tests): every workgroup takes the hash path of the wide ranges
     __shared__ int lcnt[kCntRange], lbase[kCntRange];
     __shared__ int s_min, s_max;
     if (threadIdx.x == 0) {
@@ -2335,7 +2334,7 @@ extern "C" int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns, int64_t
     PADNE_HIP_CHECK(hipMemsetAsync(d_nlisted, 0, sizeof(int) * 2, s));
     if (n_tri > 0)
         hipLaunchKernelGGL(asm_count_tri, dim3(nblk(n_tri, 256 * kCntTris)), dim3(256), 0, s, (long long)n_tri, d_tri, (int)n_mesh,
-                           d_voff, d_toff, d_ninc, d_inc, d_err, getenv("PADNE_ASM_HASH") != nullptr ? 1 : 0);
+                           d_voff, d_toff, d_ninc, d_inc, d_err, ctx->opt.force_asm_hash ? 1 : 0);
     if (n_coo > 0)
         hipLaunchKernelGGL(asm_count_coo, dim3(nblk(n_coo)), dim3(256), 0, s, (long long)n_coo, d_crow, d_ncoo);
     // 2 the rows that go through the slots (stamps, hubs, the unknowns behind the vertices; long fans): lists, slot counts, offsets
@@ -2439,8 +2438,8 @@ extern "C" int padne_assemble_system(padne_ctx *ctx, int64_t n_unknowns, int64_t
                                        (const int *)(d_nlisted + 1), (const int *)d_fans, (const int *)d_slot, (const long long *)d_key,
                                        (const double *)d_val, (const int *)m->rowptr, m->cols, m->vals, nnz_bound, d_err);
             };
-            // PADNE_ASM_TWO_PASS=1 takes the second path at once (its test; a caller that knows the chip is oversubscribed)
-            bool two_pass = getenv("PADNE_ASM_TWO_PASS") != nullptr;
+            // PADNE_FORCE=asm_two_pass takes the second path at once (its test; a caller that knows the chip is oversubscribed)
+            bool two_pass = ctx->opt.force_asm_two_pass;
             if (e == hipSuccess && !two_pass) {
                 hipLaunchKernelGGL(asm_rows_in_place, dim3(workers + 1), dim3(128), 0, s, args);
                 place_listed_rows();
@@ -2600,7 +2599,7 @@ int csr_relabel(padne_ctx *ctx, const padne_csr *m, const int32_t *row_map_host,
         PADNE_HIP_CHECK(hipMemcpyAsync(d_cmap, col_map_host, sizeof(int) * (size_t)m->n_cols, hipMemcpyDefault, s));
     }
     PADNE_HIP_CHECK(hipMemsetAsync(d_err, 0, sizeof(int) * ERR_WORDS, s));
-    if (m->n_rows > 0 && m->n_cols > 0 && n_rows_out > 0 && n_cols_out > 0 && getenv("PADNE_RELABEL_SLOTS") == nullptr) {
+    if (m->n_rows > 0 && m->n_cols > 0 && n_rows_out > 0 && n_cols_out > 0 && !ctx->opt.force_relabel_slots) {
         // maps that only drop indices (the reduction to the potential block): count, scan, copy -- see map_is_compaction
         static_assert(ERR_WORDS >= 6, "two triples of flag words");
         hipLaunchKernelGGL(map_is_compaction, dim3(nblk(m->n_rows)), dim3(256), 0, s, (long long)m->n_rows, (const int *)d_map,
@@ -2674,7 +2673,7 @@ int csr_relabel(padne_ctx *ctx, const padne_csr *m, const int32_t *row_map_host,
             return PADNE_E_INVALID;
         }
         const int h_dup = h_flags[0];
-        if (h_dup == 0 && getenv("PADNE_RELABEL_SLOTS") == nullptr) {
+        if (h_dup == 0 && !ctx->opt.force_relabel_slots) {
             if (m->n_rows > 0)
                 hipLaunchKernelGGL(relabel_count_direct, dim3(nblk(m->n_rows)), dim3(256), 0, s, (long long)m->n_rows, m->rowptr,
                                    m->cols, d_map, d_cmap, d_cnt);

@@ -1,6 +1,8 @@
 // C ABI plumbing: contexts, device memory, CSR hand-off, SpMV entry points, timing.
 #include "common.hpp"
 
+#include <algorithm>
+
 #include <math.h>
 #include <stdarg.h>
 #include <string.h>
@@ -9,6 +11,51 @@
 namespace padne {
 
 std::atomic<long long> g_launch_count{0};
+
+void options_from_env(padne_options *o) {
+    *o = padne_options();
+    auto on = [](const char *name) { const char *e = getenv(name); return e != nullptr && e[0] != '\0' && !(e[0] == '0' && e[1] == '\0'); };
+    auto has = [](const char *list, const char *word) {
+        const size_t n = strlen(word);
+        for (const char *p = list; p != nullptr && *p != '\0';) {
+            const char *q = strchr(p, ',');
+            const size_t len = q != nullptr ? (size_t)(q - p) : strlen(p);
+            if (len >= n && strncmp(p, word, n) == 0 && (len == n || p[n] == ':')) return p;
+            p = q != nullptr ? q + 1 : nullptr;
+        }
+        return (const char *)nullptr;
+    };
+    o->amg_f64 = on("PADNE_AMG_F64");
+    if (const char *e = getenv("PADNE_AMG_W")) o->amg_w = strcmp(e, "none") == 0 ? 0 : (strcmp(e, "fine") == 0 ? 1 : 2);
+    o->amg_exchange_all = on("PADNE_AMG_EXCHANGE_ALL");
+    o->pcg_p64 = on("PADNE_PCG_P64");
+    o->gj_vector = on("PADNE_GJ_VECTOR");
+    o->no_batch = on("PADNE_NO_BATCH");
+    o->no_mailbox = on("PADNE_NO_MAILBOX");
+    o->no_p2p = on("PADNE_NO_P2P");
+    o->no_split = on("PADNE_NO_SPLIT");
+    o->no_xwindow = on("PADNE_NO_XWINDOW");
+    if (const char *e = getenv("PADNE_CG_SINGLE_REDUCTION")) o->cg_single_reduction = atoi(e) != 0 ? 1 : 0;
+    if (const char *e = getenv("PADNE_LOCKSTEP_NARROW")) o->lockstep_narrow = atoi(e);
+    if (const char *e = getenv("PADNE_AMG_COARSE_N")) o->amg_coarse_n = std::min(4096, std::max(16, atoi(e)));
+    if (const char *e = getenv("PADNE_AMG_GATHER_N")) o->amg_gather_n = atoll(e);
+    if (const char *e = getenv("PADNE_P2P_TIMEOUT_MS")) {
+        const long v = atol(e);
+        if (v > 0 && v <= 600000) o->p2p_timeout_ms = (unsigned)v;
+    }
+    if (const char *f = getenv("PADNE_FORCE")) {
+        o->force_asm_hash = has(f, "asm_hash") != nullptr;
+        o->force_asm_two_pass = has(f, "asm_two_pass") != nullptr;
+        o->force_relabel_slots = has(f, "relabel_slots") != nullptr;
+        o->force_transpose_cursors = has(f, "transpose_cursors") != nullptr;
+        if (const char *w = has(f, "spgemm_split")) o->force_spgemm_split = w[12] == ':' ? atoll(w + 13) : 30000;
+    }
+    if (const char *v = getenv("PADNE_VERBOSE")) {
+        o->verbose_amg = has(v, "amg") != nullptr;
+        o->verbose_xw = has(v, "xw") != nullptr;
+        o->verbose_pool = has(v, "pool") != nullptr;
+    }
+}
 
 static thread_local char g_err[1024] = "";
 
@@ -55,7 +102,7 @@ void *pool_alloc(padne_ctx *ctx, size_t bytes) {
         return p;
     }
     void *p = nullptr;
-    static const bool trace = getenv("PADNE_POOL_TRACE") != nullptr;      // every miss of the cache (steady state: none)
+    const bool trace = ctx->opt.verbose_pool;      // every miss of the cache (steady state: none)
     if (trace) fprintf(stderr, "[pool] %s hipMalloc %zu bytes (cached %zu)\n", ctx->is_aux ? "aux" : "main", want, ctx->pool_cached_bytes);
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) {   // give cached blocks back to the driver and retry once
@@ -85,7 +132,7 @@ void pool_free(padne_ctx *ctx, void *p) {
         return;
     }
     if (ctx->pool_cached_bytes + it->second > kPoolCacheLimit) {
-        if (getenv("PADNE_POOL_TRACE") != nullptr) fprintf(stderr, "[pool] cache limit: hipFree %zu bytes\n", it->second);
+        if (ctx->opt.verbose_pool) fprintf(stderr, "[pool] cache limit: hipFree %zu bytes\n", it->second);
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipFree(p);
         ctx->pool_sizes.erase(it);
@@ -106,14 +153,7 @@ void pool_release_all(padne_ctx *ctx) {
 }
 
 static int ctx_init_resources(padne_ctx *ctx) {
-    int prio_least = 0, prio_greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    int prio = prio_least;
-    if (ctx->is_aux) {
-        const char *e = getenv("PADNE_AUX_PRIO");          // (experiment)
-        if (e != nullptr && e[0] == 'h') prio = prio_greatest;
-    }
-    if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio) != hipSuccess ||
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void **)&ctx->partials, sizeof(double) * 8 * kMaxPartials) != hipSuccess ||
         hipMalloc((void **)&ctx->scalars, sizeof(double) * 64) != hipSuccess ||
         hipMalloc((void **)&ctx->status, 1024) != hipSuccess ||
@@ -128,8 +168,7 @@ static int ctx_init_resources(padne_ctx *ctx) {
     hipMemsetAsync(ctx->status, 0, 1024, ctx->stream);
     hipStreamSynchronize(ctx->stream);
     // the mailbox is an optimisation: without host-coherent memory (or with PADNE_NO_MAILBOX=1) read_back copies and synchronises
-    if (getenv("PADNE_NO_MAILBOX") == nullptr &&
-        hipHostMalloc((void **)&ctx->mailbox, 4096, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess) {
+    if (hipHostMalloc((void **)&ctx->mailbox, 4096, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess) {
         if (hipHostGetDevicePointer((void **)&ctx->mailbox_dev, ctx->mailbox, 0) == hipSuccess) {
             memset(ctx->mailbox, 0, 4096);
         } else {
@@ -157,7 +196,7 @@ __global__ void mail_post_kernel(const unsigned char *__restrict__ src, int n_by
 
 MailTicket mail_ticket(padne_ctx *ctx) {
     MailTicket t;
-    if (ctx->mailbox_dev == nullptr) return t;
+    if (ctx->mailbox_dev == nullptr || ctx->opt.no_mailbox) return t;
     t.seq = ++ctx->mail_seq;
     const size_t off = (size_t)(t.seq & 31ull) * 8;       // 32 slots of 64 bytes; one request is in flight at a time
     t.slot_host = ctx->mailbox + off;
@@ -219,6 +258,7 @@ padne_ctx *aux_context(padne_ctx *ctx) {
     a->parent = ctx;
     a->rank = ctx->rank;
     a->world = ctx->world;
+    a->opt = ctx->opt;
     if (ctx_init_resources(a) != PADNE_OK) {
         padne_ctx_destroy(a);
         return nullptr;
@@ -292,6 +332,15 @@ __global__ void dot_partial_kernel(const long long n, const double *__restrict__
 
 using namespace padne;
 
+// (test header) the environment switches again, for a context that lives across a change of them
+extern "C" int padne_ctx_reload_options(padne_ctx *ctx) {
+    PADNE_REQUIRE(ctx, "ctx");
+    options_from_env(&ctx->opt);
+    ctx->p2p_timeout_ms = ctx->opt.p2p_timeout_ms;
+    if (ctx->aux != nullptr) ctx->aux->opt = ctx->opt;
+    return PADNE_OK;
+}
+
 extern "C" int padne_launch_count(long long *count) {
     PADNE_REQUIRE(count, "null argument");
     *count = g_launch_count.load(std::memory_order_relaxed);
@@ -326,6 +375,8 @@ int padne_ctx_create(int device, padne_ctx **out) {
     PADNE_HIP_CHECK(hipSetDevice(device));
     padne_ctx *ctx = new padne_ctx();
     ctx->device = device;
+    options_from_env(&ctx->opt);       // the PADNE_* switches are read here, once
+    ctx->p2p_timeout_ms = ctx->opt.p2p_timeout_ms;
     if (ctx_init_resources(ctx) != PADNE_OK) {
         padne_ctx_destroy(ctx);
         return PADNE_E_HIP;

@@ -251,35 +251,6 @@ int comm_allgather_f32(padne_ctx *ctx, const float *send, float *recv, int count
     return allgather_impl(ctx, send, recv, count_per_rank, false, ctx->stream);
 }
 
-// The halo all-gather of a communicator run on the context's SECOND stream, between two events: queued right behind the
-// pack kernel, it travels while the main stream computes the interior tiles of the product it is for; the main stream
-// waits for it (comm_allgather_side_join) in front of the boundary tiles.  Collectives of one communicator never overlap
-// each other this way: the next one on the main stream is queued behind the join.  false: not available (no
-// communicator, the team) or not asked for -- the caller gathers on the main stream as before.  OPT-IN
-// (PADNE_COMM_OVERLAP=1): collectives of one communicator on two streams have only been run with a one-rank communicator
-// here -- no box of this round had a second GPU -- and the default of a path the multi-GPU bench takes must be what has
-// run on several GPUs.
-bool comm_allgather_side(padne_ctx *ctx, const void *send, void *recv, int count_per_rank, bool f64, int *rc) {
-    *rc = PADNE_OK;
-    if (ctx->comm == nullptr || ctx->team != nullptr || ctx->is_aux || getenv("PADNE_COMM_OVERLAP") == nullptr) return false;
-    padne_ctx *aux = aux_context(ctx);
-    if (aux == nullptr) return false;
-    if ((*rc = stream_order(ctx, aux)) != PADNE_OK) return true;               // behind the pack kernel
-    if ((*rc = allgather_impl(ctx, send, recv, count_per_rank, f64, aux->stream)) != PADNE_OK) return true;
-    if (hipEventRecord(aux->ev_order, aux->stream) != hipSuccess) {
-        set_error("event record failed");
-        *rc = PADNE_E_HIP;
-    }
-    return true;
-}
-
-int comm_allgather_side_join(padne_ctx *ctx) {
-    padne_ctx *aux = ctx->aux;
-    PADNE_REQUIRE(aux != nullptr, "no side stream");
-    PADNE_HIP_CHECK(hipStreamWaitEvent(ctx->stream, aux->ev_order, 0));
-    return PADNE_OK;
-}
-
 // ---- peer-to-peer halo exchange ------------------------------------------------------------------------------------
 // In-process team: the ranks are contexts of one process on one device, so a peer's mailbox is an ordinary device
 // pointer, registered with the team; "the stores have landed" = every rank has drained its stream (host barrier).  One
@@ -293,7 +264,7 @@ int comm_allgather_side_join(padne_ctx *ctx) {
 // sender has completed its receive of e + 1 every rank has consumed e, and entry e % kP2pRing is rewritten at e + kP2pRing.
 // Tested with two PROCESSES on one GPU (tests/test_two_processes_gpu.py); between two GPUs the same stores cross xGMI.
 bool comm_p2p_enabled(const padne_ctx *ctx) {
-    return (ctx->team != nullptr || ctx->p2p_ipc) && getenv("PADNE_NO_P2P") == nullptr;
+    return (ctx->team != nullptr || ctx->p2p_ipc) && !ctx->opt.no_p2p;
 }
 
 // the in-process team regrows its rings on demand; mailboxes shared between processes have the size they were exported
@@ -302,14 +273,10 @@ bool comm_p2p_fits(const padne_ctx *ctx, int m) {
     return ctx->team != nullptr || (ctx->p2p_ipc && m <= ctx->p2p_m_cap);
 }
 
-// does a halo exchange of this context run beside what is queued between its two halves?  (peer-to-peer stores: the
-// arrival is all that is left for the second half; a communicator: only with the all-gather on the second stream.)  Where
-// it does not, splitting a product into interior and boundary tiles buys nothing and costs a launch: the split plans are
-// built only where this holds
-bool comm_exchange_overlaps(const padne_ctx *ctx) {
-    if (comm_p2p_enabled(ctx)) return true;
-    return ctx->comm != nullptr && ctx->team == nullptr && getenv("PADNE_COMM_OVERLAP") != nullptr;
-}
+// does a halo exchange of this context run beside what is queued between its two halves?  (Peer-to-peer stores: the arrival
+// is all that is left for the second half.)  Where it does not -- an all-gather on the same stream -- splitting a product
+// into interior and boundary tiles buys nothing and costs a launch: the split plans are built only where this holds
+bool comm_exchange_overlaps(const padne_ctx *ctx) { return comm_p2p_enabled(ctx); }
 
 void comm_p2p_release(padne_ctx *ctx) {
     for (void *p : ctx->p2p_ipc_mapped)
@@ -498,10 +465,7 @@ extern "C" int padne_ctx_p2p_export(padne_ctx *ctx, int32_t slots_per_rank, void
     memcpy(handle64, &h, 64);
     ctx->p2p_m_cap = slots_per_rank;
     ctx->p2p_seq = 0;
-    if (const char *t = getenv("PADNE_P2P_TIMEOUT_MS")) {
-        const long v = atol(t);
-        if (v > 0 && v <= 600000) ctx->p2p_timeout_ms = (unsigned)v;
-    }
+    ctx->p2p_timeout_ms = ctx->opt.p2p_timeout_ms;
     return PADNE_OK;
 }
 

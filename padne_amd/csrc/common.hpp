@@ -108,8 +108,37 @@ struct padne_csr {
     int64_t mesh_n_vert = 0, mesh_n_tri = 0, mesh_n_mesh = 0;
 };
 
+// The PADNE_* environment switches, read ONCE when a context is created (padne_ctx_reload_options of the test header reads
+// them again): what a context does never depends on a getenv in the middle of a call.  INTEGRATION.md lists them.
+struct padne_options {
+    // alternatives of the product path that tests compare against the default
+    bool amg_f64 = false;              // PADNE_AMG_F64=1: the multigrid cycle in double precision
+    int amg_w = 2;                     // PADNE_AMG_W=none|fine: fused up-leg operator W on no level / the fine level only (default: all)
+    bool amg_exchange_all = false;     // PADNE_AMG_EXCHANGE_ALL=1: the last partitioned level exchanges instead of computing from the tail
+    bool pcg_p64 = false;              // PADNE_PCG_P64=1: the search direction of the loop stays in double precision
+    bool gj_vector = false;            // PADNE_GJ_VECTOR=1: the dense inverse by the vector kernel (16 pivots per launch)
+    bool no_batch = false;             // PADNE_NO_BATCH=1: right-hand sides one at a time
+    bool no_mailbox = false;           // PADNE_NO_MAILBOX=1: host looks by copy + synchronise
+    bool no_p2p = false;               // PADNE_NO_P2P=1: halo exchanges as all-gathers
+    bool no_split = false;             // PADNE_NO_SPLIT=1: products behind an exchange in one launch
+    bool no_xwindow = false;           // PADNE_NO_XWINDOW=1: no x-window plans (SpMV and the setup kernels that use them)
+    int cg_single_reduction = -1;      // PADNE_CG_SINGLE_REDUCTION=0|1: force the loop form (default: by communicator)
+    int lockstep_narrow = -1;          // PADNE_LOCKSTEP_NARROW=0|2: never / always the narrow lockstep widths
+    // sizes
+    int amg_coarse_n = 2048;           // PADNE_AMG_COARSE_N: coarsest-level size the dense inverse takes
+    long long amg_gather_n = 0;        // PADNE_AMG_GATHER_N: level size below which a partitioned hierarchy is gathered (0: default)
+    unsigned p2p_timeout_ms = 20000;   // PADNE_P2P_TIMEOUT_MS
+    // PADNE_FORCE=<path>[,<path>...]: send everything through a path that the data takes only rarely (tests)
+    bool force_asm_hash = false, force_asm_two_pass = false, force_relabel_slots = false, force_transpose_cursors = false;
+    long long force_spgemm_split = 0;  // spgemm_split:<slots>
+    // PADNE_VERBOSE=amg,xw,pool: diagnostics on stderr
+    bool verbose_amg = false, verbose_xw = false, verbose_pool = false;
+};
+namespace padne { void options_from_env(padne_options *o); }
+
 struct padne_ctx {
     int device = 0;
+    padne_options opt;
     hipStream_t stream = nullptr;
     // reduction scratch
     double *partials = nullptr;      // [8][kMaxPartials]
@@ -283,8 +312,6 @@ int stream_order(padne_ctx *earlier, padne_ctx *later);
 int comm_allreduce_sum_f64(padne_ctx *ctx, double *dev_buf, int count);
 int comm_allgather_f64(padne_ctx *ctx, const double *send, double *recv, int count_per_rank);
 int comm_allgather_f32(padne_ctx *ctx, const float *send, float *recv, int count_per_rank);
-bool comm_allgather_side(padne_ctx *ctx, const void *send, void *recv, int count_per_rank, bool f64, int *rc);   // comm.hip
-int comm_allgather_side_join(padne_ctx *ctx);
 void comm_destroy(padne_ctx *ctx);
 void comm_abort(padne_ctx *ctx);   // a rank that leaves a collective phase with an error: wake the team / abort the communicator
 // Peer-to-peer halo exchange: instead of packing its exported values into its own segment and taking part in an
@@ -319,7 +346,6 @@ int halo_exchange_plan_f32(padne_ctx *ctx, const HaloPlan &plan, float *v, const
 // the same exchange in two halves (pcg.hip): what needs no remote value goes between them
 struct HaloTicket {
     bool p2p = false;
-    bool side = false;               // the all-gather is already under way on the second stream
     size_t entry_off = 0;
     unsigned long long seq1 = 0;     // mailboxes shared between processes: the exchange's sequence number + 1 (0: in-process team)
 };

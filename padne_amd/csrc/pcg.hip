@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void pcg_update_xr_kernel(
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const double pi = p[i];
         const double ri = r[i] - alpha * q[i];
-        x[i] += alpha * pi;
+        if (x != nullptr) x[i] += alpha * pi;      // (null: the Lanczos steps of the multigrid setup have no iterate)
         r[i] = ri;
         const double zi = dinv[i] * ri;
         s_rz += ri * zi;
@@ -459,7 +459,6 @@ __global__ void halo_unpack_kernel(T *__restrict__ v, long long n_owned, int m, 
 template <typename T>
 static int halo_send_t(padne_ctx *ctx, const HaloPlan &plan, T *v, const int32_t *done_flag, HaloTicket *tk) {
     tk->p2p = false;
-    tk->side = false;
     if (plan.m <= 0) return PADNE_OK;
     if (comm_p2p_enabled(ctx) && comm_p2p_fits(ctx, plan.m)) {
         void **peers = nullptr;
@@ -480,11 +479,7 @@ static int halo_send_t(padne_ctx *ctx, const HaloPlan &plan, T *v, const int32_t
                            plan.export_idx, plan.n_export, seg_off, done_flag);
         PADNE_HIP_CHECK(hipGetLastError());
     }
-    // with a communicator the all-gather starts NOW, on the second stream: what the caller queues before halo_recv (the
-    // interior tiles of the product) runs beside it
-    int rc = PADNE_OK;
-    tk->side = comm_allgather_side(ctx, v + seg_off, v + plan.n_owned, plan.m, sizeof(T) == 8, &rc);
-    return rc;
+    return PADNE_OK;      // (the all-gather itself is halo_recv's: same stream, nothing runs beside it)
 }
 
 static int allgather_t(padne_ctx *ctx, const double *send, double *recv, int count) { return comm_allgather_f64(ctx, send, recv, count); }
@@ -502,7 +497,6 @@ static int halo_recv_t(padne_ctx *ctx, const HaloPlan &plan, T *v, const int32_t
         PADNE_HIP_CHECK(hipGetLastError());
         return PADNE_OK;
     }
-    if (tk.side) return comm_allgather_side_join(ctx);
     const long long seg_off = plan.n_owned + (long long)ctx->rank * plan.m;
     return allgather_t(ctx, v + seg_off, v + plan.n_owned, plan.m);
 }
@@ -1423,16 +1417,38 @@ static int solve_batch(padne_ctx *ctx, const padne_csr *a, const double *b_cols,
 }
 
 // ---- largest eigenvalue of D^-1 A from the Lanczos coefficients of a few Jacobi-PCG steps ------------
-__global__ void fill_pseudo_random(long long n, double *__restrict__ v) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+// start of the Lanczos steps in one launch: r = b (pseudo-random, never stored), p = D^-1 r and their partial sums; the first
+// workgroup clears the history and the status words, the exchange area behind p is cleared (four memsets and two kernels
+// before)
+__global__ __launch_bounds__(256) void lanczos_init_kernel(const long long n, const double *__restrict__ dinv,
+                                                           double *__restrict__ r, double *__restrict__ p,
+                                                           const long long n_tail, double *__restrict__ hist, const int n_hist,
+                                                           PcgStatus *__restrict__ st, double *__restrict__ part_rz,
+                                                           double *__restrict__ part_rr, double *__restrict__ part_bb) {
+    __shared__ double red[4];
+    if (blockIdx.x == 0) {
+        for (int j = threadIdx.x; j < n_hist; j += 256) hist[j] = 0.0;
+        if (threadIdx.x < (int)(sizeof(PcgStatus) / sizeof(int))) ((int *)st)[threadIdx.x] = 0;
+    }
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_tail; i += (long long)gridDim.x * 256) p[n + i] = 0.0;
+    double rz = 0.0, rr = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         unsigned int h = (unsigned int)i * 2654435761u + 0x9e3779b9u;
         h ^= h >> 16;
         h *= 2246822519u;
         h ^= h >> 13;
         h *= 3266489917u;
         h ^= h >> 16;
-        v[i] = (double)h * (2.0 / 4294967296.0) - 1.0;
+        const double ri = (double)h * (2.0 / 4294967296.0) - 1.0;
+        const double zi = dinv[i] * ri;
+        r[i] = ri;
+        p[i] = zi;
+        rz += ri * zi;
+        rr += ri * ri;
     }
+    block_store_partial(rz, red, part_rz + blockIdx.x);
+    block_store_partial(rr, red, part_rr + blockIdx.x);
+    block_store_partial(rr, red, part_bb + blockIdx.x);
 }
 
 static double tridiag_max_eig(const std::vector<double> &d, const std::vector<double> &e) {
@@ -1501,14 +1517,12 @@ int lanczos_enqueue(padne_ctx *ctx, const padne_csr *a, int steps, LanczosJob *j
     if (job->hist == nullptr) return PADNE_E_NOMEM;
     double *hist = job->hist;
     double *H_rz = hist, *H_pq = hist + 2 * steps + 2;      // rz of step k at H_rz[2 k], its r.r right behind it
-    PADNE_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(double) * ((size_t)3 * steps + 4), s));
-    PADNE_HIP_CHECK(hipMemsetAsync(st, 0, sizeof(PcgStatus), s));
-    PADNE_HIP_CHECK(hipMemsetAsync(x, 0, sizeof(double) * (size_t)n, s));
-    if (nc > n) PADNE_HIP_CHECK(hipMemsetAsync(p + n, 0, sizeof(double) * (size_t)(nc - n), s));
-    hipLaunchKernelGGL(fill_pseudo_random, dim3(gv), dim3(256), 0, s, n, b);
-    hipLaunchKernelGGL(pcg_init_kernel, dim3(gv), dim3(256), 0, s, n, b, (const double *)nullptr, a->dinv, r, p,
-                       slot(ctx, SLOT_RZ0), slot(ctx, SLOT_RR), slot(ctx, SLOT_BB));
+    static_assert(sizeof(PcgStatus) % sizeof(int) == 0 && sizeof(PcgStatus) / sizeof(int) <= 256, "cleared by one workgroup");
+    hipLaunchKernelGGL(lanczos_init_kernel, dim3(gv), dim3(256), 0, s, n, (const double *)a->dinv, r, p, nc - n, hist,
+                       3 * steps + 4, st, slot(ctx, SLOT_RZ0), slot(ctx, SLOT_RR), slot(ctx, SLOT_BB));
     PADNE_HIP_CHECK(hipGetLastError());
+    (void)x;
+    (void)b;
     auto fold = [&](const double *first_slot, int P, double *out) -> int {
         hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(256), 0, s, first_slot, P, kMaxPartials, 1, out);
         PADNE_HIP_CHECK(hipGetLastError());
@@ -1529,8 +1543,8 @@ int lanczos_enqueue(padne_ctx *ctx, const padne_csr *a, int steps, LanczosJob *j
         // consumers read per-workgroup partials on one GPU and the reduced scalars across ranks
         const double *rz_old = dist ? H_rz + 2 * k : rz_old_part, *pq = dist ? H_pq + k : slot(ctx, SLOT_PQ);
         const int Pz = dist ? 1 : gv, Pq = dist ? 1 : gs;
-        hipLaunchKernelGGL(pcg_update_xr_kernel, dim3(gv), dim3(256), 0, s, n, rz_old, Pz, pq, Pq, p, q, a->dinv, x, r,
-                           rz_new_part, slot(ctx, SLOT_RR), st);
+        hipLaunchKernelGGL(pcg_update_xr_kernel, dim3(gv), dim3(256), 0, s, n, rz_old, Pz, pq, Pq, p, q, a->dinv,
+                           (double *)nullptr, r, rz_new_part, slot(ctx, SLOT_RR), st);
         PADNE_HIP_CHECK(hipGetLastError());
         if (dist) {
             // r.z and r.r of the step travel in ONE all-reduce (two per Lanczos step in all, three before)
@@ -1762,7 +1776,7 @@ static int solve_spd_dev_impl(padne_ctx *ctx, const padne_csr *a, const void *b_
     const long long n = ctx->halo_on ? ctx->halo_n_owned : a->n_rows;
     int k_first = 0;
     if (use_amg && !ctx->halo_on && !comm_active(ctx) && pm == a && amg_supports_batch8(a) &&
-        getenv("PADNE_NO_BATCH") == nullptr) {
+        !ctx->opt.no_batch) {
         // Groups of right-hand sides advance in lockstep (one pass over the operators per iteration for all of them); a
         // group whose cycle breaks down falls through to the one-at-a-time path below.  The kernels exist in widths 8, 4
         // and 2; MEASURED at N = 5 M (scripts/exp_lockstep_widths.py, profiles/r04_lockstep_widths.json) a lockstep solve
@@ -1807,8 +1821,7 @@ static int solve_spd_dev_impl(padne_ctx *ctx, const padne_csr *a, const void *b_
             *ok = true;
             return PADNE_OK;
         };
-        const char *narrow_env = getenv("PADNE_LOCKSTEP_NARROW");
-        const int narrow = narrow_env == nullptr ? 1 : atoi(narrow_env);
+        const int narrow = ctx->opt.lockstep_narrow < 0 ? 1 : ctx->opt.lockstep_narrow;
         bool ok = true;
         while (ok && n_rhs - k_first >= 2) {
             const int rest = n_rhs - k_first;
@@ -1825,9 +1838,8 @@ static int solve_spd_dev_impl(padne_ctx *ctx, const padne_csr *a, const void *b_
     }
     // row-partitioned multigrid runs use the single-reduction loop (one all-reduce per iteration); PADNE_CG_SINGLE_REDUCTION
     // = 1 / 0 forces it on (also on one GPU, for tests) or off
-    const char *sr_env = getenv("PADNE_CG_SINGLE_REDUCTION");
     const bool dist_run = comm_active(ctx);
-    const bool single_reduction = use_amg && (sr_env != nullptr ? atoi(sr_env) != 0 : dist_run);
+    const bool single_reduction = use_amg && (ctx->opt.cg_single_reduction >= 0 ? ctx->opt.cg_single_reduction != 0 : dist_run);
     for (int k = k_first; k < n_rhs; ++k) {
         const int status_before = local.status;
         if (single_reduction)

@@ -648,7 +648,7 @@ static int launch_spmv_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals,
 bool spmv_resid_pre_ok(const padne_csr *m) {
     const bool long_rows = m->xw_state != 1 && m->n_rows < 500000 && m->nnz > 8 * m->n_rows + 4 * (m->n_rows >> 3);
     return m->vals32 != nullptr && m->dinv32 != nullptr && !split_in_use(m) && !use_wave_per_row(m) && !long_rows &&
-           !(m->xw_state == 1 && m->xw_nruns == kXwRunsWide) && getenv("PADNE_AMG_RESID_XA") == nullptr;
+           !(m->xw_state == 1 && m->xw_nruns == kXwRunsWide);
 }
 int launch_spmv_f32_resid_pre(padne_ctx *ctx, const padne_csr *m, const float *b, float *resid, const int32_t *done_flag,
                               const float *dinv32, float c) {
@@ -661,7 +661,7 @@ int launch_spmv_f32_resid_pre(padne_ctx *ctx, const padne_csr *m, const float *b
 // double form).  false from spmv_x32_ok: the caller keeps p in double.
 bool spmv_x32_ok(const padne_csr *m) {
     return m->vals != nullptr && !split_in_use(m) && !use_wave_per_row(m) && !(m->xw_state == 1 && m->xw_nruns == kXwRunsWide) &&
-           getenv("PADNE_PCG_P64") == nullptr;
+           !(m->owner != nullptr && m->owner->opt.pcg_p64);
 }
 int launch_spmv_dot_x32(padne_ctx *ctx, const padne_csr *m, const float *x, double *y, double *partials, const int32_t *done_flag) {
     PADNE_REQUIRE(spmv_x32_ok(m), "single-precision search direction on this operator");
@@ -858,7 +858,7 @@ int csr_build_xw_plan(padne_ctx *ctx, padne_csr *m) {
     // problem do qualify with runs of 128 (96 % of the tiles of A_1 of config C4), the prolongators do not (five bands of
     // aggregates); measured, the plan of A_1 / A_2 costs 0.3-0.8 ms of setup and buys nothing per iteration (1030 us
     // either way: those passes are not gather-bound), so they keep the gather path.
-    if (m->n_rows < 65536 || m->hierarchy_operator || m->nnz > 64LL * m->n_rows || getenv("PADNE_NO_XWINDOW") != nullptr)
+    if (m->n_rows < 65536 || m->hierarchy_operator || m->nnz > 64LL * m->n_rows || ctx->opt.no_xwindow)
         return PADNE_OK;
     padne_ctx *owner = m->owner ? m->owner : ctx;
     const int n_tiles = (int)((m->n_rows + 63) / 64);
@@ -891,7 +891,7 @@ int csr_build_xw_plan(padne_ctx *ctx, padne_csr *m) {
         h_ok = h8[0] + h8[1] + h8[2] + h8[3] + h8[4] + h8[5] + h8[6] + h8[7];
     }
     pool_free(ctx, d_ok);
-    if (getenv("PADNE_XW_VERBOSE") != nullptr)
+    if (ctx->opt.verbose_xw)
         fprintf(stderr, "[spmv] x-window plan: %d of %d tiles qualify with runs of %d\n", h_ok, n_tiles, run);
     if (e != hipSuccess || 2LL * h_ok < n_tiles) {     // fewer than half of the tiles qualify: not worth the extra array
         pool_free(owner, desc);
@@ -992,8 +992,7 @@ __global__ __launch_bounds__(256) void xw_plan_wide_kernel(int n_rows, int n_wti
 
 int csr_build_xw_plan_wide(padne_ctx *ctx, padne_csr *m, int grid_cap) {
     static_assert(kXwRunsWide * kXwRunWide <= 256, "8-bit positions");
-    if (m->xw_state == 1 || m->n_rows < 65536 || m->vals32 == nullptr || getenv("PADNE_NO_XWINDOW") != nullptr ||
-        getenv("PADNE_NO_XWINDOW_WIDE") != nullptr)
+    if (m->xw_state == 1 || m->n_rows < 65536 || m->vals32 == nullptr || ctx->opt.no_xwindow)
         return PADNE_OK;
     padne_ctx *owner = m->owner ? m->owner : ctx;
     const int n_tiles = (int)((m->n_rows + 63) / 64);
@@ -1011,7 +1010,7 @@ int csr_build_xw_plan_wide(padne_ctx *ctx, padne_csr *m, int grid_cap) {
     hipLaunchKernelGGL(xw_plan_wide_kernel, dim3(g), dim3(256), 0, ctx->stream, (int)m->n_rows, n_tiles, m->rowptr, m->cols,
                        (int *)desc, (unsigned char *)lidx);
     PADNE_HIP_CHECK(hipGetLastError());
-    if (getenv("PADNE_XW_VERBOSE") != nullptr) {            // (diagnostics only: this look at the host stalls the stream)
+    if (ctx->opt.verbose_xw) {            // (diagnostics only: this look at the host stalls the stream)
         std::vector<int> h((size_t)n_tiles * kXwDescWide);
         PADNE_HIP_CHECK(hipMemcpyAsync(h.data(), desc, sizeof(int) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
         PADNE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1056,7 +1055,7 @@ int csr_build_split_plan(padne_ctx *ctx, padne_csr *m, long long n_owned) {
     if (m->split_state != 0) return PADNE_OK;
     m->split_state = -1;
     // (only where the exchange really runs beside the interior tiles: otherwise the second launch is pure overhead)
-    if (m->n_cols <= n_owned || m->n_rows < 64 * 64 || getenv("PADNE_NO_SPLIT") != nullptr || !comm_exchange_overlaps(ctx))
+    if (m->n_cols <= n_owned || m->n_rows < 64 * 64 || ctx->opt.no_split || !comm_exchange_overlaps(ctx))
         return PADNE_OK;
     padne_ctx *owner = m->owner ? m->owner : ctx;
     const int n_tiles = (int)((m->n_rows + 63) / 64);

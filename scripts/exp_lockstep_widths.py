@@ -32,13 +32,13 @@ for n_rhs in (2, 3, 4, 8):
     b = ctx.to_device(B[:n_rhs].copy()); x = ctx.empty((n_rhs, nv - 1))
     rec = {}
     for label, env in (("lockstep", None), ("one_at_a_time", "1")):
-        if env: os.environ["PADNE_NO_BATCH"] = env
+        if env: os.environ["PADNE_NO_BATCH"] = env; ctx.reload_options()
         A.solve_spd_dev(b, x, n_rhs=n_rhs, precond="amg")
         best = None
         for _ in range(3):
             r = A.solve_spd_dev(b, x, n_rhs=n_rhs, precond="amg")
             if best is None or r.seconds < best.seconds: best = r
-        os.environ.pop("PADNE_NO_BATCH", None)
+        os.environ.pop("PADNE_NO_BATCH", None); ctx.reload_options()
         rec[label] = {"solve_ms": best.seconds * 1e3, "iterations_total": int(best.iterations), "in_single_solves": best.seconds / single}
         sol = x.numpy().copy()
         if label == "lockstep": ref = sol

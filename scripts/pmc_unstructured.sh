@@ -3,7 +3,7 @@
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in SEPARATE passes (counter traffic of the f64 product per launch, x2 on the
 # fetches as everywhere on gfx950).  usage (GPU box, repo root):  bash scripts/pmc_unstructured.sh gpurun_out/r04_unstructured [side]
 OUT="$GRAFT_REPO_ROOT/$1"; SIDE=${2:-1620}; mkdir -p "$OUT"; export TMPDIR=/tmp; cd /tmp
-PADNE_XW_VERBOSE=1 timeout -k 10 900 python3 $GRAFT_REPO_ROOT/scripts/unstructured_roofline.py --side $SIDE > "$OUT/run.log" 2> "$OUT/run.err" || { tail -5 "$OUT/run.err"; exit 1; }
+PADNE_VERBOSE=xw timeout -k 10 900 python3 $GRAFT_REPO_ROOT/scripts/unstructured_roofline.py --side $SIDE > "$OUT/run.log" 2> "$OUT/run.err" || { tail -5 "$OUT/run.err"; exit 1; }
 echo "timing run done"
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 600 rocprofv3 --pmc $C --output-format csv -d "$OUT/$C" -o run -- python3 $GRAFT_REPO_ROOT/scripts/unstructured_roofline.py --side $SIDE --spmv-only > "$OUT/$C.log" 2>&1 || exit 2

@@ -43,9 +43,9 @@ for name in ["C2", "C3", "C4", "C5"]:
         xs8 = ctx.to_device(np.random.default_rng(2).uniform(-1, 1, A.shape[1] * 8)); ys8 = ctx.empty(A.shape[0] * 8)
         t8 = min(A.spmm8_time(xs8, ys8, 5, 30) for _ in range(3))
         rec.update({"spmm8_us": t8 * 1e6, "spmm8_gbs_algorithmic": A.spmm8_bytes / t8 / 1e9, "spmm8_vs_8_spmv": 8 * t_spmv / t8})
-        os.environ["PADNE_NO_BATCH"] = "1"
+        os.environ["PADNE_NO_BATCH"] = "1"; ctx.reload_options()
         t = time.perf_counter(); r1 = A.solve_spd_dev(b, x, n_rhs=8, precond="amg", rebuild=True); w1 = time.perf_counter() - t
-        del os.environ["PADNE_NO_BATCH"]
+        del os.environ["PADNE_NO_BATCH"]; ctx.reload_options()
         rec.update({"one_at_a_time": {"iterations_total": r1.iterations, "solve_ms_all_rhs": r1.seconds * 1e3, "wall_ms": w1 * 1e3},
                     "batched_vs_one_at_a_time_max_rel_diff": float(np.abs(xb - x.numpy()).max() / np.abs(xb).max())})
         del xs8, ys8

@@ -89,7 +89,7 @@ def measure(plan, label):
     nr, nnz = A.shape[0], A.nnz
     x = ctx.to_device(np.random.default_rng(1).uniform(-1, 1, A.shape[1]))
     y = ctx.empty(nr)
-    t = A.spmv_time(x, y, 5, args.launches)                      # (the first launch builds the x-window plan: PADNE_XW_VERBOSE reports it)
+    t = A.spmv_time(x, y, 5, args.launches)                      # (the first launch builds the x-window plan: PADNE_VERBOSE=xw reports it)
     rec = {"rows": nr, "nnz": nnz, "nnz_per_row": nnz / nr, "spmv_bytes_algorithmic": A.spmv_bytes,
            "spmv_us_standalone": t * 1e6, "spmv_gbs_standalone": A.spmv_bytes / t / 1e9,
            "spmv_frac_of_8TBs_standalone": A.spmv_bytes / t / 1e9 / 8000.0}

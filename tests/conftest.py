@@ -80,3 +80,22 @@ def ctx():
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture
+def switches(monkeypatch):
+    """The PADNE_* environment switches of the library, which reads them ONCE per context (at creation): set / unset one and
+    every live context reads them again; on the way out the environment is restored and read once more."""
+    from padne_amd import _hip
+
+    class Switches:
+        def set(self, name, value="1"):
+            monkeypatch.setenv(name, str(value))
+            _hip.reload_options_everywhere()
+
+        def unset(self, name):
+            monkeypatch.delenv(name, raising=False)
+            _hip.reload_options_everywhere()
+    yield Switches()
+    monkeypatch.undo()
+    _hip.reload_options_everywhere()

@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     test_names = declared_symbols("padne_hip_test.h")
     # (+ one introspection call the multi-rank tests use to see that the product split is really in use)
     assert test_names and all(n.startswith(("padne_team_", "padne_ctx_join_team", "padne_csr_split_tiles", "padne_ctx_lockstep_groups",
-                                                   "padne_asm_second_path_count", "padne_ctx_halo_exchange_time")) for n in test_names)
+                                                   "padne_asm_second_path_count", "padne_ctx_halo_exchange_time", "padne_ctx_reload_options")) for n in test_names)
     assert not set(test_names) & set(names)
     for name in test_names:
         assert hasattr(lib, name) and name in _hip.TEST_SIGNATURES

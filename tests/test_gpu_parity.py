@@ -431,7 +431,7 @@ def test_multigrid_hierarchy_is_galerkin_and_partition_of_unity(ctx):
         assert P.shape[1] < 0.5 * P.shape[0]
 
 
-def test_mailbox_round_trips_change_nothing_but_the_waiting(ctx, monkeypatch):
+def test_mailbox_round_trips_change_nothing_but_the_waiting(ctx, switches):
     """Counts and flags of the setup reach the host through a host-coherent page the device posts into (read_back,
     mail_ticket in capi.hip) instead of memcpy + synchronise.  A context created with PADNE_NO_MAILBOX=1 takes the old
     route: same hierarchy decisions, so the same iterations and bit-identical potentials -- also for the assembly and the
@@ -451,7 +451,7 @@ def test_mailbox_round_trips_change_nothing_but_the_waiting(ctx, monkeypatch):
         d.close()
         return res
     with_mail = run(ctx)
-    monkeypatch.setenv("PADNE_NO_MAILBOX", "1")
+    switches.set("PADNE_NO_MAILBOX", "1")
     other = _hip.Context(0)
     try:
         without = run(other)
@@ -462,66 +462,18 @@ def test_mailbox_round_trips_change_nothing_but_the_waiting(ctx, monkeypatch):
     assert np.linalg.norm(A @ with_mail.x - b) <= 1e-11 * np.linalg.norm(b)
 
 
-@pytest.mark.parametrize("layers,nx,ny,coarse_n", [(2, 180, 150, None), (2, 180, 150, 200), (8, 240, 200, None), (3, 90, 70, 40)])
-def test_two_pivot_blocks_per_launch_of_the_dense_inverse_are_the_same_bits(ctx, monkeypatch, layers, nx, ny, coarse_n):
-    """The coarsest operator is inverted by a blocked Gauss-Jordan without pivoting: 16 pivots per launch (`gj_block_step`),
-    or 32 -- two steps fused in one launch (`gj_block_step2`: what the second step reads of other tiles as the first leaves
-    it is recomputed from the old matrix), with the two 16 x 16 inversions of a fused step done once, by an extra workgroup
-    of the launch BEFORE it (`gj_block_step2<true>`; PADNE_GJ_NO_LOOKAHEAD=1: by every workgroup itself).  Every entry goes
-    through the same operations in the same order: the double-precision cycle built on any of the three inverses applies
-    to a random vector with the same bits, for coarsest levels of a handful to ~1100 unknowns (odd and even numbers of
-    pivot blocks, a last block of fewer than 16 pivots)."""
-    monkeypatch.setenv("PADNE_AMG_F64", "1")
-    monkeypatch.setenv("PADNE_GJ_VECTOR", "1")      # (the default form runs on the matrix cores: its own test below)
-    if coarse_n is not None:
-        monkeypatch.setenv("PADNE_AMG_COARSE_N", str(coarse_n))
-    sysm = synthetic.layered_system(layers, nx, ny, via_lattice=5)
-    els = [("R", int(a), int(b), float(r)) for a, b, r in zip(*sysm.resistors)]
-    els += [("I", int(f), int(t), float(i)) for f, t, i in zip(*sysm.current_sources)]
-    Lo, ro = O.assemble_system([(m[0], m[1], m[2]) for m in sysm.meshes], 0, els, 0)
-    n = sysm.n_vertices
-    A = (-Lo[1:n, 1:n]).tocsr()
-    A.sort_indices()
-    b = -ro[1:n]
-    probe = np.random.default_rng(7).uniform(-1, 1, n - 1)
-
-    def run(c):
-        d = c.csr_from_scipy(A)
-        res = d.solve_spd(b, precond="amg", rtol=1e-12)
-        n_coarse = d.amg_shapes()[-1]["A"][0]
-        z = d.amg_apply(probe)
-        d.close()
-        return res, n_coarse, z
-    other = _hip.Context(0)
-    try:
-        two, n_two, z_two = run(other)
-    finally:
-        other.close()
-    for switch in ("PADNE_GJ_NO_LOOKAHEAD", "PADNE_GJ_ONE_STEP"):
-        monkeypatch.setenv(switch, "1")
-        other = _hip.Context(0)
-        try:
-            one, n_one, z_one = run(other)
-        finally:
-            other.close()
-        assert n_one == n_two and n_one <= 2048, n_one
-        assert one.levels == two.levels and one.iterations == two.iterations
-        assert np.array_equal(z_one, z_two) and np.array_equal(one.x, two.x), f"{switch}: coarsest level of {n_one} unknowns"
-    assert np.linalg.norm(A @ two.x - b) <= 1e-11 * np.linalg.norm(b)
-
-
 @pytest.mark.parametrize("layers,nx,ny,coarse_n", [(2, 180, 150, None), (2, 180, 150, 200), (8, 240, 200, None), (3, 90, 70, 400),
                                                   (8, 400, 330, None)])
-def test_dense_inverse_on_the_matrix_cores_against_the_vector_kernels(monkeypatch, layers, nx, ny, coarse_n):
+def test_dense_inverse_on_the_matrix_cores_against_the_vector_kernels(switches, layers, nx, ny, coarse_n):
     """Default form of the coarsest-level inverse: 64 pivots per launch, the rank-64 updates as v_mfma_f64_16x16x4_f64 products
     (`gj64_step`), the next pivot block inverted by workgroup 0 of the launch before.  Against the vector kernels
     (PADNE_GJ_VECTOR=1): the sums are formed in another order, so the double-precision cycle built on either inverse agrees to
     rounding times the conditioning of the coarsest operator -- not bit for bit --, the solves take the same iterations and give
     the same potentials; coarsest levels from 65 unknowns (below that the vector kernels run anyway) to ~1900, sizes that are
     and are not multiples of 64 and of the 96 x 32 tile."""
-    monkeypatch.setenv("PADNE_AMG_F64", "1")
+    switches.set("PADNE_AMG_F64", "1")
     if coarse_n is not None:
-        monkeypatch.setenv("PADNE_AMG_COARSE_N", str(coarse_n))
+        switches.set("PADNE_AMG_COARSE_N", str(coarse_n))
     sysm = synthetic.layered_system(layers, nx, ny, via_lattice=5)
     els = [("R", int(a), int(b), float(r)) for a, b, r in zip(*sysm.resistors)]
     els += [("I", int(f), int(t), float(i)) for f, t, i in zip(*sysm.current_sources)]
@@ -544,7 +496,7 @@ def test_dense_inverse_on_the_matrix_cores_against_the_vector_kernels(monkeypatc
             c.close()
         return res, n_coarse, z
     cores, n_cores, z_cores = run()
-    monkeypatch.setenv("PADNE_GJ_VECTOR", "1")
+    switches.set("PADNE_GJ_VECTOR", "1")
     vec, n_vec, z_vec = run()
     assert n_cores == n_vec and 64 < n_vec <= 2048, n_vec
     assert cores.levels == vec.levels and abs(cores.iterations - vec.iterations) <= 1
@@ -554,11 +506,11 @@ def test_dense_inverse_on_the_matrix_cores_against_the_vector_kernels(monkeypatc
     assert np.linalg.norm(A @ cores.x - b) <= 1e-11 * np.linalg.norm(b)
 
 
-def test_fused_up_leg_of_the_fine_level_is_the_same_cycle(ctx, monkeypatch):
+def test_fused_up_leg_of_the_fine_level_is_the_same_cycle(ctx, switches):
     """Level 0 of the float cycle applies coarse correction, post-smoothing sweep and the exit product of r.z in ONE
     sparse product with W = P - c D^-1 A P (built from the merge slots of A P on the second stream).  Algebraically the
     same V(1,1) cycle as prolongation + damped Jacobi: same iteration count (one either way for float rounding), same
-    potentials to the solve tolerance, against PADNE_AMG_NO_W=1 on the same matrix."""
+    potentials to the solve tolerance, against PADNE_AMG_W=none on the same matrix."""
     sysm = synthetic.layered_system(3, 260, 200, via_lattice=5)
     els = [("R", int(a), int(b), float(r)) for a, b, r in zip(*sysm.resistors)]
     els += [("I", int(f), int(t), float(i)) for f, t, i in zip(*sysm.current_sources)]
@@ -575,7 +527,7 @@ def test_fused_up_leg_of_the_fine_level_is_the_same_cycle(ctx, monkeypatch):
         d.close()
         return res
     with_w = run()
-    monkeypatch.setenv("PADNE_AMG_NO_W", "1")
+    switches.set("PADNE_AMG_W", "none")
     without = run()
     assert with_w.precond_fallbacks == 0 and without.precond_fallbacks == 0
     assert with_w.levels == without.levels >= 3
@@ -586,9 +538,9 @@ def test_fused_up_leg_of_the_fine_level_is_the_same_cycle(ctx, monkeypatch):
         assert np.linalg.norm(A @ res.x - b) <= 1e-11 * np.linalg.norm(b)
 
 
-def test_fused_up_leg_of_the_inner_levels_is_the_same_cycle(ctx, monkeypatch):
+def test_fused_up_leg_of_the_inner_levels_is_the_same_cycle(ctx, switches):
     """The inner levels take the same W form of the up-leg (built at the end of the setup, when the Lanczos estimate has
-    settled the level's damping): against PADNE_AMG_W_FINE_ONLY=1 (W on the fine level only) one cycle applied to a probe
+    settled the level's damping): against PADNE_AMG_W=fine (W on the fine level only) one cycle applied to a probe
     agrees to float rounding, the single solve and the lockstep solve of four and eight right-hand sides take the same
     iterations (one either way) and give the same potentials to the solve tolerance."""
     sysm = synthetic.layered_system(3, 260, 200, via_lattice=5)
@@ -612,7 +564,7 @@ def test_fused_up_leg_of_the_inner_levels_is_the_same_cycle(ctx, monkeypatch):
         d.close()
         return one, z, four, eight
     inner = run()
-    monkeypatch.setenv("PADNE_AMG_W_FINE_ONLY", "1")
+    switches.set("PADNE_AMG_W", "fine")
     fine_only = run()
     assert inner[0].levels == fine_only[0].levels >= 4      # at least two inner levels carry a W
     assert np.abs(inner[1] - fine_only[1]).max() <= 2e-5 * np.abs(fine_only[1]).max()
@@ -627,11 +579,11 @@ def test_fused_up_leg_of_the_inner_levels_is_the_same_cycle(ctx, monkeypatch):
 
 
 @pytest.mark.parametrize("hub", [False, True])
-def test_windowed_setup_kernels_build_the_same_hierarchy(ctx, monkeypatch, hub):
+def test_windowed_setup_kernels_build_the_same_hierarchy(ctx, switches, hub):
     """A fine level with an x-window plan (>= 65536 rows, band matrix) takes the windowed setup kernels: one-byte
     neighbour positions in the independent-set rounds, the decision fused into the second pass, prolongator rows merged
     in registers and written straight into CSR, A P consumed from its merge slots.  Same operations in the same order as
-    the general kernels: every operator of the hierarchy is BIT-IDENTICAL to the one PADNE_AMG_NO_XW=1 builds -- with
+    the general kernels: every operator of the hierarchy is BIT-IDENTICAL to the one PADNE_NO_XWINDOW=1 builds -- with
     tiles that have no plan (via rows) inside the same launches, and (hub) with a row of more than 13 entries, which
     sends the prolongator of the whole level back to the general kernel."""
     sysm = synthetic.layered_system(2, 300, 240, via_lattice=6)
@@ -652,9 +604,9 @@ def test_windowed_setup_kernels_build_the_same_hierarchy(ctx, monkeypatch, hub):
         ops = [(d.amg_level(l, "A"), d.amg_level(l, "P"), d.amg_level(l, "R")) for l in range(res.levels - 1)]
         d.close()
         return res, ops
-    monkeypatch.setenv("PADNE_XW_VERBOSE", "1")
+    switches.set("PADNE_VERBOSE", "xw")
     res_w, ops_w = hierarchy()
-    monkeypatch.setenv("PADNE_AMG_NO_XW", "1")
+    switches.set("PADNE_NO_XWINDOW", "1")
     res_g, ops_g = hierarchy()
     assert res_w.levels == res_g.levels >= 3 and res_w.iterations == res_g.iterations
     assert np.array_equal(res_w.x, res_g.x)
@@ -670,11 +622,11 @@ def test_windowed_setup_kernels_build_the_same_hierarchy(ctx, monkeypatch, hub):
 
 
 @pytest.mark.parametrize("precision", ["f32", "f64"])
-def test_multigrid_preconditioner_is_symmetric_positive_definite(ctx, monkeypatch, precision):
+def test_multigrid_preconditioner_is_symmetric_positive_definite(ctx, switches, precision):
     """The cycle runs on single-precision copies of its operators by default (PADNE_AMG_F64=1: double): a fixed
     linear SPD operator up to the rounding of the working precision."""
     if precision == "f64":
-        monkeypatch.setenv("PADNE_AMG_F64", "1")
+        switches.set("PADNE_AMG_F64", "1")
     tol = 1e-10 if precision == "f64" else 2e-5
     A, b, _, _, _ = layered_spd(2, 70, 60, 4)
     d = ctx.csr_from_scipy(A)
@@ -689,12 +641,12 @@ def test_multigrid_preconditioner_is_symmetric_positive_definite(ctx, monkeypatc
     assert np.array_equal(d.amg_apply(r1), z1)                          # deterministic
     # both precisions precondition the same operator: M32 r = M64 r to single-precision rounding
     if precision == "f32":
-        monkeypatch.setenv("PADNE_AMG_F64", "1")
+        switches.set("PADNE_AMG_F64", "1")
         d64 = ctx.csr_from_scipy(A)
         assert np.abs(d64.amg_apply(r1) - z1).max() <= 2e-5 * np.abs(z1).max()
 
 
-def test_search_direction_stored_in_single_precision_solves_the_same_system(monkeypatch):
+def test_search_direction_stored_in_single_precision_solves_the_same_system(switches):
     """On one GPU the multigrid-preconditioned loop keeps its search direction as p / ||b|| in single precision
     (`csr_spmv_kernel<SPMV_DOT, double, double, double, ..., float>` multiplies it in double; x += alpha p and r -= alpha A p
     use the very same stored vector, so b - A x is tracked to double rounding).  Against PADNE_PCG_P64=1 (p in double): the
@@ -713,9 +665,9 @@ def test_search_direction_stored_in_single_precision_solves_the_same_system(monk
         return out
     for A, b, _, _, _ in cases:
         f32 = run(A, b)
-        monkeypatch.setenv("PADNE_PCG_P64", "1")
+        switches.set("PADNE_PCG_P64", "1")
         f64 = run(A, b)
-        monkeypatch.delenv("PADNE_PCG_P64")
+        switches.unset("PADNE_PCG_P64")
         for a, c, s in zip(f32, f64, (1.0, 1e-30, 1e30)):
             assert a.precond_fallbacks == 0 and c.precond_fallbacks == 0
             assert abs(a.iterations - c.iterations) <= 1, (a.iterations, c.iterations)
@@ -724,7 +676,7 @@ def test_search_direction_stored_in_single_precision_solves_the_same_system(monk
         assert not np.array_equal(f32[0].x, f64[0].x), "the switch changed nothing"
 
 
-def test_warm_start_whose_residual_lies_thirty_orders_below_the_right_hand_side(monkeypatch):
+def test_warm_start_whose_residual_lies_thirty_orders_below_the_right_hand_side(switches):
     """The single-precision vectors of the loop (cycle input, z, the stored search direction) are kept in units of ||b||;
     from an initial guess whose residual is 1e-30 ||b|| they would be denormals or zero (p.q = 0: a breakdown where the
     double loop iterated).  The unit of a warm start is therefore ||r_0||.  Two islands: the guess solves the first one
@@ -740,7 +692,7 @@ def test_warm_start_whose_residual_lies_thirty_orders_below_the_right_hand_side(
     delta = 1e-30 * b1 / np.abs(b1).max()
     for p64 in (False, True):
         if p64:
-            monkeypatch.setenv("PADNE_PCG_P64", "1")
+            switches.set("PADNE_PCG_P64", "1")
         c = _hip.Context(0)
         try:
             d = c.csr_from_scipy(A)
@@ -756,38 +708,6 @@ def test_warm_start_whose_residual_lies_thirty_orders_below_the_right_hand_side(
             c.close()
 
 
-def test_fine_level_of_the_cycle_formed_from_its_right_hand_side_alone(monkeypatch):
-    """The fine level of the float cycle never stores its pre-smoothed iterate x = c D^-1 b: the residual product stages
-    c * dinv .* b instead of x (`SPMV_RESID_PRE`), the up-leg takes c D^-1 (b + residual) + W e and r.z against b.  Against
-    PADNE_AMG_RESID_XA=1 (iterate stored and read, r.z against the double residual): the cycle applied to a probe agrees to
-    float rounding, single and lockstep solves take the same iterations (one either way) and give the same potentials -- on
-    a system with an x-window plan, on one without, and through a one-rank halo plan with the hierarchy on the owned block
-    (the path where CG keeps z in double)."""
-    for A, b, _, _, _ in (layered_spd(2, 70, 60, 4), layered_spd(3, 260, 200, 5)):
-        probe = np.random.default_rng(3).uniform(-1, 1, A.shape[0])
-
-        def run():
-            c = _hip.Context(0)
-            try:
-                d = c.csr_from_scipy(A)
-                one = d.solve_spd(b, precond="amg", rtol=1e-12)
-                z = d.amg_apply(probe)
-                four = d.solve_spd(np.stack([b, 2.0 * b, -b, 0.5 * b]), precond="amg", rtol=1e-12)
-                d.close()
-            finally:
-                c.close()
-            return one, z, four
-        new = run()
-        monkeypatch.setenv("PADNE_AMG_RESID_XA", "1")
-        old = run()
-        monkeypatch.delenv("PADNE_AMG_RESID_XA")
-        assert abs(new[0].iterations - old[0].iterations) <= 1 and abs(new[2].iterations - old[2].iterations) <= 4
-        assert np.abs(new[1] - old[1]).max() <= 2e-5 * np.abs(old[1]).max()
-        assert np.abs(new[0].x - old[0].x).max() <= 1e-9 * np.abs(old[0].x).max()
-        assert np.abs(new[2].x - old[2].x).max() <= 1e-9 * np.abs(old[2].x).max()
-        assert np.linalg.norm(A @ new[0].x - b) <= 2e-12 * np.linalg.norm(b)
-
-
 def test_single_precision_cycle_is_independent_of_the_units_of_the_system(ctx):
     """The cycle input is normalised by ||b||, so right-hand sides of 1e-30 A or 1e+30 A converge like 1 A ones."""
     A, b, _, _, _ = layered_spd(2, 70, 60, 4)
@@ -799,13 +719,13 @@ def test_single_precision_cycle_is_independent_of_the_units_of_the_system(ctx):
         assert np.abs(res.x / scale - base.x).max() <= 1e-9 * np.abs(base.x).max()
 
 
-def test_sparse_products_of_the_setup_split_their_rows_when_the_slots_exceed_the_index_space(ctx, monkeypatch):
+def test_sparse_products_of_the_setup_split_their_rows_when_the_slots_exceed_the_index_space(ctx, switches):
     """A*P of a 130 M-row Laplacian has more product slots than 32-bit offsets address: the product is then formed in
-    row halves and stacked.  PADNE_SPGEMM_SPLIT_SLOTS lowers the limit so that a small system takes that path (several
+    row halves and stacked.  PADNE_FORCE=spgemm_split:<slots> lowers the limit so that a small system takes that path (several
     levels of recursion); hierarchy and solution must not change."""
     A, b, _, _, _ = layered_spd(2, 90, 80, 4)
     base = ctx.csr_from_scipy(A).solve_spd(b, precond="amg")
-    monkeypatch.setenv("PADNE_SPGEMM_SPLIT_SLOTS", "30000")
+    switches.set("PADNE_FORCE", "spgemm_split:30000")
     d = ctx.csr_from_scipy(A)
     res = d.solve_spd(b, precond="amg")
     assert res.levels == base.levels and res.levels >= 2 and res.precond_fallbacks == 0
@@ -814,15 +734,15 @@ def test_sparse_products_of_the_setup_split_their_rows_when_the_slots_exceed_the
     assert np.abs(res.x - base.x).max() <= 1e-9 * np.abs(base.x).max()
 
 
-def test_transposes_of_the_setup_through_cursors_and_the_sort(ctx, monkeypatch):
+def test_transposes_of_the_setup_through_cursors_and_the_sort(ctx, switches):
     """The transposition of a prolongator places every entry in the order of its row (per column the list of the 64-row
     waves that hold it, inside a wave a mask of the rows in a hash table of the columns met): the rows of the restriction
     come out in column order.  Columns met by more waves than a list holds, and the rows of a wave with more entries than
-    its table takes, go through a cursor per column and are sorted afterwards.  PADNE_TRANSPOSE_CURSORS sends every wave
+    its table takes, go through a cursor per column and are sorted afterwards.  PADNE_FORCE=transpose_cursors sends every wave
     that way: the restriction operators -- and with them the hierarchy and the solve -- must be the same bit for bit."""
     A, b, _, _, _ = layered_spd(3, 150, 110, 5)
     base = ctx.csr_from_scipy(A).solve_spd(b, precond="amg")
-    monkeypatch.setenv("PADNE_TRANSPOSE_CURSORS", "1")
+    switches.set("PADNE_FORCE", "transpose_cursors")
     res = ctx.csr_from_scipy(A).solve_spd(b, precond="amg")
     assert res.levels == base.levels and res.levels >= 3 and res.precond_fallbacks == 0
     assert res.operator_complexity == base.operator_complexity and res.iterations == base.iterations
@@ -1154,14 +1074,10 @@ def test_coaxial_structure_end_to_end(ctx):
 
 # ---- multi-GPU code path on one GPU ---------------------------------------------------------------
 
-@pytest.mark.parametrize("side_stream", [False, True])
-def test_halo_and_rccl_path_with_one_rank_communicator(monkeypatch, side_stream):
+def test_halo_and_rccl_path_with_one_rank_communicator():
     """Exercises pack -> ncclAllGather -> SpMV on exchange columns -> fold -> ncclAllReduce with a
     1-rank RCCL communicator: off-diagonal couplings to a subset of unknowns are re-routed through
-    the exchange area, which must not change the solution.  ``side_stream``: the all-gather queued on the context's second
-    stream between two events (PADNE_COMM_OVERLAP=1), beside whatever the main stream computes in between."""
-    if side_stream:
-        monkeypatch.setenv("PADNE_COMM_OVERLAP", "1")
+    the exchange area, which must not change the solution."""
     xy, tri = synthetic.jittered_grid(70, 50, seed=6)
     A = (-2082.5 * O.laplace_operator(xy, tri).tocsr()[1:, 1:]).tocsr()
     n = A.shape[0]
@@ -1419,7 +1335,7 @@ def test_regulator_star_and_multi_island_problem_end_to_end(ctx):
     L.dev.close()
 
 
-def test_five_regulators_advance_in_lockstep_and_match_the_direct_solve(ctx, monkeypatch):
+def test_five_regulators_advance_in_lockstep_and_match_the_direct_solve(ctx, switches):
     """K regulators add K right-hand sides to a solve (the gain columns, `solver.py:512-538`).  With K + 1 >= 5 they advance
     in lockstep through the batched cycle (a group of up to eight, zero-padded), one pass over the matrix and the hierarchy
     per iteration for all of them; fewer are solved one after the other (a lockstep iteration costs about 2.4 single
@@ -1458,7 +1374,7 @@ def test_five_regulators_advance_in_lockstep_and_match_the_direct_solve(ctx, mon
     assert np.abs(v[:n_pot] - v_ref[:n_pot]).max() <= REL_TOL * np.abs(v_ref[:n_pot]).max()
     assert np.abs(v[n_pot:] - v_ref[n_pot:]).max() <= 1e-7 * np.abs(v_ref[n_pot:]).max()
     assert info.residual_norm < 1e-9
-    monkeypatch.setenv("PADNE_NO_BATCH", "1")
+    switches.set("PADNE_NO_BATCH", "1")
     v1, info1 = solver.solve_system(Lo, ro)
     assert ctx.lockstep_groups() == groups_before + 1      # ... and one at a time with the batched path switched off
     assert np.abs(v1[:n_pot] - v_ref[:n_pot]).max() <= REL_TOL * np.abs(v_ref[:n_pot]).max()
@@ -1466,7 +1382,7 @@ def test_five_regulators_advance_in_lockstep_and_match_the_direct_solve(ctx, mon
 
 
 @pytest.mark.parametrize("n_reg", [1, 2, 3])
-def test_one_to_three_regulators_in_the_narrow_lockstep_widths(ctx, monkeypatch, n_reg):
+def test_one_to_three_regulators_in_the_narrow_lockstep_widths(ctx, switches, n_reg):
     """One to three regulators are two to four right-hand sides (`solver.py:512-538`).  The lockstep kernels exist in
     widths 2 and 4 as well as 8; measured, only exactly four right-hand sides gain from them (3.3
     against 4.0 single solves; two cost 2.3 against 2.0 -- profiles/r04_lockstep_widths.json), so that is what the default
@@ -1499,12 +1415,12 @@ def test_one_to_three_regulators_in_the_narrow_lockstep_widths(ctx, monkeypatch,
     v, info = solver.solve_system(Lo, ro)
     check(v, info)
     assert ctx.lockstep_groups() == before + (1 if n_reg == 3 else 0)
-    monkeypatch.setenv("PADNE_LOCKSTEP_NARROW", "2")
+    switches.set("PADNE_LOCKSTEP_NARROW", "2")
     before = ctx.lockstep_groups()
     v2, info2 = solver.solve_system(Lo, ro)
     check(v2, info2)
     assert ctx.lockstep_groups() == before + 1             # width 2, or width 4 (zero-padded for two regulators)
-    monkeypatch.setenv("PADNE_LOCKSTEP_NARROW", "0")
+    switches.set("PADNE_LOCKSTEP_NARROW", "0")
     before = ctx.lockstep_groups()
     v0, info0 = solver.solve_system(Lo, ro)
     check(v0, info0)
@@ -1669,7 +1585,7 @@ def test_config_c2_assembly_bit_for_bit_and_solve_at_full_size(ctx):
     assert int(np.argmax(v[:nv])) == t and int(np.argmin(v[:nv])) == f
 
 
-def test_headline_config_at_full_size(ctx, monkeypatch):
+def test_headline_config_at_full_size(ctx, switches):
     """Config C4 of BASELINE.json itself (8 layers of 1118x1118, N = 10 M, the bench workload), through the
     properties that need no direct solve: the windowed and the gather path of the product agree bit for bit, the
     mesh rows annihilate constants, the solve reaches the requested residual, conserves the current through
@@ -1698,11 +1614,11 @@ def test_headline_config_at_full_size(ctx, monkeypatch):
     # vertex's couplings, i.e. non-zero only in its handful of neighbours
     ones = A.matvec(np.ones(n))
     assert np.count_nonzero(np.abs(ones) > 1e-9 * np.abs(y_win).max()) <= 16
-    monkeypatch.setenv("PADNE_NO_XWINDOW", "1")
+    switches.set("PADNE_NO_XWINDOW", "1")
     A_gather = Ld.reduce(imap, nv - 1, -1.0)
     assert np.array_equal(A_gather.matvec(x), y_win)
     A_gather.close()
-    monkeypatch.delenv("PADNE_NO_XWINDOW")
+    switches.unset("PADNE_NO_XWINDOW")
     Ld.close()
     keep = np.flatnonzero(imap[:nv] >= 0)
     f, t = int(sysm.current_sources[0][0]), int(sysm.current_sources[1][0])
@@ -1876,10 +1792,10 @@ def test_assemblies_running_side_by_side_on_one_gpu_are_the_serial_result(ctx):
 
 
 @pytest.mark.parametrize("case", ["grid_with_stamps", "delaunay_fans"])
-def test_second_path_of_the_row_kernel_is_the_first_bit_for_bit(ctx, monkeypatch, case):
+def test_second_path_of_the_row_kernel_is_the_first_bit_for_bit(ctx, switches, case):
     """When the in-kernel scan of `asm_rows_in_place` gives up (a chip shared with other work can starve its scanner until
     a bounded wait runs out) the host builds the rows again in two passes -- lengths, an ordinary scan, fill -- instead of
-    failing the assembly.  PADNE_ASM_TWO_PASS=1 takes that path at once: structure and
+    failing the assembly.  PADNE_FORCE=asm_two_pass takes that path at once: structure and
     values of the single-pass result and of the oracle bit for bit, right angles (rows shorter than their fans), stamps,
     an internal node, fans of up to 12 triangles and a hub among them; the counter of the test header shows that the
     second path really ran."""
@@ -1920,7 +1836,7 @@ def test_second_path_of_the_row_kernel_is_the_first_bit_for_bit(ctx, monkeypatch
         return got
     first = assemble()
     before = _hip.asm_second_path_count()
-    monkeypatch.setenv("PADNE_ASM_TWO_PASS", "1")
+    switches.set("PADNE_FORCE", "asm_two_pass")
     second = assemble()
     assert _hip.asm_second_path_count() == before + 1
     for got in (first, second):
@@ -1939,17 +1855,17 @@ def test_randomised_assembly_is_the_oracle_bit_for_bit(ctx):
     assert fz.run(16, seed0=5, verbose=False) > 12          # the sweep reached vertices beyond the in-LDS path
 
 
-def test_incidence_pass_through_the_hash_table_of_wide_vertex_ranges(ctx, monkeypatch):
+def test_incidence_pass_through_the_hash_table_of_wide_vertex_ranges(ctx, switches):
     """The incidence pass counts the corners of a workgroup's triangles in LDS, indexed by vertex while the vertices lie
     within 4096 of each other, through a hash table of the vertices met when they do not (unordered triangle lists, mesh
-    lines longer than that).  PADNE_ASM_HASH sends every workgroup through the hash table: the same matrices bit for bit."""
+    lines longer than that).  PADNE_FORCE=asm_hash sends every workgroup through the hash table: the same matrices bit for bit."""
     import importlib.util
     import os
     spec = importlib.util.spec_from_file_location(
         "fuzz_assembly", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_assembly.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
-    monkeypatch.setenv("PADNE_ASM_HASH", "1")
+    switches.set("PADNE_FORCE", "asm_hash")
     assert fz.run(10, seed0=9, verbose=False) > 12
 
 
@@ -2147,16 +2063,16 @@ def test_layer_partitioned_solver_with_several_ranks_on_one_gpu(world, precond):
             assert n_p2p <= (1 + 2 * 2 - 1) * its + 4, (n_p2p, iters)
 
 
-def test_peer_to_peer_halo_stores_are_the_all_gather_bit_for_bit(monkeypatch):
+def test_peer_to_peer_halo_stores_are_the_all_gather_bit_for_bit(switches):
     """The same solve with the halo exchanged by peer stores (default with the in-process team) and by all-gathers
     (PADNE_NO_P2P=1): the values that arrive are the same, so iterations and potentials are bit-identical; only the kind of
     communication differs (calls[3] against calls[1] / calls[2] of padne_comm_call_counts).  (Both runs with one launch per
     product: the interior / boundary split, which regroups the dot-product partials, is only built where the exchange
     overlaps the interior tiles, i.e. not for the all-gather form.)"""
     sysm = synthetic.layered_system(8, 90, 70, via_lattice=5)
-    monkeypatch.setenv("PADNE_NO_SPLIT", "1")
+    switches.set("PADNE_NO_SPLIT", "1")
     v_p2p, it_p2p, res_p2p = run_team(sysm, 4, "amg")
-    monkeypatch.setenv("PADNE_NO_P2P", "1")
+    switches.set("PADNE_NO_P2P", "1")
     v_ag, it_ag, res_ag = run_team(sysm, 4, "amg")
     assert it_p2p == it_ag and np.array_equal(v_p2p, v_ag)
     assert res_ag.collectives[3] == 0 and res_p2p.collectives[3] > 0
@@ -2166,7 +2082,7 @@ def test_peer_to_peer_halo_stores_are_the_all_gather_bit_for_bit(monkeypatch):
     assert res_ag.split_tiles[0] == (0, 0)                # no overlap, no split
 
 
-def test_products_split_into_interior_and_boundary_tiles_around_the_exchange(monkeypatch):
+def test_products_split_into_interior_and_boundary_tiles_around_the_exchange(switches):
     """every product of a row-partitioned level that follows a halo exchange is launched in two parts
     -- the 64-row tiles whose columns are all owned while the exchange is under way, the tiles that read an exchange slot
     once it has landed (csr_build_split_plan).  Same products, same sums per row; only the grouping of the dot-product
@@ -2179,7 +2095,7 @@ def test_products_split_into_interior_and_boundary_tiles_around_the_exchange(mon
     (int0, bnd0), (int1, bnd1) = res_split.split_tiles            # the fine operator and the first coarse one are split
     assert bnd0 > 0 and int0 > 4 * bnd0 and int0 + bnd0 == (36000 + 63) // 64
     assert bnd1 > 0 and int1 > 0
-    monkeypatch.setenv("PADNE_NO_SPLIT", "1")
+    switches.set("PADNE_NO_SPLIT", "1")
     v_one, it_one, res_one = run_team(sysm, 4, "amg")
     assert res_one.split_tiles[0] == (0, 0)
     assert abs(it_split - it_one) <= 1
@@ -2187,14 +2103,14 @@ def test_products_split_into_interior_and_boundary_tiles_around_the_exchange(mon
     assert res_split.rel_residual <= 1.1e-12 and res_one.rel_residual <= 1.1e-12
 
 
-def test_last_partitioned_level_computes_its_neighbours_from_the_tail(monkeypatch):
+def test_last_partitioned_level_computes_its_neighbours_from_the_tail(switches):
     """Up-leg of the last row-partitioned level: the other ranks' values after the coarse correction, x1 + P e, are
     computed locally (x1 came with the down-leg exchange, the remote rows of P with the setup, e is the tail solution
     every rank holds) instead of exchanged.  Same arithmetic as on the owning rank: bit-identical potentials, the same
     iterations, one float exchange less per cycle than with PADNE_AMG_EXCHANGE_ALL=1."""
     sysm = synthetic.layered_system(8, 90, 70, via_lattice=5)
     v_new, it_new, res_new = run_team(sysm, 4, "amg")
-    monkeypatch.setenv("PADNE_AMG_EXCHANGE_ALL", "1")
+    switches.set("PADNE_AMG_EXCHANGE_ALL", "1")
     v_old, it_old, res_old = run_team(sysm, 4, "amg")
     assert it_new == it_old
     assert np.array_equal(v_new, v_old)
@@ -2204,13 +2120,13 @@ def test_last_partitioned_level_computes_its_neighbours_from_the_tail(monkeypatc
     assert its - 1 <= saved <= its + 1, (saved, its, res_old.collectives, res_new.collectives)
 
 
-def test_single_reduction_cg_is_the_textbook_iteration(ctx, monkeypatch):
+def test_single_reduction_cg_is_the_textbook_iteration(ctx, switches):
     """The rearranged loop of the row-partitioned runs (one global reduction per iteration) on ONE GPU against the
     textbook loop: same iterates up to rounding, same iteration count (+-1), same answer as the direct solve."""
     A, b, Lo, ro, n = layered_spd(4, 120, 100, 6)
     d = ctx.csr_from_scipy(A)
     ref = d.solve_spd(b, precond="amg")
-    monkeypatch.setenv("PADNE_CG_SINGLE_REDUCTION", "1")
+    switches.set("PADNE_CG_SINGLE_REDUCTION", "1")
     sr = d.solve_spd(b, precond="amg")
     again = d.solve_spd(b, precond="amg")
     assert sr.status == _hip.OK and abs(sr.iterations - ref.iterations) <= 1 and sr.rel_residual <= 1.1e-12
@@ -2384,9 +2300,9 @@ def test_problem_fixtures_with_sources_on_several_ranks(ctx, name, world):
         assert sol.solver_info.residual_norm < 1e-9
 
 
-def test_row_partitioned_hierarchy_with_several_exchanged_levels(monkeypatch):
+def test_row_partitioned_hierarchy_with_several_exchanged_levels(switches):
     """Force three row-partitioned levels (default: everything below 262144 unknowns is gathered)."""
-    monkeypatch.setenv("PADNE_AMG_GATHER_N", "700")
+    switches.set("PADNE_AMG_GATHER_N", "700")
     sysm = synthetic.layered_system(8, 90, 70, via_lattice=5)
     els = [("R", int(a), int(b), float(r)) for a, b, r in zip(*sysm.resistors)]
     els += [("I", int(f), int(t), float(i)) for f, t, i in zip(*sysm.current_sources)]
@@ -2398,7 +2314,7 @@ def test_row_partitioned_hierarchy_with_several_exchanged_levels(monkeypatch):
         assert res.levels >= 4 and iters < 60
 
 
-def test_batched_right_hand_sides_in_lockstep(ctx, monkeypatch):
+def test_batched_right_hand_sides_in_lockstep(ctx, switches):
     """Config C5 at test size: 11 current-source configurations = one lockstep group of 8 + 3 solved one at a time
     (and 14 = 8 + a padded group of 6); every column must match the direct solve and the one-at-a-time path."""
     A, b, Lo, ro, n = layered_spd(4, 120, 100, 6)
@@ -2414,7 +2330,7 @@ def test_batched_right_hand_sides_in_lockstep(ctx, monkeypatch):
     d = ctx.csr_from_scipy(A)
     res = d.solve_spd(B, precond="amg")
     assert res.rel_residual <= 1.1e-12 and res.precond_fallbacks == 0
-    monkeypatch.setenv("PADNE_NO_BATCH", "1")
+    switches.set("PADNE_NO_BATCH", "1")
     seq = d.solve_spd(B, precond="amg")
     import scipy.sparse.linalg as spla
     lu = spla.splu(A.tocsc())
@@ -2426,7 +2342,7 @@ def test_batched_right_hand_sides_in_lockstep(ctx, monkeypatch):
     assert np.all(res.x[5] == 0.0)
     # the lockstep group does not cost more iterations per column than the one-at-a-time path
     assert res.iterations <= seq.iterations + 8
-    monkeypatch.delenv("PADNE_NO_BATCH")
+    switches.unset("PADNE_NO_BATCH")
     # a lockstep group started from a good guess stops at once; from a perturbed guess it still converges
     warm = d.solve_spd(B[:8], precond="amg", x0=res.x[:8])
     assert warm.iterations <= 8 and warm.rel_residual <= 1.1e-12
@@ -2441,7 +2357,7 @@ def test_batched_right_hand_sides_in_lockstep(ctx, monkeypatch):
         assert np.abs(res14.x[c] - ref).max() <= REL_TOL * max(np.abs(ref).max(), 1e-300)
 
 
-def test_x_window_tiles_and_gather_tiles_in_one_product(ctx, monkeypatch):
+def test_x_window_tiles_and_gather_tiles_in_one_product(ctx, switches):
     """A scan-line mesh matrix large enough for the x-window plan, with lumped couplings to far-away unknowns in some
     rows (those tiles keep the gather path): the product is bit-identical to scipy's and to the plan-free kernel."""
     sysm = synthetic.layered_system(2, 260, 260, via_lattice=6)
@@ -2454,13 +2370,13 @@ def test_x_window_tiles_and_gather_tiles_in_one_product(ctx, monkeypatch):
     assert A.shape[0] > 65536
     x = np.random.default_rng(0).uniform(-1, 1, A.shape[0])
     y_plan = ctx.csr_from_scipy(A).matvec(x)
-    monkeypatch.setenv("PADNE_NO_XWINDOW", "1")
+    switches.set("PADNE_NO_XWINDOW", "1")
     y_gather = ctx.csr_from_scipy(A).matvec(x)
     assert np.array_equal(y_plan, A @ x)
     assert np.array_equal(y_plan, y_gather)
     # random band matrices: three bands of varying width (some tiles fit runs of 72, some need 128, some none),
     # ragged rows, empty rows, 1 % of the rows with far-away columns, a rectangular shape
-    monkeypatch.delenv("PADNE_NO_XWINDOW")
+    switches.unset("PADNE_NO_XWINDOW")
     rng = np.random.default_rng(33)
     for n, ncols, half in ((70001, 70001, 20), (90000, 90500, 45), (66000, 66000, 70)):
         rows, cols = [], []
@@ -2554,7 +2470,7 @@ def test_spmm8_columns_are_bitwise_the_single_vector_products(ctx):
             assert np.array_equal(yj, M @ X[:, j])            # and both equal scipy's CSR product bit for bit
 
 
-def test_relabel_with_injective_maps_is_the_slot_path_bit_for_bit(ctx, monkeypatch):
+def test_relabel_with_injective_maps_is_the_slot_path_bit_for_bit(ctx, switches):
     """Eliminations and permutations (injective row and column maps) are relabelled directly -- count, scan, write,
     rows re-sorted by their new columns -- instead of through slots and a merge: same matrix, bit for bit, including
     rows longer than the in-LDS sort, dropped rows / columns and exact zeros."""
@@ -2584,15 +2500,15 @@ def test_relabel_with_injective_maps_is_the_slot_path_bit_for_bit(ctx, monkeypat
         d = ctx.csr_from_scipy(src)
         for name, fn in cases:
             direct = fn(d).to_scipy()
-            monkeypatch.setenv("PADNE_RELABEL_SLOTS", "1")
+            switches.set("PADNE_FORCE", "relabel_slots")
             slots = fn(d).to_scipy()
-            monkeypatch.delenv("PADNE_RELABEL_SLOTS")
+            switches.unset("PADNE_FORCE")
             assert direct.shape == slots.shape and np.array_equal(direct.indptr, slots.indptr), name
             assert np.array_equal(direct.indices, slots.indices) and np.array_equal(direct.data, slots.data), name
             assert direct.has_sorted_indices and direct.nnz > 0 and np.all(direct.data != 0.0)
 
 
-def test_maps_that_only_drop_indices_are_relabelled_by_a_copy_with_holes(ctx, monkeypatch):
+def test_maps_that_only_drop_indices_are_relabelled_by_a_copy_with_holes(ctx, switches):
     """The reduction to the potential block drops indices and keeps the order of the rest (solver.py:544-560: no ground
     vertex, no multiplier row): count, scan, copy -- no histogram, no sort.  Against scipy and against the slot path, bit for
     bit: one hole, holes at both ends, scattered holes, a run of holes longer than the look-ahead of the map test (which the
@@ -2626,9 +2542,9 @@ def test_maps_that_only_drop_indices_are_relabelled_by_a_copy_with_holes(ctx, mo
             dm = ctx.to_device(m)
             dev = d.reduce(dm, n_out, -1.0).to_scipy()
             dm.free()
-            monkeypatch.setenv("PADNE_RELABEL_SLOTS", "1")
+            switches.set("PADNE_FORCE", "relabel_slots")
             slots = d.reduce(m, n_out, -1.0).to_scipy()
-            monkeypatch.delenv("PADNE_RELABEL_SLOTS")
+            switches.unset("PADNE_FORCE")
             for got in (host, dev, slots):
                 assert got.shape == ref.shape and got.has_sorted_indices, name
                 assert np.array_equal(got.indptr, ref.indptr) and np.array_equal(got.indices, ref.indices), name

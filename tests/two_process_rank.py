@@ -70,10 +70,12 @@ def main():
     out["split_tiles"] = [int(x) for x in ds.A.split_tiles(-1)]
     # the same with the exchanges as all-gathers (the mailboxes stay mapped, the library does not use them)
     os.environ["PADNE_NO_P2P"] = "1"
+    ctx.reload_options()                                       # (the switches are read once per context)
     c0 = ctx.comm_call_counts()[0]
     res3 = ds.solve(rtol=1e-12)
     c1 = ctx.comm_call_counts()[0]
     del os.environ["PADNE_NO_P2P"]
+    ctx.reload_options()
     out["calls_per_solve_allgather"] = [int(b - a) for a, b in zip(c0, c1)]
     out["iterations_allgather"] = int(res3.iterations)
     sol_ag = ds.solution().copy()
@@ -81,8 +83,10 @@ def main():
     out["p2p_exchange_us"] = ctx.halo_exchange_time(300) * 1e6
     out["exchange_slots_per_rank"] = int(plan.m)
     os.environ["PADNE_NO_P2P"] = "1"
+    ctx.reload_options()
     out["allgather_exchange_us_gloo"] = ctx.halo_exchange_time(30) * 1e6
     del os.environ["PADNE_NO_P2P"]
+    ctx.reload_options()
     out["max_abs_difference"] = float(np.abs(sol - sol_ag).max())
     out["bit_identical"] = bool(np.array_equal(sol, sol_ag))
     # potentials of all ranks against the reference's direct solve on the oracle-assembled system (rank 0)
