@@ -1853,7 +1853,12 @@ __device__ __forceinline__ void gj_invert_block16(double (&dd)[4], const int lan
         double dcol[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) dcol[q] = __shfl(dd[q], (lane & 48) | p, 64);
-        const double inv = 1.0 / dpp;
+        // 1 / pivot by the hardware reciprocal + two Newton steps (the pivots of a symmetric positive definite block are
+        // positive and far from the ends of the exponent range): the correctly rounded division is a dozen dependent
+        // instructions in a chain of 64 pivots that a launch of the big step waits for
+        double inv = __builtin_amdgcn_rcp(dpp);
+        inv = fma(inv, fma(-dpp, inv, 1.0), inv);
+        inv = fma(inv, fma(-dpp, inv, 1.0), inv);
         const double rp = drow * inv;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -2051,54 +2056,55 @@ __device__ __forceinline__ void gj64_tile(const int n, const int k0, const int b
     }
 }
 
-// In-place inversion of a 64 x 64 block in LDS by one workgroup: four block steps of 16 pivots, the 16 x 16 pivot block by
-// wave 0 (gj_invert_block16), the rest of the block by everybody.  N0 holds the block and receives the inverse; N1, R, D16 are
-// scratch.  Ends with a barrier.
+// In-place inversion of a 64 x 64 block in LDS by one workgroup: four block steps of 16 pivots.  The 16 x 16 pivot block is
+// inverted by wave 0 (gj_invert_block16); the rest of a step is the unified formula of the big step on 16 x 16 blocks,
+//     next = C~ - L~ (D16 P~)        (C~: pivot rows and columns zeroed, P~: pivot rows with the identity in the pivot columns,
+//                                     L~: pivot columns with MINUS the identity in the pivot rows)
+// on the matrix cores: wave w owns the 16 columns 16 w .., forms R = D16 P~ for them (four v_mfma_f64_16x16x4_f64; the rows of
+// D16 are read permuted so that the result's register layout is the B-operand layout of the second product, as in gj64_tile)
+// and takes its four row blocks through four k-steps each.  Everything a wave needs of the old block that does not depend on
+// D16 is in registers before the barrier behind the inversion.  Until round 5 both products were vector FMAs fed from LDS
+// (~270 LDS reads per thread and block step: the step was bound by LDS bandwidth, 7 us of it beside a 1.6 us inversion), and
+// a launch of the big step waited 35 us for this workgroup while its tiles needed 26.  N0 holds the block and receives the
+// inverse; N1, D16 are scratch.  Ends with a barrier.  Sums in the order of the matrix cores.
 constexpr int kGjLd = kGjM + 1;
-__device__ __forceinline__ void gj64_invert_lds(double (*N0)[kGjLd], double (*N1)[kGjLd], double (*R)[kGjM], double (*D16)[kGjBlock]) {
-    const int t = threadIdx.x, lane = t & 63, eb = lane & 15, ea0 = lane >> 4;
+__device__ __forceinline__ void gj64_invert_lds(double (*N0)[kGjLd], double (*N1)[kGjLd], double (*D16)[kGjBlock]) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 15, g = lane >> 4;
     double (*cur)[kGjLd] = N0, (*nxt)[kGjLd] = N1;
     for (int bb = 0; bb < kGjM / kGjBlock; ++bb) {
         const int pb = bb * kGjBlock;
+        gj_v4d acc[4];
+        double aop[4][4], bop[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[rb][r] = (rb == bb || w == bb) ? 0.0 : cur[16 * rb + g + 4 * r][16 * w + j];
+            // (A operand: row j of the block, pivot 4 g + m in k-step m; minus L~)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) aop[rb][m] = rb == bb ? (j == 4 * g + m ? 1.0 : 0.0) : -cur[16 * rb + j][pb + 4 * g + m];
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) bop[m] = w == bb ? (4 * m + g == j ? 1.0 : 0.0) : cur[pb + 4 * m + g][16 * w + j];
         if (t < 64) {
             double dd[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) dd[q] = cur[pb + ea0 + 4 * q][pb + eb];
+            for (int q = 0; q < 4; ++q) dd[q] = cur[pb + g + 4 * q][pb + j];
             gj_invert_block16(dd, lane);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) D16[ea0 + 4 * q][eb] = dd[q];
+            for (int q = 0; q < 4; ++q) D16[g + 4 * q][j] = dd[q];
         }
         __syncthreads();
-        // the new pivot rows: R = D16 * [pivot rows with the identity in the pivot columns]
+        gj_v4d rr = {0.0, 0.0, 0.0, 0.0};
+        const int prow = 4 * (j & 3) + (j >> 2);          // row j of the first product stands for pivot 4 (j & 3) + (j >> 2)
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            const int e = t + 256 * h, a = e / kGjM, j = e % kGjM;
-            double v;
-            if (j >= pb && j < pb + kGjBlock) {
-                v = D16[a][j - pb];
-            } else {
-                v = 0.0;
+        for (int m = 0; m < 4; ++m) rr = __builtin_amdgcn_mfma_f64_16x16x4f64(D16[prow][4 * m + g], bop[m], rr, 0, 0, 0);
+        // rr[m] of lane (g, j) = R[4 g + m][16 w + j]: the B operand of k-step m
 #pragma unroll
-                for (int b = 0; b < kGjBlock; ++b) v = fma(D16[a][b], cur[pb + b][j], v);
-            }
-            R[a][j] = v;
-        }
-        __syncthreads();
-        {
-            const int j = t & 63, i0 = 16 * (t >> 6);
-            const bool pcol = j >= pb && j < pb + kGjBlock;
-            double rj[kGjBlock];
+        for (int rb = 0; rb < 4; ++rb) {
 #pragma unroll
-            for (int b = 0; b < kGjBlock; ++b) rj[b] = R[b][j];
+            for (int m = 0; m < 4; ++m) acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[rb][m], rr[m], acc[rb], 0, 0, 0);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int i = i0 + q;
-                double v = pcol ? 0.0 : cur[i][j];
-#pragma unroll
-                for (int b = 0; b < kGjBlock; ++b) v = fma(-cur[i][pb + b], rj[b], v);
-                if (i >= pb && i < pb + kGjBlock) v = R[i - pb][j];
-                nxt[i][j] = v;
-            }
+            for (int r = 0; r < 4; ++r) nxt[16 * rb + g + 4 * r][16 * w + j] = acc[rb][r];
         }
         __syncthreads();
         double (*sw)[kGjLd] = cur;
@@ -2110,14 +2116,14 @@ __device__ __forceinline__ void gj64_invert_lds(double (*N0)[kGjLd], double (*N1
 
 // D^-1 of the first step's pivot block -> side (operand order)
 __global__ __launch_bounds__(256) void gj64_prepare(int n, int k0, int bs, const double *__restrict__ in, double *__restrict__ side) {
-    __shared__ double N0[kGjM][kGjLd], N1[kGjM][kGjLd], R[kGjBlock][kGjM], D16[kGjBlock][kGjBlock];
+    __shared__ double N0[kGjM][kGjLd], N1[kGjM][kGjLd], D16[kGjBlock][kGjBlock];
     const int t = threadIdx.x;
     for (int e = t; e < kGjM * kGjM; e += 256) {
         const int a = e / kGjM, b = e % kGjM;
         N0[a][b] = (a < bs && b < bs) ? in[(size_t)(k0 + a) * n + k0 + b] : (a == b ? 1.0 : 0.0);
     }
     __syncthreads();
-    gj64_invert_lds(N0, N1, R, D16);
+    gj64_invert_lds(N0, N1, D16);
     for (int e = t; e < kGjM * kGjM; e += 256) side[gj64_side_off(e / kGjM, e % kGjM)] = N0[e / kGjM][e % kGjM];
 }
 
@@ -2126,7 +2132,7 @@ __global__ __launch_bounds__(256) void gj64_prepare(int n, int k0, int bs, const
 __global__ __launch_bounds__(256) void gj64_step(int n, int k0, int bs, const double *__restrict__ in, double *__restrict__ out,
                                                  const double *__restrict__ side, double *__restrict__ side_next, int next_bs,
                                                  int n_ct, int n_tiles) {
-    __shared__ double N0[kGjM][kGjLd], N1[kGjM][kGjLd], R[kGjBlock][kGjM], D16[kGjBlock][kGjBlock];
+    __shared__ double N0[kGjM][kGjLd], N1[kGjM][kGjLd], D16[kGjBlock][kGjBlock];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     if (blockIdx.x > 0) {
         const int tile = ((int)blockIdx.x - 1) * 4 + w;
@@ -2145,7 +2151,7 @@ __global__ __launch_bounds__(256) void gj64_step(int n, int k0, int bs, const do
         N0[a][b] = (a < next_bs && b < next_bs) ? v : (a == b ? 1.0 : 0.0);
     });
     __syncthreads();
-    gj64_invert_lds(N0, N1, R, D16);
+    gj64_invert_lds(N0, N1, D16);
     for (int e = t; e < kGjM * kGjM; e += 256) side_next[gj64_side_off(e / kGjM, e % kGjM)] = N0[e / kGjM][e % kGjM];
 }
 
