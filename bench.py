@@ -135,7 +135,7 @@ def step_counter_traffic():
     """HBM-side bytes of one timed step by the hardware counters (profiles/<round>_step_traffic.json, written by
     scripts/pmc_setup_sum.py from separate rocprofv3 --pmc passes of the same command; the newest round that has one);
     (None, None) if there is none."""
-    for rd in ("r04", "r03"):
+    for rd in ("r05", "r04", "r03"):
         try:
             return json.load(open(os.path.join(ROOT, "profiles", rd + "_step_traffic.json"))), f"profiles/{rd}_step_traffic.json"
         except Exception:
@@ -612,19 +612,22 @@ def main():
             asm_ms = float(np.mean(asm_warm)) * 1e3
             red_ms = float(np.mean(red_warm)) * 1e3
             asm_bytes = 16 * nv + 12 * int(mto[-1]) + 12 * int(L_nnz)
-            asm_traffic = None
-            try:
-                asm_traffic = json.load(open(os.path.join(ROOT, "profiles", "r04_assembly_traffic.json")))
-            except Exception:
-                pass
+            asm_traffic, asm_traffic_file = None, None
+            for rd in ("r05", "r04"):
+                try:
+                    asm_traffic = json.load(open(os.path.join(ROOT, "profiles", rd + "_assembly_traffic.json")))
+                    asm_traffic_file = f"profiles/{rd}_assembly_traffic.json"
+                    break
+                except Exception:
+                    continue
             out["assembly"] = {
                 "ms": asm_ms, "ms_min": float(np.min(asm_warm)) * 1e3, "ms_cold_first_call": t_assemble * 1e3,
                 "repeats": ASSEMBLY_REPEATS, "algorithmic_bytes": int(asm_bytes), "bytes_rule": "16 N + 12 T + 12 nnz (= 124 N at 7 nnz/row)",
                 "achieved": asm_bytes / (asm_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": asm_bytes / (asm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "traffic": asm_traffic.get("bytes_per_assembly") if asm_traffic else None,
-                "traffic_static_from": "profiles/r04_assembly_traffic.json (rocprofv3 --pmc passes, scripts/pmc_asm.sh; not collected in "
-                                       "this run)" if asm_traffic else None,
+                "traffic_static_from": (asm_traffic_file + " (rocprofv3 --pmc passes, scripts/pmc_asm.sh; not collected in this run)")
+                                       if asm_traffic else None,
                 "reduce_ms": red_ms, "reduce_ms_host_map": float(np.mean(red_warm_host)) * 1e3,
                 "what": "padne_assemble_system on device-resident meshes + host stamp lists -> CSR L (wall time per call, warm, "
                         "host looks included); reduce_ms: L -> A = -P^T L P (padne_csr_reduce: drop the ground vertex and the "

@@ -2,7 +2,7 @@
 table and the SpMV-by-grid summary from the raw csv files."""
 import csv, glob, json, collections, shutil, os
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RD = os.environ.get("PADNE_ROUND", "r04")        # prefix of the files written under profiles/
+RD = os.environ.get("PADNE_ROUND", "r05")        # prefix of the files written under profiles/
 F = os.path.join(R, "gpurun_out", "final"); P = os.path.join(R, "profiles")
 for src, dst in (("bench_c4_1gpu_amg.json", RD + "_bench_c4_1gpu_amg.json"), ("bench_c4_1gpu_amg.json", RD + "_bench_c4_1gpu.json"),
                  ("bench_c4_1gpu_jacobi.json", RD + "_bench_c4_1gpu_jacobi.json"), ("stats/run_kernel_stats.csv", RD + "_bench_c4_amg_kernel_stats.csv"),

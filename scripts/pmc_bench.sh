@@ -4,7 +4,7 @@
 # usage (on the GPU box, from the repo root):  bash scripts/pmc_bench.sh gpurun_out/pmc_r01
 OUT="$GRAFT_REPO_ROOT/$1"; mkdir -p "$OUT"; export TMPDIR=/tmp; cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d "$OUT/$C" -o run -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-seam > "$OUT/$C.log" 2>&1 || exit 1
+  rocprofv3 --pmc $C --output-format csv -d "$OUT/$C" -o run -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-seam --no-c5 --no-rank-proxy > "$OUT/$C.log" 2>&1 || exit 1
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, json, sys, collections
@@ -27,7 +27,7 @@ dot = names[0]
 cal = [k for k in acc["FETCH_SIZE"] if "pcg_update_p_z_kernel" in k][0]
 f_dot, n_dot = big(dot, "FETCH_SIZE"); w_dot, _ = big(dot, "WRITE_SIZE")
 f_cal, n_cal = big(cal, "FETCH_SIZE"); w_cal, _ = big(cal, "WRITE_SIZE")
-rec = {"kernel": dot, "workload": "C4 (N=10M, nnz=70M)", "round": 4, "launches_averaged": n_dot,
+rec = {"kernel": dot, "workload": "C4 (N=10M, nnz=70M)", "round": 5, "launches_averaged": n_dot,
        "FETCH_SIZE_KB": f_dot, "WRITE_SIZE_KB": w_dot,
        "bytes_per_launch": 2 * f_dot * 1024 + w_dot * 1024,
        "algorithmic_bytes_per_launch": 999452960,

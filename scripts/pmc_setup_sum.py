@@ -9,7 +9,7 @@ out = sys.argv[1]
 LOOP = ("csr_spmv_kernel<1,", "csr_spmv_kernel<2, float", "csr_spmv_kernel<6, float", "csr_spmv_kernel<7, float", "csr_spmv_kernel<3, float",
         "csr_spmv_kernel<4, float", "csr_spmv_kernel<0, float", "csr_spmv_kernel<8, float", "p_hat_from_z", "csr_spmv_wpr_kernel", "dense_gemv", "pcg_update_xr_entry", "pcg_update_p_z",
         "pcg_init", "fold_partials", "residual_kernel", "pcg_set_tolerance", "csr_spmv_kernel<0, double", "mail_post")
-BUILD = ("asm_", "grid_mesh", "generate", "relabel", "reduce_", "map_is_injective", "merge_rows", "compact_rows", "nn_", "kkt_", "halo_",
+BUILD = ("asm_", "grid_mesh", "generate", "relabel", "reduce_", "map_is_injective", "map_is_compaction", "merge_rows", "compact_rows", "nn_", "kkt_", "halo_",
          "sort_long_rows_wave<1024, 4>", "fill_value_i32")
 SOLVES = 2
 acc = {}
