@@ -1965,9 +1965,13 @@ __device__ __host__ inline int gj64_side_off(int a, int b) {      // D^-1[a][b] 
 
 // One wave: the tile of 16 NRB rows from r0, 16 NCB columns from c0, through the step with the pivots [k0, k0 + bs).
 // sink(row, col, value) receives every entry of the tile (also those outside the matrix: the caller decides).
+// u_lds (may be null): the four waves of the workgroup own four row tiles of ONE column block and share U = D^-1 P~ through LDS --
+// wave w forms its quarter (the 16 rows of U of pivot block w: a quarter of the 128 products every wave made for itself) and
+// takes the other three from there; ALL four waves must call (the barrier), `active` tells whether the wave's row tile exists.
 template <int NRB, int NCB, typename Sink>
 __device__ __forceinline__ void gj64_tile(const int n, const int k0, const int bs, const double *__restrict__ in,
-                                          const double *__restrict__ side, const int r0, const int c0, const int lane, Sink sink) {
+                                          const double *__restrict__ side, const int r0, const int c0, const int lane, Sink sink,
+                                          double *u_lds = nullptr, const int w = 0, const bool active = true) {
     const int j = lane & 15, g = lane >> 4;
     auto load_a = [&](int rb, double (&a)[16]) {
         const int row = r0 + 16 * rb + j;
@@ -2021,14 +2025,38 @@ __device__ __forceinline__ void gj64_tile(const int n, const int k0, const int b
             else if (col < n && k < bs) v = in[(size_t)(k0 + k) * n + col];
             pb[ks][cb] = v;
         }
+    if (u_lds == nullptr) {
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks)
+        for (int ks = 0; ks < 16; ++ks)
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            const double a = side[(kb * 16 + ks) * 64 + lane];
+            for (int kb = 0; kb < 4; ++kb) {
+                const double a = side[(kb * 16 + ks) * 64 + lane];
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) U[kb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, pb[ks][cb], U[kb][cb], 0, 0, 0);
+                for (int cb = 0; cb < NCB; ++cb) U[kb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, pb[ks][cb], U[kb][cb], 0, 0, 0);
+            }
+    } else {
+        gj_v4d mine[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) mine[cb] = (gj_v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const double a = side[(w * 16 + ks) * 64 + lane];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) mine[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, pb[ks][cb], mine[cb], 0, 0, 0);
         }
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) u_lds[((w * NCB + cb) * 4 + r) * 64 + lane] = mine[cb][r];
+        __syncthreads();
+        if (!active) return;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) U[kb][cb][r] = u_lds[((kb * NCB + cb) * 4 + r) * 64 + lane];
+    }
     // the tile, a row block at a time, the next block's operands in flight
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb) {
@@ -2135,12 +2163,13 @@ __global__ __launch_bounds__(256) void gj64_step(int n, int k0, int bs, const do
     __shared__ double N0[kGjM][kGjLd], N1[kGjM][kGjLd], D16[kGjBlock][kGjBlock];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     if (blockIdx.x > 0) {
-        const int tile = ((int)blockIdx.x - 1) * 4 + w;
-        if (tile >= n_tiles) return;
-        const int r0 = (tile / n_ct) * kGjTR, c0 = (tile % n_ct) * kGjTC;
-        gj64_tile<kGjTR / 16, kGjTC / 16>(n, k0, bs, in, side, r0, c0, lane, [&](int row, int col, double v) {
+        // the four waves of a workgroup: four row tiles of one column block (they share U through LDS: N0 is free here)
+        const int b = (int)blockIdx.x - 1, n_rt = n_tiles / n_ct;
+        const int c0 = (b % n_ct) * kGjTC, rt = (b / n_ct) * 4 + w;
+        static_assert(sizeof(N0) >= sizeof(double) * 4 * (kGjTC / 16) * 4 * 64, "room for U");
+        gj64_tile<kGjTR / 16, kGjTC / 16>(n, k0, bs, in, side, rt * kGjTR, c0, lane, [&](int row, int col, double v) {
             if (row < n && col < n) out[(size_t)row * n + col] = v;
-        });
+        }, &N0[0][0], w, rt < n_rt);
         return;
     }
     if (next_bs <= 0) return;
@@ -3175,8 +3204,8 @@ static int dense_inverse(padne_ctx *ctx, const padne_csr *A, double **inv_out) {
         if (mfma) {
             double *side = nullptr;
             PADNE_TRY(sc.alloc(&side, (size_t)2 * kGjM * kGjM));
-            const int n_ct = (n + kGjTC - 1) / kGjTC, n_tiles = n_ct * ((n + kGjTR - 1) / kGjTR);
-            const unsigned g64 = 1u + (unsigned)((n_tiles + 3) / 4);
+            const int n_ct = (n + kGjTC - 1) / kGjTC, n_rt = (n + kGjTR - 1) / kGjTR, n_tiles = n_ct * n_rt;
+            const unsigned g64 = 1u + (unsigned)(n_ct * ((n_rt + 3) / 4));      // (a workgroup: four row tiles of one column block)
             hipLaunchKernelGGL(gj64_prepare, dim3(1), dim3(256), 0, s, n, 0, std::min(kGjM, n), (const double *)src, side);
             int par = 0;
             for (int k = 0; k < n; k += kGjM) {
