@@ -2084,8 +2084,45 @@ __device__ __forceinline__ void gj64_tile(const int n, const int k0, const int b
     }
 }
 
+// The 16 x 16 pivot block of gj64_invert_lds, inverted in place by one wave with (almost) no LDS traffic: lane 16 c + r holds
+// row r, columns 4 c .. 4 c + 3.  The pivot row reaches the lanes of its 16-lane row by DPP (row_newbcast: one move per
+// 32-bit half, no memory pipe), the pivot by a scalar read, and only the lane's own entry of the pivot column crosses the
+// 16-lane rows through ds_bpermute -- two per pivot where gj_invert_block16 makes twelve.  Same formulas.
+template <int P>
+__device__ __forceinline__ double gj_row_bcast(const double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + P, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + P, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int P>
+__device__ __forceinline__ void gj_pivot_rows16(double (&a)[4], const int lane) {
+    constexpr int pc = P >> 2, pm = P & 3;
+    const int r = lane & 15, c = lane >> 4;
+    double rp[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) rp[m] = gj_row_bcast<P>(a[m]);
+    const double dpp = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[pm]), pc * 16 + P),
+                                        __builtin_amdgcn_readlane(__double2loint(a[pm]), pc * 16 + P));
+    const double cp = __shfl(a[pm], pc * 16 + r, 64);
+    double inv = __builtin_amdgcn_rcp(dpp);
+    inv = fma(inv, fma(-dpp, inv, 1.0), inv);
+    inv = fma(inv, fma(-dpp, inv, 1.0), inv);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const bool pcol = c == pc && m == pm;
+        const double rm = rp[m] * inv;
+        a[m] = r == P ? (pcol ? inv : rm) : (pcol ? -cp * inv : a[m] - cp * rm);
+    }
+}
+__device__ __forceinline__ void gj_invert_rows16(double (&a)[4], const int lane) {
+    gj_pivot_rows16<0>(a, lane);  gj_pivot_rows16<1>(a, lane);  gj_pivot_rows16<2>(a, lane);  gj_pivot_rows16<3>(a, lane);
+    gj_pivot_rows16<4>(a, lane);  gj_pivot_rows16<5>(a, lane);  gj_pivot_rows16<6>(a, lane);  gj_pivot_rows16<7>(a, lane);
+    gj_pivot_rows16<8>(a, lane);  gj_pivot_rows16<9>(a, lane);  gj_pivot_rows16<10>(a, lane); gj_pivot_rows16<11>(a, lane);
+    gj_pivot_rows16<12>(a, lane); gj_pivot_rows16<13>(a, lane); gj_pivot_rows16<14>(a, lane); gj_pivot_rows16<15>(a, lane);
+}
+
 // In-place inversion of a 64 x 64 block in LDS by one workgroup: four block steps of 16 pivots.  The 16 x 16 pivot block is
-// inverted by wave 0 (gj_invert_block16); the rest of a step is the unified formula of the big step on 16 x 16 blocks,
+// inverted by wave 0 (gj_invert_rows16); the rest of a step is the unified formula of the big step on 16 x 16 blocks,
 //     next = C~ - L~ (D16 P~)        (C~: pivot rows and columns zeroed, P~: pivot rows with the identity in the pivot columns,
 //                                     L~: pivot columns with MINUS the identity in the pivot rows)
 // on the matrix cores: wave w owns the 16 columns 16 w .., forms R = D16 P~ for them (four v_mfma_f64_16x16x4_f64; the rows of
@@ -2114,12 +2151,12 @@ __device__ __forceinline__ void gj64_invert_lds(double (*N0)[kGjLd], double (*N1
 #pragma unroll
         for (int m = 0; m < 4; ++m) bop[m] = w == bb ? (4 * m + g == j ? 1.0 : 0.0) : cur[pb + 4 * m + g][16 * w + j];
         if (t < 64) {
-            double dd[4];
+            double dd[4];                                  // (row j, columns 4 g .. 4 g + 3: the layout of gj_invert_rows16)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) dd[q] = cur[pb + g + 4 * q][pb + j];
-            gj_invert_block16(dd, lane);
+            for (int m = 0; m < 4; ++m) dd[m] = cur[pb + j][pb + 4 * g + m];
+            gj_invert_rows16(dd, lane);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) D16[g + 4 * q][j] = dd[q];
+            for (int m = 0; m < 4; ++m) D16[j][4 * g + m] = dd[m];
         }
         __syncthreads();
         gj_v4d rr = {0.0, 0.0, 0.0, 0.0};
