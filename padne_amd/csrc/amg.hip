@@ -4506,14 +4506,7 @@ __global__ __launch_bounds__(256) void dense_gemm_xk(int n, const float *__restr
     if (lane < K) y[(size_t)row * K + j] = s;
 }
 
-// z8 = M^-1 r8 for k interleaved right-hand sides; partials_rz [k][kMaxPartials]; bb2 [k]
-template <int K>
-static int amg_apply_batch_k(padne_ctx *ctx, const padne_csr *A0, const double *r8, double *z8, double *partials_rz,
-                             const int32_t *done_flag, const double *bb2) {
-    Amg *amg = (Amg *)A0->amg;
-    PADNE_REQUIRE(amg != nullptr && amg->f32 && !amg->dist, "the batched cycle needs the single-GPU single-precision hierarchy");
-    hipStream_t s = ctx->stream;
-    const int nl = (int)amg->levels.size();
+static int amg_batch_vectors(padne_ctx *ctx, Amg *amg) {
     for (AmgLevel &L : amg->levels) {
         if (L.b8 != nullptr) continue;
         const size_t bytes = sizeof(float) * 8 * (size_t)(L.n > 0 ? L.n : 1);      // (room for the widest form)
@@ -4523,6 +4516,31 @@ static int amg_apply_batch_k(padne_ctx *ctx, const padne_csr *A0, const double *
         L.tmp8 = (float *)pool_alloc(ctx, bytes);
         if (!L.b8 || !L.xa8 || !L.xb8 || !L.tmp8) return PADNE_E_NOMEM;
     }
+    return PADNE_OK;
+}
+
+// buffers of the batched cycle's entry stage, for the caller that fuses it into its x / r update (pcg.hip, solve_batch)
+int amg_batch_entry_args(padne_ctx *ctx, const padne_csr *A0, float *jac, const float **dinv32, float **b8, float **xa8) {
+    Amg *amg = (Amg *)A0->amg;
+    PADNE_REQUIRE(amg != nullptr && amg->f32 && !amg->dist && amg->levels.size() >= 2, "batched cycle");
+    PADNE_TRY(amg_batch_vectors(ctx, amg));
+    const AmgLevel &L = amg->levels[0];
+    *jac = (float)L.jac;
+    *dinv32 = L.A->dinv32;
+    *b8 = L.b8;
+    *xa8 = L.xa8;
+    return PADNE_OK;
+}
+
+// z8 = M^-1 r8 for k interleaved right-hand sides; partials_rz [k][kMaxPartials]; bb2 [k]
+template <int K>
+static int amg_apply_batch_k(padne_ctx *ctx, const padne_csr *A0, const double *r8, double *z8, double *partials_rz,
+                             const int32_t *done_flag, const double *bb2, const bool entry_done) {
+    Amg *amg = (Amg *)A0->amg;
+    PADNE_REQUIRE(amg != nullptr && amg->f32 && !amg->dist, "the batched cycle needs the single-GPU single-precision hierarchy");
+    hipStream_t s = ctx->stream;
+    const int nl = (int)amg->levels.size();
+    PADNE_TRY(amg_batch_vectors(ctx, amg));
     for (int l = 0; l < nl; ++l) {
         AmgLevel &L = amg->levels[l];
         if (l == nl - 1) {
@@ -4532,7 +4550,9 @@ static int amg_apply_batch_k(padne_ctx *ctx, const padne_csr *A0, const double *
             break;
         }
         const int gv = (int)std::min<long long>((L.n * K + 255) / 256, 2048);
-        if (l == 0)
+        if (l == 0 && entry_done) {
+            // the caller's x / r update has written b = r / ||b|| and the first sweep (pcg8_update_xr_kernel)
+        } else if (l == 0)
             hipLaunchKernelGGL(amg_entry_f32xk_kernel<K>, dim3(gv > 0 ? gv : 1), dim3(256), 0, s, L.n, r8, bb2, (float)L.jac,
                                (const float *)L.A->dinv32, L.b8, L.xa8, done_flag);
         else
@@ -4570,11 +4590,11 @@ static int amg_apply_batch_k(padne_ctx *ctx, const padne_csr *A0, const double *
 }
 
 int amg_apply_batch(padne_ctx *ctx, const padne_csr *A0, int k, const double *r8, double *z8, double *partials_rz,
-                    const int32_t *done_flag, const double *bb2) {
+                    const int32_t *done_flag, const double *bb2, bool entry_done) {
     switch (k) {
-        case 8: return amg_apply_batch_k<8>(ctx, A0, r8, z8, partials_rz, done_flag, bb2);
-        case 4: return amg_apply_batch_k<4>(ctx, A0, r8, z8, partials_rz, done_flag, bb2);
-        case 2: return amg_apply_batch_k<2>(ctx, A0, r8, z8, partials_rz, done_flag, bb2);
+        case 8: return amg_apply_batch_k<8>(ctx, A0, r8, z8, partials_rz, done_flag, bb2, entry_done);
+        case 4: return amg_apply_batch_k<4>(ctx, A0, r8, z8, partials_rz, done_flag, bb2, entry_done);
+        case 2: return amg_apply_batch_k<2>(ctx, A0, r8, z8, partials_rz, done_flag, bb2, entry_done);
         default: set_error("lockstep width %d", k); return PADNE_E_INVALID;
     }
 }

@@ -1146,7 +1146,8 @@ static int solve_one_single_reduction(padne_ctx *ctx, const padne_csr *a, const 
 // lockstep iteration costs less than as many single ones -- the width is a template parameter of every kernel below and a
 // run-time argument of the host functions)
 int amg_apply_batch(padne_ctx *ctx, const padne_csr *A0, int k, const double *r8, double *z8, double *partials_rz,
-                    const int32_t *done_flag, const double *bb2);
+                    const int32_t *done_flag, const double *bb2, bool entry_done = false);
+int amg_batch_entry_args(padne_ctx *ctx, const padne_csr *A0, float *jac, const float **dinv32, float **b8, float **xa8);
 bool amg_supports_batch8(const padne_csr *A0);
 
 struct Pcg8Status {
@@ -1220,17 +1221,33 @@ __global__ __launch_bounds__(256) void pcg8_update_xr_kernel(const long long n, 
                                                              const double *__restrict__ pq, const double *__restrict__ p,
                                                              const double *__restrict__ q, double *__restrict__ x,
                                                              double *__restrict__ r, double *__restrict__ part_rr,
-                                                             const Pcg8Status *__restrict__ st) {
+                                                             const Pcg8Status *__restrict__ st,
+                                                             // entry stage of the batched cycle (b32 may be null): b = r / ||b||
+                                                             // and the first sweep, as amg_entry_f32xk_kernel -- the residual
+                                                             // is in a register here and need not be read again
+                                                             const double *__restrict__ bb2, const float c,
+                                                             const float *__restrict__ dinv32, float *__restrict__ b32,
+                                                             float *__restrict__ xa32) {
     __shared__ double red[4][8];
     if (st->done) return;
     const int j = threadIdx.x & (K - 1);
     const double alpha = st->col_done[j] ? 0.0 : rz[j] / pq[j];
+    double s_inv = 1.0;
+    if (b32 != nullptr) {
+        const double s2 = bb2[j];
+        if (s2 > 0.0) s_inv = 1.0 / sqrt(s2);
+    }
     double s_rr = 0.0;
     for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n * K; t += (long long)gridDim.x * 256) {
         const double ri = r[t] - alpha * q[t];
         x[t] += alpha * p[t];
         r[t] = ri;
         s_rr += ri * ri;
+        if (b32 != nullptr) {
+            const float v = (float)(ri * s_inv);
+            b32[t] = v;
+            xa32[t] = c * dinv32[t / K] * v;
+        }
     }
     block_store_partial8<K>(s_rr, red, part_rr);
 }
@@ -1325,6 +1342,10 @@ static int solve_batch(padne_ctx *ctx, const padne_csr *a, const double *b_cols,
     } else {
         PADNE_HIP_CHECK(hipMemsetAsync(x8, 0, sizeof(double) * nv, s));
     }
+    // (the entry stage of the cycle rides on the x / r update of the loop)
+    float e_jac = 0.f, *e_b8 = nullptr, *e_xa8 = nullptr;
+    const float *e_dinv32 = nullptr;
+    PADNE_TRY(amg_batch_entry_args(ctx, a, &e_jac, &e_dinv32, &e_b8, &e_xa8));
     int restarts = 0, total_iters = 0, code = PADNE_OK;
     double true_rr[8] = {0}, prev_true_rr[8] = {0}, bb[8] = {0}, tol2[8] = {0};
     int col_iters[8] = {0};
@@ -1350,9 +1371,9 @@ static int solve_batch(padne_ctx *ctx, const padne_csr *a, const double *b_cols,
                 PADNE_TRY(launch_spmm_mode(ctx, a, K, SPMV_DOT, p8, q8, p8, pslot(P_PQ), &st->done, nullptr, nullptr, 0.0));
                 PADNE_TRY(fold(pslot(P_PQ), gs, scal + C_PQ));
                 hipLaunchKernelGGL(pcg8_update_xr_kernel<K>, dim3(gv), dim3(256), 0, s, n, rz_old, scal + C_PQ, p8, q8, x8, r8,
-                                   pslot(P_RR), st);
+                                   pslot(P_RR), st, (const double *)(scal + C_BB), e_jac, e_dinv32, e_b8, e_xa8);
                 PADNE_HIP_CHECK(hipGetLastError());
-                PADNE_TRY(amg_apply_batch(ctx, a, K, r8, z8, pslot(rz_new_slot), &st->done, scal + C_BB));
+                PADNE_TRY(amg_apply_batch(ctx, a, K, r8, z8, pslot(rz_new_slot), &st->done, scal + C_BB, true));
                 PADNE_TRY(fold(pslot(rz_new_slot), gs, rz_new));
                 PADNE_TRY(fold(pslot(P_RR), gv, scal + C_RR));
                 hipLaunchKernelGGL(pcg8_update_p_kernel<K>, dim3(gv), dim3(256), 0, s, n, rz_new, rz_old, scal + C_RR,
