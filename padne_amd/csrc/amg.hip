@@ -44,12 +44,6 @@ struct AmgLevel {
     padne_csr *P = nullptr;         // n_l x n_{l+1}
     padne_csr *R = nullptr;         // n_{l+1} x n_l
     padne_csr *W = nullptr;         // P - c D^-1 A P, single-precision values only (the fine level of the float cycle)
-    // small inner levels of the float cycle (launch-bound: a kernel there costs its launch, not its bytes) in TWO products
-    // instead of three: down  b_{l+1} = W^T b_l  (= R (b - A c D^-1 b): residual of the sweep from zero, restricted),
-    // up  x_l = [S | W] [b_l ; e_{l+1}]  with  S = c D^-1 (2 I - c A D^-1)  (both sweeps of the right-hand side + the correction)
-    padne_csr *Wt = nullptr;        // n_{l+1} x n_l
-    padne_csr *SU = nullptr;        // n_l x (n_l + n_{l+1}), single-precision values only
-    float *cat = nullptr;           // [b_l ; x_{l+1}]: the level's right-hand side and the coarse solution behind it
     double lambda = 2.0;            // Gershgorin bound of D^-1 A
     double jac = 0.0;               // Jacobi damping 1/theta_c
     long long n = 0;
@@ -73,7 +67,6 @@ struct Amg {
     int n_coarse = 0;
     // single-precision cycle: the operators of every level have float copies and all cycle vectors are float
     bool f32 = false;
-    bool reuse_prepared = false;    // amg_prepare_reuse has run
     float *coarse_inv32 = nullptr;
     // row-partitioned hierarchy: below the gather level every rank holds the whole operator (`tail`, with its
     // own single-GPU hierarchy) and runs the rest of the cycle redundantly
@@ -2890,7 +2883,7 @@ static int transpose(padne_ctx *ctx, const padne_csr *M, padne_csr **T) {
         if (g >= (unsigned)kNumXcd) g -= g % kNumXcd;
         hipLaunchKernelGGL(sort_csr_rows_seg, dim3(g > 0 ? g : 1), dim3(256), 0, s, (int)nc, (const int *)m->rowptr, m->cols, m->vals,
                            n_long, long_list, (const int *)npairs);
-        hipLaunchKernelGGL(sort_listed_csr_rows, dim3(2048), dim3(256), 0, s, (const int *)n_long, (const int *)long_list,
+        hipLaunchKernelGGL(sort_listed_csr_rows, dim3(256), dim3(256), 0, s, (const int *)n_long, (const int *)long_list,
                            (const int *)m->rowptr, m->cols, m->vals);
         e = hipGetLastError();
     }
@@ -3134,7 +3127,7 @@ __global__ __launch_bounds__(256) void w_from_slots_kernel(int n, const int *__r
                                                            const int *__restrict__ pc, const double *__restrict__ pv,
                                                            const double *__restrict__ dinv, const double c,
                                                            const int *__restrict__ wr, int *__restrict__ wc,
-                                                           float *__restrict__ wv, double *__restrict__ wv64) {
+                                                           float *__restrict__ wv) {
     __shared__ int rp_all[4][65];
     __shared__ int sp_all[4][65];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -3175,14 +3168,12 @@ __global__ __launch_bounds__(256) void w_from_slots_kernel(int n, const int *__r
             }
             wc[k] = col;
             wv[k] = (float)v;
-            if (wv64 != nullptr) wv64[k] = v;
         }
         // the SpMV streams four non-zeros per lane and load: the three entries behind the last one must be valid columns
         // (csr_alloc zeroes the padding of ordinary matrices; W's arrays are sized by the slot count, its end is known here)
         if (r0 + nr == n && lane < 4) {
             wc[d1 + lane] = 0;
             wv[d1 + lane] = 0.f;
-            if (wv64 != nullptr) wv64[d1 + lane] = 0.0;
         }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
@@ -3195,7 +3186,7 @@ __global__ __launch_bounds__(256) void w_from_slots_kernel(int n, const int *__r
 // other stream inverts the coarsest operator, 51 dependent launches of seven workgroups each, and a launch that finds every
 // CU full of this build's waves waits for them (149 instead of 36 us behind the full grid of level 1)
 static int build_w_operator(padne_ctx *ctx, const padne_csr *A, const padne_csr *P, const SlotRows &ap, long long n_slots,
-                            double c, padne_csr **W_out, int grid_cap = 0, bool keep64 = false) {
+                            double c, padne_csr **W_out, int grid_cap = 0) {
     hipStream_t s = ctx->stream;
     const int n = (int)A->n_rows;
     Scratch sc(ctx);
@@ -3214,110 +3205,20 @@ static int build_w_operator(padne_ctx *ctx, const padne_csr *A, const padne_csr 
     W->rowptr = (int32_t *)pool_alloc(ctx, sizeof(int32_t) * ((size_t)n + 1));
     W->cols = (int32_t *)pool_alloc(ctx, sizeof(int32_t) * ((size_t)n_slots + kPadNnz));
     W->vals32 = (float *)pool_alloc(ctx, sizeof(float) * ((size_t)n_slots + kPadNnz));
-    if (keep64) W->vals = (double *)pool_alloc(ctx, sizeof(double) * ((size_t)n_slots + kPadNnz));      // (its transpose is formed in double)
-    if (!W->rowptr || !W->cols || !W->vals32 || (keep64 && !W->vals)) return PADNE_E_NOMEM;
+    if (!W->rowptr || !W->cols || !W->vals32) return PADNE_E_NOMEM;
     hipLaunchKernelGGL(slot_row_lengths, dim3(nblk(n)), dim3(256), 0, s, n, ap.begin, ap.end, len);
     PADNE_HIP_CHECK(hipGetLastError());
     PADNE_TRY(exclusive_scan_i32_async(ctx, len, W->rowptr, n));
     unsigned gw = nblk(((long long)n + 63) / 64, 4);
     if (grid_cap > 0 && gw > (unsigned)grid_cap) gw = (unsigned)grid_cap;
     hipLaunchKernelGGL(w_from_slots_kernel, dim3(gw), dim3(256), 0, s, n, ap.begin, ap.key, ap.val,
-                       P->rowptr, P->cols, P->vals, A->dinv, c, (const int *)W->rowptr, W->cols, W->vals32, W->vals);
+                       P->rowptr, P->cols, P->vals, A->dinv, c, (const int *)W->rowptr, W->cols, W->vals32);
     PADNE_HIP_CHECK(hipGetLastError());
     // its x-window plan: twelve short runs per tile (spmv.hip, csr_build_xw_plan_wide), on this stream, no look at the host
     W->xw_state = 0;
     PADNE_TRY(csr_build_xw_plan_wide(ctx, W, grid_cap));
     if (W->xw_state != 1) W->xw_state = -1;
     *W_out = w_owner.release();
-    return PADNE_OK;
-}
-
-// ---- two-product form of the small inner levels (AmgLevel::Wt, SU) ---------------------------------------------------
-// entries behind the true end of a matrix whose arrays are sized by a bound: the products stream four entries per lane and
-// load, what lies behind the last entry must be a valid column
-__global__ void csr_zero_behind_end(const int *__restrict__ rowptr, int n_rows, int *__restrict__ cols, double *__restrict__ vals,
-                                    float *__restrict__ vals32) {
-    const int e = rowptr[n_rows] + threadIdx.x;
-    if (threadIdx.x < 8) {
-        cols[e] = 0;
-        if (vals != nullptr) vals[e] = 0.0;
-        if (vals32 != nullptr) vals32[e] = 0.f;
-    }
-}
-__global__ void su_count(int n, const int *__restrict__ ar, const int *__restrict__ wr, int *__restrict__ len) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) len[i] = (ar[i + 1] - ar[i]) + (wr[i + 1] - wr[i]);
-}
-// row i of [S | W]:  s_ij = c d_i (2 delta_ij - c a_ij d_j)  (d = 1 / diag) on the pattern of A, then the row of W with its
-// columns moved behind the n columns of S
-__global__ void su_fill(int n, const int *__restrict__ ar, const int *__restrict__ ac, const double *__restrict__ av,
-                        const double *__restrict__ dinv, const double c, const int *__restrict__ wr, const int *__restrict__ wc,
-                        const float *__restrict__ wv, const int *__restrict__ ur, int *__restrict__ uc, float *__restrict__ uv) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int o = ur[i];
-    const double di = dinv[i];
-    for (int k = ar[i]; k < ar[i + 1]; ++k) {
-        const int j = ac[k];
-        uc[o] = j;
-        uv[o] = (float)(c * di * ((j == i ? 2.0 : 0.0) - c * av[k] * dinv[j]));
-        ++o;
-    }
-    for (int k = wr[i]; k < wr[i + 1]; ++k) {
-        uc[o] = n + wc[k];
-        uv[o] = wv[k];
-        ++o;
-    }
-}
-
-// level L (square A with 1/diag, W with double values kept, damping L.jac settled): W^T, [S | W] and the vector they share.
-// Queued on ctx's stream without a look at the host.
-constexpr long long kSuMaxRows = 400000;      // above that a level's products are bound by bytes: the three-product form moves fewer
-static int build_su_operators(padne_ctx *ctx, AmgLevel &L, long long n_coarse) {
-    hipStream_t s = ctx->stream;
-    const padne_csr *A = L.A;
-    padne_csr *W = L.W;
-    const int n = (int)A->n_rows;
-    PADNE_REQUIRE(W != nullptr && W->vals != nullptr && A->dinv != nullptr && W->n_cols == n_coarse, "two-product form of a level");
-    // W^T through the ordinary transposition (in double), then its single-precision copy
-    PADNE_TRY(transpose(ctx, W, &L.Wt));
-    hipLaunchKernelGGL(csr_zero_behind_end, dim3(1), dim3(64), 0, s, (const int *)L.Wt->rowptr, (int)L.Wt->n_rows, L.Wt->cols,
-                       L.Wt->vals, (float *)nullptr);
-    PADNE_HIP_CHECK(hipGetLastError());
-    L.Wt->hierarchy_operator = true;
-    L.Wt->xw_state = -1;
-    PADNE_TRY(csr_build_f32(ctx, L.Wt));
-    // [S | W]
-    struct CsrDrop { void operator()(padne_csr *m) const { if (m) padne_csr_destroy(m); } };
-    std::unique_ptr<padne_csr, CsrDrop> owner(new padne_csr());
-    padne_csr *U = owner.get();
-    const long long cap = A->nnz + W->nnz;
-    PADNE_REQUIRE(cap < 2147483647LL - kPadNnz, "two-product form: too many entries");
-    U->n_rows = n;
-    U->n_cols = (long long)n + n_coarse;
-    U->nnz = cap;                          // capacity; the row pointers hold the truth
-    U->device = ctx->device;
-    U->owner = ctx;
-    U->hierarchy_operator = true;
-    U->xw_state = -1;
-    U->rowptr = (int32_t *)pool_alloc(ctx, sizeof(int32_t) * ((size_t)n + 1));
-    U->cols = (int32_t *)pool_alloc(ctx, sizeof(int32_t) * ((size_t)cap + kPadNnz));
-    U->vals32 = (float *)pool_alloc(ctx, sizeof(float) * ((size_t)cap + kPadNnz));
-    if (!U->rowptr || !U->cols || !U->vals32) return PADNE_E_NOMEM;
-    Scratch sc(ctx);
-    int *len = nullptr;
-    PADNE_TRY(sc.alloc(&len, (size_t)n + 1));
-    hipLaunchKernelGGL(su_count, dim3(nblk(n)), dim3(256), 0, s, n, (const int *)A->rowptr, (const int *)W->rowptr, len);
-    PADNE_HIP_CHECK(hipGetLastError());
-    PADNE_TRY(exclusive_scan_i32_async(ctx, len, U->rowptr, n));
-    hipLaunchKernelGGL(su_fill, dim3(nblk(n)), dim3(256), 0, s, n, (const int *)A->rowptr, (const int *)A->cols,
-                       (const double *)A->vals, (const double *)A->dinv, L.jac, (const int *)W->rowptr, (const int *)W->cols,
-                       (const float *)W->vals32, (const int *)U->rowptr, U->cols, U->vals32);
-    hipLaunchKernelGGL(csr_zero_behind_end, dim3(1), dim3(64), 0, s, (const int *)U->rowptr, n, U->cols, (double *)nullptr, U->vals32);
-    PADNE_HIP_CHECK(hipGetLastError());
-    L.cat = (float *)pool_alloc(ctx, sizeof(float) * (size_t)((long long)n + n_coarse + 8));
-    if (L.cat == nullptr) return PADNE_E_NOMEM;
-    L.SU = owner.release();
     return PADNE_OK;
 }
 
@@ -3386,9 +3287,6 @@ void amg_destroy(void *p) {
         pool_free(amg->ctx, L.e_ext);
         if (L.R) padne_csr_destroy(L.R);
         if (L.W) padne_csr_destroy(L.W);
-        if (L.Wt) padne_csr_destroy(L.Wt);
-        if (L.SU) padne_csr_destroy(L.SU);
-        pool_free(amg->ctx, L.cat);
         pool_free(amg->ctx, L.b);
         pool_free(amg->ctx, L.xa);
         pool_free(amg->ctx, L.xb);
@@ -3702,9 +3600,7 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         if (rc != PADNE_OK) break;
         AmgLevel &L = amg->levels[(size_t)ks->level];
         if (L.P == nullptr || L.A->dinv == nullptr) continue;
-        // (small levels keep W's values in double as well: the two-product form of a REUSED hierarchy is made from them,
-        //  amg_prepare_reuse)
-        rc = build_w_operator(aux, L.A, L.P, ks->rows, ks->rows.n_slots, L.jac, &L.W, 512, L.A->n_rows <= kSuMaxRows);
+        rc = build_w_operator(aux, L.A, L.P, ks->rows, ks->rows.n_slots, L.jac, &L.W, 512);
     }
     if (rc == PADNE_OK && two) rc = stream_order(aux, ctx);      // the cycle runs on the main stream
     if (rc != PADNE_OK) {
@@ -4320,12 +4216,6 @@ static int amg_apply_f32(padne_ctx *ctx, Amg *amg, const double *r, double *z, d
         return PADNE_E_INVALID;
     }
     bool fused_start = false;      // the restriction onto this level has already written its pre-smoothed start
-    // right-hand side and solution of a level: a level in the two-product form (AmgLevel::SU) keeps its right-hand side and the
-    // solution of the level BELOW it in one vector, [b_l ; x_{l+1}]
-    auto B = [&](int l) { return amg->levels[l].cat != nullptr ? amg->levels[l].cat : (float *)amg->levels[l].b; };
-    auto XB = [&](int l) {
-        return l > 0 && amg->levels[l - 1].cat != nullptr ? amg->levels[l - 1].cat + amg->levels[l - 1].n : (float *)amg->levels[l].xb;
-    };
     // last partitioned level of a row-partitioned hierarchy: the values of the other ranks' vertices after the coarse
     // correction, x1 + P e, are computed here -- x1 came with the down-leg exchange, their rows of P with the setup, e is
     // the tail solution every rank holds -- instead of a second exchange (same arithmetic as on the owning rank: bitwise
@@ -4335,7 +4225,7 @@ static int amg_apply_f32(padne_ctx *ctx, Amg *amg, const double *r, double *z, d
                             amg->tail_slot_idx != nullptr;
     for (int l = 0; l < nl; ++l) {
         AmgLevel &L = amg->levels[l];
-        float *b = B(l), *xa = (float *)L.xa, *tmp = (float *)L.tmp;
+        float *b = (float *)L.b, *xa = (float *)L.xa, *tmp = (float *)L.tmp;
         if (l == nl - 1) {
             if (amg->dist) {
                 // gather level: float pieces travel, the redundant tail cycle runs in double (launch-bound anyway)
@@ -4359,15 +4249,9 @@ static int amg_apply_f32(padne_ctx *ctx, Amg *amg, const double *r, double *z, d
                 break;
             }
             hipLaunchKernelGGL(dense_gemv<float>, dim3((amg->n_coarse + 3) / 4), dim3(256), 0, s, amg->n_coarse,
-                               amg->n_coarse, (const float *)amg->coarse_inv32, (const float *)b, XB(l));
+                               amg->n_coarse, (const float *)amg->coarse_inv32, (const float *)b, (float *)L.xb);
             PADNE_HIP_CHECK(hipGetLastError());
             break;
-        }
-        if (L.SU != nullptr) {
-            // two-product form: the residual of the sweep from zero, restricted, in one product with W^T
-            PADNE_TRY(launch_spmv_f32(ctx, L.Wt, SPMV_PLAIN, b, B(l + 1), nullptr, done_flag, nullptr, nullptr, 0.f));
-            fused_start = false;
-            continue;
         }
         const int gv = (int)std::min<long long>((L.n + 255) / 256, 1024);
         if (l == 0 && entry_done) {
@@ -4396,26 +4280,21 @@ static int amg_apply_f32(padne_ctx *ctx, Amg *amg, const double *r, double *z, d
         // the restriction also leaves the first sweep of the level below (from a zero start: x = c D^-1 b), unless that
         // level is the coarsest (solved directly) -- one short launch less per level
         AmgLevel &Lc = amg->levels[l + 1];
-        fused_start = l + 1 < nl - 1 && Lc.A->dinv32 != nullptr && Lc.SU == nullptr;      // (a two-product level has no first sweep)
+        fused_start = l + 1 < nl - 1 && Lc.A->dinv32 != nullptr;
         if (fused_start)
-            PADNE_TRY(launch_spmv_f32_restrict(ctx, L.R, tmp, B(l + 1), (float *)Lc.xa, done_flag, Lc.A->dinv32,
+            PADNE_TRY(launch_spmv_f32_restrict(ctx, L.R, tmp, (float *)Lc.b, (float *)Lc.xa, done_flag, Lc.A->dinv32,
                                                (float)Lc.jac));
         else
-            PADNE_TRY(launch_spmv_f32(ctx, L.R, SPMV_PLAIN, tmp, B(l + 1), nullptr, done_flag, nullptr, nullptr, 0.f));
+            PADNE_TRY(launch_spmv_f32(ctx, L.R, SPMV_PLAIN, tmp, (float *)Lc.b, nullptr, done_flag, nullptr, nullptr, 0.f));
     }
     for (int l = nl - 2; l >= 0; --l) {
         AmgLevel &L = amg->levels[l];
-        float *b = B(l), *xa = (float *)L.xa;
-        if (L.SU != nullptr) {
-            // x = S b + W e: both sweeps of the right-hand side and the coarse correction, [b ; e] one vector
-            PADNE_TRY(launch_spmv_f32(ctx, L.SU, SPMV_PLAIN, b, XB(l), nullptr, done_flag, nullptr, nullptr, 0.f));
-            continue;
-        }
+        float *b = (float *)L.b, *xa = (float *)L.xa;
         if (L.W != nullptr && amg->dist) {
             // row-partitioned level: the same product, its input the coarse solution with the other ranks' exported values
             // behind it -- computed from the tail solution on the last partitioned level (e_ext), exchanged otherwise: one
             // exchange of the COARSE level's vector instead of one of this level's corrected iterate
-            float *e = XB(l + 1);
+            float *e = (float *)amg->levels[l + 1].xb;
             if (local_halo && l == nl - 2)
                 e = L.e_ext;
             else
@@ -4424,7 +4303,7 @@ static int amg_apply_f32(padne_ctx *ctx, Amg *amg, const double *r, double *z, d
                 PADNE_TRY(launch_spmv_f32_wup_exit(ctx, L.W, e, z, r, partials_rz, done_flag, xa, (const float *)L.tmp,
                                                    L.A->dinv32, (float)L.jac, bb2, z32, nullptr));
             else
-                PADNE_TRY(launch_spmv_f32_wup(ctx, L.W, e, XB(l), done_flag, xa, (const float *)L.tmp, L.A->dinv32,
+                PADNE_TRY(launch_spmv_f32_wup(ctx, L.W, e, (float *)L.xb, done_flag, xa, (const float *)L.tmp, L.A->dinv32,
                                               (float)L.jac));
             continue;
         }
@@ -4432,15 +4311,15 @@ static int amg_apply_f32(padne_ctx *ctx, Amg *amg, const double *r, double *z, d
             // coarse correction + post-smoothing (+ exit) in one product with W = P - c D^-1 A P (tmp still holds the
             // residual of the pre-smoothed iterate that the down-leg restricted)
             if (l == 0)
-                PADNE_TRY(launch_spmv_f32_wup_exit(ctx, L.W, (const float *)XB(1), z, r, partials_rz, done_flag, xa,
+                PADNE_TRY(launch_spmv_f32_wup_exit(ctx, L.W, (const float *)amg->levels[1].xb, z, r, partials_rz, done_flag, xa,
                                                    (const float *)L.tmp, L.A->dinv32, (float)L.jac, bb2, z32,
                                                    spmv_resid_pre_ok(L.A) ? (const float *)b : nullptr));      // (as the down-leg decided)
             else
-                PADNE_TRY(launch_spmv_f32_wup(ctx, L.W, (const float *)XB(l + 1), XB(l), done_flag, xa,
+                PADNE_TRY(launch_spmv_f32_wup(ctx, L.W, (const float *)amg->levels[l + 1].xb, (float *)L.xb, done_flag, xa,
                                               (const float *)L.tmp, L.A->dinv32, (float)L.jac));
             continue;
         }
-        PADNE_TRY(launch_spmv_f32(ctx, L.P, SPMV_ADD, (const float *)XB(l + 1), xa, nullptr, done_flag,
+        PADNE_TRY(launch_spmv_f32(ctx, L.P, SPMV_ADD, (const float *)amg->levels[l + 1].xb, xa, nullptr, done_flag,
                                   nullptr, nullptr, 0.f));
         HaloTicket tk;
         const bool exchange = amg->dist && !(local_halo && l == nl - 2);
@@ -4452,7 +4331,7 @@ static int amg_apply_f32(padne_ctx *ctx, Amg *amg, const double *r, double *z, d
             if (exchange && part == SPMV_INTERIOR) PADNE_TRY(halo_send_f32(ctx, L.halo, xa, done_flag, &tk));
             if (exchange && part == SPMV_BOUNDARY) PADNE_TRY(halo_recv_f32(ctx, L.halo, xa, done_flag, tk));
             if (l > 0)
-                PADNE_TRY(launch_spmv_f32_part(ctx, L.A, SPMV_JACOBI, part, xa, XB(l), nullptr, done_flag, b, L.A->dinv32,
+                PADNE_TRY(launch_spmv_f32_part(ctx, L.A, SPMV_JACOBI, part, xa, (float *)L.xb, nullptr, done_flag, b, L.A->dinv32,
                                                (float)L.jac));
             else
                 PADNE_TRY(launch_spmv_f32_exit_part(ctx, L.A, part, xa, z, r, partials_rz, done_flag, b, L.A->dinv32,
@@ -4606,23 +4485,6 @@ bool amg_supports_batch8(const padne_csr *A0) {
 
 // buffers of the single-precision entry stage, for callers that fuse it into their own kernel (false: double cycle)
 // number of per-workgroup r.z partials the last stage of the cycle writes (the grid of that launch)
-// A hierarchy that is used AGAIN (a further right-hand side on the same matrix: the cached plan of solve_system, the extra
-// solves of regulators) gets the two-product form of its small inner levels (AmgLevel::Wt, SU): one launch less per level
-// and cycle -- 12 of 129 us per iteration at a million unknowns.  Forming W^T and [S | W] costs 0.2-0.4 ms per level, more than
-// the 28 iterations of ONE solve save: a hierarchy that is rebuilt for every solve (the benchmark's step) never pays it.
-int amg_prepare_reuse(padne_ctx *ctx, padne_csr *A0) {
-    Amg *amg = (Amg *)A0->amg;
-    if (amg == nullptr || amg->reuse_prepared || amg->dist || !amg->f32) return PADNE_OK;
-    amg->reuse_prepared = true;
-    const int nl = (int)amg->levels.size();
-    for (int l = 1; l + 1 < nl; ++l) {
-        AmgLevel &L = amg->levels[(size_t)l];
-        if (L.W == nullptr || L.W->vals == nullptr || L.P == nullptr || L.SU != nullptr || L.A->n_rows > kSuMaxRows) continue;
-        PADNE_TRY(build_su_operators(ctx, L, L.P->n_cols));
-    }
-    return PADNE_OK;
-}
-
 int amg_rz_partials(const padne_csr *A0) {
     const Amg *amg = (const Amg *)A0->amg;
     if (amg != nullptr && amg->f32 && !amg->levels.empty() && amg->levels[0].W != nullptr)

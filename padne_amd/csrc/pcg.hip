@@ -578,7 +578,6 @@ static int halo_product_dot(padne_ctx *ctx, const padne_csr *a, double *v, doubl
 }
 
 int amg_setup(padne_ctx *ctx, padne_csr *A0);
-int amg_prepare_reuse(padne_ctx *ctx, padne_csr *A0);
 int amg_apply(padne_ctx *ctx, const padne_csr *A0, const double *r, double *z, double *partials_rz,
               const int32_t *done_flag, const double *bb2 = nullptr, bool entry_done = false, float *z32 = nullptr);
 bool amg_f32_entry_args(const padne_csr *A0, float *jac, const float **dinv32, float **b32, float **xa32);
@@ -1785,7 +1784,6 @@ static int solve_spd_dev_impl(padne_ctx *ctx, const padne_csr *a, const void *b_
         } else if (rc_setup != PADNE_OK) {
             return rc_setup;
         } else {
-            if (!fresh) PADNE_TRY(amg_prepare_reuse(ctx, pm));      // (a hierarchy in use again: the forms that pay from the second solve on)
             double setup_s = 0.0;
             amg_info(pm, &local.levels, &local.operator_complexity, &setup_s, nullptr);
             if (fresh) local.precond_setup_seconds = setup_s;
