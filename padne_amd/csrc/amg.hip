@@ -2883,7 +2883,7 @@ static int transpose(padne_ctx *ctx, const padne_csr *M, padne_csr **T) {
         if (g >= (unsigned)kNumXcd) g -= g % kNumXcd;
         hipLaunchKernelGGL(sort_csr_rows_seg, dim3(g > 0 ? g : 1), dim3(256), 0, s, (int)nc, (const int *)m->rowptr, m->cols, m->vals,
                            n_long, long_list, (const int *)npairs);
-        hipLaunchKernelGGL(sort_listed_csr_rows, dim3(256), dim3(256), 0, s, (const int *)n_long, (const int *)long_list,
+        hipLaunchKernelGGL(sort_listed_csr_rows, dim3(2048), dim3(256), 0, s, (const int *)n_long, (const int *)long_list,
                            (const int *)m->rowptr, m->cols, m->vals);
         e = hipGetLastError();
     }
