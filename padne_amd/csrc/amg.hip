@@ -28,6 +28,7 @@
 #include "common.hpp"
 
 #include <functional>
+#include <type_traits>
 #include <memory>
 
 #include <algorithm>
@@ -1352,15 +1353,178 @@ __global__ __launch_bounds__(128) void spgemm_rows_lds_pipe(int n_rows, const in
     row_len[i] = m;
 }
 
-// Wave-per-row variant for rows with tens to hundreds of products (R * (A P) on every level, A * P below the
-// finest): the thread-per-row list kernels above serialise ~100 sorted insertions per thread, this one spreads a
-// row over the 64 lanes of a wave.
-//   1. lanes = entries of the X row: lengths of the Y rows they select, wave prefix sum -> product offsets;
-//   2. the products (column, x*y) are written to LDS in generation order (k, q), lane-strided;
-//   3. distinct columns: open-addressing hash set in LDS (integer CAS only), compacted and rank-sorted;
-//   4. lane j owns the j-th distinct column and adds ITS products in generation order while all lanes walk the
-//      product list together (broadcast LDS reads) -> bit-identical to spgemm_rows, no float atomics.
-// Rows that do not fit (X row > 64 entries, > CAPP products, > HT/2 distinct columns) are flagged for spgemm_rows_redo.
+// Wave-per-row (or half-wave-per-row) kernels for rows with tens to hundreds of products (R * (A P) on every level,
+// A * P below the finest): the thread-per-row list kernels above serialise ~100 sorted insertions per thread, these
+// spread a row over the lanes of a wave.  A row is worked through in chunks of LANES products, in generation order:
+//   1. lanes = entries of the X row: lengths of the Y rows they select, prefix sum -> product offsets.  The entries
+//      that have products are packed, and a bit per entry at its first product tells product p which entry it belongs
+//      to (a population count instead of a bisection);
+//   2. a chunk's products (column c, x*y) look c up in an open-addressing table in LDS (integer CAS only).  The lane
+//      that claims a free slot numbers the column (in order of appearance) and leaves the number beside the key;
+//   3. every product sets ITS lane's bit in the mask of its column, and lane j -- owner of column number j -- adds the
+//      products its mask names, lowest lane first, to a register.  Chunks in order and bits in lane order: every
+//      column sees its products in generation order, hence bit-identical to spgemm_rows with no float atomics;
+//   4. after the last chunk the owners rank their columns among the row's and store (column, sum) in rank order.
+// (Before: the products were stored, the table compacted and rank-sorted, every product bisected the sorted columns
+// and one ballot per column told its owner which products to add -- ~2.5 times the wave instructions, which is what
+// bounds these kernels: R (A P) of C4's fine level 1.35 ms.)
+// Rows that do not fit (X row > LANES entries, > CAPP products, > HT/2 distinct columns) are flagged (row_len -1).
+template <int CAPP, int HT, int LANES>
+struct SpgemmRowLds {
+    using Mask = typename std::conditional<LANES == 64, unsigned long long, unsigned>::type;
+    int ht[HT];                        // column keys
+    int hidx[HT];                      // number of the column in that slot
+    int dk[HT / 2];                    // column by number
+    Mask mask[HT / 2];                 // lanes of the current chunk whose product belongs to the column
+    double pvb[LANES];                 // the chunk's products
+    double xs[LANES];                  // packed X entries: value, first Y position, first product
+    int ys[LANES];
+    int offc[LANES];
+    unsigned long long bits[CAPP / 64];
+};
+
+// All lanes of the wave call this together (`has_row` false: the lane group only keeps step).  Returns the number of
+// distinct columns stored at K / V, or -1 when the row does not fit.
+template <int CAPP, int HT, int LANES>
+__device__ __forceinline__ int spgemm_row_by_masks(SpgemmRowLds<CAPP, HT, LANES> &S, const int sl, const int sub,
+                                                   const bool has_row, const int nx, const int len, const int ystart,
+                                                   const double a, const int *__restrict__ yc, const double *__restrict__ yv,
+                                                   const int ycs, long long *__restrict__ K, double *__restrict__ V) {
+    using Mask = typename SpgemmRowLds<CAPP, HT, LANES>::Mask;
+    static_assert(CAPP % 64 == 0 && CAPP / 64 <= LANES && 64 % LANES == 0, "bits of the product offsets");
+    constexpr int NC = (HT / 2 + LANES - 1) / LANES;          // columns per owner lane
+    constexpr int EMPTY = -1;
+    const unsigned long long sub_mask = (LANES == 64 ? ~0ull : ((1ull << LANES) - 1ull));
+    const int shift = sub * LANES;
+    const unsigned long long below = (1ull << sl) - 1ull;
+    int incl = len;
+#pragma unroll
+    for (int d = 1; d < LANES; d <<= 1) {
+        const int t = __shfl_up(incl, d, LANES);
+        if (sl >= d) incl += t;
+    }
+    const int np = __shfl(incl, LANES - 1, LANES);
+    const bool live = has_row && nx <= LANES && np <= CAPP;
+    const unsigned long long have = (__ballot(live && len > 0) >> shift) & sub_mask;
+    if (live) {
+        for (int h = sl; h < HT; h += LANES) S.ht[h] = EMPTY;
+        for (int h = sl; h < HT / 2; h += LANES) S.mask[h] = (Mask)0;
+        if (sl < CAPP / 64) S.bits[sl] = 0ull;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (len > 0) {
+            const int pos = __popcll(have & below);
+            const int o = incl - len;
+            S.offc[pos] = o;
+            S.ys[pos] = ystart;
+            S.xs[pos] = a;
+            atomicOr(&S.bits[o >> 6], 1ull << (o & 63));
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    int np_w = live ? np : 0;                                 // chunks the wave walks: those of its longest row
+    if (LANES == 64) {
+        np_w = __builtin_amdgcn_readfirstlane(np_w);
+    } else {
+        int m = 0;
+#pragma unroll
+        for (int g = 0; g < 64 / LANES; ++g) m = max(m, __builtin_amdgcn_readlane(np_w, g * LANES));
+        np_w = m;
+    }
+    int cnt = 0, pre = 0;
+    bool overflow = false;
+    double acc[NC];
+#pragma unroll
+    for (int u = 0; u < NC; ++u) acc[u] = -0.0;               // -0 + v == v for every v: the first product is taken as it is
+    for (int base = 0; base < np_w; base += LANES) {
+        const int p = base + sl;
+        const bool mine = live && p < np;
+        unsigned long long word = 0ull;
+        if (live && base < np) word = S.bits[base >> 6];
+        int c = 0;
+        if (mine) {
+            const int kk = pre + __popcll(word & (~0ull >> (63 - (p & 63)))) - 1;
+            const int q = S.ys[kk] + (p - S.offc[kk]);
+            c = yc[(long long)q * ycs];
+            S.pvb[sl] = S.xs[kk] * yv[q];
+        }
+        if (((base + LANES) & 63) == 0) pre += __popcll(word);
+        bool pending = mine;
+        unsigned h = ((unsigned)c * 2654435761u) >> 7;
+        int probes = 0, idx = -1;
+        for (;;) {
+            int old = EMPTY - 1;
+            if (pending) {
+                h &= (HT - 1);
+                old = atomicCAS(&S.ht[h], EMPTY, c);
+            }
+            const bool won = pending && old == EMPTY;
+            const unsigned long long wm = (__ballot(won) >> shift) & sub_mask;
+            if (won) {
+                idx = cnt + __popcll(wm & below);
+                S.hidx[h] = idx;
+                if (idx < HT / 2) S.dk[idx] = c;
+            }
+            cnt += __popcll(wm);
+            // (LDS serves a wave's accesses in the order they were issued: the number stored by the winner is there
+            // for the lanes that met its key in the same round)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (pending) {
+                if (old == EMPTY) {
+                    pending = false;
+                } else if (old == c) {
+                    idx = S.hidx[h];
+                    pending = false;
+                } else {
+                    ++h;
+                    if (++probes >= HT) {
+                        overflow = true;
+                        pending = false;
+                    }
+                }
+            }
+            if (!__any(pending)) break;
+        }
+        if (mine && idx >= 0 && idx < HT / 2) atomicOr(&S.mask[idx], (Mask)1 << sl);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < NC; ++u) {
+            const int j = sl + u * LANES;
+            if (live && j < cnt && j < HT / 2) {
+                Mask m = S.mask[j];
+                if (m != (Mask)0) {
+                    S.mask[j] = (Mask)0;
+                    do {
+                        const int b = (LANES == 64 ? __ffsll((long long)m) : __ffs((int)m)) - 1;
+                        acc[u] += S.pvb[b];
+                        m &= m - (Mask)1;
+                    } while (m != (Mask)0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+    const bool any_overflow = ((__ballot(overflow) >> shift) & sub_mask) != 0ull;
+    const int nd = cnt;
+    const bool ok = live && !any_overflow && nd <= HT / 2;
+#pragma unroll
+    for (int u = 0; u < NC; ++u) {
+        const int j = sl + u * LANES;
+        if (ok && j < nd) {
+            const int kq = S.dk[j];
+            int rank = 0;
+            for (int t = 0; t < nd; ++t) rank += S.dk[t] < kq ? 1 : 0;
+            K[rank] = (long long)kq << 32;
+            V[rank] = acc[u];
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    return ok ? nd : -1;
+}
+
 template <int CAPP, int HT>
 __global__ __launch_bounds__(256) void spgemm_rows_wave(int n_rows, const int *__restrict__ xr, const int *__restrict__ xc,
                                                         const double *__restrict__ xv, const int *__restrict__ yr,
@@ -1371,18 +1535,8 @@ __global__ __launch_bounds__(256) void spgemm_rows_wave(int n_rows, const int *_
                                                         const int *__restrict__ list_count = nullptr) {
     // row_list / list_count: the kernel works through that list of rows (the ones an earlier pass left, collected by
     // collect_pending_rows) instead of striding over all rows looking for them
-    __shared__ int s_pc[4][CAPP];
-    __shared__ double s_pv[4][CAPP];
-    __shared__ int s_ht[4][HT];
-    __shared__ int s_dk[4][HT / 2];
-    __shared__ int s_sk[4][HT / 2];
-    __shared__ int s_off[4][65];
-    __shared__ int s_ys[4][64];
-    __shared__ double s_xv[4][64];
+    __shared__ SpgemmRowLds<CAPP, HT, 64> s_rows[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int *pc = s_pc[w], *ht = s_ht[w], *dk = s_dk[w], *sk = s_sk[w], *off = s_off[w], *ys = s_ys[w];
-    double *pv = s_pv[w], *xs = s_xv[w];
-    constexpr int EMPTY = -1;
     // The loads that lead to a row's products form a chain of four dependent global accesses (xr -> xc/xv -> yr ->
     // yc/yv); the first three are issued one row ahead so that only the last one is exposed.
     const int stride = gridDim.x * 4;
@@ -1410,130 +1564,17 @@ __global__ __launch_bounds__(256) void spgemm_rows_wave(int n_rows, const int *_
     for (int t = blockIdx.x * 4 + w; t < n_iter; t += stride) {
         const int nx = nx_n, len = len_n, ystart = ystart_n, i = row_n;
         const double a = a_n;
-        const bool skip = only_flagged && row_len[i] >= 0;      // finished by the sub-wave pass
+        const bool skip = only_flagged && row_len[i] >= 0;      // finished by an earlier pass
         prefetch(t + stride);
         if (skip) continue;
-        if (nx > 64) {
-            if (lane == 0) row_len[i] = -1;
-            continue;
-        }
-        // 1. product offsets
-        int incl = len;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int t = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += t;
-        }
-        const int np = __shfl(incl, 63, 64);
-        if (np > CAPP) {
-            if (lane == 0) row_len[i] = -1;
-            continue;
-        }
-        off[lane] = incl - len;
-        if (lane == 63) off[64] = np;
-        ys[lane] = ystart;
-        xs[lane] = a;
-        for (int h = lane; h < HT; h += 64) ht[h] = EMPTY;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        // 2. products in generation order, 3a. hash-set insertion of their columns
-        bool overflow = false;
-        for (int p = lane; p < np; p += 64) {
-            int lo = 0, hi = nx;                       // largest k with off[k] <= p
-            while (hi - lo > 1) {
-                const int m = (lo + hi) >> 1;
-                if (off[m] <= p) lo = m; else hi = m;
-            }
-            const int q = ys[lo] + (p - off[lo]);
-            const int c = yc[(long long)q * ycs];
-            pc[p] = c;
-            pv[p] = xs[lo] * yv[q];
-            unsigned h = ((unsigned)c * 2654435761u) >> 7;
-            int probes = 0;
-            for (;;) {
-                h &= (HT - 1);
-                const int old = atomicCAS(&ht[h], EMPTY, c);
-                if (old == EMPTY || old == c) break;
-                ++h;
-                if (++probes >= HT) { overflow = true; break; }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        // 3b. compact the table into dk[0..nd)
-        int nd = 0;
-        for (int h0 = 0; h0 < HT; h0 += 64) {
-            const int kv = ht[h0 + lane];
-            const unsigned long long mask = __ballot(kv != EMPTY);
-            const int pos = nd + __popcll(mask & ((1ull << lane) - 1ull));
-            if (kv != EMPTY && pos < HT / 2) dk[pos] = kv;
-            nd += __popcll(mask);
-        }
-        if (__any(overflow) || nd > HT / 2) {
-            if (lane == 0) row_len[i] = -1;
-            __builtin_amdgcn_wave_barrier();
-            continue;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        // 3c. rank sort (keys are distinct)
-        for (int q = lane; q < nd; q += 64) {
-            const int kq = dk[q];
-            int rank = 0;
-            for (int t = 0; t < nd; ++t) rank += dk[t] < kq ? 1 : 0;
-            sk[rank] = kq;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        // 4. every lane sums the products of its column(s) in generation order
-        long long *K = key + slot_ptr[i];
-        double *V = val + slot_ptr[i];
-        // (ranks by bisection + one ballot per rank instead of every lane walking the whole product list: see
-        // spgemm_rows_sub, step 4)
-        for (int q0 = 0; q0 < nd; q0 += 64) {
-            const int q = q0 + lane;
-            const int q1 = min(q0 + 64, nd);
-            double acc = 0.0;
-            bool first = true;
-            for (int base = 0; base < np; base += 64) {
-                const int p = base + lane;
-                int rk = -1;
-                if (p < np) {
-                    const int c = pc[p];
-                    int lo = 0, hi = nd;                   // largest t with sk[t] <= c (c is one of them)
-                    while (hi - lo > 1) {
-                        const int m = (lo + hi) >> 1;
-                        if (sk[m] <= c) lo = m; else hi = m;
-                    }
-                    rk = lo;
-                }
-                unsigned long long mine = 0ull;
-                for (int t = q0; t < q1; ++t) {
-                    const unsigned long long m = __ballot(rk == t);
-                    if (q == t) mine = m;
-                }
-                while (mine != 0ull) {
-                    const int b = __ffsll((long long)mine) - 1;
-                    const double v = pv[base + b];
-                    acc = first ? v : acc + v;
-                    first = false;
-                    mine &= mine - 1ull;
-                }
-            }
-            if (q < nd) {
-                K[q] = (long long)sk[q] << 32;
-                V[q] = acc;
-            }
-        }
+        const int nd = spgemm_row_by_masks<CAPP, HT, 64>(s_rows[w], lane, 0, true, nx, len, ystart, a, yc, yv, ycs,
+                                                         key + slot_ptr[i], val + slot_ptr[i]);
         if (lane == 0) row_len[i] = nd;
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
-// The same algorithm with LANES (32) lanes per row, i.e. two rows per wave and half the LDS per row: the wave
-// kernel above is bound by the latency of its dependent phases, not by issue slots (~750 wave instructions per row
-// against 7 us per row at full occupancy), so what counts is the number of rows in flight per CU.  Rows that do not
-// fit the smaller limits are flagged and finished by the wave kernel (only_flagged) and, beyond that, spgemm_rows_redo.
+// The same with LANES (32) lanes per row, i.e. two rows per wave and half the LDS per row.  Rows that do not fit the
+// smaller limits are flagged and finished by the wave kernel (only_flagged) and, beyond that, spgemm_rows_redo.
 template <int CAPP, int HT, int LANES>
 __global__ __launch_bounds__(256) void spgemm_rows_sub(int n_rows, const int *__restrict__ xr, const int *__restrict__ xc,
                                                        const double *__restrict__ xv, const int *__restrict__ yr,
@@ -1541,20 +1582,9 @@ __global__ __launch_bounds__(256) void spgemm_rows_sub(int n_rows, const int *__
                                                        const int *__restrict__ slot_ptr, long long *__restrict__ key,
                                                        double *__restrict__ val, int *__restrict__ row_len) {
     constexpr int G = 256 / LANES;                    // rows (lane groups) per workgroup
-    __shared__ int s_pc[G][CAPP];
-    __shared__ double s_pv[G][CAPP];
-    __shared__ int s_ht[G][HT];
-    __shared__ int s_dk[G][HT / 2];
-    __shared__ int s_sk[G][HT / 2];
-    __shared__ int s_off[G][LANES + 1];
-    __shared__ int s_ys[G][LANES];
-    __shared__ double s_xv[G][LANES];
+    __shared__ SpgemmRowLds<CAPP, HT, LANES> s_rows[G];
     const int lane = threadIdx.x & 63;
     const int sl = lane % LANES, sub = lane / LANES, g = threadIdx.x / LANES;
-    const unsigned long long sub_mask = (LANES == 64 ? ~0ull : ((1ull << LANES) - 1ull));
-    int *pc = s_pc[g], *ht = s_ht[g], *dk = s_dk[g], *sk = s_sk[g], *off = s_off[g], *ys = s_ys[g];
-    double *pv = s_pv[g], *xs = s_xv[g];
-    constexpr int EMPTY = -1;
     // every XCD sweeps its own contiguous eighth of the rows (see xcd_bid): the rows of Y that neighbouring rows of X
     // gather (the slots of A P around an aggregate) are then still in that XCD's L2 when the next row asks for them
     const int nslab = (gridDim.x % kNumXcd == 0) ? kNumXcd : 1;
@@ -1578,121 +1608,16 @@ __global__ __launch_bounds__(256) void spgemm_rows_sub(int n_rows, const int *__
         }
     };
     prefetch(row_first);
-    for (int i = row_first; i < row_end; i += stride) {
+    // (the lane groups of a wave stay together to the end of the longer sweep: the row routine is called wave-wide)
+    for (int i = row_first; __any(i < row_end); i += stride) {
+        const bool has_row = i < row_end;
         const int nx = nx_n, len = len_n, ystart = ystart_n;
         const double a = a_n;
         prefetch(i + stride);
-        if (nx > LANES) {
-            if (sl == 0) row_len[i] = -1;
-            continue;
-        }
-        int incl = len;
-#pragma unroll
-        for (int d = 1; d < LANES; d <<= 1) {
-            const int t = __shfl_up(incl, d, LANES);
-            if (sl >= d) incl += t;
-        }
-        const int np = __shfl(incl, LANES - 1, LANES);
-        if (np > CAPP) {
-            if (sl == 0) row_len[i] = -1;
-            continue;
-        }
-        off[sl] = incl - len;
-        if (sl == LANES - 1) off[LANES] = np;
-        ys[sl] = ystart;
-        xs[sl] = a;
-        for (int h = sl; h < HT; h += LANES) ht[h] = EMPTY;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        bool overflow = false;
-        for (int p = sl; p < np; p += LANES) {
-            int lo = 0, hi = nx;
-            while (hi - lo > 1) {
-                const int m = (lo + hi) >> 1;
-                if (off[m] <= p) lo = m; else hi = m;
-            }
-            const int q = ys[lo] + (p - off[lo]);
-            const int c = yc[(long long)q * ycs];
-            pc[p] = c;
-            pv[p] = xs[lo] * yv[q];
-            unsigned h = ((unsigned)c * 2654435761u) >> 7;
-            int probes = 0;
-            for (;;) {
-                h &= (HT - 1);
-                const int old = atomicCAS(&ht[h], EMPTY, c);
-                if (old == EMPTY || old == c) break;
-                ++h;
-                if (++probes >= HT) { overflow = true; break; }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        int nd = 0;
-        for (int h0 = 0; h0 < HT; h0 += LANES) {
-            const int kv = ht[h0 + sl];
-            const unsigned long long mask = (__ballot(kv != EMPTY) >> (sub * LANES)) & sub_mask;
-            const int pos = nd + __popcll(mask & ((1ull << sl) - 1ull));
-            if (kv != EMPTY && pos < HT / 2) dk[pos] = kv;
-            nd += __popcll(mask);
-        }
-        const bool any_overflow = ((__ballot(overflow) >> (sub * LANES)) & sub_mask) != 0ull;
-        if (any_overflow || nd > HT / 2) {
-            if (sl == 0) row_len[i] = -1;
-            continue;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        for (int q = sl; q < nd; q += LANES) {
-            const int kq = dk[q];
-            int rank = 0;
-            for (int t = 0; t < nd; ++t) rank += dk[t] < kq ? 1 : 0;
-            sk[rank] = kq;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        long long *K = key + slot_ptr[i];
-        double *V = val + slot_ptr[i];
-        // 4. lane q owns the q-th distinct column (nd <= HT / 2 <= LANES) and adds ITS products in generation order.
-        //    Every lane walking the whole product list (np broadcast reads and compares per lane, nd of LANES lanes with
-        //    anything to add) was instruction-bound: ~550 wave instructions for the 92 products of a row of R (A P) on the
-        //    fine level, 1.5 of the kernel's 2.7 ms.  Instead the products find the rank of their column by bisection in
-        //    the sorted list, a ballot per rank tells lane q which products of the chunk are its own, and it adds just
-        //    those -- still in generation order (chunks in order, bits of a ballot in lane order).
-        static_assert(HT / 2 <= LANES, "one lane per distinct column");
-        double acc = 0.0;
-        bool first = true;
-        for (int base = 0; base < np; base += LANES) {
-            const int p = base + sl;
-            int rk = -1;
-            if (p < np) {
-                const int c = pc[p];
-                int lo = 0, hi = nd;                       // largest q with sk[q] <= c (c is one of them)
-                while (hi - lo > 1) {
-                    const int m = (lo + hi) >> 1;
-                    if (sk[m] <= c) lo = m; else hi = m;
-                }
-                rk = lo;
-            }
-            unsigned long long mine = 0ull;
-            for (int q = 0; q < nd; ++q) {
-                const unsigned long long m = __ballot(rk == q);
-                if (sl == q) mine = m;
-            }
-            mine = (mine >> (sub * LANES)) & sub_mask;
-            while (mine != 0ull) {
-                const int b = __ffsll((long long)mine) - 1;
-                const double v = pv[base + b];
-                acc = first ? v : acc + v;
-                first = false;
-                mine &= mine - 1ull;
-            }
-        }
-        if (sl < nd) {
-            K[sl] = (long long)sk[sl] << 32;
-            V[sl] = acc;
-        }
-        if (sl == 0) row_len[i] = nd;
-        __builtin_amdgcn_wave_barrier();
+        const int place = has_row ? slot_ptr[i] : 0;
+        const int nd = spgemm_row_by_masks<CAPP, HT, LANES>(s_rows[g], sl, sub, has_row, nx, len, ystart, a, yc, yv, ycs,
+                                                            key + place, val + place);
+        if (has_row && sl == 0) row_len[i] = nd;
     }
 }
 
@@ -3048,7 +2973,7 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
                 // short rows: two rows per wave with small limits first (2.5 KiB of LDS per row: 56 rows in flight per
                 // CU), then one row per wave for the rows that did not fit
                 unsigned gs = (unsigned)std::min<long long>(((long long)n + 7) / 8, 16384);
-                hipLaunchKernelGGL((spgemm_rows_sub<128, 64, 32>), dim3(gs), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
+                hipLaunchKernelGGL((spgemm_rows_sub<256, 64, 32>), dim3(gs), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
                                    y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len);
                 hipLaunchKernelGGL(collect_pending_rows, dim3(nblk(n)), dim3(256), 0, s, n, (const int *)row_len, pend, pend_count);
                 hipLaunchKernelGGL((spgemm_rows_wave<256, 128>), dim3(gl), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
@@ -3401,7 +3326,7 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
     PADNE_TRY(csr_build_dinv(ctx, A0));
     PADNE_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
     t_amg_verbose = ctx->opt.verbose_amg;
-    padne_ctx *aux = aux_context(ctx);
+    padne_ctx *aux = ctx->opt.setup_one_stream ? nullptr : aux_context(ctx);
     if (aux == nullptr) aux = ctx;
     const bool two = aux != ctx;
     // single-precision cycle?  (decided from 1/diag of the fine matrix, before anything is queued)

@@ -35,6 +35,7 @@ void options_from_env(padne_options *o) {
     o->no_p2p = on("PADNE_NO_P2P");
     o->no_split = on("PADNE_NO_SPLIT");
     o->no_xwindow = on("PADNE_NO_XWINDOW");
+    o->setup_one_stream = on("PADNE_SETUP_ONE_STREAM");
     if (const char *e = getenv("PADNE_CG_SINGLE_REDUCTION")) o->cg_single_reduction = atoi(e) != 0 ? 1 : 0;
     if (const char *e = getenv("PADNE_LOCKSTEP_NARROW")) o->lockstep_narrow = atoi(e);
     if (const char *e = getenv("PADNE_AMG_COARSE_N")) o->amg_coarse_n = std::min(4096, std::max(16, atoi(e)));

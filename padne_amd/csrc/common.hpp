@@ -122,6 +122,7 @@ struct padne_options {
     bool no_p2p = false;               // PADNE_NO_P2P=1: halo exchanges as all-gathers
     bool no_split = false;             // PADNE_NO_SPLIT=1: products behind an exchange in one launch
     bool no_xwindow = false;           // PADNE_NO_XWINDOW=1: no x-window plans (SpMV and the setup kernels that use them)
+    bool setup_one_stream = false;     // PADNE_SETUP_ONE_STREAM=1: the side work of the multigrid setup on the main stream (traces with standalone kernel times)
     int cg_single_reduction = -1;      // PADNE_CG_SINGLE_REDUCTION=0|1: force the loop form (default: by communicator)
     int lockstep_narrow = -1;          // PADNE_LOCKSTEP_NARROW=0|2: never / always the narrow lockstep widths
     // sizes

@@ -621,6 +621,28 @@ def test_windowed_setup_kernels_build_the_same_hierarchy(ctx, switches, hub):
     assert abs(ops_w[1][0] - ref).max() <= 1e-12 * abs(ref).max()
 
 
+def test_setup_on_one_stream_builds_the_same_hierarchy(ctx, switches):
+    """PADNE_SETUP_ONE_STREAM=1 (a switch for kernel traces: standalone times of the setup's side kernels) queues the
+    side work of the multigrid setup on the main stream: the same kernels in another order of execution, hence the same
+    operators and the same solution bit for bit."""
+    A, b, _, _, _ = layered_spd(2, 150, 130, 5)
+
+    def hierarchy():
+        d = ctx.csr_from_scipy(A)
+        res = d.solve_spd(b, precond="amg")
+        ops = [(d.amg_level(l, "A"), d.amg_level(l, "P")) for l in range(res.levels - 1)]
+        d.close()
+        return res, ops
+    res_two, ops_two = hierarchy()
+    switches.set("PADNE_SETUP_ONE_STREAM", "1")
+    res_one, ops_one = hierarchy()
+    assert res_one.levels == res_two.levels >= 2 and res_one.iterations == res_two.iterations
+    assert np.array_equal(res_one.x, res_two.x)
+    for (A1, P1), (A2, P2) in zip(ops_one, ops_two):
+        for U, V in ((A1, A2), (P1, P2)):
+            assert np.array_equal(U.indptr, V.indptr) and np.array_equal(U.indices, V.indices) and np.array_equal(U.data, V.data)
+
+
 @pytest.mark.parametrize("precision", ["f32", "f64"])
 def test_multigrid_preconditioner_is_symmetric_positive_definite(ctx, switches, precision):
     """The cycle runs on single-precision copies of its operators by default (PADNE_AMG_F64=1: double): a fixed
