@@ -1239,7 +1239,8 @@ __global__ __launch_bounds__(128) void spgemm_rows_lds_pipe(int n_rows, const in
                                                             const int *__restrict__ ye, const int *__restrict__ slot_ptr,
                                                             long long *__restrict__ key, double *__restrict__ val,
                                                             int *__restrict__ row_len, int *__restrict__ begin) {
-    __shared__ int Kc[CAP][128];
+    static_assert(CAP % 2 == 0, "keys are kept in pairs");
+    __shared__ int2 Kc[CAP / 2][128];
     __shared__ double Vc[CAP][128];
     const int t = threadIdx.x;
     const int i = xcd_bid() * 128 + t;
@@ -1247,21 +1248,36 @@ __global__ __launch_bounds__(128) void spgemm_rows_lds_pipe(int n_rows, const in
     if (begin == nullptr && !live) return;
     int m = 0;
     bool overflow = false;
-    auto insert = [&](const int c, const double v) {
-        int lo = 0;
-        while (lo < m && Kc[lo][t] < c) ++lo;          // lists are a handful of entries long
-        if (lo < m && Kc[lo][t] == c) {
-            Vc[lo][t] += v;
-        } else if (m == CAP) {
-            overflow = true;
-        } else {
-            for (int u = m; u > lo; --u) {
-                Kc[u][t] = Kc[u - 1][t];
-                Vc[u][t] = Vc[u - 1][t];
+    // The list of a row is kept in order of APPEARANCE and sorted once at the end.  (It used to be kept sorted: a search
+    // loop, a shift loop and three-way branching per product, each lane with its own trip counts -- 4150 scalar and 1700
+    // vector instructions per wave of 64 rows, the scalar unit 72 % busy: the kernel was bound by the issue of the
+    // instructions that steer divergent lanes.)  Now a product is compared with the keys of the list as far as the longest
+    // list of the wave reaches -- free places hold -1, no column -- and is either added to the sum it found or appended:
+    // straight-line code under a predicate, the sums of a column still in generation order.
+#pragma unroll
+    for (int u = 0; u < CAP / 2; ++u) Kc[u][t] = make_int2(-1, -1);
+    auto insert = [&](const bool act, const int c, const double v) {
+        int pos = -1;
+#pragma unroll
+        for (int u = 0; u < CAP; u += 2) {
+            if (__all(u >= m)) break;
+            const int2 kk = Kc[u >> 1][t];
+            pos = kk.x == c ? u : pos;
+            pos = kk.y == c ? u + 1 : pos;
+        }
+        if (act && !overflow) {
+            const bool found = pos >= 0;
+            if (!found && m == CAP) {
+                overflow = true;
+            } else {
+                const int p = found ? pos : m;
+                const double base = found ? Vc[p][t] : -0.0;      // -0 + v == v: the first product is taken as it is
+                Vc[p][t] = base + v;
+                if (!found) {
+                    reinterpret_cast<int *>(&Kc[p >> 1][t])[p & 1] = c;
+                    ++m;
+                }
             }
-            Kc[lo][t] = c;
-            Vc[lo][t] = v;
-            ++m;
         }
     };
     const int x0 = live ? xr[i] : 0, x1 = live ? xr[i + 1] : 0;
@@ -1314,9 +1330,9 @@ __global__ __launch_bounds__(128) void spgemm_rows_lds_pipe(int n_rows, const in
             if (u + 1 < KC) fetch(u + 1, cb[(u + 1) & 1], vb[(u + 1) & 1]);
 #pragma unroll
             for (int w = 0; w < QC; ++w)
-                if (w < ln[u] && !overflow) insert(cb[u & 1][w], a[u] * vb[u & 1][w]);
+                if (__any(w < ln[u])) insert(w < ln[u], cb[u & 1][w], a[u] * vb[u & 1][w]);
             for (int q = QC; q < ln[u] && !overflow; ++q)          // a Y row longer than the buffer: the rest one by one
-                insert(yc[(long long)(ys[u] + q) * YCS], a[u] * yv[ys[u] + q]);
+                insert(true, yc[(long long)(ys[u] + q) * YCS], a[u] * yv[ys[u] + q]);
         }
     }
     int place = live ? slot_ptr[i] : 0;
@@ -1346,9 +1362,24 @@ __global__ __launch_bounds__(128) void spgemm_rows_lds_pipe(int n_rows, const in
     }
     long long *K = key + place;
     double *V = val + place;
-    for (int u = 0; u < m; ++u) {
-        K[u] = (long long)Kc[u][t] << 32;
-        V[u] = Vc[u][t];
+    // the list goes out in column order: an entry's place is the number of smaller keys
+    int kr[CAP];
+#pragma unroll
+    for (int u = 0; u < CAP; u += 2) {
+        const int2 kk = Kc[u >> 1][t];
+        kr[u] = u < m ? kk.x : 2147483647;
+        kr[u + 1] = u + 1 < m ? kk.y : 2147483647;
+    }
+#pragma unroll
+    for (int u = 0; u < CAP; ++u) {
+        if (__all(u >= m)) break;
+        int rank = 0;
+#pragma unroll
+        for (int w = 0; w < CAP; ++w) rank += kr[w] < kr[u] ? 1 : 0;
+        if (u < m) {
+            K[rank] = (long long)kr[u] << 32;
+            V[rank] = Vc[u][t];
+        }
     }
     row_len[i] = m;
 }
