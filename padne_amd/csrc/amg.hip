@@ -1400,6 +1400,20 @@ __global__ __launch_bounds__(128) void spgemm_rows_lds_pipe(int n_rows, const in
 // and one ballot per column told its owner which products to add -- ~2.5 times the wave instructions, which is what
 // bounds these kernels: R (A P) of C4's fine level 1.35 ms.)
 // Rows that do not fit (X row > LANES entries, > CAPP products, > HT/2 distinct columns) are flagged (row_len -1).
+// Inclusive prefix sum over groups of LANES (32 or 64) lanes, all lanes active: four shifts within the rows of 16 lanes,
+// then the last lane of a row added to the whole next row (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3)
+// -- six vector instructions instead of five rounds of index arithmetic, ds_bpermute and select.
+template <int LANES>
+__device__ __forceinline__ int scan_incl_lanes(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    if (LANES == 64) x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return x;
+}
+
 template <int CAPP, int HT, int LANES>
 struct SpgemmRowLds {
     using Mask = typename std::conditional<LANES == 64, unsigned long long, unsigned>::type;
@@ -1428,13 +1442,10 @@ __device__ __forceinline__ int spgemm_row_by_masks(SpgemmRowLds<CAPP, HT, LANES>
     const unsigned long long sub_mask = (LANES == 64 ? ~0ull : ((1ull << LANES) - 1ull));
     const int shift = sub * LANES;
     const unsigned long long below = (1ull << sl) - 1ull;
-    int incl = len;
-#pragma unroll
-    for (int d = 1; d < LANES; d <<= 1) {
-        const int t = __shfl_up(incl, d, LANES);
-        if (sl >= d) incl += t;
-    }
-    const int np = __shfl(incl, LANES - 1, LANES);
+    static_assert(LANES == 32 || LANES == 64, "the scan below");
+    const int incl = scan_incl_lanes<LANES>(len);
+    const int np = LANES == 64 ? __builtin_amdgcn_readlane(incl, 63)
+                               : (sub != 0 ? __builtin_amdgcn_readlane(incl, 63) : __builtin_amdgcn_readlane(incl, 31));
     const bool live = has_row && nx <= LANES && np <= CAPP;
     const unsigned long long have = (__ballot(live && len > 0) >> shift) & sub_mask;
     if (live) {
@@ -1482,14 +1493,16 @@ __device__ __forceinline__ int spgemm_row_by_masks(SpgemmRowLds<CAPP, HT, LANES>
         if (((base + LANES) & 63) == 0) pre += __popcll(word);
         bool pending = mine;
         unsigned h = ((unsigned)c * 2654435761u) >> 7;
-        int probes = 0, idx = -1;
-        for (;;) {
-            int old = EMPTY - 1;
-            if (pending) {
-                h &= (HT - 1);
-                old = atomicCAS(&S.ht[h], EMPTY, c);
+        int idx = -1;
+        for (int round = 0; __any(pending); ++round) {
+            if (round == HT) {                                 // the table is full of other columns
+                overflow = overflow || pending;
+                break;
             }
-            const bool won = pending && old == EMPTY;
+            h &= (HT - 1);
+            int old = EMPTY - 1;
+            if (pending) old = atomicCAS(&S.ht[h], EMPTY, c);
+            const bool won = old == EMPTY;
             const unsigned long long wm = (__ballot(won) >> shift) & sub_mask;
             if (won) {
                 idx = cnt + __popcll(wm & below);
@@ -1499,22 +1512,11 @@ __device__ __forceinline__ int spgemm_row_by_masks(SpgemmRowLds<CAPP, HT, LANES>
             cnt += __popcll(wm);
             // (LDS serves a wave's accesses in the order they were issued: the number stored by the winner is there
             // for the lanes that met its key in the same round)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (pending) {
-                if (old == EMPTY) {
-                    pending = false;
-                } else if (old == c) {
-                    idx = S.hidx[h];
-                    pending = false;
-                } else {
-                    ++h;
-                    if (++probes >= HT) {
-                        overflow = true;
-                        pending = false;
-                    }
-                }
-            }
-            if (!__any(pending)) break;
+            asm volatile("" ::: "memory");
+            const bool hit = pending && old == c;
+            if (hit) idx = S.hidx[h];
+            pending = pending && !won && !hit;
+            ++h;
         }
         if (mine && idx >= 0 && idx < HT / 2) atomicOr(&S.mask[idx], (Mask)1 << sl);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1623,29 +1625,52 @@ __global__ __launch_bounds__(256) void spgemm_rows_sub(int n_rows, const int *__
     const int row_end = (int)((long long)(slab + 1) * n_rows / nslab);
     const int row_first = (int)((long long)slab * n_rows / nslab) + (int)(blockIdx.x / nslab) * G + g;
     const int stride = (int)(gridDim.x / nslab) * G;
-    int nx_n = 0, len_n = 0, ystart_n = 0;
-    double a_n = 0.0;
-    auto prefetch = [&](int row) {
-        nx_n = 0; len_n = 0; ystart_n = 0; a_n = 0.0;
-        if (row < row_end) {
-            const int x0 = xr[row];
-            nx_n = xr[row + 1] - x0;
-            if (nx_n <= LANES && sl < nx_n) {
-                const int mid = xc[x0 + sl];
-                a_n = xv[x0 + sl];
-                ystart_n = yr[mid];
-                len_n = ye[mid] - ystart_n;
-            }
+    // The loads that lead to a row's products form a chain of four dependent global accesses (xr -> xc / xv -> yr / ye ->
+    // yc / yv).  The first three run as a pipeline over the rows of the sweep: an iteration asks for the row bounds of
+    // the row three ahead, the entries of the row two ahead and the Y bounds (and the place) of the next row, each from
+    // what the iteration before received -- independent loads, in flight while the current row is worked on, instead of
+    // a chain the wave waits through row by row (five exposed latencies per row before, one now).
+    int row_a = row_first < row_end ? row_first : row_end, x0_a = 0, x1_a = 0;     // stage A: bounds of the row of X
+    int row_b = row_end, x0_b = 0, x1_b = 0, mid_b = 0;                            // stage B: its entries
+    double a_b = 0.0;
+    int row_c = row_end, nx_c = 0, ys_c = 0, ye_c = 0, place_c = 0;                // stage C: bounds in Y, place of the result
+    double a_c = 0.0;
+    auto load_a = [&]() {
+        x0_a = 0; x1_a = 0;
+        if (row_a < row_end) {
+            x0_a = xr[row_a];
+            x1_a = xr[row_a + 1];
         }
     };
-    prefetch(row_first);
+    auto advance = [&]() {
+        const int nx_b = x1_b - x0_b;
+        row_c = row_b; nx_c = nx_b; a_c = a_b; ys_c = 0; ye_c = 0; place_c = 0;
+        if (row_b < row_end) {
+            place_c = slot_ptr[row_b];
+            if (nx_b <= LANES && sl < nx_b) {
+                ys_c = yr[mid_b];
+                ye_c = ye[mid_b];
+            }
+        }
+        const int nx_a = x1_a - x0_a;
+        row_b = row_a; x0_b = x0_a; x1_b = x1_a; mid_b = 0; a_b = 0.0;
+        if (row_a < row_end && nx_a <= LANES && sl < nx_a) {
+            mid_b = xc[x0_a + sl];
+            a_b = xv[x0_a + sl];
+        }
+        row_a = row_a < row_end - stride ? row_a + stride : row_end;
+        load_a();
+    };
+    load_a();
+    advance();
+    advance();                                     // (stage C now holds the first row)
     // (the lane groups of a wave stay together to the end of the longer sweep: the row routine is called wave-wide)
-    for (int i = row_first; __any(i < row_end); i += stride) {
+    while (__any(row_c < row_end)) {
+        const int i = row_c;
         const bool has_row = i < row_end;
-        const int nx = nx_n, len = len_n, ystart = ystart_n;
-        const double a = a_n;
-        prefetch(i + stride);
-        const int place = has_row ? slot_ptr[i] : 0;
+        const int nx = nx_c, ystart = ys_c, len = ye_c - ys_c, place = place_c;
+        const double a = a_c;
+        advance();
         const int nd = spgemm_row_by_masks<CAPP, HT, LANES>(s_rows[g], sl, sub, has_row, nx, len, ystart, a, yc, yv, ycs,
                                                             key + place, val + place);
         if (has_row && sl == 0) row_len[i] = nd;
