@@ -1185,6 +1185,34 @@ __global__ void spgemm_count(int n_rows, const int *__restrict__ xr, const int *
     cnt[i] = c > 2000000000LL ? 2000000000 : (int)c;   // the scan rejects totals beyond int32
 }
 
+// The same count with LPR lanes per row, for rows of X beyond the eight entries the kernel above takes at once (the
+// restriction: 22 entries per row on the fine level of C4, where a thread walked the other 14 one dependent load after
+// the other -- 203 us for 30 M entries).
+template <int LPR>
+__global__ __launch_bounds__(256) void spgemm_count_lanes(int n_rows, const int *__restrict__ xr, const int *__restrict__ xc,
+                                                          const int *__restrict__ yr, const int *__restrict__ ye, int *__restrict__ cnt) {
+    const long long tid = (long long)xcd_bid() * blockDim.x + threadIdx.x;
+    const long long i = tid / LPR;
+    const int l = (int)(tid % LPR);
+    long long c = 0;
+    if (i < n_rows) {
+        const int k0 = xr[i], k1 = xr[i + 1];
+        int k = k0 + l;
+        for (; k + LPR < k1; k += 2 * LPR) {
+            const int m0 = xc[k], m1 = xc[k + LPR];
+            const int b0 = yr[m0], e0 = ye[m0], b1 = yr[m1], e1 = ye[m1];
+            c += (e0 - b0) + (e1 - b1);
+        }
+        if (k < k1) {
+            const int m0 = xc[k];
+            c += ye[m0] - yr[m0];
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < LPR; d <<= 1) c += __shfl_xor(c, d, 64);
+    if (i < n_rows && l == 0) cnt[i] = c > 2000000000LL ? 2000000000 : (int)c;
+}
+
 __global__ void spgemm_rows(int n_rows, const int *__restrict__ xr, const int *__restrict__ xc,
                             const double *__restrict__ xv, const int *__restrict__ yr, const int *__restrict__ yc,
                             const double *__restrict__ yv, const int *__restrict__ ye, const int ycs, const int *__restrict__ slot_ptr,
@@ -1400,7 +1428,7 @@ __global__ __launch_bounds__(128) void spgemm_rows_lds_pipe(int n_rows, const in
 // and one ballot per column told its owner which products to add -- ~2.5 times the wave instructions, which is what
 // bounds these kernels: R (A P) of C4's fine level 1.35 ms.)
 // Rows that do not fit (X row > LANES entries, > CAPP products, > HT/2 distinct columns) are flagged (row_len -1).
-// Inclusive prefix sum over groups of LANES (32 or 64) lanes, all lanes active: four shifts within the rows of 16 lanes,
+// Inclusive prefix sum over groups of LANES (16, 32 or 64) lanes, all lanes active: four shifts within the rows of 16 lanes,
 // then the last lane of a row added to the whole next row (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3)
 // -- six vector instructions instead of five rounds of index arithmetic, ds_bpermute and select.
 template <int LANES>
@@ -1409,7 +1437,7 @@ __device__ __forceinline__ int scan_incl_lanes(int x) {
     x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
     x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
     x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    if (LANES >= 32) x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
     if (LANES == 64) x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
     return x;
 }
@@ -1442,10 +1470,11 @@ __device__ __forceinline__ int spgemm_row_by_masks(SpgemmRowLds<CAPP, HT, LANES>
     const unsigned long long sub_mask = (LANES == 64 ? ~0ull : ((1ull << LANES) - 1ull));
     const int shift = sub * LANES;
     const unsigned long long below = (1ull << sl) - 1ull;
-    static_assert(LANES == 32 || LANES == 64, "the scan below");
+    static_assert(LANES == 16 || LANES == 32 || LANES == 64, "the scan below");
     const int incl = scan_incl_lanes<LANES>(len);
-    const int np = LANES == 64 ? __builtin_amdgcn_readlane(incl, 63)
-                               : (sub != 0 ? __builtin_amdgcn_readlane(incl, 63) : __builtin_amdgcn_readlane(incl, 31));
+    const int np = LANES == 64   ? __builtin_amdgcn_readlane(incl, 63)
+                   : LANES == 32 ? (sub != 0 ? __builtin_amdgcn_readlane(incl, 63) : __builtin_amdgcn_readlane(incl, 31))
+                                 : __builtin_amdgcn_update_dpp(0, incl, 0x15F, 0xf, 0xf, false);      // row_newbcast:15
     const bool live = has_row && nx <= LANES && np <= CAPP;
     const unsigned long long have = (__ballot(live && len > 0) >> shift) & sub_mask;
     if (live) {
@@ -2928,7 +2957,15 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
     PADNE_TRY(sc.alloc(&slot_ptr, (size_t)n + 1));
     PADNE_TRY(sc.alloc(&row_len, (size_t)n + 1));
     // (no zeroing: spgemm_count stores every one of the n entries the scan reads)
-    if (n > 0) hipLaunchKernelGGL(spgemm_count, dim3(nblk(n)), dim3(256), 0, s, n, X->rowptr, X->cols, y_begin, y_end, cnt);
+    if (n > 0) {
+        const double x_avg = (double)X->nnz / (double)n;       // (0 for the row views of the split below: thread per row)
+        if (x_avg > 48.0)
+            hipLaunchKernelGGL((spgemm_count_lanes<32>), dim3(nblk((long long)n * 32)), dim3(256), 0, s, n, X->rowptr, X->cols, y_begin, y_end, cnt);
+        else if (x_avg > 16.0)
+            hipLaunchKernelGGL((spgemm_count_lanes<8>), dim3(nblk((long long)n * 8)), dim3(256), 0, s, n, X->rowptr, X->cols, y_begin, y_end, cnt);
+        else
+            hipLaunchKernelGGL(spgemm_count, dim3(nblk(n)), dim3(256), 0, s, n, X->rowptr, X->cols, y_begin, y_end, cnt);
+    }
     PADNE_HIP_CHECK(hipGetLastError());
     int64_t n_slots = 0;
     int rc_scan = PADNE_OK;
@@ -3026,11 +3063,19 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
             PADNE_TRY(sc.alloc(&pend_count, 1));
             PADNE_HIP_CHECK(hipMemsetAsync(pend_count, 0, sizeof(int), s));
             if (avg <= 110.0) {
-                // short rows: two rows per wave with small limits first (2.5 KiB of LDS per row: 56 rows in flight per
-                // CU), then one row per wave for the rows that did not fit
-                unsigned gs = (unsigned)std::min<long long>(((long long)n + 7) / 8, 16384);
-                hipLaunchKernelGGL((spgemm_rows_sub<256, 64, 32>), dim3(gs), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
-                                   y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len);
+                // short rows: two rows per wave with small limits first (1.5 KiB of LDS per row), or four where the rows
+                // of X are short as well (A P below the finest level: 13 entries, 30 products); then one row per wave for
+                // the rows that did not fit
+                const double x_avg = (double)X->nnz / (double)n;
+                if (x_avg > 0.0 && x_avg <= 14.0 && avg <= 48.0) {
+                    unsigned gs = (unsigned)std::min<long long>(((long long)n + 15) / 16, 16384);
+                    hipLaunchKernelGGL((spgemm_rows_sub<128, 32, 16>), dim3(gs), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
+                                       y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len);
+                } else {
+                    unsigned gs = (unsigned)std::min<long long>(((long long)n + 7) / 8, 16384);
+                    hipLaunchKernelGGL((spgemm_rows_sub<256, 64, 32>), dim3(gs), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
+                                       y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len);
+                }
                 hipLaunchKernelGGL(collect_pending_rows, dim3(nblk(n)), dim3(256), 0, s, n, (const int *)row_len, pend, pend_count);
                 hipLaunchKernelGGL((spgemm_rows_wave<256, 128>), dim3(gl), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
                                    y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len, 1, (const int *)pend,
