@@ -2942,8 +2942,11 @@ __global__ void slot_row_ends(int n, const int *__restrict__ slot_ptr, const int
 // Y are read then).  `keep_slots`: leave the product in ITS slots (no scan, no compaction) and return no matrix.
 // while_counting: called once the count and the scan of the slot offsets are queued and before the host waits for their
 // total -- what it launches (on another stream) is launched while they run instead of in front of them
+// while_multiplying: called once the row kernels are queued, before the product is compacted (again: launches for the
+// other stream made while this one has work, not while it waits for the host)
 static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_csr **C, const SlotRows *y_slots = nullptr,
-                  SlotRows *keep_slots = nullptr, const std::function<int()> *while_counting = nullptr) {
+                  SlotRows *keep_slots = nullptr, const std::function<int()> *while_counting = nullptr,
+                  const std::function<int()> *while_multiplying = nullptr) {
     const int *y_begin = y_slots != nullptr ? y_slots->begin : Y->rowptr;
     const int *y_end = y_slots != nullptr ? y_slots->end : Y->rowptr + 1;
     const int *y_cols = y_slots != nullptr ? (const int *)y_slots->key + 1 : Y->cols;      // upper half of a little-endian key
@@ -3107,6 +3110,7 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
         }
     }
     PADNE_HIP_CHECK(hipGetLastError());
+    if (while_multiplying != nullptr) PADNE_TRY((*while_multiplying)());
     if (keep_slots != nullptr) {
         keep_slots->release();
         int *end = (int *)pool_alloc(ctx, sizeof(int) * (size_t)(n > 0 ? n : 1));
@@ -3473,8 +3477,8 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         // the main stream is busy with R (A P): the one host thread that launches for both streams then starts the level's
         // aggregation without first spending 30 launches on the other stream (the small levels are launch-bound)
         const bool lanczos = lvl > 0 && A->n_rows > ctx->opt.amg_coarse_n;
-        auto queue_level_extras = [&]() -> int {
-            if (two) PADNE_TRY(stream_order(ctx, aux));
+        auto queue_level_extras = [&](const bool ordered = false) -> int {
+            if (two && !ordered) PADNE_TRY(stream_order(ctx, aux));
             if (lanczos) {
                 // the Gershgorin bound is loose on the coarse operators (2.8 against ~1.7): it is tightened with the largest
                 // Ritz value of 8 Lanczos steps (converges from below; 8 % margin keeps the sweep stable; 12 steps gave the
@@ -3535,25 +3539,31 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         const bool with_w = lvl == 0 && want_f32 && ap_rows.valid && ctx->opt.amg_w >= 1;
         if (amg_verbose() && AP != nullptr) fprintf(stderr, "[amg]   AP nnz=%lld\n", (long long)AP->nnz);
         if (two && (rc = stream_order(aux, ctx)) != PADNE_OK) { if (AP) padne_csr_destroy(AP); amg->levels.push_back(L); break; }
-        if (with_w) {                       // after the join above: the main stream waits for R, not for W
-            const double c0 = 1.0 / (0.5 * (L.lambda + L.lambda / kChebRatio));      // level 0 keeps its Gershgorin bound: L.jac below
-            if (two && (rc = stream_order(ctx, aux)) != PADNE_OK) { if (AP) padne_csr_destroy(AP); amg->levels.push_back(L); break; }
-            if ((rc = build_w_operator(aux, A, L.P, ap_rows, ap_rows.n_slots, c0, &L.W)) != PADNE_OK) {
-                if (two) (void)hipStreamSynchronize(aux->stream);      // it may have queued reads of the slots that go with this scope
-                if (AP) padne_csr_destroy(AP);
-                amg->levels.push_back(L);
-                break;
+        // What the second stream gets next -- W of the fine level, the level's extras: some forty launches -- is queued
+        // once the row kernels of R (A P) are: made in front of that product they kept this stream waiting for the host
+        // (0.4 ms per level in a trace)
+        // (the second stream may start on it now -- the event of what it reads, the slots of A P included, is recorded here, in
+        // front of the product, not behind its row kernels)
+        if (two && (rc = stream_order(ctx, aux)) != PADNE_OK) { if (AP) padne_csr_destroy(AP); amg->levels.push_back(L); break; }
+        bool side_queued = false;
+        const std::function<int()> queue_side = [&]() -> int {
+            side_queued = true;
+            if (with_w) {                   // after the join above: the main stream waits for R, not for W
+                const double c0 = 1.0 / (0.5 * (L.lambda + L.lambda / kChebRatio));      // level 0 keeps its Gershgorin bound: L.jac below
+                PADNE_TRY(build_w_operator(aux, A, L.P, ap_rows, ap_rows.n_slots, c0, &L.W));
             }
-        }
-        if ((rc = queue_level_extras()) != PADNE_OK) { if (AP) padne_csr_destroy(AP); amg->levels.push_back(L); break; }
+            return queue_level_extras(true);
+        };
         if (ap_rows.valid) {
             padne_csr ap_shape;
             ap_shape.n_rows = ap_rows.n_rows;
             ap_shape.n_cols = ap_rows.n_cols;
-            rc = spgemm(ctx, L.R, &ap_shape, &Ac, &ap_rows);
+            rc = spgemm(ctx, L.R, &ap_shape, &Ac, &ap_rows, nullptr, nullptr, &queue_side);
         } else {
-            rc = spgemm(ctx, L.R, AP, &Ac);
+            rc = spgemm(ctx, L.R, AP, &Ac, nullptr, nullptr, nullptr, &queue_side);
         }
+        if (rc == PADNE_OK && !side_queued) rc = queue_side();      // (the product was split: its halves do not call back)
+        if (rc != PADNE_OK && two) (void)hipStreamSynchronize(aux->stream);      // it may have queued reads of the slots that go with this scope
         pt.lap("R*(AP)");
         if (amg_verbose() && rc == PADNE_OK) fprintf(stderr, "[amg]   Ac: n=%lld nnz=%lld\n", (long long)Ac->n_rows, (long long)Ac->nnz);
         if (AP) padne_csr_destroy(AP);
