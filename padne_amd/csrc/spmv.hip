@@ -326,24 +326,45 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
     double dot_acc = 0.0;
     int rs = 0, re = 0;
     int4 d = make_int4(0, 0, 0, 0);
+    // A tile is a chain of dependent accesses: its row pointers and descriptor, then the runs of x and the stream of the
+    // matrix they delimit, then LDS.  The head of the chain is asked for one tile ahead (and, for a list of tiles, the
+    // tile's number one further ahead): it arrives while the tile in front of it is being multiplied.
+    int wt_n = -1, wt_nn = -1, rs_n = 0, re_n = 0, wide_n = 0;
+    int4 d_n = make_int4(0, 0, 0, 0);
+    auto tile_at = [&](const int it) -> int { return it < s1 ? (LIST ? tile_list[it] : it) : -1; };
+    auto fetch_head = [&](const int wt) {
+        rs_n = 0;
+        re_n = 0;
+        wide_n = 0;
+        d_n = make_int4(0, 0, 0, 0);
+        if (wt < 0) return;
+        const int r = wt * 64 + lane;
+        if (r < n_rows) {
+            rs_n = rowptr[r];
+            re_n = rowptr[r + 1];
+        }
+        if (WIDE) {
+            if (lane < kXwDescWide) wide_n = reinterpret_cast<const int *>(xw_desc)[(size_t)wt * kXwDescWide + lane];
+        } else if (xw_desc != nullptr) {
+            d_n = xw_desc[wt];
+        }
+    };
+    wt_n = tile_at(s0 + wx);
+    wt_nn = tile_at(s0 + wx + wps);
+    fetch_head(wt_n);
     for (int it = s0 + wx; it < s1; it += wps) {
-        const int wt = LIST ? tile_list[it] : it;
+        const int wt = wt_n;
         const int row0 = wt * 64;
         const int row1 = min(row0 + 64, n_rows);
         const int r = row0 + lane;
-        rs = 0;
-        re = 0;
-        if (r < n_rows) {
-            rs = rowptr[r];
-            re = rowptr[r + 1];
-        }
-        int wide_mine = 0;                                  // WIDE: lane k holds int k of the tile's descriptor
-        if (WIDE) {
-            if (lane < kXwDescWide) wide_mine = reinterpret_cast<const int *>(xw_desc)[(size_t)wt * kXwDescWide + lane];
-            d.w = __shfl(wide_mine, kXwDescWide - 1, 64);
-        } else if (xw_desc != nullptr) {
-            d = xw_desc[wt];
-        }
+        rs = rs_n;
+        re = re_n;
+        d = d_n;
+        const int wide_mine = wide_n;                       // WIDE: lane k holds int k of the tile's descriptor
+        if (WIDE) d.w = __shfl(wide_mine, kXwDescWide - 1, 64);
+        wt_n = wt_nn;
+        wt_nn = tile_at(it + 2 * wps);
+        fetch_head(wt_n);
         const int k0 = __shfl(rs, 0, 64);
         const int k1 = __shfl(re, row1 - row0 - 1, 64);
         XT acc = 0;
