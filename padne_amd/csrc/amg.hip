@@ -1587,94 +1587,54 @@ __device__ __forceinline__ int spgemm_row_by_masks(SpgemmRowLds<CAPP, HT, LANES>
     return ok ? nd : -1;
 }
 
-template <int CAPP, int HT>
-__global__ __launch_bounds__(256) void spgemm_rows_wave(int n_rows, const int *__restrict__ xr, const int *__restrict__ xc,
-                                                        const double *__restrict__ xv, const int *__restrict__ yr,
-                                                        const int *__restrict__ yc, const double *__restrict__ yv, const int *__restrict__ ye, const int ycs,
-                                                        const int *__restrict__ slot_ptr, long long *__restrict__ key,
-                                                        double *__restrict__ val, int *__restrict__ row_len,
-                                                        const int only_flagged, const int *__restrict__ row_list = nullptr,
-                                                        const int *__restrict__ list_count = nullptr) {
-    // row_list / list_count: the kernel works through that list of rows (the ones an earlier pass left, collected by
-    // collect_pending_rows) instead of striding over all rows looking for them
-    __shared__ SpgemmRowLds<CAPP, HT, 64> s_rows[4];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    // The loads that lead to a row's products form a chain of four dependent global accesses (xr -> xc/xv -> yr ->
-    // yc/yv); the first three are issued one row ahead so that only the last one is exposed.
-    const int stride = gridDim.x * 4;
-    const int n_iter = row_list != nullptr ? *list_count : n_rows;
-    int nx_n = 0, len_n = 0, ystart_n = 0, row_n = 0;
-    double a_n = 0.0;
-    auto prefetch = [&](int t) {
-        nx_n = 0; len_n = 0; ystart_n = 0; a_n = 0.0; row_n = 0;
-        if (t < n_iter) {
-            const int row = row_list != nullptr ? row_list[t] : t;
-            row_n = row;
-            if (!(only_flagged && row_len[row] >= 0)) {
-                const int x0 = xr[row];
-                nx_n = xr[row + 1] - x0;
-                if (nx_n <= 64 && lane < nx_n) {
-                    const int mid = xc[x0 + lane];
-                    a_n = xv[x0 + lane];
-                    ystart_n = yr[mid];
-                    len_n = ye[mid] - ystart_n;
-                }
-            }
-        }
-    };
-    prefetch(blockIdx.x * 4 + w);
-    for (int t = blockIdx.x * 4 + w; t < n_iter; t += stride) {
-        const int nx = nx_n, len = len_n, ystart = ystart_n, i = row_n;
-        const double a = a_n;
-        const bool skip = only_flagged && row_len[i] >= 0;      // finished by an earlier pass
-        prefetch(t + stride);
-        if (skip) continue;
-        const int nd = spgemm_row_by_masks<CAPP, HT, 64>(s_rows[w], lane, 0, true, nx, len, ystart, a, yc, yv, ycs,
-                                                         key + slot_ptr[i], val + slot_ptr[i]);
-        if (lane == 0) row_len[i] = nd;
-    }
-}
-
-// The same with LANES (32) lanes per row, i.e. two rows per wave and half the LDS per row.  Rows that do not fit the
-// smaller limits are flagged and finished by the wave kernel (only_flagged) and, beyond that, spgemm_rows_redo.
-template <int CAPP, int HT, int LANES>
-__global__ __launch_bounds__(256) void spgemm_rows_sub(int n_rows, const int *__restrict__ xr, const int *__restrict__ xc,
-                                                       const double *__restrict__ xv, const int *__restrict__ yr,
-                                                       const int *__restrict__ yc, const double *__restrict__ yv, const int *__restrict__ ye, const int ycs,
-                                                       const int *__restrict__ slot_ptr, long long *__restrict__ key,
-                                                       double *__restrict__ val, int *__restrict__ row_len) {
+// The kernel around it: 256 / LANES lane groups per workgroup, each working through its share of the rows -- every XCD
+// a contiguous eighth of them (see xcd_bid: the rows of Y that neighbouring rows of X gather, the slots of A P around an
+// aggregate, are then still in that XCD's L2 when the next row asks for them), or the list of rows an earlier pass
+// flagged (row_list / list_count, collected by collect_pending_rows; rows of the list that a pass in between has
+// finished are skipped).
+// The loads that lead to a row's products form a chain of dependent global accesses (row number -> xr -> xc / xv ->
+// yr / ye -> yc / yv).  All but the last run as a pipeline over the rows of the sweep: an iteration asks for the number of
+// the row four ahead, the bounds of the row three ahead, the entries of the row two ahead and the Y bounds (and the
+// place) of the next row, each from what the iteration before received -- independent loads, in flight while the
+// current row is worked on, instead of a chain the wave waits through row by row (five exposed latencies per row
+// before, one now).
+template <int CAPP, int HT, int LANES, bool LIST>
+__global__ __launch_bounds__(256) void spgemm_rows_lanes(int n_rows, const int *__restrict__ xr, const int *__restrict__ xc,
+                                                         const double *__restrict__ xv, const int *__restrict__ yr,
+                                                         const int *__restrict__ yc, const double *__restrict__ yv, const int *__restrict__ ye, const int ycs,
+                                                         const int *__restrict__ slot_ptr, long long *__restrict__ key,
+                                                         double *__restrict__ val, int *__restrict__ row_len,
+                                                         const int *__restrict__ row_list = nullptr,
+                                                         const int *__restrict__ list_count = nullptr) {
     constexpr int G = 256 / LANES;                    // rows (lane groups) per workgroup
     __shared__ SpgemmRowLds<CAPP, HT, LANES> s_rows[G];
     const int lane = threadIdx.x & 63;
     const int sl = lane % LANES, sub = lane / LANES, g = threadIdx.x / LANES;
-    // every XCD sweeps its own contiguous eighth of the rows (see xcd_bid): the rows of Y that neighbouring rows of X
-    // gather (the slots of A P around an aggregate) are then still in that XCD's L2 when the next row asks for them
-    const int nslab = (gridDim.x % kNumXcd == 0) ? kNumXcd : 1;
-    const int slab = blockIdx.x % nslab;
-    const int row_end = (int)((long long)(slab + 1) * n_rows / nslab);
-    const int row_first = (int)((long long)slab * n_rows / nslab) + (int)(blockIdx.x / nslab) * G + g;
-    const int stride = (int)(gridDim.x / nslab) * G;
-    // The loads that lead to a row's products form a chain of four dependent global accesses (xr -> xc / xv -> yr / ye ->
-    // yc / yv).  The first three run as a pipeline over the rows of the sweep: an iteration asks for the row bounds of
-    // the row three ahead, the entries of the row two ahead and the Y bounds (and the place) of the next row, each from
-    // what the iteration before received -- independent loads, in flight while the current row is worked on, instead of
-    // a chain the wave waits through row by row (five exposed latencies per row before, one now).
-    int row_a = row_first < row_end ? row_first : row_end, x0_a = 0, x1_a = 0;     // stage A: bounds of the row of X
-    int row_b = row_end, x0_b = 0, x1_b = 0, mid_b = 0;                            // stage B: its entries
+    constexpr bool listed = LIST;                      // (a template parameter: the sweep over all rows carries no lengths of an earlier pass)
+    int t_l, t_end, stride;                            // positions in the sweep: t_l, t_l + stride, ... < t_end
+    if (listed) {
+        t_end = *list_count;
+        t_l = (int)blockIdx.x * G + g;
+        stride = (int)gridDim.x * G;
+    } else {
+        const int nslab = (gridDim.x % kNumXcd == 0) ? kNumXcd : 1;
+        const int slab = blockIdx.x % nslab;
+        t_end = (int)((long long)(slab + 1) * n_rows / nslab);
+        t_l = (int)((long long)slab * n_rows / nslab) + (int)(blockIdx.x / nslab) * G + g;
+        stride = (int)(gridDim.x / nslab) * G;
+    }
+    if (t_l > t_end) t_l = t_end;
+    // row < 0: no row.  len_*: the row's length as an earlier pass left it (listed rows only; >= 0: finished)
+    int row_l = -1;                                                                 // stage L: the row's number
+    int row_a = -1, x0_a = 0, x1_a = 0, len_a = -1;                                 // stage A: bounds of the row of X
+    int row_b = -1, x0_b = 0, x1_b = 0, len_b = -1, mid_b = 0;                      // stage B: its entries
     double a_b = 0.0;
-    int row_c = row_end, nx_c = 0, ys_c = 0, ye_c = 0, place_c = 0;                // stage C: bounds in Y, place of the result
+    int row_c = -1, nx_c = 0, len_c = -1, ys_c = 0, ye_c = 0, place_c = 0;          // stage C: bounds in Y, place of the result
     double a_c = 0.0;
-    auto load_a = [&]() {
-        x0_a = 0; x1_a = 0;
-        if (row_a < row_end) {
-            x0_a = xr[row_a];
-            x1_a = xr[row_a + 1];
-        }
-    };
     auto advance = [&]() {
         const int nx_b = x1_b - x0_b;
-        row_c = row_b; nx_c = nx_b; a_c = a_b; ys_c = 0; ye_c = 0; place_c = 0;
-        if (row_b < row_end) {
+        row_c = row_b; nx_c = nx_b; len_c = len_b; a_c = a_b; ys_c = 0; ye_c = 0; place_c = 0;
+        if (row_b >= 0) {
             place_c = slot_ptr[row_b];
             if (nx_b <= LANES && sl < nx_b) {
                 ys_c = yr[mid_b];
@@ -1682,21 +1642,29 @@ __global__ __launch_bounds__(256) void spgemm_rows_sub(int n_rows, const int *__
             }
         }
         const int nx_a = x1_a - x0_a;
-        row_b = row_a; x0_b = x0_a; x1_b = x1_a; mid_b = 0; a_b = 0.0;
-        if (row_a < row_end && nx_a <= LANES && sl < nx_a) {
+        row_b = row_a; x0_b = x0_a; x1_b = x1_a; len_b = len_a; mid_b = 0; a_b = 0.0;
+        if (row_a >= 0 && nx_a <= LANES && sl < nx_a) {
             mid_b = xc[x0_a + sl];
             a_b = xv[x0_a + sl];
         }
-        row_a = row_a < row_end - stride ? row_a + stride : row_end;
-        load_a();
+        row_a = row_l; x0_a = 0; x1_a = 0; len_a = -1;
+        if (row_a >= 0) {
+            x0_a = xr[row_a];
+            x1_a = xr[row_a + 1];
+            if (listed) len_a = row_len[row_a];
+        }
+        row_l = -1;
+        if (t_l < t_end) row_l = listed ? row_list[t_l] : t_l;
+        t_l = t_l < t_end - stride ? t_l + stride : t_end;
     };
-    load_a();
+    advance();
+    advance();
     advance();
     advance();                                     // (stage C now holds the first row)
     // (the lane groups of a wave stay together to the end of the longer sweep: the row routine is called wave-wide)
-    while (__any(row_c < row_end)) {
+    while (__any(row_c >= 0)) {
         const int i = row_c;
-        const bool has_row = i < row_end;
+        const bool has_row = i >= 0 && !(listed && len_c >= 0);
         const int nx = nx_c, ystart = ys_c, len = ye_c - ys_c, place = place_c;
         const double a = a_c;
         advance();
@@ -3052,8 +3020,8 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
                 PADNE_TRY(sc.alloc(&pend_count, 1));
                 PADNE_HIP_CHECK(hipMemsetAsync(pend_count, 0, sizeof(int), s));
                 hipLaunchKernelGGL(collect_pending_rows, dim3(nblk(n)), dim3(256), 0, s, n, (const int *)row_len, pend, pend_count);
-                hipLaunchKernelGGL((spgemm_rows_wave<1024, 512>), dim3(256), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals, y_begin,
-                                   y_cols, y_vals, y_end, y_cs, place, key, val, row_len, 1, (const int *)pend, (const int *)pend_count);
+                hipLaunchKernelGGL((spgemm_rows_lanes<1024, 512, 64, true>), dim3(256), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals, y_begin,
+                                   y_cols, y_vals, y_end, y_cs, place, key, val, row_len, (const int *)pend, (const int *)pend_count);
                 hipLaunchKernelGGL(spgemm_rows_redo, dim3(nblk(n, 128)), dim3(128), 0, s, n, X->rowptr, X->cols, X->vals,
                                    y_begin, y_cols, y_vals, y_end, y_cs, place, key, val, row_len);
             }
@@ -3072,27 +3040,27 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
                 const double x_avg = (double)X->nnz / (double)n;
                 if (x_avg > 0.0 && x_avg <= 14.0 && avg <= 48.0) {
                     unsigned gs = (unsigned)std::min<long long>(((long long)n + 15) / 16, 16384);
-                    hipLaunchKernelGGL((spgemm_rows_sub<128, 32, 16>), dim3(gs), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
+                    hipLaunchKernelGGL((spgemm_rows_lanes<128, 32, 16, false>), dim3(gs), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
                                        y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len);
                 } else {
                     unsigned gs = (unsigned)std::min<long long>(((long long)n + 7) / 8, 16384);
-                    hipLaunchKernelGGL((spgemm_rows_sub<256, 64, 32>), dim3(gs), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
+                    hipLaunchKernelGGL((spgemm_rows_lanes<256, 64, 32, false>), dim3(gs), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
                                        y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len);
                 }
                 hipLaunchKernelGGL(collect_pending_rows, dim3(nblk(n)), dim3(256), 0, s, n, (const int *)row_len, pend, pend_count);
-                hipLaunchKernelGGL((spgemm_rows_wave<256, 128>), dim3(gl), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
-                                   y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len, 1, (const int *)pend,
+                hipLaunchKernelGGL((spgemm_rows_lanes<256, 128, 64, true>), dim3(gl), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
+                                   y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len, (const int *)pend,
                                    (const int *)pend_count);
             } else {
                 // coarse levels: rows of a few hundred products, some of a thousand
-                hipLaunchKernelGGL((spgemm_rows_wave<512, 256>), dim3(gw), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
-                                   y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len, 0);
+                hipLaunchKernelGGL((spgemm_rows_lanes<512, 256, 64, false>), dim3(gw), dim3(256), 0, s, n, X->rowptr, X->cols, X->vals,
+                                   y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len);
                 hipLaunchKernelGGL(collect_pending_rows, dim3(nblk(n)), dim3(256), 0, s, n, (const int *)row_len, pend, pend_count);
             }
             // a second wave pass with doubled limits keeps the few long rows (aggregates next to a via hub) away from the
             // serial fallback (0.5 ms for a handful of rows)
-            hipLaunchKernelGGL((spgemm_rows_wave<1024, 512>), dim3(std::min(gl, 1024u)), dim3(256), 0, s, n, X->rowptr, X->cols,
-                               X->vals, y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len, 1, (const int *)pend,
+            hipLaunchKernelGGL((spgemm_rows_lanes<1024, 512, 64, true>), dim3(std::min(gl, 1024u)), dim3(256), 0, s, n, X->rowptr, X->cols,
+                               X->vals, y_begin, y_cols, y_vals, y_end, y_cs, slot_ptr, key, val, row_len, (const int *)pend,
                                (const int *)pend_count);
             if (dense_lds <= 150 * 1024) {
                 // rows beyond the wave kernels' limits over a small column space: the dense accumulator, a workgroup each
