@@ -181,7 +181,10 @@ __global__ __launch_bounds__(256) void strength_mark(int n, int n_wtiles, const 
                                                      int *__restrict__ scol, double *__restrict__ bound_partial,
                                                      const int4 *__restrict__ xw_desc = nullptr,
                                                      const unsigned char *__restrict__ xw_lidx = nullptr,
-                                                     const int xw_run = 0, unsigned char *__restrict__ spos = nullptr) {
+                                                     const int xw_run = 0, unsigned char *__restrict__ spos = nullptr,
+                                                     float *__restrict__ vals32 = nullptr) {
+    // vals32 (optional): the single-precision copy of the values the multigrid cycle multiplies with, written while the
+    // values stream by (the copy as a pass of its own read the fine matrix once more: 140 us)
     // bound_partial (optional): per-workgroup maxima of the Gershgorin bounds of D^-1 A (second row of kMaxPartials) and of D_F^-1 A_F, the filtered operator
     // the prolongator is smoothed with -- the same sums, in the same order, as gershgorin_filtered_kernel forms them
     // one lane per row, taken here from the values this pass streams anyway (a separate pass over A cost 0.4 ms).
@@ -227,6 +230,7 @@ __global__ __launch_bounds__(256) void strength_mark(int n, int n_wtiles, const 
                     const int i = row0 + rl;
                     const int c = cols[e];
                     const double v = vals[e];
+                    if (vals32 != nullptr) vals32[e] = (float)v;
                     const bool st = c != i && strong(v, dr, dinv[c], theta2);
                     scol[e] = st ? c : i;
                     if (windowed) spos[e] = st ? xw_lidx[e] : (unsigned char)sp;
@@ -2363,7 +2367,8 @@ static int gershgorin(padne_ctx *ctx, const padne_csr *A, double *lambda, bool f
 
 // aggregates of A -> device array agg[n], count n_agg
 static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_out, int *n_agg, double *lambda_f = nullptr,
-                     double *lambda_plain = nullptr, unsigned char **spos_out = nullptr, int **scol_out = nullptr) {
+                     double *lambda_plain = nullptr, unsigned char **spos_out = nullptr, int **scol_out = nullptr,
+                     float *vals32_out = nullptr) {
     hipStream_t s = ctx->stream;
     const int n = (int)A->n_rows;
     const double theta2 = kTheta * kTheta;
@@ -2403,7 +2408,7 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
                        spos != nullptr ? spos + A->nnz : (unsigned char *)nullptr, kPadNnz);
     hipLaunchKernelGGL(strength_mark, gm, b, 0, s, n, n_wt, A->rowptr, A->cols, A->vals, A->dinv, theta2, scol, bound_part,
                        xw ? A->xw_desc : (const int4 *)nullptr, xw ? (const unsigned char *)A->xw_lidx : (const unsigned char *)nullptr,
-                       xw ? A->xw_run : 0, spos);
+                       xw ? A->xw_run : 0, spos, vals32_out);
     PADNE_HIP_CHECK(hipGetLastError());
     // one round = one-hop maxima, two-hop maxima, decision; on a windowed matrix the decision rides on the second pass;
     // small levels with long rows (a few thousand rows of dozens of entries) take a wave per row
@@ -3445,6 +3450,7 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         // the main stream is busy with R (A P): the one host thread that launches for both streams then starts the level's
         // aggregation without first spending 30 launches on the other stream (the small levels are launch-bound)
         const bool lanczos = lvl > 0 && A->n_rows > ctx->opt.amg_coarse_n;
+        bool w_expected = false;             // the level's fused up-leg operator is on its way: P is not multiplied with in single precision
         auto queue_level_extras = [&](const bool ordered = false) -> int {
             if (two && !ordered) PADNE_TRY(stream_order(ctx, aux));
             if (lanczos) {
@@ -3458,7 +3464,8 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
                 PADNE_TRY(lanczos_enqueue(aux, A, kLanczosSteps, &pj->job));
             }
             if (want_f32) PADNE_TRY(csr_build_f32(aux, const_cast<padne_csr *>(A)));
-            if (want_f32 && L.P != nullptr) PADNE_TRY(csr_build_f32(aux, L.P));      // (and of the level's P and R, once they exist)
+            // (and of the level's R and P, once they exist; P only where the cycle will have no W to go up with: see the end of the setup)
+            if (want_f32 && L.P != nullptr && !w_expected) PADNE_TRY(csr_build_f32(aux, L.P));
             if (want_f32 && L.R != nullptr) PADNE_TRY(csr_build_f32(aux, L.R));
             return PADNE_OK;
         };
@@ -3474,7 +3481,15 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         double lambda_f = 2.0;      // Gershgorin bound of the filtered operator, a by-product of the strength pass
         unsigned char *spos = nullptr;
         int *scol = nullptr;
-        if ((rc = aggregate(ctx, sc, A, &agg, &n_agg, &lambda_f, &L.lambda, &spos, &scol)) != PADNE_OK) { amg->levels.push_back(L); break; }
+        // (the single-precision copy of A's values comes out of the strength pass, which streams them anyway)
+        float *v32 = nullptr;
+        if (want_f32 && A->vals32 == nullptr && A->nnz > 0) {
+            padne_csr *Am = const_cast<padne_csr *>(A);
+            v32 = (float *)pool_alloc(Am->owner ? Am->owner : ctx, sizeof(float) * ((size_t)A->nnz + kPadNnz));      // padded like vals
+            if (v32 == nullptr) { rc = PADNE_E_NOMEM; amg->levels.push_back(L); break; }
+            Am->vals32 = v32;
+        }
+        if ((rc = aggregate(ctx, sc, A, &agg, &n_agg, &lambda_f, &L.lambda, &spos, &scol, v32)) != PADNE_OK) { amg->levels.push_back(L); break; }
         pt.lap("aggregate");
         if (n_agg == 0 || (double)n_agg > 0.8 * (double)A->n_rows) {   // coarsening stalled: stop here
             rc = queue_level_extras();
@@ -3513,6 +3528,7 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         // (the second stream may start on it now -- the event of what it reads, the slots of A P included, is recorded here, in
         // front of the product, not behind its row kernels)
         if (two && (rc = stream_order(ctx, aux)) != PADNE_OK) { if (AP) padne_csr_destroy(AP); amg->levels.push_back(L); break; }
+        w_expected = with_w || (lvl > 0 && want_f32 && w_inner && ap_rows.valid);
         bool side_queued = false;
         const std::function<int()> queue_side = [&]() -> int {
             side_queued = true;
@@ -3606,6 +3622,9 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         if (L.P == nullptr || L.A->dinv == nullptr) continue;
         rc = build_w_operator(aux, L.A, L.P, ks->rows, ks->rows.n_slots, L.jac, &L.W, 512);
     }
+    // a level that came out without W goes up with P: its single-precision copy, left out above
+    for (AmgLevel &L : amg->levels)
+        if (rc == PADNE_OK && want_f32 && L.P != nullptr && L.W == nullptr) rc = csr_build_f32(aux, L.P);
     if (rc == PADNE_OK && two) rc = stream_order(aux, ctx);      // the cycle runs on the main stream
     if (rc != PADNE_OK) {
         if (two) (void)hipStreamSynchronize(aux->stream);

@@ -1117,13 +1117,14 @@ __global__ void f32_copy_kernel(long long n, const double *__restrict__ src, flo
 // single-precision copies of the values and of 1/diag (kept with the matrix, freed with it).  The copies come from
 // the pool of the context whose stream writes them first (pool_free of the matrix' owner finds either pool).
 int csr_build_f32(padne_ctx *ctx, padne_csr *m) {
-    if (m->vals32 != nullptr) return PADNE_OK;
     padne_ctx *owner = ctx->is_aux ? ctx : (m->owner ? m->owner : ctx);
-    m->vals32 = (float *)pool_alloc(owner, sizeof(float) * ((size_t)m->nnz + kPadNnz));   // padded like vals
-    if (m->vals32 == nullptr) return PADNE_E_NOMEM;
-    if (m->nnz > 0)
-        hipLaunchKernelGGL(f32_copy_kernel, dim3((unsigned)std::min<long long>((m->nnz + 255) / 256, 8192)), dim3(256), 0,
-                           ctx->stream, (long long)m->nnz, m->vals, m->vals32);
+    if (m->vals32 == nullptr) {          // (else: an earlier solve's copy, or the one the strength pass of the setup has written)
+        m->vals32 = (float *)pool_alloc(owner, sizeof(float) * ((size_t)m->nnz + kPadNnz));   // padded like vals
+        if (m->vals32 == nullptr) return PADNE_E_NOMEM;
+        if (m->nnz > 0)
+            hipLaunchKernelGGL(f32_copy_kernel, dim3((unsigned)std::min<long long>((m->nnz + 255) / 256, 8192)), dim3(256), 0,
+                               ctx->stream, (long long)m->nnz, m->vals, m->vals32);
+    }
     if (m->dinv != nullptr && m->dinv32 == nullptr) {
         m->dinv32 = (float *)pool_alloc(owner, sizeof(float) * (size_t)(m->n_rows > 0 ? m->n_rows : 1));
         if (m->dinv32 == nullptr) return PADNE_E_NOMEM;
