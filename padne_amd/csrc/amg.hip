@@ -2449,9 +2449,11 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
     // Rounds are enqueued in batches between two reads of the open count (a host synchronisation costs ~30 us, as
     // much as a round on a small level): one round per batch while a pass over the level is expensive, four on the
     // small levels, where a superfluous round after the last vertex was decided is cheaper than the wait.
+    // (the first two rounds are never the last ones of a large level -- the test below asks for two -- so they go together)
     const int full_batch = n > 200000 ? 1 : 4;
     while (round < kMaxRounds && open_count > 0 && (!compact_ok || round < 2 || open_count > n / 8)) {
-        for (int rep = 0; rep < full_batch && round < kMaxRounds; ++rep, ++round) {
+        const int reps = (round == 0 && compact_ok && full_batch < 2) ? 2 : full_batch;
+        for (int rep = 0; rep < reps && round < kMaxRounds; ++rep, ++round) {
             launch_round(counter + round);
         }
         PADNE_HIP_CHECK(hipGetLastError());
@@ -2480,7 +2482,10 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
                 break;
             }
             const dim3 gl(nblk(cnt));
-            const int batch = cnt > 200000 ? 1 : 3;
+            // three rounds between two looks at the host: the grids of the second and third are those of the first, their
+            // lists are shorter (the kernels read the length on the device), and what an idle stream costs while the
+            // host looks is more than the lanes that find nothing to do
+            const int batch = 3;
             for (int rep = 0; rep < batch && cur + 1 < kMaxRounds; ++rep, ++round) {
                 hipLaunchKernelGGL(mis_two_hop_max, dim3(nblk((long long)cnt * kHopLanes)), b, 0, s, counters + cur, list_a, srow, scol, w0, m2);
                 hipLaunchKernelGGL(mis_decide_list, gl, b, 0, s, counters + cur, list_a, m2, w0, state, list_b, counters + cur + 1);
