@@ -723,9 +723,10 @@ __global__ void flag_unaggregated(int n, const int *__restrict__ agg, int *__res
     if (i < n) flag[i] = agg[i] < 0 ? 1 : 0;
 }
 
-__global__ void agg_singletons(int n, const int *__restrict__ scan, int base, int *__restrict__ agg) {
+// (base_dev: the number of roots, where the scan that numbered them left its 64-bit total)
+__global__ void agg_singletons(int n, const int *__restrict__ scan, const long long *__restrict__ base_dev, int *__restrict__ agg) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && agg[i] < 0) agg[i] = base + scan[i];
+    if (i < n && agg[i] < 0) agg[i] = (int)*base_dev + scan[i];
 }
 
 // lambda = max_i dinv_i * sum_j |a_ij|  (one partial max per workgroup)
@@ -2482,10 +2483,10 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
                 break;
             }
             const dim3 gl(nblk(cnt));
-            // three rounds between two looks at the host: the grids of the second and third are those of the first, their
+            // four rounds between two looks at the host: the grids of the second and third are those of the first, their
             // lists are shorter (the kernels read the length on the device), and what an idle stream costs while the
             // host looks is more than the lanes that find nothing to do
-            const int batch = 3;
+            const int batch = 4;
             for (int rep = 0; rep < batch && cur + 1 < kMaxRounds; ++rep, ++round) {
                 hipLaunchKernelGGL(mis_two_hop_max, dim3(nblk((long long)cnt * kHopLanes)), b, 0, s, counters + cur, list_a, srow, scol, w0, m2);
                 hipLaunchKernelGGL(mis_decide_list, gl, b, 0, s, counters + cur, list_a, m2, w0, state, list_b, counters + cur + 1);
@@ -2508,17 +2509,25 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
     }
     // number the roots
     hipLaunchKernelGGL(flag_state, g, b, 0, s, n, state, flag, 1);
-    int64_t n_roots = 0;
-    PADNE_TRY(exclusive_scan_i32(ctx, flag, scan, n, &n_roots));
+    // The host needs the two totals (roots, singletons) only as their sum: both scans are queued, the kernel that numbers
+    // the singletons reads the number of roots on the device, and the host looks once
+    ScanTicket t_roots, t_single;
+    long long h_roots[2] = {0, 0}, h_single[2] = {0, 0};
+    PADNE_TRY(scan_i32_begin(ctx, flag, scan, n, &t_roots, true));
     hipLaunchKernelGGL(agg_from_roots, g, b, 0, s, n, state, scan, agg0);
     hipLaunchKernelGGL(agg_join, g, b, 0, s, n, srow, scol, A->vals, agg0, agg1);
     hipLaunchKernelGGL(agg_join, g, b, 0, s, n, srow, scol, A->vals, agg1, agg0);
     hipLaunchKernelGGL(flag_unaggregated, g, b, 0, s, n, agg0, flag);
+    int rc_scan = scan_i32_begin(ctx, flag, scan, n, &t_single, true);
+    if (rc_scan == PADNE_OK && t_roots.bs != nullptr)
+        hipLaunchKernelGGL(agg_singletons, g, b, 0, s, n, scan, (const long long *)(t_roots.bs + t_roots.nb), agg0);
+    const int rc_roots = scan_i32_end(ctx, &t_roots, h_roots);
+    if (rc_scan == PADNE_OK) rc_scan = scan_i32_end(ctx, &t_single, h_single);
+    PADNE_TRY(rc_roots);
+    PADNE_TRY(rc_scan);
     PADNE_HIP_CHECK(hipGetLastError());
-    int64_t n_single = 0;
-    PADNE_TRY(exclusive_scan_i32(ctx, flag, scan, n, &n_single));
-    hipLaunchKernelGGL(agg_singletons, g, b, 0, s, n, scan, (int)n_roots, agg0);
-    PADNE_HIP_CHECK(hipGetLastError());
+    const long long n_roots = h_roots[0], n_single = h_single[0];
+    PADNE_REQUIRE(n_roots >= 0 && n_single >= 0 && n_roots + n_single < 2147483647LL, "aggregate count out of range");
     *agg_out = agg0;
     *n_agg = (int)(n_roots + n_single);
     if (spos_out != nullptr) *spos_out = spos;      // lives in the caller's scratch, like agg
