@@ -2642,17 +2642,19 @@ __global__ __launch_bounds__(128) void prolong_rows_lds(int n, const int *__rest
 // slots, no compaction.  Tiles without a plan (rows with far couplings) take cols / scol from global memory.
 constexpr int kPxSlots = 14;        // identity + up to 13 entries of the row of A (longer rows: the whole matrix falls back)
 constexpr int kPxChunk = 640;       // entries of a 64-row tile staged at once (10 per row)
-template <bool FILL, int SLOTS>
-__device__ __forceinline__ void prolong_row_regs(const int w, const int rs, const int re, const int k0, const int self,
+// (merge: the row's kept aggregates c[k] / sums / keep flags in registers, returns their number; store: an entry's place is
+// the number of kept aggregates below it)
+template <int SLOTS>
+__device__ __forceinline__ int prolong_row_merge(const bool live, const int w, const int rs, const int re, const int k0, const int self,
                                                  const bool windowed, const double di, const double omega, const int r,
                                                  const unsigned char (*Ls)[kPxChunk], const unsigned char (*Ss)[kPxChunk],
                                                  const double (*Vs)[kPxChunk], const int (*As)[3 * 88],
                                                  const int *__restrict__ cols, const int *__restrict__ scol,
-                                                 const double *__restrict__ vals,
-                                                 const int *__restrict__ agg, int *__restrict__ row_len,
-                                                 const int *__restrict__ out_rowptr, int *__restrict__ out_cols,
-                                                 double *__restrict__ out_vals) {
-    const int len = re - rs;
+                                                 const double *__restrict__ vals, const int *__restrict__ agg,
+                                                 int (&c)[SLOTS], double (&sum)[SLOTS], bool (&keep)[SLOTS]) {
+    // (every lane of the wave runs this, a lane without a row -- `live` false -- as a row of no entries that keeps nothing:
+    // straight-line code up to the prefix sum of the lengths, which all lanes take part in)
+    const int len = live ? re - rs : 0;
     // the row in registers: slot 0 is the identity part of P, slot k + 1 entry k of the row of A
     int el[SLOTS - 1], es[SLOTS - 1];
     double ev[SLOTS - 1];
@@ -2669,8 +2671,7 @@ __device__ __forceinline__ void prolong_row_regs(const int w, const int rs, cons
     const bool keep_all = !(dF * di > 0.05);
     if (keep_all) dF = 1.0 / di;
     const double wgt = -omega / dF;
-    const int ai = windowed ? As[w][self] : agg[r];
-    int c[SLOTS];
+    const int ai = live ? (windowed ? As[w][self] : agg[r]) : 0;
     double v[SLOTS];
     c[0] = ai;
     v[0] = 1.0;
@@ -2684,8 +2685,6 @@ __device__ __forceinline__ void prolong_row_regs(const int w, const int rs, cons
         c[k + 1] = diag ? ai : cj;
         v[k + 1] = diag ? -omega : (used ? wgt * ev[k] : 0.0);
     }
-    bool keep[SLOTS];
-    double sum[SLOTS];
     int o = 0;
 #pragma unroll
     for (int k = 0; k < SLOTS; ++k) {
@@ -2696,36 +2695,41 @@ __device__ __forceinline__ void prolong_row_regs(const int w, const int rs, cons
 #pragma unroll
         for (int j = k + 1; j < SLOTS; ++j) t = c[j] == c[k] ? t + v[j] : t;
         sum[k] = t;
-        keep[k] = first && t != 0.0;
+        keep[k] = live && first && t != 0.0;
         o += keep[k] ? 1 : 0;
     }
-    if (!FILL) {
-        row_len[r] = o;
-    } else {
-        const int base = out_rowptr[r];
+    return o;
+}
+
+template <int SLOTS>
+__device__ __forceinline__ void prolong_row_store(const int (&c)[SLOTS], const double (&sum)[SLOTS], const bool (&keep)[SLOTS],
+                                                  const int base, int *__restrict__ out_cols, double *__restrict__ out_vals) {
 #pragma unroll
-        for (int k = 0; k < SLOTS; ++k) {
-            int rank = 0;
+    for (int k = 0; k < SLOTS; ++k) {
+        int rank = 0;
 #pragma unroll
-            for (int j = 0; j < SLOTS; ++j) rank += (keep[j] && c[j] < c[k]) ? 1 : 0;
-            if (keep[k]) {
-                out_cols[base + rank] = c[k];
-                out_vals[base + rank] = sum[k];
-            }
+        for (int j = 0; j < SLOTS; ++j) rank += (keep[j] && c[j] < c[k]) ? 1 : 0;
+        if (keep[k]) {
+            out_cols[base + rank] = c[k];
+            out_vals[base + rank] = sum[k];
         }
     }
 }
 
-template <bool FILL>
-__global__ __launch_bounds__(256) void prolong_rows_xw(int n, int n_wtiles, const int *__restrict__ rowptr,
+// ONE pass: the finished rows of a tile go back to back into a staging area, from the tile's own place there -- the tile's
+// first entry of A plus its first row number: a row of P has at most one entry more than its row of A, so the places of
+// the tiles need no scan -- with their lengths; the scan of the lengths then gives the row pointers and `prolong_unstage`
+// moves every tile's run (contiguous on both sides) to its place in the CSR arrays.  Before: a counting pass with the
+// same arithmetic as the filling pass (385 us of instruction issue on the fine level of C4) to learn the row pointers
+// first; the move is 150 us of streaming.
+__global__ __launch_bounds__(256, 5) void prolong_rows_xw(int n, int n_wtiles, const int *__restrict__ rowptr,
                                                        const int *__restrict__ cols, const double *__restrict__ vals,
                                                        const double *__restrict__ dinv, const int *__restrict__ scol,
                                                        const unsigned char *__restrict__ lidx,
                                                        const unsigned char *__restrict__ spos,
                                                        const int4 *__restrict__ xw_desc, const int run, const double omega,
                                                        const int *__restrict__ agg, int *__restrict__ row_len,
-                                                       const int *__restrict__ out_rowptr, int *__restrict__ out_cols,
-                                                       double *__restrict__ out_vals, int *__restrict__ gave_up) {
+                                                       int *__restrict__ st_cols, double *__restrict__ st_vals) {
     __shared__ unsigned char Ls[4][kPxChunk], Ss[4][kPxChunk];     // window position / strength position of an entry
     __shared__ double Vs[4][kPxChunk];
     __shared__ int As[4][3 * 88];
@@ -2747,7 +2751,7 @@ __global__ __launch_bounds__(256) void prolong_rows_xw(int n, int n_wtiles, cons
         const int k1 = __shfl(re, row1 - row0 - 1, 64);
         const bool too_long = re - rs > kPxSlots - 1;
         if (__any(too_long)) {                                // wave-uniform; the scan of the lengths reports the -1 to the host
-            if (!FILL && r < row1) row_len[r] = -1;
+            if (r < row1) row_len[r] = -1;
             continue;
         }
         const bool windowed = d.w != 0 && k1 - k0 <= kPxChunk;
@@ -2767,18 +2771,47 @@ __global__ __launch_bounds__(256) void prolong_rows_xw(int n, int n_wtiles, cons
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        if (r < row1) {
-            const int self = windowed ? xw_position(d, run, r) : r;
-            // nearly every row of a mesh operator has at most 9 entries: the short instantiation does a third of the compares
-            if (__all(re - rs <= 9))
-                prolong_row_regs<FILL, 10>(w, rs, re, k0, self, windowed, di, omega, r, Ls, Ss, Vs, As, cols, scol, vals, agg,
-                                           row_len, out_rowptr, out_cols, out_vals);
-            else
-                prolong_row_regs<FILL, kPxSlots>(w, rs, re, k0, self, windowed, di, omega, r, Ls, Ss, Vs, As, cols, scol, vals,
-                                                 agg, row_len, out_rowptr, out_cols, out_vals);
+        const int self = windowed ? xw_position(d, run, r) : r;
+        const int tile_base = k0 + row0;
+        // nearly every row of a mesh operator has at most 9 entries: the short instantiation does a third of the compares
+        if (__all(re - rs <= 9)) {
+            int c[10];
+            double sum[10];
+            bool keep[10];
+            const int o = prolong_row_merge<10>(r < row1, w, rs, re, k0, self, windowed, di, omega, r, Ls, Ss, Vs, As, cols, scol, vals, agg, c, sum, keep);
+            const int before = scan_incl_lanes<64>(o) - o;
+            if (r < row1) row_len[r] = o;
+            prolong_row_store<10>(c, sum, keep, tile_base + before, st_cols, st_vals);
+        } else {
+            int c[kPxSlots];
+            double sum[kPxSlots];
+            bool keep[kPxSlots];
+            const int o = prolong_row_merge<kPxSlots>(r < row1, w, rs, re, k0, self, windowed, di, omega, r, Ls, Ss, Vs, As, cols, scol, vals, agg, c, sum, keep);
+            const int before = scan_incl_lanes<64>(o) - o;
+            if (r < row1) row_len[r] = o;
+            prolong_row_store<kPxSlots>(c, sum, keep, tile_base + before, st_cols, st_vals);
         }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// the staged runs of the tiles to their places in the CSR arrays (a wave per tile; source and destination contiguous)
+__global__ __launch_bounds__(256) void prolong_unstage(int n, int n_wtiles, const int *__restrict__ a_rowptr,
+                                                       const int *__restrict__ rowptr, const int *__restrict__ st_cols,
+                                                       const double *__restrict__ st_vals, int *__restrict__ cols,
+                                                       double *__restrict__ vals) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const XcdSweep sw = xcd_sweep(n_wtiles, 4, w);
+    for (long long wt = sw.t0; wt < sw.t1; wt += sw.stride) {
+        const int row0 = (int)wt * 64;
+        const int row1 = min(row0 + 64, n);
+        const int src = a_rowptr[row0] + row0;
+        const int d0 = rowptr[row0], d1 = rowptr[row1];
+        for (int k = lane; k < d1 - d0; k += 64) {
+            cols[d0 + k] = st_cols[src + k];
+            vals[d0 + k] = st_vals[src + k];
+        }
     }
 }
 
@@ -2794,15 +2827,17 @@ static int build_prolongator(padne_ctx *ctx, const padne_csr *A, const int *agg,
     const int n = (int)A->n_rows;
     Scratch sc(ctx);
     if (spos != nullptr && scol != nullptr && A->xw_state == 1 && A->xw_run <= 85 && n > 0) {
-        // windowed fine level: count, scan, fill straight into the CSR arrays
-        int *row_len = nullptr, *rowptr_tmp = nullptr, *gave_up = nullptr;
+        // windowed fine level: the rows staged tile by tile, the scan of their lengths, the tiles' runs moved into the CSR arrays
+        int *row_len = nullptr, *rowptr_tmp = nullptr, *st_cols = nullptr;
+        double *st_vals = nullptr;
         PADNE_TRY(sc.alloc(&row_len, (size_t)n + 1));
         PADNE_TRY(sc.alloc(&rowptr_tmp, (size_t)n + 1));
+        PADNE_TRY(sc.alloc(&st_cols, (size_t)A->nnz + (size_t)n));
+        PADNE_TRY(sc.alloc(&st_vals, (size_t)A->nnz + (size_t)n));
         const int n_wt = (n + 63) / 64;
         const dim3 g((unsigned)std::min((n_wt + 3) / 4, 8192)), b(256);
-        hipLaunchKernelGGL(prolong_rows_xw<false>, g, b, 0, s, n, n_wt, A->rowptr, A->cols, A->vals, A->dinv, scol,
-                           (const unsigned char *)A->xw_lidx, spos, A->xw_desc, A->xw_run, omega, agg, row_len,
-                           (const int *)nullptr, (int *)nullptr, (double *)nullptr, gave_up);
+        hipLaunchKernelGGL(prolong_rows_xw, g, b, 0, s, n, n_wt, A->rowptr, A->cols, A->vals, A->dinv, scol,
+                           (const unsigned char *)A->xw_lidx, spos, A->xw_desc, A->xw_run, omega, agg, row_len, st_cols, st_vals);
         PADNE_HIP_CHECK(hipGetLastError());
         int64_t nnz = 0;
         bool h_gave_up = false;          // a row that gave up left the length -1
@@ -2811,9 +2846,8 @@ static int build_prolongator(padne_ctx *ctx, const padne_csr *A, const int *agg,
             padne_csr *m = nullptr;
             PADNE_TRY(csr_alloc(ctx, n, n_agg, nnz, &m));
             PADNE_HIP_CHECK(hipMemcpyAsync(m->rowptr, rowptr_tmp, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyDeviceToDevice, s));
-            hipLaunchKernelGGL(prolong_rows_xw<true>, g, b, 0, s, n, n_wt, A->rowptr, A->cols, A->vals, A->dinv, scol,
-                               (const unsigned char *)A->xw_lidx, spos, A->xw_desc, A->xw_run, omega, agg, (int *)nullptr,
-                               (const int *)m->rowptr, m->cols, m->vals, gave_up);
+            hipLaunchKernelGGL(prolong_unstage, dim3((unsigned)std::min((n_wt + 3) / 4, 2048)), b, 0, s, n, n_wt, A->rowptr,
+                               (const int *)rowptr_tmp, (const int *)st_cols, (const double *)st_vals, m->cols, m->vals);
             PADNE_HIP_CHECK(hipGetLastError());
             *P = m;
             return PADNE_OK;
