@@ -2544,7 +2544,8 @@ __global__ __launch_bounds__(128) void prolong_rows_lds(int n, const int *__rest
                                                         double theta2, double omega, const int *__restrict__ agg,
                                                         const int *__restrict__ slot_ptr, long long *__restrict__ key,
                                                         double *__restrict__ val, int *__restrict__ row_len) {
-    __shared__ int Kc[CAP][128];
+    static_assert(CAP % 2 == 0, "keys are kept in pairs");
+    __shared__ int2 Kc[CAP / 2][128];
     __shared__ double Vc[CAP][128];
     const int t = threadIdx.x;
     const int i = blockIdx.x * 128 + t;
@@ -2572,10 +2573,40 @@ __global__ __launch_bounds__(128) void prolong_rows_lds(int n, const int *__rest
     if (keep_all) dF = 1.0 / di;
     const double w = -omega / dF;
     const int ai = agg[i];
+    // The row's list in order of APPEARANCE (as in spgemm_rows_lds_pipe: a contribution is compared with the list as far
+    // as the longest list of the wave reaches and added or appended under a predicate; a sorted list cost a search loop, a
+    // shift loop and three-way branching per contribution, every lane with its own trip counts).  The sums of an aggregate
+    // still add up in the order of the row; the list is put in order once, at the end.
+#pragma unroll
+    for (int u = 0; u < CAP / 2; ++u) Kc[u][t] = make_int2(-1, -1);
     int m = 1;
-    Kc[0][t] = ai;
+    reinterpret_cast<int *>(&Kc[0][t])[0] = ai;
     Vc[0][t] = 1.0;
     bool overflow = false;
+    auto insert = [&](const bool act, const int c, const double v) {
+        int pos = -1;
+#pragma unroll
+        for (int u = 0; u < CAP; u += 2) {
+            if (__all(u >= m)) break;
+            const int2 kk = Kc[u >> 1][t];
+            pos = kk.x == c ? u : pos;
+            pos = kk.y == c ? u + 1 : pos;
+        }
+        if (act && !overflow) {
+            const bool found = pos >= 0;
+            if (!found && m == CAP) {
+                overflow = true;
+            } else {
+                const int p = found ? pos : m;
+                const double base = found ? Vc[p][t] : -0.0;      // -0 + v == v: a new aggregate starts with its first contribution
+                Vc[p][t] = base + v;
+                if (!found) {
+                    reinterpret_cast<int *>(&Kc[p >> 1][t])[p & 1] = c;
+                    ++m;
+                }
+            }
+        }
+    };
     for (int kb = k0; kb < k1 && !overflow; kb += 8) {
         const int4 ca = load_i4_unaligned(cols + kb), cb = load_i4_unaligned(cols + kb + 4);
         const double2 v0 = load_d2_unaligned(vals + kb), v1 = load_d2_unaligned(vals + kb + 2),
@@ -2592,41 +2623,39 @@ __global__ __launch_bounds__(128) void prolong_rows_lds(int n, const int *__rest
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            if (kb + u >= k1 || overflow) continue;
-            int c;
-            double v;
-            if (j[u] == i) { c = ai; v = -omega; }
-            else if (keep_all || strong(a[u], di, dj[u], theta2)) { c = aj[u]; v = w * a[u]; }
-            else continue;
-            int lo = 0;
-            while (lo < m && Kc[lo][t] < c) ++lo;
-            if (lo < m && Kc[lo][t] == c) {
-                Vc[lo][t] = Vc[lo][t] + v;
-            } else {
-                if (m == CAP) { overflow = true; continue; }
-                for (int q = m; q > lo; --q) {
-                    Kc[q][t] = Kc[q - 1][t];
-                    Vc[q][t] = Vc[q - 1][t];
-                }
-                Kc[lo][t] = c;
-                Vc[lo][t] = v;
-                ++m;
-            }
+            const bool on = kb + u < k1;
+            const bool diag = on && j[u] == i;
+            const bool act = on && (diag || keep_all || strong(a[u], di, dj[u], theta2));
+            if (__any(act)) insert(act, diag ? ai : aj[u], diag ? -omega : w * a[u]);
         }
     }
     if (overflow) {
         row_len[i] = -1;
         return;
     }
+    // aggregates whose contributions cancelled are dropped (their key sorts behind all others), the rest goes out in order
+    int o = 0;
+    for (int u = 0; u < m; ++u) {
+        if (Vc[u][t] != 0.0) ++o;
+        else reinterpret_cast<int *>(&Kc[u >> 1][t])[u & 1] = 0x7fffffff;
+    }
     long long *K = key + slot_ptr[i];
     double *V = val + slot_ptr[i];
-    int o = 0;
-    for (int u = 0; u < m; ++u)
-        if (Vc[u][t] != 0.0) {
-            K[o] = (long long)Kc[u][t] << 32;
-            V[o] = Vc[u][t];
-            ++o;
+    for (int u = 0; u < CAP; ++u) {
+        if (__all(u >= m)) break;
+        const int ku = u < m ? reinterpret_cast<const int *>(&Kc[u >> 1][t])[u & 1] : 0x7fffffff;
+        int rank = 0;
+        for (int q = 0; q < CAP; q += 2) {
+            if (__all(q >= m)) break;
+            const int2 kk = Kc[q >> 1][t];
+            rank += (q < m && kk.x < ku) ? 1 : 0;
+            rank += (q + 1 < m && kk.y < ku) ? 1 : 0;
         }
+        if (ku != 0x7fffffff) {
+            K[rank] = (long long)ku << 32;
+            V[rank] = Vc[u][t];
+        }
+    }
     row_len[i] = o;
 }
 
