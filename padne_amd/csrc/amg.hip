@@ -109,6 +109,20 @@ __device__ __forceinline__ double2 load_d2_unaligned(const double *p) {
     return make_double2(v.x, v.y);
 }
 
+// Inclusive prefix sum over groups of LANES (16, 32 or 64) lanes, all lanes active: four shifts within the rows of 16 lanes,
+// then the last lane of a row added to the whole next row (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3)
+// -- six vector instructions instead of five rounds of index arithmetic, ds_bpermute and select.
+template <int LANES>
+__device__ __forceinline__ int scan_incl_lanes(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    if (LANES >= 32) x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    if (LANES == 64) x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return x;
+}
+
 // ---- XCD-aware row order --------------------------------------------------------------------------------------------
 // Workgroups are dealt to the 8 XCDs round-robin (b, b + 8, b + 16, ... share an XCD and its private 4 MiB L2).  A kernel
 // that walks the rows in workgroup order therefore shows every XCD rows from all over the matrix, and whatever the rows
@@ -1375,13 +1389,10 @@ __global__ __launch_bounds__(128) void spgemm_rows_lds_pipe(int n_rows, const in
         const int tile0 = i - lane, tile1 = min(tile0 + 64, n_rows);
         const int len = (live && !overflow) ? m : 0;
         const int bound = (live && overflow) ? slot_ptr[i + 1] - slot_ptr[i] : 0;
-        int incl = len, back = bound;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int a1 = __shfl_up(incl, d, 64), b1 = __shfl_down(back, d, 64);
-            if (lane >= d) incl += a1;
-            if (lane + d < 64) back += b1;
-        }
+        // (prefix sums of the lengths from the front, of the bounds from the back: total - prefix + own)
+        const int incl = scan_incl_lanes<64>(len);
+        const int bound_incl = scan_incl_lanes<64>(bound);
+        const int back = __builtin_amdgcn_readlane(bound_incl, 63) - bound_incl + bound;
         if (tile0 < n_rows) {
             const int r_begin = slot_ptr[tile0], r_end = slot_ptr[tile1];
             place = overflow ? r_end - back : r_begin + (incl - len);
@@ -1433,20 +1444,6 @@ __global__ __launch_bounds__(128) void spgemm_rows_lds_pipe(int n_rows, const in
 // and one ballot per column told its owner which products to add -- ~2.5 times the wave instructions, which is what
 // bounds these kernels: R (A P) of C4's fine level 1.35 ms.)
 // Rows that do not fit (X row > LANES entries, > CAPP products, > HT/2 distinct columns) are flagged (row_len -1).
-// Inclusive prefix sum over groups of LANES (16, 32 or 64) lanes, all lanes active: four shifts within the rows of 16 lanes,
-// then the last lane of a row added to the whole next row (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3)
-// -- six vector instructions instead of five rounds of index arithmetic, ds_bpermute and select.
-template <int LANES>
-__device__ __forceinline__ int scan_incl_lanes(int x) {
-    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
-    if (LANES >= 32) x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
-    if (LANES == 64) x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
-    return x;
-}
-
 template <int CAPP, int HT, int LANES>
 struct SpgemmRowLds {
     using Mask = typename std::conditional<LANES == 64, unsigned long long, unsigned>::type;

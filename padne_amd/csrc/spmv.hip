@@ -930,6 +930,18 @@ int csr_build_xw_plan(padne_ctx *ctx, padne_csr *m) {
     return PADNE_OK;
 }
 
+// minimum over the 64 lanes of a wave (all active), as a scalar: four shifts within the rows of 16 lanes, the rows' last lanes
+// handed on (row_bcast:15, row_bcast:31), lane 63 read -- seven instructions where six rounds of __shfl_xor are thirty
+__device__ __forceinline__ int wave_min_i32(int v) {
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x111, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x112, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x114, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x118, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x142, 0xa, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // The wide plan: greedy cover of a tile's columns by up to twelve runs of 20; every tile decides for itself (no count comes
 // back to the host: the plan is built on the second stream beside the Galerkin product, a look at the host there would
 // hold the main chain up), tiles that need more runs -- the two mesh lines a tile at a line's end touches -- keep the
@@ -967,8 +979,7 @@ __global__ __launch_bounds__(256) void xw_plan_wide_kernel(int n_rows, int n_wti
                     if (c > bound && c < mn) mn = c;
                 }
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) mn = min(mn, __shfl_xor(mn, off, 64));
+            mn = wave_min_i32(mn);
             if (q == kXwRunsWide) {
                 fits = mn == 0x7fffffff;
             } else {
