@@ -3157,7 +3157,9 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
         }
     }
     PADNE_HIP_CHECK(hipGetLastError());
-    if (while_multiplying != nullptr) PADNE_TRY((*while_multiplying)());
+    // (with a compaction behind the row kernels the call is made once its scan is queued as well: on a small level the row
+    // kernels are over before the host has made forty launches for the other stream)
+    if (while_multiplying != nullptr && keep_slots != nullptr) PADNE_TRY((*while_multiplying)());
     if (keep_slots != nullptr) {
         keep_slots->release();
         int *end = (int *)pool_alloc(ctx, sizeof(int) * (size_t)(n > 0 ? n : 1));
@@ -3180,7 +3182,9 @@ static int spgemm(padne_ctx *ctx, const padne_csr *X, const padne_csr *Y, padne_
         if (C != nullptr) *C = nullptr;
         return PADNE_OK;
     }
-    return csr_from_slots(ctx, n, Y->n_cols, row_begin != nullptr ? row_begin : slot_ptr, key, val, row_len, C);
+    auto trampoline = [](void *f) -> int { return (*static_cast<const std::function<int()> *>(f))(); };
+    return csr_from_slots(ctx, n, Y->n_cols, row_begin != nullptr ? row_begin : slot_ptr, key, val, row_len, C,
+                          while_multiplying != nullptr ? +trampoline : nullptr, const_cast<std::function<int()> *>(while_multiplying));
 }
 
 // ---- W = P - c D^-1 (A P): coarse correction and post-smoothing of a level in ONE product ----------------------------

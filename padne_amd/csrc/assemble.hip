@@ -2122,14 +2122,33 @@ int merge_slots_generic(padne_ctx *ctx, long long n_rows, const int *slot_ptr, l
     return PADNE_OK;
 }
 
+// while_scanning: called between the launch of the scan of the row lengths and the look at its total (what the caller
+// launches there, for another stream, is launched while this stream works)
 int csr_from_slots(padne_ctx *ctx, long long n_rows, long long n_cols, const int *slot_ptr, const long long *key,
-                   const double *val, const int *row_len, padne_csr **out) {
+                   const double *val, const int *row_len, padne_csr **out, int (*while_scanning)(void *), void *while_scanning_arg) {
     hipStream_t s = ctx->stream;
     Scratch sc(ctx);
     int *rowptr_tmp = nullptr;
     PADNE_TRY(sc.alloc(&rowptr_tmp, (size_t)n_rows + 1));
     int64_t nnz = 0;
-    PADNE_TRY(exclusive_scan_i32(ctx, row_len, rowptr_tmp, n_rows, &nnz));
+    {
+        ScanTicket ticket;
+        long long h[2] = {0, 0};
+        PADNE_TRY(scan_i32_begin(ctx, row_len, rowptr_tmp, n_rows, &ticket, true));
+        const int rc_cb = while_scanning != nullptr ? while_scanning(while_scanning_arg) : PADNE_OK;
+        const int rc_scan = scan_i32_end(ctx, &ticket, h);
+        PADNE_TRY(rc_cb);
+        PADNE_TRY(rc_scan);
+        if (h[0] < 0 || h[1] != 0) {
+            set_error("scan of negative counts");
+            return PADNE_E_INVALID;
+        }
+        if (h[0] >= 2147483647LL) {
+            set_error("%lld entries exceed the 32-bit index space", h[0]);
+            return PADNE_E_TOOLARGE;
+        }
+        nnz = h[0];
+    }
     padne_csr *m = nullptr;
     PADNE_TRY(csr_alloc(ctx, n_rows, n_cols, nnz, &m));
     hipError_t e = hipMemcpyAsync(m->rowptr, rowptr_tmp, sizeof(int32_t) * (size_t)(n_rows + 1),

@@ -413,7 +413,8 @@ int merge_slots_generic(padne_ctx *ctx, long long n_rows, const int *slot_ptr, l
 int sort_slots_exact(padne_ctx *ctx, long long n_rows, const int *slot_ptr, long long *key, double *val, int *row_len_scratch);
 // rows already compacted at their slot offsets (key >> 32 = column) -> new CSR matrix
 int csr_from_slots(padne_ctx *ctx, long long n_rows, long long n_cols, const int *slot_ptr, const long long *key,
-                   const double *val, const int *row_len, padne_csr **out);
+                   const double *val, const int *row_len, padne_csr **out,
+                   int (*while_scanning)(void *) = nullptr, void *while_scanning_arg = nullptr);
 // the same when every row fills its slots exactly (slot_ptr is the row pointer): no scan, no synchronisation
 int csr_from_exact_slots(padne_ctx *ctx, long long n_rows, long long n_cols, long long nnz, const int *slot_ptr,
                          const long long *key, const double *val, padne_csr **out);
