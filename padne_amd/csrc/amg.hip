@@ -4515,7 +4515,7 @@ int amg_batch_entry_args(padne_ctx *ctx, const padne_csr *A0, float *jac, const 
 // z8 = M^-1 r8 for k interleaved right-hand sides; partials_rz [k][kMaxPartials]; bb2 [k]
 template <int K>
 static int amg_apply_batch_k(padne_ctx *ctx, const padne_csr *A0, const double *r8, double *z8, double *partials_rz,
-                             const int32_t *done_flag, const double *bb2, const bool entry_done) {
+                             const int32_t *done_flag, const double *bb2, const bool entry_done, float *z32) {
     Amg *amg = (Amg *)A0->amg;
     PADNE_REQUIRE(amg != nullptr && amg->f32 && !amg->dist, "the batched cycle needs the single-GPU single-precision hierarchy");
     hipStream_t s = ctx->stream;
@@ -4551,7 +4551,7 @@ static int amg_apply_batch_k(padne_ctx *ctx, const padne_csr *A0, const double *
             // non-zeros of the fine level per lockstep iteration
             if (l == 0)
                 PADNE_TRY(launch_spmm_f32_wup_exit(ctx, L.W, K, amg->levels[1].xb8, z8, r8, partials_rz, done_flag, L.xa8,
-                                                   L.tmp8, L.A->dinv32, (float)L.jac, bb2));
+                                                   L.tmp8, L.A->dinv32, (float)L.jac, bb2, z32));
             else
                 PADNE_TRY(launch_spmm_f32_wup(ctx, L.W, K, amg->levels[l + 1].xb8, L.xb8, done_flag, L.xa8, L.tmp8,
                                               L.A->dinv32, (float)L.jac));
@@ -4564,17 +4564,19 @@ static int amg_apply_batch_k(padne_ctx *ctx, const padne_csr *A0, const double *
                                       (float)L.jac));
         else
             PADNE_TRY(launch_spmm_f32_exit(ctx, L.A, K, L.xa8, z8, r8, partials_rz, done_flag, L.b8, L.A->dinv32,
-                                           (float)L.jac, bb2));
+                                           (float)L.jac, bb2, z32));
     }
     return PADNE_OK;
 }
 
+// z32 (optional, instead of z8): z in single precision and without its factor sqrt(bb2[j]) -- the r.z partials are those of
+// the double it stands for (the lockstep loop keeps z and the search directions as floats, like the single loop)
 int amg_apply_batch(padne_ctx *ctx, const padne_csr *A0, int k, const double *r8, double *z8, double *partials_rz,
-                    const int32_t *done_flag, const double *bb2, bool entry_done) {
+                    const int32_t *done_flag, const double *bb2, bool entry_done, float *z32) {
     switch (k) {
-        case 8: return amg_apply_batch_k<8>(ctx, A0, r8, z8, partials_rz, done_flag, bb2, entry_done);
-        case 4: return amg_apply_batch_k<4>(ctx, A0, r8, z8, partials_rz, done_flag, bb2, entry_done);
-        case 2: return amg_apply_batch_k<2>(ctx, A0, r8, z8, partials_rz, done_flag, bb2, entry_done);
+        case 8: return amg_apply_batch_k<8>(ctx, A0, r8, z8, partials_rz, done_flag, bb2, entry_done, z32);
+        case 4: return amg_apply_batch_k<4>(ctx, A0, r8, z8, partials_rz, done_flag, bb2, entry_done, z32);
+        case 2: return amg_apply_batch_k<2>(ctx, A0, r8, z8, partials_rz, done_flag, bb2, entry_done, z32);
         default: set_error("lockstep width %d", k); return PADNE_E_INVALID;
     }
 }

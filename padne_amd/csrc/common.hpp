@@ -252,10 +252,10 @@ int launch_spmm_f32(padne_ctx *ctx, const padne_csr *m, int k, int mode, const f
                     const int32_t *done_flag, const float *aux1, const float *aux2, float scale);
 int launch_spmm_f32_exit(padne_ctx *ctx, const padne_csr *m, int k, const float *x, double *y, const double *dot_with,
                          double *partials, const int32_t *done_flag, const float *aux1, const float *aux2,
-                         float scale, const double *out_scale2);
+                         float scale, const double *out_scale2, float *y32 = nullptr);
 int launch_spmm_f32_wup_exit(padne_ctx *ctx, const padne_csr *w, int k, const float *e, double *z, const double *dot_with,
                              double *partials, const int32_t *done_flag, const float *x_pre, const float *r_pre,
-                             const float *dinv32, float scale, const double *out_scale2);
+                             const float *dinv32, float scale, const double *out_scale2, float *z32 = nullptr);
 bool spmv_resid_pre_ok(const padne_csr *m);
 int launch_spmv_f32_resid_pre(padne_ctx *ctx, const padne_csr *m, const float *b, float *resid, const int32_t *done_flag,
                               const float *dinv32, float c);

@@ -1145,7 +1145,7 @@ static int solve_one_single_reduction(padne_ctx *ctx, const padne_csr *a, const 
 // lockstep iteration costs less than as many single ones -- the width is a template parameter of every kernel below and a
 // run-time argument of the host functions)
 int amg_apply_batch(padne_ctx *ctx, const padne_csr *A0, int k, const double *r8, double *z8, double *partials_rz,
-                    const int32_t *done_flag, const double *bb2, bool entry_done = false);
+                    const int32_t *done_flag, const double *bb2, bool entry_done = false, float *z32 = nullptr);
 int amg_batch_entry_args(padne_ctx *ctx, const padne_csr *A0, float *jac, const float **dinv32, float **b8, float **xa8);
 bool amg_supports_batch8(const padne_csr *A0);
 
@@ -1154,6 +1154,11 @@ struct Pcg8Status {
     int32_t col_done[8];
     int32_t col_iters[8];
     double rr[8], tol2[8], bb[8];
+    // what the x / r update of an iteration read of `done` and `col_done` (values from BEFORE its launch): the p update of the
+    // same iteration carries the deferred x += alpha p and must take the same decisions in every workgroup, whatever its
+    // workgroup 0 has written to `done` / `col_done` in the meantime
+    int32_t done_seen, pad2;
+    int32_t col_seen[8];
 };
 
 // sums over this thread's strided share of an interleaved vector end up per column j = threadIdx.x & (K - 1);
@@ -1251,6 +1256,95 @@ __global__ __launch_bounds__(256) void pcg8_update_xr_kernel(const long long n, 
     block_store_partial8<K>(s_rr, red, part_rr);
 }
 
+// p = z of a (re)start, z as the cycle leaves it: floats in units of sqrt(unit2[j])
+template <int K>
+__global__ void p8_from_z32_kernel(const long long n, const float *__restrict__ z32, const double *__restrict__ unit2,
+                                   double *__restrict__ p) {
+    const double s2 = unit2[threadIdx.x & (K - 1)];
+    const double z_mul = s2 > 0.0 ? sqrt(s2) : 1.0;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n * K; t += (long long)gridDim.x * 256)
+        p[t] = (double)z32[t] * z_mul;
+}
+
+// The two vector updates of the lockstep loop with z in single precision (in units of ||b_j||, as the cycle leaves it) and
+// x += alpha p riding on the p update: p is read once per iteration instead of twice, z crosses memory as floats (per
+// iteration and right-hand side 24 bytes less in the x / r update, 8 less in the cycle's exit, 4 more in the p update).
+// The search directions stay doubles here: stored as floats (the single loop's form) the 8-wide product converts two
+// floats per non-zero and lane at the rate of double-precision arithmetic and is bound by it -- 512 against 330 us at
+// N = 5 M, more than the vector kernels save.
+template <int K>
+__global__ __launch_bounds__(256) void pcg8_update_r_entry_kernel(const long long n, const double *__restrict__ rz,
+                                                                const double *__restrict__ pq, const double *__restrict__ q,
+                                                                double *__restrict__ r, double *__restrict__ part_rr,
+                                                                Pcg8Status *__restrict__ st, const double *__restrict__ unit2,
+                                                                const float c, const float *__restrict__ dinv32,
+                                                                float *__restrict__ b32, float *__restrict__ xa32) {
+    __shared__ double red[4][8];
+    const int stop = st->done;              // written by an EARLIER launch: every workgroup of this one reads the same value
+    const int j = threadIdx.x & (K - 1);
+    const int frozen = st->col_done[j];
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) st->done_seen = stop;
+        if (threadIdx.x < K) st->col_seen[threadIdx.x] = frozen;
+    }
+    if (stop) return;
+    const double s2 = unit2[j];
+    const double s_inv = s2 > 0.0 ? 1.0 / sqrt(s2) : 1.0;
+    const double alpha = frozen ? 0.0 : rz[j] / pq[j];
+    double s_rr = 0.0;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n * K; t += (long long)gridDim.x * 256) {
+        const double ri = r[t] - alpha * q[t];
+        r[t] = ri;
+        s_rr += ri * ri;
+        const float v = (float)(ri * s_inv);
+        b32[t] = v;
+        xa32[t] = c * dinv32[t / K] * v;
+    }
+    block_store_partial8<K>(s_rr, red, part_rr);
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void pcg8_update_p_z_kernel(const long long n, const double *__restrict__ rz_new,
+                                                                const double *__restrict__ rz_old, const double *__restrict__ rr,
+                                                                const double *__restrict__ pq, const double *__restrict__ unit2,
+                                                                const float *__restrict__ z32, double *__restrict__ p,
+                                                                double *__restrict__ x, Pcg8Status *__restrict__ st,
+                                                                const int max_iter) {
+    if (st->done_seen) return;
+    const int j = threadIdx.x & (K - 1);
+    const int frozen = st->col_seen[j];
+    const double s2 = unit2[j];
+    const double z_mul = s2 > 0.0 ? sqrt(s2) : 1.0;
+    const double beta = frozen ? 0.0 : rz_new[j] / rz_old[j];
+    const double alpha = frozen ? 0.0 : rz_old[j] / pq[j];
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n * K; t += (long long)gridDim.x * 256) {
+        const double pi = p[t];
+        x[t] += alpha * pi;
+        p[t] = (double)z32[t] * z_mul + beta * pi;
+    }
+    if (blockIdx.x == 0) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int it = st->iters + 1;
+            st->iters = it;
+            int all = 1;
+            for (int c = 0; c < K; ++c) {
+                if (st->col_done[c]) continue;
+                st->col_iters[c] += 1;
+                st->rr[c] = rr[c];
+                if (!(pq[c] > 0.0) || !(rr[c] == rr[c]) || !(rz_new[c] > 0.0)) {
+                    st->code = PADNE_E_BREAKDOWN;
+                } else if (rr[c] <= st->tol2[c]) {
+                    st->col_done[c] = 1;
+                    continue;
+                }
+                all = 0;
+            }
+            if (all || st->code != PADNE_OK || it >= max_iter) st->done = 1;
+        }
+    }
+}
+
 template <int K>
 __global__ __launch_bounds__(256) void pcg8_update_p_kernel(const long long n, const double *__restrict__ rz_new,
                                                             const double *__restrict__ rz_old, const double *__restrict__ rr,
@@ -1318,7 +1412,7 @@ static int solve_batch(padne_ctx *ctx, const padne_csr *a, const double *b_cols,
     PADNE_TRY(sc.alloc(&scal, 64));
     enum { P_PQ = 0, P_RZ0 = 1, P_RZ1 = 2, P_RR = 3, P_BB = 4, P_TMP = 5 };
     auto pslot = [&](int k) { return part + (size_t)k * 8 * kMaxPartials; };
-    enum { C_PQ = 0, C_RZ0 = 8, C_RZ1 = 16, C_RR = 24, C_BB = 32, C_TRUE = 40 };
+    enum { C_PQ = 0, C_RZ0 = 8, C_RZ1 = 16, C_RR = 24, C_BB = 32, C_TRUE = 40, C_NRM = 48 };
     Pcg8Status *st = (Pcg8Status *)ctx->status;
     Pcg8Status *hst = (Pcg8Status *)ctx->pinned;
     const int gv = vec_grid(n * K);
@@ -1345,6 +1439,11 @@ static int solve_batch(padne_ctx *ctx, const padne_csr *a, const double *b_cols,
     float e_jac = 0.f, *e_b8 = nullptr, *e_xa8 = nullptr;
     const float *e_dinv32 = nullptr;
     PADNE_TRY(amg_batch_entry_args(ctx, a, &e_jac, &e_dinv32, &e_b8, &e_xa8));
+    // z in single precision, in z8's own memory, with x += alpha p on the p update (PADNE_PCG_P64=1: the loop of rounds 3-4,
+    // z in double and x updated beside r); its unit is ||b_j||, from an initial guess ||r_0,j|| of the first start (see solve_one)
+    const bool hat = !ctx->opt.pcg_p64;
+    float *z32 = hat ? (float *)z8 : nullptr;
+    const double *unit2 = (hat && x_is_guess) ? scal + C_NRM : scal + C_BB;
     int restarts = 0, total_iters = 0, code = PADNE_OK;
     double true_rr[8] = {0}, prev_true_rr[8] = {0}, bb[8] = {0}, tol2[8] = {0};
     int col_iters[8] = {0};
@@ -1355,9 +1454,16 @@ static int solve_batch(padne_ctx *ctx, const padne_csr *a, const double *b_cols,
         PADNE_HIP_CHECK(hipGetLastError());
         PADNE_TRY(fold(pslot(P_RR), gv, scal + C_RR));
         PADNE_TRY(fold(pslot(P_BB), gv, scal + C_BB));
-        PADNE_TRY(amg_apply_batch(ctx, a, K, r8, z8, pslot(P_RZ0), nullptr, scal + C_BB));
+        if (hat && x_is_guess && restarts == 0)
+            PADNE_HIP_CHECK(hipMemcpyAsync(scal + C_NRM, scal + C_RR, sizeof(double) * 8, hipMemcpyDeviceToDevice, s));
+        PADNE_TRY(amg_apply_batch(ctx, a, K, r8, z8, pslot(P_RZ0), nullptr, unit2, false, z32));
         PADNE_TRY(fold(pslot(P_RZ0), gs, scal + C_RZ0));
-        PADNE_HIP_CHECK(hipMemcpyAsync(p8, z8, sizeof(double) * nv, hipMemcpyDeviceToDevice, s));
+        if (hat) {
+            hipLaunchKernelGGL(p8_from_z32_kernel<K>, dim3(gv), dim3(256), 0, s, n, (const float *)z32, unit2, p8);
+            PADNE_HIP_CHECK(hipGetLastError());
+        } else {
+            PADNE_HIP_CHECK(hipMemcpyAsync(p8, z8, sizeof(double) * nv, hipMemcpyDeviceToDevice, s));
+        }
         hipLaunchKernelGGL(pcg8_set_tolerance_kernel, dim3(1), dim3(64), 0, s, st, scal + C_RR, scal + C_BB, o->rtol,
                            o->atol, restarts > 0 ? 1 : 0, K);
         PADNE_HIP_CHECK(hipGetLastError());
@@ -1367,17 +1473,31 @@ static int solve_batch(padne_ctx *ctx, const padne_csr *a, const double *b_cols,
             for (int k = 0; k < check_every; ++k) {
                 double *rz_old = scal + (parity ? C_RZ1 : C_RZ0), *rz_new = scal + (parity ? C_RZ0 : C_RZ1);
                 const int rz_new_slot = parity ? P_RZ0 : P_RZ1;
-                PADNE_TRY(launch_spmm_mode(ctx, a, K, SPMV_DOT, p8, q8, p8, pslot(P_PQ), &st->done, nullptr, nullptr, 0.0));
-                PADNE_TRY(fold(pslot(P_PQ), gs, scal + C_PQ));
-                hipLaunchKernelGGL(pcg8_update_xr_kernel<K>, dim3(gv), dim3(256), 0, s, n, rz_old, scal + C_PQ, p8, q8, x8, r8,
-                                   pslot(P_RR), st, (const double *)(scal + C_BB), e_jac, e_dinv32, e_b8, e_xa8);
-                PADNE_HIP_CHECK(hipGetLastError());
-                PADNE_TRY(amg_apply_batch(ctx, a, K, r8, z8, pslot(rz_new_slot), &st->done, scal + C_BB, true));
-                PADNE_TRY(fold(pslot(rz_new_slot), gs, rz_new));
-                PADNE_TRY(fold(pslot(P_RR), gv, scal + C_RR));
-                hipLaunchKernelGGL(pcg8_update_p_kernel<K>, dim3(gv), dim3(256), 0, s, n, rz_new, rz_old, scal + C_RR,
-                                   scal + C_PQ, z8, p8, st, max_iter - total_iters);
-                PADNE_HIP_CHECK(hipGetLastError());
+                if (hat) {
+                    PADNE_TRY(launch_spmm_mode(ctx, a, K, SPMV_DOT, p8, q8, p8, pslot(P_PQ), &st->done, nullptr, nullptr, 0.0));
+                    PADNE_TRY(fold(pslot(P_PQ), gs, scal + C_PQ));
+                    hipLaunchKernelGGL(pcg8_update_r_entry_kernel<K>, dim3(gv), dim3(256), 0, s, n, rz_old, scal + C_PQ, q8, r8,
+                                       pslot(P_RR), st, unit2, e_jac, e_dinv32, e_b8, e_xa8);
+                    PADNE_HIP_CHECK(hipGetLastError());
+                    PADNE_TRY(amg_apply_batch(ctx, a, K, r8, z8, pslot(rz_new_slot), &st->done, unit2, true, z32));
+                    PADNE_TRY(fold(pslot(rz_new_slot), gs, rz_new));
+                    PADNE_TRY(fold(pslot(P_RR), gv, scal + C_RR));
+                    hipLaunchKernelGGL(pcg8_update_p_z_kernel<K>, dim3(gv), dim3(256), 0, s, n, rz_new, rz_old, scal + C_RR,
+                                       scal + C_PQ, unit2, (const float *)z32, p8, x8, st, max_iter - total_iters);
+                    PADNE_HIP_CHECK(hipGetLastError());
+                } else {
+                    PADNE_TRY(launch_spmm_mode(ctx, a, K, SPMV_DOT, p8, q8, p8, pslot(P_PQ), &st->done, nullptr, nullptr, 0.0));
+                    PADNE_TRY(fold(pslot(P_PQ), gs, scal + C_PQ));
+                    hipLaunchKernelGGL(pcg8_update_xr_kernel<K>, dim3(gv), dim3(256), 0, s, n, rz_old, scal + C_PQ, p8, q8, x8, r8,
+                                       pslot(P_RR), st, (const double *)(scal + C_BB), e_jac, e_dinv32, e_b8, e_xa8);
+                    PADNE_HIP_CHECK(hipGetLastError());
+                    PADNE_TRY(amg_apply_batch(ctx, a, K, r8, z8, pslot(rz_new_slot), &st->done, scal + C_BB, true));
+                    PADNE_TRY(fold(pslot(rz_new_slot), gs, rz_new));
+                    PADNE_TRY(fold(pslot(P_RR), gv, scal + C_RR));
+                    hipLaunchKernelGGL(pcg8_update_p_kernel<K>, dim3(gv), dim3(256), 0, s, n, rz_new, rz_old, scal + C_RR,
+                                       scal + C_PQ, z8, p8, st, max_iter - total_iters);
+                    PADNE_HIP_CHECK(hipGetLastError());
+                }
                 parity ^= 1;
             }
             PADNE_HIP_CHECK(hipMemcpyAsync(hst, st, sizeof(Pcg8Status), hipMemcpyDeviceToHost, s));

@@ -22,10 +22,14 @@ constexpr int kSpmmChunk = 512;      // non-zeros staged per wave per pass (6 Ki
 
 // K = 8, 4 or 2 right-hand sides (the narrow forms serve one to three regulators, pcg.hip): K / 2 lanes share a row,
 // 128 / K rows form a group, a wave works through its 64 rows in K / 2 groups.
-template <int K, int MODE, typename VT, typename XT, typename YT>
+// ST (default XT): the type the multiplied vectors are STORED in.  <K, SPMV_DOT, double, double, double, float> -- q = A p with the
+// search directions kept as floats, multiplied in double, the single loop's form -- was built and measured in round 5 and is NOT
+// used: two conversions per non-zero and lane run at the rate of double-precision arithmetic, the product became bound by
+// them (512 against 330 us at N = 5 M).  The parameter stays for the gathers' type.
+template <int K, int MODE, typename VT, typename XT, typename YT, typename ST = XT>
 __global__ __launch_bounds__(kSpmvThreads) void csr_spmm_kernel(
     const int n_rows, const int n_wtiles, const int *__restrict__ rowptr, const int *__restrict__ cols,
-    const VT *__restrict__ vals, const XT *__restrict__ x, YT *__restrict__ y, const double *__restrict__ dot_with,
+    const VT *__restrict__ vals, const ST *__restrict__ x, YT *__restrict__ y, const double *__restrict__ dot_with,
     double *__restrict__ partials /* [8][kMaxPartials] */, const int *__restrict__ done_flag,
     const XT *__restrict__ aux1, const XT *__restrict__ aux2, const XT scale,
     const double *__restrict__ out_scale2 /* [K] or null */, const XT *__restrict__ aux0 /* SPMV_WUP: [n][K] */) {
@@ -57,7 +61,9 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmm_kernel(
     const int wps = (G / nslab) * 4;
     const int s0 = (int)((long long)slab * n_wtiles / nslab);
     const int s1 = (int)((long long)(slab + 1) * n_wtiles / nslab);
+    static_assert(sizeof(ST) == sizeof(XT) || MODE == SPMV_DOT || MODE == SPMV_PLAIN, "stored type: products only");
     struct alignas(2 * sizeof(XT)) X2 { XT a, b; };
+    struct alignas(2 * sizeof(ST)) S2 { ST a, b; };
     struct alignas(2 * sizeof(YT)) Y2 { YT a, b; };
 
     double dot0 = 0.0, dot1 = 0.0;
@@ -96,7 +102,7 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmm_kernel(
                 const int lo = max(grs[g], base), hi = min(gre[g], base + kSpmmChunk);
                 XT a0 = acc0[g], a1 = acc1[g];
                 for (int k = lo; k < hi; k += 8) {             // up to eight 16-byte gathers in flight per lane
-                    X2 xv[8];
+                    S2 xv[8];
                     XT vv[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
@@ -104,15 +110,15 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmm_kernel(
                         xv[u].b = 0;
                         vv[u] = 0;
                         if (k + u < hi) {
-                            xv[u] = *reinterpret_cast<const X2 *>(x + (size_t)cs[k + u - base] * K + j);
+                            xv[u] = *reinterpret_cast<const S2 *>(x + (size_t)cs[k + u - base] * K + j);
                             vv[u] = (XT)vs[k + u - base];
                         }
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u)
                         if (k + u < hi) {
-                            a0 += vv[u] * xv[u].a;
-                            a1 += vv[u] * xv[u].b;
+                            a0 += vv[u] * (XT)xv[u].a;
+                            a1 += vv[u] * (XT)xv[u].b;
                         }
                 }
                 acc0[g] = a0;
@@ -134,8 +140,14 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmm_kernel(
             } else if (MODE == SPMV_DOT) {
                 out2.a = (YT)a0;
                 out2.b = (YT)a1;
-                dot0 += dot_with[o] * (double)a0;
-                dot1 += dot_with[o + 1] * (double)a1;
+                if (sizeof(ST) != sizeof(XT)) {                    // p.q with the stored p
+                    const S2 xs = *reinterpret_cast<const S2 *>(x + o);
+                    dot0 += (double)xs.a * (double)a0;
+                    dot1 += (double)xs.b * (double)a1;
+                } else {
+                    dot0 += dot_with[o] * (double)a0;
+                    dot1 += dot_with[o + 1] * (double)a1;
+                }
             } else if (MODE == SPMV_RESID) {
                 const X2 b = *reinterpret_cast<const X2 *>(aux1 + o);
                 out2.a = (YT)(b.a - a0);
@@ -151,8 +163,9 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmm_kernel(
                 const XT o0 = xp.a + d * rp.a + a0, o1 = xp.b + d * rp.b + a1;
                 if (dot_with != nullptr) {
                     const double d0 = (double)o0 * out_mul0, d1 = (double)o1 * out_mul1;
-                    out2.a = (YT)d0;
-                    out2.b = (YT)d1;
+                    // (a float result leaves unscaled, as in spmv.hip: the consumer multiplies, the same double comes out)
+                    out2.a = sizeof(YT) == 4 ? (YT)o0 : (YT)d0;
+                    out2.b = sizeof(YT) == 4 ? (YT)o1 : (YT)d1;
                     dot0 += dot_with[o] * d0;
                     dot1 += dot_with[o + 1] * d1;
                 } else {      // inner level of the cycle
@@ -161,13 +174,13 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmm_kernel(
                 }
             } else {
                 const X2 b = *reinterpret_cast<const X2 *>(aux1 + o);
-                const X2 xo = *reinterpret_cast<const X2 *>(x + o);
+                const S2 xo = *reinterpret_cast<const S2 *>(x + o);
                 const XT d = scale * aux2[r];
-                const XT o0 = xo.a + d * (b.a - a0), o1 = xo.b + d * (b.b - a1);
+                const XT o0 = (XT)xo.a + d * (b.a - a0), o1 = (XT)xo.b + d * (b.b - a1);
                 if (dot_with != nullptr) {
                     const double d0 = (double)o0 * out_mul0, d1 = (double)o1 * out_mul1;
-                    out2.a = (YT)d0;
-                    out2.b = (YT)d1;
+                    out2.a = sizeof(YT) == 4 ? (YT)o0 : (YT)d0;
+                    out2.b = sizeof(YT) == 4 ? (YT)o1 : (YT)d1;
                     dot0 += dot_with[o] * d0;
                     dot1 += dot_with[o + 1] * d1;
                 } else {
@@ -259,10 +272,17 @@ int launch_spmm_f32(padne_ctx *ctx, const padne_csr *m, int k, int mode, const f
 #undef ARGS
 }
 
+// (y32 instead of y: z leaves in single precision and without its factor, the r.z partials are those of the double)
 int launch_spmm_f32_exit(padne_ctx *ctx, const padne_csr *m, int k, const float *x, double *y, const double *dot_with,
                          double *partials, const int32_t *done_flag, const float *aux1, const float *aux2,
-                         float scale, const double *out_scale2) {
+                         float scale, const double *out_scale2, float *y32) {
     PADNE_REQUIRE(m->vals32 != nullptr && dot_with != nullptr, "single-precision exit stage");
+    if (y32 != nullptr) {
+#define ARGS ctx, m, m->vals32, SPMV_JACOBI, x, y32, dot_with, partials, done_flag, aux1, aux2, scale, out_scale2
+        PADNE_SPMM_WIDTH(k, (launch_spmm_typed<8, float, float, float>(ARGS)), (launch_spmm_typed<4, float, float, float>(ARGS)),
+                         (launch_spmm_typed<2, float, float, float>(ARGS)))
+#undef ARGS
+    }
 #define ARGS ctx, m, m->vals32, SPMV_JACOBI, x, y, dot_with, partials, done_flag, aux1, aux2, scale, out_scale2
     PADNE_SPMM_WIDTH(k, (launch_spmm_typed<8, float, float, double>(ARGS)), (launch_spmm_typed<4, float, float, double>(ARGS)),
                      (launch_spmm_typed<2, float, float, double>(ARGS)))
@@ -273,8 +293,14 @@ int launch_spmm_f32_exit(padne_ctx *ctx, const padne_csr *m, int k, const float 
 // partial sums of dot_with . z per right-hand side (the lockstep counterpart of launch_spmv_f32_wup_exit)
 int launch_spmm_f32_wup_exit(padne_ctx *ctx, const padne_csr *w, int k, const float *e, double *z, const double *dot_with,
                              double *partials, const int32_t *done_flag, const float *x_pre, const float *r_pre,
-                             const float *dinv32, float scale, const double *out_scale2) {
+                             const float *dinv32, float scale, const double *out_scale2, float *z32) {
     PADNE_REQUIRE(w->vals32 != nullptr && dot_with != nullptr, "single-precision W stage");
+    if (z32 != nullptr) {
+#define ARGS ctx, w, w->vals32, SPMV_WUP, e, z32, dot_with, partials, done_flag, r_pre, dinv32, scale, out_scale2, x_pre
+        PADNE_SPMM_WIDTH(k, (launch_spmm_typed<8, float, float, float>(ARGS)), (launch_spmm_typed<4, float, float, float>(ARGS)),
+                         (launch_spmm_typed<2, float, float, float>(ARGS)))
+#undef ARGS
+    }
 #define ARGS ctx, w, w->vals32, SPMV_WUP, e, z, dot_with, partials, done_flag, r_pre, dinv32, scale, out_scale2, x_pre
     PADNE_SPMM_WIDTH(k, (launch_spmm_typed<8, float, float, double>(ARGS)), (launch_spmm_typed<4, float, float, double>(ARGS)),
                      (launch_spmm_typed<2, float, float, double>(ARGS)))

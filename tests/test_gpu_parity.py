@@ -2371,6 +2371,18 @@ def test_batched_right_hand_sides_in_lockstep(ctx, switches):
     rough = d.solve_spd(B[:8], precond="amg", x0=res.x[:8] * (1.0 + 1e-3))
     assert rough.rel_residual <= 1.1e-12 and rough.iterations < res.iterations
     assert np.abs(rough.x - res.x[:8]).max() <= REL_TOL * np.abs(res.x[:8]).max()
+    # the loop of rounds 3-4 (z in double, x updated beside r: PADNE_PCG_P64=1) reaches the same solutions in as many iterations
+    switches.set("PADNE_PCG_P64", "1")
+    old = d.solve_spd(B[:8], precond="amg")
+    switches.unset("PADNE_PCG_P64")
+    new = d.solve_spd(B[:8], precond="amg")
+    assert old.rel_residual <= 1.1e-12 and abs(old.iterations - new.iterations) <= 8
+    for c in range(8):
+        assert np.abs(old.x[c] - new.x[c]).max() <= REL_TOL * max(np.abs(new.x[c]).max(), 1e-300)
+    # a guess whose residual lies thirty orders below the right-hand sides: the single-precision vectors of the loop are
+    # in units of that first residual, not of ||b|| (floats of 1e-30 ||b|| would be denormals or zero)
+    tiny = d.solve_spd(B[:8], precond="amg", x0=res.x[:8] * (1.0 + 1e-30))
+    assert tiny.status == _hip.OK and tiny.rel_residual <= 1.1e-12
     B14 = np.vstack([B, B[:3] * 0.5])
     res14 = d.solve_spd(B14, precond="amg")
     assert res14.rel_residual <= 1.1e-12
