@@ -621,6 +621,53 @@ def test_windowed_setup_kernels_build_the_same_hierarchy(ctx, switches, hub):
     assert abs(ops_w[1][0] - ref).max() <= 1e-12 * abs(ref).max()
 
 
+def test_sparse_products_with_rows_beyond_every_limit_of_the_lane_group_kernels(ctx):
+    """Vertices with 13 ... 600 far neighbours make rows that leave the lane-group product kernels at every one of their limits --
+    more entries of X than lanes (16, 32, 64), more products than the bit string of their first products holds, more distinct
+    columns than half the hash table -- and go down the chain of passes (list of flagged rows with a whole wave, dense
+    accumulator, one thread per row).  Whatever pass forms a row: R = P^T exactly, A_c = R (A P) to rounding against scipy,
+    the same bits from two setups, and the solve agrees with the direct one."""
+    sysm = synthetic.layered_system(2, 300, 240, via_lattice=6)
+    els = [("R", int(a), int(b), float(r)) for a, b, r in zip(*sysm.resistors)]
+    els += [("I", int(f), int(t), float(i)) for f, t, i in zip(*sysm.current_sources)]
+    rng = np.random.default_rng(11)
+    nv = sysm.n_vertices
+    for h, deg in enumerate((13, 20, 40, 80, 200, 600)):
+        hub = 300 * (17 + 31 * h) + 11 * h + 7
+        far = rng.choice(np.arange(1, nv), size=deg, replace=False)
+        els += [("R", int(hub), int(f), 0.05 + 0.01 * (k % 7)) for k, f in enumerate(far) if int(f) != hub]
+    Lo, ro = O.assemble_system([(m[0], m[1], m[2]) for m in sysm.meshes], 0, els, 0)
+    A = (-Lo[1:nv, 1:nv]).tocsr()
+    A.sort_indices()
+    b = -ro[1:nv]
+    assert np.diff(A.indptr).max() > 500
+
+    def hierarchy():
+        d = ctx.csr_from_scipy(A)
+        res = d.solve_spd(b, precond="amg")
+        ops = [(d.amg_level(l, "A"), d.amg_level(l, "P"), d.amg_level(l, "R")) for l in range(res.levels - 1)]
+        ops.append((d.amg_level(res.levels - 1, "A"), None, None))
+        d.close()
+        return res, ops
+    res, ops = hierarchy()
+    res2, ops2 = hierarchy()
+    assert res.status == _hip.OK and res.levels >= 3 and res.rel_residual <= 1.1e-12
+    assert np.array_equal(res.x, res2.x)
+    for (Al, P, R), (Al2, P2, R2) in zip(ops, ops2):
+        assert np.array_equal(Al.indptr, Al2.indptr) and np.array_equal(Al.indices, Al2.indices) and np.array_equal(Al.data, Al2.data)
+        if P is not None:
+            assert np.array_equal(P.data, P2.data) and np.array_equal(R.data, R2.data)
+    for lvl in range(len(ops) - 1):
+        Al, P, R = ops[lvl]
+        Ac = ops[lvl + 1][0]
+        assert abs(R - P.T).max() == 0.0 and R.has_sorted_indices and Ac.has_sorted_indices
+        ref = (P.T @ Al @ P).tocsr()
+        assert abs(Ac - ref).max() <= 1e-12 * abs(ref).max()
+    import scipy.sparse.linalg as spla
+    ref = spla.spsolve(A.tocsc(), b)
+    assert np.abs(res.x - ref).max() <= REL_TOL * np.abs(ref).max()
+
+
 def test_setup_on_one_stream_builds_the_same_hierarchy(ctx, switches):
     """PADNE_SETUP_ONE_STREAM=1 (a switch for kernel traces: standalone times of the setup's side kernels) queues the
     side work of the multigrid setup on the main stream: the same kernels in another order of execution, hence the same
