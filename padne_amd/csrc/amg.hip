@@ -10,19 +10,20 @@
 //              aggregate of its strongest aggregated neighbour (two passes); vertices without strong
 //              neighbours become singletons
 //   prolong    P = (I - omega D_F^-1 A_F) T,  T = piecewise constant, A_F = A with the weak entries lumped into
-//              the diagonal,  omega = 4 / (3 lambda),  lambda = Gershgorin bound of D_F^-1 A_F
-//   restrict   R = P^T stored explicitly (CSR) so that restriction is the same SpMV kernel
-//   coarse     A_c = R (A P) by two row-wise sparse products: one thread per row with sorted lists in LDS for
-//              short rows, one wave per row (hash set + per-lane ordered sums) for medium rows, a dense LDS
+//              the diagonal,  omega = 1.5 / lambda,  lambda = Gershgorin bound of D_F^-1 A_F
+//   restrict   R = P^T stored explicitly (CSR, placed in column order without a sort) so that restriction is the same SpMV kernel
+//   coarse     A_c = R (A P) by two row-wise sparse products: one thread per row with a short list in LDS for the fine
+//              level's A P, 16 / 32 / 64 lanes per row with a lane mask per column everywhere else, a dense LDS
 //              accumulator for the long rows of the coarse levels; products are always added in generation order
-// until n <= 2048, where the dense inverse is formed by a blocked Gauss-Jordan (SPD: no pivoting).
+// until n <= 2048, where the dense inverse is formed by a blocked Gauss-Jordan on the f64 matrix cores (SPD: no pivoting).
 //
 // Apply: V(1,1) cycle with damped Jacobi (first-degree Chebyshev on [lambda/10, lambda]); every
-// stage is the SpMV kernel of spmv.hip with a different epilogue (residual, prolong-add,
-// Jacobi sweep), so the fine level costs three matrix passes per CG iteration.  The cycle is a
+// stage is the SpMV kernel of spmv.hip with a different epilogue (residual formed from the right-hand side alone,
+// restriction with the first sweep of the level below, coarse correction + post-smoothing in ONE product with
+// W = P - c D^-1 A P), so the fine level costs two and a half matrix passes per CG iteration.  The cycle is a
 // fixed symmetric positive definite linear operator, hence plain PCG applies.  By default it runs in
-// single precision on float copies of its operators (amg_apply_f32), also for 8 interleaved right-hand
-// sides at once (amg_apply_batch8).
+// single precision on float copies of its operators (amg_apply_f32), also for 8 / 4 / 2 interleaved right-hand
+// sides at once (amg_apply_batch).
 //
 // Row-partitioned runs (one rank per GPU): one hierarchy over all ranks, see amg_setup_dist below.
 #include "common.hpp"
@@ -2657,15 +2658,14 @@ __global__ __launch_bounds__(128) void prolong_rows_lds(int n, const int *__rest
 }
 
 // The prolongator rows of a matrix with an x-window plan (the fine level: 10 M rows of 7 entries).  The one-thread-per-
-// row kernel above walks its row with strided, dependent global loads, merges by sorted insertion in LDS (a chain of
-// dependent LDS round trips with divergent trip counts) and parks the rows in 16-byte slots that a second kernel
-// compacts.  Here a wave streams the 64 rows of a tile into LDS with coalesced loads, stages the aggregates of the
+// row kernel above walks its row with strided, dependent global loads, keeps a list per lane in LDS and parks the rows in
+// 16-byte slots that a second kernel compacts.  Here a wave streams the 64 rows of a tile into LDS with coalesced loads, stages the aggregates of the
 // tile's three runs of neighbours, and every lane merges its row IN REGISTERS without data-dependent control flow: the
 // row's contributions (aggregate, value) sit in fixed slots, `first` marks the first slot of every aggregate, its sum
 // runs over the later slots of the same aggregate in slot order (the order prolong_rows_lds adds them in), and the
 // rank of an aggregate among the kept ones is where its entry goes -- all O(m^2) compares on m <= 14 registers.
-// Two passes with the same arithmetic: COUNT leaves the row lengths, FILL writes the finished CSR rows in place: no
-// slots, no compaction.  Tiles without a plan (rows with far couplings) take cols / scol from global memory.
+// One pass (prolong_rows_xw below: the rows of a tile staged back to back, then moved); tiles without a plan (rows with far
+// couplings) take cols / scol from global memory.
 constexpr int kPxSlots = 14;        // identity + up to 13 entries of the row of A (longer rows: the whole matrix falls back)
 constexpr int kPxChunk = 640;       // entries of a 64-row tile staged at once (10 per row)
 // (merge: the row's kept aggregates c[k] / sums / keep flags in registers, returns their number; store: an entry's place is

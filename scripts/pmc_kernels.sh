@@ -15,7 +15,7 @@ for f in glob.glob(f"{out}/set*/**/*counter_collection.csv", recursive=True):
         k = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("padne::", "")[:60] + " g=" + row.get("Grid_Size", row.get("Grid_Size_X", "?"))
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 import os
-want = tuple(os.environ["PMC_KERNELS"].split(",")) if os.environ.get("PMC_KERNELS") else ("spgemm_rows_lds", "spgemm_rows_sub", "spgemm_rows_wave", "csr_spmv_kernel<2", "csr_spmv_kernel<6", "csr_spmv_kernel<1", "transpose_fill", "strength_mark", "agg_join", "prolong_rows_xw", "w_from_slots", "nbr_max_xw", "spgemm_count")
+want = tuple(os.environ["PMC_KERNELS"].split(",")) if os.environ.get("PMC_KERNELS") else ("spgemm_rows_lds", "spgemm_rows_lanes", "csr_spmv_kernel<2", "csr_spmv_kernel<6", "csr_spmv_kernel<1", "transpose_fill", "strength_mark", "agg_join", "prolong_rows_xw", "w_from_slots", "nbr_max_xw", "spgemm_count")
 names = sorted({c for k in acc for c in acc[k]})
 print("kernel".ljust(75), " ".join(n.rjust(16) for n in names))
 for k in sorted(acc):
