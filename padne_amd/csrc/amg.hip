@@ -3551,7 +3551,8 @@ int amg_setup(padne_ctx *ctx, padne_csr *A0) {
         };
         if (coarsest && (rc = queue_level_extras()) != PADNE_OK) { amg->levels.push_back(L); break; }
         if (coarsest) {
-            rc = gershgorin(ctx, A, &L.lambda);
+            // (no bound of D^-1 A here: the coarsest operator is inverted, never smoothed -- the bound cost a pass of one thread
+            // per row over rows of hundreds of entries and a look at the host in front of the inverse, 50 us)
             amg->levels.push_back(L);
             break;
         }
