@@ -19,6 +19,9 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
+if os.environ.get("PADNE_AB_LIB"):      # another build of the library (same-box A/B)
+    from padne_amd import _hip as _hip_ab
+    _hip_ab.LIB_PATH = os.path.abspath(os.environ["PADNE_AB_LIB"])
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--side", type=int, default=1620)
