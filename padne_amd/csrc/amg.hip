@@ -2852,7 +2852,9 @@ static int build_prolongator(padne_ctx *ctx, const padne_csr *A, const int *agg,
     hipStream_t s = ctx->stream;
     const int n = (int)A->n_rows;
     Scratch sc(ctx);
-    if (spos != nullptr && scol != nullptr && A->xw_state == 1 && A->xw_run <= 85 && n > 0) {
+    // (the staging places are 32-bit: first entry of the tile + first row of the tile)
+    if (spos != nullptr && scol != nullptr && A->xw_state == 1 && A->xw_run <= 85 && n > 0 &&
+        (long long)A->nnz + (long long)n < 2147483647LL) {
         // windowed fine level: the rows staged tile by tile, the scan of their lengths, the tiles' runs moved into the CSR arrays
         int *row_len = nullptr, *rowptr_tmp = nullptr, *st_cols = nullptr;
         double *st_vals = nullptr;
