@@ -4463,7 +4463,7 @@ __global__ void amg_entry_f32xk_kernel(long long n, const double *__restrict__ r
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n * K; t += (long long)gridDim.x * blockDim.x) {
         const float v = (float)(r[t] * s_inv);
         b[t] = v;
-        x[t] = c * dinv[t / K] * v;
+        if (x != nullptr) x[t] = c * dinv[t / K] * v;      // (null: the level forms its first sweep from b itself)
     }
 }
 
@@ -4555,8 +4555,10 @@ static int amg_apply_batch_k(padne_ctx *ctx, const padne_csr *A0, const double *
             // still holds the residual of the pre-smoothed iterate that the down-leg restricted): 52 M instead of 24 + 70 M
             // non-zeros of the fine level per lockstep iteration
             if (l == 0)
-                PADNE_TRY(launch_spmm_f32_wup_exit(ctx, L.W, K, amg->levels[1].xb8, z8, r8, partials_rz, done_flag, L.xa8,
-                                                   L.tmp8, L.A->dinv32, (float)L.jac, bb2, z32));
+                PADNE_TRY(launch_spmm_f32_wup_exit(ctx, L.W, K, amg->levels[1].xb8, z8, r8, partials_rz, done_flag,
+                                                   L.A->dinv32 != nullptr ? (const float *)nullptr : (const float *)L.xa8, L.tmp8,
+                                                   L.A->dinv32, (float)L.jac, bb2, z32,
+                                                   L.A->dinv32 != nullptr ? (const float *)L.b8 : (const float *)nullptr));
             else
                 PADNE_TRY(launch_spmm_f32_wup(ctx, L.W, K, amg->levels[l + 1].xb8, L.xb8, done_flag, L.xa8, L.tmp8,
                                               L.A->dinv32, (float)L.jac));

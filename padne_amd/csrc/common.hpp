@@ -255,7 +255,8 @@ int launch_spmm_f32_exit(padne_ctx *ctx, const padne_csr *m, int k, const float 
                          float scale, const double *out_scale2, float *y32 = nullptr);
 int launch_spmm_f32_wup_exit(padne_ctx *ctx, const padne_csr *w, int k, const float *e, double *z, const double *dot_with,
                              double *partials, const int32_t *done_flag, const float *x_pre, const float *r_pre,
-                             const float *dinv32, float scale, const double *out_scale2, float *z32 = nullptr);
+                             const float *dinv32, float scale, const double *out_scale2, float *z32 = nullptr,
+                             const float *rhs = nullptr);
 bool spmv_resid_pre_ok(const padne_csr *m);
 int launch_spmv_f32_resid_pre(padne_ctx *ctx, const padne_csr *m, const float *b, float *resid, const int32_t *done_flag,
                               const float *dinv32, float c);

@@ -1250,7 +1250,7 @@ __global__ __launch_bounds__(256) void pcg8_update_xr_kernel(const long long n, 
         if (b32 != nullptr) {
             const float v = (float)(ri * s_inv);
             b32[t] = v;
-            xa32[t] = c * dinv32[t / K] * v;
+            if (xa32 != nullptr) xa32[t] = c * dinv32[t / K] * v;
         }
     }
     block_store_partial8<K>(s_rr, red, part_rr);
@@ -1298,7 +1298,7 @@ __global__ __launch_bounds__(256) void pcg8_update_r_entry_kernel(const long lon
         s_rr += ri * ri;
         const float v = (float)(ri * s_inv);
         b32[t] = v;
-        xa32[t] = c * dinv32[t / K] * v;
+        if (xa32 != nullptr) xa32[t] = c * dinv32[t / K] * v;      // (null: the cycle forms its first sweep from b32 itself)
     }
     block_store_partial8<K>(s_rr, red, part_rr);
 }

@@ -32,7 +32,8 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmm_kernel(
     const VT *__restrict__ vals, const ST *__restrict__ x, YT *__restrict__ y, const double *__restrict__ dot_with,
     double *__restrict__ partials /* [8][kMaxPartials] */, const int *__restrict__ done_flag,
     const XT *__restrict__ aux1, const XT *__restrict__ aux2, const XT scale,
-    const double *__restrict__ out_scale2 /* [K] or null */, const XT *__restrict__ aux0 /* SPMV_WUP: [n][K] */) {
+    const double *__restrict__ out_scale2 /* [K] or null */, const XT *__restrict__ aux0 /* SPMV_WUP: [n][K] */,
+    const XT *__restrict__ rhs /* SPMV_WUP exit without aux0: the fine level's right-hand side [n][K] */) {
     static_assert(K == 8 || K == 4 || K == 2, "lockstep widths");
     constexpr int LPR = K / 2;                              // lanes per row (each takes two right-hand sides)
     constexpr int RPG = 64 / LPR;                           // rows per group
@@ -152,22 +153,46 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmm_kernel(
                 const X2 b = *reinterpret_cast<const X2 *>(aux1 + o);
                 out2.a = (YT)(b.a - a0);
                 out2.b = (YT)(b.b - a1);
+
             } else if (MODE == SPMV_ADD) {
                 const Y2 old = *reinterpret_cast<const Y2 *>(y + o);
                 out2.a = old.a + (YT)a0;
                 out2.b = old.b + (YT)a1;
             } else if (MODE == SPMV_WUP) {
                 // exit stage of the cycle in the W form (spmv.hip): z = x_pre + c D^-1 r_pre + W e, r.z partials
-                const X2 xp = *reinterpret_cast<const X2 *>(aux0 + o), rp = *reinterpret_cast<const X2 *>(aux1 + o);
+                const X2 rp = *reinterpret_cast<const X2 *>(aux1 + o);
                 const XT d = scale * aux2[r];
-                const XT o0 = xp.a + d * rp.a + a0, o1 = xp.b + d * rp.b + a1;
-                if (dot_with != nullptr) {
+                XT o0, o1;
+                X2 rb;
+                rb.a = 0;
+                rb.b = 0;
+                if (rhs != nullptr) {
+                    // exit stage of the fine level formed from its right-hand side (spmv.hip, SPMV_WUP with y2): the pre-smoothed
+                    // iterate is c D^-1 of it, so x_pre + c D^-1 r_pre = c D^-1 (b + r_pre) and x_pre is not read; r.z is taken
+                    // against it too (4 instead of 8 bytes per row and right-hand side).  (The residual of the sweep from
+                    // zero formed from the right-hand side as well -- b and 1/diag gathered per non-zero, the single
+                    // cycle's form -- was measured in round 5 and is not used here: 69.3 against 66.9 ms for config C5, the
+                    // 8-wide product pays for every instruction per non-zero.)
+                    rb = *reinterpret_cast<const X2 *>(rhs + o);
+                    o0 = d * (rb.a + rp.a) + a0;
+                    o1 = d * (rb.b + rp.b) + a1;
+                } else {
+                    const X2 xp = *reinterpret_cast<const X2 *>(aux0 + o);
+                    o0 = xp.a + d * rp.a + a0;
+                    o1 = xp.b + d * rp.b + a1;
+                }
+                if (dot_with != nullptr || rhs != nullptr) {
                     const double d0 = (double)o0 * out_mul0, d1 = (double)o1 * out_mul1;
                     // (a float result leaves unscaled, as in spmv.hip: the consumer multiplies, the same double comes out)
                     out2.a = sizeof(YT) == 4 ? (YT)o0 : (YT)d0;
                     out2.b = sizeof(YT) == 4 ? (YT)o1 : (YT)d1;
-                    dot0 += dot_with[o] * d0;
-                    dot1 += dot_with[o + 1] * d1;
+                    if (rhs != nullptr) {
+                        dot0 += ((double)rb.a * out_mul0) * d0;
+                        dot1 += ((double)rb.b * out_mul1) * d1;
+                    } else {
+                        dot0 += dot_with[o] * d0;
+                        dot1 += dot_with[o + 1] * d1;
+                    }
                 } else {      // inner level of the cycle
                     out2.a = (YT)o0;
                     out2.b = (YT)o1;
@@ -214,7 +239,8 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmm_kernel(
 template <int K, typename VT, typename XT, typename YT>
 static int launch_spmm_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals, int mode, const XT *x, YT *y,
                              const double *dot_with, double *partials, const int32_t *done_flag, const XT *aux1,
-                             const XT *aux2, XT scale, const double *out_scale2, const XT *aux0 = nullptr) {
+                             const XT *aux2, XT scale, const double *out_scale2, const XT *aux0 = nullptr,
+                             const XT *rhs = nullptr) {
     if (m->n_rows == 0) return PADNE_OK;
     const int n_tiles = (int)((m->n_rows + 63) / 64);
     long long g = (m->n_rows + kSpmvRows - 1) / kSpmvRows;
@@ -224,7 +250,7 @@ static int launch_spmm_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals,
 #define PADNE_SPMM_LAUNCH(M)                                                                                      \
     hipLaunchKernelGGL((csr_spmm_kernel<K, M, VT, XT, YT>), dim3((unsigned)g), dim3(kSpmvThreads), 0, ctx->stream, \
                        (int)m->n_rows, n_tiles, m->rowptr, m->cols, vals, x, y, dot_with, partials, done_flag,     \
-                       aux1, aux2, scale, out_scale2, aux0)
+                       aux1, aux2, scale, out_scale2, aux0, rhs)
     switch (mode) {
         case SPMV_PLAIN: PADNE_SPMM_LAUNCH(SPMV_PLAIN); break;
         case SPMV_DOT: PADNE_SPMM_LAUNCH(SPMV_DOT); break;
@@ -293,15 +319,16 @@ int launch_spmm_f32_exit(padne_ctx *ctx, const padne_csr *m, int k, const float 
 // partial sums of dot_with . z per right-hand side (the lockstep counterpart of launch_spmv_f32_wup_exit)
 int launch_spmm_f32_wup_exit(padne_ctx *ctx, const padne_csr *w, int k, const float *e, double *z, const double *dot_with,
                              double *partials, const int32_t *done_flag, const float *x_pre, const float *r_pre,
-                             const float *dinv32, float scale, const double *out_scale2, float *z32) {
-    PADNE_REQUIRE(w->vals32 != nullptr && dot_with != nullptr, "single-precision W stage");
+                             const float *dinv32, float scale, const double *out_scale2, float *z32, const float *rhs) {
+    PADNE_REQUIRE(w->vals32 != nullptr && (dot_with != nullptr || rhs != nullptr) && (x_pre != nullptr || rhs != nullptr),
+                  "single-precision W stage");
     if (z32 != nullptr) {
-#define ARGS ctx, w, w->vals32, SPMV_WUP, e, z32, dot_with, partials, done_flag, r_pre, dinv32, scale, out_scale2, x_pre
+#define ARGS ctx, w, w->vals32, SPMV_WUP, e, z32, dot_with, partials, done_flag, r_pre, dinv32, scale, out_scale2, x_pre, rhs
         PADNE_SPMM_WIDTH(k, (launch_spmm_typed<8, float, float, float>(ARGS)), (launch_spmm_typed<4, float, float, float>(ARGS)),
                          (launch_spmm_typed<2, float, float, float>(ARGS)))
 #undef ARGS
     }
-#define ARGS ctx, w, w->vals32, SPMV_WUP, e, z, dot_with, partials, done_flag, r_pre, dinv32, scale, out_scale2, x_pre
+#define ARGS ctx, w, w->vals32, SPMV_WUP, e, z, dot_with, partials, done_flag, r_pre, dinv32, scale, out_scale2, x_pre, rhs
     PADNE_SPMM_WIDTH(k, (launch_spmm_typed<8, float, float, double>(ARGS)), (launch_spmm_typed<4, float, float, double>(ARGS)),
                      (launch_spmm_typed<2, float, float, double>(ARGS)))
 #undef ARGS
