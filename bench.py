@@ -510,6 +510,26 @@ def main():
             shapes_now = hierarchy_shapes()      # (of the last timed step's hierarchy, while the matrix is alive)
         except Exception:
             shapes_now = None
+    # launches of one step, of its setup and per iteration (library-side count, outside the timed region): a whole step, a
+    # solve on the cached hierarchy, a shorter solve on it
+    launches = None
+    if not distributed_path and args.precond == "amg":
+        try:
+            c0 = _hip.launch_count()
+            solver()
+            ctx.synchronize()
+            c1 = _hip.launch_count()
+            cached = A.solve_spd_dev(b, x, rtol=RTOL, precond=args.precond, rebuild=False)
+            ctx.synchronize()
+            c2 = _hip.launch_count()
+            short = A.solve_spd_dev(b, x, rtol=1e-5, precond=args.precond, rebuild=False)
+            ctx.synchronize()
+            c3 = _hip.launch_count()
+            d_it = max(int(cached.iterations) - int(short.iterations), 1)
+            launches = {"per_step": int(c1 - c0), "per_setup": int((c1 - c0) - (c2 - c1)),
+                        "per_iteration": round(((c2 - c1) - (c3 - c2)) / d_it, 1)}
+        except Exception as exc:
+            launches = {"error": repr(exc)}
     c5 = proxy = None
     if not distributed_path and args.precond == "amg" and args.workload == "C4":
         A.close()
@@ -563,7 +583,8 @@ def main():
             "preconditioner": {"kind": args.precond, "levels": int(last.levels),
                                "operator_complexity": float(last.operator_complexity),
                                "setup_ms_per_step": float(last.setup_seconds) * 1e3,
-                               "solve_ms_per_step": float(last.seconds) * 1e3},
+                               "solve_ms_per_step": float(last.seconds) * 1e3,
+                               **({"launches": launches} if launches is not None else {})},
             "iterations": int(last.iterations), "restarts": int(last.restarts),
             "rel_residual": float(last.rel_residual),
             "us_per_iteration": last.seconds / max(last.iterations, 1) * 1e6,
