@@ -3439,14 +3439,14 @@ static int f32_range(padne_ctx *ctx, const padne_csr *A0, double *lo_out, double
     return PADNE_OK;
 }
 
-static int enable_f32(padne_ctx *ctx, Amg *amg) {
-    if (ctx->opt.amg_f64 || amg->levels.size() < 2) return PADNE_OK;
-    if (amg->levels[0].A->hierarchy_operator) return PADNE_OK;   // the gathered tail of a row-partitioned hierarchy
-    hipStream_t s = ctx->stream;
+// Does the cycle run in single precision?  Decided from the range of 1/diag of the fine matrix -- in a row-partitioned run
+// from the range over ALL ranks: the same decision everywhere.
+static int decide_f32(padne_ctx *ctx, const padne_csr *A0, bool dist, bool *want) {
+    *want = false;
+    if (ctx->opt.amg_f64 || A0->hierarchy_operator) return PADNE_OK;   // (hierarchy_operator: the gathered tail of a row-partitioned hierarchy)
     double lo = 0.0, hi = 0.0;
-    PADNE_TRY(f32_range(ctx, amg->levels[0].A, &lo, &hi));
-    if (amg->dist) {
-        // the same decision on every rank
+    PADNE_TRY(f32_range(ctx, A0, &lo, &hi));
+    if (dist) {
         std::vector<double> mine = {lo, hi}, all;
         PADNE_TRY(host_allgather(ctx, mine, all));
         for (int q = 0; q < ctx->world; ++q) {
@@ -3454,7 +3454,18 @@ static int enable_f32(padne_ctx *ctx, Amg *amg) {
             if (all[(size_t)q * 2 + 1] > hi || !(all[(size_t)q * 2 + 1] == all[(size_t)q * 2 + 1])) hi = all[(size_t)q * 2 + 1];
         }
     }
-    if (!(lo >= 1e-15) || !(hi <= 1e15)) return PADNE_OK;
+    *want = lo >= 1e-15 && hi <= 1e15;
+    return PADNE_OK;
+}
+
+// known: the decision if the caller has taken it already (amg_setup_dist, before it builds the up-leg operators), -1 otherwise
+static int enable_f32(padne_ctx *ctx, Amg *amg, int known = -1) {
+    if (ctx->opt.amg_f64 || amg->levels.size() < 2) return PADNE_OK;
+    if (amg->levels[0].A->hierarchy_operator) return PADNE_OK;   // the gathered tail of a row-partitioned hierarchy
+    hipStream_t s = ctx->stream;
+    bool want = known == 1;
+    if (known < 0) PADNE_TRY(decide_f32(ctx, amg->levels[0].A, amg->dist, &want));
+    if (!want) return PADNE_OK;
     for (AmgLevel &L : amg->levels) {
         PADNE_TRY(csr_build_f32(ctx, const_cast<padne_csr *>(L.A)));
         if (L.P) PADNE_TRY(csr_build_f32(ctx, L.P));
@@ -4126,6 +4137,9 @@ static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0) {
     const auto t_begin = std::chrono::steady_clock::now();
     t_amg_verbose = ctx->opt.verbose_amg;
     const long long gather_n = gather_n_limit(ctx, W);
+    // single-precision cycle?  Decided up front: the fused up-leg operators W are read by that cycle only
+    bool want_f32 = false;
+    PADNE_TRY(decide_f32(ctx, A0, true, &want_f32));
     Amg *amg = new Amg();
     amg->device = ctx->device;
     amg->ctx = ctx;
@@ -4249,8 +4263,9 @@ static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0) {
             ap_shape.n_rows = ap_rows.n_rows;
             ap_shape.n_cols = ap_rows.n_cols;
             rc = spgemm(ctx, Lr.R, &ap_shape, &Ac, &ap_rows);
-            if (rc == PADNE_OK && A->dinv != nullptr && (ctx->opt.amg_w == 2 || (ctx->opt.amg_w == 1 && lvl == 0))) {
-                rc = build_w_operator(ctx, A, Lr.P, ap_rows, ap_rows.n_slots, Lr.jac, &Lr.W);
+            if (rc == PADNE_OK && want_f32 && A->dinv != nullptr && (ctx->opt.amg_w == 2 || (ctx->opt.amg_w == 1 && lvl == 0))) {
+                // (the twelve-run window plan pays on the fine level only, as on one GPU: ~1 % of an inner level's tiles qualify)
+                rc = build_w_operator(ctx, A, Lr.P, ap_rows, ap_rows.n_slots, Lr.jac, &Lr.W, 0, lvl == 0);
                 if (rc == PADNE_OK) Lr.W->n_cols = P_ext->n_cols;
             }
         } else {
@@ -4297,7 +4312,7 @@ static int amg_setup_dist(padne_ctx *ctx, padne_csr *A0) {
         return rc;
     }
     amg->operator_complexity = nnz_total / (double)(A0->nnz > 0 ? A0->nnz : 1);
-    if ((rc = enable_f32(ctx, amg)) != PADNE_OK) {
+    if ((rc = enable_f32(ctx, amg, want_f32 ? 1 : 0)) != PADNE_OK) {
         amg_destroy(amg);
         return rc;
     }

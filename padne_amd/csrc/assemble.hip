@@ -1923,11 +1923,13 @@ struct __attribute__((packed, aligned(4))) RlD2 { double x, y; };
 // kept entries per row, one lane per row, eight entries per step (two unaligned 16-byte loads)
 __global__ __launch_bounds__(256) void relabel_count_ordered(long long n_rows, const int *__restrict__ rowptr,
                                                              const int *__restrict__ cols, const int *__restrict__ map,
-                                                             const int *__restrict__ cmap, int *__restrict__ cnt) {
+                                                             const int *__restrict__ cmap, const int n_out, int *__restrict__ cnt) {
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
     const int t = map[r];
-    if (t < 0) return;
+    // (launched before the host has read map_is_compaction's verdict: an entry outside the result is that kernel's to report,
+    // not this one's to write through)
+    if (t < 0 || t >= n_out) return;
     const int k0 = rowptr[r], k1 = rowptr[r + 1];
     int c = 0;
     for (int k = k0; k < k1; k += 8) {
@@ -2618,7 +2620,9 @@ int csr_relabel(padne_ctx *ctx, const padne_csr *m, const int32_t *row_map_host,
         PADNE_HIP_CHECK(hipMemcpyAsync(d_cmap, col_map_host, sizeof(int) * (size_t)m->n_cols, hipMemcpyDefault, s));
     }
     PADNE_HIP_CHECK(hipMemsetAsync(d_err, 0, sizeof(int) * ERR_WORDS, s));
-    if (m->n_rows > 0 && m->n_cols > 0 && n_rows_out > 0 && n_cols_out > 0 && !ctx->opt.force_relabel_slots) {
+    if (m->n_rows > 0 && m->n_cols > 0 && n_rows_out > 0 && n_cols_out > 0 && !ctx->opt.force_relabel_slots && !m->cols_unsorted) {
+        // (a copy keeps the order of a row's entries: the source's columns must ascend, as everything built on the device
+        // does and padne_csr_from_host checks for what it uploads)
         // maps that only drop indices (the reduction to the potential block): count, scan, copy -- see map_is_compaction
         static_assert(ERR_WORDS >= 6, "two triples of flag words");
         hipLaunchKernelGGL(map_is_compaction, dim3(nblk(m->n_rows)), dim3(256), 0, s, (long long)m->n_rows, (const int *)d_map,
@@ -2628,7 +2632,7 @@ int csr_relabel(padne_ctx *ctx, const padne_csr *m, const int32_t *row_map_host,
                                (const int *)d_cmap, (int)n_cols_out, d_err + 3);
         // (the counts are those of any one-to-one map; taken before the verdict is known, for one look at the host less)
         hipLaunchKernelGGL(relabel_count_ordered, dim3(nblk(m->n_rows)), dim3(256), 0, s, (long long)m->n_rows, m->rowptr, m->cols,
-                           (const int *)d_map, (const int *)d_cmap, d_cnt);
+                           (const int *)d_map, (const int *)d_cmap, (int)n_rows_out, d_cnt);
         PADNE_HIP_CHECK(hipGetLastError());
         int h_flags[6] = {0, 0, 0, 0, 0, 0};
         PADNE_TRY(read_back(ctx, d_err, sizeof(h_flags), h_flags));

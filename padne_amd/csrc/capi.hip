@@ -474,9 +474,18 @@ int padne_csr_from_host(padne_ctx *ctx, int64_t n_rows, int64_t n_cols, const in
     for (int64_t i = 0; i < n_rows; ++i) PADNE_REQUIRE(indptr[i] <= indptr[i + 1], "indptr not monotone");
     for (int64_t k = 0; k < nnz; ++k)
         PADNE_REQUIRE(indices[k] >= 0 && indices[k] < n_cols, "column index out of range");
+    // (scipy's canonical form has ascending columns, but the layout does not demand it: remembered, not refused)
+    bool unsorted = false;
+    for (int64_t i = 0; i < n_rows && !unsorted; ++i)
+        for (int64_t k = indptr[i] + 1; k < indptr[i + 1]; ++k)
+            if (indices[k - 1] >= indices[k]) {
+                unsorted = true;
+                break;
+            }
     PADNE_HIP_CHECK(hipSetDevice(ctx->device));
     padne_csr *m = nullptr;
     PADNE_TRY(csr_alloc(ctx, n_rows, n_cols, nnz, &m));
+    m->cols_unsorted = unsorted;
     hipError_t e = hipMemcpyAsync(m->rowptr, indptr, sizeof(int32_t) * (size_t)(n_rows + 1),
                                   hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && nnz > 0)

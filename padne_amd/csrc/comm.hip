@@ -515,7 +515,10 @@ extern "C" int padne_ctx_p2p_selftest(padne_ctx *ctx, int32_t *ok_out) {
     constexpr int kRounds = 2 * kP2pRing + 1;
     PADNE_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t n = (size_t)m + (size_t)ctx->world * (size_t)m;
-    auto value = [](int r, int t, int k) { return 131072.0 * (r + 1) + 16384.0 * (t % 8) + (double)(k % 16384); };   // (integers below 2^24 up to 126 ranks: exact in single precision too)
+    // (integers below 2^24 up to 126 ranks: exact in single precision too; every round has values of its own -- rounds t and
+    // t + kP2pRing use the same ring entry, and stale data of the earlier one must not pass for the later one's)
+    static_assert(kRounds <= 16, "a round's values lie 8192 apart inside a rank's 131072");
+    auto value = [](int r, int t, int k) { return 131072.0 * (r + 1) + 8192.0 * t + (double)(k % 8192); };
     std::vector<double> h(n, -1.0);
     std::vector<float> hf(n, -1.f);
     std::vector<int> idx((size_t)m);
@@ -537,7 +540,10 @@ extern "C" int padne_ctx_p2p_selftest(padne_ctx *ctx, int32_t *ok_out) {
     plan.m = m;
     plan.n_export = m;
     plan.export_idx = d_idx;
-    for (int t = 0; t < kRounds && e == hipSuccess && rc == PADNE_OK && ok; ++t) {
+    // (a rank that has seen a wrong value goes through the remaining exchanges all the same: its peers would otherwise sit
+    // out the time limit of every round it skipped)
+    const bool run = ok;
+    for (int t = 0; t < kRounds && e == hipSuccess && rc == PADNE_OK && run; ++t) {
         const bool f64 = (t & 1) == 0;
         if (f64) {
             std::fill(h.begin(), h.end(), -1.0);

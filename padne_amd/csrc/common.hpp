@@ -47,11 +47,17 @@ void set_error(const char *fmt, ...);
     } while (0)
 
 }  // namespace padne
+// Every kernel launch of the library goes through hipLaunchKernelGGL (no <<< >>> in the sources) and is counted here
+// (padne_launch_count: the launches per step / setup / iteration of the bench line).  The macro is restated on the
+// public launch syntax -- not on a private macro of one HIP release.  Counted: kernels and hipMemsetAsync (a fill
+// kernel).  NOT counted: hipMemcpyAsync -- the device-to-device copies a setup queues (row pointers of a result copied
+// out of a scan, a blit kernel each in a trace; the one-GPU CG iteration queues none) and the small copies to and
+// from the host.  A trace therefore shows a few more dispatches than the count: 510 against 494 per C4 setup.
 #undef hipLaunchKernelGGL
-#define hipLaunchKernelGGL(kernelName, ...)                                                 \
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)   \
     do {                                                                                   \
         ::padne::g_launch_count.fetch_add(1, std::memory_order_relaxed);                   \
-        hipLaunchKernelGGLInternal((kernelName), __VA_ARGS__);                             \
+        kernelName<<<(numBlocks), (numThreads), (memPerBlock), (streamId)>>>(__VA_ARGS__); \
     } while (0)
 #define hipMemsetAsync(...) (::padne::g_launch_count.fetch_add(1, std::memory_order_relaxed), hipMemsetAsync(__VA_ARGS__))
 namespace padne {
@@ -99,6 +105,8 @@ struct padne_csr {
     int split_n_int = 0, split_n_bnd = 0;
     int split_state = 0;                 // 0 = not examined, 1 = in use, -1 = not a row-partitioned operator / switched off
     bool hierarchy_operator = false;   // multigrid-internal operator: may use the wave-per-row SpMV
+    bool cols_unsorted = false;        // an uploaded matrix (padne_csr_from_host) with a row whose columns do not ascend: paths
+                                       // that count on column order (the order-preserving relabel) leave it to the general ones
     padne_csr *prec_block = nullptr;   // borrowed: owned x owned diagonal block for the preconditioner
     // the mesh the system was assembled from stays on the device with it (padne_assemble_system), so that the
     // post-processing of the solution (padne_csr_power_density) does not upload 40 bytes per vertex again

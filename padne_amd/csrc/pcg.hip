@@ -652,7 +652,7 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
     const bool defer_x = fuse_entry;      // x += alpha p rides on the p update (12 us per iteration at 10 M unknowns)
     float *z32 = defer_x && !dist && !halo ? (float *)z : nullptr;      // z of the loop: single precision, in z's own memory
     // ... and the search direction with it: p is stored as floats (in p's own memory), multiplied in double (csr_spmv_kernel
-    // <..., float>): 8 bytes per row less in q = A p and in the p update, the same iteration counts (scripts/exp_p32.py)
+    // <..., float>): 8 bytes per row less in q = A p and in the p update, the same iteration counts (scripts/lab/exp_p32.py)
     float *p32 = z32 != nullptr && spmv_x32_ok(a) ? (float *)p : nullptr;
 
     PADNE_HIP_CHECK(hipMemsetAsync(st, 0, sizeof(PcgStatus), s));

@@ -1,7 +1,7 @@
 """Numerical prototype (CPU, scipy) of the smoothed-aggregation AMG preconditioner planned for the device.
 Dev tool only: explores aggregation / smoothing choices and iteration counts before writing kernels."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, scipy.sparse as sp
 from oracle import padne_oracle as O
 from padne_amd import synthetic as S

@@ -3,7 +3,7 @@ coarsening on selected levels (fewer / smaller coarse levels = less launch-bound
 Recipe as csrc/amg.hip: theta = 0.08 strength, MIS-2 aggregates, filtered prolongator smoothing with
 omega = 1.5 / Gershgorin(filtered), V(1,1) damped Jacobi c = 1 / (0.55 lambda), exact coarsest solve."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spla
 import amg_proto as P
 from oracle import padne_oracle as O

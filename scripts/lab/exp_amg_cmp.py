@@ -1,6 +1,6 @@
 """Compare the device V-cycle with the scipy prototype on the same matrix (debug)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spla
 import amg_proto as P
 from oracle import padne_oracle as O

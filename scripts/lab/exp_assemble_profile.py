@@ -1,5 +1,5 @@
 import cProfile, os, pstats, sys, time
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import bench
 from padne_amd import mesh, solver, synthetic

@@ -1,7 +1,7 @@
 """Single-GPU emulation of the multi-GPU preconditioner: CG on the full C4 matrix, multigrid built on the
 matrix with the inter-layer (via) couplings removed = block-Jacobi across 8 layer ranks."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import bench
 from padne_amd import _hip, synthetic

@@ -1,7 +1,7 @@
 """CPU (scipy) experiment: the exact solve on the coarsest level (a dense inverse: 2 ms of Gauss-Jordan in every setup)
 replaced by k Chebyshev sweeps on D^-1 A (a fixed polynomial: still a fixed SPD preconditioner).  python scripts/exp_coarse_cheb.py 8 220"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spla
 import amg_proto as P
 import exp_aggressive as E

@@ -3,7 +3,7 @@ recipe?  x0 = FMG(b): restrict b to every level, solve the coarsest exactly, and
 V(1,1) cycle of that level's own hierarchy to the level's residual.  Cost of the start: about 1.2 cycles.
 python scripts/exp_fmg.py 8 220"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import amg_proto as P
 import exp_aggressive as E

@@ -1,6 +1,6 @@
 """Debug: strongly graded Delaunay mesh, two layers with a conductivity jump."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, scipy.spatial, scipy.sparse as sp
 from oracle import padne_oracle as O
 from padne_amd import _hip

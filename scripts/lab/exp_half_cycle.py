@@ -2,7 +2,7 @@
 (f32 as shipped / f16 with a power-of-two scale per operator / bf16).  python scripts/exp_half_cycle.py [layers] [nx]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, scipy.sparse as sp
 import amg_proto as AP
 from oracle import padne_oracle as O

@@ -1,6 +1,6 @@
 """Timing of padne_nearest_vertex (connection snapping on the device) for a few point / query counts."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from padne_amd import _hip
 ctx = _hip.Context(0)

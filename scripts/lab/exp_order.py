@@ -1,6 +1,6 @@
 """Experiment: SpMV time with natural (row-major) vs Morton-ordered unknowns (C4 size)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import bench
 from padne_amd import _hip, synthetic

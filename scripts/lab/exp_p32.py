@@ -1,7 +1,7 @@
 """CPU (scipy) experiment: PCG with the search direction rounded to single precision every iteration (x and r updated with
 the rounded vector, so b - A x stays tracked) against the plain loop, on the device's multigrid recipe (exp_aggressive.build)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import exp_aggressive as E
 import amg_proto as P

@@ -1,7 +1,7 @@
 """Host-inclusive cost of the Python seam at bench scale: assemble_from_arrays + solve_system + power density
 through padne_amd.solver (host buffers in, host buffers out), config C4."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import bench
 from padne_amd import mesh, solver, synthetic

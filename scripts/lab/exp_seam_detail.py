@@ -1,6 +1,6 @@
 """Where solve_system's time goes at bench scale: wall time of every device call of one solve_system."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import bench
 from padne_amd import _hip, mesh, solver, synthetic

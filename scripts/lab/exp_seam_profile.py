@@ -1,7 +1,7 @@
 """Host profile of solve_system(L, r) on config C4 with the plan cached (a further right-hand side): where the time between
 the device solve and the caller goes.  python scripts/exp_seam_profile.py"""
 import cProfile, io, os, pstats, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import bench
 from padne_amd import _hip, solver, synthetic

@@ -1,6 +1,6 @@
 """Host-vector solve (padne_solve_spd) against the device-vector solve (padne_solve_spd_dev) of the same reduced system."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import bench
 from padne_amd import _hip, synthetic

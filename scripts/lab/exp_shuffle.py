@@ -1,6 +1,6 @@
 """SpMV on a 1M-node mesh: scan-line numbering vs shuffled (CGAL-like worst case) vs shuffled + Z-order."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from padne_amd import _hip, synthetic, reduction
 ctx = _hip.Context(0)

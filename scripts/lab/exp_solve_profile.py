@@ -1,16 +1,19 @@
-"""Where does the FIRST solve() of a process spend its time (module load, allocator warm-up)?"""
+"""cProfile of the whole Python seam padne_amd.solver.solve() on a Problem-level input with ~1 M vertices
+(two layers, via-like resistors, a voltage source and a load) -- where does host time go outside the device?"""
 import cProfile, os, pstats, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-t00 = time.perf_counter()
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from padne_amd import mesh, problem, solver, structured
-size = 0.6
+
+size = float(sys.argv[1]) if len(sys.argv) > 1 else 0.6
 W, H = 420.0, 420.0
 top = problem.Layer(shape=structured.Shapes.of(structured.Rect(0, 0, W, H)), name="F.Cu", conductance=2082.5)
 bot = problem.Layer(shape=structured.Shapes.of(structured.Rect(0, 0, W, H)), name="B.Cu", conductance=2082.5)
 P = mesh.Point
 rng = np.random.default_rng(0)
 nets = []
+conns = lambda layer, x, y: problem.Connection(layer=layer, point=P(x, y))
+vias = []
 for k in range(200):
     x, y = rng.uniform(5, W - 5), rng.uniform(5, H - 5)
     a, b = problem.NodeID(), problem.NodeID()
@@ -23,7 +26,10 @@ nets.append(problem.Network(connections=[problem.Connection(top, P(W - 10, H - 1
                             elements=[problem.Resistor(l_a, l_b, 0.05)]))
 prob = problem.Problem(layers=[top, bot], networks=nets)
 mesher = structured.StructuredMesher(mesh.Mesher.Config(maximum_size=size), jitter=0.2)
-print(f"imports + problem: {time.perf_counter() - t00:.3f} s", flush=True)
-t0 = time.perf_counter(); ctx = solver.get_context(); print(f"context: {time.perf_counter() - t0:.3f} s", flush=True)
+t0 = time.perf_counter(); sol = solver.solve(prob, mesher=mesher); t1 = time.perf_counter()
+nv = sum(len(ls.meshes[0].vertices) if hasattr(ls.meshes[0], "vertices") else 0 for ls in sol.layer_solutions)
+print(f"first solve() {t1 - t0:.3f} s", flush=True)
+for _ in range(2):
+    t0 = time.perf_counter(); sol = solver.solve(prob, mesher=mesher); print(f"solve() again {time.perf_counter() - t0:.3f} s", flush=True)
 pr = cProfile.Profile(); pr.enable(); sol = solver.solve(prob, mesher=mesher); pr.disable()
-pstats.Stats(pr).sort_stats("tottime").print_stats(12)
+st = pstats.Stats(pr); st.sort_stats("cumulative").print_stats(28)

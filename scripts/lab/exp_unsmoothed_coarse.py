@@ -1,7 +1,7 @@
 """CPU (scipy) experiment: smoothed aggregation on the fine level only, plain (unsmoothed) aggregation below -- the coarse
 levels' A P, R = P^T and R (A P) would then be index bookkeeping instead of sparse products.  python scripts/exp_unsmoothed_coarse.py 8 220"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, scipy.sparse as sp
 import amg_proto as P
 import exp_aggressive as E

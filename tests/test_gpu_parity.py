@@ -2630,10 +2630,30 @@ def test_maps_that_only_drop_indices_are_relabelled_by_a_copy_with_holes(ctx, sw
                 assert got.shape == ref.shape and got.has_sorted_indices, name
                 assert np.array_equal(got.indptr, ref.indptr) and np.array_equal(got.indices, ref.indices), name
                 assert np.array_equal(got.data, ref.data), name
-    bad, _ = cmap_of([3])
-    bad[9] = n                        # out of range
-    with pytest.raises(ValueError):
-        ctx.csr_from_scipy(M).reduce(bad, n - 1, 1.0)
+    for far in (n, 2 * n, 2**31 - 1):     # out of range, by one and by far (nothing may be written through such an entry)
+        bad, _ = cmap_of([3])
+        bad[9] = far
+        with pytest.raises(ValueError):
+            ctx.csr_from_scipy(M).reduce(bad, n - 1, 1.0)
+    # the C ABI takes rows whose columns do not ascend (padne_csr_from_host does not demand scipy's canonical form): a copy
+    # would keep their order, so such a matrix goes through the general path and comes out sorted
+    from padne_amd import _hip
+    U = M.copy()
+    for r in (5, 33, n - 1):
+        k0, k1 = U.indptr[r], U.indptr[r + 1]
+        U.indices[k0:k1] = U.indices[k0:k1][::-1].copy()
+        U.data[k0:k1] = U.data[k0:k1][::-1].copy()
+    indptr, indices, data = U.indptr.astype(np.int32), U.indices.astype(np.int32), U.data.astype(np.float64)
+    h = _hip._P()
+    _hip._check(ctx._lib.padne_csr_from_host(ctx._h, n, n, _hip._ptr(indptr, _hip._PI32), _hip._ptr(indices, _hip._PI32),
+                                             _hip._ptr(data, _hip._PF64), _hip.C.byref(h)))
+    du = _hip.CsrMatrix(ctx, h)
+    m, keep = cmap_of(drops["scattered"])
+    got = du.reduce(m, int(keep.sum()), -1.0).to_scipy()
+    ref = (-1.0 * M[keep][:, keep]).tocsr()
+    ref.sort_indices()
+    assert np.array_equal(got.indptr, ref.indptr) and np.array_equal(got.indices, ref.indices)
+    assert np.array_equal(got.data, ref.data)
 
 
 def test_relabel_and_vstack_against_scipy(ctx):
