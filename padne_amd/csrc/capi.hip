@@ -29,6 +29,7 @@ void options_from_env(padne_options *o) {
     if (const char *e = getenv("PADNE_AMG_W")) o->amg_w = strcmp(e, "none") == 0 ? 0 : (strcmp(e, "fine") == 0 ? 1 : 2);
     o->amg_exchange_all = on("PADNE_AMG_EXCHANGE_ALL");
     o->pcg_p64 = on("PADNE_PCG_P64");
+    o->pcg_no_xhist = on("PADNE_PCG_NO_XHIST");
     o->gj_vector = on("PADNE_GJ_VECTOR");
     o->no_batch = on("PADNE_NO_BATCH");
     o->no_mailbox = on("PADNE_NO_MAILBOX");
@@ -49,6 +50,7 @@ void options_from_env(padne_options *o) {
         o->force_asm_two_pass = has(f, "asm_two_pass") != nullptr;
         o->force_relabel_slots = has(f, "relabel_slots") != nullptr;
         o->force_transpose_cursors = has(f, "transpose_cursors") != nullptr;
+        o->force_xhist_small = has(f, "xhist_small") != nullptr;
         if (const char *w = has(f, "spgemm_split")) o->force_spgemm_split = w[12] == ':' ? atoll(w + 13) : 30000;
     }
     if (const char *v = getenv("PADNE_VERBOSE")) {

@@ -124,6 +124,7 @@ struct padne_options {
     int amg_w = 2;                     // PADNE_AMG_W=none|fine: fused up-leg operator W on no level / the fine level only (default: all)
     bool amg_exchange_all = false;     // PADNE_AMG_EXCHANGE_ALL=1: the last partitioned level exchanges instead of computing from the tail
     bool pcg_p64 = false;              // PADNE_PCG_P64=1: the search direction of the loop stays in double precision
+    bool pcg_no_xhist = false;         // PADNE_PCG_NO_XHIST=1: x updated in every iteration instead of from the kept search directions
     bool gj_vector = false;            // PADNE_GJ_VECTOR=1: the dense inverse by the vector kernel (16 pivots per launch)
     bool no_batch = false;             // PADNE_NO_BATCH=1: right-hand sides one at a time
     bool no_mailbox = false;           // PADNE_NO_MAILBOX=1: host looks by copy + synchronise
@@ -139,6 +140,7 @@ struct padne_options {
     unsigned p2p_timeout_ms = 20000;   // PADNE_P2P_TIMEOUT_MS
     // PADNE_FORCE=<path>[,<path>...]: send everything through a path that the data takes only rarely (tests)
     bool force_asm_hash = false, force_asm_two_pass = false, force_relabel_slots = false, force_transpose_cursors = false;
+    bool force_xhist_small = false;    // xhist_small: eight places for the kept search directions (the ring wraps within a solve)
     long long force_spgemm_split = 0;  // spgemm_split:<slots>
     // PADNE_VERBOSE=amg,xw,pool: diagnostics on stderr
     bool verbose_amg = false, verbose_xw = false, verbose_pool = false;

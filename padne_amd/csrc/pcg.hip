@@ -270,7 +270,9 @@ __global__ __launch_bounds__(256) void pcg_update_p_z_kernel(
     const int P_rz, const double *__restrict__ part_rr, const int P_rr, const double *__restrict__ part_pq,
     const int P_pq, const double *__restrict__ z, double *__restrict__ p, PcgStatus *__restrict__ st,
     const int max_iter, double *__restrict__ x_deferred, const float *__restrict__ z32, const double *__restrict__ bb2,
-    float *__restrict__ p32) {
+    float *__restrict__ p32, float *__restrict__ p32_next = nullptr, double *__restrict__ alpha_out = nullptr) {
+    // p32_next / alpha_out (the search directions of a solve KEPT, solve_one): the new direction goes to a place of its own
+    // and the step length along the old one is left for pcg_x_flush_kernel -- x is not touched here (x_deferred is null)
     __shared__ double red[4];
     // NOT st->done: workgroup 0 of this very launch sets it, and this kernel carries the deferred x += alpha p -- a
     // workgroup dispatched after that store would skip its slice of the last update.  done_seen is what the x/r update of
@@ -291,10 +293,16 @@ __global__ __launch_bounds__(256) void pcg_update_p_z_kernel(
             // r -= alpha^ q (alpha^ = alpha ||b||) stay consistent to double rounding; what the rounding of p costs is conjugacy
             // at the 1e-7 level, which the cycle's own single precision costs already
             const double alpha_hat = alpha / z_mul;
-            for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-                const double pi = (double)p32[i];
-                x_deferred[i] += alpha_hat * pi;
-                p32[i] = (float)((double)z32[i] + beta * pi);
+            if (p32_next != nullptr) {
+                if (blockIdx.x == 0 && threadIdx.x == 0) *alpha_out = alpha_hat;
+                for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+                    p32_next[i] = (float)((double)z32[i] + beta * (double)p32[i]);
+            } else {
+                for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+                    const double pi = (double)p32[i];
+                    x_deferred[i] += alpha_hat * pi;
+                    p32[i] = (float)((double)z32[i] + beta * pi);
+                }
             }
         } else {
             for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
@@ -331,6 +339,39 @@ __global__ __launch_bounds__(256) void pcg_update_p_z_kernel(
                 st->done = 1;
             }
         }
+    }
+}
+
+// x += sum over the iterations j in [j0, min(j1, completed)) of alpha_j p_j, each row's terms added in the order of the
+// iterations: the bits of the running update x += alpha_j p_j, which read and wrote x in every iteration (16 bytes per
+// row and iteration; this reads 4).  p_j lies in slot j % n_slots of `hist`, alpha_j in alpha[j % n_slots]; `completed`
+// is the status word's count (iterations queued behind the one that converged returned at their first kernel).
+__global__ __launch_bounds__(256) void pcg_x_flush_kernel(const long long n, const float *__restrict__ hist, const size_t slot_stride,
+                                                          const int n_slots, const double *__restrict__ alpha, const int j0,
+                                                          const int j1, const PcgStatus *__restrict__ st, double *__restrict__ x) {
+    __shared__ double a_s[64];
+    __shared__ int s_s[64];
+    const int hi = min(j1, st->iters);
+    const int cnt = hi - j0;
+    if (cnt <= 0) return;
+    if ((int)threadIdx.x < cnt && threadIdx.x < 64) {
+        a_s[threadIdx.x] = alpha[(j0 + threadIdx.x) % n_slots];
+        s_s[threadIdx.x] = (j0 + threadIdx.x) % n_slots;
+    }
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        double xi = x[i];
+        int k = 0;
+        for (; k + 4 <= cnt; k += 4) {      // four loads in flight, the additions in order
+            const float p0 = hist[(size_t)s_s[k] * slot_stride + i], p1 = hist[(size_t)s_s[k + 1] * slot_stride + i],
+                        p2 = hist[(size_t)s_s[k + 2] * slot_stride + i], p3 = hist[(size_t)s_s[k + 3] * slot_stride + i];
+            xi += a_s[k] * (double)p0;
+            xi += a_s[k + 1] * (double)p1;
+            xi += a_s[k + 2] * (double)p2;
+            xi += a_s[k + 3] * (double)p3;
+        }
+        for (; k < cnt; ++k) xi += a_s[k] * (double)hist[(size_t)s_s[k] * slot_stride + i];
+        x[i] = xi;
     }
 }
 
@@ -625,7 +666,18 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
     if (amg)
         PADNE_REQUIRE(prec->n_rows == n && (prec->n_cols == n || prec == a),
                       "preconditioner must be the matrix itself or its owned x owned block");
-    PADNE_TRY(ensure_workspace(ctx, sizeof(double) * (size_t)(2 * n + 2 * nc + nr) + 4096));
+    // The search directions of a one-GPU multigrid solve are kept (single precision, 4 bytes per row and iteration) and x is
+    // formed from them when the loop has ended -- or when the ring of kXHist places is full -- instead of being read and
+    // written in every iteration: pcg_x_flush_kernel.  A place per iteration up to 2 GiB of them, at least eight.
+    constexpr int kXHist = 32;
+    int n_hist = 0;
+    if (amg && !dist && !halo && !ctx->opt.pcg_p64 && !ctx->opt.pcg_no_xhist && n > 0) {
+        n_hist = (int)std::min<long long>(kXHist, std::max<long long>(8, ((long long)2 << 30) / (4 * n)));
+        if (ctx->opt.force_xhist_small) n_hist = 8;
+    }
+    const size_t hist_stride = ((size_t)n + 63) & ~(size_t)63;      // floats per place
+    const size_t base_bytes = (sizeof(double) * (size_t)(2 * n + 2 * nc + nr) + 4096 + 255) & ~(size_t)255;
+    PADNE_TRY(ensure_workspace(ctx, base_bytes + (n_hist > 0 ? sizeof(float) * hist_stride * (size_t)n_hist + sizeof(double) * kXHist : 0)));
     double *r = (double *)ctx->ws;
     double *z = r + n;          // [n]   multigrid output
     double *p = z + n;          // [nc]
@@ -654,6 +706,11 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
     // ... and the search direction with it: p is stored as floats (in p's own memory), multiplied in double (csr_spmv_kernel
     // <..., float>): 8 bytes per row less in q = A p and in the p update, the same iteration counts (scripts/lab/exp_p32.py)
     float *p32 = z32 != nullptr && spmv_x32_ok(a) ? (float *)p : nullptr;
+    if (p32 == nullptr) n_hist = 0;
+    float *hist = n_hist > 0 ? (float *)((char *)ctx->ws + base_bytes) : nullptr;
+    double *alpha_hist = n_hist > 0 ? (double *)(hist + hist_stride * (size_t)n_hist) : nullptr;
+    if (hist != nullptr) p32 = hist;      // direction j of a (re)start lies in place j % n_hist
+    auto p_place = [&](long long j) { return hist + hist_stride * (size_t)(j % n_hist); };
 
     PADNE_HIP_CHECK(hipMemsetAsync(st, 0, sizeof(PcgStatus), s));
     if (halo) PADNE_HIP_CHECK(hipMemsetAsync(p + n, 0, sizeof(double) * (size_t)(nc - n), s));
@@ -698,6 +755,7 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
                 PADNE_HIP_CHECK(hipMemcpyAsync(scal + S_NRM, scal + S_RR, sizeof(double), hipMemcpyDeviceToDevice, s));
             PADNE_TRY(amg_apply(ctx, prec, r, z, slot(ctx, SLOT_RZ0), nullptr, bb_scalar));
             if (p32 != nullptr) {
+                if (hist != nullptr) p32 = hist;      // direction 0 of this (re)start
                 hipLaunchKernelGGL(p_hat_from_z_kernel, dim3(gv), dim3(256), 0, s, n, (const double *)z, bb_scalar, p32);
                 PADNE_HIP_CHECK(hipGetLastError());
             } else {
@@ -721,6 +779,15 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
         PADNE_HIP_CHECK(hipGetLastError());
         int parity = 0;
         bool done = false;
+        long long jq = 0, jf = 0;      // iterations of this (re)start queued / covered by a flush of x
+        auto flush_x = [&]() -> int {
+            if (hist == nullptr || jq == jf) return PADNE_OK;
+            hipLaunchKernelGGL(pcg_x_flush_kernel, dim3(gv), dim3(256), 0, s, n, (const float *)hist, hist_stride, n_hist,
+                               (const double *)alpha_hist, (int)jf, (int)jq, (const PcgStatus *)st, x);
+            PADNE_HIP_CHECK(hipGetLastError());
+            jf = jq;
+            return PADNE_OK;
+        };
         while (!done) {
             for (int k = 0; k < check_every; ++k) {
                 const int rz_old_slot = parity ? SLOT_RZ1 : SLOT_RZ0;
@@ -743,6 +810,7 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
                     ev_b.push_back(e1);
                     PADNE_HIP_CHECK(hipEventRecord(e0, s));
                 }
+                if (hist != nullptr) p32 = p_place(jq);
                 if (p32 != nullptr) PADNE_TRY(launch_spmv_dot_x32(ctx, a, p32, q, slot(ctx, SLOT_PQ), &st->done));
                 else PADNE_TRY(halo_product_dot(ctx, a, p, q, slot(ctx, SLOT_PQ), &st->done));
                 if (sampled) PADNE_HIP_CHECK(hipEventRecord(ev_b.back(), s));
@@ -765,9 +833,18 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
                         PADNE_TRY(fold(slot(ctx, SLOT_RR), gv, kMaxPartials, 1, s_new + 1));
                         PADNE_TRY(allreduce(s_new, 2));
                     }
-                    hipLaunchKernelGGL(pcg_update_p_z_kernel, dim3(gv), dim3(256), 0, s, n, rz_new, rz_old, Pz, rr, Pr,
-                                       pq, Pq, z, p, st, max_iter - total_iters, defer_x ? x : (double *)nullptr,
-                                       (const float *)z32, bb_scalar, p32);
+                    if (hist != nullptr) {
+                        hipLaunchKernelGGL(pcg_update_p_z_kernel, dim3(gv), dim3(256), 0, s, n, rz_new, rz_old, Pz, rr, Pr,
+                                           pq, Pq, z, p, st, max_iter - total_iters, (double *)nullptr, (const float *)z32,
+                                           bb_scalar, p32, p_place(jq + 1), alpha_hist + (jq % n_hist));
+                        ++jq;
+                        // the place of direction jf is written again by iteration jf + n_hist - 1
+                        if (jq - jf >= n_hist - 1) PADNE_TRY(flush_x());
+                    } else {
+                        hipLaunchKernelGGL(pcg_update_p_z_kernel, dim3(gv), dim3(256), 0, s, n, rz_new, rz_old, Pz, rr, Pr,
+                                           pq, Pq, z, p, st, max_iter - total_iters, defer_x ? x : (double *)nullptr,
+                                           (const float *)z32, bb_scalar, p32);
+                    }
                 } else {
                     hipLaunchKernelGGL(pcg_update_xr_kernel, dim3(gv), dim3(256), 0, s, n, rz_old, Pz, pq, Pq, p, q,
                                        a->dinv, x, r, slot(ctx, rz_new_slot), slot(ctx, SLOT_RR), st);
@@ -788,6 +865,7 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
             PADNE_TRY(read_back(ctx, st, sizeof(PcgStatus), hst));
             done = hst->done != 0;
         }
+        PADNE_TRY(flush_x());
         total_iters += hst->iters;
         code = hst->code;
         bb = hst->bb;

@@ -257,7 +257,160 @@ def problem_mixed():
     return dict(layers=[("top", 2082.5), ("bottom", 1041.25)], meshes=[(xy0, tri0, 0), (xy1, tri1, 1)], networks=nets)
 
 
-PROBLEM_CASES = {"problem_c1": problem_c1, "problem_mixed": problem_mixed}
+# ---- unstructured islands: the shapes of the projects the reference benchmarks (benchmarks/benchmarks.py:282) ----------
+
+def delaunay_island(seed, x0, y0, w, h, spacing, hole=None):
+    """A Delaunay mesh of the rectangle [x0, x0+w] x [y0, y0+h] (irregular boundary spacing, scattered interior points
+    at least 0.55 spacing apart), optionally with a circular hole (cx, cy, r) whose rim carries points of its own: what
+    CGAL's conforming triangulation of a pad-shaped island looks like to the solver -- irregular degrees, boundary
+    vertices, a hole.  Returns (xy, tri) with counter-clockwise triangles, no unused points; raises if not manifold."""
+    import scipy.spatial
+    from oracle import padne_oracle as O
+    rng = np.random.default_rng(seed)
+
+    def edge(a, b):
+        n = max(2, int(round(np.hypot(*(np.subtract(b, a))) / spacing)))
+        t = (np.arange(n) + rng.uniform(-0.25, 0.25, n)) / n
+        t[0] = 0.0
+        return np.asarray(a, float) + np.outer(np.sort(t), np.subtract(b, a))
+    c = [(x0, y0), (x0 + w, y0), (x0 + w, y0 + h), (x0, y0 + h)]
+    pts = [edge(c[i], c[(i + 1) % 4]) for i in range(4)]
+    n_rim = 0
+    if hole is not None:
+        cx, cy, r = hole
+        k = max(8, int(round(2 * np.pi * r / (0.7 * spacing))))
+        ang = (np.arange(k) + rng.uniform(-0.2, 0.2, k)) * 2 * np.pi / k
+        rim = np.stack([cx + r * np.cos(ang), cy + r * np.sin(ang)], 1)
+        n_rim = len(rim)
+        pts.insert(0, rim)
+    fixed = np.concatenate(pts)
+    inner = []
+    target = int(w * h / spacing ** 2)
+    tries = 0
+    while len(inner) < target and tries < 60 * target:
+        tries += 1
+        q = rng.uniform([x0 + 0.5 * spacing, y0 + 0.5 * spacing], [x0 + w - 0.5 * spacing, y0 + h - 0.5 * spacing])
+        if hole is not None and np.hypot(q[0] - hole[0], q[1] - hole[1]) < hole[2] + 0.45 * spacing:
+            continue
+        allp = np.concatenate([fixed, np.array(inner).reshape(-1, 2)])
+        if np.min(np.hypot(allp[:, 0] - q[0], allp[:, 1] - q[1])) < 0.55 * spacing:
+            continue
+        inner.append(q)
+    xy = np.concatenate([fixed, np.array(inner).reshape(-1, 2)])
+    tri = scipy.spatial.Delaunay(xy).simplices.astype(np.int32)
+    if hole is not None:
+        tri = tri[~np.all(tri < n_rim, axis=1)]                  # the triangles that fill the hole: all three corners on its rim
+    a, b, cc = xy[tri[:, 0]], xy[tri[:, 1]], xy[tri[:, 2]]
+    cross = (b[:, 0] - a[:, 0]) * (cc[:, 1] - a[:, 1]) - (b[:, 1] - a[:, 1]) * (cc[:, 0] - a[:, 0])
+    keep = np.abs(cross) > 1e-9 * spacing ** 2                   # flat triangles along the straight edges
+    tri, cross = tri[keep], cross[keep]
+    tri[cross < 0] = tri[cross < 0][:, [0, 2, 1]]
+    used = np.unique(tri)
+    remap = -np.ones(len(xy), dtype=np.int64)
+    remap[used] = np.arange(len(used))
+    xy, tri = xy[used], remap[tri].astype(np.int32)
+    O.check_manifold(len(xy), tri)
+    return xy, tri
+
+
+def via_ring(node, l_from, l_to, x, y, drill, r_via):
+    """One plated hole between two layers: 16 resistors of 16 R_via on the ring of the drill (kicad.py:818-836)."""
+    conns, els = [], []
+    for px, py in ring_points(x, y, drill):
+        a, b = next(node), next(node)
+        conns += [(l_from, px, py, a), (l_to, px, py, b)]
+        els.append(("R", a, b, r_via * 16))
+    return dict(connections=conns, elements=els)
+
+
+def problem_many_meshes():
+    """`many_meshes`-like (benchmarks/benchmarks.py:282): 34 Delaunay islands over two layers (17 per layer, half of them
+    with a hole), a plated hole through every pair of islands that lie above each other, 0.02-0.08 Ohm links between
+    neighbouring islands, a 5 V source, three current loads, a star of four resistors around an internal node -- and an
+    18th island on the top layer that nothing drives: the connectivity pre-pass (solver.py:862-870) hands such copper
+    to produce_layer_solutions as a disconnected mesh, outside the system."""
+    sigma = synthetic.DEFAULT_SHEET_CONDUCTANCE
+    cells = [(12.0 * (k % 6), 10.0 * (k // 6)) for k in range(18)]
+    rng = np.random.default_rng(2024)
+    meshes, centre = [], {}
+    for layer in range(2):
+        for k in range(17):
+            x0, y0 = cells[k]
+            w, h = 7.0 + 3.5 * rng.random(), 5.5 + 3.0 * rng.random()
+            hole = None
+            if (k + layer) % 2 == 0:
+                hole = (x0 + w * (0.3 + 0.4 * rng.random()), y0 + h * (0.35 + 0.3 * rng.random()), 0.9 + 0.5 * rng.random())
+            xy, tri = delaunay_island(1000 * layer + k, x0, y0, w, h, 0.55 + 0.15 * rng.random(), hole)
+            meshes.append((xy, tri, layer))
+            centre[(layer, k)] = (x0, y0, w, h)
+    disc = [delaunay_island(777, cells[17][0], cells[17][1], 8.0, 6.0, 0.6, (cells[17][0] + 4.0, cells[17][1] + 3.0, 1.0)) + (0,)]
+
+    def at(layer, k, fx, fy):
+        x0, y0, w, h = centre[(layer, k)]
+        return x0 + fx * w, y0 + fy * h
+    node = iter(range(10 ** 9))
+    nets = []
+    r_via = 0.135 / (synthetic.COPPER_CONDUCTIVITY * np.pi * ((0.15 + 0.035) ** 2 - 0.15 ** 2))
+    for k in range(17):
+        x, y = at(0, k, 0.12, 0.15)
+        nets.append(via_ring(node, 0, 1, x, y, 0.3, r_via))
+    for k in range(16):                                            # links: even k on the top layer, odd k on the bottom one
+        layer = k % 2
+        a, b = next(node), next(node)
+        xa, ya = at(layer, k, 0.85, 0.8)
+        xb, yb = at(layer, k + 1, 0.15, 0.8)
+        nets.append(dict(connections=[(layer, xa, ya, a), (layer, xb, yb, b)], elements=[("R", a, b, 0.02 + 0.004 * k)]))
+    p, n = next(node), next(node)
+    nets.append(dict(connections=[(0,) + at(0, 0, 0.5, 0.9) + (p,), (1,) + at(1, 16, 0.5, 0.1) + (n,)], elements=[("V", p, n, 5.0)]))
+    for k, cur in ((5, 0.8), (9, 1.3), (13, 0.45)):
+        f, t = next(node), next(node)
+        nets.append(dict(connections=[(1,) + at(1, k, 0.7, 0.5) + (f,), (1,) + at(1, 16, 0.3, 0.3) + (t,)], elements=[("I", f, t, cur)]))
+    hub = next(node)                                              # no connection: an internal node (solver.py:437-447)
+    arms = [(0, 3), (0, 7), (0, 11), (1, 14)]
+    conns, els = [], []
+    for j, (layer, k) in enumerate(arms):
+        a = next(node)
+        conns.append((layer,) + at(layer, k, 0.55, 0.55) + (a,))
+        els.append(("R", a, hub, 0.5 + 0.25 * j))
+    nets.append(dict(connections=conns, elements=els))
+    return dict(layers=[("F.Cu", sigma), ("B.Cu", sigma)], meshes=meshes, networks=nets, disconnected=disc)
+
+
+def problem_two_planes():
+    """`two_big_planes`-like: two unstructured planes (one with a cut-out), stitched by nine plated holes; a 3.3 V source whose
+    positive terminal is tied to three pads of the top plane by 0 V glue sources and whose negative terminal to two pads
+    of the bottom plane (kicad.py:659-710), one current load across the planes."""
+    sigma = synthetic.DEFAULT_SHEET_CONDUCTANCE
+    top = delaunay_island(31, 0.0, 0.0, 60.0, 40.0, 0.75)
+    bottom = delaunay_island(32, 0.0, 0.0, 60.0, 40.0, 0.8, (38.0, 22.0, 6.0))
+    node = iter(range(10 ** 9))
+    nets = []
+    r_via = 1.51 / (synthetic.COPPER_CONDUCTIVITY * np.pi * ((0.2 + 0.035) ** 2 - 0.2 ** 2))
+    for i in range(3):
+        for j in range(3):
+            nets.append(via_ring(node, 0, 1, 8.0 + 21.5 * i + 0.37 * j, 6.0 + 13.7 * j + 0.21 * i, 0.4, r_via))
+    p, n = next(node), next(node)
+    g1, g2, g3 = next(node), next(node), next(node)
+    nets.append(dict(connections=[(0, 3.1, 3.2, p), (1, 56.3, 36.1, n), (0, 3.1, 5.74, g1), (0, 5.64, 3.2, g2), (1, 56.3, 33.56, g3)],
+                     elements=[("V", p, n, 3.3), ("V", g1, p, 0.0), ("V", g2, g1, 0.0), ("V", g3, n, 0.0)]))
+    f, t = next(node), next(node)
+    nets.append(dict(connections=[(0, 51.0, 9.0, f), (1, 12.0, 30.0, t)], elements=[("I", f, t, 2.0)]))
+    return dict(layers=[("F.Cu", sigma), ("B.Cu", 0.5 * sigma)], meshes=[top + (0,), bottom + (1,)], networks=nets)
+
+
+def problem_simple_trace():
+    """`simple_geometry`-like: one long thin trace; the pads of the source and of the load lie ON or just OUTSIDE the
+    copper outline, so every connection snaps to a boundary vertex of the mesh (NodeIndexer.create, solver.py:425-435:
+    nearest vertex, whatever the distance)."""
+    xy, tri = delaunay_island(5, 0.0, 0.0, 30.0, 1.2, 0.3)
+    nets = [dict(connections=[(0, -0.2, 0.61, 0), (0, 30.3, 0.57, 1)], elements=[("V", 0, 1, 1.0)]),
+            dict(connections=[(0, 14.93, 1.2, 2), (0, 15.11, -0.4, 3)], elements=[("R", 2, 3, 0.05)]),
+            dict(connections=[(0, 7.52, 1.35, 4), (0, 22.4, 0.0, 5)], elements=[("I", 4, 5, 0.3), ("R", 4, 5, 2.0)])]
+    return dict(layers=[("F.Cu", synthetic.DEFAULT_SHEET_CONDUCTANCE)], meshes=[(xy, tri, 0)], networks=nets)
+
+
+PROBLEM_CASES = {"problem_c1": problem_c1, "problem_mixed": problem_mixed, "problem_many_meshes": problem_many_meshes,
+                 "problem_two_planes": problem_two_planes, "problem_simple_trace": problem_simple_trace}
 
 
 def encode_problem(spec):
@@ -276,6 +429,11 @@ def encode_problem(spec):
             els.append(row)
     d["connections"] = np.array(conn, float).reshape(-1, 5)
     d["pelements"] = np.array(els, float).reshape(-1, 8)
+    d["n_disc"] = np.int64(len(spec.get("disconnected", [])))
+    for k, (xy, tri, layer) in enumerate(spec.get("disconnected", [])):
+        d[f"disc_xy{k}"] = np.asarray(xy, float)
+        d[f"disc_tri{k}"] = np.asarray(tri, np.int32)
+        d[f"disc_layer{k}"] = np.int64(layer)
     return d
 
 
@@ -315,7 +473,13 @@ def run_reference_problem(spec):
     nix = S.NodeIndexer.create(prob, meshes, m2l, vindex, networks)
     L, r = S.assemble_system(prob, meshes, m2l, vindex, networks, nix)
     v, info = S.solve_system(L, r)
-    sols = S.produce_layer_solutions(layers, vindex, meshes, m2l, v, [[] for _ in layers])
+    disc_by_layer = [[] for _ in layers]
+    for xy, tri, layer in spec.get("disconnected", []):
+        disc_by_layer[int(layer)].append(M.Mesh.from_triangle_soup([M.Point(float(x), float(y)) for x, y in xy],
+                                                                   [tuple(int(i) for i in t) for t in tri]))
+    sols = S.produce_layer_solutions(layers, vindex, meshes, m2l, v, disc_by_layer)
+    for ls, dl in zip(sols, disc_by_layer):
+        assert len(ls.disconnected_meshes) == len(dl) and all(a is b for a, b in zip(ls.disconnected_meshes, dl))
     Lc = L.tocsr()
     Lc.sort_indices()
     out = dict(L_indptr=Lc.indptr.astype(np.int64), L_indices=Lc.indices.astype(np.int64), L_data=Lc.data, r=r, v=v,
@@ -350,7 +514,10 @@ def encode_inputs(spec):
 
 
 def main():
+    only = set(sys.argv[1:])               # names to (re)generate; none given: all
     for name, fn in CASES.items():
+        if only and name not in only:
+            continue
         spec = fn()
         data = encode_inputs(spec)
         data.update(run_reference(spec))
@@ -359,6 +526,8 @@ def main():
         print(f"{name}: N={int(data['N'])} nnz={len(data['L_data'])} |v|max={np.abs(data['v']).max():.4g} "
               f"res={float(data['residual_norm']):.2e} -> {os.path.relpath(path, ROOT)}")
     for name, fn in PROBLEM_CASES.items():
+        if only and name not in only:
+            continue
         spec = fn()
         data = encode_problem(spec)
         data.update(run_reference_problem(spec))

@@ -745,6 +745,42 @@ def test_search_direction_stored_in_single_precision_solves_the_same_system(swit
         assert not np.array_equal(f32[0].x, f64[0].x), "the switch changed nothing"
 
 
+def test_x_formed_from_the_kept_search_directions_has_the_bits_of_the_running_update(switches):
+    """The one-GPU loop keeps its search directions (single precision, a place per iteration) and forms
+    x = x_0 + sum_j alpha_j p_j when the loop has ended (`pcg_x_flush_kernel`), each row's terms in the order of the
+    iterations, instead of reading and writing x in every iteration.  Same products, same additions, same order: bit for bit
+    the x of the running update (PADNE_PCG_NO_XHIST=1), the same iterations -- cold, from an initial guess, with a ring of
+    eight places that wraps several times within a solve (PADNE_FORCE=xhist_small, a tolerance that takes > 30 iterations
+    and a restart from the true residual), and through a second solve on the same context (the places are reused)."""
+    A, b, _, _, _ = layered_spd(3, 200, 150, 5)
+    rng = np.random.default_rng(8)
+    x0 = rng.uniform(-1, 1, A.shape[0]) * 1e-3
+
+    def run():
+        c = _hip.Context(0)
+        try:
+            d = c.csr_from_scipy(A)
+            out = [d.solve_spd(b, precond="amg", rtol=1e-12), d.solve_spd(b, precond="amg", rtol=1e-12, x0=x0),
+                   d.solve_spd(b, precond="amg", rtol=1e-15, max_iter=70), d.solve_spd(2.0 * b, precond="amg", rtol=1e-12)]
+            d.close()
+        finally:
+            c.close()
+        return out
+    kept = run()
+    switches.set("PADNE_FORCE", "xhist_small")
+    ring = run()
+    switches.unset("PADNE_FORCE")
+    switches.set("PADNE_PCG_NO_XHIST", "1")
+    running = run()
+    switches.unset("PADNE_PCG_NO_XHIST")
+    assert kept[2].iterations > 30, "the third solve is meant to wrap the ring of eight"
+    for k, g, r in zip(kept, ring, running):
+        assert k.precond_fallbacks == 0 and k.status == r.status == g.status
+        assert k.iterations == r.iterations == g.iterations and k.restarts == r.restarts == g.restarts
+        assert np.array_equal(k.x, r.x) and np.array_equal(g.x, r.x)
+    assert np.linalg.norm(A @ kept[0].x - b) <= 2e-12 * np.linalg.norm(b)
+
+
 def test_warm_start_whose_residual_lies_thirty_orders_below_the_right_hand_side(switches):
     """The single-precision vectors of the loop (cycle input, z, the stored search direction) are kept in units of ||b||;
     from an initial guess whose residual is 1e-30 ||b|| they would be denormals or zero (p.q = 0: a breakdown where the
@@ -910,9 +946,21 @@ def test_problem_fixture_through_solve(ctx, name, family):
                                    for c in net.connections], elements=list(net.elements)) for net in prob.networks]
     prob = P.Problem(layers=layers, networks=nets)
     mesher = FixtureMesher(by_geom)
+    n_disc = int(g.get("n_disc", 0))
     with warnings.catch_warnings():
         warnings.simplefilter("error", solver.SolverWarning)
-        sol = solver.solve(prob, mesher=mesher)
+        if n_disc == 0:
+            sol = solver.solve(prob, mesher=mesher)
+        else:
+            # copper that nothing drives (solver.py:862-870: the connectivity pre-pass keeps it out of the system and hands it
+            # to produce_layer_solutions as it is): the post-meshing entry point, with the meshes the fixture lists
+            disc = [[] for _ in layers]
+            for k in range(n_disc):
+                disc[int(g[f"disc_layer{k}"])].append(mesh.Mesh(g[f"disc_xy{k}"], g[f"disc_tri{k}"]))
+            handed = [m for li in range(len(layers)) for m in per_layer.get(li, [])]
+            sol = solver.solve_meshed(prob, handed, [m[2] for m in ms], disconnected_meshes_by_layer=disc)
+            for ls, dl in zip(sol.layer_solutions, disc):
+                assert len(ls.disconnected_meshes) == len(dl) and all(a is b for a, b in zip(ls.disconnected_meshes, dl))
     n_vert = sum(len(m[0]) for m in ms)
     scale = np.abs(g["v"][:n_vert]).max()
     worst = 0.0
@@ -2333,7 +2381,8 @@ def test_solve_with_the_rows_dealt_to_several_ranks(ctx, n_layers, world):
             assert sol.solver_info.residual_norm < 1e-9 and sol.solver_info.iterations < 80
 
 
-@pytest.mark.parametrize("name,world", [("problem_c1", 2), ("problem_c1", 4), ("problem_mixed", 2)])
+@pytest.mark.parametrize("name,world", [("problem_c1", 2), ("problem_c1", 4), ("problem_mixed", 2), ("problem_two_planes", 2),
+                                        ("problem_many_meshes", 4), ("problem_simple_trace", 2)])
 def test_problem_fixtures_with_sources_on_several_ranks(ctx, name, world):
     """``solve(prob, partition=...)`` on the reference-generated Problem fixtures: config C1 of BASELINE.json (the
     via_tht_4layer-like board: four layers, via rings, three resistors, one 1 V source) and the mixed network (resistors,
