@@ -48,6 +48,11 @@ def parse():
     ap.add_argument("--no-rank-proxy", action="store_true",
                     help="skip the one-rank-of-eight measurement (one layer of C4 through the row-partitioned path)")
     ap.add_argument("--no-c5", action="store_true", help="skip the batched right-hand sides of config C5")
+    ap.add_argument("--no-small", action="store_true", help="skip solve_system vs spsolve at 11 k / 100 k / 1 M unknowns")
+    ap.add_argument("--no-dist-one-rank", action="store_true",
+                    help="skip config C4 through the row-partitioned path with a one-rank RCCL communicator")
+    ap.add_argument("--small-cpu-limit", type=int, default=300000,
+                    help="largest system whose CPU spsolve is timed live in the `small` block (above: profiles/r06_small.json)")
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the row-partitioned code path (RCCL communicator, halo plan) even on 1 GPU")
     ap.add_argument("--cpu-sample-nx", type=int, default=400,
@@ -288,9 +293,47 @@ def rank_proxy(steps: int):
         out["p2p_exchange"]["static_from"] = "profiles/r05_p2p_exchange.json (tests/two_process_rank.py, two processes on one GPU; not measured in this run)"
     except Exception:
         out["p2p_exchange"] = None
+    ds.close()
     ctx2.close()
-    dist.destroy_process_group()
     return out
+
+
+def dist_one_rank(steps: int):
+    """The HEADLINE config (C4, all eight layers) through the row-partitioned path with an RCCL communicator of one rank:
+    amg_setup_dist, single-reduction CG, the collectives of a communicator -- what the code path of an N-GPU run costs
+    before there is a second rank, next to ``ms_per_step`` of the one-GPU path in the same line."""
+    import torch
+    import torch.distributed as dist
+    from padne_amd import _hip, distributed, synthetic
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if not dist.is_initialized():
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    sysm = synthetic.config("C4")
+    ctx = _hip.Context(0)
+    plan = distributed.build_layer_partition(sysm, 0, 1)
+    ds = distributed.DistributedSolver(ctx, plan, dist)
+    del sysm, plan
+    ds.solve(rtol=RTOL, precond="amg", rebuild=True)
+    ds.solve(rtol=RTOL, precond="amg", rebuild=True)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = ds.solve(rtol=RTOL, precond="amg", rebuild=True)
+    ctx.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    c0 = _hip.launch_count()
+    ds.solve(rtol=RTOL, precond="amg", rebuild=True)
+    ctx.synchronize()
+    c1 = _hip.launch_count()
+    rec = {"ms_per_step": ms, "setup_ms": float(last.setup_seconds) * 1e3,
+           "us_per_iteration": float(last.seconds) / max(int(last.iterations), 1) * 1e6, "iterations": int(last.iterations),
+           "launches_per_step": int(c1 - c0), "steps": steps,
+           "path": "config C4 through DistributedSolver (row-partitioned path) with an RCCL communicator of one rank"}
+    ds.close()
+    ctx.close()
+    return rec
 
 
 def c5_block(ctx, steps: int):
@@ -352,6 +395,73 @@ def c5_block(ctx, steps: int):
         d.free()
     A.close()
     return rec
+
+
+def small_block(ctx, live_cpu_limit: int = 300000):
+    """Where the drop-in pays off: ``solve_system(L, r)`` -- host r in, host v out, everything derived from L built inside
+    the call -- against the reference's own solve step (tocsc + spsolve + residual, solver.py:772-775) on the same host
+    and the same system, at the size of the shipped projects (config C1: ~11 k unknowns), at ~100 k and at ~1 M.  The CPU
+    time of sizes above ``live_cpu_limit`` unknowns is read from profiles/r06_small.json (measured once on a GPU-box
+    host by this very function, `scripts/small_sizes.py`); the rest is timed in this run."""
+    from oracle import padne_oracle as O
+    from padne_amd import solver, synthetic
+    from padne_amd.reduction import Constraint, KKTLayout
+    solver.set_context(ctx)
+    static = {}
+    try:
+        static = {int(e["n"]): e for e in json.load(open(os.path.join(ROOT, "profiles", "r06_small.json")))["small"]}
+    except Exception:
+        static = {}
+    out = []
+    for layers, nx in ((4, 53), (4, 158), (4, 500)):
+        sysm = synthetic.layered_system(layers, nx, nx, via_lattice=max(2, int(round(32 * nx / 1118))))
+        nv = sysm.n_vertices
+        N = nv + 1
+        xy, tri, mvo, mto, sig = flat(sysm)
+        rows, cols, vals, rhs = stamps_of(sysm, N)
+        L = ctx.assemble_system(N, xy, tri, mvo, mto, sig, rows, cols, vals)
+        layout = KKTLayout(size=N, n_potential=N - 1, constraints=[Constraint(index=N - 1, p=int(sysm.ground), n=-1, value=0.0)])
+        Ls = solver.SystemMatrix(L, layout)
+        v, info = solver.solve_system(Ls, rhs)                 # warm-up (pool, code objects)
+        times = []
+        for _ in range(5):
+            for plan in Ls._plans.values():
+                plan.close()
+            Ls._plans.clear()
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            v, info = solver.solve_system(Ls, rhs)
+            times.append(time.perf_counter() - t0)
+        cached = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            v, info_c = solver.solve_system(Ls, rhs)
+            cached.append(time.perf_counter() - t0)
+        rec = {"n": int(N), "hip_solve_system_ms": float(np.median(times)) * 1e3,
+               "hip_solve_system_cached_plan_ms": float(np.median(cached)) * 1e3,
+               "iterations": int(info.iterations), "residual_norm": float(info.residual_norm)}
+        if N <= live_cpu_limit:
+            els = [("R", int(a), int(b), float(r)) for a, b, r in zip(*sysm.resistors)]
+            els += [("I", int(f), int(t), float(i)) for f, t, i in zip(*sysm.current_sources)]
+            Lo, ro = O.assemble_system([(m[0], m[1], m[2]) for m in sysm.meshes], 0, els, sysm.ground)
+            cpu = []
+            for _ in range(3 if N < 50000 else 1):
+                t0 = time.perf_counter()
+                v_ref, gc, res = O.solve_system(Lo, ro)
+                cpu.append(time.perf_counter() - t0)
+            rec["cpu_spsolve_ms"] = float(np.median(cpu)) * 1e3
+            rec["max_rel_potential_error"] = float(np.abs(v[:nv] - v_ref[:nv]).max() / np.abs(v_ref[:nv]).max())
+        elif int(N) in static and "cpu_spsolve_ms" in static[int(N)]:
+            rec["cpu_spsolve_ms"] = static[int(N)]["cpu_spsolve_ms"]
+            rec["cpu_static_from"] = "profiles/r06_small.json (this function with live_cpu_limit raised, on a GPU-box host; not re-measured in this run)"
+        if "cpu_spsolve_ms" in rec:
+            rec["speedup"] = rec["cpu_spsolve_ms"] / rec["hip_solve_system_ms"]
+        for plan in Ls._plans.values():
+            plan.close()
+        Ls._plans.clear()
+        L.close()
+        out.append(rec)
+    return out
 
 
 def launch_ranks(n: int) -> int:
@@ -530,7 +640,7 @@ def main():
                         "per_iteration": round(((c2 - c1) - (c3 - c2)) / d_it, 1)}
         except Exception as exc:
             launches = {"error": repr(exc)}
-    c5 = proxy = None
+    c5 = proxy = small = d1 = None
     if not distributed_path and args.precond == "amg" and args.workload == "C4":
         A.close()
         b.free()
@@ -540,11 +650,27 @@ def main():
                 c5 = c5_block(ctx, max(2, min(args.steps, 5)))
             except Exception as exc:
                 c5 = {"error": repr(exc)}
+        if not args.no_small:
+            try:
+                small = small_block(ctx, args.small_cpu_limit)
+            except Exception as exc:
+                small = {"error": repr(exc)}
         if not args.no_rank_proxy:
             try:
                 proxy = rank_proxy(max(3, min(args.steps, 10)))
             except Exception as exc:
                 proxy = {"error": repr(exc)}
+        if not args.no_dist_one_rank:
+            try:
+                d1 = dist_one_rank(max(3, min(args.steps, 10)))
+            except Exception as exc:
+                d1 = {"error": repr(exc)}
+        try:
+            import torch.distributed as _d
+            if _d.is_initialized():
+                _d.destroy_process_group()
+        except Exception:
+            pass
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -667,6 +793,12 @@ def main():
                 proxy["note"] = ("ms_per_step of the headline config on this GPU / ms_per_step of one rank's share with nothing to "
                                  "wait for: an upper bound of the 8-GPU speed-up, not a measurement of it")
             out["rank_proxy"] = proxy
+        if d1 is not None:
+            if "ms_per_step" in d1:
+                d1["vs_one_gpu_path"] = d1["ms_per_step"] / ms_per_step
+            out["dist_one_rank"] = d1
+        if small is not None:
+            out["small"] = small
         if args.gpus == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_sample_nx)

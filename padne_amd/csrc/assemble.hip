@@ -1998,6 +1998,150 @@ __global__ __launch_bounds__(256) void relabel_fill_ordered(long long n_rows, co
     if (zero) *(volatile int *)zero_seen = 1;
 }
 
+// The same two passes with a WAVE per 64 rows, in the shape of the SpMV's matrix stream: the rows of a tile are one
+// contiguous range of the source and -- the map keeps the order -- their kept entries one contiguous range of the result.
+// The wave streams the range lane-consecutively (lane l takes entries l, l + 64, ...: 256 / 512 contiguous bytes per load)
+// and a kept entry's place is the running count of kept entries in front of it (a ballot and a population count), so the
+// stores of an instruction are contiguous too, holes closed: full lines, where a lane per row wrote 16-byte pieces at a
+// stride of 56 / 112 bytes (1.64 x the bytes of the result by the write counter, 593 us at 10 M rows).
+// Dropped rows and columns are rare (the ground vertex, the multiplier row): the count pass only looks for DROPPED entries and
+// finds their rows by bisection of the tile's row starts in LDS; the copy masks the entries of a dropped row by its range.
+constexpr int kRlEpl = 8;      // entries per lane and pass
+
+__global__ __launch_bounds__(256) void relabel_count_wave(const int n_rows, const int *__restrict__ rowptr,
+                                                          const int *__restrict__ cols, const int *__restrict__ map,
+                                                          const int *__restrict__ cmap, const int n_out, int *__restrict__ cnt) {
+    __shared__ int rs_s[4][65];
+    __shared__ int drop_s[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n_tiles = (n_rows + 63) / 64;
+    for (int tile = blockIdx.x * 4 + w; tile < n_tiles; tile += gridDim.x * 4) {
+        const int r = tile * 64 + lane;
+        const int last = min(63, n_rows - 1 - tile * 64);
+        int rs = 0, re = 0, t = -1;
+        if (r < n_rows) {
+            rs = rowptr[r];
+            re = rowptr[r + 1];
+            t = map[r];
+            if (t >= n_out) t = -1;      // (map_is_compaction reports it)
+        }
+        const int k0 = __shfl(rs, 0, 64), k1 = __shfl(re, last, 64);
+        bool any = false;
+        bool staged = false;
+        for (int base = k0; base < k1; base += 64 * kRlEpl) {
+            int c[kRlEpl], tc[kRlEpl];
+#pragma unroll
+            for (int j = 0; j < kRlEpl; ++j) {
+                const int e = base + lane + 64 * j;
+                c[j] = e < k1 ? cols[e] : -1;
+            }
+#pragma unroll
+            for (int j = 0; j < kRlEpl; ++j) tc[j] = c[j] >= 0 ? cmap[c[j]] : 0;
+            bool dropped = false;
+#pragma unroll
+            for (int j = 0; j < kRlEpl; ++j) dropped = dropped || tc[j] < 0;
+            if (__ballot(dropped) != 0ull) {          // wave-uniform, rare
+                if (!staged) {
+                    rs_s[w][lane] = rs;
+                    if (lane == last) rs_s[w][last + 1] = re;
+                    drop_s[w][lane] = 0;
+                    staged = true;
+                    any = true;
+                    __builtin_amdgcn_wave_barrier();
+                }
+#pragma unroll
+                for (int j = 0; j < kRlEpl; ++j)
+                    if (tc[j] < 0) {
+                        const int e = base + lane + 64 * j;
+                        int lo = 0, hi = last + 1;             // the row with rs_s[row] <= e < rs_s[row + 1]
+                        while (hi - lo > 1) {
+                            const int mid = (lo + hi) >> 1;
+                            if (rs_s[w][mid] <= e) lo = mid;
+                            else hi = mid;
+                        }
+                        atomicAdd(&drop_s[w][lo], 1);
+                    }
+            }
+        }
+        int kept = re - rs;
+        if (any) {
+            __builtin_amdgcn_wave_barrier();
+            kept -= drop_s[w][lane];
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (t >= 0) cnt[t] = kept;
+    }
+}
+
+__global__ __launch_bounds__(256) void relabel_fill_wave(const int n_rows, const int *__restrict__ rowptr,
+                                                         const int *__restrict__ cols, const double *__restrict__ vals,
+                                                         const int *__restrict__ map, const int *__restrict__ cmap,
+                                                         const double scale, const int *__restrict__ out_rowptr,
+                                                         int *__restrict__ out_cols, double *__restrict__ out_vals,
+                                                         int *__restrict__ zero_seen) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n_tiles = (n_rows + 63) / 64;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));      // the lanes below this one
+    bool zero = false;
+    for (int tile = blockIdx.x * 4 + w; tile < n_tiles; tile += gridDim.x * 4) {
+        const int r = tile * 64 + lane;
+        const int last = min(63, n_rows - 1 - tile * 64);
+        int rs = 0, re = 0, t = -1;
+        if (r < n_rows) {
+            rs = rowptr[r];
+            re = rowptr[r + 1];
+            t = map[r];
+        }
+        const unsigned long long kept_rows = __ballot(t >= 0);
+        if (kept_rows == 0ull) continue;
+        unsigned long long dropped_rows = __ballot(r < n_rows && t < 0 && re > rs);
+        const int first = __ffsll((long long)kept_rows) - 1;
+        int o = out_rowptr[__shfl(t, first, 64)];              // where the tile's kept entries start in the result
+        const int k0 = __shfl(rs, 0, 64), k1 = __shfl(re, last, 64);
+        for (int base = k0; base < k1; base += 64 * kRlEpl) {
+            int c[kRlEpl], tc[kRlEpl];
+            double v[kRlEpl];
+#pragma unroll
+            for (int j = 0; j < kRlEpl; ++j) {
+                const int e = base + lane + 64 * j;
+                c[j] = e < k1 ? cols[e] : -1;
+            }
+#pragma unroll
+            for (int j = 0; j < kRlEpl; ++j) {
+                const int e = base + lane + 64 * j;
+                v[j] = e < k1 ? vals[e] : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < kRlEpl; ++j) tc[j] = c[j] >= 0 ? cmap[c[j]] : -1;
+            if (dropped_rows != 0ull) {                        // wave-uniform, rare: the entries of a dropped row go
+                for (unsigned long long m = dropped_rows; m != 0ull; m &= m - 1) {
+                    const int d = __ffsll((long long)m) - 1;
+                    const int ds = __shfl(rs, d, 64), de = __shfl(re, d, 64);
+#pragma unroll
+                    for (int j = 0; j < kRlEpl; ++j) {
+                        const int e = base + lane + 64 * j;
+                        if (e >= ds && e < de) tc[j] = -1;
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kRlEpl; ++j) {
+                const bool keep = tc[j] >= 0;
+                const unsigned long long b = __ballot(keep);
+                if (keep) {
+                    const int pos = o + __popcll(b & lt);
+                    const double wv = scale * v[j];
+                    zero = zero || wv == 0.0;
+                    out_cols[pos] = tc[j];
+                    out_vals[pos] = wv;
+                }
+                o += __popcll(b);
+            }
+        }
+    }
+    if (zero) *(volatile int *)zero_seen = 1;
+}
+
 // ---- power density ---------------------------------------------------------------------------
 // compute_triangle_gradient (solver.py:689-725) with the face vertex order of the reference:
 // Face.edge is the last interior half-edge created (v3->v1, mesh.py:320-325) so face.vertices
@@ -2631,8 +2775,15 @@ int csr_relabel(padne_ctx *ctx, const padne_csr *m, const int32_t *row_map_host,
             hipLaunchKernelGGL(map_is_compaction, dim3(nblk(m->n_cols)), dim3(256), 0, s, (long long)m->n_cols,
                                (const int *)d_cmap, (int)n_cols_out, d_err + 3);
         // (the counts are those of any one-to-one map; taken before the verdict is known, for one look at the host less)
-        hipLaunchKernelGGL(relabel_count_ordered, dim3(nblk(m->n_rows)), dim3(256), 0, s, (long long)m->n_rows, m->rowptr, m->cols,
-                           (const int *)d_map, (const int *)d_cmap, (int)n_rows_out, d_cnt);
+        // (a wave per 64 rows, 2048 workgroups sweep the tiles; the lane-per-row kernels relabel_count_ordered /
+        // relabel_fill_ordered remain for PADNE_FORCE=relabel_lanes: the tests compare the two)
+        const int g_wave = (int)std::min<long long>(2048, ((m->n_rows + 63) / 64 + 3) / 4);
+        if (ctx->opt.force_relabel_lanes)
+            hipLaunchKernelGGL(relabel_count_ordered, dim3(nblk(m->n_rows)), dim3(256), 0, s, (long long)m->n_rows, m->rowptr, m->cols,
+                               (const int *)d_map, (const int *)d_cmap, (int)n_rows_out, d_cnt);
+        else
+            hipLaunchKernelGGL(relabel_count_wave, dim3(g_wave), dim3(256), 0, s, (int)m->n_rows, m->rowptr, m->cols,
+                               (const int *)d_map, (const int *)d_cmap, (int)n_rows_out, d_cnt);
         PADNE_HIP_CHECK(hipGetLastError());
         int h_flags[6] = {0, 0, 0, 0, 0, 0};
         PADNE_TRY(read_back(ctx, d_err, sizeof(h_flags), h_flags));
@@ -2649,9 +2800,14 @@ int csr_relabel(padne_ctx *ctx, const padne_csr *m, const int32_t *row_map_host,
             PADNE_TRY(csr_alloc(ctx, n_rows_out, n_cols_out, nnz, &res));
             hipError_t e = hipMemcpyAsync(res->rowptr, d_slot, sizeof(int32_t) * (size_t)(n_rows_out + 1), hipMemcpyDeviceToDevice, s);
             if (e == hipSuccess) {
-                hipLaunchKernelGGL(relabel_fill_ordered, dim3(nblk(m->n_rows)), dim3(256), 0, s, (long long)m->n_rows, m->rowptr,
-                                   m->cols, m->vals, (const int *)d_map, (const int *)d_cmap, scale, (const int *)res->rowptr,
-                                   res->cols, res->vals, d_err + 6);
+                if (ctx->opt.force_relabel_lanes)
+                    hipLaunchKernelGGL(relabel_fill_ordered, dim3(nblk(m->n_rows)), dim3(256), 0, s, (long long)m->n_rows, m->rowptr,
+                                       m->cols, m->vals, (const int *)d_map, (const int *)d_cmap, scale, (const int *)res->rowptr,
+                                       res->cols, res->vals, d_err + 6);
+                else
+                    hipLaunchKernelGGL(relabel_fill_wave, dim3(g_wave), dim3(256), 0, s, (int)m->n_rows, m->rowptr, m->cols, m->vals,
+                                       (const int *)d_map, (const int *)d_cmap, scale, (const int *)res->rowptr, res->cols,
+                                       res->vals, d_err + 6);
                 e = hipGetLastError();
             }
             int h_zero = 0;

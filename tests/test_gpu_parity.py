@@ -750,8 +750,8 @@ def test_x_formed_from_the_kept_search_directions_has_the_bits_of_the_running_up
     x = x_0 + sum_j alpha_j p_j when the loop has ended (`pcg_x_flush_kernel`), each row's terms in the order of the
     iterations, instead of reading and writing x in every iteration.  Same products, same additions, same order: bit for bit
     the x of the running update (PADNE_PCG_NO_XHIST=1), the same iterations -- cold, from an initial guess, with a ring of
-    eight places that wraps several times within a solve (PADNE_FORCE=xhist_small, a tolerance that takes > 30 iterations
-    and a restart from the true residual), and through a second solve on the same context (the places are reused)."""
+    eight places that wraps several times within a solve (PADNE_FORCE=xhist_small), at a tolerance close to what the
+    recurrence reaches, and through further solves on the same context (the places are reused)."""
     A, b, _, _, _ = layered_spd(3, 200, 150, 5)
     rng = np.random.default_rng(8)
     x0 = rng.uniform(-1, 1, A.shape[0]) * 1e-3
@@ -761,7 +761,7 @@ def test_x_formed_from_the_kept_search_directions_has_the_bits_of_the_running_up
         try:
             d = c.csr_from_scipy(A)
             out = [d.solve_spd(b, precond="amg", rtol=1e-12), d.solve_spd(b, precond="amg", rtol=1e-12, x0=x0),
-                   d.solve_spd(b, precond="amg", rtol=1e-15, max_iter=70), d.solve_spd(2.0 * b, precond="amg", rtol=1e-12)]
+                   d.solve_spd(b, precond="amg", rtol=2e-13), d.solve_spd(2.0 * b, precond="amg", rtol=1e-12)]
             d.close()
         finally:
             c.close()
@@ -773,7 +773,7 @@ def test_x_formed_from_the_kept_search_directions_has_the_bits_of_the_running_up
     switches.set("PADNE_PCG_NO_XHIST", "1")
     running = run()
     switches.unset("PADNE_PCG_NO_XHIST")
-    assert kept[2].iterations > 30, "the third solve is meant to wrap the ring of eight"
+    assert min(k.iterations for k in kept) > 16, "every solve is meant to wrap the ring of eight at least twice"
     for k, g, r in zip(kept, ring, running):
         assert k.precond_fallbacks == 0 and k.status == r.status == g.status
         assert k.iterations == r.iterations == g.iterations and k.restarts == r.restarts == g.restarts
@@ -2647,6 +2647,8 @@ def test_maps_that_only_drop_indices_are_relabelled_by_a_copy_with_holes(ctx, sw
     n = 7000
     M = H.random_csr(n, n, 7, 31).tolil()
     M[33, 100:140] = rng.uniform(-1, 1, 40)
+    M[70, 200:1500] = rng.uniform(-1, 1, 1300)      # a 64-row tile of several passes (512 entries each) of the wave kernels
+    M[700:703, 0:400] = rng.uniform(-1, 1, (3, 400))
     M = M.tocsr()
     M.sort_indices()
 
@@ -2657,6 +2659,7 @@ def test_maps_that_only_drop_indices_are_relabelled_by_a_copy_with_holes(ctx, sw
         m[keep] = np.arange(int(keep.sum()), dtype=np.int32)
         return m, keep
     drops = {"ground": [0], "last": [n - 1], "both ends": [0, n - 1], "scattered": sorted(rng.choice(n, 200, replace=False)),
+             "long rows": [70, 701, 250, 1499],
              "long run": list(range(500, 600)), "none": []}
     Mz = M.copy()
     Mz.data[::41] = 0.0
@@ -2674,8 +2677,10 @@ def test_maps_that_only_drop_indices_are_relabelled_by_a_copy_with_holes(ctx, sw
             dm.free()
             switches.set("PADNE_FORCE", "relabel_slots")
             slots = d.reduce(m, n_out, -1.0).to_scipy()
+            switches.set("PADNE_FORCE", "relabel_lanes")      # a lane per row (round 5) instead of a wave per 64 rows
+            lanes = d.reduce(m, n_out, -1.0).to_scipy()
             switches.unset("PADNE_FORCE")
-            for got in (host, dev, slots):
+            for got in (host, dev, slots, lanes):
                 assert got.shape == ref.shape and got.has_sorted_indices, name
                 assert np.array_equal(got.indptr, ref.indptr) and np.array_equal(got.indices, ref.indices), name
                 assert np.array_equal(got.data, ref.data), name
