@@ -400,7 +400,8 @@ def c5_block(ctx, steps: int):
 def small_block(ctx, live_cpu_limit: int = 300000):
     """Where the drop-in pays off: ``solve_system(L, r)`` -- host r in, host v out, everything derived from L built inside
     the call -- against the reference's own solve step (tocsc + spsolve + residual, solver.py:772-775) on the same host
-    and the same system, at the size of the shipped projects (config C1: ~11 k unknowns), at ~100 k and at ~1 M.  The CPU
+    and the same system, at ~1 k and ~3 k unknowns (where the crossover lies), at the size of the shipped projects (config
+    C1: ~11 k unknowns), at ~100 k and at ~1 M.  The CPU
     time of sizes above ``live_cpu_limit`` unknowns is read from profiles/r06_small.json (measured once on a GPU-box
     host by this very function, `scripts/small_sizes.py`); the rest is timed in this run."""
     from oracle import padne_oracle as O
@@ -413,7 +414,7 @@ def small_block(ctx, live_cpu_limit: int = 300000):
     except Exception:
         static = {}
     out = []
-    for layers, nx in ((4, 53), (4, 158), (4, 500)):
+    for layers, nx in ((4, 16), (4, 28), (4, 53), (4, 158), (4, 500)):
         sysm = synthetic.layered_system(layers, nx, nx, via_lattice=max(2, int(round(32 * nx / 1118))))
         nv = sysm.n_vertices
         N = nv + 1

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from padne_amd import _hip
 lib = os.path.abspath(sys.argv[1])
 _hip.LIB_PATH = lib
-sys.argv = ["bench.py"] + sys.argv[2:] + ["--no-cpu-baseline", "--no-seam"]
+sys.argv = ["bench.py"] + sys.argv[2:] + ["--no-cpu-baseline", "--no-seam", "--no-small", "--no-dist-one-rank"]
 import bench
 buf = io.StringIO()
 with contextlib.redirect_stdout(buf):

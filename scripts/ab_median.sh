@@ -4,7 +4,7 @@
 A=$1; B=$2; N=${3:-7}; shift; shift; shift
 TMP=$(mktemp)
 for i in $(seq $N); do
-  for L in $A $B; do python scripts/ab_bench_lib.py $L --steps 12 --warmup 2 --no-c5 --no-rank-proxy "$@" 2>/dev/null | tail -1 >> $TMP; done
+  for L in $A $B; do python scripts/ab_bench_lib.py $L --steps 12 --warmup 2 --no-c5 --no-rank-proxy --no-small --no-dist-one-rank "$@" 2>/dev/null | tail -1 >> $TMP; done
 done
 python3 - $TMP <<'PY'
 import sys, statistics, collections

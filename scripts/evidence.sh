@@ -7,4 +7,4 @@ O=gpurun_out/evidence; mkdir -p $O; cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 echo fuzz done
 timeout -k 10 300 python scripts/parity_report.py > $O/parity_report.log 2>&1 && cp gpurun_out/parity_report.json $O/; echo parity done
 timeout -k 10 900 python scripts/exp_p2p_exchange.py > $O/p2p.log 2>&1 && cp gpurun_out/p2p_exchange.json $O/; echo p2p done
-bash scripts/gpu_prof.sh evid_c4 "" --no-c5 --no-rank-proxy > $O/prof_c4.log 2>&1; cp gpurun_out/evid_c4_setup.txt gpurun_out/evid_c4_iteration.txt gpurun_out/evid_c4_streams.txt $O/ 2>/dev/null; echo profile done
+bash scripts/gpu_prof.sh evid_c4 "" --no-c5 --no-rank-proxy --no-small --no-dist-one-rank > $O/prof_c4.log 2>&1; cp gpurun_out/evid_c4_setup.txt gpurun_out/evid_c4_iteration.txt gpurun_out/evid_c4_streams.txt $O/ 2>/dev/null; echo profile done

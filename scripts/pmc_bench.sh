@@ -4,7 +4,7 @@
 # usage (on the GPU box, from the repo root):  bash scripts/pmc_bench.sh gpurun_out/pmc_r01
 OUT="$GRAFT_REPO_ROOT/$1"; mkdir -p "$OUT"; export TMPDIR=/tmp; cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d "$OUT/$C" -o run -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-seam --no-c5 --no-rank-proxy > "$OUT/$C.log" 2>&1 || exit 1
+  rocprofv3 --pmc $C --output-format csv -d "$OUT/$C" -o run -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-seam --no-c5 --no-rank-proxy --no-small --no-dist-one-rank > "$OUT/$C.log" 2>&1 || exit 1
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, json, sys, collections
