@@ -141,7 +141,6 @@ struct padne_options {
     // PADNE_FORCE=<path>[,<path>...]: send everything through a path that the data takes only rarely (tests)
     bool force_asm_hash = false, force_asm_two_pass = false, force_relabel_slots = false, force_transpose_cursors = false;
     bool force_relabel_lanes = false;  // relabel_lanes: the order-preserving relabel with a lane per row (the form of round 5)
-    bool force_pcg_p_kernel = false;   // pcg_p_kernel: p = z + beta p by a kernel of its own instead of inside the staging of q = A p
     bool force_xhist_small = false;    // xhist_small: eight places for the kept search directions (the ring wraps within a solve)
     long long force_spgemm_split = 0;  // spgemm_split:<slots>
     // PADNE_VERBOSE=amg,xw,pool: diagnostics on stderr
@@ -274,8 +273,6 @@ int launch_spmv_f32_resid_pre(padne_ctx *ctx, const padne_csr *m, const float *b
                               const float *dinv32, float c);
 bool spmv_x32_ok(const padne_csr *m);
 int launch_spmv_dot_x32(padne_ctx *ctx, const padne_csr *m, const float *x, double *y, double *partials, const int32_t *done_flag);
-int launch_spmv_dot_pfold(padne_ctx *ctx, const padne_csr *m, const float *z, const float *p_old, float *p_out, double *y,
-                          double *partials, const int32_t *done_flag, const double *part_rz_new, const double *part_rz_old, int P_rz);
 int launch_spmv_f32_wup(padne_ctx *ctx, const padne_csr *w, const float *e, float *x_out, const int32_t *done_flag,
                         const float *x_pre, const float *r_pre, const float *dinv32, float scale);
 int launch_spmm_f32_wup(padne_ctx *ctx, const padne_csr *w, int k, const float *e, float *x_out, const int32_t *done_flag,

@@ -342,37 +342,6 @@ __global__ __launch_bounds__(256) void pcg_update_p_z_kernel(
     }
 }
 
-// The bookkeeping of an iteration whose p update rides on the next product (csr_spmv_pfold_kernel): one workgroup leaves the
-// step length for pcg_x_flush_kernel, counts the iteration and takes the stopping decision -- what workgroup 0 of
-// pcg_update_p_z_kernel does, from the same sums in the same order.
-__global__ __launch_bounds__(256) void pcg_book_kernel(const double *__restrict__ part_rz_new, const double *__restrict__ part_rz_old,
-                                                       const int P_rz, const double *__restrict__ part_rr, const int P_rr,
-                                                       const double *__restrict__ part_pq, const int P_pq, PcgStatus *__restrict__ st,
-                                                       const int max_iter, const double *__restrict__ bb2, double *__restrict__ alpha_out) {
-    __shared__ double red[4];
-    if (st->done_seen) return;
-    const double rz_new = block_total(part_rz_new, P_rz, red);
-    const double rz_old = block_total(part_rz_old, P_rz, red);
-    const double s2 = *bb2;
-    const double z_mul = s2 > 0.0 ? sqrt(s2) : 1.0;
-    const double alpha = rz_old / block_total(part_pq, P_pq, red);
-    const double rr = block_total(part_rr, P_rr, red);
-    const double pq = block_total(part_pq, P_pq, red);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        *alpha_out = alpha / z_mul;
-        const int it = st->iters + 1;
-        st->iters = it;
-        st->rr = rr;
-        if (!(pq > 0.0) || !(rr == rr) || !(rz_new > 0.0)) {
-            st->code = PADNE_E_BREAKDOWN;
-            st->done = 1;
-        } else if (rr <= st->tol2 || it >= max_iter) {
-            st->done = 1;
-        }
-    }
-}
-
 // x += sum over the iterations j in [j0, min(j1, completed)) of alpha_j p_j, each row's terms added in the order of the
 // iterations: the bits of the running update x += alpha_j p_j, which read and wrote x in every iteration (16 bytes per
 // row and iteration; this reads 4).  p_j lies in slot j % n_slots of `hist`, alpha_j in alpha[j % n_slots]; `completed`
@@ -742,7 +711,6 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
     double *alpha_hist = n_hist > 0 ? (double *)(hist + hist_stride * (size_t)n_hist) : nullptr;
     if (hist != nullptr) p32 = hist;      // direction j of a (re)start lies in place j % n_hist
     auto p_place = [&](long long j) { return hist + hist_stride * (size_t)(j % n_hist); };
-    const bool fold_p = hist != nullptr && !ctx->opt.force_pcg_p_kernel;      // the p update inside the staging of q = A p
 
     PADNE_HIP_CHECK(hipMemsetAsync(st, 0, sizeof(PcgStatus), s));
     if (halo) PADNE_HIP_CHECK(hipMemsetAsync(p + n, 0, sizeof(double) * (size_t)(nc - n), s));
@@ -843,13 +811,7 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
                     PADNE_HIP_CHECK(hipEventRecord(e0, s));
                 }
                 if (hist != nullptr) p32 = p_place(jq);
-                if (fold_p && jq > 0)
-                    // p_jq = z + beta p_(jq-1) formed inside the staging of the product: beta = r.z at the start of this
-                    // iteration (rz_old) / r.z one iteration earlier (its partials still lie where this iteration's cycle
-                    // will write: rz_new)
-                    PADNE_TRY(launch_spmv_dot_pfold(ctx, a, (const float *)z32, p_place(jq - 1), p32, q, slot(ctx, SLOT_PQ), &st->done,
-                                                    rz_old, rz_new, Pz));
-                else if (p32 != nullptr) PADNE_TRY(launch_spmv_dot_x32(ctx, a, p32, q, slot(ctx, SLOT_PQ), &st->done));
+                if (p32 != nullptr) PADNE_TRY(launch_spmv_dot_x32(ctx, a, p32, q, slot(ctx, SLOT_PQ), &st->done));
                 else PADNE_TRY(halo_product_dot(ctx, a, p, q, slot(ctx, SLOT_PQ), &st->done));
                 if (sampled) PADNE_HIP_CHECK(hipEventRecord(ev_b.back(), s));
                 if (dist) {
@@ -871,12 +833,7 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
                         PADNE_TRY(fold(slot(ctx, SLOT_RR), gv, kMaxPartials, 1, s_new + 1));
                         PADNE_TRY(allreduce(s_new, 2));
                     }
-                    if (fold_p) {
-                        hipLaunchKernelGGL(pcg_book_kernel, dim3(1), dim3(256), 0, s, rz_new, rz_old, Pz, rr, Pr, pq, Pq, st,
-                                           max_iter - total_iters, bb_scalar, alpha_hist + (jq % n_hist));
-                        ++jq;
-                        if (jq - jf >= n_hist - 1) PADNE_TRY(flush_x());
-                    } else if (hist != nullptr) {
+                    if (hist != nullptr) {
                         hipLaunchKernelGGL(pcg_update_p_z_kernel, dim3(gv), dim3(256), 0, s, n, rz_new, rz_old, Pz, rr, Pr,
                                            pq, Pq, z, p, st, max_iter - total_iters, (double *)nullptr, (const float *)z32,
                                            bb_scalar, p32, p_place(jq + 1), alpha_hist + (jq % n_hist));

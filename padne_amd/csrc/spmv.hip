@@ -701,178 +701,6 @@ int launch_spmv_dot_x32(padne_ctx *ctx, const padne_csr *m, const float *x, doub
     return PADNE_OK;
 }
 
-// q = A p with the UPDATE of the search direction folded into the staging (pcg.hip, the one-GPU multigrid loop):
-//     p = z + beta p_old,   beta = (sum of rz_new partials) / (sum of rz_old partials),
-// z and p_old stored in single precision.  A tile stages its runs of x as float(double(z) + beta double(p_old)) -- the very
-// expression pcg_update_p_z_kernel stored, so every tile that stages an entry forms the same float -- writes p for its own 64
-// rows to p_out (a place of its own: other tiles still read p_old) and takes p.q against that float.  What it replaces is a
-// kernel that read z and p and wrote p once more (12 bytes per row and a launch); what it costs is a second window of
-// staged reads (z beside p_old, mostly L2 hits: neighbouring tiles stage the same entries) and two conversions per staged entry.
-template <int RUN>
-__device__ __forceinline__ void stage_windows_fold(const float *__restrict__ z, const float *__restrict__ p_old, const double beta,
-                                                   const int n_cols, const int4 d, float *xs, const int lane) {
-    constexpr int PER = 4, PPR = RUN / PER, NP = kXwRuns * PPR;
-    struct alignas(4) PieceG { float v[PER]; };
-    struct alignas(16) PieceL { float v[PER]; };
-#pragma unroll
-    for (int c0 = 0; c0 < NP; c0 += 64) {
-        const int c = c0 + lane;
-        if (c < NP) {
-            const int q = c / PPR, i = c - q * PPR;
-            const int g0 = (q == 0 ? d.x : (q == 1 ? d.y : d.z)) + PER * i;
-            PieceL pl;
-            if (g0 + PER - 1 < n_cols) {
-                const PieceG zg = *reinterpret_cast<const PieceG *>(z + g0);
-                const PieceG pg = *reinterpret_cast<const PieceG *>(p_old + g0);
-#pragma unroll
-                for (int t = 0; t < PER; ++t) pl.v[t] = (float)((double)zg.v[t] + beta * (double)pg.v[t]);
-            } else {
-#pragma unroll
-                for (int t = 0; t < PER; ++t) pl.v[t] = (g0 + t < n_cols) ? (float)((double)z[g0 + t] + beta * (double)p_old[g0 + t]) : 0.f;
-            }
-            *reinterpret_cast<PieceL *>(xs + q * RUN + PER * i) = pl;
-        }
-    }
-}
-
-__global__ __launch_bounds__(kSpmvThreads) void csr_spmv_pfold_kernel(
-    const int n_rows, const int n_cols, const int n_wtiles, const int *__restrict__ rowptr, const int *__restrict__ cols,
-    const double *__restrict__ vals, const float *__restrict__ z, const float *__restrict__ p_old, float *__restrict__ p_out,
-    double *__restrict__ y, double *__restrict__ partials, const int *__restrict__ done_flag,
-    const double *__restrict__ part_rz_new, const double *__restrict__ part_rz_old, const int P_rz,
-    const int4 *__restrict__ xw_desc, const void *__restrict__ xw_lidx, const int xw_run) {
-    __shared__ double prod_all[4 * 64 * kEpl];
-    extern __shared__ __attribute__((aligned(16))) unsigned char xs_dyn[];
-    float *xs_all = reinterpret_cast<float *>(xs_dyn);
-    __shared__ double red[4];
-    if (*done_flag != 0) return;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    // beta, from the same partial sums in the same order in every workgroup (as pcg_update_p_z_kernel formed it)
-    double beta;
-    {
-        double a = 0.0, b = 0.0;
-        for (int i = threadIdx.x; i < P_rz; i += 256) a += part_rz_new[i];
-        for (int i = threadIdx.x; i < P_rz; i += 256) b += part_rz_old[i];
-        a = wave_sum(a);
-        if (lane == 0) red[w] = a;
-        __syncthreads();
-        const double rz_new = (red[0] + red[1]) + (red[2] + red[3]);
-        __syncthreads();
-        b = wave_sum(b);
-        if (lane == 0) red[w] = b;
-        __syncthreads();
-        const double rz_old = (red[0] + red[1]) + (red[2] + red[3]);
-        __syncthreads();
-        beta = rz_new / rz_old;
-    }
-    double *prod = prod_all + w * 64 * kEpl;
-    float *xs = xs_all + w * (kXwRuns * xw_run);
-    const int G = gridDim.x;
-    const int nslab = (G % kNumXcd == 0) ? kNumXcd : 1;
-    const int slab = blockIdx.x % nslab;
-    const int wx = (blockIdx.x / nslab) * 4 + w;
-    const int wps = (G / nslab) * 4;
-    const int s0 = (int)((long long)slab * n_wtiles / nslab);
-    const int s1 = (int)((long long)(slab + 1) * n_wtiles / nslab);
-    double dot_acc = 0.0;
-    int rs_n = 0, re_n = 0;
-    int4 d_n = make_int4(0, 0, 0, 0);
-    float z_n = 0.f, p_n = 0.f;
-    auto fetch_head = [&](const int wt) {
-        rs_n = 0;
-        re_n = 0;
-        z_n = 0.f;
-        p_n = 0.f;
-        d_n = make_int4(0, 0, 0, 0);
-        if (wt >= s1) return;
-        const int r = wt * 64 + lane;
-        if (r < n_rows) {
-            rs_n = rowptr[r];
-            re_n = rowptr[r + 1];
-            z_n = z[r];
-            p_n = p_old[r];
-        }
-        if (xw_desc != nullptr) d_n = xw_desc[wt];
-    };
-    fetch_head(s0 + wx);
-    for (int wt = s0 + wx; wt < s1; wt += wps) {
-        const int row0 = wt * 64;
-        const int row1 = min(row0 + 64, n_rows);
-        const int r = row0 + lane;
-        const int rs = rs_n, re = re_n;
-        const int4 d = d_n;
-        const float pn = (float)((double)z_n + beta * (double)p_n);      // this lane's row of the new direction
-        fetch_head(wt + wps);
-        const int k0 = __shfl(rs, 0, 64);
-        const int k1 = __shfl(re, row1 - row0 - 1, 64);
-        double acc = 0;
-        const bool windowed = xw_desc != nullptr && d.w != 0;
-        if (windowed) {
-            const int top = kXwRuns * xw_run - 1;
-            if (xw_run <= kXwRunShort) {
-                stage_windows_fold<kXwRunShort>(z, p_old, beta, n_cols, d, xs, lane);
-                acc = xw_stream_tile<4, unsigned char, double, double, float>(vals, (const unsigned char *)xw_lidx, xs, prod, k0, k1, rs, re, lane, top);
-            } else {
-                stage_windows_fold<kXwRunLong>(z, p_old, beta, n_cols, d, xs, lane);
-                acc = xw_stream_tile<2, unsigned short, double, double, float>(vals, (const unsigned short *)xw_lidx, xs, prod, k0, k1, rs, re, lane, top);
-            }
-        } else if (k1 > k0) {
-            // gather path: four consecutive non-zeros per lane and load, both vectors gathered, the direction formed per entry
-            for (int base = k0 & ~3;;) {
-                constexpr int NJ = kEpl / 4;
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const int e = base + 4 * lane + 256 * j;
-                    int4 cw = make_int4(0, 0, 0, 0);
-                    double v4[4] = {0, 0, 0, 0};
-                    float x4[4] = {0, 0, 0, 0};
-                    if (e < k1) {
-                        cw = *reinterpret_cast<const int4 *>(cols + e);
-                        const double2 a = *reinterpret_cast<const double2 *>(vals + e), b2 = *reinterpret_cast<const double2 *>(vals + e + 2);
-                        v4[0] = a.x; v4[1] = a.y; v4[2] = b2.x; v4[3] = b2.y;
-                        const int cc[4] = {cw.x, cw.y, cw.z, cw.w};
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) x4[t] = (float)((double)z[cc[t]] + beta * (double)p_old[cc[t]]);
-                    }
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) prod[4 * lane + 256 * j + t] = v4[t] * (double)x4[t];
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                const int lo = max(rs, base), hi = min(re, base + kWaveChunk);
-                for (int k = lo; k < hi; ++k) acc += prod[k - base];
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                base += kWaveChunk;
-                if (base >= k1) break;
-            }
-        }
-        if (r < row1) {
-            y[r] = acc;
-            p_out[r] = pn;
-            dot_acc += (double)pn * acc;
-        }
-    }
-    const double s = block_sum_256(dot_acc, red);
-    if (threadIdx.x == 0) partials[blockIdx.x] = s;
-}
-
-int launch_spmv_dot_pfold(padne_ctx *ctx, const padne_csr *m, const float *z, const float *p_old, float *p_out, double *y,
-                          double *partials, const int32_t *done_flag, const double *part_rz_new, const double *part_rz_old, int P_rz) {
-    PADNE_REQUIRE(spmv_x32_ok(m) && done_flag != nullptr, "single-precision search direction on this operator");
-    if (m->n_rows == 0) return PADNE_OK;
-    const int n_tiles = (int)((m->n_rows + 63) / 64);
-    const int g = spmv_grid(m);
-    const size_t xs_bytes = m->xw_state == 1 ? sizeof(float) * 4 * kXwRuns * (size_t)m->xw_run : 0;
-    const int4 *xw_desc = m->xw_state == 1 ? m->xw_desc : nullptr;
-    const void *xw_lidx = m->xw_state == 1 ? (const void *)m->xw_lidx : nullptr;
-    hipLaunchKernelGGL(csr_spmv_pfold_kernel, dim3(g), dim3(kSpmvThreads), xs_bytes, ctx->stream, (int)m->n_rows, (int)m->n_cols,
-                       n_tiles, m->rowptr, m->cols, m->vals, z, p_old, p_out, y, partials, done_flag, part_rz_new, part_rz_old,
-                       P_rz, xw_desc, xw_lidx, m->xw_run);
-    PADNE_HIP_CHECK(hipGetLastError());
-    return PADNE_OK;
-}
-
 int launch_spmv_mode(padne_ctx *ctx, const padne_csr *m, int mode, const double *x, double *y,
                      const double *dot_with, double *partials, const int32_t *done_flag, const double *aux1,
                      const double *aux2, double scale) {

@@ -10,11 +10,7 @@ def short(n):
     n = n.replace("padne::", "").replace("void ", "")
     return n.split("(")[0][:56]
 if what == "iteration":
-    # the kernel that ends an iteration: the bookkeeping kernel of the loop whose p update rides on the product (round 6), the p
-    # update of the earlier loop; of the one-GPU headline solves only (grid of one workgroup / of the vector kernels)
-    k = [i for i, r in enumerate(rows) if "pcg_book_kernel" in r[0] and r[3] - r[2] > 1500]
-    if len(k) < 12:
-        k = [i for i, r in enumerate(rows) if "pcg_update_p_z_kernel" in r[0]]
+    k = [i for i, r in enumerate(rows) if "pcg_update_p_z_kernel" in r[0]]
     a, b = k[-12], k[-11]          # one whole iteration in the middle of the last solve
     seg = rows[a + 1:b + 1]
 else:

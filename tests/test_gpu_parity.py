@@ -751,10 +751,8 @@ def test_x_formed_from_the_kept_search_directions_has_the_bits_of_the_running_up
     iterations, instead of reading and writing x in every iteration.  Same products, same additions, same order: bit for bit
     the x of the running update (PADNE_PCG_NO_XHIST=1), the same iterations -- cold, from an initial guess, with a ring of
     eight places that wraps several times within a solve (PADNE_FORCE=xhist_small), at a tolerance close to what the
-    recurrence reaches, and through further solves on the same context (the places are reused).  The update of the search
-    direction itself rides on the staging of the next product (`csr_spmv_pfold_kernel`: every tile forms
-    float(z + beta p) for the entries it stages, the expression the update kernel stored): against PADNE_FORCE=pcg_p_kernel,
-    same bits -- on a system whose tiles take the x-window path and, gathered, on one without a plan."""
+    recurrence reaches, and through further solves on the same context (the places are reused) -- on a system whose
+    product takes the x-window path and on one without a plan (the gather path)."""
     A, b, _, _, _ = layered_spd(3, 200, 150, 5)
     rng = np.random.default_rng(8)
     x0 = rng.uniform(-1, 1, A.shape[0]) * 1e-3
@@ -781,18 +779,14 @@ def _x_from_kept_directions(switches, A, b, x0):
     switches.set("PADNE_FORCE", "xhist_small")
     ring = run()
     switches.unset("PADNE_FORCE")
-    switches.set("PADNE_FORCE", "pcg_p_kernel")      # p = z + beta p by a kernel of its own, not inside the staging of q = A p
-    own = run()
-    switches.unset("PADNE_FORCE")
     switches.set("PADNE_PCG_NO_XHIST", "1")
     running = run()
     switches.unset("PADNE_PCG_NO_XHIST")
     assert min(k.iterations for k in kept) > 16, "every solve is meant to wrap the ring of eight at least twice"
-    for k, g, o, r in zip(kept, ring, own, running):
-        assert k.precond_fallbacks == 0 and k.status == r.status == g.status == o.status
-        assert k.iterations == r.iterations == g.iterations == o.iterations
-        assert k.restarts == r.restarts == g.restarts == o.restarts
-        assert np.array_equal(k.x, r.x) and np.array_equal(g.x, r.x) and np.array_equal(o.x, r.x)
+    for k, g, r in zip(kept, ring, running):
+        assert k.precond_fallbacks == 0 and k.status == r.status == g.status
+        assert k.iterations == r.iterations == g.iterations and k.restarts == r.restarts == g.restarts
+        assert np.array_equal(k.x, r.x) and np.array_equal(g.x, r.x)
     assert np.linalg.norm(A @ kept[0].x - b) <= 2e-12 * np.linalg.norm(b)
 
 
