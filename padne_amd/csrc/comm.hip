@@ -221,6 +221,11 @@ int comm_allreduce_sum_f64(padne_ctx *ctx, double *dev_buf, int count) {
         ++g_calls[0];
         g_bytes[0] += 8LL * count;
     }
+    // (a communicator of one rank: the sum over the ranks is the value itself.  Not a call into the library for it: on a
+    // one-rank communicator every ncclAllReduce / ncclAllGather allocates and frees a small buffer -- hipExtMallocWithFlags on
+    // the calling thread, hipFree on a helper thread, 780 of each in ten solves of the bench (profiles/r06_hip_api_dist.csv) --
+    // and a hipFree waits for the device while it holds the runtime's lock: the launches of the solve queued behind it.)
+    if (ctx->world == 1) return PADNE_OK;
     if (ctx->team != nullptr) return team_allreduce(ctx, dev_buf, count);
     if (ctx->hostcoll_fn != nullptr) return hostcoll_allreduce(ctx, dev_buf, count);
     if (ctx->comm == nullptr) return PADNE_OK;
@@ -235,6 +240,11 @@ static int allgather_impl(padne_ctx *ctx, const void *send, void *recv, int coun
     if (comm_active(ctx)) {
         ++g_calls[kind];
         g_bytes[kind] += (long long)elem * count_per_rank;
+    }
+    if (ctx->world == 1) {      // one rank: what is gathered is what was sent (see comm_allreduce_sum_f64)
+        if (send != recv)
+            PADNE_HIP_CHECK(hipMemcpyAsync(recv, send, elem * (size_t)count_per_rank, hipMemcpyDeviceToDevice, stream));
+        return PADNE_OK;
     }
     if (ctx->team != nullptr) return team_allgather(ctx, send, recv, elem * (size_t)count_per_rank);
     if (ctx->hostcoll_fn != nullptr) return hostcoll_allgather(ctx, send, recv, elem * (size_t)count_per_rank, stream);
