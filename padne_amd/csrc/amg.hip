@@ -2226,6 +2226,39 @@ __global__ __launch_bounds__(256) void dense_gemv(int n_rows, int n, const T *__
     if (lane == 0) y[row] = s;
 }
 
+// the same product as the WHOLE preconditioner of a system the dense inverse takes as it stands (a hierarchy of one level:
+// boards of a few hundred to two thousand unknowns): z = Inv r with the partial sums of r . z, one per workgroup of four rows
+__global__ __launch_bounds__(256) void dense_gemv_dot(int n, const double *__restrict__ inv, const double *__restrict__ r,
+                                                      double *__restrict__ z, double *__restrict__ partials,
+                                                      const int *__restrict__ done_flag) {
+    __shared__ double red[4];
+    if (done_flag != nullptr && *done_flag != 0) return;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + w;
+    double rz = 0.0;
+    if (row < n) {
+        const double *ir = inv + (size_t)row * n;
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        int c = lane;
+        for (; c + 192 < n; c += 256) {
+            s0 += ir[c] * r[c];
+            s1 += ir[c + 64] * r[c + 64];
+            s2 += ir[c + 128] * r[c + 128];
+            s3 += ir[c + 192] * r[c + 192];
+        }
+        for (; c < n; c += 64) s0 += ir[c] * r[c];
+        double s = (s0 + s1) + (s2 + s3);
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) {
+            z[row] = s;
+            rz = r[row] * s;
+        }
+    }
+    if (lane == 0) red[w] = rz;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 template <typename T>
 __global__ void scale_dinv_kernel(long long n, T c, const T *__restrict__ dinv, const T *__restrict__ b,
                                   T *__restrict__ x, const int *__restrict__ done_flag) {
@@ -4612,6 +4645,7 @@ bool amg_supports_batch8(const padne_csr *A0) {
 // number of per-workgroup r.z partials the last stage of the cycle writes (the grid of that launch)
 int amg_rz_partials(const padne_csr *A0) {
     const Amg *amg = (const Amg *)A0->amg;
+    if (amg != nullptr && !amg->dist && amg->levels.size() == 1 && amg->n_coarse > 0) return (amg->n_coarse + 3) / 4;      // dense_gemv_dot
     if (amg != nullptr && amg->f32 && !amg->levels.empty() && amg->levels[0].W != nullptr)
         return spmv_grid(amg->levels[0].W);
     return spmv_partials(A0);
@@ -4653,7 +4687,11 @@ int amg_apply(padne_ctx *ctx, const padne_csr *A0, const double *r, double *z, d
                 PADNE_TRY(amg_apply(ctx, amg->tail, amg->tail_r, amg->tail_z, nullptr, done_flag, nullptr, false));
                 PADNE_HIP_CHECK(hipMemcpyAsync(out, amg->tail_z + amg->tail_off, sizeof(double) * (size_t)L.n,
                                                hipMemcpyDeviceToDevice, s));
-            } else if (amg->n_coarse > 0)
+            } else if (amg->n_coarse > 0 && l == 0 && partials_rz != nullptr)
+                // a hierarchy of one level: the inverse IS the preconditioner (amg_rz_partials: one partial per four rows)
+                hipLaunchKernelGGL(dense_gemv_dot, dim3((amg->n_coarse + 3) / 4), dim3(256), 0, s, amg->n_coarse,
+                                   (const double *)amg->coarse_inv, b, out, partials_rz, done_flag);
+            else if (amg->n_coarse > 0)
                 hipLaunchKernelGGL(dense_gemv<double>, dim3((amg->n_coarse + 3) / 4), dim3(256), 0, s, amg->n_coarse,
                                    amg->n_coarse, (const double *)amg->coarse_inv, b, out);
             PADNE_HIP_CHECK(hipGetLastError());
@@ -4679,8 +4717,8 @@ int amg_apply(padne_ctx *ctx, const padne_csr *A0, const double *r, double *z, d
         PADNE_TRY(launch_spmv_mode(ctx, L.A, SPMV_JACOBI, L.xa, out, nullptr, (l == 0) ? partials_rz : nullptr,
                                    done_flag, b, L.A->dinv, L.jac));
     }
-    if (nl == 1 && partials_rz != nullptr) {
-        set_error("multigrid with a single level is not supported as a preconditioner");
+    if (nl == 1 && partials_rz != nullptr && (amg->dist || amg->n_coarse <= 0)) {
+        set_error("a hierarchy of one level serves as a preconditioner only through its dense inverse");
         return PADNE_E_INVALID;
     }
     return PADNE_OK;

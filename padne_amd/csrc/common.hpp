@@ -77,6 +77,7 @@ constexpr int kPinnedSlots = 16;
 constexpr int kPinnedSlotBase = 4096;
 constexpr int kPinnedBytes = kPinnedSlotBase + 512 * kPinnedSlots;
 
+constexpr int kTinySystem = 32;      // systems up to this size are solved with the diagonal preconditioner (no hierarchy is built)
 constexpr int kSpmmK = 8;            // right-hand sides of the batched path (spmm.hip), interleaved [n][8]
 
 }  // namespace padne

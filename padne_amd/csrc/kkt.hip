@@ -645,7 +645,7 @@ extern "C" int padne_kkt_solve(padne_ctx *ctx, padne_kkt *k, const double *r_hos
         amg_destroy(k->A->amg);
         k->A->amg = nullptr;
     }
-    const bool want_amg = opts->precond == 1 && nf > 1024;
+    const bool want_amg = opts->precond == 1 && nf > kTinySystem;
     double setup_s = 0.0;
     if (nf > 0) {
         PADNE_TRY(csr_build_dinv(ctx, k->A));

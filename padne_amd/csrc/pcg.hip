@@ -1964,7 +1964,9 @@ static int solve_spd_dev_impl(padne_ctx *ctx, const padne_csr *a, const void *b_
     const bool global_hierarchy = ctx->halo_on && a->prec_block == nullptr;
     PADNE_REQUIRE(!(opts->precond == 1 && global_hierarchy && a->n_rows != n_owned),
                   "row-partitioned multigrid needs a matrix with exactly the owned rows");
-    bool use_amg = opts->precond == 1 && (global_hierarchy || n_owned > 1024);
+    // (systems of a few dozen unknowns stay with Jacobi; up to the size the dense inverse takes -- 2048 -- the "hierarchy" is that
+    // inverse alone: an exact preconditioner, the loop ends after one or two iterations where Jacobi took hundreds)
+    bool use_amg = opts->precond == 1 && (global_hierarchy || n_owned > kTinySystem);
     if (use_amg) {
         PADNE_REQUIRE(pm->n_rows == n_owned && (global_hierarchy || pm->n_cols == n_owned),
                       "preconditioner block must be owned x owned");
@@ -1985,7 +1987,7 @@ static int solve_spd_dev_impl(padne_ctx *ctx, const padne_csr *a, const void *b_
             double setup_s = 0.0;
             amg_info(pm, &local.levels, &local.operator_complexity, &setup_s, nullptr);
             if (fresh) local.precond_setup_seconds = setup_s;
-            if (local.levels < 2) {      // the whole matrix fits the dense coarse solve: nothing to cycle over, use Jacobi
+            if (local.levels < 2 && global_hierarchy) {      // (a row-partitioned hierarchy of one level: nothing to cycle over, use Jacobi)
                 use_amg = false;
                 local.levels = 0;
                 local.operator_complexity = 0.0;
@@ -2058,7 +2060,8 @@ static int solve_spd_dev_impl(padne_ctx *ctx, const padne_csr *a, const void *b_
     // row-partitioned multigrid runs use the single-reduction loop (one all-reduce per iteration); PADNE_CG_SINGLE_REDUCTION
     // = 1 / 0 forces it on (also on one GPU, for tests) or off
     const bool dist_run = comm_active(ctx);
-    const bool single_reduction = use_amg && (ctx->opt.cg_single_reduction >= 0 ? ctx->opt.cg_single_reduction != 0 : dist_run);
+    const bool single_reduction = use_amg && (dist_run || local.levels >= 2) &&      // (a hierarchy of one level: the plain loop)
+                                  (ctx->opt.cg_single_reduction >= 0 ? ctx->opt.cg_single_reduction != 0 : dist_run);
     for (int k = k_first; k < n_rhs; ++k) {
         const int status_before = local.status;
         if (single_reduction)

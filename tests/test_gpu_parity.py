@@ -412,6 +412,33 @@ def layered_spd(nl=3, nx=90, ny=70, lattice=5):
     return A, -ro[1:n], Lo, ro, n
 
 
+def test_small_systems_are_preconditioned_by_their_dense_inverse(ctx):
+    """A system the coarsest-level inverse takes as it stands (up to 2048 unknowns: the boards of a few hundred to two
+    thousand vertices the reference is mostly run on) is a hierarchy of ONE level: the inverse itself is the preconditioner
+    (`dense_gemv_dot`), the loop ends after a step or two where the diagonal preconditioner took hundreds -- and the
+    potentials are those of scipy's direct solve.  Beyond 2048 the cycle takes over (two levels), below 33 Jacobi stays."""
+    import scipy.sparse.linalg as spla
+    for nl, nx, ny in ((1, 6, 5), (1, 12, 9), (2, 20, 14), (2, 36, 28), (4, 23, 22), (4, 24, 22)):
+        A, b, _, _, n = layered_spd(nl, nx, ny, 4)
+        d = ctx.csr_from_scipy(A)
+        res = d.solve_spd(b, precond="amg", rtol=1e-12)
+        jac = d.solve_spd(b, precond="jacobi", rtol=1e-12)
+        ref = spla.spsolve(A.tocsc(), b)
+        assert res.status == _hip.OK and res.precond_fallbacks == 0
+        assert np.abs(res.x - ref).max() <= 1e-9 * np.abs(ref).max(), (A.shape, res.iterations)
+        assert np.linalg.norm(A @ res.x - b) <= 2e-12 * np.linalg.norm(b)
+        if A.shape[0] <= 32:
+            assert res.levels == 0 and res.iterations == jac.iterations
+        elif A.shape[0] <= 2048:
+            assert res.levels == 1 and res.iterations <= 3 < jac.iterations, (A.shape, res.iterations, jac.iterations)
+        else:
+            assert res.levels >= 2 and res.iterations < 40
+        # a second right-hand side on the cached inverse, and a warm start
+        res2 = d.solve_spd(2.0 * b, precond="amg", rtol=1e-12, x0=res.x)
+        assert res2.status == _hip.OK and np.abs(res2.x - 2.0 * ref).max() <= 1e-9 * np.abs(ref).max()
+        d.close()
+
+
 def test_multigrid_hierarchy_is_galerkin_and_partition_of_unity(ctx):
     A, b, _, _, _ = layered_spd()
     d = ctx.csr_from_scipy(A)
