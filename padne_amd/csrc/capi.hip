@@ -411,6 +411,12 @@ int padne_ctx_destroy(padne_ctx *ctx) {
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     if (ctx->ev_order) hipEventDestroy(ctx->ev_order);
+    for (hipStream_t &cs : ctx->copy_stream)
+        if (cs != nullptr) {
+            (void)hipStreamSynchronize(cs);
+            (void)hipStreamDestroy(cs);
+            cs = nullptr;
+        }
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return PADNE_OK;

@@ -186,6 +186,9 @@ struct padne_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // second stream of the context (its own pool, workspace and reduction scratch): independent chains of short,
     // latency-bound kernels of the multigrid setup run there next to the main chain (aux_context, stream_order)
+    // the streams host vectors of a solve_system plan travel on (kkt.hip: parallel_copy), made on first use and kept: a stream
+    // costs 2 ms to create on a fresh process, four of them per plan were 8 of the 11 ms of a cold solve_system at 10 k unknowns
+    hipStream_t copy_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     padne_ctx *aux = nullptr, *parent = nullptr;
     bool is_aux = false;
     unsigned long long lockstep_groups = 0;      // groups of right-hand sides this context has solved in lockstep (test introspection)

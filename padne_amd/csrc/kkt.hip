@@ -46,7 +46,6 @@ struct padne_kkt {
     double *Z = nullptr;                 // [n_extra * N] expanded extra solutions (regulators)
     int n_extra_cap = 0, n_extra = 0;
     bool has_c = false, solved = false;
-    hipStream_t copy_stream[padne::kCopyStreams] = {nullptr, nullptr, nullptr, nullptr};
     double setup_seconds_last = 0.0;
 };
 
@@ -406,13 +405,27 @@ static int vgrid(long long n) {
 // A pageable host buffer crosses PCIe through the runtime's pinned staging area at the speed of ONE host core's memcpy
 // (8-10 GB/s: 8-10 ms for the 80 MB of a 10 M-unknown vector); kCopyStreams threads, each with a stream and a quarter
 // of the vector, bring it close to the link.  Blocks the caller until all parts have arrived.
+static int copy_streams(padne_ctx *ctx, int count) {      // the context's first `count` copy streams exist
+    static_assert(kCopyStreams == sizeof(ctx->copy_stream) / sizeof(ctx->copy_stream[0]), "the context holds the copy streams");
+    for (int t = 0; t < count; ++t)
+        if (ctx->copy_stream[t] == nullptr && hipStreamCreateWithFlags(&ctx->copy_stream[t], hipStreamNonBlocking) != hipSuccess) {
+            ctx->copy_stream[t] = nullptr;
+            set_error("stream creation failed");
+            return PADNE_E_HIP;
+        }
+    return PADNE_OK;
+}
+
 static int parallel_copy(padne_kkt *k, void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
     const int device = k->ctx->device;
+    hipStream_t *copy_stream = k->ctx->copy_stream;
     if (bytes < ((size_t)8 << 20)) {
-        PADNE_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, kind, k->copy_stream[0]));
-        PADNE_HIP_CHECK(hipStreamSynchronize(k->copy_stream[0]));
+        PADNE_TRY(copy_streams(k->ctx, 1));
+        PADNE_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, kind, copy_stream[0]));
+        PADNE_HIP_CHECK(hipStreamSynchronize(copy_stream[0]));
         return PADNE_OK;
     }
+    PADNE_TRY(copy_streams(k->ctx, kCopyStreams));
     hipError_t err[kCopyStreams];
     std::thread th[kCopyStreams];
     const size_t chunk = ((bytes / kCopyStreams) + 4095) & ~(size_t)4095;
@@ -422,8 +435,8 @@ static int parallel_copy(padne_kkt *k, void *dst, const void *src, size_t bytes,
         th[t] = std::thread([=, &err]() {
             if (len == 0) return;
             hipError_t e = hipSetDevice(device);
-            if (e == hipSuccess) e = hipMemcpyAsync((char *)dst + off, (const char *)src + off, len, kind, k->copy_stream[t]);
-            if (e == hipSuccess) e = hipStreamSynchronize(k->copy_stream[t]);
+            if (e == hipSuccess) e = hipMemcpyAsync((char *)dst + off, (const char *)src + off, len, kind, copy_stream[t]);
+            if (e == hipSuccess) e = hipStreamSynchronize(copy_stream[t]);
             err[t] = e;
         });
     }
@@ -440,12 +453,9 @@ static void kkt_free(padne_kkt *k) {
     if (k == nullptr) return;
     padne_ctx *ctx = k->ctx;
     if (ctx != nullptr && ctx->stream != nullptr) (void)hipStreamSynchronize(ctx->stream);
-    for (hipStream_t &s : k->copy_stream)
-        if (s != nullptr) {
-            (void)hipStreamSynchronize(s);
-            (void)hipStreamDestroy(s);
-            s = nullptr;
-        }
+    if (ctx != nullptr)
+        for (hipStream_t cs : ctx->copy_stream)
+            if (cs != nullptr) (void)hipStreamSynchronize(cs);
     if (k->A != nullptr) padne_csr_destroy(k->A);
     for (void *p : {(void *)k->imap, (void *)k->src_of, (void *)k->tied_member, (void *)k->tied_target, (void *)k->tied_order,
                     (void *)k->tied_gptr, (void *)k->r, (void *)k->v,
@@ -496,11 +506,8 @@ extern "C" int padne_kkt_create(padne_ctx *ctx, const padne_csr *L, int64_t n_po
         kkt_free(k);
         return code;
     };
-    for (hipStream_t &cs : k->copy_stream)
-        if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) {
-            set_error("stream creation failed");
-            return fail(PADNE_E_HIP);
-        }
+    // (the copy streams of the context, made here on the calling thread: the copies themselves run on threads of their own)
+    if (copy_streams(ctx, sizeof(double) * (size_t)(N > 0 ? N : 1) >= ((size_t)8 << 20) ? kCopyStreams : 1) != PADNE_OK) return fail(PADNE_E_HIP);
     const size_t nN = (size_t)(N > 0 ? N : 1), nF = (size_t)(n_free > 0 ? n_free : 1), nT = (size_t)(n_tied > 0 ? n_tied : 1);
     k->imap = (int32_t *)pool_alloc(ctx, sizeof(int32_t) * nN);
     k->src_of = (int32_t *)pool_alloc(ctx, sizeof(int32_t) * nF);
