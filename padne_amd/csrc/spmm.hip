@@ -26,21 +26,14 @@ constexpr int kSpmmChunk = 512;      // non-zeros staged per wave per pass (6 Ki
 // search directions kept as floats, multiplied in double, the single loop's form -- was built and measured in round 5 and is NOT
 // used: two conversions per non-zero and lane run at the rate of double-precision arithmetic, the product became bound by
 // them (512 against 330 us at N = 5 M).  The parameter stays for the gathers' type.
-// WIN: the operator carries the SpMV's x-window plan of three runs of 72 (csr_build_xw_plan: the fine level of a mesh
-// numbered by scan lines or strips).  A qualifying tile stages its three runs of X -- 72 entries of K right-hand sides each,
-// contiguous in the interleaved layout: 13.8 KB in double precision -- into the wave's LDS slice with 16-byte loads and
-// reads a non-zero's line X[col][j, j + 1] from there through the one-byte position of the plan: what the gathers cost was
-// their trip through the texture path (one 64-byte line per non-zero and row: the product ran no faster with every gather
-// an L1 hit, scripts/lab/exp_spmm_gather_floor.py), not their misses.  Other tiles gather as before, tile by tile.
-template <int K, int MODE, typename VT, typename XT, typename YT, typename ST = XT, bool WIN = false>
+template <int K, int MODE, typename VT, typename XT, typename YT, typename ST = XT>
 __global__ __launch_bounds__(kSpmvThreads) void csr_spmm_kernel(
     const int n_rows, const int n_wtiles, const int *__restrict__ rowptr, const int *__restrict__ cols,
     const VT *__restrict__ vals, const ST *__restrict__ x, YT *__restrict__ y, const double *__restrict__ dot_with,
     double *__restrict__ partials /* [8][kMaxPartials] */, const int *__restrict__ done_flag,
     const XT *__restrict__ aux1, const XT *__restrict__ aux2, const XT scale,
     const double *__restrict__ out_scale2 /* [K] or null */, const XT *__restrict__ aux0 /* SPMV_WUP: [n][K] */,
-    const XT *__restrict__ rhs /* SPMV_WUP exit without aux0: the fine level's right-hand side [n][K] */,
-    const int n_cols, const int4 *__restrict__ xw_desc, const unsigned char *__restrict__ xw_lidx) {
+    const XT *__restrict__ rhs /* SPMV_WUP exit without aux0: the fine level's right-hand side [n][K] */) {
     static_assert(K == 8 || K == 4 || K == 2, "lockstep widths");
     constexpr int LPR = K / 2;                              // lanes per row (each takes two right-hand sides)
     constexpr int RPG = 64 / LPR;                           // rows per group
@@ -49,8 +42,6 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmm_kernel(
     __shared__ int cs_all[4 * kSpmmChunk];
     __shared__ VT vs_all[4 * kSpmmChunk];
     __shared__ double red[4][K];
-    constexpr int kWinRun = 72, kWinElems = 3 * kWinRun * K;      // staged entries of X per wave (WIN)
-    extern __shared__ __attribute__((aligned(16))) unsigned char xs_dyn[];      // WIN: 4 * kWinElems entries of ST
 
     if (done_flag != nullptr && *done_flag != 0) return;
 
@@ -58,7 +49,6 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmm_kernel(
     const int rsub = lane / LPR, j = (lane % LPR) * 2;     // this lane's columns: j, j + 1
     int *cs = cs_all + w * kSpmmChunk;
     VT *vs = vs_all + w * kSpmmChunk;
-    ST *xs = reinterpret_cast<ST *>(xs_dyn) + (WIN ? w * kWinElems : 0);
     double out_mul0 = 1.0, out_mul1 = 1.0;
     if (out_scale2 != nullptr) {
         const double a0 = out_scale2[j], a1 = out_scale2[j + 1];
@@ -88,29 +78,6 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmm_kernel(
         }
         const int k0 = __shfl(rs, 0, 64);
         const int k1 = __shfl(re, row1 - row0 - 1, 64);
-        bool windowed = false;                                  // wave-uniform
-        if (WIN) {
-            const int4 d = xw_desc[wt];
-            windowed = d.w != 0;
-            if (windowed) {
-                constexpr int PER = 16 / (int)sizeof(ST), PPR = kWinRun * K / PER, NP = 3 * PPR;
-                struct alignas(16) Piece { ST v[PER]; };
-                const size_t n_elems = (size_t)n_cols * K;
-#pragma unroll 2
-                for (int c = lane; c < NP; c += 64) {
-                    const int q = c / PPR, i = c - q * PPR;
-                    const size_t g0 = (size_t)(q == 0 ? d.x : (q == 1 ? d.y : d.z)) * K + (size_t)i * PER;
-                    Piece pc;
-                    if (g0 + PER <= n_elems) {
-                        pc = *reinterpret_cast<const Piece *>(x + g0);
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < PER; ++t) pc.v[t] = g0 + t < n_elems ? x[g0 + t] : (ST)0;
-                    }
-                    *reinterpret_cast<Piece *>(xs + q * kWinRun * K + i * PER) = pc;
-                }
-            }
-        }
         XT acc0[NG], acc1[NG];
         int grs[NG], gre[NG];
 #pragma unroll
@@ -125,7 +92,7 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmm_kernel(
             for (int q = 0; q < kSpmmChunk / 64; ++q) {
                 const int e = base + lane + 64 * q;
                 if (e < k1) {
-                    cs[lane + 64 * q] = (WIN && windowed) ? (int)xw_lidx[e] : cols[e];
+                    cs[lane + 64 * q] = cols[e];
                     vs[lane + 64 * q] = vals[e];
                 }
             }
@@ -144,8 +111,7 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmm_kernel(
                         xv[u].b = 0;
                         vv[u] = 0;
                         if (k + u < hi) {
-                            if (WIN && windowed) xv[u] = *reinterpret_cast<const S2 *>(xs + min(cs[k + u - base], 3 * kWinRun - 1) * K + j);
-                            else xv[u] = *reinterpret_cast<const S2 *>(x + (size_t)cs[k + u - base] * K + j);
+                            xv[u] = *reinterpret_cast<const S2 *>(x + (size_t)cs[k + u - base] * K + j);
                             vv[u] = (XT)vs[k + u - base];
                         }
                     }
@@ -270,22 +236,6 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmm_kernel(
     }
 }
 
-// the windowed form: width 8, an operator with the three-run plan of 72 (one-byte positions), not switched off
-static bool spmm_windowed(const padne_csr *m, int k) {
-    return k == 8 && m->xw_state == 1 && m->xw_nruns == 3 && m->xw_run == 72 && m->xw_desc != nullptr && m->xw_lidx != nullptr &&
-           !(m->owner != nullptr && m->owner->opt.force_spmm_gather);
-}
-// workgroups of a product (= the partial sums it leaves per right-hand side).  Windowed, a workgroup holds its four waves'
-// runs of X beside the staged matrix chunk -- 80 KB in double precision, 52 KB in single -- so two / three fit a CU: the
-// persistent sweep runs that many per CU instead of queueing a second round
-static long long spmm_grid_of(const padne_csr *m, int k, int elem_bytes) {
-    long long g = (m->n_rows + kSpmvRows - 1) / kSpmvRows;
-    if (g > kMaxPartials) g = kMaxPartials;
-    if (spmm_windowed(m, k)) g = std::min<long long>(g, elem_bytes == 8 ? 512 : 768);
-    if (g >= kNumXcd) g -= g % kNumXcd;
-    return g < 1 ? 1 : g;
-}
-
 template <int K, typename VT, typename XT, typename YT>
 static int launch_spmm_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals, int mode, const XT *x, YT *y,
                              const double *dot_with, double *partials, const int32_t *done_flag, const XT *aux1,
@@ -293,25 +243,14 @@ static int launch_spmm_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals,
                              const XT *rhs = nullptr) {
     if (m->n_rows == 0) return PADNE_OK;
     const int n_tiles = (int)((m->n_rows + 63) / 64);
-    const bool win = spmm_windowed(m, K);
-    const long long g = spmm_grid_of(m, K, (int)sizeof(XT));
-    const size_t xs_bytes = win ? sizeof(XT) * 4 * 3 * 72 * (size_t)K : 0;
-#define PADNE_SPMM_LAUNCH(M)                                                                                               \
-    do {                                                                                                                   \
-        if (win) {                                                                                                         \
-            /* (static + dynamic LDS of the windowed form exceed the 64 KiB a launch gets without asking) */              \
-            (void)hipFuncSetAttribute((const void *)csr_spmm_kernel<K, M, VT, XT, YT, XT, K == 8>,                         \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)xs_bytes);                          \
-            hipLaunchKernelGGL((csr_spmm_kernel<K, M, VT, XT, YT, XT, K == 8>), dim3((unsigned)g), dim3(kSpmvThreads), xs_bytes, \
-                               ctx->stream, (int)m->n_rows, n_tiles, m->rowptr, m->cols, vals, x, y, dot_with, partials,   \
-                               done_flag, aux1, aux2, scale, out_scale2, aux0, rhs, (int)m->n_cols, m->xw_desc,            \
-                               (const unsigned char *)m->xw_lidx);                                                         \
-        } else                                                                                                             \
-            hipLaunchKernelGGL((csr_spmm_kernel<K, M, VT, XT, YT>), dim3((unsigned)g), dim3(kSpmvThreads), 0, ctx->stream, \
-                               (int)m->n_rows, n_tiles, m->rowptr, m->cols, vals, x, y, dot_with, partials, done_flag,     \
-                               aux1, aux2, scale, out_scale2, aux0, rhs, (int)m->n_cols, (const int4 *)nullptr,            \
-                               (const unsigned char *)nullptr);                                                            \
-    } while (0)
+    long long g = (m->n_rows + kSpmvRows - 1) / kSpmvRows;
+    if (g > kMaxPartials) g = kMaxPartials;
+    if (g >= kNumXcd) g -= g % kNumXcd;
+    if (g < 1) g = 1;
+#define PADNE_SPMM_LAUNCH(M)                                                                                      \
+    hipLaunchKernelGGL((csr_spmm_kernel<K, M, VT, XT, YT>), dim3((unsigned)g), dim3(kSpmvThreads), 0, ctx->stream, \
+                       (int)m->n_rows, n_tiles, m->rowptr, m->cols, vals, x, y, dot_with, partials, done_flag,     \
+                       aux1, aux2, scale, out_scale2, aux0, rhs)
     switch (mode) {
         case SPMV_PLAIN: PADNE_SPMM_LAUNCH(SPMV_PLAIN); break;
         case SPMV_DOT: PADNE_SPMM_LAUNCH(SPMV_DOT); break;
@@ -326,7 +265,12 @@ static int launch_spmm_typed(padne_ctx *ctx, const padne_csr *m, const VT *vals,
     return PADNE_OK;
 }
 
-int spmm8_grid(const padne_csr *m) { return (int)spmm_grid_of(m, kSpmmK, (int)sizeof(double)); }
+int spmm8_grid(const padne_csr *m) {
+    long long g = (m->n_rows + kSpmvRows - 1) / kSpmvRows;
+    if (g > kMaxPartials) g = kMaxPartials;
+    if (g >= kNumXcd) g -= g % kNumXcd;
+    return (int)(g < 1 ? 1 : g);
+}
 
 // the width is a run-time choice of the caller (8 for config C5 and groups of regulators, 4 / 2 for one to three)
 #define PADNE_SPMM_WIDTH(k, CALL8, CALL4, CALL2)                       \
@@ -433,7 +377,6 @@ extern "C" int padne_spmm8_dev(padne_ctx *ctx, const padne_csr *m, const void *x
     PADNE_REQUIRE(ctx && m && x_dev && y_dev, "null argument");
     PADNE_REQUIRE(repeat >= 1, "repeat");
     PADNE_HIP_CHECK(hipSetDevice(ctx->device));
-    PADNE_TRY(csr_build_xw_plan(ctx, const_cast<padne_csr *>(m)));      // (as padne_spmv_dev: the plan the solver would use)
     for (int i = 0; i < repeat; ++i)
         PADNE_TRY(launch_spmm8_mode(ctx, m, SPMV_PLAIN, (const double *)x_dev, (double *)y_dev, nullptr, nullptr, nullptr,
                                     nullptr, nullptr, 0.0));
@@ -446,7 +389,6 @@ extern "C" int padne_spmm8_time(padne_ctx *ctx, const padne_csr *m, const void *
     PADNE_REQUIRE(ctx && m && x_dev && y_dev && seconds_per_launch, "null argument");
     PADNE_REQUIRE(repeat >= 1 && warmup >= 0, "repeat / warmup");
     PADNE_HIP_CHECK(hipSetDevice(ctx->device));
-    PADNE_TRY(csr_build_xw_plan(ctx, const_cast<padne_csr *>(m)));
     for (int i = 0; i < warmup; ++i)
         PADNE_TRY(launch_spmm8_mode(ctx, m, SPMV_PLAIN, (const double *)x_dev, (double *)y_dev, nullptr, nullptr, nullptr,
                                     nullptr, nullptr, 0.0));

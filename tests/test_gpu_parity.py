@@ -2626,31 +2626,17 @@ def test_connections_equidistant_from_several_vertices_snap_like_the_kd_tree(ctx
     assert np.array_equal(snapped, ref)
 
 
-def test_spmm8_columns_are_bitwise_the_single_vector_products(ctx, switches):
-    """8 interleaved right-hand sides through one pass over the matrix; ragged rows, empty rows, long rows.  On an operator
-    with the x-window plan (a mesh numbered by scan lines: every tile's columns lie in three runs of 72) the product stages
-    those runs of X in LDS and reads them through the plan's one-byte positions; with a few rows coupled to far-away
-    unknowns some tiles gather instead, inside the same launch; PADNE_FORCE=spmm_gather gathers everywhere.  Same bits."""
+def test_spmm8_columns_are_bitwise_the_single_vector_products(ctx):
+    """8 interleaved right-hand sides through one pass over the matrix; ragged rows, empty rows, long rows."""
     rng = np.random.default_rng(3)
-    A, _, _, _, _ = layered_spd(3, 150, 110, 5)
-    Afar = A.tolil()
-    for i, jcol in ((700, 20000), (20000, 700), (33000, 5), (5, 33000)):
-        Afar[i, jcol] = -0.25
-    Afar = Afar.tocsr()
-    Afar.sort_indices()
-    for M in (H.random_csr(5000, 5000, 7, 21), H.random_csr(777, 900, 40, 22), H.random_csr(130, 64, 300, 23), A, Afar):
+    for M in (H.random_csr(5000, 5000, 7, 21), H.random_csr(777, 900, 40, 22), H.random_csr(130, 64, 300, 23)):
         d = ctx.csr_from_scipy(M)
         X = rng.uniform(-1, 1, (M.shape[1], 8))
         Y = d.matmat8(X)
-        switches.set("PADNE_FORCE", "spmm_gather")
-        Yg = d.matmat8(X)
-        switches.unset("PADNE_FORCE")
-        assert np.array_equal(Y, Yg)
         for j in range(8):
             yj = d.matvec(np.ascontiguousarray(X[:, j]))
             assert np.array_equal(Y[:, j], yj)
             assert np.array_equal(yj, M @ X[:, j])            # and both equal scipy's CSR product bit for bit
-        d.close()
 
 
 def test_relabel_with_injective_maps_is_the_slot_path_bit_for_bit(ctx, switches):
