@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-rank-proxy", action="store_true",
                     help="skip the one-rank-of-eight measurement (one layer of C4 through the row-partitioned path)")
     ap.add_argument("--no-c5", action="store_true", help="skip the batched right-hand sides of config C5")
+    ap.add_argument("--no-launch-count", action="store_true",
+                    help="skip the three extra solves that count the library's launches per step / setup / iteration (counter runs)")
     ap.add_argument("--no-small", action="store_true", help="skip solve_system vs spsolve at 11 k / 100 k / 1 M unknowns")
     ap.add_argument("--no-dist-one-rank", action="store_true",
                     help="skip config C4 through the row-partitioned path with a one-rank RCCL communicator")
@@ -119,7 +121,7 @@ def cpu_baseline(nx: int):
 def full_size_cpu_record():
     """The reference's solve call on the WHOLE workload, measured once per round on a GPU box host (scripts/direct_full.py ->
     profiles/<round>_direct_full.json; 11 minutes of one core, far beyond the bounded sample this bench may time)."""
-    for rd in ("r05", "r02"):
+    for rd in ("r06", "r05", "r02"):
         path = os.path.join(ROOT, "profiles", rd + "_direct_full.json")
         try:
             doc = json.load(open(path))
@@ -140,7 +142,7 @@ def step_counter_traffic():
     """HBM-side bytes of one timed step by the hardware counters (profiles/<round>_step_traffic.json, written by
     scripts/pmc_setup_sum.py from separate rocprofv3 --pmc passes of the same command; the newest round that has one);
     (None, None) if there is none."""
-    for rd in ("r05", "r04", "r03"):
+    for rd in ("r06", "r05", "r04", "r03"):
         try:
             return json.load(open(os.path.join(ROOT, "profiles", rd + "_step_traffic.json"))), f"profiles/{rd}_step_traffic.json"
         except Exception:
@@ -288,11 +290,15 @@ def rank_proxy(steps: int):
     rec = timed(lambda rebuild, rtol=RTOL: ds.solve(rtol=rtol, precond="amg", rebuild=rebuild), ctx2.synchronize)
     out.update(rec)
     out["path"] = "row-partitioned (amg_setup_dist, single-reduction CG, RCCL communicator of one rank)"
-    try:
-        out["p2p_exchange"] = json.load(open(os.path.join(ROOT, "profiles", "r05_p2p_exchange.json")))
-        out["p2p_exchange"]["static_from"] = "profiles/r05_p2p_exchange.json (tests/two_process_rank.py, two processes on one GPU; not measured in this run)"
-    except Exception:
-        out["p2p_exchange"] = None
+    out["p2p_exchange"] = None
+    for rd in ("r06", "r05"):
+        try:
+            out["p2p_exchange"] = json.load(open(os.path.join(ROOT, "profiles", rd + "_p2p_exchange.json")))
+            out["p2p_exchange"]["static_from"] = (f"profiles/{rd}_p2p_exchange.json (tests/two_process_rank.py, two processes on one GPU; "
+                                                  "not measured in this run)")
+            break
+        except Exception:
+            continue
     ds.close()
     ctx2.close()
     return out
@@ -625,7 +631,7 @@ def main():
     # launches of one step, of its setup and per iteration (library-side count, outside the timed region): a whole step, a
     # solve on the cached hierarchy, a shorter solve on it
     launches = None
-    if not distributed_path and args.precond == "amg":
+    if not distributed_path and args.precond == "amg" and not args.no_launch_count:
         try:
             c0 = _hip.launch_count()
             solver()
@@ -762,7 +768,7 @@ def main():
             red_ms = float(np.mean(red_warm)) * 1e3
             asm_bytes = 16 * nv + 12 * int(mto[-1]) + 12 * int(L_nnz)
             asm_traffic, asm_traffic_file = None, None
-            for rd in ("r05", "r04"):
+            for rd in ("r06", "r05", "r04"):
                 try:
                     asm_traffic = json.load(open(os.path.join(ROOT, "profiles", rd + "_assembly_traffic.json")))
                     asm_traffic_file = f"profiles/{rd}_assembly_traffic.json"

@@ -4,7 +4,7 @@ OUT="$GRAFT_REPO_ROOT/$1"; shift; mkdir -p "$OUT"; export TMPDIR=/tmp; cd /tmp
 i=0
 for SET in "$@"; do
   i=$((i+1))
-  timeout -k 5 200 rocprofv3 --pmc $SET --output-format csv -d "$OUT/set$i" -o run -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-seam --no-c5 --no-rank-proxy --no-small --no-dist-one-rank > "$OUT/set$i.log" 2>&1 || { tail -5 "$OUT/set$i.log"; exit 1; }
+  timeout -k 5 200 rocprofv3 --pmc $SET --output-format csv -d "$OUT/set$i" -o run -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-seam --no-c5 --no-rank-proxy --no-small --no-dist-one-rank --no-launch-count > "$OUT/set$i.log" 2>&1 || { tail -5 "$OUT/set$i.log"; exit 1; }
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections

@@ -1,5 +1,6 @@
 """HBM-side traffic of one timed step of bench.py (multigrid setup + CG iterations) from the two --pmc passes of
-scripts/pmc_bench.sh (FETCH_SIZE, WRITE_SIZE per kernel launch of `bench.py --steps 1 --warmup 0 --no-seam`):
+scripts/pmc_bench.sh (FETCH_SIZE, WRITE_SIZE per kernel launch of `bench.py --steps 1 --warmup 0 --no-seam --no-launch-count`
+and none of the side blocks):
 bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024 (gfx950 correction, MI355X_MICROARCH.md, calibrated in spmv_traffic.json).
 That command runs TWO solves (the timed step and the one that samples the SpMV with events): sums are halved.  Kernels of
 the workload build (mesh generation, assembly, reduction) are left out.
@@ -7,7 +8,7 @@ the workload build (mesh generation, assembly, reduction) are left out.
 import collections, csv, glob, json, sys
 out = sys.argv[1]
 LOOP = ("csr_spmv_kernel<1,", "csr_spmv_kernel<2, float", "csr_spmv_kernel<6, float", "csr_spmv_kernel<7, float", "csr_spmv_kernel<3, float",
-        "csr_spmv_kernel<4, float", "csr_spmv_kernel<0, float", "csr_spmv_kernel<8, float", "p_hat_from_z", "csr_spmv_wpr_kernel", "dense_gemv", "pcg_update_xr_entry", "pcg_update_p_z",
+        "csr_spmv_kernel<4, float", "csr_spmv_kernel<0, float", "csr_spmv_kernel<8, float", "p_hat_from_z", "csr_spmv_wpr_kernel", "dense_gemv", "pcg_update_xr_entry", "pcg_update_p_z", "pcg_x_flush",
         "pcg_init", "fold_partials", "residual_kernel", "pcg_set_tolerance", "csr_spmv_kernel<0, double", "mail_post")
 BUILD = ("asm_", "grid_mesh", "generate", "relabel", "reduce_", "map_is_injective", "map_is_compaction", "merge_rows", "compact_rows", "nn_", "kkt_", "halo_",
          "sort_long_rows_wave<1024, 4>", "fill_value_i32")
