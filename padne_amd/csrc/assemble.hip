@@ -1892,11 +1892,7 @@ __global__ __launch_bounds__(128) void relabel_fill_direct(long long n_rows, con
 // holes: count, scan, copy.  (Through the general direct path the same call cost 1.8 ms at 10 M rows: a histogram for the
 // injectivity test, a thread walking every row entry by entry, an insertion sort in LDS per row.)
 // flag[0] = 1: not such a map; flag[1] = 1: an entry outside [-1, n_out); flag[2] = 1: some index maps to 0
-// drop (optional, the column map's launch): drop[0] counts the dropped indices, drop[1 .. kRlDropList] lists the first few -- a
-// map that drops only a handful (the ground vertex, the multiplier rows) lets the relabel kernels do without the map
-constexpr int kRlDropList = 8;
-__global__ void map_is_compaction(long long n, const int *__restrict__ map, int n_out, int *__restrict__ flag,
-                                  int *__restrict__ drop = nullptr) {
+__global__ void map_is_compaction(long long n, const int *__restrict__ map, int n_out, int *__restrict__ flag) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int t = map[i];
@@ -1904,13 +1900,7 @@ __global__ void map_is_compaction(long long n, const int *__restrict__ map, int 
         *(volatile int *)(flag + 1) = 1;
         return;
     }
-    if (t < 0) {
-        if (drop != nullptr) {
-            const int k = atomicAdd(&drop[0], 1);
-            if (k < kRlDropList) drop[1 + k] = (int)i;
-        }
-        return;
-    }
+    if (t < 0) return;
     if (t == 0) *(volatile int *)(flag + 2) = 1;
     // the next kept index carries t + 1 (the last one n_out - 1): with an index that maps to 0 this makes the kept values
     // 0, 1, ..., n_out - 1 in order.  A run of more than 64 dropped indices is not followed: the general path takes such maps
@@ -2018,41 +2008,13 @@ __global__ __launch_bounds__(256) void relabel_fill_ordered(long long n_rows, co
 // finds their rows by bisection of the tile's row starts in LDS; the copy masks the entries of a dropped row by its range.
 constexpr int kRlEpl = 8;      // entries per lane and pass
 
-// Where column c goes under a map that only drops indices: c minus the dropped indices in front of it, -1 if it is one of
-// them.  With at most kRlDropList dropped indices (the reduction to the potential block drops the ground vertex and the
-// multiplier rows) that is eight compares against registers instead of a gather from the map per entry -- the gathers
-// were what the two passes waited for (124 and 348 us at 10 M rows with them).
-struct RlDrops {
-    int n, d[kRlDropList];
-};
-__device__ __forceinline__ RlDrops rl_load_drops(const int *__restrict__ drop) {
-    RlDrops r;
-    r.n = drop != nullptr ? drop[0] : kRlDropList + 1;
-#pragma unroll
-    for (int i = 0; i < kRlDropList; ++i) r.d[i] = (r.n <= kRlDropList && i < r.n) ? drop[1 + i] : 0x7fffffff;
-    return r;
-}
-__device__ __forceinline__ int rl_mapped(const RlDrops &dr, const int c) {
-    int before = 0;
-    bool hit = false;
-#pragma unroll
-    for (int i = 0; i < kRlDropList; ++i) {
-        before += dr.d[i] < c ? 1 : 0;
-        hit = hit || dr.d[i] == c;
-    }
-    return hit ? -1 : c - before;
-}
-
 __global__ __launch_bounds__(256) void relabel_count_wave(const int n_rows, const int *__restrict__ rowptr,
                                                           const int *__restrict__ cols, const int *__restrict__ map,
-                                                          const int *__restrict__ cmap, const int n_out, int *__restrict__ cnt,
-                                                          const int *__restrict__ drop) {
+                                                          const int *__restrict__ cmap, const int n_out, int *__restrict__ cnt) {
     __shared__ int rs_s[4][65];
     __shared__ int drop_s[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int n_tiles = (n_rows + 63) / 64;
-    const RlDrops dr = rl_load_drops(drop);
-    const bool by_list = dr.n <= kRlDropList;      // (uniform over the launch)
     for (int tile = blockIdx.x * 4 + w; tile < n_tiles; tile += gridDim.x * 4) {
         const int r = tile * 64 + lane;
         const int last = min(63, n_rows - 1 - tile * 64);
@@ -2073,13 +2035,8 @@ __global__ __launch_bounds__(256) void relabel_count_wave(const int n_rows, cons
                 const int e = base + lane + 64 * j;
                 c[j] = e < k1 ? cols[e] : -1;
             }
-            if (by_list) {
 #pragma unroll
-                for (int j = 0; j < kRlEpl; ++j) tc[j] = c[j] >= 0 ? rl_mapped(dr, c[j]) : 0;
-            } else {
-#pragma unroll
-                for (int j = 0; j < kRlEpl; ++j) tc[j] = c[j] >= 0 ? cmap[c[j]] : 0;
-            }
+            for (int j = 0; j < kRlEpl; ++j) tc[j] = c[j] >= 0 ? cmap[c[j]] : 0;
             bool dropped = false;
 #pragma unroll
             for (int j = 0; j < kRlEpl; ++j) dropped = dropped || tc[j] < 0;
@@ -2121,11 +2078,9 @@ __global__ __launch_bounds__(256) void relabel_fill_wave(const int n_rows, const
                                                          const int *__restrict__ map, const int *__restrict__ cmap,
                                                          const double scale, const int *__restrict__ out_rowptr,
                                                          int *__restrict__ out_cols, double *__restrict__ out_vals,
-                                                         int *__restrict__ zero_seen, const int *__restrict__ drop) {
+                                                         int *__restrict__ zero_seen) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int n_tiles = (n_rows + 63) / 64;
-    const RlDrops dr = rl_load_drops(drop);
-    const bool by_list = dr.n <= kRlDropList;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));      // the lanes below this one
     bool zero = false;
     for (int tile = blockIdx.x * 4 + w; tile < n_tiles; tile += gridDim.x * 4) {
@@ -2156,13 +2111,8 @@ __global__ __launch_bounds__(256) void relabel_fill_wave(const int n_rows, const
                 const int e = base + lane + 64 * j;
                 v[j] = e < k1 ? vals[e] : 0.0;
             }
-            if (by_list) {
 #pragma unroll
-                for (int j = 0; j < kRlEpl; ++j) tc[j] = c[j] >= 0 ? rl_mapped(dr, c[j]) : -1;
-            } else {
-#pragma unroll
-                for (int j = 0; j < kRlEpl; ++j) tc[j] = c[j] >= 0 ? cmap[c[j]] : -1;
-            }
+            for (int j = 0; j < kRlEpl; ++j) tc[j] = c[j] >= 0 ? cmap[c[j]] : -1;
             if (dropped_rows != 0ull) {                        // wave-uniform, rare: the entries of a dropped row go
                 for (unsigned long long m = dropped_rows; m != 0ull; m &= m - 1) {
                     const int d = __ffsll((long long)m) - 1;
@@ -2819,18 +2769,11 @@ int csr_relabel(padne_ctx *ctx, const padne_csr *m, const int32_t *row_map_host,
         // does and padne_csr_from_host checks for what it uploads)
         // maps that only drop indices (the reduction to the potential block): count, scan, copy -- see map_is_compaction
         static_assert(ERR_WORDS >= 6, "two triples of flag words");
-        // (the dropped COLUMN indices are listed by the launch that examines the column map; the list is only used with the
-        // verdict that the map is such a map -- the count kernel's results are thrown away otherwise)
-        int *d_drop = nullptr;
-        PADNE_TRY(sc.alloc(&d_drop, (size_t)kRlDropList + 1));
-        PADNE_HIP_CHECK(hipMemsetAsync(d_drop, 0, sizeof(int) * (kRlDropList + 1), s));
-        const bool square_map = d_cmap == d_map && m->n_rows == m->n_cols;
         hipLaunchKernelGGL(map_is_compaction, dim3(nblk(m->n_rows)), dim3(256), 0, s, (long long)m->n_rows, (const int *)d_map,
-                           (int)n_rows_out, d_err, square_map ? d_drop : (int *)nullptr);
+                           (int)n_rows_out, d_err);
         if (d_cmap != d_map)
             hipLaunchKernelGGL(map_is_compaction, dim3(nblk(m->n_cols)), dim3(256), 0, s, (long long)m->n_cols,
-                               (const int *)d_cmap, (int)n_cols_out, d_err + 3, d_drop);
-        const int *drop_list = (square_map || d_cmap != d_map) ? d_drop : nullptr;
+                               (const int *)d_cmap, (int)n_cols_out, d_err + 3);
         // (the counts are those of any one-to-one map; taken before the verdict is known, for one look at the host less)
         // (a wave per 64 rows, 2048 workgroups sweep the tiles; the lane-per-row kernels relabel_count_ordered /
         // relabel_fill_ordered remain for PADNE_FORCE=relabel_lanes: the tests compare the two)
@@ -2840,7 +2783,7 @@ int csr_relabel(padne_ctx *ctx, const padne_csr *m, const int32_t *row_map_host,
                                (const int *)d_map, (const int *)d_cmap, (int)n_rows_out, d_cnt);
         else
             hipLaunchKernelGGL(relabel_count_wave, dim3(g_wave), dim3(256), 0, s, (int)m->n_rows, m->rowptr, m->cols,
-                               (const int *)d_map, (const int *)d_cmap, (int)n_rows_out, d_cnt, drop_list);
+                               (const int *)d_map, (const int *)d_cmap, (int)n_rows_out, d_cnt);
         PADNE_HIP_CHECK(hipGetLastError());
         int h_flags[6] = {0, 0, 0, 0, 0, 0};
         PADNE_TRY(read_back(ctx, d_err, sizeof(h_flags), h_flags));
@@ -2864,7 +2807,7 @@ int csr_relabel(padne_ctx *ctx, const padne_csr *m, const int32_t *row_map_host,
                 else
                     hipLaunchKernelGGL(relabel_fill_wave, dim3(g_wave), dim3(256), 0, s, (int)m->n_rows, m->rowptr, m->cols, m->vals,
                                        (const int *)d_map, (const int *)d_cmap, scale, (const int *)res->rowptr, res->cols,
-                                       res->vals, d_err + 6, drop_list);
+                                       res->vals, d_err + 6);
                 e = hipGetLastError();
             }
             int h_zero = 0;
