@@ -670,6 +670,7 @@ static int solve_one(padne_ctx *ctx, const padne_csr *a, const padne_csr *prec, 
     // formed from them when the loop has ended -- or when the ring of kXHist places is full -- instead of being read and
     // written in every iteration: pcg_x_flush_kernel.  A place per iteration up to 2 GiB of them, at least eight.
     constexpr int kXHist = 32;
+    static_assert(kXHist <= 64, "pcg_x_flush_kernel holds the step lengths of one flush in 64 words of LDS");
     int n_hist = 0;
     if (amg && !dist && !halo && !ctx->opt.pcg_p64 && !ctx->opt.pcg_no_xhist && n > 0) {
         n_hist = (int)std::min<long long>(kXHist, std::max<long long>(8, ((long long)2 << 30) / (4 * n)));
