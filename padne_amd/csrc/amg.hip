@@ -580,140 +580,6 @@ __global__ __launch_bounds__(256) void mis_decide(int n, unsigned int *__restric
     }
 }
 
-// ALL rounds of a small level in ONE launch.  On a level of up to 200 000 vertices a round is three launches of a few
-// microseconds of work each (one-hop maxima, two-hop maxima, decisions), a dozen rounds per level, a look at the host after
-// every fourth: 36 launches and three looks where the arithmetic is a few hundred kilobytes.  Here a grid that is resident
-// as a whole (two workgroups per CU at most) goes through the rounds with two barriers per round -- a counter in memory,
-// bumped once per workgroup and polled by one lane, with an agent-scope release in front of the arrival and an acquire
-// behind the wait so that the words another XCD wrote are read from memory and not from a stale line -- and leaves when a
-// round ends with no open vertex.  Maxima do not depend on the order of evaluation: the words and states after every round
-// are those of the three-launch rounds, bit for bit (test_small_levels_choose_their_roots_in_one_launch).
-// Every wait is bounded: a workgroup that has polled kCoopMaxPolls times sets the abort word, everybody leaves at the next
-// poll, and the host runs the level again through the launches (from the start: the words of an abandoned round are
-// neither those before nor those after it).
-constexpr int kCoopMaxN = 200000;
-constexpr int kCoopMaxPolls = 1 << 21;
-struct MisCoop {           // [0] arrivals at the barrier, [1] abort, [2] rounds run, [3] open vertices left
-    unsigned int w[4];
-};
-__device__ __forceinline__ bool coop_barrier(unsigned int *bar, const unsigned int target, int *s_ok) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int ok = 1;
-        for (int polls = 0; __hip_atomic_load(&bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++polls) {
-            if (polls > kCoopMaxPolls || __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                __hip_atomic_store(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = 0;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(4);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        *s_ok = ok;
-    }
-    __syncthreads();
-    return *s_ok != 0;
-}
-
-// max(in[r], max over the strong neighbours of r) for the rows of this workgroup's share; WPR: a wave per row (long rows),
-// otherwise a wave per 64 rows with the neighbours' words parked in LDS (nbr_max's form).  f(r, m) is called by one lane per row.
-template <bool WPR, typename F>
-__device__ __forceinline__ void coop_row_max(const int n, const int *__restrict__ srow, const int *__restrict__ scol,
-                                             const unsigned int *in, unsigned int *park, F f) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (WPR) {
-        for (long long r = (long long)blockIdx.x * 4 + w; r < n; r += (long long)gridDim.x * 4) {
-            const int rs = srow[r], re = srow[r + 1];
-            unsigned int m = in[r];
-            for (int k = rs + lane; k < re; k += 64) {
-                const unsigned int v = in[scol[k]];
-                m = v > m ? v : m;
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const unsigned int o = __shfl_down(m, off, 64);
-                m = o > m ? o : m;
-            }
-            if (lane == 0) f((int)r, m);
-        }
-    } else {
-        constexpr int CH = 512;
-        const int n_wtiles = (n + 63) / 64;
-        for (long long wt = (long long)blockIdx.x * 4 + w; wt < n_wtiles; wt += (long long)gridDim.x * 4) {
-            const int row0 = (int)wt * 64;
-            const int row1 = min(row0 + 64, n);
-            const int r = row0 + lane;
-            int rs = 0, re = 0;
-            unsigned int m = 0;
-            if (r < row1) {
-                rs = srow[r];
-                re = srow[r + 1];
-                m = in[r];
-            }
-            const int k0 = __shfl(rs, 0, 64);
-            const int k1 = __shfl(re, row1 - row0 - 1, 64);
-            for (int base = k0; base < k1; base += CH) {
-#pragma unroll
-                for (int j = 0; j < CH / 64; ++j) {
-                    const int e = base + lane + 64 * j;
-                    park[lane + 64 * j] = (e < k1) ? in[scol[e]] : 0u;
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                const int lo = max(rs, base), hi = min(re, base + CH);
-                for (int k = lo; k < hi; ++k) {
-                    const unsigned int v = park[k - base];
-                    m = v > m ? v : m;
-                }
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-            }
-            if (r < row1) f(r, m);
-        }
-    }
-}
-
-template <bool WPR>
-__global__ __launch_bounds__(256) void mis_rounds_coop(const int n, const int *__restrict__ srow, const int *__restrict__ scol,
-                                                       unsigned int *word, unsigned int *w1, signed char *state,
-                                                       unsigned int *open_of_round /* [max_rounds], zeroed */, MisCoop *co,
-                                                       const int max_rounds) {
-    __shared__ unsigned int park_all[4 * 512];
-    __shared__ int s_ok, s_open[4];
-    unsigned int *park = park_all + (threadIdx.x >> 6) * 512;
-    const unsigned int G = gridDim.x;
-    unsigned int arrivals = 0;
-    int round = 0;
-    unsigned int left = 1u;
-    for (; round < max_rounds && left != 0u; ++round) {
-        // one-hop maxima of the words
-        coop_row_max<WPR>(n, srow, scol, word, park, [&](const int r, const unsigned int m) { w1[r] = m; });
-        arrivals += G;
-        if (!coop_barrier(co->w, arrivals, &s_ok)) return;
-        // two-hop maxima and the decisions of the round (in place: this pass reads only w1)
-        int open = 0;
-        coop_row_max<WPR>(n, srow, scol, w1, park, [&](const int r, const unsigned int top) {
-            if (state[r] == 0 && mis_decide_one(r, top, word, state)) ++open;
-        });
-        for (int off = 32; off > 0; off >>= 1) open += __shfl_down(open, off, 64);
-        if ((threadIdx.x & 63) == 0) s_open[threadIdx.x >> 6] = open;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const int t = s_open[0] + s_open[1] + s_open[2] + s_open[3];
-            if (t) __hip_atomic_fetch_add(&open_of_round[round], (unsigned int)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        arrivals += G;
-        if (!coop_barrier(co->w, arrivals, &s_ok)) return;
-        left = __hip_atomic_load(&open_of_round[round], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        co->w[2] = (unsigned int)round;
-        co->w[3] = left;
-    }
-}
-
 // Late rounds touch only the vertices that are still open (a few per cent after three or four rounds, while a
 // full neighbour-max pass streams the whole strength graph): compact list + direct two-hop maximum per vertex.
 // Same words, same decisions as the full rounds, so the aggregates do not depend on where the switch happens.
@@ -2610,38 +2476,6 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
     };
     int open_count = n;
     int round = 0;
-    // small levels: all rounds in one launch (mis_rounds_coop).  Not for the contexts of an in-process team: eight ranks on one
-    // device would queue more workgroups than the device holds at once, and a barrier of a grid that is not resident as a whole
-    // only ends at its poll limit
-    if (!xw && n > 0 && n <= kCoopMaxN && ctx->team == nullptr && !ctx->opt.force_mis_launches) {
-        MisCoop *co = nullptr;
-        PADNE_TRY(sc.alloc(&co, 1));
-        PADNE_HIP_CHECK(hipMemsetAsync(co, 0, sizeof(MisCoop), s));
-        const long long units = long_rows ? ((long long)n + 3) / 4 : ((long long)n_wt + 3) / 4;
-        const dim3 gc((unsigned)std::max<long long>(1, std::min<long long>(512, units)));      // two workgroups per CU: resident as a whole
-        if (long_rows)
-            hipLaunchKernelGGL(mis_rounds_coop<true>, gc, b, 0, s, n, srow, (const int *)scol, w0, w1, state, (unsigned int *)counter, co, kMaxRounds);
-        else
-            hipLaunchKernelGGL(mis_rounds_coop<false>, gc, b, 0, s, n, srow, (const int *)scol, w0, w1, state, (unsigned int *)counter, co, kMaxRounds);
-        PADNE_HIP_CHECK(hipGetLastError());
-        unsigned int h_co[4] = {0, 0, 0, 0};
-        if (bound_pending) {
-            bound_pending = false;
-            PADNE_TRY(read_back2(ctx, co, sizeof(h_co), h_co, bound2, sizeof(h_bound2), h_bound2));
-        } else {
-            PADNE_TRY(read_back(ctx, co, sizeof(h_co), h_co));
-        }
-        if (h_co[1] == 0u && h_co[3] == 0u) {
-            open_count = 0;
-            round = (int)h_co[2];
-        } else {
-            // a wait ran out (or the rounds did): the level again, from its start, through the launches -- same result
-            if (amg_verbose()) fprintf(stderr, "[amg]   independent set in one launch given up (abort %u, open %u): launches\n", h_co[1], h_co[3]);
-            hipLaunchKernelGGL(mis_init_words, dim3(nblk(std::max(n, kPadNnz))), b, 0, s, n, w0, state, counter, 2 * kMaxRounds + 4,
-                               (unsigned char *)nullptr, 0);
-            PADNE_HIP_CHECK(hipGetLastError());
-        }
-    }
     // the compact rounds pay off on sparse rows only: a direct two-hop maximum visits (nnz/row)^2 words per vertex
     const bool compact_ok = A->nnz <= 16LL * n;
     // Rounds are enqueued in batches between two reads of the open count (a host synchronisation costs ~30 us, as

@@ -51,7 +51,6 @@ void options_from_env(padne_options *o) {
         o->force_relabel_slots = has(f, "relabel_slots") != nullptr;
         o->force_transpose_cursors = has(f, "transpose_cursors") != nullptr;
         o->force_xhist_small = has(f, "xhist_small") != nullptr;
-        o->force_mis_launches = has(f, "mis_launches") != nullptr;
         o->force_relabel_lanes = has(f, "relabel_lanes") != nullptr;
         if (const char *w = has(f, "spgemm_split")) o->force_spgemm_split = w[12] == ':' ? atoll(w + 13) : 30000;
     }

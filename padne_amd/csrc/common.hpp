@@ -142,7 +142,6 @@ struct padne_options {
     // PADNE_FORCE=<path>[,<path>...]: send everything through a path that the data takes only rarely (tests)
     bool force_asm_hash = false, force_asm_two_pass = false, force_relabel_slots = false, force_transpose_cursors = false;
     bool force_relabel_lanes = false;  // relabel_lanes: the order-preserving relabel with a lane per row (the form of round 5)
-    bool force_mis_launches = false;   // mis_launches: the independent-set rounds of the small levels launch by launch (not in one launch)
     bool force_xhist_small = false;    // xhist_small: eight places for the kept search directions (the ring wraps within a solve)
     long long force_spgemm_split = 0;  // spgemm_split:<slots>
     // PADNE_VERBOSE=amg,xw,pool: diagnostics on stderr

@@ -605,40 +605,6 @@ def test_fused_up_leg_of_the_inner_levels_is_the_same_cycle(ctx, switches):
         assert np.linalg.norm(R) <= 1e-11 * np.linalg.norm(rhs)
 
 
-def test_small_levels_choose_their_roots_in_one_launch(ctx, switches):
-    """On a level of up to 200 000 vertices all independent-set rounds run in ONE launch (`mis_rounds_coop`: a grid resident as
-    a whole, two barriers per round, every wait bounded) instead of three launches per round and a look at the host every
-    fourth round.  Maxima do not depend on the order of evaluation: every operator of the hierarchy is BIT-IDENTICAL to the
-    one PADNE_FORCE=mis_launches builds -- where the fine level itself is small (no x-window plan: a shuffled numbering; a
-    plain one), where only the coarse levels are, with the short rows of a first coarse level (64 rows per wave) and the
-    long rows of the levels below (a wave per row) -- and the same again on a second build (run-to-run reproducible)."""
-    rng = np.random.default_rng(17)
-    small, bs, _, _, _ = layered_spd(2, 150, 120, 5)                  # 36 k rows: the fine level goes through the one launch
-    perm = rng.permutation(small.shape[0])
-    shuffled = small[perm][:, perm].tocsr()
-    shuffled.sort_indices()
-    big, bb, _, _, _ = layered_spd(3, 420, 330, 6)                    # 416 k rows: levels 1-3 do
-    for A, b in ((small, bs), (shuffled, bs[perm]), (big, bb)):
-        def hierarchy():
-            d = ctx.csr_from_scipy(A)
-            res = d.solve_spd(b, precond="amg")
-            ops = [(d.amg_level(l, "A"), d.amg_level(l, "P")) for l in range(res.levels - 1)]
-            d.close()
-            return res, ops
-        res_c, ops_c = hierarchy()
-        res_c2, ops_c2 = hierarchy()
-        switches.set("PADNE_FORCE", "mis_launches")
-        res_l, ops_l = hierarchy()
-        switches.unset("PADNE_FORCE")
-        assert res_c.levels == res_l.levels >= 3 and res_c.iterations == res_l.iterations == res_c2.iterations
-        assert np.array_equal(res_c.x, res_l.x) and np.array_equal(res_c.x, res_c2.x)
-        for other in (ops_l, ops_c2):
-            for (Ac, Pc), (Al, Pl) in zip(ops_c, other):
-                for C_, L_ in ((Ac, Al), (Pc, Pl)):
-                    assert C_.shape == L_.shape and np.array_equal(C_.indptr, L_.indptr) and np.array_equal(C_.indices, L_.indices)
-                    assert np.array_equal(C_.data, L_.data)
-
-
 @pytest.mark.parametrize("hub", [False, True])
 def test_windowed_setup_kernels_build_the_same_hierarchy(ctx, switches, hub):
     """A fine level with an x-window plan (>= 65536 rows, band matrix) takes the windowed setup kernels: one-byte
