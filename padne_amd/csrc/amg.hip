@@ -310,8 +310,10 @@ __global__ __launch_bounds__(256) void nbr_max(int n, int n_wtiles, const int *_
     __shared__ T park_all[4 * CH];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     T *park = park_all + w * CH;
-    const long long W = (long long)gridDim.x * 4, gw = (long long)blockIdx.x * 4 + w;
-    for (long long wt = gw; wt < n_wtiles; wt += W) {
+    // (every XCD sweeps one contiguous eighth of the tiles, as the SpMV does: the words the rows of a tile gather are those of
+    // the tiles next to it, still in this XCD's L2)
+    const XcdSweep sw = xcd_sweep(n_wtiles, 4, w);
+    for (long long wt = sw.t0; wt < sw.t1; wt += sw.stride) {
         const int row0 = (int)wt * 64;
         const int row1 = min(row0 + 64, n);
         const int r = row0 + lane;
@@ -405,8 +407,8 @@ __global__ __launch_bounds__(256) void nbr_max_xw(int n, int n_wtiles, const int
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     T *park = park_all + w * CH;
     T *xs = xs_all + w * 3 * 88;
-    const long long W = (long long)gridDim.x * 4, gw = (long long)blockIdx.x * 4 + w;
-    for (long long wt = gw; wt < n_wtiles; wt += W) {
+    const XcdSweep sw = xcd_sweep(n_wtiles, 4, w);      // (an eighth of the tiles per XCD: neighbouring tiles stage the same runs)
+    for (long long wt = sw.t0; wt < sw.t1; wt += sw.stride) {
         const int row0 = (int)wt * 64;
         const int row1 = min(row0 + 64, n);
         const int r = row0 + lane;
@@ -2424,7 +2426,9 @@ static int aggregate(padne_ctx *ctx, Scratch &sc, const padne_csr *A, int **agg_
     int *scol = nullptr;
     PADNE_TRY(sc.alloc(&scol, (size_t)(A->nnz > 0 ? A->nnz : 1)));
     const int n_wt = (n + 63) / 64;
-    const dim3 gm((unsigned)std::min(2048, (n_wt + 3) / 4 > 0 ? (n_wt + 3) / 4 : 1));
+    int gm_x = std::min(2048, (n_wt + 3) / 4 > 0 ? (n_wt + 3) / 4 : 1);
+    if (gm_x >= kNumXcd) gm_x -= gm_x % kNumXcd;      // (a multiple of the XCDs: the tile kernels sweep one slab per XCD)
+    const dim3 gm((unsigned)gm_x);
     // lambda_f: the Gershgorin bound of the filtered operator comes out of the same pass
     double *bound_part = lambda_f != nullptr ? ctx->partials + 6 * kMaxPartials : nullptr;
     double *bound2 = nullptr;            // their maxima: filtered | plain
