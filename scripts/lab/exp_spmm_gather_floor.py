@@ -5,7 +5,6 @@ gather an L1 hit -- and against a copy whose columns are shuffled over the whole
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
-import scipy.sparse as sp
 from padne_amd import _hip, synthetic
 import bench
 
@@ -26,8 +25,7 @@ x1 = ctx.to_device(rng.uniform(-1, 1, n)); y1 = ctx.empty(n)
 def t8(mat):
     return min(mat.spmm8_time(x8, y8, 5, 30) for _ in range(3))
 print(f"as it is:            {t8(A)*1e6:7.1f} us  (SpMV {A.spmv_time(x1, y1, 5, 50)*1e6:.1f} us)", flush=True)
-F = sp.csr_matrix((M.data, M.indices % 64, M.indptr), shape=M.shape)        # (unsorted duplicates are fine for a timing)
-dF = _hip.CsrMatrix(ctx, None) if False else None
+# (rows with repeated, unsorted columns are fine for a timing: uploaded through the C ABI as they are)
 h = _hip._P()
 ip, ix, dt = M.indptr.astype(np.int32), (M.indices % 64).astype(np.int32), M.data.astype(np.float64)
 _hip._check(ctx._lib.padne_csr_from_host(ctx._h, n, n, _hip._ptr(ip, _hip._PI32), _hip._ptr(ix, _hip._PI32), _hip._ptr(dt, _hip._PF64), _hip.C.byref(h)))
