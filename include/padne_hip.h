@@ -127,7 +127,10 @@ int padne_dev_memset(padne_ctx *ctx, void *dev, int value, int64_t bytes);
 
 /* ---- matrices ------------------------------------------------------------------------------ */
 /* upload a host CSR (scipy layout: int32 indptr[n_rows+1], int32 indices[nnz], f64 data[nnz]).
- * Replaces L.tocsc() as the hand-off of the assembled system, solver.py:772. */
+ * Replaces L.tocsc() as the hand-off of the assembled system, solver.py:772.
+ * The columns of a row need not ascend (scipy's canonical form does; the layout does not demand it): the upload remembers a
+ * matrix whose rows do not, and the paths that count on column order (the order-preserving relabel of padne_csr_reduce)
+ * leave such a matrix to the general ones, which sort. */
 int padne_csr_from_host(padne_ctx *ctx, int64_t n_rows, int64_t n_cols,
                         const int32_t *indptr, const int32_t *indices, const double *data,
                         padne_csr **out);
