@@ -48,6 +48,29 @@ __device__ __forceinline__ double block_total(const double *__restrict__ partial
     return t;
 }
 
+// two such sums in ONE pass over the workgroup (the loads of both arrays in flight together, one pair of barriers): every
+// sum adds the same terms in the same order as block_total, hence the same bits.  `red2` = 8 doubles of LDS.
+__device__ __forceinline__ void block_total2(const double *__restrict__ pa, const int Pa, const double *__restrict__ pb, const int Pb,
+                                             double *red2, double *ta, double *tb) {
+    double sa = 0.0, sb = 0.0;
+    const int P = Pa > Pb ? Pa : Pb;
+    for (int i = threadIdx.x; i < P; i += 256) {
+        if (i < Pa) sa += pa[i];
+        if (i < Pb) sb += pb[i];
+    }
+    sa = wave_sum_v(sa);
+    sb = wave_sum_v(sb);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+        red2[w] = sa;
+        red2[4 + w] = sb;
+    }
+    __syncthreads();
+    *ta = (red2[0] + red2[1]) + (red2[2] + red2[3]);
+    *tb = (red2[4] + red2[5]) + (red2[6] + red2[7]);
+    __syncthreads();
+}
+
 __device__ __forceinline__ void block_store_partial(double v, double *red, double *out) {
     v = wave_sum_v(v);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -232,12 +255,12 @@ __global__ __launch_bounds__(256) void pcg_update_xr_entry_kernel(
     const int P_pq, const double *__restrict__ p, const double *__restrict__ q, double *__restrict__ x,
     double *__restrict__ r, double *__restrict__ part_rr, PcgStatus *__restrict__ st, const double *__restrict__ bb2,
     const float c, const float *__restrict__ dinv32, float *__restrict__ b32, float *__restrict__ xa32, const int p_hat) {
-    __shared__ double red[4];
+    __shared__ double red[8];
     const int stop = st->done;              // written by an EARLIER launch: every workgroup of this one reads the same value
     if (blockIdx.x == 0 && threadIdx.x == 0) st->done_seen = stop;
     if (stop) return;
-    const double rz = block_total(part_rz, P_rz, red);
-    const double pq = block_total(part_pq, P_pq, red);
+    double rz, pq;
+    block_total2(part_rz, P_rz, part_pq, P_pq, red, &rz, &pq);
     const double s2 = *bb2;
     const double s_inv = s2 > 0.0 ? 1.0 / sqrt(s2) : 1.0;
     // p_hat: the search direction is stored as p / ||b|| in single precision (solve_one), q and p.q are those of the stored
@@ -273,20 +296,23 @@ __global__ __launch_bounds__(256) void pcg_update_p_z_kernel(
     float *__restrict__ p32, float *__restrict__ p32_next = nullptr, double *__restrict__ alpha_out = nullptr) {
     // p32_next / alpha_out (the search directions of a solve KEPT, solve_one): the new direction goes to a place of its own
     // and the step length along the old one is left for pcg_x_flush_kernel -- x is not touched here (x_deferred is null)
-    __shared__ double red[4];
+    __shared__ double red[8];
     // NOT st->done: workgroup 0 of this very launch sets it, and this kernel carries the deferred x += alpha p -- a
     // workgroup dispatched after that store would skip its slice of the last update.  done_seen is what the x/r update of
     // this iteration read, i.e. a value from before this launch
     if (st->done_seen) return;
-    const double rz_new = block_total(part_rz_new, P_rz, red);
-    const double rz_old = block_total(part_rz_old, P_rz, red);
+    double rz_new, rz_old;
+    block_total2(part_rz_new, P_rz, part_rz_old, P_rz, red, &rz_new, &rz_old);
     const double beta = rz_new / rz_old;
     if (z32 != nullptr) {
         // the cycle left z in single precision and without its factor ||b|| (amg_apply, z32): the same double the exit stage
         // took its r.z from; with the deferred x update
         const double s2 = *bb2;
         const double z_mul = s2 > 0.0 ? sqrt(s2) : 1.0;
-        const double alpha = rz_old / block_total(part_pq, P_pq, red);
+        // (the step length: every workgroup's where x rides on this update, the first workgroup's alone where the search
+        // directions are kept and it is only recorded)
+        const bool need_alpha = p32_next == nullptr || blockIdx.x == 0;
+        const double alpha = need_alpha ? rz_old / block_total(part_pq, P_pq, red) : 0.0;
         if (p32 != nullptr) {
             // the search direction is KEPT in single precision, in the units of the cycle (p^ = p / ||b||, like z32: right-hand
             // sides of 1e-30 A or 1e+30 A stay in range): q = A p^ was formed from this very float, so x += alpha^ p^ and
