@@ -303,8 +303,8 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
     ST *xs_all = reinterpret_cast<ST *>(xs_dyn);
     __shared__ double red[4];
 
-    if (done_flag != nullptr && *done_flag != 0) return;
-
+    // (the early exit of a converged solve is taken BEHIND the first loads of the kernel -- the stop word is a dependent load of
+    // its own, a microsecond in front of everything else when it is waited for first; the loads it overtakes are harmless)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     XT *prod = prod_all + w * 64 * kEplGather;
     ST *xs = xs_all + w * (WIDE ? kXwRunsWide * kXwRunWide : kXwRuns * xw_run);
@@ -352,6 +352,7 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_kernel(
     wt_n = tile_at(s0 + wx);
     wt_nn = tile_at(s0 + wx + wps);
     fetch_head(wt_n);
+    if (done_flag != nullptr && *done_flag != 0) return;
     for (int it = s0 + wx; it < s1; it += wps) {
         const int wt = wt_n;
         const int row0 = wt * 64;
@@ -451,17 +452,24 @@ __global__ __launch_bounds__(kSpmvThreads) void csr_spmv_wpr_kernel(
     const XT *__restrict__ aux0) {
     constexpr bool WITH_DOT = (MODE == SPMV_DOT) || (MODE == SPMV_DOT_AUX) || (MODE == SPMV_JACOBI);
     __shared__ double red[4];
-    if (done_flag != nullptr && *done_flag != 0) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int W = gridDim.x * 4;
+    // (the first row's bounds are asked for in front of the stop word, as in the tile kernel)
+    const int r_first = blockIdx.x * 4 + w;
+    int rs_first = 0, re_first = 0;
+    if (r_first < n_rows) {
+        rs_first = rowptr[r_first];
+        re_first = rowptr[r_first + 1];
+    }
+    if (done_flag != nullptr && *done_flag != 0) return;
     double out_mul = 1.0;
     if (out_scale2 != nullptr) {
         const double s2 = *out_scale2;
         out_mul = s2 > 0.0 ? sqrt(s2) : 1.0;
     }
     double dot_acc = 0.0;
-    for (int r = blockIdx.x * 4 + w; r < n_rows; r += W) {
-        const int rs = rowptr[r], re = rowptr[r + 1];
+    for (int r = r_first; r < n_rows; r += W) {
+        const int rs = r == r_first ? rs_first : rowptr[r], re = r == r_first ? re_first : rowptr[r + 1];
         XT acc = 0;
         for (int k = rs + lane; k < re; k += 64) acc += (XT)vals[k] * x[cols[k]];
         acc = wave_sum_t(acc);
