@@ -622,6 +622,15 @@ class KktPlan:
         out = np.zeros((1 + len(extras), max(len(pidx), 1)), dtype=np.float64)
         opts = CsrMatrix._opts(rtol, 0.0, max_iter, 0, False, precond=precond, rebuild=rebuild)
         info = SolveInfo()
+        # the vector stage 2 will hand back: its pages are touched while the device solves (a fresh 80 MB array at 10 M
+        # unknowns is 20 000 page faults in the path of the copy that brings v home)
+        self._v_next, self._v_toucher = None, None
+        if self.N >= (1 << 20):
+            import threading
+            v_next = np.empty(self.N, dtype=np.float64)
+            self._v_next = v_next
+            self._v_toucher = threading.Thread(target=C.memset, args=(v_next.ctypes.data, 0, v_next.nbytes), daemon=True)
+            self._v_toucher.start()
         rc = self.ctx._lib.padne_kkt_solve(self.ctx._h, self._h, _ptr(r, _PF64), kidx.shape[0], _ptr(kidx, _PI64),
                                            _ptr(kval, _PF64), len(extras), _ptr(ptr, _PI64), _ptr(rows, _PI64),
                                            _ptr(vals, _PF64), pidx.shape[0], _ptr(pidx, _PI64), _ptr(out, _PF64),
@@ -638,7 +647,12 @@ class KktPlan:
         coeff = _f64(extra_coeff)
         midx = _i64(sorted(multipliers))
         mval = _f64([multipliers[int(i)] for i in midx])
-        v = np.empty(self.N, dtype=np.float64)
+        toucher, v = getattr(self, "_v_toucher", None), getattr(self, "_v_next", None)
+        self._v_next, self._v_toucher = None, None
+        if toucher is not None:
+            toucher.join()
+        if v is None:
+            v = np.empty(self.N, dtype=np.float64)
         norm = C.c_double()
         _check(self.ctx._lib.padne_kkt_finish(self.ctx._h, self._h, coeff.shape[0], _ptr(coeff, _PF64), midx.shape[0],
                                               _ptr(midx, _PI64), _ptr(mval, _PF64), _ptr(v, _PF64), C.byref(norm)))
