@@ -625,7 +625,7 @@ class KktPlan:
         # the vector stage 2 will hand back: its pages are touched while the device solves (a fresh 80 MB array at 10 M
         # unknowns is 20 000 page faults in the path of the copy that brings v home)
         self._v_next, self._v_toucher = None, None
-        if self.N >= (1 << 20):
+        if self.N >= (1 << 18):
             import threading
             v_next = np.empty(self.N, dtype=np.float64)
             self._v_next = v_next
