@@ -629,7 +629,8 @@ class KktPlan:
             import threading
             v_next = np.empty(self.N, dtype=np.float64)
             self._v_next = v_next
-            self._v_toucher = threading.Thread(target=C.memset, args=(v_next.ctypes.data, 0, v_next.nbytes), daemon=True)
+            # (the thread holds the array itself, not just its address: it outlives a plan that is dropped on an error path)
+            self._v_toucher = threading.Thread(target=lambda a=v_next: C.memset(a.ctypes.data, 0, a.nbytes), daemon=True)
             self._v_toucher.start()
         rc = self.ctx._lib.padne_kkt_solve(self.ctx._h, self._h, _ptr(r, _PF64), kidx.shape[0], _ptr(kidx, _PI64),
                                            _ptr(kval, _PF64), len(extras), _ptr(ptr, _PI64), _ptr(rows, _PI64),
